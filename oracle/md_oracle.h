@@ -1,0 +1,123 @@
+/*
+ * md_oracle.h -- CPU restatement (FP64, plain C) of the strained-MD stress sampler that
+ * SCEMa runs behind STMDProblem<3>::strain (reference: headers/stmd_problem.h:84-383).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (scema_amd/, include/) may link,
+ * import or execute this code; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in LAMMPS 17Nov16 (packages KSPACE,
+ * MOLECULE, RIGID), an un-vendored dependency that is absent from /root/reference
+ * (README.md:31-37, CMakeLists/archer.CMakeLists.txt:28-39) and the reference ships no
+ * golden stresses for any OPLS system.  This file restates the published algorithms that the
+ * reference's scripts select (lammps_scripts_opls/in.set.lammps:13-57, in.strain.lammps:68-124,
+ * ELASTIC/in.homogenization.lammps:45-96) and is pinned by known-answer / invariant tests
+ * (tests/test_oracle_*.py), not by reference outputs.
+ */
+#ifndef MD_ORACLE_H
+#define MD_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* energy / virial parts */
+enum {
+  OMD_LJ = 0,      /* pair lj/cut                            */
+  OMD_COUL = 1,    /* pair coul/long real space (+special corrections) */
+  OMD_BOND = 2,
+  OMD_ANGLE = 3,
+  OMD_DIHEDRAL = 4,
+  OMD_IMPROPER = 5,
+  OMD_KSPACE = 6,  /* reciprocal Ewald sum (+self, for the energy) */
+  OMD_SHAKE = 7,   /* constraint forces (virial only)        */
+  OMD_NPART = 8
+};
+
+typedef struct {
+  double cut_lj;        /* in.set.lammps:40  pair_style lj/cut/coul/long 12.0 9.0 */
+  double cut_coul;
+  double skin;          /* in.set.lammps:27  neighbor 2.0 bin */
+  int    neigh_delay;   /* in.set.lammps:32  neigh_modify every 1 delay 5 check yes */
+  double kspace_accuracy;   /* in.set.lammps:36 kspace_style pppm 0.0001 */
+  double shake_tol;     /* in.strain.lammps:71 fix shake 0.001 20 1000 m 1.0 */
+  int    shake_maxiter;
+  double shake_mass;    /* <= 0: no SHAKE */
+  double t_period;      /* in.strain.lammps:80 fix nvt temp T T 100.0 */
+  int    t_chain;       /* Nose-Hoover chain length (fix nvt default 3) */
+} omd_params;
+
+void omd_default_params(omd_params *p);
+
+typedef struct omd_sim omd_sim;
+
+/* All index arrays are 0-based atom indices; type arrays are 0-based type indices.
+ * angle/improper equilibrium values are in radians.  eps/sigma are full ntypes x ntypes
+ * matrices (the restart file carries mixed coefficients). */
+omd_sim *omd_create(int natoms, int ntypes, const int *type, const double *charge,
+                    const double *mass_per_type, const double *eps, const double *sigma,
+                    int nbonds, const int *bond_atoms, const int *bond_type, int nbondtypes,
+                    const double *bond_coeff /* K,r0 */,
+                    int nangles, const int *angle_atoms, const int *angle_type, int nangletypes,
+                    const double *angle_coeff /* K,theta0 */,
+                    int ndihedrals, const int *dihedral_atoms, const int *dihedral_type,
+                    int ndihedraltypes, const double *dihedral_coeff /* K1..K4 */,
+                    int nimpropers, const int *improper_atoms, const int *improper_type,
+                    int nimpropertypes, const double *improper_coeff /* K,chi0 */,
+                    const double special_lj[3], const double special_coul[3],
+                    const omd_params *params);
+void omd_destroy(omd_sim *s);
+
+/* box = {xlo,ylo,zlo, xhi,yhi,zhi, xy,xz,yz}; x,v are [natoms*3] */
+void omd_set_state(omd_sim *s, const double box[9], const double *x, const double *v);
+void omd_get_state(const omd_sim *s, double box[9], double *x, double *v);
+
+int omd_natoms(const omd_sim *s);
+int omd_nconstraints(const omd_sim *s);
+int omd_nclusters(const omd_sim *s);
+double omd_tdof(const omd_sim *s);
+double omd_g_ewald(const omd_sim *s);
+int omd_nkvec(const omd_sim *s);
+int omd_npairs(const omd_sim *s);   /* unique pairs currently in the neighbour list */
+
+/* (Re)initialise run-level quantities exactly as a fresh LAMMPS "run" does:
+ * g_ewald and the k-vector set from the current box, neighbour list rebuild.
+ * use_shake selects whether SHAKE'd bonds are removed from the bond list. */
+void omd_setup(omd_sim *s, int use_shake);
+/* test hook: keep g_ewald and the k-vector set of the last setup (for d/d(strain) tests) */
+void omd_freeze_kspace(omd_sim *s, int frozen);
+
+/* Static evaluation at the current state (after omd_setup): forces [natoms*3],
+ * energies[OMD_NPART], virials[OMD_NPART*6] in order xx,yy,zz,xy,xz,yz (kcal/mol).
+ * SHAKE part is left zero. */
+void omd_compute(omd_sim *s, double *f, double *energies, double *virials);
+
+/* kinetic tensor (kcal/mol, order xx,yy,zz,xy,xz,yz) and temperature */
+double omd_temperature(const omd_sim *s, double ke_tensor[6]);
+
+/* One "run N" of velocity-Verlet with fix shake + fix nvt (+ fix deform if rates != NULL)
+ * (+ fix ave/time of the pressure tensor if press_avg != NULL).  Restates the per-step
+ * order of SURVEY.md A.2.  rates = engineering strain rates {xx,yy,zz,xy,xz,yz} in 1/fs.
+ * nvt: 0 = NVE (no thermostat), 1 = Nose-Hoover chain.
+ * If trace != NULL it receives per step 8 doubles: T, pe, ke, nh_energy, vol, pxx,pyy,pzz. */
+int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int use_shake,
+            const double *rates, double *press_avg /* 6, atm */, double *trace);
+
+/* Full stress evaluation = STMDProblem::lammps_straining (stmd_problem.h:84-383) for OPLS:
+ * strain_len = MDSim.strain in deal.II raw order xx,yy,zz,xy,xz,yz (Angstrom, i.e. strain x
+ * init_length, stmd_sync.h:552-557).  stress_out in Pa, same order.  Returns nts. */
+int omd_eval(omd_sim *s, const double strain_len[6], double timestep_length, double temperature,
+             double strain_rate, int nsteps_sample, double stress_out[6]);
+
+/* host arithmetic of stmd_problem.h:221-244, exposed for golden tests */
+int omd_nts(const double true_strain[6], double strain_rate, double dt);
+double omd_round_rate(double rate);      /* "%.6e" round trip, stmd_problem.h:241 */
+double omd_round_f(double v);            /* "%f"   round trip, stmd_problem.h:164,235 */
+
+/* timing of the last omd_eval: seconds spent in pair / kspace / neigh / other */
+void omd_last_timing(const omd_sim *s, double t[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,139 @@
+"""Synthetic OPLS-AA replica generator (SURVEY.md §8(d) "PE-10k").
+
+The reference ships no OPLS nanoscale input (materials `g0`/`epoxy80` are only named:
+input_configurations/inputs_dogbone_cuboid.json:42), so benchmarks and parity tests use a
+deterministic all-atom polyethylene crystal whose force-field *styles* are exactly the ones
+`lammps_scripts_opls/in.set.lammps:36-57` selects (lj/cut/coul/long, harmonic bonds/angles,
+OPLS dihedrals, SHAKE on X-H, special_bonds 0/0/1 from in.init.lammps:31).
+
+All index arrays are 0-based; types are 0-based (C=0, H=1).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BOLTZ = 0.0019872067
+MVV2E = 48.88821291 ** 2
+
+# orthorhombic polyethylene cell (Angstrom)
+PE_A, PE_B, PE_C = 7.40, 4.93, 2.534
+
+
+def build_pe(nx: int = 6, ny: int = 9, nz: int = 16, temperature: float = 300.0, seed: int = 1234,
+             jitter: float = 0.0) -> dict:
+    """All-atom PE crystal, 12 atoms per cell, chains bonded through the periodic z boundary.
+
+    6x9x16 -> 10 368 atoms, box 44.40 x 44.37 x 40.54 A (the PE-10k replica of SURVEY.md §8d).
+    Returns a dict of numpy arrays describing topology, coefficients, box, positions, velocities.
+    """
+    rcc, rch = 1.529, 1.090
+    half_c = 0.5 * PE_C
+    dperp = np.sqrt(rcc ** 2 - half_c ** 2) * 0.5  # zig-zag amplitude
+    hh = np.deg2rad(107.8) * 0.5
+    chains = [((0.0, 0.0), np.deg2rad(45.0)), ((0.5 * PE_A, 0.5 * PE_B), np.deg2rad(-45.0))]
+
+    nchain = 2 * nx * ny
+    ncar = 2 * nz  # carbons per chain
+    natoms = nchain * ncar * 3
+    x = np.zeros((natoms, 3))
+    typ = np.zeros(natoms, dtype=np.int32)
+    q = np.zeros(natoms)
+    mol = np.zeros(natoms, dtype=np.int32)
+
+    def cidx(ch, k):  # carbon k of chain ch
+        return (ch * ncar + (k % ncar)) * 3
+
+    ch = 0
+    for ix in range(nx):
+        for iy in range(ny):
+            for (cx, cy), phi in chains:
+                u = np.array([np.cos(phi), np.sin(phi), 0.0])
+                w = np.array([-np.sin(phi), np.cos(phi), 0.0])
+                ax = np.array([ix * PE_A + cx + 0.25 * PE_A, iy * PE_B + cy + 0.25 * PE_B, 0.0])
+                for k in range(ncar):
+                    s = 1.0 if k % 2 == 0 else -1.0
+                    pc = ax + s * dperp * u + np.array([0, 0, (k + 0.5) * half_c])
+                    i = cidx(ch, k)
+                    x[i] = pc
+                    x[i + 1] = pc + rch * (s * np.cos(hh) * u + np.sin(hh) * w)
+                    x[i + 2] = pc + rch * (s * np.cos(hh) * u - np.sin(hh) * w)
+                    typ[i], typ[i + 1], typ[i + 2] = 0, 1, 1
+                    q[i], q[i + 1], q[i + 2] = -0.12, 0.06, 0.06
+                    mol[i:i + 3] = ch
+                ch += 1
+
+    bonds, btype, angles, atype, dihs, dtype = [], [], [], [], [], []
+    for ch in range(nchain):
+        for k in range(ncar):
+            c0, c1 = cidx(ch, k), cidx(ch, k + 1)
+            cm = cidx(ch, k - 1)
+            c2 = cidx(ch, k + 2)
+            bonds += [(c0, c1), (c0, c0 + 1), (c0, c0 + 2)]
+            btype += [0, 1, 1]
+            angles += [(cm, c0, c1), (cm, c0, c0 + 1), (cm, c0, c0 + 2), (c1, c0, c0 + 1), (c1, c0, c0 + 2),
+                       (c0 + 1, c0, c0 + 2)]
+            atype += [0, 1, 1, 1, 1, 2]
+            # dihedrals about c0-c1
+            for X, tx in ((cm, 'C'), (c0 + 1, 'H'), (c0 + 2, 'H')):
+                for Y, ty in ((c2, 'C'), (c1 + 1, 'H'), (c1 + 2, 'H')):
+                    if tx == 'C' and ty == 'C':
+                        dihs.append((X, c0, c1, Y)); dtype.append(0)
+                    elif tx == 'H' and ty == 'C':
+                        dihs.append((X, c0, c1, Y)); dtype.append(1)
+                    elif tx == 'C' and ty == 'H':
+                        dihs.append((Y, c1, c0, X)); dtype.append(1)
+                    else:
+                        dihs.append((X, c0, c1, Y)); dtype.append(2)
+
+    mass = np.array([12.011, 1.008])
+    eps1 = np.array([0.066, 0.030])
+    sig1 = np.array([3.50, 2.50])
+    eps = np.sqrt(np.outer(eps1, eps1))   # geometric mixing (pair_modify default for this style)
+    sigma = np.sqrt(np.outer(sig1, sig1))
+
+    box = np.array([0.0, 0.0, 0.0, nx * PE_A, ny * PE_B, nz * PE_C, 0.0, 0.0, 0.0])
+
+    rng = np.random.default_rng(seed)
+    if jitter > 0.0:
+        x = x + rng.normal(0.0, jitter, x.shape)
+    m = mass[typ]
+    v = rng.normal(0.0, 1.0, (natoms, 3)) * np.sqrt(BOLTZ * temperature / (m * MVV2E))[:, None]
+    v -= (m[:, None] * v).sum(0) / m.sum()
+    tcur = (m[:, None] * v * v).sum() * MVV2E / ((3 * natoms - 3) * BOLTZ)
+    if tcur > 0:
+        v *= np.sqrt(temperature / tcur)
+
+    return dict(
+        natoms=natoms, ntypes=2, type=typ, charge=q, mol=mol, mass=mass, eps=eps, sigma=sigma,
+        bonds=np.array(bonds, dtype=np.int32).reshape(-1, 2), bond_type=np.array(btype, dtype=np.int32),
+        bond_coeff=np.array([[268.0, 1.529], [340.0, 1.090]]),
+        angles=np.array(angles, dtype=np.int32).reshape(-1, 3), angle_type=np.array(atype, dtype=np.int32),
+        angle_coeff=np.array([[58.35, np.deg2rad(112.7)], [37.5, np.deg2rad(110.7)], [33.0, np.deg2rad(107.8)]]),
+        dihedrals=np.array(dihs, dtype=np.int32).reshape(-1, 4), dihedral_type=np.array(dtype, dtype=np.int32),
+        dihedral_coeff=np.array([[1.3, -0.05, 0.2, 0.0], [0.0, 0.0, 0.3, 0.0], [0.0, 0.0, 0.3, 0.0]]),
+        impropers=np.zeros((0, 4), dtype=np.int32), improper_type=np.zeros(0, dtype=np.int32),
+        improper_coeff=np.zeros((0, 2)),
+        special_lj=np.array([0.0, 0.0, 1.0]), special_coul=np.array([0.0, 0.0, 1.0]),
+        box=box, x=np.ascontiguousarray(x), v=np.ascontiguousarray(v),
+    )
+
+
+def build_pe10k(seed: int = 1234) -> dict:
+    return build_pe(6, 9, 16, 300.0, seed)
+
+
+def synthetic_strains(n_sims: int, box_lengths, seed: int = 2026, scale: float = 1.0) -> np.ndarray:
+    """eps_zz ~ U(1.0e-3,1.8e-3), eps_xx=eps_yy=-0.3 eps_zz, shears ~ U(-1e-4,1e-4).
+
+    Returns the Angstrom-valued MDSim.strain (raw order xx,yy,zz,xy,xz,yz), i.e. true strain times
+    the box length the reference pairs with each component (stmd_sync.h:552-557):
+    diag x own length, xy x Lz, yz x Lx, xz x Ly.
+    """
+    rng = np.random.default_rng(seed)
+    lx, ly, lz = box_lengths
+    out = np.zeros((n_sims, 6))
+    for i in range(n_sims):
+        ezz = rng.uniform(1.0e-3, 1.8e-3) * scale
+        sh = rng.uniform(-1.0e-4, 1.0e-4, 3) * scale
+        out[i] = [-0.3 * ezz * lx, -0.3 * ezz * ly, ezz * lz, sh[0] * lz, sh[1] * ly, sh[2] * lx]
+    return out

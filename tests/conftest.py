@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` tests must not silently pass on a box without a GPU
+    pass
+
+
+@pytest.fixture(scope="session")
+def small_pe():
+    """360-atom PE crystal with jitter + tilt, used with reduced cutoffs (box >= 2*(rc+skin))."""
+    from scema_amd.systems import build_pe
+    d = build_pe(2, 3, 5, jitter=0.05, seed=7)
+    d["box"][6:9] = [0.7, -0.4, 0.5]
+    return d
