@@ -1,0 +1,160 @@
+/*
+ * scema_md.h -- C ABI of the MI355X-native microscale stress-evaluation engine that drops into
+ * SCEMa's STMDProblem / STMDSync path.
+ *
+ * Plain C: pointers and sizes only, no torch / HIP / C++ types.  Each entry point names the
+ * reference interface it replaces (paths relative to the SCEMa tree).
+ *
+ * Tensor conventions (reference): rank-2 symmetric tensors travel as 6 doubles in deal.II raw
+ * order xx,yy,zz,xy,xz,yz (headers/scale_bridging_data.h:12-19, FE_problem.h:1344-1346); rank-4
+ * stiffness as 36 doubles in init.*.stiff file order (headers/read_write.h:149-171).
+ */
+#ifndef SCEMA_MD_H
+#define SCEMA_MD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCEMA_MD_OK 0
+#define SCEMA_MD_ERR_ARG 1        /* bad argument / unknown force field (stmd_problem.h:462-467) */
+#define SCEMA_MD_ERR_NOSTATE 2    /* required replica / state missing (stmd_problem.h:125-132 asserts) */
+#define SCEMA_MD_ERR_DEVICE 3     /* HIP runtime failure */
+#define SCEMA_MD_ERR_BOX 4        /* box smaller than 2*(cutoff+skin), or tilt flip needed */
+#define SCEMA_MD_ERR_IO 5
+#define SCEMA_MD_ERR_OVERFLOW 6   /* neighbour capacity exceeded even after regrowth */
+
+#define SCEMA_MD_NPART 8          /* lj, coul, bond, angle, dihedral, improper, kspace, shake */
+#define SCEMA_MD_QP_NONE ((int32_t)0xFFFFFFFF) /* most_recent_qp_id "none": uint32 max as int, stmd_problem.h:126 */
+
+typedef struct scema_md_engine scema_md_engine;
+
+/* Run-level settings = what the reference's LAMMPS scripts fix for the OPLS path
+ * (lammps_scripts_opls/in.set.lammps:27-40, in.strain.lammps:71,80). */
+typedef struct {
+  double cut_lj;           /* 12.0  pair_style lj/cut/coul/long 12.0 9.0 */
+  double cut_coul;         /*  9.0 */
+  double skin;             /*  2.0  neighbor 2.0 bin */
+  int32_t neigh_delay;     /*  5    neigh_modify every 1 delay 5 check yes */
+  double kspace_accuracy;  /* 1e-4  kspace_style pppm 0.0001 (sets g_ewald; reciprocal sum = Ewald) */
+  double shake_tol;        /* 1e-3  fix shake 0.001 20 1000 m 1.0 */
+  int32_t shake_maxiter;   /* 20 */
+  double shake_mass;       /* 1.0 ; <= 0 disables SHAKE */
+  double t_period;         /* 100.0 fix nvt temp T T 100.0 */
+  int32_t t_chain;         /* 3 */
+  int32_t device;          /* HIP device ordinal */
+  int32_t max_batch;       /* simulations advanced together per launch group; 0 = all that fit */
+  int32_t profile;         /* !=0: HIP-event timing of every pair-kernel launch (scema_md_get_profile) */
+} scema_md_params;
+
+void scema_md_default_params(scema_md_params *p);
+
+/* Content of one equilibrated replica = what init.<mat>_<rep>.bin carries in the reference
+ * (stmd_problem.h:99-100, stmd_sync.h:388).  0-based atom and type indices; angles in radians;
+ * eps/sigma are ntypes x ntypes (already mixed).  box = xlo,ylo,zlo,xhi,yhi,zhi,xy,xz,yz. */
+typedef struct {
+  int32_t natoms, ntypes;
+  const int32_t *type;
+  const double *charge;
+  const double *mass;      /* per type */
+  const double *eps, *sigma;
+  int32_t nbonds, nbondtypes;
+  const int32_t *bond_atoms, *bond_type;
+  const double *bond_coeff;      /* K, r0 */
+  int32_t nangles, nangletypes;
+  const int32_t *angle_atoms, *angle_type;
+  const double *angle_coeff;     /* K, theta0 */
+  int32_t ndihedrals, ndihedraltypes;
+  const int32_t *dihedral_atoms, *dihedral_type;
+  const double *dihedral_coeff;  /* K1..K4 (dihedral_style opls) */
+  int32_t nimpropers, nimpropertypes;
+  const int32_t *improper_atoms, *improper_type;
+  const double *improper_coeff;  /* K, chi0 */
+  double special_lj[3], special_coul[3]; /* in.init.lammps:31 -> 0 0 1 */
+  double box[9];
+  const double *x, *v;           /* [natoms*3] */
+} scema_md_system;
+
+/* Mirrors HMM::MDSim<3> (headers/md_sim.h:15-58). */
+typedef struct {
+  int32_t qp_id, most_recent_qp_id, replica /* 1-based */, material;
+  const char *matid, *time_id, *output_folder, *restart_folder, *scripts_folder, *log_file, *force_field;
+  double strain[6];      /* IN  raw order; Angstrom (strain x init_length, stmd_sync.h:552-557) */
+  double stiffness[36];  /* IN  Hooke mode only, file order */
+  double timestep_length, temperature, strain_rate;
+  int32_t nsteps_sample;
+  int32_t output_homog, checkpoint;
+  double stress[6];      /* OUT Pa, raw order: -<P> * 101325 (stmd_problem.h:335-341) */
+  int32_t stress_updated;/* OUT */
+} scema_mdsim;
+
+/* ---- engine lifetime ---- */
+int scema_md_create(const scema_md_params *p, scema_md_engine **out);
+void scema_md_destroy(scema_md_engine *e);
+const char *scema_md_last_error(const scema_md_engine *e);
+
+/* ---- replica registry: replaces "read_restart init.<mat>_<rep>.bin" (stmd_problem.h:204) ---- */
+int scema_md_register_replica(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_system *sys);
+/* reads a replica file written by scema_md_write_replica_file (our container for init.*.bin) */
+int scema_md_load_replica_file(scema_md_engine *e, const char *matid, int32_t replica, const char *path);
+int scema_md_write_replica_file(const char *path, const scema_md_system *sys);
+
+/* ---- the hot path ---- */
+/* Replaces STMDProblem<3>::strain (stmd_problem.h:458-496) for the whole vector that
+ * STMDSync::execute_inside_md_simulations iterates (stmd_sync.h:570-618).  Simulations
+ * i with i % world == rank are evaluated on this engine's GPU (the reference's round robin,
+ * stmd_sync.h:583); the others are left untouched (stress_updated = 0).  State branch rule of
+ * stmd_problem.h:116-138,185-207: load from most_recent_qp_id if != qp_id, else qp_id, else the
+ * registered init state; always store under qp_id.  hooke != 0: sigma = C:eps (stmd_problem.h:479-483). */
+int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims, int32_t hooke,
+                          int32_t rank, int32_t world);
+/* literal per-simulation drop-in */
+int scema_md_strain(scema_md_engine *e, scema_mdsim *sim, int32_t hooke);
+
+/* Device-side result buffer of the last scema_md_strain_batch: 6*ceil(n_sims/world) doubles in
+ * HBM, local simulation k (= global index k*world+rank) at offset 6k; the operand of the one
+ * all-gather that replaces STMDSync::share_stresses (stmd_sync.h:620-726). */
+void *scema_md_local_stress_device_ptr(scema_md_engine *e);
+int32_t scema_md_local_stress_count(const scema_md_engine *e);
+/* after the caller's all-gather into gathered[world][6*ceil(n/world)] (host memory): fill
+ * sims[i].stress / stress_updated for every i (rank-0 bookkeeping of stmd_sync.h:698-725) */
+int scema_md_scatter_gathered(const double *gathered, int32_t world, scema_mdsim *sims, int32_t n_sims);
+
+/* ---- persistent per-(qp,mat,replica) state: replaces last.<qp>.<mat>_<rep>.dump / lcts.* files
+ * (stmd_problem.h:108-138,257-273; stmd_sync.h:167-187) ---- */
+int scema_md_has_state(const scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica);
+int scema_md_get_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica,
+                       double box[9], double *x, double *v);
+int scema_md_set_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica,
+                       const double box[9], const double *x, const double *v);
+int scema_md_drop_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica);
+int scema_md_save_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path);
+int scema_md_load_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path);
+
+/* ---- parity / measurement hooks ---- */
+/* Static evaluation at the stored state of (qp,mat,rep) (qp_id = SCEMA_MD_QP_NONE: the registered
+ * init state): forces [natoms*3], energies[SCEMA_MD_NPART], virials[SCEMA_MD_NPART*6] (kcal/mol). */
+int scema_md_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t use_shake,
+                           double *f, double *energies, double *virials, double *info /* [8]: g_ewald,nk,npairs,tdof,... */);
+/* One "run": nsteps of Verlet + SHAKE + NVT (+deform if rates) (+pressure average if press_avg). */
+int scema_md_debug_run(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t nsteps,
+                       double dt, double temperature, int32_t nvt, int32_t use_shake, const double *rates,
+                       double *press_avg);
+
+typedef struct {
+  int64_t pair_launches;      /* timed pair-kernel launches */
+  double pair_ms;             /* sum of their HIP-event durations */
+  double pair_alg_bytes;      /* algorithmic bytes of those launches, SURVEY.md 8(d) formula */
+  int64_t md_steps;           /* simulation-steps advanced (sum over simulations) */
+  int64_t neigh_builds;
+  double unique_pairs_per_sim;/* average unique pairs within cutoff+skin at the last build */
+  int64_t evals;
+} scema_md_profile;
+int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1303,6 +1303,13 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
       s->t_current = omd_temperature(s, NULL);
       nhc_temp_integrate(s, dt, temperature);
     }
+    /* end_of_step: pressure sample (the reference never combines it with fix deform in one run;
+     * when a test does, the sample uses the box the forces were computed in) */
+    if (press_avg && step <= nwin * nav) {
+      double p[6];
+      pressure_tensor(s, p);
+      for (int k = 0; k < 6; k++) psum[k] += p[k];
+    }
     /* end_of_step: fix deform (erate, remap x) */
     if (rates) {
       double t = step * dt;
@@ -1338,12 +1345,6 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
         s->x[3 * i + 1] = bn.h[1] * l1 + bn.h[3] * l2 + bn.lo[1];
         s->x[3 * i + 2] = bn.h[2] * l2 + bn.lo[2];
       }
-    }
-    /* end_of_step: pressure sample */
-    if (press_avg && step <= nwin * nav) {
-      double p[6];
-      pressure_tensor(s, p);
-      for (int k = 0; k < 6; k++) psum[k] += p[k];
     }
     if (trace) {
       double ke[6], p[6];

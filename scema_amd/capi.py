@@ -1,0 +1,252 @@
+"""ctypes binding of the C ABI declared in include/scema_md.h (libscema_md.so).
+
+This is the only way Python reaches the engine: plain pointers and sizes, no torch types.  The
+library is built in-tree by `scema_amd/csrc/Makefile` (`__graft_entry__.build()`); there is no CPU
+fallback -- a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscema_md.so")
+
+NPART = 8
+PARTS = ["lj", "coul", "bond", "angle", "dihedral", "improper", "kspace", "shake"]
+QP_NONE = -1  # uint32 max as int32 (stmd_problem.h:126)
+
+# every symbol include/scema_md.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "scema_md_default_params", "scema_md_create", "scema_md_destroy", "scema_md_last_error",
+    "scema_md_register_replica", "scema_md_load_replica_file", "scema_md_write_replica_file",
+    "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
+    "scema_md_local_stress_count", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
+    "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file",
+    "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("cut_lj", C.c_double), ("cut_coul", C.c_double), ("skin", C.c_double), ("neigh_delay", C.c_int32),
+                ("kspace_accuracy", C.c_double), ("shake_tol", C.c_double), ("shake_maxiter", C.c_int32),
+                ("shake_mass", C.c_double), ("t_period", C.c_double), ("t_chain", C.c_int32), ("device", C.c_int32),
+                ("max_batch", C.c_int32), ("profile", C.c_int32)]
+
+
+_P = C.c_void_p
+
+
+class System(C.Structure):
+    _fields_ = [("natoms", C.c_int32), ("ntypes", C.c_int32), ("type", _P), ("charge", _P), ("mass", _P),
+                ("eps", _P), ("sigma", _P),
+                ("nbonds", C.c_int32), ("nbondtypes", C.c_int32), ("bond_atoms", _P), ("bond_type", _P), ("bond_coeff", _P),
+                ("nangles", C.c_int32), ("nangletypes", C.c_int32), ("angle_atoms", _P), ("angle_type", _P), ("angle_coeff", _P),
+                ("ndihedrals", C.c_int32), ("ndihedraltypes", C.c_int32), ("dihedral_atoms", _P), ("dihedral_type", _P),
+                ("dihedral_coeff", _P),
+                ("nimpropers", C.c_int32), ("nimpropertypes", C.c_int32), ("improper_atoms", _P), ("improper_type", _P),
+                ("improper_coeff", _P),
+                ("special_lj", C.c_double * 3), ("special_coul", C.c_double * 3), ("box", C.c_double * 9), ("x", _P), ("v", _P)]
+
+
+class MDSim(C.Structure):
+    """Mirror of HMM::MDSim<3> (headers/md_sim.h:15-58)."""
+    _fields_ = [("qp_id", C.c_int32), ("most_recent_qp_id", C.c_int32), ("replica", C.c_int32), ("material", C.c_int32),
+                ("matid", C.c_char_p), ("time_id", C.c_char_p), ("output_folder", C.c_char_p),
+                ("restart_folder", C.c_char_p), ("scripts_folder", C.c_char_p), ("log_file", C.c_char_p),
+                ("force_field", C.c_char_p),
+                ("strain", C.c_double * 6), ("stiffness", C.c_double * 36),
+                ("timestep_length", C.c_double), ("temperature", C.c_double), ("strain_rate", C.c_double),
+                ("nsteps_sample", C.c_int32), ("output_homog", C.c_int32), ("checkpoint", C.c_int32),
+                ("stress", C.c_double * 6), ("stress_updated", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("pair_launches", C.c_int64), ("pair_ms", C.c_double), ("pair_alg_bytes", C.c_double),
+                ("md_steps", C.c_int64), ("neigh_builds", C.c_int64), ("unique_pairs_per_sim", C.c_double),
+                ("evals", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libscema_md.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(make -C scema_amd/csrc); the engine has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.scema_md_last_error.restype = C.c_char_p
+        L.scema_md_last_error.argtypes = [_P]
+        L.scema_md_local_stress_device_ptr.restype = C.c_void_p
+        L.scema_md_local_stress_device_ptr.argtypes = [_P]
+        L.scema_md_local_stress_count.argtypes = [_P]
+        L.scema_md_destroy.argtypes = [_P]
+        L.scema_md_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().scema_md_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def make_system(d: dict):
+    """Build a `System` struct from the dict produced by scema_amd.systems.build_pe; returns
+    (struct, keepalive list)."""
+    a = lambda k, t: np.ascontiguousarray(d[k], dtype=t)
+    keep = dict(type=a("type", np.int32), charge=a("charge", np.float64), mass=a("mass", np.float64),
+                eps=a("eps", np.float64), sigma=a("sigma", np.float64),
+                bonds=a("bonds", np.int32), bond_type=a("bond_type", np.int32), bond_coeff=a("bond_coeff", np.float64),
+                angles=a("angles", np.int32), angle_type=a("angle_type", np.int32), angle_coeff=a("angle_coeff", np.float64),
+                dihedrals=a("dihedrals", np.int32), dihedral_type=a("dihedral_type", np.int32),
+                dihedral_coeff=a("dihedral_coeff", np.float64),
+                impropers=a("impropers", np.int32), improper_type=a("improper_type", np.int32),
+                improper_coeff=a("improper_coeff", np.float64), x=a("x", np.float64), v=a("v", np.float64))
+    s = System()
+    s.natoms = int(d["natoms"]); s.ntypes = int(d["ntypes"])
+    s.type = _p(keep["type"]); s.charge = _p(keep["charge"]); s.mass = _p(keep["mass"])
+    s.eps = _p(keep["eps"]); s.sigma = _p(keep["sigma"])
+    s.nbonds = len(keep["bond_type"]); s.nbondtypes = len(keep["bond_coeff"])
+    s.bond_atoms = _p(keep["bonds"]); s.bond_type = _p(keep["bond_type"]); s.bond_coeff = _p(keep["bond_coeff"])
+    s.nangles = len(keep["angle_type"]); s.nangletypes = len(keep["angle_coeff"])
+    s.angle_atoms = _p(keep["angles"]); s.angle_type = _p(keep["angle_type"]); s.angle_coeff = _p(keep["angle_coeff"])
+    s.ndihedrals = len(keep["dihedral_type"]); s.ndihedraltypes = len(keep["dihedral_coeff"])
+    s.dihedral_atoms = _p(keep["dihedrals"]); s.dihedral_type = _p(keep["dihedral_type"])
+    s.dihedral_coeff = _p(keep["dihedral_coeff"])
+    s.nimpropers = len(keep["improper_type"]); s.nimpropertypes = len(keep["improper_coeff"])
+    s.improper_atoms = _p(keep["impropers"]); s.improper_type = _p(keep["improper_type"])
+    s.improper_coeff = _p(keep["improper_coeff"])
+    s.special_lj[:] = list(np.asarray(d["special_lj"], float))
+    s.special_coul[:] = list(np.asarray(d["special_coul"], float))
+    s.box[:] = list(np.asarray(d["box"], float))
+    s.x = _p(keep["x"]); s.v = _p(keep["v"])
+    return s, keep
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    """Thin owner of a `scema_md_engine*`."""
+
+    def __init__(self, params: Params | None = None, **kw):
+        L = lib()
+        self.params = params if params is not None else default_params(**kw)
+        self.h = C.c_void_p()
+        rc = L.scema_md_create(C.byref(self.params), C.byref(self.h))
+        if rc != 0:
+            raise EngineError(f"scema_md_create failed (rc={rc}): no usable HIP device; the engine has no CPU fallback")
+        self._natoms = {}
+
+    def close(self):
+        if self.h:
+            lib().scema_md_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(f"rc={rc}: {lib().scema_md_last_error(self.h).decode()}")
+
+    def register_replica(self, matid: str, replica: int, sysd: dict):
+        s, keep = make_system(sysd)
+        self._chk(lib().scema_md_register_replica(self.h, matid.encode(), C.c_int32(replica), C.byref(s)))
+        self._natoms[(matid, replica)] = int(sysd["natoms"])
+
+    def load_replica_file(self, matid: str, replica: int, path: str, natoms: int | None = None):
+        self._chk(lib().scema_md_load_replica_file(self.h, matid.encode(), C.c_int32(replica), path.encode()))
+        if natoms is not None:
+            self._natoms[(matid, replica)] = natoms
+
+    def strain_batch(self, sims, hooke: bool = False, rank: int = 0, world: int = 1):
+        arr = (MDSim * len(sims))(*sims) if not isinstance(sims, C.Array) else sims
+        self._chk(lib().scema_md_strain_batch(self.h, arr, C.c_int32(len(arr)), C.c_int32(1 if hooke else 0),
+                                              C.c_int32(rank), C.c_int32(world)))
+        return arr
+
+    def local_stress_ptr(self):
+        return lib().scema_md_local_stress_device_ptr(self.h), lib().scema_md_local_stress_count(self.h)
+
+    def has_state(self, qp, matid, replica) -> bool:
+        return bool(lib().scema_md_has_state(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica)))
+
+    def get_state(self, qp, matid, replica):
+        n = self._natoms[(matid, replica)]
+        box = np.zeros(9); x = np.zeros((n, 3)); v = np.zeros((n, 3))
+        self._chk(lib().scema_md_get_state(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), _p(box), _p(x), _p(v)))
+        return box, x, v
+
+    def set_state(self, qp, matid, replica, box, x, v):
+        box = np.ascontiguousarray(box, np.float64); x = np.ascontiguousarray(x, np.float64); v = np.ascontiguousarray(v, np.float64)
+        self._chk(lib().scema_md_set_state(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), _p(box), _p(x), _p(v)))
+
+    def drop_state(self, qp, matid, replica):
+        self._chk(lib().scema_md_drop_state(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica)))
+
+    def save_state_file(self, qp, matid, replica, path):
+        self._chk(lib().scema_md_save_state_file(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), path.encode()))
+
+    def load_state_file(self, qp, matid, replica, path):
+        self._chk(lib().scema_md_load_state_file(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), path.encode()))
+
+    def debug_compute(self, matid, replica, qp=QP_NONE, use_shake=False):
+        n = self._natoms[(matid, replica)]
+        f = np.zeros((n, 3)); e = np.zeros(NPART); w = np.zeros((NPART, 6)); info = np.zeros(8)
+        self._chk(lib().scema_md_debug_compute(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica),
+                                               C.c_int32(1 if use_shake else 0), _p(f), _p(e), _p(w), _p(info)))
+        return f, e, w, dict(g_ewald=info[0], nk=int(info[1]), npairs=info[2], tdof=info[3], t_current=info[4],
+                             maxneigh_seen=int(info[5]), maxneigh=int(info[6]), nclus=int(info[7]))
+
+    def debug_run(self, matid, replica, nsteps, dt, temperature, qp=QP_NONE, nvt=True, use_shake=True, rates=None, sample=False):
+        r = None if rates is None else np.ascontiguousarray(rates, np.float64)
+        pavg = np.zeros(6) if sample else None
+        self._chk(lib().scema_md_debug_run(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), C.c_int32(nsteps),
+                                           C.c_double(dt), C.c_double(temperature), C.c_int32(1 if nvt else 0),
+                                           C.c_int32(1 if use_shake else 0), _p(r), _p(pavg)))
+        return pavg
+
+    def profile(self, reset=False) -> dict:
+        p = Profile()
+        self._chk(lib().scema_md_get_profile(self.h, C.byref(p), C.c_int32(1 if reset else 0)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+def make_sim(qp_id: int, matid: str, replica: int, strain_len, *, most_recent: int | None = None, material: int = 0,
+             dt=2.0, temperature=300.0, strain_rate=1e-4, nss=100, force_field="opls", stiffness=None,
+             time_id="0-0", output_folder="", restart_folder="", scripts_folder="", log_file="none",
+             checkpoint=False) -> MDSim:
+    m = MDSim()
+    m.qp_id = qp_id
+    m.most_recent_qp_id = qp_id if most_recent is None else most_recent
+    m.replica = replica
+    m.material = material
+    m.matid = matid.encode(); m.time_id = time_id.encode(); m.output_folder = output_folder.encode()
+    m.restart_folder = restart_folder.encode(); m.scripts_folder = scripts_folder.encode()
+    m.log_file = log_file.encode(); m.force_field = force_field.encode()
+    m.strain[:] = list(np.asarray(strain_len, float))
+    if stiffness is not None:
+        m.stiffness[:] = list(np.asarray(stiffness, float).ravel())
+    m.timestep_length = dt; m.temperature = temperature; m.strain_rate = strain_rate
+    m.nsteps_sample = nss
+    m.output_homog = 0
+    m.checkpoint = 1 if checkpoint else 0
+    return m

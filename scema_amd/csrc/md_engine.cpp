@@ -1,0 +1,1216 @@
+// md_engine.cpp -- batch engine behind the C ABI of include/scema_md.h.
+//
+// Replaces STMDProblem<3>::lammps_straining (reference headers/stmd_problem.h:84-383): instead of
+// two LAMMPS lifetimes and three restart files per quadrature-point replica, every replica state
+// (x, v, box) stays resident in HBM keyed by (qp_id, matid, replica); a whole vector of MDSim
+// requests is advanced in lockstep by the kernels of md_kernels.hip, one launch per stage for the
+// whole batch, with no host synchronisation inside a run.
+//
+// Host-side arithmetic restated here, with the reference line it follows:
+//   lbdim / strain correction ........ stmd_problem.h:210-225
+//   nts rule ......................... stmd_problem.h:229-232
+//   "%f" dts/tempt, "%.6e" rates ..... stmd_problem.h:164,235,241
+//   state branch rule ................ stmd_problem.h:116-138,185-207
+//   stress = -<P> * 1.01325e5 ........ stmd_problem.h:335-341
+//   Hooke fallback ................... stmd_problem.h:386-392,479-483
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/scema_md.h"
+#include "md_kernels.h"
+#include "md_types.h"
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes && p) return hipSuccess;
+    release();
+    if (n == 0) n = 8;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct HostBox {
+  double lo[3], h[6], hinv[6], vol;
+};
+static void box_derive(const double *b, HostBox &o) {
+  for (int d = 0; d < 3; d++) o.lo[d] = b[d];
+  o.h[0] = b[3] - b[0]; o.h[1] = b[4] - b[1]; o.h[2] = b[5] - b[2];
+  o.h[3] = b[8]; o.h[4] = b[7]; o.h[5] = b[6];
+  o.hinv[0] = 1.0 / o.h[0]; o.hinv[1] = 1.0 / o.h[1]; o.hinv[2] = 1.0 / o.h[2];
+  o.hinv[3] = -o.h[3] / (o.h[1] * o.h[2]);
+  o.hinv[4] = (o.h[3] * o.h[5] - o.h[1] * o.h[4]) / (o.h[0] * o.h[1] * o.h[2]);
+  o.hinv[5] = -o.h[5] / (o.h[0] * o.h[1]);
+  o.vol = o.h[0] * o.h[1] * o.h[2];
+}
+static void perp_widths(const HostBox &b, double w[3]) {
+  w[0] = 1.0 / std::sqrt(b.hinv[0] * b.hinv[0] + b.hinv[5] * b.hinv[5] + b.hinv[4] * b.hinv[4]);
+  w[1] = 1.0 / std::sqrt(b.hinv[1] * b.hinv[1] + b.hinv[3] * b.hinv[3]);
+  w[2] = 1.0 / std::fabs(b.hinv[2]);
+}
+
+// -------------------------------------------------------------------------------------------
+// Topology of one (material, replica): immutable, shared by every quadrature point that uses it
+// -------------------------------------------------------------------------------------------
+struct Topo {
+  int natoms = 0, ntypes = 0;
+  std::vector<int> type;
+  std::vector<double> q, mass_atom, lj;
+  int nbonds = 0, nbonds_noshake = 0, nangles = 0, ndihedrals = 0, nimpropers = 0, nspecial = 0, nclus = 0, ncons = 0;
+  double qsqsum = 0, qsum = 0, excl_cut = 0;
+  double init_box[9];
+  std::vector<double> init_x, init_v;
+  // device copies
+  DevBuf d_type, d_q, d_mass, d_lj, d_bond_at, d_bond_cf, d_angle_at, d_angle_cf, d_dih_at, d_dih_cf, d_imp_at, d_imp_cf,
+      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d;
+};
+
+struct State {
+  Topo *topo = nullptr;
+  double box[9];
+  DevBuf x, v;
+};
+
+struct Slot {
+  int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
+  DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
+      xbak, vbak;
+};
+
+struct ActiveSim {
+  State *st = nullptr;
+  int user_index = -1;  // index into the caller's sims[]
+  int nsteps = 0;
+  double rates[6] = {0, 0, 0, 0, 0, 0};
+  double dt = 0, temperature = 0;
+  int nts = 0, nss = 0;
+  double pavg[6];
+};
+
+struct Profile {
+  long long pair_launches = 0;
+  double pair_ms = 0, pair_alg_bytes = 0;
+  long long md_steps = 0, neigh_builds = 0, evals = 0;
+  double unique_pairs_sum = 0;
+  long long unique_pairs_n = 0;
+};
+
+}  // namespace
+
+struct scema_md_engine {
+  scema_md_params p;
+  hipStream_t stream = nullptr;
+  std::map<std::string, std::unique_ptr<Topo>> topos;
+  std::map<std::string, std::unique_ptr<State>> states;
+  std::vector<std::unique_ptr<Slot>> slots;
+  DevBuf d_sims, d_sc, d_local_stress;
+  int local_stress_count = 0;
+  std::vector<SimDev> h_sims;
+  std::vector<SimScalars> h_sc;
+  std::vector<hipEvent_t> ev_pool;
+  Profile prof;
+  std::string err;
+  double neigh_grow = 1.0;
+};
+
+namespace {
+
+int fail(scema_md_engine *e, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf;
+  return code;
+}
+
+#define HIPCHK(call)                                                                                     \
+  do {                                                                                                   \
+    hipError_t _e = (call);                                                                              \
+    if (_e != hipSuccess) return fail(e, SCEMA_MD_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(_e)); \
+  } while (0)
+
+std::string topo_key(const char *matid, int replica) { return std::string(matid ? matid : "") + "_" + std::to_string(replica); }
+std::string state_key(int qp, const char *matid, int replica) { return std::to_string(qp) + "." + topo_key(matid, replica); }
+
+template <class T>
+int upload(scema_md_engine *e, DevBuf &b, const std::vector<T> &v) {
+  HIPCHK(b.ensure(v.size() * sizeof(T)));
+  if (!v.empty()) HIPCHK(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return SCEMA_MD_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// topology preprocessing
+// -------------------------------------------------------------------------------------------
+int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
+  const int n = s->natoms;
+  if (n <= 0 || s->ntypes <= 0 || s->ntypes > MD_MAXTYPES) return fail(e, SCEMA_MD_ERR_ARG, "natoms/ntypes out of range");
+  if (n > MD_JMASK) return fail(e, SCEMA_MD_ERR_ARG, "too many atoms for the 27-bit neighbour index");
+  t.natoms = n;
+  t.ntypes = s->ntypes;
+  t.type.assign(s->type, s->type + n);
+  t.q.assign(s->charge, s->charge + n);
+  t.mass_atom.resize(n);
+  for (int i = 0; i < n; i++) {
+    if (t.type[i] < 0 || t.type[i] >= s->ntypes) return fail(e, SCEMA_MD_ERR_ARG, "atom type out of range");
+    t.mass_atom[i] = s->mass[t.type[i]];
+    t.qsqsum += t.q[i] * t.q[i];
+    t.qsum += t.q[i];
+  }
+  const int nt2 = s->ntypes * s->ntypes;
+  t.lj.resize(4 * nt2);
+  for (int k = 0; k < nt2; k++) {
+    const double s6 = std::pow(s->sigma[k], 6.0), s12 = s6 * s6;
+    t.lj[k] = 48.0 * s->eps[k] * s12;
+    t.lj[nt2 + k] = 24.0 * s->eps[k] * s6;
+    t.lj[2 * nt2 + k] = 4.0 * s->eps[k] * s12;
+    t.lj[3 * nt2 + k] = 4.0 * s->eps[k] * s6;
+  }
+  // ---- bond graph -> 1-2 / 1-3 / 1-4 partners (lowest level wins) ----
+  std::vector<std::vector<int>> adj(n);
+  double max_r0 = 0.0;
+  for (int b = 0; b < s->nbonds; b++) {
+    const int a = s->bond_atoms[2 * b], c = s->bond_atoms[2 * b + 1];
+    if (a < 0 || a >= n || c < 0 || c >= n || a == c) return fail(e, SCEMA_MD_ERR_ARG, "bad bond %d", b);
+    adj[a].push_back(c);
+    adj[c].push_back(a);
+    max_r0 = std::max(max_r0, s->bond_coeff[2 * s->bond_type[b] + 1]);
+  }
+  std::vector<int> sp_at;
+  std::vector<double> sp_cf;
+  std::vector<std::vector<int>> excl(n);
+  std::vector<int> level(n, 0), frontier, next, touched;
+  int max_excl_level = 0;
+  for (int i = 0; i < n; i++) {
+    level[i] = -1;
+    touched.assign(1, i);
+    frontier.assign(1, i);
+    for (int lvl = 1; lvl <= 3; lvl++) {
+      next.clear();
+      for (int a : frontier)
+        for (int c : adj[a])
+          if (level[c] == 0) {
+            level[c] = lvl;
+            next.push_back(c);
+            touched.push_back(c);
+          }
+      frontier.swap(next);
+    }
+    for (int c : touched) {
+      if (c > i) {
+        const int lvl = level[c];
+        const double wl = s->special_lj[lvl - 1], wc = s->special_coul[lvl - 1];
+        if (!(wl == 1.0 && wc == 1.0)) {
+          sp_at.push_back(i);
+          sp_at.push_back(c);
+          sp_cf.push_back(wl);
+          sp_cf.push_back(wc);
+          excl[i].push_back(c);
+          excl[c].push_back(i);
+          max_excl_level = std::max(max_excl_level, lvl);
+        }
+      }
+    }
+    for (int c : touched) level[c] = 0;
+  }
+  t.nspecial = (int)sp_cf.size() / 2;
+  std::vector<int> ex_start(n + 1, 0), ex_list;
+  for (int i = 0; i < n; i++) {
+    std::sort(excl[i].begin(), excl[i].end());
+    ex_start[i + 1] = ex_start[i] + (int)excl[i].size();
+    ex_list.insert(ex_list.end(), excl[i].begin(), excl[i].end());
+  }
+  // build-time exclusion gate: an excluded pair is at most max_excl_level bonds apart
+  t.excl_cut = 1.5 * max_excl_level * max_r0;
+  // ---- fix shake ... m <mass>: star clusters ----
+  std::vector<char> shaken(s->nbonds, 0);
+  std::vector<int> nsh(n, 0);
+  if (e->p.shake_mass > 0.0)
+    for (int b = 0; b < s->nbonds; b++) {
+      const int a = s->bond_atoms[2 * b], c = s->bond_atoms[2 * b + 1];
+      if (std::fabs(t.mass_atom[a] - e->p.shake_mass) <= 0.1 || std::fabs(t.mass_atom[c] - e->p.shake_mass) <= 0.1) {
+        shaken[b] = 1;
+        nsh[a]++;
+        nsh[c]++;
+      }
+    }
+  std::vector<int> cl_of(n, -1), clus_at, clus_n;
+  std::vector<double> clus_d;
+  for (int b = 0; b < s->nbonds; b++) {
+    if (!shaken[b]) continue;
+    const int a = s->bond_atoms[2 * b], c = s->bond_atoms[2 * b + 1];
+    int cen, sat;
+    if (nsh[a] > nsh[c] || (nsh[a] == nsh[c] && a < c)) { cen = a; sat = c; } else { cen = c; sat = a; }
+    if (nsh[sat] != 1) return fail(e, SCEMA_MD_ERR_ARG, "SHAKE cluster is not star shaped (atom %d)", sat);
+    int cl = cl_of[cen];
+    if (cl < 0) {
+      cl = (int)clus_n.size();
+      cl_of[cen] = cl;
+      clus_n.push_back(1);
+      clus_at.insert(clus_at.end(), {cen, 0, 0, 0});
+      clus_d.insert(clus_d.end(), {0.0, 0.0, 0.0});
+    }
+    const int k = clus_n[cl];
+    if (k >= 4) return fail(e, SCEMA_MD_ERR_ARG, "SHAKE cluster of more than 4 atoms");
+    clus_at[4 * cl + k] = sat;
+    clus_d[3 * cl + (k - 1)] = s->bond_coeff[2 * s->bond_type[b] + 1];
+    clus_n[cl] = k + 1;
+    t.ncons++;
+  }
+  t.nclus = (int)clus_n.size();
+  // ---- per-term coefficient expansion; unconstrained bonds first ----
+  std::vector<int> bond_at, angle_at(s->angle_atoms, s->angle_atoms + 3 * (size_t)s->nangles),
+      dih_at(s->dihedral_atoms, s->dihedral_atoms + 4 * (size_t)s->ndihedrals),
+      imp_at(s->improper_atoms, s->improper_atoms + 4 * (size_t)s->nimpropers);
+  std::vector<double> bond_cf, angle_cf, dih_cf, imp_cf;
+  for (int pass = 0; pass < 2; pass++)
+    for (int b = 0; b < s->nbonds; b++) {
+      if ((int)shaken[b] != pass) continue;
+      bond_at.push_back(s->bond_atoms[2 * b]);
+      bond_at.push_back(s->bond_atoms[2 * b + 1]);
+      bond_cf.push_back(s->bond_coeff[2 * s->bond_type[b]]);
+      bond_cf.push_back(s->bond_coeff[2 * s->bond_type[b] + 1]);
+      if (pass == 0) t.nbonds_noshake++;
+    }
+  t.nbonds = s->nbonds;
+  t.nangles = s->nangles;
+  t.ndihedrals = s->ndihedrals;
+  t.nimpropers = s->nimpropers;
+  for (int m = 0; m < s->nangles; m++) {
+    angle_cf.push_back(s->angle_coeff[2 * s->angle_type[m]]);
+    angle_cf.push_back(s->angle_coeff[2 * s->angle_type[m] + 1]);
+  }
+  for (int m = 0; m < s->ndihedrals; m++)
+    for (int k = 0; k < 4; k++) dih_cf.push_back(s->dihedral_coeff[4 * s->dihedral_type[m] + k]);
+  for (int m = 0; m < s->nimpropers; m++) {
+    imp_cf.push_back(s->improper_coeff[2 * s->improper_type[m]]);
+    imp_cf.push_back(s->improper_coeff[2 * s->improper_type[m] + 1]);
+  }
+  for (size_t k = 0; k < angle_at.size(); k++)
+    if (angle_at[k] < 0 || angle_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad angle atom");
+  for (size_t k = 0; k < dih_at.size(); k++)
+    if (dih_at[k] < 0 || dih_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad dihedral atom");
+  for (size_t k = 0; k < imp_at.size(); k++)
+    if (imp_at[k] < 0 || imp_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad improper atom");
+  std::memcpy(t.init_box, s->box, sizeof t.init_box);
+  t.init_x.assign(s->x, s->x + 3 * (size_t)n);
+  t.init_v.assign(s->v, s->v + 3 * (size_t)n);
+  int rc;
+  if ((rc = upload(e, t.d_type, t.type))) return rc;
+  if ((rc = upload(e, t.d_q, t.q))) return rc;
+  if ((rc = upload(e, t.d_mass, t.mass_atom))) return rc;
+  if ((rc = upload(e, t.d_lj, t.lj))) return rc;
+  if ((rc = upload(e, t.d_bond_at, bond_at))) return rc;
+  if ((rc = upload(e, t.d_bond_cf, bond_cf))) return rc;
+  if ((rc = upload(e, t.d_angle_at, angle_at))) return rc;
+  if ((rc = upload(e, t.d_angle_cf, angle_cf))) return rc;
+  if ((rc = upload(e, t.d_dih_at, dih_at))) return rc;
+  if ((rc = upload(e, t.d_dih_cf, dih_cf))) return rc;
+  if ((rc = upload(e, t.d_imp_at, imp_at))) return rc;
+  if ((rc = upload(e, t.d_imp_cf, imp_cf))) return rc;
+  if ((rc = upload(e, t.d_sp_at, sp_at))) return rc;
+  if ((rc = upload(e, t.d_sp_cf, sp_cf))) return rc;
+  if ((rc = upload(e, t.d_ex_start, ex_start))) return rc;
+  if ((rc = upload(e, t.d_ex_list, ex_list))) return rc;
+  if ((rc = upload(e, t.d_clus_at, clus_at))) return rc;
+  if ((rc = upload(e, t.d_clus_n, clus_n))) return rc;
+  if ((rc = upload(e, t.d_clus_d, clus_d))) return rc;
+  return SCEMA_MD_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// Ewald run parameters from the current box: g_ewald rule of "kspace_style pppm <acc>"
+// (in.set.lammps:36) and the k-vector set of the reciprocal sum it approximates
+// -------------------------------------------------------------------------------------------
+struct EwaldSetup {
+  double g = 0.0;
+  std::vector<int> kn;
+  int kmaxd[3] = {0, 0, 0};
+};
+void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, EwaldSetup &out) {
+  out = EwaldSetup();
+  if (t.qsqsum == 0.0) return;
+  HostBox b;
+  box_derive(box, b);
+  const double accuracy = p.kspace_accuracy * MD_QQRD2E;
+  const double q2 = t.qsqsum * MD_QQRD2E;
+  const double rc = p.cut_coul;
+  const double tt = accuracy * std::sqrt((double)t.natoms * rc * b.h[0] * b.h[1] * b.h[2]) / (2.0 * q2);
+  out.g = (tt >= 1.0) ? (1.35 - 0.15 * std::log(accuracy)) / rc : std::sqrt(-std::log(tt)) / rc;
+  const double g = out.g;
+  int kmax[3];
+  double gsqmx = 0.0;
+  for (int d = 0; d < 3; d++) {
+    const double L = b.h[d];
+    int km = 1;
+    for (;;) {
+      const double err = 2.0 * q2 * g / L * std::sqrt(1.0 / (MD_PI * km * t.natoms)) * std::exp(-MD_PI * MD_PI * km * km / (g * g * L * L));
+      if (err <= accuracy) break;
+      km++;
+    }
+    kmax[d] = km;
+    const double u = 2.0 * MD_PI * km / L;
+    gsqmx = std::max(gsqmx, u * u);
+  }
+  gsqmx *= 1.00001;
+  const int r0 = kmax[0] + 2, r1 = kmax[1] + 2, r2 = kmax[2] + 2;
+  for (int n1 = 0; n1 <= r0; n1++)
+    for (int n2 = -r1; n2 <= r1; n2++)
+      for (int n3 = -r2; n3 <= r2; n3++) {
+        if (n1 == 0 && (n2 < 0 || (n2 == 0 && n3 <= 0))) continue;
+        const double kx = 2.0 * MD_PI * (b.hinv[0] * n1);
+        const double ky = 2.0 * MD_PI * (b.hinv[5] * n1 + b.hinv[1] * n2);
+        const double kz = 2.0 * MD_PI * (b.hinv[4] * n1 + b.hinv[3] * n2 + b.hinv[2] * n3);
+        if (kx * kx + ky * ky + kz * kz > gsqmx) continue;
+        out.kn.push_back(n1);
+        out.kn.push_back(n2);
+        out.kn.push_back(n3);
+        out.kmaxd[0] = std::max(out.kmaxd[0], std::abs(n1));
+        out.kmaxd[1] = std::max(out.kmaxd[1], std::abs(n2));
+        out.kmaxd[2] = std::max(out.kmaxd[2], std::abs(n3));
+      }
+}
+
+// fix-deform box at time t (same expression as k_post)
+void deform_box(const double *box0, const double *rates, double t, double *out) {
+  for (int d = 0; d < 3; d++) {
+    const double L0 = box0[3 + d] - box0[d];
+    out[d] = box0[d] - 0.5 * L0 * rates[d] * t;
+    out[3 + d] = box0[3 + d] + 0.5 * L0 * rates[d] * t;
+  }
+  out[6] = box0[6] + rates[3] * (box0[4] - box0[1]) * t;
+  out[7] = box0[7] + rates[4] * (box0[5] - box0[2]) * t;
+  out[8] = box0[8] + rates[5] * (box0[5] - box0[2]) * t;
+}
+
+double round_trip(const char *fmt, double v) {
+  char buf[512];
+  snprintf(buf, sizeof buf, fmt, v);
+  return strtod(buf, nullptr);
+}
+
+// -------------------------------------------------------------------------------------------
+// one "run" of a batch
+// -------------------------------------------------------------------------------------------
+struct RunSpec {
+  int nvt = 1, use_shake = 1, deform = 0, sample = 0, ev_always = 0;
+  int static_only = 0;  // parity hook: forces of the potential only (no constraint forces)
+};
+
+int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncells, int nk) {
+  const int npad = (natoms + 255) / 256 * 256;
+  if (natoms > sl.cap_atoms) {
+    HIPCHK(sl.f.ensure(3 * (size_t)natoms * 8));
+    HIPCHK(sl.wrapn.ensure(3 * (size_t)natoms * 4));
+    HIPCHK(sl.xhold.ensure(3 * (size_t)natoms * 8));
+    HIPCHK(sl.cell_of.ensure((size_t)natoms * 4));
+    HIPCHK(sl.slot_tmp.ensure((size_t)natoms * 4));
+    HIPCHK(sl.xbak.ensure(3 * (size_t)natoms * 8));
+    HIPCHK(sl.vbak.ensure(3 * (size_t)natoms * 8));
+    HIPCHK(sl.xq.ensure((size_t)npad * 32));
+    HIPCHK(sl.stype.ensure((size_t)npad * 4));
+    HIPCHK(sl.perm.ensure((size_t)npad * 4));
+    HIPCHK(sl.numneigh.ensure((size_t)npad * 4));
+    sl.cap_atoms = natoms;
+    sl.cap_pad = npad;
+    sl.cap_neigh = 0;
+  }
+  if ((size_t)maxneigh * npad > (size_t)sl.cap_neigh * sl.cap_pad || sl.cap_neigh == 0) {
+    HIPCHK(sl.neigh.ensure((size_t)maxneigh * npad * 4));
+    sl.cap_neigh = maxneigh;
+  }
+  if (ncells + 1 > sl.cap_cells) {
+    HIPCHK(sl.cell_count.ensure((size_t)(ncells + 1) * 4));
+    HIPCHK(sl.cell_start.ensure((size_t)(ncells + 1) * 4));
+    HIPCHK(sl.cell_fill.ensure((size_t)(ncells + 1) * 4));
+    sl.cap_cells = ncells + 1;
+  }
+  if (nk > sl.cap_k || sl.cap_k == 0) {
+    const int kc = std::max(nk, 64);
+    HIPCHK(sl.kn.ensure((size_t)kc * 3 * 4));
+    HIPCHK(sl.sfac.ensure((size_t)kc * 2 * 8));
+    HIPCHK(sl.kvec.ensure((size_t)kc * 4 * 8));
+    sl.cap_k = kc;
+  }
+  return SCEMA_MD_OK;
+}
+
+// Advance sims[0..ns) (already assigned to slots 0..ns-1, scalars' box valid on the device).
+// On return the per-sim SimScalars are in e->h_sc.
+int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &spec) {
+  const int ns = (int)sims.size();
+  const scema_md_params &P = e->p;
+  const double rlist = std::max(P.cut_lj, P.cut_coul) + P.skin;
+  // order: longest run first, so the active simulations are always a prefix
+  std::vector<int> order(ns);
+  for (int i = 0; i < ns; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
+  e->h_sims.assign(ns, SimDev());
+  int maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
+  std::vector<int> kn_all;
+  // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
+  for (int pos = 0; pos < ns; pos++) {
+    const int i = order[pos];
+    ActiveSim &A = sims[i];
+    Topo &T = *A.st->topo;
+    const SimScalars &hsc = e->h_sc[i];
+    // box range over this run -> cell grid that stays valid while the box deforms
+    double box_end[9];
+    std::memcpy(box_end, hsc.box, sizeof box_end);
+    if (spec.deform) deform_box(hsc.box, A.rates, A.nsteps * A.dt, box_end);
+    HostBox b0, b1;
+    box_derive(hsc.box, b0);
+    box_derive(box_end, b1);
+    double w0[3], w1[3];
+    perp_widths(b0, w0);
+    perp_widths(b1, w1);
+    SimDev S;
+    std::memset(&S, 0, sizeof S);
+    for (int d = 0; d < 3; d++) {
+      const double w = std::min(w0[d], w1[d]);
+      if (w < 2.0 * rlist) return fail(e, SCEMA_MD_ERR_BOX, "box width %.3f < 2*(cutoff+skin) = %.3f in dim %d", w, 2 * rlist, d);
+      int nc = (int)std::floor(w / (0.5 * rlist * 1.0001));
+      nc = std::max(1, std::min(nc, 64));
+      S.nc[d] = nc;
+      S.mst[d] = (int)std::ceil(rlist / (w / nc) - 1e-12);
+    }
+    if (spec.deform) {
+      const double tol = 1.0000001;
+      if (std::fabs(box_end[6]) > 0.5 * b1.h[0] * tol || std::fabs(box_end[7]) > 0.5 * b1.h[0] * tol || std::fabs(box_end[8]) > 0.5 * b1.h[1] * tol)
+        return fail(e, SCEMA_MD_ERR_BOX, "strain needs a triclinic box flip (fix deform flip yes): not supported");
+    }
+    S.ncells = S.nc[0] * S.nc[1] * S.nc[2];
+    EwaldSetup ew;
+    ewald_setup(P, T, hsc.box, ew);
+    S.nk = (int)ew.kn.size() / 3;
+    for (int d = 0; d < 3; d++) S.kmaxd[d] = ew.kmaxd[d];
+    S.g_ewald = ew.g;
+    S.natoms = T.natoms;
+    S.npad = (T.natoms + 255) / 256 * 256;
+    S.ntypes = T.ntypes;
+    const double rho = T.natoms / std::min(b0.vol, b1.vol);
+    int maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.15 * e->neigh_grow) + 48;
+    maxneigh = std::min(maxneigh, T.natoms);
+    Slot &sl = *e->slots[i];
+    int rc = ensure_slot(e, sl, T.natoms, maxneigh, S.ncells, S.nk);
+    if (rc) return rc;
+    S.maxneigh = maxneigh;
+    S.nbonds = T.nbonds; S.nbonds_noshake = T.nbonds_noshake; S.nangles = T.nangles; S.ndihedrals = T.ndihedrals;
+    S.nimpropers = T.nimpropers; S.nspecial = T.nspecial; S.nclus = T.nclus;
+    S.nsteps = A.nsteps;
+    S.nav = 0; S.nwin = 0;
+    if (spec.sample) {
+      // in.homogenization.lammps:57 : nav = nss/10 (nss/1000 beyond 10000 steps); nss/nav windows
+      S.nav = (A.nsteps > 10000) ? A.nsteps / 1000 : A.nsteps / 10;
+      if (S.nav < 1) S.nav = 1;
+      S.nwin = A.nsteps / S.nav;
+    }
+    S.nvt = spec.nvt;
+    S.use_shake = (spec.use_shake && T.nclus > 0) ? 1 : 0;
+    S.deform = spec.deform;
+    S.t_chain = std::min(P.t_chain, MD_MAXCHAIN);
+    S.neigh_delay = P.neigh_delay;
+    S.shake_maxiter = P.shake_maxiter;
+    S.dt = A.dt;
+    S.t_target = A.temperature;
+    S.t_freq = 1.0 / P.t_period;
+    S.tdof = 3.0 * T.natoms - 3.0 - (S.use_shake ? T.ncons : 0);
+    S.qsqsum = T.qsqsum; S.qsum = T.qsum;
+    S.cut_lj2 = P.cut_lj * P.cut_lj; S.cut_coul2 = P.cut_coul * P.cut_coul; S.rlist2 = rlist * rlist;
+    S.skin = P.skin;
+    S.excl_cut2 = std::min(T.excl_cut * T.excl_cut, S.rlist2);
+    S.shake_tol = P.shake_tol;
+    for (int k = 0; k < 6; k++) S.rates[k] = A.rates[k];
+    S.type = T.d_type.as<int>(); S.q = T.d_q.as<double>(); S.mass = T.d_mass.as<double>(); S.lj = T.d_lj.as<double>();
+    S.bond_at = T.d_bond_at.as<int>(); S.bond_cf = T.d_bond_cf.as<double>();
+    S.angle_at = T.d_angle_at.as<int>(); S.angle_cf = T.d_angle_cf.as<double>();
+    S.dihedral_at = T.d_dih_at.as<int>(); S.dihedral_cf = T.d_dih_cf.as<double>();
+    S.improper_at = T.d_imp_at.as<int>(); S.improper_cf = T.d_imp_cf.as<double>();
+    S.special_at = T.d_sp_at.as<int>(); S.special_cf = T.d_sp_cf.as<double>();
+    S.ex_start = T.d_ex_start.as<int>(); S.ex_list = T.d_ex_list.as<int>();
+    S.clus_at = T.d_clus_at.as<int>(); S.clus_n = T.d_clus_n.as<int>(); S.clus_d = T.d_clus_d.as<double>();
+    S.x = A.st->x.as<double>(); S.v = A.st->v.as<double>(); S.f = sl.f.as<double>();
+    S.xq = sl.xq.as<double4>(); S.stype = sl.stype.as<int>(); S.perm = sl.perm.as<int>(); S.slot_tmp = sl.slot_tmp.as<int>();
+    S.wrapn = sl.wrapn.as<int>(); S.xhold = sl.xhold.as<double>();
+    S.cell_of = sl.cell_of.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
+    S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
+    S.kn = sl.kn.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
+    S.sc = e->d_sc.as<SimScalars>() + i;
+    if (S.nk > 0) HIPCHK(hipMemcpyAsync(sl.kn.p, ew.kn.data(), ew.kn.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // ew.kn is a local
+    e->h_sims[pos] = S;
+    maxatoms = std::max(maxatoms, S.natoms); maxpad = std::max(maxpad, S.npad); maxcells = std::max(maxcells, S.ncells);
+    maxk = std::max(maxk, S.nk);
+    for (int d = 0; d < 3; d++) mmax = std::max(mmax, S.kmaxd[d] + 1);
+    maxb = std::max(maxb, S.nbonds); maxa = std::max(maxa, S.nangles); maxd = std::max(maxd, S.ndihedrals);
+    maxi = std::max(maxi, S.nimpropers); maxs = std::max(maxs, S.nspecial); maxclus = std::max(maxclus, S.use_shake ? S.nclus : 0);
+    maxsteps = std::max(maxsteps, A.nsteps);
+  }
+  if ((size_t)64 * 3 * mmax * 16 > 150 * 1024) return fail(e, SCEMA_MD_ERR_ARG, "k-space index range too large for the LDS phase tables");
+  HIPCHK(e->d_sims.ensure((size_t)ns * sizeof(SimDev)));
+  HIPCHK(hipMemcpyAsync(e->d_sims.p, e->h_sims.data(), (size_t)ns * sizeof(SimDev), hipMemcpyHostToDevice, e->stream));
+  const SimDev *D = e->d_sims.as<SimDev>();
+  hipStream_t st = e->stream;
+  const int ev = (spec.sample || spec.ev_always) ? 1 : 0;
+  // ---- setup (step 0) ----
+  mdk_phase_init(st, D, ns);
+  mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells);
+  mdk_pair(st, D, ns, maxpad, ev);
+  mdk_bonded(st, D, ns, maxb, maxa, maxd, maxi, maxs);
+  mdk_ewald(st, D, ns, maxatoms, maxk, mmax);
+  if (!spec.static_only) mdk_shake(st, D, ns, maxclus, 0.5);
+  mdk_final_integrate(st, D, ns, maxatoms, 0);
+  mdk_setup_post(st, D, ns);
+  // ---- steps ----
+  const bool prof = e->p.profile != 0;
+  size_t ev_used = 0;
+  std::vector<double> launch_bytes;
+  for (int step = 1; step <= maxsteps; step++) {
+    int na = 0;
+    while (na < ns && e->h_sims[na].nsteps >= step) na++;
+    if (na == 0) break;
+    mdk_pre(st, D, na);
+    mdk_initial_integrate(st, D, na, maxatoms);
+    mdk_neighbor(st, D, na, maxatoms, maxpad, maxcells);
+    if (prof) {
+      if (ev_used + 2 > e->ev_pool.size()) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        e->ev_pool.push_back(a);
+        e->ev_pool.push_back(b);
+      }
+      HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
+    }
+    mdk_pair(st, D, na, maxpad, ev);
+    if (prof) {
+      HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
+      ev_used += 2;
+      launch_bytes.push_back((double)na);
+    }
+    mdk_bonded(st, D, na, maxb, maxa, maxd, maxi, maxs);
+    mdk_ewald(st, D, na, maxatoms, maxk, mmax);
+    mdk_shake(st, D, na, maxclus, 1.0);
+    mdk_final_integrate(st, D, na, maxatoms, 1);
+    mdk_post(st, D, na);
+    if (spec.deform) mdk_remap(st, D, na, maxatoms);
+    e->prof.md_steps += na;
+  }
+  mdk_phase_end(st, D, ns, maxatoms);
+  HIPCHK(hipMemcpyAsync(e->h_sc.data(), e->d_sc.p, (size_t)ns * sizeof(SimScalars), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  if (prof) {
+    // algorithmic bytes of one pair launch: per simulation N*(4*nbar + 56) + 48 with
+    // nbar = stored neighbours per atom of the (full) list
+    double per_sim_bytes = 0.0;  // averaged over the batch; active prefix differs only for ragged nts
+    std::vector<double> simbytes(ns);
+    for (int pos = 0; pos < ns; pos++) {
+      const int i = order[pos];
+      simbytes[pos] = 4.0 * (double)e->h_sc[i].nentries + 56.0 * e->h_sims[pos].natoms + 48.0;
+      per_sim_bytes += simbytes[pos];
+    }
+    (void)per_sim_bytes;
+    for (size_t l = 0; l < launch_bytes.size(); l++) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[2 * l], e->ev_pool[2 * l + 1]));
+      e->prof.pair_ms += ms;
+      e->prof.pair_launches += 1;
+      const int na = (int)launch_bytes[l];
+      for (int pos = 0; pos < na; pos++) e->prof.pair_alg_bytes += simbytes[pos];
+    }
+  }
+  int fault = 0;
+  for (int i = 0; i < ns; i++) {
+    fault |= e->h_sc[i].overflow;
+    e->prof.neigh_builds += e->h_sc[i].nbuilds;
+    e->prof.unique_pairs_sum += 0.5 * (double)e->h_sc[i].nentries;
+    e->prof.unique_pairs_n += 1;
+  }
+  if (fault & 2) return fail(e, SCEMA_MD_ERR_ARG, "an excluded (special) pair stretched beyond the exclusion gate; topology or state is broken");
+  if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
+  return SCEMA_MD_OK;
+}
+
+int prepare_slots(scema_md_engine *e, std::vector<ActiveSim> &sims) {
+  const int ns = (int)sims.size();
+  while ((int)e->slots.size() < ns) e->slots.emplace_back(new Slot());
+  HIPCHK(e->d_sc.ensure((size_t)std::max(ns, 1) * sizeof(SimScalars)));
+  e->h_sc.assign(ns, SimScalars());
+  for (int i = 0; i < ns; i++) {
+    std::memset(&e->h_sc[i], 0, sizeof(SimScalars));
+    std::memcpy(e->h_sc[i].box, sims[i].st->box, 9 * sizeof(double));
+    e->h_sc[i].vscale = 1.0;
+  }
+  HIPCHK(hipMemcpyAsync(e->d_sc.p, e->h_sc.data(), (size_t)ns * sizeof(SimScalars), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return SCEMA_MD_OK;
+}
+
+// scalars that must not leak from one run into the next when h_sc is re-uploaded
+int reupload_scalars(scema_md_engine *e, int ns) {
+  for (int i = 0; i < ns; i++) {
+    e->h_sc[i].overflow = 0;
+    e->h_sc[i].nbuilds = 0;
+    e->h_sc[i].maxneigh_seen = 0;
+  }
+  HIPCHK(hipMemcpyAsync(e->d_sc.p, e->h_sc.data(), (size_t)ns * sizeof(SimScalars), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return SCEMA_MD_OK;
+}
+
+State *find_state(scema_md_engine *e, int qp, const char *matid, int replica) {
+  auto it = e->states.find(state_key(qp, matid, replica));
+  return it == e->states.end() ? nullptr : it->second.get();
+}
+Topo *find_topo(scema_md_engine *e, const char *matid, int replica) {
+  auto it = e->topos.find(topo_key(matid, replica));
+  return it == e->topos.end() ? nullptr : it->second.get();
+}
+
+int make_state(scema_md_engine *e, Topo *t, const double *box, const double *x, const double *v, bool from_device,
+               std::unique_ptr<State> &out) {
+  out.reset(new State());
+  out->topo = t;
+  std::memcpy(out->box, box, 9 * sizeof(double));
+  const size_t bytes = 3 * (size_t)t->natoms * sizeof(double);
+  HIPCHK(out->x.ensure(bytes));
+  HIPCHK(out->v.ensure(bytes));
+  const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(hipMemcpy(out->x.p, x, bytes, kind));
+  HIPCHK(hipMemcpy(out->v.p, v, bytes, kind));
+  return SCEMA_MD_OK;
+}
+
+// state branch rule of stmd_problem.h:116-138,185-207
+int resolve_state(scema_md_engine *e, const scema_mdsim &m, State **out) {
+  Topo *t = find_topo(e, m.matid, m.replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered (init.%s_%d.bin missing)", m.matid, m.replica, m.matid, m.replica);
+  State *src = nullptr;
+  if (m.qp_id != m.most_recent_qp_id) {
+    src = find_state(e, m.most_recent_qp_id, m.matid, m.replica);
+    if (m.most_recent_qp_id == SCEMA_MD_QP_NONE) {
+      if (src) return fail(e, SCEMA_MD_ERR_NOSTATE, "state exists for the 'none' quadrature point id");
+    } else if (!src)
+      return fail(e, SCEMA_MD_ERR_NOSTATE, "no state last.%d.%s_%d to branch from", m.most_recent_qp_id, m.matid, m.replica);
+  } else {
+    src = find_state(e, m.qp_id, m.matid, m.replica);
+  }
+  State *dst = find_state(e, m.qp_id, m.matid, m.replica);
+  if (src && src == dst) {
+    *out = dst;
+    return SCEMA_MD_OK;
+  }
+  std::unique_ptr<State> ns;
+  int rc;
+  if (src)
+    rc = make_state(e, t, src->box, src->x.as<double>(), src->v.as<double>(), true, ns);
+  else
+    rc = make_state(e, t, t->init_box, t->init_x.data(), t->init_v.data(), false, ns);
+  if (rc) return rc;
+  *out = ns.get();
+  e->states[state_key(m.qp_id, m.matid, m.replica)] = std::move(ns);
+  return SCEMA_MD_OK;
+}
+
+void hooke(const double *c, const double *eps, double *out) {
+  static const int RAW_OF[3][3] = {{0, 3, 4}, {3, 1, 5}, {4, 5, 2}};
+  static const int FILE_OF[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  for (int k = 0; k < 3; k++)
+    for (int l = k; l < 3; l++) {
+      double acc = 0.0;
+      for (int m = 0; m < 3; m++)
+        for (int n = 0; n < 3; n++) acc += c[FILE_OF[k][l] * 6 + FILE_OF[m][n]] * eps[RAW_OF[m][n]];
+      out[RAW_OF[k][l]] = acc;
+    }
+}
+
+// full evaluation (phase A + phase B) of a chunk of simulations, with overflow retry
+int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk) {
+  const int ns = (int)chunk.size();
+  for (int attempt = 0; attempt < 4; attempt++) {
+    int rc = prepare_slots(e, chunk);
+    if (rc) return rc;
+    // backup for a retry after neighbour overflow
+    for (int i = 0; i < ns; i++) {
+      Slot &sl = *e->slots[i];
+      const size_t bytes = 3 * (size_t)chunk[i].st->topo->natoms * 8;
+      HIPCHK(sl.xbak.ensure(bytes));
+      HIPCHK(sl.vbak.ensure(bytes));
+      HIPCHK(hipMemcpyAsync(sl.xbak.p, chunk[i].st->x.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(sl.vbak.p, chunk[i].st->v.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+    }
+    RunSpec A;
+    A.deform = 1;
+    for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nts;
+    rc = run_phase(e, chunk, A);
+    if (rc == SCEMA_MD_OK) {
+      rc = reupload_scalars(e, ns);
+      if (rc) return rc;
+      RunSpec B;
+      B.sample = 1;
+      for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nss;
+      rc = run_phase(e, chunk, B);
+    }
+    if (rc == SCEMA_MD_OK) {
+      for (int i = 0; i < ns; i++) {
+        const SimScalars &sc = e->h_sc[i];
+        std::memcpy(chunk[i].st->box, sc.box, 9 * sizeof(double));
+        for (int k = 0; k < 6; k++) chunk[i].pavg[k] = sc.psum[k] / (double)std::max(sc.nsamples, 1);
+      }
+      e->prof.evals += ns;
+      return SCEMA_MD_OK;
+    }
+    if (rc != SCEMA_MD_ERR_OVERFLOW) return rc;
+    // restore and grow
+    for (int i = 0; i < ns; i++) {
+      Slot &sl = *e->slots[i];
+      const size_t bytes = 3 * (size_t)chunk[i].st->topo->natoms * 8;
+      HIPCHK(hipMemcpyAsync(chunk[i].st->x.p, sl.xbak.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(chunk[i].st->v.p, sl.vbak.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->neigh_grow *= 1.5;
+  }
+  return fail(e, SCEMA_MD_ERR_OVERFLOW, "neighbour capacity exceeded after regrowth");
+}
+
+}  // namespace
+
+// ===========================================================================================
+// C ABI
+// ===========================================================================================
+extern "C" {
+
+void scema_md_default_params(scema_md_params *p) {
+  p->cut_lj = 12.0;
+  p->cut_coul = 9.0;
+  p->skin = 2.0;
+  p->neigh_delay = 5;
+  p->kspace_accuracy = 1.0e-4;
+  p->shake_tol = 1.0e-3;
+  p->shake_maxiter = 20;
+  p->shake_mass = 1.0;
+  p->t_period = 100.0;
+  p->t_chain = 3;
+  p->device = 0;
+  p->max_batch = 0;
+  p->profile = 0;
+}
+
+int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
+  if (!out) return SCEMA_MD_ERR_ARG;
+  *out = nullptr;
+  scema_md_engine *e = new scema_md_engine();
+  if (p) e->p = *p; else scema_md_default_params(&e->p);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    delete e;
+    return SCEMA_MD_ERR_DEVICE;  // no GPU: the product path has no CPU fallback
+  }
+  if (hipSetDevice(e->p.device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete e;
+    return SCEMA_MD_ERR_DEVICE;
+  }
+  *out = e;
+  return SCEMA_MD_OK;
+}
+
+void scema_md_destroy(scema_md_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->p.device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  e->states.clear();
+  e->topos.clear();
+  e->slots.clear();
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+const char *scema_md_last_error(const scema_md_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+int scema_md_register_replica(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_system *sys) {
+  if (!e || !matid || !sys) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  std::unique_ptr<Topo> t(new Topo());
+  int rc = build_topo(e, sys, *t);
+  if (rc) return rc;
+  // re-registering a replica invalidates every state that was derived from the old one
+  const std::string suffix = "." + topo_key(matid, replica);
+  for (auto it = e->states.begin(); it != e->states.end();) {
+    const std::string &k = it->first;
+    if (k.size() >= suffix.size() && k.compare(k.size() - suffix.size(), suffix.size(), suffix) == 0) it = e->states.erase(it);
+    else ++it;
+  }
+  e->topos[topo_key(matid, replica)] = std::move(t);
+  return SCEMA_MD_OK;
+}
+
+// ---- replica container file (our stand-in for the LAMMPS binary restart init.<mat>_<rep>.bin) ----
+static const char REPL_MAGIC[8] = {'S', 'C', 'E', 'M', 'A', 'M', 'D', '1'};
+static const char STATE_MAGIC[8] = {'S', 'C', 'E', 'M', 'A', 'S', 'T', '1'};
+
+int scema_md_write_replica_file(const char *path, const scema_md_system *s) {
+  FILE *fp = fopen(path, "wb");
+  if (!fp) return SCEMA_MD_ERR_IO;
+  int32_t hdr[10] = {s->natoms, s->ntypes, s->nbonds, s->nbondtypes, s->nangles, s->nangletypes, s->ndihedrals, s->ndihedraltypes, s->nimpropers, s->nimpropertypes};
+  bool ok = fwrite(REPL_MAGIC, 1, 8, fp) == 8 && fwrite(hdr, 4, 10, fp) == 10;
+  auto W = [&](const void *p, size_t sz, size_t n) { if (ok && n) ok = fwrite(p, sz, n, fp) == n; };
+  W(s->special_lj, 8, 3); W(s->special_coul, 8, 3); W(s->box, 8, 9);
+  W(s->type, 4, s->natoms); W(s->charge, 8, s->natoms); W(s->mass, 8, s->ntypes);
+  W(s->eps, 8, (size_t)s->ntypes * s->ntypes); W(s->sigma, 8, (size_t)s->ntypes * s->ntypes);
+  W(s->bond_atoms, 4, 2 * (size_t)s->nbonds); W(s->bond_type, 4, s->nbonds); W(s->bond_coeff, 8, 2 * (size_t)s->nbondtypes);
+  W(s->angle_atoms, 4, 3 * (size_t)s->nangles); W(s->angle_type, 4, s->nangles); W(s->angle_coeff, 8, 2 * (size_t)s->nangletypes);
+  W(s->dihedral_atoms, 4, 4 * (size_t)s->ndihedrals); W(s->dihedral_type, 4, s->ndihedrals); W(s->dihedral_coeff, 8, 4 * (size_t)s->ndihedraltypes);
+  W(s->improper_atoms, 4, 4 * (size_t)s->nimpropers); W(s->improper_type, 4, s->nimpropers); W(s->improper_coeff, 8, 2 * (size_t)s->nimpropertypes);
+  W(s->x, 8, 3 * (size_t)s->natoms); W(s->v, 8, 3 * (size_t)s->natoms);
+  fclose(fp);
+  return ok ? SCEMA_MD_OK : SCEMA_MD_ERR_IO;
+}
+
+int scema_md_load_replica_file(scema_md_engine *e, const char *matid, int32_t replica, const char *path) {
+  if (!e || !path) return SCEMA_MD_ERR_ARG;
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return fail(e, SCEMA_MD_ERR_IO, "cannot open %s", path);
+  char magic[16] = {0};
+  if (fread(magic, 1, 8, fp) != 8) { fclose(fp); return fail(e, SCEMA_MD_ERR_IO, "short file %s", path); }
+  if (std::memcmp(magic, REPL_MAGIC, 8) != 0) {
+    fclose(fp);
+    if (std::memcmp(magic, "LammpS R", 8) == 0)
+      return fail(e, SCEMA_MD_ERR_IO, "%s is a LAMMPS binary restart; convert it with write_data and scema_amd.lammps_data (SURVEY row f-1)", path);
+    return fail(e, SCEMA_MD_ERR_IO, "%s: unknown replica file format", path);
+  }
+  int32_t h[10];
+  bool ok = fread(h, 4, 10, fp) == 10;
+  scema_md_system s;
+  std::memset(&s, 0, sizeof s);
+  std::vector<int32_t> type, ba, bt, aa, at, da, dt, ia, it;
+  std::vector<double> q, mass, eps, sig, bc, ac, dc, ic, x, v;
+  auto R = [&](void *p, size_t sz, size_t n) { if (ok && n) ok = fread(p, sz, n, fp) == n; };
+  if (ok) {
+    s.natoms = h[0]; s.ntypes = h[1]; s.nbonds = h[2]; s.nbondtypes = h[3]; s.nangles = h[4]; s.nangletypes = h[5];
+    s.ndihedrals = h[6]; s.ndihedraltypes = h[7]; s.nimpropers = h[8]; s.nimpropertypes = h[9];
+    for (int k = 0; k < 10; k++) if (h[k] < 0) ok = false;
+  }
+  if (ok) {
+    R(s.special_lj, 8, 3); R(s.special_coul, 8, 3); R(s.box, 8, 9);
+    type.resize(s.natoms); q.resize(s.natoms); mass.resize(s.ntypes); eps.resize((size_t)s.ntypes * s.ntypes); sig.resize(eps.size());
+    ba.resize(2 * (size_t)s.nbonds); bt.resize(s.nbonds); bc.resize(2 * (size_t)s.nbondtypes);
+    aa.resize(3 * (size_t)s.nangles); at.resize(s.nangles); ac.resize(2 * (size_t)s.nangletypes);
+    da.resize(4 * (size_t)s.ndihedrals); dt.resize(s.ndihedrals); dc.resize(4 * (size_t)s.ndihedraltypes);
+    ia.resize(4 * (size_t)s.nimpropers); it.resize(s.nimpropers); ic.resize(2 * (size_t)s.nimpropertypes);
+    x.resize(3 * (size_t)s.natoms); v.resize(x.size());
+    R(type.data(), 4, type.size()); R(q.data(), 8, q.size()); R(mass.data(), 8, mass.size()); R(eps.data(), 8, eps.size()); R(sig.data(), 8, sig.size());
+    R(ba.data(), 4, ba.size()); R(bt.data(), 4, bt.size()); R(bc.data(), 8, bc.size());
+    R(aa.data(), 4, aa.size()); R(at.data(), 4, at.size()); R(ac.data(), 8, ac.size());
+    R(da.data(), 4, da.size()); R(dt.data(), 4, dt.size()); R(dc.data(), 8, dc.size());
+    R(ia.data(), 4, ia.size()); R(it.data(), 4, it.size()); R(ic.data(), 8, ic.size());
+    R(x.data(), 8, x.size()); R(v.data(), 8, v.size());
+  }
+  fclose(fp);
+  if (!ok) return fail(e, SCEMA_MD_ERR_IO, "truncated or corrupt replica file %s", path);
+  s.type = type.data(); s.charge = q.data(); s.mass = mass.data(); s.eps = eps.data(); s.sigma = sig.data();
+  s.bond_atoms = ba.data(); s.bond_type = bt.data(); s.bond_coeff = bc.data();
+  s.angle_atoms = aa.data(); s.angle_type = at.data(); s.angle_coeff = ac.data();
+  s.dihedral_atoms = da.data(); s.dihedral_type = dt.data(); s.dihedral_coeff = dc.data();
+  s.improper_atoms = ia.data(); s.improper_type = it.data(); s.improper_coeff = ic.data();
+  s.x = x.data(); s.v = v.data();
+  for (int b = 0; b < s.nbonds; b++) if (bt[b] < 0 || bt[b] >= s.nbondtypes) return fail(e, SCEMA_MD_ERR_IO, "bad bond type in %s", path);
+  for (int b = 0; b < s.nangles; b++) if (at[b] < 0 || at[b] >= s.nangletypes) return fail(e, SCEMA_MD_ERR_IO, "bad angle type in %s", path);
+  for (int b = 0; b < s.ndihedrals; b++) if (dt[b] < 0 || dt[b] >= s.ndihedraltypes) return fail(e, SCEMA_MD_ERR_IO, "bad dihedral type in %s", path);
+  for (int b = 0; b < s.nimpropers; b++) if (it[b] < 0 || it[b] >= s.nimpropertypes) return fail(e, SCEMA_MD_ERR_IO, "bad improper type in %s", path);
+  return scema_md_register_replica(e, matid, replica, &s);
+}
+
+// ---- the hot path ----
+int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims, int32_t hooke_mode, int32_t rank, int32_t world) {
+  if (!e || (!sims && n_sims > 0) || n_sims < 0 || world <= 0 || rank < 0 || rank >= world) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(e->p.device));
+  const int per_rank = (n_sims + world - 1) / world;
+  e->local_stress_count = per_rank;
+  HIPCHK(e->d_local_stress.ensure((size_t)std::max(per_rank, 1) * 6 * sizeof(double)));
+  std::vector<double> local(6 * (size_t)std::max(per_rank, 1), 0.0);
+  std::vector<ActiveSim> act;
+  for (int i = 0; i < n_sims; i++) {
+    sims[i].stress_updated = 0;
+    // stmd_problem.h:462-467
+    const char *ff = sims[i].force_field ? sims[i].force_field : "";
+    if (std::strcmp(ff, "opls") != 0 && std::strcmp(ff, "reax") != 0)
+      return fail(e, SCEMA_MD_ERR_ARG, "Error: Force field is %s but only 'opls' and 'reax' are implemented... ", ff);
+    if (i % world != rank) continue;
+    if (hooke_mode) {
+      hooke(sims[i].stiffness, sims[i].strain, sims[i].stress);
+      sims[i].stress_updated = 1;
+      continue;
+    }
+    if (std::strcmp(ff, "reax") == 0) return fail(e, SCEMA_MD_ERR_ARG, "force field 'reax' is not built yet (SURVEY row f-4)");
+    ActiveSim A;
+    int rc = resolve_state(e, sims[i], &A.st);
+    if (rc) return rc;
+    A.user_index = i;
+    // stmd_problem.h:213-225
+    const double lb[3] = {A.st->box[3] - A.st->box[0], A.st->box[4] - A.st->box[1], A.st->box[5] - A.st->box[2]};
+    const double *sl = sims[i].strain;
+    double eps[6];
+    eps[0] = sl[0] / lb[0]; eps[1] = sl[1] / lb[1]; eps[2] = sl[2] / lb[2];
+    eps[3] = sl[3] / lb[2];  // [0][1] /= lbdim[2]
+    eps[5] = sl[5] / lb[0];  // [1][2] /= lbdim[0]
+    eps[4] = sl[4] / lb[1];  // [2][0] /= lbdim[1]
+    // stmd_problem.h:229-232
+    const double nrm = std::sqrt(eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2] + 2.0 * (eps[3] * eps[3] + eps[4] * eps[4] + eps[5] * eps[5]));
+    const double strain_time = nrm / sims[i].strain_rate;
+    int nts = (int)(std::ceil((strain_time / sims[i].timestep_length) / 10.0) * 10);
+    nts = std::max(nts, 10);
+    A.nts = nts;
+    A.nss = sims[i].nsteps_sample;
+    if (A.nss < 1) return fail(e, SCEMA_MD_ERR_ARG, "number of sampling steps must be >= 1");
+    A.dt = round_trip("%f", sims[i].timestep_length);
+    A.temperature = round_trip("%f", sims[i].temperature);
+    for (int k = 0; k < 6; k++) A.rates[k] = round_trip("%.6e", eps[k] / (nts * sims[i].timestep_length));
+    act.push_back(A);
+  }
+  const int maxb = e->p.max_batch > 0 ? e->p.max_batch : 1024;
+  for (size_t off = 0; off < act.size(); off += maxb) {
+    std::vector<ActiveSim> chunk(act.begin() + off, act.begin() + std::min(act.size(), off + (size_t)maxb));
+    // rates are consumed per attempt: keep a copy for retries
+    int rc = eval_chunk(e, chunk);
+    if (rc) return rc;
+    for (auto &A : chunk) {
+      scema_mdsim &m = sims[A.user_index];
+      for (int k = 0; k < 6; k++) m.stress[k] = A.pavg[k] * (-1.0) * 1.01325e+05;  // stmd_problem.h:340
+      m.stress_updated = 1;
+    }
+  }
+  for (int i = rank; i < n_sims; i += world)
+    if (sims[i].stress_updated)
+      for (int k = 0; k < 6; k++) local[6 * (size_t)(i / world) + k] = sims[i].stress[k];
+  HIPCHK(hipMemcpy(e->d_local_stress.p, local.data(), local.size() * sizeof(double), hipMemcpyHostToDevice));
+  return SCEMA_MD_OK;
+}
+
+int scema_md_strain(scema_md_engine *e, scema_mdsim *sim, int32_t hooke_mode) { return scema_md_strain_batch(e, sim, 1, hooke_mode, 0, 1); }
+
+void *scema_md_local_stress_device_ptr(scema_md_engine *e) { return e ? e->d_local_stress.p : nullptr; }
+int32_t scema_md_local_stress_count(const scema_md_engine *e) { return e ? e->local_stress_count : 0; }
+
+int scema_md_scatter_gathered(const double *gathered, int32_t world, scema_mdsim *sims, int32_t n_sims) {
+  if (!gathered || !sims || world <= 0) return SCEMA_MD_ERR_ARG;
+  const int per_rank = (n_sims + world - 1) / world;
+  for (int i = 0; i < n_sims; i++) {
+    const double *src = gathered + ((size_t)(i % world) * per_rank + (size_t)(i / world)) * 6;
+    for (int k = 0; k < 6; k++) sims[i].stress[k] = src[k];
+    sims[i].stress_updated = 1;
+  }
+  return SCEMA_MD_OK;
+}
+
+// ---- state management ----
+int scema_md_has_state(const scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica) {
+  if (!e) return 0;
+  return e->states.count(state_key(qp_id, matid, replica)) ? 1 : 0;
+}
+
+int scema_md_get_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double box[9], double *x, double *v) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, replica);
+  const size_t bytes = 3 * (size_t)t->natoms * 8;
+  if (qp_id == SCEMA_MD_QP_NONE) {
+    if (box) std::memcpy(box, t->init_box, 9 * 8);
+    if (x) std::memcpy(x, t->init_x.data(), bytes);
+    if (v) std::memcpy(v, t->init_v.data(), bytes);
+    return SCEMA_MD_OK;
+  }
+  State *s = find_state(e, qp_id, matid, replica);
+  if (!s) return fail(e, SCEMA_MD_ERR_NOSTATE, "no state for qp %d %s_%d", qp_id, matid, replica);
+  if (box) std::memcpy(box, s->box, 9 * 8);
+  if (x) HIPCHK(hipMemcpy(x, s->x.p, bytes, hipMemcpyDeviceToHost));
+  if (v) HIPCHK(hipMemcpy(v, s->v.p, bytes, hipMemcpyDeviceToHost));
+  return SCEMA_MD_OK;
+}
+
+int scema_md_set_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const double box[9], const double *x, const double *v) {
+  if (!e || !box || !x || !v) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, replica);
+  std::unique_ptr<State> ns;
+  int rc = make_state(e, t, box, x, v, false, ns);
+  if (rc) return rc;
+  e->states[state_key(qp_id, matid, replica)] = std::move(ns);
+  return SCEMA_MD_OK;
+}
+
+int scema_md_drop_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  (void)hipSetDevice(e->p.device);
+  e->states.erase(state_key(qp_id, matid, replica));
+  return SCEMA_MD_OK;
+}
+
+int scema_md_save_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path) {
+  if (!e || !path) return SCEMA_MD_ERR_ARG;
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, replica);
+  std::vector<double> x(3 * (size_t)t->natoms), v(x.size());
+  double box[9];
+  int rc = scema_md_get_state(e, qp_id, matid, replica, box, x.data(), v.data());
+  if (rc) return rc;
+  FILE *fp = fopen(path, "wb");
+  if (!fp) return fail(e, SCEMA_MD_ERR_IO, "cannot write %s", path);
+  int32_t n = t->natoms;
+  bool ok = fwrite(STATE_MAGIC, 1, 8, fp) == 8 && fwrite(&n, 4, 1, fp) == 1 && fwrite(box, 8, 9, fp) == 9 &&
+            fwrite(x.data(), 8, x.size(), fp) == x.size() && fwrite(v.data(), 8, v.size(), fp) == v.size();
+  fclose(fp);
+  return ok ? SCEMA_MD_OK : fail(e, SCEMA_MD_ERR_IO, "short write %s", path);
+}
+
+int scema_md_load_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path) {
+  if (!e || !path) return SCEMA_MD_ERR_ARG;
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, replica);
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return fail(e, SCEMA_MD_ERR_IO, "cannot open %s", path);
+  char magic[8];
+  int32_t n = 0;
+  double box[9];
+  std::vector<double> x(3 * (size_t)t->natoms), v(x.size());
+  bool ok = fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, STATE_MAGIC, 8) == 0 && fread(&n, 4, 1, fp) == 1 && n == t->natoms &&
+            fread(box, 8, 9, fp) == 9 && fread(x.data(), 8, x.size(), fp) == x.size() && fread(v.data(), 8, v.size(), fp) == v.size();
+  fclose(fp);
+  if (!ok) return fail(e, SCEMA_MD_ERR_IO, "%s is not a state file of %s_%d", path, matid, replica);
+  return scema_md_set_state(e, qp_id, matid, replica, box, x.data(), v.data());
+}
+
+// ---- parity / measurement hooks ----
+// qp_id == SCEMA_MD_QP_NONE: a temporary copy of the registered init state (held by `tmp`)
+static int debug_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, State **out, std::unique_ptr<State> &tmp) {
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, replica);
+  if (qp_id == SCEMA_MD_QP_NONE) {
+    int rc = make_state(e, t, t->init_box, t->init_x.data(), t->init_v.data(), false, tmp);
+    if (rc) return rc;
+    *out = tmp.get();
+    return SCEMA_MD_OK;
+  }
+  State *s = find_state(e, qp_id, matid, replica);
+  if (!s) return fail(e, SCEMA_MD_ERR_NOSTATE, "no state for qp %d", qp_id);
+  *out = s;
+  return SCEMA_MD_OK;
+}
+
+int scema_md_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t use_shake, double *f,
+                           double *energies, double *virials, double *info) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  State *s = nullptr;
+  std::unique_ptr<State> tmp;
+  int rc = debug_state(e, qp_id, matid, replica, &s, tmp);
+  if (rc) return rc;
+  std::vector<ActiveSim> sims(1);
+  sims[0].st = s;
+  sims[0].nsteps = 0;
+  sims[0].dt = 1.0;
+  sims[0].temperature = 300.0;
+  for (int attempt = 0; attempt < 4; attempt++) {
+    if ((rc = prepare_slots(e, sims))) return rc;
+    RunSpec R;
+    R.use_shake = use_shake;
+    R.ev_always = 1;
+    R.static_only = 1;
+    R.nvt = 0;
+    rc = run_phase(e, sims, R);
+    if (rc != SCEMA_MD_ERR_OVERFLOW) break;
+    e->neigh_grow *= 1.5;
+  }
+  if (rc) return rc;
+  const SimScalars &sc = e->h_sc[0];
+  if (f) HIPCHK(hipMemcpy(f, e->slots[0]->f.p, 3 * (size_t)s->topo->natoms * 8, hipMemcpyDeviceToHost));
+  if (energies) std::memcpy(energies, sc.eng, sizeof sc.eng);
+  if (virials) std::memcpy(virials, sc.vir, sizeof sc.vir);
+  if (info) {
+    info[0] = e->h_sims[0].g_ewald;
+    info[1] = e->h_sims[0].nk;
+    info[2] = 0.5 * (double)sc.nentries;
+    info[3] = e->h_sims[0].tdof;
+    info[4] = sc.t_current;
+    info[5] = sc.maxneigh_seen;
+    info[6] = e->h_sims[0].maxneigh;
+    info[7] = s->topo->nclus;
+  }
+  return SCEMA_MD_OK;
+}
+
+int scema_md_debug_run(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t nsteps, double dt,
+                       double temperature, int32_t nvt, int32_t use_shake, const double *rates, double *press_avg) {
+  if (!e || nsteps < 0) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  if (qp_id == SCEMA_MD_QP_NONE) return fail(e, SCEMA_MD_ERR_ARG, "debug_run needs a stored state (scema_md_set_state first)");
+  State *s = nullptr;
+  std::unique_ptr<State> tmp;
+  int rc = debug_state(e, qp_id, matid, replica, &s, tmp);
+  if (rc) return rc;
+  std::vector<ActiveSim> sims(1);
+  sims[0].st = s;
+  sims[0].nsteps = nsteps;
+  sims[0].dt = dt;
+  sims[0].temperature = temperature;
+  if (rates) for (int k = 0; k < 6; k++) sims[0].rates[k] = rates[k];
+  if ((rc = prepare_slots(e, sims))) return rc;
+  RunSpec R;
+  R.nvt = nvt;
+  R.use_shake = use_shake;
+  R.deform = rates ? 1 : 0;
+  R.sample = press_avg ? 1 : 0;
+  rc = run_phase(e, sims, R);
+  if (rc) return rc;
+  const SimScalars &sc = e->h_sc[0];
+  std::memcpy(s->box, sc.box, 9 * sizeof(double));
+  if (press_avg) for (int k = 0; k < 6; k++) press_avg[k] = sc.psum[k] / (double)std::max(sc.nsamples, 1);
+  return SCEMA_MD_OK;
+}
+
+int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset) {
+  if (!e || !out) return SCEMA_MD_ERR_ARG;
+  out->pair_launches = e->prof.pair_launches;
+  out->pair_ms = e->prof.pair_ms;
+  out->pair_alg_bytes = e->prof.pair_alg_bytes;
+  out->md_steps = e->prof.md_steps;
+  out->neigh_builds = e->prof.neigh_builds;
+  out->unique_pairs_per_sim = e->prof.unique_pairs_n ? e->prof.unique_pairs_sum / e->prof.unique_pairs_n : 0.0;
+  out->evals = e->prof.evals;
+  if (reset) e->prof = Profile();
+  return SCEMA_MD_OK;
+}
+
+}  // extern "C"

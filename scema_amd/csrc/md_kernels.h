@@ -1,0 +1,18 @@
+// md_kernels.h -- host-callable launch wrappers of the gfx950 kernels in md_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+struct SimDev;
+void mdk_phase_init(hipStream_t st, const SimDev *d, int ns);
+void mdk_setup_post(hipStream_t st, const SimDev *d, int ns);
+void mdk_pre(hipStream_t st, const SimDev *d, int ns);
+void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms);
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells);
+void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int ev);
+void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxb, int maxa, int maxd, int maxi, int maxs);
+void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax);
+void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);
+void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);
+void mdk_post(hipStream_t st, const SimDev *d, int ns);
+void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms);
+void mdk_phase_end(hipStream_t st, const SimDev *d, int ns, int maxatoms);

@@ -1,0 +1,1092 @@
+// md_kernels.hip -- hand-written gfx950 kernels of the batched MD micro-solver.
+//
+// Every kernel runs on a 2-D grid: blockIdx.y = simulation (quadrature-point replica),
+// blockIdx.x = tile of that simulation, so one launch advances the whole batch one stage.
+// Nothing here synchronises with the host: neighbour rebuilds are decided on the device
+// (sc->rebuild) and the rebuild kernels return immediately when the flag is clear.
+//
+// What each kernel implements (reference: the LAMMPS styles chosen by
+// lammps_scripts_opls/in.set.lammps:27-57, in.strain.lammps:71-100,
+// ELASTIC/in.homogenization.lammps:57-64):
+//   k_pre / k_initial_integrate / k_final_integrate / k_post ... fix nvt (NH chain) + Verlet (K9)
+//   k_bin / k_cell_scan / k_cell_fill / k_cell_sort / k_pack / k_neigh_build ... K1
+//   k_pair ............... lj/cut/coul/long real space, force + virial (K2, the roofline kernel)
+//   k_term<...> .......... bond/angle harmonic, dihedral opls, improper harmonic, special pairs (K4-K7,S4)
+//   k_ewald_* ............ reciprocal Ewald sum (K3)
+//   k_shake .............. fix shake (K8)
+//   k_remap .............. fix deform ... remap x (K10)
+//   pressure sample in k_post ... compute pressure + fix ave/time (K11)
+#include <hip/hip_runtime.h>
+
+#include "md_kernels.h"
+#include "md_types.h"
+
+#define TPB 256
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+struct BoxD {
+  double lo[3], h[6], hinv[6], vol;
+};
+
+__device__ __forceinline__ void box_derive(const double *b, BoxD &o) {
+  o.lo[0] = b[0]; o.lo[1] = b[1]; o.lo[2] = b[2];
+  o.h[0] = b[3] - b[0]; o.h[1] = b[4] - b[1]; o.h[2] = b[5] - b[2];
+  o.h[3] = b[8]; o.h[4] = b[7]; o.h[5] = b[6];
+  o.hinv[0] = 1.0 / o.h[0]; o.hinv[1] = 1.0 / o.h[1]; o.hinv[2] = 1.0 / o.h[2];
+  o.hinv[3] = -o.h[3] / (o.h[1] * o.h[2]);
+  o.hinv[4] = (o.h[3] * o.h[5] - o.h[1] * o.h[4]) / (o.h[0] * o.h[1] * o.h[2]);
+  o.hinv[5] = -o.h[5] / (o.h[0] * o.h[1]);
+  o.vol = o.h[0] * o.h[1] * o.h[2];
+}
+
+__device__ __forceinline__ void minimg(const BoxD &b, double &dx, double &dy, double &dz) {
+  double l0 = b.hinv[0] * dx + b.hinv[5] * dy + b.hinv[4] * dz;
+  double l1 = b.hinv[1] * dy + b.hinv[3] * dz;
+  double l2 = b.hinv[2] * dz;
+  l0 -= rint(l0); l1 -= rint(l1); l2 -= rint(l2);
+  dx = b.h[0] * l0 + b.h[5] * l1 + b.h[4] * l2;
+  dy = b.h[1] * l1 + b.h[3] * l2;
+  dz = b.h[2] * l2;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum of NV values per thread, result atomically added to dst[0..NV)
+template <int NV>
+__device__ __forceinline__ void block_atomic_add(double (&vals)[NV], double *dst, double *lds /* >= NV*(TPB/64) */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    double s = wave_sum(vals[k]);
+    if (lane == 0) lds[k * (TPB / 64) + wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+    for (int w = 0; w < TPB / 64; w++) s += lds[threadIdx.x * (TPB / 64) + w];
+    if (s != 0.0) atomicAdd(&dst[threadIdx.x], s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Nose-Hoover chain half step (fix nvt; one sub-cycle, no drag).  Returns the velocity factor.
+// ------------------------------------------------------------------------------------------
+__device__ double nhc_half(const SimDev &S, SimScalars &sc) {
+  const int mt = S.t_chain;
+  const double dt = S.dt, dthalf = 0.5 * dt, dt4 = 0.25 * dt, dt8 = 0.125 * dt;
+  const double t_target = S.t_target;
+  const double ke_target = S.tdof * MD_BOLTZ * t_target;
+  double kecurrent = S.tdof * MD_BOLTZ * sc.t_current;
+  const double tf2 = S.t_freq * S.t_freq;
+  sc.eta_mass[0] = S.tdof * MD_BOLTZ * t_target / tf2;
+  for (int k = 1; k < mt; k++) sc.eta_mass[k] = MD_BOLTZ * t_target / tf2;
+  sc.eta_dotdot[0] = (sc.eta_mass[0] > 0.0) ? (kecurrent - ke_target) / sc.eta_mass[0] : 0.0;
+  double expfac;
+  for (int k = mt - 1; k > 0; k--) {
+    expfac = exp(-dt8 * sc.eta_dot[k + 1]);
+    sc.eta_dot[k] *= expfac;
+    sc.eta_dot[k] += sc.eta_dotdot[k] * dt4;
+    sc.eta_dot[k] *= expfac;
+  }
+  expfac = exp(-dt8 * sc.eta_dot[1]);
+  sc.eta_dot[0] *= expfac;
+  sc.eta_dot[0] += sc.eta_dotdot[0] * dt4;
+  sc.eta_dot[0] *= expfac;
+  const double factor = exp(-dthalf * sc.eta_dot[0]);
+  sc.t_current *= factor * factor;
+  kecurrent = S.tdof * MD_BOLTZ * sc.t_current;
+  sc.eta_dotdot[0] = (sc.eta_mass[0] > 0.0) ? (kecurrent - ke_target) / sc.eta_mass[0] : 0.0;
+  for (int k = 0; k < mt; k++) sc.eta[k] += dthalf * sc.eta_dot[k];
+  sc.eta_dot[0] *= expfac;
+  sc.eta_dot[0] += sc.eta_dotdot[0] * dt4;
+  sc.eta_dot[0] *= expfac;
+  for (int k = 1; k < mt; k++) {
+    expfac = exp(-dt8 * sc.eta_dot[k + 1]);
+    sc.eta_dot[k] *= expfac;
+    sc.eta_dotdot[k] = (sc.eta_mass[k - 1] * sc.eta_dot[k - 1] * sc.eta_dot[k - 1] - MD_BOLTZ * t_target) / sc.eta_mass[k];
+    sc.eta_dot[k] += sc.eta_dotdot[k] * dt4;
+    sc.eta_dot[k] *= expfac;
+  }
+  return factor;
+}
+
+__device__ void box_corners(const double *box, double *c /*24*/) {
+  BoxD b;
+  box_derive(box, b);
+  int k = 0;
+  for (int iz = 0; iz < 2; iz++)
+    for (int iy = 0; iy < 2; iy++)
+      for (int ix = 0; ix < 2; ix++) {
+        c[3 * k + 0] = b.h[0] * ix + b.h[5] * iy + b.h[4] * iz + b.lo[0];
+        c[3 * k + 1] = b.h[1] * iy + b.h[3] * iz + b.lo[1];
+        c[3 * k + 2] = b.h[2] * iz + b.lo[2];
+        k++;
+      }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_phase_init : start of a "run": thermostat reset, accumulators, forced rebuild
+// ------------------------------------------------------------------------------------------
+__global__ void k_phase_init(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.x];
+  SimScalars &sc = *S.sc;
+  if (threadIdx.x == 0) {
+    for (int k = 0; k <= MD_MAXCHAIN; k++) sc.eta[k] = sc.eta_dot[k] = sc.eta_dotdot[k] = sc.eta_mass[k] = 0.0;
+    for (int k = 0; k < 9; k++) { sc.box0[k] = sc.box[k]; sc.box_prev[k] = sc.box[k]; }
+    for (int k = 0; k < 6; k++) { sc.psum[k] = 0.0; sc.ke[k] = 0.0; }
+    for (int k = 0; k < MD_NPART * 6; k++) sc.vir[k] = 0.0;
+    for (int k = 0; k < MD_NPART; k++) sc.eng[k] = 0.0;
+    sc.vscale = 1.0;
+    sc.nsamples = 0;
+    sc.step = 0;
+    sc.ago = 0;
+    sc.check = 1;
+    sc.rebuild = 1;
+    sc.deltasq = 0.0;
+  }
+  for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;
+  for (int k = threadIdx.x; k < S.ncells; k += blockDim.x) S.cell_count[k] = 0;
+}
+
+// k_setup_post : after the step-0 force evaluation: fix nvt setup (t_current, chain masses)
+__global__ void k_setup_post(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.x];
+  SimScalars &sc = *S.sc;
+  if (threadIdx.x == 0) {
+    sc.t_current = (sc.ke[0] + sc.ke[1] + sc.ke[2]) / (S.tdof * MD_BOLTZ);
+    if (S.nvt) {
+      const double tf2 = S.t_freq * S.t_freq;
+      sc.eta_mass[0] = S.tdof * MD_BOLTZ * S.t_target / tf2;
+      for (int k = 1; k < S.t_chain; k++) sc.eta_mass[k] = MD_BOLTZ * S.t_target / tf2;
+      for (int k = 1; k < S.t_chain; k++)
+        sc.eta_dotdot[k] = (sc.eta_mass[k - 1] * sc.eta_dot[k - 1] * sc.eta_dot[k - 1] - MD_BOLTZ * S.t_target) / sc.eta_mass[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pre : beginning of a step (tiny, one block per simulation)
+// ------------------------------------------------------------------------------------------
+__global__ void k_pre(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.x];
+  SimScalars &sc = *S.sc;
+  if (threadIdx.x == 0) {
+    sc.step += 1;
+    sc.ago += 1;
+    sc.rebuild = 0;
+    sc.check = (sc.ago >= S.neigh_delay) ? 1 : 0;
+    // neighbour trigger threshold with a deforming triclinic box: the two largest box-corner
+    // displacements since the last build are taken off the skin
+    double c[24];
+    box_corners(sc.box, c);
+    double d1 = 0.0, d2 = 0.0;
+    for (int k = 0; k < 8; k++) {
+      double dx = c[3 * k] - sc.corners_hold[3 * k], dy = c[3 * k + 1] - sc.corners_hold[3 * k + 1],
+             dz = c[3 * k + 2] - sc.corners_hold[3 * k + 2];
+      double d = sqrt(dx * dx + dy * dy + dz * dz);
+      if (d > d1) d1 = d;
+      else if (d > d2) d2 = d;
+    }
+    double delta = 0.5 * (S.skin - (d1 + d2));
+    sc.deltasq = delta * delta;
+    if (S.nvt) sc.vscale *= nhc_half(S, sc);
+    for (int k = 0; k < 6; k++) sc.ke[k] = 0.0;
+    for (int k = 0; k < MD_NPART * 6; k++) sc.vir[k] = 0.0;
+    for (int k = 0; k < MD_NPART; k++) sc.eng[k] = 0.0;
+  }
+  for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;
+  for (int k = threadIdx.x; k < S.ncells; k += blockDim.x) S.cell_count[k] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_initial_integrate : v = v*vscale + dt/2 f/m ; x += dt v ; displacement check
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_initial_integrate(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= S.natoms) return;
+  SimScalars &sc = *S.sc;
+  const double vs = sc.vscale;
+  const double dtfm = 0.5 * S.dt * MD_FTM2V / S.mass[i];
+  double dsq = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double v = S.v[3 * i + k] * vs + dtfm * S.f[3 * i + k];
+    double x = S.x[3 * i + k] + S.dt * v;
+    S.v[3 * i + k] = v;
+    S.x[3 * i + k] = x;
+    double d = x - S.xhold[3 * i + k];
+    dsq += d * d;
+  }
+  if (sc.check && dsq > sc.deltasq) sc.rebuild = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// neighbour build pipeline (all early-exit unless sc->rebuild)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_bin(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  SimScalars &sc = *S.sc;
+  if (!sc.rebuild) return;
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    box_corners(sc.box, sc.corners_hold);
+  }
+  if (i >= S.natoms) return;
+  BoxD b;
+  box_derive(sc.box, b);
+  double x0 = S.x[3 * i], x1 = S.x[3 * i + 1], x2 = S.x[3 * i + 2];
+  S.xhold[3 * i] = x0; S.xhold[3 * i + 1] = x1; S.xhold[3 * i + 2] = x2;
+  double d0 = x0 - b.lo[0], d1 = x1 - b.lo[1], d2 = x2 - b.lo[2];
+  double l[3];
+  l[0] = b.hinv[0] * d0 + b.hinv[5] * d1 + b.hinv[4] * d2;
+  l[1] = b.hinv[1] * d1 + b.hinv[3] * d2;
+  l[2] = b.hinv[2] * d2;
+  int c[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    double fl = floor(l[d]);
+    S.wrapn[3 * i + d] = (int)fl;
+    double w = l[d] - fl;
+    if (w >= 1.0) w = 0.0;
+    int cc = (int)(w * S.nc[d]);
+    if (cc >= S.nc[d]) cc = S.nc[d] - 1;
+    c[d] = cc;
+  }
+  const int cell = (c[2] * S.nc[1] + c[1]) * S.nc[0] + c[0];
+  S.cell_of[i] = cell;
+  atomicAdd(&S.cell_count[cell], 1);
+}
+
+__global__ __launch_bounds__(TPB) void k_cell_scan(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.x];
+  SimScalars &sc = *S.sc;
+  if (!sc.rebuild) return;
+  __shared__ int s_part[TPB];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int start = 0; start < S.ncells; start += TPB) {
+    int idx = start + threadIdx.x;
+    int v = (idx < S.ncells) ? S.cell_count[idx] : 0;
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    // Hillis-Steele inclusive scan
+    for (int o = 1; o < TPB; o <<= 1) {
+      int t = (threadIdx.x >= o) ? s_part[threadIdx.x - o] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int incl = s_part[threadIdx.x];
+    int base = s_base;
+    if (idx < S.ncells) {
+      S.cell_start[idx] = base + incl - v;
+      S.cell_fill[idx] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == TPB - 1) s_base = base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    S.cell_start[S.ncells] = s_base;
+    sc.ago = 0;
+    sc.nbuilds += 1;
+    sc.nentries = 0ull;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_cell_fill(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  if (!S.sc->rebuild) return;
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= S.natoms) return;
+  const int c = S.cell_of[i];
+  const int slot = S.cell_start[c] + atomicAdd(&S.cell_fill[c], 1);
+  S.slot_tmp[slot] = i;
+}
+
+// deterministic order inside each cell: ascending atom index (the atomic fill order is not)
+__global__ __launch_bounds__(TPB) void k_cell_sort(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  if (!S.sc->rebuild) return;
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= S.ncells) return;
+  const int b = S.cell_start[c], e = S.cell_start[c + 1];
+  for (int s = b; s < e; s++) {
+    // rank of slot_tmp[s] among the members
+    int a = S.slot_tmp[s], r = 0;
+    for (int t = b; t < e; t++) r += (S.slot_tmp[t] < a) ? 1 : 0;
+    S.perm[b + r] = a;
+  }
+}
+
+// k_pack : every step : slot-ordered wrapped coordinates (+charge), 32-byte records
+__global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  const int s = blockIdx.x * TPB + threadIdx.x;
+  if (s >= S.npad) return;
+  if (s >= S.natoms) {
+    if (S.sc->rebuild) { S.xq[s] = make_double4(0, 0, 0, 0); S.stype[s] = 0; }
+    return;
+  }
+  BoxD b;
+  box_derive(S.sc->box, b);
+  const int a = S.perm[s];
+  const int w0 = S.wrapn[3 * a], w1 = S.wrapn[3 * a + 1], w2 = S.wrapn[3 * a + 2];
+  double4 r;
+  r.x = S.x[3 * a] - (b.h[0] * w0 + b.h[5] * w1 + b.h[4] * w2);
+  r.y = S.x[3 * a + 1] - (b.h[1] * w1 + b.h[3] * w2);
+  r.z = S.x[3 * a + 2] - (b.h[2] * w2);
+  r.w = S.q[a];
+  S.xq[s] = r;
+  S.stype[s] = S.type[a];
+}
+
+// k_neigh_build : full neighbour list, one thread per slot, transposed storage neigh[k*npad+i]
+__global__ __launch_bounds__(TPB) void k_neigh_build(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  SimScalars &sc = *S.sc;
+  if (!sc.rebuild) return;
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  __shared__ double s_red[TPB / 64];
+  int n = 0;
+  if (i < S.natoms) {
+    BoxD b;
+    box_derive(sc.box, b);
+    const double4 xi = S.xq[i];
+    const int ai = S.perm[i];
+    const int ci = S.cell_of[ai];
+    const int c0 = ci % S.nc[0], c1 = (ci / S.nc[0]) % S.nc[1], c2 = ci / (S.nc[0] * S.nc[1]);
+    const int exb = S.ex_start[ai], exe = S.ex_start[ai + 1];
+    for (int o2 = -S.mst[2]; o2 <= S.mst[2]; o2++) {
+      int a2 = c2 + o2, s2 = 0;
+      while (a2 < 0) { a2 += S.nc[2]; s2 -= 1; }
+      while (a2 >= S.nc[2]) { a2 -= S.nc[2]; s2 += 1; }
+      for (int o1 = -S.mst[1]; o1 <= S.mst[1]; o1++) {
+        int a1 = c1 + o1, s1 = 0;
+        while (a1 < 0) { a1 += S.nc[1]; s1 -= 1; }
+        while (a1 >= S.nc[1]) { a1 -= S.nc[1]; s1 += 1; }
+        for (int o0 = -S.mst[0]; o0 <= S.mst[0]; o0++) {
+          int a0 = c0 + o0, s0 = 0;
+          while (a0 < 0) { a0 += S.nc[0]; s0 -= 1; }
+          while (a0 >= S.nc[0]) { a0 -= S.nc[0]; s0 += 1; }
+          if (s0 < -1 || s0 > 1 || s1 < -1 || s1 > 1 || s2 < -1 || s2 > 1) continue;
+          const double sx = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
+          const double sy = b.h[1] * s1 + b.h[3] * s2;
+          const double sz = b.h[2] * s2;
+          const int code = ((s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1)) << MD_JBITS;
+          const int cj = (a2 * S.nc[1] + a1) * S.nc[0] + a0;
+          const int jb = S.cell_start[cj], je = S.cell_start[cj + 1];
+          for (int j = jb; j < je; j++) {
+            const double4 xj = S.xq[j];
+            const double dx = xi.x - xj.x - sx, dy = xi.y - xj.y - sy, dz = xi.z - xj.z - sz;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 >= S.rlist2) continue;
+            if (j == i && code == (13 << MD_JBITS)) continue;
+            if (r2 < S.excl_cut2) {
+              const int aj = S.perm[j];
+              bool ex = false;
+              for (int e = exb; e < exe; e++) ex |= (S.ex_list[e] == aj);
+              if (ex) continue;
+            }
+            if (n < S.maxneigh) S.neigh[(size_t)n * S.npad + i] = code | j;
+            n++;
+          }
+        }
+      }
+    }
+    S.numneigh[i] = (n < S.maxneigh) ? n : S.maxneigh;
+    if (n > S.maxneigh) atomicOr(&sc.overflow, 1);
+    atomicMax(&sc.maxneigh_seen, n);
+  } else if (i < S.npad) {
+    S.numneigh[i] = 0;
+  }
+  // statistics: stored entries
+  double cnt = wave_sum((double)n);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < TPB / 64; w++) t += s_red[w];
+    atomicAdd(&sc.nentries, (unsigned long long)t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pair : lj/cut/coul/long real-space force (+virial, +energy) on the full list.
+//   one thread per slot i; neighbour rows are read coalesced (row k of the transposed list);
+//   j records are 32-byte gathers served by L2 (slots are cell-sorted); the force is written
+//   once per atom (no atomics); the virial is reduced wave -> block -> one atomic per block.
+// ------------------------------------------------------------------------------------------
+template <bool EV>
+__global__ __launch_bounds__(TPB) void k_pair(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  SimScalars &sc = *S.sc;
+  __shared__ double s_shift[27 * 3];
+  __shared__ double s_lj[4 * MD_MAXTYPES * MD_MAXTYPES];
+  __shared__ double s_red[14 * (TPB / 64)];
+  if (threadIdx.x < 27) {
+    BoxD b;
+    box_derive(sc.box, b);
+    const int s0 = threadIdx.x % 3 - 1, s1 = (threadIdx.x / 3) % 3 - 1, s2 = threadIdx.x / 9 - 1;
+    s_shift[3 * threadIdx.x + 0] = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
+    s_shift[3 * threadIdx.x + 1] = b.h[1] * s1 + b.h[3] * s2;
+    s_shift[3 * threadIdx.x + 2] = b.h[2] * s2;
+  }
+  const int nt = S.ntypes;
+  for (int k = threadIdx.x; k < 4 * nt * nt; k += TPB) s_lj[k] = S.lj[k];
+  __syncthreads();
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  double fx = 0, fy = 0, fz = 0;
+  double acc[14];
+#pragma unroll
+  for (int k = 0; k < 14; k++) acc[k] = 0.0;  // vlj[6], vcoul[6], elj, ecoul
+  if (i < S.natoms) {
+    const double4 xi = S.xq[i];
+    const int ti = S.stype[i];
+    const int nn = S.numneigh[i];
+    const double g = S.g_ewald;
+    const double qi = MD_QQRD2E * xi.w;
+    const int *nb = S.neigh + i;
+    const size_t stride = S.npad;
+    for (int k = 0; k < nn; k++) {
+      const int e = nb[(size_t)k * stride];
+      const int j = e & MD_JMASK;
+      const int c = ((unsigned)e) >> MD_JBITS;
+      const double4 xj = S.xq[j];
+      const double dx = xi.x - xj.x - s_shift[3 * c], dy = xi.y - xj.y - s_shift[3 * c + 1],
+                   dz = xi.z - xj.z - s_shift[3 * c + 2];
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq >= S.cut_lj2 && rsq >= S.cut_coul2) continue;
+      const double r2inv = 1.0 / rsq;
+      double flj = 0.0, fc = 0.0;
+      if (rsq < S.cut_coul2) {
+        const double r = sqrt(rsq);
+        const double grij = g * r;
+        const double expm2 = exp(-grij * grij);
+        const double erfcv = erfc(grij);
+        const double pref = qi * xj.w / r;
+        fc = pref * (erfcv + MD_EWALD_F * grij * expm2) * r2inv;
+        if (EV) acc[13] += pref * erfcv;
+      }
+      if (rsq < S.cut_lj2) {
+        const int tt = ti * nt + S.stype[j];
+        const double r6inv = r2inv * r2inv * r2inv;
+        flj = r6inv * (s_lj[tt] * r6inv - s_lj[nt * nt + tt]) * r2inv;
+        if (EV) acc[12] += r6inv * (s_lj[2 * nt * nt + tt] * r6inv - s_lj[3 * nt * nt + tt]);
+      }
+      const double fp = flj + fc;
+      fx += dx * fp; fy += dy * fp; fz += dz * fp;
+      if (EV) {
+        acc[0] += dx * dx * flj; acc[1] += dy * dy * flj; acc[2] += dz * dz * flj;
+        acc[3] += dx * dy * flj; acc[4] += dx * dz * flj; acc[5] += dy * dz * flj;
+        acc[6] += dx * dx * fc; acc[7] += dy * dy * fc; acc[8] += dz * dz * fc;
+        acc[9] += dx * dy * fc; acc[10] += dx * dz * fc; acc[11] += dy * dz * fc;
+      }
+    }
+    const int a = S.perm[i];
+    S.f[3 * a] = fx; S.f[3 * a + 1] = fy; S.f[3 * a + 2] = fz;
+  }
+  if (EV) {
+    // full list: every pair visited twice
+#pragma unroll
+    for (int k = 0; k < 14; k++) acc[k] *= 0.5;
+    double v6[6], e1[1];
+    for (int k = 0; k < 6; k++) v6[k] = acc[k];
+    block_atomic_add<6>(v6, sc.vir + P_LJ * 6, s_red);
+    for (int k = 0; k < 6; k++) v6[k] = acc[6 + k];
+    block_atomic_add<6>(v6, sc.vir + P_COUL * 6, s_red);
+    e1[0] = acc[12];
+    block_atomic_add<1>(e1, sc.eng + P_LJ, s_red);
+    e1[0] = acc[13];
+    block_atomic_add<1>(e1, sc.eng + P_COUL, s_red);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bonded terms and special pairs : one thread per term, f64 atomics into f
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fadd(double *f, int i, double x, double y, double z) {
+  atomicAdd(&f[3 * i], x); atomicAdd(&f[3 * i + 1], y); atomicAdd(&f[3 * i + 2], z);
+}
+__device__ __forceinline__ void vt(double *v, double ax, double ay, double az, double fx, double fy, double fz) {
+  v[0] += ax * fx; v[1] += ay * fy; v[2] += az * fz; v[3] += ax * fy; v[4] += ax * fz; v[5] += ay * fz;
+}
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
+  c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// torsion geometry shared by dihedral opls and improper harmonic:
+// F=r1-r2, G=r2-r3, H=r4-r3, A=FxG, B=HxG, c=A.B/(|A||B|) ; dc[k] = d c / d r_k
+__device__ double torsion_cos(const BoxD &b, const double *x, const int *at, double *F, double *G, double *H, double dc[4][3]) {
+  for (int k = 0; k < 3; k++) {
+    F[k] = x[3 * at[0] + k] - x[3 * at[1] + k];
+    G[k] = x[3 * at[1] + k] - x[3 * at[2] + k];
+    H[k] = x[3 * at[3] + k] - x[3 * at[2] + k];
+  }
+  minimg(b, F[0], F[1], F[2]); minimg(b, G[0], G[1], G[2]); minimg(b, H[0], H[1], H[2]);
+  double A[3], B[3];
+  cross3(F, G, A); cross3(H, G, B);
+  const double a2 = dot3(A, A), b2 = dot3(B, B);
+  const double ia = 1.0 / sqrt(a2), ib = 1.0 / sqrt(b2);
+  double c = dot3(A, B) * ia * ib;
+  c = fmin(1.0, fmax(-1.0, c));
+  double gA[3], gB[3];
+  for (int k = 0; k < 3; k++) {
+    gA[k] = B[k] * ia * ib - c * A[k] / a2;
+    gB[k] = A[k] * ia * ib - c * B[k] / b2;
+  }
+  double GxgA[3], GxgB[3], gAxF[3], gBxH[3];
+  cross3(G, gA, GxgA); cross3(G, gB, GxgB); cross3(gA, F, gAxF); cross3(gB, H, gBxH);
+  for (int k = 0; k < 3; k++) {
+    dc[0][k] = GxgA[k];
+    dc[3][k] = GxgB[k];
+    dc[1][k] = -GxgA[k] + gAxF[k] + gBxH[k];
+    dc[2][k] = -(gAxF[k] + gBxH[k]) - GxgB[k];
+  }
+  return c;
+}
+
+enum { T_BOND = 0, T_ANGLE = 1, T_DIHEDRAL = 2, T_IMPROPER = 3, T_SPECIAL = 4 };
+
+template <int T>
+__global__ __launch_bounds__(TPB) void k_term(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  SimScalars &sc = *S.sc;
+  __shared__ double s_red[8 * (TPB / 64)];
+  int nterm;
+  if (T == T_BOND) nterm = S.use_shake ? S.nbonds_noshake : S.nbonds;
+  else if (T == T_ANGLE) nterm = S.nangles;
+  else if (T == T_DIHEDRAL) nterm = S.ndihedrals;
+  else if (T == T_IMPROPER) nterm = S.nimpropers;
+  else nterm = S.nspecial;
+  if ((int)(blockIdx.x * TPB) >= nterm) return;
+  const int m = blockIdx.x * TPB + threadIdx.x;
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};  // virial[6], energy
+  double v2[7] = {0, 0, 0, 0, 0, 0, 0}; // special pairs: coulomb part
+  if (m < nterm) {
+    BoxD b;
+    box_derive(sc.box, b);
+    const double *x = S.x;
+    if (T == T_BOND) {
+      const int i1 = S.bond_at[2 * m], i2 = S.bond_at[2 * m + 1];
+      const double K = S.bond_cf[2 * m], r0 = S.bond_cf[2 * m + 1];
+      double dx = x[3 * i1] - x[3 * i2], dy = x[3 * i1 + 1] - x[3 * i2 + 1], dz = x[3 * i1 + 2] - x[3 * i2 + 2];
+      minimg(b, dx, dy, dz);
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      const double dr = r - r0, rk = K * dr;
+      const double fb = (r > 0.0) ? -2.0 * rk / r : 0.0;
+      v[6] = rk * dr;
+      fadd(S.f, i1, dx * fb, dy * fb, dz * fb);
+      fadd(S.f, i2, -dx * fb, -dy * fb, -dz * fb);
+      vt(v, dx, dy, dz, dx * fb, dy * fb, dz * fb);
+    } else if (T == T_ANGLE) {
+      const int i1 = S.angle_at[3 * m], i2 = S.angle_at[3 * m + 1], i3 = S.angle_at[3 * m + 2];
+      const double K = S.angle_cf[2 * m], th0 = S.angle_cf[2 * m + 1];
+      double d1[3], d2[3];
+      for (int k = 0; k < 3; k++) { d1[k] = x[3 * i1 + k] - x[3 * i2 + k]; d2[k] = x[3 * i3 + k] - x[3 * i2 + k]; }
+      minimg(b, d1[0], d1[1], d1[2]); minimg(b, d2[0], d2[1], d2[2]);
+      const double rsq1 = dot3(d1, d1), rsq2 = dot3(d2, d2);
+      const double r1 = sqrt(rsq1), r2 = sqrt(rsq2);
+      double c = dot3(d1, d2) / (r1 * r2);
+      c = fmin(1.0, fmax(-1.0, c));
+      double sn = sqrt(1.0 - c * c);
+      if (sn < 0.001) sn = 0.001;
+      const double dth = acos(c) - th0, tk = K * dth;
+      v[6] = tk * dth;
+      const double a = -2.0 * tk / sn;
+      const double a11 = a * c / rsq1, a12 = -a / (r1 * r2), a22 = a * c / rsq2;
+      double f1[3], f3[3];
+      for (int k = 0; k < 3; k++) { f1[k] = a11 * d1[k] + a12 * d2[k]; f3[k] = a22 * d2[k] + a12 * d1[k]; }
+      fadd(S.f, i1, f1[0], f1[1], f1[2]);
+      fadd(S.f, i2, -(f1[0] + f3[0]), -(f1[1] + f3[1]), -(f1[2] + f3[2]));
+      fadd(S.f, i3, f3[0], f3[1], f3[2]);
+      vt(v, d1[0], d1[1], d1[2], f1[0], f1[1], f1[2]);
+      vt(v, d2[0], d2[1], d2[2], f3[0], f3[1], f3[2]);
+    } else if (T == T_DIHEDRAL || T == T_IMPROPER) {
+      const int *at = (T == T_DIHEDRAL) ? S.dihedral_at + 4 * m : S.improper_at + 4 * m;
+      double F[3], G[3], H[3], dc[4][3];
+      const double c = torsion_cos(b, x, at, F, G, H, dc);
+      double dEdc;
+      if (T == T_DIHEDRAL) {
+        const double *K = S.dihedral_cf + 4 * m;
+        const double c2 = c * c;
+        const double cos2 = 2.0 * c2 - 1.0, cos3 = (4.0 * c2 - 3.0) * c, cos4 = 8.0 * c2 * c2 - 8.0 * c2 + 1.0;
+        v[6] = 0.5 * (K[0] * (1.0 + c) + K[1] * (1.0 - cos2) + K[2] * (1.0 + cos3) + K[3] * (1.0 - cos4));
+        dEdc = 0.5 * (K[0] - K[1] * 4.0 * c + K[2] * (12.0 * c2 - 3.0) - K[3] * (32.0 * c2 * c - 16.0 * c));
+      } else {
+        const double K = S.improper_cf[2 * m], chi0 = S.improper_cf[2 * m + 1];
+        double sn = sqrt(1.0 - c * c);
+        if (sn < 0.001) sn = 0.001;
+        const double dchi = acos(c) - chi0;
+        v[6] = K * dchi * dchi;
+        dEdc = -2.0 * K * dchi / sn;
+      }
+      double ff[4][3];
+      for (int a = 0; a < 4; a++) {
+        for (int k = 0; k < 3; k++) ff[a][k] = -dEdc * dc[a][k];
+        fadd(S.f, at[a], ff[a][0], ff[a][1], ff[a][2]);
+      }
+      vt(v, F[0] + G[0], F[1] + G[1], F[2] + G[2], ff[0][0], ff[0][1], ff[0][2]);
+      vt(v, G[0], G[1], G[2], ff[1][0], ff[1][1], ff[1][2]);
+      vt(v, H[0], H[1], H[2], ff[3][0], ff[3][1], ff[3][2]);
+    } else {  // special pair: weighted real-space term (k-space minus (1-f_coul) q q / r)
+      const int i = S.special_at[2 * m], j = S.special_at[2 * m + 1];
+      const double wlj = S.special_cf[2 * m], wc = S.special_cf[2 * m + 1];
+      double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+      minimg(b, dx, dy, dz);
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq >= S.excl_cut2) atomicOr(&sc.overflow, 2);  // excluded pair escaped the build-time exclusion gate
+      const double r2inv = 1.0 / rsq;
+      double flj = 0.0, fc = 0.0;
+      if (rsq < S.cut_coul2 && S.g_ewald > 0.0) {
+        const double r = sqrt(rsq), grij = S.g_ewald * r;
+        const double expm2 = exp(-grij * grij);
+        const double pref = MD_QQRD2E * S.q[i] * S.q[j] / r;
+        const double e = wc - erf(grij);
+        fc = pref * (e + MD_EWALD_F * grij * expm2) * r2inv;
+        v2[6] = pref * e;
+      }
+      if (rsq < S.cut_lj2 && wlj != 0.0) {
+        const int nt = S.ntypes, tt = S.type[i] * nt + S.type[j];
+        const double r6inv = r2inv * r2inv * r2inv;
+        flj = wlj * r6inv * (S.lj[tt] * r6inv - S.lj[nt * nt + tt]) * r2inv;
+        v[6] = wlj * r6inv * (S.lj[2 * nt * nt + tt] * r6inv - S.lj[3 * nt * nt + tt]);
+      }
+      const double fp = flj + fc;
+      fadd(S.f, i, dx * fp, dy * fp, dz * fp);
+      fadd(S.f, j, -dx * fp, -dy * fp, -dz * fp);
+      vt(v, dx, dy, dz, dx * flj, dy * flj, dz * flj);
+      vt(v2, dx, dy, dz, dx * fc, dy * fc, dz * fc);
+    }
+  }
+  const int part = (T == T_BOND) ? P_BOND : (T == T_ANGLE) ? P_ANGLE : (T == T_DIHEDRAL) ? P_DIHEDRAL : (T == T_IMPROPER) ? P_IMPROPER : P_LJ;
+  double v6[6], e1[1];
+  for (int k = 0; k < 6; k++) v6[k] = v[k];
+  block_atomic_add<6>(v6, sc.vir + part * 6, s_red);
+  e1[0] = v[6];
+  block_atomic_add<1>(e1, sc.eng + part, s_red);
+  if (T == T_SPECIAL) {
+    for (int k = 0; k < 6; k++) v6[k] = v2[k];
+    block_atomic_add<6>(v6, sc.vir + P_COUL * 6, s_red);
+    e1[0] = v2[6];
+    block_atomic_add<1>(e1, sc.eng + P_COUL, s_red);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// reciprocal Ewald sum
+// ------------------------------------------------------------------------------------------
+#define EW_ATOMS 64        // atoms staged per block in k_ewald_sfac
+extern __shared__ double2 s_dyn[];  // phase tables, sized by the launch (3*Mmax entries per atom)
+
+__device__ __forceinline__ void atom_phase(const SimDev &S, const BoxD &b, int a, double &t0, double &t1, double &t2) {
+  const double d0 = S.x[3 * a] - b.lo[0], d1 = S.x[3 * a + 1] - b.lo[1], d2 = S.x[3 * a + 2] - b.lo[2];
+  double l0 = b.hinv[0] * d0 + b.hinv[5] * d1 + b.hinv[4] * d2;
+  double l1 = b.hinv[1] * d1 + b.hinv[3] * d2;
+  double l2 = b.hinv[2] * d2;
+  t0 = 2.0 * MD_PI * (l0 - floor(l0));
+  t1 = 2.0 * MD_PI * (l1 - floor(l1));
+  t2 = 2.0 * MD_PI * (l2 - floor(l2));
+}
+
+// S(k) = sum_i q_i exp(i k.r_i): threads own k-vectors, atoms are staged through LDS as
+// per-atom tables exp(i m theta_d), m = 0..kmax_d (layout [atom][d][m] keeps lanes on
+// consecutive 16-byte slots)
+__global__ __launch_bounds__(TPB) void k_ewald_sfac(const SimDev *sims, int EW_MAXM) {
+  const SimDev &S = sims[blockIdx.y];
+  if (S.nk == 0) return;
+  const int a0 = blockIdx.x * EW_ATOMS;
+  if (a0 >= S.natoms) return;
+  double2 *s_tab = s_dyn;  // [EW_ATOMS][3][EW_MAXM]
+  __shared__ double s_q[EW_ATOMS];
+  const int na = min(EW_ATOMS, S.natoms - a0);
+  const int M0 = S.kmaxd[0] + 1, M1 = S.kmaxd[1] + 1, M2 = S.kmaxd[2] + 1;
+  const int MS = 3 * EW_MAXM;
+  if (threadIdx.x < 3 * EW_ATOMS) {
+    const int la = threadIdx.x / 3, d = threadIdx.x % 3;
+    if (la < na) {
+      BoxD b;
+      box_derive(S.sc->box, b);
+      double t[3];
+      atom_phase(S, b, a0 + la, t[0], t[1], t[2]);
+      double s1, c1;
+      sincos(t[d], &s1, &c1);
+      const int M = (d == 0) ? M0 : (d == 1) ? M1 : M2;
+      double cr = 1.0, ci = 0.0;
+      double2 *tab = s_tab + la * MS + d * EW_MAXM;
+      for (int m = 0; m < M; m++) {
+        tab[m] = make_double2(cr, ci);
+        const double nr = cr * c1 - ci * s1, ni = ci * c1 + cr * s1;
+        cr = nr; ci = ni;
+      }
+      if (d == 0) s_q[la] = S.q[a0 + la];
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < S.nk; k += TPB) {
+    const int n1 = S.kn[3 * k], n2 = S.kn[3 * k + 1], n3 = S.kn[3 * k + 2];
+    const int m2 = abs(n2), m3 = abs(n3);
+    const double sg2 = (n2 < 0) ? -1.0 : 1.0, sg3 = (n3 < 0) ? -1.0 : 1.0;
+    double Sr = 0.0, Si = 0.0;
+    for (int la = 0; la < na; la++) {
+      const double2 e1 = s_tab[la * MS + n1];
+      double2 e2 = s_tab[la * MS + EW_MAXM + m2];
+      double2 e3 = s_tab[la * MS + 2 * EW_MAXM + m3];
+      e2.y *= sg2; e3.y *= sg3;
+      const double c12 = e1.x * e2.x - e1.y * e2.y, s12 = e1.y * e2.x + e1.x * e2.y;
+      const double cc = c12 * e3.x - s12 * e3.y, ss = s12 * e3.x + c12 * e3.y;
+      const double q = s_q[la];
+      Sr += q * cc; Si += q * ss;
+    }
+    atomicAdd(&S.sfac[2 * k], Sr);
+    atomicAdd(&S.sfac[2 * k + 1], Si);
+  }
+}
+
+// per-k coefficients for the current box + energy / virial of the reciprocal sum
+__global__ __launch_bounds__(TPB) void k_ewald_post(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  SimScalars &sc = *S.sc;
+  if (S.nk == 0) return;
+  __shared__ double s_red[8 * (TPB / 64)];
+  if ((int)(blockIdx.x * TPB) >= S.nk) return;
+  const int k = blockIdx.x * TPB + threadIdx.x;
+  double v[6] = {0, 0, 0, 0, 0, 0}, e[1] = {0};
+  if (k < S.nk) {
+    BoxD b;
+    box_derive(sc.box, b);
+    const int n1 = S.kn[3 * k], n2 = S.kn[3 * k + 1], n3 = S.kn[3 * k + 2];
+    const double kx = 2.0 * MD_PI * (b.hinv[0] * n1);
+    const double ky = 2.0 * MD_PI * (b.hinv[5] * n1 + b.hinv[1] * n2);
+    const double kz = 2.0 * MD_PI * (b.hinv[4] * n1 + b.hinv[3] * n2 + b.hinv[2] * n3);
+    const double sqk = kx * kx + ky * ky + kz * kz;
+    const double g2inv = 1.0 / (S.g_ewald * S.g_ewald);
+    const double ug = 4.0 * MD_PI / b.vol * exp(-0.25 * sqk * g2inv) / sqk;
+    S.kvec[4 * k] = kx; S.kvec[4 * k + 1] = ky; S.kvec[4 * k + 2] = kz; S.kvec[4 * k + 3] = ug;
+    const double Sr = S.sfac[2 * k], Si = S.sfac[2 * k + 1];
+    const double uk = MD_QQRD2E * ug * (Sr * Sr + Si * Si);
+    const double vterm = -2.0 * (1.0 / sqk + 0.25 * g2inv);
+    e[0] = uk;
+    v[0] = uk * (1.0 + vterm * kx * kx); v[1] = uk * (1.0 + vterm * ky * ky); v[2] = uk * (1.0 + vterm * kz * kz);
+    v[3] = uk * vterm * kx * ky; v[4] = uk * vterm * kx * kz; v[5] = uk * vterm * ky * kz;
+    if (k == 0) {
+      // self energy and neutralising background
+      e[0] -= MD_QQRD2E * (S.g_ewald * S.qsqsum / sqrt(MD_PI) + 0.5 * MD_PI * S.qsum * S.qsum / (S.g_ewald * S.g_ewald * b.vol));
+    }
+  }
+  block_atomic_add<6>(v, sc.vir + P_KSPACE * 6, s_red);
+  block_atomic_add<1>(e, sc.eng + P_KSPACE, s_red);
+}
+
+// F_i = 2 q_i sum_k ug k (sin_i Sr - cos_i Si): one thread per atom, own phase tables in LDS
+#define EWF_TPB 128
+__global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int EW_MAXM) {
+  const SimDev &S = sims[blockIdx.y];
+  if (S.nk == 0) return;
+  if ((int)(blockIdx.x * EWF_TPB) >= S.natoms) return;
+  double2 *s_tab = s_dyn;  // [3][EW_MAXM][thread]
+  const int a = blockIdx.x * EWF_TPB + threadIdx.x;
+  const bool act = a < S.natoms;
+  const int M[3] = {S.kmaxd[0] + 1, S.kmaxd[1] + 1, S.kmaxd[2] + 1};
+  if (act) {
+    BoxD b;
+    box_derive(S.sc->box, b);
+    double t[3];
+    atom_phase(S, b, a, t[0], t[1], t[2]);
+    for (int d = 0; d < 3; d++) {
+      double s1, c1;
+      sincos(t[d], &s1, &c1);
+      double cr = 1.0, ci = 0.0;
+      for (int m = 0; m < M[d]; m++) {
+        s_tab[(d * EW_MAXM + m) * EWF_TPB + threadIdx.x] = make_double2(cr, ci);
+        const double nr = cr * c1 - ci * s1, ni = ci * c1 + cr * s1;
+        cr = nr; ci = ni;
+      }
+    }
+  }
+  double fx = 0, fy = 0, fz = 0;
+  if (act) {
+    for (int k = 0; k < S.nk; k++) {
+      const int n1 = S.kn[3 * k], n2 = S.kn[3 * k + 1], n3 = S.kn[3 * k + 2];
+      const double2 e1 = s_tab[(n1)*EWF_TPB + threadIdx.x];
+      double2 e2 = s_tab[(EW_MAXM + abs(n2)) * EWF_TPB + threadIdx.x];
+      double2 e3 = s_tab[(2 * EW_MAXM + abs(n3)) * EWF_TPB + threadIdx.x];
+      if (n2 < 0) e2.y = -e2.y;
+      if (n3 < 0) e3.y = -e3.y;
+      const double c12 = e1.x * e2.x - e1.y * e2.y, s12 = e1.y * e2.x + e1.x * e2.y;
+      const double cc = c12 * e3.x - s12 * e3.y, ss = s12 * e3.x + c12 * e3.y;
+      const double Sr = S.sfac[2 * k], Si = S.sfac[2 * k + 1];
+      const double pf = S.kvec[4 * k + 3] * (ss * Sr - cc * Si);
+      fx += pf * S.kvec[4 * k]; fy += pf * S.kvec[4 * k + 1]; fz += pf * S.kvec[4 * k + 2];
+    }
+    const double pq = 2.0 * MD_QQRD2E * S.q[a];
+    atomicAdd(&S.f[3 * a], pq * fx);
+    atomicAdd(&S.f[3 * a + 1], pq * fy);
+    atomicAdd(&S.f[3 * a + 2], pq * fz);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_shake : fix shake, one thread per star cluster (central atom + 1..3 satellites)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_shake(const SimDev *sims, double dtfsq_scale) {
+  const SimDev &S = sims[blockIdx.y];
+  SimScalars &sc = *S.sc;
+  if (!S.use_shake || S.nclus == 0) return;
+  if ((int)(blockIdx.x * TPB) >= S.nclus) return;
+  __shared__ double s_red[6 * (TPB / 64)];
+  const int cl = blockIdx.x * TPB + threadIdx.x;
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  if (cl < S.nclus) {
+    BoxD b;
+    box_derive(sc.box, b);
+    const double dtv = S.dt, dtfsq = dtfsq_scale * S.dt * S.dt * MD_FTM2V;
+    const int na = S.clus_n[cl], nb = na - 1;
+    const int *at = S.clus_at + 4 * cl;
+    const double *dist = S.clus_d + 3 * cl;
+    double invm[4], xs[4][3], xc[4][3];
+    // v is exact here: k_initial_integrate folded the deferred NH factor in before the drift
+    for (int a = 0; a < na; a++) {
+      const int i = at[a];
+      invm[a] = 1.0 / S.mass[i];
+      for (int k = 0; k < 3; k++) {
+        xc[a][k] = S.x[3 * i + k];
+        xs[a][k] = xc[a][k] + dtv * S.v[3 * i + k] + dtfsq * invm[a] * S.f[3 * i + k];
+      }
+    }
+    double r[3][3], sv[3][3];
+    for (int k = 0; k < nb; k++) {
+      for (int c = 0; c < 3; c++) { r[k][c] = xc[0][c] - xc[k + 1][c]; sv[k][c] = xs[0][c] - xs[k + 1][c]; }
+      minimg(b, r[k][0], r[k][1], r[k][2]);
+      minimg(b, sv[k][0], sv[k][1], sv[k][2]);
+    }
+    double lam[3] = {0, 0, 0};
+    if (nb == 1) {
+      const double m01 = invm[0] + invm[1];
+      const double r01sq = dot3(r[0], r[0]), s01sq = dot3(sv[0], sv[0]);
+      const double a = m01 * m01 * r01sq, bb = 2.0 * m01 * dot3(sv[0], r[0]), c = s01sq - dist[0] * dist[0];
+      double determ = bb * bb - 4.0 * a * c;
+      if (determ < 0.0) determ = 0.0;
+      const double l1 = (-bb + sqrt(determ)) / (2.0 * a), l2 = (-bb - sqrt(determ)) / (2.0 * a);
+      lam[0] = (fabs(l1) <= fabs(l2)) ? l1 : l2;
+    } else {
+      double A[3][3] = {{0}}, Ai[3][3] = {{0}}, M[3][3] = {{0}};
+      for (int k = 0; k < nb; k++)
+        for (int j = 0; j < nb; j++) {
+          M[k][j] = invm[0] + (k == j ? invm[k + 1] : 0.0);
+          A[k][j] = 2.0 * M[k][j] * dot3(sv[k], r[j]);
+        }
+      if (nb == 2) {
+        const double det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+        Ai[0][0] = A[1][1] / det; Ai[0][1] = -A[0][1] / det; Ai[1][0] = -A[1][0] / det; Ai[1][1] = A[0][0] / det;
+      } else {
+        const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                           A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+        const double id = 1.0 / det;
+        Ai[0][0] = id * (A[1][1] * A[2][2] - A[1][2] * A[2][1]);
+        Ai[0][1] = -id * (A[0][1] * A[2][2] - A[0][2] * A[2][1]);
+        Ai[0][2] = id * (A[0][1] * A[1][2] - A[0][2] * A[1][1]);
+        Ai[1][0] = -id * (A[1][0] * A[2][2] - A[1][2] * A[2][0]);
+        Ai[1][1] = id * (A[0][0] * A[2][2] - A[0][2] * A[2][0]);
+        Ai[1][2] = -id * (A[0][0] * A[1][2] - A[0][2] * A[1][0]);
+        Ai[2][0] = id * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+        Ai[2][1] = -id * (A[0][0] * A[2][1] - A[0][1] * A[2][0]);
+        Ai[2][2] = id * (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
+      }
+      double ssq[3];
+      for (int k = 0; k < nb; k++) ssq[k] = dot3(sv[k], sv[k]);
+      bool done = false;
+      int iter = 0;
+      while (!done && iter < S.shake_maxiter) {
+        double rhs[3];
+        for (int k = 0; k < nb; k++) {
+          double w[3] = {0, 0, 0};
+          for (int j = 0; j < nb; j++)
+            for (int c = 0; c < 3; c++) w[c] += M[k][j] * lam[j] * r[j][c];
+          rhs[k] = dist[k] * dist[k] - ssq[k] - dot3(w, w);
+        }
+        double ln[3];
+        done = true;
+        for (int k = 0; k < nb; k++) {
+          ln[k] = 0.0;
+          for (int j = 0; j < nb; j++) ln[k] += Ai[k][j] * rhs[j];
+          if (fabs(ln[k] - lam[k]) > S.shake_tol) done = false;
+        }
+        for (int k = 0; k < nb; k++) lam[k] = ln[k];
+        for (int k = 0; k < nb; k++)
+          if (isnan(lam[k])) done = true;
+        iter++;
+      }
+    }
+    double f0[3] = {0, 0, 0};
+    for (int k = 0; k < nb; k++) {
+      const double l = lam[k] / dtfsq;
+      const double ff[3] = {l * r[k][0], l * r[k][1], l * r[k][2]};
+      for (int c = 0; c < 3; c++) {
+        f0[c] += ff[c];
+        S.f[3 * at[k + 1] + c] -= ff[c];
+      }
+      vt(v, r[k][0], r[k][1], r[k][2], ff[0], ff[1], ff[2]);
+    }
+    for (int c = 0; c < 3; c++) S.f[3 * at[0] + c] += f0[c];
+  }
+  block_atomic_add<6>(v, sc.vir + P_SHAKE * 6, s_red);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_final_integrate : v += dt/2 f/m ; kinetic tensor
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_final_integrate(const SimDev *sims, int kick) {
+  const SimDev &S = sims[blockIdx.y];
+  SimScalars &sc = *S.sc;
+  __shared__ double s_red[6 * (TPB / 64)];
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  double ke[6] = {0, 0, 0, 0, 0, 0};
+  if (i < S.natoms) {
+    const double m = S.mass[i];
+    const double dtfm = kick ? 0.5 * S.dt * MD_FTM2V / m : 0.0;
+    double v[3];
+    for (int k = 0; k < 3; k++) {
+      v[k] = S.v[3 * i + k];
+      if (kick) { v[k] += dtfm * S.f[3 * i + k]; S.v[3 * i + k] = v[k]; }
+    }
+    const double mm = m * MD_MVV2E;
+    ke[0] = mm * v[0] * v[0]; ke[1] = mm * v[1] * v[1]; ke[2] = mm * v[2] * v[2];
+    ke[3] = mm * v[0] * v[1]; ke[4] = mm * v[0] * v[2]; ke[5] = mm * v[1] * v[2];
+  }
+  block_atomic_add<6>(ke, sc.ke, s_red);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_post : end of step (tiny): thermostat second half, pressure sample, fix deform box update
+// ------------------------------------------------------------------------------------------
+__global__ void k_post(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.x];
+  SimScalars &sc = *S.sc;
+  if (threadIdx.x != 0) return;
+  sc.t_current = (sc.ke[0] + sc.ke[1] + sc.ke[2]) / (S.tdof * MD_BOLTZ);
+  double f2 = 1.0;
+  if (S.nvt) f2 = nhc_half(S, sc);
+  sc.vscale = f2;
+  for (int k = 0; k < 6; k++) sc.ke[k] *= f2 * f2;
+  // fix ave/time 1 nav nav c_thermo_press[*] ave running
+  if (S.nav > 0 && sc.step <= S.nwin * S.nav) {
+    BoxD b;
+    box_derive(sc.box, b);
+    for (int k = 0; k < 6; k++) {
+      double w = 0.0;
+      for (int p = 0; p < MD_NPART; p++) w += sc.vir[p * 6 + k];
+      sc.psum[k] += (sc.ke[k] + w) / b.vol * MD_NKTV2P;
+    }
+    sc.nsamples += 1;
+  }
+  // fix deform 1 ... erate ... : box(t) linear in t about the box centre, tilts by Ly0/Lz0
+  if (S.deform) {
+    for (int k = 0; k < 9; k++) sc.box_prev[k] = sc.box[k];
+    const double t = sc.step * S.dt;
+    for (int d = 0; d < 3; d++) {
+      const double L0 = sc.box0[3 + d] - sc.box0[d];
+      sc.box[d] = sc.box0[d] - 0.5 * L0 * S.rates[d] * t;
+      sc.box[3 + d] = sc.box0[3 + d] + 0.5 * L0 * S.rates[d] * t;
+    }
+    sc.box[6] = sc.box0[6] + S.rates[3] * (sc.box0[4] - sc.box0[1]) * t;
+    sc.box[7] = sc.box0[7] + S.rates[4] * (sc.box0[5] - sc.box0[2]) * t;
+    sc.box[8] = sc.box0[8] + S.rates[5] * (sc.box0[5] - sc.box0[2]) * t;
+  }
+}
+
+// k_remap : fix deform ... remap x : x -> lamda(old box) -> x(new box)
+__global__ __launch_bounds__(TPB) void k_remap(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  if (!S.deform) return;
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= S.natoms) return;
+  BoxD bo, bn;
+  box_derive(S.sc->box_prev, bo);
+  box_derive(S.sc->box, bn);
+  const double d0 = S.x[3 * i] - bo.lo[0], d1 = S.x[3 * i + 1] - bo.lo[1], d2 = S.x[3 * i + 2] - bo.lo[2];
+  const double l0 = bo.hinv[0] * d0 + bo.hinv[5] * d1 + bo.hinv[4] * d2;
+  const double l1 = bo.hinv[1] * d1 + bo.hinv[3] * d2;
+  const double l2 = bo.hinv[2] * d2;
+  S.x[3 * i] = bn.h[0] * l0 + bn.h[5] * l1 + bn.h[4] * l2 + bn.lo[0];
+  S.x[3 * i + 1] = bn.h[1] * l1 + bn.h[3] * l2 + bn.lo[1];
+  S.x[3 * i + 2] = bn.h[2] * l2 + bn.lo[2];
+}
+
+// k_scale_v : apply the deferred thermostat factor at the end of a run
+__global__ __launch_bounds__(TPB) void k_scale_v(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= S.natoms) return;
+  const double vs = S.sc->vscale;
+  for (int k = 0; k < 3; k++) S.v[3 * i + k] *= vs;
+}
+__global__ void k_phase_end(const SimDev *sims) {
+  if (threadIdx.x == 0) sims[blockIdx.x].sc->vscale = 1.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static inline dim3 grid2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)ns, 1); }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void mdk_phase_init(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_phase_init, dim3(ns), dim3(64), 0, st, d); }
+void mdk_setup_post(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_setup_post, dim3(ns), dim3(64), 0, st, d); }
+void mdk_pre(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_pre, dim3(ns), dim3(64), 0, st, d); }
+void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
+  hipLaunchKernelGGL(k_initial_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
+}
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells) {
+  hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_cell_scan, dim3(ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_cell_fill, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_cell_sort, grid2(cdiv(maxcells, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_neigh_build, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
+}
+void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
+  hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
+}
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int ev) {
+  if (ev) hipLaunchKernelGGL(k_pair<true>, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
+  else hipLaunchKernelGGL(k_pair<false>, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
+}
+void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxb, int maxa, int maxd, int maxi, int maxs) {
+  if (maxs > 0) hipLaunchKernelGGL(k_term<T_SPECIAL>, grid2(cdiv(maxs, TPB), ns), dim3(TPB), 0, st, d);
+  if (maxb > 0) hipLaunchKernelGGL(k_term<T_BOND>, grid2(cdiv(maxb, TPB), ns), dim3(TPB), 0, st, d);
+  if (maxa > 0) hipLaunchKernelGGL(k_term<T_ANGLE>, grid2(cdiv(maxa, TPB), ns), dim3(TPB), 0, st, d);
+  if (maxd > 0) hipLaunchKernelGGL(k_term<T_DIHEDRAL>, grid2(cdiv(maxd, TPB), ns), dim3(TPB), 0, st, d);
+  if (maxi > 0) hipLaunchKernelGGL(k_term<T_IMPROPER>, grid2(cdiv(maxi, TPB), ns), dim3(TPB), 0, st, d);
+}
+void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax) {
+  if (maxk <= 0) return;
+  hipLaunchKernelGGL(k_ewald_sfac, grid2(cdiv(maxatoms, EW_ATOMS), ns), dim3(TPB), (size_t)EW_ATOMS * 3 * mmax * sizeof(double2), st, d, mmax);
+  hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), (size_t)EWF_TPB * 3 * mmax * sizeof(double2), st, d, mmax);
+}
+void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
+  if (maxclus <= 0) return;
+  hipLaunchKernelGGL(k_shake, grid2(cdiv(maxclus, TPB), ns), dim3(TPB), 0, st, d, dtfsq_scale);
+}
+void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick) {
+  hipLaunchKernelGGL(k_final_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d, kick);
+}
+void mdk_post(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_post, dim3(ns), dim3(64), 0, st, d); }
+void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
+  hipLaunchKernelGGL(k_remap, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
+}
+void mdk_phase_end(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
+  hipLaunchKernelGGL(k_scale_v, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_phase_end, dim3(ns), dim3(64), 0, st, d);
+}

@@ -1,0 +1,94 @@
+// md_types.h -- device-visible data layout of the batched MD micro-solver (gfx950).
+//
+// One SimDev per simulation that is being advanced in the current launch group; kernels are
+// launched on 2-D grids with blockIdx.y = simulation, so one launch covers the whole batch of
+// quadrature-point replicas (DESIGN.md "Data layout in HBM").
+#pragma once
+#include <stdint.h>
+
+#define MD_MAXCHAIN 8
+#define MD_NPART 8
+#define MD_MAXTYPES 16
+#define MD_JMASK 0x07FFFFFF /* neighbour entry: low 27 bits = slot of j, high 5 bits = image code */
+#define MD_JBITS 27
+
+// units real
+#define MD_BOLTZ 0.0019872067
+#define MD_MVV2E (48.88821291 * 48.88821291)
+#define MD_FTM2V (1.0 / 48.88821291 / 48.88821291)
+#define MD_NKTV2P 68568.415
+#define MD_QQRD2E 332.06371
+#define MD_EWALD_F 1.12837916709551257390
+#define MD_PI 3.14159265358979323846
+
+enum { P_LJ = 0, P_COUL = 1, P_BOND = 2, P_ANGLE = 3, P_DIHEDRAL = 4, P_IMPROPER = 5, P_KSPACE = 6, P_SHAKE = 7 };
+
+// mutable per-simulation scalars, resident in HBM (one cache line group per simulation)
+struct SimScalars {
+  double box[9];       // current xlo,ylo,zlo,xhi,yhi,zhi,xy,xz,yz
+  double box_prev[9];  // box before the last fix-deform update (remap source)
+  double box0[9];      // fix-deform reference box (start of the run)
+  double vir[MD_NPART * 6];
+  double eng[MD_NPART];
+  double ke[6];
+  double t_current;
+  double eta[MD_MAXCHAIN + 1], eta_dot[MD_MAXCHAIN + 1], eta_dotdot[MD_MAXCHAIN + 1], eta_mass[MD_MAXCHAIN + 1];
+  double vscale;       // deferred Nose-Hoover velocity scale, applied by the next kick
+  double psum[6];      // running sum of the sampled pressure tensor (atm)
+  double deltasq;      // neighbour trigger: (skin - corner motion)^2 / 4
+  double corners_hold[24];
+  unsigned long long nentries;  // neighbour entries stored at the last build (full list)
+  int nsamples;
+  int step;
+  int ago;
+  int check;           // ago >= delay
+  int rebuild;
+  int overflow;
+  int maxneigh_seen;
+  int nbuilds;
+};
+
+struct SimDev {
+  // sizes
+  int natoms, npad, ntypes;
+  int nbonds, nangles, ndihedrals, nimpropers, nspecial, nclus;
+  int maxneigh;
+  int nc[3], ncells, mst[3];  // cell grid and stencil half-widths
+  int nk, kmaxd[3];
+  int nsteps;                 // steps of this run for this simulation
+  int nav, nwin;              // fix ave/time windows (0 = no sampling)
+  int nvt, use_shake, deform;
+  int t_chain, neigh_delay, shake_maxiter;
+  // scalars
+  double dt, t_target, t_freq, tdof, g_ewald, qsqsum, qsum;
+  double cut_lj2, cut_coul2, rlist2, skin, excl_cut2, shake_tol;
+  double rates[6];
+  // topology (shared by all simulations of one (material, replica))
+  const int *type;
+  const double *q, *mass;       // per atom
+  const double *lj;             // 4 * ntypes^2 : lj1,lj2,lj3,lj4
+  const int *bond_at; const double *bond_cf;        // 2 ints, (K,r0); SHAKE'd bonds at the end
+  int nbonds_noshake;
+  const int *angle_at; const double *angle_cf;      // 3 ints, (K,theta0)
+  const int *dihedral_at; const double *dihedral_cf;// 4 ints, (K1..K4)
+  const int *improper_at; const double *improper_cf;// 4 ints, (K,chi0)
+  const int *special_at; const double *special_cf;  // 2 ints, (f_lj,f_coul)
+  const int *ex_start, *ex_list;
+  const int *clus_at, *clus_n; const double *clus_d;
+  // state
+  double *x, *v, *f;
+  // pair structures
+  double4 *xq;      // slot-ordered wrapped positions + charge
+  int *stype;       // slot-ordered type
+  int *perm;        // slot -> atom
+  int *slot_tmp;    // unsorted cell fill
+  int *wrapn;       // atom -> integer wrap (3)
+  double *xhold;
+  int *cell_of, *cell_count, *cell_start, *cell_fill;
+  int *numneigh, *neigh;
+  // ewald
+  const int *kn;    // 3 ints per k
+  double *sfac;     // 2 per k
+  double *kvec;     // 4 per k : kx,ky,kz,ug
+  SimScalars *sc;
+};

@@ -1,0 +1,42 @@
+"""CPU-side checks of the C-ABI library: it loads and exports every symbol include/scema_md.h declares;
+without a GPU engine creation fails loudly (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _built():
+    import __graft_entry__ as g
+    g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    _built()
+    from scema_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "scema_md.h")).read()
+    declared = set(re.findall(r"\b(scema_md_[a-z_]+)\s*\(", hdr))
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    L = capi.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_struct_layouts_match_header_sizes():
+    from scema_amd import capi
+    # QP wire record is 112 bytes (scale_bridging_data.h:12-19); MDSim mirror must keep C alignment
+    assert ctypes.sizeof(capi.MDSim) % 8 == 0
+    assert capi.MDSim.strain.offset % 8 == 0 and capi.MDSim.stress.offset % 8 == 0
+
+
+def test_no_gpu_means_loud_failure():
+    _built()
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from scema_amd import capi
+    with pytest.raises(capi.EngineError):
+        capi.Engine()

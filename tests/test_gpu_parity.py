@@ -1,0 +1,134 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle on identical seeded
+inputs.  FP64 throughout; tolerances are stated at each assert (summation order differs, nothing else)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_small():
+    from scema_amd import capi
+    p = capi.default_params(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+    e = capi.Engine(p)
+    yield e
+    e.close()
+
+
+def oracle_small(d, **kw):
+    from oracle import pyoracle as po
+    base = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+    base.update(kw)
+    return po.Oracle(d, po.default_params(**base))
+
+
+def relerr(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+@pytest.mark.parametrize("use_shake", [False, True])
+def test_static_forces_energies_virials(small_pe, eng_small, use_shake):
+    from scema_amd import capi
+    eng_small.register_replica("pe", 1, small_pe)
+    f, e, w, info = eng_small.debug_compute("pe", 1, use_shake=use_shake)
+    o = oracle_small(small_pe)
+    o.setup(use_shake=use_shake)
+    fo, eo, wo = o.compute()
+    assert info["nk"] == o.nkvec and abs(info["g_ewald"] - o.g_ewald) < 1e-14
+    assert info["npairs"] == o.npairs          # same unique pairs within cutoff+skin
+    assert info["tdof"] == o.tdof
+    assert relerr(f, fo) < 1e-11
+    for part in range(7):
+        scale = max(1.0, abs(eo[part]))
+        assert abs(e[part] - eo[part]) < 1e-10 * scale, capi.PARTS[part]
+        assert np.abs(w[part] - wo[part]).max() < 1e-10 * max(1.0, np.abs(wo[part]).max()), capi.PARTS[part]
+
+
+def test_static_full_cutoffs_midsize():
+    """3456-atom PE crystal at the reference's real cutoffs (12 / 9 / skin 2, kspace 1e-4)."""
+    from scema_amd import capi
+    from scema_amd.systems import build_pe
+    from oracle import pyoracle as po
+    d = build_pe(4, 6, 12, jitter=0.03, seed=11)
+    d["box"][6:9] = [0.4, -0.3, 0.2]
+    e = capi.Engine()
+    e.register_replica("g0", 1, d)
+    f, en, w, info = e.debug_compute("g0", 1, use_shake=True)
+    o = po.Oracle(d)
+    o.setup(True)
+    fo, eo, wo = o.compute()
+    assert info["npairs"] == o.npairs and info["nk"] == o.nkvec
+    assert relerr(f, fo) < 1e-11
+    assert np.abs(en[:7] - eo[:7]).max() < 1e-9 * np.abs(eo).max()
+    assert np.abs(w[:7] - wo[:7]).max() < 1e-9 * np.abs(wo).max()
+    e.close()
+
+
+@pytest.mark.parametrize("mode", ["nve", "nvt_shake", "nvt_shake_deform"])
+def test_short_run_trajectory(small_pe, eng_small, mode):
+    """20 steps of the full per-step order (A.2) land on the same state as the oracle."""
+    eng_small.register_replica("pe", 2, small_pe)
+    nvt = mode != "nve"
+    shake = mode != "nve"
+    rates = np.array([1e-5, -2e-5, 3e-5, 1.5e-5, -0.5e-5, 2.5e-5]) if mode.endswith("deform") else None
+    nsteps, dt = 20, 1.0
+    eng_small.set_state(5, "pe", 2, small_pe["box"], small_pe["x"], small_pe["v"])
+    pavg = eng_small.debug_run("pe", 2, nsteps, dt, 300.0, qp=5, nvt=nvt, use_shake=shake, rates=rates, sample=True)
+    box, x, v = eng_small.get_state(5, "pe", 2)
+    o = oracle_small(small_pe)
+    pavg_o, _ = o.run(nsteps, dt, 300.0, nvt=nvt, use_shake=shake, rates=rates, sample=True)
+    bo, xo, vo = o.get_state()
+    assert np.abs(box - bo).max() < 1e-12
+    assert np.abs(x - xo).max() < 1e-9          # Angstrom
+    assert relerr(v, vo) < 1e-8
+    assert relerr(pavg, pavg_o) < 1e-8
+    eng_small.drop_state(5, "pe", 2)
+
+
+def test_full_evaluation_matches_oracle(small_pe, eng_small):
+    """scema_md_strain_batch == omd_eval (F8): strain in Angstrom -> stress in Pa, within 1e-6 relative
+    (the north-star budget is 1e-4)."""
+    from scema_amd import capi
+    eng_small.register_replica("pe", 3, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    strain = np.array([-0.3 * 1.2e-3 * lens[0], -0.3 * 1.2e-3 * lens[1], 1.2e-3 * lens[2], 5e-5 * lens[2], -3e-5 * lens[1], 2e-5 * lens[0]])
+    sims = [capi.make_sim(7, "pe", 3, strain, nss=20, most_recent=capi.QP_NONE)]
+    out = eng_small.strain_batch(sims)
+    got = np.array(out[0].stress[:])
+    assert out[0].stress_updated == 1
+    o = oracle_small(small_pe)
+    exp, nts = o.eval(strain, 2.0, 300.0, 1e-4, 20)
+    assert nts == 10
+    assert relerr(got, exp) < 1e-6
+    # state persisted under qp 7 and matches the oracle's end state
+    box, x, v = eng_small.get_state(7, "pe", 3)
+    bo, xo, vo = o.get_state()
+    assert np.abs(box - bo).max() < 1e-12 and np.abs(x - xo).max() < 1e-8
+    # second call continues from the stored state (history dependence), again matching the oracle
+    sims2 = [capi.make_sim(7, "pe", 3, 0.5 * strain, nss=20)]
+    got2 = np.array(eng_small.strain_batch(sims2)[0].stress[:])
+    exp2, _ = o.eval(0.5 * strain, 2.0, 300.0, 1e-4, 20)
+    assert relerr(got2, exp2) < 1e-6
+
+
+def test_batch_is_independent_and_ordered(small_pe, eng_small):
+    """A batch of sims with different strains / nts equals the same sims run one by one."""
+    from scema_amd import capi
+    eng_small.register_replica("pe", 4, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    rng = np.random.default_rng(5)
+    strains = []
+    for i in range(5):
+        ezz = rng.uniform(1e-3, 6e-3)    # nts 10..30: ragged batch
+        strains.append(np.array([-0.3 * ezz * lens[0], -0.3 * ezz * lens[1], ezz * lens[2], 0, 0, 0]))
+    sims = [capi.make_sim(100 + i, "pe", 4, s, nss=10, most_recent=capi.QP_NONE) for i, s in enumerate(strains)]
+    out = eng_small.strain_batch(sims)
+    batch = np.array([o.stress[:] for o in out])
+    for i, s in enumerate(strains):
+        eng_small.drop_state(100 + i, "pe", 4)
+    single = []
+    for i, s in enumerate(strains):
+        o1 = eng_small.strain_batch([capi.make_sim(100 + i, "pe", 4, s, nss=10, most_recent=capi.QP_NONE)])
+        single.append(o1[0].stress[:])
+    assert relerr(batch, np.array(single)) < 1e-9
