@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""bench.py -- stress evaluations per second of the MI355X-native strained-MD path.
+
+One "step" = one STMDSync::update() worth of work: a batch of `--sims` quadrature-point replicas
+(default 576 x PE-10k), each strained for nts=10 MD steps and sampled for nss=100 MD
+steps, starting from the state the previous step left in HBM.  With N GPUs the batch is sharded
+round-robin (simulation i -> rank i % N, stmd_sync.h:583) and the stresses return through one
+RCCL all-gather, so the total work per step is fixed ("strong" scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(d, strain, nss):
+    """The oracle (CPU restatement, NOT LAMMPS) timed on one host core for one evaluation."""
+    from oracle import pyoracle as po
+    o = po.Oracle(d)
+    t0 = time.time()
+    _, nts = o.eval(strain, 2.0, 300.0, 1e-4, nss)
+    dt = time.time() - t0
+    tm = o.timing()
+    return {"value": 1.0 / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"1 PE-10k evaluation ({nts}+{nss} MD steps) on 1 host core of {os.cpu_count()}: {dt:.1f} s "
+                      f"(pair {tm['pair']:.1f} s, kspace {tm['kspace']:.1f} s, neigh {tm['neigh']:.1f} s); "
+                      "CPU restatement (oracle/md_oracle.c), not LAMMPS"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sims", type=int, default=576, help="quadrature-point replicas per update()")
+    ap.add_argument("--nss", type=int, default=100)
+    ap.add_argument("--cells", type=int, nargs=3, default=[6, 9, 16], help="PE supercell (6 9 16 = PE-10k)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from scema_amd import capi
+    from scema_amd.systems import build_pe, synthetic_strains
+
+    d = build_pe(*args.cells)
+    eng = capi.Engine(capi.default_params(device=local_rank, profile=1))
+    eng.register_replica("g0", 1, d)
+    lens = d["box"][3:6] - d["box"][:3]
+    n = args.sims
+    per_rank = (n + world - 1) // world
+
+    send = torch.zeros(6 * per_rank, dtype=torch.float64, device="cuda")
+    recv = torch.zeros(6 * per_rank * world, dtype=torch.float64, device="cuda")
+    checksum = 0.0
+
+    def update(istep):
+        nonlocal checksum
+        strains = synthetic_strains(n, lens, seed=2026 + istep)
+        first = istep == 0
+        sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=(capi.QP_NONE if first else q))
+                for q in range(n)]
+        arr = eng.strain_batch(sims, rank=rank, world=world)
+        if world > 1:
+            eng.copy_local_stress(send.data_ptr(), True)
+            dist.all_gather_into_tensor(recv, send)          # the one collective (replaces share_stresses)
+            if rank == 0:
+                eng.scatter_gathered(recv.cpu().numpy(), world, arr)
+        if rank == 0:
+            checksum = float(sum(a.stress[2] for a in arr))
+        return arr
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        update(w)
+    eng.profile(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        update(args.warmup + k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = eng.profile()
+
+    if rank == 0:
+        value = n * args.steps / elapsed
+        pair_s = prof["pair_ms"] * 1e-3
+        achieved = prof["pair_alg_bytes"] / pair_s / 1e9 if pair_s > 0 else 0.0
+        out = {
+            "metric": "stress_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n} x PE-{d['natoms']} OPLS replicas per update(), 10+{args.nss} MD steps each "
+                                   "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + Ewald 1e-4 + SHAKE + NVT), persistent per-QP state",
+                       "n_sims": n, "atoms_per_replica": int(d["natoms"]), "md_steps_per_eval": 10 + args.nss,
+                       "sharding": f"sim i -> rank i % {world}", "stress_zz_checksum_Pa": checksum},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": "k_pair (lj/cut/coul/long force+virial, full list)",
+                         "launches": prof["pair_launches"],
+                         "avg_launch_ms": prof["pair_ms"] / max(prof["pair_launches"], 1),
+                         "alg_bytes_per_launch": prof["pair_alg_bytes"] / max(prof["pair_launches"], 1),
+                         "rank0_pair_share_of_wall": pair_s / elapsed},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, synthetic_strains(1, lens, seed=2026)[0], args.nss)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,8 @@ int scema_md_strain(scema_md_engine *e, scema_mdsim *sim, int32_t hooke);
  * all-gather that replaces STMDSync::share_stresses (stmd_sync.h:620-726). */
 void *scema_md_local_stress_device_ptr(scema_md_engine *e);
 int32_t scema_md_local_stress_count(const scema_md_engine *e);
+/* copy that buffer into caller memory (a device pointer, e.g. the send buffer of the all-gather, or host) */
+int scema_md_copy_local_stress(scema_md_engine *e, void *dst, int32_t dst_on_device);
 /* after the caller's all-gather into gathered[world][6*ceil(n/world)] (host memory): fill
  * sims[i].stress / stress_updated for every i (rank-0 bookkeeping of stmd_sync.h:698-725) */
 int scema_md_scatter_gathered(const double *gathered, int32_t world, scema_mdsim *sims, int32_t n_sims);

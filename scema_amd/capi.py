@@ -23,7 +23,7 @@ SYMBOLS = [
     "scema_md_default_params", "scema_md_create", "scema_md_destroy", "scema_md_last_error",
     "scema_md_register_replica", "scema_md_load_replica_file", "scema_md_write_replica_file",
     "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
-    "scema_md_local_stress_count", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
+    "scema_md_local_stress_count", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
     "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file",
     "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile",
 ]
@@ -185,6 +185,13 @@ class Engine:
 
     def local_stress_ptr(self):
         return lib().scema_md_local_stress_device_ptr(self.h), lib().scema_md_local_stress_count(self.h)
+
+    def copy_local_stress(self, dst_ptr: int, on_device: bool):
+        self._chk(lib().scema_md_copy_local_stress(self.h, C.c_void_p(dst_ptr), C.c_int32(1 if on_device else 0)))
+
+    def scatter_gathered(self, gathered: np.ndarray, world: int, arr):
+        g = np.ascontiguousarray(gathered, np.float64)
+        self._chk(lib().scema_md_scatter_gathered(_p(g), C.c_int32(world), arr, C.c_int32(len(arr))))
 
     def has_state(self, qp, matid, replica) -> bool:
         return bool(lib().scema_md_has_state(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica)))

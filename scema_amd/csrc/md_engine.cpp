@@ -399,6 +399,84 @@ void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, Ewa
       }
 }
 
+// Real-space Ewald factor erfc(x) + 2x/sqrt(pi) exp(-x^2) = 1 - x H(u), u = x^2.  H is entire in u:
+// H(u) = 2/sqrt(pi) sum_{n>=1} (-1)^(n+1) u^n/n! 2n/(2n+1).  Fit H on [0, (g rc)^2] by Chebyshev
+// interpolation (degree grown until the tail is below 1e-17 relative) and hand the kernel monomial
+// coefficients in t = 2u/umax - 1.  All in long double; the fit is checked against H on a fine grid.
+static long double coul_H(long double u) {
+  const long double c = 2.0L / sqrtl(acosl(-1.0L));
+  if (u < 1.0L) {
+    long double term = 1.0L, sum = 0.0L;
+    for (int n = 1; n < 200; n++) {
+      term *= u / n;  // u^n/n!
+      const long double t = term * (2.0L * n) / (2.0L * n + 1.0L);
+      sum += (n % 2 == 1) ? t : -t;
+      if (t < 1e-24L * fabsl(sum)) break;
+    }
+    return c * sum;
+  }
+  const long double x = sqrtl(u);
+  return (erfl(x) - c * x * expl(-u)) / x;
+}
+
+static double fit_coul_poly(double g, double rc, double *poly, int *npoly, double *uscale) {
+  if (g <= 0.0) {
+    poly[0] = 0.0;
+    *npoly = 1;
+    *uscale = 0.0;
+    return 0.0;
+  }
+  const long double umax = (long double)(g * rc) * (g * rc) * 1.000001L;
+  const long double PI = acosl(-1.0L);
+  std::vector<long double> c;
+  int N = 10;
+  for (; N <= MD_MAXPOLY; N += 2) {
+    c.assign(N, 0.0L);
+    std::vector<long double> fv(N);
+    for (int j = 0; j < N; j++) fv[j] = coul_H(0.5L * umax * (cosl(PI * (j + 0.5L) / N) + 1.0L));
+    for (int k = 0; k < N; k++) {
+      long double s = 0.0L;
+      for (int j = 0; j < N; j++) s += fv[j] * cosl(PI * k * (j + 0.5L) / N);
+      c[k] = 2.0L * s / N;
+    }
+    long double cmax = 0.0L;
+    for (int k = 0; k < N; k++) cmax = std::max(cmax, fabsl(c[k]));
+    if (fabsl(c[N - 1]) + fabsl(c[N - 2]) < 1e-17L * cmax) break;
+  }
+  if (N > MD_MAXPOLY) N = MD_MAXPOLY;
+  // Chebyshev -> monomial in t
+  std::vector<long double> a(N, 0.0L), Tkm1(N, 0.0L), Tk(N, 0.0L), Tn(N, 0.0L);
+  Tkm1[0] = 1.0L;                      // T0
+  a[0] += 0.5L * c[0];
+  if (N > 1) {
+    Tk[1] = 1.0L;                      // T1
+    a[1] += c[1];
+  }
+  for (int k = 2; k < N; k++) {
+    std::fill(Tn.begin(), Tn.end(), 0.0L);
+    for (int m = 0; m < N - 1; m++) Tn[m + 1] += 2.0L * Tk[m];
+    for (int m = 0; m < N; m++) Tn[m] -= Tkm1[m];
+    for (int m = 0; m < N; m++) a[m] += c[k] * Tn[m];
+    Tkm1 = Tk;
+    Tk = Tn;
+  }
+  for (int m = 0; m < N; m++) poly[m] = (double)a[m];
+  for (int m = N; m < MD_MAXPOLY; m++) poly[m] = 0.0;
+  *npoly = N;
+  *uscale = (double)(2.0L / umax);
+  // self-check in double arithmetic, as the kernel evaluates it
+  double maxerr = 0.0;
+  for (int s = 0; s <= 400; s++) {
+    const double u = (double)umax * s / 400.0 / 1.000001;
+    const double t = u * (*uscale) - 1.0;
+    double p = poly[N - 1];
+    for (int m = N - 2; m >= 0; m--) p = std::fma(p, t, poly[m]);
+    const double x = std::sqrt(u);
+    maxerr = std::max(maxerr, std::fabs(x * (p - (double)coul_H(u))));
+  }
+  return maxerr;
+}
+
 // fix-deform box at time t (same expression as k_post)
 void deform_box(const double *box0, const double *rates, double t, double *out) {
   for (int d = 0; d < 3; d++) {
@@ -474,7 +552,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   for (int i = 0; i < ns; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
   e->h_sims.assign(ns, SimDev());
-  int maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
+  int maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
   std::vector<int> kn_all;
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
@@ -513,12 +591,21 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.nk = (int)ew.kn.size() / 3;
     for (int d = 0; d < 3; d++) S.kmaxd[d] = ew.kmaxd[d];
     S.g_ewald = ew.g;
+    {
+      const double perr = fit_coul_poly(ew.g, P.cut_coul, S.coul_poly, &S.coul_npoly, &S.coul_uscale);
+      if (perr > 1e-12) return fail(e, SCEMA_MD_ERR_ARG, "real-space Ewald polynomial fit error %.3e too large (g*rc = %.3f)", perr, ew.g * P.cut_coul);
+    }
+    {
+      const double m = 0.25 * P.skin;
+      S.seg_a2 = (P.cut_coul + m) * (P.cut_coul + m);
+      S.seg_b2 = (P.cut_lj + m) * (P.cut_lj + m);
+    }
     S.natoms = T.natoms;
     S.npad = (T.natoms + 255) / 256 * 256;
     S.ntypes = T.ntypes;
     const double rho = T.natoms / std::min(b0.vol, b1.vol);
     int maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.15 * e->neigh_grow) + 48;
-    maxneigh = std::min(maxneigh, T.natoms);
+    maxneigh = (std::min(maxneigh, T.natoms) + 63) / 64 * 64;
     Slot &sl = *e->slots[i];
     int rc = ensure_slot(e, sl, T.natoms, maxneigh, S.ncells, S.nk);
     if (rc) return rc;
@@ -569,6 +656,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     e->h_sims[pos] = S;
     maxatoms = std::max(maxatoms, S.natoms); maxpad = std::max(maxpad, S.npad); maxcells = std::max(maxcells, S.ncells);
     maxk = std::max(maxk, S.nk);
+    maxpoly = std::max(maxpoly, S.coul_npoly);
     for (int d = 0; d < 3; d++) mmax = std::max(mmax, S.kmaxd[d] + 1);
     maxb = std::max(maxb, S.nbonds); maxa = std::max(maxa, S.nangles); maxd = std::max(maxd, S.ndihedrals);
     maxi = std::max(maxi, S.nimpropers); maxs = std::max(maxs, S.nspecial); maxclus = std::max(maxclus, S.use_shake ? S.nclus : 0);
@@ -583,7 +671,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // ---- setup (step 0) ----
   mdk_phase_init(st, D, ns);
   mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells);
-  mdk_pair(st, D, ns, maxpad, ev);
+  mdk_pair(st, D, ns, maxpad, ev, spec.ev_always, maxpoly);
   mdk_bonded(st, D, ns, maxb, maxa, maxd, maxi, maxs);
   mdk_ewald(st, D, ns, maxatoms, maxk, mmax);
   if (!spec.static_only) mdk_shake(st, D, ns, maxclus, 0.5);
@@ -610,7 +698,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
-    mdk_pair(st, D, na, maxpad, ev);
+    mdk_pair(st, D, na, maxpad, ev, spec.ev_always, maxpoly);
     if (prof) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;
@@ -1021,6 +1109,14 @@ int scema_md_strain(scema_md_engine *e, scema_mdsim *sim, int32_t hooke_mode) { 
 
 void *scema_md_local_stress_device_ptr(scema_md_engine *e) { return e ? e->d_local_stress.p : nullptr; }
 int32_t scema_md_local_stress_count(const scema_md_engine *e) { return e ? e->local_stress_count : 0; }
+
+int scema_md_copy_local_stress(scema_md_engine *e, void *dst, int32_t dst_on_device) {
+  if (!e || !dst) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  HIPCHK(hipMemcpy(dst, e->d_local_stress.p, (size_t)std::max(e->local_stress_count, 0) * 6 * sizeof(double),
+                   dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+  return SCEMA_MD_OK;
+}
 
 int scema_md_scatter_gathered(const double *gathered, int32_t world, scema_mdsim *sims, int32_t n_sims) {
   if (!gathered || !sims || world <= 0) return SCEMA_MD_ERR_ARG;

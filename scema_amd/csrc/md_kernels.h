@@ -1,4 +1,4 @@
-// md_kernels.h -- host-callable launch wrappers of the gfx950 kernels in md_kernels.hip
+// md_kernels.h -- host-callable launch wrappers of the gfx950 kernels (md_kernels.hip, md_pair.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 struct SimDev;
@@ -7,8 +7,10 @@ void mdk_setup_post(hipStream_t st, const SimDev *d, int ns);
 void mdk_pre(hipStream_t st, const SimDev *d, int ns);
 void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms);
 void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells);
+void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad);
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int ev);
+// vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int vir, int eng, int npoly);
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxb, int maxa, int maxd, int maxi, int maxs);
 void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax);
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);

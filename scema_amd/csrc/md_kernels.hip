@@ -18,14 +18,11 @@
 //   pressure sample in k_post ... compute pressure + fix ave/time (K11)
 #include <hip/hip_runtime.h>
 
+#include "md_device.h"
 #include "md_kernels.h"
 #include "md_types.h"
 
-#define TPB 256
-
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
+#if 0  // moved to md_device.h
 struct BoxD {
   double lo[3], h[6], hinv[6], vol;
 };
@@ -74,6 +71,7 @@ __device__ __forceinline__ void block_atomic_add(double (&vals)[NV], double *dst
     if (s != 0.0) atomicAdd(&dst[threadIdx.x], s);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Nose-Hoover chain half step (fix nvt; one sub-cycle, no drag).  Returns the velocity factor.
@@ -350,7 +348,8 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   S.stype[s] = S.type[a];
 }
 
-// k_neigh_build : full neighbour list, one thread per slot, transposed storage neigh[k*npad+i]
+// k_neigh_build and k_pair live in md_pair.hip (round-1 first versions kept below for reference)
+#if 0
 __global__ __launch_bounds__(TPB) void k_neigh_build(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   SimScalars &sc = *S.sc;
@@ -510,6 +509,7 @@ __global__ __launch_bounds__(TPB) void k_pair(const SimDev *sims) {
     block_atomic_add<1>(e1, sc.eng + P_COUL, s_red);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // bonded terms and special pairs : one thread per term, f64 atomics into f
@@ -1053,14 +1053,10 @@ void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int max
   hipLaunchKernelGGL(k_cell_fill, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_sort, grid2(cdiv(maxcells, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
-  hipLaunchKernelGGL(k_neigh_build, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
+  mdk_neigh_build(st, d, ns, maxpad);
 }
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
-}
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int ev) {
-  if (ev) hipLaunchKernelGGL(k_pair<true>, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
-  else hipLaunchKernelGGL(k_pair<false>, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
 }
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxb, int maxa, int maxd, int maxi, int maxs) {
   if (maxs > 0) hipLaunchKernelGGL(k_term<T_SPECIAL>, grid2(cdiv(maxs, TPB), ns), dim3(TPB), 0, st, d);

@@ -9,8 +9,13 @@
 #define MD_MAXCHAIN 8
 #define MD_NPART 8
 #define MD_MAXTYPES 16
-#define MD_JMASK 0x07FFFFFF /* neighbour entry: low 27 bits = slot of j, high 5 bits = image code */
-#define MD_JBITS 27
+#define MD_MAXPOLY 48
+#define MD_NBINS 28
+#define MD_JMASK 0x003FFFFF /* neighbour entry: [21:0] slot of j, [26:22] type of j, [31:27] image code */
+#define MD_TYPE_SHIFT 22
+#define MD_TYPE_MASK 0x1F
+#define MD_CODE_SHIFT 27
+
 
 // units real
 #define MD_BOLTZ 0.0019872067
@@ -63,6 +68,13 @@ struct SimDev {
   double dt, t_target, t_freq, tdof, g_ewald, qsqsum, qsum;
   double cut_lj2, cut_coul2, rlist2, skin, excl_cut2, shake_tol;
   double rates[6];
+  // real-space Ewald factor erfc(x) + 2x/sqrt(pi) exp(-x^2) = 1 - x H(u), u = x^2 = g^2 r^2:
+  // H as a polynomial in t = u*coul_uscale - 1 on [-1,1] (fitted per run from g_ewald, cut_coul)
+  int coul_npoly;
+  double coul_uscale;
+  double coul_poly[MD_MAXPOLY];
+  // neighbour rows are ordered by build-time distance shells of width rlist/MD_NBINS
+  double seg_a2, seg_b2;  // row segments by build-time distance: (cut_coul+m)^2, (cut_lj+m)^2
   // topology (shared by all simulations of one (material, replica))
   const int *type;
   const double *q, *mass;       // per atom
