@@ -522,7 +522,8 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     sl.cap_neigh = 0;
   }
   if ((size_t)maxneigh * npad > (size_t)sl.cap_neigh * sl.cap_pad || sl.cap_neigh == 0) {
-    HIPCHK(sl.neigh.ensure((size_t)maxneigh * npad * 4));
+    // + slack: k_pair prefetches entry rows unconditionally, up to 5 rows past the last atom's row
+    HIPCHK(sl.neigh.ensure((size_t)maxneigh * npad * 4 + 8192));
     sl.cap_neigh = maxneigh;
   }
   if (ncells + 1 > sl.cap_cells) {
