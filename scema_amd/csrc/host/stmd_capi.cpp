@@ -1,0 +1,52 @@
+// stmd_capi.cpp -- extern "C" face of the host layer (include/scema_stmd.h)
+#include <cstring>
+#include <new>
+
+#include "stmd_sync.h"
+
+struct scema_stmd {
+  scema::STMDSync sync;
+  std::string err;
+  scema_stmd(scema_md_engine *e, int r, int w, scema_allgather_fn ag, void *ctx) : sync(e, r, w, ag, ctx) {}
+};
+
+extern "C" {
+
+int scema_stmd_create(scema_md_engine *engine, int32_t rank, int32_t world, scema_allgather_fn allgather, void *ctx, scema_stmd **out) {
+  if (!out || world <= 0 || rank < 0 || rank >= world) return SCEMA_MD_ERR_ARG;
+  *out = new (std::nothrow) scema_stmd(engine, rank, world, allgather, ctx);
+  return *out ? SCEMA_MD_OK : SCEMA_MD_ERR_ARG;
+}
+void scema_stmd_destroy(scema_stmd *s) { delete s; }
+const char *scema_stmd_last_error(const scema_stmd *s) { return s ? s->sync.last_error().c_str() : "null handle"; }
+
+int scema_stmd_init(scema_stmd *s, const scema_stmd_config *cfg) {
+  if (!s || !cfg) return SCEMA_MD_ERR_ARG;
+  return s->sync.init(*cfg);
+}
+
+int scema_stmd_update(scema_stmd *s, int32_t timestep, double present_time, int32_t newtonstep, scema_qp *update_list, int32_t n_qp) {
+  if (!s || (n_qp > 0 && !update_list) || n_qp < 0) return SCEMA_MD_ERR_ARG;
+  scema::ScaleBridgingData sbd;
+  sbd.update_list.assign(update_list, update_list + n_qp);
+  int rc = s->sync.update(timestep, present_time, newtonstep, sbd);
+  if (rc) return rc;
+  for (int i = 0; i < n_qp; i++) std::memcpy(update_list[i].update_stress, sbd.update_list[i].update_stress, 6 * sizeof(double));
+  return SCEMA_MD_OK;
+}
+
+int scema_stmd_replica_data(const scema_stmd *s, int32_t material, int32_t replica0, double *init_length, double *init_stress, double *rotam,
+                            double *rho) {
+  if (!s) return SCEMA_MD_ERR_ARG;
+  const auto &reps = s->sync.replicas();
+  const size_t idx = (size_t)material * s->sync.nreplicas() + replica0;
+  if (material < 0 || replica0 < 0 || idx >= reps.size()) return SCEMA_MD_ERR_ARG;
+  const scema::ReplicaData &r = reps[idx];
+  if (init_length) for (int i = 0; i < 3; i++) init_length[i] = r.init_length[i];
+  if (init_stress) for (int i = 0; i < 6; i++) init_stress[i] = r.init_stress.raw[i];
+  if (rotam) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rotam[3 * i + j] = r.rotam.m[i][j];
+  if (rho) *rho = r.rho;
+  return SCEMA_MD_OK;
+}
+
+}  // extern "C"

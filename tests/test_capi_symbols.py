@@ -17,11 +17,15 @@ def _built():
 def test_library_exports_every_declared_symbol():
     _built()
     from scema_amd import capi
+    from scema_amd import stmd
     hdr = open(os.path.join(ROOT, "include", "scema_md.h")).read()
     declared = set(re.findall(r"\b(scema_md_[a-z_]+)\s*\(", hdr))
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    hdr2 = open(os.path.join(ROOT, "include", "scema_stmd.h")).read()
+    declared2 = set(re.findall(r"\b(scema_stmd_[a-z_]+)\s*\(", hdr2))
+    assert declared2 == set(stmd.SYMBOLS), declared2 ^ set(stmd.SYMBOLS)
     L = capi.lib()
-    for s in declared:
+    for s in declared | declared2:
         assert hasattr(L, s), s
 
 

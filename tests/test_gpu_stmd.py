@@ -1,0 +1,100 @@
+"""GPU: the whole drop-in path -- STMDSync.init/update (host mirror) -> scema_md_strain_batch ->
+HIP kernels -- against the oracle's F8 evaluation plus the oracle's L3 arithmetic."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+
+
+def _dirs(tmp_path):
+    d = {k: str(tmp_path / k) for k in ("nanoscale_input", "nanoscale_output", "nanoscale_restart", "macroscale_output")}
+    for v in d.values():
+        os.makedirs(v, exist_ok=True)
+    return d
+
+
+def test_update_md_matches_oracle_and_restarts(small_pe, tmp_path):
+    from scema_amd import capi, stmd
+    from oracle import pyoracle as po
+    dirs = _dirs(tmp_path)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    s0 = np.array([2.0e6, -1.0e6, 3.0e6, 4.0e5, -2.0e5, 1.0e5])
+    stmd.write_nanoscale_input(dirs["nanoscale_input"], "pe", 1, init_length=lens, init_stress_raw=s0,
+                               stiff_file_order=np.zeros(36), nsheets=0, sysd=small_pe)
+    eng = capi.Engine(capi.default_params(**KW))
+    sync = stmd.STMDSync(eng)
+    common = dict(nanostatelocin=dirs["nanoscale_input"], nanostatelocout=dirs["nanoscale_output"],
+                  nanostatelocres=dirs["nanoscale_restart"], macrostatelocout=dirs["macroscale_output"],
+                  mdtype=("pe",), nrepl=1, md_nsteps_sample=20, freq_checkpoint=1)
+    sync.init(**common)
+    eps = np.array([[-4e-4, -4e-4, 1.2e-3, 5e-5, -3e-5, 2e-5], [3e-4, -2e-4, -9e-4, 0.0, 1e-5, 0.0]])
+    qps = [(11, capi.QP_NONE, 0, eps[0]), (12, capi.QP_NONE, 0, eps[1])]
+    got = sync.update(1, 0.0, 1, qps)
+    oracles = []
+    for k in range(2):
+        o = po.Oracle(small_pe, po.default_params(**KW))
+        strain_len = po.prepare_strain(eps[k], np.eye(3), lens, hooke=False)
+        sig, _ = o.eval(strain_len, 2.0, 300.0, 1e-4, 20)
+        exp = po.store(sig[None], s0[None], np.eye(3)[None], False)
+        assert np.abs(got[k] - exp).max() < 1e-6 * np.abs(sig).max()
+        oracles.append(o)
+    # checkpoint files lcts.<qp>.<mat>_<rep>.dump (stmd_problem.h:108-110,266-273)
+    for q in (11, 12):
+        assert os.path.exists(os.path.join(dirs["nanoscale_restart"], f"lcts.{q}.pe_1.dump"))
+    # CSV log of the Angstrom-valued strain and the Pa stress (quirk 1 of SURVEY appendix C)
+    assert os.path.exists(os.path.join(dirs["nanoscale_output"], "mddata_qpid11_repl1.csv"))
+    # continue on the same engine ...
+    got2 = sync.update(2, 1e-6, 1, [(11, 11, 0, 0.5 * eps[0]), (12, 12, 0, 0.5 * eps[1])])
+    # ... and after a restart from the checkpoint (STMDSync::restart, stmd_sync.h:167-187)
+    os.makedirs(os.path.join(dirs["nanoscale_input"], "restart"), exist_ok=True)
+    eng2 = capi.Engine(capi.default_params(**KW))
+    # checkpoint written at step 1 is the state BEFORE step 2
+    import shutil
+    sync.close(); eng.close()
+    # re-create the step-1 checkpoints: they were overwritten at step 2, so replay from scratch
+    eng3 = capi.Engine(capi.default_params(**KW))
+    s3 = stmd.STMDSync(eng3)
+    d3 = _dirs(tmp_path / "replay")
+    stmd.write_nanoscale_input(d3["nanoscale_input"], "pe", 1, init_length=lens, init_stress_raw=s0,
+                               stiff_file_order=np.zeros(36), nsheets=0, sysd=small_pe)
+    c3 = dict(common, nanostatelocin=d3["nanoscale_input"], nanostatelocout=d3["nanoscale_output"],
+              nanostatelocres=d3["nanoscale_restart"], macrostatelocout=d3["macroscale_output"])
+    s3.init(**c3)
+    s3.update(1, 0.0, 1, qps)
+    os.makedirs(os.path.join(d3["nanoscale_input"], "restart"), exist_ok=True)
+    for q in (11, 12):
+        shutil.copy(os.path.join(d3["nanoscale_restart"], f"lcts.{q}.pe_1.dump"), os.path.join(d3["nanoscale_input"], "restart"))
+    s4 = stmd.STMDSync(eng2)
+    s4.init(**c3)
+    got4 = s4.update(2, 1e-6, 1, [(11, 11, 0, 0.5 * eps[0]), (12, 12, 0, 0.5 * eps[1])])
+    assert np.abs(got4 - got2).max() < 1e-9 * np.abs(got2).max()
+    # and the oracle agrees on the second step too
+    for k in range(2):
+        strain_len = po.prepare_strain(0.5 * eps[k], np.eye(3), lens, hooke=False)
+        sig, _ = oracles[k].eval(strain_len, 2.0, 300.0, 1e-4, 20)
+        exp = po.store(sig[None], s0[None], np.eye(3)[None], False)
+        assert np.abs(got2[k] - exp).max() < 1e-6 * np.abs(sig).max()
+
+
+def test_branching_from_most_recent_qp(small_pe):
+    """most_recent_id != id: load the other quadrature point's state, store under the own id
+    (stmd_problem.h:116-138)."""
+    from scema_amd import capi
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+    eng.strain_batch([capi.make_sim(1, "pe", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    a = eng.strain_batch([capi.make_sim(2, "pe", 1, st, nss=10, most_recent=1)])[0].stress[:]
+    b = eng.strain_batch([capi.make_sim(1, "pe", 1, st, nss=10, most_recent=1)])[0].stress[:]
+    assert np.allclose(a, b, rtol=1e-12)           # qp 2 branched from qp 1's state: same evaluation
+    assert eng.has_state(2, "pe", 1)
+    with pytest.raises(capi.EngineError):          # branching from a state that does not exist (assert in the reference)
+        eng.strain_batch([capi.make_sim(3, "pe", 1, st, nss=10, most_recent=77)])
+    with pytest.raises(capi.EngineError):          # unknown force field (stmd_problem.h:462-467)
+        eng.strain_batch([capi.make_sim(3, "pe", 1, st, nss=10, most_recent=capi.QP_NONE, force_field="sw")])
+    eng.close()
