@@ -88,7 +88,7 @@ struct Topo {
   std::vector<double> init_x, init_v;
   // device copies
   DevBuf d_type, d_q, d_mass, d_lj, d_bond_at, d_bond_cf, d_angle_at, d_angle_cf, d_dih_at, d_dih_cf, d_imp_at, d_imp_cf,
-      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d;
+      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_aterm_start, d_aterm;
 };
 
 struct State {
@@ -320,6 +320,30 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
     if (dih_at[k] < 0 || dih_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad dihedral atom");
   for (size_t k = 0; k < imp_at.size(); k++)
     if (imp_at[k] < 0 || imp_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad improper atom");
+  // ---- per-atom term lists for the atomic-free bonded kernel (sorted by kind inside each atom) ----
+  std::vector<std::vector<int>> per_atom(n);
+  auto add_term = [&](int atom, int kind, int role, int idx) { per_atom[atom].push_back(kind | (role << 3) | (idx << 5)); };
+  for (int m = 0; m < s->nbonds; m++) {
+    const int kind = (m < t.nbonds_noshake) ? AT_BOND : AT_BOND_SHAKEN;
+    add_term(bond_at[2 * m], kind, 0, m);
+    add_term(bond_at[2 * m + 1], kind, 1, m);
+  }
+  for (int m = 0; m < s->nangles; m++)
+    for (int r = 0; r < 3; r++) add_term(angle_at[3 * m + r], AT_ANGLE, r, m);
+  for (int m = 0; m < s->ndihedrals; m++)
+    for (int r = 0; r < 4; r++) add_term(dih_at[4 * m + r], AT_DIHEDRAL, r, m);
+  for (int m = 0; m < s->nimpropers; m++)
+    for (int r = 0; r < 4; r++) add_term(imp_at[4 * m + r], AT_IMPROPER, r, m);
+  for (int m = 0; m < t.nspecial; m++) {
+    add_term(sp_at[2 * m], AT_SPECIAL, 0, m);
+    add_term(sp_at[2 * m + 1], AT_SPECIAL, 1, m);
+  }
+  std::vector<int> aterm_start(n + 1, 0), aterm;
+  for (int i = 0; i < n; i++) {
+    std::sort(per_atom[i].begin(), per_atom[i].end(), [](int a, int b) { return (a & 7) != (b & 7) ? (a & 7) < (b & 7) : a < b; });
+    aterm_start[i + 1] = aterm_start[i] + (int)per_atom[i].size();
+    aterm.insert(aterm.end(), per_atom[i].begin(), per_atom[i].end());
+  }
   std::memcpy(t.init_box, s->box, sizeof t.init_box);
   t.init_x.assign(s->x, s->x + 3 * (size_t)n);
   t.init_v.assign(s->v, s->v + 3 * (size_t)n);
@@ -343,6 +367,8 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   if ((rc = upload(e, t.d_clus_at, clus_at))) return rc;
   if ((rc = upload(e, t.d_clus_n, clus_n))) return rc;
   if ((rc = upload(e, t.d_clus_d, clus_d))) return rc;
+  if ((rc = upload(e, t.d_aterm_start, aterm_start))) return rc;
+  if ((rc = upload(e, t.d_aterm, aterm))) return rc;
   return SCEMA_MD_OK;
 }
 
@@ -644,6 +670,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.improper_at = T.d_imp_at.as<int>(); S.improper_cf = T.d_imp_cf.as<double>();
     S.special_at = T.d_sp_at.as<int>(); S.special_cf = T.d_sp_cf.as<double>();
     S.ex_start = T.d_ex_start.as<int>(); S.ex_list = T.d_ex_list.as<int>();
+    S.aterm_start = T.d_aterm_start.as<int>(); S.aterm = T.d_aterm.as<int>();
     S.clus_at = T.d_clus_at.as<int>(); S.clus_n = T.d_clus_n.as<int>(); S.clus_d = T.d_clus_d.as<double>();
     S.x = A.st->x.as<double>(); S.v = A.st->v.as<double>(); S.f = sl.f.as<double>();
     S.xq = sl.xq.as<double4>(); S.stype = sl.stype.as<int>(); S.perm = sl.perm.as<int>(); S.slot_tmp = sl.slot_tmp.as<int>();
@@ -673,7 +700,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   mdk_phase_init(st, D, ns);
   mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells);
   mdk_pair(st, D, ns, maxpad, ev, spec.ev_always, maxpoly);
-  mdk_bonded(st, D, ns, maxb, maxa, maxd, maxi, maxs);
+  mdk_bonded_atom(st, D, ns, maxatoms, spec.ev_always);
   mdk_ewald(st, D, ns, maxatoms, maxk, mmax);
   if (!spec.static_only) mdk_shake(st, D, ns, maxclus, 0.5);
   mdk_final_integrate(st, D, ns, maxatoms, 0);
@@ -705,7 +732,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       ev_used += 2;
       launch_bytes.push_back((double)na);
     }
-    mdk_bonded(st, D, na, maxb, maxa, maxd, maxi, maxs);
+    mdk_bonded_atom(st, D, na, maxatoms, spec.ev_always);
     mdk_ewald(st, D, na, maxatoms, maxk, mmax);
     mdk_shake(st, D, na, maxclus, 1.0);
     mdk_final_integrate(st, D, na, maxatoms, 1);

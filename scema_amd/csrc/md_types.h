@@ -26,6 +26,9 @@
 #define MD_EWALD_F 1.12837916709551257390
 #define MD_PI 3.14159265358979323846
 
+// per-atom term list entry: kind (3 bits) | role of the atom in the term (2 bits) | term index << 5
+enum { AT_BOND = 0, AT_BOND_SHAKEN = 1, AT_ANGLE = 2, AT_DIHEDRAL = 3, AT_IMPROPER = 4, AT_SPECIAL = 5 };
+
 enum { P_LJ = 0, P_COUL = 1, P_BOND = 2, P_ANGLE = 3, P_DIHEDRAL = 4, P_IMPROPER = 5, P_KSPACE = 6, P_SHAKE = 7 };
 
 // mutable per-simulation scalars, resident in HBM (one cache line group per simulation)
@@ -86,6 +89,7 @@ struct SimDev {
   const int *improper_at; const double *improper_cf;// 4 ints, (K,chi0)
   const int *special_at; const double *special_cf;  // 2 ints, (f_lj,f_coul)
   const int *ex_start, *ex_list;
+  const int *aterm_start, *aterm;  // per-atom lists of the bonded terms / special pairs the atom takes part in
   const int *clus_at, *clus_n; const double *clus_d;
   // state
   double *x, *v, *f;
