@@ -529,9 +529,12 @@ struct RunSpec {
   int static_only = 0;  // parity hook: forces of the potential only (no constraint forces)
 };
 
+// slots: every cell is padded to a multiple of MD_CLUSTER slots (i-clusters never straddle cells)
+static int padded_slots(int natoms, int ncells) { return (natoms + (MD_CLUSTER - 1) * ncells + 255) / 256 * 256; }
+
 int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncells, int nk) {
-  const int npad = (natoms + 255) / 256 * 256;
-  if (natoms > sl.cap_atoms) {
+  const int npad = padded_slots(natoms, ncells);
+  if (natoms > sl.cap_atoms || npad > sl.cap_pad) {
     HIPCHK(sl.f.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.wrapn.ensure(3 * (size_t)natoms * 4));
     HIPCHK(sl.xhold.ensure(3 * (size_t)natoms * 8));
@@ -547,9 +550,9 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     sl.cap_pad = npad;
     sl.cap_neigh = 0;
   }
-  if ((size_t)maxneigh * npad > (size_t)sl.cap_neigh * sl.cap_pad || sl.cap_neigh == 0) {
-    // + slack: k_pair prefetches entry rows unconditionally, up to 5 rows past the last atom's row
-    HIPCHK(sl.neigh.ensure((size_t)maxneigh * npad * 4 + 8192));
+  if (maxneigh > sl.cap_neigh || sl.cap_neigh == 0) {
+    // one row of maxneigh entries per cluster of MD_CLUSTER slots
+    HIPCHK(sl.neigh.ensure((size_t)maxneigh * (npad / MD_CLUSTER) * 4 + 8192));
     sl.cap_neigh = maxneigh;
   }
   if (ncells + 1 > sl.cap_cells) {
@@ -628,11 +631,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       S.seg_b2 = (P.cut_lj + m) * (P.cut_lj + m);
     }
     S.natoms = T.natoms;
-    S.npad = (T.natoms + 255) / 256 * 256;
+    S.npad = padded_slots(T.natoms, S.ncells);
     S.ntypes = T.ntypes;
     const double rho = T.natoms / std::min(b0.vol, b1.vol);
-    int maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.15 * e->neigh_grow) + 48;
-    maxneigh = (std::min(maxneigh, T.natoms) + 63) / 64 * 64;
+    // row capacity of one i-cluster: the union of 4 neighbour spheres whose centres are within a cell
+    // (about 15 % more than one sphere), plus fluctuation headroom; regrown on overflow
+    int maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.45 * e->neigh_grow) + 64;
+    maxneigh = (std::min(maxneigh, S.npad) + 63) / 64 * 64;
     Slot &sl = *e->slots[i];
     int rc = ensure_slot(e, sl, T.natoms, maxneigh, S.ncells, S.nk);
     if (rc) return rc;

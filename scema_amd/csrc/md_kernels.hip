@@ -271,9 +271,13 @@ __global__ __launch_bounds__(TPB) void k_cell_scan(const SimDev *sims) {
   __shared__ int s_base;
   if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
+  // every slot is a pad slot until k_cell_sort places an atom there
+  for (int s = threadIdx.x; s < S.npad; s += TPB) S.perm[s] = -1;
   for (int start = 0; start < S.ncells; start += TPB) {
     int idx = start + threadIdx.x;
-    int v = (idx < S.ncells) ? S.cell_count[idx] : 0;
+    // cells are padded to a multiple of MD_CLUSTER slots so that a cluster of MD_CLUSTER
+    // consecutive slots never straddles two cells (k_pair works on such clusters)
+    int v = (idx < S.ncells) ? (S.cell_count[idx] + MD_CLUSTER - 1) / MD_CLUSTER * MD_CLUSTER : 0;
     s_part[threadIdx.x] = v;
     __syncthreads();
     // Hillis-Steele inclusive scan
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(TPB) void k_cell_sort(const SimDev *sims) {
   if (!S.sc->rebuild) return;
   const int c = blockIdx.x * TPB + threadIdx.x;
   if (c >= S.ncells) return;
-  const int b = S.cell_start[c], e = S.cell_start[c + 1];
+  const int b = S.cell_start[c], e = b + S.cell_count[c];  // the rest of the cell's range stays pad (-1)
   for (int s = b; s < e; s++) {
     // rank of slot_tmp[s] among the members
     int a = S.slot_tmp[s], r = 0;
@@ -331,13 +335,13 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   const int s = blockIdx.x * TPB + threadIdx.x;
   if (s >= S.npad) return;
-  if (s >= S.natoms) {
-    if (S.sc->rebuild) { S.xq[s] = make_double4(0, 0, 0, 0); S.stype[s] = 0; }
+  const int a = S.perm[s];
+  if (a < 0) {  // pad slot: a record no real atom is ever within the list cutoff of
+    if (S.sc->rebuild) { S.xq[s] = make_double4(1.0e15, 1.0e15, 1.0e15, 0.0); S.stype[s] = 0; }
     return;
   }
   BoxD b;
   box_derive(S.sc->box, b);
-  const int a = S.perm[s];
   const int w0 = S.wrapn[3 * a], w1 = S.wrapn[3 * a + 1], w2 = S.wrapn[3 * a + 2];
   double4 r;
   r.x = S.x[3 * a] - (b.h[0] * w0 + b.h[5] * w1 + b.h[4] * w2);

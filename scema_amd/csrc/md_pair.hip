@@ -1,28 +1,33 @@
 // md_pair.hip -- neighbour-list build and the lj/cut/coul/long pair kernel (the roofline kernel).
 //
-// Work decomposition (round-1 measurements in DESIGN.md): ONE WAVE PER ATOM i, the 64 lanes span
-// i's neighbour row.  A thread-per-atom kernel with per-lane j gathers was L1/TA bound on gfx950
-// (183 L1 accesses per 64 pairs, nothing coalesces).  With lanes over neighbours:
-//   * neigh[i*maxneigh + k] : the row of atom i is contiguous -> a wave reads 256 B per instruction;
-//   * inside a row the entries keep slot (= cell) order, so the 32-byte j records a wave gathers
-//     fall into a few runs of consecutive slots -> a few cache lines per instruction, not 64;
-//   * i's data is wave-uniform (scalar registers), the force on i is one wave reduction per atom;
-//   * each row is stored in three segments by build-time distance: A (< cut_coul + m) needs
-//     coulomb + LJ, B (< cut_lj + m) LJ only, C the skin.  Every lane still tests r^2 against the
-//     cutoffs (results never depend on the segments); the segments only make the three regimes
-//     wave-uniform so whole waves skip the expensive branches.
-//   entry = image code (5 bits) | j type (5 bits) | j slot (22 bits)
+// Work decomposition (measurements of every step are in DESIGN.md §5):
+//   * i-CLUSTERS: 4 consecutive slots of one cell (cells are padded to multiples of 4 slots, pad
+//     slots hold far-away dummy records).  The four atoms are < a cell diagonal apart, so their
+//     neighbour sets overlap ~87 %: the cluster owns ONE row = the union of its atoms' neighbours,
+//     each entry carrying a 4-bit mask of which i atoms list that j.
+//   * ONE WAVE PER CLUSTER, the 64 lanes span the row: neigh[cl*maxrow + k] is contiguous (256 B per
+//     wave instruction); a lane gathers its j record once and evaluates it against up to 4 i atoms
+//     held in scalar registers -> 4x fewer row bytes from HBM and 4x fewer record gathers through
+//     L1 than one row per atom, and four independent pair evaluations per lane for ILP.
+//   * rows keep slot (= cell) order inside three segments by build-time distance (A: may need
+//     coulomb, B: LJ only, C: skin), so gathers fall into runs of consecutive slots and the three
+//     regimes are wave-uniform branches.  Every lane still tests r^2 against the cutoffs: results
+//     never depend on the segments or on the cluster grouping.
+//   * forces: per-lane partial sums for the 4 atoms, one wave reduction per cluster, written once
+//     (no atomics); virial: wave -> block -> one atomic per block and component.
+//   entry = image code [31:27] | i-mask [26:23] | j slot [22:0]
 //
 // Reference semantics: pair_style lj/cut/coul/long 12.0 9.0 (in.set.lammps:40), neighbor 2.0 bin
-// (in.set.lammps:27); special_bonds 0 0 1 pairs are excluded here and handled in k_term<T_SPECIAL>.
+// (in.set.lammps:27); special_bonds 0 0 1 pairs are excluded here and handled in k_bonded_atom.
 #include <hip/hip_runtime.h>
 
 #include "md_device.h"
 #include "md_kernels.h"
 
-#define WPB 4               // waves per block
-#define AW 4                // atoms per wave (k_pair sweeps them row-interleaved)
-#define APB (WPB * AW)      // atoms per block
+#define WPB 4    // waves per block
+#define CPW 2    // clusters per wave (sequential)
+#define CPB (WPB * CPW)
+#define NI MD_CLUSTER
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 template <class T>
@@ -48,23 +53,25 @@ __device__ __forceinline__ bool xcd_map(int ntiles, int nsims, int &sim, int &ti
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int popc_below(unsigned long long m) {
-  // number of set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
 // ------------------------------------------------------------------------------------------
-// k_neigh_build : wave per atom; lanes scan runs of candidate slots (coalesced), ballots compact
-// the accepted ones into the three row segments, in slot order
+// k_neigh_build : wave per cluster; lanes scan runs of candidate slots (coalesced), test them
+// against the cluster's atoms, ballots compact the accepted ones into the three row segments
 // ------------------------------------------------------------------------------------------
+struct ClusterI {
+  double x[NI], y[NI], z[NI];
+  int atom[NI];   // real atom index or -1 (pad)
+};
+
 template <int PASS>
-__device__ __forceinline__ void scan_atom(const SimDev &S, const BoxD &b, int i, double xi0, double xi1, double xi2, int ai,
-                                          int ci, int &nA, int &nB, int &nC, int offB, int offC) {
+__device__ __forceinline__ void scan_cluster(const SimDev &S, const BoxD &b, int s0slot, const ClusterI &ci, int cell, int &nA, int &nB,
+                                             int &nC, int offB, int offC, unsigned long long &npairs) {
   const int lane = lane_id();
-  const int c0 = ci % S.nc[0], c1 = (ci / S.nc[0]) % S.nc[1], c2 = ci / (S.nc[0] * S.nc[1]);
-  const int exb = S.ex_start[ai], exe = S.ex_start[ai + 1];
+  const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);
-  const GLOBAL_AS int *stype = as_global(S.stype);
-  GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)i * S.maxneigh;
+  GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)(s0slot / NI) * S.maxneigh;
   const double ra2 = S.seg_a2, rb2 = S.seg_b2;
   for (int o2 = -S.mst[2]; o2 <= S.mst[2]; o2++) {
     int a2 = c2 + o2, s2 = 0;
@@ -82,7 +89,6 @@ __device__ __forceinline__ void scan_atom(const SimDev &S, const BoxD &b, int i,
         int a0 = c0 + o0, s0 = 0;
         while (a0 < 0) { a0 += S.nc[0]; s0 -= 1; }
         while (a0 >= S.nc[0]) { a0 -= S.nc[0]; s0 += 1; }
-        // extend the run while the cells stay consecutive under the same image
         int len = 1;
         while (o0 + len <= S.mst[0] && a0 + len < S.nc[0]) len++;
         o0 += len;
@@ -90,26 +96,36 @@ __device__ __forceinline__ void scan_atom(const SimDev &S, const BoxD &b, int i,
         const double sx = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
         const double sy = b.h[1] * s1 + b.h[3] * s2;
         const double sz = b.h[2] * s2;
+        const bool home = (s0 == 0 && s1 == 0 && s2 == 0);
         const int code = ((s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1)) << MD_CODE_SHIFT;
         const int cj = (a2 * S.nc[1] + a1) * S.nc[0] + a0;
         const int jb = S.cell_start[cj], je = S.cell_start[cj + len];
         for (int base = jb; base < je; base += 64) {
           const int j = base + lane;
-          bool acc = false;
-          double r2 = 0.0;
+          int mask = 0;
+          double rmin = 1.0e300;
           if (j < je) {
-            const double dx = xi0 - xq[4 * (size_t)j] - sx, dy = xi1 - xq[4 * (size_t)j + 1] - sy, dz = xi2 - xq[4 * (size_t)j + 2] - sz;
-            r2 = dx * dx + dy * dy + dz * dz;
-            acc = r2 < S.rlist2 && !(j == i && s0 == 0 && s1 == 0 && s2 == 0);
-            if (acc && r2 < S.excl_cut2) {
-              const int aj = S.perm[j];
-              for (int e = exb; e < exe; e++) acc = acc && (S.ex_list[e] != aj);
+            const double xj = xq[4 * (size_t)j] + sx, yj = xq[4 * (size_t)j + 1] + sy, zj = xq[4 * (size_t)j + 2] + sz;
+            int aj = -2;
+#pragma unroll
+            for (int a = 0; a < NI; a++) {
+              const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
+              const double r2 = dx * dx + dy * dy + dz * dz;
+              bool acc = ci.atom[a] >= 0 && r2 < S.rlist2 && !(home && j == s0slot + a);
+              if (acc && r2 < S.excl_cut2) {
+                if (aj == -2) aj = S.perm[j];
+                for (int e = S.ex_start[ci.atom[a]]; e < S.ex_start[ci.atom[a] + 1]; e++) acc = acc && (S.ex_list[e] != aj);
+              }
+              if (acc) {
+                mask |= 1 << a;
+                rmin = fmin(rmin, r2);
+              }
             }
           }
-          const bool isA = acc && r2 < ra2, isB = acc && !isA && r2 < rb2, isC = acc && !isA && !isB;
+          const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB;
           const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC);
-          if (PASS == 1 && acc) {
-            const int entry = code | (stype[j] << MD_TYPE_SHIFT) | j;
+          if (PASS == 1 && mask) {
+            const int entry = code | (mask << MD_MASK_SHIFT) | j;
             int pos;
             if (isA) pos = nA + popc_below(mA);
             else if (isB) pos = offB + nB + popc_below(mB);
@@ -117,6 +133,7 @@ __device__ __forceinline__ void scan_atom(const SimDev &S, const BoxD &b, int i,
             if (pos < S.maxneigh) row[pos] = entry;
           }
           nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC);
+          if (PASS == 0) npairs += __popc(mask);
         }
       }
     }
@@ -132,27 +149,38 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   BoxD b;
   box_derive(sc.box, b);
-  unsigned long long entries = 0;
+  unsigned long long npairs = 0;
   int nmax = 0;
-  for (int a = 0; a < AW; a++) {
-    const int i = tile * APB + wave * AW + a;  // wave-uniform
-    if (i >= S.natoms) break;
-    const double xi0 = S.xq[i].x, xi1 = S.xq[i].y, xi2 = S.xq[i].z;
-    const int ai = S.perm[i];
-    const int ci = S.cell_of[ai];
+  for (int c = 0; c < CPW; c++) {
+    const int cl = tile * CPB + wave * CPW + c;  // wave-uniform
+    const int s0 = cl * NI;
+    if (s0 >= S.npad) break;
+    ClusterI ci;
+#pragma unroll
+    for (int a = 0; a < NI; a++) {
+      ci.atom[a] = S.perm[s0 + a];
+      ci.x[a] = S.xq[s0 + a].x; ci.y[a] = S.xq[s0 + a].y; ci.z[a] = S.xq[s0 + a].z;
+    }
+    if (ci.atom[0] < 0) {  // empty cluster (pad only)
+      if (lane_id() == 0) S.numneigh[cl] = 0;
+      continue;
+    }
+    const int cell = S.cell_of[ci.atom[0]];
     int nA = 0, nB = 0, nC = 0;
-    scan_atom<0>(S, b, i, xi0, xi1, xi2, ai, ci, nA, nB, nC, 0, 0);
+    scan_cluster<0>(S, b, s0, ci, cell, nA, nB, nC, 0, 0, npairs);
     const int n = nA + nB + nC;
     int pA = 0, pB = 0, pC = 0;
-    scan_atom<1>(S, b, i, xi0, xi1, xi2, ai, ci, pA, pB, pC, nA, nA + nB);
-    if (lane_id() == 0) S.numneigh[i] = (n < S.maxneigh) ? n : S.maxneigh;
-    entries += n;
+    unsigned long long dummy = 0;
+    scan_cluster<1>(S, b, s0, ci, cell, pA, pB, pC, nA, nA + nB, dummy);
+    if (lane_id() == 0) S.numneigh[cl] = (n < S.maxneigh) ? n : S.maxneigh;
     nmax = max(nmax, n);
   }
+  // npairs was accumulated per lane
+  double cnt = wave_sum((double)npairs);
   if (lane_id() == 0) {
     if (nmax > S.maxneigh) atomicOr(&sc.overflow, 1);
     atomicMax(&sc.maxneigh_seen, nmax);
-    atomicAdd(&sc.nentries, entries);
+    atomicAdd(&sc.nentries, (unsigned long long)cnt);
   }
 }
 
@@ -187,51 +215,57 @@ __global__ __launch_bounds__(WPB * 64) void k_pair(const SimDev *__restrict__ si
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);
+  const GLOBAL_AS int *stype = as_global(S.stype);
   const double g = S.g_ewald, g2u = g * g * S.coul_uscale;
   const double cutc2 = S.cut_coul2, cutl2 = S.cut_lj2;
   const double cutmax2 = fmax(cutc2, cutl2);
-  const int maxneigh = S.maxneigh;
+  const int maxrow = S.maxneigh;
   double vl[6] = {0, 0, 0, 0, 0, 0}, vc[6] = {0, 0, 0, 0, 0, 0};
   double elj = 0, ecoul = 0;
-  // ---- row-interleaved sweep over the PA atoms of this wave ----
-  // Consecutive slots are spatial neighbours, so row r of atom i and row r of atom i+1 hold almost
-  // the same j slots.  One atom's row sweep touches 1490 x 32 B = 47 KB, more than the 32 KB L1, so
-  // sweeping atom after atom re-fetched everything from L2 (31 % L1 misses, TCP stalled 62 % of the
-  // time on pending misses).  Interleaving the atoms row by row lets the lines fetched for one
-  // atom's row serve the other PA-1 atoms, and puts PA independent rows in flight per wave.
-  constexpr int PA = AW;
-  const int i0 = tile * APB + wave * AW;  // wave-uniform
-  double xi0[PA], xi1[PA], xi2[PA], qi[PA], fx[PA], fy[PA], fz[PA];
-  int ti[PA], nn[PA];
-  const GLOBAL_AS int *row[PA];
-  int nmax = 0;
+  for (int c = 0; c < CPW; c++) {
+    const int cl = tile * CPB + wave * CPW + c;  // wave-uniform
+    const int s0 = cl * NI;
+    if (s0 >= S.npad) break;
+    const int nn = S.numneigh[cl];
+    if (nn == 0) continue;
+    double xi[NI], yi[NI], zi[NI], qi[NI], fx[NI], fy[NI], fz[NI];
+    int ti[NI];
 #pragma unroll
-  for (int a = 0; a < PA; a++) {
-    const int i = (i0 + a < S.natoms) ? i0 + a : S.natoms - 1;
-    xi0[a] = S.xq[i].x; xi1[a] = S.xq[i].y; xi2[a] = S.xq[i].z;
-    qi[a] = MD_QQRD2E * S.xq[i].w;
-    ti[a] = S.stype[i] * nt;
-    nn[a] = (i0 + a < S.natoms) ? S.numneigh[i] : 0;
-    row[a] = as_global(S.neigh) + (size_t)i * maxneigh;
-    fx[a] = fy[a] = fz[a] = 0.0;
-    nmax = max(nmax, nn[a]);
-  }
-  for (int k0 = 0; k0 < nmax; k0 += 64) {
-    int e[PA];
-    double xj[PA][4];
-#pragma unroll
-    for (int a = 0; a < PA; a++) e[a] = (k0 + lane < nn[a]) ? row[a][k0 + lane] : -1;
-#pragma unroll
-    for (int a = 0; a < PA; a++) {
-      const size_t j4 = 4 * (size_t)((e[a] == -1) ? 0 : (e[a] & MD_JMASK));
-      xj[a][0] = xq[j4]; xj[a][1] = xq[j4 + 1]; xj[a][2] = xq[j4 + 2]; xj[a][3] = xq[j4 + 3];
+    for (int a = 0; a < NI; a++) {
+      xi[a] = S.xq[s0 + a].x; yi[a] = S.xq[s0 + a].y; zi[a] = S.xq[s0 + a].z;
+      qi[a] = MD_QQRD2E * S.xq[s0 + a].w;
+      ti[a] = S.stype[s0 + a] * nt;
+      fx[a] = fy[a] = fz[a] = 0.0;
     }
+    const GLOBAL_AS int *row = as_global(S.neigh) + (size_t)cl * maxrow;
+    // one row ahead: entry + record + type of row r+1 are in flight while row r is evaluated
+    int e_n = (lane < nn) ? row[lane] : 0;
+    double xn0, xn1, xn2, xn3;
+    int tn;
+    {
+      const size_t j = (size_t)(e_n & MD_JMASK);
+      xn0 = xq[4 * j]; xn1 = xq[4 * j + 1]; xn2 = xq[4 * j + 2]; xn3 = xq[4 * j + 3];
+      tn = stype[j];
+    }
+    for (int k0 = 0; k0 < nn; k0 += 64) {
+      const int e = e_n;
+      const double xj = xn0, yj = xn1, zj = xn2, qj = xn3;
+      const int tj = tn;
+      {
+        const int kn = k0 + 64 + lane;
+        e_n = (kn < nn) ? row[kn] : 0;
+        const size_t j = (size_t)(e_n & MD_JMASK);
+        xn0 = xq[4 * j]; xn1 = xq[4 * j + 1]; xn2 = xq[4 * j + 2]; xn3 = xq[4 * j + 3];
+        tn = stype[j];
+      }
+      const int mask = (e >> MD_MASK_SHIFT) & 0xF;  // 0 for the padding of the last row
+      if (mask == 0) continue;
+      const int cs = 4 * (((unsigned)e) >> MD_CODE_SHIFT);
+      const double xs = xj + s_shift[cs], ys = yj + s_shift[cs + 1], zs = zj + s_shift[cs + 2];
 #pragma unroll
-    for (int a = 0; a < PA; a++) {
-      const int ee = e[a];
-      if (ee != -1) {
-        const int c = 4 * (((unsigned)ee) >> MD_CODE_SHIFT);
-        const double dx = xi0[a] - xj[a][0] - s_shift[c], dy = xi1[a] - xj[a][1] - s_shift[c + 1], dz = xi2[a] - xj[a][2] - s_shift[c + 2];
+      for (int a = 0; a < NI; a++) {
+        if (!(mask & (1 << a))) continue;
+        const double dx = xi[a] - xs, dy = yi[a] - ys, dz = zi[a] - zs;
         const double rsq = dx * dx + dy * dy + dz * dz;
         if (rsq < cutmax2) {
           const double rinv = rsqrt(rsq);
@@ -244,12 +278,12 @@ __global__ __launch_bounds__(WPB * 64) void k_pair(const SimDev *__restrict__ si
             double p = cp[NP - 1];
 #pragma unroll
             for (int m = NP - 2; m >= 0; m--) p = fma(p, t, cp[m]);
-            const double pref = qi[a] * xj[a][3] * rinv;
+            const double pref = qi[a] * qj * rinv;
             fc = pref * fma(-x, p, 1.0) * r2inv;
             if (ENG) ecoul += pref * erfc(x);
           }
           if (rsq < cutl2) {
-            const int tt = ti[a] + ((ee >> MD_TYPE_SHIFT) & MD_TYPE_MASK);
+            const int tt = ti[a] + tj;
             const double r6inv = r2inv * r2inv * r2inv;
             flj = r6inv * (s_lj[tt] * r6inv - s_lj[nt2 + tt]) * r2inv;
             if (ENG) elj += r6inv * (s_lj[2 * nt2 + tt] * r6inv - s_lj[3 * nt2 + tt]);
@@ -267,13 +301,13 @@ __global__ __launch_bounds__(WPB * 64) void k_pair(const SimDev *__restrict__ si
         }
       }
     }
-  }
 #pragma unroll
-  for (int a = 0; a < PA; a++) {
-    const double sx = wave_sum(fx[a]), sy = wave_sum(fy[a]), sz = wave_sum(fz[a]);
-    if (lane == 0 && i0 + a < S.natoms) {
-      const int at = S.perm[i0 + a];
-      S.f[3 * at] = sx; S.f[3 * at + 1] = sy; S.f[3 * at + 2] = sz;
+    for (int a = 0; a < NI; a++) {
+      const double sx = wave_sum(fx[a]), sy = wave_sum(fy[a]), sz = wave_sum(fz[a]);
+      if (lane == 0) {
+        const int at = S.perm[s0 + a];
+        if (at >= 0) { S.f[3 * at] = sx; S.f[3 * at + 1] = sy; S.f[3 * at + 2] = sz; }
+      }
     }
   }
   if (VIR) {
@@ -294,8 +328,8 @@ __global__ __launch_bounds__(WPB * 64) void k_pair(const SimDev *__restrict__ si
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(cdiv(ns, 8) * 8 * ntiles), 1, 1); }
 
-void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
-  const int ntiles = cdiv(maxatoms, APB);
+void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad) {
+  const int ntiles = cdiv(maxpad / NI, CPB);
   hipLaunchKernelGGL(k_neigh_build, grid_xcd(ntiles, ns), dim3(WPB * 64), 0, st, d, ntiles, ns);
 }
 
@@ -307,8 +341,8 @@ static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int
   else hipLaunchKernelGGL((k_pair<false, false, NP>), g, dim3(WPB * 64), 0, st, d, ntiles, ns);
 }
 
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxatoms, int vir, int eng, int npoly) {
-  const int ntiles = cdiv(maxatoms, APB);
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int vir, int eng, int npoly) {
+  const int ntiles = cdiv(maxpad / NI, CPB);
   if (npoly <= 16) launch_pair<16>(st, d, ns, ntiles, vir, eng);
   else if (npoly <= 20) launch_pair<20>(st, d, ns, ntiles, vir, eng);
   else if (npoly <= 24) launch_pair<24>(st, d, ns, ntiles, vir, eng);

@@ -11,9 +11,9 @@
 #define MD_MAXTYPES 16
 #define MD_MAXPOLY 48
 #define MD_NBINS 28
-#define MD_JMASK 0x003FFFFF /* neighbour entry: [21:0] slot of j, [26:22] type of j, [31:27] image code */
-#define MD_TYPE_SHIFT 22
-#define MD_TYPE_MASK 0x1F
+#define MD_CLUSTER 4          /* atoms per i-cluster (consecutive slots inside one cell) */
+#define MD_JMASK 0x007FFFFF   /* cluster-row entry: [22:0] slot of j, [26:23] which of the 4 i atoms list j, [31:27] image code */
+#define MD_MASK_SHIFT 23
 #define MD_CODE_SHIFT 27
 
 
