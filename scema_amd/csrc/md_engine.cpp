@@ -427,7 +427,7 @@ void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, Ewa
 
 // Real-space Ewald factor erfc(x) + 2x/sqrt(pi) exp(-x^2) = 1 - x H(u), u = x^2.  H is entire in u:
 // H(u) = 2/sqrt(pi) sum_{n>=1} (-1)^(n+1) u^n/n! 2n/(2n+1).  Fit H on [0, (g rc)^2] by Chebyshev
-// interpolation (degree grown until the tail is below 1e-17 relative) and hand the kernel monomial
+// interpolation (degree grown until the tail is below 2e-16 relative) and hand the kernel monomial
 // coefficients in t = 2u/umax - 1.  All in long double; the fit is checked against H on a fine grid.
 static long double coul_H(long double u) {
   const long double c = 2.0L / sqrtl(acosl(-1.0L));
@@ -467,7 +467,7 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
     }
     long double cmax = 0.0L;
     for (int k = 0; k < N; k++) cmax = std::max(cmax, fabsl(c[k]));
-    if (fabsl(c[N - 1]) + fabsl(c[N - 2]) < 1e-17L * cmax) break;
+    if (fabsl(c[N - 1]) + fabsl(c[N - 2]) < 2e-16L * cmax) break;
   }
   if (N > MD_MAXPOLY) N = MD_MAXPOLY;
   // Chebyshev -> monomial in t

@@ -52,6 +52,15 @@ __device__ __forceinline__ bool xcd_map(int ntiles, int nsims, int &sim, int &ti
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// 1/sqrt(x): hardware estimate (v_rsq_f64, ~2^-26 relative) + one third-order correction
+// y (1 + e/2 + 3 e^2/8), e = 1 - x y^2; the remaining error is O(e^3) < 1e-22 -> correctly
+// rounded to within 1 ulp, at 6 instructions instead of the ~10 of the library routine
+__device__ __forceinline__ double rsqrt_f64(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y, e * fma(0.375, e, 0.5), y);
+}
 __device__ __forceinline__ int popc_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
 // ------------------------------------------------------------------------------------------
 // NP = number of polynomial coefficients kept in scalar registers (>= fitted degree+1, 0-padded)
 template <bool VIR, bool ENG, int NP>
-__global__ __launch_bounds__(WPB * 64) void k_pair(const SimDev *__restrict__ sims, int ntiles, int nsims) {
+__global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__ sims, int ntiles, int nsims) {
   int sim, tile;
   if (!xcd_map(ntiles, nsims, sim, tile)) return;
   const SimDev &S = sims[sim];
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pair(const SimDev *__restrict__ si
         const double dx = xi[a] - xs, dy = yi[a] - ys, dz = zi[a] - zs;
         const double rsq = dx * dx + dy * dy + dz * dz;
         if (rsq < cutmax2) {
-          const double rinv = rsqrt(rsq);
+          const double rinv = rsqrt_f64(rsq);
           const double r2inv = rinv * rinv;
           double flj = 0.0, fc = 0.0;
           if (rsq < cutc2) {
@@ -290,7 +299,14 @@ __global__ __launch_bounds__(WPB * 64) void k_pair(const SimDev *__restrict__ si
           }
           const double fp = flj + fc;
           fx[a] = fma(dx, fp, fx[a]); fy[a] = fma(dy, fp, fy[a]); fz[a] = fma(dz, fp, fz[a]);
-          if (VIR) {
+          if (VIR && !ENG) {
+            // production: one lumped pair virial (the pressure sums all parts anyway)
+            const double xl = dx * fp, yl = dy * fp, zl = dz * fp;
+            vl[0] = fma(dx, xl, vl[0]); vl[1] = fma(dy, yl, vl[1]); vl[2] = fma(dz, zl, vl[2]);
+            vl[3] = fma(dx, yl, vl[3]); vl[4] = fma(dx, zl, vl[4]); vl[5] = fma(dy, zl, vl[5]);
+          }
+          if (VIR && ENG) {
+            // parity hook: LJ and coulomb parts separately
             const double xl = dx * flj, yl = dy * flj, zl = dz * flj;
             vl[0] = fma(dx, xl, vl[0]); vl[1] = fma(dy, yl, vl[1]); vl[2] = fma(dz, zl, vl[2]);
             vl[3] = fma(dx, yl, vl[3]); vl[4] = fma(dx, zl, vl[4]); vl[5] = fma(dy, zl, vl[5]);
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(WPB * 64) void k_pair(const SimDev *__restrict__ si
     // full list: every pair is visited from both ends
     for (int k = 0; k < 6; k++) { vl[k] *= 0.5; vc[k] *= 0.5; }
     block_atomic_add<6>(vl, sc.vir + P_LJ * 6, s_red);
-    block_atomic_add<6>(vc, sc.vir + P_COUL * 6, s_red);
+    if (ENG) block_atomic_add<6>(vc, sc.vir + P_COUL * 6, s_red);
   }
   if (ENG) {
     double e1[1];
@@ -343,7 +359,9 @@ static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int
 
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int vir, int eng, int npoly) {
   const int ntiles = cdiv(maxpad / NI, CPB);
-  if (npoly <= 16) launch_pair<16>(st, d, ns, ntiles, vir, eng);
+  if (npoly <= 12) launch_pair<12>(st, d, ns, ntiles, vir, eng);
+  else if (npoly <= 14) launch_pair<14>(st, d, ns, ntiles, vir, eng);
+  else if (npoly <= 16) launch_pair<16>(st, d, ns, ntiles, vir, eng);
   else if (npoly <= 20) launch_pair<20>(st, d, ns, ntiles, vir, eng);
   else if (npoly <= 24) launch_pair<24>(st, d, ns, ntiles, vir, eng);
   else if (npoly <= 32) launch_pair<32>(st, d, ns, ntiles, vir, eng);
