@@ -33,7 +33,10 @@ __global__ __launch_bounds__(TPB) void k_bonded_atom(const SimDev *__restrict__ 
   const SimDev &S = sims[blockIdx.y];
   SimScalars &sc = *S.sc;
   __shared__ double s_red[8 * (TPB / 64)];
-  const int i = blockIdx.x * TPB + threadIdx.x;
+  // atoms are visited in the order aterm_order: sorted by their term-count signature, so the lanes of
+  // a wave walk lists of the same shape (all-carbon waves, all-hydrogen waves) instead of idling
+  const int tid = blockIdx.x * TPB + threadIdx.x;
+  const int i = (tid < S.natoms) ? S.aterm_order[tid] : S.natoms;
   double ftot[3] = {0, 0, 0};
   double vsum[6] = {0, 0, 0, 0, 0, 0};
   if (i < S.natoms) {

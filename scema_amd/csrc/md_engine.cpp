@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <memory>
 #include <string>
@@ -88,7 +89,7 @@ struct Topo {
   std::vector<double> init_x, init_v;
   // device copies
   DevBuf d_type, d_q, d_mass, d_lj, d_bond_at, d_bond_cf, d_angle_at, d_angle_cf, d_dih_at, d_dih_cf, d_imp_at, d_imp_cf,
-      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_aterm_start, d_aterm;
+      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_aterm_start, d_aterm, d_aterm_order;
 };
 
 struct State {
@@ -369,6 +370,22 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   if ((rc = upload(e, t.d_clus_d, clus_d))) return rc;
   if ((rc = upload(e, t.d_aterm_start, aterm_start))) return rc;
   if ((rc = upload(e, t.d_aterm, aterm))) return rc;
+  {
+    // order atoms by (number of terms, kinds) so that a wave's 64 atoms have lists of the same shape
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    auto sig = [&](int a) {
+      long long sgn = 0;
+      int cnt[8] = {0};
+      for (int t2 : per_atom[a]) cnt[t2 & 7]++;
+      for (int k = 7; k >= 0; k--) sgn = sgn * 64 + std::min(cnt[k], 63);
+      return sgn;
+    };
+    std::vector<long long> sigs(n);
+    for (int i = 0; i < n; i++) sigs[i] = sig(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sigs[a] != sigs[b] ? sigs[a] > sigs[b] : a < b; });
+    if ((rc = upload(e, t.d_aterm_order, order))) return rc;
+  }
   return SCEMA_MD_OK;
 }
 
@@ -515,6 +532,12 @@ void deform_box(const double *box0, const double *rates, double t, double *out) 
   out[8] = box0[8] + rates[5] * (box0[5] - box0[2]) * t;
 }
 
+double wall_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
 double round_trip(const char *fmt, double v) {
   char buf[512];
   snprintf(buf, sizeof buf, fmt, v);
@@ -635,8 +658,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.ntypes = T.ntypes;
     const double rho = T.natoms / std::min(b0.vol, b1.vol);
     // row capacity of one i-cluster: the union of 4 neighbour spheres whose centres are within a cell
-    // (about 15 % more than one sphere), plus fluctuation headroom; regrown on overflow
-    int maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.45 * e->neigh_grow) + 64;
+    // (measured on PE-10k: mean ~1.4x, max 1.59x one sphere), plus headroom; regrown on overflow
+    int maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 2.2 * e->neigh_grow) + 128;
     maxneigh = (std::min(maxneigh, S.npad) + 63) / 64 * 64;
     Slot &sl = *e->slots[i];
     int rc = ensure_slot(e, sl, T.natoms, maxneigh, S.ncells, S.nk);
@@ -675,7 +698,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.improper_at = T.d_imp_at.as<int>(); S.improper_cf = T.d_imp_cf.as<double>();
     S.special_at = T.d_sp_at.as<int>(); S.special_cf = T.d_sp_cf.as<double>();
     S.ex_start = T.d_ex_start.as<int>(); S.ex_list = T.d_ex_list.as<int>();
-    S.aterm_start = T.d_aterm_start.as<int>(); S.aterm = T.d_aterm.as<int>();
+    S.aterm_start = T.d_aterm_start.as<int>(); S.aterm = T.d_aterm.as<int>(); S.aterm_order = T.d_aterm_order.as<int>();
     S.clus_at = T.d_clus_at.as<int>(); S.clus_n = T.d_clus_n.as<int>(); S.clus_d = T.d_clus_d.as<double>();
     S.x = A.st->x.as<double>(); S.v = A.st->v.as<double>(); S.f = sl.f.as<double>();
     S.xq = sl.xq.as<double4>(); S.stype = sl.stype.as<int>(); S.perm = sl.perm.as<int>(); S.slot_tmp = sl.slot_tmp.as<int>();
@@ -892,7 +915,9 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk) {
     RunSpec A;
     A.deform = 1;
     for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nts;
+    const double t_a0 = wall_s();
     rc = run_phase(e, chunk, A);
+    const double t_a1 = wall_s();
     if (rc == SCEMA_MD_OK) {
       rc = reupload_scalars(e, ns);
       if (rc) return rc;
@@ -900,6 +925,7 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk) {
       B.sample = 1;
       for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nss;
       rc = run_phase(e, chunk, B);
+      if (getenv("SCEMA_MD_TIMING")) fprintf(stderr, "[scema_md] chunk of %d: phase A %.1f ms, phase B %.1f ms (attempt %d)\n", ns, 1e3 * (t_a1 - t_a0), 1e3 * (wall_s() - t_a1), attempt);
     }
     if (rc == SCEMA_MD_OK) {
       for (int i = 0; i < ns; i++) {

@@ -792,13 +792,23 @@ __global__ __launch_bounds__(TPB) void k_ewald_post(const SimDev *sims) {
   block_atomic_add<1>(e, sc.eng + P_KSPACE, s_red);
 }
 
-// F_i = 2 q_i sum_k ug k (sin_i Sr - cos_i Si): one thread per atom, own phase tables in LDS
+// F_i = 2 q_i sum_k ug k (sin_i Sr - cos_i Si): one thread per atom, own phase tables in LDS;
+// the per-k data (indices, ug*S(k), k vector) is staged through LDS in chunks and read as
+// broadcasts, instead of nine wave-uniform global loads per (atom, k)
 #define EWF_TPB 128
+#define EWF_KC 64
+struct __attribute__((aligned(16))) EwK {
+  double pr, pi;   // ug * Re S, ug * Im S
+  double kx, ky;
+  double kz;
+  int n1, n23;     // n1 ; (n2 + 64) | (n3 + 64) << 8
+};
 __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int EW_MAXM) {
   const SimDev &S = sims[blockIdx.y];
   if (S.nk == 0) return;
   if ((int)(blockIdx.x * EWF_TPB) >= S.natoms) return;
   double2 *s_tab = s_dyn;  // [3][EW_MAXM][thread]
+  __shared__ EwK s_k[EWF_KC];
   const int a = blockIdx.x * EWF_TPB + threadIdx.x;
   const bool act = a < S.natoms;
   const int M[3] = {S.kmaxd[0] + 1, S.kmaxd[1] + 1, S.kmaxd[2] + 1};
@@ -819,24 +829,42 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
     }
   }
   double fx = 0, fy = 0, fz = 0;
-  if (act) {
-    for (int k = 0; k < S.nk; k++) {
-      const int n1 = S.kn[3 * k], n2 = S.kn[3 * k + 1], n3 = S.kn[3 * k + 2];
-      const double2 e1 = s_tab[(n1)*EWF_TPB + threadIdx.x];
-      double2 e2 = s_tab[(EW_MAXM + abs(n2)) * EWF_TPB + threadIdx.x];
-      double2 e3 = s_tab[(2 * EW_MAXM + abs(n3)) * EWF_TPB + threadIdx.x];
-      if (n2 < 0) e2.y = -e2.y;
-      if (n3 < 0) e3.y = -e3.y;
-      const double c12 = e1.x * e2.x - e1.y * e2.y, s12 = e1.y * e2.x + e1.x * e2.y;
-      const double cc = c12 * e3.x - s12 * e3.y, ss = s12 * e3.x + c12 * e3.y;
-      const double Sr = S.sfac[2 * k], Si = S.sfac[2 * k + 1];
-      const double pf = S.kvec[4 * k + 3] * (ss * Sr - cc * Si);
-      fx += pf * S.kvec[4 * k]; fy += pf * S.kvec[4 * k + 1]; fz += pf * S.kvec[4 * k + 2];
+  for (int kb = 0; kb < S.nk; kb += EWF_KC) {
+    __syncthreads();
+    if (threadIdx.x < EWF_KC && kb + threadIdx.x < S.nk) {
+      const int k = kb + threadIdx.x;
+      EwK e;
+      const double ug = S.kvec[4 * k + 3];
+      e.pr = ug * S.sfac[2 * k]; e.pi = ug * S.sfac[2 * k + 1];
+      e.kx = S.kvec[4 * k]; e.ky = S.kvec[4 * k + 1]; e.kz = S.kvec[4 * k + 2];
+      e.n1 = S.kn[3 * k];
+      e.n23 = (S.kn[3 * k + 1] + 64) | ((S.kn[3 * k + 2] + 64) << 8);
+      s_k[threadIdx.x] = e;
     }
+    __syncthreads();
+    if (act) {
+      const int kc = min(EWF_KC, S.nk - kb);
+      for (int kk = 0; kk < kc; kk++) {
+        const EwK e = s_k[kk];
+        const int n2 = (e.n23 & 0xFF) - 64, n3 = ((e.n23 >> 8) & 0xFF) - 64;
+        const double2 e1 = s_tab[(e.n1) * EWF_TPB + threadIdx.x];
+        double2 e2 = s_tab[(EW_MAXM + abs(n2)) * EWF_TPB + threadIdx.x];
+        double2 e3 = s_tab[(2 * EW_MAXM + abs(n3)) * EWF_TPB + threadIdx.x];
+        if (n2 < 0) e2.y = -e2.y;
+        if (n3 < 0) e3.y = -e3.y;
+        const double c12 = e1.x * e2.x - e1.y * e2.y, s12 = e1.y * e2.x + e1.x * e2.y;
+        const double cc = c12 * e3.x - s12 * e3.y, ss = s12 * e3.x + c12 * e3.y;
+        const double pf = ss * e.pr - cc * e.pi;
+        fx = fma(pf, e.kx, fx); fy = fma(pf, e.ky, fy); fz = fma(pf, e.kz, fz);
+      }
+    }
+  }
+  if (act) {
+    // every atom is owned by exactly one thread and the kernels of a step are stream-ordered
     const double pq = 2.0 * MD_QQRD2E * S.q[a];
-    atomicAdd(&S.f[3 * a], pq * fx);
-    atomicAdd(&S.f[3 * a + 1], pq * fy);
-    atomicAdd(&S.f[3 * a + 2], pq * fz);
+    S.f[3 * a] += pq * fx;
+    S.f[3 * a + 1] += pq * fy;
+    S.f[3 * a + 2] += pq * fz;
   }
 }
 

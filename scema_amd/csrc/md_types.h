@@ -89,6 +89,7 @@ struct SimDev {
   const int *improper_at; const double *improper_cf;// 4 ints, (K,chi0)
   const int *special_at; const double *special_cf;  // 2 ints, (f_lj,f_coul)
   const int *ex_start, *ex_list;
+  const int *aterm_order;          // atoms sorted by the shape of their term list (wave-uniform work)
   const int *aterm_start, *aterm;  // per-atom lists of the bonded terms / special pairs the atom takes part in
   const int *clus_at, *clus_n; const double *clus_d;
   // state
