@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--nss", type=int, default=100)
     ap.add_argument("--cells", type=int, nargs=3, default=[6, 9, 16], help="PE supercell (6 9 16 = PE-10k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo = host all-gather, lets several ranks share one GPU in tests")
     args = ap.parse_args()
 
     import torch
@@ -54,23 +56,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     from scema_amd import capi
     from scema_amd.systems import build_pe, synthetic_strains
 
     d = build_pe(*args.cells)
-    eng = capi.Engine(capi.default_params(device=local_rank, profile=1))
+    eng = capi.Engine(capi.default_params(device=device, profile=1))
     eng.register_replica("g0", 1, d)
     lens = d["box"][3:6] - d["box"][:3]
     n = args.sims
     per_rank = (n + world - 1) // world
 
-    send = torch.zeros(6 * per_rank, dtype=torch.float64, device="cuda")
-    recv = torch.zeros(6 * per_rank * world, dtype=torch.float64, device="cuda")
+    gdev = "cuda" if args.dist_backend == "nccl" else "cpu"
+    send = torch.zeros(6 * per_rank, dtype=torch.float64, device=gdev)
+    recv = torch.zeros(6 * per_rank * world, dtype=torch.float64, device=gdev)
     checksum = 0.0
 
     def update(istep):
@@ -81,8 +88,13 @@ def main():
                 for q in range(n)]
         arr = eng.strain_batch(sims, rank=rank, world=world)
         if world > 1:
-            eng.copy_local_stress(send.data_ptr(), True)
-            dist.all_gather_into_tensor(recv, send)          # the one collective (replaces share_stresses)
+            eng.copy_local_stress(send.data_ptr(), gdev == "cuda")
+            if gdev == "cuda":
+                dist.all_gather_into_tensor(recv, send)      # the one collective (replaces share_stresses)
+            else:
+                parts = [torch.empty_like(send) for _ in range(world)]
+                dist.all_gather(parts, send)
+                recv.copy_(torch.cat(parts))
             if rank == 0:
                 eng.scatter_gathered(recv.cpu().numpy(), world, arr)
         if rank == 0:
@@ -105,12 +117,21 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = eng.profile()
 
     if rank == 0:
+        # HBM traffic of the pair kernel comes from PMC counters, which cannot be collected inside a timed
+        # run: tools/pmc_traffic.sh measures bytes per replica-step (separate FETCH_SIZE / WRITE_SIZE passes,
+        # gfx950 x2 correction on FETCH_SIZE) and commits them under profiles/; scaled here to one launch
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pair_traffic.json")
+        if os.path.exists(tpath) and d["natoms"] == 10368:
+            tj = json.load(open(tpath))
+            traffic = tj["hbm_bytes_per_sim_step_corrected"] * ((n + world - 1) // world)
+            traffic_src = "profiles/pair_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 on FETCH_SIZE)"
         value = n * args.steps / elapsed
         pair_s = prof["pair_ms"] * 1e-3
         achieved = prof["pair_alg_bytes"] / pair_s / 1e9 if pair_s > 0 else 0.0
@@ -123,7 +144,8 @@ def main():
                        "n_sims": n, "atoms_per_replica": int(d["natoms"]), "md_steps_per_eval": 10 + args.nss,
                        "sharding": f"sim i -> rank i % {world}", "stress_zz_checksum_Pa": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "k_pair (lj/cut/coul/long force+virial, full list)",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_pair (lj/cut/coul/long force+virial; full list as 4-atom cluster rows)",
                          "launches": prof["pair_launches"],
                          "avg_launch_ms": prof["pair_ms"] / max(prof["pair_launches"], 1),
                          "alg_bytes_per_launch": prof["pair_alg_bytes"] / max(prof["pair_launches"], 1),
