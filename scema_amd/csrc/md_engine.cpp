@@ -605,7 +605,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   for (int i = 0; i < ns; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
   e->h_sims.assign(ns, SimDev());
-  int maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
+  int maxrow = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
   std::vector<int> kn_all;
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
@@ -665,6 +665,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     int rc = ensure_slot(e, sl, T.natoms, maxneigh, S.ncells, S.nk);
     if (rc) return rc;
     S.maxneigh = maxneigh;
+    maxrow = std::max(maxrow, maxneigh);
     S.nbonds = T.nbonds; S.nbonds_noshake = T.nbonds_noshake; S.nangles = T.nangles; S.ndihedrals = T.ndihedrals;
     S.nimpropers = T.nimpropers; S.nspecial = T.nspecial; S.nclus = T.nclus;
     S.nsteps = A.nsteps;
@@ -726,7 +727,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const int ev = (spec.sample || spec.ev_always) ? 1 : 0;
   // ---- setup (step 0) ----
   mdk_phase_init(st, D, ns);
-  mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells);
+  mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow);
   mdk_pair(st, D, ns, maxpad, ev, spec.ev_always, maxpoly);
   mdk_bonded_atom(st, D, ns, maxatoms, spec.ev_always);
   mdk_ewald(st, D, ns, maxatoms, maxk, mmax);
@@ -743,7 +744,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (na == 0) break;
     mdk_pre(st, D, na);
     mdk_initial_integrate(st, D, na, maxatoms);
-    mdk_neighbor(st, D, na, maxatoms, maxpad, maxcells);
+    mdk_neighbor(st, D, na, maxatoms, maxpad, maxcells, maxrow);
     if (prof) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;

@@ -6,8 +6,8 @@ void mdk_phase_init(hipStream_t st, const SimDev *d, int ns);
 void mdk_setup_post(hipStream_t st, const SimDev *d, int ns);
 void mdk_pre(hipStream_t st, const SimDev *d, int ns);
 void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms);
-void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells);
-void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad);
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow);
+void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad, int maxrow);
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int vir, int eng, int npoly);

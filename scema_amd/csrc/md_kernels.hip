@@ -1079,13 +1079,13 @@ void mdk_pre(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_pre
 void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
   hipLaunchKernelGGL(k_initial_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
 }
-void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells) {
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow) {
   hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_scan, dim3(ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_fill, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_sort, grid2(cdiv(maxcells, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
-  mdk_neigh_build(st, d, ns, maxpad);
+  mdk_neigh_build(st, d, ns, maxpad, maxrow);
 }
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);

@@ -74,124 +74,125 @@ struct ClusterI {
   int atom[NI];   // real atom index or -1 (pad)
 };
 
-template <int PASS>
-__device__ __forceinline__ void scan_cluster(const SimDev &S, const BoxD &b, int s0slot, const ClusterI &ci, int cell, int &nA, int &nB,
-                                             int &nC, int offB, int offC, unsigned long long &npairs) {
-  const int lane = lane_id();
-  const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
-  const GLOBAL_AS double *xq = as_global((const double *)S.xq);
-  GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)(s0slot / NI) * S.maxneigh;
-  const double ra2 = S.seg_a2, rb2 = S.seg_b2;
-  for (int o2 = -S.mst[2]; o2 <= S.mst[2]; o2++) {
-    int a2 = c2 + o2, s2 = 0;
-    while (a2 < 0) { a2 += S.nc[2]; s2 -= 1; }
-    while (a2 >= S.nc[2]) { a2 -= S.nc[2]; s2 += 1; }
-    if (s2 < -1 || s2 > 1) continue;
-    for (int o1 = -S.mst[1]; o1 <= S.mst[1]; o1++) {
-      int a1 = c1 + o1, s1 = 0;
-      while (a1 < 0) { a1 += S.nc[1]; s1 -= 1; }
-      while (a1 >= S.nc[1]) { a1 -= S.nc[1]; s1 += 1; }
-      if (s1 < -1 || s1 > 1) continue;
-      // the x range of cells [c0-m, c0+m] is one or more contiguous slot runs, one per image
-      int o0 = -S.mst[0];
-      while (o0 <= S.mst[0]) {
-        int a0 = c0 + o0, s0 = 0;
-        while (a0 < 0) { a0 += S.nc[0]; s0 -= 1; }
-        while (a0 >= S.nc[0]) { a0 -= S.nc[0]; s0 += 1; }
-        int len = 1;
-        while (o0 + len <= S.mst[0] && a0 + len < S.nc[0]) len++;
-        o0 += len;
-        if (s0 < -1 || s0 > 1) continue;
-        const double sx = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
-        const double sy = b.h[1] * s1 + b.h[3] * s2;
-        const double sz = b.h[2] * s2;
-        const bool home = (s0 == 0 && s1 == 0 && s2 == 0);
-        const int code = ((s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1)) << MD_CODE_SHIFT;
-        const int cj = (a2 * S.nc[1] + a1) * S.nc[0] + a0;
-        const int jb = S.cell_start[cj], je = S.cell_start[cj + len];
-        for (int base = jb; base < je; base += 64) {
-          const int j = base + lane;
-          int mask = 0;
-          double rmin = 1.0e300;
-          if (j < je) {
-            const double xj = xq[4 * (size_t)j] + sx, yj = xq[4 * (size_t)j + 1] + sy, zj = xq[4 * (size_t)j + 2] + sz;
-            int aj = -2;
-#pragma unroll
-            for (int a = 0; a < NI; a++) {
-              const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
-              const double r2 = dx * dx + dy * dy + dz * dz;
-              bool acc = ci.atom[a] >= 0 && r2 < S.rlist2 && !(home && j == s0slot + a);
-              if (acc && r2 < S.excl_cut2) {
-                if (aj == -2) aj = S.perm[j];
-                for (int e = S.ex_start[ci.atom[a]]; e < S.ex_start[ci.atom[a] + 1]; e++) acc = acc && (S.ex_list[e] != aj);
-              }
-              if (acc) {
-                mask |= 1 << a;
-                rmin = fmin(rmin, r2);
-              }
-            }
-          }
-          const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB;
-          const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC);
-          if (PASS == 1 && mask) {
-            const int entry = code | (mask << MD_MASK_SHIFT) | j;
-            int pos;
-            if (isA) pos = nA + popc_below(mA);
-            else if (isB) pos = offB + nB + popc_below(mB);
-            else pos = offC + nC + popc_below(mC);
-            if (pos < S.maxneigh) row[pos] = entry;
-          }
-          nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC);
-          if (PASS == 0) npairs += __popc(mask);
-        }
-      }
-    }
-  }
-}
+// single pass: accepted entries are compacted (ballot + prefix popcount) into three per-wave LDS
+// lists, one per distance segment, then copied to the cluster's row A|B|C with coalesced stores
+extern __shared__ int s_lists[];  // [WPB][capA + capB + capC]
 
-__global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims) {
+__global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capA, int capB,
+                                                          int capC) {
   int sim, tile;
   if (!xcd_map(ntiles, nsims, sim, tile)) return;
   const SimDev &S = sims[sim];
   SimScalars &sc = *S.sc;
   if (!sc.rebuild) return;
+  const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int *la = s_lists + wave * (capA + capB + capC), *lb = la + capA, *lc = lb + capB;
   BoxD b;
   box_derive(sc.box, b);
+  const GLOBAL_AS double *xq = as_global((const double *)S.xq);
+  const double ra2 = S.seg_a2, rb2 = S.seg_b2;
   unsigned long long npairs = 0;
-  int nmax = 0;
+  int nmax = 0, over = 0;
   for (int c = 0; c < CPW; c++) {
     const int cl = tile * CPB + wave * CPW + c;  // wave-uniform
-    const int s0 = cl * NI;
-    if (s0 >= S.npad) break;
+    const int s0slot = cl * NI;
+    if (s0slot >= S.npad) break;
     ClusterI ci;
 #pragma unroll
     for (int a = 0; a < NI; a++) {
-      ci.atom[a] = S.perm[s0 + a];
-      ci.x[a] = S.xq[s0 + a].x; ci.y[a] = S.xq[s0 + a].y; ci.z[a] = S.xq[s0 + a].z;
+      ci.atom[a] = S.perm[s0slot + a];
+      ci.x[a] = S.xq[s0slot + a].x; ci.y[a] = S.xq[s0slot + a].y; ci.z[a] = S.xq[s0slot + a].z;
     }
     if (ci.atom[0] < 0) {  // empty cluster (pad only)
-      if (lane_id() == 0) S.numneigh[cl] = 0;
+      if (lane == 0) S.numneigh[cl] = 0;
       continue;
     }
     const int cell = S.cell_of[ci.atom[0]];
+    const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
     int nA = 0, nB = 0, nC = 0;
-    scan_cluster<0>(S, b, s0, ci, cell, nA, nB, nC, 0, 0, npairs);
+    for (int o2 = -S.mst[2]; o2 <= S.mst[2]; o2++) {
+      int a2 = c2 + o2, s2 = 0;
+      while (a2 < 0) { a2 += S.nc[2]; s2 -= 1; }
+      while (a2 >= S.nc[2]) { a2 -= S.nc[2]; s2 += 1; }
+      if (s2 < -1 || s2 > 1) continue;
+      for (int o1 = -S.mst[1]; o1 <= S.mst[1]; o1++) {
+        int a1 = c1 + o1, s1 = 0;
+        while (a1 < 0) { a1 += S.nc[1]; s1 -= 1; }
+        while (a1 >= S.nc[1]) { a1 -= S.nc[1]; s1 += 1; }
+        if (s1 < -1 || s1 > 1) continue;
+        // the x range of cells [c0-m, c0+m] is one or more contiguous slot runs, one per image
+        int o0 = -S.mst[0];
+        while (o0 <= S.mst[0]) {
+          int a0 = c0 + o0, s0 = 0;
+          while (a0 < 0) { a0 += S.nc[0]; s0 -= 1; }
+          while (a0 >= S.nc[0]) { a0 -= S.nc[0]; s0 += 1; }
+          int len = 1;
+          while (o0 + len <= S.mst[0] && a0 + len < S.nc[0]) len++;
+          o0 += len;
+          if (s0 < -1 || s0 > 1) continue;
+          const double sx = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
+          const double sy = b.h[1] * s1 + b.h[3] * s2;
+          const double sz = b.h[2] * s2;
+          const bool home = (s0 == 0 && s1 == 0 && s2 == 0);
+          const int code = ((s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1)) << MD_CODE_SHIFT;
+          const int cj = (a2 * S.nc[1] + a1) * S.nc[0] + a0;
+          const int jb = S.cell_start[cj], je = S.cell_start[cj + len];
+          for (int base = jb; base < je; base += 64) {
+            const int j = base + lane;
+            int mask = 0;
+            double rmin = 1.0e300;
+            if (j < je) {
+              const double xj = xq[4 * (size_t)j] + sx, yj = xq[4 * (size_t)j + 1] + sy, zj = xq[4 * (size_t)j + 2] + sz;
+              int aj = -2;
+#pragma unroll
+              for (int a = 0; a < NI; a++) {
+                const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                bool acc = ci.atom[a] >= 0 && r2 < S.rlist2 && !(home && j == s0slot + a);
+                if (acc && r2 < S.excl_cut2) {
+                  if (aj == -2) aj = S.perm[j];
+                  for (int e = S.ex_start[ci.atom[a]]; e < S.ex_start[ci.atom[a] + 1]; e++) acc = acc && (S.ex_list[e] != aj);
+                }
+                if (acc) {
+                  mask |= 1 << a;
+                  rmin = fmin(rmin, r2);
+                }
+              }
+            }
+            const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB;
+            const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC);
+            if (mask) {
+              const int entry = code | (mask << MD_MASK_SHIFT) | j;
+              if (isA) { const int pos = nA + popc_below(mA); if (pos < capA) la[pos] = entry; }
+              else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
+              else { const int pos = nC + popc_below(mC); if (pos < capC) lc[pos] = entry; }
+            }
+            nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC);
+            npairs += __popc(mask);
+          }
+        }
+      }
+    }
     const int n = nA + nB + nC;
-    int pA = 0, pB = 0, pC = 0;
-    unsigned long long dummy = 0;
-    scan_cluster<1>(S, b, s0, ci, cell, pA, pB, pC, nA, nA + nB, dummy);
-    if (lane_id() == 0) S.numneigh[cl] = (n < S.maxneigh) ? n : S.maxneigh;
+    if (nA > capA || nB > capB || nC > capC || n > S.maxneigh) over = 1;
+    // LDS lists -> row (A | B | C); same-wave LDS traffic is processed in order
+    GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)cl * S.maxneigh;
+    const int mA_ = min(nA, capA), mB_ = min(nB, capB), mC_ = min(nC, capC);
+    for (int k = lane; k < mA_; k += 64) if (k < S.maxneigh) row[k] = la[k];
+    for (int k = lane; k < mB_; k += 64) if (mA_ + k < S.maxneigh) row[mA_ + k] = lb[k];
+    for (int k = lane; k < mC_; k += 64) if (mA_ + mB_ + k < S.maxneigh) row[mA_ + mB_ + k] = lc[k];
+    if (lane == 0) S.numneigh[cl] = min(mA_ + mB_ + mC_, S.maxneigh);
     nmax = max(nmax, n);
   }
-  // npairs was accumulated per lane
-  double cnt = wave_sum((double)npairs);
-  if (lane_id() == 0) {
-    if (nmax > S.maxneigh) atomicOr(&sc.overflow, 1);
+  const double cnt = wave_sum((double)npairs);
+  if (lane == 0) {
+    if (over) atomicOr(&sc.overflow, 1);
     atomicMax(&sc.maxneigh_seen, nmax);
     atomicAdd(&sc.nentries, (unsigned long long)cnt);
   }
 }
+
 
 // ------------------------------------------------------------------------------------------
 // k_pair
@@ -344,9 +345,12 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(cdiv(ns, 8) * 8 * ntiles), 1, 1); }
 
-void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad) {
+void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad, int maxrow) {
   const int ntiles = cdiv(maxpad / NI, CPB);
-  hipLaunchKernelGGL(k_neigh_build, grid_xcd(ntiles, ns), dim3(WPB * 64), 0, st, d, ntiles, ns);
+  // per-wave LDS lists: any one segment can hold well over its expected share of a full row
+  const int capA = (int)(0.40 * maxrow) / 64 * 64 + 64, capB = (int)(0.50 * maxrow) / 64 * 64 + 64, capC = (int)(0.45 * maxrow) / 64 * 64 + 64;
+  const size_t lds = (size_t)WPB * (capA + capB + capC) * sizeof(int);
+  hipLaunchKernelGGL(k_neigh_build, grid_xcd(ntiles, ns), dim3(WPB * 64), lds, st, d, ntiles, ns, capA, capB, capC);
 }
 
 template <int NP>
