@@ -100,7 +100,7 @@ struct State {
 
 struct Slot {
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
-  DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
+  DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
       xbak, vbak;
 };
 
@@ -562,6 +562,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.wrapn.ensure(3 * (size_t)natoms * 4));
     HIPCHK(sl.xhold.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.cell_of.ensure((size_t)natoms * 4));
+    HIPCHK(sl.ckey.ensure((size_t)natoms * 4));
     HIPCHK(sl.slot_tmp.ensure((size_t)natoms * 4));
     HIPCHK(sl.xbak.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.vbak.ensure(3 * (size_t)natoms * 8));
@@ -704,7 +705,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.x = A.st->x.as<double>(); S.v = A.st->v.as<double>(); S.f = sl.f.as<double>();
     S.xq = sl.xq.as<double4>(); S.stype = sl.stype.as<int>(); S.perm = sl.perm.as<int>(); S.slot_tmp = sl.slot_tmp.as<int>();
     S.wrapn = sl.wrapn.as<int>(); S.xhold = sl.xhold.as<double>();
-    S.cell_of = sl.cell_of.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
+    S.cell_of = sl.cell_of.as<int>(); S.ckey = sl.ckey.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
     S.kn = sl.kn.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(TPB) void k_bin(const SimDev *sims) {
   l[1] = b.hinv[1] * d1 + b.hinv[3] * d2;
   l[2] = b.hinv[2] * d2;
   int c[3];
+  int key = 0;
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     double fl = floor(l[d]);
@@ -257,7 +258,13 @@ __global__ __launch_bounds__(TPB) void k_bin(const SimDev *sims) {
     int cc = (int)(w * S.nc[d]);
     if (cc >= S.nc[d]) cc = S.nc[d] - 1;
     c[d] = cc;
+    // position inside the cell on an 8x8x8 grid -> Morton key: consecutive slots of a cell are
+    // spatial neighbours, which keeps the 4-atom i-clusters of k_pair compact
+    int sub = (int)((w * S.nc[d] - cc) * 8.0);
+    sub = sub < 0 ? 0 : (sub > 7 ? 7 : sub);
+    key |= ((sub & 1) << d) | ((sub & 2) << (d + 2)) | ((sub & 4) << (d + 4));
   }
+  S.ckey[i] = key;
   const int cell = (c[2] * S.nc[1] + c[1]) * S.nc[0] + c[0];
   S.cell_of[i] = cell;
   atomicAdd(&S.cell_count[cell], 1);
@@ -315,7 +322,8 @@ __global__ __launch_bounds__(TPB) void k_cell_fill(const SimDev *sims) {
   S.slot_tmp[slot] = i;
 }
 
-// deterministic order inside each cell: ascending atom index (the atomic fill order is not)
+// deterministic order inside each cell: ascending (Morton key of the sub-cell position, atom index);
+// the atomic fill order is not deterministic
 __global__ __launch_bounds__(TPB) void k_cell_sort(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   if (!S.sc->rebuild) return;
@@ -324,8 +332,14 @@ __global__ __launch_bounds__(TPB) void k_cell_sort(const SimDev *sims) {
   const int b = S.cell_start[c], e = b + S.cell_count[c];  // the rest of the cell's range stays pad (-1)
   for (int s = b; s < e; s++) {
     // rank of slot_tmp[s] among the members
-    int a = S.slot_tmp[s], r = 0;
-    for (int t = b; t < e; t++) r += (S.slot_tmp[t] < a) ? 1 : 0;
+    const int a = S.slot_tmp[s];
+    const int ka = S.ckey[a];
+    int r = 0;
+    for (int t = b; t < e; t++) {
+      const int o = S.slot_tmp[t];
+      const int ko = S.ckey[o];
+      r += (ko < ka || (ko == ka && o < a)) ? 1 : 0;
+    }
     S.perm[b + r] = a;
   }
 }

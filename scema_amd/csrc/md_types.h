@@ -101,7 +101,7 @@ struct SimDev {
   int *slot_tmp;    // unsorted cell fill
   int *wrapn;       // atom -> integer wrap (3)
   double *xhold;
-  int *cell_of, *cell_count, *cell_start, *cell_fill;
+  int *cell_of, *ckey, *cell_count, *cell_start, *cell_fill;
   int *numneigh, *neigh;
   // ewald
   const int *kn;    // 3 ints per k
