@@ -74,12 +74,13 @@ struct ClusterI {
   int atom[NI];   // real atom index or -1 (pad)
 };
 
-// single pass: accepted entries are compacted (ballot + prefix popcount) into three per-wave LDS
-// lists, one per distance segment, then copied to the cluster's row A|B|C with coalesced stores
-extern __shared__ int s_lists[];  // [WPB][capA + capB + capC]
+// single pass: accepted entries are compacted with ballots + prefix popcounts.  Segment A grows
+// forward from the start of the cluster's row, segment C backward from its end, segment B is
+// collected in a per-wave LDS list and appended behind A at the end: row = [A | B | ... | C reversed].
+// Only B needs LDS (7.6 KB per wave at PE-10k), which keeps 5 blocks per CU resident.
+extern __shared__ int s_lists[];  // [WPB][capB]
 
-__global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capA, int capB,
-                                                          int capC) {
+__global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capB) {
   int sim, tile;
   if (!xcd_map(ntiles, nsims, sim, tile)) return;
   const SimDev &S = sims[sim];
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
   if (!sc.rebuild) return;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int *la = s_lists + wave * (capA + capB + capC), *lb = la + capA, *lc = lb + capB;
+  int *lb = s_lists + wave * capB;
+  const int maxrow = S.maxneigh;
   BoxD b;
   box_derive(sc.box, b);
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);
@@ -105,9 +107,10 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
       ci.x[a] = S.xq[s0slot + a].x; ci.y[a] = S.xq[s0slot + a].y; ci.z[a] = S.xq[s0slot + a].z;
     }
     if (ci.atom[0] < 0) {  // empty cluster (pad only)
-      if (lane == 0) S.numneigh[cl] = 0;
+      if (lane == 0) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
       continue;
     }
+    GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)cl * maxrow;
     const int cell = S.cell_of[ci.atom[0]];
     const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
     int nA = 0, nB = 0, nC = 0;
@@ -164,9 +167,9 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
             const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC);
             if (mask) {
               const int entry = code | (mask << MD_MASK_SHIFT) | j;
-              if (isA) { const int pos = nA + popc_below(mA); if (pos < capA) la[pos] = entry; }
+              if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) row[pos] = entry; }
               else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
-              else { const int pos = nC + popc_below(mC); if (pos < capC) lc[pos] = entry; }
+              else { const int pos = maxrow - 1 - (nC + popc_below(mC)); if (pos >= 0) row[pos] = entry; }
             }
             nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC);
             npairs += __popc(mask);
@@ -175,14 +178,12 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
       }
     }
     const int n = nA + nB + nC;
-    if (nA > capA || nB > capB || nC > capC || n > S.maxneigh) over = 1;
-    // LDS lists -> row (A | B | C); same-wave LDS traffic is processed in order
-    GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)cl * S.maxneigh;
-    const int mA_ = min(nA, capA), mB_ = min(nB, capB), mC_ = min(nC, capC);
-    for (int k = lane; k < mA_; k += 64) if (k < S.maxneigh) row[k] = la[k];
-    for (int k = lane; k < mB_; k += 64) if (mA_ + k < S.maxneigh) row[mA_ + k] = lb[k];
-    for (int k = lane; k < mC_; k += 64) if (mA_ + mB_ + k < S.maxneigh) row[mA_ + mB_ + k] = lc[k];
-    if (lane == 0) S.numneigh[cl] = min(mA_ + mB_ + mC_, S.maxneigh);
+    const bool bad = nB > capB || n > maxrow;
+    if (bad) over = 1;
+    // B: LDS list -> behind A (same-wave LDS traffic is processed in order)
+    const int mB_ = bad ? 0 : nB;
+    for (int k = lane; k < mB_; k += 64) row[nA + k] = lb[k];
+    if (lane == 0) { S.numneigh[2 * cl] = bad ? 0 : nA + nB; S.numneigh[2 * cl + 1] = bad ? 0 : nC; }
     nmax = max(nmax, n);
   }
   const double cnt = wave_sum((double)npairs);
@@ -236,8 +237,9 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
     const int cl = tile * CPB + wave * CPW + c;  // wave-uniform
     const int s0 = cl * NI;
     if (s0 >= S.npad) break;
-    const int nn = S.numneigh[cl];
+    const int nab = S.numneigh[2 * cl], nn = nab + S.numneigh[2 * cl + 1];  // [A|B] from the front, C reversed from the back
     if (nn == 0) continue;
+#define ROW_AT(k) row[((k) < nab) ? (k) : (maxrow - 1 - ((k) - nab))]
     double xi[NI], yi[NI], zi[NI], qi[NI], fx[NI], fy[NI], fz[NI];
     int ti[NI];
 #pragma unroll
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
     }
     const GLOBAL_AS int *row = as_global(S.neigh) + (size_t)cl * maxrow;
     // one row ahead: entry + record + type of row r+1 are in flight while row r is evaluated
-    int e_n = (lane < nn) ? row[lane] : 0;
+    int e_n = (lane < nn) ? ROW_AT(lane) : 0;
     double xn0, xn1, xn2, xn3;
     int tn;
     {
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
       const int tj = tn;
       {
         const int kn = k0 + 64 + lane;
-        e_n = (kn < nn) ? row[kn] : 0;
+        e_n = (kn < nn) ? ROW_AT(kn) : 0;
         const size_t j = (size_t)(e_n & MD_JMASK);
         xn0 = xq[4 * j]; xn1 = xq[4 * j + 1]; xn2 = xq[4 * j + 2]; xn3 = xq[4 * j + 3];
         tn = stype[j];
@@ -347,10 +349,10 @@ static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(cdiv(ns
 
 void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad, int maxrow) {
   const int ntiles = cdiv(maxpad / NI, CPB);
-  // per-wave LDS lists: any one segment can hold well over its expected share of a full row
-  const int capA = (int)(0.40 * maxrow) / 64 * 64 + 64, capB = (int)(0.50 * maxrow) / 64 * 64 + 64, capC = (int)(0.45 * maxrow) / 64 * 64 + 64;
-  const size_t lds = (size_t)WPB * (capA + capB + capC) * sizeof(int);
-  hipLaunchKernelGGL(k_neigh_build, grid_xcd(ntiles, ns), dim3(WPB * 64), lds, st, d, ntiles, ns, capA, capB, capC);
+  // per-wave LDS list of segment B: well over its expected share (~40 %) of a full row
+  const int capB = (int)(0.55 * maxrow) / 64 * 64 + 64;
+  const size_t lds = (size_t)WPB * capB * sizeof(int);
+  hipLaunchKernelGGL(k_neigh_build, grid_xcd(ntiles, ns), dim3(WPB * 64), lds, st, d, ntiles, ns, capB);
 }
 
 template <int NP>
