@@ -1322,6 +1322,7 @@ int scema_md_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid,
     info[3] = e->h_sims[0].tdof;
     info[4] = sc.t_current;
     info[5] = sc.maxneigh_seen;
+    info[4] = (double)sc.nrowent;  // row entries stored (t_current is not needed by the callers)
     info[6] = e->h_sims[0].maxneigh;
     info[7] = s->topo->nclus;
   }

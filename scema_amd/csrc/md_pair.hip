@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
   box_derive(sc.box, b);
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);
   const double ra2 = S.seg_a2, rb2 = S.seg_b2;
-  unsigned long long npairs = 0;
+  unsigned long long npairs = 0, nrowent = 0;
   int nmax = 0, over = 0;
   for (int c = 0; c < CPW; c++) {
     const int cl = tile * CPB + wave * CPW + c;  // wave-uniform
@@ -185,12 +185,14 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
     for (int k = lane; k < mB_; k += 64) row[nA + k] = lb[k];
     if (lane == 0) { S.numneigh[2 * cl] = bad ? 0 : nA + nB; S.numneigh[2 * cl + 1] = bad ? 0 : nC; }
     nmax = max(nmax, n);
+    nrowent += n;
   }
   const double cnt = wave_sum((double)npairs);
   if (lane == 0) {
     if (over) atomicOr(&sc.overflow, 1);
     atomicMax(&sc.maxneigh_seen, nmax);
     atomicAdd(&sc.nentries, (unsigned long long)cnt);
+    atomicAdd(&sc.nrowent, nrowent);
   }
 }
 

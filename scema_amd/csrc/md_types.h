@@ -45,7 +45,8 @@ struct SimScalars {
   double psum[6];      // running sum of the sampled pressure tensor (atm)
   double deltasq;      // neighbour trigger: (skin - corner motion)^2 / 4
   double corners_hold[24];
-  unsigned long long nentries;  // neighbour entries stored at the last build (full list)
+  unsigned long long nentries;  // (i,j) pairs listed at the last build (= entries of a full per-atom list)
+  unsigned long long nrowent;   // row entries actually stored (one per (cluster, j))
   int nsamples;
   int step;
   int ago;
