@@ -100,6 +100,13 @@ int scema_md_register_replica(scema_md_engine *e, const char *matid, int32_t rep
 /* reads a replica file written by scema_md_write_replica_file (our container for init.*.bin) */
 int scema_md_load_replica_file(scema_md_engine *e, const char *matid, int32_t replica, const char *path);
 int scema_md_write_replica_file(const char *path, const scema_md_system *sys);
+/* LAMMPS text data file of atom_style full (`write_data` of a replica equilibrated with the reference's
+ * in.init.lammps): register it directly, or convert it to the replica container.  special_bonds weights are
+ * not stored in data files; NULL means the reference's "lj/coul 0 0 1" (in.init.lammps:31). */
+int scema_md_load_lammps_data(scema_md_engine *e, const char *matid, int32_t replica, const char *path,
+                              const double special_lj[3], const double special_coul[3]);
+int scema_md_convert_lammps_data(const char *data_path, const char *replica_path, const double special_lj[3],
+                                 const double special_coul[3]);
 
 /* ---- the hot path ---- */
 /* Replaces STMDProblem<3>::strain (stmd_problem.h:458-496) for the whole vector that

@@ -22,6 +22,7 @@ QP_NONE = -1  # uint32 max as int32 (stmd_problem.h:126)
 SYMBOLS = [
     "scema_md_default_params", "scema_md_create", "scema_md_destroy", "scema_md_last_error",
     "scema_md_register_replica", "scema_md_load_replica_file", "scema_md_write_replica_file",
+    "scema_md_load_lammps_data", "scema_md_convert_lammps_data",
     "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
     "scema_md_local_stress_count", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
     "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file",
@@ -176,6 +177,12 @@ class Engine:
         self._chk(lib().scema_md_load_replica_file(self.h, matid.encode(), C.c_int32(replica), path.encode()))
         if natoms is not None:
             self._natoms[(matid, replica)] = natoms
+
+    def load_lammps_data(self, matid: str, replica: int, path: str, natoms: int, special_lj=None, special_coul=None):
+        slj = None if special_lj is None else np.ascontiguousarray(special_lj, np.float64)
+        sc = None if special_coul is None else np.ascontiguousarray(special_coul, np.float64)
+        self._chk(lib().scema_md_load_lammps_data(self.h, matid.encode(), C.c_int32(replica), path.encode(), _p(slj), _p(sc)))
+        self._natoms[(matid, replica)] = natoms
 
     def strain_batch(self, sims, hooke: bool = False, rank: int = 0, world: int = 1):
         arr = (MDSim * len(sims))(*sims) if not isinstance(sims, C.Array) else sims

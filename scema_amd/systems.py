@@ -137,3 +137,87 @@ def synthetic_strains(n_sims: int, box_lengths, seed: int = 2026, scale: float =
         sh = rng.uniform(-1.0e-4, 1.0e-4, 3) * scale
         out[i] = [-0.3 * ezz * lx, -0.3 * ezz * ly, ezz * lz, sh[0] * lz, sh[1] * ly, sh[2] * lx]
     return out
+
+
+def write_lammps_data(path: str, d: dict, title: str = "scema_amd synthetic replica") -> None:
+    """Write the system as a LAMMPS data file of atom_style full (what `write_data` produces), so the same
+    replica can be run through the reference's own scripts where LAMMPS is available, and read back by
+    scema_md_load_lammps_data.  Pair coefficients are written per pair (PairIJ Coeffs)."""
+    n = int(d["natoms"]); nt = int(d["ntypes"])
+    box = [float(b) for b in np.asarray(d["box"], float)]   # plain floats: repr() must not say np.float64(..)
+    with open(path, "w") as f:
+        f.write(f"LAMMPS data file: {title}\n\n")
+        f.write(f"{n} atoms\n{nt} atom types\n")
+        f.write(f"{len(d['bond_type'])} bonds\n{len(d['bond_coeff'])} bond types\n")
+        f.write(f"{len(d['angle_type'])} angles\n{len(d['angle_coeff'])} angle types\n")
+        f.write(f"{len(d['dihedral_type'])} dihedrals\n{len(d['dihedral_coeff'])} dihedral types\n")
+        f.write(f"{len(d['improper_type'])} impropers\n{len(d['improper_coeff'])} improper types\n\n")
+        f.write(f"{box[0]!r} {box[3]!r} xlo xhi\n{box[1]!r} {box[4]!r} ylo yhi\n{box[2]!r} {box[5]!r} zlo zhi\n")
+        f.write(f"{box[6]!r} {box[7]!r} {box[8]!r} xy xz yz\n\n")
+        f.write("Masses\n\n")
+        for t in range(nt):
+            f.write(f"{t + 1} {float(d['mass'][t])!r}\n")
+        f.write("\nPairIJ Coeffs # lj/cut/coul/long\n\n")
+        for a in range(nt):
+            for b in range(a, nt):
+                f.write(f"{a + 1} {b + 1} {float(d['eps'][a][b])!r} {float(d['sigma'][a][b])!r}\n")
+        if len(d["bond_coeff"]):
+            f.write("\nBond Coeffs # harmonic\n\n")
+            for t, (k, r0) in enumerate(d["bond_coeff"]):
+                f.write(f"{t + 1} {float(k)!r} {float(r0)!r}\n")
+        if len(d["angle_coeff"]):
+            f.write("\nAngle Coeffs # harmonic\n\n")
+            for t, (k, th) in enumerate(d["angle_coeff"]):
+                f.write(f"{t + 1} {float(k)!r} {float(np.rad2deg(th))!r}\n")
+        if len(d["dihedral_coeff"]):
+            f.write("\nDihedral Coeffs # opls\n\n")
+            for t, ks in enumerate(d["dihedral_coeff"]):
+                f.write(f"{t + 1} " + " ".join(repr(float(k)) for k in ks) + "\n")
+        if len(d["improper_coeff"]):
+            f.write("\nImproper Coeffs # harmonic\n\n")
+            for t, (k, chi) in enumerate(d["improper_coeff"]):
+                f.write(f"{t + 1} {float(k)!r} {float(np.rad2deg(chi))!r}\n")
+        f.write("\nAtoms # full\n\n")
+        mol = d.get("mol", np.zeros(n, dtype=np.int32))
+        for i in range(n):
+            x = d["x"][i]
+            f.write(f"{i + 1} {int(mol[i]) + 1} {int(d['type'][i]) + 1} {float(d['charge'][i])!r} {float(x[0])!r} {float(x[1])!r} {float(x[2])!r} 0 0 0\n")
+        f.write("\nVelocities\n\n")
+        for i in range(n):
+            v = d["v"][i]
+            f.write(f"{i + 1} {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}\n")
+        for name, key, tkey in (("Bonds", "bonds", "bond_type"), ("Angles", "angles", "angle_type"),
+                                ("Dihedrals", "dihedrals", "dihedral_type"), ("Impropers", "impropers", "improper_type")):
+            if len(d[tkey]):
+                f.write(f"\n{name}\n\n")
+                for m, (row, t) in enumerate(zip(d[key], d[tkey])):
+                    f.write(f"{m + 1} {int(t) + 1} " + " ".join(str(int(a) + 1) for a in row) + "\n")
+
+
+def read_replica_file(path: str) -> dict:
+    """Read the engine's replica container (scema_md_write_replica_file) back into the dict form."""
+    import struct
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:8] != b"SCEMAMD1":
+        raise ValueError(f"{path}: not a replica container")
+    h = struct.unpack_from("<10i", raw, 8)
+    n, nt, nb, nbt, na, nat, nd, ndt, ni, nit = h
+    off = 8 + 40
+
+    def take(dtype, count, shape=None):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=dtype, count=count, offset=off).copy()
+        off += a.nbytes
+        return a if shape is None else a.reshape(shape)
+
+    slj = take("<f8", 3); sc = take("<f8", 3); box = take("<f8", 9)
+    d = dict(natoms=n, ntypes=nt, special_lj=slj, special_coul=sc, box=box)
+    d["type"] = take("<i4", n); d["charge"] = take("<f8", n); d["mass"] = take("<f8", nt)
+    d["eps"] = take("<f8", nt * nt, (nt, nt)); d["sigma"] = take("<f8", nt * nt, (nt, nt))
+    d["bonds"] = take("<i4", 2 * nb, (nb, 2)); d["bond_type"] = take("<i4", nb); d["bond_coeff"] = take("<f8", 2 * nbt, (nbt, 2))
+    d["angles"] = take("<i4", 3 * na, (na, 3)); d["angle_type"] = take("<i4", na); d["angle_coeff"] = take("<f8", 2 * nat, (nat, 2))
+    d["dihedrals"] = take("<i4", 4 * nd, (nd, 4)); d["dihedral_type"] = take("<i4", nd); d["dihedral_coeff"] = take("<f8", 4 * ndt, (ndt, 4))
+    d["impropers"] = take("<i4", 4 * ni, (ni, 4)); d["improper_type"] = take("<i4", ni); d["improper_coeff"] = take("<f8", 2 * nit, (nit, 2))
+    d["x"] = take("<f8", 3 * n, (n, 3)); d["v"] = take("<f8", 3 * n, (n, 3))
+    return d
