@@ -132,3 +132,43 @@ def test_batch_is_independent_and_ordered(small_pe, eng_small):
         o1 = eng_small.strain_batch([capi.make_sim(100 + i, "pe", 4, s, nss=10, most_recent=capi.QP_NONE)])
         single.append(o1[0].stress[:])
     assert relerr(batch, np.array(single)) < 1e-9
+
+
+def test_lammps_data_file_registers_the_same_system(small_pe, eng_small, tmp_path):
+    """A `write_data`-style text file read by scema_md_load_lammps_data gives the same forces as the arrays."""
+    from scema_amd.systems import write_lammps_data
+    p = str(tmp_path / "pe.data")
+    write_lammps_data(p, small_pe)
+    eng_small.register_replica("pe", 8, small_pe)
+    f0, e0, w0, _ = eng_small.debug_compute("pe", 8)
+    eng_small.load_lammps_data("pe", 9, p, natoms=small_pe["natoms"])
+    f1, e1, w1, _ = eng_small.debug_compute("pe", 9)
+    assert relerr(f1, f0) < 1e-12 and np.abs(e1 - e0).max() < 1e-9 * np.abs(e0).max()
+
+
+def test_empty_batch_and_hooke_mode(small_pe, eng_small):
+    from scema_amd import capi
+    import ctypes as C
+    assert capi.lib().scema_md_strain_batch(eng_small.h, None, C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(1)) == 0
+    Cst = np.arange(36, dtype=float).reshape(6, 6); Cst = (Cst + Cst.T) * 1e8
+    eps = np.array([1e-3, -2e-4, 5e-4, 3e-4, -1e-4, 2e-4])
+    out = eng_small.strain_batch([capi.make_sim(0, "nomat", 1, eps, stiffness=Cst)], hooke=True)   # no replica needed
+    from oracle import pyoracle as po
+    assert np.allclose(out[0].stress[:], po.hooke(Cst.ravel(), eps), rtol=1e-14)
+    assert out[0].stress_updated == 1
+
+
+def test_ragged_world_sharding_leaves_other_ranks_untouched(small_pe, eng_small):
+    """rank 1 of 3 evaluates simulations 1 and 4 only; the others keep stress_updated = 0."""
+    from scema_amd import capi
+    eng_small.register_replica("pe", 10, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+    sims = [capi.make_sim(200 + i, "pe", 10, st * (1 + 0.1 * i), nss=10, most_recent=capi.QP_NONE) for i in range(5)]
+    out = eng_small.strain_batch(sims, rank=1, world=3)
+    assert [o.stress_updated for o in out] == [0, 1, 0, 0, 1]
+    ptr, cnt = eng_small.local_stress_ptr()
+    assert cnt == 2 and ptr
+    host = np.zeros(12)
+    eng_small.copy_local_stress(host.ctypes.data, False)
+    assert np.allclose(host[:6], out[1].stress[:]) and np.allclose(host[6:], out[4].stress[:])
