@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--sims", type=int, default=576, help="quadrature-point replicas per update()")
     ap.add_argument("--nss", type=int, default=100)
     ap.add_argument("--cells", type=int, nargs=3, default=[6, 9, 16], help="PE supercell (6 9 16 = PE-10k)")
+    ap.add_argument("--strain-set", default="balanced", choices=["balanced", "file3d", "imbalanced"],
+                    help="balanced: nts=10 for every replica (default, SURVEY 8d); file3d: x5 strains at rate 2e-4 (nts=30); "
+                         "imbalanced: eps_zz log-uniform in [1e-3,2e-2] (nts 10..100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = host all-gather, lets several ranks share one GPU in tests")
@@ -82,9 +85,11 @@ def main():
 
     def update(istep):
         nonlocal checksum
-        strains = synthetic_strains(n, lens, seed=2026 + istep)
+        strains = synthetic_strains(n, lens, seed=2026 + istep, scale=(5.0 if args.strain_set == "file3d" else 1.0),
+                                    mode=("imbalanced" if args.strain_set == "imbalanced" else "balanced"))
         first = istep == 0
-        sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=(capi.QP_NONE if first else q))
+        sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=(capi.QP_NONE if first else q),
+                              strain_rate=(2e-4 if args.strain_set == "file3d" else 1e-4))
                 for q in range(n)]
         arr = eng.strain_batch(sims, rank=rank, world=world)
         if world > 1:
@@ -141,7 +146,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n} x PE-{d['natoms']} OPLS replicas per update(), 10+{args.nss} MD steps each "
                                    "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + Ewald 1e-4 + SHAKE + NVT), persistent per-QP state",
-                       "n_sims": n, "atoms_per_replica": int(d["natoms"]), "md_steps_per_eval": 10 + args.nss,
+                       "strain_set": args.strain_set, "n_sims": n, "atoms_per_replica": int(d["natoms"]), "md_steps_per_eval": 10 + args.nss,
                        "sharding": f"sim i -> rank i % {world}", "stress_zz_checksum_Pa": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_src,

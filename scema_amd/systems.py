@@ -122,7 +122,7 @@ def build_pe10k(seed: int = 1234) -> dict:
     return build_pe(6, 9, 16, 300.0, seed)
 
 
-def synthetic_strains(n_sims: int, box_lengths, seed: int = 2026, scale: float = 1.0) -> np.ndarray:
+def synthetic_strains(n_sims: int, box_lengths, seed: int = 2026, scale: float = 1.0, mode: str = "balanced") -> np.ndarray:
     """eps_zz ~ U(1.0e-3,1.8e-3), eps_xx=eps_yy=-0.3 eps_zz, shears ~ U(-1e-4,1e-4).
 
     Returns the Angstrom-valued MDSim.strain (raw order xx,yy,zz,xy,xz,yz), i.e. true strain times
@@ -133,7 +133,10 @@ def synthetic_strains(n_sims: int, box_lengths, seed: int = 2026, scale: float =
     lx, ly, lz = box_lengths
     out = np.zeros((n_sims, 6))
     for i in range(n_sims):
-        ezz = rng.uniform(1.0e-3, 1.8e-3) * scale
+        if mode == "imbalanced":   # eps_zz log-uniform in [1e-3, 2e-2] -> nts from 10 to 100, ragged batch
+            ezz = float(np.exp(rng.uniform(np.log(1.0e-3), np.log(2.0e-2))))
+        else:
+            ezz = rng.uniform(1.0e-3, 1.8e-3) * scale
         sh = rng.uniform(-1.0e-4, 1.0e-4, 3) * scale
         out[i] = [-0.3 * ezz * lx, -0.3 * ezz * ly, ezz * lz, sh[0] * lz, sh[1] * ly, sh[2] * lx]
     return out
