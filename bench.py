@@ -72,7 +72,9 @@ def main():
     from scema_amd.systems import build_pe, synthetic_strains
 
     d = build_pe(*args.cells)
-    eng = capi.Engine(capi.default_params(device=device, profile=1))
+    # ablation knobs for kernel experiments only (never set in a reported run)
+    extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
+    eng = capi.Engine(capi.default_params(device=device, profile=1, **extra))
     eng.register_replica("g0", 1, d)
     lens = d["box"][3:6] - d["box"][:3]
     n = args.sims

@@ -352,7 +352,11 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   if (s >= S.npad) return;
   const int a = S.perm[s];
   if (a < 0) {  // pad slot: a record no real atom is ever within the list cutoff of
-    if (S.sc->rebuild) { S.xq[s] = make_double4(1.0e15, 1.0e15, 1.0e15, 0.0); S.stype[s] = 0; }
+    if (S.sc->rebuild) {
+      double *xy = (double *)S.xq + 2 * (size_t)s, *zq = (double *)S.xq + 2 * (size_t)S.npad + 2 * (size_t)s;
+      xy[0] = 1.0e15; xy[1] = 1.0e15; zq[0] = 1.0e15; zq[1] = 0.0;
+      S.stype[s] = 0;
+    }
     return;
   }
   BoxD b;
@@ -363,7 +367,9 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   r.y = S.x[3 * a + 1] - (b.h[1] * w1 + b.h[3] * w2);
   r.z = S.x[3 * a + 2] - (b.h[2] * w2);
   r.w = S.q[a];
-  S.xq[s] = r;
+  // two arrays of 16-byte halves: (x,y)[npad], (z,q)[npad]  (see md_pair.hip)
+  double *xy = (double *)S.xq + 2 * (size_t)s, *zq = (double *)S.xq + 2 * (size_t)S.npad + 2 * (size_t)s;
+  xy[0] = r.x; xy[1] = r.y; zq[0] = r.z; zq[1] = r.w;
   S.stype[s] = S.type[a];
 }
 
@@ -1114,9 +1120,14 @@ void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxb, int maxa, int
 }
 void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax) {
   if (maxk <= 0) return;
-  hipLaunchKernelGGL(k_ewald_sfac, grid2(cdiv(maxatoms, EW_ATOMS), ns), dim3(TPB), (size_t)EW_ATOMS * 3 * mmax * sizeof(double2), st, d, mmax);
+  const size_t lds_s = (size_t)EW_ATOMS * 3 * mmax * sizeof(double2), lds_f = (size_t)EWF_TPB * 3 * mmax * sizeof(double2);
+  // more than 64 KB of dynamic LDS needs an explicit opt-in (large k ranges: small cut_coul or tight accuracy)
+  static size_t optin_s = 0, optin_f = 0;
+  if (lds_s > 64 * 1024 && lds_s > optin_s) { (void)hipFuncSetAttribute((const void *)k_ewald_sfac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); optin_s = lds_s; }
+  if (lds_f > 64 * 1024 && lds_f > optin_f) { (void)hipFuncSetAttribute((const void *)k_ewald_force, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f); optin_f = lds_f; }
+  hipLaunchKernelGGL(k_ewald_sfac, grid2(cdiv(maxatoms, EW_ATOMS), ns), dim3(TPB), lds_s, st, d, mmax);
   hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
-  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), (size_t)EWF_TPB * 3 * mmax * sizeof(double2), st, d, mmax);
+  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), lds_f, st, d, mmax);
 }
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
   if (maxclus <= 0) return;

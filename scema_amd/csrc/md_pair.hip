@@ -29,6 +29,14 @@
 #define CPB (WPB * CPW)
 #define NI MD_CLUSTER
 
+// slot records are stored as two arrays of 16-byte halves, (x,y)[npad] then (z,q)[npad]: a wave's gather
+// instruction then touches 16 B per lane at stride 16 (half the cache lines of 32-byte records read as two
+// 16-byte halves at stride 32)
+#define XQ_X(S, s) (((const double *)(S).xq)[2 * (size_t)(s)])
+#define XQ_Y(S, s) (((const double *)(S).xq)[2 * (size_t)(s) + 1])
+#define XQ_Z(S, s) (((const double *)(S).xq)[2 * (size_t)(S).npad + 2 * (size_t)(s)])
+#define XQ_Q(S, s) (((const double *)(S).xq)[2 * (size_t)(S).npad + 2 * (size_t)(s) + 1])
+
 #define GLOBAL_AS __attribute__((address_space(1)))
 template <class T>
 __device__ __forceinline__ const GLOBAL_AS T *as_global(const T *p) {
@@ -92,7 +100,8 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
   const int maxrow = S.maxneigh;
   BoxD b;
   box_derive(sc.box, b);
-  const GLOBAL_AS double *xq = as_global((const double *)S.xq);
+  const GLOBAL_AS double *xq = as_global((const double *)S.xq);               // (x,y) halves
+  const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;                          // (z,q) halves
   const double ra2 = S.seg_a2, rb2 = S.seg_b2;
   unsigned long long npairs = 0, nrowent = 0;
   int nmax = 0, over = 0;
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
 #pragma unroll
     for (int a = 0; a < NI; a++) {
       ci.atom[a] = S.perm[s0slot + a];
-      ci.x[a] = S.xq[s0slot + a].x; ci.y[a] = S.xq[s0slot + a].y; ci.z[a] = S.xq[s0slot + a].z;
+      ci.x[a] = XQ_X(S, s0slot + a); ci.y[a] = XQ_Y(S, s0slot + a); ci.z[a] = XQ_Z(S, s0slot + a);
     }
     if (ci.atom[0] < 0) {  // empty cluster (pad only)
       if (lane == 0) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
             int mask = 0;
             double rmin = 1.0e300;
             if (j < je) {
-              const double xj = xq[4 * (size_t)j] + sx, yj = xq[4 * (size_t)j + 1] + sy, zj = xq[4 * (size_t)j + 2] + sz;
+              const double xj = xq[2 * (size_t)j] + sx, yj = xq[2 * (size_t)j + 1] + sy, zj = zq[2 * (size_t)j] + sz;
               int aj = -2;
 #pragma unroll
               for (int a = 0; a < NI; a++) {
@@ -227,7 +236,8 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
   __syncthreads();
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const GLOBAL_AS double *xq = as_global((const double *)S.xq);
+  const GLOBAL_AS double *xq = as_global((const double *)S.xq);   // (x,y) halves
+  const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;              // (z,q) halves
   const GLOBAL_AS int *stype = as_global(S.stype);
   const double g = S.g_ewald, g2u = g * g * S.coul_uscale;
   const double cutc2 = S.cut_coul2, cutl2 = S.cut_lj2;
@@ -246,8 +256,8 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
     int ti[NI];
 #pragma unroll
     for (int a = 0; a < NI; a++) {
-      xi[a] = S.xq[s0 + a].x; yi[a] = S.xq[s0 + a].y; zi[a] = S.xq[s0 + a].z;
-      qi[a] = MD_QQRD2E * S.xq[s0 + a].w;
+      xi[a] = XQ_X(S, s0 + a); yi[a] = XQ_Y(S, s0 + a); zi[a] = XQ_Z(S, s0 + a);
+      qi[a] = MD_QQRD2E * XQ_Q(S, s0 + a);
       ti[a] = S.stype[s0 + a] * nt;
       fx[a] = fy[a] = fz[a] = 0.0;
     }
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
     int tn;
     {
       const size_t j = (size_t)(e_n & MD_JMASK);
-      xn0 = xq[4 * j]; xn1 = xq[4 * j + 1]; xn2 = xq[4 * j + 2]; xn3 = xq[4 * j + 3];
+      xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
       tn = stype[j];
     }
     for (int k0 = 0; k0 < nn; k0 += 64) {
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
         const int kn = k0 + 64 + lane;
         e_n = (kn < nn) ? ROW_AT(kn) : 0;
         const size_t j = (size_t)(e_n & MD_JMASK);
-        xn0 = xq[4 * j]; xn1 = xq[4 * j + 1]; xn2 = xq[4 * j + 2]; xn3 = xq[4 * j + 3];
+        xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
         tn = stype[j];
       }
       const int mask = (e >> MD_MASK_SHIFT) & 0xF;  // 0 for the padding of the last row
