@@ -26,6 +26,13 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
   c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
 }
 __device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// 1/sqrt(x) to 1 ulp in 6 instructions (hardware estimate + one third-order correction); replaces the
+// sqrt + divide pairs of the textbook formulas
+__device__ __forceinline__ double rsq64(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y, e * fma(0.375, e, 0.5), y);
+}
 
 // PARTS: also split virial / energy per part (parity hook); otherwise one lumped virial
 template <bool PARTS>
@@ -56,9 +63,11 @@ __global__ __launch_bounds__(TPB) void k_bonded_atom(const SimDev *__restrict__ 
         const double K = S.bond_cf[2 * m], r0 = S.bond_cf[2 * m + 1];
         double d[3] = {x[3 * i1] - x[3 * i2], x[3 * i1 + 1] - x[3 * i2 + 1], x[3 * i1 + 2] - x[3 * i2 + 2]};
         minimg(b, d[0], d[1], d[2]);
-        const double r = sqrt(dot3(d, d));
+        const double rsq = dot3(d, d);
+        const double rinv = (rsq > 0.0) ? rsq64(rsq) : 0.0;
+        const double r = rsq * rinv;
         const double dr = r - r0, rk = K * dr;
-        const double fb = (r > 0.0) ? -2.0 * rk / r : 0.0;
+        const double fb = -2.0 * rk * rinv;
         const double sgn = (role == 0) ? 1.0 : -1.0;
         for (int k = 0; k < 3; k++) fo[k] = sgn * d[k] * fb;
         if (role == 0) { vt(v, d, fo); en = rk * dr; }
@@ -70,14 +79,14 @@ __global__ __launch_bounds__(TPB) void k_bonded_atom(const SimDev *__restrict__ 
         for (int k = 0; k < 3; k++) { d1[k] = x[3 * i1 + k] - x[3 * i2 + k]; d2[k] = x[3 * i3 + k] - x[3 * i2 + k]; }
         minimg(b, d1[0], d1[1], d1[2]); minimg(b, d2[0], d2[1], d2[2]);
         const double rsq1 = dot3(d1, d1), rsq2 = dot3(d2, d2);
-        const double r1 = sqrt(rsq1), r2 = sqrt(rsq2);
-        double c = dot3(d1, d2) / (r1 * r2);
+        const double r1i = rsq64(rsq1), r2i = rsq64(rsq2);
+        double c = dot3(d1, d2) * (r1i * r2i);
         c = fmin(1.0, fmax(-1.0, c));
-        double sn = sqrt(1.0 - c * c);
-        if (sn < 0.001) sn = 0.001;
+        const double s2 = 1.0 - c * c;
+        const double sni = (s2 > 1.0e-6) ? rsq64(s2) : 1000.0;  // 1/sin(theta), sin clamped at 0.001
         const double dth = acos(c) - th0, tk = K * dth;
-        const double a = -2.0 * tk / sn;
-        const double a11 = a * c / rsq1, a12 = -a / (r1 * r2), a22 = a * c / rsq2;
+        const double a = -2.0 * tk * sni;
+        const double a11 = a * c * (r1i * r1i), a12 = -a * (r1i * r2i), a22 = a * c * (r2i * r2i);
         double f1[3], f3[3];
         for (int k = 0; k < 3; k++) { f1[k] = a11 * d1[k] + a12 * d2[k]; f3[k] = a22 * d2[k] + a12 * d1[k]; }
         if (role == 0) { for (int k = 0; k < 3; k++) fo[k] = f1[k]; vt(v, d1, f1); en = tk * dth; }
@@ -97,11 +106,13 @@ __global__ __launch_bounds__(TPB) void k_bonded_atom(const SimDev *__restrict__ 
         double A[3], B[3];
         cross3(F, G, A); cross3(H, G, B);
         const double a2 = dot3(A, A), b2 = dot3(B, B);
-        const double ia = 1.0 / sqrt(a2), ib = 1.0 / sqrt(b2);
-        double c = dot3(A, B) * ia * ib;
+        const double ia = rsq64(a2), ib = rsq64(b2);
+        const double iab = ia * ib;
+        double c = dot3(A, B) * iab;
         c = fmin(1.0, fmax(-1.0, c));
+        const double ca = c * (ia * ia), cb = c * (ib * ib);
         double gA[3], gB[3];
-        for (int k = 0; k < 3; k++) { gA[k] = B[k] * ia * ib - c * A[k] / a2; gB[k] = A[k] * ia * ib - c * B[k] / b2; }
+        for (int k = 0; k < 3; k++) { gA[k] = B[k] * iab - ca * A[k]; gB[k] = A[k] * iab - cb * B[k]; }
         double dEdc;
         if (kind == AT_DIHEDRAL) {
           const double *K = S.dihedral_cf + 4 * m;

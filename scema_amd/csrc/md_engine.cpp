@@ -520,6 +520,24 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
   return maxerr;
 }
 
+struct PolyFit { int n; double uscale, err; double c[MD_MAXPOLY]; };
+static std::map<long, PolyFit> &poly_cache() { static std::map<long, PolyFit> m; return m; }
+static double cached_coul_poly(scema_md_engine *, double g, double rc, double *poly, int *npoly, double *uscale) {
+  if (g <= 0.0) return fit_coul_poly(g, rc, poly, npoly, uscale);
+  const double x = g * rc;
+  const long key = (long)std::ceil(x * 16.0);          // x rounded up to 1/16
+  auto it = poly_cache().find(key);
+  if (it == poly_cache().end()) {
+    PolyFit f;
+    f.err = fit_coul_poly(key / 16.0, 1.0, f.c, &f.n, &f.uscale);
+    it = poly_cache().emplace(key, f).first;
+  }
+  std::memcpy(poly, it->second.c, sizeof(double) * MD_MAXPOLY);
+  *npoly = it->second.n;
+  *uscale = it->second.uscale;
+  return it->second.err;
+}
+
 // fix-deform box at time t (same expression as k_post)
 void deform_box(const double *box0, const double *rates, double t, double *out) {
   for (int d = 0; d < 3; d++) {
@@ -607,7 +625,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
   e->h_sims.assign(ns, SimDev());
   int maxrow = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
-  std::vector<int> kn_all;
+  std::vector<std::vector<int>> kn_stage;
+  kn_stage.reserve(ns);
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
@@ -646,7 +665,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     for (int d = 0; d < 3; d++) S.kmaxd[d] = ew.kmaxd[d];
     S.g_ewald = ew.g;
     {
-      const double perr = fit_coul_poly(ew.g, P.cut_coul, S.coul_poly, &S.coul_npoly, &S.coul_uscale);
+      // H depends on u only: fit once per (rounded-up) range and share it between simulations
+      const double perr = cached_coul_poly(e, ew.g, P.cut_coul, S.coul_poly, &S.coul_npoly, &S.coul_uscale);
       if (perr > 1e-12) return fail(e, SCEMA_MD_ERR_ARG, "real-space Ewald polynomial fit error %.3e too large (g*rc = %.3f)", perr, ew.g * P.cut_coul);
     }
     {
@@ -709,8 +729,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
     S.kn = sl.kn.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;
-    if (S.nk > 0) HIPCHK(hipMemcpyAsync(sl.kn.p, ew.kn.data(), ew.kn.size() * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));  // ew.kn is a local
+    if (S.nk > 0) {
+      kn_stage.push_back(std::move(ew.kn));  // must stay alive until the copies have been consumed
+      HIPCHK(hipMemcpyAsync(sl.kn.p, kn_stage.back().data(), kn_stage.back().size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
     e->h_sims[pos] = S;
     maxatoms = std::max(maxatoms, S.natoms); maxpad = std::max(maxpad, S.npad); maxcells = std::max(maxcells, S.ncells);
     maxk = std::max(maxk, S.nk);
