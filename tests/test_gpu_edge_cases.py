@@ -1,0 +1,132 @@
+"""GPU edge cases of the hot path: heterogeneous batches, uncharged systems (no k-space), tiny systems,
+sampling-window rules, and the error paths the reference handles with exit(1)/assert."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+KW = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+
+
+def relerr(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+def _lens(d):
+    return d["box"][3:6] - d["box"][:3]
+
+
+def test_heterogeneous_batch_two_materials(small_pe):
+    """One update() with replicas of different size and topology: each equals its own single run and the oracle."""
+    from scema_amd import capi
+    from scema_amd.systems import build_pe
+    from oracle import pyoracle as po
+    big = build_pe(3, 4, 6, jitter=0.04, seed=21)            # 864 atoms, different box
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("a", 1, small_pe)
+    eng.register_replica("b", 1, big)
+    sa = np.array([-3e-4, -3e-4, 1.0e-3, 0, 0, 0]) * np.array([*_lens(small_pe), _lens(small_pe)[2], _lens(small_pe)[1], _lens(small_pe)[0]])
+    sb = np.array([4e-4, -2e-4, -1.5e-3, 0, 0, 0]) * np.array([*_lens(big), _lens(big)[2], _lens(big)[1], _lens(big)[0]])
+    sims = [capi.make_sim(0, "a", 1, sa, nss=10, most_recent=capi.QP_NONE, material=0),
+            capi.make_sim(1, "b", 1, sb, nss=10, most_recent=capi.QP_NONE, material=1),
+            capi.make_sim(2, "a", 1, 2 * sa, nss=10, most_recent=capi.QP_NONE, material=0)]
+    out = eng.strain_batch(sims)
+    got = [np.array(o.stress[:]) for o in out]
+    for d, st, g in ((small_pe, sa, got[0]), (big, sb, got[1]), (small_pe, 2 * sa, got[2])):
+        exp, _ = po.Oracle(d, po.default_params(**KW)).eval(st, 2.0, 300.0, 1e-4, 10)
+        assert relerr(g, exp) < 1e-6
+    eng.close()
+
+
+def _fcc(n_cell=4, a=5.3, charges=False):
+    basis = [(0, 0, 0), (.5, .5, 0), (.5, 0, .5), (0, .5, .5)]
+    x = np.array([[(i + b[0]) * a, (j + b[1]) * a, (k + b[2]) * a] for i in range(n_cell) for j in range(n_cell) for k in range(n_cell) for b in basis])
+    rng = np.random.default_rng(3)
+    x += rng.normal(0, 0.05, x.shape)
+    n = len(x); L = n_cell * a
+    z = lambda *s: np.zeros(s, np.int32)
+    m = 39.95
+    v = rng.normal(0, 1, (n, 3)) * np.sqrt(0.0019872067 * 80.0 / (m * 48.88821291 ** 2)); v -= v.mean(0)
+    return dict(natoms=n, ntypes=1, type=z(n), charge=np.zeros(n), mass=np.array([m]), eps=np.array([[0.238]]), sigma=np.array([[3.405]]),
+                bonds=z(0, 2), bond_type=z(0), bond_coeff=np.zeros((0, 2)), angles=z(0, 3), angle_type=z(0), angle_coeff=np.zeros((0, 2)),
+                dihedrals=z(0, 4), dihedral_type=z(0), dihedral_coeff=np.zeros((0, 4)), impropers=z(0, 4), improper_type=z(0),
+                improper_coeff=np.zeros((0, 2)), special_lj=np.ones(3), special_coul=np.ones(3),
+                box=np.array([0, 0, 0, L, L, L, 0, 0, 0.0]), x=x, v=v)
+
+
+def test_uncharged_atomic_system_no_kspace_no_shake():
+    """LJ argon: q = 0 everywhere (g_ewald = 0, no k-vectors), no bonds, no SHAKE clusters."""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    d = _fcc()
+    kw = dict(cut_lj=8.5, cut_coul=8.5, skin=2.0)
+    eng = capi.Engine(capi.default_params(**kw))
+    eng.register_replica("ar", 1, d)
+    f, e, w, info = eng.debug_compute("ar", 1)
+    o = po.Oracle(d, po.default_params(**kw)); o.setup(False)
+    fo, eo, wo = o.compute()
+    assert info["nk"] == 0 and info["nclus"] == 0 and info["npairs"] == o.npairs
+    assert relerr(f, fo) < 1e-11 and abs(e[0] - eo[0]) < 1e-10 * abs(eo[0]) and relerr(w[0], wo[0]) < 1e-10
+    L = d["box"][3]
+    st = np.array([2e-4 * L, 2e-4 * L, -5e-4 * L, 1e-4 * L, 0, 0])
+    got = np.array(eng.strain_batch([capi.make_sim(0, "ar", 1, st, nss=20, temperature=80.0, most_recent=capi.QP_NONE)])[0].stress[:])
+    exp, _ = o.eval(st, 2.0, 80.0, 1e-4, 20)
+    assert relerr(got, exp) < 1e-6
+    eng.close()
+
+
+def test_two_atoms_closed_form():
+    """Smallest possible system: two LJ+coulomb atoms in a 60 A box; force equals the analytic pair force."""
+    from scema_amd import capi
+    r = 4.2
+    z = lambda *s: np.zeros(s, np.int32)
+    d = dict(natoms=2, ntypes=1, type=z(2), charge=np.array([0.3, -0.3]), mass=np.array([12.0]), eps=np.array([[0.1]]), sigma=np.array([[3.4]]),
+             bonds=z(0, 2), bond_type=z(0), bond_coeff=np.zeros((0, 2)), angles=z(0, 3), angle_type=z(0), angle_coeff=np.zeros((0, 2)),
+             dihedrals=z(0, 4), dihedral_type=z(0), dihedral_coeff=np.zeros((0, 4)), impropers=z(0, 4), improper_type=z(0),
+             improper_coeff=np.zeros((0, 2)), special_lj=np.ones(3), special_coul=np.ones(3),
+             box=np.array([0, 0, 0, 60, 60, 60, 0, 0, 0.0]), x=np.array([[30.0, 30, 30], [30 + r, 30, 30]]), v=np.zeros((2, 3)))
+    eng = capi.Engine(capi.default_params(shake_mass=0.0))
+    eng.register_replica("two", 1, d)
+    f, e, w, info = eng.debug_compute("two", 1)
+    from oracle import pyoracle as po
+    o = po.Oracle(d, po.default_params(shake_mass=0.0)); o.setup(False)
+    fo, eo, wo = o.compute()
+    assert np.abs(f - fo).max() < 1e-11 * np.abs(fo).max()
+    s6 = (3.4 / r) ** 6
+    assert abs(e[0] - 4 * 0.1 * (s6 * s6 - s6)) < 1e-13
+    eng.close()
+
+
+def test_sampling_window_rule(small_pe):
+    """nss = 25: nav = 2, 12 windows -> the average runs over steps 1..24 (in.homogenization.lammps:57-59)."""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    eng.set_state(1, "pe", 1, small_pe["box"], small_pe["x"], small_pe["v"])
+    pavg = eng.debug_run("pe", 1, 25, 1.0, 300.0, qp=1, sample=True)
+    o = po.Oracle(small_pe, po.default_params(**KW))
+    pavg_o, _ = o.run(25, 1.0, 300.0, sample=True)
+    assert relerr(pavg, pavg_o) < 1e-8
+    eng.close()
+
+
+def test_error_paths(small_pe):
+    from scema_amd import capi
+    eng = capi.Engine()                                           # reference cutoffs: 2*(12+2) = 28 A > 14.8 A box
+    eng.register_replica("pe", 1, small_pe)
+    lens = _lens(small_pe)
+    st = np.array([0, 0, 1e-3 * lens[2], 0, 0, 0])
+    with pytest.raises(capi.EngineError, match="box width"):
+        eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    eng.close()
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    with pytest.raises(capi.EngineError, match="flip|box width"):   # a shear that tilts the box past L/2 (or squeezes it first)
+        eng.strain_batch([capi.make_sim(0, "pe", 1, np.array([0, 0, 0, 0.9 * lens[0] * lens[2] / lens[1], 0, 0]), nss=10,
+                                        most_recent=capi.QP_NONE, strain_rate=1e-2)])
+    with pytest.raises(capi.EngineError, match="not registered"):
+        eng.strain_batch([capi.make_sim(0, "nomat", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    with pytest.raises(capi.EngineError, match="reax"):           # config 5 is a 'next' row: explicit, not silent
+        eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10, most_recent=capi.QP_NONE, force_field="reax")])
+    eng.close()
