@@ -122,6 +122,23 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
     GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)cl * maxrow;
     const int cell = S.cell_of[ci.atom[0]];
     const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
+    // bounding sphere of the cluster's real atoms: one test rejects a candidate for all four atoms
+    double bx = 0.0, by = 0.0, bz = 0.0, brad2 = 0.0;
+    {
+      int nreal = 0;
+#pragma unroll
+      for (int a = 0; a < NI; a++)
+        if (ci.atom[a] >= 0) { bx += ci.x[a]; by += ci.y[a]; bz += ci.z[a]; nreal++; }
+      bx /= nreal; by /= nreal; bz /= nreal;
+#pragma unroll
+      for (int a = 0; a < NI; a++)
+        if (ci.atom[a] >= 0) {
+          const double dx = ci.x[a] - bx, dy = ci.y[a] - by, dz = ci.z[a] - bz;
+          brad2 = fmax(brad2, dx * dx + dy * dy + dz * dz);
+        }
+    }
+    const double breach = sqrt(S.rlist2) + sqrt(brad2) * 1.0000001 + 1.0e-9;
+    const double breach2 = breach * breach;
     int nA = 0, nB = 0, nC = 0;
     for (int o2 = -S.mst[2]; o2 <= S.mst[2]; o2++) {
       int a2 = c2 + o2, s2 = 0;
@@ -157,6 +174,8 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
             if (j < je) {
               const double xj = xq[2 * (size_t)j] + sx, yj = xq[2 * (size_t)j + 1] + sy, zj = zq[2 * (size_t)j] + sz;
               int aj = -2;
+              const double cx = bx - xj, cy = by - yj, cz = bz - zj;
+              if (cx * cx + cy * cy + cz * cz < breach2)
 #pragma unroll
               for (int a = 0; a < NI; a++) {
                 const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
