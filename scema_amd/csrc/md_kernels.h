@@ -11,7 +11,6 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad, int ma
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int vir, int eng, int npoly);
-void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxb, int maxa, int maxd, int maxi, int maxs);
 // atom-centric, atomic-free bonded terms + special pairs; parts != 0: per-part virial/energy (parity hook)
 void mdk_bonded_atom(hipStream_t st, const SimDev *d, int ns, int maxatoms, int parts);
 void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax);

@@ -10,8 +10,8 @@
 // ELASTIC/in.homogenization.lammps:57-64):
 //   k_pre / k_initial_integrate / k_final_integrate / k_post ... fix nvt (NH chain) + Verlet (K9)
 //   k_bin / k_cell_scan / k_cell_fill / k_cell_sort / k_pack / k_neigh_build ... K1
-//   k_pair ............... lj/cut/coul/long real space, force + virial (K2, the roofline kernel)
-//   k_term<...> .......... bond/angle harmonic, dihedral opls, improper harmonic, special pairs (K4-K7,S4)
+//   (md_pair.hip)   k_neigh_build, k_pair ... K1, K2 (the roofline kernel)
+//   (md_bonded.hip) k_bonded_atom ........... K4-K7, S4
 //   k_ewald_* ............ reciprocal Ewald sum (K3)
 //   k_shake .............. fix shake (K8)
 //   k_remap .............. fix deform ... remap x (K10)
@@ -22,56 +22,6 @@
 #include "md_kernels.h"
 #include "md_types.h"
 
-#if 0  // moved to md_device.h
-struct BoxD {
-  double lo[3], h[6], hinv[6], vol;
-};
-
-__device__ __forceinline__ void box_derive(const double *b, BoxD &o) {
-  o.lo[0] = b[0]; o.lo[1] = b[1]; o.lo[2] = b[2];
-  o.h[0] = b[3] - b[0]; o.h[1] = b[4] - b[1]; o.h[2] = b[5] - b[2];
-  o.h[3] = b[8]; o.h[4] = b[7]; o.h[5] = b[6];
-  o.hinv[0] = 1.0 / o.h[0]; o.hinv[1] = 1.0 / o.h[1]; o.hinv[2] = 1.0 / o.h[2];
-  o.hinv[3] = -o.h[3] / (o.h[1] * o.h[2]);
-  o.hinv[4] = (o.h[3] * o.h[5] - o.h[1] * o.h[4]) / (o.h[0] * o.h[1] * o.h[2]);
-  o.hinv[5] = -o.h[5] / (o.h[0] * o.h[1]);
-  o.vol = o.h[0] * o.h[1] * o.h[2];
-}
-
-__device__ __forceinline__ void minimg(const BoxD &b, double &dx, double &dy, double &dz) {
-  double l0 = b.hinv[0] * dx + b.hinv[5] * dy + b.hinv[4] * dz;
-  double l1 = b.hinv[1] * dy + b.hinv[3] * dz;
-  double l2 = b.hinv[2] * dz;
-  l0 -= rint(l0); l1 -= rint(l1); l2 -= rint(l2);
-  dx = b.h[0] * l0 + b.h[5] * l1 + b.h[4] * l2;
-  dy = b.h[1] * l1 + b.h[3] * l2;
-  dz = b.h[2] * l2;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-
-// block-wide sum of NV values per thread, result atomically added to dst[0..NV)
-template <int NV>
-__device__ __forceinline__ void block_atomic_add(double (&vals)[NV], double *dst, double *lds /* >= NV*(TPB/64) */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    double s = wave_sum(vals[k]);
-    if (lane == 0) lds[k * (TPB / 64) + wave] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < NV) {
-    double s = 0.0;
-    for (int w = 0; w < TPB / 64; w++) s += lds[threadIdx.x * (TPB / 64) + w];
-    if (s != 0.0) atomicAdd(&dst[threadIdx.x], s);
-  }
-}
-#endif
 
 // ------------------------------------------------------------------------------------------
 // Nose-Hoover chain half step (fix nvt; one sub-cycle, no drag).  Returns the velocity factor.
@@ -373,339 +323,11 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   S.stype[s] = S.type[a];
 }
 
-// k_neigh_build and k_pair live in md_pair.hip (round-1 first versions kept below for reference)
-#if 0
-__global__ __launch_bounds__(TPB) void k_neigh_build(const SimDev *sims) {
-  const SimDev &S = sims[blockIdx.y];
-  SimScalars &sc = *S.sc;
-  if (!sc.rebuild) return;
-  const int i = blockIdx.x * TPB + threadIdx.x;
-  __shared__ double s_red[TPB / 64];
-  int n = 0;
-  if (i < S.natoms) {
-    BoxD b;
-    box_derive(sc.box, b);
-    const double4 xi = S.xq[i];
-    const int ai = S.perm[i];
-    const int ci = S.cell_of[ai];
-    const int c0 = ci % S.nc[0], c1 = (ci / S.nc[0]) % S.nc[1], c2 = ci / (S.nc[0] * S.nc[1]);
-    const int exb = S.ex_start[ai], exe = S.ex_start[ai + 1];
-    for (int o2 = -S.mst[2]; o2 <= S.mst[2]; o2++) {
-      int a2 = c2 + o2, s2 = 0;
-      while (a2 < 0) { a2 += S.nc[2]; s2 -= 1; }
-      while (a2 >= S.nc[2]) { a2 -= S.nc[2]; s2 += 1; }
-      for (int o1 = -S.mst[1]; o1 <= S.mst[1]; o1++) {
-        int a1 = c1 + o1, s1 = 0;
-        while (a1 < 0) { a1 += S.nc[1]; s1 -= 1; }
-        while (a1 >= S.nc[1]) { a1 -= S.nc[1]; s1 += 1; }
-        for (int o0 = -S.mst[0]; o0 <= S.mst[0]; o0++) {
-          int a0 = c0 + o0, s0 = 0;
-          while (a0 < 0) { a0 += S.nc[0]; s0 -= 1; }
-          while (a0 >= S.nc[0]) { a0 -= S.nc[0]; s0 += 1; }
-          if (s0 < -1 || s0 > 1 || s1 < -1 || s1 > 1 || s2 < -1 || s2 > 1) continue;
-          const double sx = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
-          const double sy = b.h[1] * s1 + b.h[3] * s2;
-          const double sz = b.h[2] * s2;
-          const int code = ((s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1)) << MD_JBITS;
-          const int cj = (a2 * S.nc[1] + a1) * S.nc[0] + a0;
-          const int jb = S.cell_start[cj], je = S.cell_start[cj + 1];
-          for (int j = jb; j < je; j++) {
-            const double4 xj = S.xq[j];
-            const double dx = xi.x - xj.x - sx, dy = xi.y - xj.y - sy, dz = xi.z - xj.z - sz;
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 >= S.rlist2) continue;
-            if (j == i && code == (13 << MD_JBITS)) continue;
-            if (r2 < S.excl_cut2) {
-              const int aj = S.perm[j];
-              bool ex = false;
-              for (int e = exb; e < exe; e++) ex |= (S.ex_list[e] == aj);
-              if (ex) continue;
-            }
-            if (n < S.maxneigh) S.neigh[(size_t)n * S.npad + i] = code | j;
-            n++;
-          }
-        }
-      }
-    }
-    S.numneigh[i] = (n < S.maxneigh) ? n : S.maxneigh;
-    if (n > S.maxneigh) atomicOr(&sc.overflow, 1);
-    atomicMax(&sc.maxneigh_seen, n);
-  } else if (i < S.npad) {
-    S.numneigh[i] = 0;
-  }
-  // statistics: stored entries
-  double cnt = wave_sum((double)n);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0;
-    for (int w = 0; w < TPB / 64; w++) t += s_red[w];
-    atomicAdd(&sc.nentries, (unsigned long long)t);
-  }
-}
+// k_neigh_build and k_pair live in md_pair.hip, the bonded terms in md_bonded.hip
 
-// ------------------------------------------------------------------------------------------
-// k_pair : lj/cut/coul/long real-space force (+virial, +energy) on the full list.
-//   one thread per slot i; neighbour rows are read coalesced (row k of the transposed list);
-//   j records are 32-byte gathers served by L2 (slots are cell-sorted); the force is written
-//   once per atom (no atomics); the virial is reduced wave -> block -> one atomic per block.
-// ------------------------------------------------------------------------------------------
-template <bool EV>
-__global__ __launch_bounds__(TPB) void k_pair(const SimDev *sims) {
-  const SimDev &S = sims[blockIdx.y];
-  SimScalars &sc = *S.sc;
-  __shared__ double s_shift[27 * 3];
-  __shared__ double s_lj[4 * MD_MAXTYPES * MD_MAXTYPES];
-  __shared__ double s_red[14 * (TPB / 64)];
-  if (threadIdx.x < 27) {
-    BoxD b;
-    box_derive(sc.box, b);
-    const int s0 = threadIdx.x % 3 - 1, s1 = (threadIdx.x / 3) % 3 - 1, s2 = threadIdx.x / 9 - 1;
-    s_shift[3 * threadIdx.x + 0] = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
-    s_shift[3 * threadIdx.x + 1] = b.h[1] * s1 + b.h[3] * s2;
-    s_shift[3 * threadIdx.x + 2] = b.h[2] * s2;
-  }
-  const int nt = S.ntypes;
-  for (int k = threadIdx.x; k < 4 * nt * nt; k += TPB) s_lj[k] = S.lj[k];
-  __syncthreads();
-  const int i = blockIdx.x * TPB + threadIdx.x;
-  double fx = 0, fy = 0, fz = 0;
-  double acc[14];
-#pragma unroll
-  for (int k = 0; k < 14; k++) acc[k] = 0.0;  // vlj[6], vcoul[6], elj, ecoul
-  if (i < S.natoms) {
-    const double4 xi = S.xq[i];
-    const int ti = S.stype[i];
-    const int nn = S.numneigh[i];
-    const double g = S.g_ewald;
-    const double qi = MD_QQRD2E * xi.w;
-    const int *nb = S.neigh + i;
-    const size_t stride = S.npad;
-    for (int k = 0; k < nn; k++) {
-      const int e = nb[(size_t)k * stride];
-      const int j = e & MD_JMASK;
-      const int c = ((unsigned)e) >> MD_JBITS;
-      const double4 xj = S.xq[j];
-      const double dx = xi.x - xj.x - s_shift[3 * c], dy = xi.y - xj.y - s_shift[3 * c + 1],
-                   dz = xi.z - xj.z - s_shift[3 * c + 2];
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq >= S.cut_lj2 && rsq >= S.cut_coul2) continue;
-      const double r2inv = 1.0 / rsq;
-      double flj = 0.0, fc = 0.0;
-      if (rsq < S.cut_coul2) {
-        const double r = sqrt(rsq);
-        const double grij = g * r;
-        const double expm2 = exp(-grij * grij);
-        const double erfcv = erfc(grij);
-        const double pref = qi * xj.w / r;
-        fc = pref * (erfcv + MD_EWALD_F * grij * expm2) * r2inv;
-        if (EV) acc[13] += pref * erfcv;
-      }
-      if (rsq < S.cut_lj2) {
-        const int tt = ti * nt + S.stype[j];
-        const double r6inv = r2inv * r2inv * r2inv;
-        flj = r6inv * (s_lj[tt] * r6inv - s_lj[nt * nt + tt]) * r2inv;
-        if (EV) acc[12] += r6inv * (s_lj[2 * nt * nt + tt] * r6inv - s_lj[3 * nt * nt + tt]);
-      }
-      const double fp = flj + fc;
-      fx += dx * fp; fy += dy * fp; fz += dz * fp;
-      if (EV) {
-        acc[0] += dx * dx * flj; acc[1] += dy * dy * flj; acc[2] += dz * dz * flj;
-        acc[3] += dx * dy * flj; acc[4] += dx * dz * flj; acc[5] += dy * dz * flj;
-        acc[6] += dx * dx * fc; acc[7] += dy * dy * fc; acc[8] += dz * dz * fc;
-        acc[9] += dx * dy * fc; acc[10] += dx * dz * fc; acc[11] += dy * dz * fc;
-      }
-    }
-    const int a = S.perm[i];
-    S.f[3 * a] = fx; S.f[3 * a + 1] = fy; S.f[3 * a + 2] = fz;
-  }
-  if (EV) {
-    // full list: every pair visited twice
-#pragma unroll
-    for (int k = 0; k < 14; k++) acc[k] *= 0.5;
-    double v6[6], e1[1];
-    for (int k = 0; k < 6; k++) v6[k] = acc[k];
-    block_atomic_add<6>(v6, sc.vir + P_LJ * 6, s_red);
-    for (int k = 0; k < 6; k++) v6[k] = acc[6 + k];
-    block_atomic_add<6>(v6, sc.vir + P_COUL * 6, s_red);
-    e1[0] = acc[12];
-    block_atomic_add<1>(e1, sc.eng + P_LJ, s_red);
-    e1[0] = acc[13];
-    block_atomic_add<1>(e1, sc.eng + P_COUL, s_red);
-  }
-}
-#endif
-
-// ------------------------------------------------------------------------------------------
-// bonded terms and special pairs : one thread per term, f64 atomics into f
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fadd(double *f, int i, double x, double y, double z) {
-  atomicAdd(&f[3 * i], x); atomicAdd(&f[3 * i + 1], y); atomicAdd(&f[3 * i + 2], z);
-}
+__device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void vt(double *v, double ax, double ay, double az, double fx, double fy, double fz) {
   v[0] += ax * fx; v[1] += ay * fy; v[2] += az * fz; v[3] += ax * fy; v[4] += ax * fz; v[5] += ay * fz;
-}
-__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
-  c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
-}
-__device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-
-// torsion geometry shared by dihedral opls and improper harmonic:
-// F=r1-r2, G=r2-r3, H=r4-r3, A=FxG, B=HxG, c=A.B/(|A||B|) ; dc[k] = d c / d r_k
-__device__ double torsion_cos(const BoxD &b, const double *x, const int *at, double *F, double *G, double *H, double dc[4][3]) {
-  for (int k = 0; k < 3; k++) {
-    F[k] = x[3 * at[0] + k] - x[3 * at[1] + k];
-    G[k] = x[3 * at[1] + k] - x[3 * at[2] + k];
-    H[k] = x[3 * at[3] + k] - x[3 * at[2] + k];
-  }
-  minimg(b, F[0], F[1], F[2]); minimg(b, G[0], G[1], G[2]); minimg(b, H[0], H[1], H[2]);
-  double A[3], B[3];
-  cross3(F, G, A); cross3(H, G, B);
-  const double a2 = dot3(A, A), b2 = dot3(B, B);
-  const double ia = 1.0 / sqrt(a2), ib = 1.0 / sqrt(b2);
-  double c = dot3(A, B) * ia * ib;
-  c = fmin(1.0, fmax(-1.0, c));
-  double gA[3], gB[3];
-  for (int k = 0; k < 3; k++) {
-    gA[k] = B[k] * ia * ib - c * A[k] / a2;
-    gB[k] = A[k] * ia * ib - c * B[k] / b2;
-  }
-  double GxgA[3], GxgB[3], gAxF[3], gBxH[3];
-  cross3(G, gA, GxgA); cross3(G, gB, GxgB); cross3(gA, F, gAxF); cross3(gB, H, gBxH);
-  for (int k = 0; k < 3; k++) {
-    dc[0][k] = GxgA[k];
-    dc[3][k] = GxgB[k];
-    dc[1][k] = -GxgA[k] + gAxF[k] + gBxH[k];
-    dc[2][k] = -(gAxF[k] + gBxH[k]) - GxgB[k];
-  }
-  return c;
-}
-
-enum { T_BOND = 0, T_ANGLE = 1, T_DIHEDRAL = 2, T_IMPROPER = 3, T_SPECIAL = 4 };
-
-template <int T>
-__global__ __launch_bounds__(TPB) void k_term(const SimDev *sims) {
-  const SimDev &S = sims[blockIdx.y];
-  SimScalars &sc = *S.sc;
-  __shared__ double s_red[8 * (TPB / 64)];
-  int nterm;
-  if (T == T_BOND) nterm = S.use_shake ? S.nbonds_noshake : S.nbonds;
-  else if (T == T_ANGLE) nterm = S.nangles;
-  else if (T == T_DIHEDRAL) nterm = S.ndihedrals;
-  else if (T == T_IMPROPER) nterm = S.nimpropers;
-  else nterm = S.nspecial;
-  if ((int)(blockIdx.x * TPB) >= nterm) return;
-  const int m = blockIdx.x * TPB + threadIdx.x;
-  double v[7] = {0, 0, 0, 0, 0, 0, 0};  // virial[6], energy
-  double v2[7] = {0, 0, 0, 0, 0, 0, 0}; // special pairs: coulomb part
-  if (m < nterm) {
-    BoxD b;
-    box_derive(sc.box, b);
-    const double *x = S.x;
-    if (T == T_BOND) {
-      const int i1 = S.bond_at[2 * m], i2 = S.bond_at[2 * m + 1];
-      const double K = S.bond_cf[2 * m], r0 = S.bond_cf[2 * m + 1];
-      double dx = x[3 * i1] - x[3 * i2], dy = x[3 * i1 + 1] - x[3 * i2 + 1], dz = x[3 * i1 + 2] - x[3 * i2 + 2];
-      minimg(b, dx, dy, dz);
-      const double r = sqrt(dx * dx + dy * dy + dz * dz);
-      const double dr = r - r0, rk = K * dr;
-      const double fb = (r > 0.0) ? -2.0 * rk / r : 0.0;
-      v[6] = rk * dr;
-      fadd(S.f, i1, dx * fb, dy * fb, dz * fb);
-      fadd(S.f, i2, -dx * fb, -dy * fb, -dz * fb);
-      vt(v, dx, dy, dz, dx * fb, dy * fb, dz * fb);
-    } else if (T == T_ANGLE) {
-      const int i1 = S.angle_at[3 * m], i2 = S.angle_at[3 * m + 1], i3 = S.angle_at[3 * m + 2];
-      const double K = S.angle_cf[2 * m], th0 = S.angle_cf[2 * m + 1];
-      double d1[3], d2[3];
-      for (int k = 0; k < 3; k++) { d1[k] = x[3 * i1 + k] - x[3 * i2 + k]; d2[k] = x[3 * i3 + k] - x[3 * i2 + k]; }
-      minimg(b, d1[0], d1[1], d1[2]); minimg(b, d2[0], d2[1], d2[2]);
-      const double rsq1 = dot3(d1, d1), rsq2 = dot3(d2, d2);
-      const double r1 = sqrt(rsq1), r2 = sqrt(rsq2);
-      double c = dot3(d1, d2) / (r1 * r2);
-      c = fmin(1.0, fmax(-1.0, c));
-      double sn = sqrt(1.0 - c * c);
-      if (sn < 0.001) sn = 0.001;
-      const double dth = acos(c) - th0, tk = K * dth;
-      v[6] = tk * dth;
-      const double a = -2.0 * tk / sn;
-      const double a11 = a * c / rsq1, a12 = -a / (r1 * r2), a22 = a * c / rsq2;
-      double f1[3], f3[3];
-      for (int k = 0; k < 3; k++) { f1[k] = a11 * d1[k] + a12 * d2[k]; f3[k] = a22 * d2[k] + a12 * d1[k]; }
-      fadd(S.f, i1, f1[0], f1[1], f1[2]);
-      fadd(S.f, i2, -(f1[0] + f3[0]), -(f1[1] + f3[1]), -(f1[2] + f3[2]));
-      fadd(S.f, i3, f3[0], f3[1], f3[2]);
-      vt(v, d1[0], d1[1], d1[2], f1[0], f1[1], f1[2]);
-      vt(v, d2[0], d2[1], d2[2], f3[0], f3[1], f3[2]);
-    } else if (T == T_DIHEDRAL || T == T_IMPROPER) {
-      const int *at = (T == T_DIHEDRAL) ? S.dihedral_at + 4 * m : S.improper_at + 4 * m;
-      double F[3], G[3], H[3], dc[4][3];
-      const double c = torsion_cos(b, x, at, F, G, H, dc);
-      double dEdc;
-      if (T == T_DIHEDRAL) {
-        const double *K = S.dihedral_cf + 4 * m;
-        const double c2 = c * c;
-        const double cos2 = 2.0 * c2 - 1.0, cos3 = (4.0 * c2 - 3.0) * c, cos4 = 8.0 * c2 * c2 - 8.0 * c2 + 1.0;
-        v[6] = 0.5 * (K[0] * (1.0 + c) + K[1] * (1.0 - cos2) + K[2] * (1.0 + cos3) + K[3] * (1.0 - cos4));
-        dEdc = 0.5 * (K[0] - K[1] * 4.0 * c + K[2] * (12.0 * c2 - 3.0) - K[3] * (32.0 * c2 * c - 16.0 * c));
-      } else {
-        const double K = S.improper_cf[2 * m], chi0 = S.improper_cf[2 * m + 1];
-        double sn = sqrt(1.0 - c * c);
-        if (sn < 0.001) sn = 0.001;
-        const double dchi = acos(c) - chi0;
-        v[6] = K * dchi * dchi;
-        dEdc = -2.0 * K * dchi / sn;
-      }
-      double ff[4][3];
-      for (int a = 0; a < 4; a++) {
-        for (int k = 0; k < 3; k++) ff[a][k] = -dEdc * dc[a][k];
-        fadd(S.f, at[a], ff[a][0], ff[a][1], ff[a][2]);
-      }
-      vt(v, F[0] + G[0], F[1] + G[1], F[2] + G[2], ff[0][0], ff[0][1], ff[0][2]);
-      vt(v, G[0], G[1], G[2], ff[1][0], ff[1][1], ff[1][2]);
-      vt(v, H[0], H[1], H[2], ff[3][0], ff[3][1], ff[3][2]);
-    } else {  // special pair: weighted real-space term (k-space minus (1-f_coul) q q / r)
-      const int i = S.special_at[2 * m], j = S.special_at[2 * m + 1];
-      const double wlj = S.special_cf[2 * m], wc = S.special_cf[2 * m + 1];
-      double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
-      minimg(b, dx, dy, dz);
-      const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq >= S.excl_cut2) atomicOr(&sc.overflow, 2);  // excluded pair escaped the build-time exclusion gate
-      const double r2inv = 1.0 / rsq;
-      double flj = 0.0, fc = 0.0;
-      if (rsq < S.cut_coul2 && S.g_ewald > 0.0) {
-        const double r = sqrt(rsq), grij = S.g_ewald * r;
-        const double expm2 = exp(-grij * grij);
-        const double pref = MD_QQRD2E * S.q[i] * S.q[j] / r;
-        const double e = wc - erf(grij);
-        fc = pref * (e + MD_EWALD_F * grij * expm2) * r2inv;
-        v2[6] = pref * e;
-      }
-      if (rsq < S.cut_lj2 && wlj != 0.0) {
-        const int nt = S.ntypes, tt = S.type[i] * nt + S.type[j];
-        const double r6inv = r2inv * r2inv * r2inv;
-        flj = wlj * r6inv * (S.lj[tt] * r6inv - S.lj[nt * nt + tt]) * r2inv;
-        v[6] = wlj * r6inv * (S.lj[2 * nt * nt + tt] * r6inv - S.lj[3 * nt * nt + tt]);
-      }
-      const double fp = flj + fc;
-      fadd(S.f, i, dx * fp, dy * fp, dz * fp);
-      fadd(S.f, j, -dx * fp, -dy * fp, -dz * fp);
-      vt(v, dx, dy, dz, dx * flj, dy * flj, dz * flj);
-      vt(v2, dx, dy, dz, dx * fc, dy * fc, dz * fc);
-    }
-  }
-  const int part = (T == T_BOND) ? P_BOND : (T == T_ANGLE) ? P_ANGLE : (T == T_DIHEDRAL) ? P_DIHEDRAL : (T == T_IMPROPER) ? P_IMPROPER : P_LJ;
-  double v6[6], e1[1];
-  for (int k = 0; k < 6; k++) v6[k] = v[k];
-  block_atomic_add<6>(v6, sc.vir + part * 6, s_red);
-  e1[0] = v[6];
-  block_atomic_add<1>(e1, sc.eng + part, s_red);
-  if (T == T_SPECIAL) {
-    for (int k = 0; k < 6; k++) v6[k] = v2[k];
-    block_atomic_add<6>(v6, sc.vir + P_COUL * 6, s_red);
-    e1[0] = v2[6];
-    block_atomic_add<1>(e1, sc.eng + P_COUL, s_red);
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1110,13 +732,6 @@ void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int max
 }
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
-}
-void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxb, int maxa, int maxd, int maxi, int maxs) {
-  if (maxs > 0) hipLaunchKernelGGL(k_term<T_SPECIAL>, grid2(cdiv(maxs, TPB), ns), dim3(TPB), 0, st, d);
-  if (maxb > 0) hipLaunchKernelGGL(k_term<T_BOND>, grid2(cdiv(maxb, TPB), ns), dim3(TPB), 0, st, d);
-  if (maxa > 0) hipLaunchKernelGGL(k_term<T_ANGLE>, grid2(cdiv(maxa, TPB), ns), dim3(TPB), 0, st, d);
-  if (maxd > 0) hipLaunchKernelGGL(k_term<T_DIHEDRAL>, grid2(cdiv(maxd, TPB), ns), dim3(TPB), 0, st, d);
-  if (maxi > 0) hipLaunchKernelGGL(k_term<T_IMPROPER>, grid2(cdiv(maxi, TPB), ns), dim3(TPB), 0, st, d);
 }
 void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax) {
   if (maxk <= 0) return;
