@@ -1,8 +1,8 @@
 // md_types.h -- device-visible data layout of the batched MD micro-solver (gfx950).
 //
-// One SimDev per simulation that is being advanced in the current launch group; kernels are
-// launched on 2-D grids with blockIdx.y = simulation, so one launch covers the whole batch of
-// quadrature-point replicas (DESIGN.md "Data layout in HBM").
+// One SimDev per simulation that is being advanced in the current launch group; every kernel's grid
+// covers all simulations of the group, so one launch advances the whole batch of quadrature-point
+// replicas one stage (DESIGN.md "Data layout in HBM").
 #pragma once
 #include <stdint.h>
 
@@ -10,7 +10,6 @@
 #define MD_NPART 8
 #define MD_MAXTYPES 16
 #define MD_MAXPOLY 48
-#define MD_NBINS 28
 #define MD_CLUSTER 4          /* atoms per i-cluster (consecutive slots inside one cell) */
 #define MD_JMASK 0x007FFFFF   /* cluster-row entry: [22:0] slot of j, [26:23] which of the 4 i atoms list j, [31:27] image code */
 #define MD_MASK_SHIFT 23
@@ -61,7 +60,7 @@ struct SimDev {
   // sizes
   int natoms, npad, ntypes;
   int nbonds, nangles, ndihedrals, nimpropers, nspecial, nclus;
-  int maxneigh;
+  int maxneigh;               // capacity (entries) of one i-cluster row
   int nc[3], ncells, mst[3];  // cell grid and stencil half-widths
   int nk, kmaxd[3];
   int nsteps;                 // steps of this run for this simulation
@@ -77,7 +76,6 @@ struct SimDev {
   int coul_npoly;
   double coul_uscale;
   double coul_poly[MD_MAXPOLY];
-  // neighbour rows are ordered by build-time distance shells of width rlist/MD_NBINS
   double seg_a2, seg_b2;  // row segments by build-time distance: (cut_coul+m)^2, (cut_lj+m)^2
   // topology (shared by all simulations of one (material, replica))
   const int *type;
@@ -96,14 +94,14 @@ struct SimDev {
   // state
   double *x, *v, *f;
   // pair structures
-  double4 *xq;      // slot-ordered wrapped positions + charge
+  double4 *xq;      // slot records as two arrays of 16-byte halves: (x,y)[npad] then (z,q)[npad] (wrapped positions, charge)
   int *stype;       // slot-ordered type
   int *perm;        // slot -> atom
   int *slot_tmp;    // unsorted cell fill
   int *wrapn;       // atom -> integer wrap (3)
   double *xhold;
   int *cell_of, *ckey, *cell_count, *cell_start, *cell_fill;
-  int *numneigh, *neigh;
+  int *numneigh, *neigh;  // per cluster: {entries in segments A+B (front), entries in segment C (back)}; rows of maxneigh entries
   // ewald
   const int *kn;    // 3 ints per k
   double *sfac;     // 2 per k
