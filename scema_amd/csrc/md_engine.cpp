@@ -685,6 +685,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     Slot &sl = *e->slots[i];
     int rc = ensure_slot(e, sl, T.natoms, maxneigh, S.ncells, S.nk);
     if (rc) return rc;
+    if ((size_t)4 * ((int)(0.55 * maxneigh) / 64 * 64 + 64) * sizeof(int) > 150 * 1024)
+      return fail(e, SCEMA_MD_ERR_ARG, "neighbour rows of %d entries per cluster do not fit the build kernel's LDS lists (system too dense for the cutoff)", maxneigh);
     S.maxneigh = maxneigh;
     maxrow = std::max(maxrow, maxneigh);
     S.nbonds = T.nbonds; S.nbonds_noshake = T.nbonds_noshake; S.nangles = T.nangles; S.ndihedrals = T.ndihedrals;

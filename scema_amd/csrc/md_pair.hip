@@ -383,6 +383,8 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad, int ma
   // per-wave LDS list of segment B: well over its expected share (~40 %) of a full row
   const int capB = (int)(0.55 * maxrow) / 64 * 64 + 64;
   const size_t lds = (size_t)WPB * capB * sizeof(int);
+  static size_t optin = 0;  // more than 64 KB of dynamic LDS needs an explicit opt-in (very dense systems)
+  if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_neigh_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
   hipLaunchKernelGGL(k_neigh_build, grid_xcd(ntiles, ns), dim3(WPB * 64), lds, st, d, ntiles, ns, capB);
 }
 
