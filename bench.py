@@ -71,7 +71,7 @@ def main():
     from scema_amd import capi
     from scema_amd.systems import build_pe, synthetic_strains
 
-    d = build_pe(*args.cells)
+    d = build_pe(*args.cells, shake_project=True)   # seed 1234, 300 K, SHAKE-projected velocities
     # ablation knobs for kernel experiments only (never set in a reported run)
     extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
     eng = capi.Engine(capi.default_params(device=device, profile=1, **extra))

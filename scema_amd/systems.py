@@ -20,7 +20,7 @@ PE_A, PE_B, PE_C = 7.40, 4.93, 2.534
 
 
 def build_pe(nx: int = 6, ny: int = 9, nz: int = 16, temperature: float = 300.0, seed: int = 1234,
-             jitter: float = 0.0) -> dict:
+             jitter: float = 0.0, shake_project: bool = False) -> dict:
     """All-atom PE crystal, 12 atoms per cell, chains bonded through the periodic z boundary.
 
     6x9x16 -> 10 368 atoms, box 44.40 x 44.37 x 40.54 A (the PE-10k replica of SURVEY.md §8d).
@@ -99,7 +99,25 @@ def build_pe(nx: int = 6, ny: int = 9, nz: int = 16, temperature: float = 300.0,
     m = mass[typ]
     v = rng.normal(0.0, 1.0, (natoms, 3)) * np.sqrt(BOLTZ * temperature / (m * MVV2E))[:, None]
     v -= (m[:, None] * v).sum(0) / m.sum()
-    tcur = (m[:, None] * v * v).sum() * MVV2E / ((3 * natoms - 3) * BOLTZ)
+    dof = 3 * natoms - 3
+    if shake_project:
+        # "... then SHAKE-projected": remove the relative velocity along every constrained X-H bond
+        # (mass-weighted, a few sweeps because the two C-H bonds of a CH2 share the carbon), then scale to T with
+        # the constrained number of degrees of freedom, so a fix-shake run starts at the requested temperature
+        ch = [(a, b) for (a, b), t in zip(bonds, btype) if t == 1]
+        ia = np.array([a for a, _ in ch]); ib = np.array([b for _, b in ch])
+        dvec = x[ia] - x[ib]
+        dvec /= np.linalg.norm(dvec, axis=1)[:, None]
+        for _ in range(50):
+            for sel in (slice(0, None, 2), slice(1, None, 2)):   # the two H of a carbon in separate half-sweeps
+                a, b, dh = ia[sel], ib[sel], dvec[sel]
+                rel = ((v[a] - v[b]) * dh).sum(1)
+                ma, mb = m[a], m[b]
+                v[a] -= (mb / (ma + mb) * rel)[:, None] * dh
+                v[b] += (ma / (ma + mb) * rel)[:, None] * dh
+        v -= (m[:, None] * v).sum(0) / m.sum()
+        dof -= len(ch)
+    tcur = (m[:, None] * v * v).sum() * MVV2E / (dof * BOLTZ)
     if tcur > 0:
         v *= np.sqrt(temperature / tcur)
 
@@ -119,7 +137,8 @@ def build_pe(nx: int = 6, ny: int = 9, nz: int = 16, temperature: float = 300.0,
 
 
 def build_pe10k(seed: int = 1234) -> dict:
-    return build_pe(6, 9, 16, 300.0, seed)
+    """The PE-10k benchmark replica of SURVEY.md 8(d): 10 368 atoms, 300 K with SHAKE-projected velocities."""
+    return build_pe(6, 9, 16, 300.0, seed, shake_project=True)
 
 
 def synthetic_strains(n_sims: int, box_lengths, seed: int = 2026, scale: float = 1.0, mode: str = "balanced") -> np.ndarray:
