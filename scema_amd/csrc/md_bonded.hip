@@ -189,7 +189,9 @@ __global__ __launch_bounds__(TPB) void k_bonded_atom(const SimDev *__restrict__ 
         for (int k = 0; k < 6; k++) vsum[k] += v[k] + v2[k];
       }
     }
-    S.f[3 * i] += ftot[0]; S.f[3 * i + 1] += ftot[1]; S.f[3 * i + 2] += ftot[2];
+    // total so far = pair force (slot-ordered, from k_pair) + bonded terms
+    const size_t sl = (size_t)S.slot_of[i], np = (size_t)S.npad;
+    S.f[3 * i] = S.fs[sl] + ftot[0]; S.f[3 * i + 1] = S.fs[np + sl] + ftot[1]; S.f[3 * i + 2] = S.fs[2 * np + sl] + ftot[2];
   }
   if (!PARTS) block_atomic_add<6>(vsum, sc.vir + P_BOND * 6, s_red);  // lumped: the pressure sums all parts anyway
 }

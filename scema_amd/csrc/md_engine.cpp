@@ -100,6 +100,8 @@ struct State {
 
 struct Slot {
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
+  size_t cap_jtab = 0;
+  DevBuf fs, slot_of, tile_nj, tile_jtab;
   DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
       xbak, vbak;
 };
@@ -573,10 +575,12 @@ struct RunSpec {
 // slots: every cell is padded to a multiple of MD_CLUSTER slots (i-clusters never straddle cells)
 static int padded_slots(int natoms, int ncells) { return (natoms + (MD_CLUSTER - 1) * ncells + 255) / 256 * 256; }
 
-int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncells, int nk) {
+int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncells, int nk, int capj) {
   const int npad = padded_slots(natoms, ncells);
   if (natoms > sl.cap_atoms || npad > sl.cap_pad) {
     HIPCHK(sl.f.ensure(3 * (size_t)natoms * 8));
+    HIPCHK(sl.slot_of.ensure((size_t)natoms * 4));
+    HIPCHK(sl.fs.ensure(3 * (size_t)npad * 8));
     HIPCHK(sl.wrapn.ensure(3 * (size_t)natoms * 4));
     HIPCHK(sl.xhold.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.cell_of.ensure((size_t)natoms * 4));
@@ -601,7 +605,12 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.cell_count.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.cell_start.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.cell_fill.ensure((size_t)(ncells + 1) * 4));
+    HIPCHK(sl.tile_nj.ensure((size_t)(ncells + 1) * 4));
     sl.cap_cells = ncells + 1;
+  }
+  if ((size_t)ncells * capj > sl.cap_jtab || sl.cap_jtab == 0) {
+    HIPCHK(sl.tile_jtab.ensure((size_t)ncells * capj * 4 + 1024));
+    sl.cap_jtab = (size_t)ncells * capj;
   }
   if (nk > sl.cap_k || sl.cap_k == 0) {
     const int kc = std::max(nk, 64);
@@ -624,7 +633,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   for (int i = 0; i < ns; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
   e->h_sims.assign(ns, SimDev());
-  int maxrow = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
+  int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
   std::vector<std::vector<int>> kn_stage;
   kn_stage.reserve(ns);
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
@@ -645,14 +654,49 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     perp_widths(b1, w1);
     SimDev S;
     std::memset(&S, 0, sizeof S);
-    for (int d = 0; d < 3; d++) {
-      const double w = std::min(w0[d], w1[d]);
-      if (w < 2.0 * rlist) return fail(e, SCEMA_MD_ERR_BOX, "box width %.3f < 2*(cutoff+skin) = %.3f in dim %d", w, 2 * rlist, d);
-      int nc = (int)std::floor(w / (0.5 * rlist * 1.0001));
-      nc = std::max(1, std::min(nc, 64));
-      S.nc[d] = nc;
-      S.mst[d] = (int)std::ceil(rlist / (w / nc) - 1e-12);
+    for (int d = 0; d < 3; d++)
+      if (std::min(w0[d], w1[d]) < 2.0 * rlist)
+        return fail(e, SCEMA_MD_ERR_BOX, "box width %.3f < 2*(cutoff+skin) = %.3f in dim %d", std::min(w0[d], w1[d]), 2 * rlist, d);
+    // Cell grid = tiling of k_pair (one workgroup per cell): cells of >= rlist/k per dimension.  k = 2 unless the
+    // j table of a tile (the images of the half stencil within rlist of the cell, 28 B of LDS each) would not fit
+    // two workgroups per CU; denser systems get smaller cells.
+    const double rho = T.natoms / std::min(b0.vol, b1.vol);
+    int capj = 0, maxneigh = 0;
+    bool fits = false;
+    for (int k = 2; k <= 8 && !fits; k++) {
+      int ncells = 1;
+      for (int d = 0; d < 3; d++) {
+        const double w = std::min(w0[d], w1[d]);
+        int nc = (int)std::floor(w / (rlist / k * 1.0001));
+        nc = std::max(1, std::min(nc, 64));
+        S.nc[d] = nc;
+        S.mst[d] = (int)std::ceil(rlist / (w / nc) - 1e-12);
+        ncells *= nc;
+      }
+      // Cartesian extents of one cell (bounding box of its edge vectors), the larger of the two boxes
+      double ext[3] = {0, 0, 0};
+      for (const HostBox *hb : {&b0, &b1}) {
+        ext[0] = std::max(ext[0], std::fabs(hb->h[0]) / S.nc[0] + std::fabs(hb->h[5]) / S.nc[1] + std::fabs(hb->h[4]) / S.nc[2]);
+        ext[1] = std::max(ext[1], std::fabs(hb->h[1]) / S.nc[1] + std::fabs(hb->h[3]) / S.nc[2]);
+        ext[2] = std::max(ext[2], std::fabs(hb->h[2]) / S.nc[2]);
+      }
+      const double r = rlist;
+      const double vmink = ext[0] * ext[1] * ext[2] + 2.0 * r * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2]) +
+                           MD_PI * r * r * (ext[0] + ext[1] + ext[2]) + 4.0 / 3.0 * MD_PI * r * r * r;
+      const double vmin = std::min(b0.vol, b1.vol);
+      const double rho_slots = (T.natoms + 1.5 * ncells) / vmin;
+      const double cellvol = std::max(b0.vol, b1.vol) / ncells;
+      double cj = rho_slots * (0.5 * vmink + cellvol * (S.mst[0] + 1.0)) * 1.10 * e->neigh_grow + 64.0;
+      cj = std::min(cj, (double)padded_slots(T.natoms, ncells) * 14.0);
+      capj = ((int)std::ceil(cj) + 63) / 64 * 64;
+      // row capacity of one i-cluster: the union of 4 half neighbour spheres whose centres are within a cell, plus
+      // headroom; regrown on overflow
+      maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.25 * e->neigh_grow) + 128;
+      maxneigh = (std::min(maxneigh, capj) + 63) / 64 * 64;
+      fits = capj <= MD_MAXJTAB && mdk_pair_lds_bytes(capj) <= 74 * 1024 && mdk_neigh_lds_bytes(capj, maxneigh) <= 150 * 1024;
     }
+    if (!fits)
+      return fail(e, SCEMA_MD_ERR_ARG, "the j table of a cell tile (%d entries) does not fit the LDS of the pair kernel (system too dense for the cutoff)", capj);
     if (spec.deform) {
       const double tol = 1.0000001;
       if (std::fabs(box_end[6]) > 0.5 * b1.h[0] * tol || std::fabs(box_end[7]) > 0.5 * b1.h[0] * tol || std::fabs(box_end[8]) > 0.5 * b1.h[1] * tol)
@@ -677,18 +721,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.natoms = T.natoms;
     S.npad = padded_slots(T.natoms, S.ncells);
     S.ntypes = T.ntypes;
-    const double rho = T.natoms / std::min(b0.vol, b1.vol);
-    // row capacity of one i-cluster: the union of 4 neighbour spheres whose centres are within a cell
-    // (measured on PE-10k: mean ~1.4x, max 1.59x one sphere), plus headroom; regrown on overflow
-    int maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 2.2 * e->neigh_grow) + 128;
-    maxneigh = (std::min(maxneigh, S.npad) + 63) / 64 * 64;
     Slot &sl = *e->slots[i];
-    int rc = ensure_slot(e, sl, T.natoms, maxneigh, S.ncells, S.nk);
+    int rc = ensure_slot(e, sl, T.natoms, maxneigh, S.ncells, S.nk, capj);
     if (rc) return rc;
-    if ((size_t)4 * ((int)(0.55 * maxneigh) / 64 * 64 + 64) * sizeof(int) > 150 * 1024)
-      return fail(e, SCEMA_MD_ERR_ARG, "neighbour rows of %d entries per cluster do not fit the build kernel's LDS lists (system too dense for the cutoff)", maxneigh);
     S.maxneigh = maxneigh;
+    S.capj = capj;
     maxrow = std::max(maxrow, maxneigh);
+    maxcapj = std::max(maxcapj, capj);
     S.nbonds = T.nbonds; S.nbonds_noshake = T.nbonds_noshake; S.nangles = T.nangles; S.ndihedrals = T.ndihedrals;
     S.nimpropers = T.nimpropers; S.nspecial = T.nspecial; S.nclus = T.nclus;
     S.nsteps = A.nsteps;
@@ -729,6 +768,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.wrapn = sl.wrapn.as<int>(); S.xhold = sl.xhold.as<double>();
     S.cell_of = sl.cell_of.as<int>(); S.ckey = sl.ckey.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
+    S.fs = sl.fs.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>();
     S.kn = sl.kn.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;
     if (S.nk > 0) {
@@ -753,8 +793,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const int ev = (spec.sample || spec.ev_always) ? 1 : 0;
   // ---- setup (step 0) ----
   mdk_phase_init(st, D, ns);
-  mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow);
-  mdk_pair(st, D, ns, maxpad, ev, spec.ev_always, maxpoly);
+  mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
+  mdk_pair(st, D, ns, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
   mdk_bonded_atom(st, D, ns, maxatoms, spec.ev_always);
   mdk_ewald(st, D, ns, maxatoms, maxk, mmax);
   if (!spec.static_only) mdk_shake(st, D, ns, maxclus, 0.5);
@@ -770,7 +810,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (na == 0) break;
     mdk_pre(st, D, na);
     mdk_initial_integrate(st, D, na, maxatoms);
-    mdk_neighbor(st, D, na, maxatoms, maxpad, maxcells, maxrow);
+    mdk_neighbor(st, D, na, maxatoms, maxpad, maxcells, maxrow, maxcapj);
     if (prof) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;
@@ -781,7 +821,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
-    mdk_pair(st, D, na, maxpad, ev, spec.ev_always, maxpoly);
+    mdk_pair(st, D, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
     if (prof) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;
@@ -818,6 +858,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       const int na = (int)launch_bytes[l];
       for (int pos = 0; pos < na; pos++) e->prof.pair_alg_bytes += simbytes[pos];
     }
+  }
+  if (getenv("SCEMA_MD_TIMING") && ns > 0) {
+    const SimScalars &c = e->h_sc[0];
+    const SimDev &S0 = e->h_sims[0];
+    fprintf(stderr, "[scema_md] sim 0: cells %dx%dx%d, j table max %d of %d, row max %d of %d, row entries/cluster %.1f, listed pairs/atom %.1f, builds %d\n",
+            S0.nc[0], S0.nc[1], S0.nc[2], c.maxj_seen, S0.capj, c.maxneigh_seen, S0.maxneigh, (double)c.nrowent / (S0.npad / MD_CLUSTER),
+            (double)c.nentries / S0.natoms, c.nbuilds);
   }
   int fault = 0;
   for (int i = 0; i < ns; i++) {

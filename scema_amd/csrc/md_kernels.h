@@ -6,11 +6,14 @@ void mdk_phase_init(hipStream_t st, const SimDev *d, int ns);
 void mdk_setup_post(hipStream_t st, const SimDev *d, int ns);
 void mdk_pre(hipStream_t st, const SimDev *d, int ns);
 void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms);
-void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow);
-void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad, int maxrow);
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj);
+void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int maxrow, int capj);
+// dynamic LDS of the tile kernels for a j-table capacity (the engine sizes the cell grid so that these fit)
+size_t mdk_pair_lds_bytes(int capj);
+size_t mdk_neigh_lds_bytes(int capj, int maxrow);
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int vir, int eng, int npoly);
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly);
 // atom-centric, atomic-free bonded terms + special pairs; parts != 0: per-part virial/energy (parity hook)
 void mdk_bonded_atom(hipStream_t st, const SimDev *d, int ns, int maxatoms, int parts);
 void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax);

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(TPB) void k_cell_sort(const SimDev *sims) {
       r += (ko < ka || (ko == ka && o < a)) ? 1 : 0;
     }
     S.perm[b + r] = a;
+    S.slot_of[a] = b + r;
   }
 }
 
@@ -300,6 +301,8 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   const int s = blockIdx.x * TPB + threadIdx.x;
   if (s >= S.npad) return;
+  // k_pair accumulates into the slot-ordered pair forces with atomics
+  S.fs[s] = 0.0; S.fs[(size_t)S.npad + s] = 0.0; S.fs[2 * (size_t)S.npad + s] = 0.0;
   const int a = S.perm[s];
   if (a < 0) {  // pad slot: a record no real atom is ever within the list cutoff of
     if (S.sc->rebuild) {
@@ -722,13 +725,13 @@ void mdk_pre(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_pre
 void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
   hipLaunchKernelGGL(k_initial_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
 }
-void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow) {
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj) {
   hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_scan, dim3(ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_fill, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_sort, grid2(cdiv(maxcells, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
-  mdk_neigh_build(st, d, ns, maxpad, maxrow);
+  mdk_neigh_build(st, d, ns, maxcells, maxrow, capj);
 }
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);

@@ -1,21 +1,25 @@
 // md_pair.hip -- neighbour-list build and the lj/cut/coul/long pair kernel (the roofline kernel).
 //
 // Work decomposition (measurements of every step are in DESIGN.md §5):
-//   * i-CLUSTERS: 4 consecutive slots of one cell (cells are padded to multiples of 4 slots, pad
-//     slots hold far-away dummy records).  The four atoms are < a cell diagonal apart, so their
-//     neighbour sets overlap ~87 %: the cluster owns ONE row = the union of its atoms' neighbours,
-//     each entry carrying a 4-bit mask of which i atoms list that j.
-//   * ONE WAVE PER CLUSTER, the 64 lanes span the row: neigh[cl*maxrow + k] is contiguous (256 B per
-//     wave instruction); a lane gathers its j record once and evaluates it against up to 4 i atoms
-//     held in scalar registers -> 4x fewer row bytes from HBM and 4x fewer record gathers through
-//     L1 than one row per atom, and four independent pair evaluations per lane for ILP.
-//   * rows keep slot (= cell) order inside three segments by build-time distance (A: may need
-//     coulomb, B: LJ only, C: skin), so gathers fall into runs of consecutive slots and the three
-//     regimes are wave-uniform branches.  Every lane still tests r^2 against the cutoffs: results
-//     never depend on the segments or on the cluster grouping.
-//   * forces: per-lane partial sums for the 4 atoms, one wave reduction per cluster, written once
-//     (no atomics); virial: wave -> block -> one atomic per block and component.
-//   entry = image code [31:27] | i-mask [26:23] | j slot [22:0]
+//   * TILE = one cell of the binning grid, one 512-thread workgroup per tile.  Every unordered pair
+//     is evaluated ONCE (Newton's third law): the tile of cell c owns the pairs (i in c, j in c+o)
+//     for the cell offsets o that are lexicographically positive (o2 > 0 | o2 == 0 & o1 > 0 | ... ),
+//     offsets counted before periodic wrapping, plus the pairs inside c with slot(j) > slot(i).
+//     The rule is integer-only and antisymmetric, so no pair is lost or doubled.
+//   * J TABLE: the tile's candidate j images (slot | image code), own cell first, are numbered
+//     0..nj-1 at build time.  k_pair keeps one FP64 force accumulator per table entry in LDS
+//     (24 B x ~2 100 entries for PE-10k): reaction forces are LDS atomics (ds_add_f64), the table is
+//     flushed once per tile with coalesced global atomics into the slot-ordered force array.
+//   * i-CLUSTERS: 4 consecutive slots of the cell (cells are padded to multiples of 4 slots, pad
+//     slots hold far-away dummy records).  A cluster owns ONE row = the union of its atoms'
+//     neighbours, each entry carrying a 4-bit mask of which i atoms list that j.
+//   * ONE WAVE PER CLUSTER, the 64 lanes span the row (contiguous 256 B per wave instruction); a lane
+//     gathers its j record once and evaluates it against up to 4 i atoms held in scalar registers.
+//   * rows keep table order inside three segments by build-time distance (A: may need coulomb,
+//     B: LJ only, C: skin), so the three regimes are wave-uniform branches.  Every lane still tests
+//     r^2 against the cutoffs: results never depend on the segments or on the cluster grouping.
+//   entry = i-mask [20:17] | type of j [16:13] | index into the tile's j table [12:0]
+//   j table entry = image code [27:23] | j slot [22:0]
 //
 // Reference semantics: pair_style lj/cut/coul/long 12.0 9.0 (in.set.lammps:40), neighbor 2.0 bin
 // (in.set.lammps:27); special_bonds 0 0 1 pairs are excluded here and handled in k_bonded_atom.
@@ -24,14 +28,16 @@
 #include "md_device.h"
 #include "md_kernels.h"
 
-#define WPB 4    // waves per block
-#define CPW 2    // clusters per wave (sequential)
-#define CPB (WPB * CPW)
+#define TW 8               // waves per tile workgroup
+#define TT (TW * 64)
 #define NI MD_CLUSTER
+#define E_LMASK 0x1FFF
+#define E_TYPE_SHIFT 13
+#define E_MASK_SHIFT 17
+#define CODE_HOME 13       // image code of (0,0,0)
 
 // slot records are stored as two arrays of 16-byte halves, (x,y)[npad] then (z,q)[npad]: a wave's gather
-// instruction then touches 16 B per lane at stride 16 (half the cache lines of 32-byte records read as two
-// 16-byte halves at stride 32)
+// instruction then touches 16 B per lane at stride 16
 #define XQ_X(S, s) (((const double *)(S).xq)[2 * (size_t)(s)])
 #define XQ_Y(S, s) (((const double *)(S).xq)[2 * (size_t)(s) + 1])
 #define XQ_Z(S, s) (((const double *)(S).xq)[2 * (size_t)(S).npad + 2 * (size_t)(s)])
@@ -49,8 +55,9 @@ __device__ __forceinline__ GLOBAL_AS T *as_global_w(T *p) {
 
 // XCD-aware block -> (simulation, tile) map.  Workgroups are dealt round-robin over the 8 XCDs
 // (block L lands on XCD L % 8), each with its own 4 MiB L2.  A simulation's j gathers touch its
-// whole 332 KB position table, so all tiles of one simulation are placed on ONE XCD: simulation
-// s uses the blocks with L % 8 == s % 8.  Placement only affects speed, never results.
+// whole 332 KB position table and its force atomics its 250 KB force table, so all tiles of one
+// simulation are placed on ONE XCD: simulation s uses the blocks with L % 8 == s % 8.
+// Placement only affects speed, never results.
 __device__ __forceinline__ bool xcd_map(int ntiles, int nsims, int &sim, int &tile) {
   const int L = blockIdx.x;
   const int x = L & 7, w = L >> 3;
@@ -72,43 +79,172 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
 __device__ __forceinline__ int popc_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// LDS FP64 atomic add without return value (ds_add_f64)
+__device__ __forceinline__ void lds_add(double *p, double v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// block-wide sum of NV values per thread over the TW waves of a tile workgroup, atomically added to dst[0..NV)
+template <int NV>
+__device__ __forceinline__ void tile_atomic_add(double (&vals)[NV], double *dst, double *lds /* >= NV*TW */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    double s = wave_sum(vals[k]);
+    if (lane == 0) lds[k * TW + wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+    for (int w = 0; w < TW; w++) s += lds[threadIdx.x * TW + w];
+    if (s != 0.0) atomicAdd(&dst[threadIdx.x], s);
+  }
+}
 
 // ------------------------------------------------------------------------------------------
-// k_neigh_build : wave per cluster; lanes scan runs of candidate slots (coalesced), test them
-// against the cluster's atoms, ballots compact the accepted ones into the three row segments
+// k_neigh_build : workgroup per cell.
+//   phase 1 (all threads): candidate j images of the half stencil, pruned against the bounding box
+//            of the cell's atoms, numbered into the tile's j table (deterministic order)
+//   phase 2 (wave per cluster): the table is tested against the cluster's 4 atoms; ballots compact
+//            the accepted entries into the three row segments
 // ------------------------------------------------------------------------------------------
 struct ClusterI {
   double x[NI], y[NI], z[NI];
   int atom[NI];   // real atom index or -1 (pad)
 };
 
-// single pass: accepted entries are compacted with ballots + prefix popcounts.  Segment A grows
-// forward from the start of the cluster's row, segment C backward from its end, segment B is
-// collected in a per-wave LDS list and appended behind A at the end: row = [A | B | ... | C reversed].
-// Only B needs LDS (7.6 KB per wave at PE-10k), which keeps 5 blocks per CU resident.
-extern __shared__ int s_lists[];  // [WPB][capB]
+extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists of segment B
 
-__global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capB) {
-  int sim, tile;
-  if (!xcd_map(ntiles, nsims, sim, tile)) return;
+__global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB) {
+  int sim, cell;
+  if (!xcd_map(ntiles, nsims, sim, cell)) return;
   const SimDev &S = sims[sim];
   SimScalars &sc = *S.sc;
   if (!sc.rebuild) return;
+  if (cell >= S.ncells) return;
+  const int cs = S.cell_start[cell], ce = S.cell_start[cell + 1], nown = ce - cs;
+  if (nown == 0) {
+    if (threadIdx.x == 0) S.tile_nj[cell] = 0;
+    return;
+  }
+  __shared__ double s_shift[27 * 3];
+  __shared__ double s_box[6];   // bounding box of the cell's real atoms
+  __shared__ int s_wcnt[TW];
+  int *s_jtab = s_build;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int *lb = s_lists + wave * capB;
-  const int maxrow = S.maxneigh;
+  int *lb = s_build + capj + wave * capB;
   BoxD b;
   box_derive(sc.box, b);
+  if (threadIdx.x < 27) {
+    const int s0 = threadIdx.x % 3 - 1, s1 = (threadIdx.x / 3) % 3 - 1, s2 = threadIdx.x / 9 - 1;
+    s_shift[3 * threadIdx.x + 0] = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
+    s_shift[3 * threadIdx.x + 1] = b.h[1] * s1 + b.h[3] * s2;
+    s_shift[3 * threadIdx.x + 2] = b.h[2] * s2;
+  }
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);               // (x,y) halves
   const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;                          // (z,q) halves
+  if (wave == 0) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int s = cs + lane; s < ce; s += 64)
+      if (S.perm[s] >= 0) {
+        const double x = xq[2 * (size_t)s], y = xq[2 * (size_t)s + 1], z = zq[2 * (size_t)s];
+        lo[0] = fmin(lo[0], x); hi[0] = fmax(hi[0], x);
+        lo[1] = fmin(lo[1], y); hi[1] = fmax(hi[1], y);
+        lo[2] = fmin(lo[2], z); hi[2] = fmax(hi[2], z);
+      }
+    for (int d = 0; d < 3; d++) {
+      const double l = wave_min(lo[d]), h = wave_max(hi[d]);
+      if (lane == 0) { s_box[d] = l; s_box[3 + d] = h; }
+    }
+  }
+  // own cell first: table index l <-> slot cs + l (pads included), so the cluster atoms know their own index
+  for (int l = threadIdx.x; l < nown && l < capj; l += TT) s_jtab[l] = (cs + l) | (CODE_HOME << 23);
+  __syncthreads();
+  const double blo0 = s_box[0], blo1 = s_box[1], blo2 = s_box[2], bhi0 = s_box[3], bhi1 = s_box[4], bhi2 = s_box[5];
+  const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
+  int nj = nown;
+  for (int o2 = 0; o2 <= S.mst[2]; o2++) {
+    int a2 = c2 + o2, s2 = 0;
+    while (a2 >= S.nc[2]) { a2 -= S.nc[2]; s2 += 1; }
+    if (s2 > 1) continue;
+    for (int o1 = (o2 == 0 ? 0 : -S.mst[1]); o1 <= S.mst[1]; o1++) {
+      int a1 = c1 + o1, s1 = 0;
+      while (a1 < 0) { a1 += S.nc[1]; s1 -= 1; }
+      while (a1 >= S.nc[1]) { a1 -= S.nc[1]; s1 += 1; }
+      if (s1 < -1 || s1 > 1) continue;
+      // the x range of cells is one or more contiguous slot runs, one per image
+      int o0 = (o2 == 0 && o1 == 0) ? 1 : -S.mst[0];
+      while (o0 <= S.mst[0]) {
+        int a0 = c0 + o0, s0 = 0;
+        while (a0 < 0) { a0 += S.nc[0]; s0 -= 1; }
+        while (a0 >= S.nc[0]) { a0 -= S.nc[0]; s0 += 1; }
+        int len = 1;
+        while (o0 + len <= S.mst[0] && a0 + len < S.nc[0]) len++;
+        o0 += len;
+        if (s0 < -1 || s0 > 1) continue;
+        const int code = (s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1);
+        const double sx = s_shift[3 * code], sy = s_shift[3 * code + 1], sz = s_shift[3 * code + 2];
+        const int cj = (a2 * S.nc[1] + a1) * S.nc[0] + a0;
+        const int jb = S.cell_start[cj], je = S.cell_start[cj + len];
+        for (int base = jb; base < je; base += TT) {
+          const int j = base + threadIdx.x;
+          bool ok = false;
+          if (j < je) {
+            const double xj = xq[2 * (size_t)j] + sx, yj = xq[2 * (size_t)j + 1] + sy, zj = zq[2 * (size_t)j] + sz;
+            const double ex = fmax(0.0, fmax(blo0 - xj, xj - bhi0)), ey = fmax(0.0, fmax(blo1 - yj, yj - bhi1)),
+                         ez = fmax(0.0, fmax(blo2 - zj, zj - bhi2));
+            ok = ex * ex + ey * ey + ez * ez < S.rlist2;
+          }
+          const unsigned long long m = __ballot(ok);
+          if (lane == 0) s_wcnt[wave] = __popcll(m);
+          __syncthreads();
+          int before = 0, total = 0;
+#pragma unroll
+          for (int w = 0; w < TW; w++) {
+            const int cw = s_wcnt[w];
+            before += (w < wave) ? cw : 0;
+            total += cw;
+          }
+          if (ok) {
+            const int pos = nj + before + popc_below(m);
+            if (pos < capj) s_jtab[pos] = j | (code << 23);
+          }
+          nj += total;
+          __syncthreads();
+        }
+      }
+    }
+  }
+  if (nj > capj || nj > S.capj) {   // uniform: table overflow -> the engine regrows and retries
+    if (threadIdx.x == 0) { S.tile_nj[cell] = 0; atomicOr(&sc.overflow, 1); atomicMax(&sc.maxj_seen, nj); }
+    for (int cl = cs / NI + threadIdx.x; cl < ce / NI; cl += TT) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
+    return;
+  }
+  {
+    GLOBAL_AS int *gj = as_global_w(S.tile_jtab) + (size_t)cell * S.capj;
+    for (int l = threadIdx.x; l < nj; l += TT) gj[l] = s_jtab[l];
+    if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
+  }
+  // ---- phase 2 ----
+  const int maxrow = S.maxneigh;
   const double ra2 = S.seg_a2, rb2 = S.seg_b2;
+  const GLOBAL_AS int *stype = as_global(S.stype);
   unsigned long long npairs = 0, nrowent = 0;
   int nmax = 0, over = 0;
-  for (int c = 0; c < CPW; c++) {
-    const int cl = tile * CPB + wave * CPW + c;  // wave-uniform
+  for (int cl = cs / NI + wave; cl < ce / NI; cl += TW) {
     const int s0slot = cl * NI;
-    if (s0slot >= S.npad) break;
     ClusterI ci;
 #pragma unroll
     for (int a = 0; a < NI; a++) {
@@ -120,8 +256,6 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
       continue;
     }
     GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)cl * maxrow;
-    const int cell = S.cell_of[ci.atom[0]];
-    const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
     // bounding sphere of the cluster's real atoms: one test rejects a candidate for all four atoms
     double bx = 0.0, by = 0.0, bz = 0.0, brad2 = 0.0;
     {
@@ -140,70 +274,45 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
     const double breach = sqrt(S.rlist2) + sqrt(brad2) * 1.0000001 + 1.0e-9;
     const double breach2 = breach * breach;
     int nA = 0, nB = 0, nC = 0;
-    for (int o2 = -S.mst[2]; o2 <= S.mst[2]; o2++) {
-      int a2 = c2 + o2, s2 = 0;
-      while (a2 < 0) { a2 += S.nc[2]; s2 -= 1; }
-      while (a2 >= S.nc[2]) { a2 -= S.nc[2]; s2 += 1; }
-      if (s2 < -1 || s2 > 1) continue;
-      for (int o1 = -S.mst[1]; o1 <= S.mst[1]; o1++) {
-        int a1 = c1 + o1, s1 = 0;
-        while (a1 < 0) { a1 += S.nc[1]; s1 -= 1; }
-        while (a1 >= S.nc[1]) { a1 -= S.nc[1]; s1 += 1; }
-        if (s1 < -1 || s1 > 1) continue;
-        // the x range of cells [c0-m, c0+m] is one or more contiguous slot runs, one per image
-        int o0 = -S.mst[0];
-        while (o0 <= S.mst[0]) {
-          int a0 = c0 + o0, s0 = 0;
-          while (a0 < 0) { a0 += S.nc[0]; s0 -= 1; }
-          while (a0 >= S.nc[0]) { a0 -= S.nc[0]; s0 += 1; }
-          int len = 1;
-          while (o0 + len <= S.mst[0] && a0 + len < S.nc[0]) len++;
-          o0 += len;
-          if (s0 < -1 || s0 > 1) continue;
-          const double sx = b.h[0] * s0 + b.h[5] * s1 + b.h[4] * s2;
-          const double sy = b.h[1] * s1 + b.h[3] * s2;
-          const double sz = b.h[2] * s2;
-          const bool home = (s0 == 0 && s1 == 0 && s2 == 0);
-          const int code = ((s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1)) << MD_CODE_SHIFT;
-          const int cj = (a2 * S.nc[1] + a1) * S.nc[0] + a0;
-          const int jb = S.cell_start[cj], je = S.cell_start[cj + len];
-          for (int base = jb; base < je; base += 64) {
-            const int j = base + lane;
-            int mask = 0;
-            double rmin = 1.0e300;
-            if (j < je) {
-              const double xj = xq[2 * (size_t)j] + sx, yj = xq[2 * (size_t)j + 1] + sy, zj = zq[2 * (size_t)j] + sz;
-              int aj = -2;
-              const double cx = bx - xj, cy = by - yj, cz = bz - zj;
-              if (cx * cx + cy * cy + cz * cz < breach2)
+    for (int base = 0; base < nj; base += 64) {
+      const int l = base + lane;
+      int mask = 0, j = 0;
+      double rmin = 1.0e300;
+      if (l < nj) {
+        const int jt = s_jtab[l];
+        j = jt & MD_JMASK;
+        const int code = jt >> 23;
+        const double xj = xq[2 * (size_t)j] + s_shift[3 * code], yj = xq[2 * (size_t)j + 1] + s_shift[3 * code + 1],
+                     zj = zq[2 * (size_t)j] + s_shift[3 * code + 2];
+        const bool own = l < nown;   // same cell, same image: each pair once, by slot order
+        int aj = -2;
+        const double cx = bx - xj, cy = by - yj, cz = bz - zj;
+        if (cx * cx + cy * cy + cz * cz < breach2)
 #pragma unroll
-              for (int a = 0; a < NI; a++) {
-                const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
-                const double r2 = dx * dx + dy * dy + dz * dz;
-                bool acc = ci.atom[a] >= 0 && r2 < S.rlist2 && !(home && j == s0slot + a);
-                if (acc && r2 < S.excl_cut2) {
-                  if (aj == -2) aj = S.perm[j];
-                  for (int e = S.ex_start[ci.atom[a]]; e < S.ex_start[ci.atom[a] + 1]; e++) acc = acc && (S.ex_list[e] != aj);
-                }
-                if (acc) {
-                  mask |= 1 << a;
-                  rmin = fmin(rmin, r2);
-                }
-              }
+          for (int a = 0; a < NI; a++) {
+            const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            bool acc = ci.atom[a] >= 0 && r2 < S.rlist2 && !(own && j <= s0slot + a);
+            if (acc && r2 < S.excl_cut2) {
+              if (aj == -2) aj = S.perm[j];
+              for (int e = S.ex_start[ci.atom[a]]; e < S.ex_start[ci.atom[a] + 1]; e++) acc = acc && (S.ex_list[e] != aj);
             }
-            const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB;
-            const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC);
-            if (mask) {
-              const int entry = code | (mask << MD_MASK_SHIFT) | j;
-              if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) row[pos] = entry; }
-              else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
-              else { const int pos = maxrow - 1 - (nC + popc_below(mC)); if (pos >= 0) row[pos] = entry; }
+            if (acc) {
+              mask |= 1 << a;
+              rmin = fmin(rmin, r2);
             }
-            nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC);
-            npairs += __popc(mask);
           }
-        }
       }
+      const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB;
+      const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC);
+      if (mask) {
+        const int entry = l | (stype[j] << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT);
+        if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) row[pos] = entry; }
+        else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
+        else { const int pos = maxrow - 1 - (nC + popc_below(mC)); if (pos >= 0) row[pos] = entry; }
+      }
+      nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC);
+      npairs += __popc(mask);
     }
     const int n = nA + nB + nC;
     const bool bad = nB > capB || n > maxrow;
@@ -219,7 +328,8 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
   if (lane == 0) {
     if (over) atomicOr(&sc.overflow, 1);
     atomicMax(&sc.maxneigh_seen, nmax);
-    atomicAdd(&sc.nentries, (unsigned long long)cnt);
+    // nentries counts what a full per-atom list would store: every unordered pair from both ends
+    atomicAdd(&sc.nentries, 2ull * (unsigned long long)cnt);
     atomicAdd(&sc.nrowent, nrowent);
   }
 }
@@ -229,15 +339,22 @@ __global__ __launch_bounds__(WPB * 64) void k_neigh_build(const SimDev *__restri
 // k_pair
 // ------------------------------------------------------------------------------------------
 // NP = number of polynomial coefficients kept in scalar registers (>= fitted degree+1, 0-padded)
+extern __shared__ double s_pair[];  // [3][capj] reaction-force accumulators, then int [capj] j table
+
 template <bool VIR, bool ENG, int NP>
-__global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__ sims, int ntiles, int nsims) {
-  int sim, tile;
-  if (!xcd_map(ntiles, nsims, sim, tile)) return;
+__global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj) {
+  int sim, cell;
+  if (!xcd_map(ntiles, nsims, sim, cell)) return;
   const SimDev &S = sims[sim];
+  if (cell >= S.ncells) return;
+  const int cs = S.cell_start[cell], ce = S.cell_start[cell + 1];
+  if (ce == cs) return;
   SimScalars &sc = *S.sc;
   __shared__ double s_shift[27 * 4];
-  __shared__ double s_lj[4 * MD_MAXTYPES * MD_MAXTYPES];
-  __shared__ double s_red[8 * WPB];
+  __shared__ double s_lj[2 * MD_MAXTYPES * MD_MAXTYPES];
+  __shared__ double s_red[8 * TW];
+  double *s_fx = s_pair, *s_fy = s_pair + capj, *s_fz = s_pair + 2 * (size_t)capj;
+  int *s_jtab = (int *)(s_pair + 3 * (size_t)capj);
   if (threadIdx.x < 27) {
     BoxD b;
     box_derive(sc.box, b);
@@ -248,7 +365,15 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
     s_shift[4 * threadIdx.x + 3] = 0.0;
   }
   const int nt = S.ntypes, nt2 = nt * nt;
-  for (int k = threadIdx.x; k < 4 * nt2; k += WPB * 64) s_lj[k] = S.lj[k];
+  for (int k = threadIdx.x; k < 2 * nt2; k += TT) s_lj[k] = S.lj[k];
+  const int nj = S.tile_nj[cell];
+  {
+    const GLOBAL_AS int *gj = as_global(S.tile_jtab) + (size_t)cell * S.capj;
+    for (int l = threadIdx.x; l < nj; l += TT) {
+      s_jtab[l] = gj[l];
+      s_fx[l] = 0.0; s_fy[l] = 0.0; s_fz[l] = 0.0;
+    }
+  }
   double cp[NP];
 #pragma unroll
   for (int m = 0; m < NP; m++) cp[m] = S.coul_poly[m];
@@ -257,17 +382,15 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);   // (x,y) halves
   const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;              // (z,q) halves
-  const GLOBAL_AS int *stype = as_global(S.stype);
   const double g = S.g_ewald, g2u = g * g * S.coul_uscale;
   const double cutc2 = S.cut_coul2, cutl2 = S.cut_lj2;
   const double cutmax2 = fmax(cutc2, cutl2);
   const int maxrow = S.maxneigh;
   double vl[6] = {0, 0, 0, 0, 0, 0}, vc[6] = {0, 0, 0, 0, 0, 0};
   double elj = 0, ecoul = 0;
-  for (int c = 0; c < CPW; c++) {
-    const int cl = tile * CPB + wave * CPW + c;  // wave-uniform
+  if (nj > 0)
+  for (int cl = cs / NI + wave; cl < ce / NI; cl += TW) {   // wave-uniform
     const int s0 = cl * NI;
-    if (s0 >= S.npad) break;
     const int nab = S.numneigh[2 * cl], nn = nab + S.numneigh[2 * cl + 1];  // [A|B] from the front, C reversed from the back
     if (nn == 0) continue;
 #define ROW_AT(k) row[((k) < nab) ? (k) : (maxrow - 1 - ((k) - nab))]
@@ -281,30 +404,30 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
       fx[a] = fy[a] = fz[a] = 0.0;
     }
     const GLOBAL_AS int *row = as_global(S.neigh) + (size_t)cl * maxrow;
-    // one row ahead: entry + record + type of row r+1 are in flight while row r is evaluated
+    // one row chunk ahead: entry + table entry + record of chunk r+1 are in flight while chunk r is evaluated
     int e_n = (lane < nn) ? ROW_AT(lane) : 0;
+    int jt_n = s_jtab[e_n & E_LMASK];
     double xn0, xn1, xn2, xn3;
-    int tn;
     {
-      const size_t j = (size_t)(e_n & MD_JMASK);
+      const size_t j = (size_t)(jt_n & MD_JMASK);
       xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
-      tn = stype[j];
     }
     for (int k0 = 0; k0 < nn; k0 += 64) {
-      const int e = e_n;
+      const int e = e_n, jt = jt_n;
       const double xj = xn0, yj = xn1, zj = xn2, qj = xn3;
-      const int tj = tn;
       {
         const int kn = k0 + 64 + lane;
         e_n = (kn < nn) ? ROW_AT(kn) : 0;
-        const size_t j = (size_t)(e_n & MD_JMASK);
+        jt_n = s_jtab[e_n & E_LMASK];
+        const size_t j = (size_t)(jt_n & MD_JMASK);
         xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
-        tn = stype[j];
       }
-      const int mask = (e >> MD_MASK_SHIFT) & 0xF;  // 0 for the padding of the last row
+      const int mask = (e >> E_MASK_SHIFT) & 0xF;  // 0 for the padding of the last chunk
       if (mask == 0) continue;
-      const int cs = 4 * (((unsigned)e) >> MD_CODE_SHIFT);
-      const double xs = xj + s_shift[cs], ys = yj + s_shift[cs + 1], zs = zj + s_shift[cs + 2];
+      const int cs4 = 4 * (jt >> 23);
+      const double xs = xj + s_shift[cs4], ys = yj + s_shift[cs4 + 1], zs = zj + s_shift[cs4 + 2];
+      const int tj = (e >> E_TYPE_SHIFT) & 0xF;
+      double gx = 0.0, gy = 0.0, gz = 0.0;   // reaction force on j
 #pragma unroll
       for (int a = 0; a < NI; a++) {
         if (!(mask & (1 << a))) continue;
@@ -329,16 +452,12 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
             const int tt = ti[a] + tj;
             const double r6inv = r2inv * r2inv * r2inv;
             flj = r6inv * (s_lj[tt] * r6inv - s_lj[nt2 + tt]) * r2inv;
-            if (ENG) elj += r6inv * (s_lj[2 * nt2 + tt] * r6inv - s_lj[3 * nt2 + tt]);
+            if (ENG) elj += r6inv * (S.lj[2 * nt2 + tt] * r6inv - S.lj[3 * nt2 + tt]);
           }
           const double fp = flj + fc;
-          fx[a] = fma(dx, fp, fx[a]); fy[a] = fma(dy, fp, fy[a]); fz[a] = fma(dz, fp, fz[a]);
-          if (VIR && !ENG) {
-            // production: one lumped pair virial (the pressure sums all parts anyway)
-            const double xl = dx * fp, yl = dy * fp, zl = dz * fp;
-            vl[0] = fma(dx, xl, vl[0]); vl[1] = fma(dy, yl, vl[1]); vl[2] = fma(dz, zl, vl[2]);
-            vl[3] = fma(dx, yl, vl[3]); vl[4] = fma(dx, zl, vl[4]); vl[5] = fma(dy, zl, vl[5]);
-          }
+          const double tx = dx * fp, ty = dy * fp, tz = dz * fp;
+          fx[a] += tx; fy[a] += ty; fz[a] += tz;
+          gx -= tx; gy -= ty; gz -= tz;
           if (VIR && ENG) {
             // parity hook: LJ and coulomb parts separately
             const double xl = dx * flj, yl = dy * flj, zl = dz * flj;
@@ -350,59 +469,94 @@ __global__ __launch_bounds__(WPB * 64, 4) void k_pair(const SimDev *__restrict__
           }
         }
       }
+      const int l = e & E_LMASK;
+      lds_add(&s_fx[l], gx); lds_add(&s_fy[l], gy); lds_add(&s_fz[l], gz);
     }
+    // forces on the cluster's own atoms: wave reduction, then into the atoms' own table entries (own cell first)
 #pragma unroll
     for (int a = 0; a < NI; a++) {
       const double sx = wave_sum(fx[a]), sy = wave_sum(fy[a]), sz = wave_sum(fz[a]);
       if (lane == 0) {
-        const int at = S.perm[s0 + a];
-        if (at >= 0) { S.f[3 * at] = sx; S.f[3 * at + 1] = sy; S.f[3 * at + 2] = sz; }
+        const int l = s0 - cs + a;
+        lds_add(&s_fx[l], sx); lds_add(&s_fy[l], sy); lds_add(&s_fz[l], sz);
+      }
+    }
+  }
+  __syncthreads();
+  // flush the tile's accumulators: consecutive table entries are runs of consecutive slots -> coalesced atomics.
+  // Production virial (one lumped pair virial, the pressure sums all parts anyway): the tile's pairs contribute
+  // sum_pairs (r_i - r_j) (x) F_ij = sum over table entries of r_l (x) (force accumulated on entry l), with the
+  // image position r_l; the accumulated forces of a tile sum to zero, so positions are taken relative to the
+  // tile's first slot.  This costs 6 FMAs per table entry instead of 6 per pair.
+  {
+    double *fs = S.fs;
+    const size_t np = (size_t)S.npad;
+    const double rx = XQ_X(S, cs), ry = XQ_Y(S, cs), rz = XQ_Z(S, cs);
+    for (int l = threadIdx.x; l < nj; l += TT) {
+      const double ax = s_fx[l], ay = s_fy[l], az = s_fz[l];
+      if (ax != 0.0 || ay != 0.0 || az != 0.0) {
+        const int jt = s_jtab[l];
+        const size_t slot = (size_t)(jt & MD_JMASK);
+        atomicAdd(fs + slot, ax); atomicAdd(fs + np + slot, ay); atomicAdd(fs + 2 * np + slot, az);
+        if (VIR && !ENG) {
+          const int c4 = 4 * (jt >> 23);
+          const double px = xq[2 * slot] + s_shift[c4] - rx, py = xq[2 * slot + 1] + s_shift[c4 + 1] - ry, pz = zq[2 * slot] + s_shift[c4 + 2] - rz;
+          vl[0] = fma(px, ax, vl[0]); vl[1] = fma(py, ay, vl[1]); vl[2] = fma(pz, az, vl[2]);
+          vl[3] = fma(px, ay, vl[3]); vl[4] = fma(px, az, vl[4]); vl[5] = fma(py, az, vl[5]);
+        }
       }
     }
   }
   if (VIR) {
-    // full list: every pair is visited from both ends
-    for (int k = 0; k < 6; k++) { vl[k] *= 0.5; vc[k] *= 0.5; }
-    block_atomic_add<6>(vl, sc.vir + P_LJ * 6, s_red);
-    if (ENG) block_atomic_add<6>(vc, sc.vir + P_COUL * 6, s_red);
+    tile_atomic_add<6>(vl, sc.vir + P_LJ * 6, s_red);
+    if (ENG) tile_atomic_add<6>(vc, sc.vir + P_COUL * 6, s_red);
   }
   if (ENG) {
     double e1[1];
-    e1[0] = 0.5 * elj;
-    block_atomic_add<1>(e1, sc.eng + P_LJ, s_red);
-    e1[0] = 0.5 * ecoul;
-    block_atomic_add<1>(e1, sc.eng + P_COUL, s_red);
+    e1[0] = elj;
+    tile_atomic_add<1>(e1, sc.eng + P_LJ, s_red);
+    e1[0] = ecoul;
+    tile_atomic_add<1>(e1, sc.eng + P_COUL, s_red);
   }
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(cdiv(ns, 8) * 8 * ntiles), 1, 1); }
 
-void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxpad, int maxrow) {
-  const int ntiles = cdiv(maxpad / NI, CPB);
+size_t mdk_pair_lds_bytes(int capj) { return (size_t)capj * (3 * sizeof(double) + sizeof(int)); }
+int mdk_neigh_capB(int maxrow) { return (int)(0.6 * maxrow) / 64 * 64 + 64; }
+size_t mdk_neigh_lds_bytes(int capj, int maxrow) { return ((size_t)capj + (size_t)TW * mdk_neigh_capB(maxrow)) * sizeof(int); }
+
+void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int maxrow, int capj) {
   // per-wave LDS list of segment B: well over its expected share (~40 %) of a full row
-  const int capB = (int)(0.55 * maxrow) / 64 * 64 + 64;
-  const size_t lds = (size_t)WPB * capB * sizeof(int);
-  static size_t optin = 0;  // more than 64 KB of dynamic LDS needs an explicit opt-in (very dense systems)
+  const int capB = mdk_neigh_capB(maxrow);
+  const size_t lds = mdk_neigh_lds_bytes(capj, maxrow);
+  static size_t optin = 0;  // more than 64 KB of dynamic LDS needs an explicit opt-in
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_neigh_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  hipLaunchKernelGGL(k_neigh_build, grid_xcd(ntiles, ns), dim3(WPB * 64), lds, st, d, ntiles, ns, capB);
+  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB);
+}
+
+template <bool VIR, bool ENG, int NP>
+static void launch_pair_v(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj) {
+  const size_t lds = mdk_pair_lds_bytes(capj);
+  static size_t optin = 0;
+  if (lds > 48 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pair<VIR, ENG, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+  hipLaunchKernelGGL((k_pair<VIR, ENG, NP>), grid_xcd(ntiles, ns), dim3(TT), lds, st, d, ntiles, ns, capj);
 }
 
 template <int NP>
-static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int vir, int eng) {
-  const dim3 g = grid_xcd(ntiles, ns);
-  if (eng) hipLaunchKernelGGL((k_pair<true, true, NP>), g, dim3(WPB * 64), 0, st, d, ntiles, ns);
-  else if (vir) hipLaunchKernelGGL((k_pair<true, false, NP>), g, dim3(WPB * 64), 0, st, d, ntiles, ns);
-  else hipLaunchKernelGGL((k_pair<false, false, NP>), g, dim3(WPB * 64), 0, st, d, ntiles, ns);
+static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj, int vir, int eng) {
+  if (eng) launch_pair_v<true, true, NP>(st, d, ns, ntiles, capj);
+  else if (vir) launch_pair_v<true, false, NP>(st, d, ns, ntiles, capj);
+  else launch_pair_v<false, false, NP>(st, d, ns, ntiles, capj);
 }
 
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxpad, int vir, int eng, int npoly) {
-  const int ntiles = cdiv(maxpad / NI, CPB);
-  if (npoly <= 12) launch_pair<12>(st, d, ns, ntiles, vir, eng);
-  else if (npoly <= 14) launch_pair<14>(st, d, ns, ntiles, vir, eng);
-  else if (npoly <= 16) launch_pair<16>(st, d, ns, ntiles, vir, eng);
-  else if (npoly <= 20) launch_pair<20>(st, d, ns, ntiles, vir, eng);
-  else if (npoly <= 24) launch_pair<24>(st, d, ns, ntiles, vir, eng);
-  else if (npoly <= 32) launch_pair<32>(st, d, ns, ntiles, vir, eng);
-  else launch_pair<MD_MAXPOLY>(st, d, ns, ntiles, vir, eng);
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly) {
+  if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 14) launch_pair<14>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 16) launch_pair<16>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 20) launch_pair<20>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 24) launch_pair<24>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 32) launch_pair<32>(st, d, ns, maxcells, capj, vir, eng);
+  else launch_pair<MD_MAXPOLY>(st, d, ns, maxcells, capj, vir, eng);
 }

@@ -11,9 +11,8 @@
 #define MD_MAXTYPES 16
 #define MD_MAXPOLY 48
 #define MD_CLUSTER 4          /* atoms per i-cluster (consecutive slots inside one cell) */
-#define MD_JMASK 0x007FFFFF   /* cluster-row entry: [22:0] slot of j, [26:23] which of the 4 i atoms list j, [31:27] image code */
-#define MD_MASK_SHIFT 23
-#define MD_CODE_SHIFT 27
+#define MD_JMASK 0x007FFFFF   /* tile j-table entry: [22:0] slot of j, [27:23] image code (md_pair.hip) */
+#define MD_MAXJTAB 8191       /* row entries carry a 13-bit index into the tile's j table */
 
 
 // units real
@@ -53,6 +52,7 @@ struct SimScalars {
   int rebuild;
   int overflow;
   int maxneigh_seen;
+  int maxj_seen;       // largest tile j table at the last builds
   int nbuilds;
 };
 
@@ -61,6 +61,7 @@ struct SimDev {
   int natoms, npad, ntypes;
   int nbonds, nangles, ndihedrals, nimpropers, nspecial, nclus;
   int maxneigh;               // capacity (entries) of one i-cluster row
+  int capj;                   // capacity (entries) of one tile's (= cell's) j table
   int nc[3], ncells, mst[3];  // cell grid and stencil half-widths
   int nk, kmaxd[3];
   int nsteps;                 // steps of this run for this simulation
@@ -93,6 +94,10 @@ struct SimDev {
   const int *clus_at, *clus_n; const double *clus_d;
   // state
   double *x, *v, *f;
+  double *fs;       // pair forces in slot order, [3][npad] (zeroed by k_pack, filled by k_pair, folded into f by k_bonded_atom)
+  int *slot_of;     // atom -> slot
+  int *tile_nj;     // per cell: entries of its j table
+  int *tile_jtab;   // per cell: capj entries (image code | slot), own cell first
   // pair structures
   double4 *xq;      // slot records as two arrays of 16-byte halves: (x,y)[npad] then (z,q)[npad] (wrapped positions, charge)
   int *stype;       // slot-ordered type
