@@ -101,7 +101,7 @@ struct State {
 struct Slot {
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
   size_t cap_jtab = 0;
-  DevBuf fs, slot_of, tile_nj, tile_jtab;
+  DevBuf fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
   DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
       xbak, vbak;
 };
@@ -581,6 +581,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.f.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.slot_of.ensure((size_t)natoms * 4));
     HIPCHK(sl.fs.ensure(3 * (size_t)npad * 8));
+    HIPCHK(sl.tile_order.ensure((size_t)npad * 4));
     HIPCHK(sl.wrapn.ensure(3 * (size_t)natoms * 4));
     HIPCHK(sl.xhold.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.cell_of.ensure((size_t)natoms * 4));
@@ -606,6 +607,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.cell_start.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.cell_fill.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.tile_nj.ensure((size_t)(ncells + 1) * 4));
+    HIPCHK(sl.tile_wstart.ensure((size_t)(ncells + 1) * 9 * 4));
     sl.cap_cells = ncells + 1;
   }
   if ((size_t)ncells * capj > sl.cap_jtab || sl.cap_jtab == 0) {
@@ -768,7 +770,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.wrapn = sl.wrapn.as<int>(); S.xhold = sl.xhold.as<double>();
     S.cell_of = sl.cell_of.as<int>(); S.ckey = sl.ckey.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
-    S.fs = sl.fs.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>();
+    S.fs = sl.fs.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>();
     S.kn = sl.kn.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;
     if (S.nk > 0) {

@@ -324,6 +324,65 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     nmax = max(nmax, n);
     nrowent += n;
   }
+  // Schedule of k_pair, fixed here: longest-processing-time-first list scheduling of the tile's rows over the TW
+  // waves.  tile_order holds the tile's clusters grouped by wave (longest row first), tile_wstart the TW+1 group
+  // boundaries.  Rows were written by other waves -> barrier + own-workgroup visibility first.
+  __threadfence_block();
+  __syncthreads();
+  if (wave == 0) {
+    const int c0i = cs / NI, nclus = nown / NI;
+    int *wst = S.tile_wstart + (size_t)cell * (TW + 1);
+    if (nclus <= 64) {
+      const int i = lane;
+      const int cnt_i = (i < nclus) ? S.numneigh[2 * (c0i + i)] + S.numneigh[2 * (c0i + i) + 1] : -1;
+      int rank = 0;
+      for (int j = 0; j < nclus; j++) {
+        const int cj = __shfl(cnt_i, j, 64);
+        rank += (cj > cnt_i || (cj == cnt_i && j < i)) ? 1 : 0;
+      }
+      if (i >= nclus) rank = -1;
+      int load[TW], num[TW];
+#pragma unroll
+      for (int w = 0; w < TW; w++) { load[w] = 0; num[w] = 0; }
+      int my_w = 0, my_pos = 0;
+      for (int r = 0; r < nclus; r++) {            // wave-uniform greedy
+        const unsigned long long m = __ballot(rank == r);
+        const int src = __ffsll((long long)m) - 1;
+        const int c = __shfl(cnt_i, src, 64);
+        int wmin = 0, lmin = load[0];
+#pragma unroll
+        for (int w = 1; w < TW; w++)
+          if (load[w] < lmin) { lmin = load[w]; wmin = w; }
+        int pos = 0;
+#pragma unroll
+        for (int w = 0; w < TW; w++)
+          if (w == wmin) { pos = num[w]; num[w] += 1; load[w] += c + 32; }   // + per-row overhead (reduction, setup)
+        if (lane == src) { my_w = wmin; my_pos = pos; }
+      }
+      int start = 0, my_start = 0;
+#pragma unroll
+      for (int w = 0; w < TW; w++) {
+        if (lane == w) wst[w] = start;
+        if (my_w == w) my_start = start;
+        start += num[w];
+      }
+      if (lane == TW) wst[TW] = start;
+      if (i < nclus) S.tile_order[c0i + my_start + my_pos] = c0i + i;
+    } else {
+      // very large cells: round robin
+      for (int w = lane; w <= TW; w += 64) {
+        int st = 0;
+        for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
+        wst[w] = st;
+      }
+      for (int i = lane; i < nclus; i += 64) {
+        const int w = i % TW;
+        int st = 0;
+        for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
+        S.tile_order[c0i + st + i / TW] = c0i + i;
+      }
+    }
+  }
   const double cnt = wave_sum((double)npairs);
   if (lane == 0) {
     if (over) atomicOr(&sc.overflow, 1);
@@ -388,8 +447,11 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   const int maxrow = S.maxneigh;
   double vl[6] = {0, 0, 0, 0, 0, 0}, vc[6] = {0, 0, 0, 0, 0, 0};
   double elj = 0, ecoul = 0;
+  // this wave's rows, fixed at build time (longest first)
+  const int p_begin = S.tile_wstart[(size_t)cell * (TW + 1) + wave], p_end = S.tile_wstart[(size_t)cell * (TW + 1) + wave + 1];
   if (nj > 0)
-  for (int cl = cs / NI + wave; cl < ce / NI; cl += TW) {   // wave-uniform
+  for (int p = p_begin; p < p_end; p++) {
+    const int cl = S.tile_order[cs / NI + p];   // wave-uniform
     const int s0 = cl * NI;
     const int nab = S.numneigh[2 * cl], nn = nab + S.numneigh[2 * cl + 1];  // [A|B] from the front, C reversed from the back
     if (nn == 0) continue;
@@ -404,8 +466,10 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       fx[a] = fy[a] = fz[a] = 0.0;
     }
     const GLOBAL_AS int *row = as_global(S.neigh) + (size_t)cl * maxrow;
-    // one row chunk ahead: entry + table entry + record of chunk r+1 are in flight while chunk r is evaluated
+    // software pipeline: while chunk r is evaluated, the table entry + record of chunk r+1 and the row
+    // entries of chunk r+2 are in flight (row entries stream from HBM, records come from L1/L2)
     int e_n = (lane < nn) ? ROW_AT(lane) : 0;
+    int e_nn = (64 + lane < nn) ? ROW_AT(64 + lane) : 0;
     int jt_n = s_jtab[e_n & E_LMASK];
     double xn0, xn1, xn2, xn3;
     {
@@ -416,11 +480,12 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       const int e = e_n, jt = jt_n;
       const double xj = xn0, yj = xn1, zj = xn2, qj = xn3;
       {
-        const int kn = k0 + 64 + lane;
-        e_n = (kn < nn) ? ROW_AT(kn) : 0;
+        e_n = e_nn;
         jt_n = s_jtab[e_n & E_LMASK];
         const size_t j = (size_t)(jt_n & MD_JMASK);
         xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
+        const int kn = k0 + 128 + lane;
+        e_nn = (kn < nn) ? ROW_AT(kn) : 0;
       }
       const int mask = (e >> E_MASK_SHIFT) & 0xF;  // 0 for the padding of the last chunk
       if (mask == 0) continue;

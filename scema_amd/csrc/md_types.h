@@ -97,6 +97,8 @@ struct SimDev {
   double *fs;       // pair forces in slot order, [3][npad] (zeroed by k_pack, filled by k_pair, folded into f by k_bonded_atom)
   int *slot_of;     // atom -> slot
   int *tile_nj;     // per cell: entries of its j table
+  int *tile_order;  // per cell, at its cluster range: the cell's clusters grouped by the wave of k_pair that takes them
+  int *tile_wstart; // per cell: 9 group boundaries into tile_order (k_pair's schedule, fixed at build time)
   int *tile_jtab;   // per cell: capj entries (image code | slot), own cell first
   // pair structures
   double4 *xq;      // slot records as two arrays of 16-byte halves: (x,y)[npad] then (z,q)[npad] (wrapped positions, charge)
