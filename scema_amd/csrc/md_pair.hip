@@ -89,6 +89,19 @@ __device__ __forceinline__ double wave_min(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
   return v;
 }
+// cross-lane move through the DPP path of the VALU (no LDS traffic): every lane reads the lane selected by CTRL
+// inside its row of 16 (quad_perm / row_shr), lanes without a source read 0
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+#define DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define DPP_ROW_SHR4 0x114
+#define DPP_ROW_SHR8 0x118
+
 // LDS FP64 atomic add without return value (ds_add_f64)
 __device__ __forceinline__ void lds_add(double *p, double v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -410,7 +423,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   if (ce == cs) return;
   SimScalars &sc = *S.sc;
   __shared__ double s_shift[27 * 4];
-  __shared__ double s_lj[2 * MD_MAXTYPES * MD_MAXTYPES];
+  __shared__ __attribute__((aligned(16))) double s_lj[2 * MD_MAXTYPES * MD_MAXTYPES];
   __shared__ double s_red[8 * TW];
   double *s_fx = s_pair, *s_fy = s_pair + capj, *s_fz = s_pair + 2 * (size_t)capj;
   int *s_jtab = (int *)(s_pair + 3 * (size_t)capj);
@@ -424,7 +437,8 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     s_shift[4 * threadIdx.x + 3] = 0.0;
   }
   const int nt = S.ntypes, nt2 = nt * nt;
-  for (int k = threadIdx.x; k < 2 * nt2; k += TT) s_lj[k] = S.lj[k];
+  // (lj1, lj2) of a type pair side by side: one 16-byte LDS read per LJ evaluation
+  for (int k = threadIdx.x; k < 2 * nt2; k += TT) s_lj[k] = S.lj[(k & 1) * nt2 + (k >> 1)];
   const int nj = S.tile_nj[cell];
   {
     const GLOBAL_AS int *gj = as_global(S.tile_jtab) + (size_t)cell * S.capj;
@@ -516,7 +530,8 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
           if (rsq < cutl2) {
             const int tt = ti[a] + tj;
             const double r6inv = r2inv * r2inv * r2inv;
-            flj = r6inv * (s_lj[tt] * r6inv - s_lj[nt2 + tt]) * r2inv;
+            const double2 lj12 = ((const double2 *)s_lj)[tt];
+            flj = r6inv * (lj12.x * r6inv - lj12.y) * r2inv;
             if (ENG) elj += r6inv * (S.lj[2 * nt2 + tt] * r6inv - S.lj[3 * nt2 + tt]);
           }
           const double fp = flj + fc;
@@ -537,13 +552,26 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       const int l = e & E_LMASK;
       lds_add(&s_fx[l], gx); lds_add(&s_fy[l], gy); lds_add(&s_fz[l], gz);
     }
-    // forces on the cluster's own atoms: wave reduction, then into the atoms' own table entries (own cell first)
+    // Forces on the cluster's own atoms: 12 per-lane partial sums -> the atoms' own table entries (own cell
+    // first).  Transposing butterfly over the quad (lane i ends up with component c of atom i&3), then a row
+    // scan: lanes 12..15 of each row of 16 hold the row totals and add them to LDS.  81 VALU instructions and 3
+    // LDS atomics per cluster instead of 144 ds_bpermute.
+    {
+      const bool b0 = lane & 1, b1 = lane & 2;
+      double u[3];
 #pragma unroll
-    for (int a = 0; a < NI; a++) {
-      const double sx = wave_sum(fx[a]), sy = wave_sum(fy[a]), sz = wave_sum(fz[a]);
-      if (lane == 0) {
-        const int l = s0 - cs + a;
-        lds_add(&s_fx[l], sx); lds_add(&s_fy[l], sy); lds_add(&s_fz[l], sz);
+      for (int c = 0; c < 3; c++) {
+        const double *f = (c == 0) ? fx : (c == 1) ? fy : fz;
+        const double w0 = (b0 ? f[1] : f[0]) + dpp_mov<DPP_QUAD_XOR1>(b0 ? f[0] : f[1]);
+        const double w1 = (b0 ? f[3] : f[2]) + dpp_mov<DPP_QUAD_XOR1>(b0 ? f[2] : f[3]);
+        double t = (b1 ? w1 : w0) + dpp_mov<DPP_QUAD_XOR2>(b1 ? w0 : w1);
+        t += dpp_mov<DPP_ROW_SHR4>(t);
+        t += dpp_mov<DPP_ROW_SHR8>(t);
+        u[c] = t;
+      }
+      if ((lane & 12) == 12) {
+        const int l = s0 - cs + (lane & 3);
+        lds_add(&s_fx[l], u[0]); lds_add(&s_fy[l], u[1]); lds_add(&s_fz[l], u[2]);
       }
     }
   }
