@@ -152,15 +152,18 @@ __global__ __launch_bounds__(TPB) void k_bonded_atom(const SimDev *__restrict__ 
         minimg(b, d[0], d[1], d[2]);
         const double rsq = dot3(d, d);
         if (rsq >= S.excl_cut2) atomicOr(&sc.overflow, 2);  // excluded pair escaped the build-time exclusion gate
-        const double r2inv = 1.0 / rsq;
+        const double rinv = rsq64(rsq), r2inv = rinv * rinv;
         double flj = 0.0, fc = 0.0;
         if (rsq < S.cut_coul2 && S.g_ewald > 0.0) {
-          const double r = sqrt(rsq), grij = S.g_ewald * r;
-          const double expm2 = exp(-grij * grij);
-          const double pref = MD_QQRD2E * S.q[a0] * S.q[a1] / r;
-          const double e = wc - erf(grij);
-          fc = pref * (e + MD_EWALD_F * grij * expm2) * r2inv;
-          if (role == 0) en2 = pref * e;
+          // erf(x) - 2x/sqrt(pi) exp(-x^2) = x H(x^2): the polynomial of k_pair (md_pair.hip) instead of erf + exp
+          const double g = S.g_ewald;
+          const double t = fma(rsq, g * g * S.coul_uscale, -1.0);
+          double p = S.coul_poly[S.coul_npoly - 1];
+          for (int m = S.coul_npoly - 2; m >= 0; m--) p = fma(p, t, S.coul_poly[m]);
+          const double grij = g * rsq * rinv;
+          const double pref = MD_QQRD2E * S.q[a0] * S.q[a1] * rinv;
+          fc = pref * fma(-grij, p, wc) * r2inv;
+          if (PARTS && role == 0) en2 = pref * (wc - erf(grij));
         }
         if (rsq < S.cut_lj2 && wlj != 0.0) {
           const int nt = S.ntypes, tt = S.type[a0] * nt + S.type[a1];

@@ -786,7 +786,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     maxi = std::max(maxi, S.nimpropers); maxs = std::max(maxs, S.nspecial); maxclus = std::max(maxclus, S.use_shake ? S.nclus : 0);
     maxsteps = std::max(maxsteps, A.nsteps);
   }
-  if ((size_t)128 * 3 * mmax * 16 + 4096 > 160 * 1024)
+  if ((size_t)64 * 3 * mmax * 16 + 4096 > 160 * 1024)
     return fail(e, SCEMA_MD_ERR_ARG, "k-space index range (|n| up to %d) too large for the LDS phase tables; raise cut_coul or loosen kspace_accuracy", mmax - 1);
   HIPCHK(e->d_sims.ensure((size_t)ns * sizeof(SimDev)));
   HIPCHK(hipMemcpyAsync(e->d_sims.p, e->h_sims.data(), (size_t)ns * sizeof(SimDev), hipMemcpyHostToDevice, e->stream));

@@ -438,42 +438,41 @@ __global__ __launch_bounds__(TPB) void k_ewald_post(const SimDev *sims) {
   block_atomic_add<1>(e, sc.eng + P_KSPACE, s_red);
 }
 
-// F_i = 2 q_i sum_k ug k (sin_i Sr - cos_i Si): one thread per atom, own phase tables in LDS;
-// the per-k data (indices, ug*S(k), k vector) is staged through LDS in chunks and read as
-// broadcasts, instead of nine wave-uniform global loads per (atom, k)
-#define EWF_TPB 128
+// F_i = 2 q_i sum_k ug k (sin_i Sr - cos_i Si), one thread per atom.  The phase exp(i k.r_i) =
+// e1^n1 e2^n2 e3^n3 is carried as a cursor over the k list (lexicographic in (n1,n2,n3), so the
+// usual move is n3 -> n3+1 = one complex multiplication by e3; row and slab changes are re-derived
+// from the running power of e1).  No per-atom tables: nothing in LDS but the per-k data (indices,
+// ug*S(k), k vector), staged in chunks and read as broadcasts.
+#define EWF_TPB 256
 #define EWF_KC 64
 struct __attribute__((aligned(16))) EwK {
   double pr, pi;   // ug * Re S, ug * Im S
   double kx, ky;
   double kz;
-  int n1, n23;     // n1 ; (n2 + 64) | (n3 + 64) << 8
+  int n1, n23;     // n1 ; (n2 + 128) | (n3 + 128) << 8
 };
-__global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int EW_MAXM) {
+__device__ __forceinline__ void cmul(double &pr, double &pi, double c, double s) {
+  const double nr = pr * c - pi * s, ni = pi * c + pr * s;
+  pr = nr; pi = ni;
+}
+__global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   if (S.nk == 0) return;
   if ((int)(blockIdx.x * EWF_TPB) >= S.natoms) return;
-  double2 *s_tab = s_dyn;  // [3][EW_MAXM][thread]
   __shared__ EwK s_k[EWF_KC];
-  const int a = blockIdx.x * EWF_TPB + threadIdx.x;
-  const bool act = a < S.natoms;
-  const int M[3] = {S.kmaxd[0] + 1, S.kmaxd[1] + 1, S.kmaxd[2] + 1};
-  if (act) {
+  const int a = min((int)(blockIdx.x * EWF_TPB + threadIdx.x), S.natoms - 1);
+  const bool act = (int)(blockIdx.x * EWF_TPB + threadIdx.x) < S.natoms;
+  double c1, s1, c2, s2, c3, s3;
+  {
     BoxD b;
     box_derive(S.sc->box, b);
     double t[3];
     atom_phase(S, b, a, t[0], t[1], t[2]);
-    for (int d = 0; d < 3; d++) {
-      double s1, c1;
-      sincos(t[d], &s1, &c1);
-      double cr = 1.0, ci = 0.0;
-      for (int m = 0; m < M[d]; m++) {
-        s_tab[(d * EW_MAXM + m) * EWF_TPB + threadIdx.x] = make_double2(cr, ci);
-        const double nr = cr * c1 - ci * s1, ni = ci * c1 + cr * s1;
-        cr = nr; ci = ni;
-      }
-    }
+    sincos(t[0], &s1, &c1); sincos(t[1], &s2, &c2); sincos(t[2], &s3, &c3);
   }
+  double e1r = 1.0, e1i = 0.0;   // e1^m1
+  double pr = 1.0, pi = 0.0;     // e1^m1 e2^m2 e3^m3
+  int m1 = 0, m2 = 0, m3 = 0;    // cursor (wave-uniform)
   double fx = 0, fy = 0, fz = 0;
   for (int kb = 0; kb < S.nk; kb += EWF_KC) {
     __syncthreads();
@@ -484,25 +483,25 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
       e.pr = ug * S.sfac[2 * k]; e.pi = ug * S.sfac[2 * k + 1];
       e.kx = S.kvec[4 * k]; e.ky = S.kvec[4 * k + 1]; e.kz = S.kvec[4 * k + 2];
       e.n1 = S.kn[3 * k];
-      e.n23 = (S.kn[3 * k + 1] + 64) | ((S.kn[3 * k + 2] + 64) << 8);
+      e.n23 = (S.kn[3 * k + 1] + 128) | ((S.kn[3 * k + 2] + 128) << 8);
       s_k[threadIdx.x] = e;
     }
     __syncthreads();
-    if (act) {
-      const int kc = min(EWF_KC, S.nk - kb);
-      for (int kk = 0; kk < kc; kk++) {
-        const EwK e = s_k[kk];
-        const int n2 = (e.n23 & 0xFF) - 64, n3 = ((e.n23 >> 8) & 0xFF) - 64;
-        const double2 e1 = s_tab[(e.n1) * EWF_TPB + threadIdx.x];
-        double2 e2 = s_tab[(EW_MAXM + abs(n2)) * EWF_TPB + threadIdx.x];
-        double2 e3 = s_tab[(2 * EW_MAXM + abs(n3)) * EWF_TPB + threadIdx.x];
-        if (n2 < 0) e2.y = -e2.y;
-        if (n3 < 0) e3.y = -e3.y;
-        const double c12 = e1.x * e2.x - e1.y * e2.y, s12 = e1.y * e2.x + e1.x * e2.y;
-        const double cc = c12 * e3.x - s12 * e3.y, ss = s12 * e3.x + c12 * e3.y;
-        const double pf = ss * e.pr - cc * e.pi;
-        fx = fma(pf, e.kx, fx); fy = fma(pf, e.ky, fy); fz = fma(pf, e.kz, fz);
+    const int kc = min(EWF_KC, S.nk - kb);
+    for (int kk = 0; kk < kc; kk++) {
+      const EwK e = s_k[kk];
+      const int n1 = __builtin_amdgcn_readfirstlane(e.n1), n23 = __builtin_amdgcn_readfirstlane(e.n23);
+      const int n2 = (n23 & 0xFF) - 128, n3 = ((n23 >> 8) & 0xFF) - 128;
+      if (n1 != m1) {   // next slab: restart from the running power of e1 (bounds the length of the recurrences)
+        while (m1 < n1) { cmul(e1r, e1i, c1, s1); m1++; }
+        pr = e1r; pi = e1i; m2 = 0; m3 = 0;
       }
+      while (m2 < n2) { cmul(pr, pi, c2, s2); m2++; }
+      while (m2 > n2) { cmul(pr, pi, c2, -s2); m2--; }
+      while (m3 < n3) { cmul(pr, pi, c3, s3); m3++; }
+      while (m3 > n3) { cmul(pr, pi, c3, -s3); m3--; }
+      const double pf = pi * e.pr - pr * e.pi;
+      fx = fma(pf, e.kx, fx); fy = fma(pf, e.ky, fy); fz = fma(pf, e.kz, fz);
     }
   }
   if (act) {
@@ -738,14 +737,13 @@ void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
 }
 void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax) {
   if (maxk <= 0) return;
-  const size_t lds_s = (size_t)EW_ATOMS * 3 * mmax * sizeof(double2), lds_f = (size_t)EWF_TPB * 3 * mmax * sizeof(double2);
+  const size_t lds_s = (size_t)EW_ATOMS * 3 * mmax * sizeof(double2);
   // more than 64 KB of dynamic LDS needs an explicit opt-in (large k ranges: small cut_coul or tight accuracy)
-  static size_t optin_s = 0, optin_f = 0;
+  static size_t optin_s = 0;
   if (lds_s > 64 * 1024 && lds_s > optin_s) { (void)hipFuncSetAttribute((const void *)k_ewald_sfac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); optin_s = lds_s; }
-  if (lds_f > 64 * 1024 && lds_f > optin_f) { (void)hipFuncSetAttribute((const void *)k_ewald_force, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f); optin_f = lds_f; }
   hipLaunchKernelGGL(k_ewald_sfac, grid2(cdiv(maxatoms, EW_ATOMS), ns), dim3(TPB), lds_s, st, d, mmax);
   hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
-  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), lds_f, st, d, mmax);
+  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d);
 }
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
   if (maxclus <= 0) return;
