@@ -89,7 +89,8 @@ struct Topo {
   std::vector<double> init_x, init_v;
   // device copies
   DevBuf d_type, d_q, d_mass, d_lj, d_bond_at, d_bond_cf, d_angle_at, d_angle_cf, d_dih_at, d_dih_cf, d_imp_at, d_imp_cf,
-      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_aterm_start, d_aterm, d_aterm_order;
+      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_bondsh_at, d_bondsh_cf, d_bt_desc, d_bt_atoms;
+  int bt_ntile = 0, bt_maxloc = 1;
 };
 
 struct State {
@@ -323,30 +324,92 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
     if (dih_at[k] < 0 || dih_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad dihedral atom");
   for (size_t k = 0; k < imp_at.size(); k++)
     if (imp_at[k] < 0 || imp_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad improper atom");
-  // ---- per-atom term lists for the atomic-free bonded kernel (sorted by kind inside each atom) ----
-  std::vector<std::vector<int>> per_atom(n);
-  auto add_term = [&](int atom, int kind, int role, int idx) { per_atom[atom].push_back(kind | (role << 3) | (idx << 5)); };
-  for (int m = 0; m < s->nbonds; m++) {
-    const int kind = (m < t.nbonds_noshake) ? AT_BOND : AT_BOND_SHAKEN;
-    add_term(bond_at[2 * m], kind, 0, m);
-    add_term(bond_at[2 * m + 1], kind, 1, m);
+  // ---- bonded tiles (md_bonded.hip): every term is evaluated once by the workgroup that owns it ----
+  // Atoms are ranked by a breadth-first walk of the bond graph, so that consecutive ranks are topological
+  // neighbours whatever the numbering of the input.  A tile = BT_OWNERS consecutive ranks; it owns the terms
+  // whose lowest-ranked atom is one of its owners, and carries the list of all atoms those terms touch
+  // (owners + a halo of up to three bonds): positions are staged and forces accumulated per tile in LDS under
+  // local indices, one flush per local atom.
+  std::vector<int> rank(n, -1), by_rank;
+  by_rank.reserve(n);
+  {
+    std::vector<int> queue;
+    for (int root = 0; root < n; root++) {
+      if (rank[root] >= 0) continue;
+      rank[root] = (int)by_rank.size();
+      by_rank.push_back(root);
+      queue.assign(1, root);
+      for (size_t h = 0; h < queue.size(); h++)
+        for (int c : adj[queue[h]])
+          if (rank[c] < 0) {
+            rank[c] = (int)by_rank.size();
+            by_rank.push_back(c);
+            queue.push_back(c);
+          }
+    }
   }
-  for (int m = 0; m < s->nangles; m++)
-    for (int r = 0; r < 3; r++) add_term(angle_at[3 * m + r], AT_ANGLE, r, m);
-  for (int m = 0; m < s->ndihedrals; m++)
-    for (int r = 0; r < 4; r++) add_term(dih_at[4 * m + r], AT_DIHEDRAL, r, m);
-  for (int m = 0; m < s->nimpropers; m++)
-    for (int r = 0; r < 4; r++) add_term(imp_at[4 * m + r], AT_IMPROPER, r, m);
-  for (int m = 0; m < t.nspecial; m++) {
-    add_term(sp_at[2 * m], AT_SPECIAL, 0, m);
-    add_term(sp_at[2 * m + 1], AT_SPECIAL, 1, m);
+  const int ntile = (n + BT_OWNERS - 1) / BT_OWNERS;
+  struct TermRef { int kind, idx; };
+  std::vector<std::vector<TermRef>> tile_terms(ntile);
+  auto owner_tile = [&](const int *atoms, int cnt) {
+    int r = rank[atoms[0]];
+    for (int k = 1; k < cnt; k++) r = std::min(r, rank[atoms[k]]);
+    return r / BT_OWNERS;
+  };
+  for (int m = 0; m < s->nbonds; m++) tile_terms[owner_tile(&bond_at[2 * m], 2)].push_back({m < t.nbonds_noshake ? BT_BOND : BT_BOND_SHAKEN, m});
+  for (int m = 0; m < s->nangles; m++) tile_terms[owner_tile(&angle_at[3 * m], 3)].push_back({BT_ANGLE, m});
+  for (int m = 0; m < s->ndihedrals; m++) tile_terms[owner_tile(&dih_at[4 * m], 4)].push_back({BT_DIHEDRAL, m});
+  for (int m = 0; m < s->nimpropers; m++) tile_terms[owner_tile(&imp_at[4 * m], 4)].push_back({BT_IMPROPER, m});
+  for (int m = 0; m < t.nspecial; m++) tile_terms[owner_tile(&sp_at[2 * m], 2)].push_back({BT_SPECIAL, m});
+  // tile-ordered term arrays with local atom indices
+  std::vector<int> bt_desc((size_t)ntile * BT_DESC, 0), bt_atoms;
+  std::vector<int> l_at[BT_NKIND];
+  std::vector<double> l_cf[BT_NKIND];
+  const int natm[BT_NKIND] = {2, 2, 3, 4, 4, 2}, ncf[BT_NKIND] = {2, 2, 2, 4, 2, 6};
+  std::vector<int> local_of(n, -1);
+  t.bt_maxloc = 1;
+  for (int tl = 0; tl < ntile; tl++) {
+    int *desc = &bt_desc[(size_t)tl * BT_DESC];
+    desc[0] = (int)bt_atoms.size();
+    std::vector<int> members;
+    auto local = [&](int atom) {
+      if (local_of[atom] < 0) {
+        local_of[atom] = (int)members.size();
+        members.push_back(atom);
+      }
+      return local_of[atom];
+    };
+    for (int kind = 0; kind < BT_NKIND; kind++) {
+      desc[2 + 2 * kind] = (int)l_at[kind].size() / natm[kind];
+      int cnt = 0;
+      for (const TermRef &tr : tile_terms[tl]) {
+        if (tr.kind != kind) continue;
+        const int m = tr.idx;
+        const int *at = (kind <= BT_BOND_SHAKEN) ? &bond_at[2 * m] : (kind == BT_ANGLE) ? &angle_at[3 * m] : (kind == BT_DIHEDRAL) ? &dih_at[4 * m]
+                        : (kind == BT_IMPROPER) ? &imp_at[4 * m] : &sp_at[2 * m];
+        for (int k = 0; k < natm[kind]; k++) l_at[kind].push_back(local(at[k]));
+        if (kind <= BT_BOND_SHAKEN) { l_cf[kind].push_back(bond_cf[2 * m]); l_cf[kind].push_back(bond_cf[2 * m + 1]); }
+        else if (kind == BT_ANGLE) { l_cf[kind].push_back(angle_cf[2 * m]); l_cf[kind].push_back(angle_cf[2 * m + 1]); }
+        else if (kind == BT_DIHEDRAL) { for (int k = 0; k < 4; k++) l_cf[kind].push_back(dih_cf[4 * m + k]); }
+        else if (kind == BT_IMPROPER) { l_cf[kind].push_back(imp_cf[2 * m]); l_cf[kind].push_back(imp_cf[2 * m + 1]); }
+        else {
+          // special pair: everything the term needs, so the kernel looks up neither types nor charges
+          const int a0 = at[0], a1 = at[1], tt = t.type[a0] * s->ntypes + t.type[a1];
+          const double wl = sp_cf[2 * m], wc = sp_cf[2 * m + 1];
+          l_cf[kind].push_back(wl * t.lj[tt]); l_cf[kind].push_back(wl * t.lj[nt2 + tt]);
+          l_cf[kind].push_back(MD_QQRD2E * t.q[a0] * t.q[a1]); l_cf[kind].push_back(wc);
+          l_cf[kind].push_back(wl * t.lj[2 * nt2 + tt]); l_cf[kind].push_back(wl * t.lj[3 * nt2 + tt]);
+        }
+        cnt++;
+      }
+      desc[3 + 2 * kind] = cnt;
+    }
+    desc[1] = (int)members.size();
+    t.bt_maxloc = std::max(t.bt_maxloc, (int)members.size());
+    for (int atom : members) { bt_atoms.push_back(atom); local_of[atom] = -1; }
   }
-  std::vector<int> aterm_start(n + 1, 0), aterm;
-  for (int i = 0; i < n; i++) {
-    std::sort(per_atom[i].begin(), per_atom[i].end(), [](int a, int b) { return (a & 7) != (b & 7) ? (a & 7) < (b & 7) : a < b; });
-    aterm_start[i + 1] = aterm_start[i] + (int)per_atom[i].size();
-    aterm.insert(aterm.end(), per_atom[i].begin(), per_atom[i].end());
-  }
+  t.bt_ntile = ntile;
+  (void)ncf;
   std::memcpy(t.init_box, s->box, sizeof t.init_box);
   t.init_x.assign(s->x, s->x + 3 * (size_t)n);
   t.init_v.assign(s->v, s->v + 3 * (size_t)n);
@@ -355,39 +418,25 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   if ((rc = upload(e, t.d_q, t.q))) return rc;
   if ((rc = upload(e, t.d_mass, t.mass_atom))) return rc;
   if ((rc = upload(e, t.d_lj, t.lj))) return rc;
-  if ((rc = upload(e, t.d_bond_at, bond_at))) return rc;
-  if ((rc = upload(e, t.d_bond_cf, bond_cf))) return rc;
-  if ((rc = upload(e, t.d_angle_at, angle_at))) return rc;
-  if ((rc = upload(e, t.d_angle_cf, angle_cf))) return rc;
-  if ((rc = upload(e, t.d_dih_at, dih_at))) return rc;
-  if ((rc = upload(e, t.d_dih_cf, dih_cf))) return rc;
-  if ((rc = upload(e, t.d_imp_at, imp_at))) return rc;
-  if ((rc = upload(e, t.d_imp_cf, imp_cf))) return rc;
-  if ((rc = upload(e, t.d_sp_at, sp_at))) return rc;
-  if ((rc = upload(e, t.d_sp_cf, sp_cf))) return rc;
+  if ((rc = upload(e, t.d_bond_at, l_at[BT_BOND]))) return rc;
+  if ((rc = upload(e, t.d_bond_cf, l_cf[BT_BOND]))) return rc;
+  if ((rc = upload(e, t.d_bondsh_at, l_at[BT_BOND_SHAKEN]))) return rc;
+  if ((rc = upload(e, t.d_bondsh_cf, l_cf[BT_BOND_SHAKEN]))) return rc;
+  if ((rc = upload(e, t.d_angle_at, l_at[BT_ANGLE]))) return rc;
+  if ((rc = upload(e, t.d_angle_cf, l_cf[BT_ANGLE]))) return rc;
+  if ((rc = upload(e, t.d_dih_at, l_at[BT_DIHEDRAL]))) return rc;
+  if ((rc = upload(e, t.d_dih_cf, l_cf[BT_DIHEDRAL]))) return rc;
+  if ((rc = upload(e, t.d_imp_at, l_at[BT_IMPROPER]))) return rc;
+  if ((rc = upload(e, t.d_imp_cf, l_cf[BT_IMPROPER]))) return rc;
+  if ((rc = upload(e, t.d_sp_at, l_at[BT_SPECIAL]))) return rc;
+  if ((rc = upload(e, t.d_sp_cf, l_cf[BT_SPECIAL]))) return rc;
+  if ((rc = upload(e, t.d_bt_desc, bt_desc))) return rc;
+  if ((rc = upload(e, t.d_bt_atoms, bt_atoms))) return rc;
   if ((rc = upload(e, t.d_ex_start, ex_start))) return rc;
   if ((rc = upload(e, t.d_ex_list, ex_list))) return rc;
   if ((rc = upload(e, t.d_clus_at, clus_at))) return rc;
   if ((rc = upload(e, t.d_clus_n, clus_n))) return rc;
   if ((rc = upload(e, t.d_clus_d, clus_d))) return rc;
-  if ((rc = upload(e, t.d_aterm_start, aterm_start))) return rc;
-  if ((rc = upload(e, t.d_aterm, aterm))) return rc;
-  {
-    // order atoms by (number of terms, kinds) so that a wave's 64 atoms have lists of the same shape
-    std::vector<int> order(n);
-    for (int i = 0; i < n; i++) order[i] = i;
-    auto sig = [&](int a) {
-      long long sgn = 0;
-      int cnt[8] = {0};
-      for (int t2 : per_atom[a]) cnt[t2 & 7]++;
-      for (int k = 7; k >= 0; k--) sgn = sgn * 64 + std::min(cnt[k], 63);
-      return sgn;
-    };
-    std::vector<long long> sigs(n);
-    for (int i = 0; i < n; i++) sigs[i] = sig(i);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sigs[a] != sigs[b] ? sigs[a] > sigs[b] : a < b; });
-    if ((rc = upload(e, t.d_aterm_order, order))) return rc;
-  }
   return SCEMA_MD_OK;
 }
 
@@ -635,6 +684,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   for (int i = 0; i < ns; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
   e->h_sims.assign(ns, SimDev());
+  int maxbt = 1, maxloc = 1;
   int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
   std::vector<std::vector<int>> kn_stage;
   kn_stage.reserve(ns);
@@ -763,7 +813,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.improper_at = T.d_imp_at.as<int>(); S.improper_cf = T.d_imp_cf.as<double>();
     S.special_at = T.d_sp_at.as<int>(); S.special_cf = T.d_sp_cf.as<double>();
     S.ex_start = T.d_ex_start.as<int>(); S.ex_list = T.d_ex_list.as<int>();
-    S.aterm_start = T.d_aterm_start.as<int>(); S.aterm = T.d_aterm.as<int>(); S.aterm_order = T.d_aterm_order.as<int>();
+    S.bondsh_at = T.d_bondsh_at.as<int>(); S.bondsh_cf = T.d_bondsh_cf.as<double>();
+    S.bt_desc = T.d_bt_desc.as<int>(); S.bt_atoms = T.d_bt_atoms.as<int>(); S.bt_ntile = T.bt_ntile;
+    maxbt = std::max(maxbt, T.bt_ntile); maxloc = std::max(maxloc, T.bt_maxloc);
     S.clus_at = T.d_clus_at.as<int>(); S.clus_n = T.d_clus_n.as<int>(); S.clus_d = T.d_clus_d.as<double>();
     S.x = A.st->x.as<double>(); S.v = A.st->v.as<double>(); S.f = sl.f.as<double>();
     S.xq = sl.xq.as<double4>(); S.stype = sl.stype.as<int>(); S.perm = sl.perm.as<int>(); S.slot_tmp = sl.slot_tmp.as<int>();
@@ -797,7 +849,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   mdk_phase_init(st, D, ns);
   mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
   mdk_pair(st, D, ns, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
-  mdk_bonded_atom(st, D, ns, maxatoms, spec.ev_always);
+  mdk_bonded(st, D, ns, maxbt, maxloc, spec.ev_always);
   mdk_ewald(st, D, ns, maxatoms, maxk, mmax);
   if (!spec.static_only) mdk_shake(st, D, ns, maxclus, 0.5);
   mdk_final_integrate(st, D, ns, maxatoms, 0);
@@ -829,7 +881,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       ev_used += 2;
       launch_bytes.push_back((double)na);
     }
-    mdk_bonded_atom(st, D, na, maxatoms, spec.ev_always);
+    mdk_bonded(st, D, na, maxbt, maxloc, spec.ev_always);
     mdk_ewald(st, D, na, maxatoms, maxk, mmax);
     mdk_shake(st, D, na, maxclus, 1.0);
     mdk_final_integrate(st, D, na, maxatoms, 1);

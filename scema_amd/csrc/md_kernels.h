@@ -14,8 +14,8 @@ size_t mdk_neigh_lds_bytes(int capj, int maxrow);
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly);
-// atom-centric, atomic-free bonded terms + special pairs; parts != 0: per-part virial/energy (parity hook)
-void mdk_bonded_atom(hipStream_t st, const SimDev *d, int ns, int maxatoms, int parts);
+// bonded terms + special pairs, one workgroup per bonded tile; parts != 0: per-part virial/energy (parity hook)
+void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int parts);
 void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax);
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);

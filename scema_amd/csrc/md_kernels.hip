@@ -11,7 +11,7 @@
 //   k_pre / k_initial_integrate / k_final_integrate / k_post ... fix nvt (NH chain) + Verlet (K9)
 //   k_bin / k_cell_scan / k_cell_fill / k_cell_sort / k_pack / k_neigh_build ... K1
 //   (md_pair.hip)   k_neigh_build, k_pair ... K1, K2 (the roofline kernel)
-//   (md_bonded.hip) k_bonded_atom ........... K4-K7, S4
+//   (md_bonded.hip) k_bonded ................ K4-K7, S4
 //   k_ewald_* ............ reciprocal Ewald sum (K3)
 //   k_shake .............. fix shake (K8)
 //   k_remap .............. fix deform ... remap x (K10)
@@ -457,7 +457,6 @@ __device__ __forceinline__ void cmul(double &pr, double &pi, double c, double s)
 }
 __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
-  if (S.nk == 0) return;
   if ((int)(blockIdx.x * EWF_TPB) >= S.natoms) return;
   __shared__ EwK s_k[EWF_KC];
   const int a = min((int)(blockIdx.x * EWF_TPB + threadIdx.x), S.natoms - 1);
@@ -505,11 +504,13 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims) {
     }
   }
   if (act) {
+    // f (atom order) = pair + bonded forces (slot order, accumulated by k_pair and k_bonded) + reciprocal part;
     // every atom is owned by exactly one thread and the kernels of a step are stream-ordered
     const double pq = 2.0 * MD_QQRD2E * S.q[a];
-    S.f[3 * a] += pq * fx;
-    S.f[3 * a + 1] += pq * fy;
-    S.f[3 * a + 2] += pq * fz;
+    const size_t sl = (size_t)S.slot_of[a], np = (size_t)S.npad;
+    S.f[3 * a] = S.fs[sl] + pq * fx;
+    S.f[3 * a + 1] = S.fs[np + sl] + pq * fy;
+    S.f[3 * a + 2] = S.fs[2 * np + sl] + pq * fz;
   }
 }
 
@@ -736,7 +737,10 @@ void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
 }
 void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax) {
-  if (maxk <= 0) return;
+  if (maxk <= 0) {  // no charges anywhere: the force kernel still assembles f from the slot-ordered pair + bonded forces
+    hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d);
+    return;
+  }
   const size_t lds_s = (size_t)EW_ATOMS * 3 * mmax * sizeof(double2);
   // more than 64 KB of dynamic LDS needs an explicit opt-in (large k ranges: small cut_coul or tight accuracy)
   static size_t optin_s = 0;

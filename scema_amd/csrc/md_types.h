@@ -24,8 +24,11 @@
 #define MD_EWALD_F 1.12837916709551257390
 #define MD_PI 3.14159265358979323846
 
-// per-atom term list entry: kind (3 bits) | role of the atom in the term (2 bits) | term index << 5
-enum { AT_BOND = 0, AT_BOND_SHAKEN = 1, AT_ANGLE = 2, AT_DIHEDRAL = 3, AT_IMPROPER = 4, AT_SPECIAL = 5 };
+// bonded tiles (md_bonded.hip): kinds of terms; descriptor of one tile = BT_DESC ints:
+// [0] offset into bt_atoms, [1] local atoms, then (first term, number of terms) per kind
+enum { BT_BOND = 0, BT_BOND_SHAKEN = 1, BT_ANGLE = 2, BT_DIHEDRAL = 3, BT_IMPROPER = 4, BT_SPECIAL = 5, BT_NKIND = 6 };
+#define BT_DESC 16
+#define BT_OWNERS 128        /* owner atoms (consecutive breadth-first ranks of the bond graph) per tile */
 
 enum { P_LJ = 0, P_COUL = 1, P_BOND = 2, P_ANGLE = 3, P_DIHEDRAL = 4, P_IMPROPER = 5, P_KSPACE = 6, P_SHAKE = 7 };
 
@@ -82,15 +85,17 @@ struct SimDev {
   const int *type;
   const double *q, *mass;       // per atom
   const double *lj;             // 4 * ntypes^2 : lj1,lj2,lj3,lj4
-  const int *bond_at; const double *bond_cf;        // 2 ints, (K,r0); SHAKE'd bonds at the end
+  // bonded terms, grouped by tile, atoms as indices into the tile's local atom list
+  const int *bond_at; const double *bond_cf;        // 2 ints, (K,r0): bonds that stay harmonic
+  const int *bondsh_at; const double *bondsh_cf;    // the bonds fix shake constrains (harmonic only when SHAKE is off)
   int nbonds_noshake;
   const int *angle_at; const double *angle_cf;      // 3 ints, (K,theta0)
   const int *dihedral_at; const double *dihedral_cf;// 4 ints, (K1..K4)
   const int *improper_at; const double *improper_cf;// 4 ints, (K,chi0)
-  const int *special_at; const double *special_cf;  // 2 ints, (f_lj,f_coul)
+  const int *special_at; const double *special_cf;  // 2 ints, (w_lj*lj1, w_lj*lj2, qqrd2e*qi*qj, w_coul, w_lj*lj3, w_lj*lj4)
   const int *ex_start, *ex_list;
-  const int *aterm_order;          // atoms sorted by the shape of their term list (wave-uniform work)
-  const int *aterm_start, *aterm;  // per-atom lists of the bonded terms / special pairs the atom takes part in
+  const int *bt_desc, *bt_atoms;   // tile descriptors, local atom lists
+  int bt_ntile;
   const int *clus_at, *clus_n; const double *clus_d;
   // state
   double *x, *v, *f;
