@@ -513,31 +513,17 @@ static long double coul_H(long double u) {
   return (erfl(x) - c * x * expl(-u)) / x;
 }
 
-static double fit_coul_poly(double g, double rc, double *poly, int *npoly, double *uscale) {
-  if (g <= 0.0) {
-    poly[0] = 0.0;
-    *npoly = 1;
-    *uscale = 0.0;
-    return 0.0;
-  }
-  const long double umax = (long double)(g * rc) * (g * rc) * 1.000001L;
+// One Chebyshev fit of H on [0, umax] with N coefficients, converted to monomials in t; returns the maximum
+// error of x*H (the quantity the force uses), evaluated in double arithmetic exactly as the kernel does.
+static double fit_coul_poly_n(long double umax, int N, double *poly) {
   const long double PI = acosl(-1.0L);
-  std::vector<long double> c;
-  int N = 10;
-  for (; N <= MD_MAXPOLY; N += 2) {
-    c.assign(N, 0.0L);
-    std::vector<long double> fv(N);
-    for (int j = 0; j < N; j++) fv[j] = coul_H(0.5L * umax * (cosl(PI * (j + 0.5L) / N) + 1.0L));
-    for (int k = 0; k < N; k++) {
-      long double s = 0.0L;
-      for (int j = 0; j < N; j++) s += fv[j] * cosl(PI * k * (j + 0.5L) / N);
-      c[k] = 2.0L * s / N;
-    }
-    long double cmax = 0.0L;
-    for (int k = 0; k < N; k++) cmax = std::max(cmax, fabsl(c[k]));
-    if (fabsl(c[N - 1]) + fabsl(c[N - 2]) < 2e-16L * cmax) break;
+  std::vector<long double> c(N, 0.0L), fv(N);
+  for (int j = 0; j < N; j++) fv[j] = coul_H(0.5L * umax * (cosl(PI * (j + 0.5L) / N) + 1.0L));
+  for (int k = 0; k < N; k++) {
+    long double s = 0.0L;
+    for (int j = 0; j < N; j++) s += fv[j] * cosl(PI * k * (j + 0.5L) / N);
+    c[k] = 2.0L * s / N;
   }
-  if (N > MD_MAXPOLY) N = MD_MAXPOLY;
   // Chebyshev -> monomial in t
   std::vector<long double> a(N, 0.0L), Tkm1(N, 0.0L), Tk(N, 0.0L), Tn(N, 0.0L);
   Tkm1[0] = 1.0L;                      // T0
@@ -556,19 +542,38 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
   }
   for (int m = 0; m < N; m++) poly[m] = (double)a[m];
   for (int m = N; m < MD_MAXPOLY; m++) poly[m] = 0.0;
-  *npoly = N;
-  *uscale = (double)(2.0L / umax);
-  // self-check in double arithmetic, as the kernel evaluates it
+  const double uscale = (double)(2.0L / umax);
   double maxerr = 0.0;
   for (int s = 0; s <= 400; s++) {
     const double u = (double)umax * s / 400.0 / 1.000001;
-    const double t = u * (*uscale) - 1.0;
+    const double t = u * uscale - 1.0;
     double p = poly[N - 1];
     for (int m = N - 2; m >= 0; m--) p = std::fma(p, t, poly[m]);
     const double x = std::sqrt(u);
     maxerr = std::max(maxerr, std::fabs(x * (p - (double)coul_H(u))));
   }
   return maxerr;
+}
+
+// Smallest even number of coefficients whose fit error is below 2e-13 (absolute, on a factor of order one):
+// three orders below the parity budget of the forces (1e-11 relative), seven below LAMMPS' own table
+// (pair_modify table 12: ~1e-6).  Every coefficient is one FP64 FMA per coulomb pair in k_pair.
+static double fit_coul_poly(double g, double rc, double *poly, int *npoly, double *uscale) {
+  if (g <= 0.0) {
+    poly[0] = 0.0;
+    *npoly = 1;
+    *uscale = 0.0;
+    return 0.0;
+  }
+  const long double umax = (long double)(g * rc) * (g * rc) * 1.000001L;
+  *uscale = (double)(2.0L / umax);
+  double err = 0.0;
+  for (int N = 8; N <= MD_MAXPOLY; N += 2) {
+    err = fit_coul_poly_n(umax, N, poly);
+    *npoly = N;
+    if (err < 2e-13) break;
+  }
+  return err;
 }
 
 struct PolyFit { int n; double uscale, err; double c[MD_MAXPOLY]; };

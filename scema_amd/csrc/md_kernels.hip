@@ -274,25 +274,32 @@ __global__ __launch_bounds__(TPB) void k_cell_fill(const SimDev *sims) {
 }
 
 // deterministic order inside each cell: ascending (Morton key of the sub-cell position, atom index);
-// the atomic fill order is not deterministic
-__global__ __launch_bounds__(TPB) void k_cell_sort(const SimDev *sims) {
+// the atomic fill order is not deterministic.  One wave per cell: a lane ranks its member against all members.
+__global__ __launch_bounds__(64) void k_cell_sort(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   if (!S.sc->rebuild) return;
-  const int c = blockIdx.x * TPB + threadIdx.x;
+  const int c = blockIdx.x;
   if (c >= S.ncells) return;
-  const int b = S.cell_start[c], e = b + S.cell_count[c];  // the rest of the cell's range stays pad (-1)
-  for (int s = b; s < e; s++) {
-    // rank of slot_tmp[s] among the members
-    const int a = S.slot_tmp[s];
-    const int ka = S.ckey[a];
+  const int b = S.cell_start[c], n = S.cell_count[c];  // the rest of the cell's range stays pad (-1)
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + (int)threadIdx.x;
+    const int a = (i < n) ? S.slot_tmp[b + i] : 0;
+    const int ka = (i < n) ? S.ckey[a] : 0;
     int r = 0;
-    for (int t = b; t < e; t++) {
-      const int o = S.slot_tmp[t];
-      const int ko = S.ckey[o];
-      r += (ko < ka || (ko == ka && o < a)) ? 1 : 0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int j = j0 + (int)threadIdx.x;
+      const int o_l = (j < n) ? S.slot_tmp[b + j] : 0x7fffffff;
+      const int ko_l = (j < n) ? S.ckey[o_l] : 0x7fffffff;
+      const int m = min(64, n - j0);
+      for (int t = 0; t < m; t++) {
+        const int o = __shfl(o_l, t, 64), ko = __shfl(ko_l, t, 64);
+        r += (ko < ka || (ko == ka && o < a)) ? 1 : 0;
+      }
     }
-    S.perm[b + r] = a;
-    S.slot_of[a] = b + r;
+    if (i < n) {
+      S.perm[b + r] = a;
+      S.slot_of[a] = b + r;
+    }
   }
 }
 
@@ -729,7 +736,7 @@ void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int max
   hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_scan, dim3(ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_fill, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
-  hipLaunchKernelGGL(k_cell_sort, grid2(cdiv(maxcells, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_cell_sort, grid2(maxcells, ns), dim3(64), 0, st, d);
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
   mdk_neigh_build(st, d, ns, maxcells, maxrow, capj);
 }

@@ -645,9 +645,11 @@ static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int
 }
 
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly) {
-  if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng);
+  if (npoly <= 10) launch_pair<10>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 14) launch_pair<14>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 16) launch_pair<16>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 18) launch_pair<18>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 20) launch_pair<20>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 24) launch_pair<24>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 32) launch_pair<32>(st, d, ns, maxcells, capj, vir, eng);
