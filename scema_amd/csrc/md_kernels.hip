@@ -346,67 +346,110 @@ __device__ __forceinline__ void vt(double *v, double ax, double ay, double az, d
 #define EW_ATOMS 64        // atoms staged per block in k_ewald_sfac
 extern __shared__ double2 s_dyn[];  // phase tables, sized by the launch (3*Mmax entries per atom)
 
+// fractional coordinates of atom a in [0,1): the phase angles of the Ewald sums are 2 pi times these, taken with
+// sincospi (exact argument reduction, a fraction of the cost of sincos)
 __device__ __forceinline__ void atom_phase(const SimDev &S, const BoxD &b, int a, double &t0, double &t1, double &t2) {
   const double d0 = S.x[3 * a] - b.lo[0], d1 = S.x[3 * a + 1] - b.lo[1], d2 = S.x[3 * a + 2] - b.lo[2];
   double l0 = b.hinv[0] * d0 + b.hinv[5] * d1 + b.hinv[4] * d2;
   double l1 = b.hinv[1] * d1 + b.hinv[3] * d2;
   double l2 = b.hinv[2] * d2;
-  t0 = 2.0 * MD_PI * (l0 - floor(l0));
-  t1 = 2.0 * MD_PI * (l1 - floor(l1));
-  t2 = 2.0 * MD_PI * (l2 - floor(l2));
+  t0 = l0 - floor(l0);
+  t1 = l1 - floor(l1);
+  t2 = l2 - floor(l2);
 }
 
-// S(k) = sum_i q_i exp(i k.r_i): threads own k-vectors, atoms are staged through LDS as
-// per-atom tables exp(i m theta_d), m = 0..kmax_d (layout [atom][d][m] keeps lanes on
-// consecutive 16-byte slots)
-__global__ __launch_bounds__(TPB) void k_ewald_sfac(const SimDev *sims, int EW_MAXM) {
+// S(k) = sum_i q_i exp(i k.r_i): threads own GROUPS of k-vectors (n1, +-n2, +-n3), atoms are staged
+// through LDS as per-atom tables exp(i m theta_d), m = 0..kmax_d (layout [atom][d][m] keeps lanes on
+// consecutive 16-byte slots).  The up to four members of a group share the three table reads and the
+// products of the phase factors: 3 LDS reads and ~32 FP64 operations per (atom, group) instead of
+// 12 reads and ~48 operations (the kernel was LDS-bandwidth bound with one k-vector per thread).
+// Blocks of one simulation add into the same S(k) with global atomics, which execute at the memory side and
+// serialise per address: the atoms of a simulation are therefore spread over only EW_PARTS blocks, each walking
+// its share of the atoms in chunks of EW_ATOMS and keeping the partial sums in registers.
+#define EW_PARTS 16
+__global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_MAXM, int gthreads) {
   const SimDev &S = sims[blockIdx.y];
   if (S.nk == 0) return;
-  const int a0 = blockIdx.x * EW_ATOMS;
-  if (a0 >= S.natoms) return;
   double2 *s_tab = s_dyn;  // [EW_ATOMS][3][EW_MAXM]
   __shared__ double s_q[EW_ATOMS];
-  const int na = min(EW_ATOMS, S.natoms - a0);
   const int M0 = S.kmaxd[0] + 1, M1 = S.kmaxd[1] + 1, M2 = S.kmaxd[2] + 1;
   const int MS = 3 * EW_MAXM;
-  if (threadIdx.x < 3 * EW_ATOMS) {
-    const int la = threadIdx.x / 3, d = threadIdx.x % 3;
-    if (la < na) {
-      BoxD b;
-      box_derive(S.sc->box, b);
-      double t[3];
-      atom_phase(S, b, a0 + la, t[0], t[1], t[2]);
-      double s1, c1;
-      sincos(t[d], &s1, &c1);
-      const int M = (d == 0) ? M0 : (d == 1) ? M1 : M2;
-      double cr = 1.0, ci = 0.0;
-      double2 *tab = s_tab + la * MS + d * EW_MAXM;
-      for (int m = 0; m < M; m++) {
-        tab[m] = make_double2(cr, ci);
-        const double nr = cr * c1 - ci * s1, ni = ci * c1 + cr * s1;
-        cr = nr; ci = ni;
-      }
-      if (d == 0) s_q[la] = S.q[a0 + la];
-    }
+  const int nchunk = (S.natoms + EW_ATOMS - 1) / EW_ATOMS;
+  // gthreads threads span the groups; the block's nsplit = blockDim / gthreads thread sets interleave the atoms
+  const int nsplit = blockDim.x / gthreads, part = threadIdx.x / gthreads;
+  const int gi = threadIdx.x % gthreads;   // the fast path covers ngrp <= gthreads (checked by the launch)
+  int n1 = 0, m2 = 0, m3 = 0, kpp = -1, kmp = -1, kpm = -1, kmm = -1;
+  if (gi < S.ngrp) {
+    const int4 Ga = ((const int4 *)S.kgrp)[2 * gi], Gb = ((const int4 *)S.kgrp)[2 * gi + 1];
+    n1 = Ga.x; m2 = Ga.y; m3 = Ga.z;
+    kpp = Ga.w; kmp = Gb.x; kpm = Gb.y; kmm = Gb.z;
   }
-  __syncthreads();
-  for (int k = threadIdx.x; k < S.nk; k += TPB) {
-    const int n1 = S.kn[3 * k], n2 = S.kn[3 * k + 1], n3 = S.kn[3 * k + 2];
-    const int m2 = abs(n2), m3 = abs(n3);
-    const double sg2 = (n2 < 0) ? -1.0 : 1.0, sg3 = (n3 < 0) ? -1.0 : 1.0;
-    double Sr = 0.0, Si = 0.0;
-    for (int la = 0; la < na; la++) {
-      const double2 e1 = s_tab[la * MS + n1];
-      double2 e2 = s_tab[la * MS + EW_MAXM + m2];
-      double2 e3 = s_tab[la * MS + 2 * EW_MAXM + m3];
-      e2.y *= sg2; e3.y *= sg3;
-      const double c12 = e1.x * e2.x - e1.y * e2.y, s12 = e1.y * e2.x + e1.x * e2.y;
-      const double cc = c12 * e3.x - s12 * e3.y, ss = s12 * e3.x + c12 * e3.y;
-      const double q = s_q[la];
-      Sr += q * cc; Si += q * ss;
+  double rpp = 0, ipp = 0, rmp = 0, imp = 0, rpm = 0, ipm = 0, rmm = 0, imm = 0;   // (sign of n2, sign of n3)
+  BoxD b;
+  box_derive(S.sc->box, b);
+  for (int ch = blockIdx.x; ch < nchunk; ch += EW_PARTS) {
+    const int a0 = ch * EW_ATOMS;
+    const int na = min(EW_ATOMS, S.natoms - a0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 3 * EW_ATOMS; idx += blockDim.x) {
+      const int la = idx / 3, d = idx % 3;
+      if (la < na) {
+        double t[3];
+        atom_phase(S, b, a0 + la, t[0], t[1], t[2]);
+        double s1, c1;
+        sincospi(2.0 * t[d], &s1, &c1);
+        const int M = (d == 0) ? M0 : (d == 1) ? M1 : M2;
+        double cr = 1.0, ci = 0.0;
+        double2 *tab = s_tab + la * MS + d * EW_MAXM;
+        for (int m = 0; m < M; m++) {
+          tab[m] = make_double2(cr, ci);
+          const double nr = cr * c1 - ci * s1, ni = ci * c1 + cr * s1;
+          cr = nr; ci = ni;
+        }
+        if (d == 0) s_q[la] = S.q[a0 + la];
+      }
     }
-    atomicAdd(&S.sfac[2 * k], Sr);
-    atomicAdd(&S.sfac[2 * k + 1], Si);
+    __syncthreads();
+    if (gi < S.ngrp)
+      for (int la = part; la < na; la += nsplit) {
+        const double2 e1 = s_tab[la * MS + n1];
+        const double2 e2 = s_tab[la * MS + EW_MAXM + m2];
+        const double2 e3 = s_tab[la * MS + 2 * EW_MAXM + m3];
+        const double q = s_q[la];
+        const double a = e1.x * e2.x, bb = e1.y * e2.y, c = e1.y * e2.x, d = e1.x * e2.y;
+        const double c12p = q * (a - bb), s12p = q * (c + d);   // e1 e2
+        const double c12m = q * (a + bb), s12m = q * (c - d);   // e1 conj(e2)
+        rpp += c12p * e3.x - s12p * e3.y; ipp += s12p * e3.x + c12p * e3.y;
+        rpm += c12p * e3.x + s12p * e3.y; ipm += s12p * e3.x - c12p * e3.y;
+        rmp += c12m * e3.x - s12m * e3.y; imp += s12m * e3.x + c12m * e3.y;
+        rmm += c12m * e3.x + s12m * e3.y; imm += s12m * e3.x - c12m * e3.y;
+      }
+  }
+  // all indices are in registers: the atomics go out back to back
+  double *sf = S.sfac;
+  if (kpp >= 0) { atomicAdd(&sf[2 * kpp], rpp); atomicAdd(&sf[2 * kpp + 1], ipp); }
+  if (kmp >= 0) { atomicAdd(&sf[2 * kmp], rmp); atomicAdd(&sf[2 * kmp + 1], imp); }
+  if (kpm >= 0) { atomicAdd(&sf[2 * kpm], rpm); atomicAdd(&sf[2 * kpm + 1], ipm); }
+  if (kmm >= 0) { atomicAdd(&sf[2 * kmm], rmm); atomicAdd(&sf[2 * kmm + 1], imm); }
+  // more groups than threads (very large k sets): the rest one group at a time, tables rebuilt per chunk
+  for (int g2 = gthreads + (int)threadIdx.x; g2 < S.ngrp; g2 += blockDim.x) {
+    const int *G = S.kgrp + 8 * g2;
+    for (int mm = 0; mm < 4; mm++) {
+      const int k = G[3 + mm];
+      if (k < 0) continue;
+      const int a1 = S.kn[3 * k], a2 = S.kn[3 * k + 1], a3 = S.kn[3 * k + 2];
+      double sr = 0.0, si = 0.0;
+      for (int ch = blockIdx.x; ch < nchunk; ch += EW_PARTS)
+        for (int la = 0; la < EW_ATOMS && ch * EW_ATOMS + la < S.natoms; la++) {
+          double t[3];
+          atom_phase(S, b, ch * EW_ATOMS + la, t[0], t[1], t[2]);
+          double s1, c1;
+          sincospi(2.0 * (a1 * t[0] + a2 * t[1] + a3 * t[2]), &s1, &c1);
+          sr += S.q[ch * EW_ATOMS + la] * c1; si += S.q[ch * EW_ATOMS + la] * s1;
+        }
+      atomicAdd(&sf[2 * k], sr);
+      atomicAdd(&sf[2 * k + 1], si);
+    }
   }
 }
 
@@ -474,7 +517,7 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims) {
     box_derive(S.sc->box, b);
     double t[3];
     atom_phase(S, b, a, t[0], t[1], t[2]);
-    sincos(t[0], &s1, &c1); sincos(t[1], &s2, &c2); sincos(t[2], &s3, &c3);
+    sincospi(2.0 * t[0], &s1, &c1); sincospi(2.0 * t[1], &s2, &c2); sincospi(2.0 * t[2], &s3, &c3);
   }
   double e1r = 1.0, e1i = 0.0;   // e1^m1
   double pr = 1.0, pi = 0.0;     // e1^m1 e2^m2 e3^m3
@@ -743,7 +786,7 @@ void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int max
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
 }
-void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax) {
+void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax, int maxgrp) {
   if (maxk <= 0) {  // no charges anywhere: the force kernel still assembles f from the slot-ordered pair + bonded forces
     hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d);
     return;
@@ -752,7 +795,9 @@ void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, 
   // more than 64 KB of dynamic LDS needs an explicit opt-in (large k ranges: small cut_coul or tight accuracy)
   static size_t optin_s = 0;
   if (lds_s > 64 * 1024 && lds_s > optin_s) { (void)hipFuncSetAttribute((const void *)k_ewald_sfac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); optin_s = lds_s; }
-  hipLaunchKernelGGL(k_ewald_sfac, grid2(cdiv(maxatoms, EW_ATOMS), ns), dim3(TPB), lds_s, st, d, mmax);
+  // threads own groups of k-vectors: the block size that wastes the fewest lanes
+  const int gthreads = maxgrp <= 64 ? 64 : (maxgrp <= 128 ? 128 : 256);
+  hipLaunchKernelGGL(k_ewald_sfac, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
   hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d);
 }

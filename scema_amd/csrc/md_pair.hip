@@ -581,22 +581,30 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   // sum_pairs (r_i - r_j) (x) F_ij = sum over table entries of r_l (x) (force accumulated on entry l), with the
   // image position r_l; the accumulated forces of a tile sum to zero, so positions are taken relative to the
   // tile's first slot.  This costs 6 FMAs per table entry instead of 6 per pair.
-  {
-    double *fs = S.fs;
-    const size_t np = (size_t)S.npad;
+  // Loads and atomics are kept in separate passes: the memory counter of a wave is in-order, so a load issued
+  // after an atomic would wait for the atomic's round trip.
+  if (VIR && !ENG) {
     const double rx = XQ_X(S, cs), ry = XQ_Y(S, cs), rz = XQ_Z(S, cs);
     for (int l = threadIdx.x; l < nj; l += TT) {
       const double ax = s_fx[l], ay = s_fy[l], az = s_fz[l];
       if (ax != 0.0 || ay != 0.0 || az != 0.0) {
         const int jt = s_jtab[l];
         const size_t slot = (size_t)(jt & MD_JMASK);
+        const int c4 = 4 * (jt >> 23);
+        const double px = xq[2 * slot] + s_shift[c4] - rx, py = xq[2 * slot + 1] + s_shift[c4 + 1] - ry, pz = zq[2 * slot] + s_shift[c4 + 2] - rz;
+        vl[0] = fma(px, ax, vl[0]); vl[1] = fma(py, ay, vl[1]); vl[2] = fma(pz, az, vl[2]);
+        vl[3] = fma(px, ay, vl[3]); vl[4] = fma(px, az, vl[4]); vl[5] = fma(py, az, vl[5]);
+      }
+    }
+  }
+  {
+    double *fs = S.fs;
+    const size_t np = (size_t)S.npad;
+    for (int l = threadIdx.x; l < nj; l += TT) {
+      const double ax = s_fx[l], ay = s_fy[l], az = s_fz[l];
+      if (ax != 0.0 || ay != 0.0 || az != 0.0) {
+        const size_t slot = (size_t)(s_jtab[l] & MD_JMASK);
         atomicAdd(fs + slot, ax); atomicAdd(fs + np + slot, ay); atomicAdd(fs + 2 * np + slot, az);
-        if (VIR && !ENG) {
-          const int c4 = 4 * (jt >> 23);
-          const double px = xq[2 * slot] + s_shift[c4] - rx, py = xq[2 * slot + 1] + s_shift[c4 + 1] - ry, pz = zq[2 * slot] + s_shift[c4 + 2] - rz;
-          vl[0] = fma(px, ax, vl[0]); vl[1] = fma(py, ay, vl[1]); vl[2] = fma(pz, az, vl[2]);
-          vl[3] = fma(px, ay, vl[3]); vl[4] = fma(px, az, vl[4]); vl[5] = fma(py, az, vl[5]);
-        }
       }
     }
   }
