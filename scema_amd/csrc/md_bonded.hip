@@ -8,7 +8,8 @@
 //     terms whose lowest-ranked atom is one of them (built once per topology, md_engine.cpp build_topo);
 //   * the tile's atoms (owners + halo) get local indices; their positions are staged in LDS, the forces of
 //     all terms accumulate in LDS (ds_add_f64), and the tile is flushed with one global atomic triple per
-//     local atom into the slot-ordered force array that k_pair also accumulates into;
+//     local atom into the bonded-force array fb, which is indexed by breadth-first rank: a tile's owners are
+//     128 consecutive entries and its halo lies next to them, so the atomics of a wave share cache lines;
 //   * kinds are processed one after the other, so the lanes of a wave run the same formula.
 //
 // Virial of a term = sum_a (r_a - r_ref) (x) F_a with r_ref = atom 3 for torsions, the vertex for angles,
@@ -244,15 +245,15 @@ __global__ __launch_bounds__(BT_TPB) void k_bonded(const SimDev *__restrict__ si
     }
   }
   __syncthreads();
-  // flush: one atomic triple per local atom into the slot-ordered force array (shared with k_pair)
+  // flush: one atomic triple per local atom into fb (rank order; the tile's own atoms first = consecutive)
   {
-    double *fs = S.fs;
-    const size_t np = (size_t)S.npad;
+    double *fb = S.fb;
+    const int *rk = S.bt_rank;
     for (int l = threadIdx.x; l < nloc; l += BT_TPB) {
       const double ax = s_f[3 * l], ay = s_f[3 * l + 1], az = s_f[3 * l + 2];
       if (ax != 0.0 || ay != 0.0 || az != 0.0) {
-        const size_t slot = (size_t)S.slot_of[atoms[l]];
-        atomicAdd(fs + slot, ax); atomicAdd(fs + np + slot, ay); atomicAdd(fs + 2 * np + slot, az);
+        const size_t r = (size_t)rk[atoms[l]];
+        atomicAdd(fb + 3 * r, ax); atomicAdd(fb + 3 * r + 1, ay); atomicAdd(fb + 3 * r + 2, az);
       }
     }
   }

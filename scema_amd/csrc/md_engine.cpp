@@ -89,7 +89,7 @@ struct Topo {
   std::vector<double> init_x, init_v;
   // device copies
   DevBuf d_type, d_q, d_mass, d_lj, d_bond_at, d_bond_cf, d_angle_at, d_angle_cf, d_dih_at, d_dih_cf, d_imp_at, d_imp_cf,
-      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_bondsh_at, d_bondsh_cf, d_bt_desc, d_bt_atoms;
+      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_bondsh_at, d_bondsh_cf, d_bt_desc, d_bt_atoms, d_bt_rank;
   int bt_ntile = 0, bt_maxloc = 1;
 };
 
@@ -102,7 +102,7 @@ struct State {
 struct Slot {
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
   size_t cap_jtab = 0;
-  DevBuf fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
+  DevBuf fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
   DevBuf kgrp;
   DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
       xbak, vbak;
@@ -372,14 +372,23 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   for (int tl = 0; tl < ntile; tl++) {
     int *desc = &bt_desc[(size_t)tl * BT_DESC];
     desc[0] = (int)bt_atoms.size();
+    // local atom list sorted by rank: the tile's own atoms are consecutive, and so are the flush atomics of a wave
     std::vector<int> members;
-    auto local = [&](int atom) {
-      if (local_of[atom] < 0) {
-        local_of[atom] = (int)members.size();
-        members.push_back(atom);
-      }
-      return local_of[atom];
+    auto term_atoms = [&](const TermRef &tr, int &cnt) -> const int * {
+      const int m = tr.idx;
+      cnt = natm[tr.kind];
+      return (tr.kind <= BT_BOND_SHAKEN) ? &bond_at[2 * m] : (tr.kind == BT_ANGLE) ? &angle_at[3 * m] : (tr.kind == BT_DIHEDRAL) ? &dih_at[4 * m]
+             : (tr.kind == BT_IMPROPER) ? &imp_at[4 * m] : &sp_at[2 * m];
     };
+    for (const TermRef &tr : tile_terms[tl]) {
+      int cnt;
+      const int *at = term_atoms(tr, cnt);
+      for (int k = 0; k < cnt; k++)
+        if (local_of[at[k]] < 0) { local_of[at[k]] = 0; members.push_back(at[k]); }
+    }
+    std::sort(members.begin(), members.end(), [&](int a, int b) { return rank[a] < rank[b]; });
+    for (size_t l = 0; l < members.size(); l++) local_of[members[l]] = (int)l;
+    auto local = [&](int atom) { return local_of[atom]; };
     for (int kind = 0; kind < BT_NKIND; kind++) {
       desc[2 + 2 * kind] = (int)l_at[kind].size() / natm[kind];
       int cnt = 0;
@@ -433,6 +442,7 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   if ((rc = upload(e, t.d_sp_cf, l_cf[BT_SPECIAL]))) return rc;
   if ((rc = upload(e, t.d_bt_desc, bt_desc))) return rc;
   if ((rc = upload(e, t.d_bt_atoms, bt_atoms))) return rc;
+  if ((rc = upload(e, t.d_bt_rank, rank))) return rc;
   if ((rc = upload(e, t.d_ex_start, ex_start))) return rc;
   if ((rc = upload(e, t.d_ex_list, ex_list))) return rc;
   if ((rc = upload(e, t.d_clus_at, clus_at))) return rc;
@@ -650,12 +660,13 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.f.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.slot_of.ensure((size_t)natoms * 4));
     HIPCHK(sl.fs.ensure(3 * (size_t)npad * 8));
+    HIPCHK(sl.fb.ensure(3 * (size_t)npad * 8));
     HIPCHK(sl.tile_order.ensure((size_t)npad * 4));
     HIPCHK(sl.wrapn.ensure(3 * (size_t)natoms * 4));
     HIPCHK(sl.xhold.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.cell_of.ensure((size_t)natoms * 4));
     HIPCHK(sl.ckey.ensure((size_t)natoms * 4));
-    HIPCHK(sl.slot_tmp.ensure((size_t)natoms * 4));
+    HIPCHK(sl.slot_tmp.ensure((size_t)npad * 4));   // indexed by (padded) slot
     HIPCHK(sl.xbak.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.vbak.ensure(3 * (size_t)natoms * 8));
     HIPCHK(sl.xq.ensure((size_t)npad * 32));
@@ -836,7 +847,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.special_at = T.d_sp_at.as<int>(); S.special_cf = T.d_sp_cf.as<double>();
     S.ex_start = T.d_ex_start.as<int>(); S.ex_list = T.d_ex_list.as<int>();
     S.bondsh_at = T.d_bondsh_at.as<int>(); S.bondsh_cf = T.d_bondsh_cf.as<double>();
-    S.bt_desc = T.d_bt_desc.as<int>(); S.bt_atoms = T.d_bt_atoms.as<int>(); S.bt_ntile = T.bt_ntile;
+    S.bt_desc = T.d_bt_desc.as<int>(); S.bt_atoms = T.d_bt_atoms.as<int>(); S.bt_rank = T.d_bt_rank.as<int>(); S.bt_ntile = T.bt_ntile;
     maxbt = std::max(maxbt, T.bt_ntile); maxloc = std::max(maxloc, T.bt_maxloc);
     S.clus_at = T.d_clus_at.as<int>(); S.clus_n = T.d_clus_n.as<int>(); S.clus_d = T.d_clus_d.as<double>();
     S.x = A.st->x.as<double>(); S.v = A.st->v.as<double>(); S.f = sl.f.as<double>();
@@ -844,7 +855,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.wrapn = sl.wrapn.as<int>(); S.xhold = sl.xhold.as<double>();
     S.cell_of = sl.cell_of.as<int>(); S.ckey = sl.ckey.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
-    S.fs = sl.fs.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>();
+    S.fs = sl.fs.as<double>(); S.fb = sl.fb.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>();
     S.kn = sl.kn.as<int>(); S.kgrp = sl.kgrp.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;
     if (S.nk > 0) {

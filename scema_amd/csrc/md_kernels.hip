@@ -310,6 +310,7 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   if (s >= S.npad) return;
   // k_pair accumulates into the slot-ordered pair forces with atomics
   S.fs[s] = 0.0; S.fs[(size_t)S.npad + s] = 0.0; S.fs[2 * (size_t)S.npad + s] = 0.0;
+  S.fb[3 * (size_t)s] = 0.0; S.fb[3 * (size_t)s + 1] = 0.0; S.fb[3 * (size_t)s + 2] = 0.0;   // npad >= natoms entries
   const int a = S.perm[s];
   if (a < 0) {  // pad slot: a record no real atom is ever within the list cutoff of
     if (S.sc->rebuild) {
@@ -554,13 +555,13 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims) {
     }
   }
   if (act) {
-    // f (atom order) = pair + bonded forces (slot order, accumulated by k_pair and k_bonded) + reciprocal part;
+    // f (atom order) = pair forces (slot order, k_pair) + bonded forces (rank order, k_bonded) + reciprocal part;
     // every atom is owned by exactly one thread and the kernels of a step are stream-ordered
     const double pq = 2.0 * MD_QQRD2E * S.q[a];
-    const size_t sl = (size_t)S.slot_of[a], np = (size_t)S.npad;
-    S.f[3 * a] = S.fs[sl] + pq * fx;
-    S.f[3 * a + 1] = S.fs[np + sl] + pq * fy;
-    S.f[3 * a + 2] = S.fs[2 * np + sl] + pq * fz;
+    const size_t sl = (size_t)S.slot_of[a], np = (size_t)S.npad, r = (size_t)S.bt_rank[a];
+    S.f[3 * a] = S.fs[sl] + S.fb[3 * r] + pq * fx;
+    S.f[3 * a + 1] = S.fs[np + sl] + S.fb[3 * r + 1] + pq * fy;
+    S.f[3 * a + 2] = S.fs[2 * np + sl] + S.fb[3 * r + 2] + pq * fz;
   }
 }
 

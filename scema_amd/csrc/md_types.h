@@ -95,11 +95,13 @@ struct SimDev {
   const int *special_at; const double *special_cf;  // 2 ints, (w_lj*lj1, w_lj*lj2, qqrd2e*qi*qj, w_coul, w_lj*lj3, w_lj*lj4)
   const int *ex_start, *ex_list;
   const int *bt_desc, *bt_atoms;   // tile descriptors, local atom lists
+  const int *bt_rank;              // atom -> breadth-first rank in the bond graph (index into fb)
   int bt_ntile;
   const int *clus_at, *clus_n; const double *clus_d;
   // state
   double *x, *v, *f;
-  double *fs;       // pair forces in slot order, [3][npad] (zeroed by k_pack, filled by k_pair, folded into f by k_bonded_atom)
+  double *fs;       // pair forces in slot order, [3][npad] (zeroed by k_pack, accumulated by k_pair, folded into f by k_ewald_force)
+  double *fb;       // bonded forces in breadth-first-rank order, [natoms][3] (zeroed by k_pack, accumulated by k_bonded)
   int *slot_of;     // atom -> slot
   int *tile_nj;     // per cell: entries of its j table
   int *tile_order;  // per cell, at its cluster range: the cell's clusters grouped by the wave of k_pair that takes them
