@@ -37,6 +37,24 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// block-wide sum of NV values per thread over NW waves, result atomically added to dst[0..NV)
+template <int NV, int NW>
+__device__ __forceinline__ void block_atomic_add_n(double (&vals)[NV], double *dst, double *lds /* >= NV*NW */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    double s = wave_sum(vals[k]);
+    if (lane == 0) lds[k * NW + wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+    for (int w = 0; w < NW; w++) s += lds[threadIdx.x * NW + w];
+    if (s != 0.0) atomicAdd(&dst[threadIdx.x], s);
+  }
+}
+
 // block-wide sum of NV values per thread, result atomically added to dst[0..NV)
 template <int NV>
 __device__ __forceinline__ void block_atomic_add(double (&vals)[NV], double *dst, double *lds /* >= NV*(TPB/64) */) {

@@ -102,7 +102,7 @@ struct State {
 struct Slot {
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
   size_t cap_jtab = 0;
-  DevBuf fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
+  DevBuf virp, fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
   DevBuf kgrp;
   DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
       xbak, vbak;
@@ -688,6 +688,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.cell_fill.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.tile_nj.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.tile_wstart.ensure((size_t)(ncells + 1) * 9 * 4));
+    HIPCHK(sl.virp.ensure((size_t)(ncells + 1) * MD_TILE_WAVES * 6 * 8));
     sl.cap_cells = ncells + 1;
   }
   if ((size_t)ncells * capj > sl.cap_jtab || sl.cap_jtab == 0) {
@@ -855,7 +856,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.wrapn = sl.wrapn.as<int>(); S.xhold = sl.xhold.as<double>();
     S.cell_of = sl.cell_of.as<int>(); S.ckey = sl.ckey.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
-    S.fs = sl.fs.as<double>(); S.fb = sl.fb.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>();
+    S.fs = sl.fs.as<double>(); S.fb = sl.fb.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>(); S.virp = sl.virp.as<double>();
     S.kn = sl.kn.as<int>(); S.kgrp = sl.kgrp.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;
     if (S.nk > 0) {
@@ -887,7 +888,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
   mdk_pair(st, D, ns, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
   mdk_bonded(st, D, ns, maxbt, maxloc, spec.ev_always);
-  mdk_ewald(st, D, ns, maxatoms, maxk, mmax, maxgrp);
+  mdk_ewald(st, D, ns, maxatoms, maxk, mmax, maxgrp, (ev && !spec.ev_always) ? 1 : 0);
   if (!spec.static_only) mdk_shake(st, D, ns, maxclus, 0.5);
   mdk_final_integrate(st, D, ns, maxatoms, 0);
   mdk_setup_post(st, D, ns);
@@ -919,7 +920,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       launch_bytes.push_back((double)na);
     }
     mdk_bonded(st, D, na, maxbt, maxloc, spec.ev_always);
-    mdk_ewald(st, D, na, maxatoms, maxk, mmax, maxgrp);
+    mdk_ewald(st, D, na, maxatoms, maxk, mmax, maxgrp, (ev && !spec.ev_always) ? 1 : 0);
     mdk_shake(st, D, na, maxclus, 1.0);
     mdk_final_integrate(st, D, na, maxatoms, 1);
     mdk_post(st, D, na);

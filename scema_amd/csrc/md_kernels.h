@@ -16,7 +16,9 @@ void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly);
 // bonded terms + special pairs, one workgroup per bonded tile; parts != 0: per-part virial/energy (parity hook)
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int parts);
-void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax, int maxgrp);
+// pairvir != 0: k_ewald_force also folds the production pair virial (slot-ordered forces x positions + the
+// per-wave image-shift partials of k_pair) into the virial of the step
+void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax, int maxgrp, int pairvir);
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);
 void mdk_post(hipStream_t st, const SimDev *d, int ns);

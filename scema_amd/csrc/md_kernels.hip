@@ -506,10 +506,11 @@ __device__ __forceinline__ void cmul(double &pr, double &pi, double c, double s)
   const double nr = pr * c - pi * s, ni = pi * c + pr * s;
   pr = nr; pi = ni;
 }
-__global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims) {
+__global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int pairvir) {
   const SimDev &S = sims[blockIdx.y];
   if ((int)(blockIdx.x * EWF_TPB) >= S.natoms) return;
   __shared__ EwK s_k[EWF_KC];
+  __shared__ double s_red[8 * (EWF_TPB / 64)];
   const int a = min((int)(blockIdx.x * EWF_TPB + threadIdx.x), S.natoms - 1);
   const bool act = (int)(blockIdx.x * EWF_TPB + threadIdx.x) < S.natoms;
   double c1, s1, c2, s2, c3, s3;
@@ -554,14 +555,32 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims) {
       fx = fma(pf, e.kx, fx); fy = fma(pf, e.ky, fy); fz = fma(pf, e.kz, fz);
     }
   }
+  double pv[6] = {0, 0, 0, 0, 0, 0};
   if (act) {
     // f (atom order) = pair forces (slot order, k_pair) + bonded forces (rank order, k_bonded) + reciprocal part;
     // every atom is owned by exactly one thread and the kernels of a step are stream-ordered
     const double pq = 2.0 * MD_QQRD2E * S.q[a];
     const size_t sl = (size_t)S.slot_of[a], np = (size_t)S.npad, r = (size_t)S.bt_rank[a];
-    S.f[3 * a] = S.fs[sl] + S.fb[3 * r] + pq * fx;
-    S.f[3 * a + 1] = S.fs[np + sl] + S.fb[3 * r + 1] + pq * fy;
-    S.f[3 * a + 2] = S.fs[2 * np + sl] + S.fb[3 * r + 2] + pq * fz;
+    const double px = S.fs[sl], py = S.fs[np + sl], pz = S.fs[2 * np + sl];
+    S.f[3 * a] = px + S.fb[3 * r] + pq * fx;
+    S.f[3 * a + 1] = py + S.fb[3 * r + 1] + pq * fy;
+    S.f[3 * a + 2] = pz + S.fb[3 * r + 2] + pq * fz;
+    if (pairvir) {
+      // pair virial, part 1: wrapped slot position (x) total pair force of the slot (part 2 = k_pair's partials)
+      const double *xy = (const double *)S.xq + 2 * sl, *zq = (const double *)S.xq + 2 * np + 2 * sl;
+      const double x = xy[0], y = xy[1], z = zq[0];
+      pv[0] = x * px; pv[1] = y * py; pv[2] = z * pz; pv[3] = x * py; pv[4] = x * pz; pv[5] = y * pz;
+    }
+  }
+  if (pairvir) {
+    const int nrows = S.ncells * MD_TILE_WAVES;   // one row of 6 per cell and wave of k_pair
+    const int nblk = (S.natoms + EWF_TPB - 1) / EWF_TPB;   // blocks of this simulation that got this far
+    for (int r = blockIdx.x * EWF_TPB + threadIdx.x; r < nrows; r += nblk * EWF_TPB) {
+      const double *vp = S.virp + (size_t)r * 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) pv[k] += vp[k];
+    }
+    block_atomic_add_n<6, EWF_TPB / 64>(pv, S.sc->vir + P_LJ * 6, s_red);
   }
 }
 
@@ -787,9 +806,9 @@ void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int max
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
 }
-void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax, int maxgrp) {
+void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax, int maxgrp, int pairvir) {
   if (maxk <= 0) {  // no charges anywhere: the force kernel still assembles f from the slot-ordered pair + bonded forces
-    hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d);
+    hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d, pairvir);
     return;
   }
   const size_t lds_s = (size_t)EW_ATOMS * 3 * mmax * sizeof(double2);
@@ -800,7 +819,7 @@ void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, 
   const int gthreads = maxgrp <= 64 ? 64 : (maxgrp <= 128 ? 128 : 256);
   hipLaunchKernelGGL(k_ewald_sfac, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
   hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
-  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d);
+  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d, pairvir);
 }
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
   if (maxclus <= 0) return;

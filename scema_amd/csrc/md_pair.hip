@@ -28,7 +28,7 @@
 #include "md_device.h"
 #include "md_kernels.h"
 
-#define TW 8               // waves per tile workgroup
+#define TW MD_TILE_WAVES    // waves per tile workgroup
 #define TT (TW * 64)
 #define NI MD_CLUSTER
 #define E_LMASK 0x1FFF
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
   __shared__ double s_shift[27 * 3];
   __shared__ double s_box[6];   // bounding box of the cell's real atoms
   __shared__ int s_wcnt[TW];
+  __shared__ int s_cost[64];
   int *s_jtab = s_build;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
       ci.x[a] = XQ_X(S, s0slot + a); ci.y[a] = XQ_Y(S, s0slot + a); ci.z[a] = XQ_Z(S, s0slot + a);
     }
     if (ci.atom[0] < 0) {  // empty cluster (pad only)
-      if (lane == 0) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
+      if (lane == 0) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; if (cl - cs / NI < 64) s_cost[cl - cs / NI] = 0; }
       continue;
     }
     GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)cl * maxrow;
@@ -333,7 +334,11 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     // B: LDS list -> behind A (same-wave LDS traffic is processed in order)
     const int mB_ = bad ? 0 : nB;
     for (int k = lane; k < mB_; k += 64) row[nA + k] = lb[k];
-    if (lane == 0) { S.numneigh[2 * cl] = bad ? 0 : nA + nB; S.numneigh[2 * cl + 1] = bad ? 0 : nC; }
+    if (lane == 0) {
+      S.numneigh[2 * cl] = bad ? 0 : nA + nB; S.numneigh[2 * cl + 1] = bad ? 0 : nC;
+      // cost of the row in k_pair (FP64 instructions per entry of the three segments + per-row overhead)
+      if (cl - cs / NI < 64) s_cost[cl - cs / NI] = bad ? 0 : 5 * nA + 3 * nB + (3 * nC) / 2 + 96;
+    }
     nmax = max(nmax, n);
     nrowent += n;
   }
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     int *wst = S.tile_wstart + (size_t)cell * (TW + 1);
     if (nclus <= 64) {
       const int i = lane;
-      const int cnt_i = (i < nclus) ? S.numneigh[2 * (c0i + i)] + S.numneigh[2 * (c0i + i) + 1] : -1;
+      const int cnt_i = (i < nclus) ? s_cost[i] : -1;
       int rank = 0;
       for (int j = 0; j < nclus; j++) {
         const int cj = __shfl(cnt_i, j, 64);
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
         int pos = 0;
 #pragma unroll
         for (int w = 0; w < TW; w++)
-          if (w == wmin) { pos = num[w]; num[w] += 1; load[w] += c + 32; }   // + per-row overhead (reduction, setup)
+          if (w == wmin) { pos = num[w]; num[w] += 1; load[w] += c; }
         if (lane == src) { my_w = wmin; my_pos = pos; }
       }
       int start = 0, my_start = 0;
@@ -420,7 +425,10 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   const SimDev &S = sims[sim];
   if (cell >= S.ncells) return;
   const int cs = S.cell_start[cell], ce = S.cell_start[cell + 1];
-  if (ce == cs) return;
+  if (ce == cs) {   // empty cell: its virial partials are still read by k_ewald_force
+    if (VIR && !ENG && threadIdx.x < TW * 6) S.virp[(size_t)cell * TW * 6 + threadIdx.x] = 0.0;
+    return;
+  }
   SimScalars &sc = *S.sc;
   __shared__ double s_shift[27 * 4];
   __shared__ __attribute__((aligned(16))) double s_lj[2 * MD_MAXTYPES * MD_MAXTYPES];
@@ -581,17 +589,17 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   // sum_pairs (r_i - r_j) (x) F_ij = sum over table entries of r_l (x) (force accumulated on entry l), with the
   // image position r_l; the accumulated forces of a tile sum to zero, so positions are taken relative to the
   // tile's first slot.  This costs 6 FMAs per table entry instead of 6 per pair.
-  // Loads and atomics are kept in separate passes: the memory counter of a wave is in-order, so a load issued
-  // after an atomic would wait for the atomic's round trip.
+  // Production virial (one lumped pair virial; the pressure sums all parts anyway): the tile's pairs contribute
+  // sum_pairs (r_i - r_j) (x) F_ij = sum over table entries l of (x_slot(l) + shift_l) (x) F_l, F_l = force
+  // accumulated on entry l.  Summed over all tiles the first part is sum_slots x_slot (x) fs_slot, which
+  // k_ewald_force takes from the finished slot-ordered forces; the tile only adds the image-shift part of its
+  // non-home entries (shift from LDS, no position gathers), one partial sum per wave, stored without atomics.
   if (VIR && !ENG) {
-    const double rx = XQ_X(S, cs), ry = XQ_Y(S, cs), rz = XQ_Z(S, cs);
     for (int l = threadIdx.x; l < nj; l += TT) {
-      const double ax = s_fx[l], ay = s_fy[l], az = s_fz[l];
-      if (ax != 0.0 || ay != 0.0 || az != 0.0) {
-        const int jt = s_jtab[l];
-        const size_t slot = (size_t)(jt & MD_JMASK);
-        const int c4 = 4 * (jt >> 23);
-        const double px = xq[2 * slot] + s_shift[c4] - rx, py = xq[2 * slot + 1] + s_shift[c4 + 1] - ry, pz = zq[2 * slot] + s_shift[c4 + 2] - rz;
+      const int code = s_jtab[l] >> 23;
+      if (code != CODE_HOME) {
+        const double ax = s_fx[l], ay = s_fy[l], az = s_fz[l];
+        const double px = s_shift[4 * code], py = s_shift[4 * code + 1], pz = s_shift[4 * code + 2];
         vl[0] = fma(px, ax, vl[0]); vl[1] = fma(py, ay, vl[1]); vl[2] = fma(pz, az, vl[2]);
         vl[3] = fma(px, ay, vl[3]); vl[4] = fma(px, az, vl[4]); vl[5] = fma(py, az, vl[5]);
       }
@@ -608,9 +616,17 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       }
     }
   }
-  if (VIR) {
+  if (VIR && !ENG) {
+    double *vp = S.virp + ((size_t)cell * TW + wave) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double t = wave_sum(vl[k]);
+      if (lane == 0) vp[k] = t;
+    }
+  }
+  if (VIR && ENG) {
     tile_atomic_add<6>(vl, sc.vir + P_LJ * 6, s_red);
-    if (ENG) tile_atomic_add<6>(vc, sc.vir + P_COUL * 6, s_red);
+    tile_atomic_add<6>(vc, sc.vir + P_COUL * 6, s_red);
   }
   if (ENG) {
     double e1[1];

@@ -10,6 +10,7 @@
 #define MD_NPART 8
 #define MD_MAXTYPES 16
 #define MD_MAXPOLY 48
+#define MD_TILE_WAVES 8       /* waves of a k_pair tile workgroup (md_pair.hip) */
 #define MD_CLUSTER 4          /* atoms per i-cluster (consecutive slots inside one cell) */
 #define MD_JMASK 0x007FFFFF   /* tile j-table entry: [22:0] slot of j, [27:23] image code (md_pair.hip) */
 #define MD_MAXJTAB 8191       /* row entries carry a 13-bit index into the tile's j table */
@@ -105,6 +106,7 @@ struct SimDev {
   int *slot_of;     // atom -> slot
   int *tile_nj;     // per cell: entries of its j table
   int *tile_order;  // per cell, at its cluster range: the cell's clusters grouped by the wave of k_pair that takes them
+  double *virp;     // per cell and wave of k_pair: 6 partial sums of the pair virial's image-shift part (no atomics)
   int *tile_wstart; // per cell: 9 group boundaries into tile_order (k_pair's schedule, fixed at build time)
   int *tile_jtab;   // per cell: capj entries (image code | slot), own cell first
   // pair structures
