@@ -510,6 +510,7 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
   const SimDev &S = sims[blockIdx.y];
   if ((int)(blockIdx.x * EWF_TPB) >= S.natoms) return;
   __shared__ EwK s_k[EWF_KC];
+  __shared__ int s_run[EWF_KC];
   __shared__ double s_red[8 * (EWF_TPB / 64)];
   const int a = min((int)(blockIdx.x * EWF_TPB + threadIdx.x), S.natoms - 1);
   const bool act = (int)(blockIdx.x * EWF_TPB + threadIdx.x) < S.natoms;
@@ -537,9 +538,22 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
       e.n23 = (S.kn[3 * k + 1] + 128) | ((S.kn[3 * k + 2] + 128) << 8);
       s_k[threadIdx.x] = e;
     }
+    if (threadIdx.x < EWF_KC) {
+      // length of the run of k-vectors that continue this one's row (same n1, n2; n3 + 1 each), inside the chunk
+      const int t = threadIdx.x, kc0 = min(EWF_KC, S.nk - kb);
+      int run = 0;
+      if (t < kc0) {
+        const int a1 = S.kn[3 * (kb + t)], a2 = S.kn[3 * (kb + t) + 1], a3 = S.kn[3 * (kb + t) + 2];
+        while (t + run + 1 < kc0 && S.kn[3 * (kb + t + run + 1)] == a1 && S.kn[3 * (kb + t + run + 1) + 1] == a2 &&
+               S.kn[3 * (kb + t + run + 1) + 2] == a3 + run + 1)
+          run++;
+      }
+      s_run[t] = run;
+    }
     __syncthreads();
     const int kc = min(EWF_KC, S.nk - kb);
-    for (int kk = 0; kk < kc; kk++) {
+    for (int kk = 0; kk < kc;) {
+      // head of a row (or of a chunk): general move of the cursor
       const EwK e = s_k[kk];
       const int n1 = __builtin_amdgcn_readfirstlane(e.n1), n23 = __builtin_amdgcn_readfirstlane(e.n23);
       const int n2 = (n23 & 0xFF) - 128, n3 = ((n23 >> 8) & 0xFF) - 128;
@@ -551,8 +565,20 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
       while (m2 > n2) { cmul(pr, pi, c2, -s2); m2--; }
       while (m3 < n3) { cmul(pr, pi, c3, s3); m3++; }
       while (m3 > n3) { cmul(pr, pi, c3, -s3); m3--; }
-      const double pf = pi * e.pr - pr * e.pi;
-      fx = fma(pf, e.kx, fx); fy = fma(pf, e.ky, fy); fz = fma(pf, e.kz, fz);
+      {
+        const double pf = pi * e.pr - pr * e.pi;
+        fx = fma(pf, e.kx, fx); fy = fma(pf, e.ky, fy); fz = fma(pf, e.kz, fz);
+      }
+      // rest of the row: n3 -> n3 + 1 = one complex multiplication each, no scalar control
+      const int run = __builtin_amdgcn_readfirstlane(s_run[kk]);
+      for (int r = 1; r <= run; r++) {
+        const EwK g = s_k[kk + r];
+        cmul(pr, pi, c3, s3);
+        const double pf = pi * g.pr - pr * g.pi;
+        fx = fma(pf, g.kx, fx); fy = fma(pf, g.ky, fy); fz = fma(pf, g.kz, fz);
+      }
+      m3 += run;
+      kk += run + 1;
     }
   }
   double pv[6] = {0, 0, 0, 0, 0, 0};
