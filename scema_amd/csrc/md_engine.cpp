@@ -1153,6 +1153,8 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     delete e;
     return SCEMA_MD_ERR_DEVICE;
   }
+  // test hook: start with undersized neighbour capacities, so that the overflow -> restore -> regrow path runs
+  if (const char *g0 = getenv("SCEMA_MD_NEIGH_GROW0")) e->neigh_grow = std::max(0.05, atof(g0));
   *out = e;
   return SCEMA_MD_OK;
 }

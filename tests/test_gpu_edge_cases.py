@@ -111,6 +111,45 @@ def test_sampling_window_rule(small_pe):
     eng.close()
 
 
+def test_neighbour_overflow_regrow(small_pe, monkeypatch):
+    """Undersized j tables / rows (test hook): the evaluation is restored from its backup, capacities grow x1.5 per
+    attempt, and the result equals the normally sized run."""
+    from scema_amd import capi
+    lens = _lens(small_pe)
+    st = np.array([-3e-4 * lens[0], -3e-4 * lens[1], 1e-3 * lens[2], 0, 0, 0])
+    res = []
+    for grow0 in (None, "0.2"):
+        if grow0 is None:
+            monkeypatch.delenv("SCEMA_MD_NEIGH_GROW0", raising=False)
+        else:
+            monkeypatch.setenv("SCEMA_MD_NEIGH_GROW0", grow0)
+        eng = capi.Engine(capi.default_params(**KW))
+        eng.register_replica("pe", 1, small_pe)
+        res.append(np.array(eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10, most_recent=capi.QP_NONE)])[0].stress[:]))
+        eng.close()
+    assert relerr(res[1], res[0]) < 1e-9
+
+
+def test_smaller_cells_when_the_j_table_would_not_fit():
+    """Long cutoff on the 3456-atom crystal: the tile j table of rlist/2 cells exceeds the LDS budget, the engine
+    switches to rlist/3 cells (stencil +-3); forces, energies and virials still match the oracle."""
+    from scema_amd import capi
+    from scema_amd.systems import build_pe
+    from oracle import pyoracle as po
+    d = build_pe(4, 6, 12, jitter=0.03, seed=5)
+    kw = dict(cut_lj=12.7, cut_coul=9.0, skin=2.0)
+    eng = capi.Engine(capi.default_params(**kw))
+    eng.register_replica("g0", 1, d)
+    f, en, w, info = eng.debug_compute("g0", 1, use_shake=True)
+    o = po.Oracle(d, po.default_params(**kw)); o.setup(True)
+    fo, eo, wo = o.compute()
+    assert info["npairs"] == o.npairs
+    assert relerr(f, fo) < 1e-11
+    assert np.abs(en[:7] - eo[:7]).max() < 1e-9 * np.abs(eo).max()
+    assert np.abs(w[:7] - wo[:7]).max() < 1e-9 * np.abs(wo).max()
+    eng.close()
+
+
 def test_error_paths(small_pe):
     from scema_amd import capi
     eng = capi.Engine()                                           # reference cutoffs: 2*(12+2) = 28 A > 14.8 A box
