@@ -131,6 +131,8 @@ struct Profile {
 struct scema_md_engine {
   scema_md_params p;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;          // side stream: structure factors next to the bonded kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::map<std::string, std::unique_ptr<Topo>> topos;
   std::map<std::string, std::unique_ptr<State>> states;
   std::vector<std::unique_ptr<Slot>> slots;
@@ -706,6 +708,30 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
   return SCEMA_MD_OK;
 }
 
+// After k_pair: bonded terms on the main stream, structure factors + per-k coefficients on the side stream (both
+// are small, latency-bound kernels that need only the positions), joined before the per-atom reciprocal force.
+static hipError_t force_stage(scema_md_engine *e, const SimDev *D, int ns, int maxbt, int maxloc, int maxatoms, int maxk, int mmax,
+                              int maxgrp, int parts, int pairvir) {
+  hipStream_t st = e->stream;
+  const bool side = maxk > 0 && e->stream2 != nullptr;
+  if (side) {
+    hipError_t rc = hipEventRecord(e->ev_fork, st);
+    if (rc != hipSuccess) return rc;
+    if ((rc = hipStreamWaitEvent(e->stream2, e->ev_fork, 0)) != hipSuccess) return rc;
+    mdk_ewald_recip(e->stream2, D, ns, maxk, mmax, maxgrp);
+    if ((rc = hipEventRecord(e->ev_join, e->stream2)) != hipSuccess) return rc;
+  }
+  mdk_bonded(st, D, ns, maxbt, maxloc, parts);
+  if (side) {
+    hipError_t rc = hipStreamWaitEvent(st, e->ev_join, 0);
+    if (rc != hipSuccess) return rc;
+  } else {
+    mdk_ewald_recip(st, D, ns, maxk, mmax, maxgrp);
+  }
+  mdk_ewald_force(st, D, ns, maxatoms, pairvir);
+  return hipSuccess;
+}
+
 // Advance sims[0..ns) (already assigned to slots 0..ns-1, scalars' box valid on the device).
 // On return the per-sim SimScalars are in e->h_sc.
 int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &spec) {
@@ -887,8 +913,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   mdk_phase_init(st, D, ns);
   mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
   mdk_pair(st, D, ns, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
-  mdk_bonded(st, D, ns, maxbt, maxloc, spec.ev_always);
-  mdk_ewald(st, D, ns, maxatoms, maxk, mmax, maxgrp, (ev && !spec.ev_always) ? 1 : 0);
+  HIPCHK(force_stage(e, D, ns, maxbt, maxloc, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
   if (!spec.static_only) mdk_shake(st, D, ns, maxclus, 0.5);
   mdk_final_integrate(st, D, ns, maxatoms, 0);
   mdk_setup_post(st, D, ns);
@@ -919,8 +944,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       ev_used += 2;
       launch_bytes.push_back((double)na);
     }
-    mdk_bonded(st, D, na, maxbt, maxloc, spec.ev_always);
-    mdk_ewald(st, D, na, maxatoms, maxk, mmax, maxgrp, (ev && !spec.ev_always) ? 1 : 0);
+    HIPCHK(force_stage(e, D, na, maxbt, maxloc, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
     mdk_shake(st, D, na, maxclus, 1.0);
     mdk_final_integrate(st, D, na, maxatoms, 1);
     mdk_post(st, D, na);
@@ -1153,6 +1177,12 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     delete e;
     return SCEMA_MD_ERR_DEVICE;
   }
+  if (!getenv("SCEMA_MD_ONE_STREAM")) {
+    if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)
+      e->stream2 = nullptr;   // side stream is an optimisation only
+  }
   // test hook: start with undersized neighbour capacities, so that the overflow -> restore -> regrow path runs
   if (const char *g0 = getenv("SCEMA_MD_NEIGH_GROW0")) e->neigh_grow = std::max(0.05, atof(g0));
   *out = e;
@@ -1164,6 +1194,9 @@ void scema_md_destroy(scema_md_engine *e) {
   (void)hipSetDevice(e->p.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
   e->states.clear();
   e->topos.clear();
   e->slots.clear();

@@ -16,9 +16,11 @@ void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly);
 // bonded terms + special pairs, one workgroup per bonded tile; parts != 0: per-part virial/energy (parity hook)
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int parts);
-// pairvir != 0: k_ewald_force also folds the production pair virial (slot-ordered forces x positions + the
-// per-wave image-shift partials of k_pair) into the virial of the step
-void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax, int maxgrp, int pairvir);
+// reciprocal Ewald sum in two parts, so that the first (structure factors; needs only positions) can run on a
+// second stream next to the bonded kernel.  pairvir != 0: k_ewald_force also folds the production pair virial
+// (slot-ordered forces x positions + the per-wave image-shift partials of k_pair) into the virial of the step
+void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax, int maxgrp);
+void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir);
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);
 void mdk_post(hipStream_t st, const SimDev *d, int ns);

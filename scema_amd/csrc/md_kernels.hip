@@ -832,11 +832,9 @@ void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int max
 void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
 }
-void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, int mmax, int maxgrp, int pairvir) {
-  if (maxk <= 0) {  // no charges anywhere: the force kernel still assembles f from the slot-ordered pair + bonded forces
-    hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d, pairvir);
-    return;
-  }
+// reciprocal sum, part 1 (structure factors + per-k coefficients): depends only on the positions
+void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax, int maxgrp) {
+  if (maxk <= 0) return;
   const size_t lds_s = (size_t)EW_ATOMS * 3 * mmax * sizeof(double2);
   // more than 64 KB of dynamic LDS needs an explicit opt-in (large k ranges: small cut_coul or tight accuracy)
   static size_t optin_s = 0;
@@ -845,6 +843,9 @@ void mdk_ewald(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxk, 
   const int gthreads = maxgrp <= 64 ? 64 : (maxgrp <= 128 ? 128 : 256);
   hipLaunchKernelGGL(k_ewald_sfac, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
   hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
+}
+// part 2: per-atom reciprocal force; also assembles f from the pair and bonded forces (runs even without charges)
+void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir) {
   hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d, pairvir);
 }
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
