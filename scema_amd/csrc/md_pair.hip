@@ -288,16 +288,29 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     const double breach = sqrt(S.rlist2) + sqrt(brad2) * 1.0000001 + 1.0e-9;
     const double breach2 = breach * breach;
     int nA = 0, nB = 0, nC = 0;
+    // one chunk of the table ahead: entry + record of chunk r+1 are in flight while chunk r is tested
+    int jt_n = (lane < nj) ? s_jtab[lane] : 0;
+    double pn0, pn1, pn2;
+    {
+      const size_t jn = (size_t)(jt_n & MD_JMASK);
+      pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
+    }
     for (int base = 0; base < nj; base += 64) {
       const int l = base + lane;
+      const int jt = jt_n;
+      const double px = pn0, py = pn1, pz = pn2;
+      {
+        const int ln = l + 64;
+        jt_n = (ln < nj) ? s_jtab[ln] : 0;
+        const size_t jn = (size_t)(jt_n & MD_JMASK);
+        pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
+      }
       int mask = 0, j = 0;
       double rmin = 1.0e300;
       if (l < nj) {
-        const int jt = s_jtab[l];
         j = jt & MD_JMASK;
         const int code = jt >> 23;
-        const double xj = xq[2 * (size_t)j] + s_shift[3 * code], yj = xq[2 * (size_t)j + 1] + s_shift[3 * code + 1],
-                     zj = zq[2 * (size_t)j] + s_shift[3 * code + 2];
+        const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
         const bool own = l < nown;   // same cell, same image: each pair once, by slot order
         int aj = -2;
         const double cx = bx - xj, cy = by - yj, cz = bz - zj;
