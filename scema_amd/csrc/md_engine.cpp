@@ -394,8 +394,23 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
     for (int kind = 0; kind < BT_NKIND; kind++) {
       desc[2 + 2 * kind] = (int)l_at[kind].size() / natm[kind];
       int cnt = 0;
-      for (const TermRef &tr : tile_terms[tl]) {
-        if (tr.kind != kind) continue;
+      // Terms that follow each other in the input share atoms (the nine torsions around one bond): dealt to
+      // consecutive lanes they would hit the same LDS accumulators in the same instruction.  A stride
+      // permutation spreads them over the tile instead.
+      std::vector<const TermRef *> of_kind;
+      for (const TermRef &tr : tile_terms[tl])
+        if (tr.kind == kind) of_kind.push_back(&tr);
+      const int nk_ = (int)of_kind.size();
+      int stride = 1;
+      if (nk_ > 16)
+        for (stride = 13; stride < nk_; stride += 2) {   // smallest odd stride >= 13 coprime with nk_
+          int a_ = stride, b_ = nk_;
+          while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
+          if (a_ == 1) break;
+        }
+      if (stride >= nk_) stride = 1;
+      for (int q = 0; q < nk_; q++) {
+        const TermRef &tr = *of_kind[(int)(((long long)q * stride) % std::max(nk_, 1))];
         const int m = tr.idx;
         const int *at = (kind <= BT_BOND_SHAKEN) ? &bond_at[2 * m] : (kind == BT_ANGLE) ? &angle_at[3 * m] : (kind == BT_DIHEDRAL) ? &dih_at[4 * m]
                         : (kind == BT_IMPROPER) ? &imp_at[4 * m] : &sp_at[2 * m];
