@@ -103,7 +103,7 @@ struct Slot {
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
   size_t cap_jtab = 0;
   DevBuf virp, fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
-  DevBuf kgrp;
+  DevBuf kgrp, krun;
   DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
       xbak, vbak;
 };
@@ -475,6 +475,7 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
 struct EwaldSetup {
   double g = 0.0;
   std::vector<int> kn;
+  std::vector<int> krun;   // per k: length of the run of following k-vectors that continue its row (n3 + 1 each)
   std::vector<int> kgrp;   // groups of k-vectors (n1, +-n2, +-n3): n1, |n2|, |n3|, k index of (+,+), (-,+), (+,-), (-,-) or -1, pad
   int kmaxd[3] = {0, 0, 0};
 };
@@ -520,6 +521,13 @@ void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, Ewa
         out.kmaxd[1] = std::max(out.kmaxd[1], std::abs(n2));
         out.kmaxd[2] = std::max(out.kmaxd[2], std::abs(n3));
       }
+  {
+    const int nk0 = (int)out.kn.size() / 3;
+    out.krun.assign(nk0, 0);
+    for (int k = nk0 - 2; k >= 0; k--)
+      if (out.kn[3 * k] == out.kn[3 * k + 3] && out.kn[3 * k + 1] == out.kn[3 * k + 4] && out.kn[3 * k + 2] + 1 == out.kn[3 * k + 5])
+        out.krun[k] = out.krun[k + 1] + 1;
+  }
   // k-vectors that differ only in the signs of n2, n3 share every phase-factor product of k_ewald_sfac
   std::map<long, int> gidx;
   const int nk = (int)out.kn.size() / 3;
@@ -716,6 +724,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     const int kc = std::max(nk, 64);
     HIPCHK(sl.kn.ensure((size_t)kc * 3 * 4));
     HIPCHK(sl.kgrp.ensure((size_t)kc * 8 * 4));
+    HIPCHK(sl.krun.ensure((size_t)kc * 4));
     HIPCHK(sl.sfac.ensure((size_t)kc * 2 * 8));
     HIPCHK(sl.kvec.ensure((size_t)kc * 4 * 8));
     sl.cap_k = kc;
@@ -761,7 +770,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   int maxbt = 1, maxloc = 1;
   int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
   std::vector<std::vector<int>> kn_stage;
-  kn_stage.reserve(2 * (size_t)ns);
+  kn_stage.reserve(3 * (size_t)ns);
   int maxgrp = 0;
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
@@ -898,11 +907,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.cell_of = sl.cell_of.as<int>(); S.ckey = sl.ckey.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
     S.fs = sl.fs.as<double>(); S.fb = sl.fb.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>(); S.virp = sl.virp.as<double>();
-    S.kn = sl.kn.as<int>(); S.kgrp = sl.kgrp.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
+    S.kn = sl.kn.as<int>(); S.kgrp = sl.kgrp.as<int>(); S.krun = sl.krun.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;
     if (S.nk > 0) {
       kn_stage.push_back(std::move(ew.kn));  // must stay alive until the copies have been consumed
       HIPCHK(hipMemcpyAsync(sl.kn.p, kn_stage.back().data(), kn_stage.back().size() * 4, hipMemcpyHostToDevice, e->stream));
+      kn_stage.push_back(std::move(ew.krun));
+      HIPCHK(hipMemcpyAsync(sl.krun.p, kn_stage.back().data(), kn_stage.back().size() * 4, hipMemcpyHostToDevice, e->stream));
       kn_stage.push_back(std::move(ew.kgrp));
       HIPCHK(hipMemcpyAsync(sl.kgrp.p, kn_stage.back().data(), kn_stage.back().size() * 4, hipMemcpyHostToDevice, e->stream));
       S.ngrp = (int)kn_stage.back().size() / 8;

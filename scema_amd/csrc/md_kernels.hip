@@ -506,26 +506,35 @@ __device__ __forceinline__ void cmul(double &pr, double &pi, double c, double s)
   const double nr = pr * c - pi * s, ni = pi * c + pr * s;
   pr = nr; pi = ni;
 }
+#define EWF_APT 2          // atoms per thread: two independent recurrences per lane, half the per-k LDS reads and scalar work per atom
 __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int pairvir) {
   const SimDev &S = sims[blockIdx.y];
-  if ((int)(blockIdx.x * EWF_TPB) >= S.natoms) return;
+  if ((int)(blockIdx.x * EWF_TPB * EWF_APT) >= S.natoms) return;
   __shared__ EwK s_k[EWF_KC];
   __shared__ int s_run[EWF_KC];
   __shared__ double s_red[8 * (EWF_TPB / 64)];
-  const int a = min((int)(blockIdx.x * EWF_TPB + threadIdx.x), S.natoms - 1);
-  const bool act = (int)(blockIdx.x * EWF_TPB + threadIdx.x) < S.natoms;
-  double c1, s1, c2, s2, c3, s3;
+  int at[EWF_APT];
+  bool act[EWF_APT];
+  double c1[EWF_APT], s1[EWF_APT], c2[EWF_APT], s2[EWF_APT], c3[EWF_APT], s3[EWF_APT];
   {
     BoxD b;
     box_derive(S.sc->box, b);
-    double t[3];
-    atom_phase(S, b, a, t[0], t[1], t[2]);
-    sincospi(2.0 * t[0], &s1, &c1); sincospi(2.0 * t[1], &s2, &c2); sincospi(2.0 * t[2], &s3, &c3);
+#pragma unroll
+    for (int u = 0; u < EWF_APT; u++) {
+      const int ai = (blockIdx.x * EWF_APT + u) * EWF_TPB + threadIdx.x;
+      act[u] = ai < S.natoms;
+      at[u] = min(ai, S.natoms - 1);
+      double t[3];
+      atom_phase(S, b, at[u], t[0], t[1], t[2]);
+      sincospi(2.0 * t[0], &s1[u], &c1[u]); sincospi(2.0 * t[1], &s2[u], &c2[u]); sincospi(2.0 * t[2], &s3[u], &c3[u]);
+    }
   }
-  double e1r = 1.0, e1i = 0.0;   // e1^m1
-  double pr = 1.0, pi = 0.0;     // e1^m1 e2^m2 e3^m3
+  double e1r[EWF_APT], e1i[EWF_APT];   // e1^m1
+  double pr[EWF_APT], pi[EWF_APT];     // e1^m1 e2^m2 e3^m3
+  double fx[EWF_APT], fy[EWF_APT], fz[EWF_APT];
+#pragma unroll
+  for (int u = 0; u < EWF_APT; u++) { e1r[u] = 1.0; e1i[u] = 0.0; pr[u] = 1.0; pi[u] = 0.0; fx[u] = fy[u] = fz[u] = 0.0; }
   int m1 = 0, m2 = 0, m3 = 0;    // cursor (wave-uniform)
-  double fx = 0, fy = 0, fz = 0;
   for (int kb = 0; kb < S.nk; kb += EWF_KC) {
     __syncthreads();
     if (threadIdx.x < EWF_KC && kb + threadIdx.x < S.nk) {
@@ -538,18 +547,7 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
       e.n23 = (S.kn[3 * k + 1] + 128) | ((S.kn[3 * k + 2] + 128) << 8);
       s_k[threadIdx.x] = e;
     }
-    if (threadIdx.x < EWF_KC) {
-      // length of the run of k-vectors that continue this one's row (same n1, n2; n3 + 1 each), inside the chunk
-      const int t = threadIdx.x, kc0 = min(EWF_KC, S.nk - kb);
-      int run = 0;
-      if (t < kc0) {
-        const int a1 = S.kn[3 * (kb + t)], a2 = S.kn[3 * (kb + t) + 1], a3 = S.kn[3 * (kb + t) + 2];
-        while (t + run + 1 < kc0 && S.kn[3 * (kb + t + run + 1)] == a1 && S.kn[3 * (kb + t + run + 1) + 1] == a2 &&
-               S.kn[3 * (kb + t + run + 1) + 2] == a3 + run + 1)
-          run++;
-      }
-      s_run[t] = run;
-    }
+    if (threadIdx.x < EWF_KC && kb + threadIdx.x < S.nk) s_run[threadIdx.x] = S.krun[kb + threadIdx.x];
     __syncthreads();
     const int kc = min(EWF_KC, S.nk - kb);
     for (int kk = 0; kk < kc;) {
@@ -557,50 +555,59 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
       const EwK e = s_k[kk];
       const int n1 = __builtin_amdgcn_readfirstlane(e.n1), n23 = __builtin_amdgcn_readfirstlane(e.n23);
       const int n2 = (n23 & 0xFF) - 128, n3 = ((n23 >> 8) & 0xFF) - 128;
-      if (n1 != m1) {   // next slab: restart from the running power of e1 (bounds the length of the recurrences)
-        while (m1 < n1) { cmul(e1r, e1i, c1, s1); m1++; }
-        pr = e1r; pi = e1i; m2 = 0; m3 = 0;
+#pragma unroll
+      for (int u = 0; u < EWF_APT; u++) {
+        if (n1 != m1) {   // next slab: restart from the running power of e1 (bounds the length of the recurrences)
+          for (int m = m1; m < n1; m++) cmul(e1r[u], e1i[u], c1[u], s1[u]);
+          pr[u] = e1r[u]; pi[u] = e1i[u];
+        }
+        const int f2 = (n1 != m1) ? 0 : m2, f3 = (n1 != m1) ? 0 : m3;
+        for (int m = f2; m < n2; m++) cmul(pr[u], pi[u], c2[u], s2[u]);
+        for (int m = f2; m > n2; m--) cmul(pr[u], pi[u], c2[u], -s2[u]);
+        for (int m = f3; m < n3; m++) cmul(pr[u], pi[u], c3[u], s3[u]);
+        for (int m = f3; m > n3; m--) cmul(pr[u], pi[u], c3[u], -s3[u]);
+        const double pf = pi[u] * e.pr - pr[u] * e.pi;
+        fx[u] = fma(pf, e.kx, fx[u]); fy[u] = fma(pf, e.ky, fy[u]); fz[u] = fma(pf, e.kz, fz[u]);
       }
-      while (m2 < n2) { cmul(pr, pi, c2, s2); m2++; }
-      while (m2 > n2) { cmul(pr, pi, c2, -s2); m2--; }
-      while (m3 < n3) { cmul(pr, pi, c3, s3); m3++; }
-      while (m3 > n3) { cmul(pr, pi, c3, -s3); m3--; }
-      {
-        const double pf = pi * e.pr - pr * e.pi;
-        fx = fma(pf, e.kx, fx); fy = fma(pf, e.ky, fy); fz = fma(pf, e.kz, fz);
-      }
+      m1 = n1; m2 = n2; m3 = n3;
       // rest of the row: n3 -> n3 + 1 = one complex multiplication each, no scalar control
-      const int run = __builtin_amdgcn_readfirstlane(s_run[kk]);
+      const int run = min(__builtin_amdgcn_readfirstlane(s_run[kk]), kc - 1 - kk);   // rows are cut at chunk ends
       for (int r = 1; r <= run; r++) {
         const EwK g = s_k[kk + r];
-        cmul(pr, pi, c3, s3);
-        const double pf = pi * g.pr - pr * g.pi;
-        fx = fma(pf, g.kx, fx); fy = fma(pf, g.ky, fy); fz = fma(pf, g.kz, fz);
+#pragma unroll
+        for (int u = 0; u < EWF_APT; u++) {
+          cmul(pr[u], pi[u], c3[u], s3[u]);
+          const double pf = pi[u] * g.pr - pr[u] * g.pi;
+          fx[u] = fma(pf, g.kx, fx[u]); fy[u] = fma(pf, g.ky, fy[u]); fz[u] = fma(pf, g.kz, fz[u]);
+        }
       }
       m3 += run;
       kk += run + 1;
     }
   }
   double pv[6] = {0, 0, 0, 0, 0, 0};
-  if (act) {
-    // f (atom order) = pair forces (slot order, k_pair) + bonded forces (rank order, k_bonded) + reciprocal part;
-    // every atom is owned by exactly one thread and the kernels of a step are stream-ordered
-    const double pq = 2.0 * MD_QQRD2E * S.q[a];
-    const size_t sl = (size_t)S.slot_of[a], np = (size_t)S.npad, r = (size_t)S.bt_rank[a];
-    const double px = S.fs[sl], py = S.fs[np + sl], pz = S.fs[2 * np + sl];
-    S.f[3 * a] = px + S.fb[3 * r] + pq * fx;
-    S.f[3 * a + 1] = py + S.fb[3 * r + 1] + pq * fy;
-    S.f[3 * a + 2] = pz + S.fb[3 * r + 2] + pq * fz;
-    if (pairvir) {
-      // pair virial, part 1: wrapped slot position (x) total pair force of the slot (part 2 = k_pair's partials)
-      const double *xy = (const double *)S.xq + 2 * sl, *zq = (const double *)S.xq + 2 * np + 2 * sl;
-      const double x = xy[0], y = xy[1], z = zq[0];
-      pv[0] = x * px; pv[1] = y * py; pv[2] = z * pz; pv[3] = x * py; pv[4] = x * pz; pv[5] = y * pz;
+#pragma unroll
+  for (int u = 0; u < EWF_APT; u++)
+    if (act[u]) {
+      // f (atom order) = pair forces (slot order, k_pair) + bonded forces (rank order, k_bonded) + reciprocal part;
+      // every atom is owned by exactly one thread and the kernels of a step are stream-ordered
+      const int a = at[u];
+      const double pq = 2.0 * MD_QQRD2E * S.q[a];
+      const size_t sl = (size_t)S.slot_of[a], np = (size_t)S.npad, r = (size_t)S.bt_rank[a];
+      const double px = S.fs[sl], py = S.fs[np + sl], pz = S.fs[2 * np + sl];
+      S.f[3 * a] = px + S.fb[3 * r] + pq * fx[u];
+      S.f[3 * a + 1] = py + S.fb[3 * r + 1] + pq * fy[u];
+      S.f[3 * a + 2] = pz + S.fb[3 * r + 2] + pq * fz[u];
+      if (pairvir) {
+        // pair virial, part 1: wrapped slot position (x) total pair force of the slot (part 2 = k_pair's partials)
+        const double *xy = (const double *)S.xq + 2 * sl, *zq = (const double *)S.xq + 2 * np + 2 * sl;
+        const double x = xy[0], y = xy[1], z = zq[0];
+        pv[0] += x * px; pv[1] += y * py; pv[2] += z * pz; pv[3] += x * py; pv[4] += x * pz; pv[5] += y * pz;
+      }
     }
-  }
   if (pairvir) {
     const int nrows = S.ncells * MD_TILE_WAVES;   // one row of 6 per cell and wave of k_pair
-    const int nblk = (S.natoms + EWF_TPB - 1) / EWF_TPB;   // blocks of this simulation that got this far
+    const int nblk = (S.natoms + EWF_TPB * EWF_APT - 1) / (EWF_TPB * EWF_APT);   // blocks of this simulation that got this far
     for (int r = blockIdx.x * EWF_TPB + threadIdx.x; r < nrows; r += nblk * EWF_TPB) {
       const double *vp = S.virp + (size_t)r * 6;
 #pragma unroll
@@ -846,7 +853,7 @@ void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax
 }
 // part 2: per-atom reciprocal force; also assembles f from the pair and bonded forces (runs even without charges)
 void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir) {
-  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB), ns), dim3(EWF_TPB), 0, st, d, pairvir);
+  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB * EWF_APT), ns), dim3(EWF_TPB), 0, st, d, pairvir);
 }
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
   if (maxclus <= 0) return;
