@@ -155,6 +155,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
   __shared__ double s_box[6];   // bounding box of the cell's real atoms
   __shared__ int s_wcnt[TW];
   __shared__ int s_cost[64];
+  __shared__ int s_ex[TW][NI * 16];   // exclusion lists of the cluster a wave is working on (first 16 per atom)
   int *s_jtab = s_build;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -287,6 +288,20 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     }
     const double breach = sqrt(S.rlist2) + sqrt(brad2) * 1.0000001 + 1.0e-9;
     const double breach2 = breach * breach;
+    // the four atoms' exclusion lists (1-2, 1-3 partners) into LDS once: the candidates inside the exclusion gate
+    // then compare against broadcast LDS reads instead of walking the lists in global memory lane by lane
+    int exb[NI], exn[NI];
+#pragma unroll
+    for (int a = 0; a < NI; a++) {
+      exb[a] = (ci.atom[a] >= 0) ? S.ex_start[ci.atom[a]] : 0;
+      exn[a] = (ci.atom[a] >= 0) ? S.ex_start[ci.atom[a] + 1] - exb[a] : 0;
+    }
+    {
+      const int a = lane >> 4, e = lane & 15;
+      const int na = (a == 0) ? exn[0] : (a == 1) ? exn[1] : (a == 2) ? exn[2] : exn[3];
+      const int ba = (a == 0) ? exb[0] : (a == 1) ? exb[1] : (a == 2) ? exb[2] : exb[3];
+      s_ex[wave][lane] = (e < na) ? S.ex_list[ba + e] : -1;
+    }
     int nA = 0, nB = 0, nC = 0;
     // one chunk of the table ahead: entry + record of chunk r+1 are in flight while chunk r is tested
     int jt_n = (lane < nj) ? s_jtab[lane] : 0;
@@ -322,7 +337,9 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
             bool acc = ci.atom[a] >= 0 && r2 < S.rlist2 && !(own && j <= s0slot + a);
             if (acc && r2 < S.excl_cut2) {
               if (aj == -2) aj = S.perm[j];
-              for (int e = S.ex_start[ci.atom[a]]; e < S.ex_start[ci.atom[a] + 1]; e++) acc = acc && (S.ex_list[e] != aj);
+              const int nl = min(exn[a], 16);
+              for (int e = 0; e < nl; e++) acc = acc && (s_ex[wave][a * 16 + e] != aj);
+              for (int e = 16; e < exn[a]; e++) acc = acc && (S.ex_list[exb[a] + e] != aj);
             }
             if (acc) {
               mask |= 1 << a;
