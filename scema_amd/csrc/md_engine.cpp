@@ -103,8 +103,7 @@ struct Slot {
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
   size_t cap_jtab = 0;
   DevBuf virp, fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
-  DevBuf kgrp, krun;
-  DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, kn, sfac, kvec,
+    DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, sfac, kvec,
       xbak, vbak;
 };
 
@@ -136,7 +135,8 @@ struct scema_md_engine {
   std::map<std::string, std::unique_ptr<Topo>> topos;
   std::map<std::string, std::unique_ptr<State>> states;
   std::vector<std::unique_ptr<Slot>> slots;
-  DevBuf d_sims, d_sc, d_local_stress;
+  DevBuf d_sims, d_sc, d_local_stress, d_kpack;
+  std::vector<int> h_kpack;   // host copy, alive until the stream has consumed the upload
   int local_stress_count = 0;
   std::vector<SimDev> h_sims;
   std::vector<SimScalars> h_sc;
@@ -722,9 +722,6 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
   }
   if (nk > sl.cap_k || sl.cap_k == 0) {
     const int kc = std::max(nk, 64);
-    HIPCHK(sl.kn.ensure((size_t)kc * 3 * 4));
-    HIPCHK(sl.kgrp.ensure((size_t)kc * 8 * 4));
-    HIPCHK(sl.krun.ensure((size_t)kc * 4));
     HIPCHK(sl.sfac.ensure((size_t)kc * 2 * 8));
     HIPCHK(sl.kvec.ensure((size_t)kc * 4 * 8));
     sl.cap_k = kc;
@@ -769,8 +766,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   e->h_sims.assign(ns, SimDev());
   int maxbt = 1, maxloc = 1;
   int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
-  std::vector<std::vector<int>> kn_stage;
-  kn_stage.reserve(3 * (size_t)ns);
+  // k-vector tables of all simulations (indices, row run lengths, groups), packed into one upload
+  std::vector<int> &kpack = e->h_kpack;
+  kpack.clear();
+  std::vector<size_t> koff(ns, 0);
   int maxgrp = 0;
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
@@ -907,16 +906,16 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.cell_of = sl.cell_of.as<int>(); S.ckey = sl.ckey.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
     S.fs = sl.fs.as<double>(); S.fb = sl.fb.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>(); S.virp = sl.virp.as<double>();
-    S.kn = sl.kn.as<int>(); S.kgrp = sl.kgrp.as<int>(); S.krun = sl.krun.as<int>(); S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
+    S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;
     if (S.nk > 0) {
-      kn_stage.push_back(std::move(ew.kn));  // must stay alive until the copies have been consumed
-      HIPCHK(hipMemcpyAsync(sl.kn.p, kn_stage.back().data(), kn_stage.back().size() * 4, hipMemcpyHostToDevice, e->stream));
-      kn_stage.push_back(std::move(ew.krun));
-      HIPCHK(hipMemcpyAsync(sl.krun.p, kn_stage.back().data(), kn_stage.back().size() * 4, hipMemcpyHostToDevice, e->stream));
-      kn_stage.push_back(std::move(ew.kgrp));
-      HIPCHK(hipMemcpyAsync(sl.kgrp.p, kn_stage.back().data(), kn_stage.back().size() * 4, hipMemcpyHostToDevice, e->stream));
-      S.ngrp = (int)kn_stage.back().size() / 8;
+      // layout per simulation: kn[3 nk] | krun[nk] | pad to 4 ints | kgrp[8 ngrp]
+      koff[pos] = kpack.size();
+      kpack.insert(kpack.end(), ew.kn.begin(), ew.kn.end());
+      kpack.insert(kpack.end(), ew.krun.begin(), ew.krun.end());
+      while (kpack.size() % 4) kpack.push_back(0);
+      kpack.insert(kpack.end(), ew.kgrp.begin(), ew.kgrp.end());
+      S.ngrp = (int)ew.kgrp.size() / 8;
       maxgrp = std::max(maxgrp, S.ngrp);
     }
     e->h_sims[pos] = S;
@@ -930,6 +929,16 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   }
   if ((size_t)64 * 3 * mmax * 16 + 4096 > 160 * 1024)
     return fail(e, SCEMA_MD_ERR_ARG, "k-space index range (|n| up to %d) too large for the LDS phase tables; raise cut_coul or loosen kspace_accuracy", mmax - 1);
+  HIPCHK(e->d_kpack.ensure(kpack.size() * sizeof(int) + 64));
+  if (!kpack.empty()) HIPCHK(hipMemcpyAsync(e->d_kpack.p, kpack.data(), kpack.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  for (int pos = 0; pos < ns; pos++) {
+    SimDev &S = e->h_sims[pos];
+    if (S.nk <= 0) continue;
+    const int *base = e->d_kpack.as<int>() + koff[pos];
+    S.kn = base;
+    S.krun = base + 3 * (size_t)S.nk;
+    S.kgrp = base + ((4 * (size_t)S.nk + 3) / 4) * 4;
+  }
   HIPCHK(e->d_sims.ensure((size_t)ns * sizeof(SimDev)));
   HIPCHK(hipMemcpyAsync(e->d_sims.p, e->h_sims.data(), (size_t)ns * sizeof(SimDev), hipMemcpyHostToDevice, e->stream));
   const SimDev *D = e->d_sims.as<SimDev>();
