@@ -142,6 +142,23 @@ int scema_md_drop_state(scema_md_engine *e, int32_t qp_id, const char *matid, in
 int scema_md_save_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path);
 int scema_md_load_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path);
 
+/* ---- init_material: the quantities EQMDProblem::lammps_equilibration derives from an equilibrated
+ * replica (init_material_problem.h:196-300): box lengths, initial stress (ELASTIC/in.homogenization.lammps: NVT + SHAKE
+ * sampling) and the stiffness tensor by +-strain_ampl finite strains in the six directions (ELASTIC/in.modulus.lammps,
+ * bi-displace.mod.lammps: fix deform ... delta over nsstrain steps, then nsteps_sample steps of sampling, fix nvt only).
+ * The 13 runs are one batch on the GPU.  The equilibration schedule itself (in.init.lammps: minimise, heat, cool) is not
+ * part of this call: the registered replica is taken as the equilibrated state ("Reuse of state data", :175-184).
+ * length[3]; stress[6] in Pa, file order 00,01,02,11,12,22; stiff[36] in Pa, file order of init.*.stiff. */
+typedef struct {
+  double timestep_length;  /* fs   "molecular dynamics parameters.timestep length" */
+  double temperature;      /* K */
+  int32_t nsteps_sample;   /* nssample0 = nssample */
+  double strain_ampl;      /* "up": strain perturbation amplitude */
+  double strain_rate;      /* 1/fs: nsstrain = ceil(up/(dt*rate)/10)*10 (init_material_problem.h:226) */
+} scema_md_eqparams;
+int scema_md_init_material(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_eqparams *p,
+                           double length[3], double stress[6], double stiff[36]);
+
 /* ---- parity / measurement hooks ---- */
 /* Static evaluation at the stored state of (qp,mat,rep) (qp_id = SCEMA_MD_QP_NONE: the registered
  * init state): forces [natoms*3], energies[SCEMA_MD_NPART], virials[SCEMA_MD_NPART*6] (kcal/mol). */

@@ -72,6 +72,14 @@ int scema_stmd_update(scema_stmd *s, int32_t timestep, double present_time, int3
 int scema_stmd_replica_data(const scema_stmd *s, int32_t material, int32_t replica0, double *init_length, double *init_stress,
                             double *rotam, double *rho);
 
+/* EQMDProblem<3>::equil (init_material_problem.h:309-355) for a replica that is already equilibrated and registered
+ * with the engine: computes box lengths, initial stress and stiffness on the GPU and writes
+ * lengthof / stressof / stiffof = init.<mat>_<rep>.{length,stress,stiff}, the files scema_stmd_init reads.
+ * Unknown force field -> SCEMA_MD_ERR_ARG (the reference prints and exits).  errbuf receives the message. */
+int scema_eqmd_equil(scema_md_engine *engine, const char *cmat, const char *lengthof, const char *stressof, const char *stiffof,
+                     int32_t rep, double mdts, double mdtem, int32_t mdnss, double mdss, double mdsa, const char *mdff, char *errbuf,
+                     int32_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,6 +179,52 @@ class Oracle:
 
 
 # ---- host (L3) arithmetic ----
+def init_material(o: "Oracle", dt, temperature, nss, strain_ampl, strain_rate):
+    """CPU restatement of what the reference derives from an equilibrated replica (test infrastructure):
+    EQMDProblem::lammps_equilibration, init_material_problem.h:196-300, with ELASTIC/in.homogenization.lammps
+    (NVT + SHAKE sampling -> initial stress) and ELASTIC/in.modulus.lammps + bi-displace.mod.lammps (+-up in six
+    directions from the post-sampling state, fix nvt only, fix deform delta over nsstrain steps, then sampling).
+    Returns (length[3], stress[6] Pa in file order 00,01,02,11,12,22, stiff[6,6] Pa in file order)."""
+    box0, x0, v0 = o.get_state()
+    length = np.array(box0[3:6]) - np.array(box0[:3])
+    pp, _ = o.run(nss, dt, temperature, nvt=True, use_shake=True, sample=True)           # pxx,pyy,pzz,pxy,pxz,pyz (atm)
+    stress = -np.array([pp[0], pp[3], pp[4], pp[1], pp[5], pp[2]]) * 1.01325e5               # init_material_problem.h:243-250
+    box, x, v = o.get_state()                                                                # "restart.equil"
+    nsstrain = int(np.ceil(strain_ampl / (dt * strain_rate) / 10.0) * 10)                    # :226
+    T = nsstrain * dt
+    ly0, lz0 = box[4] - box[1], box[5] - box[2]
+    xy, xz, yz = box[6], box[7], box[8]
+    p1 = np.zeros((6, 2, 6))
+    for d in range(6):
+        for k, sign in enumerate((-1.0, 1.0)):
+            r = np.zeros(6)                                                                  # raw order xx,yy,zz,xy,xz,yz
+            if d == 0:
+                r[0] = sign * strain_ampl / T; r[3] = -sign * strain_ampl * xy / (ly0 * T); r[4] = -sign * strain_ampl * xz / (lz0 * T)
+            elif d == 1:
+                r[1] = sign * strain_ampl / T; r[5] = -sign * strain_ampl * yz / (lz0 * T)
+            elif d == 2:
+                r[2] = sign * strain_ampl / T
+            elif d == 3:
+                r[5] = sign * strain_ampl / T
+            elif d == 4:
+                r[4] = sign * strain_ampl / T
+            else:
+                r[3] = sign * strain_ampl / T
+            o.set_state(box, x, v)
+            o.run(nsstrain, dt, temperature, nvt=True, use_shake=False, rates=r)
+            p1[d, k], _ = o.run(nss, dt, temperature, nvt=True, use_shake=False, sample=True)
+    raw_of_voigt = [0, 1, 2, 5, 4, 3]                                                        # d1..d6 = xx,yy,zz,yz,xz,xy
+    Cm = np.zeros((6, 6))
+    for d in range(6):
+        for i in range(6):
+            Cm[i, d] = -(p1[d, 1, raw_of_voigt[i]] - p1[d, 0, raw_of_voigt[i]]) / (2.0 * strain_ampl) * 1.01325e-4
+    call = 0.5 * (Cm + Cm.T) * 1.0e9                                                         # C{ij}all, GPa -> Pa
+    hv = [0, 3, 4, 1, 5, 2]                                    # file index -> the reference's 6x6 index (:276-295)
+    stiff = np.array([[call[hv[i], hv[j]] for j in range(6)] for i in range(6)])
+    o.set_state(box0, x0, v0)
+    return length, stress, stiff
+
+
 def nts(true_strain, rate, dt) -> int:
     e = np.ascontiguousarray(true_strain, dtype=np.float64)
     return lib().omd_nts(_p(e), C.c_double(rate), C.c_double(dt))

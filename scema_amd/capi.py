@@ -26,7 +26,7 @@ SYMBOLS = [
     "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
     "scema_md_local_stress_count", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
     "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file",
-    "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile",
+    "scema_md_init_material", "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile",
 ]
 
 
@@ -62,6 +62,12 @@ class MDSim(C.Structure):
                 ("timestep_length", C.c_double), ("temperature", C.c_double), ("strain_rate", C.c_double),
                 ("nsteps_sample", C.c_int32), ("output_homog", C.c_int32), ("checkpoint", C.c_int32),
                 ("stress", C.c_double * 6), ("stress_updated", C.c_int32)]
+
+
+class EqParams(C.Structure):
+    """scema_md_eqparams (include/scema_md.h)."""
+    _fields_ = [("timestep_length", C.c_double), ("temperature", C.c_double), ("nsteps_sample", C.c_int32),
+                ("strain_ampl", C.c_double), ("strain_rate", C.c_double)]
 
 
 class Profile(C.Structure):
@@ -237,6 +243,14 @@ class Engine:
                                            C.c_double(dt), C.c_double(temperature), C.c_int32(1 if nvt else 0),
                                            C.c_int32(1 if use_shake else 0), _p(r), _p(pavg)))
         return pavg
+
+    def init_material(self, matid, replica, dt=2.0, temperature=300.0, nss=100, strain_ampl=0.005, strain_rate=1e-4):
+        """EQMDProblem::lammps_equilibration for an equilibrated replica (init_material_problem.h:196-300): returns
+        (length[3], stress[6] Pa file order 00,01,02,11,12,22, stiff[6,6] Pa file order)."""
+        p = EqParams(dt, temperature, nss, strain_ampl, strain_rate)
+        length, stress, stiff = np.zeros(3), np.zeros(6), np.zeros(36)
+        self._chk(lib().scema_md_init_material(self.h, matid.encode(), C.c_int32(replica), C.byref(p), _p(length), _p(stress), _p(stiff)))
+        return length, stress, stiff.reshape(6, 6)
 
     def profile(self, reset=False) -> dict:
         p = Profile()

@@ -2,6 +2,7 @@
 #include <cstring>
 #include <new>
 
+#include "eqmd_problem.h"
 #include "stmd_sync.h"
 
 struct scema_stmd {
@@ -47,6 +48,19 @@ int scema_stmd_replica_data(const scema_stmd *s, int32_t material, int32_t repli
   if (rotam) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rotam[3 * i + j] = r.rotam.m[i][j];
   if (rho) *rho = r.rho;
   return SCEMA_MD_OK;
+}
+
+int scema_eqmd_equil(scema_md_engine *engine, const char *cmat, const char *lengthof, const char *stressof, const char *stiffof,
+                     int32_t rep, double mdts, double mdtem, int32_t mdnss, double mdss, double mdsa, const char *mdff, char *errbuf,
+                     int32_t errlen) {
+  if (!cmat || !lengthof || !stressof || !stiffof || !mdff) return SCEMA_MD_ERR_ARG;
+  scema::EQMDProblem eq(engine);
+  const int rc = eq.equil(cmat, lengthof, stressof, stiffof, rep, mdts, mdtem, mdnss, mdss, mdsa, mdff);
+  if (rc && errbuf && errlen > 0) {
+    std::strncpy(errbuf, eq.last_error().c_str(), (size_t)errlen - 1);
+    errbuf[errlen - 1] = 0;
+  }
+  return rc;
 }
 
 }  // extern "C"

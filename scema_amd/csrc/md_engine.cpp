@@ -1122,8 +1122,15 @@ void hooke(const double *c, const double *eps, double *out) {
     }
 }
 
+// which phases an evaluation runs and with which constraints (the hot path: strain with SHAKE, sample with SHAKE;
+// the elastic-constant runs of init_material: both without SHAKE; its homogenisation run: sampling only)
+struct EvalOpt {
+  bool phase_a = true;
+  int shake_a = 1, shake_b = 1;
+};
+
 // full evaluation (phase A + phase B) of a chunk of simulations, with overflow retry
-int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk) {
+int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt &opt = EvalOpt()) {
   const int ns = (int)chunk.size();
   for (int attempt = 0; attempt < 4; attempt++) {
     int rc = prepare_slots(e, chunk);
@@ -1139,15 +1146,19 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk) {
     }
     RunSpec A;
     A.deform = 1;
+    A.use_shake = opt.shake_a;
     for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nts;
     const double t_a0 = wall_s();
-    rc = run_phase(e, chunk, A);
+    rc = opt.phase_a ? run_phase(e, chunk, A) : SCEMA_MD_OK;
     const double t_a1 = wall_s();
     if (rc == SCEMA_MD_OK) {
-      rc = reupload_scalars(e, ns);
-      if (rc) return rc;
+      if (opt.phase_a) {
+        rc = reupload_scalars(e, ns);
+        if (rc) return rc;
+      }
       RunSpec B;
       B.sample = 1;
+      B.use_shake = opt.shake_b;
       for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nss;
       rc = run_phase(e, chunk, B);
       if (getenv("SCEMA_MD_TIMING")) fprintf(stderr, "[scema_md] chunk of %d: phase A %.1f ms, phase B %.1f ms (attempt %d)\n", ns, 1e3 * (t_a1 - t_a0), 1e3 * (wall_s() - t_a1), attempt);
@@ -1589,6 +1600,92 @@ int scema_md_debug_run(scema_md_engine *e, int32_t qp_id, const char *matid, int
   const SimScalars &sc = e->h_sc[0];
   std::memcpy(s->box, sc.box, 9 * sizeof(double));
   if (press_avg) for (int k = 0; k < 6; k++) press_avg[k] = sc.psum[k] / (double)std::max(sc.nsamples, 1);
+  return SCEMA_MD_OK;
+}
+
+// ---- init_material: what EQMDProblem::lammps_equilibration computes once the replica is equilibrated ----
+int scema_md_init_material(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_eqparams *p, double length[3],
+                           double stress[6], double stiff[36]) {
+  if (!e || !p || !length || !stress || !stiff) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered", matid ? matid : "", (int)replica);
+  if (p->nsteps_sample < 10 || p->strain_ampl <= 0.0 || p->strain_rate <= 0.0 || p->timestep_length <= 0.0)
+    return fail(e, SCEMA_MD_ERR_ARG, "init_material: nsteps_sample >= 10, strain_ampl, strain_rate, timestep_length > 0 required");
+  // box lengths after initiation (init_material_problem.h:196-208)
+  for (int d = 0; d < 3; d++) length[d] = t->init_box[3 + d] - t->init_box[d];
+  // ---- ELASTIC/in.homogenization.lammps: NVT + SHAKE sampling of the unstrained replica ----
+  std::unique_ptr<State> equil;
+  int rc = make_state(e, t, t->init_box, t->init_x.data(), t->init_v.data(), false, equil);
+  if (rc) return rc;
+  {
+    std::vector<ActiveSim> one(1);
+    one[0].st = equil.get();
+    one[0].dt = p->timestep_length;
+    one[0].temperature = p->temperature;
+    one[0].nts = 0;
+    one[0].nss = p->nsteps_sample;
+    EvalOpt o;
+    o.phase_a = false;
+    if ((rc = eval_chunk(e, one, o))) return rc;
+    // loc_rep_stress[k][l] = -pp{k+1}{l+1} * 1.01325e5 (init_material_problem.h:243-250); file order 00,01,02,11,12,22
+    static const int RAW_OF_FILE[6] = {0, 3, 4, 1, 5, 2};
+    for (int f = 0; f < 6; f++) stress[f] = -one[0].pavg[RAW_OF_FILE[f]] * 1.01325e5;
+  }
+  // ---- ELASTIC/in.modulus.lammps + bi-displace.mod.lammps: +-up in each of the six directions, from the state the
+  // homogenisation run left ("restart.equil"); fix nvt only (fix shake is commented out there); fix deform ... delta
+  // over nsstrain steps, then nssample steps of sampling ----
+  const int nsstrain = (int)(std::ceil(p->strain_ampl / (p->timestep_length * p->strain_rate) / 10.0) * 10.0);   // :226
+  const double T = nsstrain * p->timestep_length, up = p->strain_ampl;
+  const double xy = equil->box[6], xz = equil->box[7], yz = equil->box[8];
+  const double ly0 = equil->box[4] - equil->box[1], lz0 = equil->box[5] - equil->box[2];
+  std::vector<std::unique_ptr<State>> st(12);
+  std::vector<ActiveSim> runs(12);
+  for (int dir = 0; dir < 6; dir++)
+    for (int pn = 0; pn < 2; pn++) {
+      const int i = 2 * dir + pn;
+      const double sign = pn == 0 ? -1.0 : 1.0;   // "neg" first, then "pos"
+      if ((rc = make_state(e, t, equil->box, equil->x.as<double>(), equil->v.as<double>(), true, st[i]))) return rc;
+      ActiveSim &A = runs[i];
+      A.st = st[i].get();
+      A.dt = p->timestep_length;
+      A.temperature = p->temperature;
+      A.nts = nsstrain;
+      A.nss = p->nsteps_sample;
+      // engine rates (raw order xx,yy,zz,xy,xz,yz): L(t) = L0 (1 + r t); xy(t) = xy0 + r Ly0 t; xz, yz with Lz0
+      double *r = A.rates;
+      if (dir == 0) { r[0] = sign * up / T; r[3] = -sign * up * xy / (ly0 * T); r[4] = -sign * up * xz / (lz0 * T); }
+      if (dir == 1) { r[1] = sign * up / T; r[5] = -sign * up * yz / (lz0 * T); }
+      if (dir == 2) r[2] = sign * up / T;
+      if (dir == 3) r[5] = sign * up / T;   // yz delta = sign up lz0
+      if (dir == 4) r[4] = sign * up / T;   // xz delta = sign up lz0
+      if (dir == 5) r[3] = sign * up / T;   // xy delta = sign up ly0
+    }
+  {
+    EvalOpt o;
+    o.shake_a = 0;
+    o.shake_b = 0;
+    if ((rc = eval_chunk(e, runs, o))) return rc;
+  }
+  // C_i,dir = 0.5 (C_i^neg + C_i^pos), d_i = -(p_i1 - p_i0)/(delta/len0) cfac with (pxx,pyy,pzz,pyz,pxz,pxy): the
+  // unstrained p_i0 cancels in the average.  GPa: cfac = 1.01325e-4 (init.mod.lammps).
+  static const int RAW_OF_VOIGT[6] = {0, 1, 2, 5, 4, 3};
+  double C[6][6];
+  for (int dir = 0; dir < 6; dir++)
+    for (int i = 0; i < 6; i++) {
+      const double pneg = runs[2 * dir].pavg[RAW_OF_VOIGT[i]], ppos = runs[2 * dir + 1].pavg[RAW_OF_VOIGT[i]];
+      C[i][dir] = -(ppos - pneg) / (2.0 * up) * 1.01325e-4;
+    }
+  // C{ij}all: diagonal as computed, off-diagonal 0.5 (Cij + Cji); GPa -> Pa (init_material_problem.h:262-270)
+  double call[6][6];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) call[i][j] = (i == j ? C[i][i] : 0.5 * (C[i][j] + C[j][i])) * 1.0e9;
+  // 6x6 -> rank 4 exactly as init_material_problem.h:276-295 does it: index 3 -> (0,1), 4 -> (0,2), 5 -> (1,2)
+  // (the script's Voigt order is 4 = yz, 5 = xz, 6 = xy; the mapping of the reference is reproduced, not corrected).
+  // stiff: file order of read_write.h:149-171, (00,01,02,11,12,22) x (00,01,02,11,12,22).
+  static const int HOSTVOIGT_OF_FILE[6] = {0, 3, 4, 1, 5, 2};
+  for (int I = 0; I < 6; I++)
+    for (int J = 0; J < 6; J++) stiff[I * 6 + J] = call[HOSTVOIGT_OF_FILE[I]][HOSTVOIGT_OF_FILE[J]];
   return SCEMA_MD_OK;
 }
 

@@ -10,7 +10,7 @@ import numpy as np
 from . import capi
 
 SYMBOLS = ["scema_stmd_create", "scema_stmd_destroy", "scema_stmd_last_error", "scema_stmd_init",
-           "scema_stmd_update", "scema_stmd_replica_data"]
+           "scema_stmd_update", "scema_stmd_replica_data", "scema_eqmd_equil"]
 
 
 class QP(C.Structure):
@@ -135,6 +135,20 @@ class STMDSync:
         self._chk(capi.lib().scema_stmd_replica_data(self.h, C.c_int32(material), C.c_int32(replica0), capi._p(L0), capi._p(s0),
                                                      capi._p(R), C.byref(rho)))
         return dict(init_length=L0, init_stress=s0, rotam=R.reshape(3, 3), rho=rho.value)
+
+
+def eqmd_equil(engine: "capi.Engine", cmat: str, folder: str, rep: int, *, mdts=2.0, mdtem=300.0, mdnss=100, mdss=1e-4, mdsa=0.005,
+               mdff="opls"):
+    """EQMDProblem::equil for an equilibrated, registered replica: writes init.<cmat>_<rep>.{length,stress,stiff}."""
+    import os
+    base = os.path.join(folder, f"init.{cmat}_{rep}")
+    err = C.create_string_buffer(512)
+    rc = capi.lib().scema_eqmd_equil(engine.h, cmat.encode(), (base + ".length").encode(), (base + ".stress").encode(),
+                                     (base + ".stiff").encode(), C.c_int32(rep), C.c_double(mdts), C.c_double(mdtem), C.c_int32(mdnss),
+                                     C.c_double(mdss), C.c_double(mdsa), mdff.encode(), err, C.c_int32(512))
+    if rc != 0:
+        raise capi.EngineError(f"eqmd_equil rc={rc}: {err.value.decode()}")
+    return base
 
 
 def write_replica_file(path: str, sysd: dict):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(scema_md_[a-z_]+)\s*\(", hdr))
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     hdr2 = open(os.path.join(ROOT, "include", "scema_stmd.h")).read()
-    declared2 = set(re.findall(r"\b(scema_stmd_[a-z_]+)\s*\(", hdr2))
+    declared2 = set(re.findall(r"\b(scema_(?:stmd|eqmd)_[a-z_]+)\s*\(", hdr2))
     assert declared2 == set(stmd.SYMBOLS), declared2 ^ set(stmd.SYMBOLS)
     L = capi.lib()
     for s in declared | declared2:

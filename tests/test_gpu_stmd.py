@@ -98,3 +98,57 @@ def test_branching_from_most_recent_qp(small_pe):
     with pytest.raises(capi.EngineError):          # unknown force field (stmd_problem.h:462-467)
         eng.strain_batch([capi.make_sim(3, "pe", 1, st, nss=10, most_recent=capi.QP_NONE, force_field="sw")])
     eng.close()
+
+
+def test_init_material_matches_oracle(small_pe):
+    """box lengths, initial stress and the stiffness tensor of an equilibrated replica, 13 MD runs in one
+    GPU batch, against the CPU restatement of the same procedure (init_material_problem.h:196-300)."""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+    eng = capi.Engine(capi.default_params(**kw))
+    eng.register_replica("pe", 1, small_pe)
+    args = dict(dt=2.0, temperature=300.0, nss=10, strain_ampl=0.005, strain_rate=2.5e-4)   # nsstrain = 10
+    length, stress, stiff = eng.init_material("pe", 1, **args)
+    o = po.Oracle(small_pe, po.default_params(**kw))
+    lo, so, co = po.init_material(o, args["dt"], args["temperature"], args["nss"], args["strain_ampl"], args["strain_rate"])
+    assert np.allclose(length, lo, rtol=1e-14)
+    assert np.abs(stress - so).max() < 1e-6 * np.abs(so).max()
+    assert np.abs(stiff - co).max() < 1e-6 * np.abs(co).max()
+    assert np.allclose(stiff, stiff.T, rtol=0, atol=1e-9 * np.abs(stiff).max())    # C{ij}all is symmetrised
+    eng.close()
+
+
+def test_eqmd_equil_feeds_stmd_init(small_pe, tmp_path):
+    """EQMDProblem::equil writes init.<mat>_<rep>.{length,stress,stiff}; STMDSync::init reads them back (the reference's
+    init_material -> dealammps hand-over through nanoscale_input), and an update() runs on top."""
+    from scema_amd import capi, stmd
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    folder = str(tmp_path / "nano_in")
+    os.makedirs(folder)
+    length, stress, stiff = eng.init_material("pe", 1, nss=10, strain_rate=2.5e-4)
+    stmd.eqmd_equil(eng, "pe", folder, 1, mdnss=10, mdss=2.5e-4)
+    got_len = np.loadtxt(os.path.join(folder, "init.pe_1.length"))
+    got_sig = np.loadtxt(os.path.join(folder, "init.pe_1.stress"))
+    got_c = np.loadtxt(os.path.join(folder, "init.pe_1.stiff")).reshape(6, 6)
+    # the two calls are separate MD batches with atomically accumulated forces: equal to summation order
+    assert np.allclose(got_len, length, rtol=1e-15)
+    assert np.abs(got_sig - stress).max() < 1e-9 * np.abs(stress).max()
+    assert np.abs(got_c - stiff).max() < 1e-8 * np.abs(stiff).max()
+    with pytest.raises(capi.EngineError, match="Force field"):
+        stmd.eqmd_equil(eng, "pe", folder, 1, mdff="charmm")
+    # hand-over: json + bin next to the three files, then the reference's init/update sequence
+    import json
+    json.dump({"relative_density": 0.95, "Nsheets": 0, "normal_vector": {}}, open(os.path.join(folder, "pe_1.json"), "w"))
+    stmd.write_replica_file(os.path.join(folder, "init.pe_1.bin"), small_pe)
+    out = str(tmp_path / "out")
+    for d in ("nano_out", "nano_res", "macro_out"):
+        os.makedirs(os.path.join(out, d))
+    sync = stmd.STMDSync(eng)
+    sync.init(md_nsteps_sample=10, nanostatelocin=folder, nanostatelocout=os.path.join(out, "nano_out"),
+              nanostatelocres=os.path.join(out, "nano_res"), macrostatelocout=os.path.join(out, "macro_out"), mdtype=["pe"], nrepl=1)
+    rd = sync.replica_data(0, 0)
+    assert np.allclose(rd["init_length"], length, rtol=1e-15)
+    assert np.abs(np.array(rd["init_stress"])[[0, 3, 4, 1, 5, 2]] - got_sig).max() < 1e-12 * np.abs(got_sig).max()
+    eng.close()
