@@ -132,3 +132,20 @@ def test_eval_is_deterministic_and_reports_nts(small_pe):
         assert nts == 10
     assert np.array_equal(out[0], out[1])
     assert np.all(np.isfinite(out[0]))
+
+
+def test_init_material_restatement_properties(small_pe):
+    """CPU restatement of EQMDProblem::lammps_equilibration (SURVEY 8 f-2): lengths are the box, the stiffness is the
+    symmetrised 6x6 of the script mapped by the reference's index rule, and the procedure leaves the oracle's state alone."""
+    from oracle import pyoracle as po
+    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+    o = po.Oracle(small_pe, po.default_params(**kw))
+    b0, x0, v0 = o.get_state()
+    length, stress, stiff = po.init_material(o, 2.0, 300.0, 10, 0.005, 2.5e-4)
+    assert np.allclose(length, small_pe["box"][3:6] - small_pe["box"][:3])
+    assert np.all(np.isfinite(stress)) and np.all(np.isfinite(stiff))
+    assert np.allclose(stiff, stiff.T, rtol=0, atol=1e-12 * np.abs(stiff).max())
+    # a stiff crystal: the normal moduli (file indices 0, 3, 5 = 0000, 1111, 2222) are positive and of GPa order
+    assert all(1e8 < stiff[i, i] < 1e12 for i in (0, 3, 5))
+    b1, x1, v1 = o.get_state()
+    assert np.array_equal(np.asarray(b0), np.asarray(b1)) and np.array_equal(x0, x1) and np.array_equal(v0, v1)
