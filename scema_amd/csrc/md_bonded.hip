@@ -49,7 +49,7 @@ extern __shared__ double s_bt[];  // [3*maxloc] positions, [3*maxloc] forces
 
 // PARTS: also split virial / energy per part (parity hook); otherwise one lumped virial
 template <bool PARTS>
-__global__ __launch_bounds__(BT_TPB) void k_bonded(const SimDev *__restrict__ sims, int maxloc) {
+__global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__ sims, int maxloc) {
   const SimDev &S = sims[blockIdx.y];
   if ((int)blockIdx.x >= S.bt_ntile) return;
   SimScalars &sc = *S.sc;
