@@ -22,7 +22,7 @@
 //   j table entry = image code [27:23] | j slot [22:0]
 //
 // Reference semantics: pair_style lj/cut/coul/long 12.0 9.0 (in.set.lammps:40), neighbor 2.0 bin
-// (in.set.lammps:27); special_bonds 0 0 1 pairs are excluded here and handled in k_bonded_atom.
+// (in.set.lammps:27); special_bonds 0 0 1 pairs are excluded here and handled in k_bonded (md_bonded.hip).
 #include <hip/hip_runtime.h>
 
 #include "md_device.h"
@@ -56,13 +56,22 @@ __device__ __forceinline__ GLOBAL_AS T *as_global_w(T *p) {
 // XCD-aware block -> (simulation, tile) map.  Workgroups are dealt round-robin over the 8 XCDs
 // (block L lands on XCD L % 8), each with its own 4 MiB L2.  A simulation's j gathers touch its
 // whole 332 KB position table and its force atomics its 250 KB force table, so all tiles of one
-// simulation are placed on ONE XCD: simulation s uses the blocks with L % 8 == s % 8.
-// Placement only affects speed, never results.
+// simulation are placed on ONE XCD: simulation s uses the blocks with L % 8 == s % 8.  That needs
+// groups of 8 simulations; the last nsims % 8 simulations (all of them in a small batch, e.g. the
+// single-replica check of BASELINE config 2) spread their tiles over all XCDs instead, so no XCD
+// idles.  Placement only affects speed, never results.
 __device__ __forceinline__ bool xcd_map(int ntiles, int nsims, int &sim, int &tile) {
   const int L = blockIdx.x;
-  const int x = L & 7, w = L >> 3;
-  sim = (w / ntiles) * 8 + x;
-  tile = w % ntiles;
+  const int full = nsims & ~7;
+  if (L < full * ntiles) {
+    const int x = L & 7, w = L >> 3;
+    sim = (w / ntiles) * 8 + x;
+    tile = w % ntiles;
+  } else {
+    const int Lr = L - full * ntiles;
+    sim = full + Lr / ntiles;
+    tile = Lr % ntiles;
+  }
   return sim < nsims;
 }
 
@@ -668,7 +677,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(cdiv(ns, 8) * 8 * ntiles), 1, 1); }
+static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(ns * ntiles), 1, 1); }
 
 size_t mdk_pair_lds_bytes(int capj) { return (size_t)capj * (3 * sizeof(double) + sizeof(int)); }
 int mdk_neigh_capB(int maxrow) { return (int)(0.6 * maxrow) / 64 * 64 + 64; }
