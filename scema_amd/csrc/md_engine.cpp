@@ -631,11 +631,11 @@ static std::map<long, PolyFit> &poly_cache() { static std::map<long, PolyFit> m;
 static double cached_coul_poly(scema_md_engine *, double g, double rc, double *poly, int *npoly, double *uscale) {
   if (g <= 0.0) return fit_coul_poly(g, rc, poly, npoly, uscale);
   const double x = g * rc;
-  const long key = (long)std::ceil(x * 16.0);          // x rounded up to 1/16
+  const long key = (long)std::ceil(x * 64.0);          // x rounded up to 1/64
   auto it = poly_cache().find(key);
   if (it == poly_cache().end()) {
     PolyFit f;
-    f.err = fit_coul_poly(key / 16.0, 1.0, f.c, &f.n, &f.uscale);
+    f.err = fit_coul_poly(key / 64.0, 1.0, f.c, &f.n, &f.uscale);
     it = poly_cache().emplace(key, f).first;
   }
   std::memcpy(poly, it->second.c, sizeof(double) * MD_MAXPOLY);
