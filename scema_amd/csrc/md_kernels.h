@@ -11,7 +11,6 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
 // dynamic LDS of the tile kernels for a j-table capacity (the engine sizes the cell grid so that these fit)
 size_t mdk_pair_lds_bytes(int capj);
 size_t mdk_neigh_lds_bytes(int capj, int maxrow);
-void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly);
 // bonded terms + special pairs, one workgroup per bonded tile; parts != 0: per-part virial/energy (parity hook)

@@ -836,9 +836,6 @@ void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int max
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
   mdk_neigh_build(st, d, ns, maxcells, maxrow, capj);
 }
-void mdk_pack(hipStream_t st, const SimDev *d, int ns, int maxpad) {
-  hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
-}
 // reciprocal sum, part 1 (structure factors + per-k coefficients): depends only on the positions
 void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax, int maxgrp) {
   if (maxk <= 0) return;

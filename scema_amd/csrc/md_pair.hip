@@ -676,7 +676,6 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   }
 }
 
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(ns * ntiles), 1, 1); }
 
 size_t mdk_pair_lds_bytes(int capj) { return (size_t)capj * (3 * sizeof(double) + sizeof(int)); }
