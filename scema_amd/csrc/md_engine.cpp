@@ -144,6 +144,7 @@ struct scema_md_engine {
   Profile prof;
   std::string err;
   double neigh_grow = 1.0;
+  bool use_graphs = false;  // hipGraph replay of the MD step loop: opt-in (SCEMA_MD_GRAPH=1), measured slower on ROCm 7.2
 };
 
 namespace {
@@ -734,7 +735,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
 static hipError_t force_stage(scema_md_engine *e, const SimDev *D, int ns, int maxbt, int maxloc, int maxatoms, int maxk, int mmax,
                               int maxgrp, int parts, int pairvir) {
   hipStream_t st = e->stream;
-  const bool side = maxk > 0 && e->stream2 != nullptr;
+  const bool side = maxk > 0 && e->stream2 != nullptr && ns >= 16;   // small batches: the fork/join costs more than it hides
   if (side) {
     hipError_t rc = hipEventRecord(e->ev_fork, st);
     if (rc != hipSuccess) return rc;
@@ -956,14 +957,12 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const bool prof = e->p.profile != 0;
   size_t ev_used = 0;
   std::vector<double> launch_bytes;
-  for (int step = 1; step <= maxsteps; step++) {
-    int na = 0;
-    while (na < ns && e->h_sims[na].nsteps >= step) na++;
-    if (na == 0) break;
+  // one MD step of the first `na` simulations, as a sequence of launches on the engine's streams
+  auto launch_step = [&](int na, bool timed) -> int {
     mdk_pre(st, D, na);
     mdk_initial_integrate(st, D, na, maxatoms);
     mdk_neighbor(st, D, na, maxatoms, maxpad, maxcells, maxrow, maxcapj);
-    if (prof) {
+    if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;
         HIPCHK(hipEventCreate(&a));
@@ -974,7 +973,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
     mdk_pair(st, D, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
-    if (prof) {
+    if (timed) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;
       launch_bytes.push_back((double)na);
@@ -984,7 +983,48 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     mdk_final_integrate(st, D, na, maxatoms, 1);
     mdk_post(st, D, na);
     if (spec.deform) mdk_remap(st, D, na, maxatoms);
-    e->prof.md_steps += na;
+    return SCEMA_MD_OK;
+  };
+  // The step loop is launch-bound for small batches (about 20 kernels of a few microseconds each per step of a
+  // single replica): the steps that share an active count can be captured once into a hipGraph and replayed.
+  // Measured on ROCm 7.2 / MI355X (tools/graph_cmp.py, ms per update of 1 / 72 PE-10k replicas): plain launches
+  // 25.8 / 236.7 on one stream, 28.3 / 232.2 with the side stream; graph replay 26.4 / 236.9 on one stream and
+  // 55.2 / 251.3 with the side stream inside the graph -- no gain, so replay is opt-in (SCEMA_MD_GRAPH=1).  Not
+  // with per-launch event timing (profile mode), which needs the individual launches.
+  const bool use_graph = !prof && e->use_graphs;
+  for (int step = 1; step <= maxsteps;) {
+    int na = 0;
+    while (na < ns && e->h_sims[na].nsteps >= step) na++;
+    if (na == 0) break;
+    const int run_len = e->h_sims[na - 1].nsteps - step + 1;   // steps until the active prefix shrinks (sorted by nsteps)
+    bool replayed = false;
+    if (use_graph && run_len >= 4) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t gexec = nullptr;
+      bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        const int rc_l = launch_step(na, false);
+        ok = (hipStreamEndCapture(st, &graph) == hipSuccess) && rc_l == SCEMA_MD_OK && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (ok) {
+        for (int r = 0; r < run_len && ok; r++) ok = hipGraphLaunch(gexec, st) == hipSuccess;
+        if (!ok) return fail(e, SCEMA_MD_ERR_DEVICE, "hipGraphLaunch failed");
+        replayed = true;
+      } else {
+        (void)hipGetLastError();
+        e->use_graphs = false;   // capture is not available here: plain launches from now on
+      }
+      if (gexec) (void)hipGraphExecDestroy(gexec);
+      if (graph) (void)hipGraphDestroy(graph);
+    }
+    if (!replayed)
+      for (int r = 0; r < run_len; r++) {
+        const int rc_l = launch_step(na, prof);
+        if (rc_l) return rc_l;
+      }
+    e->prof.md_steps += (long long)na * run_len;
+    step += run_len;
   }
   mdk_phase_end(st, D, ns, maxatoms);
   HIPCHK(hipMemcpyAsync(e->h_sc.data(), e->d_sc.p, (size_t)ns * sizeof(SimScalars), hipMemcpyDeviceToHost, st));
@@ -1223,6 +1263,7 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     delete e;
     return SCEMA_MD_ERR_DEVICE;
   }
+  if (getenv("SCEMA_MD_GRAPH")) e->use_graphs = true;
   if (!getenv("SCEMA_MD_ONE_STREAM")) {
     if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
