@@ -1462,6 +1462,8 @@ int scema_md_copy_local_stress(scema_md_engine *e, void *dst, int32_t dst_on_dev
   HIPCHK(hipSetDevice(e->p.device));
   HIPCHK(hipMemcpy(dst, e->d_local_stress.p, (size_t)std::max(e->local_stress_count, 0) * 6 * sizeof(double),
                    dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+  // a device-to-device hipMemcpy may return before it has run: the caller hands dst to a collective on another stream
+  if (dst_on_device) HIPCHK(hipStreamSynchronize(nullptr));
   return SCEMA_MD_OK;
 }
 
