@@ -143,7 +143,9 @@ struct scema_md_engine {
   std::vector<hipEvent_t> ev_pool;
   Profile prof;
   std::string err;
-  double neigh_grow = 1.0;
+  double neigh_grow = 1.0;   // headroom factor of the cluster rows, x1.5 per overflow
+  double jtab_grow = 1.0;    // headroom factor of the tile j tables, x1.25 per overflow (-> smaller cells)
+  int overflow_bits = 0;     // what overflowed in the last run: 4 = a tile's j table, 8 = a cluster row
   bool use_graphs = false;  // hipGraph replay of the MD step loop: opt-in (SCEMA_MD_GRAPH=1), measured slower on ROCm 7.2
 };
 
@@ -793,43 +795,77 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     for (int d = 0; d < 3; d++)
       if (std::min(w0[d], w1[d]) < 2.0 * rlist)
         return fail(e, SCEMA_MD_ERR_BOX, "box width %.3f < 2*(cutoff+skin) = %.3f in dim %d", std::min(w0[d], w1[d]), 2 * rlist, d);
-    // Cell grid = tiling of k_pair (one workgroup per cell): cells of >= rlist/k per dimension.  k = 2 unless the
-    // j table of a tile (the images of the half stencil within rlist of the cell, 28 B of LDS each) would not fit
-    // two workgroups per CU; denser systems get smaller cells.
+    // Cell grid = tiling of k_pair (one workgroup per cell).  The per-tile phases of k_pair (table load, barrier,
+    // flush) are amortised over the tile's rows, so cells are made as LARGE as the LDS allows: of all grids with
+    // cell edges between rlist/2 and rlist, the one with the largest cells whose estimated j table (the images of
+    // the half stencil within rlist of the cell, 28 B of LDS each) still fits two workgroups per CU.  PE-10k:
+    // 5x6x4 cells of 8.9 x 7.4 x 10.1 A (22 clusters, 2 280 table entries) instead of 6x6x5 (14 clusters, 2 040):
+    // k_pair -3.5 %, build +8 %, step -2.4 %.  Denser systems fall back to cells of rlist/3, rlist/4, ...
     const double rho = T.natoms / std::min(b0.vol, b1.vol);
     int capj = 0, maxneigh = 0;
     bool fits = false;
-    for (int k = 2; k <= 8 && !fits; k++) {
+    auto size_grid = [&](const int nc[3], int mst[3], int &cj_out, int &mn_out) {
       int ncells = 1;
       for (int d = 0; d < 3; d++) {
         const double w = std::min(w0[d], w1[d]);
-        int nc = (int)std::floor(w / (rlist / k * 1.0001));
-        nc = std::max(1, std::min(nc, 64));
-        S.nc[d] = nc;
-        S.mst[d] = (int)std::ceil(rlist / (w / nc) - 1e-12);
-        ncells *= nc;
+        mst[d] = (int)std::ceil(rlist / (w / nc[d]) - 1e-12);
+        ncells *= nc[d];
       }
       // Cartesian extents of one cell (bounding box of its edge vectors), the larger of the two boxes
       double ext[3] = {0, 0, 0};
       for (const HostBox *hb : {&b0, &b1}) {
-        ext[0] = std::max(ext[0], std::fabs(hb->h[0]) / S.nc[0] + std::fabs(hb->h[5]) / S.nc[1] + std::fabs(hb->h[4]) / S.nc[2]);
-        ext[1] = std::max(ext[1], std::fabs(hb->h[1]) / S.nc[1] + std::fabs(hb->h[3]) / S.nc[2]);
-        ext[2] = std::max(ext[2], std::fabs(hb->h[2]) / S.nc[2]);
+        ext[0] = std::max(ext[0], std::fabs(hb->h[0]) / nc[0] + std::fabs(hb->h[5]) / nc[1] + std::fabs(hb->h[4]) / nc[2]);
+        ext[1] = std::max(ext[1], std::fabs(hb->h[1]) / nc[1] + std::fabs(hb->h[3]) / nc[2]);
+        ext[2] = std::max(ext[2], std::fabs(hb->h[2]) / nc[2]);
       }
       const double r = rlist;
+      // volume of (cell (+) ball of rlist); the table holds the half stencil: half of it plus half of the own cell.
+      // Calibrated on PE-10k grids from 6x6x5 to 4x5x4: estimate = 1.15-1.17 x the largest table seen.
       const double vmink = ext[0] * ext[1] * ext[2] + 2.0 * r * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2]) +
                            MD_PI * r * r * (ext[0] + ext[1] + ext[2]) + 4.0 / 3.0 * MD_PI * r * r * r;
       const double vmin = std::min(b0.vol, b1.vol);
       const double rho_slots = (T.natoms + 1.5 * ncells) / vmin;
       const double cellvol = std::max(b0.vol, b1.vol) / ncells;
-      double cj = rho_slots * (0.5 * vmink + cellvol * (S.mst[0] + 1.0)) * 1.10 * e->neigh_grow + 64.0;
+      double cj = rho_slots * (0.5 * vmink + 0.5 * cellvol) * 1.13 * e->jtab_grow;
       cj = std::min(cj, (double)padded_slots(T.natoms, ncells) * 14.0);
-      capj = ((int)std::ceil(cj) + 63) / 64 * 64;
+      cj_out = std::max(64, ((int)std::ceil(cj) + 63) / 64 * 64);
       // row capacity of one i-cluster: the union of 4 half neighbour spheres whose centres are within a cell, plus
       // headroom; regrown on overflow
-      maxneigh = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.25 * e->neigh_grow) + 128;
-      maxneigh = (std::min(maxneigh, capj) + 63) / 64 * 64;
-      fits = capj <= MD_MAXJTAB && mdk_pair_lds_bytes(capj) <= 74 * 1024 && mdk_neigh_lds_bytes(capj, maxneigh) <= 150 * 1024;
+      mn_out = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.25 * e->neigh_grow) + 128;
+      mn_out = (std::min(mn_out, cj_out) + 63) / 64 * 64;
+      return cj_out <= MD_MAXJTAB && mdk_pair_lds_bytes(cj_out) <= 74 * 1024 && mdk_neigh_lds_bytes(cj_out, mn_out) <= 150 * 1024;
+    };
+    {
+      int lo[3], hi[3];
+      for (int d = 0; d < 3; d++) {
+        const double w = std::min(w0[d], w1[d]);
+        lo[d] = std::max(2, std::min(64, (int)std::floor(w / (rlist * 1.0001))));
+        hi[d] = std::max(lo[d], std::min(64, (int)std::floor(w / (0.5 * rlist * 1.0001))));
+      }
+      double best = -1.0;
+      for (int n0 = lo[0]; n0 <= hi[0]; n0++)
+        for (int n1 = lo[1]; n1 <= hi[1]; n1++)
+          for (int n2 = lo[2]; n2 <= hi[2]; n2++) {
+            const int nc[3] = {n0, n1, n2};
+            int mst[3], cj, mn;
+            if (!size_grid(nc, mst, cj, mn)) continue;
+            const double vol = 1.0 / ((double)n0 * n1 * n2);
+            if (vol > best) {
+              best = vol;
+              fits = true;
+              capj = cj; maxneigh = mn;
+              for (int d = 0; d < 3; d++) { S.nc[d] = nc[d]; S.mst[d] = mst[d]; }
+            }
+          }
+    }
+    for (int k = 3; k <= 8 && !fits; k++) {
+      int nc[3], mst[3];
+      for (int d = 0; d < 3; d++) {
+        const double w = std::min(w0[d], w1[d]);
+        nc[d] = std::max(1, std::min((int)std::floor(w / (rlist / k * 1.0001)), 64));
+      }
+      fits = size_grid(nc, mst, capj, maxneigh);
+      for (int d = 0; d < 3; d++) { S.nc[d] = nc[d]; S.mst[d] = mst[d]; }
     }
     if (!fits)
       return fail(e, SCEMA_MD_ERR_ARG, "the j table of a cell tile (%d entries) does not fit the LDS of the pair kernel (system too dense for the cutoff)", capj);
@@ -1065,6 +1101,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     e->prof.unique_pairs_n += 1;
   }
   if (fault & 2) return fail(e, SCEMA_MD_ERR_ARG, "an excluded (special) pair stretched beyond the exclusion gate; topology or state is broken");
+  e->overflow_bits = fault;
   if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
   return SCEMA_MD_OK;
 }
@@ -1172,7 +1209,7 @@ struct EvalOpt {
 // full evaluation (phase A + phase B) of a chunk of simulations, with overflow retry
 int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt &opt = EvalOpt()) {
   const int ns = (int)chunk.size();
-  for (int attempt = 0; attempt < 4; attempt++) {
+  for (int attempt = 0; attempt < 6; attempt++) {
     int rc = prepare_slots(e, chunk);
     if (rc) return rc;
     // backup for a retry after neighbour overflow
@@ -1221,7 +1258,8 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
       HIPCHK(hipMemcpyAsync(chunk[i].st->v.p, sl.vbak.p, bytes, hipMemcpyDeviceToDevice, e->stream));
     }
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->neigh_grow *= 1.5;
+    if (e->overflow_bits & 4) e->jtab_grow *= 1.25;
+    if ((e->overflow_bits & 8) || !(e->overflow_bits & 4)) e->neigh_grow *= 1.5;
   }
   return fail(e, SCEMA_MD_ERR_OVERFLOW, "neighbour capacity exceeded after regrowth");
 }
@@ -1271,7 +1309,7 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
       e->stream2 = nullptr;   // side stream is an optimisation only
   }
   // test hook: start with undersized neighbour capacities, so that the overflow -> restore -> regrow path runs
-  if (const char *g0 = getenv("SCEMA_MD_NEIGH_GROW0")) e->neigh_grow = std::max(0.05, atof(g0));
+  if (const char *g0 = getenv("SCEMA_MD_NEIGH_GROW0")) e->neigh_grow = e->jtab_grow = std::max(0.05, atof(g0));
   *out = e;
   return SCEMA_MD_OK;
 }
@@ -1587,7 +1625,7 @@ int scema_md_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid,
   sims[0].nsteps = 0;
   sims[0].dt = 1.0;
   sims[0].temperature = 300.0;
-  for (int attempt = 0; attempt < 4; attempt++) {
+  for (int attempt = 0; attempt < 6; attempt++) {
     if ((rc = prepare_slots(e, sims))) return rc;
     RunSpec R;
     R.use_shake = use_shake;
@@ -1596,7 +1634,8 @@ int scema_md_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid,
     R.nvt = 0;
     rc = run_phase(e, sims, R);
     if (rc != SCEMA_MD_ERR_OVERFLOW) break;
-    e->neigh_grow *= 1.5;
+    if (e->overflow_bits & 4) e->jtab_grow *= 1.25;
+    if ((e->overflow_bits & 8) || !(e->overflow_bits & 4)) e->neigh_grow *= 1.5;
   }
   if (rc) return rc;
   const SimScalars &sc = e->h_sc[0];

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     }
   }
   if (nj > capj || nj > S.capj) {   // uniform: table overflow -> the engine regrows and retries
-    if (threadIdx.x == 0) { S.tile_nj[cell] = 0; atomicOr(&sc.overflow, 1); atomicMax(&sc.maxj_seen, nj); }
+    if (threadIdx.x == 0) { S.tile_nj[cell] = 0; atomicOr(&sc.overflow, 1 | 4); atomicMax(&sc.maxj_seen, nj); }   // 4: table
     for (int cl = cs / NI + threadIdx.x; cl < ce / NI; cl += TT) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
     return;
   }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
   }
   const double cnt = wave_sum((double)npairs);
   if (lane == 0) {
-    if (over) atomicOr(&sc.overflow, 1);
+    if (over) atomicOr(&sc.overflow, 1 | 8);   // 8: a cluster row (or its segment-B list)
     atomicMax(&sc.maxneigh_seen, nmax);
     // nentries counts what a full per-atom list would store: every unordered pair from both ends
     atomicAdd(&sc.nentries, 2ull * (unsigned long long)cnt);

@@ -118,7 +118,7 @@ def test_neighbour_overflow_regrow(small_pe, monkeypatch):
     lens = _lens(small_pe)
     st = np.array([-3e-4 * lens[0], -3e-4 * lens[1], 1e-3 * lens[2], 0, 0, 0])
     res = []
-    for grow0 in (None, "0.2"):
+    for grow0 in (None, "0.6"):
         if grow0 is None:
             monkeypatch.delenv("SCEMA_MD_NEIGH_GROW0", raising=False)
         else:
