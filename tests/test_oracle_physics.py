@@ -236,3 +236,42 @@ def test_special_pairs_cancel_kspace():
     bare = QQR2E * 0.4 * (-0.4) / r
     assert abs((ef[1] + ef[6]) - (eb[1] + eb[6]) - bare) < 1e-9
     assert abs((ff[0, 0] - fb[0, 0]) + bare / r) < 1e-9   # attraction: F_x on atom 0 = -bare/r > 0
+
+
+def _improper_only(x, K=12.5, chi0_deg=20.0):
+    """Four atoms in a 60 A box that interact through ONE harmonic improper only (no LJ, no charge, no bonds)."""
+    z = lambda *sh: np.zeros(sh, np.int32)
+    return dict(natoms=4, ntypes=1, type=z(4), charge=np.zeros(4), mass=np.array([12.0]), eps=np.zeros((1, 1)), sigma=np.ones((1, 1)),
+                bonds=z(0, 2), bond_type=z(0), bond_coeff=np.zeros((0, 2)), angles=z(0, 3), angle_type=z(0), angle_coeff=np.zeros((0, 2)),
+                dihedrals=z(0, 4), dihedral_type=z(0), dihedral_coeff=np.zeros((0, 4)),
+                impropers=np.array([[0, 1, 2, 3]], np.int32), improper_type=z(1), improper_coeff=np.array([[K, np.deg2rad(chi0_deg)]]),
+                special_lj=np.ones(3), special_coul=np.ones(3),
+                box=np.array([0, 0, 0, 60, 60, 60, 0, 0, 0.0]), x=np.asarray(x, float), v=np.zeros((4, 3)))
+
+
+def test_improper_harmonic_closed_form_and_consistency():
+    """improper_style harmonic (in.set.lammps:56): E = K (chi - chi0)^2 with chi the angle between the planes
+    (1,2,3) and (2,3,4); forces = -dE/dx by central differences; virial = sum r (x) f; zero net force and torque."""
+    K, chi0 = 12.5, 20.0
+    for chi in (35.0, 80.0, 140.0):
+        c, s_ = np.cos(np.deg2rad(chi)), np.sin(np.deg2rad(chi))
+        # atoms 2,3 on the z axis; atom 1 in the xz plane, atom 4 rotated by chi about z
+        x = np.array([[30 + 1.1, 30, 30 - 0.4], [30, 30, 30], [30, 30, 31.5], [30 + 0.9 * c, 30 + 0.9 * s_, 31.9]])
+        o = po.Oracle(_improper_only(x, K, chi0), po.default_params(shake_mass=0.0))
+        o.setup(use_shake=False)
+        f, e, w = o.compute()
+        assert abs(e[5] - K * np.deg2rad(chi - chi0) ** 2) < 1e-10
+        assert np.abs(e[[0, 1, 2, 3, 4, 6]]).max() == 0.0
+        assert np.abs(f.sum(0)).max() < 1e-10 and np.abs(np.cross(x - x.mean(0), f).sum(0)).max() < 1e-9
+        h = 1e-5
+        for i in range(4):
+            for k in range(3):
+                ep = []
+                for sgn in (1, -1):
+                    xx = x.copy(); xx[i, k] += sgn * h
+                    o2 = po.Oracle(_improper_only(xx, K, chi0), po.default_params(shake_mass=0.0)); o2.setup(use_shake=False)
+                    ep.append(o2.compute()[1][5])
+                assert abs(-(ep[0] - ep[1]) / (2 * h) - f[i, k]) < 1e-6 * max(1.0, np.abs(f).max())
+        # virial of an isolated term = sum_i r_i (x) f_i
+        wref = np.array([(x[:, a] * f[:, b]).sum() for a, b in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))])
+        assert np.abs(w[5] - wref).max() < 1e-9 * max(1.0, np.abs(wref).max())
