@@ -136,6 +136,73 @@ def build_pe(nx: int = 6, ny: int = 9, nz: int = 16, temperature: float = 300.0,
     )
 
 
+def build_ethane_oh(nx: int = 3, ny: int = 3, nz: int = 3, spacing: float = 5.2, seed: int = 5, temperature: float = 200.0) -> dict:
+    """Small molecular liquid-like lattice for SHAKE coverage: on every lattice site one ethane (C2H6: two star clusters of
+    4 atoms = C + 3 H) and one heavy-H diatomic (a cluster of 2), randomly oriented.  OPLS-style terms: bonds, angles,
+    H-C-C-H dihedrals; types 0 = C, 1 = H, 2 = O-like heavy atom; charges neutral per molecule."""
+    rng = np.random.default_rng(seed)
+    rCC, rCH, rOH = 1.529, 1.09, 0.96
+    tet = np.deg2rad(110.7)
+    x, typ, q, bonds, btype, angles, atype, dihs, dtype_ = [], [], [], [], [], [], [], [], []
+    def rot():
+        a = rng.normal(size=(3, 3)); qm, _ = np.linalg.qr(a)
+        return qm if np.linalg.det(qm) > 0 else -qm
+    for i in range(nx):
+        for j in range(ny):
+            for k in range(nz):
+                c = (np.array([i, j, k], float) + 0.5) * spacing
+                R = rot()
+                base = len(x)
+                loc = [np.array([0, 0, -rCC / 2]), np.array([0, 0, rCC / 2])]
+                for side, sgn in ((0, -1.0), (1, 1.0)):
+                    for m in range(3):
+                        phi = 2 * np.pi * m / 3 + (np.pi / 3 if side else 0.0)
+                        # H at the tetrahedral angle from the C-C axis
+                        d = np.array([np.sin(np.pi - tet) * np.cos(phi), np.sin(np.pi - tet) * np.sin(phi), sgn * np.cos(np.pi - tet)])
+                        loc.append(loc[side] + rCH * d)
+                for v in loc:
+                    x.append(c + R @ v)
+                typ += [0, 0] + [1] * 6
+                q += [-0.18, -0.18] + [0.06] * 6
+                bonds.append([base, base + 1]); btype.append(0)
+                for side in (0, 1):
+                    hs = [base + 2 + 3 * side + m for m in range(3)]
+                    for h in hs:
+                        bonds.append([base + side, h]); btype.append(1)
+                        angles.append([h, base + side, base + 1 - side]); atype.append(0)      # H-C-C
+                    for a in range(3):
+                        for b in range(a + 1, 3):
+                            angles.append([hs[a], base + side, hs[b]]); atype.append(1)          # H-C-H
+                for a in range(3):
+                    for b in range(3):
+                        dihs.append([base + 2 + a, base, base + 1, base + 5 + b]); dtype_.append(0)   # H-C-C-H
+                # heavy-H diatomic on the body-centre position of the lattice (4.5 A from the ethane centres)
+                R2 = rot()
+                o = c + 0.5 * spacing * np.ones(3)
+                b2 = len(x)
+                x.append(o); x.append(o + R2 @ np.array([rOH, 0.0, 0.0]))
+                typ += [2, 1]; q += [-0.4, 0.4]
+                bonds.append([b2, b2 + 1]); btype.append(2)
+    x = np.array(x); n = len(x)
+    mass = np.array([12.011, 1.008, 15.999])
+    eps1 = np.array([0.066, 0.030, 0.17]); sig1 = np.array([3.5, 2.5, 3.12])
+    eps = np.sqrt(np.outer(eps1, eps1)); sig = np.sqrt(np.outer(sig1, sig1))
+    L = np.array([nx, ny, nz], float) * spacing
+    typ = np.array(typ, np.int32)
+    v = rng.normal(size=(n, 3)) * np.sqrt(0.0019872067 * temperature / (mass[typ][:, None] * 48.88821291 ** 2))
+    v -= (v * mass[typ][:, None]).sum(0) / mass[typ].sum()
+    z = lambda *sh: np.zeros(sh, np.int32)
+    return dict(natoms=n, ntypes=3, type=typ, charge=np.array(q), mass=mass, eps=eps, sigma=sig,
+                bonds=np.array(bonds, np.int32), bond_type=np.array(btype, np.int32),
+                bond_coeff=np.array([[268.0, rCC], [340.0, rCH], [553.0, rOH]]),
+                angles=np.array(angles, np.int32), angle_type=np.array(atype, np.int32),
+                angle_coeff=np.array([[37.5, tet], [33.0, np.deg2rad(107.8)]]),
+                dihedrals=np.array(dihs, np.int32), dihedral_type=np.array(dtype_, np.int32), dihedral_coeff=np.array([[0.0, 0.0, 0.3, 0.0]]),
+                impropers=z(0, 4), improper_type=z(0), improper_coeff=np.zeros((0, 2)),
+                special_lj=np.array([0.0, 0.0, 1.0]), special_coul=np.array([0.0, 0.0, 1.0]),
+                box=np.array([0, 0, 0, L[0], L[1], L[2], 0.3, -0.2, 0.25]), x=x, v=v)
+
+
 def build_pe10k(seed: int = 1234) -> dict:
     """The PE-10k benchmark replica of SURVEY.md 8(d): 10 368 atoms, 300 K with SHAKE-projected velocities."""
     return build_pe(6, 9, 16, 300.0, seed, shake_project=True)

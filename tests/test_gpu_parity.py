@@ -212,3 +212,35 @@ def test_impropers_match_oracle(small_pe, eng_small):
     got = np.array(eng_small.strain_batch([capi.make_sim(7, "pe_imp", 1, st, nss=10, most_recent=capi.QP_NONE)])[0].stress[:])
     exp, _ = oracle_small(d).eval(st, 2.0, 300.0, 1e-4, 10)
     assert relerr(got, exp) < 1e-6
+
+
+def test_shake_clusters_of_two_and_four_trajectory():
+    """k_shake on clusters of 2 (closed form) and 4 atoms (fixed-point iteration), three atom types, tilted box:
+    20 steps of NVT + SHAKE + deform land on the oracle's state."""
+    from scema_amd import capi
+    from scema_amd.systems import build_ethane_oh
+    from oracle import pyoracle as po
+    d = build_ethane_oh()
+    kw = dict(cut_lj=5.5, cut_coul=5.0, skin=1.0, kspace_accuracy=1e-5)
+    eng = capi.Engine(capi.default_params(**kw))
+    eng.register_replica("eth", 1, d)
+    f, e, w, info = eng.debug_compute("eth", 1, use_shake=True)
+    o = po.Oracle(d, po.default_params(**kw))
+    o.setup(use_shake=True)
+    fo, eo, wo = o.compute()
+    assert info["nclus"] == o.nclusters and info["npairs"] == o.npairs
+    assert relerr(f, fo) < 1e-11
+    for part in range(8):
+        assert np.abs(w[part] - wo[part]).max() < 1e-10 * max(1.0, np.abs(wo[part]).max()), capi.PARTS[part]
+    rates = np.array([1e-5, -2e-5, 3e-5, 1.5e-5, -0.5e-5, 2.5e-5])
+    eng.set_state(3, "eth", 1, d["box"], d["x"], d["v"])
+    pavg = eng.debug_run("eth", 1, 20, 1.0, 200.0, qp=3, nvt=True, use_shake=True, rates=rates, sample=True)
+    box, x, v = eng.get_state(3, "eth", 1)
+    o2 = po.Oracle(d, po.default_params(**kw))
+    pavg_o, _ = o2.run(20, 1.0, 200.0, nvt=True, use_shake=True, rates=rates, sample=True)
+    bo, xo, vo = o2.get_state()
+    assert np.abs(box - bo).max() < 1e-12
+    assert np.abs(x - xo).max() < 1e-9
+    assert relerr(v, vo) < 1e-8
+    assert relerr(pavg, pavg_o) < 1e-8
+    eng.close()

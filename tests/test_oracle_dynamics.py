@@ -149,3 +149,28 @@ def test_init_material_restatement_properties(small_pe):
     assert all(1e8 < stiff[i, i] < 1e12 for i in (0, 3, 5))
     b1, x1, v1 = o.get_state()
     assert np.array_equal(np.asarray(b0), np.asarray(b1)) and np.array_equal(x0, x1) and np.array_equal(v0, v1)
+
+
+def test_shake_clusters_of_two_and_four():
+    """fix shake ... m 1.0 on a molecular system: ethane gives star clusters of 4 (C + 3 H), the heavy-H
+    diatomics clusters of 2 (closed form); every constrained bond stays at r0 within the tolerance, the constraint
+    count enters the degrees of freedom."""
+    from oracle import pyoracle as po
+    from scema_amd.systems import build_ethane_oh
+    d = build_ethane_oh()
+    kw = dict(cut_lj=5.5, cut_coul=5.0, skin=1.0, kspace_accuracy=1e-5)
+    o = po.Oracle(d, po.default_params(**kw))
+    o.setup(use_shake=True)
+    nmol = d["natoms"] // 10
+    assert o.nclusters == 3 * nmol and o.nconstraints == 7 * nmol
+    assert o.tdof == 3 * d["natoms"] - 3 - 7 * nmol
+    o.run(30, 1.0, 200.0, nvt=True, use_shake=True)
+    _, x, _ = o.get_state()
+    x = np.asarray(x).reshape(-1, 3)
+    typ = d["type"]
+    worst = 0.0
+    for (a, b), t in zip(d["bonds"], d["bond_type"]):
+        if typ[a] == 1 or typ[b] == 1:
+            r = np.linalg.norm(x[a] - x[b])          # molecules are whole (positions are unwrapped)
+            worst = max(worst, abs(r - d["bond_coeff"][t, 1]) / d["bond_coeff"][t, 1])
+    assert worst < 2e-3          # fix shake 0.001: relative bond-length tolerance per iteration sweep
