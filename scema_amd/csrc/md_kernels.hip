@@ -208,11 +208,15 @@ __global__ __launch_bounds__(TPB) void k_bin(const SimDev *sims) {
     int cc = (int)(w * S.nc[d]);
     if (cc >= S.nc[d]) cc = S.nc[d] - 1;
     c[d] = cc;
-    // position inside the cell on an 8x8x8 grid -> Morton key: consecutive slots of a cell are
-    // spatial neighbours, which keeps the 4-atom i-clusters of k_pair compact
-    int sub = (int)((w * S.nc[d] - cc) * 8.0);
-    sub = sub < 0 ? 0 : (sub > 7 ? 7 : sub);
-    key |= ((sub & 1) << d) | ((sub & 2) << (d + 2)) | ((sub & 4) << (d + 4));
+    // position inside the cell on a grid of ~1.1 A sub-cells (isotropic in Angstrom whatever the shape of the
+    // cell, at most 16 per edge) -> Morton key: consecutive slots of a cell are spatial neighbours, which keeps the
+    // 4-atom i-clusters of k_pair compact
+    const double edge = (d == 0 ? b.h[0] : d == 1 ? b.h[1] : b.h[2]) / S.nc[d];
+    int nsub = (int)ceil(edge / 1.1);
+    nsub = nsub < 2 ? 2 : (nsub > 16 ? 16 : nsub);
+    int sub = (int)((w * S.nc[d] - cc) * nsub);
+    sub = sub < 0 ? 0 : (sub > nsub - 1 ? nsub - 1 : sub);
+    key |= ((sub & 1) << d) | ((sub & 2) << (d + 2)) | ((sub & 4) << (d + 4)) | ((sub & 8) << (d + 6));
   }
   S.ckey[i] = key;
   const int cell = (c[2] * S.nc[1] + c[1]) * S.nc[0] + c[0];
