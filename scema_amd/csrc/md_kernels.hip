@@ -277,33 +277,96 @@ __global__ __launch_bounds__(TPB) void k_cell_fill(const SimDev *sims) {
   S.slot_tmp[slot] = i;
 }
 
-// deterministic order inside each cell: ascending (Morton key of the sub-cell position, atom index);
-// the atomic fill order is not deterministic.  One wave per cell: a lane ranks its member against all members.
+// Deterministic order inside each cell, chosen so that 4 consecutive slots (one i-cluster of k_pair) are spatial
+// neighbours: a k-d ordering.  The cell's atoms are split recursively at the median of the longest extent of the
+// current group (left part = half of the group's clusters, a multiple of 4 atoms) until the groups are single
+// clusters; ties by atom index, so the result does not depend on the atomic fill order.  One wave per cell, O(n^2)
+// rank counting per level in LDS (n <= 256; larger cells fall back to the Morton key of k_bin).
+#define KD_MAX 256
 __global__ __launch_bounds__(64) void k_cell_sort(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   if (!S.sc->rebuild) return;
   const int c = blockIdx.x;
   if (c >= S.ncells) return;
   const int b = S.cell_start[c], n = S.cell_count[c];  // the rest of the cell's range stays pad (-1)
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    const int i = i0 + (int)threadIdx.x;
-    const int a = (i < n) ? S.slot_tmp[b + i] : 0;
-    const int ka = (i < n) ? S.ckey[a] : 0;
-    int r = 0;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-      const int j = j0 + (int)threadIdx.x;
-      const int o_l = (j < n) ? S.slot_tmp[b + j] : 0x7fffffff;
-      const int ko_l = (j < n) ? S.ckey[o_l] : 0x7fffffff;
-      const int m = min(64, n - j0);
-      for (int t = 0; t < m; t++) {
-        const int o = __shfl(o_l, t, 64), ko = __shfl(ko_l, t, 64);
-        r += (ko < ka || (ko == ka && o < a)) ? 1 : 0;
+  if (n > KD_MAX) {
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + (int)threadIdx.x;
+      const int a = (i < n) ? S.slot_tmp[b + i] : 0;
+      const int ka = (i < n) ? S.ckey[a] : 0;
+      int r = 0;
+      for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + (int)threadIdx.x;
+        const int o_l = (j < n) ? S.slot_tmp[b + j] : 0x7fffffff;
+        const int ko_l = (j < n) ? S.ckey[o_l] : 0x7fffffff;
+        const int m = min(64, n - j0);
+        for (int t = 0; t < m; t++) {
+          const int o = __shfl(o_l, t, 64), ko = __shfl(ko_l, t, 64);
+          r += (ko < ka || (ko == ka && o < a)) ? 1 : 0;
+        }
+      }
+      if (i < n) {
+        S.perm[b + r] = a;
+        S.slot_of[a] = b + r;
       }
     }
-    if (i < n) {
-      S.perm[b + r] = a;
-      S.slot_of[a] = b + r;
+    return;
+  }
+  __shared__ double s_x[KD_MAX][3];
+  __shared__ int s_gid[KD_MAX];
+  __shared__ int s_k[2][KD_MAX], s_s[2][KD_MAX], s_e[2][KD_MAX];
+  {
+    BoxD bx;
+    box_derive(S.sc->box, bx);
+    for (int k = threadIdx.x; k < n; k += 64) {
+      const int a = S.slot_tmp[b + k];
+      const int w0 = S.wrapn[3 * a], w1 = S.wrapn[3 * a + 1], w2 = S.wrapn[3 * a + 2];
+      s_x[k][0] = S.x[3 * a] - (bx.h[0] * w0 + bx.h[5] * w1 + bx.h[4] * w2);
+      s_x[k][1] = S.x[3 * a + 1] - (bx.h[1] * w1 + bx.h[3] * w2);
+      s_x[k][2] = S.x[3 * a + 2] - (bx.h[2] * w2);
+      s_gid[k] = a;
+      s_k[0][k] = k; s_s[0][k] = 0; s_e[0][k] = n;
     }
+  }
+  int cur = 0;
+  for (int level = 0; level < 10; level++) {
+    __syncthreads();
+    bool split_any = false;
+    for (int p = threadIdx.x; p < n; p += 64) {
+      const int s0 = s_s[cur][p], e0 = s_e[cur][p], cnt = e0 - s0, k = s_k[cur][p];
+      int np = p, ns = s0, ne = e0;
+      if (cnt > 4) {
+        split_any = true;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int q = s0; q < e0; q++) {
+          const int kq = s_k[cur][q];
+          for (int d = 0; d < 3; d++) { lo[d] = fmin(lo[d], s_x[kq][d]); hi[d] = fmax(hi[d], s_x[kq][d]); }
+        }
+        const double ex0 = hi[0] - lo[0], ex1 = hi[1] - lo[1], ex2 = hi[2] - lo[2];
+        const int axis = (ex0 >= ex1 && ex0 >= ex2) ? 0 : (ex1 >= ex2 ? 1 : 2);
+        const double xp = s_x[k][axis];
+        const int gp = s_gid[k];
+        int rank = 0;
+        for (int q = s0; q < e0; q++) {
+          const int kq = s_k[cur][q];
+          const double xq_ = s_x[kq][axis];
+          rank += (xq_ < xp || (xq_ == xp && s_gid[kq] < gp)) ? 1 : 0;
+        }
+        const int nclus = (cnt + 3) / 4;
+        const int left = ((nclus + 1) / 2) * 4;   // half of the group's clusters (rounded up), always < cnt
+        np = s0 + rank;
+        if (rank < left) { ns = s0; ne = s0 + left; } else { ns = s0 + left; ne = e0; }
+      }
+      s_k[1 - cur][np] = k; s_s[1 - cur][np] = ns; s_e[1 - cur][np] = ne;
+    }
+    cur = 1 - cur;
+    if (!__any(split_any)) break;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < n; p += 64) {
+    const int a = s_gid[s_k[cur][p]];
+    S.perm[b + p] = a;
+    S.slot_of[a] = b + p;
   }
 }
 
