@@ -886,7 +886,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       if (perr > 1e-12) return fail(e, SCEMA_MD_ERR_ARG, "real-space Ewald polynomial fit error %.3e too large (g*rc = %.3f)", perr, ew.g * P.cut_coul);
     }
     {
-      const double m = 0.25 * P.skin;
+      const double m = 0.1 * P.skin;   // margin of the row segments over the cutoffs (scan 0 .. 0.6 skin: flat optimum at 0.05-0.15)
       S.seg_a2 = (P.cut_coul + m) * (P.cut_coul + m);
       S.seg_b2 = (P.cut_lj + m) * (P.cut_lj + m);
     }
