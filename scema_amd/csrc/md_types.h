@@ -29,7 +29,7 @@
 // [0] offset into bt_atoms, [1] local atoms, then (first term, number of terms) per kind
 enum { BT_BOND = 0, BT_BOND_SHAKEN = 1, BT_ANGLE = 2, BT_DIHEDRAL = 3, BT_IMPROPER = 4, BT_SPECIAL = 5, BT_NKIND = 6 };
 #define BT_DESC 16
-#define BT_OWNERS 128        /* owner atoms (consecutive breadth-first ranks of the bond graph) per tile */
+#define BT_OWNERS 192        /* owner atoms (consecutive breadth-first ranks of the bond graph) per tile */
 
 enum { P_LJ = 0, P_COUL = 1, P_BOND = 2, P_ANGLE = 3, P_DIHEDRAL = 4, P_IMPROPER = 5, P_KSPACE = 6, P_SHAKE = 7 };
 
