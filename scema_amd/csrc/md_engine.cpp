@@ -889,6 +889,12 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       const double m = 0.1 * P.skin;   // margin of the row segments over the cutoffs (scan 0 .. 0.6 skin: flat optimum at 0.05-0.15)
       S.seg_a2 = (P.cut_coul + m) * (P.cut_coul + m);
       S.seg_b2 = (P.cut_lj + m) * (P.cut_lj + m);
+      // skin pairs listed beyond cutmax + far_band sit at the back of the rows and are skipped until an atom has moved far_band/2
+      double frac = 0.5;
+      if (const char *fv = getenv("SCEMA_MD_FAR_FRAC")) frac = atof(fv);
+      S.far_band = frac * P.skin;
+      const double cm = std::max(P.cut_coul, P.cut_lj) + S.far_band;
+      S.seg_c2 = cm * cm;
     }
     S.natoms = T.natoms;
     S.npad = padded_slots(T.natoms, S.ncells);

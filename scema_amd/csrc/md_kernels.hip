@@ -98,6 +98,8 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.check = 1;
     sc.rebuild = 1;
     sc.deltasq = 0.0;
+    sc.far_dsq = 1.0e300;
+    sc.need_far = 0;
   }
   for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;
   for (int k = threadIdx.x; k < S.ncells; k += blockDim.x) S.cell_count[k] = 0;
@@ -144,6 +146,11 @@ __global__ void k_pre(const SimDev *sims) {
     }
     double delta = 0.5 * (S.skin - (d1 + d2));
     sc.deltasq = delta * delta;
+    // far skin band: a pair listed at r0 >= cutmax + far_band is inside the cutoff only after
+    // 2 dmax + (d1 + d2) >= far_band
+    const double far = 0.5 * (S.far_band - (d1 + d2));
+    sc.far_dsq = (far > 0.0) ? far * far * (1.0 - 1.0e-9) : -1.0;
+    sc.need_far = 0;
     if (S.nvt) sc.vscale *= nhc_half(S, sc);
     for (int k = 0; k < 6; k++) sc.ke[k] = 0.0;
     for (int k = 0; k < MD_NPART * 6; k++) sc.vir[k] = 0.0;
@@ -174,6 +181,7 @@ __global__ __launch_bounds__(TPB) void k_initial_integrate(const SimDev *sims) {
     dsq += d * d;
   }
   if (sc.check && dsq > sc.deltasq) sc.rebuild = 1;
+  if (dsq >= sc.far_dsq) sc.need_far = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -186,6 +194,8 @@ __global__ __launch_bounds__(TPB) void k_bin(const SimDev *sims) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     box_corners(sc.box, sc.corners_hold);
+    sc.far_dsq = 1.0e300;   // fresh list: every listed skin pair is outside the cutoff
+    sc.need_far = 0;
   }
   if (i >= S.natoms) return;
   BoxD b;

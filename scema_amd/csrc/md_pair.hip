@@ -146,7 +146,7 @@ struct ClusterI {
   int atom[NI];   // real atom index or -1 (pad)
 };
 
-extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists of segment B
+extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists: segment B from the front, C1 from the back
 
 __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB) {
   int sim, cell;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
   }
   // ---- phase 2 ----
   const int maxrow = S.maxneigh;
-  const double ra2 = S.seg_a2, rb2 = S.seg_b2;
+  const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2;
   const GLOBAL_AS int *stype = as_global(S.stype);
   unsigned long long npairs = 0, nrowent = 0;
   int nmax = 0, over = 0;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
       const int ba = (a == 0) ? exb[0] : (a == 1) ? exb[1] : (a == 2) ? exb[2] : exb[3];
       s_ex[wave][lane] = (e < na) ? S.ex_list[ba + e] : -1;
     }
-    int nA = 0, nB = 0, nC = 0;
+    int nA = 0, nB = 0, nC = 0, nD = 0;   // segments A, B, C1 (near skin band), C2 (far skin band)
     // one chunk of the table ahead: entry + record of chunk r+1 are in flight while chunk r is tested
     int jt_n = (lane < nj) ? s_jtab[lane] : 0;
     double pn0, pn1, pn2;
@@ -356,27 +356,30 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
             }
           }
       }
-      const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB;
-      const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC);
+      const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB && rmin < rc2;
+      const bool isD = mask && !isA && !isB && !isC;
+      const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC), mD = __ballot(isD);
       if (mask) {
         const int entry = l | (stype[j] << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT);
         if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) row[pos] = entry; }
         else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
-        else { const int pos = maxrow - 1 - (nC + popc_below(mC)); if (pos >= 0) row[pos] = entry; }
+        else if (isC) { const int pos = capB - 1 - (nC + popc_below(mC)); if (pos >= 0) lb[pos] = entry; }
+        else { const int pos = maxrow - 1 - (nD + popc_below(mD)); if (pos >= 0) row[pos] = entry; }
       }
-      nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC);
+      nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC); nD += __popcll(mD);
       npairs += __popc(mask);
     }
-    const int n = nA + nB + nC;
-    const bool bad = nB > capB || n > maxrow;
+    const int n = nA + nB + nC + nD;
+    const bool bad = nB + nC > capB || n > maxrow;
     if (bad) over = 1;
-    // B: LDS list -> behind A (same-wave LDS traffic is processed in order)
-    const int mB_ = bad ? 0 : nB;
+    // B, C1: LDS lists -> behind A (same-wave LDS traffic is processed in order)
+    const int mB_ = bad ? 0 : nB, mC_ = bad ? 0 : nC;
     for (int k = lane; k < mB_; k += 64) row[nA + k] = lb[k];
+    for (int k = lane; k < mC_; k += 64) row[nA + nB + k] = lb[capB - 1 - k];
     if (lane == 0) {
-      S.numneigh[2 * cl] = bad ? 0 : nA + nB; S.numneigh[2 * cl + 1] = bad ? 0 : nC;
-      // cost of the row in k_pair (FP64 instructions per entry of the three segments + per-row overhead)
-      if (cl - cs / NI < 64) s_cost[cl - cs / NI] = bad ? 0 : 5 * nA + 3 * nB + (3 * nC) / 2 + 96;
+      S.numneigh[2 * cl] = bad ? 0 : nA + nB + nC; S.numneigh[2 * cl + 1] = bad ? 0 : nD;
+      // cost of the row in k_pair (FP64 instructions per entry of the segments + per-row overhead)
+      if (cl - cs / NI < 64) s_cost[cl - cs / NI] = bad ? 0 : 5 * nA + 3 * nB + (3 * nC) / 2 + nD + 96;
     }
     nmax = max(nmax, n);
     nrowent += n;
@@ -506,6 +509,8 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   const double cutc2 = S.cut_coul2, cutl2 = S.cut_lj2;
   const double cutmax2 = fmax(cutc2, cutl2);
   const int maxrow = S.maxneigh;
+  // far skin band: walked only on steps where some atom of the replica has moved far enough for such a pair to reach the cutoff
+  const int need_far = __builtin_amdgcn_readfirstlane(S.sc->need_far);
   double vl[6] = {0, 0, 0, 0, 0, 0}, vc[6] = {0, 0, 0, 0, 0, 0};
   double elj = 0, ecoul = 0;
   // this wave's rows, fixed at build time (longest first)
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   for (int p = p_begin; p < p_end; p++) {
     const int cl = S.tile_order[cs / NI + p];   // wave-uniform
     const int s0 = cl * NI;
-    const int nab = S.numneigh[2 * cl], nn = nab + S.numneigh[2 * cl + 1];  // [A|B] from the front, C reversed from the back
+    const int nab = S.numneigh[2 * cl], nn = nab + (need_far ? S.numneigh[2 * cl + 1] : 0);  // [A|B|C1] from the front, C2 reversed from the back
     if (nn == 0) continue;
 #define ROW_AT(k) row[((k) < nab) ? (k) : (maxrow - 1 - ((k) - nab))]
     double xi[NI], yi[NI], zi[NI], qi[NI], fx[NI], fy[NI], fz[NI];

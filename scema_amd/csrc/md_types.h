@@ -46,6 +46,7 @@ struct SimScalars {
   double vscale;       // deferred Nose-Hoover velocity scale, applied by the next kick
   double psum[6];      // running sum of the sampled pressure tensor (atm)
   double deltasq;      // neighbour trigger: (skin - corner motion)^2 / 4
+  double far_dsq;      // squared atom displacement from which the far skin band (segment C2) can reach the cutoff
   double corners_hold[24];
   unsigned long long nentries;  // (i,j) pairs listed at the last build (= entries of a full per-atom list)
   unsigned long long nrowent;   // row entries actually stored (one per (cluster, j))
@@ -56,6 +57,7 @@ struct SimScalars {
   int rebuild;
   int overflow;
   int maxneigh_seen;
+  int need_far;        // this step some atom moved >= sqrt(far_dsq): k_pair walks segment C2 too
   int maxj_seen;       // largest tile j table at the last builds
   int nbuilds;
 };
@@ -82,6 +84,8 @@ struct SimDev {
   double coul_uscale;
   double coul_poly[MD_MAXPOLY];
   double seg_a2, seg_b2;  // row segments by build-time distance: (cut_coul+m)^2, (cut_lj+m)^2
+  double far_band;        // width (A) of the near skin band C1
+  double seg_c2;          // skin band split: (cutmax + skin/2)^2, beyond it segment C2 (skipped while nothing moved far enough)
   // topology (shared by all simulations of one (material, replica))
   const int *type;
   const double *q, *mass;       // per atom
@@ -117,7 +121,7 @@ struct SimDev {
   int *wrapn;       // atom -> integer wrap (3)
   double *xhold;
   int *cell_of, *ckey, *cell_count, *cell_start, *cell_fill;
-  int *numneigh, *neigh;  // per cluster: {entries in segments A+B (front), entries in segment C (back)}; rows of maxneigh entries
+  int *numneigh, *neigh;  // per cluster: {entries in segments A+B+C1 (front), entries in segment C2 (back)}; rows of maxneigh entries
   // ewald
   const int *kn;    // 3 ints per k
   const int *krun;  // per k: number of following k-vectors that continue its row (same n1, n2; n3 + 1 each)
