@@ -1098,6 +1098,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     fprintf(stderr, "[scema_md] sim 0: cells %dx%dx%d, j table max %d of %d, row max %d of %d, row entries/cluster %.1f, listed pairs/atom %.1f, builds %d\n",
             S0.nc[0], S0.nc[1], S0.nc[2], c.maxj_seen, S0.capj, c.maxneigh_seen, S0.maxneigh, (double)c.nrowent / (S0.npad / MD_CLUSTER),
             (double)c.nentries / S0.natoms, c.nbuilds);
+#ifdef PAIR_TIMING
+    fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
+            (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);
+#endif
   }
   int fault = 0;
   for (int i = 0; i < ns; i++) {

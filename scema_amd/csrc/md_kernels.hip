@@ -100,6 +100,9 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.deltasq = 0.0;
     sc.far_dsq = 1.0e300;
     sc.need_far = 0;
+#ifdef PAIR_TIMING
+    for (int k = 0; k < 8; k++) sc.dbg[k] = 0;
+#endif
   }
   for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;
   for (int k = threadIdx.x; k < S.ncells; k += blockDim.x) S.cell_count[k] = 0;

@@ -472,6 +472,9 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     return;
   }
   SimScalars &sc = *S.sc;
+#ifdef PAIR_TIMING
+  const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
   __shared__ double s_shift[27 * 4];
   __shared__ __attribute__((aligned(16))) double s_lj[2 * MD_MAXTYPES * MD_MAXTYPES];
   __shared__ double s_red[8 * TW];
@@ -490,6 +493,48 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   // (lj1, lj2) of a type pair side by side: one 16-byte LDS read per LJ evaluation
   for (int k = threadIdx.x; k < 2 * nt2; k += TT) s_lj[k] = S.lj[(k & 1) * nt2 + (k >> 1)];
   const int nj = S.tile_nj[cell];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int maxrow = S.maxneigh;
+  // far skin band: walked only on steps where some atom of the replica has moved far enough for such a pair to reach the cutoff
+  const int need_far = __builtin_amdgcn_readfirstlane(S.sc->need_far);
+  // Row headers of this wave and the first two chunks of its entry stream are requested before the tile's table is
+  // staged: none of that needs the LDS, so their latency runs under the table load and the barrier.
+  const int p_begin = S.tile_wstart[(size_t)cell * (TW + 1) + wave], p_end = S.tile_wstart[(size_t)cell * (TW + 1) + wave + 1];
+  const int nrows = (nj > 0) ? min(p_end - p_begin, 64) : 0;
+  int h_cl = 0, h_nab = 0, h_nn = 0;
+  if (lane < nrows) {
+    h_cl = S.tile_order[cs / NI + p_begin + lane];
+    h_nab = S.numneigh[2 * h_cl];
+    h_nn = (h_nab + (need_far ? S.numneigh[2 * h_cl + 1] : 0)) << 16;   // [A|B|C1] from the front, C2 reversed from the back
+  }
+#define H_KB(v) ((v) & 0xFFFF)
+#define H_KE(v) ((int)((unsigned)(v) >> 16))
+  const GLOBAL_AS int *neigh = as_global(S.neigh);
+  // prefetch cursor: the chunk two ahead of the one being evaluated
+  int pr = 0;
+  int pcl = __builtin_amdgcn_readlane(h_cl, 0), pnab = __builtin_amdgcn_readlane(h_nab, 0), pnn = __builtin_amdgcn_readlane(h_nn, 0);
+  int pk = H_KB(pnn);
+  pnn = H_KE(pnn);
+  auto fetch = [&]() -> int {
+    int v = 0;
+    if (pr < nrows) {
+      const int k = pk + lane;
+      const GLOBAL_AS int *row = neigh + (size_t)pcl * maxrow;
+      if (k < pnn) v = row[(k < pnab) ? k : (maxrow - 1 - (k - pnab))];
+      pk += 64;
+      if (pk >= pnn) {
+        pr += 1;
+        const int q = min(pr, nrows - 1);
+        pcl = __builtin_amdgcn_readlane(h_cl, q); pnab = __builtin_amdgcn_readlane(h_nab, q); pnn = __builtin_amdgcn_readlane(h_nn, q);
+        pk = H_KB(pnn);
+        pnn = H_KE(pnn);
+      }
+    }
+    return v;
+  };
+  int e_n = 0, e_nn = 0;
+  if (nrows > 0) { e_n = fetch(); e_nn = fetch(); }
   {
     const GLOBAL_AS int *gj = as_global(S.tile_jtab) + (size_t)cell * S.capj;
     for (int l = threadIdx.x; l < nj; l += TT) {
@@ -501,27 +546,33 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
 #pragma unroll
   for (int m = 0; m < NP; m++) cp[m] = S.coul_poly[m];
   __syncthreads();
-  const int lane = lane_id();
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);   // (x,y) halves
   const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;              // (z,q) halves
   const double g = S.g_ewald, g2u = g * g * S.coul_uscale;
   const double cutc2 = S.cut_coul2, cutl2 = S.cut_lj2;
   const double cutmax2 = fmax(cutc2, cutl2);
-  const int maxrow = S.maxneigh;
-  // far skin band: walked only on steps where some atom of the replica has moved far enough for such a pair to reach the cutoff
-  const int need_far = __builtin_amdgcn_readfirstlane(S.sc->need_far);
   double vl[6] = {0, 0, 0, 0, 0, 0}, vc[6] = {0, 0, 0, 0, 0, 0};
   double elj = 0, ecoul = 0;
-  // this wave's rows, fixed at build time (longest first)
-  const int p_begin = S.tile_wstart[(size_t)cell * (TW + 1) + wave], p_end = S.tile_wstart[(size_t)cell * (TW + 1) + wave + 1];
-  if (nj > 0)
-  for (int p = p_begin; p < p_end; p++) {
-    const int cl = S.tile_order[cs / NI + p];   // wave-uniform
-    const int s0 = cl * NI;
-    const int nab = S.numneigh[2 * cl], nn = nab + (need_far ? S.numneigh[2 * cl + 1] : 0);  // [A|B|C1] from the front, C2 reversed from the back
-    if (nn == 0) continue;
-#define ROW_AT(k) row[((k) < nab) ? (k) : (maxrow - 1 - ((k) - nab))]
+#ifdef PAIR_TIMING
+  const unsigned long long tm1 = __builtin_readcyclecounter();
+#endif
+  // This wave's rows, fixed at build time (longest first), run as ONE stream of 64-entry chunks: all rows of the tile
+  // index the same LDS j table, so the prefetch pipeline (row entries two chunks ahead, table entry + record one chunk
+  // ahead) runs straight across row boundaries; a boundary only swaps the i-cluster (reduce its forces, load the next
+  // cluster's records).  Row headers (cluster, counts) sit in one VGPR triple, lane r = r-th row of the wave, and are
+  // read with v_readlane: no memory latency on the row switch.
+  if (nrows > 0) {
+    int jt_n = s_jtab[e_n & E_LMASK];
+    double xn0, xn1, xn2, xn3;
+    {
+      const size_t j = (size_t)(jt_n & MD_JMASK);
+      xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
+    }
+    // evaluation cursor
+    int r = 0;
+    int s0 = __builtin_amdgcn_readlane(h_cl, 0) * NI, nn = __builtin_amdgcn_readlane(h_nn, 0);
+    int k0 = H_KB(nn);
+    nn = H_KE(nn);
     double xi[NI], yi[NI], zi[NI], qi[NI], fx[NI], fy[NI], fz[NI];
     int ti[NI];
 #pragma unroll
@@ -531,18 +582,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       ti[a] = S.stype[s0 + a] * nt;
       fx[a] = fy[a] = fz[a] = 0.0;
     }
-    const GLOBAL_AS int *row = as_global(S.neigh) + (size_t)cl * maxrow;
-    // software pipeline: while chunk r is evaluated, the table entry + record of chunk r+1 and the row
-    // entries of chunk r+2 are in flight (row entries stream from HBM, records come from L1/L2)
-    int e_n = (lane < nn) ? ROW_AT(lane) : 0;
-    int e_nn = (64 + lane < nn) ? ROW_AT(64 + lane) : 0;
-    int jt_n = s_jtab[e_n & E_LMASK];
-    double xn0, xn1, xn2, xn3;
-    {
-      const size_t j = (size_t)(jt_n & MD_JMASK);
-      xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
-    }
-    for (int k0 = 0; k0 < nn; k0 += 64) {
+    while (r < nrows) {
       const int e = e_n, jt = jt_n;
       const double xj = xn0, yj = xn1, zj = xn2, qj = xn3;
       {
@@ -550,84 +590,107 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
         jt_n = s_jtab[e_n & E_LMASK];
         const size_t j = (size_t)(jt_n & MD_JMASK);
         xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
-        const int kn = k0 + 128 + lane;
-        e_nn = (kn < nn) ? ROW_AT(kn) : 0;
+        e_nn = fetch();
       }
-      const int mask = (e >> E_MASK_SHIFT) & 0xF;  // 0 for the padding of the last chunk
-      if (mask == 0) continue;
-      const int cs4 = 4 * (jt >> 23);
-      const double xs = xj + s_shift[cs4], ys = yj + s_shift[cs4 + 1], zs = zj + s_shift[cs4 + 2];
-      const int tj = (e >> E_TYPE_SHIFT) & 0xF;
-      double gx = 0.0, gy = 0.0, gz = 0.0;   // reaction force on j
+      const int mask = (e >> E_MASK_SHIFT) & 0xF;  // 0 for the padding of a row's last chunk
+      if (mask != 0) {
+        const int cs4 = 4 * (jt >> 23);
+        const double xs = xj + s_shift[cs4], ys = yj + s_shift[cs4 + 1], zs = zj + s_shift[cs4 + 2];
+        const int tj = (e >> E_TYPE_SHIFT) & 0xF;
+        double gx = 0.0, gy = 0.0, gz = 0.0;   // reaction force on j
 #pragma unroll
-      for (int a = 0; a < NI; a++) {
-        if (!(mask & (1 << a))) continue;
-        const double dx = xi[a] - xs, dy = yi[a] - ys, dz = zi[a] - zs;
-        const double rsq = dx * dx + dy * dy + dz * dz;
-        if (rsq < cutmax2) {
-          const double rinv = rsqrt_f64(rsq);
-          const double r2inv = rinv * rinv;
-          double flj = 0.0, fc = 0.0;
-          if (rsq < cutc2) {
-            // erfc(x) + 2x/sqrt(pi) exp(-x^2) = 1 - x H(u): Horner in t = u*uscale - 1
-            const double x = g * rsq * rinv;
-            const double t = fma(rsq, g2u, -1.0);
-            double p = cp[NP - 1];
+        for (int a = 0; a < NI; a++) {
+          if (!(mask & (1 << a))) continue;
+          const double dx = xi[a] - xs, dy = yi[a] - ys, dz = zi[a] - zs;
+          const double rsq = dx * dx + dy * dy + dz * dz;
+          if (rsq < cutmax2) {
+            const double rinv = rsqrt_f64(rsq);
+            const double r2inv = rinv * rinv;
+            double fp = 0.0, flj = 0.0, fc = 0.0;
+            if (rsq < cutc2) {
+              // erfc(x) + 2x/sqrt(pi) exp(-x^2) = 1 - x H(u): Horner in t = u*uscale - 1
+              const double x = g * rsq * rinv;
+              const double t = fma(rsq, g2u, -1.0);
+              double p = cp[NP - 1];
 #pragma unroll
-            for (int m = NP - 2; m >= 0; m--) p = fma(p, t, cp[m]);
-            const double pref = qi[a] * qj * rinv;
-            fc = pref * fma(-x, p, 1.0) * r2inv;
-            if (ENG) ecoul += pref * erfc(x);
+              for (int m = NP - 2; m >= 0; m--) p = fma(p, t, cp[m]);
+              const double pref = qi[a] * qj * rinv;
+              fp = pref * fma(-x, p, 1.0) * r2inv;
+              if (ENG) { fc = fp; ecoul += pref * erfc(x); }
+            }
+            if (rsq < cutl2) {
+              const double r6inv = r2inv * r2inv * r2inv;
+              const double2 lj12 = ((const double2 *)s_lj)[ti[a] + tj];
+              const double w = r6inv * (lj12.x * r6inv - lj12.y);
+              fp = fma(w, r2inv, fp);
+              if (ENG) {
+                const int tt = ti[a] + tj;
+                flj = w * r2inv;
+                elj += r6inv * (S.lj[2 * nt2 + tt] * r6inv - S.lj[3 * nt2 + tt]);
+              }
+            }
+            const double tx = dx * fp, ty = dy * fp, tz = dz * fp;
+            fx[a] += tx; fy[a] += ty; fz[a] += tz;
+            gx -= tx; gy -= ty; gz -= tz;
+            if (VIR && ENG) {
+              // parity hook: LJ and coulomb parts separately
+              const double xl = dx * flj, yl = dy * flj, zl = dz * flj;
+              vl[0] = fma(dx, xl, vl[0]); vl[1] = fma(dy, yl, vl[1]); vl[2] = fma(dz, zl, vl[2]);
+              vl[3] = fma(dx, yl, vl[3]); vl[4] = fma(dx, zl, vl[4]); vl[5] = fma(dy, zl, vl[5]);
+              const double xc = dx * fc, yc = dy * fc, zc = dz * fc;
+              vc[0] = fma(dx, xc, vc[0]); vc[1] = fma(dy, yc, vc[1]); vc[2] = fma(dz, zc, vc[2]);
+              vc[3] = fma(dx, yc, vc[3]); vc[4] = fma(dx, zc, vc[4]); vc[5] = fma(dy, zc, vc[5]);
+            }
           }
-          if (rsq < cutl2) {
-            const int tt = ti[a] + tj;
-            const double r6inv = r2inv * r2inv * r2inv;
-            const double2 lj12 = ((const double2 *)s_lj)[tt];
-            flj = r6inv * (lj12.x * r6inv - lj12.y) * r2inv;
-            if (ENG) elj += r6inv * (S.lj[2 * nt2 + tt] * r6inv - S.lj[3 * nt2 + tt]);
-          }
-          const double fp = flj + fc;
-          const double tx = dx * fp, ty = dy * fp, tz = dz * fp;
-          fx[a] += tx; fy[a] += ty; fz[a] += tz;
-          gx -= tx; gy -= ty; gz -= tz;
-          if (VIR && ENG) {
-            // parity hook: LJ and coulomb parts separately
-            const double xl = dx * flj, yl = dy * flj, zl = dz * flj;
-            vl[0] = fma(dx, xl, vl[0]); vl[1] = fma(dy, yl, vl[1]); vl[2] = fma(dz, zl, vl[2]);
-            vl[3] = fma(dx, yl, vl[3]); vl[4] = fma(dx, zl, vl[4]); vl[5] = fma(dy, zl, vl[5]);
-            const double xc = dx * fc, yc = dy * fc, zc = dz * fc;
-            vc[0] = fma(dx, xc, vc[0]); vc[1] = fma(dy, yc, vc[1]); vc[2] = fma(dz, zc, vc[2]);
-            vc[3] = fma(dx, yc, vc[3]); vc[4] = fma(dx, zc, vc[4]); vc[5] = fma(dy, zc, vc[5]);
+        }
+        const int l = e & E_LMASK;
+        lds_add(&s_fx[l], gx); lds_add(&s_fy[l], gy); lds_add(&s_fz[l], gz);
+      }
+      k0 += 64;
+      if (k0 >= nn) {
+        // Row finished.  Forces on the cluster's own atoms: 12 per-lane partial sums -> the atoms' own table entries
+        // (own cell first).  Transposing butterfly over the quad (lane i ends up with component c of atom i&3), then
+        // a row scan: lanes 12..15 of each row of 16 hold the row totals and add them to LDS.  81 VALU instructions
+        // and 3 LDS atomics per cluster instead of 144 ds_bpermute.
+        const bool b0 = lane & 1, b1 = lane & 2;
+        double u[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const double *f = (c == 0) ? fx : (c == 1) ? fy : fz;
+          const double w0 = (b0 ? f[1] : f[0]) + dpp_mov<DPP_QUAD_XOR1>(b0 ? f[0] : f[1]);
+          const double w1 = (b0 ? f[3] : f[2]) + dpp_mov<DPP_QUAD_XOR1>(b0 ? f[2] : f[3]);
+          double t = (b1 ? w1 : w0) + dpp_mov<DPP_QUAD_XOR2>(b1 ? w0 : w1);
+          t += dpp_mov<DPP_ROW_SHR4>(t);
+          t += dpp_mov<DPP_ROW_SHR8>(t);
+          u[c] = t;
+        }
+        if ((lane & 12) == 12) {
+          const int l = s0 - cs + (lane & 3);
+          lds_add(&s_fx[l], u[0]); lds_add(&s_fy[l], u[1]); lds_add(&s_fz[l], u[2]);
+        }
+        r += 1;
+        if (r < nrows) {
+          s0 = __builtin_amdgcn_readlane(h_cl, r) * NI; nn = __builtin_amdgcn_readlane(h_nn, r);
+          k0 = H_KB(nn);
+          nn = H_KE(nn);
+#pragma unroll
+          for (int a = 0; a < NI; a++) {
+            xi[a] = XQ_X(S, s0 + a); yi[a] = XQ_Y(S, s0 + a); zi[a] = XQ_Z(S, s0 + a);
+            qi[a] = MD_QQRD2E * XQ_Q(S, s0 + a);
+            ti[a] = S.stype[s0 + a] * nt;
+            fx[a] = fy[a] = fz[a] = 0.0;
           }
         }
       }
-      const int l = e & E_LMASK;
-      lds_add(&s_fx[l], gx); lds_add(&s_fy[l], gy); lds_add(&s_fz[l], gz);
-    }
-    // Forces on the cluster's own atoms: 12 per-lane partial sums -> the atoms' own table entries (own cell
-    // first).  Transposing butterfly over the quad (lane i ends up with component c of atom i&3), then a row
-    // scan: lanes 12..15 of each row of 16 hold the row totals and add them to LDS.  81 VALU instructions and 3
-    // LDS atomics per cluster instead of 144 ds_bpermute.
-    {
-      const bool b0 = lane & 1, b1 = lane & 2;
-      double u[3];
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const double *f = (c == 0) ? fx : (c == 1) ? fy : fz;
-        const double w0 = (b0 ? f[1] : f[0]) + dpp_mov<DPP_QUAD_XOR1>(b0 ? f[0] : f[1]);
-        const double w1 = (b0 ? f[3] : f[2]) + dpp_mov<DPP_QUAD_XOR1>(b0 ? f[2] : f[3]);
-        double t = (b1 ? w1 : w0) + dpp_mov<DPP_QUAD_XOR2>(b1 ? w0 : w1);
-        t += dpp_mov<DPP_ROW_SHR4>(t);
-        t += dpp_mov<DPP_ROW_SHR8>(t);
-        u[c] = t;
-      }
-      if ((lane & 12) == 12) {
-        const int l = s0 - cs + (lane & 3);
-        lds_add(&s_fx[l], u[0]); lds_add(&s_fy[l], u[1]); lds_add(&s_fz[l], u[2]);
-      }
     }
   }
+#ifdef PAIR_TIMING
+  const unsigned long long tm2 = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+#ifdef PAIR_TIMING
+  const unsigned long long tm3 = __builtin_readcyclecounter();
+#endif
   // flush the tile's accumulators: consecutive table entries are runs of consecutive slots -> coalesced atomics.
   // Production virial (one lumped pair virial, the pressure sums all parts anyway): the tile's pairs contribute
   // sum_pairs (r_i - r_j) (x) F_ij = sum over table entries of r_l (x) (force accumulated on entry l), with the
@@ -668,6 +731,16 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       if (lane == 0) vp[k] = t;
     }
   }
+#ifdef PAIR_TIMING
+  {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long tm4 = __builtin_readcyclecounter();
+    if (lane == 0) {
+      atomicAdd(&sc.dbg[0], tm1 - tm0); atomicAdd(&sc.dbg[1], tm2 - tm1); atomicAdd(&sc.dbg[2], tm3 - tm2);
+      atomicAdd(&sc.dbg[3], tm4 - tm3); atomicAdd(&sc.dbg[4], 1ull);
+    }
+  }
+#endif
   if (VIR && ENG) {
     tile_atomic_add<6>(vl, sc.vir + P_LJ * 6, s_red);
     tile_atomic_add<6>(vc, sc.vir + P_COUL * 6, s_red);

@@ -60,6 +60,9 @@ struct SimScalars {
   int need_far;        // this step some atom moved >= sqrt(far_dsq): k_pair walks segment C2 too
   int maxj_seen;       // largest tile j table at the last builds
   int nbuilds;
+#ifdef PAIR_TIMING
+  unsigned long long dbg[8];
+#endif
 };
 
 struct SimDev {
