@@ -108,6 +108,32 @@ int scema_md_load_lammps_data(scema_md_engine *e, const char *matid, int32_t rep
 int scema_md_convert_lammps_data(const char *data_path, const char *replica_path, const double special_lj[3],
                                  const double special_coul[3]);
 
+/* LAMMPS binary restart files in the layout of the version the reference pins (LAMMPS 17Nov16, reference README.md:31-37):
+ * the `init.<mat>_<rep>.bin` that stmd_problem.h:204 reads and the `last.*` / `lcts.*` states that stmd_problem.h:258,268
+ * write.  probe: header of any restart file.  read_atoms: tag, type, image flags (3 per atom), wrapped x, v in file order
+ * (atom_style atomic or full; NULL outputs are skipped).  load / convert: atom_style full + pair lj/cut/coul/long +
+ * bond/angle harmonic + dihedral opls + improper harmonic, units real -> replica (compare info.cut_lj / cut_coul with the
+ * engine's parameters: the engine takes its cutoffs from scema_md_params).  write: one-process restart of a replica in
+ * the same layout. */
+typedef struct {
+  char version[32], units[16], atom_style[32], pair_style[64];
+  int64_t natoms, ntimestep, nbonds, nangles, ndihedrals, nimpropers;
+  int32_t ntypes, nbondtypes, nangletypes, ndihedraltypes, nimpropertypes, triclinic, nprocs, reserved;
+  double box[9];            /* xlo,ylo,zlo,xhi,yhi,zhi,xy,xz,yz */
+  double timestep;
+  double special_lj[3], special_coul[3];
+  double cut_lj, cut_coul;  /* pair lj/cut/coul/long settings, 0 if the file has no such block */
+  double mass[16];          /* first 16 types */
+  char error[160];
+} scema_lammps_restart_info;
+int scema_md_probe_lammps_restart(const char *path, scema_lammps_restart_info *info);
+int scema_md_read_lammps_restart_atoms(const char *path, int64_t capacity, int64_t *tag, int32_t *type, int32_t *image,
+                                       double *x, double *v);
+int scema_md_load_lammps_restart(scema_md_engine *e, const char *matid, int32_t replica, const char *path);
+int scema_md_convert_lammps_restart(const char *restart_path, const char *replica_path);
+int scema_md_write_lammps_restart(const char *path, const scema_md_system *sys, double cut_lj, double cut_coul,
+                                  double timestep, int64_t ntimestep);
+
 /* ---- the hot path ---- */
 /* Replaces STMDProblem<3>::strain (stmd_problem.h:458-496) for the whole vector that
  * STMDSync::execute_inside_md_simulations iterates (stmd_sync.h:570-618).  Simulations

@@ -23,6 +23,8 @@ SYMBOLS = [
     "scema_md_default_params", "scema_md_create", "scema_md_destroy", "scema_md_last_error",
     "scema_md_register_replica", "scema_md_load_replica_file", "scema_md_write_replica_file",
     "scema_md_load_lammps_data", "scema_md_convert_lammps_data",
+    "scema_md_probe_lammps_restart", "scema_md_read_lammps_restart_atoms", "scema_md_load_lammps_restart",
+    "scema_md_convert_lammps_restart", "scema_md_write_lammps_restart",
     "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
     "scema_md_local_stress_count", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
     "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file",
@@ -143,6 +145,42 @@ def make_system(d: dict):
     return s, keep
 
 
+class RestartInfo(C.Structure):
+    """scema_lammps_restart_info (include/scema_md.h)."""
+    _fields_ = [("version", C.c_char * 32), ("units", C.c_char * 16), ("atom_style", C.c_char * 32), ("pair_style", C.c_char * 64),
+                ("natoms", C.c_int64), ("ntimestep", C.c_int64), ("nbonds", C.c_int64), ("nangles", C.c_int64),
+                ("ndihedrals", C.c_int64), ("nimpropers", C.c_int64),
+                ("ntypes", C.c_int32), ("nbondtypes", C.c_int32), ("nangletypes", C.c_int32), ("ndihedraltypes", C.c_int32),
+                ("nimpropertypes", C.c_int32), ("triclinic", C.c_int32), ("nprocs", C.c_int32), ("reserved", C.c_int32),
+                ("box", C.c_double * 9), ("timestep", C.c_double), ("special_lj", C.c_double * 3), ("special_coul", C.c_double * 3),
+                ("cut_lj", C.c_double), ("cut_coul", C.c_double), ("mass", C.c_double * 16), ("error", C.c_char * 160)]
+
+
+def probe_lammps_restart(path: str) -> RestartInfo:
+    info = RestartInfo()
+    rc = lib().scema_md_probe_lammps_restart(path.encode(), C.byref(info))
+    if rc != 0:
+        raise IOError(f"{path}: rc={rc}: {info.error.decode()}")
+    return info
+
+
+def read_lammps_restart_atoms(path: str, natoms: int) -> dict:
+    tag = np.zeros(natoms, np.int64); typ = np.zeros(natoms, np.int32); img = np.zeros((natoms, 3), np.int32)
+    x = np.zeros((natoms, 3)); v = np.zeros((natoms, 3))
+    rc = lib().scema_md_read_lammps_restart_atoms(path.encode(), C.c_int64(natoms), _p(tag), _p(typ), _p(img), _p(x), _p(v))
+    if rc != 0:
+        raise IOError(f"{path}: rc={rc}")
+    return dict(tag=tag, type=typ, image=img, x=x, v=v)
+
+
+def write_lammps_restart(path: str, sysd: dict, cut_lj: float, cut_coul: float, timestep: float = 2.0, ntimestep: int = 0):
+    s, keep = make_system(sysd)
+    rc = lib().scema_md_write_lammps_restart(path.encode(), C.byref(s), C.c_double(cut_lj), C.c_double(cut_coul),
+                                             C.c_double(timestep), C.c_int64(ntimestep))
+    if rc != 0:
+        raise IOError(f"cannot write {path} (rc={rc})")
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -188,6 +226,10 @@ class Engine:
         slj = None if special_lj is None else np.ascontiguousarray(special_lj, np.float64)
         sc = None if special_coul is None else np.ascontiguousarray(special_coul, np.float64)
         self._chk(lib().scema_md_load_lammps_data(self.h, matid.encode(), C.c_int32(replica), path.encode(), _p(slj), _p(sc)))
+        self._natoms[(matid, replica)] = natoms
+
+    def load_lammps_restart(self, matid: str, replica: int, path: str, natoms: int):
+        self._chk(lib().scema_md_load_lammps_restart(self.h, matid.encode(), C.c_int32(replica), path.encode()))
         self._natoms[(matid, replica)] = natoms
 
     def strain_batch(self, sims, hooke: bool = False, rank: int = 0, world: int = 1):

@@ -174,8 +174,14 @@ class STMDSync {
             out << in.rdbuf();
           }
           if (engine_) {
-            int rc = scema_md_load_replica_file(engine_, r.mat.c_str(), r.repl, bin.c_str());
-            if (rc) return fail(rc, scema_md_last_error(engine_));
+            // init.<mat>_<rep>.bin is either our replica container or a LAMMPS binary restart as the reference's
+            // init_material writes it (init_material_problem.h:209): told apart by the magic string
+            char magic[16] = {0};
+            { std::ifstream in(bin, std::ios::binary); in.read(magic, 15); }
+            const bool lammps = std::string(magic) == "LammpS RestartT";
+            int rc = lammps ? scema_md_load_lammps_restart(engine_, r.mat.c_str(), r.repl, bin.c_str())
+                            : scema_md_load_replica_file(engine_, r.mat.c_str(), r.repl, bin.c_str());
+            if (rc) return fail(rc, lammps ? "cannot use LAMMPS restart " + bin + " (see stderr)" : std::string(scema_md_last_error(engine_)));
           }
         } else {
           std::cerr << "Missing equilibrated initial system for material " << r.mat << " replica #" << r.repl << std::endl;

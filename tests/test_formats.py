@@ -69,3 +69,97 @@ def test_bad_files_are_rejected(tmp_path):
     p.write_text("title\n\n3 atoms\n1 atom types\n\n0 1 xlo xhi\n0 1 ylo yhi\n0 1 zlo zhi\n\nMasses\n\n1 12.0\n\nAtoms\n\n1 1 1 0.0 0 0 0\n")
     assert capi.lib().scema_md_convert_lammps_data(str(p).encode(), str(tmp_path / "o.bin").encode(), None, None) != 0   # 3 atoms declared, 1 given
     assert capi.lib().scema_md_convert_lammps_data(b"/nonexistent", str(tmp_path / "o.bin").encode(), None, None) != 0
+
+
+# ---- LAMMPS binary restart (17Nov16 layout) ----
+SIC = os.path.join(os.path.dirname(__file__), "golden", "lammps_17Nov16_init.sic_1.bin")
+
+
+def test_restart_reader_on_the_reference_fixture():
+    """The reference ships one real LAMMPS 17Nov16 restart (examples/streched_polyhedron/nanoscale_input/init.sic_1.bin,
+    written by init_material_problem.h:209; copied as data to tests/golden/): header walk, group list, fix lists and the
+    atomic per-atom block of the C++ reader against it, and against the plain-Python reader under oracle/."""
+    _built()
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import lammps_restart as lr
+    from scema_amd import capi
+    info = capi.probe_lammps_restart(SIC)
+    assert info.version == b"17 Nov 2016" and info.units == b"metal" and info.atom_style == b"atomic" and info.pair_style == b""
+    assert (info.natoms, info.ntypes, info.ntimestep, info.nprocs, info.triclinic) == (192, 1, 4, 1, 1)
+    assert (info.nbonds, info.nangles, info.ndihedrals, info.nimpropers) == (0, 0, 0, 0)
+    assert info.timestep == 0.001 and info.mass[0] == 28.06
+    # 2 x 3 x 4 diamond-cubic cells of 5.43 A (8 atoms each), slightly dilated by the preceding NPT run
+    L = np.array(info.box[3:6]) - np.array(info.box[0:3])
+    assert np.allclose(L / np.array([2, 3, 4]), 5.4309, atol=2e-3) and list(info.box[6:9]) == [0.0, 0.0, 0.0]
+    ref = lr.read_restart(SIC)
+    assert ref["NATOMS"] == 192 and ref["groups"] == ["all"] and ref["fix_global"] == [] and ref["MASS"] == [28.06]
+    assert list(info.box[0:3]) == ref["BOXLO"] and list(info.box[3:6]) == ref["BOXHI"]
+    at = capi.read_lammps_restart_atoms(SIC, 192)
+    assert sorted(at["tag"].tolist()) == list(range(1, 193)) and set(at["type"].tolist()) == {1}
+    rim = np.array([lr.as_int(a[7]) for a in ref["atoms"]])
+    assert np.array_equal(at["image"], np.stack([(rim & 1023) - 512, ((rim >> 10) & 1023) - 512, (rim >> 20) - 512], 1))
+    assert np.abs(at["image"]).max() == 1      # a few atoms crossed a face during the 4 steps
+    rx = np.array([a[1:4] for a in ref["atoms"]]); rv = np.array([a[8:11] for a in ref["atoms"]])
+    rt = np.array([lr.as_int(a[4]) for a in ref["atoms"]])
+    assert np.array_equal(at["x"], rx) and np.array_equal(at["v"], rv) and np.array_equal(at["tag"], rt)
+    lo, hi = np.array(info.box[0:3]), np.array(info.box[3:6])
+    assert np.all(at["x"] >= lo - 1e-9) and np.all(at["x"] <= hi + 1e-9)
+    # nearest-neighbour distance of the diamond lattice: a sqrt(3)/4
+    d = at["x"][None, :, :] - at["x"][:, None, :]
+    d -= np.round(d / L) * L
+    r = np.sqrt((d ** 2).sum(-1)) + np.eye(192) * 1e9
+    assert np.allclose(r.min(1), 5.4309 * np.sqrt(3) / 4, atol=5e-3)
+    # not a replica of the OPLS path: refused with a reason, not misread
+    assert capi.lib().scema_md_convert_lammps_restart(SIC.encode(), b"/tmp/never_written.bin") != 0
+
+
+def test_restart_writer_round_trip(small_pe, tmp_path):
+    """replica -> restart file in the 17Nov16 layout (atom_style full, lj/cut/coul/long, harmonic / opls blocks) ->
+    both readers -> the same replica.  Atoms outside the box are wrapped on write and unwrapped through their image
+    flags on read."""
+    _built()
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import lammps_restart as lr
+    from scema_amd import capi
+    from scema_amd.systems import read_replica_file
+    d = dict(small_pe)
+    d["x"] = np.array(d["x"], float).copy()
+    box = np.asarray(d["box"], float)
+    d["x"][0] += [box[3] - box[0], 0.0, 0.0]           # one box to the right
+    d["x"][1] -= [0.0, 2 * (box[4] - box[1]), 0.0]     # two boxes down
+    rst = str(tmp_path / "last.7.pe_1.bin"); out = str(tmp_path / "pe.bin")
+    capi.write_lammps_restart(rst, d, 12.0, 9.0, timestep=2.0, ntimestep=110)
+    info = capi.probe_lammps_restart(rst)
+    assert info.atom_style == b"full" and info.units == b"real" and info.pair_style == b"lj/cut/coul/long"
+    assert (info.natoms, info.ntimestep, info.cut_lj, info.cut_coul) == (d["natoms"], 110, 12.0, 9.0)
+    assert list(info.special_lj) == list(d["special_lj"]) and list(info.box) == list(box)
+    assert capi.lib().scema_md_convert_lammps_restart(rst.encode(), out.encode()) == 0
+    back = read_replica_file(out)
+    for k in KEYS:
+        a, b = np.asarray(back[k], float), np.asarray(d[k], float)
+        if k == "x":
+            assert np.allclose(a, b, rtol=0, atol=1e-12), k      # wrap + unwrap
+        elif k in ("bonds", "angles", "dihedrals", "impropers", "bond_type", "angle_type", "dihedral_type", "improper_type"):
+            continue                                             # term order follows the owning atoms: compared as sets below
+        else:
+            assert np.array_equal(a, b), k
+    for at_k, tp_k in (("bonds", "bond_type"), ("angles", "angle_type"), ("dihedrals", "dihedral_type"), ("impropers", "improper_type")):
+        assert len(back[tp_k]) == len(d[tp_k])
+        if len(d[tp_k]) == 0:
+            continue
+        s1 = sorted(tuple(r) + (t,) for r, t in zip(np.asarray(back[at_k]).reshape(len(back[tp_k]), -1).tolist(), list(back[tp_k])))
+        s2 = sorted(tuple(r) + (t,) for r, t in zip(np.asarray(d[at_k]).reshape(len(d[tp_k]), -1).tolist(), list(np.asarray(d[tp_k]))))
+        assert s1 == s2, at_k
+    # the plain-Python reader sees the same file the same way
+    ref = lr.read_restart(rst)
+    assert ref["ATOM_STYLE"] == "full" and ref["PAIR"] == "lj/cut/coul/long" and ref["pair_settings"]["cut_coul"] == 9.0
+    assert ref["NBONDS"] == len(d["bond_type"]) and ref["BOND"] == "harmonic" and ref["DIHEDRAL"] == "opls"
+    assert np.allclose(np.array(ref["dihedral_coeff"]).T * 2.0, np.asarray(d["dihedral_coeff"], float))   # LAMMPS keeps K/2
+    a0 = ref["atoms"][0]
+    assert lr.as_int(a0[4]) == 1 and lr.as_int(a0[7]) == (512 << 20) | (512 << 10) | 513 and a0[11] == d["charge"][0]
+    # truncated file
+    raw = open(rst, "rb").read()
+    bad = str(tmp_path / "cut.bin"); open(bad, "wb").write(raw[: len(raw) // 2])
+    assert capi.lib().scema_md_convert_lammps_restart(bad.encode(), out.encode()) != 0

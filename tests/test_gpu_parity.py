@@ -146,6 +146,20 @@ def test_lammps_data_file_registers_the_same_system(small_pe, eng_small, tmp_pat
     assert relerr(f1, f0) < 1e-12 and np.abs(e1 - e0).max() < 1e-9 * np.abs(e0).max()
 
 
+def test_lammps_restart_file_registers_the_same_system(small_pe, eng_small, tmp_path):
+    """A binary restart in the LAMMPS 17Nov16 layout (what stmd_problem.h:204 reads) registers the same replica."""
+    from scema_amd import capi
+    p = str(tmp_path / "init.pe_1.bin")
+    capi.write_lammps_restart(p, small_pe, eng_small.params.cut_lj, eng_small.params.cut_coul)
+    info = capi.probe_lammps_restart(p)
+    assert (info.cut_lj, info.cut_coul) == (eng_small.params.cut_lj, eng_small.params.cut_coul)
+    eng_small.register_replica("pe", 18, small_pe)
+    f0, e0, w0, _ = eng_small.debug_compute("pe", 18)
+    eng_small.load_lammps_restart("pe", 19, p, natoms=small_pe["natoms"])
+    f1, e1, w1, _ = eng_small.debug_compute("pe", 19)
+    assert relerr(f1, f0) < 1e-12 and np.abs(e1 - e0).max() < 1e-9 * np.abs(e0).max()
+
+
 def test_empty_batch_and_hooke_mode(small_pe, eng_small):
     from scema_amd import capi
     import ctypes as C

@@ -152,3 +152,28 @@ def test_eqmd_equil_feeds_stmd_init(small_pe, tmp_path):
     assert np.allclose(rd["init_length"], length, rtol=1e-15)
     assert np.abs(np.array(rd["init_stress"])[[0, 3, 4, 1, 5, 2]] - got_sig).max() < 1e-12 * np.abs(got_sig).max()
     eng.close()
+
+
+def test_init_bin_may_be_a_lammps_restart(small_pe, tmp_path):
+    """nanoscale_input/init.<mat>_<rep>.bin in LAMMPS' own binary restart layout (the file the reference's init_material
+    leaves there, init_material_problem.h:209) is told apart from the replica container by its magic string and gives
+    the same update() result."""
+    from scema_amd import capi, stmd
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    s0 = np.zeros(6)
+    eps = np.array([[-4e-4, -4e-4, 1.2e-3, 5e-5, -3e-5, 2e-5]])
+    res = []
+    for kind in ("container", "lammps"):
+        dirs = _dirs(tmp_path / kind)
+        stmd.write_nanoscale_input(dirs["nanoscale_input"], "pe", 1, init_length=lens, init_stress_raw=s0,
+                                   stiff_file_order=np.zeros(36), nsheets=0, sysd=small_pe)
+        if kind == "lammps":
+            capi.write_lammps_restart(os.path.join(dirs["nanoscale_input"], "init.pe_1.bin"), small_pe, KW["cut_lj"], KW["cut_coul"])
+        eng = capi.Engine(capi.default_params(**KW))
+        sync = stmd.STMDSync(eng)
+        sync.init(nanostatelocin=dirs["nanoscale_input"], nanostatelocout=dirs["nanoscale_output"],
+                  nanostatelocres=dirs["nanoscale_restart"], macrostatelocout=dirs["macroscale_output"],
+                  mdtype=("pe",), nrepl=1, md_nsteps_sample=20, freq_checkpoint=1)
+        res.append(np.array(sync.update(1, 0.0, 1, [(5, capi.QP_NONE, 0, eps[0])])))
+        sync.close(); eng.close()
+    assert np.abs(res[0] - res[1]).max() < 1e-8 * np.abs(res[0]).max()
