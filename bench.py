@@ -172,8 +172,8 @@ def main():
                          "accounting": "achieved = SURVEY 8(d) bytes of a FULL per-atom list, N*(4*n_list+56)+48 with n_list = listed "
                                        "neighbours per atom within cutoff+skin, / HIP-event time of the launches; the kernel stores each "
                                        "pair once (half of those entries, as masked cluster rows): frac_half_list prices that list instead",
-                         "binds": "FP64 VALU issue, not HBM: 75 % VALU busy and 0.30x the algorithmic bytes in HBM traffic per the PMC "
-                                  "passes under profiles/ (r01_pmc_k_pair_72sims_pair_once.csv, pair_traffic.json); SURVEY 8(d) asks for both bounds",
+                         "binds": "FP64 VALU issue, not HBM: 80 % VALU busy and 0.24x the algorithmic bytes in HBM traffic per the PMC "
+                                  "passes under profiles/ (r01_pmc_k_pair_72sims_flat_stream.csv, pair_traffic.json); SURVEY 8(d) asks for both bounds",
                          "frac_half_list": (0.5 * (prof["pair_alg_bytes"] - per_launch_fixed) + per_launch_fixed) / pair_s / 1e9 / 8000.0 if pair_s > 0 else 0.0,
                          "launches": prof["pair_launches"],
                          "avg_launch_ms": prof["pair_ms"] / max(prof["pair_launches"], 1),
