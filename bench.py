@@ -101,6 +101,11 @@ def main():
             o_s, o_m = capi.MDSim.strain.offset, capi.MDSim.most_recent_qp_id.offset
             req.update(arr=arr, keep=sims, strain=raw[:, o_s:o_s + 48].view(np.float64), recent=raw[:, o_m:o_m + 4].view(np.int32))
         req["strain"][:, :] = strains
+        # straining steps per replica (reference stmd_problem.h:222-232): nts = max(ceil(|eps|_F / rate / dt / 10) * 10, 10)
+        rate = 2e-4 if args.strain_set == "file3d" else 1e-4
+        true = np.asarray(strains, float) / np.array([lens[0], lens[1], lens[2], lens[2], lens[1], lens[0]])
+        fro = np.sqrt((true[:, :3] ** 2).sum(1) + 2.0 * (true[:, 3:] ** 2).sum(1))
+        req["nts_mean"] = float(np.maximum(np.ceil(fro / rate / 2.0 / 10.0) * 10.0, 10.0).mean())
         req["recent"][:, 0] = capi.QP_NONE if istep == 0 else np.arange(n, dtype=np.int32)
         return req["arr"]
 
@@ -162,9 +167,9 @@ def main():
             "metric": "stress_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n} x PE-{d['natoms']} OPLS replicas per update(), 10+{args.nss} MD steps each "
+            "config": {"workload": f"{n} x PE-{d['natoms']} OPLS replicas per update(), {req.get('nts_mean', 10.0):.0f}+{args.nss} MD steps each "
                                    "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + Ewald 1e-4 + SHAKE + NVT), persistent per-QP state",
-                       "strain_set": args.strain_set, "n_sims": n, "atoms_per_replica": int(d["natoms"]), "md_steps_per_eval": 10 + args.nss,
+                       "strain_set": args.strain_set, "n_sims": n, "atoms_per_replica": int(d["natoms"]), "md_steps_per_eval": req.get("nts_mean", 10.0) + args.nss,
                        "sharding": f"sim i -> rank i % {world}", "stress_zz_checksum_Pa": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_src,
