@@ -1101,6 +1101,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
 #ifdef PAIR_TIMING
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
             (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);
+    if (c.nbuilds > 0) {
+      const double nw = (double)c.nbuilds * S0.ncells * MD_TILE_WAVES;
+      fprintf(stderr, "[scema_md] k_neigh_build wave clocks (sim 0, mean per wave and build): table %.0f, rows %.0f, schedule %.0f\n",
+              (double)c.dbg[5] / nw, (double)c.dbg[6] / nw, (double)c.dbg[7] / nw);
+    }
 #endif
   }
   int fault = 0;

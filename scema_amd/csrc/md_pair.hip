@@ -155,6 +155,9 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
   SimScalars &sc = *S.sc;
   if (!sc.rebuild) return;
   if (cell >= S.ncells) return;
+#ifdef PAIR_TIMING
+  const unsigned long long tb0 = __builtin_readcyclecounter();
+#endif
   const int cs = S.cell_start[cell], ce = S.cell_start[cell + 1], nown = ce - cs;
   if (nown == 0) {
     if (threadIdx.x == 0) S.tile_nj[cell] = 0;
@@ -262,6 +265,9 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
   }
   // ---- phase 2 ----
+#ifdef PAIR_TIMING
+  const unsigned long long tb1 = __builtin_readcyclecounter();
+#endif
   const int maxrow = S.maxneigh;
   const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2;
   const GLOBAL_AS int *stype = as_global(S.stype);
@@ -280,7 +286,8 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
       continue;
     }
     GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)cl * maxrow;
-    // bounding sphere of the cluster's real atoms: one test rejects a candidate for all four atoms
+    // bounding sphere of the cluster's real atoms: 64 consecutive table entries are spatial neighbours (cell by cell,
+    // k-d order inside), so whole chunks fall outside its reach and are skipped with one test
     double bx = 0.0, by = 0.0, bz = 0.0, brad2 = 0.0;
     {
       int nreal = 0;
@@ -329,32 +336,42 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
         const size_t jn = (size_t)(jt_n & MD_JMASK);
         pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
       }
-      int mask = 0, j = 0;
-      double rmin = 1.0e300;
-      if (l < nj) {
-        j = jt & MD_JMASK;
-        const int code = jt >> 23;
-        const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
-        const bool own = l < nown;   // same cell, same image: each pair once, by slot order
-        int aj = -2;
+      // Branch-free test of the candidate against the four atoms (table entries past nj read as entry 0 and are
+      // masked out); only candidates inside the exclusion gate -- bonded neighbours, a few chunks per row -- take the
+      // wave-uniform slow path that walks the exclusion lists.
+      const bool in = l < nj;
+      const int j = jt & MD_JMASK;
+      const int code = jt >> 23;
+      const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
+      const bool own = l < nown;   // same cell, same image: each pair once, by slot order
+      {
         const double cx = bx - xj, cy = by - yj, cz = bz - zj;
-        if (cx * cx + cy * cy + cz * cz < breach2)
+        if (__ballot(in && cx * cx + cy * cy + cz * cz < breach2) == 0ull) continue;   // nothing of this chunk is in reach
+      }
+      int mask = 0, near = 0;
+      double rmin = 1.0e300;
 #pragma unroll
-          for (int a = 0; a < NI; a++) {
-            const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            bool acc = ci.atom[a] >= 0 && r2 < S.rlist2 && !(own && j <= s0slot + a);
-            if (acc && r2 < S.excl_cut2) {
-              if (aj == -2) aj = S.perm[j];
+      for (int a = 0; a < NI; a++) {
+        const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const bool acc = in && ci.atom[a] >= 0 && r2 < S.rlist2 && !(own && j <= s0slot + a);
+        mask |= acc ? (1 << a) : 0;
+        rmin = acc ? fmin(rmin, r2) : rmin;
+        near |= (acc && r2 < S.excl_cut2) ? (1 << a) : 0;
+      }
+      if (__ballot(near != 0) != 0ull) {
+        if (near) {
+          const int aj = S.perm[j];
+#pragma unroll
+          for (int a = 0; a < NI; a++)
+            if (near & (1 << a)) {
+              bool keep = true;
               const int nl = min(exn[a], 16);
-              for (int e = 0; e < nl; e++) acc = acc && (s_ex[wave][a * 16 + e] != aj);
-              for (int e = 16; e < exn[a]; e++) acc = acc && (S.ex_list[exb[a] + e] != aj);
+              for (int e = 0; e < nl; e++) keep = keep && (s_ex[wave][a * 16 + e] != aj);
+              for (int e = 16; e < exn[a]; e++) keep = keep && (S.ex_list[exb[a] + e] != aj);
+              if (!keep) mask &= ~(1 << a);   // rmin may stay too small: only the segment choice sees it, and a nearer segment is always allowed
             }
-            if (acc) {
-              mask |= 1 << a;
-              rmin = fmin(rmin, r2);
-            }
-          }
+        }
       }
       const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB && rmin < rc2;
       const bool isD = mask && !isA && !isB && !isC;
@@ -384,6 +401,9 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     nmax = max(nmax, n);
     nrowent += n;
   }
+#ifdef PAIR_TIMING
+  const unsigned long long tb2 = __builtin_readcyclecounter();
+#endif
   // Schedule of k_pair, fixed here: longest-processing-time-first list scheduling of the tile's rows over the TW
   // waves.  tile_order holds the tile's clusters grouped by wave (longest row first), tile_wstart the TW+1 group
   // boundaries.  Rows were written by other waves -> barrier + own-workgroup visibility first.
@@ -443,6 +463,12 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
       }
     }
   }
+#ifdef PAIR_TIMING
+  if (lane == 0) {
+    const unsigned long long tb3 = __builtin_readcyclecounter();
+    atomicAdd(&sc.dbg[5], tb1 - tb0); atomicAdd(&sc.dbg[6], tb2 - tb1); atomicAdd(&sc.dbg[7], tb3 - tb2);
+  }
+#endif
   const double cnt = wave_sum((double)npairs);
   if (lane == 0) {
     if (over) atomicOr(&sc.overflow, 1 | 8);   // 8: a cluster row (or its segment-B list)
