@@ -182,28 +182,50 @@ int upload(scema_md_engine *e, DevBuf &b, const std::vector<T> &v) {
 // -------------------------------------------------------------------------------------------
 int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   const int n = s->natoms;
-  if (n <= 0 || s->ntypes <= 0 || s->ntypes > MD_MAXTYPES) return fail(e, SCEMA_MD_ERR_ARG, "natoms/ntypes out of range");
+  if (n <= 0 || s->ntypes <= 0) return fail(e, SCEMA_MD_ERR_ARG, "natoms/ntypes out of range");
   if (n > MD_JMASK) return fail(e, SCEMA_MD_ERR_ARG, "too many atoms for the 27-bit neighbour index");
   t.natoms = n;
-  t.ntypes = s->ntypes;
-  t.type.assign(s->type, s->type + n);
+  // Lennard-Jones classes: atom types with identical eps/sigma rows are one class on the device (force-field
+  // generators hand out an atom type per atom name; OPLS-AA has a dozen distinct Lennard-Jones sites).  Masses stay
+  // per atom, charges are per atom anyway; the kernels index pair tables of ncls x ncls entries.
+  const int nty = s->ntypes;
+  std::vector<int> cls(nty, -1), rep;
+  for (int u = 0; u < nty; u++) {
+    for (size_t c = 0; c < rep.size() && cls[u] < 0; c++) {
+      const int v = rep[c];
+      bool same = true;
+      for (int w = 0; w < nty && same; w++)
+        same = s->eps[(size_t)u * nty + w] == s->eps[(size_t)v * nty + w] && s->sigma[(size_t)u * nty + w] == s->sigma[(size_t)v * nty + w] &&
+               s->eps[(size_t)w * nty + u] == s->eps[(size_t)w * nty + v] && s->sigma[(size_t)w * nty + u] == s->sigma[(size_t)w * nty + v];
+      if (same) cls[u] = (int)c;
+    }
+    if (cls[u] < 0) { cls[u] = (int)rep.size(); rep.push_back(u); }
+  }
+  const int ncls = (int)rep.size();
+  if (ncls > MD_MAXTYPES) return fail(e, SCEMA_MD_ERR_ARG, "%d distinct Lennard-Jones types (of %d atom types): at most %d are supported", ncls, nty, MD_MAXTYPES);
+  t.ntypes = ncls;
+  t.type.resize(n);
   t.q.assign(s->charge, s->charge + n);
   t.mass_atom.resize(n);
   for (int i = 0; i < n; i++) {
-    if (t.type[i] < 0 || t.type[i] >= s->ntypes) return fail(e, SCEMA_MD_ERR_ARG, "atom type out of range");
-    t.mass_atom[i] = s->mass[t.type[i]];
+    if (s->type[i] < 0 || s->type[i] >= nty) return fail(e, SCEMA_MD_ERR_ARG, "atom type out of range");
+    t.type[i] = cls[s->type[i]];
+    t.mass_atom[i] = s->mass[s->type[i]];
     t.qsqsum += t.q[i] * t.q[i];
     t.qsum += t.q[i];
   }
-  const int nt2 = s->ntypes * s->ntypes;
+  const int nt2 = ncls * ncls;
   t.lj.resize(4 * nt2);
-  for (int k = 0; k < nt2; k++) {
-    const double s6 = std::pow(s->sigma[k], 6.0), s12 = s6 * s6;
-    t.lj[k] = 48.0 * s->eps[k] * s12;
-    t.lj[nt2 + k] = 24.0 * s->eps[k] * s6;
-    t.lj[2 * nt2 + k] = 4.0 * s->eps[k] * s12;
-    t.lj[3 * nt2 + k] = 4.0 * s->eps[k] * s6;
-  }
+  for (int a = 0; a < ncls; a++)
+    for (int b = 0; b < ncls; b++) {
+      const size_t src = (size_t)rep[a] * nty + rep[b];
+      const int k = a * ncls + b;
+      const double s6 = std::pow(s->sigma[src], 6.0), s12 = s6 * s6;
+      t.lj[k] = 48.0 * s->eps[src] * s12;
+      t.lj[nt2 + k] = 24.0 * s->eps[src] * s6;
+      t.lj[2 * nt2 + k] = 4.0 * s->eps[src] * s12;
+      t.lj[3 * nt2 + k] = 4.0 * s->eps[src] * s6;
+    }
   // ---- bond graph -> 1-2 / 1-3 / 1-4 partners (lowest level wins) ----
   std::vector<std::vector<int>> adj(n);
   double max_r0 = 0.0;
@@ -424,7 +446,7 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
         else if (kind == BT_IMPROPER) { l_cf[kind].push_back(imp_cf[2 * m]); l_cf[kind].push_back(imp_cf[2 * m + 1]); }
         else {
           // special pair: everything the term needs, so the kernel looks up neither types nor charges
-          const int a0 = at[0], a1 = at[1], tt = t.type[a0] * s->ntypes + t.type[a1];
+          const int a0 = at[0], a1 = at[1], tt = t.type[a0] * ncls + t.type[a1];
           const double wl = sp_cf[2 * m], wc = sp_cf[2 * m + 1];
           l_cf[kind].push_back(wl * t.lj[tt]); l_cf[kind].push_back(wl * t.lj[nt2 + tt]);
           l_cf[kind].push_back(MD_QQRD2E * t.q[a0] * t.q[a1]); l_cf[kind].push_back(wc);

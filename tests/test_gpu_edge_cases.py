@@ -169,3 +169,50 @@ def test_error_paths(small_pe):
     with pytest.raises(capi.EngineError, match="reax"):           # config 5 is a 'next' row: explicit, not silent
         eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10, most_recent=capi.QP_NONE, force_field="reax")])
     eng.close()
+
+
+def _alias_types(d, copies):
+    """The same system with every atom type split into `copies` aliases (identical Lennard-Jones rows and masses), the
+    way force-field generators hand out one atom type per atom name."""
+    nt = int(d["ntypes"])
+    rng = np.random.default_rng(5)
+    out = dict(d)
+    out["ntypes"] = nt * copies
+    out["type"] = np.asarray(d["type"]) * copies + rng.integers(0, copies, size=len(d["type"]))
+    out["mass"] = np.repeat(np.asarray(d["mass"], float), copies)
+    out["eps"] = np.repeat(np.repeat(np.asarray(d["eps"], float).reshape(nt, nt), copies, 0), copies, 1).ravel()
+    out["sigma"] = np.repeat(np.repeat(np.asarray(d["sigma"], float).reshape(nt, nt), copies, 0), copies, 1).ravel()
+    return out
+
+
+def test_many_atom_types_few_lennard_jones_classes(small_pe):
+    """24 atom types that are aliases of 2 Lennard-Jones sites: the engine works on LJ classes, so the type count of the
+    data file is not limited to the 16 classes the pair tables hold; 17 genuinely different sites are refused."""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    many = _alias_types(small_pe, 12)
+    assert many["ntypes"] == 24
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    eng.register_replica("pe24", 1, many)
+    f0, e0, w0, _ = eng.debug_compute("pe", 1)
+    f1, e1, w1, _ = eng.debug_compute("pe24", 1)
+    assert np.array_equal(f0, f1) or relerr(f1, f0) < 1e-13
+    o = po.Oracle(many, po.default_params(**KW))
+    o.setup(use_shake=False)
+    assert relerr(f1, o.compute()[0]) < 1e-11      # the oracle works on the 24 types as given
+    lens = _lens(small_pe)
+    st = np.array([-3e-4, -3e-4, 1.0e-3, 0, 0, 0]) * np.array([*lens, lens[2], lens[1], lens[0]])
+    out = eng.strain_batch([capi.make_sim(0, "pe24", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    exp, _ = o.eval(st, 2.0, 300.0, 1e-4, 10)
+    assert relerr(out[0].stress[:], exp) < 1e-6
+    # 17 distinct sites
+    bad = _alias_types(small_pe, 9)     # 18 types ...
+    sg = np.asarray(bad["sigma"], float).reshape(18, 18).copy()
+    for k in range(18):                 # ... each with its own sigma
+        sg[k, :] *= 1.0 + 1e-3 * k
+        sg[:, k] *= 1.0 + 1e-3 * k
+    bad["sigma"] = sg.ravel()
+    with pytest.raises(capi.EngineError, match="Lennard-Jones"):
+        eng.register_replica("bad", 1, bad)
+    eng.close()
