@@ -216,3 +216,16 @@ def test_many_atom_types_few_lennard_jones_classes(small_pe):
     with pytest.raises(capi.EngineError, match="Lennard-Jones"):
         eng.register_replica("bad", 1, bad)
     eng.close()
+
+
+def test_lammps_lj_benchmark_step0_known_answer_on_the_gpu():
+    """The step-0 thermo line of LAMMPS' own Lennard-Jones benchmark logs (E_pair, TotEng, Press), from k_pair."""
+    from scema_amd import capi
+    from test_oracle_physics import lj_bench_system, lj_bench_check
+    d, rho = lj_bench_system(6)          # 864 atoms; per-atom values do not depend on the size
+    eng = capi.Engine(capi.default_params(cut_lj=2.5, cut_coul=2.5, skin=0.3, shake_mass=0.0))
+    eng.register_replica("lj", 1, d)
+    f, e, w, info = eng.debug_compute("lj", 1)
+    assert np.abs(f).max() < 1e-9
+    lj_bench_check(e[0], w[0], d["natoms"], rho)
+    eng.close()

@@ -275,3 +275,50 @@ def test_improper_harmonic_closed_form_and_consistency():
         # virial of an isolated term = sum_i r_i (x) f_i
         wref = np.array([(x[:, a] * f[:, b]).sum() for a, b in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))])
         assert np.abs(w[5] - wref).max() < 1e-9 * max(1.0, np.abs(wref).max())
+
+
+def lj_bench_system(nc=5):
+    """The initial state of LAMMPS' own Lennard-Jones benchmark (bench/in.lj: fcc lattice at reduced density 0.8442,
+    pair lj/cut 2.5, no shift, no tail correction) in units where eps = sigma = 1."""
+    rho = 0.8442
+    a = (4.0 / rho) ** (1.0 / 3.0)
+    basis = [(0, 0, 0), (.5, .5, 0), (.5, 0, .5), (0, .5, .5)]
+    x = np.array([[(i + b[0]) * a, (j + b[1]) * a, (k + b[2]) * a] for i in range(nc) for j in range(nc)
+                  for k in range(nc) for b in basis])
+    n = len(x); L = nc * a
+    d = dict(natoms=n, ntypes=1, type=np.zeros(n, np.int32), charge=np.zeros(n), mass=np.array([1.0]),
+             eps=np.array([[1.0]]), sigma=np.array([[1.0]]),
+             bonds=np.zeros((0, 2), np.int32), bond_type=np.zeros(0, np.int32), bond_coeff=np.zeros((0, 2)),
+             angles=np.zeros((0, 3), np.int32), angle_type=np.zeros(0, np.int32), angle_coeff=np.zeros((0, 2)),
+             dihedrals=np.zeros((0, 4), np.int32), dihedral_type=np.zeros(0, np.int32), dihedral_coeff=np.zeros((0, 4)),
+             impropers=np.zeros((0, 4), np.int32), improper_type=np.zeros(0, np.int32), improper_coeff=np.zeros((0, 2)),
+             special_lj=np.ones(3), special_coul=np.ones(3),
+             box=np.array([0, 0, 0, L, L, L, 0, 0, 0.0]), x=x, v=np.zeros_like(x))
+    return d, rho
+
+
+# thermo line of step 0 in the logs LAMMPS ships for that benchmark (bench/log.*.lj.*, identical in every release of
+# that era, 32 000 atoms, T = 1.44):   Step Temp E_pair E_mol TotEng Press  =  0 1.44 -6.7733681 0 -4.6134356 -5.0196707
+LAMMPS_LJ_BENCH_EPAIR, LAMMPS_LJ_BENCH_TOTENG, LAMMPS_LJ_BENCH_PRESS = -6.7733681, -4.6134356, -5.0196707
+
+
+def lj_bench_check(e_lj, w_lj, n, rho):
+    """E_pair and pressure per the quantities LAMMPS prints (thermo_style one, lj units)."""
+    vol = n / rho
+    epair = e_lj / n
+    assert abs(epair - LAMMPS_LJ_BENCH_EPAIR) < 6e-8                       # all printed digits
+    # TotEng = E_pair + KE with KE = 3/2 T (N-1)/N at N = 32 000
+    assert abs(epair + 1.5 * 1.44 * (1 - 1 / 32000) - LAMMPS_LJ_BENCH_TOTENG) < 6e-8
+    p = rho * 1.44 + (w_lj[0] + w_lj[1] + w_lj[2]) / (3.0 * vol)
+    assert abs(p - LAMMPS_LJ_BENCH_PRESS) < 5e-5                           # kinetic part: dof convention of the log, 1/N
+
+
+def test_lammps_lj_benchmark_step0_known_answer():
+    """A number LAMMPS itself publishes: the oracle's pair energy and virial pressure of the Lennard-Jones benchmark's
+    initial lattice agree with the step-0 thermo line of LAMMPS' bench logs (size-independent per atom)."""
+    d, rho = lj_bench_system(5)
+    o = po.Oracle(d, po.default_params(cut_lj=2.5, cut_coul=2.5, skin=0.3, shake_mass=0.0))
+    o.setup(use_shake=False)
+    f, e, w = o.compute()
+    assert np.abs(f).max() < 1e-9          # perfect lattice
+    lj_bench_check(e[0], w[0], d["natoms"], rho)
