@@ -24,8 +24,12 @@ def test_library_exports_every_declared_symbol():
     hdr2 = open(os.path.join(ROOT, "include", "scema_stmd.h")).read()
     declared2 = set(re.findall(r"\b(scema_(?:stmd|eqmd)_[a-z_]+)\s*\(", hdr2))
     assert declared2 == set(stmd.SYMBOLS), declared2 ^ set(stmd.SYMBOLS)
+    from scema_amd import cluster
+    hdr3 = open(os.path.join(ROOT, "include", "scema_cluster.h")).read()
+    declared3 = set(re.findall(r"\b(scema_hist_[a-z_]+)\s*\(", hdr3))
+    assert declared3 == set(cluster.SYMBOLS), declared3 ^ set(cluster.SYMBOLS)
     L = capi.lib()
-    for s in declared | declared2:
+    for s in declared | declared2 | declared3:
         assert hasattr(L, s), s
 
 
