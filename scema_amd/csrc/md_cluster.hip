@@ -1,9 +1,9 @@
 // md_cluster.hip -- all-pairs L2 distances between splined strain histories (include/scema_cluster.h;
 // compare_L2_norm + the pair loops of compare_histories_with_all_ranks, headers/strain2spline.h:469-487, 546-614).
 //
-// n histories of d = 6 * spline points doubles.  One workgroup of 256 threads owns a 32 x 32 tile of pairs of the upper
-// triangle; the two 32-row panels are staged through the LDS in chunks of 32 columns (16 KB), every thread carries
-// 2 x 2 pairs, and the sum over the d columns runs in ascending order with separate multiply and add (no contraction),
+// n histories of d = 6 * spline points doubles.  One workgroup of 256 threads owns a 64 x 64 tile of pairs of the upper
+// triangle; the two 64-row panels are staged through the LDS in chunks of 32 columns (33 KB), every thread carries
+// 4 x 4 pairs (8 LDS reads per 16 pair elements), and the sum over the d columns runs in ascending order with separate multiply and add (no contraction),
 // which is the reference's arithmetic: results are bit-identical to the CPU loop.  The kernel reads n*d*8 bytes and writes
 // n*n*8: for the sizes of the path (n = 576 ... 4 864, d = 60 ... 600) it is bound by the n^2 result write.
 #include <hip/hip_runtime.h>
@@ -13,7 +13,8 @@
 #include "../../include/scema_cluster.h"
 #include "../../include/scema_md.h"
 
-#define CT 32      // pair tile edge
+#define CT 64      // pair tile edge
+#define CR (CT / 16) // pairs per thread and direction
 #define CK 32      // columns staged per step
 
 // EMIT = false: the full symmetric matrix.  EMIT = true: only the pairs a < b below the threshold, appended to a list
@@ -27,10 +28,17 @@ __global__ __launch_bounds__(256) void k_hist_compare(const double *__restrict__
   while ((long long)(tj + 1) * (tj + 2) / 2 <= (long long)blockIdx.x) tj++;
   while ((long long)tj * (tj + 1) / 2 > (long long)blockIdx.x) tj--;
   const int ti = (int)((long long)blockIdx.x - (long long)tj * (tj + 1) / 2);
-  __shared__ double s_a[CT][CK + 1], s_b[CT][CK + 1];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 2 x 2 pairs each
+  __shared__ double s_raw[2 * CT * (CK + 1)];   // two panels; reused as a CT x (CT+1) transpose buffer for the mirror tile
+  double (*s_a)[CK + 1] = (double (*)[CK + 1])s_raw;
+  double (*s_b)[CK + 1] = (double (*)[CK + 1])(s_raw + CT * (CK + 1));
+  static_assert(2 * CT * (CK + 1) >= CT * (CT + 1), "transpose buffer");
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, CR x CR pairs each
   const int a0 = ti * CT, b0 = tj * CT;
-  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  double acc[CR][CR];
+#pragma unroll
+  for (int u = 0; u < CR; u++)
+#pragma unroll
+    for (int v = 0; v < CR; v++) acc[u][v] = 0.0;
   for (int k0 = 0; k0 < d; k0 += CK) {
     for (int e = threadIdx.x; e < CT * CK; e += 256) {
       const int r = e / CK, c = e % CK;
@@ -40,33 +48,47 @@ __global__ __launch_bounds__(256) void k_hist_compare(const double *__restrict__
     __syncthreads();
     const int kc = min(CK, d - k0);
     for (int c = 0; c < kc; c++) {
+      double ra[CR], rb[CR];
 #pragma unroll
-      for (int u = 0; u < 2; u++)
+      for (int u = 0; u < CR; u++) { ra[u] = s_a[ty + 16 * u][c]; rb[u] = s_b[tx + 16 * u][c]; }
 #pragma unroll
-        for (int v = 0; v < 2; v++) {
-          const double df = s_a[ty + 16 * u][c] - s_b[tx + 16 * v][c];
+      for (int u = 0; u < CR; u++)
+#pragma unroll
+        for (int v = 0; v < CR; v++) {
+          const double df = ra[u] - rb[v];
           const double sq = df * df;
           acc[u][v] = acc[u][v] + sq;
         }
     }
     __syncthreads();
   }
+  double (*s_t)[CT + 1] = (double (*)[CT + 1])s_raw;
 #pragma unroll
-  for (int u = 0; u < 2; u++)
+  for (int u = 0; u < CR; u++)
 #pragma unroll
-    for (int v = 0; v < 2; v++) {
-      const int a = a0 + ty + 16 * u, b = b0 + tx + 16 * v;
-      if (a < n && b < n) {
-        const double r = __dsqrt_rn(acc[u][v]);   // correctly rounded
-        if (!EMIT) {
-          out[(size_t)a * n + b] = r;
-          out[(size_t)b * n + a] = r;
-        } else if (a < b && r < threshold) {
-          const unsigned long long k = atomicAdd(count, 1ull);
-          if (k < cap) { pairs[k] = make_int2(a, b); out[k] = r; }
-        }
+    for (int v = 0; v < CR; v++) {
+      const int la = ty + 16 * u, lb = tx + 16 * v;
+      const int a = a0 + la, b = b0 + lb;
+      const double r = __dsqrt_rn(acc[u][v]);   // correctly rounded
+      if (!EMIT) {
+        if (a < n && b < n) out[(size_t)a * n + b] = r;   // rows of the tile: consecutive b across tx
+        s_t[lb][la] = r;                                  // the mirror tile goes through the LDS so that it is written row-wise too
+      } else if (a < n && b < n && a < b && r < threshold) {
+        const unsigned long long k = atomicAdd(count, 1ull);
+        if (k < cap) { pairs[k] = make_int2(a, b); out[k] = r; }
       }
     }
+  if (!EMIT && ti != tj) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < CR; u++)
+#pragma unroll
+      for (int v = 0; v < CR; v++) {
+        const int lb = ty + 16 * u, la = tx + 16 * v;
+        const int a = a0 + la, b = b0 + lb;
+        if (a < n && b < n) out[(size_t)b * n + a] = s_t[lb][la];
+      }
+  }
 }
 
 extern "C" {
