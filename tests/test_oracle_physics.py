@@ -297,25 +297,31 @@ def lj_bench_system(nc=5):
     return d, rho
 
 
-# thermo line of step 0 in the logs LAMMPS ships for that benchmark (bench/log.*.lj.*, identical in every release of
-# that era, 32 000 atoms, T = 1.44):   Step Temp E_pair E_mol TotEng Press  =  0 1.44 -6.7733681 0 -4.6134356 -5.0196707
-LAMMPS_LJ_BENCH_EPAIR, LAMMPS_LJ_BENCH_TOTENG, LAMMPS_LJ_BENCH_PRESS = -6.7733681, -4.6134356, -5.0196707
+# Step-0 thermo lines (Step Temp E_pair E_mol TotEng Press) of two logs LAMMPS ships for this lattice, identical in every
+# release of that era:
+#   bench/log.*.lj.*    (32 000 atoms, T = 1.44):  0 1.44 -6.7733681 0 -4.6134356 ...
+#   examples/melt/log.* ( 4 000 atoms, T = 3.0 ):  0 3    -6.7733681 0 -2.2744931 -3.7033504
+# TotEng - E_pair = 3/2 T (N-1)/N and Press = rho T (N-1)/N + W/(3V) reproduce both lines to the last printed digit.
+LAMMPS_LJ_EPAIR = -6.7733681
+LAMMPS_LJ_BENCH_TOTENG = -4.6134356
+LAMMPS_LJ_MELT_TOTENG, LAMMPS_LJ_MELT_PRESS = -2.2744931, -3.7033504
 
 
 def lj_bench_check(e_lj, w_lj, n, rho):
-    """E_pair and pressure per the quantities LAMMPS prints (thermo_style one, lj units)."""
+    """E_pair, TotEng and Press the way LAMMPS prints them (thermo_style one, lj units); per-atom lattice sums do not
+    depend on the number of cells, the kinetic parts use the logs' atom counts."""
     vol = n / rho
     epair = e_lj / n
-    assert abs(epair - LAMMPS_LJ_BENCH_EPAIR) < 6e-8                       # all printed digits
-    # TotEng = E_pair + KE with KE = 3/2 T (N-1)/N at N = 32 000
+    assert abs(epair - LAMMPS_LJ_EPAIR) < 6e-8                                                    # all printed digits
     assert abs(epair + 1.5 * 1.44 * (1 - 1 / 32000) - LAMMPS_LJ_BENCH_TOTENG) < 6e-8
-    p = rho * 1.44 + (w_lj[0] + w_lj[1] + w_lj[2]) / (3.0 * vol)
-    assert abs(p - LAMMPS_LJ_BENCH_PRESS) < 5e-5                           # kinetic part: dof convention of the log, 1/N
+    assert abs(epair + 1.5 * 3.0 * (1 - 1 / 4000) - LAMMPS_LJ_MELT_TOTENG) < 6e-8
+    p = rho * 3.0 * (1 - 1 / 4000) + (w_lj[0] + w_lj[1] + w_lj[2]) / (3.0 * vol)
+    assert abs(p - LAMMPS_LJ_MELT_PRESS) < 6e-8                                                   # all printed digits
 
 
 def test_lammps_lj_benchmark_step0_known_answer():
-    """A number LAMMPS itself publishes: the oracle's pair energy and virial pressure of the Lennard-Jones benchmark's
-    initial lattice agree with the step-0 thermo line of LAMMPS' bench logs (size-independent per atom)."""
+    """Numbers LAMMPS itself publishes: the oracle's pair energy and virial pressure of the Lennard-Jones benchmark's
+    initial lattice agree with the step-0 thermo lines of LAMMPS' bench and melt logs to every printed digit."""
     d, rho = lj_bench_system(5)
     o = po.Oracle(d, po.default_params(cut_lj=2.5, cut_coul=2.5, skin=0.3, shake_mass=0.0))
     o.setup(use_shake=False)
