@@ -1508,7 +1508,21 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     for (int k = 0; k < 6; k++) A.rates[k] = round_trip("%.6e", eps[k] / (nts * sims[i].timestep_length));
     act.push_back(A);
   }
-  const int maxb = e->p.max_batch > 0 ? e->p.max_batch : 1024;
+  // max_batch = 0: as many simulations per launch group as the free HBM holds (neighbour rows dominate: about 2 KB per
+  // atom at the default row capacity, plus tables, slot copies and backups), at most 1024, at least the slots that
+  // exist already
+  int maxb = e->p.max_batch;
+  if (maxb <= 0) {
+    size_t free_b = 0, total_b = 0;
+    size_t maxat = 1;
+    for (const ActiveSim &A : act) maxat = std::max(maxat, (size_t)A.st->topo->natoms);
+    maxb = 1024;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const double per_sim = 3300.0 * (double)maxat + 4.0e6;
+      const double fit = 0.85 * (double)free_b / per_sim + (double)e->slots.size();
+      maxb = (int)std::max(1.0, std::min(1024.0, fit));
+    }
+  }
   for (size_t off = 0; off < act.size(); off += maxb) {
     std::vector<ActiveSim> chunk(act.begin() + off, act.begin() + std::min(act.size(), off + (size_t)maxb));
     // rates are consumed per attempt: keep a copy for retries
