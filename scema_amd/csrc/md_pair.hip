@@ -718,10 +718,6 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   const unsigned long long tm3 = __builtin_readcyclecounter();
 #endif
   // flush the tile's accumulators: consecutive table entries are runs of consecutive slots -> coalesced atomics.
-  // Production virial (one lumped pair virial, the pressure sums all parts anyway): the tile's pairs contribute
-  // sum_pairs (r_i - r_j) (x) F_ij = sum over table entries of r_l (x) (force accumulated on entry l), with the
-  // image position r_l; the accumulated forces of a tile sum to zero, so positions are taken relative to the
-  // tile's first slot.  This costs 6 FMAs per table entry instead of 6 per pair.
   // Production virial (one lumped pair virial; the pressure sums all parts anyway): the tile's pairs contribute
   // sum_pairs (r_i - r_j) (x) F_ij = sum over table entries l of (x_slot(l) + shift_l) (x) F_l, F_l = force
   // accumulated on entry l.  Summed over all tiles the first part is sum_slots x_slot (x) fs_slot, which
