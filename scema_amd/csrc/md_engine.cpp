@@ -912,7 +912,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       S.seg_a2 = (P.cut_coul + m) * (P.cut_coul + m);
       S.seg_b2 = (P.cut_lj + m) * (P.cut_lj + m);
       // skin pairs listed beyond cutmax + far_band sit at the back of the rows and are skipped until an atom has moved far_band/2
-      double frac = 0.5;
+      double frac = 0.65;   // scan 0.25 .. 0.85 on PE-10k (rebuild every ~33 steps, the largest displacement passes 0.5 A after ~8): optimum 0.65-0.75
       if (const char *fv = getenv("SCEMA_MD_FAR_FRAC")) frac = atof(fv);
       S.far_band = frac * P.skin;
       const double cm = std::max(P.cut_coul, P.cut_lj) + S.far_band;
@@ -1120,6 +1120,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     fprintf(stderr, "[scema_md] sim 0: cells %dx%dx%d, j table max %d of %d, row max %d of %d, row entries/cluster %.1f, listed pairs/atom %.1f, builds %d\n",
             S0.nc[0], S0.nc[1], S0.nc[2], c.maxj_seen, S0.capj, c.maxneigh_seen, S0.maxneigh, (double)c.nrowent / (S0.npad / MD_CLUSTER),
             (double)c.nentries / S0.natoms, c.nbuilds);
+    fprintf(stderr, "[scema_md] sim 0: far skin band walked on %d of %d steps\n", c.nfar_steps, c.step);
 #ifdef PAIR_TIMING
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
             (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);

@@ -100,6 +100,7 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.deltasq = 0.0;
     sc.far_dsq = 1.0e300;
     sc.need_far = 0;
+    sc.nfar_steps = 0;
 #ifdef PAIR_TIMING
     for (int k = 0; k < 8; k++) sc.dbg[k] = 0;
 #endif
@@ -835,6 +836,7 @@ __global__ void k_post(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.x];
   SimScalars &sc = *S.sc;
   if (threadIdx.x != 0) return;
+  sc.nfar_steps += sc.need_far;
   sc.t_current = (sc.ke[0] + sc.ke[1] + sc.ke[2]) / (S.tdof * MD_BOLTZ);
   double f2 = 1.0;
   if (S.nvt) f2 = nhc_half(S, sc);

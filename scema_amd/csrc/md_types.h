@@ -57,6 +57,7 @@ struct SimScalars {
   int rebuild;
   int overflow;
   int maxneigh_seen;
+  int nfar_steps;      // steps of this phase on which the far skin band was walked (SCEMA_MD_TIMING)
   int need_far;        // this step some atom moved >= sqrt(far_dsq): k_pair walks segment C2 too
   int maxj_seen;       // largest tile j table at the last builds
   int nbuilds;
