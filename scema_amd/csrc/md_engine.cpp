@@ -1138,6 +1138,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     e->prof.unique_pairs_sum += 0.5 * (double)e->h_sc[i].nentries;
     e->prof.unique_pairs_n += 1;
   }
+  if (fault & 16) return fail(e, SCEMA_MD_ERR_ARG, "a simulation became unstable (non-finite or runaway atom positions): overlapping atoms or parameters far from the replica's equilibrium");
   if (fault & 2) return fail(e, SCEMA_MD_ERR_ARG, "an excluded (special) pair stretched beyond the exclusion gate; topology or state is broken");
   e->overflow_bits = fault;
   if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
@@ -1532,6 +1533,12 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     for (auto &A : chunk) {
       scema_mdsim &m = sims[A.user_index];
       for (int k = 0; k < 6; k++) m.stress[k] = A.pavg[k] * (-1.0) * 1.01325e+05;  // stmd_problem.h:340
+      // a replica that blew up (overlapping atoms, a time step far too long) must not hand NaN to the FE solver:
+      // LAMMPS would stop with "lost atoms" / "bond atoms missing" at this point
+      for (int k = 0; k < 6; k++)
+        if (!std::isfinite(m.stress[k]))
+          return fail(e, SCEMA_MD_ERR_ARG, "simulation of quadrature point %d (material %s, replica %d) produced a non-finite stress: unstable state or parameters",
+                      m.qp_id, m.matid ? m.matid : "?", m.replica);
       m.stress_updated = 1;
     }
   }

@@ -175,13 +175,27 @@ __global__ __launch_bounds__(TPB) void k_initial_integrate(const SimDev *sims) {
   const double vs = sc.vscale;
   const double dtfm = 0.5 * S.dt * MD_FTM2V / S.mass[i];
   double dsq = 0.0;
+  double vn[3], xn[3];
+  bool sane = true;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    double v = S.v[3 * i + k] * vs + dtfm * S.f[3 * i + k];
-    double x = S.x[3 * i + k] + S.dt * v;
-    S.v[3 * i + k] = v;
-    S.x[3 * i + k] = x;
-    double d = x - S.xhold[3 * i + k];
+    vn[k] = S.v[3 * i + k] * vs + dtfm * S.f[3 * i + k];
+    xn[k] = S.x[3 * i + k] + S.dt * vn[k];
+    sane = sane && fabs(xn[k]) < 1.0e8;   // false for NaN and for atoms flung out of any box
+  }
+  if (!sane) {
+    // A replica that blew up (overlapping atoms, absurd time step).  Positions index memory (cells, tables), so a
+    // non-finite one must never be stored: the atom is frozen where it was, the replica is flagged (bit 16) and the
+    // host reports it instead of a stress.
+    atomicOr(&sc.overflow, 16);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { vn[k] = 0.0; xn[k] = S.x[3 * i + k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    S.v[3 * i + k] = vn[k];
+    S.x[3 * i + k] = xn[k];
+    double d = xn[k] - S.xhold[3 * i + k];
     dsq += d * d;
   }
   if (sc.check && dsq > sc.deltasq) sc.rebuild = 1;
@@ -221,6 +235,7 @@ __global__ __launch_bounds__(TPB) void k_bin(const SimDev *sims) {
     if (w >= 1.0) w = 0.0;
     int cc = (int)(w * S.nc[d]);
     if (cc >= S.nc[d]) cc = S.nc[d] - 1;
+    if (cc < 0) cc = 0;
     c[d] = cc;
     // position inside the cell on a grid of ~1.1 A sub-cells (isotropic in Angstrom whatever the shape of the
     // cell, at most 16 per edge) -> Morton key: consecutive slots of a cell are spatial neighbours, which keeps the

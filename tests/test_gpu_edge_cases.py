@@ -229,3 +229,25 @@ def test_lammps_lj_benchmark_step0_known_answer_on_the_gpu():
     assert np.abs(f).max() < 1e-9
     lj_bench_check(e[0], w[0], d["natoms"], rho)
     eng.close()
+
+
+def test_unstable_replica_is_reported_not_returned(small_pe):
+    """Two atoms on top of each other: forces are non-finite from the first step.  The engine never stores a non-finite
+    position (positions index cells and tables), flags the replica and returns an error instead of a NaN stress --
+    where LAMMPS would stop with lost atoms."""
+    from scema_amd import capi
+    bad = dict(small_pe)
+    x = np.array(small_pe["x"], float).copy()
+    x[200] = x[17]                      # different chains: not an excluded pair
+    bad["x"] = x
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("bad", 1, bad)
+    eng.register_replica("pe", 1, small_pe)
+    lens = _lens(small_pe)
+    st = np.array([-3e-4, -3e-4, 1.0e-3, 0, 0, 0]) * np.array([*lens, lens[2], lens[1], lens[0]])
+    with pytest.raises(capi.EngineError, match="unstable"):
+        eng.strain_batch([capi.make_sim(0, "bad", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    # the engine is still usable, and a healthy replica next to a broken one is not what gets blamed
+    out = eng.strain_batch([capi.make_sim(1, "pe", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    assert np.all(np.isfinite(out[0].stress[:])) and out[0].stress_updated == 1
+    eng.close()
