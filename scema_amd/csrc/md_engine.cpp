@@ -1499,7 +1499,15 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     eps[4] = sl[4] / lb[1];  // [2][0] /= lbdim[1]
     // stmd_problem.h:229-232
     const double nrm = std::sqrt(eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2] + 2.0 * (eps[3] * eps[3] + eps[4] * eps[4] + eps[5] * eps[5]));
+    // requests that cannot be run: LAMMPS would stop while parsing "variable ceeps_.. equal nan" or "timestep 0"
+    if (!std::isfinite(nrm)) return fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: non-finite strain", sims[i].qp_id);
+    if (!(sims[i].strain_rate > 0.0) || !std::isfinite(sims[i].strain_rate) || !(sims[i].timestep_length > 0.0) ||
+        !std::isfinite(sims[i].timestep_length) || !(sims[i].temperature > 0.0) || !std::isfinite(sims[i].temperature))
+      return fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: strain rate, time step and temperature must be positive and finite", sims[i].qp_id);
     const double strain_time = nrm / sims[i].strain_rate;
+    if (strain_time / sims[i].timestep_length > 1.0e7)
+      return fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: %.3g straining steps requested (strain norm %.3g at rate %.3g per fs)",
+                  sims[i].qp_id, strain_time / sims[i].timestep_length, nrm, sims[i].strain_rate);
     int nts = (int)(std::ceil((strain_time / sims[i].timestep_length) / 10.0) * 10);
     nts = std::max(nts, 10);
     A.nts = nts;

@@ -166,6 +166,12 @@ def test_error_paths(small_pe):
                                         most_recent=capi.QP_NONE, strain_rate=1e-2)])
     with pytest.raises(capi.EngineError, match="not registered"):
         eng.strain_batch([capi.make_sim(0, "nomat", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    with pytest.raises(capi.EngineError, match="non-finite strain"):
+        eng.strain_batch([capi.make_sim(0, "pe", 1, np.array([np.nan, 0, 0, 0, 0, 0]), nss=10, most_recent=capi.QP_NONE)])
+    with pytest.raises(capi.EngineError, match="positive and finite"):
+        eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10, most_recent=capi.QP_NONE, strain_rate=0.0)])
+    with pytest.raises(capi.EngineError, match="straining steps requested"):
+        eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10, most_recent=capi.QP_NONE, strain_rate=1e-14)])
     with pytest.raises(capi.EngineError, match="reax"):           # config 5 is a 'next' row: explicit, not silent
         eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10, most_recent=capi.QP_NONE, force_field="reax")])
     eng.close()
