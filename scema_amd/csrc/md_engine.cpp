@@ -1183,6 +1183,15 @@ Topo *find_topo(scema_md_engine *e, const char *matid, int replica) {
 
 int make_state(scema_md_engine *e, Topo *t, const double *box, const double *x, const double *v, bool from_device,
                std::unique_ptr<State> &out) {
+  // host-provided states are checked: positions index cells and tables on the device, so nothing non-finite goes up
+  if (!from_device) {
+    for (int k = 0; k < 9; k++)
+      if (!std::isfinite(box[k])) return fail(e, SCEMA_MD_ERR_ARG, "non-finite box");
+    if (!(box[3] > box[0]) || !(box[4] > box[1]) || !(box[5] > box[2])) return fail(e, SCEMA_MD_ERR_ARG, "box with non-positive extent");
+    for (size_t k = 0; k < 3 * (size_t)t->natoms; k++)
+      if (!std::isfinite(x[k]) || !std::isfinite(v[k]) || std::fabs(x[k]) >= 1.0e8)
+        return fail(e, SCEMA_MD_ERR_ARG, "non-finite (or runaway) position or velocity of atom %zu", k / 3);
+  }
   out.reset(new State());
   out->topo = t;
   std::memcpy(out->box, box, 9 * sizeof(double));

@@ -166,6 +166,9 @@ def test_error_paths(small_pe):
                                         most_recent=capi.QP_NONE, strain_rate=1e-2)])
     with pytest.raises(capi.EngineError, match="not registered"):
         eng.strain_batch([capi.make_sim(0, "nomat", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    xb = np.array(small_pe["x"], float).copy(); xb[3, 1] = np.inf
+    with pytest.raises(capi.EngineError, match="non-finite"):       # a broken state never reaches the device
+        eng.set_state(77, "pe", 1, small_pe["box"], xb, small_pe["v"])
     with pytest.raises(capi.EngineError, match="non-finite strain"):
         eng.strain_batch([capi.make_sim(0, "pe", 1, np.array([np.nan, 0, 0, 0, 0, 0]), nss=10, most_recent=capi.QP_NONE)])
     with pytest.raises(capi.EngineError, match="positive and finite"):
