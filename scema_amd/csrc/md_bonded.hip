@@ -263,7 +263,8 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int parts) {
   const dim3 g((unsigned)maxtiles, (unsigned)ns, 1);
   const size_t lds = (size_t)6 * maxloc * sizeof(double);
-  static size_t optin = 0;
+  static size_t optin_tab[16] = {0};
+  size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 48 * 1024 && lds > optin) {
     (void)hipFuncSetAttribute((const void *)k_bonded<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)k_bonded<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -72,3 +72,12 @@ __device__ __forceinline__ void block_atomic_add(double (&vals)[NV], double *dst
     if (s != 0.0) atomicAdd(&dst[threadIdx.x], s);
   }
 }
+
+// Opt-in bookkeeping for kernels that ask for more dynamic LDS than the default limit: the attribute belongs to a
+// (kernel, device) pair, so the largest size already granted is remembered per device (engines of several GPUs may live
+// in one process).
+static inline size_t &lds_optin_slot(size_t (&table)[16]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return table[(dev >= 0 && dev < 16) ? dev : 0];
+}

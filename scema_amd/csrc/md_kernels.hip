@@ -938,7 +938,8 @@ void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax
   if (maxk <= 0) return;
   const size_t lds_s = (size_t)EW_ATOMS * 3 * mmax * sizeof(double2);
   // more than 64 KB of dynamic LDS needs an explicit opt-in (large k ranges: small cut_coul or tight accuracy)
-  static size_t optin_s = 0;
+  static size_t optin_tab[16] = {0};
+  size_t &optin_s = lds_optin_slot(optin_tab);
   if (lds_s > 64 * 1024 && lds_s > optin_s) { (void)hipFuncSetAttribute((const void *)k_ewald_sfac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); optin_s = lds_s; }
   // threads own groups of k-vectors: the block size that wastes the fewest lanes
   const int gthreads = maxgrp <= 64 ? 64 : (maxgrp <= 128 ? 128 : 256);

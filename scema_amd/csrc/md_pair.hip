@@ -786,7 +786,8 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
   // per-wave LDS list of segment B: well over its expected share (~40 %) of a full row
   const int capB = mdk_neigh_capB(maxrow);
   const size_t lds = mdk_neigh_lds_bytes(capj, maxrow);
-  static size_t optin = 0;  // more than 64 KB of dynamic LDS needs an explicit opt-in
+  static size_t optin_tab[16] = {0};  // more than 64 KB of dynamic LDS needs an explicit opt-in
+  size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_neigh_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
   hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB);
 }
@@ -794,7 +795,8 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
 template <bool VIR, bool ENG, int NP>
 static void launch_pair_v(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj) {
   const size_t lds = mdk_pair_lds_bytes(capj);
-  static size_t optin = 0;
+  static size_t optin_tab[16] = {0};
+  size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 48 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pair<VIR, ENG, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
   hipLaunchKernelGGL((k_pair<VIR, ENG, NP>), grid_xcd(ntiles, ns), dim3(TT), lds, st, d, ntiles, ns, capj);
 }
