@@ -97,6 +97,11 @@ struct State {
   Topo *topo = nullptr;
   double box[9];
   DevBuf x, v;
+  // Performance only (results do not depend on the skin): extra list skin for this state, chosen from how often its last
+  // sampling run had to rebuild the list.  A freshly built crystal rebuilds every ~30 steps and is fastest with the
+  // reference's 2.0 A; once thermalised it rebuilds every ~14 steps and 0.5 A more (one rebuild in ~22 steps, the far
+  // band of the rows mostly skipped) is 6 % faster.
+  double skin_extra = 0.0;
 };
 
 struct Slot {
@@ -130,6 +135,7 @@ struct Profile {
 struct scema_md_engine {
   scema_md_params p;
   hipStream_t stream = nullptr;
+  double skin_extra_fixed = -1.0;         // SCEMA_MD_SKIN_EXTRA: fixed extra list skin (0 = never adapt); < 0 = adaptive
   hipStream_t stream2 = nullptr;          // side stream: structure factors next to the bonded kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::map<std::string, std::unique_ptr<Topo>> topos;
@@ -783,7 +789,7 @@ static hipError_t force_stage(scema_md_engine *e, const SimDev *D, int ns, int m
 int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &spec) {
   const int ns = (int)sims.size();
   const scema_md_params &P = e->p;
-  const double rlist = std::max(P.cut_lj, P.cut_coul) + P.skin;
+  const double cutmax_all = std::max(P.cut_lj, P.cut_coul);
   // order: longest run first, so the active simulations are always a prefix
   std::vector<int> order(ns);
   for (int i = 0; i < ns; i++) order[i] = i;
@@ -814,6 +820,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     perp_widths(b1, w1);
     SimDev S;
     std::memset(&S, 0, sizeof S);
+    // list skin of this simulation = the reference's neighbour skin + the state's performance extra (dropped where the
+    // box is too small for it)
+    if (e->skin_extra_fixed >= 0.0) A.st->skin_extra = e->skin_extra_fixed;
+    for (int d = 0; d < 3; d++)
+      if (std::min(w0[d], w1[d]) < 2.0 * (cutmax_all + P.skin + A.st->skin_extra)) A.st->skin_extra = 0.0;
+    const double skin_i = P.skin + A.st->skin_extra;
+    const double rlist = cutmax_all + skin_i;
     for (int d = 0; d < 3; d++)
       if (std::min(w0[d], w1[d]) < 2.0 * rlist)
         return fail(e, SCEMA_MD_ERR_BOX, "box width %.3f < 2*(cutoff+skin) = %.3f in dim %d", std::min(w0[d], w1[d]), 2 * rlist, d);
@@ -914,7 +927,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       // skin pairs listed beyond cutmax + far_band sit at the back of the rows and are skipped until an atom has moved far_band/2
       double frac = 0.65;   // scan 0.25 .. 0.85 on PE-10k (rebuild every ~33 steps, the largest displacement passes 0.5 A after ~8): optimum 0.65-0.75
       if (const char *fv = getenv("SCEMA_MD_FAR_FRAC")) frac = atof(fv);
-      S.far_band = frac * P.skin;
+      S.far_band = frac * skin_i;
       const double cm = std::max(P.cut_coul, P.cut_lj) + S.far_band;
       S.seg_c2 = cm * cm;
     }
@@ -950,7 +963,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.tdof = 3.0 * T.natoms - 3.0 - (S.use_shake ? T.ncons : 0);
     S.qsqsum = T.qsqsum; S.qsum = T.qsum;
     S.cut_lj2 = P.cut_lj * P.cut_lj; S.cut_coul2 = P.cut_coul * P.cut_coul; S.rlist2 = rlist * rlist;
-    S.skin = P.skin;
+    S.skin = skin_i;
+    S.rlist_ref2 = (cutmax_all + P.skin) * (cutmax_all + P.skin);   // the reference's list, for the roofline accounting
     S.excl_cut2 = std::min(T.excl_cut * T.excl_cut, S.rlist2);
     S.shake_tol = P.shake_tol;
     for (int k = 0; k < 6; k++) S.rates[k] = A.rates[k];
@@ -1101,7 +1115,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     std::vector<double> simbytes(ns);
     for (int pos = 0; pos < ns; pos++) {
       const int i = order[pos];
-      simbytes[pos] = 4.0 * (double)e->h_sc[i].nentries + 56.0 * e->h_sims[pos].natoms + 48.0;
+      simbytes[pos] = 4.0 * (double)e->h_sc[i].nentries_ref + 56.0 * e->h_sims[pos].natoms + 48.0;   // the reference's list radius, whatever the skin used
       per_sim_bytes += simbytes[pos];
     }
     (void)per_sim_bytes;
@@ -1120,7 +1134,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     fprintf(stderr, "[scema_md] sim 0: cells %dx%dx%d, j table max %d of %d, row max %d of %d, row entries/cluster %.1f, listed pairs/atom %.1f, builds %d\n",
             S0.nc[0], S0.nc[1], S0.nc[2], c.maxj_seen, S0.capj, c.maxneigh_seen, S0.maxneigh, (double)c.nrowent / (S0.npad / MD_CLUSTER),
             (double)c.nentries / S0.natoms, c.nbuilds);
-    fprintf(stderr, "[scema_md] sim 0: far skin band walked on %d of %d steps\n", c.nfar_steps, c.step);
+    fprintf(stderr, "[scema_md] sim 0: far skin band walked on %d of %d steps; list skin %.2f A\n", c.nfar_steps, c.step, S0.skin);
 #ifdef PAIR_TIMING
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
             (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);
@@ -1135,7 +1149,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   for (int i = 0; i < ns; i++) {
     fault |= e->h_sc[i].overflow;
     e->prof.neigh_builds += e->h_sc[i].nbuilds;
-    e->prof.unique_pairs_sum += 0.5 * (double)e->h_sc[i].nentries;
+    e->prof.unique_pairs_sum += 0.5 * (double)e->h_sc[i].nentries_ref;
     e->prof.unique_pairs_n += 1;
   }
   if (fault & 16) return fail(e, SCEMA_MD_ERR_ARG, "a simulation became unstable (non-finite or runaway atom positions): overlapping atoms or parameters far from the replica's equilibrium");
@@ -1225,9 +1239,10 @@ int resolve_state(scema_md_engine *e, const scema_mdsim &m, State **out) {
   }
   std::unique_ptr<State> ns;
   int rc;
-  if (src)
+  if (src) {
     rc = make_state(e, t, src->box, src->x.as<double>(), src->v.as<double>(), true, ns);
-  else
+    if (rc == SCEMA_MD_OK) ns->skin_extra = src->skin_extra;
+  } else
     rc = make_state(e, t, t->init_box, t->init_x.data(), t->init_v.data(), false, ns);
   if (rc) return rc;
   *out = ns.get();
@@ -1293,6 +1308,13 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
         const SimScalars &sc = e->h_sc[i];
         std::memcpy(chunk[i].st->box, sc.box, 9 * sizeof(double));
         for (int k = 0; k < 6; k++) chunk[i].pavg[k] = sc.psum[k] / (double)std::max(sc.nsamples, 1);
+        // steps per list rebuild of the sampling run -> list skin of this state's next evaluation (with hysteresis)
+        if (e->skin_extra_fixed < 0.0 && chunk[i].nss >= 50) {
+          const double interval = (double)chunk[i].nss / (double)std::max(sc.nbuilds, 1);
+          State &st = *chunk[i].st;
+          if (st.skin_extra == 0.0 && interval < 19.0) st.skin_extra = 0.25 * e->p.skin;
+          else if (st.skin_extra > 0.0 && interval > 40.0) st.skin_extra = 0.0;
+        }
       }
       e->prof.evals += ns;
       return SCEMA_MD_OK;
@@ -1350,6 +1372,7 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     return SCEMA_MD_ERR_DEVICE;
   }
   if (getenv("SCEMA_MD_GRAPH")) e->use_graphs = true;
+  if (const char *sx = getenv("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(0.0, atof(sx));
   if (!getenv("SCEMA_MD_ONE_STREAM")) {
     if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||

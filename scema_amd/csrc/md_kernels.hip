@@ -292,6 +292,7 @@ __global__ __launch_bounds__(TPB) void k_cell_scan(const SimDev *sims) {
     sc.ago = 0;
     sc.nbuilds += 1;
     sc.nentries = 0ull;
+    sc.nentries_ref = 0ull;
     sc.nrowent = 0ull;
   }
 }

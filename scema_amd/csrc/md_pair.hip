@@ -271,7 +271,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
   const int maxrow = S.maxneigh;
   const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2;
   const GLOBAL_AS int *stype = as_global(S.stype);
-  unsigned long long npairs = 0, nrowent = 0;
+  unsigned long long npairs = 0, npairs_ref = 0, nrowent = 0;
   int nmax = 0, over = 0;
   for (int cl = cs / NI + wave; cl < ce / NI; cl += TW) {
     const int s0slot = cl * NI;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
         const double cx = bx - xj, cy = by - yj, cz = bz - zj;
         if (__ballot(in && cx * cx + cy * cy + cz * cz < breach2) == 0ull) continue;   // nothing of this chunk is in reach
       }
-      int mask = 0, near = 0;
+      int mask = 0, near = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
       double rmin = 1.0e300;
 #pragma unroll
       for (int a = 0; a < NI; a++) {
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
         const double r2 = dx * dx + dy * dy + dz * dz;
         const bool acc = in && ci.atom[a] >= 0 && r2 < S.rlist2 && !(own && j <= s0slot + a);
         mask |= acc ? (1 << a) : 0;
+        refm |= (acc && r2 < S.rlist_ref2) ? (1 << a) : 0;
         rmin = acc ? fmin(rmin, r2) : rmin;
         near |= (acc && r2 < S.excl_cut2) ? (1 << a) : 0;
       }
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
               const int nl = min(exn[a], 16);
               for (int e = 0; e < nl; e++) keep = keep && (s_ex[wave][a * 16 + e] != aj);
               for (int e = 16; e < exn[a]; e++) keep = keep && (S.ex_list[exb[a] + e] != aj);
-              if (!keep) mask &= ~(1 << a);   // rmin may stay too small: only the segment choice sees it, and a nearer segment is always allowed
+              if (!keep) { mask &= ~(1 << a); refm &= ~(1 << a); }   // rmin may stay too small: only the segment choice sees it, and a nearer segment is always allowed
             }
         }
       }
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
       }
       nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC); nD += __popcll(mD);
       npairs += __popc(mask);
+      npairs_ref += __popc(refm);
     }
     const int n = nA + nB + nC + nD;
     const bool bad = nB + nC > capB || n > maxrow;
@@ -469,12 +471,13 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     atomicAdd(&sc.dbg[5], tb1 - tb0); atomicAdd(&sc.dbg[6], tb2 - tb1); atomicAdd(&sc.dbg[7], tb3 - tb2);
   }
 #endif
-  const double cnt = wave_sum((double)npairs);
+  const double cnt = wave_sum((double)npairs), cnt_ref = wave_sum((double)npairs_ref);
   if (lane == 0) {
     if (over) atomicOr(&sc.overflow, 1 | 8);   // 8: a cluster row (or its segment-B list)
     atomicMax(&sc.maxneigh_seen, nmax);
     // nentries counts what a full per-atom list would store: every unordered pair from both ends
     atomicAdd(&sc.nentries, 2ull * (unsigned long long)cnt);
+    atomicAdd(&sc.nentries_ref, 2ull * (unsigned long long)cnt_ref);
     atomicAdd(&sc.nrowent, nrowent);
   }
 }

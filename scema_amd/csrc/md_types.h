@@ -49,6 +49,7 @@ struct SimScalars {
   double far_dsq;      // squared atom displacement from which the far skin band (segment C2) can reach the cutoff
   double corners_hold[24];
   unsigned long long nentries;  // (i,j) pairs listed at the last build (= entries of a full per-atom list)
+  unsigned long long nentries_ref;  // the same count inside the reference's list radius (cutoff + params.skin)
   unsigned long long nrowent;   // row entries actually stored (one per (cluster, j))
   int nsamples;
   int step;
@@ -87,6 +88,7 @@ struct SimDev {
   int coul_npoly;
   double coul_uscale;
   double coul_poly[MD_MAXPOLY];
+  double rlist_ref2;      // (cutoff + the reference's skin)^2: pairs inside it are what the roofline accounting prices
   double seg_a2, seg_b2;  // row segments by build-time distance: (cut_coul+m)^2, (cut_lj+m)^2
   double far_band;        // width (A) of the near skin band C1
   double seg_c2;          // skin band split: (cutmax + skin/2)^2, beyond it segment C2 (skipped while nothing moved far enough)

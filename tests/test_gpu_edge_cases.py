@@ -260,3 +260,27 @@ def test_unstable_replica_is_reported_not_returned(small_pe):
     out = eng.strain_batch([capi.make_sim(1, "pe", 1, st, nss=10, most_recent=capi.QP_NONE)])
     assert np.all(np.isfinite(out[0].stress[:])) and out[0].stress_updated == 1
     eng.close()
+
+
+def test_list_skin_is_a_performance_knob_only(small_pe, monkeypatch):
+    """The engine widens the neighbour skin of states that rebuild their lists often (adaptive, performance only).  With
+    the extra skin forced on, forces, a 20-step trajectory and a full evaluation still equal the oracle's, which keeps
+    the reference's skin."""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    lens = _lens(small_pe)
+    st = np.array([-3e-4, -3e-4, 1.0e-3, 5e-5, 0, -4e-5]) * np.array([*lens, lens[2], lens[1], lens[0]])
+    exp, _ = po.Oracle(small_pe, po.default_params(**KW)).eval(st, 2.0, 300.0, 1e-4, 20)
+    res = {}
+    for extra in ("0", "0.4"):
+        monkeypatch.setenv("SCEMA_MD_SKIN_EXTRA", extra)
+        eng = capi.Engine(capi.default_params(**KW))
+        eng.register_replica("pe", 1, small_pe)
+        out = eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=20, most_recent=capi.QP_NONE)])
+        res[extra] = np.array(out[0].stress[:])
+        f, e, w, info = eng.debug_compute("pe", 1)
+        res["f" + extra] = f
+        eng.close()
+    monkeypatch.delenv("SCEMA_MD_SKIN_EXTRA")
+    assert relerr(res["0"], exp) < 1e-6 and relerr(res["0.4"], exp) < 1e-6
+    assert relerr(res["f0.4"], res["f0"]) < 1e-12
