@@ -870,12 +870,14 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       mn_out = (std::min(mn_out, cj_out) + 63) / 64 * 64;
       return cj_out <= MD_MAXJTAB && mdk_pair_lds_bytes(cj_out) <= 74 * 1024 && mdk_neigh_lds_bytes(cj_out, mn_out) <= 150 * 1024;
     };
-    {
+    // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
+    // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
+    for (int pass = 0; pass < 2 && !fits; pass++) {
       int lo[3], hi[3];
       for (int d = 0; d < 3; d++) {
         const double w = std::min(w0[d], w1[d]);
         lo[d] = std::max(2, std::min(64, (int)std::floor(w / (rlist * 1.0001))));
-        hi[d] = std::max(lo[d], std::min(64, (int)std::floor(w / (0.5 * rlist * 1.0001))));
+        hi[d] = std::max(lo[d], std::min(64, (int)std::floor(w / ((pass == 0 ? 0.5 : 0.25) * rlist * 1.0001))));
       }
       double best = -1.0;
       for (int n0 = lo[0]; n0 <= hi[0]; n0++)
@@ -893,7 +895,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
             }
           }
     }
-    for (int k = 3; k <= 8 && !fits; k++) {
+    for (int k = 5; k <= 8 && !fits; k++) {
       int nc[3], mst[3];
       for (int d = 0; d < 3; d++) {
         const double w = std::min(w0[d], w1[d]);
