@@ -182,7 +182,8 @@ def main():
             "config": {"workload": f"{n} x PE-{d['natoms']} OPLS replicas per update(), {req.get('nts_mean', 10.0):.0f}+{args.nss} MD steps each "
                                    "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + Ewald 1e-4 + SHAKE + NVT), persistent per-QP state",
                        "strain_set": args.strain_set, "n_sims": n, "atoms_per_replica": int(d["natoms"]), "md_steps_per_eval": req.get("nts_mean", 10.0) + args.nss,
-                       "sharding": f"sim i -> rank i % {world}", "stress_zz_checksum_Pa": checksum},
+                       "sharding": f"sim i -> rank i % {world}", "stress_zz_checksum_Pa": checksum,
+                       "list_skin_A": prof.get("list_skin_mean", 0.0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_pair (lj/cut/coul/long force+virial; every pair once, 4-atom cluster rows, LDS reaction-force tiles)",

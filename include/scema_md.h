@@ -203,6 +203,7 @@ typedef struct {
   int64_t neigh_builds;
   double unique_pairs_per_sim;/* average unique pairs within cutoff+skin at the last build */
   int64_t evals;
+  double list_skin_mean;      /* mean neighbour-list skin of those evaluations: params.skin + the adaptive extra (performance only) */
 } scema_md_profile;
 int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset);
 

@@ -128,6 +128,7 @@ struct Profile {
   long long md_steps = 0, neigh_builds = 0, evals = 0;
   double unique_pairs_sum = 0;
   long long unique_pairs_n = 0;
+  double skin_sum = 0;
 };
 
 }  // namespace
@@ -1310,6 +1311,7 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
         const SimScalars &sc = e->h_sc[i];
         std::memcpy(chunk[i].st->box, sc.box, 9 * sizeof(double));
         for (int k = 0; k < 6; k++) chunk[i].pavg[k] = sc.psum[k] / (double)std::max(sc.nsamples, 1);
+        e->prof.skin_sum += e->p.skin + chunk[i].st->skin_extra;
         // steps per list rebuild of the sampling run -> list skin of this state's next evaluation (with hysteresis)
         if (e->skin_extra_fixed < 0.0 && chunk[i].nss >= 50) {
           const double interval = (double)chunk[i].nss / (double)std::max(sc.nbuilds, 1);
@@ -1881,6 +1883,7 @@ int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t rese
   out->neigh_builds = e->prof.neigh_builds;
   out->unique_pairs_per_sim = e->prof.unique_pairs_n ? e->prof.unique_pairs_sum / e->prof.unique_pairs_n : 0.0;
   out->evals = e->prof.evals;
+  out->list_skin_mean = e->prof.evals ? e->prof.skin_sum / (double)e->prof.evals : 0.0;
   if (reset) e->prof = Profile();
   return SCEMA_MD_OK;
 }

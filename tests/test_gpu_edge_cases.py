@@ -284,3 +284,24 @@ def test_list_skin_is_a_performance_knob_only(small_pe, monkeypatch):
     monkeypatch.delenv("SCEMA_MD_SKIN_EXTRA")
     assert relerr(res["0"], exp) < 1e-6 and relerr(res["0.4"], exp) < 1e-6
     assert relerr(res["f0.4"], res["f0"]) < 1e-12
+
+
+def test_list_skin_adapts_to_the_rebuild_frequency(small_pe):
+    """A state whose sampling run rebuilt its list more often than every 19 steps is evaluated with 25 % more skin next
+    time (and the profile says so); the stresses keep matching the oracle, which never changes its skin."""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    kw = dict(KW, skin=0.6)                       # a thin skin: this small hot system rebuilds every few steps
+    eng = capi.Engine(capi.default_params(profile=1, **kw))
+    eng.register_replica("pe", 1, small_pe)
+    o = po.Oracle(small_pe, po.default_params(**kw))
+    lens = _lens(small_pe)
+    st = np.array([-2e-4, -2e-4, 6e-4, 0, 0, 0]) * np.array([*lens, lens[2], lens[1], lens[0]])
+    skins = []
+    for k in range(2):
+        out = eng.strain_batch([capi.make_sim(3, "pe", 1, st, nss=60, most_recent=(capi.QP_NONE if k == 0 else 3))])
+        exp, _ = o.eval(st, 2.0, 300.0, 1e-4, 60)
+        assert relerr(out[0].stress[:], exp) < 2e-6
+        skins.append(eng.profile(reset=True)["list_skin_mean"])
+    assert skins[0] == pytest.approx(0.6) and skins[1] == pytest.approx(0.75)
+    eng.close()
