@@ -17,6 +17,14 @@ def pytest_collection_modifyitems(config, items):
     pass
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _library_is_built():
+    """The C-ABI library and the oracle are compiled once per session (a no-op when they are up to date): a fresh
+    checkout must not fail GPU tests with 'library not built', and nothing ever falls back to a CPU path instead."""
+    import __graft_entry__ as g
+    g.build()
+
+
 @pytest.fixture(scope="session")
 def small_pe():
     """360-atom PE crystal with jitter + tilt, used with reduced cutoffs (box >= 2*(rc+skin))."""
