@@ -42,7 +42,10 @@ def cpu_baseline(d, strains, nss):
         t.join()
     dt = time.time() - t0
     tm = oracles[0].timing()
+    import shutil
+    lmp = next((shutil.which(n) for n in ("lmp", "lmp_serial", "lmp_mpi", "lammps") if shutil.which(n)), None)
     return {"value": ncore / dt, "unit": "evals/s", "cores": ncore, "kind": "port",
+            "lammps_on_this_host": lmp,   # a LAMMPS found here would be the real baseline; none is installed on these images
             "sample": f"{ncore} PE-10k evaluations ({nts[0]}+{nss} MD steps each), one per host core on {ncore} of {os.cpu_count()} cores: "
                       f"{dt:.1f} s wall (replica 0: pair {tm['pair']:.1f} s, kspace {tm['kspace']:.1f} s, neigh {tm['neigh']:.1f} s); "
                       "CPU restatement (oracle/md_oracle.c), not LAMMPS"}
