@@ -148,3 +148,16 @@ def test_gpu_edge_list_equals_the_thresholded_matrix(gold):
     assert np.array_equal(pairs, np.stack([a, b], 1)) and np.array_equal(dist, dm[a, b])
     p0, d0 = cluster.edges(sp, 0.0)
     assert len(p0) == 0 and len(d0) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_identical_histories_are_an_edge_not_a_crash():
+    """Two identical histories have distance 0; the reference script would divide by it (ZeroDivisionError on the unused
+    edge weight).  Here they are simply similar: one of them takes its results from the other."""
+    from scema_amd import cluster
+    rng = np.random.default_rng(2)
+    base = np.cumsum(rng.normal(0, 1e-3, (3, 6, 6)), 1)
+    hist = np.stack([base[0], base[1], base[0], base[2]])          # histories 0 and 2 coincide
+    m = cluster.cluster([4, 7, 9, 12], hist, 8, 1e-6, 16).tolist()
+    assert m[4] == m[9] and m[4] in (4, 9)
+    assert m[7] == 7 and m[12] == 12 and all(m[i] == i for i in range(16) if i not in (4, 9))
