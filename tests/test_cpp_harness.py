@@ -33,3 +33,17 @@ def test_cpp_caller_links_and_runs(tmp_path):
         exp = po.hooke(C, eps)
         got = np.array([float(v) for v in r[3:9]])
         assert np.allclose(got, exp, rtol=1e-13, atol=1e-6)
+
+
+def test_cpp_cluster_caller_links_and_runs(tmp_path):
+    """include/scema_cluster.h from C++: spline fit, similarity lists and greedy cover on the host."""
+    import __graft_entry__ as g
+    g.build()
+    exe = str(tmp_path / "cluster_harness")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "scema_cluster_harness.cpp"),
+                           "-L" + os.path.join(ROOT, "scema_amd"), "-lscema_md", "-Wl,-rpath," + os.path.join(ROOT, "scema_amd"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = {int(l.split()[1]): int(l.split()[3]) for l in out.stdout.strip().split("\n")}
+    # quadrature points 0 and 2 share a history: the one that entered the graph last (2) runs the MD for both
+    assert m == {0: 2, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5}
