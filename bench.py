@@ -3,16 +3,23 @@
 
 One "step" = one STMDSync::update() worth of work: a batch of `--sims` quadrature-point replicas
 (default 576 x PE-10k), each strained for nts=10 MD steps and sampled for nss=100 MD
-steps, starting from the state the previous step left in HBM.  With N GPUs the batch is sharded
-round-robin (simulation i -> rank i % N, stmd_sync.h:583) and the stresses return through one
-RCCL all-gather, so the total work per step is fixed ("strong" scaling).
+steps, starting from the state the previous step left in HBM.  The replica is equilibrated once, outside
+the timed region (2 000 NVT+SHAKE steps from the synthetic crystal), so that the first and the last
+update of a run do the same work.  With N GPUs (one process per GPU) the batch is sharded by the engine's
+planner (scema_amd/csrc/host/sim_plan.h; a fresh balanced batch: simulation i -> rank i % N,
+stmd_sync.h:583) and the stresses return through ONE ncclAllGather (RCCL over xGMI) inside
+scema_md_strain_batch, so the total work per step is fixed ("strong" scaling).
+
+`python bench.py --gpus N` without RANK in the environment starts the N ranks itself (before anything
+touches a GPU) and fails if the node has fewer than N devices.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,34 +28,58 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+EQ_QP = 1 << 30   # scratch quadrature-point id of the equilibration run
 
-def cpu_baseline(d, strains, nss):
-    """The oracle (CPU restatement, NOT LAMMPS) timed on the host cores the way the reference runs its CPU path: one
-    serial MD engine per core, one replica each (stmd_sync.h:189-278 with n_sims >= ranks), up to 32 cores."""
-    import threading
+
+def _cpu_eval(k, cells, strain, nss):
+    """one oracle evaluation in a worker process (test infrastructure timed as the CPU baseline)"""
     from oracle import pyoracle as po
-    ncore = max(1, min(len(strains), os.cpu_count() or 1, 32))
-    oracles = [po.Oracle(d) for _ in range(ncore)]
-    nts = [0] * ncore
-
-    def work(k):   # the C library call releases the GIL
-        _, nts[k] = oracles[k].eval(strains[k], 2.0, 300.0, 1e-4, nss)
-
-    th = [threading.Thread(target=work, args=(k,)) for k in range(ncore)]
+    from scema_amd.systems import build_pe
+    d = build_pe(*cells, shake_project=True)
+    o = po.Oracle(d)
     t0 = time.time()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.time() - t0
-    tm = oracles[0].timing()
+    _, nts = o.eval(strain, 2.0, 300.0, 1e-4, nss)
+    t1 = time.time()
+    return k, t0, t1, int(nts), o.timing()
+
+
+def cpu_baseline(cells, strains, nss):
+    """The oracle (CPU restatement, NOT LAMMPS) timed on the host cores the way the reference runs its CPU path: one
+    serial MD engine per core, one replica each (stmd_sync.h:189-278 with n_sims >= ranks).  One PROCESS per core, started
+    before this program touches the GPU; wall = first evaluation start to last evaluation end."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
     import shutil
+    ncore = max(1, min(len(strains), os.cpu_count() or 1, 32))
+    with cf.ProcessPoolExecutor(max_workers=ncore, mp_context=mp.get_context("spawn")) as ex:
+        res = list(ex.map(_cpu_eval, range(ncore), [cells] * ncore, [strains[k] for k in range(ncore)], [nss] * ncore))
+    t0 = min(r[1] for r in res)
+    t1 = max(r[2] for r in res)
+    dt = t1 - t0
+    tm = res[0][4]
+    alone = np.mean([r[2] - r[1] for r in res])
     lmp = next((shutil.which(n) for n in ("lmp", "lmp_serial", "lmp_mpi", "lammps") if shutil.which(n)), None)
+    natoms = 12 * cells[0] * cells[1] * cells[2]
     return {"value": ncore / dt, "unit": "evals/s", "cores": ncore, "kind": "port",
             "lammps_on_this_host": lmp,   # SURVEY 8(d): a LAMMPS found here would be the real baseline; none is installed on these images
-            "sample": f"{ncore} PE-10k evaluations ({nts[0]}+{nss} MD steps each), one per host core on {ncore} of {os.cpu_count()} cores: "
-                      f"{dt:.1f} s wall (replica 0: pair {tm['pair']:.1f} s, kspace {tm['kspace']:.1f} s, neigh {tm['neigh']:.1f} s); "
-                      "CPU restatement (oracle/md_oracle.c), not LAMMPS"}
+            "sample": f"{ncore} PE-{natoms} evaluations ({res[0][3]}+{nss} MD steps each), one process per host core on {ncore} of "
+                      f"{os.cpu_count()} cores: {dt:.1f} s wall, {alone:.1f} s mean per evaluation (replica 0: pair {tm['pair']:.1f} s, "
+                      f"kspace {tm['kspace']:.1f} s, neigh {tm['neigh']:.1f} s); CPU restatement (oracle/md_oracle.c), not LAMMPS"}
+
+
+def spawn_ranks(args):
+    """--gpus N from a plain shell: start N ranks (torch.distributed.run) BEFORE any GPU call in this process."""
+    import torch
+    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if have < args.gpus and not args.share_gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
 
 
 def main():
@@ -62,62 +93,103 @@ def main():
     ap.add_argument("--strain-set", default="balanced", choices=["balanced", "file3d", "imbalanced"],
                     help="balanced: nts=10 for every replica (default, SURVEY 8d); file3d: x5 strains at rate 2e-4 (nts=30); "
                          "imbalanced: eps_zz log-uniform in [1e-3,2e-2] (nts 10..100)")
+    ap.add_argument("--equil-steps", type=int, default=2000, help="NVT+SHAKE steps that equilibrate the synthetic crystal before anything is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (default); gloo = host all-gather, lets several ranks share one GPU in tests")
+                    help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
+    ap.add_argument("--share-gpus", action="store_true", help="tests: let several ranks share a GPU (needs --dist-backend gloo)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    from scema_amd.systems import build_pe, synthetic_strains
+    d = build_pe(*args.cells, shake_project=True)   # SURVEY 8(d): seed 1234, 300 K, SHAKE-projected velocities
+    lens = d["box"][3:6] - d["box"][:3]
+    n = args.sims
+
+    # CPU baseline first: its worker processes start while nothing in this process has touched the GPU
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(tuple(args.cells), synthetic_strains(32, lens, seed=2026), args.nss)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    device = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if world > ndev and not args.share_gpus:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s)")
+    device = local_rank % ndev
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group("gloo")
+        dist.init_process_group("gloo")   # control plane only (id exchange, barrier, max of the timings); the data path is RCCL
 
     from scema_amd import capi
-    from scema_amd.systems import build_pe, synthetic_strains
-
-    d = build_pe(*args.cells, shake_project=True)   # SURVEY 8(d): seed 1234, 300 K, SHAKE-projected velocities
     # ablation knobs for kernel experiments only (never set in a reported run)
     extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
     eng = capi.Engine(capi.default_params(device=device, profile=1, **extra))
-    eng.register_replica("g0", 1, d)
-    lens = d["box"][3:6] - d["box"][:3]
-    n = args.sims
-    per_rank = (n + world - 1) // world
+    if world > 1:
+        if args.dist_backend == "nccl":
+            uid = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.comm_init_rccl(uid[0], rank, world)
+        else:
+            def _ag(b):
+                t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+                parts = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(parts, t)
+                return torch.cat(parts).numpy().tobytes()
 
-    gdev = "cuda" if args.dist_backend == "nccl" else "cpu"
-    send = torch.zeros(6 * per_rank, dtype=torch.float64, device=gdev)
-    recv = torch.zeros(6 * per_rank * world, dtype=torch.float64, device=gdev)
+            def _send(b, dst):
+                dist.send(torch.frombuffer(bytearray(b), dtype=torch.uint8), dst)
+
+            def _recv(nb, src):
+                t = torch.empty(nb, dtype=torch.uint8)
+                dist.recv(t, src)
+                return t.numpy().tobytes()
+            eng.comm_init_host(rank, world, _ag, _send, _recv)
+
+    # ---- equilibrated replica (outside the timed region): rank 0 runs it, every rank registers the same state ----
+    eng.register_replica("g0", 1, d)
+    if args.equil_steps > 0:
+        state = [None]
+        if rank == 0:
+            eng.set_state(EQ_QP, "g0", 1, d["box"], d["x"], d["v"])
+            eng.debug_run("g0", 1, args.equil_steps, 2.0, 300.0, qp=EQ_QP, nvt=True, use_shake=True)
+            state[0] = eng.get_state(EQ_QP, "g0", 1)
+        if world > 1:
+            dist.broadcast_object_list(state, src=0)
+        box, x, v = state[0]
+        d = dict(d, box=box, x=x, v=v)
+        eng.register_replica("g0", 1, d)   # drops the scratch state with the old registration
+        lens = d["box"][3:6] - d["box"][:3]
     checksum = 0.0
 
     # The request vector (one MDSim per quadrature point, what prepare_md_simulations fills in C++ in the reference,
     # stmd_sync.h:491-568) is built once; every update only rewrites the strains and most_recent ids in place.
+    import ctypes
     req = {"arr": None}
+    rate = 2e-4 if args.strain_set == "file3d" else 1e-4
 
     def requests(istep):
         strains = synthetic_strains(n, lens, seed=2026 + istep, scale=(5.0 if args.strain_set == "file3d" else 1.0),
                                     mode=("imbalanced" if args.strain_set == "imbalanced" else "balanced"))
         if req["arr"] is None:
-            sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=capi.QP_NONE,
-                                  strain_rate=(2e-4 if args.strain_set == "file3d" else 1e-4)) for q in range(n)]
+            sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=capi.QP_NONE, strain_rate=rate) for q in range(n)]
             arr = (capi.MDSim * n)(*sims)
             raw = np.frombuffer(arr, dtype=np.uint8).reshape(n, ctypes.sizeof(capi.MDSim))
             o_s, o_m = capi.MDSim.strain.offset, capi.MDSim.most_recent_qp_id.offset
             req.update(arr=arr, keep=sims, strain=raw[:, o_s:o_s + 48].view(np.float64), recent=raw[:, o_m:o_m + 4].view(np.int32))
         req["strain"][:, :] = strains
         # straining steps per replica (reference stmd_problem.h:222-232): nts = max(ceil(|eps|_F / rate / dt / 10) * 10, 10)
-        rate = 2e-4 if args.strain_set == "file3d" else 1e-4
         true = np.asarray(strains, float) / np.array([lens[0], lens[1], lens[2], lens[2], lens[1], lens[0]])
         fro = np.sqrt((true[:, :3] ** 2).sum(1) + 2.0 * (true[:, 3:] ** 2).sum(1))
         req["nts_mean"] = float(np.maximum(np.ceil(fro / rate / 2.0 / 10.0) * 10.0, 10.0).mean())
@@ -126,20 +198,10 @@ def main():
 
     def update(istep):
         nonlocal checksum
-        sims = requests(istep)
-        arr = eng.strain_batch(sims, rank=rank, world=world)
-        if world > 1:
-            eng.copy_local_stress(send.data_ptr(), gdev == "cuda")
-            if gdev == "cuda":
-                dist.all_gather_into_tensor(recv, send)      # the one collective (replaces share_stresses)
-            else:
-                parts = [torch.empty_like(send) for _ in range(world)]
-                dist.all_gather(parts, send)
-                recv.copy_(torch.cat(parts))
-            if rank == 0:
-                eng.scatter_gathered(recv.cpu().numpy(), world, arr)
-        if rank == 0:
-            checksum = float(sum(a.stress[2] for a in arr))
+        # collective when a communicator is attached: states that change GPU travel first, ONE all-gather returns every stress
+        arr = eng.strain_batch(requests(istep), rank=rank, world=world)
+        assert all(a.stress_updated for a in arr)
+        checksum = float(sum(a.stress[2] for a in arr))
         return arr
 
     def fence():
@@ -158,56 +220,77 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = eng.profile()
+    comm = eng.comm_stats()
+    owner, _, cap = eng.last_plan(n)
 
     if rank == 0:
-        # HBM traffic of the pair kernel comes from PMC counters, which cannot be collected inside a timed
-        # run: tools/pmc_traffic.sh measures bytes per replica-step (separate FETCH_SIZE / WRITE_SIZE passes,
-        # gfx950 x2 correction on FETCH_SIZE) and commits them under profiles/; scaled here to one launch
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "pair_traffic.json")
-        if os.path.exists(tpath) and d["natoms"] == 10368:
-            tj = json.load(open(tpath))
-            traffic = tj["hbm_bytes_per_sim_step_corrected"] * ((n + world - 1) // world)
-            traffic_src = "profiles/pair_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 on FETCH_SIZE)"
+        natoms = int(d["natoms"])
+        per_rank = int(cap)
+        # PMC figures cannot be collected inside a timed run: tools/pmc_pair.sh measures them per replica-step on the same
+        # kernel (separate rocprofv3 --pmc passes; gfx950 x2 correction on FETCH_SIZE) and commits profiles/pair_pmc.json
+        pmc = None
+        ppath = os.path.join(ROOT, "profiles", "pair_pmc.json")
+        if os.path.exists(ppath) and natoms == 10368:
+            pmc = json.load(open(ppath))
         value = n * args.steps / elapsed
         pair_s = prof["pair_ms"] * 1e-3
-        # the part of the algorithmic bytes that does not scale with the list length: (56 N + 48) per simulation and launch
-        per_launch_fixed = prof["pair_launches"] * ((n + world - 1) // world) * (56.0 * d["natoms"] + 48.0)
-        achieved = prof["pair_alg_bytes"] / pair_s / 1e9 if pair_s > 0 else 0.0
+        launches = max(prof["pair_launches"], 1)
+        avg_launch_s = pair_s / launches
+        # algorithmic bytes: N*(4*nbar + 56) + 48 per replica and launch.  full = nbar of a FULL per-atom list
+        # inside cutoff + the reference's skin (what the engine counts at build time); stored = every pair once (half of it)
+        full = prof["pair_alg_bytes"]
+        fixed = prof["pair_launches"] * per_rank * (56.0 * natoms + 48.0)
+        stored = 0.5 * (full - fixed) + fixed
+        achieved = stored / pair_s / 1e9 if pair_s > 0 else 0.0
+        roof = {"bound": "fp64_valu", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": None, "traffic_source": None,
+                "kernel": "k_pair (lj/cut/coul/long force+virial; every pair once, 4-atom cluster rows, LDS reaction-force tiles)",
+                "accounting": "achieved = SURVEY 8(d) bytes N*(4*n_stored+56)+48 with n_stored = the neighbours the kernel stores per atom "
+                              "(each pair once = half of the full list inside cutoff + the reference's 2 A skin, counted at build time) / "
+                              "HIP-event time of the launches on the engine's stream; frac_full_list_equiv prices the full list instead",
+                "frac_full_list_equiv": full / pair_s / 1e9 / 8000.0 if pair_s > 0 else 0.0,
+                "launches": prof["pair_launches"], "avg_launch_ms": 1e3 * avg_launch_s,
+                "alg_bytes_per_launch": stored / launches, "sims_per_launch": per_rank,
+                "rank0_pair_share_of_wall": pair_s / elapsed}
+        if pmc:
+            scale = per_rank   # PMC figures are per replica and launch
+            roof["traffic"] = pmc["hbm_bytes_per_sim_step_corrected"] * scale
+            roof["traffic_source"] = pmc.get("source", "profiles/pair_pmc.json")
+            insts = pmc["valu_insts_per_sim_step"] * scale
+            cyc = pmc.get("cycles_per_valu_inst", 4.0)
+            nsimd, clk = 256 * 4, 2.4e9
+            roof["fp64"] = {"valu_insts": insts, "cycles_per_inst": cyc, "simds": nsimd, "clock_hz": clk,
+                            "issue_time_ms": 1e3 * insts * cyc / (nsimd * clk), "frac": insts * cyc / (nsimd * clk) / avg_launch_s if avg_launch_s > 0 else 0.0,
+                            "note": "vector instructions of one launch (SQ_INSTS_VALU, PMC pass under profiles/) priced at the FP64 rate of 4 cycles per "
+                                    "wave instruction on a SIMD-32, over the launch time measured here: the bound that binds (HBM does not)"}
         out = {
             "metric": "stress_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n} x PE-{d['natoms']} OPLS replicas per update(), {req.get('nts_mean', 10.0):.0f}+{args.nss} MD steps each "
-                                   "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + Ewald 1e-4 + SHAKE + NVT), persistent per-QP state",
-                       "strain_set": args.strain_set, "n_sims": n, "atoms_per_replica": int(d["natoms"]), "md_steps_per_eval": req.get("nts_mean", 10.0) + args.nss,
-                       "sharding": f"sim i -> rank i % {world}", "stress_zz_checksum_Pa": checksum,
-                       "list_skin_A": prof.get("list_skin_mean", 0.0)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_pair (lj/cut/coul/long force+virial; every pair once, 4-atom cluster rows, LDS reaction-force tiles)",
-                         "accounting": "achieved = SURVEY 8(d) bytes of a FULL per-atom list, N*(4*n_list+56)+48 with n_list = listed "
-                                       "neighbours per atom within cutoff+skin, / HIP-event time of the launches; the kernel stores each "
-                                       "pair once (half of those entries, as masked cluster rows): frac_half_list prices that list instead",
-                         "binds": "FP64 VALU issue, not HBM: 80 % VALU busy and 0.24x the algorithmic bytes in HBM traffic per the PMC "
-                                  "passes under profiles/ (r01_pmc_k_pair_72sims_flat_stream.csv, pair_traffic.json); SURVEY 8(d) asks for both bounds",
-                         "frac_half_list": (0.5 * (prof["pair_alg_bytes"] - per_launch_fixed) + per_launch_fixed) / pair_s / 1e9 / 8000.0 if pair_s > 0 else 0.0,
-                         "launches": prof["pair_launches"],
-                         "avg_launch_ms": prof["pair_ms"] / max(prof["pair_launches"], 1),
-                         "alg_bytes_per_launch": prof["pair_alg_bytes"] / max(prof["pair_launches"], 1),
-                         "rank0_pair_share_of_wall": pair_s / elapsed},
+            "config": {"workload": f"{n} x PE-{natoms} OPLS replicas per update(), {req.get('nts_mean', 10.0):.0f}+{args.nss} MD steps each "
+                                   "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + Ewald 1e-4 + SHAKE + NVT), persistent per-QP state, "
+                                   f"replica equilibrated for {args.equil_steps} steps before the timed region",
+                       "strain_set": args.strain_set, "n_sims": n, "atoms_per_replica": natoms, "md_steps_per_eval": req.get("nts_mean", 10.0) + args.nss,
+                       "sharding": "engine planner (host/sim_plan.h): fresh batch i % N, then sticky to the GPU that holds the state, levelled by MD steps",
+                       "sims_on_rank0": int((owner == 0).sum()), "collective": ("ncclAllGather inside scema_md_strain_batch" if args.dist_backend == "nccl" else "host transport (gloo)") if world > 1 else None,
+                       "allgathers": comm["allgathers"], "state_migrations": comm["migrations"],
+                       "stress_zz_checksum_Pa": checksum,
+                       "list_skin_A": prof.get("list_skin_mean", 0.0),
+                       "steps_per_list_rebuild": prof["md_steps"] / max(prof["neigh_builds"], 1)},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(d, synthetic_strains(32, lens, seed=2026), args.nss)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
     eng.close()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

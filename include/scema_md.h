@@ -136,26 +136,70 @@ int scema_md_write_lammps_restart(const char *path, const scema_md_system *sys, 
 
 /* ---- the hot path ---- */
 /* Replaces STMDProblem<3>::strain (stmd_problem.h:458-496) for the whole vector that
- * STMDSync::execute_inside_md_simulations iterates (stmd_sync.h:570-618).  Simulations
- * i with i % world == rank are evaluated on this engine's GPU (the reference's round robin,
- * stmd_sync.h:583); the others are left untouched (stress_updated = 0).  State branch rule of
- * stmd_problem.h:116-138,185-207: load from most_recent_qp_id if != qp_id, else qp_id, else the
- * registered init state; always store under qp_id.  hooke != 0: sigma = C:eps (stmd_problem.h:479-483). */
+ * STMDSync::execute_inside_md_simulations iterates (stmd_sync.h:570-618).  Every rank passes the SAME vector.
+ * Which rank runs simulation i is decided by the planner of scema_amd/csrc/host/sim_plan.h (identical on every rank):
+ * a fresh balanced batch gives the reference's round robin i % world (stmd_sync.h:583); afterwards a simulation runs
+ * where the state it continues from lives (a state is resident in ONE GPU's HBM, the update_list changes from step to
+ * step, FE_problem.h:1330-1350), and ragged batches are levelled by MD steps (nts + nss).
+ * State branch rule of stmd_problem.h:116-138,185-207: load from most_recent_qp_id if != qp_id, else qp_id, else the
+ * registered init state; always store under qp_id.  hooke != 0: sigma = C:eps (stmd_problem.h:479-483).
+ *   - no communicator attached (world may still be > 1): only this rank's share is evaluated, the others are left
+ *     untouched (stress_updated = 0) and the caller gathers (scema_md_local_stress_* + scema_md_scatter_gathered);
+ *     a request whose source state lives on another rank is an error (SCEMA_MD_ERR_NOSTATE);
+ *   - communicator attached (scema_md_comm_init_*): the call is collective -- states that have to change GPU travel
+ *     first, then ONE all-gather returns every stress to every rank (replaces STMDSync::share_stresses,
+ *     stmd_sync.h:620-726): on return every sims[i].stress is set on every rank.
+ * A failed call leaves the state store as it found it. */
 int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims, int32_t hooke,
                           int32_t rank, int32_t world);
 /* literal per-simulation drop-in */
 int scema_md_strain(scema_md_engine *e, scema_mdsim *sim, int32_t hooke);
 
-/* Device-side result buffer of the last scema_md_strain_batch: 6*ceil(n_sims/world) doubles in
- * HBM, local simulation k (= global index k*world+rank) at offset 6k; the operand of the one
- * all-gather that replaces STMDSync::share_stresses (stmd_sync.h:620-726). */
+/* ---- multi-GPU: one process per GPU, the engine owns the collective ----
+ * RCCL over xGMI: rank 0 calls scema_md_comm_unique_id and the host program broadcasts the 128 bytes (MPI_Bcast in
+ * SCEMa, any store elsewhere); every rank then calls scema_md_comm_init_rccl (ncclCommInitRank on the engine's
+ * device).  Replaces the MPI traffic of stmd_sync.h:620-726 (per-simulation MPI_Isend/Recv of 6 doubles) by one
+ * ncclAllGather per update, and the shared-file-system hand-over of last.<qp>.* states by ncclSend/ncclRecv. */
+#define SCEMA_MD_COMM_ID_BYTES 128
+int scema_md_comm_unique_id(void *id /* [SCEMA_MD_COMM_ID_BYTES] */);
+int scema_md_comm_init_rccl(scema_md_engine *e, const void *id, int32_t rank, int32_t world);
+/* Host transport instead (MPI of the host program; gloo in the CPU tests): buffers are host memory.
+ * allgather: every rank contributes bytes_per_rank bytes, recv holds world * bytes_per_rank.  send/recv: blocking
+ * point-to-point (may be NULL if states never have to move).  Return 0 on success. */
+typedef int (*scema_md_host_allgather_fn)(void *ctx, const void *send, void *recv, int64_t bytes_per_rank);
+typedef int (*scema_md_host_send_fn)(void *ctx, const void *buf, int64_t bytes, int32_t dst_rank);
+typedef int (*scema_md_host_recv_fn)(void *ctx, void *buf, int64_t bytes, int32_t src_rank);
+int scema_md_comm_init_host(scema_md_engine *e, int32_t rank, int32_t world, scema_md_host_allgather_fn allgather,
+                            scema_md_host_send_fn send, scema_md_host_recv_fn recv, void *ctx);
+void scema_md_comm_destroy(scema_md_engine *e);
+int32_t scema_md_comm_world(const scema_md_engine *e);   /* 1 = no communicator */
+int32_t scema_md_comm_rank(const scema_md_engine *e);
+int scema_md_comm_stats(const scema_md_engine *e, int64_t *allgathers, int64_t *migrations);
+/* rank recorded as the owner of a stored state, -1 = none recorded (held wherever it was set) */
+int32_t scema_md_state_owner(const scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica);
+
+/* Plan of the last scema_md_strain_batch: owner[i] = rank that ran simulation i, pos[i] = its slot in that rank's
+ * result buffer, cap = slots per rank. */
+int scema_md_last_plan(const scema_md_engine *e, int32_t n_sims, int32_t *owner, int32_t *pos, int32_t *cap);
+/* Device-side result buffer of the last scema_md_strain_batch: 6*cap doubles in HBM, simulation i of this rank at
+ * offset 6*pos[i]; the operand of the all-gather when the caller runs the collective itself. */
 void *scema_md_local_stress_device_ptr(scema_md_engine *e);
-int32_t scema_md_local_stress_count(const scema_md_engine *e);
+int32_t scema_md_local_stress_count(const scema_md_engine *e);   /* = cap */
 /* copy that buffer into caller memory (a device pointer, e.g. the send buffer of the all-gather, or host) */
 int scema_md_copy_local_stress(scema_md_engine *e, void *dst, int32_t dst_on_device);
-/* after the caller's all-gather into gathered[world][6*ceil(n/world)] (host memory): fill
- * sims[i].stress / stress_updated for every i (rank-0 bookkeeping of stmd_sync.h:698-725) */
-int scema_md_scatter_gathered(const double *gathered, int32_t world, scema_mdsim *sims, int32_t n_sims);
+/* after the caller's all-gather into gathered[world][6*cap] (host memory): fill sims[i].stress / stress_updated for
+ * every i by the plan of the last scema_md_strain_batch (rank-0 bookkeeping of stmd_sync.h:698-725) */
+int scema_md_scatter_gathered(const scema_md_engine *e, const double *gathered, scema_mdsim *sims, int32_t n_sims);
+
+/* The planner alone (scema_amd/csrc/host/sim_plan.h; pure host arithmetic, no GPU): owner/pos/cap as above, moves =
+ * (simulation, from, to) triples of the states that would travel; cost NULL = equal cost; commit != 0 records the
+ * owners for the next call, as a successful scema_md_strain_batch does. */
+typedef struct scema_plan_dir scema_plan_dir;
+scema_plan_dir *scema_plan_dir_create(void);
+void scema_plan_dir_destroy(scema_plan_dir *d);
+int scema_plan_update(scema_plan_dir *d, const scema_mdsim *sims, int32_t n_sims, const double *cost, int32_t world,
+                      int32_t *owner, int32_t *pos, int32_t *cap, int32_t *moves /* 3 per move, room for n_sims */,
+                      int32_t *n_moves, int32_t commit);
 
 /* ---- persistent per-(qp,mat,replica) state: replaces last.<qp>.<mat>_<rep>.dump / lcts.* files
  * (stmd_problem.h:108-138,257-273; stmd_sync.h:167-187) ---- */

@@ -29,7 +29,14 @@ SYMBOLS = [
     "scema_md_local_stress_count", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
     "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file",
     "scema_md_init_material", "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile",
+    "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",
+    "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_state_owner", "scema_md_last_plan",
+    "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update",
 ]
+COMM_ID_BYTES = 128
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+HOST_SEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+HOST_RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 
 class Params(C.Structure):
@@ -96,6 +103,13 @@ def lib():
         L.scema_md_local_stress_count.argtypes = [_P]
         L.scema_md_destroy.argtypes = [_P]
         L.scema_md_destroy.restype = None
+        L.scema_md_comm_destroy.argtypes = [_P]
+        L.scema_md_comm_destroy.restype = None
+        L.scema_md_comm_world.argtypes = [_P]
+        L.scema_md_comm_rank.argtypes = [_P]
+        L.scema_plan_dir_create.restype = C.c_void_p
+        L.scema_plan_dir_destroy.argtypes = [_P]
+        L.scema_plan_dir_destroy.restype = None
         _lib = L
     return _lib
 
@@ -244,9 +258,67 @@ class Engine:
     def copy_local_stress(self, dst_ptr: int, on_device: bool):
         self._chk(lib().scema_md_copy_local_stress(self.h, C.c_void_p(dst_ptr), C.c_int32(1 if on_device else 0)))
 
-    def scatter_gathered(self, gathered: np.ndarray, world: int, arr):
+    def scatter_gathered(self, gathered: np.ndarray, arr):
         g = np.ascontiguousarray(gathered, np.float64)
-        self._chk(lib().scema_md_scatter_gathered(_p(g), C.c_int32(world), arr, C.c_int32(len(arr))))
+        self._chk(lib().scema_md_scatter_gathered(self.h, _p(g), arr, C.c_int32(len(arr))))
+
+    def last_plan(self, n: int):
+        """(owner[n], pos[n], cap) of the last strain_batch (host/sim_plan.h)."""
+        owner = np.zeros(n, np.int32); pos = np.zeros(n, np.int32); cap = C.c_int32(0)
+        self._chk(lib().scema_md_last_plan(self.h, C.c_int32(n), _p(owner), _p(pos), C.byref(cap)))
+        return owner, pos, cap.value
+
+    # ---- communicator: one process per GPU ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = lib().scema_md_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError(f"scema_md_comm_unique_id failed (rc={rc})")
+        return buf.raw
+
+    def comm_init_rccl(self, uid: bytes, rank: int, world: int):
+        assert len(uid) == COMM_ID_BYTES
+        self._chk(lib().scema_md_comm_init_rccl(self.h, C.c_char_p(uid), C.c_int32(rank), C.c_int32(world)))
+
+    def comm_init_host(self, rank: int, world: int, allgather, send=None, recv=None):
+        """Host transport: allgather(send: bytes) -> bytes of all ranks; send(data: bytes, dst); recv(nbytes, src) -> bytes."""
+        def _ag(ctx, sp, rp, nbytes):
+            try:
+                out = allgather(C.string_at(sp, nbytes))
+                C.memmove(rp, out, nbytes * world)
+                return 0
+            except Exception:
+                return 1
+
+        def _send(ctx, p, nbytes, dst):
+            try:
+                send(C.string_at(p, nbytes), dst)
+                return 0
+            except Exception:
+                return 1
+
+        def _recv(ctx, p, nbytes, src):
+            try:
+                C.memmove(p, recv(nbytes, src), nbytes)
+                return 0
+            except Exception:
+                return 1
+
+        self._cb = (HOST_ALLGATHER_FN(_ag), HOST_SEND_FN(_send) if send else C.cast(None, HOST_SEND_FN),
+                    HOST_RECV_FN(_recv) if recv else C.cast(None, HOST_RECV_FN))
+        self._chk(lib().scema_md_comm_init_host(self.h, C.c_int32(rank), C.c_int32(world), self._cb[0], self._cb[1], self._cb[2], None))
+
+    def comm_destroy(self):
+        lib().scema_md_comm_destroy(self.h)
+
+    def comm_stats(self) -> dict:
+        a = C.c_int64(0); m = C.c_int64(0)
+        self._chk(lib().scema_md_comm_stats(self.h, C.byref(a), C.byref(m)))
+        return dict(allgathers=a.value, migrations=m.value)
+
+    def state_owner(self, qp, matid, replica) -> int:
+        return int(lib().scema_md_state_owner(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica)))
 
     def has_state(self, qp, matid, replica) -> bool:
         return bool(lib().scema_md_has_state(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica)))
@@ -320,3 +392,30 @@ def make_sim(qp_id: int, matid: str, replica: int, strain_len, *, most_recent: i
     m.output_homog = 0
     m.checkpoint = 1 if checkpoint else 0
     return m
+
+
+class PlanDir:
+    """The planner alone (scema_plan_* of include/scema_md.h; pure host arithmetic, runs without a GPU)."""
+
+    def __init__(self):
+        self.h = C.c_void_p(lib().scema_plan_dir_create())
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().scema_plan_dir_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def update(self, sims, world: int, cost=None, commit: bool = True):
+        arr = (MDSim * len(sims))(*sims) if not isinstance(sims, C.Array) else sims
+        n = len(arr)
+        owner = np.zeros(n, np.int32); pos = np.zeros(n, np.int32); cap = C.c_int32(0)
+        moves = np.zeros((max(n, 1), 3), np.int32); nm = C.c_int32(0)
+        c = None if cost is None else np.ascontiguousarray(cost, np.float64)
+        rc = lib().scema_plan_update(self.h, arr, C.c_int32(n), _p(c), C.c_int32(world), _p(owner), _p(pos), C.byref(cap), _p(moves),
+                                     C.byref(nm), C.c_int32(1 if commit else 0))
+        if rc != 0:
+            raise EngineError(f"scema_plan_update rc={rc}")
+        return owner, pos, cap.value, moves[:nm.value].copy()

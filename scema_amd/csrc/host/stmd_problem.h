@@ -25,7 +25,7 @@ class STMDProblem {
     return run(one, approx_md_with_hookes_law, 0, 1);
   }
 
-  // all simulations of one update(); simulation i is evaluated here iff i % world == rank
+  // all simulations of one update(); the engine's planner decides which of them run on this rank
   int strain_batch(std::vector<MDSim> &sims, bool approx_md_with_hookes_law) {
     std::vector<MDSim *> p;
     for (auto &s : sims) p.push_back(&s);
@@ -51,13 +51,17 @@ class STMDProblem {
         return SCEMA_MD_ERR_ARG;
       }
     }
+    // which simulations this rank runs: i % world for the stateless Hooke mode (the reference's round robin,
+    // stmd_sync.h:583); for MD the engine's planner decides (states are resident on ONE GPU, host/sim_plan.h)
+    std::vector<int> owner(n);
+    for (int i = 0; i < n; i++) owner[i] = i % world;
     std::vector<int> mine;
-    for (int i = 0; i < n; i++)
-      if (i % world == rank) mine.push_back(i);
-    if (verbose_)
-      for (int i : mine) std::cout << " \t" << sims[i]->qp_id << "-" << sims[i]->replica << "-start" << std::endl << std::flush;
     if (hooke) {
       // "approximate md with hookes law": the reference's own fake backend (stmd_problem.h:479-483)
+      for (int i = 0; i < n; i++)
+        if (owner[i] == rank) mine.push_back(i);
+      if (verbose_)
+        for (int i : mine) std::cout << " \t" << sims[i]->qp_id << "-" << sims[i]->replica << "-start" << std::endl << std::flush;
       for (int i : mine) {
         sims[i]->stress = stress_from_hookes_law(sims[i]->strain, sims[i]->stiffness);
         sims[i]->stress_updated = true;
@@ -74,9 +78,18 @@ class STMDProblem {
         err_ = scema_md_last_error(engine_);
         return rc;
       }
+      if (world > 1) (void)scema_md_last_plan(engine_, n, owner.data(), nullptr, nullptr);
+      for (int i = 0; i < n; i++)
+        if (owner[i] == rank) mine.push_back(i);
+      if (verbose_)
+        for (int i : mine) std::cout << " \t" << sims[i]->qp_id << "-" << sims[i]->replica << "-start" << std::endl << std::flush;
+      // with a communicator attached to the engine every stress is already here (one all-gather inside the call)
+      for (int i = 0; i < n; i++)
+        if (c[i].stress_updated) {
+          for (int k = 0; k < 6; k++) sims[i]->stress.raw[k] = c[i].stress[k];
+          sims[i]->stress_updated = true;
+        }
       for (int i : mine) {
-        for (int k = 0; k < 6; k++) sims[i]->stress.raw[k] = c[i].stress[k];
-        sims[i]->stress_updated = c[i].stress_updated != 0;
         // reference stmd_problem.h:266-273: lcts.<qp>.<mat>_<rep>.dump every "checkpoint frequency" steps
         if (sims[i]->checkpoint && !sims[i]->restart_folder.empty()) {
           const std::string path = sims[i]->restart_folder + "/lcts." + std::to_string(sims[i]->qp_id) + "." + sims[i]->matid + "_" +

@@ -4,6 +4,7 @@
 #pragma once
 #include <dirent.h>
 
+#include <algorithm>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -261,7 +262,7 @@ class STMDSync {
     return request_simulations;
   }
 
-  // reference stmd_sync.h:570-618: round robin i % n_md_batches, here i % world (one GPU per batch)
+  // reference stmd_sync.h:570-618: round robin i % n_md_batches; here one GPU per batch, dealt by the engine's planner
   int execute_inside_md_simulations(std::vector<MDSim> &md_simulations) {
     STMDProblem stmd_problem(engine_, rank_, world_, verbose);
     int rc = stmd_problem.strain_batch(md_simulations, approx_md_with_hookes_law);
@@ -269,19 +270,30 @@ class STMDSync {
     return SCEMA_MD_OK;
   }
 
-  // reference stmd_sync.h:620-726: 6 doubles per simulation to everybody, ONE collective
+  // reference stmd_sync.h:620-726: 6 doubles per simulation to everybody, ONE collective.  With a communicator attached
+  // to the engine (scema_md_comm_init_rccl / _host) that all-gather already ran inside scema_md_strain_batch and every
+  // stress is here; otherwise it runs through the host program's callback, laid out by the engine's plan (MD) or by
+  // the round robin i % world (stateless Hooke mode).
   int share_stresses(std::vector<MDSim> &md_simulations) {
     const int n = (int)md_simulations.size();
-    if (world_ > 1) {
-      if (!allgather_) return fail(SCEMA_MD_ERR_ARG, "world > 1 needs an all-gather callback");
-      const int per_rank = (n + world_ - 1) / world_;
-      std::vector<double> local(6 * (size_t)per_rank, 0.0), gathered(6 * (size_t)per_rank * world_, 0.0);
-      for (int i = rank_; i < n; i += world_)
-        for (int k = 0; k < 6; k++) local[6 * (size_t)(i / world_) + k] = md_simulations[i].stress.raw[k];
-      int rc = allgather_(ag_ctx_, approx_md_with_hookes_law ? nullptr : engine_, local.data(), 6 * per_rank, gathered.data());
+    bool complete = true;
+    for (int i = 0; i < n; i++) complete = complete && md_simulations[i].stress_updated;
+    if (world_ > 1 && !complete) {
+      if (!allgather_) return fail(SCEMA_MD_ERR_ARG, "world > 1 needs an all-gather: attach a communicator to the engine or pass a callback");
+      const bool md = engine_ && !approx_md_with_hookes_law;
+      std::vector<int> owner(n), pos(n);
+      int per_rank = (n + world_ - 1) / world_;
+      for (int i = 0; i < n; i++) { owner[i] = i % world_; pos[i] = i / world_; }
+      if (md && scema_md_last_plan(engine_, n, owner.data(), pos.data(), &per_rank) != SCEMA_MD_OK)
+        return fail(SCEMA_MD_ERR_ARG, "no plan recorded for this request vector");
+      std::vector<double> local(6 * (size_t)std::max(per_rank, 1), 0.0), gathered(6 * (size_t)std::max(per_rank, 1) * world_, 0.0);
+      for (int i = 0; i < n; i++)
+        if (owner[i] == rank_)
+          for (int k = 0; k < 6; k++) local[6 * (size_t)pos[i] + k] = md_simulations[i].stress.raw[k];
+      int rc = allgather_(ag_ctx_, md ? engine_ : nullptr, local.data(), 6 * per_rank, gathered.data());
       if (rc) return fail(SCEMA_MD_ERR_DEVICE, "all-gather of the stresses failed");
       for (int i = 0; i < n; i++) {
-        const double *src = gathered.data() + ((size_t)(i % world_) * per_rank + (size_t)(i / world_)) * 6;
+        const double *src = gathered.data() + ((size_t)owner[i] * per_rank + (size_t)pos[i]) * 6;
         for (int k = 0; k < 6; k++) md_simulations[i].stress.raw[k] = src[k];
         md_simulations[i].stress_updated = true;
       }

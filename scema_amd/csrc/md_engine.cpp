@@ -14,6 +14,7 @@
 //   stress = -<P> * 1.01325e5 ........ stmd_problem.h:335-341
 //   Hooke fallback ................... stmd_problem.h:386-392,479-483
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -28,6 +29,7 @@
 #include <vector>
 
 #include "../../include/scema_md.h"
+#include "host/sim_plan.h"
 #include "md_kernels.h"
 #include "md_types.h"
 
@@ -122,6 +124,21 @@ struct ActiveSim {
   double pavg[6];
 };
 
+// One process per GPU: the communicator of the engine.  RCCL (xGMI) for the GPU box, or transport callbacks of the host
+// program (MPI in SCEMa, gloo in the CPU tests).  Replaces the MPI calls of stmd_sync.h:620-726.
+struct Comm {
+  int kind = 0;   // 0 none, 1 RCCL, 2 host callbacks
+  int rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  scema_md_host_allgather_fn ag = nullptr;
+  scema_md_host_send_fn send = nullptr;
+  scema_md_host_recv_fn recv = nullptr;
+  void *ctx = nullptr;
+  DevBuf d_gather, d_box;
+  std::vector<double> h_gather;
+  long long migrations = 0, allgathers = 0;
+};
+
 struct Profile {
   long long pair_launches = 0;
   double pair_ms = 0, pair_alg_bytes = 0;
@@ -154,6 +171,9 @@ struct scema_md_engine {
   double jtab_grow = 1.0;    // headroom factor of the tile j tables, x1.25 per overflow (-> smaller cells)
   int overflow_bits = 0;     // what overflowed in the last run: 4 = a tile's j table, 8 = a cluster row
   bool use_graphs = false;  // hipGraph replay of the MD step loop: opt-in (SCEMA_MD_GRAPH=1), measured slower on ROCm 7.2
+  Comm comm;
+  scema::OwnerDirectory dir;   // state key -> owning rank, identical on every rank (host/sim_plan.h)
+  scema::SimPlan last_plan;
 };
 
 namespace {
@@ -1215,16 +1235,43 @@ int make_state(scema_md_engine *e, Topo *t, const double *box, const double *x, 
   const size_t bytes = 3 * (size_t)t->natoms * sizeof(double);
   HIPCHK(out->x.ensure(bytes));
   HIPCHK(out->v.ensure(bytes));
+  // on the engine's stream (created non-blocking: it does not order against the null stream), so that every later
+  // consumer -- backups, kernels -- sees the copy; host sources may be freed by the caller, so those are waited for
   const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  HIPCHK(hipMemcpy(out->x.p, x, bytes, kind));
-  HIPCHK(hipMemcpy(out->v.p, v, bytes, kind));
+  HIPCHK(hipMemcpyAsync(out->x.p, x, bytes, kind, e->stream));
+  HIPCHK(hipMemcpyAsync(out->v.p, v, bytes, kind, e->stream));
+  if (!from_device) HIPCHK(hipStreamSynchronize(e->stream));
+  return SCEMA_MD_OK;
+}
+
+// buffers of a state whose content arrives from another rank
+int make_empty_state(scema_md_engine *e, Topo *t, std::unique_ptr<State> &out) {
+  out.reset(new State());
+  out->topo = t;
+  std::memset(out->box, 0, sizeof out->box);
+  const size_t bytes = 3 * (size_t)t->natoms * sizeof(double);
+  HIPCHK(out->x.ensure(bytes));
+  HIPCHK(out->v.ensure(bytes));
   return SCEMA_MD_OK;
 }
 
 // state branch rule of stmd_problem.h:116-138,185-207
-int resolve_state(scema_md_engine *e, const scema_mdsim &m, State **out) {
+// `incoming`: the source state as it arrived from the rank that owned it (scema::PlanMove); it becomes the state of
+// qp_id directly.  `created`: set when a new state object was stored under qp_id, with the state it displaced (if any),
+// so that a failed update can put things back.
+int resolve_state(scema_md_engine *e, const scema_mdsim &m, State **out, std::unique_ptr<State> *incoming = nullptr,
+                  bool *created = nullptr, std::unique_ptr<State> *displaced = nullptr) {
   Topo *t = find_topo(e, m.matid, m.replica);
   if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered (init.%s_%d.bin missing)", m.matid, m.replica, m.matid, m.replica);
+  if (created) *created = false;
+  if (incoming && *incoming) {
+    *out = incoming->get();
+    auto &slot = e->states[state_key(m.qp_id, m.matid, m.replica)];
+    if (displaced) *displaced = std::move(slot);
+    slot = std::move(*incoming);
+    if (created) *created = true;
+    return SCEMA_MD_OK;
+  }
   State *src = nullptr;
   if (m.qp_id != m.most_recent_qp_id) {
     src = find_state(e, m.most_recent_qp_id, m.matid, m.replica);
@@ -1249,7 +1296,10 @@ int resolve_state(scema_md_engine *e, const scema_mdsim &m, State **out) {
     rc = make_state(e, t, t->init_box, t->init_x.data(), t->init_v.data(), false, ns);
   if (rc) return rc;
   *out = ns.get();
-  e->states[state_key(m.qp_id, m.matid, m.replica)] = std::move(ns);
+  auto &slot = e->states[state_key(m.qp_id, m.matid, m.replica)];
+  if (displaced) *displaced = std::move(slot);
+  slot = std::move(ns);
+  if (created) *created = true;
   return SCEMA_MD_OK;
 }
 
@@ -1323,7 +1373,18 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
       e->prof.evals += ns;
       return SCEMA_MD_OK;
     }
-    if (rc != SCEMA_MD_ERR_OVERFLOW) return rc;
+    if (rc != SCEMA_MD_ERR_OVERFLOW) {
+      // instability, box error, non-finite stress, device error: the reference would have stopped before write_restart
+      // (stmd_problem.h:258), so the stored states must not keep the half-advanced positions
+      for (int i = 0; i < ns; i++) {
+        Slot &sl = *e->slots[i];
+        const size_t bytes = 3 * (size_t)chunk[i].st->topo->natoms * 8;
+        (void)hipMemcpyAsync(chunk[i].st->x.p, sl.xbak.p, bytes, hipMemcpyDeviceToDevice, e->stream);
+        (void)hipMemcpyAsync(chunk[i].st->v.p, sl.vbak.p, bytes, hipMemcpyDeviceToDevice, e->stream);
+      }
+      (void)hipStreamSynchronize(e->stream);
+      return rc;
+    }
     // restore and grow
     for (int i = 0; i < ns; i++) {
       Slot &sl = *e->slots[i];
@@ -1336,6 +1397,118 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
     if ((e->overflow_bits & 8) || !(e->overflow_bits & 4)) e->neigh_grow *= 1.5;
   }
   return fail(e, SCEMA_MD_ERR_OVERFLOW, "neighbour capacity exceeded after regrowth");
+}
+
+#define NCCLCHK(call)                                                                                         \
+  do {                                                                                                    \
+    ncclResult_t _r = (call);                                                                             \
+    if (_r != ncclSuccess) return fail(e, SCEMA_MD_ERR_DEVICE, "%s failed: %s", #call, ncclGetErrorString(_r)); \
+  } while (0)
+
+// Replica states change GPU (scema::PlanMove): x, v and the box of the source state of simulation m.sim go from rank
+// m.from to rank m.to, where they become the state that simulation continues from.  The source rank keeps its copy when
+// another quadrature point branches from it (most_recent_qp_id != qp_id); a state that merely moved is dropped there after
+// the update.  RCCL: one group of point-to-point sends/receives over xGMI on the engine's stream; host transport: the
+// moves in plan order, blocking send/recv pairs (every rank walks the same list, so the pairs cannot cross).
+int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, const std::vector<std::string> &src_keys,
+                   std::map<int, std::unique_ptr<State>> &incoming) {
+  Comm &c = e->comm;
+  const int nm = (int)plan.moves.size();
+  std::vector<double> hbox(9 * (size_t)nm, 0.0);
+  std::vector<State *> src(nm, nullptr);
+  for (int k = 0; k < nm; k++) {
+    const scema::PlanMove &m = plan.moves[k];
+    Topo *t = find_topo(e, sims[m.sim].matid, sims[m.sim].replica);
+    if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered on rank %d", sims[m.sim].matid, sims[m.sim].replica, c.rank);
+    if (c.rank == m.from) {
+      auto it = e->states.find(src_keys[m.sim]);
+      if (it == e->states.end())
+        return fail(e, SCEMA_MD_ERR_NOSTATE, "rank %d is recorded as the owner of state %s but does not hold it", c.rank, src_keys[m.sim].c_str());
+      src[k] = it->second.get();
+      std::memcpy(&hbox[9 * (size_t)k], src[k]->box, 9 * sizeof(double));
+    }
+    if (c.rank == m.to) {
+      int rc = make_empty_state(e, t, incoming[m.sim]);
+      if (rc) return rc;
+    }
+  }
+  if (c.kind == 1) {
+    HIPCHK(c.d_box.ensure(hbox.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(c.d_box.p, hbox.data(), hbox.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    NCCLCHK(ncclGroupStart());
+    for (int k = 0; k < nm; k++) {
+      const scema::PlanMove &m = plan.moves[k];
+      double *dbox = c.d_box.as<double>() + 9 * (size_t)k;
+      if (c.rank == m.from) {
+        const size_t cnt = 3 * (size_t)src[k]->topo->natoms;
+        NCCLCHK(ncclSend(src[k]->x.p, cnt, ncclDouble, m.to, c.nccl, e->stream));
+        NCCLCHK(ncclSend(src[k]->v.p, cnt, ncclDouble, m.to, c.nccl, e->stream));
+        NCCLCHK(ncclSend(dbox, 9, ncclDouble, m.to, c.nccl, e->stream));
+      }
+      if (c.rank == m.to) {
+        State *d = incoming[m.sim].get();
+        const size_t cnt = 3 * (size_t)d->topo->natoms;
+        NCCLCHK(ncclRecv(d->x.p, cnt, ncclDouble, m.from, c.nccl, e->stream));
+        NCCLCHK(ncclRecv(d->v.p, cnt, ncclDouble, m.from, c.nccl, e->stream));
+        NCCLCHK(ncclRecv(dbox, 9, ncclDouble, m.from, c.nccl, e->stream));
+      }
+    }
+    NCCLCHK(ncclGroupEnd());
+    HIPCHK(hipMemcpyAsync(hbox.data(), c.d_box.p, hbox.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < nm; k++)
+      if (c.rank == plan.moves[k].to) std::memcpy(incoming[plan.moves[k].sim]->box, &hbox[9 * (size_t)k], 9 * sizeof(double));
+  } else {
+    if (!c.send || !c.recv) return fail(e, SCEMA_MD_ERR_ARG, "the host communicator has no send/recv callbacks: replica states cannot move between ranks");
+    std::vector<double> buf;
+    for (int k = 0; k < nm; k++) {
+      const scema::PlanMove &m = plan.moves[k];
+      if (c.rank != m.from && c.rank != m.to) continue;
+      State *st = (c.rank == m.from) ? src[k] : incoming[m.sim].get();
+      const size_t n3 = 3 * (size_t)st->topo->natoms;
+      buf.resize(2 * n3 + 9);
+      if (c.rank == m.from) {
+        HIPCHK(hipMemcpyAsync(buf.data(), st->x.p, n3 * 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(buf.data() + n3, st->v.p, n3 * 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        std::memcpy(buf.data() + 2 * n3, st->box, 9 * sizeof(double));
+        if (c.send(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.to)) return fail(e, SCEMA_MD_ERR_DEVICE, "host send of a replica state to rank %d failed", m.to);
+      } else {
+        if (c.recv(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.from)) return fail(e, SCEMA_MD_ERR_DEVICE, "host receive of a replica state from rank %d failed", m.from);
+        HIPCHK(hipMemcpyAsync(st->x.p, buf.data(), n3 * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(st->v.p, buf.data() + n3, n3 * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        std::memcpy(st->box, buf.data() + 2 * n3, 9 * sizeof(double));
+      }
+    }
+  }
+  c.migrations += nm;
+  return SCEMA_MD_OK;
+}
+
+// ONE all-gather of 6*cap doubles per rank, then every rank fills every sims[i].stress (all ranks hold all stresses, so
+// the second share_scale_bridging_data broadcast of the caller, dealammps.cc:458, is not needed).
+int allgather_stresses(scema_md_engine *e, const std::vector<double> &local, scema_mdsim *sims, int n_sims) {
+  Comm &c = e->comm;
+  const scema::SimPlan &plan = e->last_plan;
+  const size_t cnt = 6 * (size_t)std::max(plan.cap, 1);
+  c.h_gather.assign(cnt * c.world, 0.0);
+  if (c.kind == 1) {
+    HIPCHK(c.d_gather.ensure(cnt * c.world * sizeof(double)));
+    NCCLCHK(ncclAllGather(e->d_local_stress.p, c.d_gather.p, cnt, ncclDouble, c.nccl, e->stream));
+    HIPCHK(hipMemcpyAsync(c.h_gather.data(), c.d_gather.p, cnt * c.world * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  } else {
+    if (!c.ag || c.ag(c.ctx, local.data(), c.h_gather.data(), (int64_t)(cnt * sizeof(double))))
+      return fail(e, SCEMA_MD_ERR_DEVICE, "host all-gather of the stresses failed");
+  }
+  c.allgathers += 1;
+  for (int i = 0; i < n_sims; i++) {
+    const double *src = c.h_gather.data() + ((size_t)plan.owner[i] * cnt + 6 * (size_t)plan.pos[i]);
+    for (int k = 0; k < 6; k++) sims[i].stress[k] = src[k];
+    sims[i].stress_updated = 1;
+  }
+  return SCEMA_MD_OK;
 }
 
 }  // namespace
@@ -1393,6 +1566,9 @@ void scema_md_destroy(scema_md_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->p.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  scema_md_comm_destroy(e);
+  e->comm.d_gather.release();
+  e->comm.d_box.release();
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -1419,6 +1595,7 @@ int scema_md_register_replica(scema_md_engine *e, const char *matid, int32_t rep
     if (k.size() >= suffix.size() && k.compare(k.size() - suffix.size(), suffix.size(), suffix) == 0) it = e->states.erase(it);
     else ++it;
   }
+  e->dir.erase_suffix(suffix);
   e->topos[topo_key(matid, replica)] = std::move(t);
   return SCEMA_MD_OK;
 }
@@ -1500,55 +1677,110 @@ int scema_md_load_replica_file(scema_md_engine *e, const char *matid, int32_t re
 }
 
 // ---- the hot path ----
+// straining steps of a request (stmd_problem.h:213-232) for a box of the given lengths
+static int nts_rule(const scema_mdsim &m, const double lb[3], double eps[6], double *norm) {
+  const double *sl = m.strain;
+  eps[0] = sl[0] / lb[0]; eps[1] = sl[1] / lb[1]; eps[2] = sl[2] / lb[2];
+  eps[3] = sl[3] / lb[2];  // [0][1] /= lbdim[2]
+  eps[5] = sl[5] / lb[0];  // [1][2] /= lbdim[0]
+  eps[4] = sl[4] / lb[1];  // [2][0] /= lbdim[1]
+  // stmd_problem.h:229-232
+  const double nrm = std::sqrt(eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2] + 2.0 * (eps[3] * eps[3] + eps[4] * eps[4] + eps[5] * eps[5]));
+  if (norm) *norm = nrm;
+  if (!std::isfinite(nrm) || !(m.strain_rate > 0.0) || !(m.timestep_length > 0.0)) return 10;
+  const double steps = nrm / m.strain_rate / m.timestep_length;
+  if (!(steps < 1.0e7)) return 10;
+  return std::max((int)(std::ceil(steps / 10.0) * 10), 10);
+}
+
 int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims, int32_t hooke_mode, int32_t rank, int32_t world) {
   if (!e || (!sims && n_sims > 0) || n_sims < 0 || world <= 0 || rank < 0 || rank >= world) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
+  if (e->comm.kind && (e->comm.rank != rank || e->comm.world != world))
+    return fail(e, SCEMA_MD_ERR_ARG, "rank/world (%d/%d) differ from the attached communicator (%d/%d)", rank, world, e->comm.rank, e->comm.world);
   HIPCHK(hipSetDevice(e->p.device));
-  const int per_rank = (n_sims + world - 1) / world;
-  e->local_stress_count = per_rank;
-  HIPCHK(e->d_local_stress.ensure((size_t)std::max(per_rank, 1) * 6 * sizeof(double)));
-  std::vector<double> local(6 * (size_t)std::max(per_rank, 1), 0.0);
-  std::vector<ActiveSim> act;
+  // ---- who runs what (host/sim_plan.h): identical on every rank ----
+  std::vector<std::string> src_keys(n_sims), dst_keys(n_sims);
+  std::vector<double> cost(n_sims, 1.0);
   for (int i = 0; i < n_sims; i++) {
     sims[i].stress_updated = 0;
     // stmd_problem.h:462-467
     const char *ff = sims[i].force_field ? sims[i].force_field : "";
     if (std::strcmp(ff, "opls") != 0 && std::strcmp(ff, "reax") != 0)
       return fail(e, SCEMA_MD_ERR_ARG, "Error: Force field is %s but only 'opls' and 'reax' are implemented... ", ff);
-    if (i % world != rank) continue;
+    if (hooke_mode) continue;   // sigma = C:eps has no state: the fresh-batch rule of the planner = i % world (stmd_sync.h:583)
+    if (std::strcmp(ff, "reax") == 0) return fail(e, SCEMA_MD_ERR_ARG, "force field 'reax' is not built yet (SURVEY row f-4)");
+    dst_keys[i] = state_key(sims[i].qp_id, sims[i].matid, sims[i].replica);
+    // stmd_problem.h:116-120: the state is read under most_recent_qp_id ("none" -> init.<mat>_<rep>.bin)
+    if (sims[i].most_recent_qp_id == sims[i].qp_id) src_keys[i] = dst_keys[i];
+    else if (sims[i].most_recent_qp_id != SCEMA_MD_QP_NONE) src_keys[i] = state_key(sims[i].most_recent_qp_id, sims[i].matid, sims[i].replica);
+    // cost = MD steps of the evaluation, estimated with the replica's initial box (known to every rank)
+    if (Topo *t = find_topo(e, sims[i].matid, sims[i].replica)) {
+      const double lb0[3] = {t->init_box[3] - t->init_box[0], t->init_box[4] - t->init_box[1], t->init_box[5] - t->init_box[2]};
+      double eps0[6];
+      cost[i] = (double)nts_rule(sims[i], lb0, eps0, nullptr) + (double)std::max(sims[i].nsteps_sample, 1);
+    }
+  }
+  e->last_plan = e->dir.plan(src_keys, dst_keys, cost, world);
+  const scema::SimPlan &plan = e->last_plan;
+  const int per_rank = plan.cap;
+  e->local_stress_count = per_rank;
+  HIPCHK(e->d_local_stress.ensure((size_t)std::max(per_rank, 1) * 6 * sizeof(double)));
+  std::vector<double> local(6 * (size_t)std::max(per_rank, 1), 0.0);
+  // ---- states that have to change GPU first ----
+  std::map<int, std::unique_ptr<State>> incoming;
+  if (!hooke_mode && !plan.moves.empty()) {
+    if (!e->comm.kind) {
+      const scema::PlanMove &m = plan.moves[0];
+      return fail(e, SCEMA_MD_ERR_NOSTATE, "the state %s that quadrature point %d continues from lives on rank %d but the simulation is planned on rank %d: "
+                  "attach a communicator (scema_md_comm_init_rccl / scema_md_comm_init_host) so that states can move between GPUs",
+                  src_keys[m.sim].c_str(), sims[m.sim].qp_id, m.from, m.to);
+    }
+    int rc = migrate_states(e, sims, plan, src_keys, incoming);
+    if (rc) return rc;
+  }
+  // ---- this rank's share ----
+  std::vector<ActiveSim> act;
+  struct Created { std::string key; std::unique_ptr<State> displaced; };
+  std::vector<Created> created;
+  auto undo = [&]() {   // a failed update leaves the state store as it found it (the reference stops before write_restart)
+    for (auto it = created.rbegin(); it != created.rend(); ++it) {
+      if (it->displaced) e->states[it->key] = std::move(it->displaced);
+      else e->states.erase(it->key);
+    }
+    created.clear();
+  };
+  for (int i = 0; i < n_sims; i++) {
+    if (plan.owner[i] != rank) continue;
     if (hooke_mode) {
       hooke(sims[i].stiffness, sims[i].strain, sims[i].stress);
       sims[i].stress_updated = 1;
       continue;
     }
-    if (std::strcmp(ff, "reax") == 0) return fail(e, SCEMA_MD_ERR_ARG, "force field 'reax' is not built yet (SURVEY row f-4)");
     ActiveSim A;
-    int rc = resolve_state(e, sims[i], &A.st);
-    if (rc) return rc;
+    bool was_created = false;
+    std::unique_ptr<State> displaced;
+    auto inc = incoming.find(i);
+    int rc = resolve_state(e, sims[i], &A.st, inc == incoming.end() ? nullptr : &inc->second, &was_created, &displaced);
+    if (rc) { undo(); return rc; }
+    if (was_created) created.push_back({dst_keys[i], std::move(displaced)});
     A.user_index = i;
     // stmd_problem.h:213-225
     const double lb[3] = {A.st->box[3] - A.st->box[0], A.st->box[4] - A.st->box[1], A.st->box[5] - A.st->box[2]};
-    const double *sl = sims[i].strain;
-    double eps[6];
-    eps[0] = sl[0] / lb[0]; eps[1] = sl[1] / lb[1]; eps[2] = sl[2] / lb[2];
-    eps[3] = sl[3] / lb[2];  // [0][1] /= lbdim[2]
-    eps[5] = sl[5] / lb[0];  // [1][2] /= lbdim[0]
-    eps[4] = sl[4] / lb[1];  // [2][0] /= lbdim[1]
-    // stmd_problem.h:229-232
-    const double nrm = std::sqrt(eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2] + 2.0 * (eps[3] * eps[3] + eps[4] * eps[4] + eps[5] * eps[5]));
+    double eps[6], nrm = 0.0;
+    const int nts = nts_rule(sims[i], lb, eps, &nrm);
     // requests that cannot be run: LAMMPS would stop while parsing "variable ceeps_.. equal nan" or "timestep 0"
-    if (!std::isfinite(nrm)) return fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: non-finite strain", sims[i].qp_id);
-    if (!(sims[i].strain_rate > 0.0) || !std::isfinite(sims[i].strain_rate) || !(sims[i].timestep_length > 0.0) ||
-        !std::isfinite(sims[i].timestep_length) || !(sims[i].temperature > 0.0) || !std::isfinite(sims[i].temperature))
-      return fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: strain rate, time step and temperature must be positive and finite", sims[i].qp_id);
-    const double strain_time = nrm / sims[i].strain_rate;
-    if (strain_time / sims[i].timestep_length > 1.0e7)
-      return fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: %.3g straining steps requested (strain norm %.3g at rate %.3g per fs)",
-                  sims[i].qp_id, strain_time / sims[i].timestep_length, nrm, sims[i].strain_rate);
-    int nts = (int)(std::ceil((strain_time / sims[i].timestep_length) / 10.0) * 10);
-    nts = std::max(nts, 10);
+    int bad = 0;
+    if (!std::isfinite(nrm)) bad = fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: non-finite strain", sims[i].qp_id);
+    else if (!(sims[i].strain_rate > 0.0) || !std::isfinite(sims[i].strain_rate) || !(sims[i].timestep_length > 0.0) ||
+             !std::isfinite(sims[i].timestep_length) || !(sims[i].temperature > 0.0) || !std::isfinite(sims[i].temperature))
+      bad = fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: strain rate, time step and temperature must be positive and finite", sims[i].qp_id);
+    else if (nrm / sims[i].strain_rate / sims[i].timestep_length > 1.0e7)
+      bad = fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: %.3g straining steps requested (strain norm %.3g at rate %.3g per fs)",
+                 sims[i].qp_id, nrm / sims[i].strain_rate / sims[i].timestep_length, nrm, sims[i].strain_rate);
+    else if (sims[i].nsteps_sample < 1) bad = fail(e, SCEMA_MD_ERR_ARG, "number of sampling steps must be >= 1");
+    if (bad) { undo(); return bad; }
     A.nts = nts;
     A.nss = sims[i].nsteps_sample;
-    if (A.nss < 1) return fail(e, SCEMA_MD_ERR_ARG, "number of sampling steps must be >= 1");
     A.dt = round_trip("%f", sims[i].timestep_length);
     A.temperature = round_trip("%f", sims[i].temperature);
     for (int k = 0; k < 6; k++) A.rates[k] = round_trip("%.6e", eps[k] / (nts * sims[i].timestep_length));
@@ -1571,25 +1803,38 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   }
   for (size_t off = 0; off < act.size(); off += maxb) {
     std::vector<ActiveSim> chunk(act.begin() + off, act.begin() + std::min(act.size(), off + (size_t)maxb));
-    // rates are consumed per attempt: keep a copy for retries
     int rc = eval_chunk(e, chunk);
-    if (rc) return rc;
+    if (rc) { undo(); return rc; }
     for (auto &A : chunk) {
       scema_mdsim &m = sims[A.user_index];
       for (int k = 0; k < 6; k++) m.stress[k] = A.pavg[k] * (-1.0) * 1.01325e+05;  // stmd_problem.h:340
       // a replica that blew up (overlapping atoms, a time step far too long) must not hand NaN to the FE solver:
       // LAMMPS would stop with "lost atoms" / "bond atoms missing" at this point
       for (int k = 0; k < 6; k++)
-        if (!std::isfinite(m.stress[k]))
+        if (!std::isfinite(m.stress[k])) {
+          undo();
           return fail(e, SCEMA_MD_ERR_ARG, "simulation of quadrature point %d (material %s, replica %d) produced a non-finite stress: unstable state or parameters",
                       m.qp_id, m.matid ? m.matid : "?", m.replica);
+        }
       m.stress_updated = 1;
     }
   }
-  for (int i = rank; i < n_sims; i += world)
-    if (sims[i].stress_updated)
-      for (int k = 0; k < 6; k++) local[6 * (size_t)(i / world) + k] = sims[i].stress[k];
-  HIPCHK(hipMemcpy(e->d_local_stress.p, local.data(), local.size() * sizeof(double), hipMemcpyHostToDevice));
+  // ---- bookkeeping: every state now lives under its own key on the rank that ran it; stale copies elsewhere go ----
+  if (!hooke_mode && world > 1) {
+    e->dir.commit(plan, dst_keys);
+    for (int i = 0; i < n_sims; i++)
+      if (plan.owner[i] != rank) e->states.erase(dst_keys[i]);
+  }
+  for (int i = 0; i < n_sims; i++)
+    if (plan.owner[i] == rank && sims[i].stress_updated)
+      for (int k = 0; k < 6; k++) local[6 * (size_t)plan.pos[i] + k] = sims[i].stress[k];
+  HIPCHK(hipMemcpyAsync(e->d_local_stress.p, local.data(), local.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  // ---- the one collective of the update (replaces STMDSync::share_stresses, stmd_sync.h:620-726) ----
+  if (e->comm.kind && world > 1) {
+    int rc = allgather_stresses(e, local, sims, n_sims);
+    if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
   return SCEMA_MD_OK;
 }
 
@@ -1601,21 +1846,126 @@ int32_t scema_md_local_stress_count(const scema_md_engine *e) { return e ? e->lo
 int scema_md_copy_local_stress(scema_md_engine *e, void *dst, int32_t dst_on_device) {
   if (!e || !dst) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
-  HIPCHK(hipMemcpy(dst, e->d_local_stress.p, (size_t)std::max(e->local_stress_count, 0) * 6 * sizeof(double),
-                   dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
-  // a device-to-device hipMemcpy may return before it has run: the caller hands dst to a collective on another stream
-  if (dst_on_device) HIPCHK(hipStreamSynchronize(nullptr));
+  HIPCHK(hipMemcpyAsync(dst, e->d_local_stress.p, (size_t)std::max(e->local_stress_count, 0) * 6 * sizeof(double),
+                        dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
+  // the caller hands dst to a collective on another stream
+  HIPCHK(hipStreamSynchronize(e->stream));
   return SCEMA_MD_OK;
 }
 
-int scema_md_scatter_gathered(const double *gathered, int32_t world, scema_mdsim *sims, int32_t n_sims) {
-  if (!gathered || !sims || world <= 0) return SCEMA_MD_ERR_ARG;
-  const int per_rank = (n_sims + world - 1) / world;
+int scema_md_last_plan(const scema_md_engine *e, int32_t n_sims, int32_t *owner, int32_t *pos, int32_t *cap) {
+  if (!e || n_sims != (int)e->last_plan.owner.size()) return SCEMA_MD_ERR_ARG;
   for (int i = 0; i < n_sims; i++) {
-    const double *src = gathered + ((size_t)(i % world) * per_rank + (size_t)(i / world)) * 6;
+    if (owner) owner[i] = e->last_plan.owner[i];
+    if (pos) pos[i] = e->last_plan.pos[i];
+  }
+  if (cap) *cap = e->last_plan.cap;
+  return SCEMA_MD_OK;
+}
+
+int scema_md_scatter_gathered(const scema_md_engine *e, const double *gathered, scema_mdsim *sims, int32_t n_sims) {
+  if (!e || !gathered || !sims || n_sims != (int)e->last_plan.owner.size()) return SCEMA_MD_ERR_ARG;
+  const scema::SimPlan &plan = e->last_plan;
+  const size_t cnt = 6 * (size_t)std::max(plan.cap, 0);
+  for (int i = 0; i < n_sims; i++) {
+    const double *src = gathered + ((size_t)plan.owner[i] * cnt + 6 * (size_t)plan.pos[i]);
     for (int k = 0; k < 6; k++) sims[i].stress[k] = src[k];
     sims[i].stress_updated = 1;
   }
+  return SCEMA_MD_OK;
+}
+
+// ---- communicator (one process per GPU) ----
+int scema_md_comm_unique_id(void *id) {
+  if (!id) return SCEMA_MD_ERR_ARG;
+  static_assert(SCEMA_MD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return SCEMA_MD_ERR_DEVICE;
+  std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return SCEMA_MD_OK;
+}
+
+int scema_md_comm_init_rccl(scema_md_engine *e, const void *id, int32_t rank, int32_t world) {
+  if (!e || !id || world <= 0 || rank < 0 || rank >= world) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
+  if (e->comm.kind) return fail(e, SCEMA_MD_ERR_ARG, "a communicator is already attached");
+  HIPCHK(hipSetDevice(e->p.device));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  NCCLCHK(ncclCommInitRank(&e->comm.nccl, world, u, rank));
+  e->comm.kind = 1;
+  e->comm.rank = rank;
+  e->comm.world = world;
+  return SCEMA_MD_OK;
+}
+
+int scema_md_comm_init_host(scema_md_engine *e, int32_t rank, int32_t world, scema_md_host_allgather_fn allgather, scema_md_host_send_fn send,
+                            scema_md_host_recv_fn recv, void *ctx) {
+  if (!e || !allgather || world <= 0 || rank < 0 || rank >= world) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
+  if (e->comm.kind) return fail(e, SCEMA_MD_ERR_ARG, "a communicator is already attached");
+  e->comm.kind = 2;
+  e->comm.rank = rank;
+  e->comm.world = world;
+  e->comm.ag = allgather;
+  e->comm.send = send;
+  e->comm.recv = recv;
+  e->comm.ctx = ctx;
+  return SCEMA_MD_OK;
+}
+
+void scema_md_comm_destroy(scema_md_engine *e) {
+  if (!e || !e->comm.kind) return;
+  (void)hipSetDevice(e->p.device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->comm.kind == 1 && e->comm.nccl) (void)ncclCommDestroy(e->comm.nccl);
+  e->comm.nccl = nullptr;
+  e->comm.kind = 0;
+  e->comm.rank = 0;
+  e->comm.world = 1;
+  e->comm.ag = nullptr; e->comm.send = nullptr; e->comm.recv = nullptr; e->comm.ctx = nullptr;
+}
+
+int32_t scema_md_comm_world(const scema_md_engine *e) { return (e && e->comm.kind) ? e->comm.world : 1; }
+int32_t scema_md_comm_rank(const scema_md_engine *e) { return (e && e->comm.kind) ? e->comm.rank : 0; }
+
+int scema_md_comm_stats(const scema_md_engine *e, int64_t *allgathers, int64_t *migrations) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  if (allgathers) *allgathers = e->comm.allgathers;
+  if (migrations) *migrations = e->comm.migrations;
+  return SCEMA_MD_OK;
+}
+
+// the recorded owner of a state: rank, or -1 when no rank is recorded (the state, if it exists, is held locally)
+int32_t scema_md_state_owner(const scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica) {
+  return e ? e->dir.owner_of(state_key(qp_id, matid, replica)) : -1;
+}
+
+// ---- the planner alone: pure host arithmetic (host/sim_plan.h), no GPU needed ----
+struct scema_plan_dir {
+  scema::OwnerDirectory dir;
+};
+scema_plan_dir *scema_plan_dir_create(void) { return new scema_plan_dir(); }
+void scema_plan_dir_destroy(scema_plan_dir *d) { delete d; }
+int scema_plan_update(scema_plan_dir *d, const scema_mdsim *sims, int32_t n_sims, const double *cost, int32_t world, int32_t *owner, int32_t *pos,
+                      int32_t *cap, int32_t *moves, int32_t *n_moves, int32_t commit) {
+  if (!d || (!sims && n_sims > 0) || n_sims < 0 || world <= 0) return SCEMA_MD_ERR_ARG;
+  std::vector<std::string> src(n_sims), dst(n_sims);
+  std::vector<double> c(n_sims, 1.0);
+  for (int i = 0; i < n_sims; i++) {
+    dst[i] = state_key(sims[i].qp_id, sims[i].matid, sims[i].replica);
+    if (sims[i].most_recent_qp_id == sims[i].qp_id) src[i] = dst[i];
+    else if (sims[i].most_recent_qp_id != SCEMA_MD_QP_NONE) src[i] = state_key(sims[i].most_recent_qp_id, sims[i].matid, sims[i].replica);
+    if (cost) c[i] = cost[i];
+  }
+  const scema::SimPlan P = d->dir.plan(src, dst, c, world);
+  for (int i = 0; i < n_sims; i++) {
+    if (owner) owner[i] = P.owner[i];
+    if (pos) pos[i] = P.pos[i];
+  }
+  if (cap) *cap = P.cap;
+  if (n_moves) *n_moves = (int32_t)P.moves.size();
+  if (moves)
+    for (size_t k = 0; k < P.moves.size(); k++) { moves[3 * k] = P.moves[k].sim; moves[3 * k + 1] = P.moves[k].from; moves[3 * k + 2] = P.moves[k].to; }
+  if (commit) d->dir.commit(P, dst);
   return SCEMA_MD_OK;
 }
 
@@ -1654,6 +2004,9 @@ int scema_md_set_state(scema_md_engine *e, int32_t qp_id, const char *matid, int
   int rc = make_state(e, t, box, x, v, false, ns);
   if (rc) return rc;
   e->states[state_key(qp_id, matid, replica)] = std::move(ns);
+  // a state handed over by the host is taken as present wherever it was handed over (every rank reads the same lcts.*
+  // files, stmd_sync.h:167-187): no rank is recorded as its only owner
+  e->dir.erase(state_key(qp_id, matid, replica));
   return SCEMA_MD_OK;
 }
 
@@ -1661,6 +2014,7 @@ int scema_md_drop_state(scema_md_engine *e, int32_t qp_id, const char *matid, in
   if (!e) return SCEMA_MD_ERR_ARG;
   (void)hipSetDevice(e->p.device);
   e->states.erase(state_key(qp_id, matid, replica));
+  e->dir.erase(state_key(qp_id, matid, replica));
   return SCEMA_MD_OK;
 }
 

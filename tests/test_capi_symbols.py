@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     from scema_amd import capi
     from scema_amd import stmd
     hdr = open(os.path.join(ROOT, "include", "scema_md.h")).read()
-    declared = set(re.findall(r"\b(scema_md_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(scema_(?:md|plan)_[a-z_]+)\s*\(", hdr))
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     hdr2 = open(os.path.join(ROOT, "include", "scema_stmd.h")).read()
     declared2 = set(re.findall(r"\b(scema_(?:stmd|eqmd)_[a-z_]+)\s*\(", hdr2))
