@@ -137,25 +137,8 @@ def main():
     extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
     eng = capi.Engine(capi.default_params(device=device, profile=1, **extra))
     if world > 1:
-        if args.dist_backend == "nccl":
-            uid = [eng.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            eng.comm_init_rccl(uid[0], rank, world)
-        else:
-            def _ag(b):
-                t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
-                parts = [torch.empty_like(t) for _ in range(world)]
-                dist.all_gather(parts, t)
-                return torch.cat(parts).numpy().tobytes()
-
-            def _send(b, dst):
-                dist.send(torch.frombuffer(bytearray(b), dtype=torch.uint8), dst)
-
-            def _recv(nb, src):
-                t = torch.empty(nb, dtype=torch.uint8)
-                dist.recv(t, src)
-                return t.numpy().tobytes()
-            eng.comm_init_host(rank, world, _ag, _send, _recv)
+        from scema_amd import comm
+        (comm.attach_rccl if args.dist_backend == "nccl" else comm.attach_gloo)(eng, rank, world)
 
     # ---- equilibrated replica (outside the timed region): rank 0 runs it, every rank registers the same state ----
     eng.register_replica("g0", 1, d)

@@ -1,0 +1,111 @@
+"""GPU: the N > 1 path of the engine itself -- two ranks (sharing the one GPU of the test box, the engine's host transport
+over gloo) run an update sequence in which the update_list shrinks, reorders and branches (FE_problem.h:1330-1350,
+stmd_problem.h:116-120) and a ragged batch forces a replica state to change rank.  Every stress must equal the
+single-rank run's: a state that stays behind, or is restarted from init because its owner changed, would show here."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+
+
+def sequence(lens):
+    """[(qp ids, most_recent ids, strains)] per update"""
+    from scema_amd import capi
+    def st(ezz, k):
+        return np.array([-0.3 * ezz * lens[0], -0.3 * ezz * lens[1], ezz * lens[2], 2e-5 * k * lens[2], -1e-5 * k * lens[1], 0.0])
+    u1 = ([0, 1, 2, 3, 4, 5], [capi.QP_NONE] * 6, [st(1.2e-3 + 1e-4 * k, k) for k in range(6)])
+    # shrunk + reordered; qp 4 gets a long straining run (nts 40); qp 7 branches from qp 2's state
+    u2 = ([4, 1, 5, 7], [4, 1, 5, 2], [st(7.0e-3, 1), st(1.0e-3, 2), st(-0.8e-3, 3), st(1.1e-3, 4)])
+    u3 = ([7, 0, 1, 2, 3, 4, 5], [7, 0, 1, 2, 3, 4, 5], [st(0.9e-3 + 1e-4 * k, k) for k in range(7)])
+    return [u1, u2, u3]
+
+
+def run_sequence(eng, lens, rank=0, world=1):
+    from scema_amd import capi
+    out = []
+    for qps, recent, strains in sequence(lens):
+        sims = [capi.make_sim(q, "pe", 1, s, nss=10, most_recent=r) for q, r, s in zip(qps, recent, strains)]
+        arr = eng.strain_batch(sims, rank=rank, world=world)
+        assert all(a.stress_updated for a in arr)
+        out.append(np.array([list(a.stress) for a in arr]))
+    return out
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+from scema_amd import capi, comm
+from scema_amd.systems import build_pe
+from test_gpu_multirank import KW, run_sequence
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+d = build_pe(2, 3, 5, jitter=0.05, seed=7)
+d["box"][6:9] = [0.7, -0.4, 0.5]
+eng = capi.Engine(capi.default_params(**KW))
+comm.attach_gloo(eng, rank, world)
+eng.register_replica("pe", 1, d)
+lens = d["box"][3:6] - d["box"][:3]
+out = run_sequence(eng, lens, rank, world)
+st = eng.comm_stats()
+owners = [eng.state_owner(q, "pe", 1) for q in range(8)]
+held = [int(eng.has_state(q, "pe", 1)) for q in range(8)]
+np.savez(sys.argv[2] + f".{rank}.npz", u1=out[0], u2=out[1], u3=out[2], stats=np.array([st["allgathers"], st["migrations"]]),
+         owners=np.array(owners), held=np.array(held))
+dist.barrier(); eng.close(); dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_follow_their_states_and_move_them_when_needed(tmp_path, small_pe):
+    from scema_amd import capi
+    (tmp_path / "worker.py").write_text(WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", str(tmp_path / "worker.py"), ROOT, str(tmp_path / "out")]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    ref = run_sequence(eng, lens)
+    eng.close()
+    got = [np.load(str(tmp_path / "out") + f".{k}.npz") for k in range(2)]
+    for k in range(2):
+        for u, name in enumerate(("u1", "u2", "u3")):
+            err = np.abs(got[k][name] - ref[u]).max() / np.abs(ref[u]).max()
+            assert err < 1e-8, (k, name, err)          # FP64 atomics only; a lost state would be O(1)
+        assert got[k]["stats"][0] == 3                  # ONE collective per update
+        assert got[k]["stats"][1] >= 1                  # the ragged second update moved a state
+    assert list(got[0]["owners"]) == list(got[1]["owners"])       # the directory is the same everywhere
+    # every state is held by exactly the rank recorded as its owner (qp 6 never existed)
+    for q in (0, 1, 2, 3, 4, 5, 7):
+        o = int(got[0]["owners"][q])
+        assert o in (0, 1) and got[o]["held"][q] == 1 and got[1 - o]["held"][q] == 0
+    assert got[0]["held"][6] == 0 and got[1]["held"][6] == 0
+
+
+def test_without_a_communicator_a_remote_source_state_is_an_error(small_pe):
+    """rank 0 of 2, nothing attached: its own share runs; a request that continues from a state rank 1 would hold says so."""
+    from scema_amd import capi
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+    sims = [capi.make_sim(q, "pe", 1, st, nss=10, most_recent=capi.QP_NONE) for q in range(4)]
+    out = eng.strain_batch(sims, rank=0, world=2)
+    assert [o.stress_updated for o in out] == [1, 0, 1, 0]
+    # qp 1 lives on rank 1 (recorded, not held here); a ragged batch that would pull it over cannot be served
+    big = st * 6.0
+    sims2 = [capi.make_sim(1, "pe", 1, st), capi.make_sim(3, "pe", 1, st), capi.make_sim(0, "pe", 1, st), capi.make_sim(9, "pe", 1, big, most_recent=3)]
+    with pytest.raises(capi.EngineError, match="communicator"):
+        eng.strain_batch(sims2, rank=0, world=2)
+    # the failed call left the store as it was: qp 0 continues normally
+    out3 = eng.strain_batch([capi.make_sim(0, "pe", 1, st), capi.make_sim(1, "pe", 1, st)], rank=0, world=2)
+    assert [o.stress_updated for o in out3] == [1, 0]
+    eng.close()
