@@ -254,7 +254,9 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
       }
     }
   }
-  if (nj > capj || nj > S.capj) {   // uniform: table overflow -> the engine regrows and retries
+  // k_pair keeps a wave's row headers in one VGPR triple (lane r = r-th row): at most 64 rows per wave, 64*TW clusters
+  // per cell.  A denser cell is reported like a table overflow (the engine retries with smaller cells), never dropped.
+  if (nj > capj || nj > S.capj || nown / NI > 64 * TW) {   // uniform: table overflow -> the engine regrows and retries
     if (threadIdx.x == 0) { S.tile_nj[cell] = 0; atomicOr(&sc.overflow, 1 | 4); atomicMax(&sc.maxj_seen, nj); }   // 4: table
     for (int cl = cs / NI + threadIdx.x; cl < ce / NI; cl += TT) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
     return;
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   // staged: none of that needs the LDS, so their latency runs under the table load and the barrier.
   const int p_begin = S.tile_wstart[(size_t)cell * (TW + 1) + wave], p_end = S.tile_wstart[(size_t)cell * (TW + 1) + wave + 1];
   const int nrows = (nj > 0) ? min(p_end - p_begin, 64) : 0;
+  if (p_end - p_begin > 64 && lane == 0) atomicOr(&sc.overflow, 1 | 4);   // cannot happen after k_neigh_build's check; loud if it ever does
   int h_cl = 0, h_nab = 0, h_nn = 0;
   if (lane < nrows) {
     h_cl = S.tile_order[cs / NI + p_begin + lane];

@@ -13,8 +13,14 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    # `-m gpu` tests must not silently pass on a box without a GPU
-    pass
+    # `-m gpu` tests must not silently pass (or skip) on a box without a GPU: the run is refused there
+    def no_gpu():
+        import torch
+        return not torch.cuda.is_available()
+
+    gpu_items = [it for it in items if it.get_closest_marker("gpu") is not None]
+    if gpu_items and "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or "") and no_gpu():
+        raise pytest.UsageError("tests marked `gpu` were selected but this box has no GPU: the engine has no CPU fallback")
 
 
 @pytest.fixture(scope="session", autouse=True)
