@@ -94,6 +94,8 @@ def main():
                     help="balanced: nts=10 for every replica (default, SURVEY 8d); file3d: x5 strains at rate 2e-4 (nts=30); "
                          "imbalanced: eps_zz log-uniform in [1e-3,2e-2] (nts 10..100)")
     ap.add_argument("--equil-steps", type=int, default=2000, help="NVT+SHAKE steps that equilibrate the synthetic crystal before anything is timed")
+    ap.add_argument("--equil-cache", default=None, help="npz file: load the equilibrated state from it if it exists, else write it (profiling runs: "
+                    "keeps the 2 000 single-replica steps out of a PMC pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
@@ -144,10 +146,15 @@ def main():
     eng.register_replica("g0", 1, d)
     if args.equil_steps > 0:
         state = [None]
-        if rank == 0:
+        if rank == 0 and args.equil_cache and os.path.exists(args.equil_cache):
+            z = np.load(args.equil_cache)
+            state[0] = (z["box"], z["x"], z["v"])
+        elif rank == 0:
             eng.set_state(EQ_QP, "g0", 1, d["box"], d["x"], d["v"])
             eng.debug_run("g0", 1, args.equil_steps, 2.0, 300.0, qp=EQ_QP, nvt=True, use_shake=True)
             state[0] = eng.get_state(EQ_QP, "g0", 1)
+            if args.equil_cache:
+                np.savez(args.equil_cache, box=state[0][0], x=state[0][1], v=state[0][2])
         if world > 1:
             dist.broadcast_object_list(state, src=0)
         box, x, v = state[0]

@@ -28,7 +28,7 @@ def test_two_rank_bench_spawns_its_ranks_and_matches_single_rank():
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     c1, c2 = one["config"]["stress_zz_checksum_Pa"], two["config"]["stress_zz_checksum_Pa"]
     assert abs(c1 - c2) <= 1e-8 * abs(c1), (c1, c2)      # FP64 atomics: summation order differs from run to run
-    assert two["config"]["allgathers"] == 2 and two["config"]["sims_on_rank0"] == 3     # one collective per timed update
+    assert two["config"]["allgathers"] == 3 and two["config"]["sims_on_rank0"] == 3     # ONE collective per update (1 warm-up + 2 timed)
     for k in ("metric", "value", "unit", "ms_per_step", "roofline", "scaling", "dtype"):
         assert k in two
 
