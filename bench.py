@@ -233,7 +233,7 @@ def main():
         # algorithmic bytes: N*(4*nbar + 56) + 48 per replica and launch.  full = nbar of a FULL per-atom list
         # inside cutoff + the reference's skin (what the engine counts at build time); stored = every pair once (half of it)
         full = prof["pair_alg_bytes"]
-        fixed = prof["pair_launches"] * per_rank * (56.0 * natoms + 48.0)
+        fixed = prof["pair_sims"] * (56.0 * natoms + 48.0)
         stored = 0.5 * (full - fixed) + fixed
         achieved = stored / pair_s / 1e9 if pair_s > 0 else 0.0
         roof = {"bound": "fp64_valu", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -244,10 +244,10 @@ def main():
                               "HIP-event time of the launches on the engine's stream; frac_full_list_equiv prices the full list instead",
                 "frac_full_list_equiv": full / pair_s / 1e9 / 8000.0 if pair_s > 0 else 0.0,
                 "launches": prof["pair_launches"], "avg_launch_ms": 1e3 * avg_launch_s,
-                "alg_bytes_per_launch": stored / launches, "sims_per_launch": per_rank,
+                "alg_bytes_per_launch": stored / launches, "sims_per_launch": prof["pair_sims"] / launches,
                 "rank0_pair_share_of_wall": pair_s / elapsed}
         if pmc:
-            scale = per_rank   # PMC figures are per replica and launch
+            scale = prof["pair_sims"] / launches   # PMC figures are per replica and launch
             roof["traffic"] = pmc["hbm_bytes_per_sim_step_corrected"] * scale
             roof["traffic_source"] = pmc.get("source", "profiles/pair_pmc.json")
             insts = pmc["valu_insts_per_sim_step"] * scale

@@ -22,7 +22,7 @@ extern "C" {
 #define SCEMA_MD_ERR_ARG 1        /* bad argument / unknown force field (stmd_problem.h:462-467) */
 #define SCEMA_MD_ERR_NOSTATE 2    /* required replica / state missing (stmd_problem.h:125-132 asserts) */
 #define SCEMA_MD_ERR_DEVICE 3     /* HIP runtime failure */
-#define SCEMA_MD_ERR_BOX 4        /* box smaller than 2*(cutoff+skin), or tilt flip needed */
+#define SCEMA_MD_ERR_BOX 4        /* box smaller than 2*(cutoff+skin) */
 #define SCEMA_MD_ERR_IO 5
 #define SCEMA_MD_ERR_OVERFLOW 6   /* neighbour capacity exceeded even after regrowth */
 
@@ -248,6 +248,8 @@ typedef struct {
   double unique_pairs_per_sim;/* average unique pairs within cutoff+skin at the last build */
   int64_t evals;
   double list_skin_mean;      /* mean neighbour-list skin of those evaluations: params.skin + the adaptive extra (performance only) */
+  int64_t pair_sims;          /* simulations summed over the timed pair launches (a large batch runs as two half batches) */
+  int64_t box_flips;          /* triclinic box flips applied during straining runs (fix deform, default flip yes) */
 } scema_md_profile;
 int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset);
 

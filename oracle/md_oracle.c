@@ -88,6 +88,7 @@ struct omd_sim {
   /* ewald */
   double g_ewald;
   int nk, *kn;
+  int nflips; /* box flips applied so far (fix deform flip yes) */
   int kspace_frozen;
   double qsqsum, qsum;
   /* neighbour list (half, newton on) */
@@ -444,6 +445,7 @@ double omd_tdof(const omd_sim *s) { return s->tdof; }
 double omd_g_ewald(const omd_sim *s) { return s->g_ewald; }
 int omd_nkvec(const omd_sim *s) { return s->nk; }
 int omd_npairs(const omd_sim *s) { return s->npairs; }
+int omd_nflips(const omd_sim *s) { return s->nflips; }
 void omd_last_timing(const omd_sim *s, double t[4]) {
   for (int k = 0; k < 4; k++) t[k] = s->timing[k];
 }
@@ -1230,6 +1232,43 @@ static double nh_energy(const omd_sim *s, double t_target) {
   return e;
 }
 
+/* ------------------------------------------------------------------ fix deform tilt rules */
+/* tilt[] = raw targets xy, xz, yz; moved by whole box lengths (new x length for xy and xz, new y length for yz) to the
+ * value closest to the current tilt RATIO (current tilt / current length), with LAMMPS' loop arithmetic */
+void omd_tilt_closest(double tilt[3], double xprd_new, double yprd_new, double xy, double xz, double yz, double xprd, double yprd) {
+  const double denom[3] = {xprd_new, xprd_new, yprd_new};
+  const double current[3] = {xy / xprd, xz / xprd, yz / yprd};
+  for (int i = 0; i < 3; i++) {
+    while (tilt[i] / denom[i] - current[i] > 0.0) tilt[i] -= denom[i];
+    while (tilt[i] / denom[i] - current[i] < 0.0) tilt[i] += denom[i];
+    if (fabs(tilt[i] / denom[i] - 1.0 - current[i]) < fabs(tilt[i] / denom[i] - current[i])) tilt[i] -= denom[i];
+  }
+}
+/* flip rule: returns 1 if a tilt (xy, xz, yz) exceeds half its box length; flipped[] = the tilts after the flip,
+ * nflip[] = lattice steps f_xy, f_xz, f_yz (a2' = a2 + f_xy a1, a3' = a3 + f_yz a2 + f_xz a1) */
+int omd_tilt_flip(const double tilt[3], double xprd, double yprd, double flipped[3], int nflip[3]) {
+  const double xprdinv = 1.0 / xprd, yprdinv = 1.0 / yprd;
+  flipped[0] = tilt[0]; flipped[1] = tilt[1]; flipped[2] = tilt[2];
+  nflip[0] = nflip[1] = nflip[2] = 0;
+  if (!(tilt[2] * yprdinv < -0.5 || tilt[2] * yprdinv > 0.5 || tilt[1] * xprdinv < -0.5 || tilt[1] * xprdinv > 0.5 ||
+        tilt[0] * xprdinv < -0.5 || tilt[0] * xprdinv > 0.5))
+    return 0;
+  if (flipped[2] * yprdinv < -0.5) {
+    flipped[2] += yprd;
+    flipped[1] += flipped[0];
+    nflip[2] = 1;
+  } else if (flipped[2] * yprdinv > 0.5) {
+    flipped[2] -= yprd;
+    flipped[1] -= flipped[0];
+    nflip[2] = -1;
+  }
+  if (flipped[1] * xprdinv < -0.5) { flipped[1] += xprd; nflip[1] = 1; }
+  if (flipped[1] * xprdinv > 0.5) { flipped[1] -= xprd; nflip[1] = -1; }
+  if (flipped[0] * xprdinv < -0.5) { flipped[0] += xprd; nflip[0] = 1; }
+  if (flipped[0] * xprdinv > 0.5) { flipped[0] -= xprd; nflip[0] = -1; }
+  return (nflip[0] || nflip[1] || nflip[2]) ? 1 : 0;
+}
+
 /* ------------------------------------------------------------------ run */
 static void pressure_tensor(const omd_sim *s, double p[6]) {
   boxq b;
@@ -1269,6 +1308,8 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
     lo0[d] = s->lo[d];
     hi0[d] = s->hi[d];
   }
+  int flip_pending = 0, flip_n[3] = {0, 0, 0};
+  double flip_tilt[3] = {0, 0, 0};
   /* fix ave/time 1 nav nav ... ave running (in.homogenization.lammps:57-59) */
   int nav = 0, nwin = 0;
   double psum[6] = {0};
@@ -1287,9 +1328,24 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
         s->x[3 * i + k] += dtv * s->v[3 * i + k];
       }
     }
-    /* neighbour decision */
+    /* neighbour decision; a pending box flip is applied first and forces the rebuild (fix deform next_reneighbor) */
     s->ago++;
-    if (s->ago >= s->p.neigh_delay && neigh_check(s)) neigh_build(s);
+    if (flip_pending) {
+      s->xy = flip_tilt[0];
+      s->xz = flip_tilt[1];
+      s->yz = flip_tilt[2];
+      /* the same reciprocal vectors in the new basis: n2 += f_xy n1, n3 += f_yz n2 + f_xz n1 (a2' = a2 + f_xy a1,
+       * a3' = a3 + f_yz a2 + f_xz a1); the k-vector SET of the run does not change */
+      for (int k = 0; k < s->nk; k++) {
+        int n1 = s->kn[3 * k], n2 = s->kn[3 * k + 1], n3 = s->kn[3 * k + 2];
+        s->kn[3 * k + 1] = n2 + flip_n[0] * n1;
+        s->kn[3 * k + 2] = n3 + flip_n[2] * n2 + flip_n[1] * n1;
+      }
+      flip_pending = 0;
+      s->nflips++;
+      neigh_build(s);
+    } else if (s->ago >= s->p.neigh_delay && neigh_check(s))
+      neigh_build(s);
     /* forces + SHAKE */
     force_compute(s);
     box_derive(s, &b);
@@ -1310,7 +1366,12 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
       pressure_tensor(s, p);
       for (int k = 0; k < 6; k++) psum[k] += p[k];
     }
-    /* end_of_step: fix deform (erate, remap x) */
+    /* end_of_step: fix deform (erate, remap x), default "flip yes" [LAMMPS 17Nov16 fix_deform.cpp end_of_step /
+     * pre_exchange, restated from its documented behaviour: SURVEY.md A.5].  Box lengths and raw tilt targets are linear
+     * in t from the box at the start of the run; a tilt target is then moved by whole box lengths to the value closest to
+     * the current tilt (so that it continues from a flipped box); the box takes the targets and the atoms are remapped
+     * affinely.  If a target then exceeds half a box length, the flipped tilts are recorded and applied at the start of
+     * the next step's reneighbouring (forced), where only the box representation changes: the lattice is the same. */
     if (rates) {
       double t = step * dt;
       double nlo[3], nhi[3];
@@ -1319,23 +1380,22 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
         nlo[d] = lo0[d] - 0.5 * L0 * rates[d] * t;
         nhi[d] = hi0[d] + 0.5 * L0 * rates[d] * t;
       }
-      double nxy = xy0 + rates[3] * (hi0[1] - lo0[1]) * t;
-      double nxz = xz0 + rates[4] * (hi0[2] - lo0[2]) * t;
-      double nyz = yz0 + rates[5] * (hi0[2] - lo0[2]) * t;
+      double tilt[3]; /* xy, xz, yz */
+      tilt[0] = xy0 + rates[3] * (hi0[1] - lo0[1]) * t;
+      tilt[1] = xz0 + rates[4] * (hi0[2] - lo0[2]) * t;
+      tilt[2] = yz0 + rates[5] * (hi0[2] - lo0[2]) * t;
       boxq bo;
       box_derive(s, &bo);
+      omd_tilt_closest(tilt, nhi[0] - nlo[0], nhi[1] - nlo[1], s->xy, s->xz, s->yz, s->hi[0] - s->lo[0], s->hi[1] - s->lo[1]);
       for (int d = 0; d < 3; d++) {
         s->lo[d] = nlo[d];
         s->hi[d] = nhi[d];
       }
-      s->xy = nxy;
-      s->xz = nxz;
-      s->yz = nyz;
+      s->xy = tilt[0];
+      s->xz = tilt[1];
+      s->yz = tilt[2];
       boxq bn;
       box_derive(s, &bn);
-      if (fabs(nxy) > 0.5 * bn.h[0] * 1.0000001 || fabs(nxz) > 0.5 * bn.h[0] * 1.0000001 ||
-          fabs(nyz) > 0.5 * bn.h[1] * 1.0000001)
-        return -1; /* box flip not restated */
       for (int i = 0; i < n; i++) {
         double d0 = s->x[3 * i] - bo.lo[0], d1 = s->x[3 * i + 1] - bo.lo[1], d2 = s->x[3 * i + 2] - bo.lo[2];
         double l0 = bo.hinv[0] * d0 + bo.hinv[5] * d1 + bo.hinv[4] * d2;
@@ -1345,6 +1405,7 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
         s->x[3 * i + 1] = bn.h[1] * l1 + bn.h[3] * l2 + bn.lo[1];
         s->x[3 * i + 2] = bn.h[2] * l2 + bn.lo[2];
       }
+      flip_pending = omd_tilt_flip(tilt, nhi[0] - nlo[0], nhi[1] - nlo[1], flip_tilt, flip_n);
     }
     if (trace) {
       double ke[6], p[6];

@@ -79,6 +79,10 @@ double omd_tdof(const omd_sim *s);
 double omd_g_ewald(const omd_sim *s);
 int omd_nkvec(const omd_sim *s);
 int omd_npairs(const omd_sim *s);   /* unique pairs currently in the neighbour list */
+int omd_nflips(const omd_sim *s);   /* triclinic box flips applied so far (fix deform, default flip yes) */
+/* fix deform's tilt rules (LAMMPS 17Nov16 fix_deform.cpp end_of_step), exposed for golden tests: tilt = xy, xz, yz */
+void omd_tilt_closest(double tilt[3], double xprd_new, double yprd_new, double xy, double xz, double yz, double xprd, double yprd);
+int omd_tilt_flip(const double tilt[3], double xprd, double yprd, double flipped[3], int nflip[3]);
 
 /* (Re)initialise run-level quantities exactly as a fresh LAMMPS "run" does:
  * g_ewald and the k-vector set from the current box, neighbour list rebuild.

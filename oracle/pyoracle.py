@@ -170,6 +170,10 @@ class Oracle:
         return lib().omd_npairs(self.h)
 
     @property
+    def nflips(self):
+        return lib().omd_nflips(self.h)
+
+    @property
     def nconstraints(self):
         return lib().omd_nconstraints(self.h)
 
@@ -223,6 +227,23 @@ def init_material(o: "Oracle", dt, temperature, nss, strain_ampl, strain_rate):
     stiff = np.array([[call[hv[i], hv[j]] for j in range(6)] for i in range(6)])
     o.set_state(box0, x0, v0)
     return length, stress, stiff
+
+
+def tilt_closest(tilt, xprd_new, yprd_new, xy, xz, yz, xprd, yprd):
+    """fix deform: raw tilt targets (xy, xz, yz) moved by whole box lengths to the value closest to the current tilt ratio"""
+    t = np.ascontiguousarray(tilt, dtype=np.float64).copy()
+    lib().omd_tilt_closest(_p(t), C.c_double(xprd_new), C.c_double(yprd_new), C.c_double(xy), C.c_double(xz), C.c_double(yz),
+                           C.c_double(xprd), C.c_double(yprd))
+    return t
+
+
+def tilt_flip(tilt, xprd, yprd):
+    """fix deform flip rule: (flipped?, tilts after the flip, lattice steps f_xy, f_xz, f_yz)"""
+    t = np.ascontiguousarray(tilt, dtype=np.float64)
+    out = np.zeros(3)
+    nf = np.zeros(3, dtype=np.int32)
+    rc = lib().omd_tilt_flip(_p(t), C.c_double(xprd), C.c_double(yprd), _p(out), _p(nf))
+    return bool(rc), out, nf
 
 
 def nts(true_strain, rate, dt) -> int:

@@ -3,13 +3,18 @@
 // History: term-centric kernels with FP64 atomics into global memory were atomic-rate
 // bound (dihedrals alone 14 % of the GPU time); the atom-centric, atomic-free kernel that replaced them
 // evaluated every dihedral four times and every angle three times and sat at 23 % VALU utilisation (a C
-// atom of polyethylene walks 48 terms serially).  Now every term is evaluated ONCE:
-//   * a tile = BT_OWNERS atoms that are consecutive in a breadth-first ranking of the bond graph, plus the
-//     terms whose lowest-ranked atom is one of them (built once per topology, md_engine.cpp build_topo);
-//   * the tile's atoms (owners + halo) get local indices; their positions are staged in LDS, the forces of
-//     all terms accumulate in LDS (ds_add_f64), and the tile is flushed with one global atomic triple per
-//     local atom into the bonded-force array fb, which is indexed by breadth-first rank: a tile's owners are
-//     128 consecutive entries and its halo lies next to them, so the atomics of a wave share cache lines;
+// atom of polyethylene walks 48 terms serially); tiles that evaluated every term once and flushed halo forces with
+// global FP64 atomics were bound by those atomics once the batch outgrew the caches (they execute at the memory
+// side: 1.56 ms per 576-replica step against 0.11 ms per 72).  Now:
+//   * a tile = BT_OWNERS atoms that are consecutive in a breadth-first ranking of the bond graph (its owners); it
+//     evaluates every term that touches an owner (built once per topology, md_engine.cpp build_topo), so a term
+//     that spans two tiles is evaluated twice -- a few per cent of the terms of a chain molecule -- and NO force
+//     ever crosses a tile: the owners' forces leave with plain coalesced stores into fb (indexed by rank), nothing
+//     is zeroed beforehand, no global atomic is issued;
+//   * the tile's atoms (owners first, then the halo) get local indices; their positions are staged in LDS and the
+//     forces of all terms accumulate in LDS (ds_add_f64);
+//   * virial and energies of a term are counted by ONE tile (the owner of its lowest-ranked atom; the others see
+//     BT_NOCOUNT on the term's first index); the lumped virial of a tile is stored per tile, without atomics;
 //   * kinds are processed one after the other, so the lanes of a wave run the same formula.
 //
 // Virial of a term = sum_a (r_a - r_ref) (x) F_a with r_ref = atom 3 for torsions, the vertex for angles,
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
   SimScalars &sc = *S.sc;
   __shared__ double s_red[8 * (BT_TPB / 64)];
   const int *desc = S.bt_desc + (size_t)blockIdx.x * BT_DESC;
-  const int nloc = desc[1];
+  const int nloc = desc[1], nown = desc[14];
   const int *atoms = S.bt_atoms + desc[0];
   double *s_x = s_bt, *s_f = s_bt + 3 * (size_t)maxloc;
   for (int l = threadIdx.x; l < nloc; l += BT_TPB) {
@@ -68,7 +73,8 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
   __syncthreads();
   double vsum[6] = {0, 0, 0, 0, 0, 0};
   // per-part sums straight to memory (parity hook: slow path, never timed)
-  auto emit = [&](int part, const double *v, double en) {
+  auto emit = [&](bool counted, int part, const double *v, double en) {
+    if (!counted) return;
     if (PARTS) {
       for (int k = 0; k < 6; k++)
         if (v[k] != 0.0) atomicAdd(&sc.vir[part * 6 + k], v[k]);
@@ -86,7 +92,8 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
     const double *cf = pass == 0 ? S.bond_cf : S.bondsh_cf;
     for (int t = threadIdx.x; t < nt; t += BT_TPB) {
       const int m = t0 + t;
-      const int l1 = at[2 * m], l2 = at[2 * m + 1];
+      const bool counted = !(at[2 * m] & BT_NOCOUNT);
+      const int l1 = at[2 * m] & BT_LMASK, l2 = at[2 * m + 1];
       const double K = cf[2 * m], r0 = cf[2 * m + 1];
       double d[3] = {s_x[3 * l1] - s_x[3 * l2], s_x[3 * l1 + 1] - s_x[3 * l2 + 1], s_x[3 * l1 + 2] - s_x[3 * l2 + 2]};
       minimg(b, d[0], d[1], d[2]);
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
       lds_add3(s_f, l2, f2);
       double v[6] = {0, 0, 0, 0, 0, 0};
       vt(v, d, f1);
-      emit(P_BOND, v, rk * dr);
+      emit(counted, P_BOND, v, rk * dr);
     }
   }
   // ---- angles ----
@@ -108,7 +115,8 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
     const int t0 = desc[2 + 2 * BT_ANGLE], nt = desc[3 + 2 * BT_ANGLE];
     for (int t = threadIdx.x; t < nt; t += BT_TPB) {
       const int m = t0 + t;
-      const int l1 = S.angle_at[3 * m], l2 = S.angle_at[3 * m + 1], l3 = S.angle_at[3 * m + 2];
+      const bool counted = !(S.angle_at[3 * m] & BT_NOCOUNT);
+      const int l1 = S.angle_at[3 * m] & BT_LMASK, l2 = S.angle_at[3 * m + 1], l3 = S.angle_at[3 * m + 2];
       const double K = S.angle_cf[2 * m], th0 = S.angle_cf[2 * m + 1];
       double d1[3], d2[3];
       for (int k = 0; k < 3; k++) { d1[k] = s_x[3 * l1 + k] - s_x[3 * l2 + k]; d2[k] = s_x[3 * l3 + k] - s_x[3 * l2 + k]; }
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
       lds_add3(s_f, l3, f3);
       double v[6] = {0, 0, 0, 0, 0, 0};
       vt(v, d1, f1); vt(v, d2, f3);
-      emit(P_ANGLE, v, tk * dth);
+      emit(counted, P_ANGLE, v, tk * dth);
     }
   }
   // ---- dihedrals (opls) and impropers (harmonic): same geometry, different dE/dcos ----
@@ -140,7 +148,8 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
     for (int t = threadIdx.x; t < nt; t += BT_TPB) {
       const int m = t0 + t;
       const int *at = atb + 4 * m;
-      const int l1 = at[0], l2 = at[1], l3 = at[2], l4 = at[3];
+      const bool counted = !(at[0] & BT_NOCOUNT);
+      const int l1 = at[0] & BT_LMASK, l2 = at[1], l3 = at[2], l4 = at[3];
       // F=r1-r2, G=r2-r3, H=r4-r3, A=FxG, B=HxG, c=A.B/(|A||B|)
       double F[3], G[3], H[3];
       for (int k = 0; k < 3; k++) {
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
       double v[6] = {0, 0, 0, 0, 0, 0};
       const double FG[3] = {F[0] + G[0], F[1] + G[1], F[2] + G[2]};
       vt(v, FG, f1); vt(v, G, f2); vt(v, H, f4);
-      emit(pass == 0 ? P_DIHEDRAL : P_IMPROPER, v, en);
+      emit(counted, pass == 0 ? P_DIHEDRAL : P_IMPROPER, v, en);
     }
   }
   // ---- special pairs: weighted real-space pair term (k-space minus (1-f_coul) q q / r) ----
@@ -205,12 +214,13 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
     const int np = S.coul_npoly;
     for (int t = threadIdx.x; t < nt; t += BT_TPB) {
       const int m = t0 + t;
-      const int l1 = S.special_at[2 * m], l2 = S.special_at[2 * m + 1];
+      const bool counted = !(S.special_at[2 * m] & BT_NOCOUNT);
+      const int l1 = S.special_at[2 * m] & BT_LMASK, l2 = S.special_at[2 * m + 1];
       const double *cf = S.special_cf + 6 * m;
       double d[3] = {s_x[3 * l1] - s_x[3 * l2], s_x[3 * l1 + 1] - s_x[3 * l2 + 1], s_x[3 * l1 + 2] - s_x[3 * l2 + 2]};
       minimg(b, d[0], d[1], d[2]);
       const double rsq = dot3(d, d);
-      if (rsq >= S.excl_cut2) atomicOr(&sc.overflow, 2);  // excluded pair escaped the build-time exclusion gate
+      if (rsq >= S.excl_cut2 && counted) atomicOr(&sc.overflow, 2);  // excluded pair escaped the build-time exclusion gate
       const double rinv = rsq64(rsq), r2inv = rinv * rinv;
       double flj = 0.0, fc = 0.0, en = 0.0, en2 = 0.0;
       if (rsq < S.cut_coul2 && g > 0.0) {
@@ -237,27 +247,35 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
         const double fl[3] = {d[0] * flj, d[1] * flj, d[2] * flj}, fq[3] = {d[0] * fc, d[1] * fc, d[2] * fc};
         vt(v, d, fl);
         vt(v2, d, fq);
-        emit(P_LJ, v, en);
-        emit(P_COUL, v2, en2);
-      } else {
+        emit(counted, P_LJ, v, en);
+        emit(counted, P_COUL, v2, en2);
+      } else if (counted) {
         vt(vsum, d, f1);
       }
     }
   }
   __syncthreads();
-  // flush: one atomic triple per local atom into fb (rank order; the tile's own atoms first = consecutive)
+  // flush: the owners' forces, plain coalesced stores (consecutive ranks = consecutive local indices); halo forces
+  // belong to the tiles that own those atoms, which evaluate the same terms themselves
   {
-    double *fb = S.fb;
-    const int *rk = S.bt_rank;
-    for (int l = threadIdx.x; l < nloc; l += BT_TPB) {
-      const double ax = s_f[3 * l], ay = s_f[3 * l + 1], az = s_f[3 * l + 2];
-      if (ax != 0.0 || ay != 0.0 || az != 0.0) {
-        const size_t r = (size_t)rk[atoms[l]];
-        atomicAdd(fb + 3 * r, ax); atomicAdd(fb + 3 * r + 1, ay); atomicAdd(fb + 3 * r + 2, az);
-      }
+    double *fb = S.fb + 3 * (size_t)blockIdx.x * BT_OWNERS;
+    for (int l = threadIdx.x; l < 3 * nown; l += BT_TPB) fb[l] = s_f[l];
+  }
+  if (!PARTS) {
+    // lumped virial of the tile (the pressure sums all parts anyway): one partial per tile, no atomics
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double sk = wave_sum(vsum[k]);
+      if (lane == 0) s_red[k * (BT_TPB / 64) + wave] = sk;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double sk = 0.0;
+      for (int w = 0; w < BT_TPB / 64; w++) sk += s_red[threadIdx.x * (BT_TPB / 64) + w];
+      S.virb[(size_t)blockIdx.x * 6 + threadIdx.x] = sk;
     }
   }
-  if (!PARTS) block_atomic_add<6>(vsum, sc.vir + P_BOND * 6, s_red);  // lumped: the pressure sums all parts anyway
 }
 
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int parts) {

@@ -109,7 +109,7 @@ struct State {
 struct Slot {
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
   size_t cap_jtab = 0;
-  DevBuf virp, fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
+  DevBuf virp, virb, fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
     DevBuf f, xq, stype, perm, slot_tmp, wrapn, xhold, cell_of, ckey, cell_count, cell_start, cell_fill, numneigh, neigh, sfac, kvec,
       xbak, vbak;
 };
@@ -142,6 +142,8 @@ struct Comm {
 struct Profile {
   long long pair_launches = 0;
   double pair_ms = 0, pair_alg_bytes = 0;
+  long long pair_sims = 0;   // simulations summed over the timed pair launches
+  long long box_flips = 0;   // triclinic box flips applied (fix deform, flip yes)
   long long md_steps = 0, neigh_builds = 0, evals = 0;
   double unique_pairs_sum = 0;
   long long unique_pairs_n = 0;
@@ -155,6 +157,10 @@ struct scema_md_engine {
   hipStream_t stream = nullptr;
   double skin_extra_fixed = -1.0;         // SCEMA_MD_SKIN_EXTRA: fixed extra list skin (0 = never adapt); < 0 = adaptive
   hipStream_t stream2 = nullptr;          // side stream: structure factors next to the bonded kernel
+  hipStream_t stream3 = nullptr;          // second half batch of a large launch group (run_phase)
+  hipEvent_t ev_up = nullptr;
+  bool split_streams = true;              // SCEMA_MD_SPLIT=0 switches the two-half pipeline off
+  int split_min = 32, split_max = 200;  // launch groups of this size range are split (larger ones gain nothing: measured 336 evals/s either way at 576)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::map<std::string, std::unique_ptr<Topo>> topos;
   std::map<std::string, std::unique_ptr<State>> states;
@@ -379,12 +385,15 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
     if (dih_at[k] < 0 || dih_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad dihedral atom");
   for (size_t k = 0; k < imp_at.size(); k++)
     if (imp_at[k] < 0 || imp_at[k] >= n) return fail(e, SCEMA_MD_ERR_ARG, "bad improper atom");
-  // ---- bonded tiles (md_bonded.hip): every term is evaluated once by the workgroup that owns it ----
+  // ---- bonded tiles (md_bonded.hip): no atomics, no zeroing ----
   // Atoms are ranked by a breadth-first walk of the bond graph, so that consecutive ranks are topological
-  // neighbours whatever the numbering of the input.  A tile = BT_OWNERS consecutive ranks; it owns the terms
-  // whose lowest-ranked atom is one of its owners, and carries the list of all atoms those terms touch
-  // (owners + a halo of up to three bonds): positions are staged and forces accumulated per tile in LDS under
-  // local indices, one flush per local atom.
+  // neighbours whatever the numbering of the input.  A tile = BT_OWNERS consecutive ranks (its owners).  It
+  // evaluates EVERY term that touches one of its owners and keeps only the forces on its owners, which it writes
+  // with plain coalesced stores (fb is indexed by rank): a term whose atoms span two tiles is evaluated by both
+  // (chain molecules cut every few hundred atoms: a few per cent of the terms; none for PE-10k, whose 96-atom
+  // rings fill a tile two by two) and counted once for the virial and the energies -- by the tile that owns its
+  // lowest-ranked atom (the others carry BT_NOCOUNT on their first atom index).  Positions of the tile's local
+  // atoms (owners first, then the halo of up to three bonds) are staged and forces accumulated per tile in LDS.
   std::vector<int> rank(n, -1), by_rank;
   by_rank.reserve(n);
   {
@@ -404,18 +413,26 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
     }
   }
   const int ntile = (n + BT_OWNERS - 1) / BT_OWNERS;
-  struct TermRef { int kind, idx; };
+  struct TermRef { int kind, idx, count; };
   std::vector<std::vector<TermRef>> tile_terms(ntile);
-  auto owner_tile = [&](const int *atoms, int cnt) {
-    int r = rank[atoms[0]];
-    for (int k = 1; k < cnt; k++) r = std::min(r, rank[atoms[k]]);
-    return r / BT_OWNERS;
+  auto add_term = [&](const int *atoms, int cnt, int kind, int idx) {
+    int rmin = rank[atoms[0]];
+    for (int k = 1; k < cnt; k++) rmin = std::min(rmin, rank[atoms[k]]);
+    int seen[4], ns_ = 0;
+    for (int k = 0; k < cnt; k++) {
+      const int tl = rank[atoms[k]] / BT_OWNERS;
+      bool dup = false;
+      for (int q = 0; q < ns_; q++) dup = dup || seen[q] == tl;
+      if (dup) continue;
+      seen[ns_++] = tl;
+      tile_terms[tl].push_back({kind, idx, tl == rmin / BT_OWNERS ? 1 : 0});
+    }
   };
-  for (int m = 0; m < s->nbonds; m++) tile_terms[owner_tile(&bond_at[2 * m], 2)].push_back({m < t.nbonds_noshake ? BT_BOND : BT_BOND_SHAKEN, m});
-  for (int m = 0; m < s->nangles; m++) tile_terms[owner_tile(&angle_at[3 * m], 3)].push_back({BT_ANGLE, m});
-  for (int m = 0; m < s->ndihedrals; m++) tile_terms[owner_tile(&dih_at[4 * m], 4)].push_back({BT_DIHEDRAL, m});
-  for (int m = 0; m < s->nimpropers; m++) tile_terms[owner_tile(&imp_at[4 * m], 4)].push_back({BT_IMPROPER, m});
-  for (int m = 0; m < t.nspecial; m++) tile_terms[owner_tile(&sp_at[2 * m], 2)].push_back({BT_SPECIAL, m});
+  for (int m = 0; m < s->nbonds; m++) add_term(&bond_at[2 * m], 2, m < t.nbonds_noshake ? BT_BOND : BT_BOND_SHAKEN, m);
+  for (int m = 0; m < s->nangles; m++) add_term(&angle_at[3 * m], 3, BT_ANGLE, m);
+  for (int m = 0; m < s->ndihedrals; m++) add_term(&dih_at[4 * m], 4, BT_DIHEDRAL, m);
+  for (int m = 0; m < s->nimpropers; m++) add_term(&imp_at[4 * m], 4, BT_IMPROPER, m);
+  for (int m = 0; m < t.nspecial; m++) add_term(&sp_at[2 * m], 2, BT_SPECIAL, m);
   // tile-ordered term arrays with local atom indices
   std::vector<int> bt_desc((size_t)ntile * BT_DESC, 0), bt_atoms;
   std::vector<int> l_at[BT_NKIND];
@@ -426,8 +443,10 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   for (int tl = 0; tl < ntile; tl++) {
     int *desc = &bt_desc[(size_t)tl * BT_DESC];
     desc[0] = (int)bt_atoms.size();
-    // local atom list sorted by rank: the tile's own atoms are consecutive, and so are the flush atomics of a wave
-    std::vector<int> members;
+    // local atom list: the owners in rank order (local index = rank - first rank of the tile), then the halo by rank
+    std::vector<int> members, halo;
+    const int r0 = tl * BT_OWNERS, r1 = std::min(n, r0 + BT_OWNERS);
+    for (int r = r0; r < r1; r++) { members.push_back(by_rank[r]); local_of[by_rank[r]] = r - r0; }
     auto term_atoms = [&](const TermRef &tr, int &cnt) -> const int * {
       const int m = tr.idx;
       cnt = natm[tr.kind];
@@ -438,10 +457,11 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
       int cnt;
       const int *at = term_atoms(tr, cnt);
       for (int k = 0; k < cnt; k++)
-        if (local_of[at[k]] < 0) { local_of[at[k]] = 0; members.push_back(at[k]); }
+        if (local_of[at[k]] < 0) { local_of[at[k]] = 0; halo.push_back(at[k]); }
     }
-    std::sort(members.begin(), members.end(), [&](int a, int b) { return rank[a] < rank[b]; });
-    for (size_t l = 0; l < members.size(); l++) local_of[members[l]] = (int)l;
+    std::sort(halo.begin(), halo.end(), [&](int a, int b) { return rank[a] < rank[b]; });
+    for (size_t l = 0; l < halo.size(); l++) { local_of[halo[l]] = (int)(members.size() + l); }
+    members.insert(members.end(), halo.begin(), halo.end());
     auto local = [&](int atom) { return local_of[atom]; };
     for (int kind = 0; kind < BT_NKIND; kind++) {
       desc[2 + 2 * kind] = (int)l_at[kind].size() / natm[kind];
@@ -466,7 +486,7 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
         const int m = tr.idx;
         const int *at = (kind <= BT_BOND_SHAKEN) ? &bond_at[2 * m] : (kind == BT_ANGLE) ? &angle_at[3 * m] : (kind == BT_DIHEDRAL) ? &dih_at[4 * m]
                         : (kind == BT_IMPROPER) ? &imp_at[4 * m] : &sp_at[2 * m];
-        for (int k = 0; k < natm[kind]; k++) l_at[kind].push_back(local(at[k]));
+        for (int k = 0; k < natm[kind]; k++) l_at[kind].push_back(local(at[k]) | ((k == 0 && !tr.count) ? BT_NOCOUNT : 0));
         if (kind <= BT_BOND_SHAKEN) { l_cf[kind].push_back(bond_cf[2 * m]); l_cf[kind].push_back(bond_cf[2 * m + 1]); }
         else if (kind == BT_ANGLE) { l_cf[kind].push_back(angle_cf[2 * m]); l_cf[kind].push_back(angle_cf[2 * m + 1]); }
         else if (kind == BT_DIHEDRAL) { for (int k = 0; k < 4; k++) l_cf[kind].push_back(dih_cf[4 * m + k]); }
@@ -484,6 +504,7 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
       desc[3 + 2 * kind] = cnt;
     }
     desc[1] = (int)members.size();
+    desc[14] = r1 - r0;   // owners
     t.bt_maxloc = std::max(t.bt_maxloc, (int)members.size());
     for (int atom : members) { bt_atoms.push_back(atom); local_of[atom] = -1; }
   }
@@ -531,6 +552,7 @@ struct EwaldSetup {
   std::vector<int> kgrp;   // groups of k-vectors (n1, +-n2, +-n3): n1, |n2|, |n3|, k index of (+,+), (-,+), (+,-), (-,-) or -1, pad
   int kmaxd[3] = {0, 0, 0};
 };
+void ewald_tables(EwaldSetup &out);
 void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, EwaldSetup &out) {
   out = EwaldSetup();
   if (t.qsqsum == 0.0) return;
@@ -573,16 +595,36 @@ void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, Ewa
         out.kmaxd[1] = std::max(out.kmaxd[1], std::abs(n2));
         out.kmaxd[2] = std::max(out.kmaxd[2], std::abs(n3));
       }
+  ewald_tables(out);
+}
+
+// row run lengths, (n1, +-n2, +-n3) groups and index ranges of a k-vector list; the list is put in lexicographic order
+// first (k_ewald_force walks it with a phase cursor).  Also used after a box flip, when the list of the run is
+// re-expressed in the new reciprocal basis.
+void ewald_tables(EwaldSetup &out) {
+  const int nk = (int)out.kn.size() / 3;
   {
-    const int nk0 = (int)out.kn.size() / 3;
-    out.krun.assign(nk0, 0);
-    for (int k = nk0 - 2; k >= 0; k--)
-      if (out.kn[3 * k] == out.kn[3 * k + 3] && out.kn[3 * k + 1] == out.kn[3 * k + 4] && out.kn[3 * k + 2] + 1 == out.kn[3 * k + 5])
-        out.krun[k] = out.krun[k + 1] + 1;
+    std::vector<int> idx(nk), kn2(out.kn.size());
+    for (int k = 0; k < nk; k++) idx[k] = k;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) {
+      for (int d = 0; d < 3; d++)
+        if (out.kn[3 * a + d] != out.kn[3 * b + d]) return out.kn[3 * a + d] < out.kn[3 * b + d];
+      return false;
+    });
+    for (int k = 0; k < nk; k++)
+      for (int d = 0; d < 3; d++) kn2[3 * k + d] = out.kn[3 * idx[k] + d];
+    out.kn.swap(kn2);
   }
+  out.krun.assign(nk, 0);
+  out.kgrp.clear();
+  for (int d = 0; d < 3; d++) out.kmaxd[d] = 0;
+  for (int k = 0; k < nk; k++)
+    for (int d = 0; d < 3; d++) out.kmaxd[d] = std::max(out.kmaxd[d], std::abs(out.kn[3 * k + d]));
+  for (int k = nk - 2; k >= 0; k--)
+    if (out.kn[3 * k] == out.kn[3 * k + 3] && out.kn[3 * k + 1] == out.kn[3 * k + 4] && out.kn[3 * k + 2] + 1 == out.kn[3 * k + 5])
+      out.krun[k] = out.krun[k + 1] + 1;
   // k-vectors that differ only in the signs of n2, n3 share every phase-factor product of k_ewald_sfac
   std::map<long, int> gidx;
-  const int nk = (int)out.kn.size() / 3;
   for (int k = 0; k < nk; k++) {
     const int n1 = out.kn[3 * k], n2 = out.kn[3 * k + 1], n3 = out.kn[3 * k + 2];
     const long key = ((long)n1 << 40) | ((long)std::abs(n2) << 20) | (long)std::abs(n3);
@@ -696,16 +738,75 @@ static double cached_coul_poly(scema_md_engine *, double g, double rc, double *p
   return it->second.err;
 }
 
-// fix-deform box at time t (same expression as k_post)
-void deform_box(const double *box0, const double *rates, double t, double *out) {
-  for (int d = 0; d < 3; d++) {
-    const double L0 = box0[3 + d] - box0[d];
-    out[d] = box0[d] - 0.5 * L0 * rates[d] * t;
-    out[3 + d] = box0[3 + d] + 0.5 * L0 * rates[d] * t;
+// fix deform's tilt rules (LAMMPS 17Nov16 fix_deform.cpp end_of_step; the oracle states them as omd_tilt_closest /
+// omd_tilt_flip, k_post as the same arithmetic on the device).  tilt = xy, xz, yz.
+void tilt_closest(double tilt[3], double xprd_new, double yprd_new, double xy, double xz, double yz, double xprd, double yprd) {
+  const double denom[3] = {xprd_new, xprd_new, yprd_new};
+  const double current[3] = {xy / xprd, xz / xprd, yz / yprd};
+  for (int i = 0; i < 3; i++) {
+    while (tilt[i] / denom[i] - current[i] > 0.0) tilt[i] -= denom[i];
+    while (tilt[i] / denom[i] - current[i] < 0.0) tilt[i] += denom[i];
+    if (std::fabs(tilt[i] / denom[i] - 1.0 - current[i]) < std::fabs(tilt[i] / denom[i] - current[i])) tilt[i] -= denom[i];
   }
-  out[6] = box0[6] + rates[3] * (box0[4] - box0[1]) * t;
-  out[7] = box0[7] + rates[4] * (box0[5] - box0[2]) * t;
-  out[8] = box0[8] + rates[5] * (box0[5] - box0[2]) * t;
+}
+int tilt_flip(const double tilt[3], double xprd, double yprd, double flipped[3], int nflip[3]) {
+  const double xprdinv = 1.0 / xprd, yprdinv = 1.0 / yprd;
+  flipped[0] = tilt[0]; flipped[1] = tilt[1]; flipped[2] = tilt[2];
+  nflip[0] = nflip[1] = nflip[2] = 0;
+  if (!(tilt[2] * yprdinv < -0.5 || tilt[2] * yprdinv > 0.5 || tilt[1] * xprdinv < -0.5 || tilt[1] * xprdinv > 0.5 ||
+        tilt[0] * xprdinv < -0.5 || tilt[0] * xprdinv > 0.5))
+    return 0;
+  if (flipped[2] * yprdinv < -0.5) { flipped[2] += yprd; flipped[1] += flipped[0]; nflip[2] = 1; }
+  else if (flipped[2] * yprdinv > 0.5) { flipped[2] -= yprd; flipped[1] -= flipped[0]; nflip[2] = -1; }
+  if (flipped[1] * xprdinv < -0.5) { flipped[1] += xprd; nflip[1] = 1; }
+  if (flipped[1] * xprdinv > 0.5) { flipped[1] -= xprd; nflip[1] = -1; }
+  if (flipped[0] * xprdinv < -0.5) { flipped[0] += xprd; nflip[0] = 1; }
+  if (flipped[0] * xprdinv > 0.5) { flipped[0] -= xprd; nflip[0] = -1; }
+  return (nflip[0] || nflip[1] || nflip[2]) ? 1 : 0;
+}
+
+// The box trajectory of a fix-deform run is known in advance (rates, dt, number of steps): the host walks it with the
+// arithmetic of k_post and finds the steps after which the triclinic box flips ("flip yes", the LAMMPS default used by
+// in.strain.lammps:94-100).  A flip is then enqueued between two steps of the device-side run: new tilts, a forced list
+// rebuild and the k-vector tables in the new reciprocal basis (run_phase).
+struct FlipEvent {
+  int step;          // the flip is detected at the end of this step and applied at the start of the next one
+  double tilt[3];    // xy, xz, yz after the flip
+  int nflip[3];      // lattice steps f_xy, f_xz, f_yz: a2' = a2 + f_xy a1, a3' = a3 + f_yz a2 + f_xz a1
+};
+void deform_trajectory(const double *box0, const double *rates, double dt, int nsteps, double *box_end, std::vector<FlipEvent> &events,
+                       std::vector<HostBox> &extremes) {
+  double cur[9];
+  std::memcpy(cur, box0, sizeof cur);
+  bool pending = false;
+  FlipEvent pe{};
+  for (int step = 1; step <= nsteps; step++) {
+    if (pending) {   // applied at the start of this step
+      cur[6] = pe.tilt[0]; cur[7] = pe.tilt[1]; cur[8] = pe.tilt[2];
+      events.push_back(pe);
+      pending = false;
+    }
+    const double t = step * dt;
+    double nb[9];
+    for (int d = 0; d < 3; d++) {
+      const double L0 = box0[3 + d] - box0[d];
+      nb[d] = box0[d] - 0.5 * L0 * rates[d] * t;
+      nb[3 + d] = box0[3 + d] + 0.5 * L0 * rates[d] * t;
+    }
+    double tilt[3] = {box0[6] + rates[3] * (box0[4] - box0[1]) * t, box0[7] + rates[4] * (box0[5] - box0[2]) * t,
+                      box0[8] + rates[5] * (box0[5] - box0[2]) * t};
+    tilt_closest(tilt, nb[3] - nb[0], nb[4] - nb[1], cur[6], cur[7], cur[8], cur[3] - cur[0], cur[4] - cur[1]);
+    nb[6] = tilt[0]; nb[7] = tilt[1]; nb[8] = tilt[2];
+    std::memcpy(cur, nb, sizeof cur);
+    pe.step = step;
+    if (tilt_flip(tilt, nb[3] - nb[0], nb[4] - nb[1], pe.tilt, pe.nflip)) {
+      pending = true;   // a flip that falls behind the last step of the run is never applied (the fix is gone by then)
+      HostBox hb;
+      box_derive(cur, hb);
+      extremes.push_back(hb);
+    }
+  }
+  std::memcpy(box_end, cur, sizeof cur);
 }
 
 double wall_s() {
@@ -738,6 +839,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.slot_of.ensure((size_t)natoms * 4));
     HIPCHK(sl.fs.ensure(3 * (size_t)npad * 8));
     HIPCHK(sl.fb.ensure(3 * (size_t)npad * 8));
+    HIPCHK(sl.virb.ensure(((size_t)natoms / BT_OWNERS + 2) * 6 * 8));
     HIPCHK(sl.tile_order.ensure((size_t)npad * 4));
     HIPCHK(sl.wrapn.ensure(3 * (size_t)natoms * 4));
     HIPCHK(sl.xhold.ensure(3 * (size_t)natoms * 8));
@@ -783,10 +885,9 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
 
 // After k_pair: bonded terms on the main stream, structure factors + per-k coefficients on the side stream (both
 // are small, latency-bound kernels that need only the positions), joined before the per-atom reciprocal force.
-static hipError_t force_stage(scema_md_engine *e, const SimDev *D, int ns, int maxbt, int maxloc, int maxatoms, int maxk, int mmax,
-                              int maxgrp, int parts, int pairvir) {
-  hipStream_t st = e->stream;
-  const bool side = maxk > 0 && e->stream2 != nullptr && ns >= 16;   // small batches: the fork/join costs more than it hides
+static hipError_t force_stage(scema_md_engine *e, hipStream_t st, bool allow_side, const SimDev *D, int ns, int maxbt, int maxloc, int maxatoms,
+                              int maxk, int mmax, int maxgrp, int parts, int pairvir) {
+  const bool side = allow_side && maxk > 0 && e->stream2 != nullptr && ns >= 16;   // small batches: the fork/join costs more than it hides
   if (side) {
     hipError_t rc = hipEventRecord(e->ev_fork, st);
     if (rc != hipSuccess) return rc;
@@ -815,6 +916,20 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   std::vector<int> order(ns);
   for (int i = 0; i < ns; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
+  // Two half batches on two streams (large batches only): every kernel but k_pair is latency bound and leaves most issue
+  // slots idle, while k_pair saturates them and holds every wave slot of the chip; with two independent halves in flight
+  // the small kernels of one half fill in as the pair workgroups of the other retire (the in-order streams fall half a
+  // step out of phase by themselves).  The halves take the even and the odd ranks of the length order, so each is
+  // itself sorted longest first.
+  const int nhalf = (e->split_streams && e->stream3 != nullptr && ns >= e->split_min && ns < e->split_max) ? 2 : 1;
+  if (nhalf == 2) {
+    std::vector<int> o2;
+    o2.reserve(ns);
+    for (int r = 0; r < ns; r += 2) o2.push_back(order[r]);
+    for (int r = 1; r < ns; r += 2) o2.push_back(order[r]);
+    order.swap(o2);
+  }
+  const int hbeg[2] = {0, nhalf == 2 ? (ns + 1) / 2 : ns}, hcnt[2] = {nhalf == 2 ? (ns + 1) / 2 : ns, nhalf == 2 ? ns / 2 : 0};
   e->h_sims.assign(ns, SimDev());
   int maxbt = 1, maxloc = 1;
   int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
@@ -823,22 +938,37 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   kpack.clear();
   std::vector<size_t> koff(ns, 0);
   int maxgrp = 0;
+  std::vector<std::vector<FlipEvent>> flips(ns);   // per position: the box flips of this run (fix deform, flip yes)
+  std::vector<EwaldSetup> ews(ns);
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
     ActiveSim &A = sims[i];
     Topo &T = *A.st->topo;
     const SimScalars &hsc = e->h_sc[i];
-    // box range over this run -> cell grid that stays valid while the box deforms
+    // box range over this run -> cell grid that stays valid while the box deforms (and flips: the tilt is largest just
+    // before a flip, those boxes are kept as extremes)
     double box_end[9];
     std::memcpy(box_end, hsc.box, sizeof box_end);
-    if (spec.deform) deform_box(hsc.box, A.rates, A.nsteps * A.dt, box_end);
-    HostBox b0, b1;
-    box_derive(hsc.box, b0);
-    box_derive(box_end, b1);
-    double w0[3], w1[3];
-    perp_widths(b0, w0);
-    perp_widths(b1, w1);
+    std::vector<HostBox> boxes(2);
+    if (spec.deform) {
+      std::vector<HostBox> extremes;
+      deform_trajectory(hsc.box, A.rates, A.dt, A.nsteps, box_end, flips[pos], extremes);
+      boxes.insert(boxes.end(), extremes.begin(), extremes.end());
+    }
+    box_derive(hsc.box, boxes[0]);
+    box_derive(box_end, boxes[1]);
+    const HostBox &b0 = boxes[0], &b1 = boxes[1];
+    double w0[3] = {1e300, 1e300, 1e300}, w1[3];   // w0 = narrowest perpendicular widths over the run
+    double vol_min = 1e300, vol_max = 0.0;
+    for (const HostBox &hb : boxes) {
+      perp_widths(hb, w1);
+      for (int d = 0; d < 3; d++) w0[d] = std::min(w0[d], w1[d]);
+      vol_min = std::min(vol_min, hb.vol);
+      vol_max = std::max(vol_max, hb.vol);
+    }
+    for (int d = 0; d < 3; d++) w1[d] = w0[d];
+    (void)b0; (void)b1;
     SimDev S;
     std::memset(&S, 0, sizeof S);
     // list skin of this simulation = the reference's neighbour skin + the state's performance extra (dropped where the
@@ -857,7 +987,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     // the half stencil within rlist of the cell, 28 B of LDS each) still fits two workgroups per CU.  PE-10k:
     // 5x6x4 cells of 8.9 x 7.4 x 10.1 A (22 clusters, 2 280 table entries) instead of 6x6x5 (14 clusters, 2 040):
     // k_pair -3.5 %, build +8 %, step -2.4 %.  Denser systems fall back to cells of rlist/3, rlist/4, ...
-    const double rho = T.natoms / std::min(b0.vol, b1.vol);
+    const double rho = T.natoms / vol_min;
     int capj = 0, maxneigh = 0;
     bool fits = false;
     auto size_grid = [&](const int nc[3], int mst[3], int &cj_out, int &mn_out) {
@@ -869,7 +999,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
       // Cartesian extents of one cell (bounding box of its edge vectors), the larger of the two boxes
       double ext[3] = {0, 0, 0};
-      for (const HostBox *hb : {&b0, &b1}) {
+      for (const HostBox &hbr : boxes) {
+        const HostBox *hb = &hbr;
         ext[0] = std::max(ext[0], std::fabs(hb->h[0]) / nc[0] + std::fabs(hb->h[5]) / nc[1] + std::fabs(hb->h[4]) / nc[2]);
         ext[1] = std::max(ext[1], std::fabs(hb->h[1]) / nc[1] + std::fabs(hb->h[3]) / nc[2]);
         ext[2] = std::max(ext[2], std::fabs(hb->h[2]) / nc[2]);
@@ -879,9 +1010,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       // Calibrated on PE-10k grids from 6x6x5 to 4x5x4: estimate = 1.15-1.17 x the largest table seen.
       const double vmink = ext[0] * ext[1] * ext[2] + 2.0 * r * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2]) +
                            MD_PI * r * r * (ext[0] + ext[1] + ext[2]) + 4.0 / 3.0 * MD_PI * r * r * r;
-      const double vmin = std::min(b0.vol, b1.vol);
+      const double vmin = vol_min;
       const double rho_slots = (T.natoms + 1.5 * ncells) / vmin;
-      const double cellvol = std::max(b0.vol, b1.vol) / ncells;
+      const double cellvol = vol_max / ncells;
       double cj = rho_slots * (0.5 * vmink + 0.5 * cellvol) * 1.13 * e->jtab_grow;
       cj = std::min(cj, (double)padded_slots(T.natoms, ncells) * 14.0);
       cj_out = std::max(64, ((int)std::ceil(cj) + 63) / 64 * 64);
@@ -927,13 +1058,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     }
     if (!fits)
       return fail(e, SCEMA_MD_ERR_ARG, "the j table of a cell tile (%d entries) does not fit the LDS of the pair kernel (system too dense for the cutoff)", capj);
-    if (spec.deform) {
-      const double tol = 1.0000001;
-      if (std::fabs(box_end[6]) > 0.5 * b1.h[0] * tol || std::fabs(box_end[7]) > 0.5 * b1.h[0] * tol || std::fabs(box_end[8]) > 0.5 * b1.h[1] * tol)
-        return fail(e, SCEMA_MD_ERR_BOX, "strain needs a triclinic box flip (fix deform flip yes): not supported");
-    }
     S.ncells = S.nc[0] * S.nc[1] * S.nc[2];
-    EwaldSetup ew;
+    EwaldSetup &ew = ews[pos];
     ewald_setup(P, T, hsc.box, ew);
     S.nk = (int)ew.kn.size() / 3;
     for (int d = 0; d < 3; d++) S.kmaxd[d] = ew.kmaxd[d];
@@ -1007,7 +1133,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.wrapn = sl.wrapn.as<int>(); S.xhold = sl.xhold.as<double>();
     S.cell_of = sl.cell_of.as<int>(); S.ckey = sl.ckey.as<int>(); S.cell_count = sl.cell_count.as<int>(); S.cell_start = sl.cell_start.as<int>();
     S.cell_fill = sl.cell_fill.as<int>(); S.numneigh = sl.numneigh.as<int>(); S.neigh = sl.neigh.as<int>();
-    S.fs = sl.fs.as<double>(); S.fb = sl.fb.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>(); S.virp = sl.virp.as<double>();
+    S.fs = sl.fs.as<double>(); S.fb = sl.fb.as<double>(); S.slot_of = sl.slot_of.as<int>(); S.tile_nj = sl.tile_nj.as<int>(); S.tile_jtab = sl.tile_jtab.as<int>(); S.tile_order = sl.tile_order.as<int>(); S.tile_wstart = sl.tile_wstart.as<int>(); S.virp = sl.virp.as<double>(); S.virb = sl.virb.as<double>();
     S.sfac = sl.sfac.as<double>(); S.kvec = sl.kvec.as<double>();
     S.sc = e->d_sc.as<SimScalars>() + i;
     if (S.nk > 0) {
@@ -1044,25 +1170,37 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   HIPCHK(e->d_sims.ensure((size_t)ns * sizeof(SimDev)));
   HIPCHK(hipMemcpyAsync(e->d_sims.p, e->h_sims.data(), (size_t)ns * sizeof(SimDev), hipMemcpyHostToDevice, e->stream));
   const SimDev *D = e->d_sims.as<SimDev>();
-  hipStream_t st = e->stream;
+  hipStream_t hs[2] = {e->stream, nhalf == 2 ? e->stream3 : e->stream};
+  if (nhalf == 2) {   // the second stream starts behind the uploads
+    HIPCHK(hipEventRecord(e->ev_up, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_up, 0));
+  }
   const int ev = (spec.sample || spec.ev_always) ? 1 : 0;
+  const bool allow_side = nhalf == 1;
   // ---- setup (step 0) ----
-  mdk_phase_init(st, D, ns);
-  mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
-  mdk_pair(st, D, ns, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
-  HIPCHK(force_stage(e, D, ns, maxbt, maxloc, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
-  if (!spec.static_only) mdk_shake(st, D, ns, maxclus, 0.5);
-  mdk_final_integrate(st, D, ns, maxatoms, 0);
-  mdk_setup_post(st, D, ns);
+  for (int h = 0; h < nhalf; h++) {
+    hipStream_t st = hs[h];
+    const SimDev *Dh = D + hbeg[h];
+    const int nh = hcnt[h];
+    mdk_phase_init(st, Dh, nh);
+    mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
+    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
+    HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
+    if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
+    mdk_final_integrate(st, Dh, nh, maxatoms, 0);
+    mdk_setup_post(st, Dh, nh);
+  }
   // ---- steps ----
   const bool prof = e->p.profile != 0;
   size_t ev_used = 0;
-  std::vector<double> launch_bytes;
-  // one MD step of the first `na` simulations, as a sequence of launches on the engine's streams
-  auto launch_step = [&](int na, bool timed) -> int {
-    mdk_pre(st, D, na);
-    mdk_initial_integrate(st, D, na, maxatoms);
-    mdk_neighbor(st, D, na, maxatoms, maxpad, maxcells, maxrow, maxcapj);
+  std::vector<std::pair<int, int>> launch_sims;   // per timed pair launch: (first position, simulations)
+  // one MD step of the first `na` simulations of half h, as a sequence of launches on that half's stream
+  auto launch_step = [&](int h, int na, bool timed) -> int {
+    hipStream_t st = hs[h];
+    const SimDev *Dh = D + hbeg[h];
+    mdk_pre(st, Dh, na);
+    mdk_initial_integrate(st, Dh, na, maxatoms);
+    mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj);
     if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;
@@ -1073,18 +1211,23 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
-    mdk_pair(st, D, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
+    mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
     if (timed) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;
-      launch_bytes.push_back((double)na);
+      launch_sims.push_back({hbeg[h], na});
     }
-    HIPCHK(force_stage(e, D, na, maxbt, maxloc, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
-    mdk_shake(st, D, na, maxclus, 1.0);
-    mdk_final_integrate(st, D, na, maxatoms, 1);
-    mdk_post(st, D, na);
-    if (spec.deform) mdk_remap(st, D, na, maxatoms);
+    HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
+    mdk_shake(st, Dh, na, maxclus, 1.0);
+    mdk_final_integrate(st, Dh, na, maxatoms, 1);
+    mdk_post(st, Dh, na);
+    if (spec.deform) mdk_remap(st, Dh, na, maxatoms);
     return SCEMA_MD_OK;
+  };
+  auto active = [&](int h, int step) {   // active prefix of half h at this step (sorted by nsteps)
+    int na = 0;
+    while (na < hcnt[h] && e->h_sims[hbeg[h] + na].nsteps >= step) na++;
+    return na;
   };
   // The step loop is launch-bound for small batches (about 20 kernels of a few microseconds each per step of a
   // single replica): the steps that share an active count can be captured once into a hipGraph and replayed.
@@ -1092,19 +1235,33 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // 25.8 / 236.7 on one stream, 28.3 / 232.2 with the side stream; graph replay 26.4 / 236.9 on one stream and
   // 55.2 / 251.3 with the side stream inside the graph -- no gain, so replay is opt-in (SCEMA_MD_GRAPH=1).  Not
   // with per-launch event timing (profile mode), which needs the individual launches.
-  const bool use_graph = !prof && e->use_graphs;
+  const bool use_graph = !prof && e->use_graphs && nhalf == 1;
+  // box flips (fix deform, flip yes): step -> positions that flip after it
+  std::map<int, std::vector<std::pair<int, int>>> flip_at;
+  for (int pos = 0; pos < ns; pos++)
+    for (size_t k = 0; k < flips[pos].size(); k++)
+      if (flips[pos][k].step < e->h_sims[pos].nsteps) flip_at[flips[pos][k].step].push_back({pos, (int)k});
+  std::vector<std::unique_ptr<DevBuf>> flip_bufs;          // k-vector tables in the new reciprocal basis, alive until the run has drained
+  std::vector<std::unique_ptr<std::vector<int>>> flip_host;
+  std::vector<std::unique_ptr<SimDev>> flip_desc;
   for (int step = 1; step <= maxsteps;) {
-    int na = 0;
-    while (na < ns && e->h_sims[na].nsteps >= step) na++;
+    const int na = active(0, step);
     if (na == 0) break;
-    const int run_len = e->h_sims[na - 1].nsteps - step + 1;   // steps until the active prefix shrinks (sorted by nsteps)
+    int run_len = e->h_sims[na - 1].nsteps - step + 1;   // steps until the active prefix shrinks (sorted by nsteps)
+    const int nb = nhalf == 2 ? active(1, step) : 0;
+    if (nb > 0) run_len = std::min(run_len, e->h_sims[hbeg[1] + nb - 1].nsteps - step + 1);
+    {
+      auto nxt = flip_at.lower_bound(step);
+      if (nxt != flip_at.end()) run_len = std::min(run_len, nxt->first - step + 1);   // the launch group ends with the flipping step
+    }
     bool replayed = false;
     if (use_graph && run_len >= 4) {
+      hipStream_t st = hs[0];
       hipGraph_t graph = nullptr;
       hipGraphExec_t gexec = nullptr;
       bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (ok) {
-        const int rc_l = launch_step(na, false);
+        const int rc_l = launch_step(0, na, false);
         ok = (hipStreamEndCapture(st, &graph) == hipSuccess) && rc_l == SCEMA_MD_OK && graph != nullptr;
       }
       if (ok) ok = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -1121,13 +1278,62 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     }
     if (!replayed)
       for (int r = 0; r < run_len; r++) {
-        const int rc_l = launch_step(na, prof);
+        int rc_l = launch_step(0, na, prof);
         if (rc_l) return rc_l;
+        if (nb > 0 && (rc_l = launch_step(1, nb, prof))) return rc_l;
       }
-    e->prof.md_steps += (long long)na * run_len;
+    e->prof.md_steps += (long long)(na + nb) * run_len;
     step += run_len;
+    // flips detected at the end of step - 1: between the two steps the box takes its flipped tilts, the list rebuild of
+    // the next step is forced and the k-vector list is re-expressed in the new reciprocal basis (same vectors:
+    // n2 += f_xy n1, n3 += f_yz n2 + f_xz n1), all stream-ordered behind the launches of step - 1
+    auto fl = flip_at.find(step - 1);
+    if (fl != flip_at.end())
+      for (const auto &pk : fl->second) {
+        const int pos = pk.first;
+        const FlipEvent &fe = flips[pos][pk.second];
+        const int h = (nhalf == 2 && pos >= hbeg[1]) ? 1 : 0;
+        SimDev &S = e->h_sims[pos];
+        EwaldSetup &ew = ews[pos];
+        if (S.nk > 0) {
+          for (int k = 0; k < S.nk; k++) {
+            const int n1 = ew.kn[3 * k], n2 = ew.kn[3 * k + 1], n3 = ew.kn[3 * k + 2];
+            ew.kn[3 * k + 1] = n2 + fe.nflip[0] * n1;
+            ew.kn[3 * k + 2] = n3 + fe.nflip[2] * n2 + fe.nflip[1] * n1;
+          }
+          ewald_tables(ew);
+          flip_host.emplace_back(new std::vector<int>());
+          std::vector<int> &hk = *flip_host.back();
+          hk.insert(hk.end(), ew.kn.begin(), ew.kn.end());
+          hk.insert(hk.end(), ew.krun.begin(), ew.krun.end());
+          while (hk.size() % 4) hk.push_back(0);
+          const size_t goff = hk.size();
+          hk.insert(hk.end(), ew.kgrp.begin(), ew.kgrp.end());
+          flip_bufs.emplace_back(new DevBuf());
+          HIPCHK(flip_bufs.back()->ensure(hk.size() * sizeof(int) + 64));
+          HIPCHK(hipMemcpyAsync(flip_bufs.back()->p, hk.data(), hk.size() * sizeof(int), hipMemcpyHostToDevice, hs[h]));
+          const int *base = flip_bufs.back()->as<int>();
+          S.kn = base;
+          S.krun = base + 3 * (size_t)S.nk;
+          S.kgrp = base + goff;
+          S.ngrp = (int)ew.kgrp.size() / 8;
+          for (int d = 0; d < 3; d++) { S.kmaxd[d] = ew.kmaxd[d]; mmax = std::max(mmax, S.kmaxd[d] + 1); }
+          maxgrp = std::max(maxgrp, S.ngrp);
+          if ((size_t)64 * 3 * mmax * 16 + 4096 > 160 * 1024)
+            return fail(e, SCEMA_MD_ERR_ARG, "k-space index range after a box flip (|n| up to %d) too large for the LDS phase tables", mmax - 1);
+          flip_desc.emplace_back(new SimDev(S));   // the source of an asynchronous upload must not change under it
+          HIPCHK(hipMemcpyAsync(e->d_sims.as<SimDev>() + pos, flip_desc.back().get(), sizeof(SimDev), hipMemcpyHostToDevice, hs[h]));
+        }
+        mdk_flip(hs[h], D + pos, fe.tilt[0], fe.tilt[1], fe.tilt[2]);
+        e->prof.box_flips += 1;
+      }
   }
-  mdk_phase_end(st, D, ns, maxatoms);
+  for (int h = 0; h < nhalf; h++) mdk_phase_end(hs[h], D + hbeg[h], hcnt[h], maxatoms);
+  if (nhalf == 2) {
+    HIPCHK(hipEventRecord(e->ev_up, e->stream3));
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_up, 0));
+  }
+  hipStream_t st = e->stream;
   HIPCHK(hipMemcpyAsync(e->h_sc.data(), e->d_sc.p, (size_t)ns * sizeof(SimScalars), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
@@ -1142,13 +1348,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       per_sim_bytes += simbytes[pos];
     }
     (void)per_sim_bytes;
-    for (size_t l = 0; l < launch_bytes.size(); l++) {
+    for (size_t l = 0; l < launch_sims.size(); l++) {
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[2 * l], e->ev_pool[2 * l + 1]));
       e->prof.pair_ms += ms;
       e->prof.pair_launches += 1;
-      const int na = (int)launch_bytes[l];
-      for (int pos = 0; pos < na; pos++) e->prof.pair_alg_bytes += simbytes[pos];
+      e->prof.pair_sims += launch_sims[l].second;
+      for (int pos = launch_sims[l].first; pos < launch_sims[l].first + launch_sims[l].second; pos++) e->prof.pair_alg_bytes += simbytes[pos];
     }
   }
   if (getenv("SCEMA_MD_TIMING") && ns > 0) {
@@ -1549,6 +1755,10 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     return SCEMA_MD_ERR_DEVICE;
   }
   if (getenv("SCEMA_MD_GRAPH")) e->use_graphs = true;
+  if (const char *sp = getenv("SCEMA_MD_SPLIT")) e->split_streams = atoi(sp) != 0;
+  if (const char *sp = getenv("SCEMA_MD_SPLIT_MIN")) e->split_min = std::max(2, atoi(sp));
+  if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess)
+    e->stream3 = nullptr;   // an optimisation only
   if (const char *sx = getenv("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(0.0, atof(sx));
   if (!getenv("SCEMA_MD_ONE_STREAM")) {
     if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -1573,6 +1783,8 @@ void scema_md_destroy(scema_md_engine *e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
+  if (e->stream3) (void)hipStreamDestroy(e->stream3);
+  if (e->ev_up) (void)hipEventDestroy(e->ev_up);
   e->states.clear();
   e->topos.clear();
   e->slots.clear();
@@ -2238,6 +2450,8 @@ int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t rese
   out->unique_pairs_per_sim = e->prof.unique_pairs_n ? e->prof.unique_pairs_sum / e->prof.unique_pairs_n : 0.0;
   out->evals = e->prof.evals;
   out->list_skin_mean = e->prof.evals ? e->prof.skin_sum / (double)e->prof.evals : 0.0;
+  out->pair_sims = e->prof.pair_sims;
+  out->box_flips = e->prof.box_flips;
   if (reset) e->prof = Profile();
   return SCEMA_MD_OK;
 }

@@ -24,4 +24,6 @@ void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfs
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);
 void mdk_post(hipStream_t st, const SimDev *d, int ns);
 void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms);
+// triclinic box flip of ONE simulation between two steps (fix deform, flip yes): new tilts, forced list rebuild
+void mdk_flip(hipStream_t st, const SimDev *sim, double xy, double xz, double yz);
 void mdk_phase_end(hipStream_t st, const SimDev *d, int ns, int maxatoms);

@@ -97,6 +97,7 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.ago = 0;
     sc.check = 1;
     sc.rebuild = 1;
+    sc.force_rebuild = 0;
     sc.deltasq = 0.0;
     sc.far_dsq = 1.0e300;
     sc.need_far = 0;
@@ -134,7 +135,8 @@ __global__ void k_pre(const SimDev *sims) {
   if (threadIdx.x == 0) {
     sc.step += 1;
     sc.ago += 1;
-    sc.rebuild = 0;
+    sc.rebuild = sc.force_rebuild;   // a box flip between two steps forces the rebuild (fix deform: next_reneighbor)
+    sc.force_rebuild = 0;
     sc.check = (sc.ago >= S.neigh_delay) ? 1 : 0;
     // neighbour trigger threshold with a deforming triclinic box: the two largest box-corner
     // displacements since the last build are taken off the skin
@@ -406,8 +408,7 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   const int s = blockIdx.x * TPB + threadIdx.x;
   if (s >= S.npad) return;
   // k_pair accumulates into the slot-ordered pair forces with atomics
-  S.fs[s] = 0.0; S.fs[(size_t)S.npad + s] = 0.0; S.fs[2 * (size_t)S.npad + s] = 0.0;
-  S.fb[3 * (size_t)s] = 0.0; S.fb[3 * (size_t)s + 1] = 0.0; S.fb[3 * (size_t)s + 2] = 0.0;   // npad >= natoms entries
+  S.fs[s] = 0.0; S.fs[(size_t)S.npad + s] = 0.0; S.fs[2 * (size_t)S.npad + s] = 0.0;   // (fb needs no zeroing: k_bonded stores every entry)
   const int a = S.perm[s];
   if (a < 0) {  // pad slot: a record no real atom is ever within the list cutoff of
     if (S.sc->rebuild) {
@@ -710,6 +711,12 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
 #pragma unroll
       for (int k = 0; k < 6; k++) pv[k] += vp[k];
     }
+    // the lumped bonded virial: one row of 6 per bonded tile (k_bonded)
+    for (int r = blockIdx.x * EWF_TPB + threadIdx.x; r < S.bt_ntile; r += nblk * EWF_TPB) {
+      const double *vp = S.virb + (size_t)r * 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) pv[k] += vp[k];
+    }
     block_atomic_add_n<6, EWF_TPB / 64>(pv, S.sc->vir + P_LJ * 6, s_red);
   }
 }
@@ -869,18 +876,42 @@ __global__ void k_post(const SimDev *sims) {
     }
     sc.nsamples += 1;
   }
-  // fix deform 1 ... erate ... : box(t) linear in t about the box centre, tilts by Ly0/Lz0
+  // fix deform 1 ... erate ... : box(t) linear in t about the box centre, raw tilt targets by Ly0/Lz0, then moved by whole
+  // box lengths to the value closest to the current tilt ratio (LAMMPS fix_deform end_of_step; after a flip the tilt
+  // continues from the flipped value).  The flip itself is decided and enqueued by the host (md_engine.cpp run_phase).
   if (S.deform) {
     for (int k = 0; k < 9; k++) sc.box_prev[k] = sc.box[k];
     const double t = sc.step * S.dt;
+    double nb[9];
     for (int d = 0; d < 3; d++) {
       const double L0 = sc.box0[3 + d] - sc.box0[d];
-      sc.box[d] = sc.box0[d] - 0.5 * L0 * S.rates[d] * t;
-      sc.box[3 + d] = sc.box0[3 + d] + 0.5 * L0 * S.rates[d] * t;
+      nb[d] = sc.box0[d] - 0.5 * L0 * S.rates[d] * t;
+      nb[3 + d] = sc.box0[3 + d] + 0.5 * L0 * S.rates[d] * t;
     }
-    sc.box[6] = sc.box0[6] + S.rates[3] * (sc.box0[4] - sc.box0[1]) * t;
-    sc.box[7] = sc.box0[7] + S.rates[4] * (sc.box0[5] - sc.box0[2]) * t;
-    sc.box[8] = sc.box0[8] + S.rates[5] * (sc.box0[5] - sc.box0[2]) * t;
+    double tilt[3] = {sc.box0[6] + S.rates[3] * (sc.box0[4] - sc.box0[1]) * t, sc.box0[7] + S.rates[4] * (sc.box0[5] - sc.box0[2]) * t,
+                      sc.box0[8] + S.rates[5] * (sc.box0[5] - sc.box0[2]) * t};
+    const double xprd_n = nb[3] - nb[0], yprd_n = nb[4] - nb[1];
+    const double xprd = sc.box[3] - sc.box[0], yprd = sc.box[4] - sc.box[1];
+    const double denom[3] = {xprd_n, xprd_n, yprd_n};
+    const double current[3] = {sc.box[6] / xprd, sc.box[7] / xprd, sc.box[8] / yprd};
+    for (int i = 0; i < 3; i++) {
+      int guard = 0;
+      while (tilt[i] / denom[i] - current[i] > 0.0 && guard++ < 64) tilt[i] -= denom[i];
+      while (tilt[i] / denom[i] - current[i] < 0.0 && guard++ < 128) tilt[i] += denom[i];
+      if (fabs(tilt[i] / denom[i] - 1.0 - current[i]) < fabs(tilt[i] / denom[i] - current[i])) tilt[i] -= denom[i];
+    }
+    for (int k = 0; k < 6; k++) sc.box[k] = nb[k];
+    sc.box[6] = tilt[0]; sc.box[7] = tilt[1]; sc.box[8] = tilt[2];
+  }
+}
+
+// k_flip : triclinic box flip between two steps: only the representation of the lattice changes (positions are
+// unwrapped and stay); the next step rebuilds cells, wraps and lists in the new box
+__global__ void k_flip(const SimDev *sim, double xy, double xz, double yz) {
+  SimScalars &sc = *sim->sc;
+  if (threadIdx.x == 0) {
+    sc.box[6] = xy; sc.box[7] = xz; sc.box[8] = yz;
+    sc.force_rebuild = 1;
   }
 }
 
@@ -959,6 +990,7 @@ void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, 
   hipLaunchKernelGGL(k_final_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d, kick);
 }
 void mdk_post(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_post, dim3(ns), dim3(64), 0, st, d); }
+void mdk_flip(hipStream_t st, const SimDev *sim, double xy, double xz, double yz) { hipLaunchKernelGGL(k_flip, dim3(1), dim3(64), 0, st, sim, xy, xz, yz); }
 void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
   hipLaunchKernelGGL(k_remap, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
 }

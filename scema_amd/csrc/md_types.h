@@ -26,9 +26,11 @@
 #define MD_PI 3.14159265358979323846
 
 // bonded tiles (md_bonded.hip): kinds of terms; descriptor of one tile = BT_DESC ints:
-// [0] offset into bt_atoms, [1] local atoms, then (first term, number of terms) per kind
+// [0] offset into bt_atoms, [1] local atoms (owners first), then (first term, number of terms) per kind, [14] owners
 enum { BT_BOND = 0, BT_BOND_SHAKEN = 1, BT_ANGLE = 2, BT_DIHEDRAL = 3, BT_IMPROPER = 4, BT_SPECIAL = 5, BT_NKIND = 6 };
-#define BT_DESC 16
+#define BT_DESC 16           /* [14] = owners of the tile */
+#define BT_NOCOUNT 0x40000000 /* on a term's first atom index: evaluated for this tile's owner forces only, virial/energy counted by another tile */
+#define BT_LMASK 0x3FFFFFFF
 #define BT_OWNERS 192        /* owner atoms (consecutive breadth-first ranks of the bond graph) per tile */
 
 enum { P_LJ = 0, P_COUL = 1, P_BOND = 2, P_ANGLE = 3, P_DIHEDRAL = 4, P_IMPROPER = 5, P_KSPACE = 6, P_SHAKE = 7 };
@@ -56,6 +58,7 @@ struct SimScalars {
   int ago;
   int check;           // ago >= delay
   int rebuild;
+  int force_rebuild;   // set by a box flip: the next step rebuilds whatever the displacements
   int overflow;
   int maxneigh_seen;
   int nfar_steps;      // steps of this phase on which the far skin band was walked (SCEMA_MD_TIMING)
@@ -112,7 +115,8 @@ struct SimDev {
   // state
   double *x, *v, *f;
   double *fs;       // pair forces in slot order, [3][npad] (zeroed by k_pack, accumulated by k_pair, folded into f by k_ewald_force)
-  double *fb;       // bonded forces in breadth-first-rank order, [natoms][3] (zeroed by k_pack, accumulated by k_bonded)
+  double *fb;       // bonded forces in breadth-first-rank order, [natoms][3] (every entry written by the tile that owns it, k_bonded)
+  double *virb;     // per bonded tile: 6 partial sums of the lumped bonded virial (no atomics; folded by k_ewald_force)
   int *slot_of;     // atom -> slot
   int *tile_nj;     // per cell: entries of its j table
   int *tile_order;  // per cell, at its cluster range: the cell's clusters grouped by the wave of k_pair that takes them
