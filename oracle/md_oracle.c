@@ -1406,6 +1406,10 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
         s->x[3 * i + 2] = bn.h[2] * l2 + bn.lo[2];
       }
       flip_pending = omd_tilt_flip(tilt, nhi[0] - nlo[0], nhi[1] - nlo[1], flip_tilt, flip_n);
+      /* A yz flip would change xz by xy, which the linear tilt targets of the other components cannot follow; LAMMPS
+       * refuses such a run at init ("Fix deform is changing yz too much with xy": in.strain.lammps deforms all six
+       * components, so yz and xy are always both active).  xy and xz flip freely. */
+      if (flip_n[2] != 0) return -2;
     }
     if (trace) {
       double ke[6], p[6];

@@ -774,7 +774,10 @@ struct FlipEvent {
   double tilt[3];    // xy, xz, yz after the flip
   int nflip[3];      // lattice steps f_xy, f_xz, f_yz: a2' = a2 + f_xy a1, a3' = a3 + f_yz a2 + f_xz a1
 };
-void deform_trajectory(const double *box0, const double *rates, double dt, int nsteps, double *box_end, std::vector<FlipEvent> &events,
+// returns false if the run would need a yz flip: that changes xz by xy, which the linear tilt targets of the other
+// components cannot follow -- LAMMPS refuses such a run ("Fix deform is changing yz too much with xy"; in.strain.lammps
+// deforms all six components, so yz and xy are always both active).  xy and xz flip freely.
+bool deform_trajectory(const double *box0, const double *rates, double dt, int nsteps, double *box_end, std::vector<FlipEvent> &events,
                        std::vector<HostBox> &extremes) {
   double cur[9];
   std::memcpy(cur, box0, sizeof cur);
@@ -800,6 +803,7 @@ void deform_trajectory(const double *box0, const double *rates, double dt, int n
     std::memcpy(cur, nb, sizeof cur);
     pe.step = step;
     if (tilt_flip(tilt, nb[3] - nb[0], nb[4] - nb[1], pe.tilt, pe.nflip)) {
+      if (pe.nflip[2] != 0) return false;
       pending = true;   // a flip that falls behind the last step of the run is never applied (the fix is gone by then)
       HostBox hb;
       box_derive(cur, hb);
@@ -807,6 +811,7 @@ void deform_trajectory(const double *box0, const double *rates, double dt, int n
     }
   }
   std::memcpy(box_end, cur, sizeof cur);
+  return true;
 }
 
 double wall_s() {
@@ -953,7 +958,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     std::vector<HostBox> boxes(2);
     if (spec.deform) {
       std::vector<HostBox> extremes;
-      deform_trajectory(hsc.box, A.rates, A.dt, A.nsteps, box_end, flips[pos], extremes);
+      if (!deform_trajectory(hsc.box, A.rates, A.dt, A.nsteps, box_end, flips[pos], extremes))
+        return fail(e, SCEMA_MD_ERR_BOX, "fix deform is changing yz too much with xy: the strain would tilt yz past half the box (a yz flip changes xz by xy, "
+                    "which LAMMPS refuses while xy is deformed too, as in.strain.lammps always does)");
       boxes.insert(boxes.end(), extremes.begin(), extremes.end());
     }
     box_derive(hsc.box, boxes[0]);

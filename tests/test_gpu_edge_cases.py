@@ -161,9 +161,11 @@ def test_error_paths(small_pe):
     eng.close()
     eng = capi.Engine(capi.default_params(**KW))
     eng.register_replica("pe", 1, small_pe)
-    with pytest.raises(capi.EngineError, match="flip|box width"):   # a shear that tilts the box past L/2 (or squeezes it first)
-        eng.strain_batch([capi.make_sim(0, "pe", 1, np.array([0, 0, 0, 0.9 * lens[0] * lens[2] / lens[1], 0, 0]), nss=10,
-                                        most_recent=capi.QP_NONE, strain_rate=1e-2)])
+    # a shear that tilts the box far past L/2 is no error: the box flips on the way (fix deform flip yes)
+    out = eng.strain_batch([capi.make_sim(0, "pe", 1, np.array([0, 0, 0, 0.9 * lens[0] * lens[2] / lens[1], 0, 0]), nss=10,
+                                          most_recent=capi.QP_NONE, strain_rate=1e-2)])
+    assert out[0].stress_updated == 1 and eng.profile()["box_flips"] >= 1
+    eng.drop_state(0, "pe", 1)
     with pytest.raises(capi.EngineError, match="not registered"):
         eng.strain_batch([capi.make_sim(0, "nomat", 1, st, nss=10, most_recent=capi.QP_NONE)])
     xb = np.array(small_pe["x"], float).copy(); xb[3, 1] = np.inf
@@ -307,20 +309,30 @@ def test_list_skin_adapts_to_the_rebuild_frequency(small_pe):
     eng.close()
 
 
+def _affine(box_old, box_new, x):
+    """positions carried affinely from one triclinic box to another (what `change_box ... remap` does)"""
+    def hmat(b):
+        return np.array([[b[3] - b[0], b[6], b[7]], [0.0, b[4] - b[1], b[8]], [0.0, 0.0, b[5] - b[2]]])
+    lam = np.linalg.solve(hmat(box_old), (np.asarray(x, float) - np.asarray(box_old[:3], float)).T)
+    return (hmat(box_new) @ lam).T + np.asarray(box_new[:3], float)
+
+
 def test_triclinic_box_flip_matches_the_oracle(small_pe):
-    """fix deform `flip yes` (the LAMMPS default behind in.strain.lammps:94-100): a shear run that carries xy across +Lx/2.
-    The box flips by one lattice vector between two steps, the list is rebuilt, the k-vector list is re-expressed in the new
-    reciprocal basis -- and the trajectory stays on the oracle's."""
+    """fix deform `flip yes` (the LAMMPS default behind in.strain.lammps:94-100): a shear run that carries xy across +Lx/2 and
+    xz across -Lx/2.  The box flips by one lattice vector between two steps, the list is rebuilt, the k-vector list is
+    re-expressed in the new reciprocal basis -- and the trajectory stays on the oracle's."""
     from scema_amd import capi
     from oracle import pyoracle as po
-    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+    kw = dict(cut_lj=4.5, cut_coul=4.0, skin=0.9, kspace_accuracy=1e-5)   # the doubly sheared box is 11.8 A wide across x
     d = dict(small_pe)
     box = np.array(small_pe["box"], float)
     lx, ly, lz = box[3] - box[0], box[4] - box[1], box[5] - box[2]
     box[6] = 0.485 * lx
-    box[8] = -0.47 * ly
+    box[7] = -0.47 * lx
+    box[8] = 0.0
     d["box"] = box
-    rates = np.array([1e-5, -1e-5, 2e-5, 0.004 * lx / ly, 0.0, -0.003 * ly / lz], float)   # xy up, yz down: both cross
+    d["x"] = _affine(small_pe["box"], box, small_pe["x"])      # chains are bonded through the periodic boundary: shear the atoms with the box
+    rates = np.array([1e-5, -1e-5, 2e-5, 0.004 * lx / ly, -0.003 * lx / lz, 1e-5], float)   # xy up, xz down: both cross
     e = capi.Engine(capi.default_params(**kw))
     e.register_replica("pe", 1, d)
     e.set_state(3, "pe", 1, d["box"], d["x"], d["v"])
@@ -330,10 +342,20 @@ def test_triclinic_box_flip_matches_the_oracle(small_pe):
     o = po.Oracle(d, po.default_params(**kw))
     o.run(nsteps, 1.0, 300.0, nvt=True, use_shake=True, rates=rates)
     bo, xo, vo = o.get_state()
-    assert o.nflips >= 2 and e.profile()["box_flips"] == o.nflips
+    assert o.nflips == 2 and e.profile()["box_flips"] == o.nflips
     assert np.abs(bx - bo).max() < 1e-11
-    assert -0.5 * lx < bx[6] < -0.4 * lx and 0.4 * ly < bx[8] < 0.5 * ly
+    assert -0.5 * lx < bx[6] < -0.4 * lx and 0.4 * lx < bx[7] < 0.5 * lx
     assert np.abs(x - xo).max() < 1e-8 and np.abs(v - vo).max() < 1e-8 * np.abs(vo).max() + 1e-12
+    # yz cannot flip while xy is deformed too (it would change xz by xy): LAMMPS refuses the run, and so do we
+    d2 = dict(d); b2 = box.copy(); b2[6] = 0.0; b2[7] = 0.0; b2[8] = 0.49 * ly
+    d2["box"] = b2; d2["x"] = _affine(small_pe["box"], b2, small_pe["x"])
+    e.register_replica("pe", 2, d2)
+    e.set_state(4, "pe", 2, d2["box"], d2["x"], d2["v"])
+    with pytest.raises(capi.EngineError, match="yz too much"):
+        e.debug_run("pe", 2, 12, 1.0, 300.0, qp=4, rates=np.array([0, 0, 0, 0, 0, 0.004 * ly / lz], float))
+    o2 = po.Oracle(d2, po.default_params(**kw))
+    with pytest.raises(RuntimeError):
+        o2.run(12, 1.0, 300.0, rates=np.array([0, 0, 0, 0, 0, 0.004 * ly / lz], float))
     e.close()
 
 
@@ -348,6 +370,7 @@ def test_persistent_state_shears_across_the_flip_over_several_updates(small_pe):
     lx, ly, lz = box[3] - box[0], box[4] - box[1], box[5] - box[2]
     box[6] = 0.42 * lx
     d["box"] = box
+    d["x"] = _affine(small_pe["box"], box, small_pe["x"])
     e = capi.Engine(capi.default_params(**kw))
     e.register_replica("pe", 1, d)
     o = po.Oracle(d, po.default_params(**kw))

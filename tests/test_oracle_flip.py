@@ -31,6 +31,14 @@ def test_tilt_target_continues_from_a_flipped_box():
     assert np.allclose(t, [0.3001, -0.2, 0.1], rtol=0, atol=1e-14)
 
 
+def _affine(box_old, box_new, x):
+    """positions carried affinely from one triclinic box to another (what `change_box ... remap` does)"""
+    def hmat(b):
+        return np.array([[b[3] - b[0], b[6], b[7]], [0.0, b[4] - b[1], b[8]], [0.0, 0.0, b[5] - b[2]]])
+    lam = np.linalg.solve(hmat(box_old), (np.asarray(x, float) - np.asarray(box_old[:3], float)).T)
+    return (hmat(box_new) @ lam).T + np.asarray(box_new[:3], float)
+
+
 def _oracle(d, **kw):
     from oracle import pyoracle as po
     base = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
@@ -61,6 +69,7 @@ def test_a_shear_run_flips_and_the_physics_does_not_notice(small_pe):
     lx, ly = box[3] - box[0], box[4] - box[1]
     box[6] = 0.485 * lx
     d["box"] = box
+    d["x"] = _affine(small_pe["box"], box, small_pe["x"])
     rate_xy = 0.004 * lx / ly          # xy grows by 0.004 Lx per fs: crosses Lx/2 after ~4 steps of 1 fs
     rates = np.array([0, 0, 0, rate_xy, 0, 0], float)
     o = _oracle(d)
