@@ -43,14 +43,51 @@ def _cpu_eval(k, cells, strain, nss):
     return k, t0, t1, int(nts), o.timing()
 
 
+def _lammps_baseline(lmp, scripts, cells, strains, nss, ncore):
+    """The reference's own CPU path: its three LAMMPS scripts on the exported replica (tools/export_lammps_case.py), one
+    serial LAMMPS per core (stmd_sync.h:189-278 with n_sims >= ranks); only the two lifetimes of an evaluation are timed."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import export_lammps_case as x
+    from scema_amd.systems import build_pe
+    d = build_pe(*cells, shake_project=True)
+    base = tempfile.mkdtemp(prefix="scema_lmp_")
+    dirs = []
+    for k in range(ncore):
+        out = os.path.join(base, str(k))
+        x.export(out, d, strains[k], scripts, nss=nss)
+        subprocess.check_call([lmp, "-in", "make_init.lammps", "-log", "none", "-screen", "none"], cwd=out)
+        dirs.append(out)
+    t0 = time.time()
+    procs = [subprocess.Popen(f"{lmp} -in phase_a.lammps -log none -screen none && {lmp} -in phase_b.lammps -log none -screen none", shell=True, cwd=o)
+             for o in dirs]
+    rcs = [p.wait() for p in procs]
+    dt = time.time() - t0
+    if any(rcs):
+        raise RuntimeError(f"LAMMPS failed in {base}")
+    return ncore / dt, dt
+
+
 def cpu_baseline(cells, strains, nss):
-    """The oracle (CPU restatement, NOT LAMMPS) timed on the host cores the way the reference runs its CPU path: one
-    serial MD engine per core, one replica each (stmd_sync.h:189-278 with n_sims >= ranks).  One PROCESS per core, started
-    before this program touches the GPU; wall = first evaluation start to last evaluation end."""
+    """The CPU path timed on the host cores the way the reference runs it: one serial MD engine per core, one replica each
+    (stmd_sync.h:189-278 with n_sims >= ranks).  If a LAMMPS executable and the reference's scripts ($SCEMA_SCRIPTS) are on
+    this host, that IS the reference path ("kind": "reference"); otherwise the oracle (CPU restatement, NOT LAMMPS), one
+    PROCESS per core, started before this program touches the GPU; wall = first evaluation start to last evaluation end."""
     import concurrent.futures as cf
     import multiprocessing as mp
     import shutil
     ncore = max(1, min(len(strains), os.cpu_count() or 1, 32))
+    lmp = next((shutil.which(n) for n in (os.environ.get("SCEMA_LAMMPS") or "lmp", "lmp_serial", "lmp_mpi", "lammps") if shutil.which(n)), None)
+    scripts = os.environ.get("SCEMA_SCRIPTS", "")
+    natoms = 12 * cells[0] * cells[1] * cells[2]
+    if lmp and os.path.isdir(scripts):
+        try:
+            rate, dt = _lammps_baseline(lmp, scripts, cells, strains, nss, ncore)
+            return {"value": rate, "unit": "evals/s", "cores": ncore, "kind": "reference", "lammps_on_this_host": lmp,
+                    "sample": f"{ncore} PE-{natoms} evaluations through the reference's in.set / in.strain / ELASTIC/in.homogenization scripts, one serial "
+                              f"LAMMPS per host core on {ncore} of {os.cpu_count()} cores: {dt:.1f} s wall"}
+        except Exception as exc:
+            print("bench.py: LAMMPS baseline failed, falling back to the CPU restatement:", exc, file=sys.stderr)
     with cf.ProcessPoolExecutor(max_workers=ncore, mp_context=mp.get_context("spawn")) as ex:
         res = list(ex.map(_cpu_eval, range(ncore), [cells] * ncore, [strains[k] for k in range(ncore)], [nss] * ncore))
     t0 = min(r[1] for r in res)
@@ -58,10 +95,8 @@ def cpu_baseline(cells, strains, nss):
     dt = t1 - t0
     tm = res[0][4]
     alone = np.mean([r[2] - r[1] for r in res])
-    lmp = next((shutil.which(n) for n in ("lmp", "lmp_serial", "lmp_mpi", "lammps") if shutil.which(n)), None)
-    natoms = 12 * cells[0] * cells[1] * cells[2]
     return {"value": ncore / dt, "unit": "evals/s", "cores": ncore, "kind": "port",
-            "lammps_on_this_host": lmp,   # a LAMMPS found here would be the real baseline; none is installed on these images
+            "lammps_on_this_host": lmp,   # a LAMMPS found here (with $SCEMA_SCRIPTS) would be the real baseline; none is installed on these images
             "sample": f"{ncore} PE-{natoms} evaluations ({res[0][3]}+{nss} MD steps each), one process per host core on {ncore} of "
                       f"{os.cpu_count()} cores: {dt:.1f} s wall, {alone:.1f} s mean per evaluation (replica 0: pair {tm['pair']:.1f} s, "
                       f"kspace {tm['kspace']:.1f} s, neigh {tm['neigh']:.1f} s); CPU restatement (oracle/md_oracle.c), not LAMMPS"}

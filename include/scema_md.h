@@ -210,7 +210,12 @@ int scema_md_set_state(scema_md_engine *e, int32_t qp_id, const char *matid, int
                        const double box[9], const double *x, const double *v);
 int scema_md_drop_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica);
 int scema_md_save_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path);
+/* load: the engine's own state container, or a LAMMPS 17Nov16 binary restart of the same replica as the reference writes
+ * last.<qp>.* / lcts.<qp>.* (told apart by the magic string; atoms matched by tag, unwrapped with the image flags) */
 int scema_md_load_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path);
+/* the state as a LAMMPS 17Nov16 binary restart (what stmd_problem.h:258,268 write), for hand-over to a LAMMPS-based run */
+int scema_md_save_state_lammps(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path,
+                               double timestep, int64_t ntimestep);
 
 /* ---- init_material: the quantities EQMDProblem::lammps_equilibration derives from an equilibrated
  * replica (init_material_problem.h:196-300): box lengths, initial stress (ELASTIC/in.homogenization.lammps: NVT + SHAKE

@@ -63,6 +63,10 @@ int scema_stmd_create(scema_md_engine *engine, int32_t rank, int32_t world, scem
                       scema_stmd **out);
 void scema_stmd_destroy(scema_stmd *s);
 const char *scema_stmd_last_error(const scema_stmd *s);
+/* on != 0: write last.<qp>.<mat>_<rep>.dump after every evaluation and the lcts.* checkpoints in LAMMPS' 17Nov16 binary
+ * restart layout, as stmd_problem.h:258,268 do, so that a LAMMPS-based SCEMa run can take the simulations over (restart
+ * files of either kind are read back by init).  Default off: states stay in HBM, checkpoints in the engine's container. */
+int scema_stmd_set_lammps_state_files(scema_stmd *s, int32_t on);
 /* STMDSync::init (stmd_sync.h:1023) */
 int scema_stmd_init(scema_stmd *s, const scema_stmd_config *cfg);
 /* STMDSync::update (stmd_sync.h:1070): update_list[i].update_strain in, .update_stress out (on every rank) */

@@ -27,7 +27,7 @@ SYMBOLS = [
     "scema_md_convert_lammps_restart", "scema_md_write_lammps_restart",
     "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
     "scema_md_local_stress_count", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
-    "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file",
+    "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file", "scema_md_save_state_lammps",
     "scema_md_init_material", "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile",
     "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_state_owner", "scema_md_last_plan",
@@ -338,6 +338,10 @@ class Engine:
 
     def save_state_file(self, qp, matid, replica, path):
         self._chk(lib().scema_md_save_state_file(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), path.encode()))
+
+    def save_state_lammps(self, qp, matid, replica, path, timestep=2.0, ntimestep=0):
+        self._chk(lib().scema_md_save_state_lammps(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), path.encode(),
+                                                   C.c_double(timestep), C.c_int64(ntimestep)))
 
     def load_state_file(self, qp, matid, replica, path):
         self._chk(lib().scema_md_load_state_file(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), path.encode()))

@@ -145,7 +145,9 @@ int walk(Reader &r, Restart &R) {
       case SPECIAL_LJ: r.dvec(dv); for (size_t k = 0; k < 3 && k < dv.size(); k++) R.special_lj[k] = dv[k]; break;
       case SPECIAL_COUL: r.dvec(dv); for (size_t k = 0; k < 3 && k < dv.size(); k++) R.special_coul[k] = dv[k]; break;
       case MASS: r.dvec(R.mass); break;
-      case NO_PAIR: R.no_pair = 1; break;
+      // 17Nov16 writes nothing for a pair style without restart info (the reference's init.sic_1.bin: pair sw, no record);
+      // later versions write NO_PAIR followed by the style name as a string: consume it, or the record walk desynchronises
+      case NO_PAIR: R.pair_style = r.str(); R.no_pair = 1; break;
       case PAIR: case BOND: case ANGLE: case DIHEDRAL: case IMPROPER: return flag;
       default:
         r.ok = false;

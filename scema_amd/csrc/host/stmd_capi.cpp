@@ -21,6 +21,12 @@ int scema_stmd_create(scema_md_engine *engine, int32_t rank, int32_t world, scem
 void scema_stmd_destroy(scema_stmd *s) { delete s; }
 const char *scema_stmd_last_error(const scema_stmd *s) { return s ? s->sync.last_error().c_str() : "null handle"; }
 
+int scema_stmd_set_lammps_state_files(scema_stmd *s, int32_t on) {
+  if (!s) return SCEMA_MD_ERR_ARG;
+  s->sync.set_lammps_state_files(on != 0);
+  return SCEMA_MD_OK;
+}
+
 int scema_stmd_init(scema_stmd *s, const scema_stmd_config *cfg) {
   if (!s || !cfg) return SCEMA_MD_ERR_ARG;
   return s->sync.init(*cfg);

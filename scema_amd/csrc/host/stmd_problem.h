@@ -16,8 +16,10 @@ namespace scema {
 class STMDProblem {
  public:
   // mdcomm/pcolor of the reference become (engine, rank, world): one engine = one GPU = one batch
-  STMDProblem(scema_md_engine *engine, int rank, int world, bool verbose)
-      : engine_(engine), rank_(rank), world_(world), verbose_(verbose) {}
+  // lammps_states: write lcts.* in LAMMPS' own restart layout and, like the reference (stmd_problem.h:258), a
+  // last.<qp>.<mat>_<rep>.dump after every evaluation, so that a LAMMPS-based run can take the simulations over
+  STMDProblem(scema_md_engine *engine, int rank, int world, bool verbose, bool lammps_states = false)
+      : engine_(engine), rank_(rank), world_(world), verbose_(verbose), lammps_states_(lammps_states) {}
 
   // reference stmd_problem.h:458-496
   int strain(MDSim &md_sim, bool approx_md_with_hookes_law) {
@@ -90,11 +92,22 @@ class STMDProblem {
           sims[i]->stress_updated = true;
         }
       for (int i : mine) {
+        const std::string tail = std::to_string(sims[i]->qp_id) + "." + sims[i]->matid + "_" + std::to_string(sims[i]->replica) + ".dump";
+        // reference stmd_problem.h:258: last.<qp>.<mat>_<rep>.dump after the straining run (here: the state after the
+        // evaluation; kept in HBM anyway, written only on request)
+        if (lammps_states_ && !sims[i]->output_folder.empty()) {
+          rc = scema_md_save_state_lammps(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica,
+                                          (sims[i]->output_folder + "/last." + tail).c_str(), sims[i]->timestep_length, 0);
+          if (rc != SCEMA_MD_OK) {
+            err_ = scema_md_last_error(engine_);
+            return rc;
+          }
+        }
         // reference stmd_problem.h:266-273: lcts.<qp>.<mat>_<rep>.dump every "checkpoint frequency" steps
         if (sims[i]->checkpoint && !sims[i]->restart_folder.empty()) {
-          const std::string path = sims[i]->restart_folder + "/lcts." + std::to_string(sims[i]->qp_id) + "." + sims[i]->matid + "_" +
-                                   std::to_string(sims[i]->replica) + ".dump";
-          rc = scema_md_save_state_file(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, path.c_str());
+          const std::string path = sims[i]->restart_folder + "/lcts." + tail;
+          rc = lammps_states_ ? scema_md_save_state_lammps(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, path.c_str(), sims[i]->timestep_length, 0)
+                              : scema_md_save_state_file(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, path.c_str());
           if (rc != SCEMA_MD_OK) {
             err_ = scema_md_last_error(engine_);
             return rc;
@@ -133,7 +146,7 @@ class STMDProblem {
 
   scema_md_engine *engine_;
   int rank_, world_;
-  bool verbose_;
+  bool verbose_, lammps_states_;
   std::string err_;
 };
 

@@ -37,6 +37,8 @@ class STMDSync {
       : engine_(engine), rank_(rank), world_(world), allgather_(ag), ag_ctx_(ctx) {}
 
   const std::string &last_error() const { return err_; }
+  // last.* after every evaluation and lcts.* checkpoints in LAMMPS' binary restart layout (stmd_problem.h:258,268)
+  void set_lammps_state_files(bool on) { lammps_state_files = on; }
   const std::vector<ReplicaData> &replicas() const { return replica_data; }
   unsigned nreplicas() const { return nrepl; }
 
@@ -264,7 +266,7 @@ class STMDSync {
 
   // reference stmd_sync.h:570-618: round robin i % n_md_batches; here one GPU per batch, dealt by the engine's planner
   int execute_inside_md_simulations(std::vector<MDSim> &md_simulations) {
-    STMDProblem stmd_problem(engine_, rank_, world_, verbose);
+    STMDProblem stmd_problem(engine_, rank_, world_, verbose, lammps_state_files);
     int rc = stmd_problem.strain_batch(md_simulations, approx_md_with_hookes_law);
     if (rc) return fail(rc, stmd_problem.last_error());
     return SCEMA_MD_OK;
@@ -355,7 +357,7 @@ class STMDSync {
   int freq_checkpoint = 1, freq_output_homog = 1;
   bool output_homog = false, checkpoint_save = false;
   std::string macrostatelocout, nanostatelocin, nanostatelocout, nanostatelocres, nanologloc, md_scripts_directory;
-  bool approx_md_with_hookes_law = false, verbose = false;
+  bool approx_md_with_hookes_law = false, verbose = false, lammps_state_files = false;
   std::vector<std::string> pending_restart;
 };
 

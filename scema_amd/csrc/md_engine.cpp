@@ -81,8 +81,33 @@ static void perp_widths(const HostBox &b, double w[3]) {
 // -------------------------------------------------------------------------------------------
 // Topology of one (material, replica): immutable, shared by every quadrature point that uses it
 // -------------------------------------------------------------------------------------------
+// the replica as it was registered (init.<mat>_<rep>.bin), kept so that a state can be written back in LAMMPS' own
+// restart layout (last.<qp>.* / lcts.<qp>.*, stmd_problem.h:258,268)
+struct SysCopy {
+  scema_md_system sys;
+  std::vector<int32_t> type, ba, bt, aa, at, da, dt, ia, it;
+  std::vector<double> q, mass, eps, sig, bc, ac, dc, ic;
+  void take(const scema_md_system &s) {
+    sys = s;
+    const size_t n = (size_t)s.natoms, nt = (size_t)s.ntypes;
+    type.assign(s.type, s.type + n); q.assign(s.charge, s.charge + n); mass.assign(s.mass, s.mass + nt);
+    eps.assign(s.eps, s.eps + nt * nt); sig.assign(s.sigma, s.sigma + nt * nt);
+    ba.assign(s.bond_atoms, s.bond_atoms + 2 * (size_t)s.nbonds); bt.assign(s.bond_type, s.bond_type + s.nbonds); bc.assign(s.bond_coeff, s.bond_coeff + 2 * (size_t)s.nbondtypes);
+    aa.assign(s.angle_atoms, s.angle_atoms + 3 * (size_t)s.nangles); at.assign(s.angle_type, s.angle_type + s.nangles); ac.assign(s.angle_coeff, s.angle_coeff + 2 * (size_t)s.nangletypes);
+    da.assign(s.dihedral_atoms, s.dihedral_atoms + 4 * (size_t)s.ndihedrals); dt.assign(s.dihedral_type, s.dihedral_type + s.ndihedrals); dc.assign(s.dihedral_coeff, s.dihedral_coeff + 4 * (size_t)s.ndihedraltypes);
+    ia.assign(s.improper_atoms, s.improper_atoms + 4 * (size_t)s.nimpropers); it.assign(s.improper_type, s.improper_type + s.nimpropers); ic.assign(s.improper_coeff, s.improper_coeff + 2 * (size_t)s.nimpropertypes);
+    sys.type = type.data(); sys.charge = q.data(); sys.mass = mass.data(); sys.eps = eps.data(); sys.sigma = sig.data();
+    sys.bond_atoms = ba.data(); sys.bond_type = bt.data(); sys.bond_coeff = bc.data();
+    sys.angle_atoms = aa.data(); sys.angle_type = at.data(); sys.angle_coeff = ac.data();
+    sys.dihedral_atoms = da.data(); sys.dihedral_type = dt.data(); sys.dihedral_coeff = dc.data();
+    sys.improper_atoms = ia.data(); sys.improper_type = it.data(); sys.improper_coeff = ic.data();
+    sys.x = nullptr; sys.v = nullptr;
+  }
+};
+
 struct Topo {
   int natoms = 0, ntypes = 0;
+  SysCopy original;
   std::vector<int> type;
   std::vector<double> q, mass_atom, lj;
   int nbonds = 0, nbonds_noshake = 0, nangles = 0, ndihedrals = 0, nimpropers = 0, nspecial = 0, nclus = 0, ncons = 0;
@@ -510,6 +535,7 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   }
   t.bt_ntile = ntile;
   (void)ncf;
+  t.original.take(*s);
   std::memcpy(t.init_box, s->box, sizeof t.init_box);
   t.init_x.assign(s->x, s->x + 3 * (size_t)n);
   t.init_v.assign(s->v, s->v + 3 * (size_t)n);
@@ -2260,15 +2286,62 @@ int scema_md_load_state_file(scema_md_engine *e, int32_t qp_id, const char *mati
   if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, replica);
   FILE *fp = fopen(path, "rb");
   if (!fp) return fail(e, SCEMA_MD_ERR_IO, "cannot open %s", path);
-  char magic[8];
+  char magic[16] = {0};
   int32_t n = 0;
   double box[9];
   std::vector<double> x(3 * (size_t)t->natoms), v(x.size());
-  bool ok = fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, STATE_MAGIC, 8) == 0 && fread(&n, 4, 1, fp) == 1 && n == t->natoms &&
-            fread(box, 8, 9, fp) == 9 && fread(x.data(), 8, x.size(), fp) == x.size() && fread(v.data(), 8, v.size(), fp) == v.size();
+  bool ok = fread(magic, 1, 8, fp) == 8;
+  if (ok && std::memcmp(magic, "LammpS R", 8) == 0) {
+    // a LAMMPS binary restart, as the reference writes last.<qp>.* / lcts.<qp>.* (stmd_problem.h:258,268): box and the
+    // per-atom block; atoms are matched by tag (file order is whatever the writing processors had), positions are
+    // unwrapped with the image flags (states are kept unwrapped here)
+    fclose(fp);
+    scema_lammps_restart_info info;
+    if (scema_md_probe_lammps_restart(path, &info) != SCEMA_MD_OK) return fail(e, SCEMA_MD_ERR_IO, "%s: %s", path, info.error);
+    if (info.natoms != t->natoms) return fail(e, SCEMA_MD_ERR_IO, "%s holds %lld atoms, replica %s_%d has %d", path, (long long)info.natoms, matid, replica, t->natoms);
+    std::vector<int64_t> tag(t->natoms);
+    std::vector<int32_t> image(3 * (size_t)t->natoms);
+    std::vector<double> xf(x.size()), vf(x.size());
+    if (scema_md_read_lammps_restart_atoms(path, t->natoms, tag.data(), nullptr, image.data(), xf.data(), vf.data()) != SCEMA_MD_OK)
+      return fail(e, SCEMA_MD_ERR_IO, "%s: cannot read the per-atom block", path);
+    std::memcpy(box, info.box, sizeof box);
+    const double hx[3] = {box[3] - box[0], box[4] - box[1], box[5] - box[2]};
+    std::vector<char> seen(t->natoms, 0);
+    for (int i = 0; i < t->natoms; i++) {
+      const int64_t a = tag[i] - 1;
+      if (a < 0 || a >= t->natoms || seen[a]) return fail(e, SCEMA_MD_ERR_IO, "%s: atom tags are not a permutation of 1..%d", path, t->natoms);
+      seen[a] = 1;
+      const int *im = &image[3 * (size_t)i];
+      x[3 * a] = xf[3 * (size_t)i] + hx[0] * im[0] + box[6] * im[1] + box[7] * im[2];
+      x[3 * a + 1] = xf[3 * (size_t)i + 1] + hx[1] * im[1] + box[8] * im[2];
+      x[3 * a + 2] = xf[3 * (size_t)i + 2] + hx[2] * im[2];
+      for (int c = 0; c < 3; c++) v[3 * a + c] = vf[3 * (size_t)i + c];
+    }
+    return scema_md_set_state(e, qp_id, matid, replica, box, x.data(), v.data());
+  }
+  ok = ok && std::memcmp(magic, STATE_MAGIC, 8) == 0 && fread(&n, 4, 1, fp) == 1 && n == t->natoms && fread(box, 8, 9, fp) == 9 &&
+       fread(x.data(), 8, x.size(), fp) == x.size() && fread(v.data(), 8, v.size(), fp) == v.size();
   fclose(fp);
   if (!ok) return fail(e, SCEMA_MD_ERR_IO, "%s is not a state file of %s_%d", path, matid, replica);
   return scema_md_set_state(e, qp_id, matid, replica, box, x.data(), v.data());
+}
+
+// The state of (qp, mat, rep) as a LAMMPS 17Nov16 binary restart: what stmd_problem.h:258 (last.<qp>.<mat>_<rep>.dump) and
+// :268 (lcts.*) write, so that a LAMMPS-based SCEMa run can pick the simulation up (and the other way round, through
+// scema_md_load_state_file).  Positions are written as stored (unwrapped, image flags 0): read_restart remaps them.
+int scema_md_save_state_lammps(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path, double timestep,
+                               int64_t ntimestep) {
+  if (!e || !path) return SCEMA_MD_ERR_ARG;
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, replica);
+  std::vector<double> x(3 * (size_t)t->natoms), v(x.size());
+  scema_md_system s = t->original.sys;
+  int rc = scema_md_get_state(e, qp_id, matid, replica, s.box, x.data(), v.data());
+  if (rc) return rc;
+  s.x = x.data();
+  s.v = v.data();
+  rc = scema_md_write_lammps_restart(path, &s, e->p.cut_lj, e->p.cut_coul, timestep, ntimestep);
+  return rc ? fail(e, rc, "cannot write %s", path) : SCEMA_MD_OK;
 }
 
 // ---- parity / measurement hooks ----

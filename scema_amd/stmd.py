@@ -9,7 +9,7 @@ import numpy as np
 
 from . import capi
 
-SYMBOLS = ["scema_stmd_create", "scema_stmd_destroy", "scema_stmd_last_error", "scema_stmd_init",
+SYMBOLS = ["scema_stmd_create", "scema_stmd_destroy", "scema_stmd_last_error", "scema_stmd_init", "scema_stmd_set_lammps_state_files",
            "scema_stmd_update", "scema_stmd_replica_data", "scema_eqmd_equil"]
 
 
@@ -80,6 +80,9 @@ class STMDSync:
         if rc != 0:
             raise capi.EngineError(f"scema_stmd_create rc={rc}")
         self.engine = engine
+
+    def set_lammps_state_files(self, on: bool = True):
+        self._chk(capi.lib().scema_stmd_set_lammps_state_files(self.h, C.c_int32(1 if on else 0)))
 
     def close(self):
         if self.h:

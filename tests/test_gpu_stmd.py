@@ -177,3 +177,48 @@ def test_init_bin_may_be_a_lammps_restart(small_pe, tmp_path):
         res.append(np.array(sync.update(1, 0.0, 1, [(5, capi.QP_NONE, 0, eps[0])])))
         sync.close(); eng.close()
     assert np.abs(res[0] - res[1]).max() < 1e-8 * np.abs(res[0]).max()
+
+
+def test_states_travel_as_lammps_restart_files(small_pe, tmp_path):
+    """With scema_stmd_set_lammps_state_files the run writes last.<qp>.* after every evaluation and its lcts.* checkpoints
+    in LAMMPS' 17Nov16 binary restart layout (stmd_problem.h:258,268), and STMDSync::restart (stmd_sync.h:167-187) reads such
+    files back: the continued run equals the uninterrupted one.  The files are also read by the second, plain-Python
+    reader (oracle/lammps_restart.py)."""
+    import shutil
+    from scema_amd import capi, stmd
+    from oracle import lammps_restart as lr
+    dirs = _dirs(tmp_path)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    s0 = np.zeros(6)
+    stmd.write_nanoscale_input(dirs["nanoscale_input"], "pe", 1, init_length=lens, init_stress_raw=s0,
+                               stiff_file_order=np.zeros(36), nsheets=0, sysd=small_pe)
+    common = dict(nanostatelocin=dirs["nanoscale_input"], nanostatelocout=dirs["nanoscale_output"],
+                  nanostatelocres=dirs["nanoscale_restart"], macrostatelocout=dirs["macroscale_output"],
+                  mdtype=("pe",), nrepl=1, md_nsteps_sample=20, freq_checkpoint=1)
+    eps = np.array([-4e-4, -4e-4, 1.2e-3, 5e-5, -3e-5, 2e-5])
+    eng = capi.Engine(capi.default_params(**KW))
+    sync = stmd.STMDSync(eng)
+    sync.set_lammps_state_files(True)
+    sync.init(**common)
+    sync.update(1, 0.0, 1, [(11, capi.QP_NONE, 0, eps)])
+    lcts = os.path.join(dirs["nanoscale_restart"], "lcts.11.pe_1.dump")
+    last = os.path.join(dirs["nanoscale_output"], "last.11.pe_1.dump")
+    for f in (lcts, last):
+        info = capi.probe_lammps_restart(f)
+        assert info.version == b"17 Nov 2016" and info.atom_style == b"full" and info.natoms == small_pe["natoms"]
+        assert info.pair_style == b"lj/cut/coul/long"
+    py = lr.read_restart(lcts)
+    box1, x1, v1 = eng.get_state(11, "pe", 1)
+    assert np.allclose([py["BOXLO"][0], py["BOXHI"][0], py["XY"]], [box1[0], box1[3], box1[6]], rtol=0, atol=1e-12)
+    assert len(py["atoms"]) == small_pe["natoms"] and py["PAIR"] == "lj/cut/coul/long"
+    # keep the step-1 files aside (step 2 overwrites them), continue in memory, then restart a fresh engine from the file
+    os.makedirs(os.path.join(dirs["nanoscale_input"], "restart"), exist_ok=True)
+    shutil.copy(lcts, os.path.join(dirs["nanoscale_input"], "restart"))
+    got2 = sync.update(2, 1e-6, 1, [(11, 11, 0, 0.5 * eps)])
+    sync.close(); eng.close()
+    eng2 = capi.Engine(capi.default_params(**KW))
+    sync2 = stmd.STMDSync(eng2)
+    sync2.init(**common)
+    got2r = sync2.update(2, 1e-6, 1, [(11, 11, 0, 0.5 * eps)])
+    assert np.abs(got2r - got2).max() < 1e-9 * np.abs(got2).max()
+    sync2.close(); eng2.close()
