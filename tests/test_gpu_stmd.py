@@ -208,6 +208,7 @@ def test_states_travel_as_lammps_restart_files(small_pe, tmp_path):
         assert info.version == b"17 Nov 2016" and info.atom_style == b"full" and info.natoms == small_pe["natoms"]
         assert info.pair_style == b"lj/cut/coul/long"
     py = lr.read_restart(lcts)
+    eng._natoms[("pe", 1)] = small_pe["natoms"]      # the replica was registered by STMDSync::init, not through this wrapper
     box1, x1, v1 = eng.get_state(11, "pe", 1)
     assert np.allclose([py["BOXLO"][0], py["BOXHI"][0], py["XY"]], [box1[0], box1[3], box1[6]], rtol=0, atol=1e-12)
     assert len(py["atoms"]) == small_pe["natoms"] and py["PAIR"] == "lj/cut/coul/long"
