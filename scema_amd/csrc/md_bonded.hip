@@ -50,26 +50,55 @@ __device__ __forceinline__ void lds_add3(double *f, int l, const double *v) {
   (void)__hip_atomic_fetch_add(&f[3 * l + 2], v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-extern __shared__ double s_bt[];  // [3*maxloc] positions, [3*maxloc] forces
+extern __shared__ double s_bt[];  // [3*maxloc] positions, [3*maxloc] forces, [maxloc] charges, [ncoef] coefficient tables, [2 or 4 x nt2] LJ table, int [maxloc] types
+
+#ifndef BT_OCC
+#define BT_OCC 4
+#endif
+#define BT_PRE 8   // descriptors a thread requests up front (chunks of its wave): covers 32 chunks = 2 048 terms per tile
 
 // PARTS: also split virial / energy per part (parity hook); otherwise one lumped virial
 template <bool PARTS>
-__global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__ sims, int maxloc) {
+__global__ __launch_bounds__(BT_TPB, BT_OCC) void k_bonded(const SimDev *__restrict__ sims, int maxloc, int maxcoef) {
   const SimDev &S = sims[blockIdx.y];
   if ((int)blockIdx.x >= S.bt_ntile) return;
   SimScalars &sc = *S.sc;
   __shared__ double s_red[8 * (BT_TPB / 64)];
   const int *desc = S.bt_desc + (size_t)blockIdx.x * BT_DESC;
-  const int nloc = desc[1], nown = desc[14];
+  const int nloc = desc[1], nown = desc[14], nchunk = desc[3];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the wave's term descriptors first: nothing below depends on them until the positions are staged, so their latency
+  // runs under the staging loads
+  const unsigned long long *td = S.bt_terms + (size_t)desc[2] * 64 + lane;
+  unsigned long long dq[BT_PRE];
+#pragma unroll
+  for (int k = 0; k < BT_PRE; k++) {
+    const int c = wave + (BT_TPB / 64) * k;
+    dq[k] = (c < nchunk) ? td[(size_t)c * 64] : 0ull;
+  }
   const int *atoms = S.bt_atoms + desc[0];
-  double *s_x = s_bt, *s_f = s_bt + 3 * (size_t)maxloc;
+  const int nt = S.ntypes, nt2 = nt * nt;
+  double *s_x = s_bt, *s_f = s_bt + 3 * (size_t)maxloc, *s_q = s_bt + 6 * (size_t)maxloc, *s_cf = s_bt + 7 * (size_t)maxloc;
+  double *s_lj = s_cf + maxcoef;
+  int *s_t = (int *)(s_lj + (PARTS ? 4 : 2) * (size_t)MD_MAXTYPES * MD_MAXTYPES);
   for (int l = threadIdx.x; l < nloc; l += BT_TPB) {
     const int a = atoms[l];
     s_x[3 * l] = S.x[3 * a]; s_x[3 * l + 1] = S.x[3 * a + 1]; s_x[3 * l + 2] = S.x[3 * a + 2];
     s_f[3 * l] = 0.0; s_f[3 * l + 1] = 0.0; s_f[3 * l + 2] = 0.0;
+    s_q[l] = S.q[a];
+    s_t[l] = S.type[a] * nt;
+  }
+  for (int k = threadIdx.x; k < S.bt_ncoef; k += BT_TPB) s_cf[k] = S.bt_coef[k];
+  // (lj1, lj2) of a type pair side by side (and lj3, lj4 behind them for the energies of the parity hook)
+  for (int k = threadIdx.x; k < 2 * nt2; k += BT_TPB) {
+    s_lj[k] = S.lj[(k & 1) * nt2 + (k >> 1)];
+    if (PARTS) s_lj[2 * nt2 + k] = S.lj[(2 + (k & 1)) * nt2 + (k >> 1)];
   }
   BoxD b;
   box_derive(sc.box, b);
+  const double g = S.g_ewald, g2u = g * g * S.coul_uscale;
+  const int np = S.coul_npoly;
+  const double *cf_bond = s_cf + S.bt_cf_off[0], *cf_angle = s_cf + S.bt_cf_off[1], *cf_dih = s_cf + S.bt_cf_off[2], *cf_imp = s_cf + S.bt_cf_off[3];
   __syncthreads();
   double vsum[6] = {0, 0, 0, 0, 0, 0};
   // per-part sums straight to memory (parity hook: slow path, never timed)
@@ -83,41 +112,35 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
       for (int k = 0; k < 6; k++) vsum[k] += v[k];
     }
   };
-  // ---- bonds (the SHAKE'd ones only while fix shake is off) ----
-  for (int pass = 0; pass < 2; pass++) {
-    if (pass == 1 && S.use_shake) break;
-    const int kind = pass == 0 ? BT_BOND : BT_BOND_SHAKEN;
-    const int t0 = desc[2 + 2 * kind], nt = desc[3 + 2 * kind];
-    const int *at = pass == 0 ? S.bond_at : S.bondsh_at;
-    const double *cf = pass == 0 ? S.bond_cf : S.bondsh_cf;
-    for (int t = threadIdx.x; t < nt; t += BT_TPB) {
-      const int m = t0 + t;
-      const bool counted = !(at[2 * m] & BT_NOCOUNT);
-      const int l1 = at[2 * m] & BT_LMASK, l2 = at[2 * m + 1];
-      const double K = cf[2 * m], r0 = cf[2 * m + 1];
-      double d[3] = {s_x[3 * l1] - s_x[3 * l2], s_x[3 * l1 + 1] - s_x[3 * l2 + 1], s_x[3 * l1 + 2] - s_x[3 * l2 + 2]};
-      minimg(b, d[0], d[1], d[2]);
-      const double rsq = dot3(d, d);
+  auto term = [&](unsigned long long d) {
+    // the kind is the same for the whole chunk (kinds are padded to whole chunks): a scalar branch
+    const int kind = __builtin_amdgcn_readfirstlane((int)(d >> BT_D_KIND_SHIFT) & 7);
+    const bool valid = (d & BT_D_VALID) != 0ull;
+    if (!__any(valid)) return;
+    const bool counted = valid && !(d & BT_D_NOCOUNT);
+    const int l1 = (int)(d & BT_D_LMASK), l2 = (int)((d >> 10) & BT_D_LMASK), l3 = (int)((d >> 20) & BT_D_LMASK), l4 = (int)((d >> 30) & BT_D_LMASK);
+    const int ty = (int)((d >> BT_D_TYPE_SHIFT) & BT_D_TMASK);
+    if (kind == BT_BOND || kind == BT_BOND_SHAKEN) {
+      // ---- bonds (the SHAKE'd ones only while fix shake is off) ----
+      if (kind == BT_BOND_SHAKEN && S.use_shake) return;
+      if (!valid) return;
+      const double K = cf_bond[2 * ty], r0 = cf_bond[2 * ty + 1];
+      double dd[3] = {s_x[3 * l1] - s_x[3 * l2], s_x[3 * l1 + 1] - s_x[3 * l2 + 1], s_x[3 * l1 + 2] - s_x[3 * l2 + 2]};
+      minimg(b, dd[0], dd[1], dd[2]);
+      const double rsq = dot3(dd, dd);
       const double rinv = (rsq > 0.0) ? rsq64(rsq) : 0.0;
       const double r = rsq * rinv;
       const double dr = r - r0, rk = K * dr;
       const double fb = -2.0 * rk * rinv;
-      const double f1[3] = {d[0] * fb, d[1] * fb, d[2] * fb}, f2[3] = {-f1[0], -f1[1], -f1[2]};
+      const double f1[3] = {dd[0] * fb, dd[1] * fb, dd[2] * fb}, f2[3] = {-f1[0], -f1[1], -f1[2]};
       lds_add3(s_f, l1, f1);
       lds_add3(s_f, l2, f2);
       double v[6] = {0, 0, 0, 0, 0, 0};
-      vt(v, d, f1);
+      vt(v, dd, f1);
       emit(counted, P_BOND, v, rk * dr);
-    }
-  }
-  // ---- angles ----
-  {
-    const int t0 = desc[2 + 2 * BT_ANGLE], nt = desc[3 + 2 * BT_ANGLE];
-    for (int t = threadIdx.x; t < nt; t += BT_TPB) {
-      const int m = t0 + t;
-      const bool counted = !(S.angle_at[3 * m] & BT_NOCOUNT);
-      const int l1 = S.angle_at[3 * m] & BT_LMASK, l2 = S.angle_at[3 * m + 1], l3 = S.angle_at[3 * m + 2];
-      const double K = S.angle_cf[2 * m], th0 = S.angle_cf[2 * m + 1];
+    } else if (kind == BT_ANGLE) {
+      if (!valid) return;
+      const double K = cf_angle[2 * ty], th0 = cf_angle[2 * ty + 1];
       double d1[3], d2[3];
       for (int k = 0; k < 3; k++) { d1[k] = s_x[3 * l1 + k] - s_x[3 * l2 + k]; d2[k] = s_x[3 * l3 + k] - s_x[3 * l2 + k]; }
       minimg(b, d1[0], d1[1], d1[2]); minimg(b, d2[0], d2[1], d2[2]);
@@ -138,18 +161,9 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
       double v[6] = {0, 0, 0, 0, 0, 0};
       vt(v, d1, f1); vt(v, d2, f3);
       emit(counted, P_ANGLE, v, tk * dth);
-    }
-  }
-  // ---- dihedrals (opls) and impropers (harmonic): same geometry, different dE/dcos ----
-  for (int pass = 0; pass < 2; pass++) {
-    const int kind = pass == 0 ? BT_DIHEDRAL : BT_IMPROPER;
-    const int t0 = desc[2 + 2 * kind], nt = desc[3 + 2 * kind];
-    const int *atb = pass == 0 ? S.dihedral_at : S.improper_at;
-    for (int t = threadIdx.x; t < nt; t += BT_TPB) {
-      const int m = t0 + t;
-      const int *at = atb + 4 * m;
-      const bool counted = !(at[0] & BT_NOCOUNT);
-      const int l1 = at[0] & BT_LMASK, l2 = at[1], l3 = at[2], l4 = at[3];
+    } else if (kind == BT_DIHEDRAL || kind == BT_IMPROPER) {
+      // ---- dihedrals (opls) and impropers (harmonic): same geometry, different dE/dcos ----
+      if (!valid) return;
       // F=r1-r2, G=r2-r3, H=r4-r3, A=FxG, B=HxG, c=A.B/(|A||B|)
       double F[3], G[3], H[3];
       for (int k = 0; k < 3; k++) {
@@ -169,8 +183,8 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
       double gA[3], gB[3];
       for (int k = 0; k < 3; k++) { gA[k] = B[k] * iab - ca * A[k]; gB[k] = A[k] * iab - cb * B[k]; }
       double dEdc, en = 0.0;
-      if (pass == 0) {
-        const double *K = S.dihedral_cf + 4 * m;
+      if (kind == BT_DIHEDRAL) {
+        const double *K = cf_dih + 4 * ty;
         const double c2 = c * c;
         dEdc = 0.5 * (K[0] - K[1] * 4.0 * c + K[2] * (12.0 * c2 - 3.0) - K[3] * (32.0 * c2 * c - 16.0 * c));
         if (PARTS) {
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
           en = 0.5 * (K[0] * (1.0 + c) + K[1] * (1.0 - cos2) + K[2] * (1.0 + cos3) + K[3] * (1.0 - cos4));
         }
       } else {
-        const double K = S.improper_cf[2 * m], chi0 = S.improper_cf[2 * m + 1];
+        const double K = cf_imp[2 * ty], chi0 = cf_imp[2 * ty + 1];
         double sn = sqrt(1.0 - c * c);
         if (sn < 0.001) sn = 0.001;
         const double dchi = acos(c) - chi0;
@@ -204,56 +218,61 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
       double v[6] = {0, 0, 0, 0, 0, 0};
       const double FG[3] = {F[0] + G[0], F[1] + G[1], F[2] + G[2]};
       vt(v, FG, f1); vt(v, G, f2); vt(v, H, f4);
-      emit(counted, pass == 0 ? P_DIHEDRAL : P_IMPROPER, v, en);
-    }
-  }
-  // ---- special pairs: weighted real-space pair term (k-space minus (1-f_coul) q q / r) ----
-  {
-    const int t0 = desc[2 + 2 * BT_SPECIAL], nt = desc[3 + 2 * BT_SPECIAL];
-    const double g = S.g_ewald, g2u = g * g * S.coul_uscale;
-    const int np = S.coul_npoly;
-    for (int t = threadIdx.x; t < nt; t += BT_TPB) {
-      const int m = t0 + t;
-      const bool counted = !(S.special_at[2 * m] & BT_NOCOUNT);
-      const int l1 = S.special_at[2 * m] & BT_LMASK, l2 = S.special_at[2 * m + 1];
-      const double *cf = S.special_cf + 6 * m;
-      double d[3] = {s_x[3 * l1] - s_x[3 * l2], s_x[3 * l1 + 1] - s_x[3 * l2 + 1], s_x[3 * l1 + 2] - s_x[3 * l2 + 2]};
-      minimg(b, d[0], d[1], d[2]);
-      const double rsq = dot3(d, d);
+      emit(counted, kind == BT_DIHEDRAL ? P_DIHEDRAL : P_IMPROPER, v, en);
+    } else {
+      // ---- special pairs: weighted real-space pair term (k-space minus (1-f_coul) q q / r) ----
+      if (!valid) return;
+      const int lvl = (int)((d >> BT_D_LVL_SHIFT) & 3);
+      const double wl = S.sp_w[lvl - 1], wc = S.sp_w[2 + lvl];
+      const int tt = s_t[l1] + s_t[l2] / nt;
+      const double qq = MD_QQRD2E * s_q[l1] * s_q[l2];
+      double dd[3] = {s_x[3 * l1] - s_x[3 * l2], s_x[3 * l1 + 1] - s_x[3 * l2 + 1], s_x[3 * l1 + 2] - s_x[3 * l2 + 2]};
+      minimg(b, dd[0], dd[1], dd[2]);
+      const double rsq = dot3(dd, dd);
       if (rsq >= S.excl_cut2 && counted) atomicOr(&sc.overflow, 2);  // excluded pair escaped the build-time exclusion gate
       const double rinv = rsq64(rsq), r2inv = rinv * rinv;
       double flj = 0.0, fc = 0.0, en = 0.0, en2 = 0.0;
       if (rsq < S.cut_coul2 && g > 0.0) {
         // erf(x) - 2x/sqrt(pi) exp(-x^2) = x H(x^2): the polynomial of k_pair (md_pair.hip) instead of erf + exp
-        const double tt = fma(rsq, g2u, -1.0);
+        const double tq = fma(rsq, g2u, -1.0);
         double p = S.coul_poly[np - 1];
-        for (int k = np - 2; k >= 0; k--) p = fma(p, tt, S.coul_poly[k]);
+        for (int k = np - 2; k >= 0; k--) p = fma(p, tq, S.coul_poly[k]);
         const double grij = g * rsq * rinv;
-        const double pref = cf[2] * rinv;
-        fc = pref * fma(-grij, p, cf[3]) * r2inv;
-        if (PARTS) en2 = pref * (cf[3] - erf(grij));
+        const double pref = qq * rinv;
+        fc = pref * fma(-grij, p, wc) * r2inv;
+        if (PARTS) en2 = pref * (wc - erf(grij));
       }
-      if (rsq < S.cut_lj2) {
+      if (rsq < S.cut_lj2 && wl != 0.0) {
         const double r6inv = r2inv * r2inv * r2inv;
-        flj = r6inv * (cf[0] * r6inv - cf[1]) * r2inv;
-        if (PARTS) en = r6inv * (cf[4] * r6inv - cf[5]);
+        flj = wl * r6inv * (s_lj[2 * tt] * r6inv - s_lj[2 * tt + 1]) * r2inv;
+        if (PARTS) en = wl * r6inv * (s_lj[2 * nt2 + 2 * tt] * r6inv - s_lj[2 * nt2 + 2 * tt + 1]);
       }
       const double fp = flj + fc;
-      const double f1[3] = {d[0] * fp, d[1] * fp, d[2] * fp}, f2[3] = {-f1[0], -f1[1], -f1[2]};
+      const double f1[3] = {dd[0] * fp, dd[1] * fp, dd[2] * fp}, f2[3] = {-f1[0], -f1[1], -f1[2]};
       lds_add3(s_f, l1, f1);
       lds_add3(s_f, l2, f2);
       if (PARTS) {
         double v[6] = {0, 0, 0, 0, 0, 0}, v2[6] = {0, 0, 0, 0, 0, 0};
-        const double fl[3] = {d[0] * flj, d[1] * flj, d[2] * flj}, fq[3] = {d[0] * fc, d[1] * fc, d[2] * fc};
-        vt(v, d, fl);
-        vt(v2, d, fq);
+        const double fl[3] = {dd[0] * flj, dd[1] * flj, dd[2] * flj}, fq[3] = {dd[0] * fc, dd[1] * fc, dd[2] * fc};
+        vt(v, dd, fl);
+        vt(v2, dd, fq);
         emit(counted, P_LJ, v, en);
         emit(counted, P_COUL, v2, en2);
       } else if (counted) {
-        vt(vsum, d, f1);
+        vt(vsum, dd, f1);
       }
     }
+  };
+  // one copy of the term code (it is large): the descriptor of pass k is picked out of the preloaded registers
+#pragma unroll 1
+  for (int k = 0; k < BT_PRE; k++) {
+    if (wave + (BT_TPB / 64) * k >= nchunk) break;
+    unsigned long long d = dq[0];
+#pragma unroll
+    for (int q = 1; q < BT_PRE; q++) d = (k == q) ? dq[q] : d;
+    term(d);
   }
+  for (int c = wave + (BT_TPB / 64) * BT_PRE; c < nchunk; c += BT_TPB / 64) term(td[(size_t)c * 64]);   // very large tiles
   __syncthreads();
   // flush: the owners' forces, plain coalesced stores (consecutive ranks = consecutive local indices); halo forces
   // belong to the tiles that own those atoms, which evaluate the same terms themselves
@@ -278,9 +297,9 @@ __global__ __launch_bounds__(BT_TPB, 4) void k_bonded(const SimDev *__restrict__
   }
 }
 
-void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int parts) {
+void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int maxcoef, int parts) {
   const dim3 g((unsigned)maxtiles, (unsigned)ns, 1);
-  const size_t lds = (size_t)6 * maxloc * sizeof(double);
+  const size_t lds = ((size_t)7 * maxloc + maxcoef + (parts ? 4 : 2) * MD_MAXTYPES * MD_MAXTYPES) * sizeof(double) + (size_t)maxloc * sizeof(int);
   static size_t optin_tab[16] = {0};
   size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 48 * 1024 && lds > optin) {
@@ -288,6 +307,6 @@ void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxlo
     (void)hipFuncSetAttribute((const void *)k_bonded<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     optin = lds;
   }
-  if (parts) hipLaunchKernelGGL(k_bonded<true>, g, dim3(BT_TPB), lds, st, d, maxloc);
-  else hipLaunchKernelGGL(k_bonded<false>, g, dim3(BT_TPB), lds, st, d, maxloc);
+  if (parts) hipLaunchKernelGGL(k_bonded<true>, g, dim3(BT_TPB), lds, st, d, maxloc, maxcoef);
+  else hipLaunchKernelGGL(k_bonded<false>, g, dim3(BT_TPB), lds, st, d, maxloc, maxcoef);
 }

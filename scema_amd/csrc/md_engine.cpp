@@ -115,9 +115,9 @@ struct Topo {
   double init_box[9];
   std::vector<double> init_x, init_v;
   // device copies
-  DevBuf d_type, d_q, d_mass, d_lj, d_bond_at, d_bond_cf, d_angle_at, d_angle_cf, d_dih_at, d_dih_cf, d_imp_at, d_imp_cf,
-      d_sp_at, d_sp_cf, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_bondsh_at, d_bondsh_cf, d_bt_desc, d_bt_atoms, d_bt_rank;
-  int bt_ntile = 0, bt_maxloc = 1;
+  DevBuf d_type, d_q, d_mass, d_lj, d_bt_terms, d_bt_coef, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_bt_desc, d_bt_atoms, d_bt_rank;
+  int bt_ntile = 0, bt_maxloc = 1, bt_maxchunk = 1, bt_ncoef = 0, bt_cf_off[4] = {0, 0, 0, 0};
+  double sp_w[6] = {0, 0, 0, 0, 0, 0};   // special_bonds weights: lj 1-2, 1-3, 1-4, coul 1-2, 1-3, 1-4
 };
 
 struct State {
@@ -458,13 +458,43 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   for (int m = 0; m < s->ndihedrals; m++) add_term(&dih_at[4 * m], 4, BT_DIHEDRAL, m);
   for (int m = 0; m < s->nimpropers; m++) add_term(&imp_at[4 * m], 4, BT_IMPROPER, m);
   for (int m = 0; m < t.nspecial; m++) add_term(&sp_at[2 * m], 2, BT_SPECIAL, m);
-  // tile-ordered term arrays with local atom indices
+  // Tile-ordered term stream: ONE 64-bit descriptor per term (BT_D_* in md_types.h: four 10-bit local atom indices, the
+  // term's type, kind, special-bond level and the count flag); coefficients are looked up by type in small tables the
+  // kernel stages in LDS.  Kinds follow each other, each padded to whole chunks of 64 descriptors, so a wave always
+  // runs one formula; chunk c of a tile goes to wave c % 4 of its workgroup, which requests all its descriptors with
+  // its first instructions: one memory latency per tile instead of one per kind and pass.
+  std::vector<int> bond_ty;   // type of the reordered bonds
+  for (int pass = 0; pass < 2; pass++)
+    for (int b2 = 0; b2 < s->nbonds; b2++)
+      if ((int)shaken[b2] == pass) bond_ty.push_back(s->bond_type[b2]);
+  std::vector<int> sp_lvl(t.nspecial, 1);
+  for (int m = 0; m < t.nspecial; m++)
+    for (int lvl = 1; lvl <= 3; lvl++)
+      if (sp_cf[2 * m] == s->special_lj[lvl - 1] && sp_cf[2 * m + 1] == s->special_coul[lvl - 1]) { sp_lvl[m] = lvl; break; }
+  // coefficient tables: bonds (K, r0), angles (K, theta0), dihedrals (K1..K4), impropers (K, chi0)
+  std::vector<double> coef;
+  int cf_off[4];
+  cf_off[0] = 0;
+  coef.insert(coef.end(), s->bond_coeff, s->bond_coeff + 2 * (size_t)s->nbondtypes);
+  cf_off[1] = (int)coef.size();
+  coef.insert(coef.end(), s->angle_coeff, s->angle_coeff + 2 * (size_t)s->nangletypes);
+  cf_off[2] = (int)coef.size();
+  coef.insert(coef.end(), s->dihedral_coeff, s->dihedral_coeff + 4 * (size_t)s->ndihedraltypes);
+  cf_off[3] = (int)coef.size();
+  coef.insert(coef.end(), s->improper_coeff, s->improper_coeff + 2 * (size_t)s->nimpropertypes);
+  if (coef.size() > BT_MAXCOEF)
+    return fail(e, SCEMA_MD_ERR_ARG, "%zu bonded coefficients (bond/angle/dihedral/improper types): at most %d fit the LDS table of the bonded kernel", coef.size(), BT_MAXCOEF);
+  if (s->nbondtypes > BT_D_TMASK + 1 || s->nangletypes > BT_D_TMASK + 1 || s->ndihedraltypes > BT_D_TMASK + 1 || s->nimpropertypes > BT_D_TMASK + 1)
+    return fail(e, SCEMA_MD_ERR_ARG, "more than %d types of one bonded kind", BT_D_TMASK + 1);
+  for (int k = 0; k < 4; k++) t.bt_cf_off[k] = cf_off[k];
+  t.bt_ncoef = (int)coef.size();
+  for (int k = 0; k < 3; k++) { t.sp_w[k] = s->special_lj[k]; t.sp_w[3 + k] = s->special_coul[k]; }
   std::vector<int> bt_desc((size_t)ntile * BT_DESC, 0), bt_atoms;
-  std::vector<int> l_at[BT_NKIND];
-  std::vector<double> l_cf[BT_NKIND];
-  const int natm[BT_NKIND] = {2, 2, 3, 4, 4, 2}, ncf[BT_NKIND] = {2, 2, 2, 4, 2, 6};
+  std::vector<unsigned long long> bt_terms;
+  const int natm[BT_NKIND] = {2, 2, 3, 4, 4, 2};
   std::vector<int> local_of(n, -1);
   t.bt_maxloc = 1;
+  t.bt_maxchunk = 1;
   for (int tl = 0; tl < ntile; tl++) {
     int *desc = &bt_desc[(size_t)tl * BT_DESC];
     desc[0] = (int)bt_atoms.size();
@@ -472,25 +502,23 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
     std::vector<int> members, halo;
     const int r0 = tl * BT_OWNERS, r1 = std::min(n, r0 + BT_OWNERS);
     for (int r = r0; r < r1; r++) { members.push_back(by_rank[r]); local_of[by_rank[r]] = r - r0; }
-    auto term_atoms = [&](const TermRef &tr, int &cnt) -> const int * {
+    auto term_atoms = [&](const TermRef &tr) -> const int * {
       const int m = tr.idx;
-      cnt = natm[tr.kind];
       return (tr.kind <= BT_BOND_SHAKEN) ? &bond_at[2 * m] : (tr.kind == BT_ANGLE) ? &angle_at[3 * m] : (tr.kind == BT_DIHEDRAL) ? &dih_at[4 * m]
              : (tr.kind == BT_IMPROPER) ? &imp_at[4 * m] : &sp_at[2 * m];
     };
     for (const TermRef &tr : tile_terms[tl]) {
-      int cnt;
-      const int *at = term_atoms(tr, cnt);
-      for (int k = 0; k < cnt; k++)
+      const int *at = term_atoms(tr);
+      for (int k = 0; k < natm[tr.kind]; k++)
         if (local_of[at[k]] < 0) { local_of[at[k]] = 0; halo.push_back(at[k]); }
     }
     std::sort(halo.begin(), halo.end(), [&](int a, int b) { return rank[a] < rank[b]; });
-    for (size_t l = 0; l < halo.size(); l++) { local_of[halo[l]] = (int)(members.size() + l); }
+    for (size_t l = 0; l < halo.size(); l++) local_of[halo[l]] = (int)(members.size() + l);
     members.insert(members.end(), halo.begin(), halo.end());
-    auto local = [&](int atom) { return local_of[atom]; };
+    if ((int)members.size() > BT_D_LMASK + 1)
+      return fail(e, SCEMA_MD_ERR_ARG, "a bonded tile touches %zu atoms (more than %d): topology too branched for the tile descriptors", members.size(), BT_D_LMASK + 1);
+    desc[2] = (int)(bt_terms.size() / 64);   // first chunk of the tile
     for (int kind = 0; kind < BT_NKIND; kind++) {
-      desc[2 + 2 * kind] = (int)l_at[kind].size() / natm[kind];
-      int cnt = 0;
       // Terms that follow each other in the input share atoms (the nine torsions around one bond): dealt to
       // consecutive lanes they would hit the same LDS accumulators in the same instruction.  A stride
       // permutation spreads them over the tile instead.
@@ -509,32 +537,26 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
       for (int q = 0; q < nk_; q++) {
         const TermRef &tr = *of_kind[(int)(((long long)q * stride) % std::max(nk_, 1))];
         const int m = tr.idx;
-        const int *at = (kind <= BT_BOND_SHAKEN) ? &bond_at[2 * m] : (kind == BT_ANGLE) ? &angle_at[3 * m] : (kind == BT_DIHEDRAL) ? &dih_at[4 * m]
-                        : (kind == BT_IMPROPER) ? &imp_at[4 * m] : &sp_at[2 * m];
-        for (int k = 0; k < natm[kind]; k++) l_at[kind].push_back(local(at[k]) | ((k == 0 && !tr.count) ? BT_NOCOUNT : 0));
-        if (kind <= BT_BOND_SHAKEN) { l_cf[kind].push_back(bond_cf[2 * m]); l_cf[kind].push_back(bond_cf[2 * m + 1]); }
-        else if (kind == BT_ANGLE) { l_cf[kind].push_back(angle_cf[2 * m]); l_cf[kind].push_back(angle_cf[2 * m + 1]); }
-        else if (kind == BT_DIHEDRAL) { for (int k = 0; k < 4; k++) l_cf[kind].push_back(dih_cf[4 * m + k]); }
-        else if (kind == BT_IMPROPER) { l_cf[kind].push_back(imp_cf[2 * m]); l_cf[kind].push_back(imp_cf[2 * m + 1]); }
-        else {
-          // special pair: everything the term needs, so the kernel looks up neither types nor charges
-          const int a0 = at[0], a1 = at[1], tt = t.type[a0] * ncls + t.type[a1];
-          const double wl = sp_cf[2 * m], wc = sp_cf[2 * m + 1];
-          l_cf[kind].push_back(wl * t.lj[tt]); l_cf[kind].push_back(wl * t.lj[nt2 + tt]);
-          l_cf[kind].push_back(MD_QQRD2E * t.q[a0] * t.q[a1]); l_cf[kind].push_back(wc);
-          l_cf[kind].push_back(wl * t.lj[2 * nt2 + tt]); l_cf[kind].push_back(wl * t.lj[3 * nt2 + tt]);
-        }
-        cnt++;
+        const int *at = term_atoms(tr);
+        unsigned long long d = BT_D_VALID | ((unsigned long long)kind << BT_D_KIND_SHIFT);
+        for (int k = 0; k < natm[kind]; k++) d |= (unsigned long long)local_of[at[k]] << (10 * k);
+        const int ty = (kind <= BT_BOND_SHAKEN) ? bond_ty[m] : (kind == BT_ANGLE) ? s->angle_type[m] : (kind == BT_DIHEDRAL) ? s->dihedral_type[m]
+                       : (kind == BT_IMPROPER) ? s->improper_type[m] : 0;
+        d |= (unsigned long long)ty << BT_D_TYPE_SHIFT;
+        if (kind == BT_SPECIAL) d |= (unsigned long long)sp_lvl[m] << BT_D_LVL_SHIFT;
+        if (!tr.count) d |= BT_D_NOCOUNT;
+        bt_terms.push_back(d);
       }
-      desc[3 + 2 * kind] = cnt;
+      while (bt_terms.size() % 64) bt_terms.push_back(0ull);   // whole chunks per kind (an invalid descriptor is all zero)
     }
+    desc[3] = (int)(bt_terms.size() / 64) - desc[2];   // chunks of the tile
     desc[1] = (int)members.size();
     desc[14] = r1 - r0;   // owners
     t.bt_maxloc = std::max(t.bt_maxloc, (int)members.size());
+    t.bt_maxchunk = std::max(t.bt_maxchunk, desc[3]);
     for (int atom : members) { bt_atoms.push_back(atom); local_of[atom] = -1; }
   }
   t.bt_ntile = ntile;
-  (void)ncf;
   t.original.take(*s);
   std::memcpy(t.init_box, s->box, sizeof t.init_box);
   t.init_x.assign(s->x, s->x + 3 * (size_t)n);
@@ -544,18 +566,8 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   if ((rc = upload(e, t.d_q, t.q))) return rc;
   if ((rc = upload(e, t.d_mass, t.mass_atom))) return rc;
   if ((rc = upload(e, t.d_lj, t.lj))) return rc;
-  if ((rc = upload(e, t.d_bond_at, l_at[BT_BOND]))) return rc;
-  if ((rc = upload(e, t.d_bond_cf, l_cf[BT_BOND]))) return rc;
-  if ((rc = upload(e, t.d_bondsh_at, l_at[BT_BOND_SHAKEN]))) return rc;
-  if ((rc = upload(e, t.d_bondsh_cf, l_cf[BT_BOND_SHAKEN]))) return rc;
-  if ((rc = upload(e, t.d_angle_at, l_at[BT_ANGLE]))) return rc;
-  if ((rc = upload(e, t.d_angle_cf, l_cf[BT_ANGLE]))) return rc;
-  if ((rc = upload(e, t.d_dih_at, l_at[BT_DIHEDRAL]))) return rc;
-  if ((rc = upload(e, t.d_dih_cf, l_cf[BT_DIHEDRAL]))) return rc;
-  if ((rc = upload(e, t.d_imp_at, l_at[BT_IMPROPER]))) return rc;
-  if ((rc = upload(e, t.d_imp_cf, l_cf[BT_IMPROPER]))) return rc;
-  if ((rc = upload(e, t.d_sp_at, l_at[BT_SPECIAL]))) return rc;
-  if ((rc = upload(e, t.d_sp_cf, l_cf[BT_SPECIAL]))) return rc;
+  if ((rc = upload(e, t.d_bt_terms, bt_terms))) return rc;
+  if ((rc = upload(e, t.d_bt_coef, coef))) return rc;
   if ((rc = upload(e, t.d_bt_desc, bt_desc))) return rc;
   if ((rc = upload(e, t.d_bt_atoms, bt_atoms))) return rc;
   if ((rc = upload(e, t.d_bt_rank, rank))) return rc;
@@ -916,7 +928,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
 
 // After k_pair: bonded terms on the main stream, structure factors + per-k coefficients on the side stream (both
 // are small, latency-bound kernels that need only the positions), joined before the per-atom reciprocal force.
-static hipError_t force_stage(scema_md_engine *e, hipStream_t st, bool allow_side, const SimDev *D, int ns, int maxbt, int maxloc, int maxatoms,
+static hipError_t force_stage(scema_md_engine *e, hipStream_t st, bool allow_side, const SimDev *D, int ns, int maxbt, int maxloc, int maxcoef, int maxatoms,
                               int maxk, int mmax, int maxgrp, int parts, int pairvir) {
   const bool side = allow_side && maxk > 0 && e->stream2 != nullptr && ns >= 16;   // small batches: the fork/join costs more than it hides
   if (side) {
@@ -926,7 +938,7 @@ static hipError_t force_stage(scema_md_engine *e, hipStream_t st, bool allow_sid
     mdk_ewald_recip(e->stream2, D, ns, maxk, mmax, maxgrp);
     if ((rc = hipEventRecord(e->ev_join, e->stream2)) != hipSuccess) return rc;
   }
-  mdk_bonded(st, D, ns, maxbt, maxloc, parts);
+  mdk_bonded(st, D, ns, maxbt, maxloc, maxcoef, parts);
   if (side) {
     hipError_t rc = hipStreamWaitEvent(st, e->ev_join, 0);
     if (rc != hipSuccess) return rc;
@@ -962,7 +974,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   }
   const int hbeg[2] = {0, nhalf == 2 ? (ns + 1) / 2 : ns}, hcnt[2] = {nhalf == 2 ? (ns + 1) / 2 : ns, nhalf == 2 ? ns / 2 : 0};
   e->h_sims.assign(ns, SimDev());
-  int maxbt = 1, maxloc = 1;
+  int maxbt = 1, maxloc = 1, maxcoef = 0;
   int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
   // k-vector tables of all simulations (indices, row run lengths, groups), packed into one upload
   std::vector<int> &kpack = e->h_kpack;
@@ -1151,15 +1163,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.shake_tol = P.shake_tol;
     for (int k = 0; k < 6; k++) S.rates[k] = A.rates[k];
     S.type = T.d_type.as<int>(); S.q = T.d_q.as<double>(); S.mass = T.d_mass.as<double>(); S.lj = T.d_lj.as<double>();
-    S.bond_at = T.d_bond_at.as<int>(); S.bond_cf = T.d_bond_cf.as<double>();
-    S.angle_at = T.d_angle_at.as<int>(); S.angle_cf = T.d_angle_cf.as<double>();
-    S.dihedral_at = T.d_dih_at.as<int>(); S.dihedral_cf = T.d_dih_cf.as<double>();
-    S.improper_at = T.d_imp_at.as<int>(); S.improper_cf = T.d_imp_cf.as<double>();
-    S.special_at = T.d_sp_at.as<int>(); S.special_cf = T.d_sp_cf.as<double>();
+    S.bt_terms = T.d_bt_terms.as<unsigned long long>(); S.bt_coef = T.d_bt_coef.as<double>(); S.bt_ncoef = T.bt_ncoef;
+    for (int k = 0; k < 4; k++) S.bt_cf_off[k] = T.bt_cf_off[k];
+    for (int k = 0; k < 6; k++) S.sp_w[k] = T.sp_w[k];
     S.ex_start = T.d_ex_start.as<int>(); S.ex_list = T.d_ex_list.as<int>();
-    S.bondsh_at = T.d_bondsh_at.as<int>(); S.bondsh_cf = T.d_bondsh_cf.as<double>();
     S.bt_desc = T.d_bt_desc.as<int>(); S.bt_atoms = T.d_bt_atoms.as<int>(); S.bt_rank = T.d_bt_rank.as<int>(); S.bt_ntile = T.bt_ntile;
     maxbt = std::max(maxbt, T.bt_ntile); maxloc = std::max(maxloc, T.bt_maxloc);
+    maxcoef = std::max(maxcoef, T.bt_ncoef);
     S.clus_at = T.d_clus_at.as<int>(); S.clus_n = T.d_clus_n.as<int>(); S.clus_d = T.d_clus_d.as<double>();
     S.x = A.st->x.as<double>(); S.v = A.st->v.as<double>(); S.f = sl.f.as<double>();
     S.xq = sl.xq.as<double4>(); S.stype = sl.stype.as<int>(); S.perm = sl.perm.as<int>(); S.slot_tmp = sl.slot_tmp.as<int>();
@@ -1218,7 +1228,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     mdk_phase_init(st, Dh, nh);
     mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
     mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
-    HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
+    HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
     mdk_final_integrate(st, Dh, nh, maxatoms, 0);
     mdk_setup_post(st, Dh, nh);
@@ -1250,7 +1260,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       ev_used += 2;
       launch_sims.push_back({hbeg[h], na});
     }
-    HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
+    HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
     mdk_shake(st, Dh, na, maxclus, 1.0);
     mdk_final_integrate(st, Dh, na, maxatoms, 1);
     mdk_post(st, Dh, na);

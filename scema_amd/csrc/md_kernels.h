@@ -14,7 +14,7 @@ size_t mdk_neigh_lds_bytes(int capj, int maxrow);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly);
 // bonded terms + special pairs, one workgroup per bonded tile; parts != 0: per-part virial/energy (parity hook)
-void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int parts);
+void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int maxcoef, int parts);
 // reciprocal Ewald sum in two parts, so that the first (structure factors; needs only positions) can run on a
 // second stream next to the bonded kernel.  pairvir != 0: k_ewald_force also folds the production pair virial
 // (slot-ordered forces x positions + the per-wave image-shift partials of k_pair) into the virial of the step

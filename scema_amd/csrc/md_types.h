@@ -26,11 +26,18 @@
 #define MD_PI 3.14159265358979323846
 
 // bonded tiles (md_bonded.hip): kinds of terms; descriptor of one tile = BT_DESC ints:
-// [0] offset into bt_atoms, [1] local atoms (owners first), then (first term, number of terms) per kind, [14] owners
+// [0] offset into bt_atoms, [1] local atoms (owners first), [2] first chunk of 64 term descriptors, [3] chunks, [14] owners
 enum { BT_BOND = 0, BT_BOND_SHAKEN = 1, BT_ANGLE = 2, BT_DIHEDRAL = 3, BT_IMPROPER = 4, BT_SPECIAL = 5, BT_NKIND = 6 };
-#define BT_DESC 16           /* [14] = owners of the tile */
-#define BT_NOCOUNT 0x40000000 /* on a term's first atom index: evaluated for this tile's owner forces only, virial/energy counted by another tile */
-#define BT_LMASK 0x3FFFFFFF
+#define BT_DESC 16           /* [2] first chunk of term descriptors, [3] chunks, [14] owners of the tile */
+/* 64-bit term descriptor: local atom indices (10 bits each) | type | special-bond level | no-count flag | kind | valid */
+#define BT_D_LMASK 0x3FF
+#define BT_D_TYPE_SHIFT 40
+#define BT_D_TMASK 0xFFF
+#define BT_D_LVL_SHIFT 52
+#define BT_D_NOCOUNT (1ull << 54) /* evaluated for this tile's owner forces only; virial/energy counted by the tile that owns the lowest-ranked atom */
+#define BT_D_KIND_SHIFT 55
+#define BT_D_VALID (1ull << 58)
+#define BT_MAXCOEF 768       /* doubles of the bonded coefficient tables staged in LDS */
 #define BT_OWNERS 192        /* owner atoms (consecutive breadth-first ranks of the bond graph) per tile */
 
 enum { P_LJ = 0, P_COUL = 1, P_BOND = 2, P_ANGLE = 3, P_DIHEDRAL = 4, P_IMPROPER = 5, P_KSPACE = 6, P_SHAKE = 7 };
@@ -99,14 +106,12 @@ struct SimDev {
   const int *type;
   const double *q, *mass;       // per atom
   const double *lj;             // 4 * ntypes^2 : lj1,lj2,lj3,lj4
-  // bonded terms, grouped by tile, atoms as indices into the tile's local atom list
-  const int *bond_at; const double *bond_cf;        // 2 ints, (K,r0): bonds that stay harmonic
-  const int *bondsh_at; const double *bondsh_cf;    // the bonds fix shake constrains (harmonic only when SHAKE is off)
+  // bonded terms: one 64-bit descriptor per term in tile order (BT_D_*), coefficient tables by type
+  const unsigned long long *bt_terms;
+  const double *bt_coef;          // bonds (K,r0) | angles (K,theta0) | dihedrals (K1..K4) | impropers (K,chi0)
+  int bt_ncoef, bt_cf_off[4];
   int nbonds_noshake;
-  const int *angle_at; const double *angle_cf;      // 3 ints, (K,theta0)
-  const int *dihedral_at; const double *dihedral_cf;// 4 ints, (K1..K4)
-  const int *improper_at; const double *improper_cf;// 4 ints, (K,chi0)
-  const int *special_at; const double *special_cf;  // 2 ints, (w_lj*lj1, w_lj*lj2, qqrd2e*qi*qj, w_coul, w_lj*lj3, w_lj*lj4)
+  double sp_w[6];                 // special_bonds weights: lj 1-2,1-3,1-4, coul 1-2,1-3,1-4
   const int *ex_start, *ex_list;
   const int *bt_desc, *bt_atoms;   // tile descriptors, local atom lists
   const int *bt_rank;              // atom -> breadth-first rank in the bond graph (index into fb)
