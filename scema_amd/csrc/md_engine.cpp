@@ -636,9 +636,13 @@ void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, Ewa
   ewald_tables(out);
 }
 
-// row run lengths, (n1, +-n2, +-n3) groups and index ranges of a k-vector list; the list is put in lexicographic order
-// first (k_ewald_force walks it with a phase cursor).  Also used after a box flip, when the list of the run is
-// re-expressed in the new reciprocal basis.
+// row run lengths, (n1, +-n2, +-n3) groups and index ranges of a k-vector list.  The list is put in SNAKE order first:
+// slabs of equal n1 ascending; the rows (n1, n2) of a slab ascending or descending in n2, alternating from slab to slab;
+// the entries of a row ascending or descending in n3, alternating from row to row.  k_ewald_force walks the list with a
+// phase cursor (one complex multiplication per k-vector inside a row): in snake order the cursor only ever moves a step
+// or two between rows instead of rewinding n3 across the whole sphere (that rewind was half of the kernel's
+// instructions).  krun[k] = +-(number of following k-vectors that continue the row), the sign is the row's direction.
+// Also used after a box flip, when the list of the run is re-expressed in the new reciprocal basis.
 void ewald_tables(EwaldSetup &out) {
   const int nk = (int)out.kn.size() / 3;
   {
@@ -649,8 +653,31 @@ void ewald_tables(EwaldSetup &out) {
         if (out.kn[3 * a + d] != out.kn[3 * b + d]) return out.kn[3 * a + d] < out.kn[3 * b + d];
       return false;
     });
+    // lexicographic -> snake
+    std::vector<int> snake;
+    snake.reserve(nk);
+    int slab = 0, rowno = 0;
+    for (int s0 = 0; s0 < nk;) {
+      int s1 = s0;
+      while (s1 < nk && out.kn[3 * idx[s1]] == out.kn[3 * idx[s0]]) s1++;
+      std::vector<std::pair<int, int>> rows;   // [begin, end) of the rows of this slab, in lexicographic order
+      for (int r0 = s0; r0 < s1;) {
+        int r1 = r0;
+        while (r1 < s1 && out.kn[3 * idx[r1] + 1] == out.kn[3 * idx[r0] + 1]) r1++;
+        rows.push_back({r0, r1});
+        r0 = r1;
+      }
+      if (slab & 1) std::reverse(rows.begin(), rows.end());
+      for (const auto &rw : rows) {
+        if (rowno & 1) for (int k = rw.second - 1; k >= rw.first; k--) snake.push_back(idx[k]);
+        else for (int k = rw.first; k < rw.second; k++) snake.push_back(idx[k]);
+        rowno++;
+      }
+      slab++;
+      s0 = s1;
+    }
     for (int k = 0; k < nk; k++)
-      for (int d = 0; d < 3; d++) kn2[3 * k + d] = out.kn[3 * idx[k] + d];
+      for (int d = 0; d < 3; d++) kn2[3 * k + d] = out.kn[3 * snake[k] + d];
     out.kn.swap(kn2);
   }
   out.krun.assign(nk, 0);
@@ -658,9 +685,14 @@ void ewald_tables(EwaldSetup &out) {
   for (int d = 0; d < 3; d++) out.kmaxd[d] = 0;
   for (int k = 0; k < nk; k++)
     for (int d = 0; d < 3; d++) out.kmaxd[d] = std::max(out.kmaxd[d], std::abs(out.kn[3 * k + d]));
-  for (int k = nk - 2; k >= 0; k--)
-    if (out.kn[3 * k] == out.kn[3 * k + 3] && out.kn[3 * k + 1] == out.kn[3 * k + 4] && out.kn[3 * k + 2] + 1 == out.kn[3 * k + 5])
-      out.krun[k] = out.krun[k + 1] + 1;
+  for (int k = nk - 2; k >= 0; k--) {
+    if (out.kn[3 * k] != out.kn[3 * k + 3] || out.kn[3 * k + 1] != out.kn[3 * k + 4]) continue;
+    const int step = out.kn[3 * k + 5] - out.kn[3 * k + 2];
+    if (step != 1 && step != -1) continue;
+    // continue the run only in the same direction
+    const int nxt = out.krun[k + 1];
+    out.krun[k] = (nxt != 0 && (nxt > 0) == (step > 0)) ? nxt + step : step;
+  }
   // k-vectors that differ only in the signs of n2, n3 share every phase-factor product of k_ewald_sfac
   std::map<long, int> gidx;
   for (int k = 0; k < nk; k++) {

@@ -470,7 +470,6 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_M
   const SimDev &S = sims[blockIdx.y];
   if (S.nk == 0) return;
   double2 *s_tab = s_dyn;  // [EW_ATOMS][3][EW_MAXM]
-  __shared__ double s_q[EW_ATOMS];
   const int M0 = S.kmaxd[0] + 1, M1 = S.kmaxd[1] + 1, M2 = S.kmaxd[2] + 1;
   const int MS = 3 * EW_MAXM;
   const int nchunk = (S.natoms + EW_ATOMS - 1) / EW_ATOMS;
@@ -483,7 +482,10 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_M
     n1 = Ga.x; m2 = Ga.y; m3 = Ga.z;
     kpp = Ga.w; kmp = Gb.x; kpm = Gb.y; kmm = Gb.z;
   }
-  double rpp = 0, ipp = 0, rmp = 0, imp = 0, rpm = 0, ipm = 0, rmm = 0, imm = 0;   // (sign of n2, sign of n3)
+  // exp(i(t1 +- t2 +- t3)) of the up to four members of a group are linear combinations of the eight real products
+  // {cos,sin}(t1) {cos,sin}(t2) {cos,sin}(t3): those are what is summed over the atoms (4 products + 8 FMAs per atom and
+  // group, the charge folded into the first table), and combined once at the end
+  double T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0, T5 = 0, T6 = 0, T7 = 0;   // ccc ccs csc css scc scs ssc sss
   BoxD b;
   box_derive(S.sc->box, b);
   for (int ch = blockIdx.x; ch < nchunk; ch += EW_PARTS) {
@@ -498,14 +500,14 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_M
         double s1, c1;
         sincospi(2.0 * t[d], &s1, &c1);
         const int M = (d == 0) ? M0 : (d == 1) ? M1 : M2;
+        const double qa = (d == 0) ? S.q[a0 + la] : 1.0;
         double cr = 1.0, ci = 0.0;
         double2 *tab = s_tab + la * MS + d * EW_MAXM;
         for (int m = 0; m < M; m++) {
-          tab[m] = make_double2(cr, ci);
+          tab[m] = make_double2(qa * cr, qa * ci);
           const double nr = cr * c1 - ci * s1, ni = ci * c1 + cr * s1;
           cr = nr; ci = ni;
         }
-        if (d == 0) s_q[la] = S.q[a0 + la];
       }
     }
     __syncthreads();
@@ -514,22 +516,18 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_M
         const double2 e1 = s_tab[la * MS + n1];
         const double2 e2 = s_tab[la * MS + EW_MAXM + m2];
         const double2 e3 = s_tab[la * MS + 2 * EW_MAXM + m3];
-        const double q = s_q[la];
-        const double a = e1.x * e2.x, bb = e1.y * e2.y, c = e1.y * e2.x, d = e1.x * e2.y;
-        const double c12p = q * (a - bb), s12p = q * (c + d);   // e1 e2
-        const double c12m = q * (a + bb), s12m = q * (c - d);   // e1 conj(e2)
-        rpp += c12p * e3.x - s12p * e3.y; ipp += s12p * e3.x + c12p * e3.y;
-        rpm += c12p * e3.x + s12p * e3.y; ipm += s12p * e3.x - c12p * e3.y;
-        rmp += c12m * e3.x - s12m * e3.y; imp += s12m * e3.x + c12m * e3.y;
-        rmm += c12m * e3.x + s12m * e3.y; imm += s12m * e3.x - c12m * e3.y;
+        const double cc = e1.x * e2.x, cs = e1.x * e2.y, sc_ = e1.y * e2.x, ss = e1.y * e2.y;
+        T0 = fma(cc, e3.x, T0); T1 = fma(cc, e3.y, T1); T2 = fma(cs, e3.x, T2); T3 = fma(cs, e3.y, T3);
+        T4 = fma(sc_, e3.x, T4); T5 = fma(sc_, e3.y, T5); T6 = fma(ss, e3.x, T6); T7 = fma(ss, e3.y, T7);
       }
   }
+  // Re = ccc - s2 s3 css - s2 ssc - s3 scs ; Im = scc + s2 csc + s3 ccs - s2 s3 sss  (s2, s3 = signs of n2, n3)
   // all indices are in registers: the atomics go out back to back
   double *sf = S.sfac;
-  if (kpp >= 0) { atomicAdd(&sf[2 * kpp], rpp); atomicAdd(&sf[2 * kpp + 1], ipp); }
-  if (kmp >= 0) { atomicAdd(&sf[2 * kmp], rmp); atomicAdd(&sf[2 * kmp + 1], imp); }
-  if (kpm >= 0) { atomicAdd(&sf[2 * kpm], rpm); atomicAdd(&sf[2 * kpm + 1], ipm); }
-  if (kmm >= 0) { atomicAdd(&sf[2 * kmm], rmm); atomicAdd(&sf[2 * kmm + 1], imm); }
+  if (kpp >= 0) { atomicAdd(&sf[2 * kpp], T0 - T3 - T6 - T5); atomicAdd(&sf[2 * kpp + 1], T4 + T2 + T1 - T7); }
+  if (kmp >= 0) { atomicAdd(&sf[2 * kmp], T0 + T3 + T6 - T5); atomicAdd(&sf[2 * kmp + 1], T4 - T2 + T1 + T7); }
+  if (kpm >= 0) { atomicAdd(&sf[2 * kpm], T0 + T3 - T6 + T5); atomicAdd(&sf[2 * kpm + 1], T4 + T2 - T1 + T7); }
+  if (kmm >= 0) { atomicAdd(&sf[2 * kmm], T0 - T3 + T6 + T5); atomicAdd(&sf[2 * kmm + 1], T4 - T2 - T1 - T7); }
   // more groups than threads (very large k sets): the rest one group at a time, tables rebuilt per chunk
   for (int g2 = gthreads + (int)threadIdx.x; g2 < S.ngrp; g2 += blockDim.x) {
     const int *G = S.kgrp + 8 * g2;
@@ -668,18 +666,23 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
         fx[u] = fma(pf, e.kx, fx[u]); fy[u] = fma(pf, e.ky, fy[u]); fz[u] = fma(pf, e.kz, fz[u]);
       }
       m1 = n1; m2 = n2; m3 = n3;
-      // rest of the row: n3 -> n3 + 1 = one complex multiplication each, no scalar control
-      const int run = min(__builtin_amdgcn_readfirstlane(s_run[kk]), kc - 1 - kk);   // rows are cut at chunk ends
+      // rest of the row: n3 -> n3 +- 1 = one complex multiplication each, no scalar control; the row's direction is the
+      // sign of its run length (snake order of the k list, md_engine.cpp ewald_tables)
+      const int srun = __builtin_amdgcn_readfirstlane(s_run[kk]);
+      const int run = min(srun < 0 ? -srun : srun, kc - 1 - kk);   // rows are cut at chunk ends
+      double s3d[EWF_APT];
+#pragma unroll
+      for (int u = 0; u < EWF_APT; u++) s3d[u] = (srun < 0) ? -s3[u] : s3[u];
       for (int r = 1; r <= run; r++) {
         const EwK g = s_k[kk + r];
 #pragma unroll
         for (int u = 0; u < EWF_APT; u++) {
-          cmul(pr[u], pi[u], c3[u], s3[u]);
+          cmul(pr[u], pi[u], c3[u], s3d[u]);
           const double pf = pi[u] * g.pr - pr[u] * g.pi;
           fx[u] = fma(pf, g.kx, fx[u]); fy[u] = fma(pf, g.ky, fy[u]); fz[u] = fma(pf, g.kz, fz[u]);
         }
       }
-      m3 += run;
+      m3 += (srun < 0) ? -run : run;
       kk += run + 1;
     }
   }

@@ -139,7 +139,7 @@ struct SimDev {
   int *numneigh, *neigh;  // per cluster: {entries in segments A+B+C1 (front), entries in segment C2 (back)}; rows of maxneigh entries
   // ewald
   const int *kn;    // 3 ints per k
-  const int *krun;  // per k: number of following k-vectors that continue its row (same n1, n2; n3 + 1 each)
+  const int *krun;  // per k: +-(number of following k-vectors that continue its row: same n1, n2; n3 + 1 or n3 - 1 each), sign = direction
   const int *kgrp;  // 8 ints per group of k-vectors (n1, +-n2, +-n3): n1, |n2|, |n3|, k index of (+,+), (-,+), (+,-), (-,-) or -1
   int ngrp;
   double *sfac;     // 2 per k

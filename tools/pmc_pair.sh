@@ -32,5 +32,19 @@ for d in sorted(glob.glob('gpurun_out/pmc_${TAG}_*/*/*_counter_collection.csv'))
         for c, val in v.items():
             out[k][c] = val / len(disp[k]); out[k]['dispatches_' + c] = len(disp[k])
             print(f"{k:40s} {c:32s} {val/len(disp[k]):16.0f}  ({len(disp[k])} dispatches)")
+kp = next((k for k in out if k.startswith('void k_pair<true, false')), None)
+if kp and 'FETCH_SIZE' in out[kp] and 'WRITE_SIZE' in out[kp] and 'SQ_INSTS_VALU' in out[kp]:
+    o = out[kp]
+    hbm = (2.0 * o['FETCH_SIZE'] + o['WRITE_SIZE']) * 1024.0
+    json.dump({"kernel": kp, "sims_per_launch": $SIMS, "dispatches": o['dispatches_SQ_INSTS_VALU'],
+               "FETCH_SIZE_KB_per_launch": o['FETCH_SIZE'], "WRITE_SIZE_KB_per_launch": o['WRITE_SIZE'],
+               "hbm_bytes_per_launch_corrected": hbm, "hbm_bytes_per_sim_step_corrected": hbm / $SIMS,
+               "valu_insts_per_launch": o['SQ_INSTS_VALU'], "valu_insts_per_sim_step": o['SQ_INSTS_VALU'] / $SIMS,
+               "cycles_per_valu_inst": 4.0,
+               "SQ_WAVE_CYCLES": o.get('SQ_WAVE_CYCLES'), "SQ_ACTIVE_INST_VALU": o.get('SQ_ACTIVE_INST_VALU'), "SQ_WAIT_ANY": o.get('SQ_WAIT_ANY'),
+               "GRBM_GUI_ACTIVE": o.get('GRBM_GUI_ACTIVE'),
+               "correction": "gfx950: FETCH_SIZE x2 for coalesced streams (MI355X_MICROARCH.md, HBM); WRITE_SIZE as read",
+               "source": "profiles/pair_pmc.json: tools/pmc_pair.sh, rocprofv3 --pmc passes (one counter group each, no tracing) on bench.py --sims $SIMS --steps 1 --warmup 0 --nss 10, equilibrated replica; batch launches only"},
+              open('gpurun_out/pair_pmc_${TAG}.json', 'w'), indent=1)
 json.dump({"sims_per_launch": $SIMS, "command": "rocprofv3 --pmc <group> --kernel-include-regex $RE -- python bench.py --sims $SIMS --steps 1 --warmup 0 --nss 10 --no-cpu-baseline --equil-cache <state after 2000 NVT+SHAKE steps>", "kernels": out}, open('gpurun_out/pmc_${TAG}.json', 'w'), indent=1)
 PY
