@@ -76,6 +76,16 @@ int scema_stmd_update(scema_stmd *s, int32_t timestep, double present_time, int3
 int scema_stmd_replica_data(const scema_stmd *s, int32_t material, int32_t replica0, double *init_length, double *init_stress,
                             double *rotam, double *rho);
 
+/* STMDSync::set_md_procs (stmd_sync.h:189-278), the arithmetic alone: how the reference cuts `n_processes` MD ranks into
+ * batches for `nmdruns` simulations -- ranks per batch = the largest admissible count (a factor or a multiple of
+ * `cores_per_node`, between `min_cores` and n_processes) not above the fair share n_processes / nmdruns; number of
+ * batches; colour of `this_process` (-1 = MPI_UNDEFINED: left over).  At this boundary a rank is a GPU and a simulation
+ * never spans GPUs, so with fewer simulations than GPUs the surplus ranks of a batch idle; with nmdruns >= n_processes
+ * the result is one rank per batch, n_processes batches (the case the engine's planner serves).  Returns
+ * SCEMA_MD_ERR_ARG where the reference prints "md_batch_n_processes is not well set" and exits. */
+int scema_stmd_set_md_procs(int32_t nmdruns, int32_t n_processes, int32_t this_process, int32_t min_cores, int32_t cores_per_node,
+                            int32_t *md_batch_n_processes, int32_t *n_md_batches, int32_t *md_batch_pcolor);
+
 /* EQMDProblem<3>::equil (init_material_problem.h:309-355) for a replica that is already equilibrated and registered
  * with the engine: computes box lengths, initial stress and stiffness on the GPU and writes
  * lengthof / stressof / stiffof = init.<mat>_<rep>.{length,stress,stiff}, the files scema_stmd_init reads.

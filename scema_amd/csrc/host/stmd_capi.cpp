@@ -1,6 +1,7 @@
 // stmd_capi.cpp -- extern "C" face of the host layer (include/scema_stmd.h)
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "eqmd_problem.h"
 #include "stmd_sync.h"
@@ -20,6 +21,43 @@ int scema_stmd_create(scema_md_engine *engine, int32_t rank, int32_t world, scem
 }
 void scema_stmd_destroy(scema_stmd *s) { delete s; }
 const char *scema_stmd_last_error(const scema_stmd *s) { return s ? s->sync.last_error().c_str() : "null handle"; }
+
+// reference stmd_sync.h:189-278
+int scema_stmd_set_md_procs(int32_t nmdruns, int32_t n_processes, int32_t this_process, int32_t min_cores, int32_t cores_per_node,
+                            int32_t *md_batch_n_processes, int32_t *n_md_batches, int32_t *md_batch_pcolor) {
+  if (n_processes <= 0 || cores_per_node <= 0 || min_cores <= 0 || this_process < 0) return SCEMA_MD_ERR_ARG;
+  const unsigned npbtch_min = (unsigned)min_cores, npnode = (unsigned)cores_per_node, P = (unsigned)n_processes;
+  unsigned fair_npbtch;
+  if (nmdruns > 0) {
+    fair_npbtch = (unsigned)(n_processes / nmdruns);
+    if (fair_npbtch == 0) fair_npbtch = 1;
+  } else {
+    fair_npbtch = P;
+  }
+  // admissible core counts: factors or multiples of the core count per node, from the minimum allocation to all
+  std::vector<unsigned> list_possible_cores_per_job;
+  for (unsigned ic = npbtch_min; ic <= P; ic++) {
+    if (ic <= npnode) {
+      if (npnode % ic == 0) list_possible_cores_per_job.push_back(ic);
+    } else if (ic % npnode == 0) {
+      list_possible_cores_per_job.push_back(ic);
+    }
+  }
+  unsigned nb = 0;   // the reference's member is left as it was when nothing is admissible; here that is an error below
+  for (unsigned ic = 0; ic < list_possible_cores_per_job.size(); ic++) {
+    if (list_possible_cores_per_job[ic] > fair_npbtch) break;
+    nb = list_possible_cores_per_job[ic];
+  }
+  if (nb < npbtch_min || nb > P || (npnode % nb != 0 && nb % npnode != 0)) return SCEMA_MD_ERR_ARG;
+  int nbatches = (int)(P / nb);
+  if (nbatches == 0) { nbatches = 1; nb = P; }
+  int colour = -1;   // MPI_UNDEFINED
+  if ((unsigned)this_process < nb * (unsigned)nbatches) colour = (int)((unsigned)this_process / nb);
+  if (md_batch_n_processes) *md_batch_n_processes = (int32_t)nb;
+  if (n_md_batches) *n_md_batches = nbatches;
+  if (md_batch_pcolor) *md_batch_pcolor = colour;
+  return SCEMA_MD_OK;
+}
 
 int scema_stmd_set_lammps_state_files(scema_stmd *s, int32_t on) {
   if (!s) return SCEMA_MD_ERR_ARG;

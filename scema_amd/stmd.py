@@ -9,7 +9,7 @@ import numpy as np
 
 from . import capi
 
-SYMBOLS = ["scema_stmd_create", "scema_stmd_destroy", "scema_stmd_last_error", "scema_stmd_init", "scema_stmd_set_lammps_state_files",
+SYMBOLS = ["scema_stmd_create", "scema_stmd_destroy", "scema_stmd_last_error", "scema_stmd_init", "scema_stmd_set_lammps_state_files", "scema_stmd_set_md_procs",
            "scema_stmd_update", "scema_stmd_replica_data", "scema_eqmd_equil"]
 
 
@@ -138,6 +138,16 @@ class STMDSync:
         self._chk(capi.lib().scema_stmd_replica_data(self.h, C.c_int32(material), C.c_int32(replica0), capi._p(L0), capi._p(s0),
                                                      capi._p(R), C.byref(rho)))
         return dict(init_length=L0, init_stress=s0, rotam=R.reshape(3, 3), rho=rho.value)
+
+
+def set_md_procs(nmdruns: int, n_processes: int, this_process: int, min_cores: int, cores_per_node: int):
+    """STMDSync::set_md_procs (stmd_sync.h:189-278): (ranks per batch, number of batches, colour of this rank; -1 = left over)"""
+    nb = C.c_int32(); nbt = C.c_int32(); col = C.c_int32()
+    rc = capi.lib().scema_stmd_set_md_procs(C.c_int32(nmdruns), C.c_int32(n_processes), C.c_int32(this_process), C.c_int32(min_cores),
+                                            C.c_int32(cores_per_node), C.byref(nb), C.byref(nbt), C.byref(col))
+    if rc != 0:
+        raise capi.EngineError("md_batch_n_processes is not well set")
+    return nb.value, nbt.value, col.value
 
 
 def eqmd_equil(engine: "capi.Engine", cmat: str, folder: str, rep: int, *, mdts=2.0, mdtem=300.0, mdnss=100, mdss=1e-4, mdsa=0.005,

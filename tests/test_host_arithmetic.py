@@ -108,3 +108,25 @@ def test_file_order_vs_raw_order(tmp_path):
     raw = po.read_sym2(str(p))
     f = g["stress_file_order"]
     assert np.allclose(raw, [f[0], f[3], f[5], f[1], f[2], f[4]], rtol=0, atol=0)
+
+
+def test_set_md_procs_golden_vectors():
+    """STMDSync::set_md_procs (stmd_sync.h:189-278): hand-derived cases.  Admissible ranks per batch are the factors and
+    the multiples of the cores per node; the largest one not above the fair share P / nmdruns is taken."""
+    import pytest
+    from scema_amd import capi, stmd
+    # 576 simulations on 8 ranks (GPUs): fair share 0 -> 1, one rank per batch, 8 batches, colour = rank
+    assert [stmd.set_md_procs(576, 8, r, 1, 8) for r in (0, 3, 7)] == [(1, 8, 0), (1, 8, 3), (1, 8, 7)]
+    # 2 simulations on 8 ranks, 8 cores per node: fair share 4 -> batches of 4 ranks, colours 0 0 0 0 1 1 1 1
+    assert [stmd.set_md_procs(2, 8, r, 1, 8)[2] for r in range(8)] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert stmd.set_md_procs(2, 8, 0, 1, 8)[:2] == (4, 2)
+    # 3 simulations on 48 ranks, 24 per node: fair share 16; admissible <= 16: 1,2,3,4,6,8,12 -> 12; 4 batches
+    assert stmd.set_md_procs(3, 48, 47, 1, 24) == (12, 4, 3)
+    # 1 simulation on 60 ranks, 24 per node: fair share 60; admissible: factors of 24 and 24, 48 -> 48; 1 batch, 12 ranks left over
+    assert stmd.set_md_procs(1, 60, 10, 1, 24) == (48, 1, 0)
+    assert stmd.set_md_procs(1, 60, 55, 1, 24) == (48, 1, -1)
+    # no update this step (nmdruns = 0): everything in one batch
+    assert stmd.set_md_procs(0, 8, 5, 1, 8) == (8, 1, 0)
+    # minimum allocation above the fair share: nothing admissible -> the reference exits
+    with pytest.raises(capi.EngineError):
+        stmd.set_md_procs(100, 8, 0, 4, 8)
