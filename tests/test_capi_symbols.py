@@ -28,8 +28,12 @@ def test_library_exports_every_declared_symbol():
     hdr3 = open(os.path.join(ROOT, "include", "scema_cluster.h")).read()
     declared3 = set(re.findall(r"\b(scema_hist_[a-z_]+)\s*\(", hdr3))
     assert declared3 == set(cluster.SYMBOLS), declared3 ^ set(cluster.SYMBOLS)
+    from scema_amd import fe
+    hdr4 = open(os.path.join(ROOT, "include", "scema_fe.h")).read()
+    declared4 = set(re.findall(r"\b(scema_fe_[a-z_]+)\s*\(", hdr4))
+    assert declared4 == set(fe.SYMBOLS), declared4 ^ set(fe.SYMBOLS)
     L = capi.lib()
-    for s in declared | declared2 | declared3:
+    for s in declared | declared2 | declared3 | declared4:
         assert hasattr(L, s), s
 
 
