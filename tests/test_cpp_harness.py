@@ -47,3 +47,27 @@ def test_cpp_cluster_caller_links_and_runs(tmp_path):
     m = {int(l.split()[1]): int(l.split()[3]) for l in out.stdout.strip().split("\n")}
     # quadrature points 0 and 2 share a history: the one that entered the graph last (2) runs the MD for both
     assert m == {0: 2, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5}
+
+
+def test_cpp_time_loop_over_the_cuboid_mesh(tmp_path):
+    """examples/scema_hmm_harness.cpp: the reference's do_timestep loop (dealammps.cc:417-474) in C++ on the C ABI -- continuum
+    stand-in + STMDSync in the Hooke test mode, 3x3x8 cells = 576 quadrature points, 10 continuum steps (BASELINE config 3)."""
+    import __graft_entry__ as g
+    g.build()
+    from scema_amd import stmd
+    exe = str(tmp_path / "hmm")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "scema_hmm_harness.cpp"),
+                           "-L" + os.path.join(ROOT, "scema_amd"), "-lscema_md", "-Wl,-rpath," + os.path.join(ROOT, "scema_amd"), "-o", exe])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "init_sic_1_stiff.json")))
+    C = np.array(gold["stiff_file_order"])
+    nin = str(tmp_path / "nin"); nout = str(tmp_path / "nout"); mout = str(tmp_path / "mout")
+    os.makedirs(nout); os.makedirs(mout)
+    stmd.write_nanoscale_input(nin, "g0", 1, init_length=[40.0, 41.0, 42.0], init_stress_raw=np.zeros(6), stiff_file_order=C, nsheets=0)
+    out = subprocess.run([exe, nin, nout, mout, "g0", "1", "3", "3", "8", "10"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [l.split() for l in out.stdout.strip().split("\n") if l.startswith("step")]
+    assert [int(r[1]) for r in rows] == list(range(1, 11))
+    nupd = [int(r[3]) for r in rows]
+    assert nupd[0] >= 72 and nupd[-1] <= 576 and all(b >= a for a, b in zip(nupd, nupd[1:]))   # the loaded layer first, then the wave spreads
+    smax = [float(r[5]) for r in rows]
+    assert smax[0] > 0 and all(np.isfinite(smax))
