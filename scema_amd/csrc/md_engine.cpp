@@ -180,7 +180,8 @@ struct Profile {
 struct scema_md_engine {
   scema_md_params p;
   hipStream_t stream = nullptr;
-  double skin_extra_fixed = -1.0;         // SCEMA_MD_SKIN_EXTRA: fixed extra list skin (0 = never adapt); < 0 = adaptive
+  double skin_extra_fixed = 0.0;          // SCEMA_MD_SKIN_EXTRA: list skin = params.skin + this (performance only; may be negative)
+  bool skin_adapt = false;                // SCEMA_MD_SKIN_ADAPT=1: per-state adaptation from the rebuild interval (round-1 behaviour)
   hipStream_t stream2 = nullptr;          // side stream: structure factors next to the bonded kernel
   hipStream_t stream3 = nullptr;          // second half batch of a large launch group (run_phase)
   hipEvent_t ev_up = nullptr;
@@ -1050,7 +1051,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     std::memset(&S, 0, sizeof S);
     // list skin of this simulation = the reference's neighbour skin + the state's performance extra (dropped where the
     // box is too small for it)
-    if (e->skin_extra_fixed >= 0.0) A.st->skin_extra = e->skin_extra_fixed;
+    if (!e->skin_adapt) A.st->skin_extra = e->skin_extra_fixed;
     for (int d = 0; d < 3; d++)
       if (std::min(w0[d], w1[d]) < 2.0 * (cutmax_all + P.skin + A.st->skin_extra)) A.st->skin_extra = 0.0;
     const double skin_i = P.skin + A.st->skin_extra;
@@ -1644,7 +1645,7 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
         for (int k = 0; k < 6; k++) chunk[i].pavg[k] = sc.psum[k] / (double)std::max(sc.nsamples, 1);
         e->prof.skin_sum += e->p.skin + chunk[i].st->skin_extra;
         // steps per list rebuild of the sampling run -> list skin of this state's next evaluation (with hysteresis)
-        if (e->skin_extra_fixed < 0.0 && chunk[i].nss >= 50) {
+        if (e->skin_adapt && chunk[i].nss >= 50) {
           const double interval = (double)chunk[i].nss / (double)std::max(sc.nbuilds, 1);
           State &st = *chunk[i].st;
           if (st.skin_extra == 0.0 && interval < 19.0) st.skin_extra = 0.25 * e->p.skin;
@@ -1834,7 +1835,8 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
   if (const char *sp = getenv("SCEMA_MD_SPLIT_MIN")) e->split_min = std::max(2, atoi(sp));
   if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess)
     e->stream3 = nullptr;   // an optimisation only
-  if (const char *sx = getenv("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(0.0, atof(sx));
+  if (const char *sx = getenv("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(-0.75 * e->p.skin, atof(sx));
+  if (const char *sx = getenv("SCEMA_MD_SKIN_ADAPT")) e->skin_adapt = atoi(sx) != 0;
   if (!getenv("SCEMA_MD_ONE_STREAM")) {
     if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||

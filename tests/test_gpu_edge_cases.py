@@ -265,16 +265,15 @@ def test_unstable_replica_is_reported_not_returned(small_pe):
 
 
 def test_list_skin_is_a_performance_knob_only(small_pe, monkeypatch):
-    """The engine widens the neighbour skin of states that rebuild their lists often (adaptive, performance only).  With
-    the extra skin forced on, forces, a 20-step trajectory and a full evaluation still equal the oracle's, which keeps
-    the reference's skin."""
+    """SCEMA_MD_SKIN_EXTRA adds to (or takes from) the neighbour skin, for performance only.  With a wider and a thinner skin
+    than the reference's, forces and a full evaluation still equal the oracle's, which keeps the reference's skin."""
     from scema_amd import capi
     from oracle import pyoracle as po
     lens = _lens(small_pe)
     st = np.array([-3e-4, -3e-4, 1.0e-3, 5e-5, 0, -4e-5]) * np.array([*lens, lens[2], lens[1], lens[0]])
     exp, _ = po.Oracle(small_pe, po.default_params(**KW)).eval(st, 2.0, 300.0, 1e-4, 20)
     res = {}
-    for extra in ("0", "0.4"):
+    for extra in ("0", "0.4", "-0.3"):
         monkeypatch.setenv("SCEMA_MD_SKIN_EXTRA", extra)
         eng = capi.Engine(capi.default_params(**KW))
         eng.register_replica("pe", 1, small_pe)
@@ -284,15 +283,17 @@ def test_list_skin_is_a_performance_knob_only(small_pe, monkeypatch):
         res["f" + extra] = f
         eng.close()
     monkeypatch.delenv("SCEMA_MD_SKIN_EXTRA")
-    assert relerr(res["0"], exp) < 1e-6 and relerr(res["0.4"], exp) < 1e-6
-    assert relerr(res["f0.4"], res["f0"]) < 1e-12
+    assert relerr(res["0"], exp) < 1e-6 and relerr(res["0.4"], exp) < 1e-6 and relerr(res["-0.3"], exp) < 1e-6
+    assert relerr(res["f0.4"], res["f0"]) < 1e-12 and relerr(res["f-0.3"], res["f0"]) < 1e-12
 
 
-def test_list_skin_adapts_to_the_rebuild_frequency(small_pe):
-    """A state whose sampling run rebuilt its list more often than every 19 steps is evaluated with 25 % more skin next
-    time (and the profile says so); the stresses keep matching the oracle, which never changes its skin."""
+def test_list_skin_adapts_to_the_rebuild_frequency(small_pe, monkeypatch):
+    """Opt-in (SCEMA_MD_SKIN_ADAPT=1): a state whose sampling run rebuilt its list more often than every 19 steps is evaluated
+    with 25 % more skin next time (and the profile says so); the stresses keep matching the oracle, which never changes its
+    skin."""
     from scema_amd import capi
     from oracle import pyoracle as po
+    monkeypatch.setenv("SCEMA_MD_SKIN_ADAPT", "1")
     kw = dict(KW, skin=0.6)                       # a thin skin: this small hot system rebuilds every few steps
     eng = capi.Engine(capi.default_params(profile=1, **kw))
     eng.register_replica("pe", 1, small_pe)
