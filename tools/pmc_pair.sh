@@ -9,6 +9,7 @@ mkdir -p gpurun_out
 CACHE=gpurun_out/equil_pe10k.npz
 # the equilibration (2 000 single-replica steps) runs once, outside the profiler
 [ -f $CACHE ] || python bench.py --sims 1 --steps 1 --warmup 0 --nss 10 --no-cpu-baseline --equil-cache $CACHE > /dev/null 2>&1
+export SCEMA_MD_SPLIT=0   # whole batch per launch: the counters are divided by the batch size
 for P in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY" \
          "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" \
          "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES_LT_64" \
