@@ -109,3 +109,26 @@ def test_without_a_communicator_a_remote_source_state_is_an_error(small_pe):
     out3 = eng.strain_batch([capi.make_sim(0, "pe", 1, st), capi.make_sim(1, "pe", 1, st)], rank=0, world=2)
     assert [o.stress_updated for o in out3] == [1, 0]
     eng.close()
+
+
+def test_rccl_calls_run_on_one_rank(small_pe):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy inside the library, on the one GPU of the test
+    box (world = 1): the stresses come back through the collective and equal the run without a communicator."""
+    from scema_amd import capi
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+    res = []
+    for with_comm in (False, True):
+        eng = capi.Engine(capi.default_params(**KW))
+        if with_comm:
+            uid = eng.comm_unique_id()
+            assert len(uid) == capi.COMM_ID_BYTES
+            eng.comm_init_rccl(uid, 0, 1)
+        eng.register_replica("pe", 1, small_pe)
+        out = eng.strain_batch([capi.make_sim(q, "pe", 1, st * (1 + 0.1 * q), nss=10, most_recent=capi.QP_NONE) for q in range(3)])
+        res.append(np.array([list(o.stress) for o in out]))
+        if with_comm:
+            assert eng.comm_stats()["allgathers"] == 1
+            eng.comm_destroy()
+        eng.close()
+    assert np.abs(res[0] - res[1]).max() < 1e-9 * np.abs(res[0]).max()
