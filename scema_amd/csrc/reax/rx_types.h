@@ -1,0 +1,91 @@
+// rx_types.h -- data layout of the ReaxFF force field path (BASELINE config 5): the parameter
+// tables of one force-field file and the per-replica work arrays in HBM.
+//
+// What it replaces in the reference: `pair_style reax/c NULL safezone 50.0 mincap 100000`, `pair_coeff * * ffield.reax.2 H C N O`,
+// `fix qeq/reax 1 0.0 10.0 1e-6 reax/c` (lammps_scripts/lammps_scripts_reax/in.strain.lammps:10-12,
+// ELASTIC/potential.mod.lammps:5-7), i.e. LAMMPS' USER-REAXC package [LAMMPS-ext].
+//
+// Rows: every per-atom list (neighbours, bonds) is stored entry-major, element (k, i) at [k * npad + i], so that a wave
+// whose lanes are consecutive atoms reads consecutive addresses at every step k of its row walk.
+#pragma once
+#include <stdint.h>
+
+#define RX_MAXT 6            /* force-field types kept (elements named by pair_coeff) */
+#define RX_MAXANG 4          /* parameter sets per valence-angle triple */
+#define RX_NGP 40
+#define RX_JMASK 0x00FFFFFF  /* row entry: [23:0] atom, [30:24] image code (sx+2) + 5 (sy+2) + 25 (sz+2) */
+#define RX_CODE0 62          /* code of the zero shift */
+
+#define RX_C_ELE 332.06371
+#define RX_KCALPMOL_TO_EV 23.02
+#define RX_EV_TO_KCALPMOL 14.4
+#define RX_THB_CUT 0.001
+#define RX_THB_CUTSQ 0.00001
+#define RX_HB_THRESHOLD 1e-2
+#define RX_BOND_CUT 5.0
+#define RX_HBOND_CUT 7.5
+#define RX_MIN_SINE 1e-10
+
+// energy parts (the order of the oracle's, so that tests compare part by part)
+enum { RX_E_BOND = 0, RX_E_LP, RX_E_OVER, RX_E_UNDER, RX_E_ANGLE, RX_E_PEN, RX_E_COA, RX_E_TORS, RX_E_CONJ, RX_E_HB, RX_E_VDW, RX_E_COUL, RX_E_POL, RX_NPART };
+
+typedef struct {
+  double r_s, valency, mass, r_vdw, epsilon, gamma, r_pi, valency_e, nlp_opt;
+  double alpha, gamma_w, valency_boc, p_ovun5, chi, eta;
+  double r_pi_pi, p_lp2, b_o_131, b_o_132, b_o_133;
+  double p_ovun2, p_val3, valency_val, p_val5;
+  int p_hbond, pad_;
+} RxSbp;
+typedef struct {
+  double De_s, De_p, De_pp, p_be1, p_bo5, v13cor, p_bo6, p_ovun1, p_be2, p_bo3, p_bo4, p_bo1, p_bo2, ovc;
+  double r_s, r_p, r_pp, p_boc3, p_boc4, p_boc5, D, alpha, r_vdW, gamma_w, gamma;
+} RxTbp;
+typedef struct { double theta_00, p_val1, p_val2, p_coa1, p_val7, p_pen1, p_val4; } RxThbPrm;
+typedef struct { int cnt, pad_; RxThbPrm prm[RX_MAXANG]; } RxThbp;
+typedef struct { int cnt, pad_; double V1, V2, V3, p_tor1, p_cot1; } RxFbp;
+typedef struct { double r0_hb, p_hb1, p_hb2, p_hb3; } RxHbp;
+
+typedef struct {
+  int nt;                 // types kept
+  int lammps_dsbo2;       // 1: the valence-angle term drops d(SBO)/d(Delta) when vlpex >= 0, as USER-REAXC's Valence_Angles does
+  double gp[RX_NGP];
+  double bo_cut, swa, swb;
+  double tap[8];
+  RxSbp sbp[RX_MAXT];
+  RxTbp tbp[RX_MAXT * RX_MAXT];
+  RxThbp thbp[RX_MAXT * RX_MAXT * RX_MAXT];
+  RxFbp fbp[RX_MAXT * RX_MAXT * RX_MAXT * RX_MAXT];
+  RxHbp hbp[RX_MAXT * RX_MAXT * RX_MAXT];
+} RxParams;
+
+// one replica's ReaxFF work set
+typedef struct {
+  int n, npad;            // atoms, row stride (n rounded up to 64)
+  int maxnb, maxbd;       // row capacities (entries)
+  double h[6], lo[3];     // box: lx, ly, lz, yz, xz, xy (LAMMPS h order) and origin
+  const int *rtype;       // [n] force-field type of every atom
+  const double *x;        // [n][3] positions (unwrapped)
+  double *q;              // [n] charges (charge equilibration)
+  // neighbour rows inside the list radius (full: j appears in i's row and i in j's)
+  int *nb_cnt;            // [n]
+  int *nb;                // [maxnb][npad]
+  // bond rows: pairs with BO' >= cutoff (full)
+  int *bd_cnt;            // [n]
+  int *bd;                // [maxbd][npad] atom | image code
+  int *bd_rev;            // [maxbd][npad] slot of this atom in the partner's row
+  double *bd_bop;         // [4][maxbd][npad] uncorrected: BO' (total, cutoff taken off), BO'_pi, BO'_pi2, r
+  double *bd_c;           // [3][maxbd][npad] dBO'_s/dd = c_s d, dBO'_pi/dd = c_pi d, dBO'_pi2/dd = c_pi2 d
+  double *bd_bo;          // [3][maxbd][npad] corrected: BO, BO_pi, BO_pi2
+  double *bd_g;           // [3][maxbd][npad] dE/d(BO, BO_pi, BO_pi2) gathered by the energy terms (each end into its own or the partner's row)
+  double *bd_cb;          // [maxbd][npad] after the back-propagation: coefficient of d in the bond force, Delta' part aside
+  double *deltap;         // [n] Delta'_i = sum BO' - valency
+  double *total_bo;       // [n] sum of corrected bond orders
+  double *cd_delta;       // [n] dE/d(Delta_i)
+  double *hd;             // [n] dE/d(Delta'_i)
+  double *f;              // [n][3]
+  // charge equilibration
+  double *hval;           // [maxnb][npad] H_ij of the row entries inside the taper radius (0 beyond)
+  double *s, *t;          // [n] the two solutions
+  double *s_hist, *t_hist;  // [4][n] and [3][n]... kept as [5][n] each: previous solutions, newest first
+  int *overflow;          // bit 1: neighbour row full, bit 2: bond row full
+} RxView;

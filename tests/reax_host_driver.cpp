@@ -1,0 +1,175 @@
+// reax_host_driver.cpp -- TEST HARNESS, not part of the product: runs the per-atom functions of scema_amd/csrc/reax/rx_core.h
+// (the arithmetic the HIP kernels of md_reax.hip execute one lane per atom) as plain loops on the host, so that
+// tests/test_reax_host.py can hold every derivative against central differences of the oracle's energy without a GPU.
+// Built by the test with g++ -DRX_HOST_TEST; nothing in scema_amd/ links it.
+#define RX_HOST_TEST 1
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../scema_amd/csrc/host/reax_ffield.h"
+#include "../scema_amd/csrc/reax/rx_core.h"
+
+namespace {
+
+struct Driver {
+  RxParams P;
+  std::vector<int> type_map;
+  std::string err;
+};
+
+}  // namespace
+
+extern "C" {
+
+void *rxh_create(const char *ffield, const char *const *elements, int nel, int lammps_dsbo2) {
+  Driver *d = new Driver();
+  std::vector<std::string> el(elements, elements + nel);
+  if (!scema::read_reax_ffield(ffield, el, d->P, d->type_map, d->err)) {
+    std::fprintf(stderr, "rxh_create: %s\n", d->err.c_str());
+    delete d;
+    return nullptr;
+  }
+  d->P.lammps_dsbo2 = lammps_dsbo2;
+  return d;
+}
+void rxh_destroy(void *h) { delete (Driver *)h; }
+int rxh_ntypes(void *h) { return ((Driver *)h)->P.nt; }
+
+// terms: bit 0 bond + lone pair + over/under, 1 angles, 2 torsions, 3 hydrogen bonds, 4 van der Waals + Coulomb + polarisation
+// q_in == NULL: charges from the equilibration (tolerance qeq_tol), returned in q_out.  Returns <0 on failure.
+int rxh_compute(void *h, int n, const int *lmp_type0, const double *x_in, const double *box, double rlist, const double *q_in, double qeq_tol, int terms,
+                double *f, double *eng, double *vir, double *q_out, int *counts /* max neighbours, max bonds, qeq iterations */) {
+  Driver *D = (Driver *)h;
+  const RxParams *P = &D->P;
+  RxView V;
+  std::memset(&V, 0, sizeof V);
+  V.n = n;
+  V.npad = (n + 63) / 64 * 64;
+  V.h[0] = box[3] - box[0]; V.h[1] = box[4] - box[1]; V.h[2] = box[5] - box[2];
+  V.h[3] = box[8]; V.h[4] = box[7]; V.h[5] = box[6];
+  for (int d = 0; d < 3; d++) V.lo[d] = box[d];
+  // wrapped copy of the positions
+  std::vector<double> x(3 * (size_t)n);
+  for (int i = 0; i < n; i++) {
+    double d0 = x_in[3 * i] - V.lo[0], d1 = x_in[3 * i + 1] - V.lo[1], d2 = x_in[3 * i + 2] - V.lo[2];
+    const double l2 = d2 / V.h[2];
+    const double l1 = (d1 - V.h[3] * l2) / V.h[1];
+    const double l0 = (d0 - V.h[5] * l1 - V.h[4] * l2) / V.h[0];
+    const double w0 = std::floor(l0), w1 = std::floor(l1), w2 = std::floor(l2);
+    x[3 * i] = x_in[3 * i] - (w0 * V.h[0] + w1 * V.h[5] + w2 * V.h[4]);
+    x[3 * i + 1] = x_in[3 * i + 1] - (w1 * V.h[1] + w2 * V.h[3]);
+    x[3 * i + 2] = x_in[3 * i + 2] - w2 * V.h[2];
+  }
+  V.x = x.data();
+  std::vector<int> rtype(n);
+  for (int i = 0; i < n; i++) rtype[i] = D->type_map[lmp_type0[i]];
+  V.rtype = rtype.data();
+  // neighbour rows: all images within the list radius
+  std::vector<std::vector<int>> rows(n);
+  const double rl2 = rlist * rlist;
+  // perpendicular widths decide how many images can come inside the list radius
+  const double vol = V.h[0] * V.h[1] * V.h[2];
+  const double wx = vol / std::sqrt(V.h[1] * V.h[2] * V.h[1] * V.h[2] + V.h[2] * V.h[5] * V.h[2] * V.h[5] + (V.h[5] * V.h[3] - V.h[1] * V.h[4]) * (V.h[5] * V.h[3] - V.h[1] * V.h[4]));
+  const double wy = vol / std::sqrt(V.h[0] * V.h[2] * V.h[0] * V.h[2] + V.h[0] * V.h[3] * V.h[0] * V.h[3]);
+  const double wz = V.h[2];
+  const int m0 = (int)std::ceil(rlist / wx), m1 = (int)std::ceil(rlist / wy), m2 = (int)std::ceil(rlist / wz);
+  if (m0 > 2 || m1 > 2 || m2 > 2) return -2;   // box thinner than half the list radius
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++)
+      for (int sz = -m2; sz <= m2; sz++)
+        for (int sy = -m1; sy <= m1; sy++)
+          for (int sx = -m0; sx <= m0; sx++) {
+            if (j == i && sx == 0 && sy == 0 && sz == 0) continue;
+            const double d0 = x[3 * j] - x[3 * i] + sx * V.h[0] + sy * V.h[5] + sz * V.h[4];
+            const double d1 = x[3 * j + 1] - x[3 * i + 1] + sy * V.h[1] + sz * V.h[3];
+            const double d2 = x[3 * j + 2] - x[3 * i + 2] + sz * V.h[2];
+            if (d0 * d0 + d1 * d1 + d2 * d2 <= rl2) rows[i].push_back(j | (((sx + 2) + 5 * (sy + 2) + 25 * (sz + 2)) << 24));
+          }
+  int maxnb = 1;
+  for (int i = 0; i < n; i++) maxnb = std::max(maxnb, (int)rows[i].size());
+  V.maxnb = maxnb;
+  V.maxbd = 48;
+  const size_t np = V.npad;
+  std::vector<int> nb_cnt(n), nb((size_t)maxnb * np, 0), bd_cnt(n), bd((size_t)V.maxbd * np), bd_rev((size_t)V.maxbd * np);
+  for (int i = 0; i < n; i++) {
+    nb_cnt[i] = (int)rows[i].size();
+    for (size_t k = 0; k < rows[i].size(); k++) nb[k * np + i] = rows[i][k];
+  }
+  std::vector<double> bop(4 * V.maxbd * np), bc(3 * V.maxbd * np), bo(3 * V.maxbd * np), bg(3 * V.maxbd * np), cb(V.maxbd * np);
+  std::vector<double> deltap(n), total_bo(n), cd_delta(n), hd(n), ff(3 * (size_t)n), q(n, 0.0), hval((size_t)maxnb * np);
+  int overflow = 0;
+  V.nb_cnt = nb_cnt.data(); V.nb = nb.data(); V.bd_cnt = bd_cnt.data(); V.bd = bd.data(); V.bd_rev = bd_rev.data();
+  V.bd_bop = bop.data(); V.bd_c = bc.data(); V.bd_bo = bo.data(); V.bd_g = bg.data(); V.bd_cb = cb.data();
+  V.deltap = deltap.data(); V.total_bo = total_bo.data(); V.cd_delta = cd_delta.data(); V.hd = hd.data(); V.f = ff.data();
+  V.q = q.data(); V.hval = hval.data(); V.overflow = &overflow;
+  int qeq_iters = 0;
+  if (q_in) {
+    for (int i = 0; i < n; i++) q[i] = q_in[i];
+  } else {
+    // fix qeq/reax: H s = -chi, H t = -1 by Jacobi-preconditioned conjugate gradients, q = s - (sum s / sum t) t
+    for (int i = 0; i < n; i++) rx_qeq_row(P, &V, i);
+    std::vector<double> sol[2];
+    for (int sys = 0; sys < 2; sys++) {
+      std::vector<double> b(n), xs(n, 0.0), r(n), d(n), qv(n), p(n);
+      for (int i = 0; i < n; i++) b[i] = sys ? -1.0 : -P->sbp[rtype[i]].chi;
+      double bn = 0.0, sig = 0.0;
+      for (int i = 0; i < n; i++) {
+        r[i] = b[i] - rx_qeq_matvec_row(P, &V, i, xs.data());
+        d[i] = r[i] / P->sbp[rtype[i]].eta;
+        bn += b[i] * b[i];
+        sig += r[i] * d[i];
+      }
+      bn = std::sqrt(bn);
+      int it = 0;
+      for (; it < 1000 && std::sqrt(sig) / bn > qeq_tol; it++) {
+        double dq = 0.0;
+        for (int i = 0; i < n; i++) { qv[i] = rx_qeq_matvec_row(P, &V, i, d.data()); dq += d[i] * qv[i]; }
+        const double alpha = sig / dq;
+        double sig_new = 0.0;
+        for (int i = 0; i < n; i++) {
+          xs[i] += alpha * d[i];
+          r[i] -= alpha * qv[i];
+          p[i] = r[i] / P->sbp[rtype[i]].eta;
+          sig_new += r[i] * p[i];
+        }
+        const double beta = sig_new / sig;
+        sig = sig_new;
+        for (int i = 0; i < n; i++) d[i] = p[i] + beta * d[i];
+      }
+      qeq_iters += it;
+      sol[sys] = xs;
+    }
+    double ss = 0.0, st = 0.0;
+    for (int i = 0; i < n; i++) { ss += sol[0][i]; st += sol[1][i]; }
+    for (int i = 0; i < n; i++) q[i] = sol[0][i] - ss / st * sol[1][i];
+  }
+  if (q_out)
+    for (int i = 0; i < n; i++) q_out[i] = q[i];
+  double e[RX_NPART], w[6];
+  for (int k = 0; k < RX_NPART; k++) e[k] = 0.0;
+  for (int k = 0; k < 6; k++) w[k] = 0.0;
+  for (int i = 0; i < n; i++) rx_bonds_prime(P, &V, i);
+  for (int i = 0; i < n; i++) rx_bonds_rev(&V, i);
+  for (int i = 0; i < n; i++) rx_bonds_corrected(P, &V, i);
+  if (terms & 1) for (int i = 0; i < n; i++) rx_atom_terms(P, &V, i, e);
+  if (terms & 2) for (int i = 0; i < n; i++) rx_angle_terms(P, &V, i, e, w);
+  if (terms & 4) for (int i = 0; i < n; i++) rx_torsion_terms(P, &V, i, e, w);
+  if (terms & 8) for (int i = 0; i < n; i++) rx_hbond_terms(P, &V, i, e, w);
+  if (terms & 16) for (int i = 0; i < n; i++) rx_nonbonded(P, &V, i, e, w);
+  for (int i = 0; i < n; i++) rx_back_corr(P, &V, i);
+  for (int i = 0; i < n; i++) rx_back_force(P, &V, i, w);
+  if (f) std::memcpy(f, ff.data(), 3 * (size_t)n * sizeof(double));
+  if (eng) std::memcpy(eng, e, sizeof e);
+  if (vir) std::memcpy(vir, w, sizeof w);
+  if (counts) {
+    int mb = 0;
+    for (int i = 0; i < n; i++) mb = std::max(mb, bd_cnt[i]);
+    counts[0] = maxnb; counts[1] = mb; counts[2] = qeq_iters;
+  }
+  return overflow ? -1 : 0;
+}
+}
