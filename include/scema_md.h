@@ -244,6 +244,31 @@ int scema_md_debug_run(scema_md_engine *e, int32_t qp_id, const char *matid, int
                        double dt, double temperature, int32_t nvt, int32_t use_shake, const double *rates,
                        double *press_avg);
 
+/* ---- ReaxFF replicas (md_force_field "reax": lammps_scripts/lammps_scripts_reax) ----
+ * configure = what the reax scripts set up in LAMMPS before every run: `pair_style reax/c NULL safezone 50.0 mincap 100000`,
+ * `pair_coeff * * <ffield> H C N O` (elements[k] = element of LAMMPS atom type k+1), `fix qeq/reax 1 0.0 10.0 <qeq_tol> reax/c`
+ * (in.strain.lammps:10-12, ELASTIC/potential.mod.lammps:5-7); no SHAKE, no k-space, `neigh_modify every 1 delay 0 check no`.
+ * qeq_tol <= 0: 1e-6.  skin < 0: default list skin (performance only: the pairs inside the 10 A taper radius do not depend
+ * on it).  scema_md_strain_batch configures by itself from MDSim.scripts_folder + "/ffield.reax.2" and H C N O, as the
+ * reference's script does, when a simulation asks for force_field "reax" and nothing was configured.  A replica for this
+ * path is registered like any other (atom types, masses, box, x, v; no bonds; charges are equilibrated every step). */
+int scema_md_reax_configure(scema_md_engine *e, const char *ffield_path, const char *const *elements, int32_t n_elements,
+                            double qeq_tol, double skin);
+/* which force field the parity hooks (scema_md_debug_run, scema_md_reax_debug_compute) use; strain_batch decides per call
+ * from MDSim.force_field */
+int scema_md_reax_activate(scema_md_engine *e, int32_t on);
+/* parity switches (-1 keeps): exact_gradient 0 = drop the d(SBO)/d(Delta) term of the valence-angle energy for atoms with
+ * vlpex >= 0, as USER-REAXC's Valence_Angles is remembered to do (unverifiable here, not energy conserving: DESIGN.md;
+ * default 1 = the exact gradient); terms = bit mask of energy-term groups evaluated (31 = all) */
+int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms, int32_t qeq_maxiter);
+/* static evaluation: f [natoms*3], eparts[13] (bond, lone pair, over, under, angle, penalty, 3-body conj., torsion, 4-body
+ * conj., hydrogen bond, van der Waals, Coulomb, polarisation; kcal/mol), virial[6] (xx,yy,zz,xy,xz,yz), charges q[natoms],
+ * info[6]: longest neighbour row, row capacity, bond-row capacity, CG iterations, image search (0 = minimum image), longest bond row */
+int scema_md_reax_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double *f, double *eparts,
+                                double *virial, double *q, double *info);
+/* out[4]: conjugate-gradient iterations, solves (two systems each), list skin, tolerance */
+int scema_md_reax_stats(const scema_md_engine *e, double *out);
+
 typedef struct {
   int64_t pair_launches;      /* timed pair-kernel launches */
   double pair_ms;             /* sum of their HIP-event durations */

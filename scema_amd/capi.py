@@ -32,6 +32,7 @@ SYMBOLS = [
     "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_state_owner", "scema_md_last_plan",
     "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update",
+    "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_debug_compute", "scema_md_reax_stats",
 ]
 COMM_ID_BYTES = 128
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -193,6 +194,23 @@ def write_lammps_restart(path: str, sysd: dict, cut_lj: float, cut_coul: float, 
                                              C.c_double(timestep), C.c_int64(ntimestep))
     if rc != 0:
         raise IOError(f"cannot write {path} (rc={rc})")
+
+
+REAX_PARTS = ["bond", "lp", "over", "under", "angle", "pen", "coa", "tors", "conj", "hb", "vdw", "coul", "pol"]
+
+
+def reax_system(symbols, x, box, v=None, elements=("H", "C", "N", "O"), masses=(1.008, 12.011, 14.007, 15.999)) -> dict:
+    """System dict of a ReaxFF replica (atom_style charge, lammps_scripts_reax/in.set.lammps:17): LAMMPS type k+1 = elements[k],
+    no bonded topology; charges are equilibrated by the engine every step."""
+    n = len(symbols)
+    nt = len(elements)
+    z2 = np.zeros((0, 2))
+    return dict(natoms=n, ntypes=nt, type=np.array([elements.index(s) for s in symbols], np.int32), charge=np.zeros(n), mass=np.array(masses, float),
+                eps=np.zeros((nt, nt)), sigma=np.ones((nt, nt)), bonds=np.zeros((0, 2), np.int32), bond_type=np.zeros(0, np.int32), bond_coeff=z2,
+                angles=np.zeros((0, 3), np.int32), angle_type=np.zeros(0, np.int32), angle_coeff=z2, dihedrals=np.zeros((0, 4), np.int32),
+                dihedral_type=np.zeros(0, np.int32), dihedral_coeff=np.zeros((0, 4)), impropers=np.zeros((0, 4), np.int32),
+                improper_type=np.zeros(0, np.int32), improper_coeff=z2, special_lj=np.zeros(3), special_coul=np.zeros(3),
+                box=np.asarray(box, float), x=np.asarray(x, float), v=np.zeros((n, 3)) if v is None else np.asarray(v, float))
 
 
 class EngineError(RuntimeError):
@@ -369,6 +387,30 @@ class Engine:
         length, stress, stiff = np.zeros(3), np.zeros(6), np.zeros(36)
         self._chk(lib().scema_md_init_material(self.h, matid.encode(), C.c_int32(replica), C.byref(p), _p(length), _p(stress), _p(stiff)))
         return length, stress, stiff.reshape(6, 6)
+
+    # ---- ReaxFF replicas (force_field "reax") ----
+    def reax_configure(self, ffield: str, elements=("H", "C", "N", "O"), qeq_tol: float = 1e-6, skin: float = -1.0):
+        """pair_coeff * * <ffield> H C N O + fix qeq/reax 1 0.0 10.0 <qeq_tol> (lammps_scripts_reax/in.strain.lammps:10-12)"""
+        arr = (C.c_char_p * len(elements))(*[e.encode() for e in elements])
+        self._chk(lib().scema_md_reax_configure(self.h, ffield.encode(), arr, C.c_int32(len(elements)), C.c_double(qeq_tol), C.c_double(skin)))
+
+    def reax_activate(self, on: bool = True):
+        self._chk(lib().scema_md_reax_activate(self.h, C.c_int32(1 if on else 0)))
+
+    def reax_set(self, exact_gradient: int = -1, terms: int = -1, qeq_maxiter: int = -1):
+        self._chk(lib().scema_md_reax_set(self.h, C.c_int32(exact_gradient), C.c_int32(terms), C.c_int32(qeq_maxiter)))
+
+    def reax_compute(self, matid, replica, qp=QP_NONE):
+        n = self._natoms[(matid, replica)]
+        f = np.zeros((n, 3)); e = np.zeros(len(REAX_PARTS)); w = np.zeros(6); q = np.zeros(n); info = np.zeros(6)
+        self._chk(lib().scema_md_reax_debug_compute(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), _p(f), _p(e), _p(w), _p(q), _p(info)))
+        return dict(f=f, e=dict(zip(REAX_PARTS, e)), w=w, q=q, maxneigh_seen=int(info[0]), maxnb=int(info[1]), maxbd=int(info[2]),
+                    qeq_iters=int(info[3]), image_search=int(info[4]), maxbonds_seen=int(info[5]))
+
+    def reax_stats(self) -> dict:
+        out = np.zeros(4)
+        self._chk(lib().scema_md_reax_stats(self.h, _p(out)))
+        return dict(qeq_iters=int(out[0]), qeq_solves=int(out[1]), skin=out[2], qeq_tol=out[3])
 
     def profile(self, reset=False) -> dict:
         p = Profile()

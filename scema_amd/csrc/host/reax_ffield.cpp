@@ -52,7 +52,7 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
   };
   Line l;
   std::memset(&P, 0, sizeof(P));
-  P.lammps_dsbo2 = 1;
+  P.lammps_dsbo2 = 0;
   if (!next(l, 1)) return false;
   const int ngp = (int)l.v[0];
   for (int k = 0; k < ngp; k++) {

@@ -29,8 +29,10 @@
 #include <vector>
 
 #include "../../include/scema_md.h"
+#include "host/reax_ffield.h"
 #include "host/sim_plan.h"
 #include "md_kernels.h"
+#include "md_reax.h"
 #include "md_types.h"
 
 namespace {
@@ -115,6 +117,8 @@ struct Topo {
   double init_box[9];
   std::vector<double> init_x, init_v;
   // device copies
+  DevBuf d_rtype;          // ReaxFF: force-field type per atom (element of the LAMMPS type), valid for rtype_stamp
+  int rtype_stamp = -1;
   DevBuf d_type, d_q, d_mass, d_lj, d_bt_terms, d_bt_coef, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_bt_desc, d_bt_atoms, d_bt_rank;
   int bt_ntile = 0, bt_maxloc = 1, bt_maxchunk = 1, bt_ncoef = 0, bt_cf_off[4] = {0, 0, 0, 0};
   double sp_w[6] = {0, 0, 0, 0, 0, 0};   // special_bonds weights: lj 1-2, 1-3, 1-4, coul 1-2, 1-3, 1-4
@@ -131,7 +135,14 @@ struct State {
   double skin_extra = 0.0;
 };
 
+// work arrays of the ReaxFF path for one batch position (reax/rx_types.h RxView points into these)
+struct RxSlot {
+  int cap_pad = 0, cap_nb = 0, cap_bd = 0;
+  DevBuf nb_cnt, nb, hval, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
+};
+
 struct Slot {
+  std::unique_ptr<RxSlot> rx;
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
   size_t cap_jtab = 0;
   DevBuf virp, virb, fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
@@ -203,6 +214,16 @@ struct scema_md_engine {
   double jtab_grow = 1.0;    // headroom factor of the tile j tables, x1.25 per overflow (-> smaller cells)
   int overflow_bits = 0;     // what overflowed in the last run: 4 = a tile's j table, 8 = a cluster row
   bool use_graphs = false;  // hipGraph replay of the MD step loop: opt-in (SCEMA_MD_GRAPH=1), measured slower on ROCm 7.2
+  // ReaxFF path (force_field "reax"): the force-field tables, settings of fix qeq/reax, list skin
+  bool rx_ready = false, reax_active = false;
+  int rx_stamp = 0;                    // bumped by every scema_md_reax_configure
+  RxParams rx_host;
+  std::vector<int> rx_type_map;        // LAMMPS type - 1 -> force-field type
+  DevBuf d_rxparams, d_rxviews;
+  std::vector<RxView> h_rxviews;
+  double rx_skin = 1.0, rx_qeq_tol = 1e-6;
+  int rx_qeq_maxiter = 200, rx_terms = 31;
+  long long rx_qeq_iters = 0, rx_qeq_solves = 0;
   Comm comm;
   scema::OwnerDirectory dir;   // state key -> owning rank, identical on every rank (host/sim_plan.h)
   scema::SimPlan last_plan;
@@ -982,9 +1003,12 @@ static hipError_t force_stage(scema_md_engine *e, hipStream_t st, bool allow_sid
   return hipSuccess;
 }
 
+#include "md_reax_engine.inc"
+
 // Advance sims[0..ns) (already assigned to slots 0..ns-1, scalars' box valid on the device).
 // On return the per-sim SimScalars are in e->h_sc.
 int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &spec) {
+  if (e->reax_active) return run_phase_reax(e, sims, spec);
   const int ns = (int)sims.size();
   const scema_md_params &P = e->p;
   const double cutmax_all = std::max(P.cut_lj, P.cut_coul);
@@ -1990,6 +2014,7 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   // ---- who runs what (host/sim_plan.h): identical on every rank ----
   std::vector<std::string> src_keys(n_sims), dst_keys(n_sims);
   std::vector<double> cost(n_sims, 1.0);
+  int n_reax = 0, n_md = 0;
   for (int i = 0; i < n_sims; i++) {
     sims[i].stress_updated = 0;
     // stmd_problem.h:462-467
@@ -1997,7 +2022,18 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     if (std::strcmp(ff, "opls") != 0 && std::strcmp(ff, "reax") != 0)
       return fail(e, SCEMA_MD_ERR_ARG, "Error: Force field is %s but only 'opls' and 'reax' are implemented... ", ff);
     if (hooke_mode) continue;   // sigma = C:eps has no state: the fresh-batch rule of the planner = i % world (stmd_sync.h:583)
-    if (std::strcmp(ff, "reax") == 0) return fail(e, SCEMA_MD_ERR_ARG, "force field 'reax' is not built yet (SURVEY row f-4)");
+    n_md++;
+    if (std::strcmp(ff, "reax") == 0) {
+      n_reax++;
+      if (!e->rx_ready) {
+        // the reference's scripts name the file and the elements: pair_coeff * * ${locs}/ffield.reax.2 H C N O
+        // (lammps_scripts_reax/in.strain.lammps:11, locs = MDSim.scripts_folder, stmd_problem.h:163)
+        static const char *hcno[4] = {"H", "C", "N", "O"};
+        const std::string path = std::string(sims[i].scripts_folder ? sims[i].scripts_folder : ".") + "/ffield.reax.2";
+        const int rc_cfg = scema_md_reax_configure(e, path.c_str(), hcno, 4, 1e-6, -1.0);
+        if (rc_cfg) return rc_cfg;
+      }
+    }
     dst_keys[i] = state_key(sims[i].qp_id, sims[i].matid, sims[i].replica);
     // stmd_problem.h:116-120: the state is read under most_recent_qp_id ("none" -> init.<mat>_<rep>.bin)
     if (sims[i].most_recent_qp_id == sims[i].qp_id) src_keys[i] = dst_keys[i];
@@ -2009,6 +2045,12 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
       cost[i] = (double)nts_rule(sims[i], lb0, eps0, nullptr) + (double)std::max(sims[i].nsteps_sample, 1);
     }
   }
+  if (n_reax != 0 && n_reax != n_md) return fail(e, SCEMA_MD_ERR_ARG, "one update mixes force fields (%d of %d simulations ask for 'reax'): md_force_field is one setting per run", n_reax, n_md);
+  struct ReaxScope {   // the force field of this update; the debug entry points keep whatever scema_md_reax_activate chose
+    scema_md_engine *e; bool saved;
+    ReaxScope(scema_md_engine *e_, bool on) : e(e_), saved(e_->reax_active) { e->reax_active = on; }
+    ~ReaxScope() { e->reax_active = saved; }
+  } reax_scope(e, n_reax > 0);
   e->last_plan = e->dir.plan(src_keys, dst_keys, cost, world);
   const scema::SimPlan &plan = e->last_plan;
   const int per_rank = plan.cap;
@@ -2563,6 +2605,110 @@ int scema_md_init_material(scema_md_engine *e, const char *matid, int32_t replic
   static const int HOSTVOIGT_OF_FILE[6] = {0, 3, 4, 1, 5, 2};
   for (int I = 0; I < 6; I++)
     for (int J = 0; J < 6; J++) stiff[I * 6 + J] = call[HOSTVOIGT_OF_FILE[I]][HOSTVOIGT_OF_FILE[J]];
+  return SCEMA_MD_OK;
+}
+
+// ---- ReaxFF path ----
+int scema_md_reax_configure(scema_md_engine *e, const char *ffield_path, const char *const *elements, int32_t n_elements, double qeq_tol, double skin) {
+  if (!e || !ffield_path || !elements || n_elements <= 0) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(e->p.device));
+  std::vector<std::string> el(elements, elements + n_elements);
+  std::string err;
+  RxParams P;
+  std::vector<int> map;
+  if (!scema::read_reax_ffield(ffield_path, el, P, map, err)) return fail(e, SCEMA_MD_ERR_IO, "%s", err.c_str());
+  if (const char *x = getenv("SCEMA_REAX_DROP_DSBO2")) P.lammps_dsbo2 = atoi(x) ? 1 : 0;
+  e->rx_host = P;
+  e->rx_type_map = map;
+  if (qeq_tol > 0.0) e->rx_qeq_tol = qeq_tol;
+  if (skin >= 0.0) e->rx_skin = skin;
+  if (const char *x = getenv("SCEMA_REAX_SKIN")) e->rx_skin = atof(x);
+  HIPCHK(e->d_rxparams.ensure(sizeof(RxParams)));
+  HIPCHK(hipMemcpyAsync(e->d_rxparams.p, &e->rx_host, sizeof(RxParams), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->rx_ready = true;
+  e->rx_stamp += 1;
+  e->reax_active = true;
+  return SCEMA_MD_OK;
+}
+int scema_md_reax_activate(scema_md_engine *e, int32_t on) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  if (on && !e->rx_ready) return fail(e, SCEMA_MD_ERR_ARG, "no ReaxFF force field loaded");
+  e->reax_active = on != 0;
+  return SCEMA_MD_OK;
+}
+int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms, int32_t qeq_maxiter) {
+  if (!e || !e->rx_ready) return fail(e, SCEMA_MD_ERR_ARG, "no ReaxFF force field loaded");
+  HIPCHK(hipSetDevice(e->p.device));
+  if (exact_gradient >= 0) {
+    e->rx_host.lammps_dsbo2 = exact_gradient ? 0 : 1;
+    HIPCHK(hipMemcpyAsync(e->d_rxparams.p, &e->rx_host, sizeof(RxParams), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  if (terms >= 0) e->rx_terms = terms;
+  if (qeq_maxiter > 0) e->rx_qeq_maxiter = qeq_maxiter;
+  return SCEMA_MD_OK;
+}
+// static evaluation of a state (qp_id SCEMA_MD_QP_NONE: the registered replica): forces, the 13 energy parts, virial, charges
+int scema_md_reax_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double *f, double *eparts, double *virial,
+                                double *q, double *info) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  if (!e->rx_ready) return fail(e, SCEMA_MD_ERR_ARG, "no ReaxFF force field loaded");
+  HIPCHK(hipSetDevice(e->p.device));
+  State *s = nullptr;
+  std::unique_ptr<State> tmp;
+  int rc = debug_state(e, qp_id, matid, replica, &s, tmp);
+  if (rc) return rc;
+  std::vector<ActiveSim> sims(1);
+  sims[0].st = s;
+  sims[0].nsteps = 0;
+  sims[0].dt = 1.0;
+  sims[0].temperature = 300.0;
+  const bool saved = e->reax_active;
+  e->reax_active = true;
+  const long long it0 = e->rx_qeq_iters;
+  for (int attempt = 0; attempt < 6; attempt++) {
+    if ((rc = prepare_slots(e, sims))) break;
+    RunSpec R;
+    R.nvt = 0;
+    R.static_only = 1;
+    rc = run_phase(e, sims, R);
+    if (rc != SCEMA_MD_ERR_OVERFLOW) break;
+    e->neigh_grow *= 1.5;
+  }
+  e->reax_active = saved;
+  if (rc) return rc;
+  const int n = s->topo->natoms;
+  const SimScalars &sc = e->h_sc[0];
+  const RxView &V = e->h_rxviews[0];
+  if (f) HIPCHK(hipMemcpy(f, e->slots[0]->f.p, 3 * (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (eparts) HIPCHK(hipMemcpy(eparts, V.eparts, RX_NPART * 8, hipMemcpyDeviceToHost));
+  if (q) HIPCHK(hipMemcpy(q, V.q, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (virial)
+    for (int k = 0; k < 6; k++) {
+      virial[k] = 0.0;
+      for (int p = 0; p < MD_NPART; p++) virial[k] += sc.vir[p * 6 + k];
+    }
+  if (info) {
+    info[0] = sc.maxneigh_seen;
+    info[1] = V.maxnb;
+    info[2] = V.maxbd;
+    info[3] = (double)(e->rx_qeq_iters - it0);
+    info[4] = V.mimg[0] + V.mimg[1] + V.mimg[2];
+    std::vector<int> bc(n);
+    HIPCHK(hipMemcpy(bc.data(), V.bd_cnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int mb = 0;
+    for (int v : bc) mb = std::max(mb, v);
+    info[5] = mb;
+  }
+  return SCEMA_MD_OK;
+}
+int scema_md_reax_stats(const scema_md_engine *e, double *out) {
+  if (!e || !out) return SCEMA_MD_ERR_ARG;
+  out[0] = (double)e->rx_qeq_iters;
+  out[1] = (double)e->rx_qeq_solves;
+  out[2] = e->rx_skin;
+  out[3] = e->rx_qeq_tol;
   return SCEMA_MD_OK;
 }
 

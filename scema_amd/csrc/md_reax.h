@@ -1,0 +1,12 @@
+// md_reax.h -- host-callable launch wrappers of the ReaxFF kernels (md_reax.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "reax/rx_types.h"
+struct SimDev;
+// zero the charge-equilibration history and the flags at the start of a run
+void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad);
+// the whole force stage of one step for the first ns replicas: (neighbour rows if the rebuild flag of the step is set,)
+// charge equilibration, bond orders, energy terms, forces into SimDev::f, virial and energies into SimScalars.
+// terms: bit 0 bond/lone pair/over/under, 1 angles, 2 torsions, 3 hydrogen bonds, 4 non-bonded (31 = all; parity hook)
+void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int terms);

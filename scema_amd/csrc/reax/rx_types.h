@@ -47,7 +47,8 @@ typedef struct { double r0_hb, p_hb1, p_hb2, p_hb3; } RxHbp;
 
 typedef struct {
   int nt;                 // types kept
-  int lammps_dsbo2;       // 1: the valence-angle term drops d(SBO)/d(Delta) when vlpex >= 0, as USER-REAXC's Valence_Angles does
+  int lammps_dsbo2;       // 1: the valence-angle term drops d(SBO)/d(Delta) when vlpex >= 0 (a reading of USER-REAXC's Valence_Angles that
+                          // could not be checked and breaks energy conservation; off by default)
   double gp[RX_NGP];
   double bo_cut, swa, swb;
   double tap[8];
@@ -85,7 +86,11 @@ typedef struct {
   double *f;              // [n][3]
   // charge equilibration
   double *hval;           // [maxnb][npad] H_ij of the row entries inside the taper radius (0 beyond)
-  double *s, *t;          // [n] the two solutions
-  double *s_hist, *t_hist;  // [4][n] and [3][n]... kept as [5][n] each: previous solutions, newest first
-  int *overflow;          // bit 1: neighbour row full, bit 2: bond row full
+  double *s, *t;          // [npad] the two solutions
+  double *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)
+  double *qwork;          // [6][npad] residuals, search directions, matrix-vector products of the two systems
+  int *qstat;             // [2] conjugate-gradient iterations and solves since the start of the run
+  double *eparts;         // [RX_NPART] energy parts of the step
+  int mimg[3];            // neighbour search: 0,0,0 = minimum image (box at least two list radii wide), else images up to mimg[d] boxes away
+  int *overflow;          // bit 1: neighbour row full, bit 2: bond row full, bit 4: charge equilibration did not converge
 } RxView;

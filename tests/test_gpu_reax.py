@@ -1,0 +1,267 @@
+"""ReaxFF path on the GPU (md_reax.hip) against the oracle (oracle/reax_oracle.c): SURVEY.md 8(f) row f-4, BASELINE config 5.
+
+PARITY UNPINNED at the oracle level (LAMMPS USER-REAXC is not available; see oracle/reax_oracle.h): what is shown here is
+that the kernels reproduce the oracle's energies term by term, its equilibrated charges, the central differences of its
+energy (forces) and its strain derivative (virial), on isolated molecules, condensed cells in both neighbour-search modes,
+and on configurations reached by the engine's own dynamics (thermostat, fix deform, list rebuilds, wrapping)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyreax as pr
+from scema_amd import capi
+from test_oracle_reax import FFIELD, _glycine_like
+from test_reax_host import BIGBOX, _check_dirs, _mixture, _pe_cell, _sym
+
+pytestmark = pytest.mark.gpu
+
+FTM2V = 1.0 / 48.88821291 / 48.88821291
+NKTV2P = 68568.415
+MVV2E = 48.88821291 * 48.88821291
+
+
+@pytest.fixture(scope="module")
+def ff():
+    f = pr.ForceField(FFIELD)
+    yield f
+    f.close()
+
+
+@pytest.fixture()
+def eng():
+    e = capi.Engine()
+    e.reax_configure(FFIELD, qeq_tol=1e-10)
+    e.reax_set(exact_gradient=1)
+    yield e
+    e.close()
+
+
+def _oracle_virial(ff, t, x, box, q):
+    w = np.zeros(6)
+    pr.lib().rxo_forces_fd(ff.h, len(t), pr._p(np.ascontiguousarray(t, dtype=np.int32)), pr._p(np.ascontiguousarray(x)), pr._p(np.ascontiguousarray(box)),
+                           pr._p(np.ascontiguousarray(q)), 1e-5, None, pr._p(w))
+    return w
+
+
+def _compare_static(ff, eng, sym, x, box, name="m", full_fd=False, seed=1):
+    t = ff.types(sym)
+    eng.register_replica(name, 1, capi.reax_system(sym, x, box))
+    r = eng.reax_compute(name, 1)
+    q, _ = ff.qeq(t, x, box=box, tol=1e-10, maxiter=500)
+    assert np.abs(r["q"] - q).max() < 1e-7 and abs(r["q"].sum()) < 1e-8
+    # energies with the engine's own charges (their difference from the oracle's is at the solver tolerance)
+    _, po = ff.energy(t, x, box=box, q=r["q"])
+    for k in pr.PARTS:
+        assert abs(r["e"][k] - po[k]) < 1e-9 * max(1.0, abs(po[k])), (k, r["e"][k], po[k])
+    f = r["f"]
+    assert np.abs(f.sum(0)).max() < 1e-6 * max(1.0, np.abs(f).max())
+    if full_fd:
+        fo = ff.forces(t, x, box=box, q=r["q"], h=1e-5)
+        assert np.abs(f - fo).max() < 2e-6 * max(1.0, np.abs(fo).max())
+    else:
+        good, worst = _check_dirs(ff, t, x, box, r["q"], f, seed=seed)
+        assert good >= 5, worst
+    w = _oracle_virial(ff, t, x, box, r["q"])
+    assert np.abs(r["w"] - w).max() < 2e-6 * np.abs(w).max(), (r["w"], w)
+    return r, po
+
+
+def test_isolated_molecule_all_terms(ff, eng):
+    t, x = _glycine_like(ff)
+    r, po = _compare_static(ff, eng, _sym(ff, t), x + 0.0, BIGBOX, full_fd=True)
+    assert r["image_search"] == 0
+    assert all(abs(po[k]) > 1e-6 for k in ("bond", "lp", "over", "under", "angle", "tors", "conj", "hb", "vdw", "coul", "pol"))
+
+
+def test_each_term_group_alone(ff, eng):
+    """the parity switch `terms` isolates a launch: its forces are the central differences of just those energy parts"""
+    t, x = _glycine_like(ff)
+    sym = _sym(ff, t)
+    eng.register_replica("m", 1, capi.reax_system(sym, x, BIGBOX))
+    q = eng.reax_compute("m", 1)["q"]
+    groups = {1: ("bond", "lp", "over", "under"), 2: ("angle", "pen", "coa"), 4: ("tors", "conj"), 8: ("hb",), 16: ("vdw", "coul", "pol")}
+    h = 1e-5
+    for mask, parts in groups.items():
+        eng.reax_set(terms=mask)
+        f = eng.reax_compute("m", 1)["f"]
+        fd = np.zeros_like(x)
+        for i in range(len(x)):
+            for c in range(3):
+                xp, xm = x.copy(), x.copy()
+                xp[i, c] += h
+                xm[i, c] -= h
+                pp, pm = ff.energy(t, xp, box=BIGBOX, q=q)[1], ff.energy(t, xm, box=BIGBOX, q=q)[1]
+                fd[i, c] = -sum(pp[k] - pm[k] for k in parts) / (2 * h)
+        assert np.abs(f - fd).max() < 2e-6 * max(1.0, np.abs(fd).max()), mask
+    eng.reax_set(terms=31)
+
+
+def test_condensed_cell_minimum_image(ff, eng):
+    from scema_amd.systems import build_pe
+    d = build_pe(3, 5, 9)                                  # 1620 atoms, 22.2 x 24.65 x 22.8 A: every width >= 2 (10 + skin)
+    x = d["x"] + 0.08 * np.random.default_rng(7).standard_normal(d["x"].shape)
+    sym = ["C" if d["mass"][k] > 5 else "H" for k in d["type"]]
+    eng.reax_configure(FFIELD, qeq_tol=1e-10, skin=1.0)
+    eng.reax_set(exact_gradient=1)
+    r, po = _compare_static(ff, eng, sym, x, d["box"])
+    assert r["image_search"] == 0 and r["maxneigh_seen"] <= r["maxnb"]
+    assert abs(po["tors"]) > 100 and abs(po["over"]) > 100
+
+
+def test_condensed_triclinic_cell_with_images(ff, eng):
+    sym, x, box = _pe_cell(ff, tilt=(3.0, -2.0, 1.5), amp=0.12)      # 20.27 A thick: several images inside the list radius
+    r, _ = _compare_static(ff, eng, sym, x, box, seed=2)
+    assert r["image_search"] > 0
+
+
+def test_mixture_with_hydrogen_bonds(ff, eng):
+    sym, x, box = _mixture()
+    r, po = _compare_static(ff, eng, sym, x, box, seed=3)
+    assert po["hb"] < -1.0
+
+
+def test_lammps_gradient_switch(ff, eng):
+    """the switch that leaves out one d(SBO)/d(Delta) term of the valence-angle energy (off by default); energies are untouched"""
+    sym, x, box = _pe_cell(ff, amp=0.1)
+    eng.register_replica("m", 1, capi.reax_system(sym, x, box))
+    a = eng.reax_compute("m", 1)
+    eng.reax_set(exact_gradient=0)
+    b = eng.reax_compute("m", 1)
+    assert a["e"] == b["e"] or all(abs(a["e"][k] - b["e"][k]) < 1e-9 * max(1.0, abs(a["e"][k])) for k in a["e"])
+    dev = np.abs(a["f"] - b["f"])
+    assert 0.0 < dev.max() < 0.1 * np.abs(a["f"]).max() and np.median(dev) < 0.01 * np.median(np.abs(a["f"]))
+
+
+def _kinetic(mass_atom, v):
+    return 0.5 * MVV2E * (mass_atom[:, None] * v * v).sum()
+
+
+def test_verlet_step_and_energy_conservation(ff, eng):
+    sym, x, box = _pe_cell(ff, amp=0.02)
+    n = len(sym)
+    rng = np.random.default_rng(0)
+    masses = dict(H=1.008, C=12.011, N=14.007, O=15.999)
+    m = np.array([masses[s] for s in sym])
+    v = rng.standard_normal((n, 3)) * np.sqrt(0.0019872067 * 300.0 / (m[:, None] * MVV2E))
+    v -= (m[:, None] * v).sum(0) / m.sum()
+    eng.register_replica("m", 1, capi.reax_system(sym, x, box, v=v))
+    eng.set_state(0, "m", 1, box, x, v)
+    r0 = eng.reax_compute("m", 1, qp=0)
+    ke = _kinetic(m, v)
+    e0 = sum(r0["e"].values()) + ke
+    # one velocity-Verlet step by hand from the oracle-checked forces
+    dt = 0.1
+    eng.debug_run("m", 1, 1, dt, 300.0, qp=0, nvt=False, use_shake=False)
+    _, x1, v1 = eng.get_state(0, "m", 1)
+    vh = v + 0.5 * dt * FTM2V * r0["f"] / m[:, None]
+    xe = x + dt * vh
+    # the engine wraps into the box when it builds its rows: compare modulo lattice vectors
+    d = x1 - xe
+    lens = box[3:6] - box[:3]
+    d -= np.round(d / lens) * lens
+    assert np.abs(d).max() < 1e-10
+    r1 = eng.reax_compute("m", 1, qp=0)
+    assert np.abs(v1 - (vh + 0.5 * dt * FTM2V * r1["f"] / m[:, None])).max() < 1e-10
+    # energy conservation over 60 fs (measured: -0.05 kcal/mol of 1285 kinetic at this step, -0.58 at 0.2 fs, +0.07 at 0.05 fs;
+    # ReaxFF's energy has small jumps at its bond-order cutoffs, so a hot disordered mixture wanders by +-7 whatever the step)
+    eng.debug_run("m", 1, 599, dt, 300.0, qp=0, nvt=False, use_shake=False)
+    _, x2, v2 = eng.get_state(0, "m", 1)
+    r2 = eng.reax_compute("m", 1, qp=0)
+    e2 = sum(r2["e"].values()) + _kinetic(m, v2)
+    assert abs(e2 - e0) < 1e-3 * ke, (e0, e2, ke)
+    assert abs(_kinetic(m, v2) - ke) > 0.05 * ke          # energy did flow between kinetic and potential
+    # and the configuration reached by the dynamics is still one the oracle agrees on
+    t = ff.types(sym)
+    _, po = ff.energy(t, x2, box=box, q=r2["q"])
+    for k in pr.PARTS:
+        assert abs(r2["e"][k] - po[k]) < 1e-9 * max(1.0, abs(po[k])), k
+    good, worst = _check_dirs(ff, t, x2, box, r2["q"], r2["f"], seed=5)
+    assert good >= 5, worst
+    # with the d(SBO)/d(Delta) term left out the same run gains about 100 kcal/mol: why that switch is off by default
+    eng.set_state(1, "m", 1, box, x, v)
+    eng.reax_set(exact_gradient=0)
+    eng.debug_run("m", 1, 600, dt, 300.0, qp=1, nvt=False, use_shake=False)
+    _, _, v3 = eng.get_state(1, "m", 1)
+    r3 = eng.reax_compute("m", 1, qp=1)
+    assert abs(sum(r3["e"].values()) + _kinetic(m, v3) - e0) > 0.02 * ke
+    eng.reax_set(exact_gradient=1)
+
+
+def test_sampled_pressure_against_the_oracle(ff, eng):
+    """compute pressure + fix ave/time of the sampling run: with a time step so short that nothing moves, the average is the
+    static pressure tensor, (sum m v v + W)/V with W the oracle's strain derivative"""
+    sym, x, box = _mixture(seed=9)
+    n = len(sym)
+    rng = np.random.default_rng(1)
+    masses = dict(H=1.008, C=12.011, N=14.007, O=15.999)
+    m = np.array([masses[s] for s in sym])
+    v = rng.standard_normal((n, 3)) * np.sqrt(0.0019872067 * 300.0 / (m[:, None] * MVV2E))
+    v -= (m[:, None] * v).sum(0) / m.sum()
+    eng.register_replica("m", 1, capi.reax_system(sym, x, box, v=v))
+    eng.set_state(0, "m", 1, box, x, v)
+    pavg = eng.debug_run("m", 1, 10, 1e-6, 300.0, qp=0, nvt=False, use_shake=False, sample=True)
+    t = ff.types(sym)
+    q, _ = ff.qeq(t, x, box=box, tol=1e-10, maxiter=500)
+    w = _oracle_virial(ff, t, x, box, q)
+    ke = MVV2E * np.array([(m * v[:, a] * v[:, b]).sum() for a, b in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))])
+    vol = np.prod(box[3:6] - box[:3])
+    ref = (ke + w) / vol * NKTV2P
+    assert np.abs(pavg - ref).max() < 1e-5 * np.abs(ref).max(), (pavg, ref)
+
+
+def test_strain_batch_with_reax_force_field(ff, tmp_path):
+    """the hot path with md_force_field "reax": configured from scripts_folder/ffield.reax.2 and H C N O as the reference's
+    script does; strained, thermostatted, sampled; the stress is -<P> 101325 of the sampling run; the state it leaves
+    behind is one the oracle agrees on; a second update continues from it"""
+    import shutil
+    scripts = tmp_path / "lammps_scripts_reax"
+    scripts.mkdir()
+    shutil.copy(FFIELD, scripts / "ffield.reax.2")
+    sym, x, box = _mixture(seed=10)
+    n = len(sym)
+    masses = dict(H=1.008, C=12.011, N=14.007, O=15.999)
+    m = np.array([masses[s] for s in sym])
+    v = np.random.default_rng(2).standard_normal((n, 3)) * np.sqrt(0.0019872067 * 300.0 / (m[:, None] * MVV2E))
+    v -= (m[:, None] * v).sum(0) / m.sum()
+    e = capi.Engine()
+    e.register_replica("g0", 1, capi.reax_system(sym, x, box, v=v))
+    lens = box[3:6] - box[:3]
+    strains = [np.array([0.004, -0.001, 0.0, 0.002, 0.0, -0.001]) * lens[[0, 1, 2, 2, 1, 0]], np.array([-0.002, 0.003, 0.001, 0.0, 0.002, 0.0]) * lens[[0, 1, 2, 2, 1, 0]]]
+    def sims(recent):
+        return [capi.make_sim(k, "g0", 1, strains[k], nss=20, dt=0.25, temperature=300.0, strain_rate=1e-3, most_recent=recent[k], force_field="reax",
+                              scripts_folder=str(scripts)) for k in range(2)]
+    out = e.strain_batch(sims([capi.QP_NONE, capi.QP_NONE]))
+    s1 = np.array([list(o.stress) for o in out])
+    assert all(o.stress_updated for o in out) and np.isfinite(s1).all() and np.abs(s1).max() > 1e5
+    assert np.abs(s1[0] - s1[1]).max() > 1e3            # different strains, different stresses
+    st = e.reax_stats()
+    assert st["qeq_solves"] > 0 and st["qeq_tol"] == 1e-6 and 2 <= st["qeq_iters"] / st["qeq_solves"] < 60
+    # the states it left: boxes strained as asked, configurations the oracle agrees on
+    e.reax_set(exact_gradient=1)
+    t = ff.types(sym)
+    for k in range(2):
+        b, xs, vs = e.get_state(k, "g0", 1)
+        eps = strains[k] / lens[[0, 1, 2, 2, 1, 0]]
+        assert np.allclose((b[3:6] - b[:3]) / lens - 1.0, eps[:3], atol=2e-5)
+        r = e.reax_compute("g0", 1, qp=k)
+        _, po = ff.energy(t, xs, box=b, q=r["q"])
+        for name in pr.PARTS:
+            assert abs(r["e"][name] - po[name]) < 1e-9 * max(1.0, abs(po[name])), name
+        good, worst = _check_dirs(ff, t, xs, b, r["q"], r["f"], seed=6 + k)
+        assert good >= 5, worst
+    # determinism of the whole update up to the order of atomic sums, and continuation from the stored states
+    e2 = capi.Engine()
+    e2.register_replica("g0", 1, capi.reax_system(sym, x, box, v=v))
+    s1b = np.array([list(o.stress) for o in e2.strain_batch(sims([capi.QP_NONE, capi.QP_NONE]))])
+    assert np.abs(s1b - s1).max() < 1e-6 * np.abs(s1).max()
+    out2 = e.strain_batch(sims([0, 1]))
+    s2 = np.array([list(o.stress) for o in out2])
+    assert np.isfinite(s2).all() and np.abs(s2 - s1).max() > 1e3
+    # a batch may not mix force fields
+    bad = sims([0, 1])
+    bad[1] = capi.make_sim(1, "g0", 1, strains[1], nss=20, dt=0.25, temperature=300.0, strain_rate=1e-3, most_recent=1, force_field="opls")
+    with pytest.raises(capi.EngineError, match="mixes force fields"):
+        e.strain_batch(bad)
+    e.close()
+    e2.close()

@@ -186,8 +186,8 @@ def test_condensed_polyethylene_cell(ff, drv, tilt):
     w = np.zeros(6)
     pr.lib().rxo_forces_fd(ff.h, len(t), pr._p(np.ascontiguousarray(t, dtype=np.int32)), pr._p(np.ascontiguousarray(x)), pr._p(box), pr._p(q), 1e-5, None, pr._p(w))
     assert np.abs(r["w"] - w).max() < 1e-6 * np.abs(w).max()
-    # USER-REAXC's valence-angle routine leaves out d(SBO)/d(Delta) for atoms with vlpex >= 0: a small, documented departure
-    # from the exact gradient that the product follows by default
+    # the switch that leaves out d(SBO)/d(Delta) for atoms with vlpex >= 0 (a reading of USER-REAXC that cannot be checked
+    # here; off by default): it changes the angle pass only
     rl = lammps(sym, x, box, q=q)
     dev = np.abs(rl["f"] - r["f"]).max()
     assert 0.0 < dev < 0.1 * np.abs(r["f"]).max()
