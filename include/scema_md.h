@@ -266,7 +266,8 @@ int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms,
  * info[6]: longest neighbour row, row capacity, bond-row capacity, CG iterations, image search (0 = minimum image), longest bond row */
 int scema_md_reax_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double *f, double *eparts,
                                 double *virial, double *q, double *info);
-/* out[4]: conjugate-gradient iterations, solves (two systems each), list skin, tolerance */
+/* out[6]: conjugate-gradient iterations, solves (two systems each), list skin, tolerance, solves finished by the single-workgroup
+ * loop, iterations currently issued as batch launches per solve */
 int scema_md_reax_stats(const scema_md_engine *e, double *out);
 
 typedef struct {

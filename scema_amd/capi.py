@@ -408,9 +408,10 @@ class Engine:
                     qeq_iters=int(info[3]), image_search=int(info[4]), maxbonds_seen=int(info[5]))
 
     def reax_stats(self) -> dict:
-        out = np.zeros(4)
+        out = np.zeros(6)
         self._chk(lib().scema_md_reax_stats(self.h, _p(out)))
-        return dict(qeq_iters=int(out[0]), qeq_solves=int(out[1]), skin=out[2], qeq_tol=out[3])
+        return dict(qeq_iters=int(out[0]), qeq_solves=int(out[1]), skin=out[2], qeq_tol=out[3], qeq_slow_solves=int(out[4]),
+                    qeq_launched_iters=int(out[5]))
 
     def profile(self, reset=False) -> dict:
         p = Profile()

@@ -194,6 +194,8 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
     RxHbp &h = P.hbp[(a * RX_MAXT + b) * RX_MAXT + c];
     h.r0_hb = l.v[3]; h.p_hb1 = l.v[4]; h.p_hb2 = l.v[5]; h.p_hb3 = l.v[6];
   }
+  for (int a = 0; a < RX_MAXT * RX_MAXT; a++)
+    P.tbp[a].powgw = (P.tbp[a].gamma_w > 0.0) ? std::pow(1.0 / P.tbp[a].gamma_w, P.gp[28]) : 0.0;
   P.bo_cut = 0.01 * P.gp[29];
   P.swa = P.gp[11];
   P.swb = P.gp[12];

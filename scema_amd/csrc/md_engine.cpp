@@ -137,7 +137,8 @@ struct State {
 
 // work arrays of the ReaxFF path for one batch position (reax/rx_types.h RxView points into these)
 struct RxSlot {
-  int cap_pad = 0, cap_nb = 0, cap_bd = 0;
+  int cap_pad = 0, cap_nb = 0, cap_bd = 0, cap_nbn = 0;
+  DevBuf nbn_cnt, nbn, qpart;
   DevBuf nb_cnt, nb, hval, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
 };
 
@@ -223,7 +224,10 @@ struct scema_md_engine {
   std::vector<RxView> h_rxviews;
   double rx_skin = 1.0, rx_qeq_tol = 1e-6;
   int rx_qeq_maxiter = 200, rx_terms = 31;
-  long long rx_qeq_iters = 0, rx_qeq_solves = 0;
+  long long rx_qeq_iters = 0, rx_qeq_solves = 0, rx_qeq_slow = 0;
+  int rx_qeq_launch_cold = 48;        // the same for the first solves of a run (empty history)
+  int rx_qeq_launch = 32;             // conjugate-gradient iterations issued as batch launches per solve (follows what the last run needed)
+  bool rx_qeq_launch_pinned = false;  // SCEMA_REAX_QEQ_LAUNCH fixes it (0: every solve runs in the single-workgroup loop)
   Comm comm;
   scema::OwnerDirectory dir;   // state key -> owning rank, identical on every rank (host/sim_plan.h)
   scema::SimPlan last_plan;
@@ -2623,6 +2627,7 @@ int scema_md_reax_configure(scema_md_engine *e, const char *ffield_path, const c
   if (qeq_tol > 0.0) e->rx_qeq_tol = qeq_tol;
   if (skin >= 0.0) e->rx_skin = skin;
   if (const char *x = getenv("SCEMA_REAX_SKIN")) e->rx_skin = atof(x);
+  if (const char *x = getenv("SCEMA_REAX_QEQ_LAUNCH")) { e->rx_qeq_launch = e->rx_qeq_launch_cold = std::max(0, atoi(x)); e->rx_qeq_launch_pinned = true; }
   HIPCHK(e->d_rxparams.ensure(sizeof(RxParams)));
   HIPCHK(hipMemcpyAsync(e->d_rxparams.p, &e->rx_host, sizeof(RxParams), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -2709,6 +2714,8 @@ int scema_md_reax_stats(const scema_md_engine *e, double *out) {
   out[1] = (double)e->rx_qeq_solves;
   out[2] = e->rx_skin;
   out[3] = e->rx_qeq_tol;
+  out[4] = (double)e->rx_qeq_slow;
+  out[5] = (double)e->rx_qeq_launch;
   return SCEMA_MD_OK;
 }
 

@@ -8,5 +8,6 @@ struct SimDev;
 void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad);
 // the whole force stage of one step for the first ns replicas: (neighbour rows if the rebuild flag of the step is set,)
 // charge equilibration, bond orders, energy terms, forces into SimDev::f, virial and energies into SimScalars.
+// qeq_launch: conjugate-gradient iterations issued as launches over the batch (replicas that need more finish inside k_rx_qeq_finish)
 // terms: bit 0 bond/lone pair/over/under, 1 angles, 2 torsions, 3 hydrogen bonds, 4 non-bonded (31 = all; parity hook)
-void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int terms);
+void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int qeq_launch, int terms);

@@ -86,8 +86,9 @@ __global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *vi
   const double ih0 = 1.0 / V.h[0], ih1 = 1.0 / V.h[1], ih2 = 1.0 / V.h[2];
   const int m0 = V.mimg[0], m1 = V.mimg[1], m2 = V.mimg[2];
   const bool minimage = (m0 | m1 | m2) == 0;
-  int cnt = 0;
+  int cnt = 0, cntn = 0;
   bool full = false;
+  const double rn2 = V.rnear2;
   for (int j0 = 0; j0 < n; j0 += TPB) {
     __syncthreads();
     const int jl = j0 + threadIdx.x;
@@ -106,27 +107,41 @@ __global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *vi
         dy -= n1 * V.h[1]; dx -= n1 * V.h[5];
         const double n0 = rint(dx * ih0);
         dx -= n0 * V.h[0];
-        if (dx * dx + dy * dy + dz * dz > rl2) continue;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 > rl2) continue;
         if (cnt >= V.maxnb) { full = true; continue; }
         const int code = (2 - (int)n0) + 5 * (2 - (int)n1) + 25 * (2 - (int)n2);
         V.nb[(size_t)cnt * np + i] = j | (code << 24);
         cnt++;
+        if (r2 <= rn2) {
+          if (cntn >= V.maxnbn) { full = true; continue; }
+          V.nbn[(size_t)cntn * np + i] = j | (code << 24);
+          cntn++;
+        }
       } else {
         for (int sz = -m2; sz <= m2; sz++)
           for (int sy = -m1; sy <= m1; sy++)
             for (int sx = -m0; sx <= m0; sx++) {
               if (j == i && sx == 0 && sy == 0 && sz == 0) continue;
               const double ex = dx + sx * V.h[0] + sy * V.h[5] + sz * V.h[4], ey = dy + sy * V.h[1] + sz * V.h[3], ez = dz + sz * V.h[2];
-              if (ex * ex + ey * ey + ez * ez > rl2) continue;
+              const double r2 = ex * ex + ey * ey + ez * ez;
+              if (r2 > rl2) continue;
               if (cnt >= V.maxnb) { full = true; continue; }
-              V.nb[(size_t)cnt * np + i] = j | (((sx + 2) + 5 * (sy + 2) + 25 * (sz + 2)) << 24);
+              const int ent = j | (((sx + 2) + 5 * (sy + 2) + 25 * (sz + 2)) << 24);
+              V.nb[(size_t)cnt * np + i] = ent;
               cnt++;
+              if (r2 <= rn2) {
+                if (cntn >= V.maxnbn) { full = true; continue; }
+                V.nbn[(size_t)cntn * np + i] = ent;
+                cntn++;
+              }
             }
       }
     }
   }
   if (live) {
     V.nb_cnt[i] = cnt;
+    V.nbn_cnt[i] = cntn;
     if (full) atomicOr(V.overflow, 1);
     atomicMax(&S.sc->maxneigh_seen, cnt);
   }
@@ -135,14 +150,206 @@ __global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *vi
 // ------------------------------------------------------------------------------------------------------------------
 // charge equilibration
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_rx_hrow(const SimDev *sims, const RxView *views, const RxParams *P) {
+// Row walks are shared by RX_KS waves: a workgroup owns 64 consecutive atoms (lane = atom), wave w takes the entries
+// k = w, w + RX_KS, ... of their rows and the partial results meet in LDS.  With one lane per atom alone a replica of a few
+// thousand atoms gives the chip a few dozen waves; this gives it RX_KS times as many, each with a short row walk.
+#define RX_KS 8
+#define RX_KT (64 * RX_KS)
+
+__global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
   (void)sims;
-  const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i < V.n) rx_qeq_row(P, &V, i);
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (i < V.n) rx_qeq_row_part(P, &V, i, threadIdx.x >> 6, RX_KS);
 }
 
+// fix qeq/reax: H s = -chi and H t = -1 by Jacobi-preconditioned conjugate gradients from the extrapolated previous solutions
+// (init_matvec: cubic for s, quadratic for t), until sqrt(r.z)/|b| <= tol for each; q = s - (sum s / sum t) t.
+//
+// The iteration runs as launches over all replicas, two per iteration (a conjugate-gradient step has two scalar products that
+// every row needs before it can go on):
+//   k_rx_qeq_sweep   y = H z (the only pass over the matrix: 12 bytes per stored entry, both systems per entry), then row-local
+//                    d = z + beta d,  q = y + beta q  (H d by linearity: only z is ever gathered),  partial sums of d.q
+//   k_rx_qeq_update  alpha = sigma / d.q;  s += alpha d;  r -= alpha q;  z = r / eta;  partial sums of r.z
+// Scalars never sit in one memory word: every workgroup writes its partial sums with plain stores and every workgroup of the
+// NEXT launch folds them in a fixed order (deterministic, no atomics, no fences inside a launch).  The host does not know the
+// iteration count: it issues as many iterations as the previous run needed plus a margin; workgroups of a converged replica
+// leave at once, and k_rx_qeq_finish -- one workgroup per replica -- finishes a replica that needs more with the in-kernel loop,
+// then forms the charges and shifts the history.
+//
+// qpart layout (doubles): [0, 2 NV) and [2 NV, 4 NV): r.z partials of even / odd iterations; [4 NV, 6 NV): b.b partials;
+// [6 NV, 6 NV + 2 NB): d.q partials.  NV = RX_QNV (update workgroups, padded), NB = sweep workgroups = npad / 64.
 #define QEQ_TPB 1024
+#define RX_QEQ_COLD 4   /* solves of a run that count as cold (the extrapolation uses four past solutions) */
+#define QEQ_UT 256
+#define RX_QNV(npad) (((npad) + QEQ_UT - 1) / QEQ_UT)
+
+// fold per-block partial pairs in a fixed order; every lane of the calling wave gets the sums
+__device__ __forceinline__ void qeq_fold(const double *part, int count, double &a, double &b) {
+  double sa = 0.0, sb = 0.0;
+  for (int k = threadIdx.x & 63; k < count; k += 64) { sa += part[2 * k]; sb += part[2 * k + 1]; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { sa += __shfl_xor(sa, m); sb += __shfl_xor(sb, m); }   // butterfly: every lane holds the same sum
+  a = sa;
+  b = sb;
+}
+struct QeqScal { double sig[2], bn[2]; bool run[2]; };
+// scalars of iteration `it` from the partial sums of the launches before it
+__device__ __forceinline__ QeqScal qeq_scalars(const RxView &V, int it, double tol) {
+  const int nv = RX_QNV(V.npad), nvl = (V.n + QEQ_UT - 1) / QEQ_UT;   // slots, slots in use
+  QeqScal Q;
+  qeq_fold(V.qpart + 2 * nv * (it & 1), nvl, Q.sig[0], Q.sig[1]);
+  qeq_fold(V.qpart + 4 * nv, nvl, Q.bn[0], Q.bn[1]);
+  Q.bn[0] = sqrt(Q.bn[0]); Q.bn[1] = sqrt(Q.bn[1]);
+  Q.run[0] = sqrt(Q.sig[0]) / Q.bn[0] > tol;
+  Q.run[1] = sqrt(Q.sig[1]) / Q.bn[1] > tol;
+  return Q;
+}
+
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views) {
+  const RxView V = views[blockIdx.y];
+  const int i = blockIdx.x * QEQ_UT + threadIdx.x;
+  if (i >= V.n) return;
+  const size_t np = V.npad;
+  const double *sh = V.s_hist, *th = V.t_hist;
+  const double s0 = 4.0 * (sh[i] + sh[2 * np + i]) - (6.0 * sh[np + i] + sh[3 * np + i]);
+  const double t0 = 3.0 * (th[i] - th[np + i]) + th[2 * np + i];
+  V.s[i] = s0; V.t[i] = t0;
+  double2 *z = (double2 *)(V.qwork + 6 * np);
+  z[i] = make_double2(s0, t0);
+}
+
+// it < 0: the first product H x0 of the solve (x0 sits in z), stored in q
+__global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, const RxParams *P, double tol, int it) {
+  const RxView V = views[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane, n = V.n;
+  if (blockIdx.x * 64 >= n) return;
+  QeqScal Q;
+  double beta_s = 0.0, beta_t = 0.0;
+  if (it >= 0) {
+    Q = qeq_scalars(V, it, tol);
+    if (!Q.run[0] && !Q.run[1]) return;
+    if (it > 0) {
+      double ps, pt;
+      qeq_fold(V.qpart + 2 * RX_QNV(V.npad) * ((it - 1) & 1), (V.n + QEQ_UT - 1) / QEQ_UT, ps, pt);
+      beta_s = Q.sig[0] / ps; beta_t = Q.sig[1] / pt;
+    }
+  }
+  const size_t np = V.npad;
+  const double2 *z = (const double2 *)(V.qwork + 6 * np);
+  const int cnt = (i < n) ? V.nb_cnt[i] : 0;
+  // wave-uniform trip count, loads predicated: the compiler can keep several entries in flight
+  int cmax = cnt;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) cmax = max(cmax, __shfl_xor(cmax, m));
+  double ys = 0.0, yt = 0.0;
+  const int *nb = V.nb + i;
+  const double *hv = V.hval + i;
+#pragma unroll 4
+  for (int k = wave; k < cmax; k += RX_KS) {
+    const bool on = k < cnt;
+    const size_t o = on ? (size_t)k * np : 0;
+    const int j = on ? (nb[o] & RX_JMASK) : 0;
+    const double h = on ? hv[o] : 0.0;
+    const double2 zj = z[j];
+    ys = fma(h, zj.x, ys);
+    yt = fma(h, zj.y, yt);
+  }
+  __shared__ double s_y[2][RX_KS][64];
+  s_y[0][wave][lane] = ys; s_y[1][wave][lane] = yt;
+  __syncthreads();
+  if (wave != 0) return;
+  double dq_s = 0.0, dq_t = 0.0;
+  if (i < n) {
+    ys = 0.0; yt = 0.0;
+#pragma unroll
+    for (int w = 0; w < RX_KS; w++) { ys += s_y[0][w][lane]; yt += s_y[1][w][lane]; }
+    const double eta = P->sbp[V.rtype[i]].eta;
+    const double2 zi = z[i];
+    ys = fma(eta, zi.x, ys); yt = fma(eta, zi.y, yt);
+    double2 *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np);
+    if (it < 0) {
+      q[i] = make_double2(ys, yt);
+    } else {
+      double2 di = d[i], qi = q[i];
+      if (Q.run[0]) { di.x = fma(beta_s, di.x, zi.x); qi.x = fma(beta_s, qi.x, ys); dq_s = di.x * qi.x; }
+      if (Q.run[1]) { di.y = fma(beta_t, di.y, zi.y); qi.y = fma(beta_t, qi.y, yt); dq_t = di.y * qi.y; }
+      d[i] = di; q[i] = qi;
+    }
+  }
+  if (it >= 0) {
+    dq_s = wave_sum(dq_s); dq_t = wave_sum(dq_t);
+    if (lane == 0) {
+      double *pb = V.qpart + 6 * RX_QNV(V.npad) + 2 * blockIdx.x;
+      pb[0] = dq_s; pb[1] = dq_t;
+    }
+  }
+}
+
+// it < 0: r = b - H x0, z = r / eta, d = q = 0, partial sums of r.z (slot of iteration 0) and b.b
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, const RxParams *P, double tol, int it) {
+  const RxView V = views[blockIdx.y];
+  const int i = blockIdx.x * QEQ_UT + threadIdx.x, n = V.n;
+  if (blockIdx.x * QEQ_UT >= n) return;
+  const size_t np = V.npad;
+  const int nv = RX_QNV(V.npad);
+  double2 *r = (double2 *)V.qwork, *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np), *z = (double2 *)(V.qwork + 6 * np);
+  __shared__ double s_red[4][QEQ_UT / 64];
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+  if (it < 0) {
+    if (i < n) {
+      const int ti = V.rtype[i];
+      const double eta = P->sbp[ti].eta, chi = P->sbp[ti].chi;
+      const double2 y = q[i];
+      const double r1 = -chi - y.x, r2 = -1.0 - y.y;
+      const double z1 = r1 / eta, z2 = r2 / eta;
+      r[i] = make_double2(r1, r2);
+      z[i] = make_double2(z1, z2);
+      d[i] = make_double2(0.0, 0.0);
+      q[i] = make_double2(0.0, 0.0);
+      p0 = r1 * z1; p1 = r2 * z2; p2 = chi * chi; p3 = 1.0;
+    }
+  } else {
+    const QeqScal Q = qeq_scalars(V, it, tol);
+    if (!Q.run[0] && !Q.run[1]) {
+      // converged: the scalar products travel on unchanged, so that every later launch sees the same (converged) state
+      if (threadIdx.x == 0) {
+        const double *pf = V.qpart + 2 * nv * (it & 1) + 2 * blockIdx.x;
+        double *pa = V.qpart + 2 * nv * ((it + 1) & 1) + 2 * blockIdx.x;
+        pa[0] = pf[0]; pa[1] = pf[1];
+      }
+      return;
+    }
+    double dq_s, dq_t;
+    qeq_fold(V.qpart + 6 * nv, (V.n + 63) / 64, dq_s, dq_t);
+    const double al_s = Q.run[0] ? Q.sig[0] / dq_s : 0.0, al_t = Q.run[1] ? Q.sig[1] / dq_t : 0.0;
+    if (i < n) {
+      const double eta = P->sbp[V.rtype[i]].eta;
+      const double2 di = d[i], qi = q[i];
+      double2 ri = r[i], zi = z[i];
+      // a converged system keeps r, z and with them its scalar product: it stays converged
+      if (Q.run[0]) { V.s[i] = fma(al_s, di.x, V.s[i]); ri.x = fma(-al_s, qi.x, ri.x); zi.x = ri.x / eta; }
+      if (Q.run[1]) { V.t[i] = fma(al_t, di.y, V.t[i]); ri.y = fma(-al_t, qi.y, ri.y); zi.y = ri.y / eta; }
+      r[i] = ri; z[i] = zi;
+      p0 = ri.x * zi.x; p1 = ri.y * zi.y;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) V.qstat[0] += 1;
+  }
+  p0 = wave_sum(p0); p1 = wave_sum(p1);
+  if (it < 0) { p2 = wave_sum(p2); p3 = wave_sum(p3); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_red[0][wave] = p0; s_red[1][wave] = p1; s_red[2][wave] = p2; s_red[3][wave] = p3; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int w = 0; w < QEQ_UT / 64; w++) { a0 += s_red[0][w]; a1 += s_red[1][w]; a2 += s_red[2][w]; a3 += s_red[3][w]; }
+    double *pa = V.qpart + 2 * nv * ((it < 0) ? 0 : ((it + 1) & 1)) + 2 * blockIdx.x;
+    pa[0] = a0; pa[1] = a1;
+    if (it < 0) { double *pc = V.qpart + 4 * nv + 2 * blockIdx.x; pc[0] = a2; pc[1] = a3; }
+  }
+}
+
 __device__ __forceinline__ void qeq_reduce2(double &a, double &b, double *lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   a = wave_sum(a);
@@ -156,94 +363,61 @@ __device__ __forceinline__ void qeq_reduce2(double &a, double &b, double *lds) {
   a = sa;
   b = sb;
 }
-// fix qeq/reax: H s = -chi and H t = -1 by Jacobi-preconditioned conjugate gradients from the extrapolated previous solutions
-// (init_matvec: cubic for s, quadratic for t), until sqrt(r.p)/|b| <= tol for each; q = s - (sum s / sum t) t.
-// work: [8][npad] doubles per replica (r, d, Hd, for both systems + spare)
-__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq(const SimDev *sims, const RxView *views, const RxParams *P, double tol, int maxiter) {
+// One workgroup per replica after `done` iterations of the launches above: a replica that has not converged yet goes on here
+// with the same recurrences on the same arrays (the result does not depend on how many iterations were issued as launches, only
+// the summation order of the scalar products differs), then q = s - (sum s / sum t) t and the history.
+__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, const RxView *views, const RxParams *P, double tol, int done, int maxiter) {
   const RxView V = views[blockIdx.x];
   (void)sims;
   __shared__ double s_red[32];
-  const int n = V.n, np = V.npad, tid = threadIdx.x;
+  const int n = V.n, tid = threadIdx.x;
+  const size_t np = V.npad;
   double *s = V.s, *t = V.t;
-  double *rs = V.qwork, *rt = V.qwork + np, *ds = V.qwork + 2 * (size_t)np, *dt = V.qwork + 3 * (size_t)np;
-  // initial guesses
-  for (int i = tid; i < n; i += QEQ_TPB) {
-    const double *sh = V.s_hist, *th = V.t_hist;
-    s[i] = 4.0 * (sh[i] + sh[2 * (size_t)np + i]) - (6.0 * sh[(size_t)np + i] + sh[3 * (size_t)np + i]);
-    t[i] = 3.0 * (th[i] - th[(size_t)np + i]) + th[2 * (size_t)np + i];
-  }
-  __syncthreads();
-  double bs2 = 0.0, bt2 = 0.0, sig_s = 0.0, sig_t = 0.0;
-  for (int i = tid; i < n; i += QEQ_TPB) {
-    const int ti = V.rtype[i];
-    const double eta = P->sbp[ti].eta, chi = P->sbp[ti].chi;
-    double ys = eta * s[i], yt = eta * t[i];
-    const int cnt = V.nb_cnt[i];
-    for (int k = 0; k < cnt; k++) {
-      const size_t o = (size_t)k * np + i;
-      const int j = V.nb[o] & RX_JMASK;
-      const double hv = V.hval[o];
-      ys += hv * s[j];
-      yt += hv * t[j];
-    }
-    const double r1 = -chi - ys, r2 = -1.0 - yt;
-    rs[i] = r1; rt[i] = r2;
-    ds[i] = r1 / eta; dt[i] = r2 / eta;
-    bs2 += chi * chi; bt2 += 1.0;
-    sig_s += r1 * r1 / eta; sig_t += r2 * r2 / eta;
-  }
-  qeq_reduce2(bs2, bt2, s_red);
-  qeq_reduce2(sig_s, sig_t, s_red);
-  const double bn_s = sqrt(bs2), bn_t = sqrt(bt2);
-  bool run_s = sqrt(sig_s) / bn_s > tol, run_t = sqrt(sig_t) / bn_t > tol;
+  const QeqScal Q = qeq_scalars(V, done, tol);
+  bool run_s = Q.run[0], run_t = Q.run[1];
   int it = 0;
-  for (; it < maxiter && (run_s || run_t); it++) {
-    // q = H d for both systems in one sweep over the rows; kept in registers (every thread owns the same rows each sweep)
-    double dq_s = 0.0, dq_t = 0.0;
-    for (int i = tid; i < n; i += QEQ_TPB) {
-      const double eta = P->sbp[V.rtype[i]].eta;
-      double ys = eta * ds[i], yt = eta * dt[i];
-      const int cnt = V.nb_cnt[i];
-      for (int k = 0; k < cnt; k++) {
-        const size_t o = (size_t)k * np + i;
-        const int j = V.nb[o] & RX_JMASK;
-        const double hv = V.hval[o];
-        ys += hv * ds[j];
-        yt += hv * dt[j];
+  if (run_s || run_t) {
+    double2 *r = (double2 *)V.qwork, *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np), *z = (double2 *)(V.qwork + 6 * np);
+    double sig_s = Q.sig[0], sig_t = Q.sig[1], prev_s = 1.0, prev_t = 1.0;
+    if (done > 0) qeq_fold(V.qpart + 2 * RX_QNV(V.npad) * ((done - 1) & 1), (n + QEQ_UT - 1) / QEQ_UT, prev_s, prev_t);
+    for (; done + it < maxiter && (run_s || run_t); it++) {
+      const double be_s = (done + it > 0) ? sig_s / prev_s : 0.0, be_t = (done + it > 0) ? sig_t / prev_t : 0.0;
+      double dq_s = 0.0, dq_t = 0.0;
+      for (int i = tid; i < n; i += QEQ_TPB) {
+        const double eta = P->sbp[V.rtype[i]].eta;
+        const double2 zi = z[i];
+        double ys = 0.0, yt = 0.0;
+        const int cnt = V.nb_cnt[i];
+        for (int k = 0; k < cnt; k++) {
+          const size_t o = (size_t)k * np + i;
+          const double2 zj = z[V.nb[o] & RX_JMASK];
+          const double hv = V.hval[o];
+          ys = fma(hv, zj.x, ys);
+          yt = fma(hv, zj.y, yt);
+        }
+        ys = fma(eta, zi.x, ys); yt = fma(eta, zi.y, yt);
+        double2 di = d[i], qi = q[i];
+        if (run_s) { di.x = fma(be_s, di.x, zi.x); qi.x = fma(be_s, qi.x, ys); dq_s += di.x * qi.x; }
+        if (run_t) { di.y = fma(be_t, di.y, zi.y); qi.y = fma(be_t, qi.y, yt); dq_t += di.y * qi.y; }
+        d[i] = di; q[i] = qi;
       }
-      V.qwork[4 * (size_t)np + i] = ys;
-      V.qwork[5 * (size_t)np + i] = yt;
-      dq_s += ds[i] * ys;
-      dq_t += dt[i] * yt;
-    }
-    qeq_reduce2(dq_s, dq_t, s_red);
-    const double al_s = run_s ? sig_s / dq_s : 0.0, al_t = run_t ? sig_t / dq_t : 0.0;
-    double sn_s = 0.0, sn_t = 0.0;
-    for (int i = tid; i < n; i += QEQ_TPB) {
-      const double eta = P->sbp[V.rtype[i]].eta;
-      if (run_s) {
-        s[i] += al_s * ds[i];
-        const double r1 = rs[i] - al_s * V.qwork[4 * (size_t)np + i];
-        rs[i] = r1;
-        sn_s += r1 * r1 / eta;
+      qeq_reduce2(dq_s, dq_t, s_red);   // its barriers also order the sweep (reads z) before the update (writes z)
+      const double al_s = run_s ? sig_s / dq_s : 0.0, al_t = run_t ? sig_t / dq_t : 0.0;
+      double sn_s = 0.0, sn_t = 0.0;
+      for (int i = tid; i < n; i += QEQ_TPB) {
+        const double eta = P->sbp[V.rtype[i]].eta;
+        const double2 di = d[i], qi = q[i];
+        double2 ri = r[i], zi = z[i];
+        if (run_s) { s[i] = fma(al_s, di.x, s[i]); ri.x = fma(-al_s, qi.x, ri.x); zi.x = ri.x / eta; }
+        if (run_t) { t[i] = fma(al_t, di.y, t[i]); ri.y = fma(-al_t, qi.y, ri.y); zi.y = ri.y / eta; }
+        r[i] = ri; z[i] = zi;
+        sn_s += ri.x * zi.x; sn_t += ri.y * zi.y;
       }
-      if (run_t) {
-        t[i] += al_t * dt[i];
-        const double r2 = rt[i] - al_t * V.qwork[5 * (size_t)np + i];
-        rt[i] = r2;
-        sn_t += r2 * r2 / eta;
-      }
+      qeq_reduce2(sn_s, sn_t, s_red);
+      if (run_s) { prev_s = sig_s; sig_s = sn_s; run_s = sqrt(sig_s) / Q.bn[0] > tol; }
+      if (run_t) { prev_t = sig_t; sig_t = sn_t; run_t = sqrt(sig_t) / Q.bn[1] > tol; }
+      __syncthreads();
     }
-    qeq_reduce2(sn_s, sn_t, s_red);
-    const double be_s = run_s ? sn_s / sig_s : 0.0, be_t = run_t ? sn_t / sig_t : 0.0;
-    for (int i = tid; i < n; i += QEQ_TPB) {
-      const double eta = P->sbp[V.rtype[i]].eta;
-      if (run_s) ds[i] = rs[i] / eta + be_s * ds[i];
-      if (run_t) dt[i] = rt[i] / eta + be_t * dt[i];
-    }
-    if (run_s) { sig_s = sn_s; run_s = sqrt(sig_s) / bn_s > tol; }
-    if (run_t) { sig_t = sn_t; run_t = sqrt(sig_t) / bn_t > tol; }
-    __syncthreads();
   }
   double ss = 0.0, st = 0.0;
   for (int i = tid; i < n; i += QEQ_TPB) { ss += s[i]; st += t[i]; }
@@ -252,12 +426,19 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq(const SimDev *sims, const Rx
   for (int i = tid; i < n; i += QEQ_TPB) {
     V.q[i] = s[i] - u * t[i];
     double *sh = V.s_hist, *th = V.t_hist;
-    sh[3 * (size_t)np + i] = sh[2 * (size_t)np + i]; sh[2 * (size_t)np + i] = sh[(size_t)np + i]; sh[(size_t)np + i] = sh[i]; sh[i] = s[i];
-    th[2 * (size_t)np + i] = th[(size_t)np + i]; th[(size_t)np + i] = th[i]; th[i] = t[i];
+    sh[3 * np + i] = sh[2 * np + i]; sh[2 * np + i] = sh[np + i]; sh[np + i] = sh[i]; sh[i] = s[i];
+    th[2 * np + i] = th[np + i]; th[np + i] = th[i]; th[i] = t[i];
   }
   if (tid == 0) {
-    V.qstat[0] += it;
+    const int total = V.qstat[0] + it;   // k_rx_qeq_update counted the launched iterations this replica took part in
+    V.qstat[0] = total;
     V.qstat[1] += 1;
+    const int mine = total - V.qstat[4];
+    V.qstat[4] = total;
+    // the first solves of a run start from an empty history and take longer: their own record
+    const int rec = (V.qstat[1] <= RX_QEQ_COLD) ? 5 : 2;
+    if (mine > V.qstat[rec]) V.qstat[rec] = mine;
+    if (it > 0) V.qstat[3] += 1;
     if (run_s || run_t) atomicOr(V.overflow, 4);
   }
 }
@@ -278,6 +459,30 @@ __device__ __forceinline__ void rx_flush(double (&e)[RX_NPART], double (&w)[6], 
   }
 }
 
+// the same for a workgroup of NW waves: one set of atomics per workgroup (same-address FP64 atomics serialise at the memory side)
+template <int NW>
+__device__ __forceinline__ void rx_flush_block(double (&e)[RX_NPART], double (&w)[6], const RxView &V, SimScalars &sc, int vpart) {
+  __shared__ double s_fl[NW][RX_NPART + 6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < RX_NPART; k++) {
+    const double s = wave_sum(e[k]);
+    if (lane == 0) s_fl[wave][k] = s;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double s = wave_sum(w[k]);
+    if (lane == 0) s_fl[wave][RX_NPART + k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < RX_NPART + 6) {
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < NW; m++) s += s_fl[m][threadIdx.x];
+    if (s != 0.0) atomicAdd(threadIdx.x < RX_NPART ? &V.eparts[threadIdx.x] : &sc.vir[vpart * 6 + threadIdx.x - RX_NPART], s);
+  }
+}
+
 __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * TPB + threadIdx.x;
@@ -293,7 +498,7 @@ __global__ __launch_bounds__(TPB) void k_rx_corr(const RxView *views, const RxPa
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i < V.n) rx_bonds_corrected(P, &V, i);
 }
-// pass: 0 atom terms, 1 angles, 2 torsions, 3 hydrogen bonds, 4 non-bonded
+// pass: 0 atom terms, 1 angles, 2 torsions, 3 hydrogen bonds (4, non-bonded: k_rx_nonbonded)
 template <int PASS>
 __global__ __launch_bounds__(RX_TPB) void k_rx_terms(const SimDev *sims, const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
@@ -308,9 +513,33 @@ __global__ __launch_bounds__(RX_TPB) void k_rx_terms(const SimDev *sims, const R
     if (PASS == 1) rx_angle_terms(P, &V, i, e, w);
     if (PASS == 2) rx_torsion_terms(P, &V, i, e, w);
     if (PASS == 3) rx_hbond_terms(P, &V, i, e, w);
-    if (PASS == 4) rx_nonbonded(P, &V, i, e, w);
   }
   rx_flush(e, w, V, *sims[blockIdx.y].sc, PASS == 4 ? P_LJ : (PASS == 1 ? P_ANGLE : (PASS == 2 ? P_DIHEDRAL : (PASS == 3 ? P_IMPROPER : P_BOND))));
+}
+// tapered van der Waals + shielded Coulomb over the full neighbour rows, RX_KS waves per row
+__global__ __launch_bounds__(RX_KT) void k_rx_nonbonded(const SimDev *sims, const RxView *views, const RxParams *P) {
+  const RxView V = views[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  double e[RX_NPART], w[6], fi[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < RX_NPART; k++) e[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) w[k] = 0.0;
+  if (i < V.n) rx_nonbonded_part(P, &V, i, wave, RX_KS, fi, e, w);
+  __shared__ double s_f[3][RX_KS][64];
+  s_f[0][wave][lane] = fi[0]; s_f[1][wave][lane] = fi[1]; s_f[2][wave][lane] = fi[2];
+  __syncthreads();
+  if (wave == 0 && i < V.n) {
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < RX_KS; m++) { f0 += s_f[0][m][lane]; f1 += s_f[1][m][lane]; f2 += s_f[2][m][lane]; }
+    atomicAdd(&V.f[3 * i], f0); atomicAdd(&V.f[3 * i + 1], f1); atomicAdd(&V.f[3 * i + 2], f2);
+    const double qi = V.q[i];
+    const int ti = V.rtype[i];
+    e[RX_E_POL] += RX_KCALPMOL_TO_EV * (P->sbp[ti].chi * qi + 0.5 * P->sbp[ti].eta * qi * qi);
+  }
+  rx_flush_block<RX_KS>(e, w, V, *sims[blockIdx.y].sc, P_LJ);
 }
 __global__ __launch_bounds__(TPB) void k_rx_back1(const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
@@ -350,7 +579,7 @@ __global__ __launch_bounds__(TPB) void k_rx_phase_init(const RxView *views) {
     for (int k = 0; k < 4; k++) V.s_hist[(size_t)k * V.npad + i] = 0.0;
     for (int k = 0; k < 3; k++) V.t_hist[(size_t)k * V.npad + i] = 0.0;
   }
-  if (i == 0) { V.qstat[0] = 0; V.qstat[1] = 0; *V.overflow = 0; }
+  if (i == 0) { for (int k = 0; k < 6; k++) V.qstat[k] = 0; *V.overflow = 0; }
 }
 
 static inline dim3 g2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)ns, 1); }
@@ -359,13 +588,22 @@ static inline int cdv(int a, int b) { return (a + b - 1) / b; }
 void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad) {
   hipLaunchKernelGGL(k_rx_phase_init, g2(cdv(maxpad, TPB), ns), dim3(TPB), 0, st, v);
 }
-void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int terms) {
-  const dim3 ga = g2(cdv(maxatoms, TPB), ns), gr = g2(cdv(maxatoms, RX_TPB), ns);
+void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int qeq_launch,
+                     int terms) {
+  const dim3 ga = g2(cdv(maxatoms, TPB), ns), gr = g2(cdv(maxatoms, RX_TPB), ns), gk = g2(cdv(maxatoms, 64), ns), gu = g2(cdv(maxatoms, QEQ_UT), ns);
   hipLaunchKernelGGL(k_rx_prepare, dim3(ns), dim3(64), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_wrap, ga, dim3(TPB), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_neigh, ga, dim3(TPB), 0, st, d, v, rlist);
-  hipLaunchKernelGGL(k_rx_hrow, ga, dim3(TPB), 0, st, d, v, P);
-  hipLaunchKernelGGL(k_rx_qeq, dim3(ns), dim3(QEQ_TPB), 0, st, d, v, P, qeq_tol, qeq_maxiter);
+  hipLaunchKernelGGL(k_rx_hrow, gk, dim3(RX_KT), 0, st, d, v, P);
+  hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v);
+  hipLaunchKernelGGL(k_rx_qeq_sweep, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, -1);
+  hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, -1);
+  const int nlaunch = qeq_launch < qeq_maxiter ? qeq_launch : qeq_maxiter;
+  for (int it = 0; it < nlaunch; it++) {
+    hipLaunchKernelGGL(k_rx_qeq_sweep, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
+    hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, it);
+  }
+  hipLaunchKernelGGL(k_rx_qeq_finish, dim3(ns), dim3(QEQ_TPB), 0, st, d, v, P, qeq_tol, nlaunch, qeq_maxiter);
   hipLaunchKernelGGL(k_rx_bonds, ga, dim3(TPB), 0, st, v, P);
   hipLaunchKernelGGL(k_rx_rev, ga, dim3(TPB), 0, st, v);
   hipLaunchKernelGGL(k_rx_corr, ga, dim3(TPB), 0, st, v, P);
@@ -373,7 +611,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   if (terms & 2) hipLaunchKernelGGL(k_rx_terms<1>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 4) hipLaunchKernelGGL(k_rx_terms<2>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, st, d, v, P);
-  if (terms & 16) hipLaunchKernelGGL(k_rx_terms<4>, gr, dim3(RX_TPB), 0, st, d, v, P);
+  if (terms & 16) hipLaunchKernelGGL(k_rx_nonbonded, gk, dim3(RX_KT), 0, st, d, v, P);
   hipLaunchKernelGGL(k_rx_back1, ga, dim3(TPB), 0, st, v, P);
   hipLaunchKernelGGL(k_rx_back2, ga, dim3(TPB), 0, st, d, v, P);
   hipLaunchKernelGGL(k_rx_finish, dim3(ns), dim3(64), 0, st, d, v);

@@ -93,9 +93,11 @@ RX_FN void rx_bonds_prime(const RxParams *P, const RxView *V, int i) {
   const size_t plane = (size_t)V->maxbd * np;
   int nb = 0;
   double sum = 0.0;
-  const int cnt = V->nb_cnt[i];
+  // the near rows hold the entries of the neighbour rows that can come inside the bond cutoff before the next rebuild, in the same order
+  const int *row = V->nbn ? V->nbn : V->nb;
+  const int cnt = V->nbn ? V->nbn_cnt[i] : V->nb_cnt[i];
   for (int k = 0; k < cnt; k++) {
-    const int e = V->nb[(size_t)k * np + i];
+    const int e = row[(size_t)k * np + i];
     double d[3];
     const int j = rx_partner(V, i, e, d);
     const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
@@ -663,43 +665,55 @@ RX_FN void rx_hbond_terms(const RxParams *P, const RxView *V, int j, double *eng
 // pass 3e: tapered shielded van der Waals and Coulomb of atom i over its full neighbour row (vdW_Coulomb_Energy): the force on
 // i only, half of each pair's energy and virial (the partner's lane does the same pair from its side) + polarisation energy
 // ------------------------------------------------------------------------------------------------------------------
-RX_FN void rx_nonbonded(const RxParams *P, const RxView *V, int i, double *eng, double *vir) {
+// entries k0, k0 + kstep, ... of the row: several waves may share a row; fi = force on i from these entries
+RX_FN void rx_nonbonded_part(const RxParams *P, const RxView *V, int i, int k0, int kstep, double *fi, double *eng, double *vir) {
   const int np = V->npad, ti = V->rtype[i], cnt = V->nb_cnt[i];
   const double p_vdW1 = P->gp[28], p_vdW1i = 1.0 / p_vdW1;
-  const double qi = V->q[i];
+  const double qi = RX_C_ELE * V->q[i];
   const double swb2 = P->swb * P->swb;
-  double fi[3] = {0, 0, 0}, evdw = 0.0, ecoul = 0.0, w[6] = {0, 0, 0, 0, 0, 0};
-  for (int k = 0; k < cnt; k++) {
+  const double xi0 = V->x[3 * i], xi1 = V->x[3 * i + 1], xi2 = V->x[3 * i + 2];
+  double evdw = 0.0, ecoul = 0.0, w[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = k0; k < cnt; k += kstep) {
     const int e = V->nb[(size_t)k * np + i];
-    double d[3];
-    const int j = rx_partner(V, i, e, d);
-    const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const int j = e & RX_JMASK;
+    double sh[3];
+    rx_shift(V, e, sh);
+    const double d0 = V->x[3 * j] - xi0 + sh[0], d1 = V->x[3 * j + 1] - xi1 + sh[1], d2 = V->x[3 * j + 2] - xi2 + sh[2];
+    const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
     if (r2 > swb2) continue;
-    const double r = sqrt(r2);
+    const double r = sqrt(r2), rinv = 1.0 / r;
     const RxTbp *t = &P->tbp[ti * RX_MAXT + V->rtype[j]];
     double dTap;
     const double Tap = rx_taper(P, r, &dTap);
-    const double powr = pow(r, p_vdW1), powg = pow(1.0 / t->gamma_w, p_vdW1);
-    const double fn13 = pow(powr + powg, p_vdW1i);
-    const double ex1 = exp(t->alpha * (1.0 - fn13 / t->r_vdW)), ex2 = exp(0.5 * t->alpha * (1.0 - fn13 / t->r_vdW));
+    // shielded distance fn13 = (r^p + gamma_w^-p)^(1/p); d(fn13)/dr = fn13 / (r^p + gamma_w^-p) * r^(p-1)
+    const double powr = exp(p_vdW1 * log(r));
+    const double sum = powr + t->powgw;
+    const double fn13 = exp(p_vdW1i * log(sum));
+    const double dfn13 = fn13 / sum * powr * rinv;
+    const double ex2 = exp(0.5 * t->alpha * (1.0 - fn13 / t->r_vdW)), ex1 = ex2 * ex2;
     const double e_v = t->D * (ex1 - 2.0 * ex2);
-    const double dfn13 = pow(powr + powg, p_vdW1i - 1.0) * pow(r, p_vdW1 - 1.0);   // d(fn13)/dr
     double dE = dTap * e_v - Tap * t->D * (t->alpha / t->r_vdW) * (ex1 - ex2) * dfn13;
-    evdw += 0.5 * Tap * e_v;
-    const double r3g = r2 * r + t->gamma, c13 = cbrt(r3g);
-    const double qq = RX_C_ELE * qi * V->q[j];
-    ecoul += 0.5 * Tap * qq / c13;
-    dE += qq * (dTap / c13 - Tap * r2 / (r3g * c13));
-    const double s = dE / r;   // dE/dd = s d ; force on i = +s d
-    fi[0] += s * d[0]; fi[1] += s * d[1]; fi[2] += s * d[2];
+    evdw += Tap * e_v;
+    const double r3g = r2 * r + t->gamma, c13i = 1.0 / cbrt(r3g);
+    const double qq = qi * V->q[j];
+    ecoul += Tap * qq * c13i;
+    dE += qq * c13i * (dTap - Tap * r2 / r3g);
+    const double s = dE * rinv;   // dE/dd = s d ; force on i = +s d
+    fi[0] += s * d0; fi[1] += s * d1; fi[2] += s * d2;
     // pair virial d (x) f_j = -s d (x) d, half per end
-    w[0] -= 0.5 * s * d[0] * d[0]; w[1] -= 0.5 * s * d[1] * d[1]; w[2] -= 0.5 * s * d[2] * d[2];
-    w[3] -= 0.5 * s * d[0] * d[1]; w[4] -= 0.5 * s * d[0] * d[2]; w[5] -= 0.5 * s * d[1] * d[2];
+    w[0] += s * d0 * d0; w[1] += s * d1 * d1; w[2] += s * d2 * d2;
+    w[3] += s * d0 * d1; w[4] += s * d0 * d2; w[5] += s * d1 * d2;
   }
-  eng[RX_E_VDW] += evdw;
-  eng[RX_E_COUL] += ecoul;
+  eng[RX_E_VDW] += 0.5 * evdw;
+  eng[RX_E_COUL] += 0.5 * ecoul;
+  for (int m = 0; m < 6; m++) vir[m] -= 0.5 * w[m];
+}
+RX_FN void rx_nonbonded(const RxParams *P, const RxView *V, int i, double *eng, double *vir) {
+  double fi[3] = {0, 0, 0};
+  rx_nonbonded_part(P, V, i, 0, 1, fi, eng, vir);
+  const int ti = V->rtype[i];
+  const double qi = V->q[i];
   eng[RX_E_POL] += RX_KCALPMOL_TO_EV * (P->sbp[ti].chi * qi + 0.5 * P->sbp[ti].eta * qi * qi);
-  for (int m = 0; m < 6; m++) vir[m] += w[m];
   for (int m = 0; m < 3; m++) RX_ATOMIC_ADD(&V->f[3 * i + m], fi[m]);
 }
 
@@ -759,10 +773,10 @@ RX_FN void rx_back_force(const RxParams *P, const RxView *V, int i, double *vir)
 // ------------------------------------------------------------------------------------------------------------------
 // charge equilibration (fix qeq/reax): matrix entries of atom i's row, H_ij = Tap(r) 14.4 / (r^3 + gamma_ij)^(1/3)
 // ------------------------------------------------------------------------------------------------------------------
-RX_FN void rx_qeq_row(const RxParams *P, const RxView *V, int i) {
+RX_FN void rx_qeq_row_part(const RxParams *P, const RxView *V, int i, int k0, int kstep) {
   const int np = V->npad, ti = V->rtype[i], cnt = V->nb_cnt[i];
   const double swb2 = P->swb * P->swb;
-  for (int k = 0; k < cnt; k++) {
+  for (int k = k0; k < cnt; k += kstep) {
     const size_t o = (size_t)k * np + i;
     double d[3];
     const int j = rx_partner(V, i, V->nb[o], d);
@@ -777,6 +791,7 @@ RX_FN void rx_qeq_row(const RxParams *P, const RxView *V, int i) {
     V->hval[o] = hv;
   }
 }
+RX_FN void rx_qeq_row(const RxParams *P, const RxView *V, int i) { rx_qeq_row_part(P, V, i, 0, 1); }
 RX_FN double rx_qeq_matvec_row(const RxParams *P, const RxView *V, int i, const double *x) {
   const int np = V->npad, cnt = V->nb_cnt[i];
   double y = P->sbp[V->rtype[i]].eta * x[i];

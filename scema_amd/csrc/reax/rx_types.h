@@ -39,6 +39,7 @@ typedef struct {
 typedef struct {
   double De_s, De_p, De_pp, p_be1, p_bo5, v13cor, p_bo6, p_ovun1, p_be2, p_bo3, p_bo4, p_bo1, p_bo2, ovc;
   double r_s, r_p, r_pp, p_boc3, p_boc4, p_boc5, D, alpha, r_vdW, gamma_w, gamma;
+  double powgw;           // (1/gamma_w)^p_vdW1: the shielding constant of the van der Waals term (derived by the reader)
 } RxTbp;
 typedef struct { double theta_00, p_val1, p_val2, p_coa1, p_val7, p_pen1, p_val4; } RxThbPrm;
 typedef struct { int cnt, pad_; RxThbPrm prm[RX_MAXANG]; } RxThbp;
@@ -70,6 +71,11 @@ typedef struct {
   // neighbour rows inside the list radius (full: j appears in i's row and i in j's)
   int *nb_cnt;            // [n]
   int *nb;                // [maxnb][npad]
+  // near rows: the entries of nb inside the bond cutoff + skin, same order (the bond-order pass walks these; NULL: walk nb)
+  int *nbn_cnt;           // [n]
+  int *nbn;               // [maxnbn][npad]
+  int maxnbn, pad0_;
+  double rnear2;          // (bond cutoff + skin)^2
   // bond rows: pairs with BO' >= cutoff (full)
   int *bd_cnt;            // [n]
   int *bd;                // [maxbd][npad] atom | image code
@@ -88,8 +94,11 @@ typedef struct {
   double *hval;           // [maxnb][npad] H_ij of the row entries inside the taper radius (0 beyond)
   double *s, *t;          // [npad] the two solutions
   double *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)
-  double *qwork;          // [6][npad] residuals, search directions, matrix-vector products of the two systems
-  int *qstat;             // [2] conjugate-gradient iterations and solves since the start of the run
+  double *qwork;          // [8][npad]: four arrays of (s-system, t-system) pairs per atom: residual r, search direction d,
+                          // matrix-vector product q = H d, preconditioned residual z = r / eta (the vector the matrix sweeps gather)
+  double *qpart;          // per-block partial sums of the solver's scalar products (layout: md_reax.hip)
+  int *qstat;             // [6] since the start of the run: iterations, solves, most iterations in one solve (cold solves aside), solves
+                          // finished by the single-workgroup loop, (scratch), most iterations in one of the run's first (cold) solves
   double *eparts;         // [RX_NPART] energy parts of the step
   int mimg[3];            // neighbour search: 0,0,0 = minimum image (box at least two list radii wide), else images up to mimg[d] boxes away
   int *overflow;          // bit 1: neighbour row full, bit 2: bond row full, bit 4: charge equilibration did not converge

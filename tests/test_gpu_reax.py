@@ -137,6 +137,28 @@ def _kinetic(mass_atom, v):
     return 0.5 * MVV2E * (mass_atom[:, None] * v * v).sum()
 
 
+def test_charges_do_not_depend_on_how_the_solver_is_launched(ff, monkeypatch):
+    """the conjugate-gradient iterations run as launches over the batch, as many as the host issues; the rest, if any, in one
+    workgroup per replica.  Same recurrences either way: no launches at all, too few, and plenty give the same charges."""
+    sym, x, box = _pe_cell(ff, amp=0.1)
+    res = []
+    for launches in ("0", "5", "200"):
+        monkeypatch.setenv("SCEMA_REAX_QEQ_LAUNCH", launches)
+        e = capi.Engine()
+        e.reax_configure(FFIELD, qeq_tol=1e-10)
+        e.register_replica("m", 1, capi.reax_system(sym, x, box))
+        r = e.reax_compute("m", 1)
+        st = e.reax_stats()
+        res.append((r["q"].copy(), r["qeq_iters"], st["qeq_slow_solves"]))
+        e.close()
+    (q0, it0, slow0), (q1, it1, slow1), (q2, it2, slow2) = res
+    assert slow0 == 1 and slow1 == 1 and slow2 == 0
+    # the scalar products are summed in another order in the two forms: a solve may stop one iteration apart at the tolerance
+    assert max(it0, it1, it2) - min(it0, it1, it2) <= 2 and it0 > 5
+    assert np.abs(q1 - q0).max() < 1e-9 and np.abs(q2 - q0).max() < 1e-9
+    assert np.abs(q0).max() > 0.05
+
+
 def test_verlet_step_and_energy_conservation(ff, eng):
     sym, x, box = _pe_cell(ff, amp=0.02)
     n = len(sym)
