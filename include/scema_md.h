@@ -97,9 +97,14 @@ const char *scema_md_last_error(const scema_md_engine *e);
 
 /* ---- replica registry: replaces "read_restart init.<mat>_<rep>.bin" (stmd_problem.h:204) ---- */
 int scema_md_register_replica(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_system *sys);
+/* atoms of a registered replica, 0 if (matid, replica) is not registered */
+int32_t scema_md_replica_natoms(scema_md_engine *e, const char *matid, int32_t replica);
 /* reads a replica file written by scema_md_write_replica_file (our container for init.*.bin) */
 int scema_md_load_replica_file(scema_md_engine *e, const char *matid, int32_t replica, const char *path);
 int scema_md_write_replica_file(const char *path, const scema_md_system *sys);
+/* a registered replica with its current initial state (e.g. after scema_md_equilibrate) as such a file: what
+ * `write_restart init.<mat>_<rep>.bin` keeps in the reference (init_material_problem.h:208-210) */
+int scema_md_save_replica_file(scema_md_engine *e, const char *matid, int32_t replica, const char *path);
 /* LAMMPS text data file of atom_style full (`write_data` of a replica equilibrated with the reference's
  * in.init.lammps): register it directly, or convert it to the replica container.  special_bonds weights are
  * not stored in data files; NULL means the reference's "lj/coul 0 0 1" (in.init.lammps:31). */
@@ -234,7 +239,32 @@ typedef struct {
 int scema_md_init_material(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_eqparams *p,
                            double length[3], double stress[6], double stiff[36]);
 
+/* ---- init_material, first part: the equilibration schedule EQMDProblem::lammps_equilibration runs when no state exists yet
+ * (init_material_problem.h:167-174: in.init.lammps).  What lammps_scripts_opls/in.init.lammps:44-215 prescribes, on the GPU:
+ * velocity create 200 K, min_style sd + minimize 1e-7 1e-11 nsinit 50000, then fix nvt 300 K (nsinit steps), fix npt iso 1 atm
+ * 300->500 K (nsinit), 500 K (5 nsinit), 500->T (nsinit), T (2 nsinit, box lengths averaged, change_box to the averages), fix nvt
+ * T (20 nsinit), fix npt T (2 nsinit, averaged, change_box), fix nvt T (nsinit); no SHAKE (commented out in the script).
+ * The equilibrated state replaces the registered initial state of the replica (what write_restart init.<mat>_<rep>.bin
+ * keeps, :208-210); length[3] = its box lengths (:196-208).  info (may be NULL) [5]: minimiser stop reason (0 energy
+ * tolerance, 1 force tolerance, 2 iterations, 3 evaluations, 4 line search), iterations, force evaluations, initial and final
+ * potential energy.  LAMMPS' random stream of `velocity create` is not reproduced (own generator, same seed semantics). */
+typedef struct {
+  int32_t nsteps_equil;    /* nsinit = "molecular dynamics parameters.number of equilibration steps" (init_material.cc:177) */
+  double timestep_length;  /* fs */
+  double temperature;      /* K, tempt */
+  int64_t seed;            /* sseed; 0 = 1234 (init_material_problem.h:167) */
+} scema_md_equilparams;
+int scema_md_equilibrate(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_equilparams *p, double length[3],
+                         double *info);
+
 /* ---- parity / measurement hooks ---- */
+/* min_style sd + minimize on a stored state; info[5] as in scema_md_equilibrate */
+int scema_md_debug_minimize(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double etol, double ftol,
+                            int32_t maxiter, int32_t maxeval, double *info);
+/* one run under fix nvt (npt 0) or fix npt ... iso (npt 1) with the target ramped t_start -> t_stop, no SHAKE; lavg (may be
+ * NULL) [3]: running average of the box lengths over the two half-run windows */
+int scema_md_debug_run_nh(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t nsteps, double dt,
+                          double t_start, double t_stop, int32_t npt, double p_target, double p_period, double *lavg);
 /* Static evaluation at the stored state of (qp,mat,rep) (qp_id = SCEMA_MD_QP_NONE: the registered
  * init state): forces [natoms*3], energies[SCEMA_MD_NPART], virials[SCEMA_MD_NPART*6] (kcal/mol). */
 int scema_md_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t use_shake,

@@ -94,6 +94,15 @@ int scema_eqmd_equil(scema_md_engine *engine, const char *cmat, const char *leng
                      int32_t rep, double mdts, double mdtem, int32_t mdnss, double mdss, double mdsa, const char *mdff, char *errbuf,
                      int32_t errlen);
 
+/* EQMDProblem<3>::equil with the reference's whole argument list (init_material_problem.h:309-315): when systof
+ * (init.<mat>_<rep>.bin) does not exist yet, the replica is read from <slocin>/<cmat>_<rep>.data (unless it is registered
+ * already), equilibrated by the schedule of in.init.lammps on the GPU (scema_md_equilibrate; mdnse = nsinit) and written to
+ * systof; then as scema_eqmd_equil.  qplogloc / scrloc (LAMMPS log and script folders) are accepted and unused. */
+int scema_eqmd_equil_full(scema_md_engine *engine, const char *cmat, const char *slocin, const char *qplogloc, const char *scrloc,
+                          const char *lengthof, const char *stressof, const char *stiffof, const char *systof, int32_t rep, double mdts,
+                          double mdtem, int32_t mdnss, int32_t mdnse, double mdss, double mdsa, const char *mdff, char *errbuf,
+                          int32_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1488,3 +1488,414 @@ int omd_eval(omd_sim *s, const double strain_len[6], double timestep_length, dou
   s->timing[3] = tot - s->timing[0] - s->timing[1] - s->timing[2];
   return nts;
 }
+
+/* ================================================================== init_material: equilibration schedule
+ * What lammps_scripts_opls/in.init.lammps asks LAMMPS for, restated [LAMMPS-ext, from the documented behaviour of
+ * 17Nov16's min_sd.cpp / min_linesearch.cpp / fix_nh.cpp; PARITY UNPINNED like the rest of this file]:
+ *   :48      velocity all create 200.0 ${sseed} rot yes dist gaussian      -> omd_velocity_create (own generator, see there)
+ *   :54-58   min_style sd ; minimize 1.0e-7 1.0e-11 ${nsi} 50000          -> omd_minimize
+ *   :105-215 fix nvt / fix npt temp T0 T1 100.0 iso 1.0 1.0 1000 ; run N   -> omd_run_nh (no SHAKE: the script's fix shake is
+ *            commented out), box-length averages over the second half of an NPT run (fix ave/time 1 nav nav ... ave running)
+ *            followed by change_box all x final 0 <lx> ... remap               -> omd_equilibrate */
+
+/* potential energy of the last force evaluation */
+static double pe_total(const omd_sim *s) {
+  double e = 0.0;
+  for (int k = 0; k < OMD_NPART; k++) e += s->eng[k];
+  return e;
+}
+/* energy_force() of a minimiser: reneighbour if needed (results do not depend on when), forces, energy */
+static double min_energy_force(omd_sim *s) {
+  s->ago++;
+  if (neigh_check(s)) neigh_build(s);
+  force_compute(s);
+  return pe_total(s);
+}
+
+/* min_style sd with the default line search (quadratic, dmax 0.1), thermo_modify norm no (units real).
+ * Stops: 0 energy tolerance, 1 force tolerance, 2 max iterations, 3 max force evaluations, 4 line search could not go on
+ * (search direction not downhill / zero force / alpha backtracked to zero / zero quadratic).  info[4]: iterations, force
+ * evaluations, initial and final potential energy. */
+int omd_minimize(omd_sim *s, double etol, double ftol, int maxiter, int maxeval, double *info) {
+  const double ALPHA_MAX = 1.0, ALPHA_REDUCE = 0.5, BACKTRACK_SLOPE = 0.4, QUADRATIC_TOL = 0.1, EMACH = 1.0e-8, EPS_QUAD = 1.0e-28,
+               EPS_ENERGY = 1.0e-8, DMAX = 0.1;
+  const int n3 = 3 * s->n;
+  omd_setup(s, 0);
+  force_compute(s);
+  double ecurrent = pe_total(s);
+  const double einitial = ecurrent;
+  double *h = (double *)xcalloc((size_t)n3, sizeof(double)), *x0 = (double *)xcalloc((size_t)n3, sizeof(double));
+  memcpy(h, s->f, (size_t)n3 * sizeof(double));
+  int neval = 0, iter = 0, stop = 2;
+  for (; iter < maxiter;) {
+    iter++;
+    const double eprevious = ecurrent, eoriginal = ecurrent;
+    int fail = 0;
+    {
+      /* linemin_quadratic */
+      double fdothall = 0.0, hmaxall = 0.0;
+      for (int i = 0; i < n3; i++) {
+        fdothall += s->f[i] * h[i];
+        hmaxall = fmax(hmaxall, fabs(h[i]));
+      }
+      if (fdothall <= 0.0) fail = 1;
+      else if (hmaxall == 0.0) fail = 1;
+      else {
+        const double alphamax = fmin(ALPHA_MAX, DMAX / hmaxall);
+        memcpy(x0, s->x, (size_t)n3 * sizeof(double));
+        double alpha = alphamax, fhprev = fdothall, engprev = eoriginal, alphaprev = 0.0;
+        for (;;) {
+          for (int i = 0; i < n3; i++) s->x[i] = x0[i] + alpha * h[i];
+          ecurrent = min_energy_force(s);
+          neval++;
+          double fh = 0.0;
+          for (int i = 0; i < n3; i++) fh += s->f[i] * h[i];
+          const double delfh = fh - fhprev;
+          if (fabs(fh) < EPS_QUAD || fabs(delfh) < EPS_QUAD) {
+            memcpy(s->x, x0, (size_t)n3 * sizeof(double));
+            ecurrent = min_energy_force(s);
+            fail = 1;
+            break;
+          }
+          const double relerr = fabs(1.0 - (0.5 * (alpha - alphaprev) * (fh + fhprev) + ecurrent) / engprev);
+          const double alpha0 = alpha - (alpha - alphaprev) * fh / delfh;
+          if (relerr <= QUADRATIC_TOL && alpha0 > 0.0 && alpha0 < alphamax) {
+            for (int i = 0; i < n3; i++) s->x[i] = x0[i] + alpha0 * h[i];
+            ecurrent = min_energy_force(s);
+            neval++;
+            if (ecurrent - eoriginal < EMACH) break;
+          }
+          const double de_ideal = -BACKTRACK_SLOPE * alpha * fdothall, de = ecurrent - eoriginal;
+          if (de <= de_ideal) break;
+          fhprev = fh;
+          engprev = ecurrent;
+          alphaprev = alpha;
+          alpha *= ALPHA_REDUCE;
+          if (alpha <= 0.0 || de_ideal >= -EMACH) {
+            memcpy(s->x, x0, (size_t)n3 * sizeof(double));
+            ecurrent = min_energy_force(s);
+            fail = 1;
+            break;
+          }
+        }
+      }
+    }
+    if (fail) { stop = 4; break; }
+    if (neval >= maxeval) { stop = 3; break; }
+    if (fabs(ecurrent - eprevious) < etol * 0.5 * (fabs(ecurrent) + fabs(eprevious) + EPS_ENERGY)) { stop = 0; break; }
+    double fdotf = 0.0;
+    for (int i = 0; i < n3; i++) fdotf += s->f[i] * s->f[i];
+    if (fdotf < ftol * ftol) { stop = 1; break; }
+    memcpy(h, s->f, (size_t)n3 * sizeof(double));
+  }
+  if (info) {
+    info[0] = iter;
+    info[1] = neval;
+    info[2] = einitial;
+    info[3] = ecurrent;
+  }
+  free(h);
+  free(x0);
+  return stop;
+}
+
+/* velocity all create T seed rot yes dist gaussian: Gaussian velocities scaled by 1/sqrt(m), zero linear and angular momentum,
+ * rescaled to exactly T with 3N-3 degrees of freedom.  LAMMPS draws from its own Park-Miller/Marsaglia streams in atom-id
+ * order (loop all); that stream is not reproduced -- any seed gives an equally valid ensemble member and the 10^5..10^6 steps
+ * that follow forget it -- so the generator here is a 64-bit SplitMix + Box-Muller, the same in the engine (host side). */
+static unsigned long long splitmix64(unsigned long long *st) {
+  unsigned long long z = (*st += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+void omd_velocity_create(omd_sim *s, double temperature, unsigned long long seed) {
+  const int n = s->n;
+  unsigned long long st = seed;
+  for (int i = 0; i < n; i++) {
+    const double m = s->mass[s->type[i]];
+    for (int k = 0; k < 3; k += 1) {
+      double u1 = ((double)(splitmix64(&st) >> 11) + 0.5) / 9007199254740992.0, u2 = ((double)(splitmix64(&st) >> 11) + 0.5) / 9007199254740992.0;
+      s->v[3 * i + k] = sqrt(-2.0 * log(u1)) * cos(2.0 * MY_PI * u2) / sqrt(m);
+    }
+  }
+  /* zero linear momentum */
+  double p[3] = {0, 0, 0}, mt = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double m = s->mass[s->type[i]];
+    mt += m;
+    for (int k = 0; k < 3; k++) p[k] += m * s->v[3 * i + k];
+  }
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) s->v[3 * i + k] -= p[k] / mt;
+  /* zero angular momentum about the centre of mass (unwrapped coordinates): v -= omega x r, I omega = L */
+  double cm[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    const double m = s->mass[s->type[i]];
+    for (int k = 0; k < 3; k++) cm[k] += m * s->x[3 * i + k] / mt;
+  }
+  double L[3] = {0, 0, 0}, I[3][3] = {{0}};
+  for (int i = 0; i < n; i++) {
+    const double m = s->mass[s->type[i]];
+    const double r[3] = {s->x[3 * i] - cm[0], s->x[3 * i + 1] - cm[1], s->x[3 * i + 2] - cm[2]};
+    const double *v = s->v + 3 * i;
+    L[0] += m * (r[1] * v[2] - r[2] * v[1]);
+    L[1] += m * (r[2] * v[0] - r[0] * v[2]);
+    L[2] += m * (r[0] * v[1] - r[1] * v[0]);
+    const double r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) I[a][b] += m * ((a == b ? r2 : 0.0) - r[a] * r[b]);
+  }
+  {
+    const double det = I[0][0] * (I[1][1] * I[2][2] - I[1][2] * I[2][1]) - I[0][1] * (I[1][0] * I[2][2] - I[1][2] * I[2][0]) +
+                       I[0][2] * (I[1][0] * I[2][1] - I[1][1] * I[2][0]);
+    double inv[3][3];
+    inv[0][0] = (I[1][1] * I[2][2] - I[1][2] * I[2][1]) / det; inv[0][1] = (I[0][2] * I[2][1] - I[0][1] * I[2][2]) / det; inv[0][2] = (I[0][1] * I[1][2] - I[0][2] * I[1][1]) / det;
+    inv[1][0] = (I[1][2] * I[2][0] - I[1][0] * I[2][2]) / det; inv[1][1] = (I[0][0] * I[2][2] - I[0][2] * I[2][0]) / det; inv[1][2] = (I[0][2] * I[1][0] - I[0][0] * I[1][2]) / det;
+    inv[2][0] = (I[1][0] * I[2][1] - I[1][1] * I[2][0]) / det; inv[2][1] = (I[0][1] * I[2][0] - I[0][0] * I[2][1]) / det; inv[2][2] = (I[0][0] * I[1][1] - I[0][1] * I[1][0]) / det;
+    double w[3];
+    for (int a = 0; a < 3; a++) w[a] = inv[a][0] * L[0] + inv[a][1] * L[1] + inv[a][2] * L[2];
+    for (int i = 0; i < n; i++) {
+      const double r[3] = {s->x[3 * i] - cm[0], s->x[3 * i + 1] - cm[1], s->x[3 * i + 2] - cm[2]};
+      s->v[3 * i] -= w[1] * r[2] - w[2] * r[1];
+      s->v[3 * i + 1] -= w[2] * r[0] - w[0] * r[2];
+      s->v[3 * i + 2] -= w[0] * r[1] - w[1] * r[0];
+    }
+  }
+  s->tdof = 3.0 * n - 3.0;
+  const double t = omd_temperature(s, NULL);
+  const double sc = sqrt(temperature / t);
+  for (int i = 0; i < 3 * n; i++) s->v[i] *= sc;
+}
+
+/* change_box all x final 0 lx y final 0 ly z final 0 lz remap (tilts kept): affine remap of the atoms into the new box */
+void omd_change_box(omd_sim *s, const double len[3]) {
+  boxq bo, bn;
+  box_derive(s, &bo);
+  for (int d = 0; d < 3; d++) {
+    s->lo[d] = 0.0;
+    s->hi[d] = len[d];
+  }
+  box_derive(s, &bn);
+  for (int i = 0; i < s->n; i++) {
+    double d0 = s->x[3 * i] - bo.lo[0], d1 = s->x[3 * i + 1] - bo.lo[1], d2 = s->x[3 * i + 2] - bo.lo[2];
+    double l0 = bo.hinv[0] * d0 + bo.hinv[5] * d1 + bo.hinv[4] * d2, l1 = bo.hinv[1] * d1 + bo.hinv[3] * d2, l2 = bo.hinv[2] * d2;
+    s->x[3 * i] = bn.h[0] * l0 + bn.h[5] * l1 + bn.h[4] * l2 + bn.lo[0];
+    s->x[3 * i + 1] = bn.h[1] * l1 + bn.h[3] * l2 + bn.lo[1];
+    s->x[3 * i + 2] = bn.h[2] * l2 + bn.lo[2];
+  }
+}
+
+/* barostat of fix npt ... iso p p pperiod (pchain 3, mtk yes, drag 0, nreset 0; tilt factors scale with their box lengths) */
+typedef struct {
+  double omega_dot, omega_mass, etap[MAXCHAIN + 1], etap_dot[MAXCHAIN + 1], etap_dotdot[MAXCHAIN + 1], etap_mass[MAXCHAIN + 1];
+  double p_freq, p_target, mtk_term2;
+  int mp;
+} baro;
+
+static double pressure_scalar(const omd_sim *s, double t_current) {
+  boxq b;
+  box_derive(s, &b);
+  double w = 0.0;
+  for (int part = 0; part < OMD_NPART; part++) w += s->vir[part * 6] + s->vir[part * 6 + 1] + s->vir[part * 6 + 2];
+  return (s->tdof * BOLTZ * t_current + w) / (3.0 * b.vol) * NKTV2P;
+}
+static void nhc_press_integrate(baro *B, double dt, double t_target) {
+  const double kt = BOLTZ * t_target, dthalf = 0.5 * dt, dt4 = 0.25 * dt, dt8 = 0.125 * dt;
+  const int mp = B->mp;
+  /* iso: the three box dimensions carry the same omega_dot, each with its own mass term */
+  double kecurrent = 3.0 * B->omega_mass * B->omega_dot * B->omega_dot;
+  const double lkt_press = kt;
+  B->etap_dotdot[0] = (kecurrent - lkt_press) / B->etap_mass[0];
+  double expfac;
+  for (int k = mp - 1; k > 0; k--) {
+    expfac = exp(-dt8 * B->etap_dot[k + 1]);
+    B->etap_dot[k] *= expfac;
+    B->etap_dot[k] += B->etap_dotdot[k] * dt4;
+    B->etap_dot[k] *= expfac;
+  }
+  expfac = exp(-dt8 * B->etap_dot[1]);
+  B->etap_dot[0] *= expfac;
+  B->etap_dot[0] += B->etap_dotdot[0] * dt4;
+  B->etap_dot[0] *= expfac;
+  for (int k = 0; k < mp; k++) B->etap[k] += dthalf * B->etap_dot[k];
+  B->omega_dot *= exp(-dthalf * B->etap_dot[0]);
+  kecurrent = 3.0 * B->omega_mass * B->omega_dot * B->omega_dot;
+  B->etap_dotdot[0] = (kecurrent - lkt_press) / B->etap_mass[0];
+  B->etap_dot[0] *= expfac;
+  B->etap_dot[0] += B->etap_dotdot[0] * dt4;
+  B->etap_dot[0] *= expfac;
+  for (int k = 1; k < mp; k++) {
+    expfac = exp(-dt8 * B->etap_dot[k + 1]);
+    B->etap_dot[k] *= expfac;
+    B->etap_dotdot[k] = (B->etap_mass[k - 1] * B->etap_dot[k - 1] * B->etap_dot[k - 1] - kt) / B->etap_mass[k];
+    B->etap_dot[k] += B->etap_dotdot[k] * dt4;
+    B->etap_dot[k] *= expfac;
+  }
+}
+static void nh_omega_dot(const omd_sim *s, baro *B, double dt, double p_current, double t_current) {
+  boxq b;
+  box_derive(s, &b);
+  const double mtk_term1 = s->tdof * BOLTZ * t_current / (3.0 * s->n);
+  const double f_omega = (p_current - B->p_target) * b.vol / (B->omega_mass * NKTV2P) + mtk_term1 / B->omega_mass;
+  B->omega_dot += f_omega * 0.5 * dt;
+  B->mtk_term2 = 3.0 * B->omega_dot / (3.0 * s->n);
+}
+static void nh_v_press(omd_sim *s, const baro *B, double dt) {
+  const double factor = exp(-0.25 * dt * (B->omega_dot + B->mtk_term2));
+  for (int i = 0; i < 3 * s->n; i++) {
+    s->v[i] *= factor;
+    s->v[i] *= factor;
+  }
+}
+/* half-step dilation about the box centre; xy scales with ly, xz and yz with lz (scalexy/scalexz/scaleyz yes) */
+static void nh_remap(omd_sim *s, const baro *B, double dt) {
+  boxq bo, bn;
+  box_derive(s, &bo);
+  const double expfac = exp(0.5 * dt * B->omega_dot);
+  for (int d = 0; d < 3; d++) {
+    const double c = 0.5 * (s->lo[d] + s->hi[d]);
+    const double lo = s->lo[d], hi = s->hi[d];
+    s->lo[d] = (lo - c) * expfac + c;
+    s->hi[d] = (hi - c) * expfac + c;
+  }
+  s->xy *= expfac;
+  s->xz *= expfac;
+  s->yz *= expfac;
+  box_derive(s, &bn);
+  for (int i = 0; i < s->n; i++) {
+    double d0 = s->x[3 * i] - bo.lo[0], d1 = s->x[3 * i + 1] - bo.lo[1], d2 = s->x[3 * i + 2] - bo.lo[2];
+    double l0 = bo.hinv[0] * d0 + bo.hinv[5] * d1 + bo.hinv[4] * d2, l1 = bo.hinv[1] * d1 + bo.hinv[3] * d2, l2 = bo.hinv[2] * d2;
+    s->x[3 * i] = bn.h[0] * l0 + bn.h[5] * l1 + bn.h[4] * l2 + bn.lo[0];
+    s->x[3 * i + 1] = bn.h[1] * l1 + bn.h[3] * l2 + bn.lo[1];
+    s->x[3 * i + 2] = bn.h[2] * l2 + bn.lo[2];
+  }
+}
+
+/* One "run N" under fix nvt (npt = 0) or fix npt ... iso (npt = 1) with a temperature ramp t_start -> t_stop over the run, no
+ * SHAKE, no deform.  lavg != NULL: box lengths averaged like fix ave/time 1 nav nav v_lx v_ly v_lz ave running with
+ * nav = nsteps / 2 (in.init.lammps:150-157: one window, the second half of the run... as the fix defines it: the nav samples
+ * that end at step nav, then those that end at 2 nav; ave running averages the two windows) -> lavg[3].
+ * trace != NULL: per step 6 doubles T, pe, ke, conserved-quantity part of thermostat + barostat, volume, scalar pressure. */
+int omd_run_nh(omd_sim *s, int nsteps, double dt, double t_start, double t_stop, int npt, double p_target, double p_period,
+               double *lavg, double *trace) {
+  const int n = s->n, mt = s->p.t_chain;
+  const double dtv = dt, dtf = 0.5 * dt * FTM2V;
+  omd_setup(s, 0);
+  force_compute(s);
+  for (int k = 0; k <= MAXCHAIN; k++) s->eta[k] = s->eta_dot[k] = s->eta_dotdot[k] = 0.0;
+  s->t_current = omd_temperature(s, NULL);
+  double t_target = t_start;
+  {
+    const double t_freq = 1.0 / s->p.t_period;
+    s->eta_mass[0] = s->tdof * BOLTZ * t_target / (t_freq * t_freq);
+    for (int k = 1; k < mt; k++) s->eta_mass[k] = BOLTZ * t_target / (t_freq * t_freq);
+    for (int k = 1; k < mt; k++)
+      s->eta_dotdot[k] = (s->eta_mass[k - 1] * s->eta_dot[k - 1] * s->eta_dot[k - 1] - BOLTZ * t_target) / s->eta_mass[k];
+  }
+  baro B;
+  memset(&B, 0, sizeof B);
+  double p_current = 0.0;
+  if (npt) {
+    B.mp = 3;
+    B.p_freq = 1.0 / p_period;
+    B.p_target = p_target;
+    const double kt = BOLTZ * t_target;
+    B.omega_mass = (n + 1) * kt / (B.p_freq * B.p_freq);   /* fixed for the run (omega_mass_flag 0) */
+    for (int k = 0; k < B.mp; k++) B.etap_mass[k] = kt / (B.p_freq * B.p_freq);
+    for (int k = 1; k < B.mp; k++) B.etap_dotdot[k] = (B.etap_mass[k - 1] * B.etap_dot[k - 1] * B.etap_dot[k - 1] - kt) / B.etap_mass[k];
+    p_current = pressure_scalar(s, s->t_current);
+  }
+  const int nav = nsteps / 2;
+  double lsum[3] = {0, 0, 0}, lrun[3] = {0, 0, 0};
+  int nwin = 0;
+  for (int step = 1; step <= nsteps; step++) {
+    /* initial_integrate */
+    if (npt) nhc_press_integrate(&B, dt, t_target);   /* thermostat target of the previous half step, as fix_nh orders it */
+    t_target = t_start + (t_stop - t_start) * (double)step / (double)nsteps;
+    nhc_temp_integrate(s, dt, t_target);
+    if (npt) {
+      p_current = pressure_scalar(s, s->t_current);   /* kinetic part after the thermostat half step, virial of the last forces */
+      nh_omega_dot(s, &B, dt, p_current, s->t_current);
+      nh_v_press(s, &B, dt);
+    }
+    for (int i = 0; i < n; i++) {
+      const double dtfm = dtf / s->mass[s->type[i]];
+      for (int k = 0; k < 3; k++) s->v[3 * i + k] += dtfm * s->f[3 * i + k];
+    }
+    if (npt) nh_remap(s, &B, dt);
+    for (int i = 0; i < 3 * n; i++) s->x[i] += dtv * s->v[i];
+    if (npt) nh_remap(s, &B, dt);
+    s->ago++;
+    if (s->ago >= s->p.neigh_delay && neigh_check(s)) neigh_build(s);
+    force_compute(s);
+    /* final_integrate */
+    for (int i = 0; i < n; i++) {
+      const double dtfm = dtf / s->mass[s->type[i]];
+      for (int k = 0; k < 3; k++) s->v[3 * i + k] += dtfm * s->f[3 * i + k];
+    }
+    if (npt) nh_v_press(s, &B, dt);
+    s->t_current = omd_temperature(s, NULL);
+    if (npt) {
+      p_current = pressure_scalar(s, s->t_current);
+      nh_omega_dot(s, &B, dt, p_current, s->t_current);
+    }
+    nhc_temp_integrate(s, dt, t_target);
+    if (npt) nhc_press_integrate(&B, dt, t_target);
+    /* end_of_step: running average of the box lengths */
+    if (lavg && nav > 0 && step <= 2 * nav) {
+      for (int d = 0; d < 3; d++) lsum[d] += s->hi[d] - s->lo[d];
+      if (step % nav == 0) {
+        for (int d = 0; d < 3; d++) {
+          lrun[d] += lsum[d] / nav;
+          lsum[d] = 0.0;
+        }
+        nwin++;
+      }
+    }
+    if (trace) {
+      double *tr = trace + 6 * (size_t)(step - 1);
+      double ke[6];
+      const double T = omd_temperature(s, ke);
+      boxq bb;
+      box_derive(s, &bb);
+      tr[0] = T;
+      tr[1] = pe_total(s);
+      tr[2] = 0.5 * (ke[0] + ke[1] + ke[2]);
+      double ec = nh_energy(s, t_target);
+      if (npt) {
+        /* fix_nh::compute_scalar, iso: 0.5 W omega_dot^2 per box dimension + p_hydro V / nktv2p + barostat chain */
+        ec += 1.5 * B.omega_mass * B.omega_dot * B.omega_dot;
+        ec += B.p_target * bb.vol / NKTV2P;
+        const double kt = BOLTZ * t_target;
+        for (int k = 0; k < B.mp; k++) ec += kt * B.etap[k] + 0.5 * B.etap_mass[k] * B.etap_dot[k] * B.etap_dot[k];
+      }
+      tr[3] = ec;
+      tr[4] = bb.vol;
+      tr[5] = npt ? p_current : pressure_scalar(s, T);
+    }
+  }
+  if (lavg)
+    for (int d = 0; d < 3; d++) lavg[d] = nwin ? lrun[d] / nwin : s->hi[d] - s->lo[d];
+  return 0;
+}
+
+/* in.init.lammps:44-215 on the registered configuration: velocities at 200 K, minimisation, the heat-up / cool-down
+ * schedule in units of nsinit steps.  lengths[3] = box lengths at the end (what init.<mat>_<rep>.length stores). */
+int omd_equilibrate(omd_sim *s, int nsinit, double dt, double tempt, unsigned long long seed, double lengths[3], double *min_info) {
+  double lav[3];
+  omd_velocity_create(s, 200.0, seed);
+  omd_minimize(s, 1.0e-7, 1.0e-11, nsinit, 50000, min_info);
+  omd_run_nh(s, nsinit, dt, 300.0, 300.0, 0, 0.0, 0.0, NULL, NULL);
+  omd_run_nh(s, nsinit, dt, 300.0, 500.0, 1, 1.0, 1000.0, NULL, NULL);
+  omd_run_nh(s, 5 * nsinit, dt, 500.0, 500.0, 1, 1.0, 1000.0, NULL, NULL);
+  omd_run_nh(s, nsinit, dt, 500.0, tempt, 1, 1.0, 1000.0, NULL, NULL);
+  omd_run_nh(s, 2 * nsinit, dt, tempt, tempt, 1, 1.0, 1000.0, lav, NULL);
+  omd_change_box(s, lav);
+  omd_run_nh(s, 20 * nsinit, dt, tempt, tempt, 0, 0.0, 0.0, NULL, NULL);
+  omd_run_nh(s, 2 * nsinit, dt, tempt, tempt, 1, 1.0, 1000.0, lav, NULL);
+  omd_change_box(s, lav);
+  omd_run_nh(s, nsinit, dt, tempt, tempt, 0, 0.0, 0.0, NULL, NULL);
+  for (int d = 0; d < 3; d++) lengths[d] = s->hi[d] - s->lo[d];
+  return 0;
+}

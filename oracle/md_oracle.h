@@ -118,6 +118,22 @@ int omd_nts(const double true_strain[6], double strain_rate, double dt);
 double omd_round_rate(double rate);      /* "%.6e" round trip, stmd_problem.h:241 */
 double omd_round_f(double v);            /* "%f"   round trip, stmd_problem.h:164,235 */
 
+/* ---- init_material's equilibration schedule (lammps_scripts_opls/in.init.lammps), see md_oracle.c ---- */
+/* min_style sd + minimize etol ftol maxiter maxeval; returns the stop reason (0 etol, 1 ftol, 2 maxiter, 3 maxeval, 4 line search);
+ * info[4] = iterations, force evaluations, initial and final potential energy */
+int omd_minimize(omd_sim *s, double etol, double ftol, int maxiter, int maxeval, double *info);
+/* velocity all create T seed rot yes dist gaussian (own random stream, see md_oracle.c) */
+void omd_velocity_create(omd_sim *s, double temperature, unsigned long long seed);
+/* change_box all x final 0 lx y final 0 ly z final 0 lz remap */
+void omd_change_box(omd_sim *s, const double len[3]);
+/* run N under fix nvt (npt 0) or fix npt temp t_start t_stop tperiod iso p p pperiod (npt 1), no SHAKE; lavg[3]: running
+ * average of the box lengths over the two half-run windows; trace: 6 doubles per step (T, pe, ke, thermostat + barostat
+ * part of the conserved quantity, volume, scalar pressure in atm) */
+int omd_run_nh(omd_sim *s, int nsteps, double dt, double t_start, double t_stop, int npt, double p_target, double p_period,
+               double *lavg, double *trace);
+/* the whole schedule of in.init.lammps:44-215 in units of nsinit steps; lengths[3] = final box lengths */
+int omd_equilibrate(omd_sim *s, int nsinit, double dt, double tempt, unsigned long long seed, double lengths[3], double *min_info);
+
 /* timing of the last omd_eval: seconds spent in pair / kspace / neigh / other */
 void omd_last_timing(const omd_sim *s, double t[4]);
 

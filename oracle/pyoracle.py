@@ -148,6 +148,34 @@ class Oracle:
             raise RuntimeError(f"omd_eval failed rc={nts}")
         return out, nts
 
+    # ---- init_material's equilibration schedule (in.init.lammps), md_oracle.c ----
+    def minimize(self, etol=1e-7, ftol=1e-11, maxiter=1000, maxeval=50000):
+        info = np.zeros(4)
+        stop = lib().omd_minimize(self.h, C.c_double(etol), C.c_double(ftol), C.c_int(maxiter), C.c_int(maxeval), _p(info))
+        return dict(stop=int(stop), iterations=int(info[0]), evaluations=int(info[1]), e_initial=info[2], e_final=info[3])
+
+    def velocity_create(self, temperature, seed=1234):
+        lib().omd_velocity_create(self.h, C.c_double(temperature), C.c_uint64(seed))
+
+    def change_box(self, lengths):
+        l = np.ascontiguousarray(lengths, dtype=np.float64)
+        lib().omd_change_box(self.h, _p(l))
+
+    def run_nh(self, nsteps, dt, t_start, t_stop=None, npt=False, p_target=1.0, p_period=1000.0, average_lengths=False, trace=False):
+        lav = np.zeros(3) if average_lengths else None
+        tr = np.zeros((nsteps, 6)) if trace else None
+        rc = lib().omd_run_nh(self.h, C.c_int(nsteps), C.c_double(dt), C.c_double(t_start), C.c_double(t_start if t_stop is None else t_stop),
+                              C.c_int(1 if npt else 0), C.c_double(p_target), C.c_double(p_period),
+                              _p(lav) if average_lengths else None, _p(tr) if trace else None)
+        if rc != 0:
+            raise RuntimeError(f"omd_run_nh failed rc={rc}")
+        return lav, tr
+
+    def equilibrate(self, nsinit, dt, tempt, seed=1234):
+        lengths, info = np.zeros(3), np.zeros(4)
+        lib().omd_equilibrate(self.h, C.c_int(nsinit), C.c_double(dt), C.c_double(tempt), C.c_uint64(seed), _p(lengths), _p(info))
+        return lengths, info
+
     def timing(self):
         t = np.zeros(4)
         lib().omd_last_timing(self.h, _p(t))

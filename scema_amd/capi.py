@@ -32,12 +32,17 @@ SYMBOLS = [
     "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_state_owner", "scema_md_last_plan",
     "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update",
+    "scema_md_replica_natoms", "scema_md_save_replica_file", "scema_md_equilibrate", "scema_md_debug_minimize", "scema_md_debug_run_nh",
     "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_debug_compute", "scema_md_reax_stats",
 ]
 COMM_ID_BYTES = 128
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 HOST_SEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 HOST_RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+
+
+class EquilParams(C.Structure):
+    _fields_ = [("nsteps_equil", C.c_int32), ("timestep_length", C.c_double), ("temperature", C.c_double), ("seed", C.c_int64)]
 
 
 class Params(C.Structure):
@@ -341,8 +346,17 @@ class Engine:
     def has_state(self, qp, matid, replica) -> bool:
         return bool(lib().scema_md_has_state(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica)))
 
+    def natoms(self, matid, replica) -> int:
+        """atoms of a registered replica (also one the library registered itself, e.g. from a file)"""
+        if (matid, replica) not in self._natoms:
+            n = int(lib().scema_md_replica_natoms(self.h, matid.encode(), C.c_int32(replica)))
+            if n <= 0:
+                raise EngineError(f"replica {matid}_{replica} is not registered")
+            self._natoms[(matid, replica)] = n
+        return self._natoms[(matid, replica)]
+
     def get_state(self, qp, matid, replica):
-        n = self._natoms[(matid, replica)]
+        n = self.natoms(matid, replica)
         box = np.zeros(9); x = np.zeros((n, 3)); v = np.zeros((n, 3))
         self._chk(lib().scema_md_get_state(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), _p(box), _p(x), _p(v)))
         return box, x, v
@@ -406,6 +420,26 @@ class Engine:
         self._chk(lib().scema_md_reax_debug_compute(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), _p(f), _p(e), _p(w), _p(q), _p(info)))
         return dict(f=f, e=dict(zip(REAX_PARTS, e)), w=w, q=q, maxneigh_seen=int(info[0]), maxnb=int(info[1]), maxbd=int(info[2]),
                     qeq_iters=int(info[3]), image_search=int(info[4]), maxbonds_seen=int(info[5]))
+
+    # ---- init_material's equilibration schedule (in.init.lammps; md_equil.hip) ----
+    def minimize(self, matid, replica, qp, etol=1e-7, ftol=1e-11, maxiter=1000, maxeval=50000) -> dict:
+        info = np.zeros(5)
+        self._chk(lib().scema_md_debug_minimize(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), C.c_double(etol), C.c_double(ftol),
+                                                C.c_int32(maxiter), C.c_int32(maxeval), _p(info)))
+        return dict(stop=int(info[0]), iterations=int(info[1]), evaluations=int(info[2]), e_initial=info[3], e_final=info[4])
+
+    def run_nh(self, matid, replica, qp, nsteps, dt, t_start, t_stop=None, npt=False, p_target=1.0, p_period=1000.0, average_lengths=False):
+        lav = np.zeros(3) if average_lengths else None
+        self._chk(lib().scema_md_debug_run_nh(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), C.c_int32(nsteps), C.c_double(dt),
+                                              C.c_double(t_start), C.c_double(t_start if t_stop is None else t_stop), C.c_int32(1 if npt else 0),
+                                              C.c_double(p_target), C.c_double(p_period), _p(lav) if average_lengths else None))
+        return lav
+
+    def equilibrate(self, matid, replica, nsteps_equil, dt, temperature, seed=1234):
+        p = EquilParams(nsteps_equil, dt, temperature, seed)
+        length, info = np.zeros(3), np.zeros(5)
+        self._chk(lib().scema_md_equilibrate(self.h, matid.encode(), C.c_int32(replica), C.byref(p), _p(length), _p(info)))
+        return length, dict(stop=int(info[0]), iterations=int(info[1]), evaluations=int(info[2]), e_initial=info[3], e_final=info[4])
 
     def reax_stats(self) -> dict:
         out = np.zeros(6)

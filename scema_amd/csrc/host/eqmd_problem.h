@@ -1,7 +1,9 @@
-// eqmd_problem.h -- host mirror of HMM::EQMDProblem<3> (reference headers/init_material_problem.h:30-355) for an
-// already equilibrated replica: equil() calls the engine's init_material (box lengths, initial stress, stiffness by
-// +-strain_ampl finite strains; 13 MD runs in one GPU batch) and writes the three files STMDSync::init reads back
-// (stmd_sync.h:382-445), with the reference's writers (read_write.h:180-244 there, read_write.h here).
+// eqmd_problem.h -- host mirror of HMM::EQMDProblem<3> (reference headers/init_material_problem.h:30-355).
+// equil() with the reference's full argument list first brings the replica to its equilibrated state -- "Compute state
+// data" (no init.<mat>_<rep>.bin yet: read <slocin>/<mat>_<rep>.data, run the schedule of in.init.lammps on the GPU, write
+// the state file) or "Reuse of state data" (:167-184) -- then calls the engine's init_material (box lengths, initial stress,
+// stiffness by +-strain_ampl finite strains; 13 MD runs in one GPU batch) and writes the three files STMDSync::init reads
+// back (stmd_sync.h:382-445), with the reference's writers (read_write.h:180-244 there, read_write.h here).
 #pragma once
 #include <string>
 
@@ -16,7 +18,53 @@ class EQMDProblem {
   explicit EQMDProblem(scema_md_engine *engine) : engine_(engine) {}
   const std::string &last_error() const { return err_; }
 
-  // arguments of EQMDProblem::equil (init_material_problem.h:309-315) that matter once the state exists:
+  // EQMDProblem::equil with every argument of the reference (init_material_problem.h:309-315): slocin = folder of
+  // <cmat>_<rep>.data (LAMMPS write_data, atom_style full), systof = init.<cmat>_<rep>.bin, mdnse = nsinit of in.init.lammps;
+  // qplogloc and scrloc (LAMMPS log and script folders) have no counterpart here and are accepted for signature parity.
+  int equil(const std::string &cmat, const std::string &slocin, const std::string &qplogloc, const std::string &scrloc, const std::string &lengthof,
+            const std::string &stressof, const std::string &stiffof, const std::string &systof, int rep, double mdts, double mdtem, int mdnss, int mdnse,
+            double mdss, double mdsa, const std::string &mdff) {
+    (void)qplogloc; (void)scrloc;
+    if (mdff != "opls" && mdff != "reax") {
+      err_ = "Error: Force field is " + mdff + " but only 'opls' and 'reax' are implemented... ";
+      return SCEMA_MD_ERR_ARG;
+    }
+    if (mdff == "reax") {
+      err_ = "init_material with force field 'reax' is not built (the straining path is: scema_md_strain_batch)";
+      return SCEMA_MD_ERR_ARG;
+    }
+    if (!engine_) {
+      err_ = "init_material needs an engine (no CPU fallback)";
+      return SCEMA_MD_ERR_DEVICE;
+    }
+    const bool registered = scema_md_replica_natoms(engine_, cmat.c_str(), rep) > 0;
+    if (!file_exists(systof)) {
+      // "Compute state data...": in.init.lammps on the data file
+      if (!registered) {
+        const std::string data = slocin + "/" + cmat + "_" + std::to_string(rep) + ".data";
+        static const double sp_lj[3] = {0.0, 0.0, 1.0}, sp_coul[3] = {0.0, 0.0, 1.0};   // special_bonds lj/coul 0.0 0.0 1.0 (in.init.lammps:33)
+        const int rc = scema_md_load_lammps_data(engine_, cmat.c_str(), rep, data.c_str(), sp_lj, sp_coul);
+        if (rc) { err_ = scema_md_last_error(engine_); return rc; }
+      }
+      scema_md_equilparams q;
+      q.nsteps_equil = mdnse;
+      q.timestep_length = mdts;
+      q.temperature = mdtem;
+      q.seed = 1234;   // init_material_problem.h:167
+      double len[3], info[5];
+      int rc = scema_md_equilibrate(engine_, cmat.c_str(), rep, &q, len, info);
+      if (rc) { err_ = scema_md_last_error(engine_); return rc; }
+      // "Saving state data..." (write_restart ${systemoutputfile}, :208-210)
+      rc = scema_md_save_replica_file(engine_, cmat.c_str(), rep, systof.c_str());
+      if (rc) { err_ = scema_md_last_error(engine_); return rc; }
+    } else if (!registered) {
+      err_ = "Reuse of state data: replica " + cmat + "_" + std::to_string(rep) + " must be registered with the engine (STMDSync::init does that from " + systof + ")";
+      return SCEMA_MD_ERR_NOSTATE;
+    }
+    return equil(cmat, lengthof, stressof, stiffof, rep, mdts, mdtem, mdnss, mdss, mdsa, mdff);
+  }
+
+  // the part of EQMDProblem::equil (init_material_problem.h:309-315) that runs once the state exists:
   // cmat, lengthof/stressof/stiffof, rep (1-based), mdts, mdtem, mdnss, mdss (strain rate), mdsa (strain amplitude), mdff
   int equil(const std::string &cmat, const std::string &lengthof, const std::string &stressof, const std::string &stiffof, int rep,
             double mdts, double mdtem, int mdnss, double mdss, double mdsa, const std::string &mdff) {

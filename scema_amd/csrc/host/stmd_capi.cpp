@@ -107,4 +107,18 @@ int scema_eqmd_equil(scema_md_engine *engine, const char *cmat, const char *leng
   return rc;
 }
 
+int scema_eqmd_equil_full(scema_md_engine *engine, const char *cmat, const char *slocin, const char *qplogloc, const char *scrloc, const char *lengthof,
+                          const char *stressof, const char *stiffof, const char *systof, int32_t rep, double mdts, double mdtem, int32_t mdnss,
+                          int32_t mdnse, double mdss, double mdsa, const char *mdff, char *errbuf, int32_t errlen) {
+  if (!cmat || !slocin || !lengthof || !stressof || !stiffof || !systof || !mdff) return SCEMA_MD_ERR_ARG;
+  scema::EQMDProblem eq(engine);
+  const int rc = eq.equil(cmat, slocin, qplogloc ? qplogloc : "", scrloc ? scrloc : "", lengthof, stressof, stiffof, systof, rep, mdts, mdtem, mdnss, mdnse,
+                          mdss, mdsa, mdff);
+  if (rc && errbuf && errlen > 0) {
+    std::strncpy(errbuf, eq.last_error().c_str(), (size_t)errlen - 1);
+    errbuf[errlen - 1] = 0;
+  }
+  return rc;
+}
+
 }  // extern "C"

@@ -81,3 +81,60 @@ static inline size_t &lds_optin_slot(size_t (&table)[16]) {
   (void)hipGetDevice(&dev);
   return table[(dev >= 0 && dev < 16) ? dev : 0];
 }
+
+// ------------------------------------------------------------------------------------------
+// Nose-Hoover chain half step (fix nvt; one sub-cycle, no drag).  Returns the velocity factor.
+// ------------------------------------------------------------------------------------------
+__device__ inline double nhc_half(const SimDev &S, SimScalars &sc) {
+  const int mt = S.t_chain;
+  const double dt = S.dt, dthalf = 0.5 * dt, dt4 = 0.25 * dt, dt8 = 0.125 * dt;
+  const double t_target = S.ramp ? sc.t_target_now : S.t_target;
+  const double ke_target = S.tdof * MD_BOLTZ * t_target;
+  double kecurrent = S.tdof * MD_BOLTZ * sc.t_current;
+  const double tf2 = S.t_freq * S.t_freq;
+  sc.eta_mass[0] = S.tdof * MD_BOLTZ * t_target / tf2;
+  for (int k = 1; k < mt; k++) sc.eta_mass[k] = MD_BOLTZ * t_target / tf2;
+  sc.eta_dotdot[0] = (sc.eta_mass[0] > 0.0) ? (kecurrent - ke_target) / sc.eta_mass[0] : 0.0;
+  double expfac;
+  for (int k = mt - 1; k > 0; k--) {
+    expfac = exp(-dt8 * sc.eta_dot[k + 1]);
+    sc.eta_dot[k] *= expfac;
+    sc.eta_dot[k] += sc.eta_dotdot[k] * dt4;
+    sc.eta_dot[k] *= expfac;
+  }
+  expfac = exp(-dt8 * sc.eta_dot[1]);
+  sc.eta_dot[0] *= expfac;
+  sc.eta_dot[0] += sc.eta_dotdot[0] * dt4;
+  sc.eta_dot[0] *= expfac;
+  const double factor = exp(-dthalf * sc.eta_dot[0]);
+  sc.t_current *= factor * factor;
+  kecurrent = S.tdof * MD_BOLTZ * sc.t_current;
+  sc.eta_dotdot[0] = (sc.eta_mass[0] > 0.0) ? (kecurrent - ke_target) / sc.eta_mass[0] : 0.0;
+  for (int k = 0; k < mt; k++) sc.eta[k] += dthalf * sc.eta_dot[k];
+  sc.eta_dot[0] *= expfac;
+  sc.eta_dot[0] += sc.eta_dotdot[0] * dt4;
+  sc.eta_dot[0] *= expfac;
+  for (int k = 1; k < mt; k++) {
+    expfac = exp(-dt8 * sc.eta_dot[k + 1]);
+    sc.eta_dot[k] *= expfac;
+    sc.eta_dotdot[k] = (sc.eta_mass[k - 1] * sc.eta_dot[k - 1] * sc.eta_dot[k - 1] - MD_BOLTZ * t_target) / sc.eta_mass[k];
+    sc.eta_dot[k] += sc.eta_dotdot[k] * dt4;
+    sc.eta_dot[k] *= expfac;
+  }
+  return factor;
+}
+
+__device__ inline void box_corners(const double *box, double *c /*24*/) {
+  BoxD b;
+  box_derive(box, b);
+  int k = 0;
+  for (int iz = 0; iz < 2; iz++)
+    for (int iy = 0; iy < 2; iy++)
+      for (int ix = 0; ix < 2; ix++) {
+        c[3 * k + 0] = b.h[0] * ix + b.h[5] * iy + b.h[4] * iz + b.lo[0];
+        c[3 * k + 1] = b.h[1] * iy + b.h[3] * iz + b.lo[1];
+        c[3 * k + 2] = b.h[2] * iz + b.lo[2];
+        k++;
+      }
+}
+

@@ -32,6 +32,7 @@
 #include "host/reax_ffield.h"
 #include "host/sim_plan.h"
 #include "md_kernels.h"
+#include "md_equil.h"
 #include "md_reax.h"
 #include "md_types.h"
 
@@ -203,7 +204,7 @@ struct scema_md_engine {
   std::map<std::string, std::unique_ptr<Topo>> topos;
   std::map<std::string, std::unique_ptr<State>> states;
   std::vector<std::unique_ptr<Slot>> slots;
-  DevBuf d_sims, d_sc, d_local_stress, d_kpack;
+  DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair;
   std::vector<int> h_kpack;   // host copy, alive until the stream has consumed the upload
   int local_stress_count = 0;
   std::vector<SimDev> h_sims;
@@ -925,9 +926,17 @@ double round_trip(const char *fmt, double v) {
 // -------------------------------------------------------------------------------------------
 // one "run" of a batch
 // -------------------------------------------------------------------------------------------
+struct EwaldSetup;
 struct RunSpec {
   int nvt = 1, use_shake = 1, deform = 0, sample = 0, ev_always = 0;
   int static_only = 0;  // parity hook: forces of the potential only (no constraint forces)
+  // equilibration schedule of init_material (md_equil.hip): fix nvt / fix npt ... iso with a temperature ramp, issued in
+  // segments (the cell grid and the k-space tables of a segment hold for box lengths within +-box_margin), and min_style sd
+  int nh = 0, npt = 0, keep = 0, nh_total = 0, lavg_nav = 0;
+  double t_start = 0, t_stop = 0, p_target = 1.0, p_period = 1000.0, box_margin = 0.0;
+  std::vector<EwaldSetup> *ew_keep = nullptr;   // k-space setup of the run's first segment, reused by the later ones
+  int minimize = 0, min_maxiter = 0, min_maxeval = 0;
+  double min_etol = 0, min_ftol = 0;
 };
 
 // slots: every cell is padded to a multiple of MD_CLUSTER slots (i-clusters never straddle cells)
@@ -1064,6 +1073,20 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     }
     box_derive(hsc.box, boxes[0]);
     box_derive(box_end, boxes[1]);
+    if (spec.nh && spec.npt && spec.box_margin > 0.0)
+      for (int sgn = -1; sgn <= 1; sgn += 2) {   // the barostat dilates the box (tilts with it): both ends of the allowed range
+        double bx[9];
+        const double f = 1.0 + sgn * spec.box_margin;
+        for (int d = 0; d < 3; d++) {
+          const double c = 0.5 * (hsc.box[d] + hsc.box[3 + d]);
+          bx[d] = c + (hsc.box[d] - c) * f;
+          bx[3 + d] = c + (hsc.box[3 + d] - c) * f;
+        }
+        for (int k = 6; k < 9; k++) bx[k] = hsc.box[k] * f;
+        HostBox hb;
+        box_derive(bx, hb);
+        boxes.push_back(hb);
+      }
     const HostBox &b0 = boxes[0], &b1 = boxes[1];
     double w0[3] = {1e300, 1e300, 1e300}, w1[3];   // w0 = narrowest perpendicular widths over the run
     double vol_min = 1e300, vol_max = 0.0;
@@ -1166,7 +1189,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       return fail(e, SCEMA_MD_ERR_ARG, "the j table of a cell tile (%d entries) does not fit the LDS of the pair kernel (system too dense for the cutoff)", capj);
     S.ncells = S.nc[0] * S.nc[1] * S.nc[2];
     EwaldSetup &ew = ews[pos];
-    ewald_setup(P, T, hsc.box, ew);
+    if (spec.ew_keep && spec.keep && (int)spec.ew_keep->size() == ns) ew = (*spec.ew_keep)[pos];   // a run keeps the k-space setup of its start
+    else ewald_setup(P, T, hsc.box, ew);
     S.nk = (int)ew.kn.size() / 3;
     for (int d = 0; d < 3; d++) S.kmaxd[d] = ew.kmaxd[d];
     S.g_ewald = ew.g;
@@ -1209,6 +1233,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.nvt = spec.nvt;
     S.use_shake = (spec.use_shake && T.nclus > 0) ? 1 : 0;
     S.deform = spec.deform;
+    if (spec.nh) {
+      S.ramp = 1; S.npt = spec.npt; S.nh_total = std::max(spec.nh_total, 1); S.lavg_nav = spec.lavg_nav;
+      S.t_start = spec.t_start; S.t_stop = spec.t_stop; S.p_target = spec.p_target; S.p_freq = 1.0 / spec.p_period; S.box_margin = spec.box_margin;
+    }
+    if (spec.minimize) {
+      S.min_etol = spec.min_etol; S.min_ftol = spec.min_ftol; S.min_dmax = 0.1; S.min_maxiter = spec.min_maxiter; S.min_maxeval = spec.min_maxeval;
+    }
     S.t_chain = std::min(P.t_chain, MD_MAXCHAIN);
     S.neigh_delay = P.neigh_delay;
     S.shake_maxiter = P.shake_maxiter;
@@ -1279,7 +1310,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     HIPCHK(hipEventRecord(e->ev_up, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_up, 0));
   }
-  const int ev = (spec.sample || spec.ev_always) ? 1 : 0;
+  const int ev = (spec.sample || spec.ev_always || (spec.nh && spec.npt)) ? 1 : 0;   // the barostat needs the virial of every step
   const bool allow_side = nhalf == 1;
   // ---- setup (step 0) ----
   for (int h = 0; h < nhalf; h++) {
@@ -1292,7 +1323,57 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
     mdk_final_integrate(st, Dh, nh, maxatoms, 0);
-    mdk_setup_post(st, Dh, nh);
+    if (spec.nh) mdk_setup_post_nh(st, Dh, nh);
+    else mdk_setup_post(st, Dh, nh);
+  }
+  if (spec.ew_keep && !spec.keep) *spec.ew_keep = ews;
+  if (spec.minimize) {
+    // min_style sd: every replica runs its own line search, decided on the device between two force evaluations; the host
+    // only looks now and then whether all of them have stopped.  x0 and the search direction live in the slot's backup arrays.
+    hipStream_t st = e->stream;
+    std::vector<double *> ptrs(2 * (size_t)ns);
+    for (int pos = 0; pos < ns; pos++) {
+      Slot &sl = *e->slots[order[pos]];
+      ptrs[pos] = sl.xbak.as<double>();
+      ptrs[ns + pos] = sl.vbak.as<double>();
+      HIPCHK(hipMemsetAsync(sl.vbak.p, 0, 3 * (size_t)e->h_sims[pos].natoms * 8, st));
+    }
+    HIPCHK(e->d_minptr.ensure(ptrs.size() * sizeof(double *)));
+    HIPCHK(hipMemcpyAsync(e->d_minptr.p, ptrs.data(), ptrs.size() * sizeof(double *), hipMemcpyHostToDevice, st));
+    double *const *x0s = e->d_minptr.as<double *>(), *const *hsd = e->d_minptr.as<double *>() + ns;
+    mdk_min_reduce(st, D, ns, maxatoms, hsd);
+    mdk_min_decide(st, D, ns);
+    const long long cap = (long long)spec.min_maxeval + 2LL * spec.min_maxiter + 8;
+    bool all_done = false;
+    for (long long ev_n = 0; ev_n < cap && !all_done;) {
+      for (int r = 0; r < 16; r++, ev_n++) {
+        mdk_min_pre(st, D, ns);
+        mdk_min_move(st, D, ns, maxatoms, x0s, hsd);
+        mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
+        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly);
+        HIPCHK(force_stage(e, st, false, D, ns, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, 1, 0));
+        mdk_min_reduce(st, D, ns, maxatoms, hsd);
+        mdk_min_decide(st, D, ns);
+      }
+      HIPCHK(hipMemcpyAsync(e->h_sc.data(), e->d_sc.p, (size_t)ns * sizeof(SimScalars), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      all_done = true;
+      for (int i = 0; i < ns; i++) {
+        if (e->h_sc[i].overflow) all_done = true;
+        else if (e->h_sc[i].min_phase != 4) { all_done = false; }
+      }
+      for (int i = 0; i < ns; i++) if (e->h_sc[i].overflow) all_done = true;
+    }
+    HIPCHK(hipMemcpyAsync(e->h_sc.data(), e->d_sc.p, (size_t)ns * sizeof(SimScalars), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    int fault_m = 0;
+    for (int i = 0; i < ns; i++) fault_m |= e->h_sc[i].overflow;
+    if (fault_m & 16) return fail(e, SCEMA_MD_ERR_ARG, "a simulation became unstable during the minimisation (non-finite positions)");
+    e->overflow_bits = (fault_m & 1) ? (fault_m & (4 | 8)) : 0;
+    if (fault_m & 1) return SCEMA_MD_ERR_OVERFLOW;
+    if (!all_done) return fail(e, SCEMA_MD_ERR_ARG, "minimiser did not stop within its evaluation budget");
+    return SCEMA_MD_OK;
   }
   // ---- steps ----
   const bool prof = e->p.profile != 0;
@@ -1302,8 +1383,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   auto launch_step = [&](int h, int na, bool timed) -> int {
     hipStream_t st = hs[h];
     const SimDev *Dh = D + hbeg[h];
-    mdk_pre(st, Dh, na);
-    mdk_initial_integrate(st, Dh, na, maxatoms);
+    if (spec.nh) { mdk_pre_nh(st, Dh, na); mdk_initial_integrate_nh(st, Dh, na, maxatoms); }
+    else { mdk_pre(st, Dh, na); mdk_initial_integrate(st, Dh, na, maxatoms); }
     mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj);
     if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
@@ -1324,7 +1405,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
     mdk_shake(st, Dh, na, maxclus, 1.0);
     mdk_final_integrate(st, Dh, na, maxatoms, 1);
-    mdk_post(st, Dh, na);
+    if (spec.nh) mdk_post_nh(st, Dh, na);
+    else mdk_post(st, Dh, na);
     if (spec.deform) mdk_remap(st, Dh, na, maxatoms);
     return SCEMA_MD_OK;
   };
@@ -1489,6 +1571,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   if (fault & 2) return fail(e, SCEMA_MD_ERR_ARG, "an excluded (special) pair stretched beyond the exclusion gate; topology or state is broken");
   e->overflow_bits = fault;
   if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
+  if (fault & 64) return SCEMA_MD_ERR_OVERFLOW;   // the barostat took the box out of the range this segment was laid out for
   return SCEMA_MD_OK;
 }
 
@@ -2312,6 +2395,24 @@ int scema_md_has_state(const scema_md_engine *e, int32_t qp_id, const char *mati
   return e->states.count(state_key(qp_id, matid, replica)) ? 1 : 0;
 }
 
+int scema_md_save_replica_file(scema_md_engine *e, const char *matid, int32_t replica, const char *path) {
+  if (!e || !matid || !path) return SCEMA_MD_ERR_ARG;
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, (int)replica);
+  scema_md_system s = t->original.sys;
+  std::memcpy(s.box, t->init_box, sizeof s.box);
+  s.x = t->init_x.data();
+  s.v = t->init_v.data();
+  const int rc = scema_md_write_replica_file(path, &s);
+  return rc ? fail(e, rc, "cannot write %s", path) : SCEMA_MD_OK;
+}
+
+int32_t scema_md_replica_natoms(scema_md_engine *e, const char *matid, int32_t replica) {
+  if (!e || !matid) return 0;
+  Topo *t = find_topo(e, matid, replica);
+  return t ? t->natoms : 0;
+}
+
 int scema_md_get_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double box[9], double *x, double *v) {
   if (!e) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
@@ -2523,6 +2624,253 @@ int scema_md_debug_run(scema_md_engine *e, int32_t qp_id, const char *matid, int
   const SimScalars &sc = e->h_sc[0];
   std::memcpy(s->box, sc.box, 9 * sizeof(double));
   if (press_avg) for (int k = 0; k < 6; k++) press_avg[k] = sc.psum[k] / (double)std::max(sc.nsamples, 1);
+  return SCEMA_MD_OK;
+}
+
+// ---- init_material: the equilibration schedule (lammps_scripts_opls/in.init.lammps:44-215) ----
+namespace {
+unsigned long long splitmix64(unsigned long long &st) {
+  unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// velocity all create T seed rot yes dist gaussian: Gaussian, zero linear and angular momentum, rescaled to T on 3N-3 degrees
+// of freedom.  LAMMPS' own random stream is not reproduced (any member of the ensemble serves; the schedule forgets it).
+void velocity_create(const Topo &t, const std::vector<double> &x, double temperature, unsigned long long seed, std::vector<double> &v) {
+  const int n = t.natoms;
+  v.assign(3 * (size_t)n, 0.0);
+  unsigned long long st = seed;
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) {
+      const double u1 = ((double)(splitmix64(st) >> 11) + 0.5) / 9007199254740992.0, u2 = ((double)(splitmix64(st) >> 11) + 0.5) / 9007199254740992.0;
+      v[3 * i + k] = std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * MD_PI * u2) / std::sqrt(t.mass_atom[i]);
+    }
+  double p[3] = {0, 0, 0}, mt = 0.0, cm[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    mt += t.mass_atom[i];
+    for (int k = 0; k < 3; k++) p[k] += t.mass_atom[i] * v[3 * i + k];
+  }
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) v[3 * i + k] -= p[k] / mt;
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) cm[k] += t.mass_atom[i] * x[3 * i + k] / mt;
+  double L[3] = {0, 0, 0}, I[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int i = 0; i < n; i++) {
+    const double m = t.mass_atom[i];
+    const double r[3] = {x[3 * i] - cm[0], x[3 * i + 1] - cm[1], x[3 * i + 2] - cm[2]};
+    const double *vv = &v[3 * i];
+    L[0] += m * (r[1] * vv[2] - r[2] * vv[1]);
+    L[1] += m * (r[2] * vv[0] - r[0] * vv[2]);
+    L[2] += m * (r[0] * vv[1] - r[1] * vv[0]);
+    const double r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) I[a][b] += m * ((a == b ? r2 : 0.0) - r[a] * r[b]);
+  }
+  const double det = I[0][0] * (I[1][1] * I[2][2] - I[1][2] * I[2][1]) - I[0][1] * (I[1][0] * I[2][2] - I[1][2] * I[2][0]) +
+                     I[0][2] * (I[1][0] * I[2][1] - I[1][1] * I[2][0]);
+  double inv[3][3];
+  inv[0][0] = (I[1][1] * I[2][2] - I[1][2] * I[2][1]) / det; inv[0][1] = (I[0][2] * I[2][1] - I[0][1] * I[2][2]) / det; inv[0][2] = (I[0][1] * I[1][2] - I[0][2] * I[1][1]) / det;
+  inv[1][0] = (I[1][2] * I[2][0] - I[1][0] * I[2][2]) / det; inv[1][1] = (I[0][0] * I[2][2] - I[0][2] * I[2][0]) / det; inv[1][2] = (I[0][2] * I[1][0] - I[0][0] * I[1][2]) / det;
+  inv[2][0] = (I[1][0] * I[2][1] - I[1][1] * I[2][0]) / det; inv[2][1] = (I[0][1] * I[2][0] - I[0][0] * I[2][1]) / det; inv[2][2] = (I[0][0] * I[1][1] - I[0][1] * I[1][0]) / det;
+  double w[3];
+  for (int a = 0; a < 3; a++) w[a] = inv[a][0] * L[0] + inv[a][1] * L[1] + inv[a][2] * L[2];
+  double ke = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double r[3] = {x[3 * i] - cm[0], x[3 * i + 1] - cm[1], x[3 * i + 2] - cm[2]};
+    v[3 * i] -= w[1] * r[2] - w[2] * r[1];
+    v[3 * i + 1] -= w[2] * r[0] - w[0] * r[2];
+    v[3 * i + 2] -= w[0] * r[1] - w[1] * r[0];
+    for (int k = 0; k < 3; k++) ke += t.mass_atom[i] * v[3 * i + k] * v[3 * i + k];
+  }
+  const double tcur = ke * MD_MVV2E / ((3.0 * n - 3.0) * MD_BOLTZ), sc = std::sqrt(temperature / tcur);
+  for (double &q : v) q *= sc;
+}
+
+struct EquilCtx {
+  scema_md_engine *e;
+  State *s;
+  DevBuf xb, vb;   // state at the start of the segment / of the minimisation, for a retry
+};
+int equil_backup(EquilCtx &c) {
+  scema_md_engine *e = c.e;
+  const size_t bytes = 3 * (size_t)c.s->topo->natoms * 8;
+  HIPCHK(c.xb.ensure(bytes));
+  HIPCHK(c.vb.ensure(bytes));
+  HIPCHK(hipMemcpyAsync(c.xb.p, c.s->x.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(c.vb.p, c.s->v.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+  return SCEMA_MD_OK;
+}
+int equil_restore(EquilCtx &c) {
+  scema_md_engine *e = c.e;
+  const size_t bytes = 3 * (size_t)c.s->topo->natoms * 8;
+  HIPCHK(hipMemcpyAsync(c.s->x.p, c.xb.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(c.s->v.p, c.vb.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+  return SCEMA_MD_OK;
+}
+void grow_lists(scema_md_engine *e) {
+  if (e->overflow_bits & 4) e->jtab_grow *= 1.25;
+  if ((e->overflow_bits & 8) || !(e->overflow_bits & 4)) e->neigh_grow *= 1.5;
+}
+// min_style sd ; minimize etol ftol maxiter maxeval.  info[4]: iterations, force evaluations, initial and final energy
+int equil_minimize(EquilCtx &c, double etol, double ftol, int maxiter, int maxeval, int *stop, double *info) {
+  scema_md_engine *e = c.e;
+  int rc = equil_backup(c);
+  if (rc) return rc;
+  std::vector<ActiveSim> sims(1);
+  sims[0].st = c.s;
+  sims[0].nsteps = 0;
+  sims[0].dt = 1.0;
+  sims[0].temperature = 300.0;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    if ((rc = prepare_slots(e, sims))) return rc;
+    RunSpec R;
+    R.nvt = 0; R.use_shake = 0; R.ev_always = 1; R.static_only = 1;
+    R.minimize = 1; R.min_etol = etol; R.min_ftol = ftol; R.min_maxiter = maxiter; R.min_maxeval = maxeval;
+    rc = run_phase(e, sims, R);
+    if (rc != SCEMA_MD_ERR_OVERFLOW) break;
+    grow_lists(e);
+    if ((rc = equil_restore(c))) return rc;
+    rc = SCEMA_MD_ERR_OVERFLOW;
+  }
+  if (rc) return rc;
+  const SimScalars &sc = e->h_sc[0];
+  if (stop) *stop = sc.min_stop;
+  if (info) { info[0] = sc.min_iter; info[1] = sc.min_neval; info[2] = sc.min_einit; info[3] = sc.min_ecur; }
+  return SCEMA_MD_OK;
+}
+// run N under fix nvt / fix npt ... iso with a ramp, in segments; lavg != NULL: box-length averages (two half-run windows)
+int equil_run_nh(EquilCtx &c, int nsteps, double dt, double t_start, double t_stop, bool npt, double p_target, double p_period, double *lavg) {
+  scema_md_engine *e = c.e;
+  if (nsteps <= 0) return SCEMA_MD_OK;
+  std::vector<ActiveSim> sims(1);
+  sims[0].st = c.s;
+  sims[0].dt = dt;
+  sims[0].temperature = t_start;
+  std::vector<EwaldSetup> ew_keep;
+  SimScalars carry;
+  std::memset(&carry, 0, sizeof carry);
+  int done = 0, seg = npt ? 250 : nsteps;
+  const double margin = 0.02;
+  bool first = true;
+  int failures = 0;
+  while (done < nsteps) {
+    const int len = std::min(seg, nsteps - done);
+    int rc = equil_backup(c);
+    if (rc) return rc;
+    sims[0].nsteps = len;
+    if (first) {
+      if ((rc = prepare_slots(e, sims))) return rc;
+    } else {
+      e->h_sc.assign(1, carry);
+      e->h_sc[0].keep_nh = 1;
+      if ((rc = reupload_scalars(e, 1))) return rc;
+    }
+    RunSpec R;
+    R.nvt = 1; R.use_shake = 0;
+    R.nh = 1; R.npt = npt ? 1 : 0; R.keep = first ? 0 : 1; R.nh_total = nsteps; R.lavg_nav = lavg ? nsteps / 2 : 0;
+    R.t_start = t_start; R.t_stop = t_stop; R.p_target = p_target; R.p_period = p_period; R.box_margin = margin;
+    R.ew_keep = &ew_keep;
+    rc = run_phase(e, sims, R);
+    if (rc == SCEMA_MD_ERR_OVERFLOW) {
+      if (++failures > 12) return fail(e, SCEMA_MD_ERR_ARG, "equilibration: a run segment kept failing (box leaving its range or lists overflowing)");
+      if (e->overflow_bits & 1) grow_lists(e);
+      else seg = std::max(10, seg / 2);   // the box left the range the segment was laid out for: shorter segments
+      if ((rc = equil_restore(c))) return rc;
+      if (!first) std::memcpy(c.s->box, carry.box, sizeof carry.box);
+      continue;
+    }
+    if (rc) return rc;
+    carry = e->h_sc[0];
+    std::memcpy(c.s->box, carry.box, sizeof carry.box);
+    done += len;
+    first = false;
+  }
+  if (lavg)
+    for (int d = 0; d < 3; d++) lavg[d] = carry.nlwin > 0 ? carry.lrun[d] / carry.nlwin : c.s->box[3 + d] - c.s->box[d];
+  return SCEMA_MD_OK;
+}
+// change_box all x final 0 lx y final 0 ly z final 0 lz remap (tilts kept)
+int equil_change_box(EquilCtx &c, const double len[3]) {
+  scema_md_engine *e = c.e;
+  double bb[18];
+  std::memcpy(bb, c.s->box, 9 * sizeof(double));
+  std::memcpy(bb + 9, c.s->box, 9 * sizeof(double));
+  for (int d = 0; d < 3; d++) { bb[9 + d] = 0.0; bb[9 + 3 + d] = len[d]; }
+  HIPCHK(e->d_boxpair.ensure(sizeof bb));
+  HIPCHK(hipMemcpyAsync(e->d_boxpair.p, bb, sizeof bb, hipMemcpyHostToDevice, e->stream));
+  mdk_change_box(e->stream, c.s->x.as<double>(), c.s->topo->natoms, e->d_boxpair.as<double>(), e->d_boxpair.as<double>() + 9);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  std::memcpy(c.s->box, bb + 9, 9 * sizeof(double));
+  return SCEMA_MD_OK;
+}
+}  // namespace
+
+// test hooks: one minimisation / one thermostatted (barostatted) run on a stored state
+int scema_md_debug_minimize(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double etol, double ftol, int32_t maxiter,
+                            int32_t maxeval, double *info) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  if (qp_id == SCEMA_MD_QP_NONE) return fail(e, SCEMA_MD_ERR_ARG, "debug_minimize needs a stored state (scema_md_set_state first)");
+  State *s = find_state(e, qp_id, matid, replica);
+  if (!s) return fail(e, SCEMA_MD_ERR_NOSTATE, "no state for qp %d", (int)qp_id);
+  EquilCtx c{e, s, DevBuf(), DevBuf()};
+  int stop = -1;
+  double inf[4] = {0, 0, 0, 0};
+  const int rc = equil_minimize(c, etol, ftol, maxiter, maxeval, &stop, inf);
+  if (rc) return rc;
+  if (info) { info[0] = stop; for (int k = 0; k < 4; k++) info[1 + k] = inf[k]; }
+  return SCEMA_MD_OK;
+}
+int scema_md_debug_run_nh(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t nsteps, double dt, double t_start,
+                          double t_stop, int32_t npt, double p_target, double p_period, double *lavg) {
+  if (!e || nsteps < 0) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  if (qp_id == SCEMA_MD_QP_NONE) return fail(e, SCEMA_MD_ERR_ARG, "debug_run_nh needs a stored state (scema_md_set_state first)");
+  State *s = find_state(e, qp_id, matid, replica);
+  if (!s) return fail(e, SCEMA_MD_ERR_NOSTATE, "no state for qp %d", (int)qp_id);
+  EquilCtx c{e, s, DevBuf(), DevBuf()};
+  return equil_run_nh(c, nsteps, dt, t_start, t_stop, npt != 0, p_target, p_period, lavg);
+}
+
+int scema_md_equilibrate(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_equilparams *p, double length[3], double *info) {
+  if (!e || !p || !length) return SCEMA_MD_ERR_ARG;
+  HIPCHK(hipSetDevice(e->p.device));
+  Topo *t = find_topo(e, matid, replica);
+  if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered", matid ? matid : "", (int)replica);
+  if (p->nsteps_equil < 2 || p->timestep_length <= 0.0 || p->temperature <= 0.0)
+    return fail(e, SCEMA_MD_ERR_ARG, "equilibrate: nsteps_equil >= 2, timestep_length > 0, temperature > 0 required");
+  const int ns = p->nsteps_equil;
+  const double dt = p->timestep_length, tempt = p->temperature;
+  // in.init.lammps:48: velocity all create 200.0 ${sseed} rot yes dist gaussian (sseed = 1234, init_material_problem.h:167)
+  std::vector<double> v0;
+  velocity_create(*t, t->init_x, 200.0, p->seed ? (unsigned long long)p->seed : 1234ull, v0);
+  std::unique_ptr<State> st;
+  int rc = make_state(e, t, t->init_box, t->init_x.data(), v0.data(), false, st);
+  if (rc) return rc;
+  EquilCtx c{e, st.get(), DevBuf(), DevBuf()};
+  int stop = -1;
+  double minfo[4] = {0, 0, 0, 0}, lav[3];
+  // :54-58 min_style sd ; minimize 1.0e-7 1.0e-11 ${nsi} 50000
+  if ((rc = equil_minimize(c, 1.0e-7, 1.0e-11, ns, 50000, &stop, minfo))) return rc;
+  // :105-215 the heat-up / cool-down schedule (fix shake is commented out in the script)
+  if ((rc = equil_run_nh(c, ns, dt, 300.0, 300.0, false, 0.0, 1000.0, nullptr))) return rc;
+  if ((rc = equil_run_nh(c, ns, dt, 300.0, 500.0, true, 1.0, 1000.0, nullptr))) return rc;
+  if ((rc = equil_run_nh(c, 5 * ns, dt, 500.0, 500.0, true, 1.0, 1000.0, nullptr))) return rc;
+  if ((rc = equil_run_nh(c, ns, dt, 500.0, tempt, true, 1.0, 1000.0, nullptr))) return rc;
+  if ((rc = equil_run_nh(c, 2 * ns, dt, tempt, tempt, true, 1.0, 1000.0, lav))) return rc;
+  if ((rc = equil_change_box(c, lav))) return rc;
+  if ((rc = equil_run_nh(c, 20 * ns, dt, tempt, tempt, false, 0.0, 1000.0, nullptr))) return rc;
+  if ((rc = equil_run_nh(c, 2 * ns, dt, tempt, tempt, true, 1.0, 1000.0, lav))) return rc;
+  if ((rc = equil_change_box(c, lav))) return rc;
+  if ((rc = equil_run_nh(c, ns, dt, tempt, tempt, false, 0.0, 1000.0, nullptr))) return rc;
+  // the equilibrated state becomes the replica's initial state (what write_restart init.<mat>_<rep>.bin keeps, :208-210)
+  std::memcpy(t->init_box, st->box, sizeof t->init_box);
+  t->init_v.assign(3 * (size_t)t->natoms, 0.0);
+  HIPCHK(hipMemcpy(t->init_x.data(), st->x.p, 3 * (size_t)t->natoms * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(t->init_v.data(), st->v.p, 3 * (size_t)t->natoms * 8, hipMemcpyDeviceToHost));
+  for (int d = 0; d < 3; d++) length[d] = st->box[3 + d] - st->box[d];
+  if (info) { info[0] = stop; for (int k = 0; k < 4; k++) info[1 + k] = minfo[k]; }
   return SCEMA_MD_OK;
 }
 

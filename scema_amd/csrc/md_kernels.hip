@@ -24,69 +24,14 @@
 
 
 // ------------------------------------------------------------------------------------------
-// Nose-Hoover chain half step (fix nvt; one sub-cycle, no drag).  Returns the velocity factor.
-// ------------------------------------------------------------------------------------------
-__device__ double nhc_half(const SimDev &S, SimScalars &sc) {
-  const int mt = S.t_chain;
-  const double dt = S.dt, dthalf = 0.5 * dt, dt4 = 0.25 * dt, dt8 = 0.125 * dt;
-  const double t_target = S.t_target;
-  const double ke_target = S.tdof * MD_BOLTZ * t_target;
-  double kecurrent = S.tdof * MD_BOLTZ * sc.t_current;
-  const double tf2 = S.t_freq * S.t_freq;
-  sc.eta_mass[0] = S.tdof * MD_BOLTZ * t_target / tf2;
-  for (int k = 1; k < mt; k++) sc.eta_mass[k] = MD_BOLTZ * t_target / tf2;
-  sc.eta_dotdot[0] = (sc.eta_mass[0] > 0.0) ? (kecurrent - ke_target) / sc.eta_mass[0] : 0.0;
-  double expfac;
-  for (int k = mt - 1; k > 0; k--) {
-    expfac = exp(-dt8 * sc.eta_dot[k + 1]);
-    sc.eta_dot[k] *= expfac;
-    sc.eta_dot[k] += sc.eta_dotdot[k] * dt4;
-    sc.eta_dot[k] *= expfac;
-  }
-  expfac = exp(-dt8 * sc.eta_dot[1]);
-  sc.eta_dot[0] *= expfac;
-  sc.eta_dot[0] += sc.eta_dotdot[0] * dt4;
-  sc.eta_dot[0] *= expfac;
-  const double factor = exp(-dthalf * sc.eta_dot[0]);
-  sc.t_current *= factor * factor;
-  kecurrent = S.tdof * MD_BOLTZ * sc.t_current;
-  sc.eta_dotdot[0] = (sc.eta_mass[0] > 0.0) ? (kecurrent - ke_target) / sc.eta_mass[0] : 0.0;
-  for (int k = 0; k < mt; k++) sc.eta[k] += dthalf * sc.eta_dot[k];
-  sc.eta_dot[0] *= expfac;
-  sc.eta_dot[0] += sc.eta_dotdot[0] * dt4;
-  sc.eta_dot[0] *= expfac;
-  for (int k = 1; k < mt; k++) {
-    expfac = exp(-dt8 * sc.eta_dot[k + 1]);
-    sc.eta_dot[k] *= expfac;
-    sc.eta_dotdot[k] = (sc.eta_mass[k - 1] * sc.eta_dot[k - 1] * sc.eta_dot[k - 1] - MD_BOLTZ * t_target) / sc.eta_mass[k];
-    sc.eta_dot[k] += sc.eta_dotdot[k] * dt4;
-    sc.eta_dot[k] *= expfac;
-  }
-  return factor;
-}
-
-__device__ void box_corners(const double *box, double *c /*24*/) {
-  BoxD b;
-  box_derive(box, b);
-  int k = 0;
-  for (int iz = 0; iz < 2; iz++)
-    for (int iy = 0; iy < 2; iy++)
-      for (int ix = 0; ix < 2; ix++) {
-        c[3 * k + 0] = b.h[0] * ix + b.h[5] * iy + b.h[4] * iz + b.lo[0];
-        c[3 * k + 1] = b.h[1] * iy + b.h[3] * iz + b.lo[1];
-        c[3 * k + 2] = b.h[2] * iz + b.lo[2];
-        k++;
-      }
-}
-
-// ------------------------------------------------------------------------------------------
 // k_phase_init : start of a "run": thermostat reset, accumulators, forced rebuild
 // ------------------------------------------------------------------------------------------
 __global__ void k_phase_init(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.x];
   SimScalars &sc = *S.sc;
   if (threadIdx.x == 0) {
-    for (int k = 0; k <= MD_MAXCHAIN; k++) sc.eta[k] = sc.eta_dot[k] = sc.eta_dotdot[k] = sc.eta_mass[k] = 0.0;
+    if (!sc.keep_nh)   // a fresh fix starts from zero; a run issued in segments (md_equil.hip) keeps its thermostat
+      for (int k = 0; k <= MD_MAXCHAIN; k++) sc.eta[k] = sc.eta_dot[k] = sc.eta_dotdot[k] = sc.eta_mass[k] = 0.0;
     for (int k = 0; k < 9; k++) { sc.box0[k] = sc.box[k]; sc.box_prev[k] = sc.box[k]; }
     for (int k = 0; k < 6; k++) { sc.psum[k] = 0.0; sc.ke[k] = 0.0; }
     for (int k = 0; k < MD_NPART * 6; k++) sc.vir[k] = 0.0;

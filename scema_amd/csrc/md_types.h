@@ -72,6 +72,21 @@ struct SimScalars {
   int need_far;        // this step some atom moved >= sqrt(far_dsq): k_pair walks segment C2 too
   int maxj_seen;       // largest tile j table at the last builds
   int nbuilds;
+  // ---- init_material's equilibration schedule only (md_equil.hip): fix npt ... iso, temperature ramps, min_style sd ----
+  int keep_nh;         // set by the host before the upload: this run continues the previous one (thermostat/barostat state, step count kept)
+  int nh_step;         // steps done of the whole fix (a run may be issued in segments: the cell grid follows the box)
+  double t_target_now; // thermostat target of the current step (ramp t_start -> t_stop over nh_total steps)
+  double omega_dot, omega_mass, mtk_term2;   // barostat (iso: the three box dimensions share one rate)
+  double etap[MD_MAXCHAIN + 1], etap_dot[MD_MAXCHAIN + 1], etap_dotdot[MD_MAXCHAIN + 1], etap_mass[MD_MAXCHAIN + 1];
+  double dil;          // exp(dt/2 omega_dot) of the current step: each of the two half-step remaps dilates by it
+  double cen[3];       // centre of the dilation (box centre)
+  double len0[3];      // box lengths at the start of the segment (the cell grid holds for +-box_margin around them)
+  double lsum[3], lrun[3];   // fix ave/time of the box lengths: window sum, sum of window means
+  int nlwin, pad1_;
+  // minimiser state (one line search at a time, decided on the device between two force evaluations)
+  int min_phase, min_stop, min_iter, min_neval, min_newdir, pad2_;
+  double min_alpha, min_alphamax, min_fdothall, min_eorig, min_eprev, min_fhprev, min_engprev, min_alphaprev, min_fh_trial, min_ecur, min_einit;
+  double min_dots[4];  // f.h, f.f, max |f| of the last evaluation (+ spare)
 #ifdef PAIR_TIMING
   unsigned long long dbg[8];
 #endif
@@ -89,6 +104,14 @@ struct SimDev {
   int nav, nwin;              // fix ave/time windows (0 = no sampling)
   int nvt, use_shake, deform;
   int t_chain, neigh_delay, shake_maxiter;
+  // equilibration schedule only (md_equil.hip)
+  int npt;                    // 1: fix npt ... iso, 0: fix nvt; both with the ramp below
+  int ramp;                   // 1: thermostat target from t_start/t_stop (else t_target)
+  int nh_total;               // steps of the whole fix (ramp denominator)
+  int lavg_nav;               // > 0: average the box lengths over windows of this many steps
+  double t_start, t_stop, p_target, p_freq, box_margin;
+  double min_etol, min_ftol, min_dmax;
+  int min_maxiter, min_maxeval;
   // scalars
   double dt, t_target, t_freq, tdof, g_ewald, qsqsum, qsum;
   double cut_lj2, cut_coul2, rlist2, skin, excl_cut2, shake_tol;

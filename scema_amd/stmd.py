@@ -10,7 +10,7 @@ import numpy as np
 from . import capi
 
 SYMBOLS = ["scema_stmd_create", "scema_stmd_destroy", "scema_stmd_last_error", "scema_stmd_init", "scema_stmd_set_lammps_state_files", "scema_stmd_set_md_procs",
-           "scema_stmd_update", "scema_stmd_replica_data", "scema_eqmd_equil"]
+           "scema_stmd_update", "scema_stmd_replica_data", "scema_eqmd_equil", "scema_eqmd_equil_full"]
 
 
 class QP(C.Structure):
@@ -159,6 +159,22 @@ def eqmd_equil(engine: "capi.Engine", cmat: str, folder: str, rep: int, *, mdts=
     rc = capi.lib().scema_eqmd_equil(engine.h, cmat.encode(), (base + ".length").encode(), (base + ".stress").encode(),
                                      (base + ".stiff").encode(), C.c_int32(rep), C.c_double(mdts), C.c_double(mdtem), C.c_int32(mdnss),
                                      C.c_double(mdss), C.c_double(mdsa), mdff.encode(), err, C.c_int32(512))
+    if rc != 0:
+        raise capi.EngineError(f"eqmd_equil rc={rc}: {err.value.decode()}")
+    return base
+
+
+def eqmd_equil_full(engine: "capi.Engine", cmat: str, slocin: str, folder: str, rep: int, *, mdts=2.0, mdtem=300.0, mdnss=100, mdnse=1000,
+                    mdss=1e-4, mdsa=0.005, mdff="opls", qplogloc="", scrloc=""):
+    """EQMDProblem::equil with the reference's argument list: if <folder>/init.<cmat>_<rep>.bin is missing, the replica is read
+    from <slocin>/<cmat>_<rep>.data and equilibrated (in.init.lammps on the GPU), then the three init.* files are written."""
+    import os
+    base = os.path.join(folder, f"init.{cmat}_{rep}")
+    err = C.create_string_buffer(512)
+    rc = capi.lib().scema_eqmd_equil_full(engine.h, cmat.encode(), slocin.encode(), qplogloc.encode(), scrloc.encode(), (base + ".length").encode(),
+                                          (base + ".stress").encode(), (base + ".stiff").encode(), (base + ".bin").encode(), C.c_int32(rep),
+                                          C.c_double(mdts), C.c_double(mdtem), C.c_int32(mdnss), C.c_int32(mdnse), C.c_double(mdss), C.c_double(mdsa),
+                                          mdff.encode(), err, C.c_int32(512))
     if rc != 0:
         raise capi.EngineError(f"eqmd_equil rc={rc}: {err.value.decode()}")
     return base
