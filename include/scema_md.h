@@ -222,6 +222,13 @@ int scema_md_load_state_file(scema_md_engine *e, int32_t qp_id, const char *mati
 int scema_md_save_state_lammps(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path,
                                double timestep, int64_t ntimestep);
 
+/* the state as a LAMMPS text dump `id type xs ys zs vx vy vz ix iy iz` (what the reax branch of the reference writes as
+ * last.<qp>.* / lcts.<qp>.*, stmd_problem.h:261-264,270-272, and re-reads with `rerun ... dump x y z vx vy vz ix iy iz box yes
+ * scaled yes`, :190-194); read back by scema_md_load_state_file.  precise 0: LAMMPS' default "%g" columns (six digits, what the
+ * reference's files hold); != 0: 17 digits (exact round trip). */
+int scema_md_save_state_dump(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path,
+                             int64_t ntimestep, int32_t precise);
+
 /* ---- init_material: the quantities EQMDProblem::lammps_equilibration derives from an equilibrated
  * replica (init_material_problem.h:196-300): box lengths, initial stress (ELASTIC/in.homogenization.lammps: NVT + SHAKE
  * sampling) and the stiffness tensor by +-strain_ampl finite strains in the six directions (ELASTIC/in.modulus.lammps,

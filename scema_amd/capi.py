@@ -32,7 +32,7 @@ SYMBOLS = [
     "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_state_owner", "scema_md_last_plan",
     "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update",
-    "scema_md_replica_natoms", "scema_md_save_replica_file", "scema_md_equilibrate", "scema_md_debug_minimize", "scema_md_debug_run_nh",
+    "scema_md_save_state_dump", "scema_md_replica_natoms", "scema_md_save_replica_file", "scema_md_equilibrate", "scema_md_debug_minimize", "scema_md_debug_run_nh",
     "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_debug_compute", "scema_md_reax_stats",
 ]
 COMM_ID_BYTES = 128
@@ -374,6 +374,10 @@ class Engine:
     def save_state_lammps(self, qp, matid, replica, path, timestep=2.0, ntimestep=0):
         self._chk(lib().scema_md_save_state_lammps(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), path.encode(),
                                                    C.c_double(timestep), C.c_int64(ntimestep)))
+
+    def save_state_dump(self, qp, matid, replica, path, ntimestep=0, precise=True):
+        self._chk(lib().scema_md_save_state_dump(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), path.encode(), C.c_int64(ntimestep),
+                                                 C.c_int32(1 if precise else 0)))
 
     def load_state_file(self, qp, matid, replica, path):
         self._chk(lib().scema_md_load_state_file(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica), path.encode()))

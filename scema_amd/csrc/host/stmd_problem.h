@@ -95,9 +95,12 @@ class STMDProblem {
         const std::string tail = std::to_string(sims[i]->qp_id) + "." + sims[i]->matid + "_" + std::to_string(sims[i]->replica) + ".dump";
         // reference stmd_problem.h:258: last.<qp>.<mat>_<rep>.dump after the straining run (here: the state after the
         // evaluation; kept in HBM anyway, written only on request)
+        // the reax branch exchanges states as text dumps (stmd_problem.h:261-264), the opls branch as binary restarts (:258)
+        const bool reax = sims[i]->force_field == "reax";
         if (lammps_states_ && !sims[i]->output_folder.empty()) {
-          rc = scema_md_save_state_lammps(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica,
-                                          (sims[i]->output_folder + "/last." + tail).c_str(), sims[i]->timestep_length, 0);
+          const std::string last = sims[i]->output_folder + "/last." + tail;
+          rc = reax ? scema_md_save_state_dump(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, last.c_str(), 0, 1)
+                    : scema_md_save_state_lammps(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, last.c_str(), sims[i]->timestep_length, 0);
           if (rc != SCEMA_MD_OK) {
             err_ = scema_md_last_error(engine_);
             return rc;
@@ -106,8 +109,9 @@ class STMDProblem {
         // reference stmd_problem.h:266-273: lcts.<qp>.<mat>_<rep>.dump every "checkpoint frequency" steps
         if (sims[i]->checkpoint && !sims[i]->restart_folder.empty()) {
           const std::string path = sims[i]->restart_folder + "/lcts." + tail;
-          rc = lammps_states_ ? scema_md_save_state_lammps(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, path.c_str(), sims[i]->timestep_length, 0)
-                              : scema_md_save_state_file(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, path.c_str());
+          rc = !lammps_states_ ? scema_md_save_state_file(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, path.c_str())
+               : reax        ? scema_md_save_state_dump(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, path.c_str(), 0, 1)
+                             : scema_md_save_state_lammps(engine_, sims[i]->qp_id, sims[i]->matid.c_str(), sims[i]->replica, path.c_str(), sims[i]->timestep_length, 0);
           if (rc != SCEMA_MD_OK) {
             err_ = scema_md_last_error(engine_);
             return rc;

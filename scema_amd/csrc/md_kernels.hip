@@ -411,6 +411,9 @@ __device__ __forceinline__ void atom_phase(const SimDev &S, const BoxD &b, int a
 // serialise per address: the atoms of a simulation are therefore spread over only EW_PARTS blocks, each walking
 // its share of the atoms in chunks of EW_ATOMS and keeping the partial sums in registers.
 #define EW_PARTS 16
+// NR = rounds of groups per thread: thread gi owns the groups gi, gi + gthreads, ... (NR of them), so that k sets of up to
+// NR * 256 groups (replicas of a few 10^4 atoms at the reference's accuracy) stay on the table path
+template <int NR>
 __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_MAXM, int gthreads) {
   const SimDev &S = sims[blockIdx.y];
   if (S.nk == 0) return;
@@ -420,17 +423,24 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_M
   const int nchunk = (S.natoms + EW_ATOMS - 1) / EW_ATOMS;
   // gthreads threads span the groups; the block's nsplit = blockDim / gthreads thread sets interleave the atoms
   const int nsplit = blockDim.x / gthreads, part = threadIdx.x / gthreads;
-  const int gi = threadIdx.x % gthreads;   // the fast path covers ngrp <= gthreads (checked by the launch)
-  int n1 = 0, m2 = 0, m3 = 0, kpp = -1, kmp = -1, kpm = -1, kmm = -1;
-  if (gi < S.ngrp) {
-    const int4 Ga = ((const int4 *)S.kgrp)[2 * gi], Gb = ((const int4 *)S.kgrp)[2 * gi + 1];
-    n1 = Ga.x; m2 = Ga.y; m3 = Ga.z;
-    kpp = Ga.w; kmp = Gb.x; kpm = Gb.y; kmm = Gb.z;
-  }
+  const int gi = threadIdx.x % gthreads;
+  int n1[NR], m2[NR], m3[NR], kpp[NR], kmp[NR], kpm[NR], kmm[NR];
   // exp(i(t1 +- t2 +- t3)) of the up to four members of a group are linear combinations of the eight real products
   // {cos,sin}(t1) {cos,sin}(t2) {cos,sin}(t3): those are what is summed over the atoms (4 products + 8 FMAs per atom and
   // group, the charge folded into the first table), and combined once at the end
-  double T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0, T5 = 0, T6 = 0, T7 = 0;   // ccc ccs csc css scc scs ssc sss
+  double T[NR][8];   // ccc ccs csc css scc scs ssc sss
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    n1[r] = 0; m2[r] = 0; m3[r] = 0; kpp[r] = -1; kmp[r] = -1; kpm[r] = -1; kmm[r] = -1;
+    const int g = r * gthreads + gi;
+    if (g < S.ngrp) {
+      const int4 Ga = ((const int4 *)S.kgrp)[2 * g], Gb = ((const int4 *)S.kgrp)[2 * g + 1];
+      n1[r] = Ga.x; m2[r] = Ga.y; m3[r] = Ga.z;
+      kpp[r] = Ga.w; kmp[r] = Gb.x; kpm[r] = Gb.y; kmm[r] = Gb.z;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) T[r][q] = 0.0;
+  }
   BoxD b;
   box_derive(S.sc->box, b);
   for (int ch = blockIdx.x; ch < nchunk; ch += EW_PARTS) {
@@ -458,23 +468,30 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_M
     __syncthreads();
     if (gi < S.ngrp)
       for (int la = part; la < na; la += nsplit) {
-        const double2 e1 = s_tab[la * MS + n1];
-        const double2 e2 = s_tab[la * MS + EW_MAXM + m2];
-        const double2 e3 = s_tab[la * MS + 2 * EW_MAXM + m3];
-        const double cc = e1.x * e2.x, cs = e1.x * e2.y, sc_ = e1.y * e2.x, ss = e1.y * e2.y;
-        T0 = fma(cc, e3.x, T0); T1 = fma(cc, e3.y, T1); T2 = fma(cs, e3.x, T2); T3 = fma(cs, e3.y, T3);
-        T4 = fma(sc_, e3.x, T4); T5 = fma(sc_, e3.y, T5); T6 = fma(ss, e3.x, T6); T7 = fma(ss, e3.y, T7);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+          const double2 e1 = s_tab[la * MS + n1[r]];
+          const double2 e2 = s_tab[la * MS + EW_MAXM + m2[r]];
+          const double2 e3 = s_tab[la * MS + 2 * EW_MAXM + m3[r]];
+          const double cc = e1.x * e2.x, cs = e1.x * e2.y, sc_ = e1.y * e2.x, ss = e1.y * e2.y;
+          T[r][0] = fma(cc, e3.x, T[r][0]); T[r][1] = fma(cc, e3.y, T[r][1]); T[r][2] = fma(cs, e3.x, T[r][2]); T[r][3] = fma(cs, e3.y, T[r][3]);
+          T[r][4] = fma(sc_, e3.x, T[r][4]); T[r][5] = fma(sc_, e3.y, T[r][5]); T[r][6] = fma(ss, e3.x, T[r][6]); T[r][7] = fma(ss, e3.y, T[r][7]);
+        }
       }
   }
   // Re = ccc - s2 s3 css - s2 ssc - s3 scs ; Im = scc + s2 csc + s3 ccs - s2 s3 sss  (s2, s3 = signs of n2, n3)
   // all indices are in registers: the atomics go out back to back
   double *sf = S.sfac;
-  if (kpp >= 0) { atomicAdd(&sf[2 * kpp], T0 - T3 - T6 - T5); atomicAdd(&sf[2 * kpp + 1], T4 + T2 + T1 - T7); }
-  if (kmp >= 0) { atomicAdd(&sf[2 * kmp], T0 + T3 + T6 - T5); atomicAdd(&sf[2 * kmp + 1], T4 - T2 + T1 + T7); }
-  if (kpm >= 0) { atomicAdd(&sf[2 * kpm], T0 + T3 - T6 + T5); atomicAdd(&sf[2 * kpm + 1], T4 + T2 - T1 + T7); }
-  if (kmm >= 0) { atomicAdd(&sf[2 * kmm], T0 - T3 + T6 + T5); atomicAdd(&sf[2 * kmm + 1], T4 - T2 - T1 - T7); }
-  // more groups than threads (very large k sets): the rest one group at a time, tables rebuilt per chunk
-  for (int g2 = gthreads + (int)threadIdx.x; g2 < S.ngrp; g2 += blockDim.x) {
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const double T0 = T[r][0], T1 = T[r][1], T2 = T[r][2], T3 = T[r][3], T4 = T[r][4], T5 = T[r][5], T6 = T[r][6], T7 = T[r][7];
+    if (kpp[r] >= 0) { atomicAdd(&sf[2 * kpp[r]], T0 - T3 - T6 - T5); atomicAdd(&sf[2 * kpp[r] + 1], T4 + T2 + T1 - T7); }
+    if (kmp[r] >= 0) { atomicAdd(&sf[2 * kmp[r]], T0 + T3 + T6 - T5); atomicAdd(&sf[2 * kmp[r] + 1], T4 - T2 + T1 + T7); }
+    if (kpm[r] >= 0) { atomicAdd(&sf[2 * kpm[r]], T0 + T3 - T6 + T5); atomicAdd(&sf[2 * kpm[r] + 1], T4 + T2 - T1 + T7); }
+    if (kmm[r] >= 0) { atomicAdd(&sf[2 * kmm[r]], T0 - T3 + T6 + T5); atomicAdd(&sf[2 * kmm[r] + 1], T4 - T2 - T1 - T7); }
+  }
+  // more groups than NR * gthreads (huge k sets): the rest one group at a time, phases recomputed per atom
+  for (int g2 = NR * gthreads + (int)threadIdx.x; g2 < S.ngrp; g2 += blockDim.x) {
     const int *G = S.kgrp + 8 * g2;
     for (int mm = 0; mm < 4; mm++) {
       const int k = G[3 + mm];
@@ -920,10 +937,16 @@ void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax
   // more than 64 KB of dynamic LDS needs an explicit opt-in (large k ranges: small cut_coul or tight accuracy)
   static size_t optin_tab[16] = {0};
   size_t &optin_s = lds_optin_slot(optin_tab);
-  if (lds_s > 64 * 1024 && lds_s > optin_s) { (void)hipFuncSetAttribute((const void *)k_ewald_sfac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); optin_s = lds_s; }
-  // threads own groups of k-vectors: the block size that wastes the fewest lanes
+  // threads own groups of k-vectors: the block size that wastes the fewest lanes; beyond 256 groups several per thread
   const int gthreads = maxgrp <= 64 ? 64 : (maxgrp <= 128 ? 128 : 256);
-  hipLaunchKernelGGL(k_ewald_sfac, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
+  const int rounds = maxgrp <= 256 ? 1 : (maxgrp <= 512 ? 2 : 4);
+  const void *fn = rounds == 1 ? (const void *)k_ewald_sfac<1> : rounds == 2 ? (const void *)k_ewald_sfac<2> : (const void *)k_ewald_sfac<4>;
+  static size_t optin_tab2[16] = {0}, optin_tab4[16] = {0};
+  size_t &optin_r = rounds == 1 ? optin_s : lds_optin_slot(rounds == 2 ? optin_tab2 : optin_tab4);
+  if (lds_s > 64 * 1024 && lds_s > optin_r) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); optin_r = lds_s; }
+  if (rounds == 1) hipLaunchKernelGGL(k_ewald_sfac<1>, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
+  else if (rounds == 2) hipLaunchKernelGGL(k_ewald_sfac<2>, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
+  else hipLaunchKernelGGL(k_ewald_sfac<4>, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
   hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
 }
 // part 2: per-atom reciprocal force; also assembles f from the pair and bonded forces (runs even without charges)

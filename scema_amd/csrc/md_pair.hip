@@ -815,7 +815,9 @@ static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int
 }
 
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly) {
-  if (npoly <= 10) launch_pair<10>(st, d, ns, maxcells, capj, vir, eng);
+  if (npoly <= 6) launch_pair<6>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 8) launch_pair<8>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 10) launch_pair<10>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 14) launch_pair<14>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 16) launch_pair<16>(st, d, ns, maxcells, capj, vir, eng);

@@ -386,3 +386,22 @@ def test_persistent_state_shears_across_the_flip_over_several_updates(small_pe):
     bx, _, _ = e.get_state(1, "pe", 1)
     assert abs(bx[6]) <= 0.5 * (bx[3] - bx[0]) * 1.02
     e.close()
+
+
+@pytest.mark.parametrize("acc,min_groups", [(3e-6, 257), (1e-6, 513), (3e-10, 1025)])
+def test_large_k_sets_stay_on_the_table_path(small_pe, acc, min_groups):
+    """replicas of a few 10^4 atoms at the reference's accuracy have more k-vector groups than a workgroup has threads (256):
+    threads then own 2 or 4 groups each (beyond 1024 groups the rest takes the plain path).  Same reciprocal energy, virial and forces as the oracle's plain sum."""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=acc)
+    e = capi.Engine(capi.default_params(**kw))
+    e.register_replica("pe", 1, small_pe)
+    f, en, w, info = e.debug_compute("pe", 1, use_shake=False)
+    o = po.Oracle(small_pe, po.default_params(**kw))
+    o.setup(False)
+    fo, eo, wo = o.compute()
+    assert info["nk"] == o.nkvec and info["nk"] > 3.2 * min_groups        # about 4 k-vectors per group
+    assert abs(en[6] - eo[6]) < 1e-10 * abs(eo[6]) and np.abs(w[6] - wo[6]).max() < 1e-10 * np.abs(wo[6]).max()
+    assert np.abs(f - fo).max() < 1e-10 * np.abs(fo).max()
+    e.close()
