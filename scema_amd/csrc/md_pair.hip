@@ -146,9 +146,11 @@ struct ClusterI {
   int atom[NI];   // real atom index or -1 (pad)
 };
 
-extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists: segment B from the front, C1 from the back
+extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists (segment B from the front, C1 from the back), then
+                                  // [NQ][qcap] 16-bit table indices: the part of the table each quarter of the cell's clusters can reach
+#define NQ 4
 
-__global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB) {
+__global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap) {
   int sim, cell;
   if (!xcd_map(ntiles, nsims, sim, cell)) return;
   const SimDev &S = sims[sim];
@@ -168,7 +170,11 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
   __shared__ int s_wcnt[TW];
   __shared__ int s_cost[64];
   __shared__ int s_ex[TW][NI * 16];   // exclusion lists of the cluster a wave is working on (first 16 per atom)
+  __shared__ double s_qbox[NQ][6];    // bounding boxes of the quarters of the cell's clusters (k-d order: quarters are compact)
+  __shared__ int s_qcnt[NQ][TW];
+  __shared__ int s_qn[NQ];            // entries of a quarter's list; -1: list overflowed, the quarter walks the whole table
   int *s_jtab = s_build;
+  unsigned short *s_qlist = (unsigned short *)(s_build + capj + TW * capB);
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int *lb = s_build + capj + wave * capB;
@@ -266,6 +272,80 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
     for (int l = threadIdx.x; l < nj; l += TT) gj[l] = s_jtab[l];
     if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
   }
+  // ---- phase 1b: which table entries can each quarter of the cell's clusters reach at all? ----
+  // A cluster tests the table with 4 atoms x 64 lanes per chunk whatever the outcome; 61 % of a cell's table is out of reach
+  // of a given cluster.  The clusters of a cell are in k-d order, so a quarter of them is a compact region: entries farther
+  // than rlist from its bounding box are left out of its list (conservative: no atom of the quarter can list them) and its
+  // clusters walk the list instead of the table.  Lists keep table order, so rows come out exactly as before.
+  const int nclus_cell = nown / NI;
+  if (wave < NQ) {
+    const int c_lo = (wave * nclus_cell) / NQ, c_hi = ((wave + 1) * nclus_cell) / NQ;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int sl = cs + c_lo * NI + lane; sl < cs + c_hi * NI; sl += 64)
+      if (S.perm[sl] >= 0) {
+        const double x = xq[2 * (size_t)sl], y = xq[2 * (size_t)sl + 1], z = zq[2 * (size_t)sl];
+        lo[0] = fmin(lo[0], x); hi[0] = fmax(hi[0], x);
+        lo[1] = fmin(lo[1], y); hi[1] = fmax(hi[1], y);
+        lo[2] = fmin(lo[2], z); hi[2] = fmax(hi[2], z);
+      }
+    for (int d = 0; d < 3; d++) {
+      const double l = wave_min(lo[d]), h = wave_max(hi[d]);
+      if (lane == 0) { s_qbox[wave][d] = l; s_qbox[wave][3 + d] = h; }
+    }
+  }
+  __syncthreads();
+  {
+    int qn[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) qn[q] = 0;
+    for (int base = 0; base < nj; base += TT) {
+      const int l = base + threadIdx.x;
+      bool ok[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) ok[q] = false;
+      if (l < nj) {
+        const int jt = s_jtab[l];
+        const size_t j = (size_t)(jt & MD_JMASK);
+        const int code = jt >> 23;
+        const double xj = xq[2 * j] + s_shift[3 * code], yj = xq[2 * j + 1] + s_shift[3 * code + 1], zj = zq[2 * j] + s_shift[3 * code + 2];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const double ex = fmax(0.0, fmax(s_qbox[q][0] - xj, xj - s_qbox[q][3])), ey = fmax(0.0, fmax(s_qbox[q][1] - yj, yj - s_qbox[q][4])),
+                       ez = fmax(0.0, fmax(s_qbox[q][2] - zj, zj - s_qbox[q][5]));
+          ok[q] = ex * ex + ey * ey + ez * ez < S.rlist2;   // an empty quarter has an inverted box: nothing passes
+        }
+      }
+      unsigned long long m[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        m[q] = __ballot(ok[q]);
+        if (lane == 0) s_qcnt[q][wave] = __popcll(m[q]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < TW; w++) {
+          const int cw = s_qcnt[q][w];
+          before += (w < wave) ? cw : 0;
+          total += cw;
+        }
+        if (ok[q]) {
+          const int pos = qn[q] + before + popc_below(m[q]);
+          if (pos < qcap) s_qlist[q * qcap + pos] = (unsigned short)l;
+        }
+        qn[q] += total;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < NQ) {
+      const int q = threadIdx.x;
+      const int n = (q == 0) ? qn[0] : (q == 1) ? qn[1] : (q == 2) ? qn[2] : qn[3];
+      s_qn[q] = (n > qcap) ? -1 : n;
+    }
+    __syncthreads();
+  }
   // ---- phase 2 ----
 #ifdef PAIR_TIMING
   const unsigned long long tb1 = __builtin_readcyclecounter();
@@ -321,31 +401,41 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
       s_ex[wave][lane] = (e < na) ? S.ex_list[ba + e] : -1;
     }
     int nA = 0, nB = 0, nC = 0, nD = 0;   // segments A, B, C1 (near skin band), C2 (far skin band)
-    // one chunk of the table ahead: entry + record of chunk r+1 are in flight while chunk r is tested
-    int jt_n = (lane < nj) ? s_jtab[lane] : 0;
+    // the part of the table this cluster's quarter can reach (or the whole table if that list overflowed)
+    int qq = 0;   // quarter q holds the clusters [q n / NQ, (q + 1) n / NQ) of the cell, as its bounding box was taken
+#pragma unroll
+    for (int q = 1; q < NQ; q++) qq += (cl - cs / NI >= (q * nclus_cell) / NQ) ? 1 : 0;
+    const int qnl = s_qn[qq];
+    const bool qall = qnl < 0;
+    const int nl = qall ? nj : qnl;
+    const unsigned short *ql = s_qlist + qq * qcap;
+    // one chunk of the list ahead: entry + record of chunk r+1 are in flight while chunk r is tested
+    int l_n = (lane < nl) ? (qall ? lane : (int)ql[lane]) : -1;
+    int jt_n = (l_n >= 0) ? s_jtab[l_n] : 0;
     double pn0, pn1, pn2;
     {
       const size_t jn = (size_t)(jt_n & MD_JMASK);
       pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
     }
-    for (int base = 0; base < nj; base += 64) {
-      const int l = base + lane;
+    for (int base = 0; base < nl; base += 64) {
+      const int l = l_n;
       const int jt = jt_n;
       const double px = pn0, py = pn1, pz = pn2;
       {
-        const int ln = l + 64;
-        jt_n = (ln < nj) ? s_jtab[ln] : 0;
+        const int in_ = base + 64 + lane;
+        l_n = (in_ < nl) ? (qall ? in_ : (int)ql[in_]) : -1;
+        jt_n = (l_n >= 0) ? s_jtab[l_n] : 0;
         const size_t jn = (size_t)(jt_n & MD_JMASK);
         pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
       }
-      // Branch-free test of the candidate against the four atoms (table entries past nj read as entry 0 and are
+      // Branch-free test of the candidate against the four atoms (lanes past the end of the list read entry 0 and are
       // masked out); only candidates inside the exclusion gate -- bonded neighbours, a few chunks per row -- take the
       // wave-uniform slow path that walks the exclusion lists.
-      const bool in = l < nj;
+      const bool in = l >= 0;
       const int j = jt & MD_JMASK;
       const int code = jt >> 23;
       const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
-      const bool own = l < nown;   // same cell, same image: each pair once, by slot order
+      const bool own = in && l < nown;   // same cell, same image: each pair once, by slot order
       {
         const double cx = bx - xj, cy = by - yj, cz = bz - zj;
         if (__ballot(in && cx * cx + cy * cy + cz * cz < breach2) == 0ull) continue;   // nothing of this chunk is in reach
@@ -786,7 +876,11 @@ static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(ns * nt
 
 size_t mdk_pair_lds_bytes(int capj) { return (size_t)capj * (3 * sizeof(double) + sizeof(int)); }
 int mdk_neigh_capB(int maxrow) { return (int)(0.6 * maxrow) / 64 * 64 + 64; }
-size_t mdk_neigh_lds_bytes(int capj, int maxrow) { return ((size_t)capj + (size_t)TW * mdk_neigh_capB(maxrow)) * sizeof(int); }
+// capacity of one quarter list (16-bit table indices): 3/4 of the table; a denser quarter walks the whole table instead
+static int neigh_qcap(int capj) { return (3 * capj / 4 + 63) / 64 * 64; }
+size_t mdk_neigh_lds_bytes(int capj, int maxrow) {
+  return ((size_t)capj + (size_t)TW * mdk_neigh_capB(maxrow)) * sizeof(int) + (size_t)NQ * neigh_qcap(capj) * sizeof(unsigned short);
+}
 
 void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int maxrow, int capj) {
   // per-wave LDS list of segment B: well over its expected share (~40 %) of a full row
@@ -795,7 +889,7 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
   static size_t optin_tab[16] = {0};  // more than 64 KB of dynamic LDS needs an explicit opt-in
   size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_neigh_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB);
+  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB, neigh_qcap(capj));
 }
 
 template <bool VIR, bool ENG, int NP>
