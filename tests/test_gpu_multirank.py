@@ -111,24 +111,46 @@ def test_without_a_communicator_a_remote_source_state_is_an_error(small_pe):
     eng.close()
 
 
-def test_rccl_calls_run_on_one_rank(small_pe):
+_RCCL_ONE = r"""
+import sys
+import numpy as np
+import torch                                           # first, as in bench.py: torch ships its own copies of the HIP runtime and of RCCL
+assert torch.cuda.is_available()
+torch.zeros(4, device="cuda").sum().item()             # torch has initialised the device and its streams
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from scema_amd import capi
+from scema_amd.systems import build_pe
+from test_gpu_multirank import KW
+d = build_pe(2, 3, 5, jitter=0.05, seed=7); d["box"][6:9] = [0.7, -0.4, 0.5]
+lens = d["box"][3:6] - d["box"][:3]
+st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+res = []
+for with_comm in (False, True):
+    eng = capi.Engine(capi.default_params(**KW))
+    if with_comm:
+        uid = eng.comm_unique_id()
+        assert len(uid) == capi.COMM_ID_BYTES
+        eng.comm_init_rccl(uid, 0, 1)
+    eng.register_replica("pe", 1, d)
+    out = eng.strain_batch([capi.make_sim(q, "pe", 1, st * (1 + 0.1 * q), nss=10, most_recent=capi.QP_NONE) for q in range(3)])
+    res.append(np.array([list(o.stress) for o in out]))
+    if with_comm:
+        assert eng.comm_stats()["allgathers"] == 1
+        eng.comm_destroy()
+    eng.close()
+assert np.abs(res[0] - res[1]).max() < 1e-9 * np.abs(res[0]).max()
+print("RCCL-ONE-RANK-OK", float(np.abs(res[0]).max()))
+"""
+
+
+def test_rccl_calls_run_on_one_rank(tmp_path):
     """ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy inside the library, on the one GPU of the test
-    box (world = 1): the stresses come back through the collective and equal the run without a communicator."""
-    from scema_amd import capi
-    lens = small_pe["box"][3:6] - small_pe["box"][:3]
-    st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
-    res = []
-    for with_comm in (False, True):
-        eng = capi.Engine(capi.default_params(**KW))
-        if with_comm:
-            uid = eng.comm_unique_id()
-            assert len(uid) == capi.COMM_ID_BYTES
-            eng.comm_init_rccl(uid, 0, 1)
-        eng.register_replica("pe", 1, small_pe)
-        out = eng.strain_batch([capi.make_sim(q, "pe", 1, st * (1 + 0.1 * q), nss=10, most_recent=capi.QP_NONE) for q in range(3)])
-        res.append(np.array([list(o.stress) for o in out]))
-        if with_comm:
-            assert eng.comm_stats()["allgathers"] == 1
-            eng.comm_destroy()
-        eng.close()
-    assert np.abs(res[0] - res[1]).max() < 1e-9 * np.abs(res[0]).max()
+    box (world = 1): the stresses come back through the collective and equal the run without a communicator.  In a process
+    of its own with torch loaded FIRST, as bench.py does it: torch ships its own copies of the HIP runtime and of RCCL, and
+    the library has to work with whichever the loader already holds."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_one.py"
+    script.write_text(_RCCL_ONE)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
