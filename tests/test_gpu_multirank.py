@@ -63,11 +63,13 @@ dist.barrier(); eng.close(); dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_follow_their_states_and_move_them_when_needed(tmp_path, small_pe):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_follow_their_states_and_move_them_when_needed(tmp_path, small_pe, world):
+    """two and four ranks sharing the test box's one GPU over the host transport (the box allows six processes on its card)"""
     from scema_amd import capi
     (tmp_path / "worker.py").write_text(WORKER)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", str(tmp_path / "worker.py"), ROOT, str(tmp_path / "out")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29547 + world), str(tmp_path / "worker.py"), ROOT, str(tmp_path / "out")]
     r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     eng = capi.Engine(capi.default_params(**KW))
@@ -75,19 +77,20 @@ def test_two_ranks_follow_their_states_and_move_them_when_needed(tmp_path, small
     lens = small_pe["box"][3:6] - small_pe["box"][:3]
     ref = run_sequence(eng, lens)
     eng.close()
-    got = [np.load(str(tmp_path / "out") + f".{k}.npz") for k in range(2)]
-    for k in range(2):
+    got = [np.load(str(tmp_path / "out") + f".{k}.npz") for k in range(world)]
+    for k in range(world):
         for u, name in enumerate(("u1", "u2", "u3")):
             err = np.abs(got[k][name] - ref[u]).max() / np.abs(ref[u]).max()
             assert err < 1e-8, (k, name, err)          # FP64 atomics only; a lost state would be O(1)
         assert got[k]["stats"][0] == 3                  # ONE collective per update
-        assert got[k]["stats"][1] >= 1                  # the ragged second update moved a state
-    assert list(got[0]["owners"]) == list(got[1]["owners"])       # the directory is the same everywhere
+        if world == 2:
+            assert got[k]["stats"][1] >= 1              # the ragged second update moved a state
+        assert list(got[k]["owners"]) == list(got[0]["owners"])   # the directory is the same everywhere
     # every state is held by exactly the rank recorded as its owner (qp 6 never existed)
     for q in (0, 1, 2, 3, 4, 5, 7):
         o = int(got[0]["owners"][q])
-        assert o in (0, 1) and got[o]["held"][q] == 1 and got[1 - o]["held"][q] == 0
-    assert got[0]["held"][6] == 0 and got[1]["held"][6] == 0
+        assert o in range(world) and [int(got[k]["held"][q]) for k in range(world)] == [1 if k == o else 0 for k in range(world)]
+    assert all(got[k]["held"][6] == 0 for k in range(world))
 
 
 def test_without_a_communicator_a_remote_source_state_is_an_error(small_pe):

@@ -118,21 +118,22 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_share_stresses_with_one_allgather(tmp_path):
-    """world_size 2 over gloo: simulations are dealt i % 2 (stmd_sync.h:583), one all-gather returns
-    6 doubles per simulation (replaces share_stresses, stmd_sync.h:620-726); every rank ends with the
-    same update_stress as the single-rank run."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_share_stresses_with_one_allgather(tmp_path, world):
+    """world_size 2 and 8 (one node of MI355X, BASELINE config 4) over gloo: simulations are dealt i % world
+    (stmd_sync.h:583), one all-gather returns 6 doubles per simulation (replaces share_stresses,
+    stmd_sync.h:620-726); every rank ends with the same update_stress as the single-rank run."""
     nin, reps = _setup(tmp_path)
     rng = np.random.default_rng(9)
-    strains = rng.normal(0, 1e-3, (7, 6))      # odd count: ragged shards
+    strains = rng.normal(0, 1e-3, (7 if world == 2 else 21, 6))      # not a multiple of the world size: ragged shards
     np.save(tmp_path / "strains.npy", strains)
     (tmp_path / "worker.py").write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", str(tmp_path / "worker.py"), ROOT, nin, str(tmp_path / "strains.npy"), str(tmp_path / "out")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29517 + world), str(tmp_path / "worker.py"), ROOT, nin, str(tmp_path / "strains.npy"), str(tmp_path / "out")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     exp = _expected(reps, strains)
-    for rank in range(2):
+    for rank in range(world):
         got = np.load(str(tmp_path / "out") + f".{rank}.npy")
         assert np.allclose(got, exp, rtol=1e-13, atol=1e-6)
