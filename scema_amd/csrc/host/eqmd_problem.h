@@ -24,13 +24,9 @@ class EQMDProblem {
   int equil(const std::string &cmat, const std::string &slocin, const std::string &qplogloc, const std::string &scrloc, const std::string &lengthof,
             const std::string &stressof, const std::string &stiffof, const std::string &systof, int rep, double mdts, double mdtem, int mdnss, int mdnse,
             double mdss, double mdsa, const std::string &mdff) {
-    (void)qplogloc; (void)scrloc;
+    (void)qplogloc;
     if (mdff != "opls" && mdff != "reax") {
       err_ = "Error: Force field is " + mdff + " but only 'opls' and 'reax' are implemented... ";
-      return SCEMA_MD_ERR_ARG;
-    }
-    if (mdff == "reax") {
-      err_ = "init_material with force field 'reax' is not built (the straining path is: scema_md_strain_batch)";
       return SCEMA_MD_ERR_ARG;
     }
     if (!engine_) {
@@ -38,6 +34,19 @@ class EQMDProblem {
       return SCEMA_MD_ERR_DEVICE;
     }
     const bool registered = scema_md_replica_natoms(engine_, cmat.c_str(), rep) > 0;
+    const bool reax = mdff == "reax";
+    if (reax) {
+      // init_material_problem.h:119-121,157-160: pair_coeff * * <scriptsloc>/ffield.reax.2 H C N O + fix qeq/reax ... 1e-6
+      if (!registered) {
+        err_ = "force field 'reax': replica " + cmat + "_" + std::to_string(rep) + " must be registered with the engine (atom_style charge data files are not read here)";
+        return SCEMA_MD_ERR_NOSTATE;
+      }
+      static const char *const elements[4] = {"H", "C", "N", "O"};
+      const std::string ff = scrloc + "/ffield.reax.2";
+      const int rc = scema_md_reax_configure(engine_, ff.c_str(), elements, 4, 1.0e-6, -1.0);   // also selects the force field for what follows
+      if (rc) { err_ = scema_md_last_error(engine_); return rc; }
+    }
+    struct Off { scema_md_engine *e; bool on; ~Off() { if (on) scema_md_reax_activate(e, 0); } } off{engine_, reax};
     if (!file_exists(systof)) {
       // "Compute state data...": in.init.lammps on the data file
       if (!registered) {
@@ -72,10 +81,7 @@ class EQMDProblem {
       err_ = "Error: Force field is " + mdff + " but only 'opls' and 'reax' are implemented... ";
       return SCEMA_MD_ERR_ARG;
     }
-    if (mdff == "reax") {
-      err_ = "force field 'reax' is not built yet";
-      return SCEMA_MD_ERR_ARG;
-    }
+    // "reax": the caller has selected the force field (scema_md_reax_configure / the full equil above does it from scrloc)
     if (!engine_) {
       err_ = "init_material needs an engine (no CPU fallback)";
       return SCEMA_MD_ERR_DEVICE;

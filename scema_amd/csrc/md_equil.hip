@@ -249,6 +249,9 @@ __global__ void k_min_pre(const SimDev *sims) {
     for (int k = 0; k < MD_NPART * 6; k++) sc.vir[k] = 0.0;
     for (int k = 0; k < MD_NPART; k++) sc.eng[k] = 0.0;
     for (int k = 0; k < 4; k++) sc.min_dots[k] = 0.0;
+    // where the previous move left x on its search line (the move of this evaluation starts from there)
+    sc.min_alpha_now = sc.min_alpha_next;
+    sc.min_alpha_next = (sc.min_phase == MIN_RESET) ? 0.0 : sc.min_alpha;
   }
   for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;
   for (int k = threadIdx.x; k < S.ncells; k += blockDim.x) S.cell_count[k] = 0;
@@ -262,11 +265,12 @@ __global__ __launch_bounds__(TPB) void k_min_move(const SimDev *sims, double *co
   if (sc.min_phase == MIN_DONE) return;
   double *x0 = x0s[blockIdx.y], *h = hs[blockIdx.y];
   const double alpha = (sc.min_phase == MIN_RESET) ? 0.0 : sc.min_alpha;
+  const double anow = sc.min_newdir ? 0.0 : sc.min_alpha_now;   // read by every thread before k_min_decide moves it on
   double dsq = 0.0;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     if (sc.min_newdir) { x0[3 * i + k] = S.x[3 * i + k]; h[3 * i + k] = S.f[3 * i + k]; }
-    const double xn = x0[3 * i + k] + alpha * h[3 * i + k];
+    const double xn = S.min_incremental ? S.x[3 * i + k] + (alpha - anow) * h[3 * i + k] : x0[3 * i + k] + alpha * h[3 * i + k];
     S.x[3 * i + k] = xn;
     const double d = xn - S.xhold[3 * i + k];
     dsq += d * d;

@@ -85,6 +85,7 @@ struct SimScalars {
   int nlwin, pad1_;
   // minimiser state (one line search at a time, decided on the device between two force evaluations)
   int min_phase, min_stop, min_iter, min_neval, min_newdir, pad2_;
+  double min_alpha_now, min_alpha_next;   // where x sits on the current search line before / after the move of this evaluation (min_incremental)
   double min_alpha, min_alphamax, min_fdothall, min_eorig, min_eprev, min_fhprev, min_engprev, min_alphaprev, min_fh_trial, min_ecur, min_einit;
   double min_dots[4];  // f.h, f.f, max |f| of the last evaluation (+ spare)
 #ifdef PAIR_TIMING
@@ -112,6 +113,7 @@ struct SimDev {
   double t_start, t_stop, p_target, p_freq, box_margin;
   double min_etol, min_ftol, min_dmax;
   int min_maxiter, min_maxeval;
+  int min_incremental;        // 1: trial points by increments x += (alpha - alpha_now) h (a force stage that wraps x at rebuilds: ReaxFF)
   // scalars
   double dt, t_target, t_freq, tdof, g_ewald, qsqsum, qsum;
   double cut_lj2, cut_coul2, rlist2, skin, excl_cut2, shake_tol;
