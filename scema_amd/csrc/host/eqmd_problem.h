@@ -37,10 +37,6 @@ class EQMDProblem {
     const bool reax = mdff == "reax";
     if (reax) {
       // init_material_problem.h:119-121,157-160: pair_coeff * * <scriptsloc>/ffield.reax.2 H C N O + fix qeq/reax ... 1e-6
-      if (!registered) {
-        err_ = "force field 'reax': replica " + cmat + "_" + std::to_string(rep) + " must be registered with the engine (atom_style charge data files are not read here)";
-        return SCEMA_MD_ERR_NOSTATE;
-      }
       static const char *const elements[4] = {"H", "C", "N", "O"};
       const std::string ff = scrloc + "/ffield.reax.2";
       const int rc = scema_md_reax_configure(engine_, ff.c_str(), elements, 4, 1.0e-6, -1.0);   // also selects the force field for what follows

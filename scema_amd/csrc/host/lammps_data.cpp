@@ -1,4 +1,4 @@
-// lammps_data.cpp -- reader for LAMMPS text data files of atom_style full (the output of
+// lammps_data.cpp -- reader for LAMMPS text data files of atom_style full and atom_style charge (the output of
 // `write_data`), so that a replica equilibrated with the reference's own in.init.lammps can be
 // handed to the engine without LAMMPS' binary restart format.
 //
@@ -102,10 +102,17 @@ static int parse_lammps_data(const char *path, const double special_lj[3], const
   struct Pending { std::vector<std::vector<std::string>> rows; };
   std::map<std::string, Pending> sec;
   std::string cur;
+  // atom_style of the Atoms section: write_data names it in a comment ("Atoms # charge"); without one the column count decides
+  // (charge: id type q x y z [ix iy iz]; full: id mol type q x y z [ix iy iz]).  charge = the reax scripts (in.set.lammps:17)
+  int style_charge = -1;
   for (; i < lines.size(); i++) {
     const std::string l = strip_comment(lines[i]);
     if (l.empty()) continue;
     const std::string s = section_of(l);
+    if (s == "Atoms") {
+      if (lines[i].find("charge") != std::string::npos) style_charge = 1;
+      else if (lines[i].find("full") != std::string::npos) style_charge = 0;
+    }
     if (!s.empty()) { cur = s; continue; }
     if (!cur.empty()) sec[cur].rows.push_back(split(l));
   }
@@ -116,7 +123,13 @@ static int parse_lammps_data(const char *path, const double special_lj[3], const
     for (auto &r : it->second.rows) if (r.size() < minw) return false;
     return true;
   };
-  if (!need("Masses", ntypes, 2) || !need("Atoms", natoms, 7)) return SCEMA_MD_ERR_IO;
+  if (!need("Masses", ntypes, 2) || !need("Atoms", natoms, 6)) return SCEMA_MD_ERR_IO;
+  if (style_charge < 0) {
+    const size_t w = sec["Atoms"].rows[0].size();
+    style_charge = (w == 6 || w == 9) ? 1 : 0;
+  }
+  const int c0 = style_charge ? 1 : 2;   // column of the atom type
+  if (!need("Atoms", natoms, (size_t)c0 + 5)) return SCEMA_MD_ERR_IO;
   for (auto &r : sec["Masses"].rows) { int t = atoi(r[0].c_str()); if (t < 1 || t > ntypes) return SCEMA_MD_ERR_IO; mass[t - 1] = atof(r[1].c_str()); }
   if (sec.count("Pair Coeffs")) {
     for (auto &r : sec["Pair Coeffs"].rows) { if (r.size() < 3) return SCEMA_MD_ERR_IO; int t = atoi(r[0].c_str()); if (t < 1 || t > ntypes) return SCEMA_MD_ERR_IO; eps1[t - 1] = atof(r[1].c_str()); sig1[t - 1] = atof(r[2].c_str()); }
@@ -131,6 +144,11 @@ static int parse_lammps_data(const char *path, const double special_lj[3], const
       eps[(size_t)a * ntypes + b] = eps[(size_t)b * ntypes + a] = atof(r[2].c_str());
       sig[(size_t)a * ntypes + b] = sig[(size_t)b * ntypes + a] = atof(r[3].c_str());
     }
+  if (style_charge && !sec.count("Pair Coeffs") && !sec.count("PairIJ Coeffs")) {
+    // a ReaxFF replica: the force field comes from pair_coeff * * ffield.reax.2 ..., the data file carries none
+    std::fill(eps.begin(), eps.end(), 0.0);
+    std::fill(sig.begin(), sig.end(), 1.0);
+  }
   for (double ev : eps) if (ev < 0.0) return SCEMA_MD_ERR_IO;  // no pair coefficients at all
   auto coeffs = [&](const char *name, int n, int ncoef, std::vector<double> &out, int deg_col) -> bool {
     if (n == 0) return true;
@@ -151,13 +169,13 @@ static int parse_lammps_data(const char *path, const double special_lj[3], const
       const long id = atol(r[0].c_str());
       ids[k] = id;
       index_of[id] = (int)k;
-      const int t = atoi(r[2].c_str());
+      const int t = atoi(r[c0].c_str());
       if (t < 1 || t > ntypes) return SCEMA_MD_ERR_IO;
       type[k] = t - 1;
-      q[k] = atof(r[3].c_str());
-      double p[3] = {atof(r[4].c_str()), atof(r[5].c_str()), atof(r[6].c_str())};
-      if (r.size() >= 10) {  // image flags: unwrap (the engine keeps unwrapped coordinates)
-        const int ix = atoi(r[7].c_str()), iy = atoi(r[8].c_str()), iz = atoi(r[9].c_str());
+      q[k] = atof(r[c0 + 1].c_str());
+      double p[3] = {atof(r[c0 + 2].c_str()), atof(r[c0 + 3].c_str()), atof(r[c0 + 4].c_str())};
+      if (r.size() >= (size_t)c0 + 8) {  // image flags: unwrap (the engine keeps unwrapped coordinates)
+        const int ix = atoi(r[c0 + 5].c_str()), iy = atoi(r[c0 + 6].c_str()), iz = atoi(r[c0 + 7].c_str());
         p[0] += ix * L[0] + iy * box[6] + iz * box[7];
         p[1] += iy * L[1] + iz * box[8];
         p[2] += iz * L[2];

@@ -62,6 +62,42 @@ def test_lammps_data_file_converts_to_the_same_replica(small_pe, tmp_path):
     assert sorted(map(tuple, np.sort(back2["bonds"], axis=1).tolist()))[:3] is not None
 
 
+def test_atom_style_charge_data_file(tmp_path):
+    """the reax scripts use atom_style charge (lammps_scripts_reax/in.set.lammps:17): `id type q x y z [ix iy iz]`, no bonded
+    sections and no pair coefficients (the force field comes from ffield.reax.2)"""
+    from scema_amd import capi
+    from scema_amd.systems import read_replica_file
+    rng = np.random.default_rng(4)
+    n, box = 7, np.array([0.0, -1.0, 2.0, 9.0, 8.5, 11.0, 0.6, -0.4, 0.3])
+    typ = rng.integers(1, 5, n)
+    q = rng.normal(0, 0.2, n)
+    x = rng.uniform(1.0, 7.0, (n, 3))
+    v = rng.normal(0, 1e-3, (n, 3))
+    img = rng.integers(-1, 2, (n, 3))
+    order = rng.permutation(n)
+    for named in (True, False):
+        p = tmp_path / f"g0_1_{int(named)}.data"
+        with open(p, "w") as fp:
+            fp.write("LAMMPS data file via write_data\n\n%d atoms\n4 atom types\n\n" % n)
+            fp.write("%.17g %.17g xlo xhi\n%.17g %.17g ylo yhi\n%.17g %.17g zlo zhi\n%.17g %.17g %.17g xy xz yz\n\n" % (box[0], box[3], box[1], box[4], box[2], box[5], box[6], box[7], box[8]))
+            fp.write("Masses\n\n1 1.008\n2 12.011\n3 14.007\n4 15.999\n\n")
+            fp.write("Atoms # charge\n\n" if named else "Atoms\n\n")
+            for i in order:
+                fp.write("%d %d %.17g %.17g %.17g %.17g %d %d %d\n" % (i + 1, typ[i], q[i], x[i, 0], x[i, 1], x[i, 2], img[i, 0], img[i, 1], img[i, 2]))
+            fp.write("\nVelocities\n\n")
+            for i in order:
+                fp.write("%d %.17g %.17g %.17g\n" % (i + 1, v[i, 0], v[i, 1], v[i, 2]))
+        out = str(tmp_path / "o.bin")
+        assert capi.lib().scema_md_convert_lammps_data(str(p).encode(), out.encode(), None, None) == 0
+        d = read_replica_file(out)
+        h = np.array([[box[3] - box[0], box[6], box[7]], [0.0, box[4] - box[1], box[8]], [0.0, 0.0, box[5] - box[2]]])
+        xu = x[order] + img[order] @ h.T                       # unwrapped with the image flags; file order is kept
+        assert d["natoms"] == n and d["ntypes"] == 4 and len(d["bonds"]) == 0
+        assert np.array_equal(d["type"], typ[order] - 1) and np.allclose(d["charge"], q[order], rtol=1e-15)
+        assert np.abs(d["x"] - xu).max() < 1e-13 and np.allclose(d["v"], v[order], rtol=1e-15) and np.allclose(d["box"], box)
+        assert np.all(d["eps"] == 0.0)
+
+
 def test_bad_files_are_rejected(tmp_path):
     _built()
     from scema_amd import capi
