@@ -234,7 +234,9 @@ int scema_md_save_state_dump(scema_md_engine *e, int32_t qp_id, const char *mati
  * sampling) and the stiffness tensor by +-strain_ampl finite strains in the six directions (ELASTIC/in.modulus.lammps,
  * bi-displace.mod.lammps: fix deform ... delta over nsstrain steps, then nsteps_sample steps of sampling, fix nvt only).
  * The 13 runs are one batch on the GPU.  The equilibration schedule itself (in.init.lammps: minimise, heat, cool) is not
- * part of this call: the registered replica is taken as the equilibrated state ("Reuse of state data", :175-184).
+ * part of this call (scema_md_equilibrate below is): the registered replica is taken as the equilibrated state ("Reuse of
+ * state data", :175-184).  With a ReaxFF force field selected (scema_md_reax_configure / scema_md_reax_activate) both calls run on
+ * the ReaxFF force stage.
  * length[3]; stress[6] in Pa, file order 00,01,02,11,12,22; stiff[36] in Pa, file order of init.*.stiff. */
 typedef struct {
   double timestep_length;  /* fs   "molecular dynamics parameters.timestep length" */
