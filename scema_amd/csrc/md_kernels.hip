@@ -689,7 +689,124 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
 // ------------------------------------------------------------------------------------------
 // k_shake : fix shake, one thread per star cluster (central atom + 1..3 satellites)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_shake(const SimDev *sims, double dtfsq_scale) {
+// One star cluster with NB satellites (NB a compile-time constant: every array below lives in registers, every loop is
+// unrolled; the generic form with run-time bounds put its arrays into scratch memory and ran at 192 VGPRs)
+template <int NB>
+__device__ __forceinline__ void shake_cluster(const SimDev &S, const BoxD &b, int cl, double dtfsq_scale, double (&v)[6]) {
+  const double dtv = S.dt, dtfsq = dtfsq_scale * S.dt * S.dt * MD_FTM2V;
+  const int *at = S.clus_at + 4 * cl;
+  const double *dist = S.clus_d + 3 * cl;
+  int ia[NB + 1];
+  double invm[NB + 1], xs[NB + 1][3], xc[NB + 1][3];
+  // v is exact here: k_initial_integrate folded the deferred NH factor in before the drift
+#pragma unroll
+  for (int a = 0; a <= NB; a++) {
+    const int i = at[a];
+    ia[a] = i;
+    invm[a] = 1.0 / S.mass[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      xc[a][k] = S.x[3 * i + k];
+      xs[a][k] = xc[a][k] + dtv * S.v[3 * i + k] + dtfsq * invm[a] * S.f[3 * i + k];
+    }
+  }
+  double r[NB][3], sv[NB][3];
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { r[k][c] = xc[0][c] - xc[k + 1][c]; sv[k][c] = xs[0][c] - xs[k + 1][c]; }
+    minimg(b, r[k][0], r[k][1], r[k][2]);
+    minimg(b, sv[k][0], sv[k][1], sv[k][2]);
+  }
+  double lam[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) lam[k] = 0.0;
+  if (NB == 1) {
+    const double m01 = invm[0] + invm[1];
+    const double r01sq = dot3(r[0], r[0]), s01sq = dot3(sv[0], sv[0]);
+    const double a = m01 * m01 * r01sq, bb = 2.0 * m01 * dot3(sv[0], r[0]), c = s01sq - dist[0] * dist[0];
+    double determ = bb * bb - 4.0 * a * c;
+    if (determ < 0.0) determ = 0.0;
+    const double l1 = (-bb + sqrt(determ)) / (2.0 * a), l2 = (-bb - sqrt(determ)) / (2.0 * a);
+    lam[0] = (fabs(l1) <= fabs(l2)) ? l1 : l2;
+  } else {
+    double A[NB][NB], Ai[NB][NB], M[NB][NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        M[k][j] = invm[0] + (k == j ? invm[k + 1] : 0.0);
+        A[k][j] = 2.0 * M[k][j] * dot3(sv[k], r[j]);
+        Ai[k][j] = 0.0;
+      }
+    if (NB == 2) {
+      const double det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+      Ai[0][0] = A[1][1] / det; Ai[0][1] = -A[0][1] / det; Ai[1][0] = -A[1][0] / det; Ai[1][1] = A[0][0] / det;
+    } else {
+      constexpr int Z = NB > 2 ? 2 : 0;   // (keeps the indices in range for the instantiations that never take this branch)
+      const double det = A[0][0] * (A[1 % NB][1 % NB] * A[Z][Z] - A[1 % NB][Z] * A[Z][1 % NB]) - A[0][1 % NB] * (A[1 % NB][0] * A[Z][Z] - A[1 % NB][Z] * A[Z][0]) +
+                         A[0][Z] * (A[1 % NB][0] * A[Z][1 % NB] - A[1 % NB][1 % NB] * A[Z][0]);
+      const double id = 1.0 / det;
+      Ai[0][0] = id * (A[1 % NB][1 % NB] * A[Z][Z] - A[1 % NB][Z] * A[Z][1 % NB]);
+      Ai[0][1 % NB] = -id * (A[0][1 % NB] * A[Z][Z] - A[0][Z] * A[Z][1 % NB]);
+      Ai[0][Z] = id * (A[0][1 % NB] * A[1 % NB][Z] - A[0][Z] * A[1 % NB][1 % NB]);
+      Ai[1 % NB][0] = -id * (A[1 % NB][0] * A[Z][Z] - A[1 % NB][Z] * A[Z][0]);
+      Ai[1 % NB][1 % NB] = id * (A[0][0] * A[Z][Z] - A[0][Z] * A[Z][0]);
+      Ai[1 % NB][Z] = -id * (A[0][0] * A[1 % NB][Z] - A[0][Z] * A[1 % NB][0]);
+      Ai[Z][0] = id * (A[1 % NB][0] * A[Z][1 % NB] - A[1 % NB][1 % NB] * A[Z][0]);
+      Ai[Z][1 % NB] = -id * (A[0][0] * A[Z][1 % NB] - A[0][1 % NB] * A[Z][0]);
+      Ai[Z][Z] = id * (A[0][0] * A[1 % NB][1 % NB] - A[0][1 % NB] * A[1 % NB][0]);
+    }
+    double ssq[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) ssq[k] = dot3(sv[k], sv[k]);
+    bool done = false;
+    int iter = 0;
+    while (!done && iter < S.shake_maxiter) {
+      double rhs[NB];
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        double w[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) w[c] += M[k][j] * lam[j] * r[j][c];
+        rhs[k] = dist[k] * dist[k] - ssq[k] - dot3(w, w);
+      }
+      double ln[NB];
+      done = true;
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        ln[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) ln[k] += Ai[k][j] * rhs[j];
+        if (fabs(ln[k] - lam[k]) > S.shake_tol) done = false;
+      }
+#pragma unroll
+      for (int k = 0; k < NB; k++) lam[k] = ln[k];
+#pragma unroll
+      for (int k = 0; k < NB; k++)
+        if (isnan(lam[k])) done = true;
+      iter++;
+    }
+  }
+  double f0[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const double l = lam[k] / dtfsq;
+    const double ff[3] = {l * r[k][0], l * r[k][1], l * r[k][2]};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      f0[c] += ff[c];
+      S.f[3 * ia[k + 1] + c] -= ff[c];
+    }
+    vt(v, r[k][0], r[k][1], r[k][2], ff[0], ff[1], ff[2]);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) S.f[3 * ia[0] + c] += f0[c];
+}
+
+__global__ __launch_bounds__(TPB, 4) void k_shake(const SimDev *sims, double dtfsq_scale) {
   const SimDev &S = sims[blockIdx.y];
   SimScalars &sc = *S.sc;
   if (!S.use_shake || S.nclus == 0) return;
@@ -700,95 +817,10 @@ __global__ __launch_bounds__(TPB) void k_shake(const SimDev *sims, double dtfsq_
   if (cl < S.nclus) {
     BoxD b;
     box_derive(sc.box, b);
-    const double dtv = S.dt, dtfsq = dtfsq_scale * S.dt * S.dt * MD_FTM2V;
-    const int na = S.clus_n[cl], nb = na - 1;
-    const int *at = S.clus_at + 4 * cl;
-    const double *dist = S.clus_d + 3 * cl;
-    double invm[4], xs[4][3], xc[4][3];
-    // v is exact here: k_initial_integrate folded the deferred NH factor in before the drift
-    for (int a = 0; a < na; a++) {
-      const int i = at[a];
-      invm[a] = 1.0 / S.mass[i];
-      for (int k = 0; k < 3; k++) {
-        xc[a][k] = S.x[3 * i + k];
-        xs[a][k] = xc[a][k] + dtv * S.v[3 * i + k] + dtfsq * invm[a] * S.f[3 * i + k];
-      }
-    }
-    double r[3][3], sv[3][3];
-    for (int k = 0; k < nb; k++) {
-      for (int c = 0; c < 3; c++) { r[k][c] = xc[0][c] - xc[k + 1][c]; sv[k][c] = xs[0][c] - xs[k + 1][c]; }
-      minimg(b, r[k][0], r[k][1], r[k][2]);
-      minimg(b, sv[k][0], sv[k][1], sv[k][2]);
-    }
-    double lam[3] = {0, 0, 0};
-    if (nb == 1) {
-      const double m01 = invm[0] + invm[1];
-      const double r01sq = dot3(r[0], r[0]), s01sq = dot3(sv[0], sv[0]);
-      const double a = m01 * m01 * r01sq, bb = 2.0 * m01 * dot3(sv[0], r[0]), c = s01sq - dist[0] * dist[0];
-      double determ = bb * bb - 4.0 * a * c;
-      if (determ < 0.0) determ = 0.0;
-      const double l1 = (-bb + sqrt(determ)) / (2.0 * a), l2 = (-bb - sqrt(determ)) / (2.0 * a);
-      lam[0] = (fabs(l1) <= fabs(l2)) ? l1 : l2;
-    } else {
-      double A[3][3] = {{0}}, Ai[3][3] = {{0}}, M[3][3] = {{0}};
-      for (int k = 0; k < nb; k++)
-        for (int j = 0; j < nb; j++) {
-          M[k][j] = invm[0] + (k == j ? invm[k + 1] : 0.0);
-          A[k][j] = 2.0 * M[k][j] * dot3(sv[k], r[j]);
-        }
-      if (nb == 2) {
-        const double det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
-        Ai[0][0] = A[1][1] / det; Ai[0][1] = -A[0][1] / det; Ai[1][0] = -A[1][0] / det; Ai[1][1] = A[0][0] / det;
-      } else {
-        const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                           A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-        const double id = 1.0 / det;
-        Ai[0][0] = id * (A[1][1] * A[2][2] - A[1][2] * A[2][1]);
-        Ai[0][1] = -id * (A[0][1] * A[2][2] - A[0][2] * A[2][1]);
-        Ai[0][2] = id * (A[0][1] * A[1][2] - A[0][2] * A[1][1]);
-        Ai[1][0] = -id * (A[1][0] * A[2][2] - A[1][2] * A[2][0]);
-        Ai[1][1] = id * (A[0][0] * A[2][2] - A[0][2] * A[2][0]);
-        Ai[1][2] = -id * (A[0][0] * A[1][2] - A[0][2] * A[1][0]);
-        Ai[2][0] = id * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-        Ai[2][1] = -id * (A[0][0] * A[2][1] - A[0][1] * A[2][0]);
-        Ai[2][2] = id * (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
-      }
-      double ssq[3];
-      for (int k = 0; k < nb; k++) ssq[k] = dot3(sv[k], sv[k]);
-      bool done = false;
-      int iter = 0;
-      while (!done && iter < S.shake_maxiter) {
-        double rhs[3];
-        for (int k = 0; k < nb; k++) {
-          double w[3] = {0, 0, 0};
-          for (int j = 0; j < nb; j++)
-            for (int c = 0; c < 3; c++) w[c] += M[k][j] * lam[j] * r[j][c];
-          rhs[k] = dist[k] * dist[k] - ssq[k] - dot3(w, w);
-        }
-        double ln[3];
-        done = true;
-        for (int k = 0; k < nb; k++) {
-          ln[k] = 0.0;
-          for (int j = 0; j < nb; j++) ln[k] += Ai[k][j] * rhs[j];
-          if (fabs(ln[k] - lam[k]) > S.shake_tol) done = false;
-        }
-        for (int k = 0; k < nb; k++) lam[k] = ln[k];
-        for (int k = 0; k < nb; k++)
-          if (isnan(lam[k])) done = true;
-        iter++;
-      }
-    }
-    double f0[3] = {0, 0, 0};
-    for (int k = 0; k < nb; k++) {
-      const double l = lam[k] / dtfsq;
-      const double ff[3] = {l * r[k][0], l * r[k][1], l * r[k][2]};
-      for (int c = 0; c < 3; c++) {
-        f0[c] += ff[c];
-        S.f[3 * at[k + 1] + c] -= ff[c];
-      }
-      vt(v, r[k][0], r[k][1], r[k][2], ff[0], ff[1], ff[2]);
-    }
-    for (int c = 0; c < 3; c++) S.f[3 * at[0] + c] += f0[c];
+    const int nb = S.clus_n[cl] - 1;
+    if (nb == 2) shake_cluster<2>(S, b, cl, dtfsq_scale, v);        // CH2
+    else if (nb == 1) shake_cluster<1>(S, b, cl, dtfsq_scale, v);
+    else if (nb == 3) shake_cluster<3>(S, b, cl, dtfsq_scale, v);   // CH3
   }
   block_atomic_add<6>(v, sc.vir + P_SHAKE * 6, s_red);
 }
