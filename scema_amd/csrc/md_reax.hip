@@ -22,6 +22,9 @@
 #include "reax/rx_core.h"
 
 #define RX_TPB 128
+#ifndef RX_OCC
+#define RX_OCC 2   /* waves per SIMD the term kernels are compiled for (the torsion pass would take 300 VGPRs unbounded: one wave per SIMD) */
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void k_rx_prepare(const SimDev *sims, RxView *views) {
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(TPB) void k_rx_corr(const RxView *views, const RxPa
 }
 // pass: 0 atom terms, 1 angles, 2 torsions, 3 hydrogen bonds (4, non-bonded: k_rx_nonbonded)
 template <int PASS>
-__global__ __launch_bounds__(RX_TPB) void k_rx_terms(const SimDev *sims, const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims, const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * RX_TPB + threadIdx.x;
   double e[RX_NPART], w[6];
