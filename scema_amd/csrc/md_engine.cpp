@@ -1157,6 +1157,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     };
     // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
     // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
+    const bool small_batch = ns * 160 < 512 && !getenv("SCEMA_MD_BIG_CELLS");
     for (int pass = 0; pass < 2 && !fits; pass++) {
       int lo[3], hi[3];
       for (int d = 0; d < 3; d++) {
@@ -1171,7 +1172,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
             const int nc[3] = {n0, n1, n2};
             int mst[3], cj, mn;
             if (!size_grid(nc, mst, cj, mn)) continue;
-            const double vol = 1.0 / ((double)n0 * n1 * n2);
+            // batches that fill the chip take the largest cells (per-tile phases amortised over more rows); small ones the
+            // most cells: a single replica on 120 tiles leaves half of the 512 workgroup slots empty and waits for one tile
+            const double vol = small_batch ? (double)n0 * n1 * n2 : 1.0 / ((double)n0 * n1 * n2);
             if (vol > best) {
               best = vol;
               fits = true;

@@ -18,6 +18,8 @@
 //   pressure sample in k_post ... compute pressure + fix ave/time (K11)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "md_device.h"
 #include "md_kernels.h"
 #include "md_types.h"
@@ -414,7 +416,7 @@ __device__ __forceinline__ void atom_phase(const SimDev &S, const BoxD &b, int a
 // NR = rounds of groups per thread: thread gi owns the groups gi, gi + gthreads, ... (NR of them), so that k sets of up to
 // NR * 256 groups (replicas of a few 10^4 atoms at the reference's accuracy) stay on the table path
 template <int NR>
-__global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_MAXM, int gthreads) {
+__global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_MAXM, int gthreads, int nparts) {
   const SimDev &S = sims[blockIdx.y];
   if (S.nk == 0) return;
   double2 *s_tab = s_dyn;  // [EW_ATOMS][3][EW_MAXM]
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_M
   }
   BoxD b;
   box_derive(S.sc->box, b);
-  for (int ch = blockIdx.x; ch < nchunk; ch += EW_PARTS) {
+  for (int ch = blockIdx.x; ch < nchunk; ch += nparts) {
     const int a0 = ch * EW_ATOMS;
     const int na = min(EW_ATOMS, S.natoms - a0);
     __syncthreads();
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(const SimDev *sims, int EW_M
       if (k < 0) continue;
       const int a1 = S.kn[3 * k], a2 = S.kn[3 * k + 1], a3 = S.kn[3 * k + 2];
       double sr = 0.0, si = 0.0;
-      for (int ch = blockIdx.x; ch < nchunk; ch += EW_PARTS)
+      for (int ch = blockIdx.x; ch < nchunk; ch += nparts)
         for (int la = 0; la < EW_ATOMS && ch * EW_ATOMS + la < S.natoms; la++) {
           double t[3];
           atom_phase(S, b, ch * EW_ATOMS + la, t[0], t[1], t[2]);
@@ -565,12 +567,14 @@ __device__ __forceinline__ void cmul(double &pr, double &pi, double c, double s)
   pr = nr; pi = ni;
 }
 #define EWF_APT 2          // atoms per thread: two independent recurrences per lane, half the per-k LDS reads and scalar work per atom
-__global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int pairvir) {
+// EWF_T threads per block: 256 for batches, 64 for small ones (a single replica then spreads over 81 instead of 21 blocks)
+template <int EWF_T>
+__global__ __launch_bounds__(EWF_T) void k_ewald_force(const SimDev *sims, int pairvir) {
   const SimDev &S = sims[blockIdx.y];
-  if ((int)(blockIdx.x * EWF_TPB * EWF_APT) >= S.natoms) return;
+  if ((int)(blockIdx.x * EWF_T * EWF_APT) >= S.natoms) return;
   __shared__ EwK s_k[EWF_KC];
   __shared__ int s_run[EWF_KC];
-  __shared__ double s_red[8 * (EWF_TPB / 64)];
+  __shared__ double s_red[8 * (EWF_T / 64)];
   int at[EWF_APT];
   bool act[EWF_APT];
   double c1[EWF_APT], s1[EWF_APT], c2[EWF_APT], s2[EWF_APT], c3[EWF_APT], s3[EWF_APT];
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
     box_derive(S.sc->box, b);
 #pragma unroll
     for (int u = 0; u < EWF_APT; u++) {
-      const int ai = (blockIdx.x * EWF_APT + u) * EWF_TPB + threadIdx.x;
+      const int ai = (blockIdx.x * EWF_APT + u) * EWF_T + threadIdx.x;
       act[u] = ai < S.natoms;
       at[u] = min(ai, S.natoms - 1);
       double t[3];
@@ -670,19 +674,19 @@ __global__ __launch_bounds__(EWF_TPB) void k_ewald_force(const SimDev *sims, int
     }
   if (pairvir) {
     const int nrows = S.ncells * MD_TILE_WAVES;   // one row of 6 per cell and wave of k_pair
-    const int nblk = (S.natoms + EWF_TPB * EWF_APT - 1) / (EWF_TPB * EWF_APT);   // blocks of this simulation that got this far
-    for (int r = blockIdx.x * EWF_TPB + threadIdx.x; r < nrows; r += nblk * EWF_TPB) {
+    const int nblk = (S.natoms + EWF_T * EWF_APT - 1) / (EWF_T * EWF_APT);   // blocks of this simulation that got this far
+    for (int r = blockIdx.x * EWF_T + threadIdx.x; r < nrows; r += nblk * EWF_T) {
       const double *vp = S.virp + (size_t)r * 6;
 #pragma unroll
       for (int k = 0; k < 6; k++) pv[k] += vp[k];
     }
     // the lumped bonded virial: one row of 6 per bonded tile (k_bonded)
-    for (int r = blockIdx.x * EWF_TPB + threadIdx.x; r < S.bt_ntile; r += nblk * EWF_TPB) {
+    for (int r = blockIdx.x * EWF_T + threadIdx.x; r < S.bt_ntile; r += nblk * EWF_T) {
       const double *vp = S.virb + (size_t)r * 6;
 #pragma unroll
       for (int k = 0; k < 6; k++) pv[k] += vp[k];
     }
-    block_atomic_add_n<6, EWF_TPB / 64>(pv, S.sc->vir + P_LJ * 6, s_red);
+    block_atomic_add_n<6, EWF_T / 64>(pv, S.sc->vir + P_LJ * 6, s_red);
   }
 }
 
@@ -976,14 +980,18 @@ void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax
   static size_t optin_tab2[16] = {0}, optin_tab4[16] = {0};
   size_t &optin_r = rounds == 1 ? optin_s : lds_optin_slot(rounds == 2 ? optin_tab2 : optin_tab4);
   if (lds_s > 64 * 1024 && lds_s > optin_r) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); optin_r = lds_s; }
-  if (rounds == 1) hipLaunchKernelGGL(k_ewald_sfac<1>, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
-  else if (rounds == 2) hipLaunchKernelGGL(k_ewald_sfac<2>, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
-  else hipLaunchKernelGGL(k_ewald_sfac<4>, grid2(EW_PARTS, ns), dim3(256), lds_s, st, d, mmax, gthreads);
+  // small batches: more blocks per simulation (a single replica would otherwise run on 16 of 256 CUs); the same-address atomics
+  // at the end of the kernel grow with the parts, which is why large batches stay at EW_PARTS
+  const int nparts = (ns * EW_PARTS >= 256) ? EW_PARTS : std::min(64, std::max(EW_PARTS, 256 / std::max(ns, 1)));
+  if (rounds == 1) hipLaunchKernelGGL(k_ewald_sfac<1>, grid2(nparts, ns), dim3(256), lds_s, st, d, mmax, gthreads, nparts);
+  else if (rounds == 2) hipLaunchKernelGGL(k_ewald_sfac<2>, grid2(nparts, ns), dim3(256), lds_s, st, d, mmax, gthreads, nparts);
+  else hipLaunchKernelGGL(k_ewald_sfac<4>, grid2(nparts, ns), dim3(256), lds_s, st, d, mmax, gthreads, nparts);
   hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
 }
 // part 2: per-atom reciprocal force; also assembles f from the pair and bonded forces (runs even without charges)
 void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir) {
-  hipLaunchKernelGGL(k_ewald_force, grid2(cdiv(maxatoms, EWF_TPB * EWF_APT), ns), dim3(EWF_TPB), 0, st, d, pairvir);
+  if (ns * cdiv(maxatoms, EWF_TPB * EWF_APT) >= 512) hipLaunchKernelGGL(k_ewald_force<EWF_TPB>, grid2(cdiv(maxatoms, EWF_TPB * EWF_APT), ns), dim3(EWF_TPB), 0, st, d, pairvir);
+  else hipLaunchKernelGGL(k_ewald_force<64>, grid2(cdiv(maxatoms, 64 * EWF_APT), ns), dim3(64), 0, st, d, pairvir);
 }
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
   if (maxclus <= 0) return;
