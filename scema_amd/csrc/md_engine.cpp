@@ -1157,7 +1157,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     };
     // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
     // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
-    const bool small_batch = ns * 160 < 512 && !getenv("SCEMA_MD_BIG_CELLS");
+    static const int small_max = getenv("SCEMA_MD_SMALL_CELLS_MAX") ? atoi(getenv("SCEMA_MD_SMALL_CELLS_MAX")) : 8;   // replicas up to which the most-cells grid is taken
+    const bool small_batch = ns <= small_max && !getenv("SCEMA_MD_BIG_CELLS");
     for (int pass = 0; pass < 2 && !fits; pass++) {
       int lo[3], hi[3];
       for (int d = 0; d < 3; d++) {
