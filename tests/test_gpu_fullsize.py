@@ -101,3 +101,44 @@ def test_config3_72_replicas_10_continuum_steps(golden, pe10k):
     print(f"config 3: correlation of accumulated eps_zz with sigma_zz over the 72 replicas {c:.4f}")
     assert c > 0.9
     eng.close()
+
+
+def test_equilibration_pieces_at_full_size_against_committed_goldens():
+    """init_material's schedule (in.init.lammps) at the reference's cutoffs on PE-10k: three steepest-descent iterations, 40 steps
+    of fix npt with a ramp, 40 steps of fix nvt with a ramp, against tests/golden/oracle_equil_pe10k.json (oracle/md_oracle.c,
+    generator tests/golden/make_golden_equil_pe10k.py).  FP64; summation order differs, nothing else."""
+    import json
+    import os
+    from scema_amd import capi
+    from scema_amd.systems import build_pe
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_equil_pe10k.json")))
+    idx = g["sample_atoms"]
+    d = build_pe(6, 9, 16, jitter=0.05, seed=11)
+    e = capi.Engine(capi.default_params(shake_mass=0.0))
+    e.register_replica("pe", 1, d)
+    e.set_state(0, "pe", 1, d["box"], d["x"], d["v"])
+    m = g["minimise"]
+    r = e.minimize("pe", 1, 0, etol=0.0, ftol=0.0, maxiter=m["maxiter"])
+    assert (r["stop"], r["iterations"], r["evaluations"]) == (m["stop"], m["iterations"], m["evaluations"])
+    assert abs(r["e_initial"] - m["e_initial"]) < 1e-10 * abs(m["e_initial"]) and abs(r["e_final"] - m["e_final"]) < 1e-10 * abs(m["e_final"])
+    assert np.abs(e.get_state(0, "pe", 1)[1][idx] - np.array(m["x"])).max() < 1e-10
+    # the velocities of the golden start state come from the generator both sides share: rebuild them with the oracle-free path
+    from oracle import pyoracle as po
+    o = po.Oracle(d, po.default_params(shake_mass=0.0))
+    o.velocity_create(g["start"]["velocity_temperature"], seed=g["start"]["velocity_seed"])
+    box, x, v = o.get_state()
+    assert np.abs(v[idx] - np.array(g["start"]["v"])).max() == 0.0
+    n = g["npt"]
+    e.set_state(1, "pe", 1, box, x, v)
+    lav = e.run_nh("pe", 1, 1, n["nsteps"], n["dt"], n["t_start"], n["t_stop"], npt=True, p_target=n["p_target"], p_period=n["p_period"], average_lengths=True)
+    b1, x1, v1 = e.get_state(1, "pe", 1)
+    errs = (np.abs(b1 - np.array(n["box"])).max(), np.abs(lav - np.array(n["lavg"])).max(), np.abs(x1[idx] - np.array(n["x"])).max(),
+            np.abs(v1[idx] - np.array(n["v"])).max())
+    print("full-size NPT vs golden: box %.2e lavg %.2e x %.2e v %.2e" % errs)
+    assert errs[0] < 1e-10 and errs[1] < 1e-10 and errs[2] < 1e-9 and errs[3] < 1e-10
+    t = g["nvt"]
+    e.set_state(2, "pe", 1, box, x, v)
+    e.run_nh("pe", 1, 2, t["nsteps"], t["dt"], t["t_start"], t["t_stop"], npt=False)
+    _, x2, v2 = e.get_state(2, "pe", 1)
+    assert np.abs(x2[idx] - np.array(t["x"])).max() < 1e-9 and np.abs(v2[idx] - np.array(t["v"])).max() < 1e-10
+    e.close()
