@@ -142,3 +142,41 @@ def test_equilibration_pieces_at_full_size_against_committed_goldens():
     _, x2, v2 = e.get_state(2, "pe", 1)
     assert np.abs(x2[idx] - np.array(t["x"])).max() < 1e-9 and np.abs(v2[idx] - np.array(t["v"])).max() < 1e-10
     e.close()
+
+
+def test_config1_and_config4_576_replicas_whole_and_as_one_eighth(golden, pe10k):
+    """BASELINE config 1 / 4: the 576 quadrature points of the 3x3x8 (dogbone) mesh in ONE update on one GPU, and the share one of
+    eight GPUs gets (simulation i -> rank i % 8, stmd_sync.h:583; 72 replicas).  The strain draws are row-stable, so quadrature
+    points 0 and 37 see exactly the strains of the committed config-3 goldens (first update)."""
+    from scema_amd import capi
+    from scema_amd.systems import synthetic_strains
+    g3, p = golden["config3"], golden["params"]
+    lens = pe10k["box"][3:6] - pe10k["box"][:3]
+    strains = synthetic_strains(576, lens, seed=g3["seed0"])
+    eng = capi.Engine()
+    eng.register_replica("g0", 1, pe10k)
+    sims = [capi.make_sim(q, "g0", 1, strains[q], nss=p["nss"], most_recent=capi.QP_NONE) for q in range(576)]
+    out = eng.strain_batch(sims)
+    whole = np.array([list(o.stress) for o in out])
+    assert np.isfinite(whole).all() and all(o.stress_updated for o in out)
+    for q, evs in g3["qps"].items():
+        assert np.allclose(evs[0]["strain_len"], strains[int(q)], rtol=0, atol=0)
+        err = relerr(whole[int(q)], evs[0]["stress"])
+        print(f"config 1: quadrature point {q} of 576 in one batch: relative error vs golden {err:.3e}")
+        assert err < TOL
+    # larger axial strain, larger axial stress, over all 576
+    assert np.corrcoef(strains[:, 2], whole[:, 2])[0, 1] > 0.9
+    eng.close()
+    # one eighth: what rank r of 8 runs (no communicator attached: only its own share comes back)
+    for rank in (0, 5):
+        e8 = capi.Engine()
+        e8.register_replica("g0", 1, pe10k)
+        sims = [capi.make_sim(q, "g0", 1, strains[q], nss=p["nss"], most_recent=capi.QP_NONE) for q in range(576)]
+        o8 = e8.strain_batch(sims, rank=rank, world=8)
+        mine = [q for q in range(576) if q % 8 == rank]
+        assert [q for q in range(576) if o8[q].stress_updated] == mine and len(mine) == 72
+        got = np.array([list(o8[q].stress) for q in mine])
+        err = np.abs(got - whole[mine]).max() / np.abs(whole[mine]).max()
+        print(f"config 4: rank {rank} of 8 (72 replicas) vs the same quadrature points in the 576 batch: {err:.3e}")
+        assert err < 1e-9
+        e8.close()
