@@ -45,6 +45,8 @@ typedef struct {
   double shake_mass;    /* <= 0: no SHAKE */
   double t_period;      /* in.strain.lammps:80 fix nvt temp T T 100.0 */
   int    t_chain;       /* Nose-Hoover chain length (fix nvt default 3) */
+  int    kspace_pppm;   /* 0: the plain Ewald sum (default, DESIGN.md deviation 1); 1: PPPM as `kspace_style pppm` asks for
+                         * (order 5, ik differentiation; grid and g_ewald by the rules of pppm.cpp as restated in md_oracle.c) */
 } omd_params;
 
 void omd_default_params(omd_params *p);
@@ -78,6 +80,7 @@ int omd_nclusters(const omd_sim *s);
 double omd_tdof(const omd_sim *s);
 double omd_g_ewald(const omd_sim *s);
 int omd_nkvec(const omd_sim *s);
+void omd_pppm_grid(const omd_sim *s, int n[3]);   /* PPPM grid of the last setup (0,0,0 with the Ewald sum) */
 int omd_npairs(const omd_sim *s);   /* unique pairs currently in the neighbour list */
 int omd_nflips(const omd_sim *s);   /* triclinic box flips applied so far (fix deform, default flip yes) */
 /* fix deform's tilt rules (LAMMPS 17Nov16 fix_deform.cpp end_of_step), exposed for golden tests: tilt = xy, xz, yz */

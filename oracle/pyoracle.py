@@ -22,7 +22,7 @@ class OmdParams(C.Structure):
     _fields_ = [("cut_lj", C.c_double), ("cut_coul", C.c_double), ("skin", C.c_double),
                 ("neigh_delay", C.c_int), ("kspace_accuracy", C.c_double), ("shake_tol", C.c_double),
                 ("shake_maxiter", C.c_int), ("shake_mass", C.c_double), ("t_period", C.c_double),
-                ("t_chain", C.c_int)]
+                ("t_chain", C.c_int), ("kspace_pppm", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -188,6 +188,12 @@ class Oracle:
     @property
     def g_ewald(self):
         return lib().omd_g_ewald(self.h)
+
+    @property
+    def pppm_grid(self):
+        n = (C.c_int * 3)()
+        lib().omd_pppm_grid(self.h, n)
+        return tuple(n)
 
     @property
     def nkvec(self):
