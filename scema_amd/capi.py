@@ -49,7 +49,7 @@ class Params(C.Structure):
     _fields_ = [("cut_lj", C.c_double), ("cut_coul", C.c_double), ("skin", C.c_double), ("neigh_delay", C.c_int32),
                 ("kspace_accuracy", C.c_double), ("shake_tol", C.c_double), ("shake_maxiter", C.c_int32),
                 ("shake_mass", C.c_double), ("t_period", C.c_double), ("t_chain", C.c_int32), ("device", C.c_int32),
-                ("max_batch", C.c_int32), ("profile", C.c_int32)]
+                ("max_batch", C.c_int32), ("profile", C.c_int32), ("kspace_style", C.c_int32)]
 
 
 _P = C.c_void_p

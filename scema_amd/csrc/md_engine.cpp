@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <array>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -33,8 +34,11 @@
 #include "../../include/scema_md.h"
 #include "host/reax_ffield.h"
 #include "host/sim_plan.h"
+#include <hipfft/hipfft.h>
+
 #include "md_kernels.h"
 #include "md_equil.h"
+#include "md_pppm.h"
 #include "md_reax.h"
 #include "md_types.h"
 
@@ -206,7 +210,8 @@ struct scema_md_engine {
   std::map<std::string, std::unique_ptr<Topo>> topos;
   std::map<std::string, std::unique_ptr<State>> states;
   std::vector<std::unique_ptr<Slot>> slots;
-  DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair;
+  DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair, d_pppm;
+  std::map<std::array<int, 4>, hipfftHandle> pppm_plans;   // (nx, ny, nz, batch) -> batched 3-d Z2Z plan over contiguous grids
   std::vector<int> h_kpack;   // host copy, alive until the stream has consumed the upload
   int local_stress_count = 0;
   std::vector<SimDev> h_sims;
@@ -821,6 +826,39 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
   return err;
 }
 
+// ---- PPPM set-up on the host (kspace_style 1): grid and g_ewald by the rules of LAMMPS' pppm.cpp as remembered [LAMMPS-ext],
+// the same arithmetic as oracle/md_oracle.c pppm_setup: per dimension the smallest n whose estimated ik error is below the
+// accuracy, raised to a product of 2, 3, 5; then g_ewald by Newton's method on (real-space error - k-space error) = 0 ----
+static double pppm_ik_error(double h, double prd, double g, double q2, double natoms) {
+  static const double ACONS5[5] = {1.0 / 23232.0, 7601.0 / 13628160.0, 143.0 / 69120.0, 517231.0 / 106536960.0, 106640677.0 / 11737571328.0};
+  double sum = 0.0;
+  for (int m = 0; m < 5; m++) sum += ACONS5[m] * std::pow(h * g, 2.0 * m);
+  return q2 * std::pow(h * g, 5.0) * std::sqrt(g * prd * std::sqrt(2.0 * MD_PI) * sum / natoms) / (prd * prd);
+}
+static void pppm_setup_host(const scema_md_params &p, const Topo &t, const double *box, double &g, int pg[3]) {
+  HostBox b;
+  box_derive(box, b);
+  const double accuracy = p.kspace_accuracy * MD_QQRD2E, q2 = t.qsqsum * MD_QQRD2E, rc = p.cut_coul, N = (double)t.natoms;
+  auto factorable = [](int n) { while (n % 2 == 0) n /= 2; while (n % 3 == 0) n /= 3; while (n % 5 == 0) n /= 5; return n == 1; };
+  for (int d = 0; d < 3; d++) {
+    int n = 2;
+    while (pppm_ik_error(b.h[d] / n, b.h[d], g, q2, N) > accuracy && n < 4096) n++;
+    while (!factorable(n)) n++;
+    pg[d] = n;
+  }
+  auto f = [&](double gg) {
+    const double df_r = 2.0 * q2 * std::exp(-gg * gg * rc * rc) / std::sqrt(N * rc * b.h[0] * b.h[1] * b.h[2]);
+    double sq = 0.0;
+    for (int d = 0; d < 3; d++) { const double e = pppm_ik_error(b.h[d] / pg[d], b.h[d], gg, q2, N); sq += e * e; }
+    return df_r - std::sqrt(sq) / std::sqrt(3.0);
+  };
+  for (int it = 0; it < 10000; it++) {
+    const double hh = 1.0e-5, f0 = f(g), f1 = f(g + hh), dg = f0 / ((f1 - f0) / hh);
+    g -= dg;
+    if (std::fabs(f0) < 1.0e-10 || std::fabs(dg) < 1.0e-5) break;
+  }
+}
+
 struct PolyFit { int n; double uscale, err; double c[MD_MAXPOLY]; };
 static std::map<long, PolyFit> &poly_cache() { static std::map<long, PolyFit> m; return m; }
 static double cached_coul_poly(scema_md_engine *, double g, double rc, double *poly, int *npoly, double *uscale) {
@@ -1057,6 +1095,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   int maxgrp = 0;
   std::vector<std::vector<FlipEvent>> flips(ns);   // per position: the box flips of this run (fix deform, flip yes)
   std::vector<EwaldSetup> ews(ns);
+  int maxgrid = 0;   // PPPM: largest grid of the batch
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
@@ -1199,8 +1238,21 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     EwaldSetup &ew = ews[pos];
     if (spec.ew_keep && spec.keep && (int)spec.ew_keep->size() == ns) ew = (*spec.ew_keep)[pos];   // a run keeps the k-space setup of its start
     else ewald_setup(P, T, hsc.box, ew);
+    if (P.kspace_style == 1 && T.qsqsum > 0.0 && !(spec.ew_keep && spec.keep)) {
+      // PPPM: the Ewald k list is not used; g_ewald is adjusted to the grid (and with it the real-space part)
+      int pgd[3];
+      double gp = ew.g;
+      pppm_setup_host(P, T, hsc.box, gp, pgd);
+      ew = EwaldSetup();
+      ew.g = gp;
+      for (int d = 0; d < 3; d++) ew.kmaxd[d] = -pgd[d];   // the grid travels in the set-up record (negative: not a k range)
+    }
+    if (P.kspace_style == 1 && T.qsqsum > 0.0) {
+      for (int d = 0; d < 3; d++) { S.pg[d] = -ew.kmaxd[d]; }
+      maxgrid = std::max(maxgrid, S.pg[0] * S.pg[1] * S.pg[2]);
+    }
     S.nk = (int)ew.kn.size() / 3;
-    for (int d = 0; d < 3; d++) S.kmaxd[d] = ew.kmaxd[d];
+    for (int d = 0; d < 3; d++) S.kmaxd[d] = std::max(ew.kmaxd[d], 0);
     S.g_ewald = ew.g;
     {
       // H depends on u only: fit once per (rounded-up) range and share it between simulations
@@ -1310,6 +1362,69 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.krun = base + 3 * (size_t)S.nk;
     S.kgrp = base + ((4 * (size_t)S.nk + 3) / 4) * 4;
   }
+  // PPPM: four complex grids and the influence function per simulation, batch-contiguous (one batched transform per stage
+  // when all simulations share the grid, which they do for one material)
+  bool pppm_uniform = true;
+  if (maxgrid > 0) {
+    HIPCHK(e->d_pppm.ensure((size_t)ns * maxgrid * (4 * sizeof(double2) + sizeof(double))));
+    double *gbase = e->d_pppm.as<double>(), *fbase = gbase + (size_t)ns * maxgrid * 8;
+    for (int pos = 0; pos < ns; pos++) {
+      SimDev &S = e->h_sims[pos];
+      S.pgrid = gbase + (size_t)pos * maxgrid * 2;          // grid g of simulation pos: complex element (g ns + pos) maxgrid
+      S.pgstride = (long long)ns * maxgrid;
+      S.pgf = fbase + (size_t)pos * maxgrid;
+      for (int d = 0; d < 3; d++) pppm_uniform = pppm_uniform && S.pg[d] == e->h_sims[0].pg[d];
+    }
+  }
+  auto pppm_plan = [&](const int pg[3], int batch, hipfftHandle &plan) -> int {
+    const std::array<int, 4> key = {pg[0], pg[1], pg[2], batch};
+    auto it = e->pppm_plans.find(key);
+    if (it == e->pppm_plans.end()) {
+      hipfftHandle h;
+      int n[3] = {pg[2], pg[1], pg[0]};   // slowest dimension first
+      // batch > 1 only for simulations that share the grid: their grids are contiguous (maxgrid = nx ny nz apart)
+      if (hipfftPlanMany(&h, 3, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2Z, batch) != HIPFFT_SUCCESS)
+        return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftPlanMany failed for a %d x %d x %d grid, batch %d", pg[0], pg[1], pg[2], batch);
+      it = e->pppm_plans.emplace(key, h).first;
+    }
+    plan = it->second;
+    return SCEMA_MD_OK;
+  };
+  // reciprocal part by PPPM for the simulations [pos0, pos0 + na) of a launch group of `full` (md_pppm.hip); after force_stage
+  auto pppm_stage = [&](hipStream_t st, int pos0, int na, int full, bool new_box) -> int {
+    if (maxgrid <= 0 || na <= 0) return SCEMA_MD_OK;
+    const SimDev *Dp = e->d_sims.as<SimDev>() + pos0;
+    mdk_pppm_spread(st, Dp, na, maxgrid);
+    auto transform = [&](int which, int dir) -> int {
+      static const bool serial_fft = getenv("SCEMA_MD_PPPM_SERIAL") != nullptr;
+      if (!serial_fft && pppm_uniform && (size_t)e->h_sims[pos0].pg[0] * e->h_sims[pos0].pg[1] * e->h_sims[pos0].pg[2] == (size_t)maxgrid) {
+        hipfftHandle plan;
+        int rc = pppm_plan(e->h_sims[pos0].pg, full, plan);
+        if (rc) return rc;
+        hipfftDoubleComplex *g = (hipfftDoubleComplex *)(e->h_sims[pos0].pgrid) + (size_t)which * e->h_sims[pos0].pgstride;
+        if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS || hipfftExecZ2Z(plan, g, g, dir) != HIPFFT_SUCCESS) return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftExecZ2Z failed");
+      } else {
+        for (int k = 0; k < na; k++) {
+          const SimDev &S = e->h_sims[pos0 + k];
+          if (S.pg[0] == 0) continue;
+          hipfftHandle plan;
+          int rc = pppm_plan(S.pg, 1, plan);
+          if (rc) return rc;
+          hipfftDoubleComplex *g = (hipfftDoubleComplex *)S.pgrid + (size_t)which * S.pgstride;
+          if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS || hipfftExecZ2Z(plan, g, g, dir) != HIPFFT_SUCCESS) return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftExecZ2Z failed");
+        }
+      }
+      return SCEMA_MD_OK;
+    };
+    int rc = transform(0, HIPFFT_FORWARD);
+    if (rc) return rc;
+    if (new_box) mdk_pppm_gf(st, Dp, na, maxgrid);
+    mdk_pppm_poisson(st, Dp, na, maxgrid);
+    for (int c = 1; c <= 3; c++)
+      if ((rc = transform(c, HIPFFT_BACKWARD))) return rc;
+    mdk_pppm_force(st, Dp, na, maxatoms);
+    return SCEMA_MD_OK;
+  };
   HIPCHK(e->d_sims.ensure((size_t)ns * sizeof(SimDev)));
   HIPCHK(hipMemcpyAsync(e->d_sims.p, e->h_sims.data(), (size_t)ns * sizeof(SimDev), hipMemcpyHostToDevice, e->stream));
   const SimDev *D = e->d_sims.as<SimDev>();
@@ -1329,6 +1444,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
     mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
     HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
+    { const int rcp = pppm_stage(st, hbeg[h], nh, nh, true); if (rcp) return rcp; }
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
     mdk_final_integrate(st, Dh, nh, maxatoms, 0);
     if (spec.nh) mdk_setup_post_nh(st, Dh, nh);
@@ -1360,6 +1476,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
         mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
         mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly);
         HIPCHK(force_stage(e, st, false, D, ns, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, 1, 0));
+        { const int rcp = pppm_stage(st, 0, ns, ns, false); if (rcp) return rcp; }
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
         mdk_min_decide(st, D, ns);
       }
@@ -1411,6 +1528,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       launch_sims.push_back({hbeg[h], na});
     }
     HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
+    { const int rcp = pppm_stage(st, hbeg[h], na, hcnt[h], spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
     mdk_shake(st, Dh, na, maxclus, 1.0);
     mdk_final_integrate(st, Dh, na, maxatoms, 1);
     if (spec.nh) mdk_post_nh(st, Dh, na);
@@ -1429,7 +1547,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // 25.8 / 236.7 on one stream, 28.3 / 232.2 with the side stream; graph replay 26.4 / 236.9 on one stream and
   // 55.2 / 251.3 with the side stream inside the graph -- no gain, so replay is opt-in (SCEMA_MD_GRAPH=1).  Not
   // with per-launch event timing (profile mode), which needs the individual launches.
-  const bool use_graph = !prof && e->use_graphs && nhalf == 1;
+  const bool use_graph = !prof && e->use_graphs && nhalf == 1 && maxgrid == 0;
   // box flips (fix deform, flip yes): step -> positions that flip after it
   std::map<int, std::vector<std::pair<int, int>>> flip_at;
   for (int pos = 0; pos < ns; pos++)
@@ -1933,6 +2051,7 @@ void scema_md_default_params(scema_md_params *p) {
   p->device = 0;
   p->max_batch = 0;
   p->profile = 0;
+  p->kspace_style = 0;
 }
 
 int scema_md_create(const scema_md_params *p, scema_md_engine **out) {

@@ -405,3 +405,45 @@ def test_large_k_sets_stay_on_the_table_path(small_pe, acc, min_groups):
     assert abs(en[6] - eo[6]) < 1e-10 * abs(eo[6]) and np.abs(w[6] - wo[6]).max() < 1e-10 * np.abs(wo[6]).max()
     assert np.abs(f - fo).max() < 1e-10 * np.abs(fo).max()
     e.close()
+
+
+@pytest.mark.parametrize("acc", [1e-4, 1e-6])
+def test_pppm_matches_the_oracle_pppm(small_pe, acc):
+    """kspace_style 1 (`kspace_style pppm`, in.set.lammps:36): charge assignment in LDS, hipFFT, influence function, field
+    interpolation -- against the oracle's PPPM (plain sums per line instead of FFTs): same grid rule, same adjusted g_ewald,
+    reciprocal energy, virial and forces to round-off; and, like the oracle's, close to the Ewald sum at the accuracy asked for."""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=acc)
+    e = capi.Engine(capi.default_params(kspace_style=1, **kw))
+    e.register_replica("pe", 1, small_pe)
+    f, en, w, info = e.debug_compute("pe", 1, use_shake=False)
+    o = po.Oracle(small_pe, po.default_params(kspace_pppm=1, **kw))
+    o.setup(False)
+    fo, eo, wo = o.compute()
+    assert info["nk"] == 0 and abs(info["g_ewald"] - o.g_ewald) < 1e-13
+    assert abs(en[6] - eo[6]) < 1e-10 * abs(eo[6]) and np.abs(w[6] - wo[6]).max() < 1e-10 * np.abs(wo[6]).max()
+    assert abs(en[1] - eo[1]) < 1e-10 * abs(eo[1])                      # real-space part with the adjusted g_ewald
+    assert np.abs(f - fo).max() < 1e-10 * np.abs(fo).max()
+    oe = po.Oracle(small_pe, po.default_params(**kw)); oe.setup(False)
+    fe = oe.compute()[0]
+    assert np.sqrt(((f - fe) ** 2).sum(1).mean()) < 12.0 * acc * 332.06371
+    e.close()
+
+
+def test_pppm_trajectory_with_deform_and_full_evaluation(small_pe):
+    """the mesh path through a whole evaluation: straining run (influence function of every step's box), sampling run, stress"""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+    e = capi.Engine(capi.default_params(kspace_style=1, **kw))
+    e.register_replica("pe", 1, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    strain = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 2e-4 * lens[2], 0.0, -1e-4 * lens[0]])
+    out = e.strain_batch([capi.make_sim(q, "pe", 1, strain * (1 + 0.2 * q), nss=20, most_recent=capi.QP_NONE) for q in range(3)])
+    for q in range(3):
+        o = po.Oracle(small_pe, po.default_params(kspace_pppm=1, **kw))
+        exp, _ = o.eval(strain * (1 + 0.2 * q), 2.0, 300.0, 1e-4, 20)
+        got = np.array(out[q].stress[:])
+        assert np.abs(got - exp).max() < 1e-7 * np.abs(exp).max(), (q, got, exp)
+    e.close()
