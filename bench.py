@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--equil-cache", default=None, help="npz file: load the equilibrated state from it if it exists, else write it (profiling runs: "
                     "keeps the 2 000 single-replica steps out of a PMC pass)")
     ap.add_argument("--monotonic", action="store_true", help="apply the tensile strain draws update after update (no unloading on odd updates)")
+    ap.add_argument("--kspace", default="ewald", choices=["ewald", "pppm"], help="reciprocal part: the Ewald sum (default, the reported configuration) "
+                    "or PPPM on hipFFT as `kspace_style pppm` asks for (SURVEY f-3; slower at this replica size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
@@ -173,6 +175,8 @@ def main():
     from scema_amd import capi
     # ablation knobs for kernel experiments only (never set in a reported run)
     extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
+    if args.kspace == "pppm":
+        extra["kspace_style"] = 1
     eng = capi.Engine(capi.default_params(device=device, profile=1, **extra))
     if world > 1:
         from scema_amd import comm
@@ -305,7 +309,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n} x PE-{natoms} OPLS replicas per update(), {req.get('nts_mean', 10.0):.0f}+{args.nss} MD steps each "
-                                   "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + Ewald 1e-4 + SHAKE + NVT), persistent per-QP state, "
+                                   "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + " + ("PPPM" if args.kspace == "pppm" else "Ewald") + " 1e-4 + SHAKE + NVT), persistent per-QP state, "
                                    f"replica equilibrated for {args.equil_steps} steps before the timed region",
                        "strain_set": args.strain_set + (" (monotonic)" if args.monotonic else " (load/unload: odd updates take the draw with the opposite sign)"), "n_sims": n, "atoms_per_replica": natoms, "md_steps_per_eval": req.get("nts_mean", 10.0) + args.nss,
                        "sharding": "engine planner (host/sim_plan.h): fresh batch i % N, then sticky to the GPU that holds the state, levelled by MD steps",

@@ -803,7 +803,7 @@ static double fit_coul_poly_n(long double umax, int N, double *poly) {
   return maxerr;
 }
 
-// Smallest even number of coefficients whose fit error is below 2e-13 (absolute, on a factor of order one):
+// Smallest number of coefficients whose fit error is below 2e-13 (absolute, on a factor of order one):
 // three orders below the parity budget of the forces (1e-11 relative), seven below LAMMPS' own table
 // (pair_modify table 12: ~1e-6).  Every coefficient is one FP64 FMA per coulomb pair in k_pair.
 static double fit_coul_poly(double g, double rc, double *poly, int *npoly, double *uscale) {
@@ -818,7 +818,7 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
   double err = 0.0, target = 2e-13;
   // measurement knob: what the precision of this factor costs (LAMMPS' own table is good to ~1e-6); parity tests run at the default
   if (const char *tv = getenv("SCEMA_MD_POLY_TOL")) target = std::min(1e-3, std::max(1e-15, atof(tv)));
-  for (int N = 6; N <= MD_MAXPOLY; N += 2) {
+  for (int N = 6; N <= MD_MAXPOLY; N++) {   // k_pair<.., 16> and beyond spill registers: an odd count that suffices is worth having
     err = fit_coul_poly_n(umax, N, poly);
     *npoly = N;
     if (err < target) break;
@@ -1362,16 +1362,18 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     S.krun = base + 3 * (size_t)S.nk;
     S.kgrp = base + ((4 * (size_t)S.nk + 3) / 4) * 4;
   }
-  // PPPM: four complex grids and the influence function per simulation, batch-contiguous (one batched transform per stage
-  // when all simulations share the grid, which they do for one material)
+  // PPPM: four complex grids and the influence function per simulation.  The charge grids of the batch are contiguous, and so
+  // are the field grids (three per simulation, simulation-major): one batched transform forward and ONE back for a launch
+  // group whose simulations share the grid, which they do for one material
   bool pppm_uniform = true;
   if (maxgrid > 0) {
     HIPCHK(e->d_pppm.ensure((size_t)ns * maxgrid * (4 * sizeof(double2) + sizeof(double))));
-    double *gbase = e->d_pppm.as<double>(), *fbase = gbase + (size_t)ns * maxgrid * 8;
+    double *gbase = e->d_pppm.as<double>(), *ebase = gbase + (size_t)ns * maxgrid * 2, *fbase = gbase + (size_t)ns * maxgrid * 8;
     for (int pos = 0; pos < ns; pos++) {
       SimDev &S = e->h_sims[pos];
-      S.pgrid = gbase + (size_t)pos * maxgrid * 2;          // grid g of simulation pos: complex element (g ns + pos) maxgrid
-      S.pgstride = (long long)ns * maxgrid;
+      S.pgrid = gbase + (size_t)pos * maxgrid * 2;
+      S.pfield = ebase + (size_t)pos * maxgrid * 6;
+      S.pgstride = (long long)maxgrid;
       S.pgf = fbase + (size_t)pos * maxgrid;
       for (int d = 0; d < 3; d++) pppm_uniform = pppm_uniform && S.pg[d] == e->h_sims[0].pg[d];
     }
@@ -1394,35 +1396,36 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   auto pppm_stage = [&](hipStream_t st, int pos0, int na, int full, bool new_box) -> int {
     if (maxgrid <= 0 || na <= 0) return SCEMA_MD_OK;
     const SimDev *Dp = e->d_sims.as<SimDev>() + pos0;
-    mdk_pppm_spread(st, Dp, na, maxgrid);
-    auto transform = [&](int which, int dir) -> int {
-      static const bool serial_fft = getenv("SCEMA_MD_PPPM_SERIAL") != nullptr;
-      if (!serial_fft && pppm_uniform && (size_t)e->h_sims[pos0].pg[0] * e->h_sims[pos0].pg[1] * e->h_sims[pos0].pg[2] == (size_t)maxgrid) {
-        hipfftHandle plan;
-        int rc = pppm_plan(e->h_sims[pos0].pg, full, plan);
-        if (rc) return rc;
-        hipfftDoubleComplex *g = (hipfftDoubleComplex *)(e->h_sims[pos0].pgrid) + (size_t)which * e->h_sims[pos0].pgstride;
-        if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS || hipfftExecZ2Z(plan, g, g, dir) != HIPFFT_SUCCESS) return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftExecZ2Z failed");
-      } else {
-        for (int k = 0; k < na; k++) {
-          const SimDev &S = e->h_sims[pos0 + k];
-          if (S.pg[0] == 0) continue;
-          hipfftHandle plan;
-          int rc = pppm_plan(S.pg, 1, plan);
-          if (rc) return rc;
-          hipfftDoubleComplex *g = (hipfftDoubleComplex *)S.pgrid + (size_t)which * S.pgstride;
-          if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS || hipfftExecZ2Z(plan, g, g, dir) != HIPFFT_SUCCESS) return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftExecZ2Z failed");
-        }
+    mdk_pppm_spread(st, Dp, na, maxgrid, maxatoms);
+    auto transform = [&](bool fields, int dir) -> int {   // the charge grids forward, or the three field grids of every simulation back
+      static const bool serial_fft = getenv("SCEMA_MD_PPPM_SERIAL") != nullptr;   // debugging: one transform per simulation and grid
+      auto exec = [&](hipfftHandle plan, double *g) -> int {
+        if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS || hipfftExecZ2Z(plan, (hipfftDoubleComplex *)g, (hipfftDoubleComplex *)g, dir) != HIPFFT_SUCCESS)
+          return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftExecZ2Z failed");
+        return SCEMA_MD_OK;
+      };
+      const SimDev &S0 = e->h_sims[pos0];
+      int rc;
+      hipfftHandle plan;
+      if (!serial_fft && pppm_uniform && (size_t)S0.pg[0] * S0.pg[1] * S0.pg[2] == (size_t)maxgrid) {
+        if ((rc = pppm_plan(S0.pg, fields ? 3 * full : full, plan))) return rc;
+        return exec(plan, fields ? S0.pfield : S0.pgrid);
+      }
+      for (int k = 0; k < na; k++) {
+        const SimDev &S = e->h_sims[pos0 + k];
+        if (S.pg[0] == 0) continue;
+        if ((rc = pppm_plan(S.pg, 1, plan))) return rc;
+        for (int c = 0; c < (fields ? 3 : 1); c++)
+          if ((rc = exec(plan, fields ? S.pfield + 2 * (size_t)c * S.pgstride : S.pgrid))) return rc;
       }
       return SCEMA_MD_OK;
     };
-    int rc = transform(0, HIPFFT_FORWARD);
+    int rc = transform(false, HIPFFT_FORWARD);
     if (rc) return rc;
     if (new_box) mdk_pppm_gf(st, Dp, na, maxgrid);
     mdk_pppm_poisson(st, Dp, na, maxgrid);
-    for (int c = 1; c <= 3; c++)
-      if ((rc = transform(c, HIPFFT_BACKWARD))) return rc;
-    mdk_pppm_force(st, Dp, na, maxatoms);
+    if ((rc = transform(true, HIPFFT_BACKWARD))) return rc;
+    mdk_pppm_force(st, Dp, na, maxgrid, maxatoms);
     return SCEMA_MD_OK;
   };
   HIPCHK(e->d_sims.ensure((size_t)ns * sizeof(SimDev)));

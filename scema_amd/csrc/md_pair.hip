@@ -914,6 +914,7 @@ void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, i
   else if (npoly <= 10) launch_pair<10>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 14) launch_pair<14>(st, d, ns, maxcells, capj, vir, eng);
+  else if (npoly <= 15) launch_pair<15>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 16) launch_pair<16>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 18) launch_pair<18>(st, d, ns, maxcells, capj, vir, eng);
   else if (npoly <= 20) launch_pair<20>(st, d, ns, maxcells, capj, vir, eng);

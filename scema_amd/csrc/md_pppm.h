@@ -5,10 +5,10 @@
 struct SimDev;
 size_t mdk_pppm_lds_limit();
 // charges -> grid 0 (complex, imaginary part 0); maxgrid = largest nx*ny*nz of the batch
-void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid);
+void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms);
 // influence function of the current box into SimDev::pgf
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid);
 // after the forward transform of grid 0: energy, virial, field spectra into grids 1..3
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid);
 // after the inverse transforms of grids 1..3: forces added to SimDev::f
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxatoms);
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms);

@@ -5,21 +5,28 @@
 // optimal influence function for ik differentiation with direct alias sums, energy and virial in reciprocal space, three
 // inverse transforms for the field, forces by the same weights.  Transforms: hipFFT, one batched plan for all replicas of a
 // launch group (they share the grid).  One launch per stage for the whole batch:
-//   k_pppm_spread   one workgroup per replica; the real grid lives in LDS while the charges are spread (ds_add_f64), then
-//                   leaves as the complex input of the transform (grids too large for the LDS: global atomics)
+//   k_pppm_spread   a few workgroups per replica, each with a private copy of the real grid in LDS while its atoms are spread
+//                   (ds_add_f64), added to the complex input of the transform at the end (grids beyond the LDS: global atomics)
 //   k_pppm_gf       influence function of the current box, 125 alias terms per mode; only when the box has changed
 //   k_pppm_poisson  energy, virial, field spectra -i k G rho(k)
-//   k_pppm_force    per atom: the 125 grid points of three field grids, added to the forces the other kernels assembled
+//   k_pppm_force    per atom: the 125 grid points of three field grids (staged in LDS when they fit), added to the forces the
+//                   other kernels assembled
 #include <hip/hip_runtime.h>
 
 #include "md_device.h"
 #include "md_pppm.h"
 #include "md_types.h"
 
+#include <algorithm>
+
+static inline dim3 grid2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)ns, 1); }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
 #define PP_ORDER 5
 #define PP_TPB 1024
 
-// weights of the order-5 cardinal B-spline at the 5 grid points i-2 .. i+2 around u, i = floor(u + 1/2) (oracle: pppm_weights)
+// weights of the order-5 cardinal B-spline at the 5 grid points i-2 .. i+2 around u, i = floor(u + 1/2) (oracle: pppm_weights;
+// the divisions of the recursion are multiplications by the rounded reciprocals here: one unit in the last place)
 __device__ __forceinline__ int pppm_weights(double u, double (&w)[PP_ORDER]) {
   const int i = (int)floor(u + 0.5);
   const double dx = (double)i - u;
@@ -34,63 +41,98 @@ __device__ __forceinline__ int pppm_weights(double u, double (&w)[PP_ORDER]) {
 #pragma unroll
       for (int j = 0; j + n <= PP_ORDER; j++) {
         const double tj = t - j;
-        m[j] = (tj * m[j] + ((double)n - tj) * m[j + 1]) / (double)(n - 1);
+        m[j] = (tj * m[j] + ((double)n - tj) * m[j + 1]) * (1.0 / (double)(n - 1));
       }
     w[k] = m[0];
   }
   return i;
 }
 __device__ __forceinline__ int pmod(int a, int n) { const int r = a % n; return r < 0 ? r + n : r; }
+// the five periodic grid indices i-2 .. i+2 of one dimension (0 <= i <= n); grids of fewer than 4 points wrap more than once
+__device__ __forceinline__ void pppm_wrap(int i, int n, int (&g)[PP_ORDER]) {
+#pragma unroll
+  for (int k = 0; k < PP_ORDER; k++) {
+    const int v = i + k - 2;
+    g[k] = v < 0 ? v + n : (v >= n ? v - n : v);
+  }
+  if (n < 4)
+#pragma unroll
+    for (int k = 0; k < PP_ORDER; k++) g[k] = pmod(i + k - 2, n);
+}
 __device__ __forceinline__ void atom_lamda(const SimDev &S, const BoxD &b, int a, double &t0, double &t1, double &t2) {
   const double d0 = S.x[3 * a] - b.lo[0], d1 = S.x[3 * a + 1] - b.lo[1], d2 = S.x[3 * a + 2] - b.lo[2];
   const double l0 = b.hinv[0] * d0 + b.hinv[5] * d1 + b.hinv[4] * d2, l1 = b.hinv[1] * d1 + b.hinv[3] * d2, l2 = b.hinv[2] * d2;
   t0 = l0 - floor(l0); t1 = l1 - floor(l1); t2 = l2 - floor(l2);
 }
 
+// grid 0 <- 0 for the spreading kernels that add to it from several workgroups
+__global__ __launch_bounds__(256) void k_pppm_zero(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  const int NG = S.pg[0] * S.pg[1] * S.pg[2], idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < NG) ((double2 *)S.pgrid)[idx] = make_double2(0.0, 0.0);
+}
+
+// Charge assignment.  Workgroup (s, r) takes the s-th of `split` contiguous atom ranges of replica r.  Within a wave the lanes
+// take atoms that are far apart in the file (lane l: atoms l*rows .. (l+1)*rows - 1 of the range, one per iteration): bonded
+// neighbours share their 125 grid points, and 64 lanes adding to the same addresses would be serialised by the LDS.  LDS = true:
+// a private copy of the real grid in LDS (ds_add_f64), added to grid 0 at the end (the only global atomics: one per grid point
+// and workgroup; a direct store when the replica has one workgroup).  LDS = false (grid beyond the LDS): global atomics throughout.
 extern __shared__ double s_grid[];
-__global__ __launch_bounds__(PP_TPB) void k_pppm_spread(const SimDev *sims, int use_lds) {
-  const SimDev &S = sims[blockIdx.x];
+template <bool LDS>
+__global__ __launch_bounds__(PP_TPB) void k_pppm_spread(const SimDev *sims, int split) {
+  const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
   if (nx == 0) return;
-  const int NG = nx * ny * nz;
+  const int NG = nx * ny * nz, T = (int)blockDim.x;
+  const int chunk = (S.natoms + split - 1) / split, a0 = (int)blockIdx.x * chunk, a1 = min(S.natoms, a0 + chunk);
+  if (a0 >= a1) return;
   BoxD b;
   box_derive(S.sc->box, b);
   double2 *rho = (double2 *)S.pgrid;
-  if (use_lds) {
-    for (int k = threadIdx.x; k < NG; k += PP_TPB) s_grid[k] = 0.0;
-  } else {
-    for (int k = threadIdx.x; k < NG; k += PP_TPB) rho[k] = make_double2(0.0, 0.0);
-    __threadfence_block();
+  if (LDS) {
+    for (int k = threadIdx.x; k < NG; k += T) s_grid[k] = 0.0;
+    __syncthreads();
   }
-  __syncthreads();
   const double delvolinv = (double)NG / b.vol;
-  for (int a = threadIdx.x; a < S.natoms; a += PP_TPB) {
+  const int rows = (a1 - a0 + 63) >> 6, lane = threadIdx.x & 63;
+  for (int r = (int)threadIdx.x >> 6; r < rows; r += T >> 6) {
+    const int a = a0 + lane * rows + r;
+    if (a >= a1) continue;
+    const double z0 = delvolinv * S.q[a];
+    if (z0 == 0.0) continue;
     double l0, l1, l2;
     atom_lamda(S, b, a, l0, l1, l2);
     double wx[PP_ORDER], wy[PP_ORDER], wz[PP_ORDER];
-    const int ix = pppm_weights(l0 * nx, wx), iy = pppm_weights(l1 * ny, wy), iz = pppm_weights(l2 * nz, wz);
-    const double z0 = delvolinv * S.q[a];
-    if (z0 == 0.0) continue;
+    int gx[PP_ORDER], gy[PP_ORDER], gz[PP_ORDER];
+    pppm_wrap(pppm_weights(l0 * nx, wx), nx, gx);
+    pppm_wrap(pppm_weights(l1 * ny, wy), ny, gy);
+    pppm_wrap(pppm_weights(l2 * nz, wz), nz, gz);
+#pragma unroll
+    for (int k = 0; k < PP_ORDER; k++) wx[k] *= z0;
 #pragma unroll
     for (int c = 0; c < PP_ORDER; c++) {
-      const int gz = pmod(iz + c - 2, nz);
 #pragma unroll
       for (int bb = 0; bb < PP_ORDER; bb++) {
-        const int gy = pmod(iy + bb - 2, ny);
-        const double zy = z0 * wz[c] * wy[bb];
-        const int row = (gz * ny + gy) * nx;
+        const double zy = wz[c] * wy[bb];
+        const int row = (gz[c] * ny + gy[bb]) * nx;
 #pragma unroll
         for (int k = 0; k < PP_ORDER; k++) {
-          const int gx = pmod(ix + k - 2, nx);
-          if (use_lds) (void)__hip_atomic_fetch_add(&s_grid[row + gx], zy * wx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          else atomicAdd(&rho[row + gx].x, zy * wx[k]);
+          if (LDS) (void)__hip_atomic_fetch_add(&s_grid[row + gx[k]], zy * wx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else atomicAdd(&rho[row + gx[k]].x, zy * wx[k]);
         }
       }
     }
   }
-  if (use_lds) {
+  if (LDS) {
     __syncthreads();
-    for (int k = threadIdx.x; k < NG; k += PP_TPB) rho[k] = make_double2(s_grid[k], 0.0);
+    if (split == 1) {
+      for (int k = threadIdx.x; k < NG; k += T) rho[k] = make_double2(s_grid[k], 0.0);
+    } else {
+      for (int k = threadIdx.x; k < NG; k += T) {
+        const double v = s_grid[k];
+        if (v != 0.0) atomicAdd(&rho[k].x, v);
+      }
+    }
   }
 }
 
@@ -139,7 +181,7 @@ __global__ __launch_bounds__(256) void k_pppm_gf(const SimDev *sims) {
   S.pgf[idx] = 4.0 * MD_PI / sqk * num / (den * den);
 }
 
-// energy, virial and the three field spectra; grid 0 holds rho(k) (unnormalised), grids 1..3 receive E_x, E_y, E_z (k)
+// energy, virial and the three field spectra; the charge grid holds rho(k) (unnormalised), the field grids receive E_x, E_y, E_z (k)
 __global__ __launch_bounds__(256) void k_pppm_poisson(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
@@ -161,9 +203,10 @@ __global__ __launch_bounds__(256) void k_pppm_poisson(const SimDev *sims) {
     const double ar = r.x * scaleinv, ai = r.y * scaleinv;
     const double pr = gf * ar, pi = gf * ai;
     const size_t gs = (size_t)S.pgstride;
-    grid[gs + idx] = make_double2(kx * pi, -kx * pr);       // (a + i b)(-i k) = b k - i a k
-    grid[2 * gs + idx] = make_double2(ky * pi, -ky * pr);
-    grid[3 * gs + idx] = make_double2(kz * pi, -kz * pr);
+    double2 *field = (double2 *)S.pfield;
+    field[idx] = make_double2(kx * pi, -kx * pr);       // (a + i b)(-i k) = b k - i a k
+    field[gs + idx] = make_double2(ky * pi, -ky * pr);
+    field[2 * gs + idx] = make_double2(kz * pi, -kz * pr);
     if (gf != 0.0) {
       const double sqk = kx * kx + ky * ky + kz * kz;
       const double eg = 0.5 * b.vol * MD_QQRD2E * gf * (ar * ar + ai * ai);
@@ -179,56 +222,90 @@ __global__ __launch_bounds__(256) void k_pppm_poisson(const SimDev *sims) {
   block_atomic_add_n<1, 4>(e, S.sc->eng + P_KSPACE, s_red);
 }
 
-// forces: the field (real parts of grids 1..3 after the inverse transforms) at the atom, by the assignment weights
-__global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims) {
+// forces: the field (real parts of grids 1..3 after the inverse transforms) at the atom, by the assignment weights.  LDS = true:
+// workgroup (s, r) stages the three real field grids of replica r in LDS once and serves the s-th of `split` atom ranges
+// (consecutive atoms in consecutive lanes: neighbours read the same grid points, which the LDS broadcasts); LDS = false reads
+// the grids through the caches.
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int split) {
   const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
   if (nx == 0) return;
-  const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= S.natoms) return;
-  const double qa = S.q[a];
-  if (qa == 0.0) return;
+  const int NG = nx * ny * nz;
+  int chunk = (S.natoms + split - 1) / split;
+  chunk = (chunk + 255) & ~255;
+  const int a0 = (int)blockIdx.x * chunk, a1 = min(S.natoms, a0 + chunk);
+  if (a0 >= a1) return;
+  const size_t gs = (size_t)S.pgstride;
+  const double2 *ex = (const double2 *)S.pfield, *ey = ex + gs, *ez = ey + gs;
+  if (LDS) {
+    for (int k = threadIdx.x; k < NG; k += 256) { s_grid[k] = ex[k].x; s_grid[NG + k] = ey[k].x; s_grid[2 * NG + k] = ez[k].x; }
+    __syncthreads();
+  }
   BoxD b;
   box_derive(S.sc->box, b);
-  const size_t gs = (size_t)S.pgstride;
-  const double2 *ex = (const double2 *)S.pgrid + gs, *ey = ex + gs, *ez = ey + gs;
-  double l0, l1, l2;
-  atom_lamda(S, b, a, l0, l1, l2);
-  double wx[PP_ORDER], wy[PP_ORDER], wz[PP_ORDER];
-  const int ix = pppm_weights(l0 * nx, wx), iy = pppm_weights(l1 * ny, wy), iz = pppm_weights(l2 * nz, wz);
-  double fx = 0.0, fy = 0.0, fz = 0.0;
+  for (int a = a0 + (int)threadIdx.x; a < a1; a += 256) {
+    const double qa = S.q[a];
+    if (qa == 0.0) continue;
+    double l0, l1, l2;
+    atom_lamda(S, b, a, l0, l1, l2);
+    double wx[PP_ORDER], wy[PP_ORDER], wz[PP_ORDER];
+    int gx[PP_ORDER], gy[PP_ORDER], gz[PP_ORDER];
+    pppm_wrap(pppm_weights(l0 * nx, wx), nx, gx);
+    pppm_wrap(pppm_weights(l1 * ny, wy), ny, gy);
+    pppm_wrap(pppm_weights(l2 * nz, wz), nz, gz);
+    double fx = 0.0, fy = 0.0, fz = 0.0;
 #pragma unroll
-  for (int c = 0; c < PP_ORDER; c++) {
-    const int gz = pmod(iz + c - 2, nz);
+    for (int c = 0; c < PP_ORDER; c++) {
 #pragma unroll
-    for (int bb = 0; bb < PP_ORDER; bb++) {
-      const int gy = pmod(iy + bb - 2, ny);
-      const double zy = wz[c] * wy[bb];
-      const size_t row = ((size_t)gz * ny + gy) * nx;
+      for (int bb = 0; bb < PP_ORDER; bb++) {
+        const double zy = wz[c] * wy[bb];
+        const int row = (gz[c] * ny + gy[bb]) * nx;
+        double rx = 0.0, ry = 0.0, rz = 0.0;
 #pragma unroll
-      for (int k = 0; k < PP_ORDER; k++) {
-        const size_t g = row + pmod(ix + k - 2, nx);
-        const double w = zy * wx[k];
-        fx = fma(w, ex[g].x, fx); fy = fma(w, ey[g].x, fy); fz = fma(w, ez[g].x, fz);
+        for (int k = 0; k < PP_ORDER; k++) {
+          const int g = row + gx[k];
+          if (LDS) { rx = fma(wx[k], s_grid[g], rx); ry = fma(wx[k], s_grid[NG + g], ry); rz = fma(wx[k], s_grid[2 * NG + g], rz); }
+          else { rx = fma(wx[k], ex[g].x, rx); ry = fma(wx[k], ey[g].x, ry); rz = fma(wx[k], ez[g].x, rz); }
+        }
+        fx = fma(zy, rx, fx); fy = fma(zy, ry, fy); fz = fma(zy, rz, fz);
       }
     }
+    const double qf = MD_QQRD2E * qa;
+    S.f[3 * a] += qf * fx; S.f[3 * a + 1] += qf * fy; S.f[3 * a + 2] += qf * fz;
   }
-  const double qf = MD_QQRD2E * qa;
-  S.f[3 * a] += qf * fx; S.f[3 * a + 1] += qf * fy; S.f[3 * a + 2] += qf * fz;
 }
 
-static inline dim3 grid2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)ns, 1); }
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 size_t mdk_pppm_lds_limit() { return 144 * 1024; }
-void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid) {
+// atom ranges per replica: enough workgroups to fill the 256 CUs several times over, none with fewer than 256 atoms
+static inline int pppm_split(int ns, int maxatoms) { return std::max(1, std::min(std::min(16, cdiv(2048, ns)), maxatoms / 256)); }
+void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms) {
   const size_t lds = (size_t)maxgrid * sizeof(double);
-  const int use_lds = lds <= mdk_pppm_lds_limit() ? 1 : 0;
+  const bool use_lds = lds <= mdk_pppm_lds_limit();
+  const int split = pppm_split(ns, maxatoms);
+  if (!use_lds || split > 1) hipLaunchKernelGGL(k_pppm_zero, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d);
+  if (!use_lds) {
+    hipLaunchKernelGGL(k_pppm_spread<false>, grid2(split, ns), dim3(256), 0, st, d, split);
+    return;
+  }
   static size_t optin_tab[16] = {0};
   size_t &optin = lds_optin_slot(optin_tab);
-  if (use_lds && lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_spread, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  hipLaunchKernelGGL(k_pppm_spread, dim3(ns), dim3(PP_TPB), use_lds ? lds : 0, st, d, use_lds);
+  if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_spread<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+  // a small grid leaves room for several workgroups per CU; a large one gets the CU to itself and brings its own sixteen waves
+  hipLaunchKernelGGL(k_pppm_spread<true>, grid2(split, ns), dim3(lds <= 36 * 1024 ? 256 : PP_TPB), lds, st, d, split);
 }
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_gf, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_poisson, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxatoms) { hipLaunchKernelGGL(k_pppm_force, grid2(cdiv(maxatoms, 256), ns), dim3(256), 0, st, d); }
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms) {
+  const size_t lds = 3 * (size_t)maxgrid * sizeof(double);
+  if (lds > mdk_pppm_lds_limit()) {
+    hipLaunchKernelGGL(k_pppm_force<false>, grid2(cdiv(maxatoms, 256), ns), dim3(256), 0, st, d, cdiv(maxatoms, 256));
+    return;
+  }
+  static size_t optin_tab[16] = {0};
+  size_t &optin = lds_optin_slot(optin_tab);
+  if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_force<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+  const int split = pppm_split(ns, maxatoms);
+  hipLaunchKernelGGL(k_pppm_force<true>, grid2(split, ns), dim3(256), lds, st, d, split);
+}

@@ -171,9 +171,9 @@ struct SimDev {
   double *kvec;     // 4 per k : kx,ky,kz,ug
   // PPPM (md_pppm.hip; pg[0] == 0: the Ewald sum above is used)
   int pg[3], pad_pg_;
-  double *pgrid;    // complex grid [nz][ny][nx] (x fastest) of this simulation: charge density / its transform; the three field components
-                    // follow pgstride complex elements apart each (the batch keeps grid g of all simulations together: one batched,
-                    // contiguous transform per stage)
+  double *pgrid;    // complex grid [nz][ny][nx] (x fastest) of this simulation: charge density / its transform
+  double *pfield;   // the three complex field grids of this simulation, pgstride complex elements apart (the batch keeps the charge
+                    // grids of all simulations together, and all field grids: one batched, contiguous transform per direction)
   long long pgstride;
   double *pgf;      // influence function [nz][ny][nx]
   SimScalars *sc;

@@ -447,3 +447,42 @@ def test_pppm_trajectory_with_deform_and_full_evaluation(small_pe):
         got = np.array(out[q].stress[:])
         assert np.abs(got - exp).max() < 1e-7 * np.abs(exp).max(), (q, got, exp)
     e.close()
+
+
+def test_pppm_grid_too_large_for_the_lds_and_mixed_grids(small_pe):
+    """a grid beyond the LDS (tight accuracy) takes the global-atomics spreading path; two replicas with different boxes (hence
+    different grids) in one batch take per-replica transforms"""
+    from copy import deepcopy
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=3e-8)
+    e = capi.Engine(capi.default_params(kspace_style=1, **kw))
+    e.register_replica("pe", 1, small_pe)
+    f, en, w, info = e.debug_compute("pe", 1, use_shake=False)
+    o = po.Oracle(small_pe, po.default_params(kspace_pppm=1, **kw))
+    o.setup(False)
+    fo, eo, wo = o.compute()
+    nx, ny, nz = o.pppm_grid
+    assert nx * ny * nz * 8 > 144 * 1024                                     # larger than the LDS budget of k_pppm_spread
+    assert abs(en[6] - eo[6]) < 1e-9 * abs(eo[6]) and np.abs(f - fo).max() < 1e-9 * np.abs(fo).max()
+    e.close()
+    # mixed grids: the second replica type lives in a box stretched by 50 % along z (18 instead of 15 grid planes)
+    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+    d2 = deepcopy(small_pe)
+    d2["box"] = d2["box"].copy(); d2["x"] = d2["x"].copy()
+    lz = d2["box"][5] - d2["box"][2]
+    d2["x"][:, 2] = d2["box"][2] + (d2["x"][:, 2] - d2["box"][2]) * 1.5
+    d2["box"][5] = d2["box"][2] + 1.5 * lz
+    e = capi.Engine(capi.default_params(kspace_style=1, **kw))
+    e.register_replica("a", 1, small_pe)
+    e.register_replica("b", 1, d2)
+    st = np.array([1e-3, -5e-4, 2e-3, 0.0, 1e-3, 0.0])
+    out = e.strain_batch([capi.make_sim(0, "a", 1, st, nss=10, most_recent=capi.QP_NONE), capi.make_sim(1, "b", 1, st, nss=10, most_recent=capi.QP_NONE)])
+    grids = []
+    for q, d in enumerate((small_pe, d2)):
+        oq = po.Oracle(d, po.default_params(kspace_pppm=1, **kw))
+        exp, _ = oq.eval(st, 2.0, 300.0, 1e-4, 10)
+        grids.append(oq.pppm_grid)
+        assert np.abs(np.array(out[q].stress[:]) - exp).max() < 1e-7 * np.abs(exp).max(), q
+    assert grids[0] != grids[1]
+    e.close()

@@ -158,3 +158,22 @@ def test_eqmd_equil_from_a_data_file_to_the_files_stmd_init_reads(tmp_path):
     bg = e2.get_state(capi.QP_NONE, "pe", 1)[0]
     assert np.allclose(bg[3:6] - bg[:3], length, rtol=1e-12)      # the equilibrated box travelled with the file
     e.close(); e2.close()
+
+
+def test_barostatted_run_with_the_mesh_solver(eng, small_pe):
+    """fix npt with kspace_style pppm: the influence function follows the box every step, the grid and g_ewald of the run's start
+    carry across segment seams"""
+    from scema_amd import capi
+    from oracle import pyoracle as po
+    e = capi.Engine(capi.default_params(kspace_style=1, **KW))
+    e.register_replica("pe", 1, small_pe)
+    o = po.Oracle(small_pe, po.default_params(shake_mass=0.0, kspace_pppm=1, **KW))
+    o.velocity_create(150.0, seed=5)
+    box, x, v = o.get_state()
+    e.set_state(0, "pe", 1, box, x, v)
+    e.run_nh("pe", 1, 0, 300, 0.5, 150.0, 200.0, npt=True, p_target=1.0, p_period=100.0)     # 250 + 50: one seam
+    o.run_nh(300, 0.5, 150.0, 200.0, npt=True, p_target=1.0, p_period=100.0)
+    bo, xo, _ = o.get_state()
+    bg, xg, _ = e.get_state(0, "pe", 1)
+    assert np.abs(bg - bo).max() < 1e-8 and np.abs(xg - xo).max() < 1e-6
+    e.close()
