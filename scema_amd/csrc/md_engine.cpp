@@ -21,6 +21,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <ctime>
 #include <array>
@@ -211,7 +212,7 @@ struct scema_md_engine {
   std::map<std::string, std::unique_ptr<State>> states;
   std::vector<std::unique_ptr<Slot>> slots;
   DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair, d_pppm;
-  std::map<std::array<int, 4>, hipfftHandle> pppm_plans;   // (nx, ny, nz, batch) -> batched 3-d Z2Z plan over contiguous grids
+  std::map<std::array<int, 5>, hipfftHandle> pppm_plans;   // (nx, ny, nz, batch, stream) -> batched 3-d Z2Z plan over contiguous grids (a plan owns work space: one per stream)
   std::vector<int> h_kpack;   // host copy, alive until the stream has consumed the upload
   int local_stress_count = 0;
   std::vector<SimDev> h_sims;
@@ -1038,7 +1039,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
 // After k_pair: bonded terms on the main stream, structure factors + per-k coefficients on the side stream (both
 // are small, latency-bound kernels that need only the positions), joined before the per-atom reciprocal force.
 static hipError_t force_stage(scema_md_engine *e, hipStream_t st, bool allow_side, const SimDev *D, int ns, int maxbt, int maxloc, int maxcoef, int maxatoms,
-                              int maxk, int mmax, int maxgrp, int parts, int pairvir) {
+                              int maxk, int mmax, int maxgrp, int parts, int pairvir, bool pppm_ahead = false) {
   const bool side = allow_side && maxk > 0 && e->stream2 != nullptr && ns >= 16;   // small batches: the fork/join costs more than it hides
   if (side) {
     hipError_t rc = hipEventRecord(e->ev_fork, st);
@@ -1054,7 +1055,11 @@ static hipError_t force_stage(scema_md_engine *e, hipStream_t st, bool allow_sid
   } else {
     mdk_ewald_recip(st, D, ns, maxk, mmax, maxgrp);
   }
-  mdk_ewald_force(st, D, ns, maxatoms, pairvir);
+  if (pppm_ahead) {   // the PPPM chain of this step ran on the side stream and left its forces in SimDev::f
+    hipError_t rc = hipStreamWaitEvent(st, e->ev_join, 0);
+    if (rc != hipSuccess) return rc;
+  }
+  mdk_ewald_force(st, D, ns, maxatoms, pairvir, pppm_ahead ? 1 : 0);
   return hipSuccess;
 }
 
@@ -1066,6 +1071,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   if (e->reax_active) return run_phase_reax(e, sims, spec);
   const int ns = (int)sims.size();
   const scema_md_params &P = e->p;
+  const auto t_enter = std::chrono::steady_clock::now();
   const double cutmax_all = std::max(P.cut_lj, P.cut_coul);
   // order: longest run first, so the active simulations are always a prefix
   std::vector<int> order(ns);
@@ -1378,8 +1384,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       for (int d = 0; d < 3; d++) pppm_uniform = pppm_uniform && S.pg[d] == e->h_sims[0].pg[d];
     }
   }
-  auto pppm_plan = [&](const int pg[3], int batch, hipfftHandle &plan) -> int {
-    const std::array<int, 4> key = {pg[0], pg[1], pg[2], batch};
+  auto pppm_plan = [&](const int pg[3], int batch, hipStream_t st, hipfftHandle &plan) -> int {
+    const std::array<int, 5> key = {pg[0], pg[1], pg[2], batch, st == e->stream ? 0 : st == e->stream2 ? 1 : 2};
     auto it = e->pppm_plans.find(key);
     if (it == e->pppm_plans.end()) {
       hipfftHandle h;
@@ -1393,7 +1399,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     return SCEMA_MD_OK;
   };
   // reciprocal part by PPPM for the simulations [pos0, pos0 + na) of a launch group of `full` (md_pppm.hip); after force_stage
-  auto pppm_stage = [&](hipStream_t st, int pos0, int na, int full, bool new_box) -> int {
+  auto pppm_stage = [&](hipStream_t st, int pos0, int na, int full, bool new_box, int add = 1) -> int {
     if (maxgrid <= 0 || na <= 0) return SCEMA_MD_OK;
     const SimDev *Dp = e->d_sims.as<SimDev>() + pos0;
     mdk_pppm_spread(st, Dp, na, maxgrid, maxatoms);
@@ -1408,13 +1414,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       int rc;
       hipfftHandle plan;
       if (!serial_fft && pppm_uniform && (size_t)S0.pg[0] * S0.pg[1] * S0.pg[2] == (size_t)maxgrid) {
-        if ((rc = pppm_plan(S0.pg, fields ? 3 * full : full, plan))) return rc;
+        if ((rc = pppm_plan(S0.pg, fields ? 3 * full : full, st, plan))) return rc;
         return exec(plan, fields ? S0.pfield : S0.pgrid);
       }
       for (int k = 0; k < na; k++) {
         const SimDev &S = e->h_sims[pos0 + k];
         if (S.pg[0] == 0) continue;
-        if ((rc = pppm_plan(S.pg, 1, plan))) return rc;
+        if ((rc = pppm_plan(S.pg, 1, st, plan))) return rc;
         for (int c = 0; c < (fields ? 3 : 1); c++)
           if ((rc = exec(plan, fields ? S.pfield + 2 * (size_t)c * S.pgstride : S.pgrid))) return rc;
       }
@@ -1425,11 +1431,27 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (new_box) mdk_pppm_gf(st, Dp, na, maxgrid);
     mdk_pppm_poisson(st, Dp, na, maxgrid);
     if ((rc = transform(true, HIPFFT_BACKWARD))) return rc;
-    mdk_pppm_force(st, Dp, na, maxgrid, maxatoms);
+    mdk_pppm_force(st, Dp, na, maxgrid, maxatoms, add);
+    return SCEMA_MD_OK;
+  };
+  // With one launch group and the side stream, the whole PPPM chain of a step (it needs the positions only) runs next to
+  // k_pair and the bonded kernel: its forces are stored in SimDev::f, and k_ewald_force, which assembles the force of the
+  // step, adds them after the join.  Otherwise the chain follows the assembly and adds to it.  PE-10k, evaluations per second
+  // with the chain on the side stream / inline: 8 replicas 210 / 183, 72: 336 / 333, 576: 369 / 368; a single replica 39.7 / 41.6
+  // (its k_pair does not fill the chip and the fork/join is pure latency), so batches below four stay inline.
+  const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= 4 && !getenv("SCEMA_MD_PPPM_INLINE");
+  auto pppm_fork = [&](hipStream_t st, int pos0, int na, int full, bool new_box) -> int {
+    if (!pppm_side) return SCEMA_MD_OK;
+    HIPCHK(hipEventRecord(e->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+    const int rc = pppm_stage(e->stream2, pos0, na, full, new_box, 0);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->ev_join, e->stream2));
     return SCEMA_MD_OK;
   };
   HIPCHK(e->d_sims.ensure((size_t)ns * sizeof(SimDev)));
   HIPCHK(hipMemcpyAsync(e->d_sims.p, e->h_sims.data(), (size_t)ns * sizeof(SimDev), hipMemcpyHostToDevice, e->stream));
+  const auto t_laid_out = std::chrono::steady_clock::now();
   const SimDev *D = e->d_sims.as<SimDev>();
   hipStream_t hs[2] = {e->stream, nhalf == 2 ? e->stream3 : e->stream};
   if (nhalf == 2) {   // the second stream starts behind the uploads
@@ -1445,9 +1467,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     const int nh = hcnt[h];
     mdk_phase_init(st, Dh, nh);
     mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
+    { const int rcp = pppm_fork(st, hbeg[h], nh, nh, true); if (rcp) return rcp; }
     mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
-    HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
-    { const int rcp = pppm_stage(st, hbeg[h], nh, nh, true); if (rcp) return rcp; }
+    HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
+    if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], nh, nh, true); if (rcp) return rcp; }
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
     mdk_final_integrate(st, Dh, nh, maxatoms, 0);
     if (spec.nh) mdk_setup_post_nh(st, Dh, nh);
@@ -1514,6 +1537,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (spec.nh) { mdk_pre_nh(st, Dh, na); mdk_initial_integrate_nh(st, Dh, na, maxatoms); }
     else { mdk_pre(st, Dh, na); mdk_initial_integrate(st, Dh, na, maxatoms); }
     mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj);
+    { const int rcp = pppm_fork(st, hbeg[h], na, hcnt[h], spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
     if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;
@@ -1530,8 +1554,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       ev_used += 2;
       launch_sims.push_back({hbeg[h], na});
     }
-    HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0));
-    { const int rcp = pppm_stage(st, hbeg[h], na, hcnt[h], spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
+    HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
+    if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], na, hcnt[h], spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
     mdk_shake(st, Dh, na, maxclus, 1.0);
     mdk_final_integrate(st, Dh, na, maxatoms, 1);
     if (spec.nh) mdk_post_nh(st, Dh, na);
@@ -1678,6 +1702,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     fprintf(stderr, "[scema_md] sim 0: cells %dx%dx%d, j table max %d of %d, row max %d of %d, row entries/cluster %.1f, listed pairs/atom %.1f, builds %d\n",
             S0.nc[0], S0.nc[1], S0.nc[2], c.maxj_seen, S0.capj, c.maxneigh_seen, S0.maxneigh, (double)c.nrowent / (S0.npad / MD_CLUSTER),
             (double)c.nentries / S0.natoms, c.nbuilds);
+    fprintf(stderr, "[scema_md] host: %.2f ms laying out %d simulations before the first launch of this run\n",
+            std::chrono::duration<double, std::milli>(t_laid_out - t_enter).count(), ns);
     fprintf(stderr, "[scema_md] sim 0: far skin band walked on %d of %d steps; list skin %.2f A\n", c.nfar_steps, c.step, S0.skin);
 #ifdef PAIR_TIMING
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",

@@ -19,7 +19,7 @@ void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxlo
 // second stream next to the bonded kernel.  pairvir != 0: k_ewald_force also folds the production pair virial
 // (slot-ordered forces x positions + the per-wave image-shift partials of k_pair) into the virial of the step
 void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax, int maxgrp);
-void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir);
+void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir, int fkeep = 0);   // fkeep: add to the forces a PPPM chain left in f
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);
 void mdk_post(hipStream_t st, const SimDev *d, int ns);

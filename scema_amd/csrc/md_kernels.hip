@@ -569,7 +569,7 @@ __device__ __forceinline__ void cmul(double &pr, double &pi, double c, double s)
 #define EWF_APT 2          // atoms per thread: two independent recurrences per lane, half the per-k LDS reads and scalar work per atom
 // EWF_T threads per block: 256 for batches, 64 for small ones (a single replica then spreads over 81 instead of 21 blocks)
 template <int EWF_T>
-__global__ __launch_bounds__(EWF_T) void k_ewald_force(const SimDev *sims, int pairvir) {
+__global__ __launch_bounds__(EWF_T) void k_ewald_force(const SimDev *sims, int pairvir, int fkeep) {
   const SimDev &S = sims[blockIdx.y];
   if ((int)(blockIdx.x * EWF_T * EWF_APT) >= S.natoms) return;
   __shared__ EwK s_k[EWF_KC];
@@ -662,9 +662,12 @@ __global__ __launch_bounds__(EWF_T) void k_ewald_force(const SimDev *sims, int p
       const double pq = 2.0 * MD_QQRD2E * S.q[a];
       const size_t sl = (size_t)S.slot_of[a], np = (size_t)S.npad, r = (size_t)S.bt_rank[a];
       const double px = S.fs[sl], py = S.fs[np + sl], pz = S.fs[2 * np + sl];
-      S.f[3 * a] = px + S.fb[3 * r] + pq * fx[u];
-      S.f[3 * a + 1] = py + S.fb[3 * r + 1] + pq * fy[u];
-      S.f[3 * a + 2] = pz + S.fb[3 * r + 2] + pq * fz[u];
+      // fkeep: the PPPM chain of this step (side stream, joined before this launch) has left its forces in f
+      const bool keep = fkeep && S.pg[0] > 0;
+      const double k0 = keep ? S.f[3 * a] : 0.0, k1 = keep ? S.f[3 * a + 1] : 0.0, k2 = keep ? S.f[3 * a + 2] : 0.0;
+      S.f[3 * a] = px + S.fb[3 * r] + pq * fx[u] + k0;
+      S.f[3 * a + 1] = py + S.fb[3 * r + 1] + pq * fy[u] + k1;
+      S.f[3 * a + 2] = pz + S.fb[3 * r + 2] + pq * fz[u] + k2;
       if (pairvir) {
         // pair virial, part 1: wrapped slot position (x) total pair force of the slot (part 2 = k_pair's partials)
         const double *xy = (const double *)S.xq + 2 * sl, *zq = (const double *)S.xq + 2 * np + 2 * sl;
@@ -989,9 +992,9 @@ void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax
   hipLaunchKernelGGL(k_ewald_post, grid2(cdiv(maxk, TPB), ns), dim3(TPB), 0, st, d);
 }
 // part 2: per-atom reciprocal force; also assembles f from the pair and bonded forces (runs even without charges)
-void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir) {
-  if (ns * cdiv(maxatoms, EWF_TPB * EWF_APT) >= 512) hipLaunchKernelGGL(k_ewald_force<EWF_TPB>, grid2(cdiv(maxatoms, EWF_TPB * EWF_APT), ns), dim3(EWF_TPB), 0, st, d, pairvir);
-  else hipLaunchKernelGGL(k_ewald_force<64>, grid2(cdiv(maxatoms, 64 * EWF_APT), ns), dim3(64), 0, st, d, pairvir);
+void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir, int fkeep) {
+  if (ns * cdiv(maxatoms, EWF_TPB * EWF_APT) >= 512) hipLaunchKernelGGL(k_ewald_force<EWF_TPB>, grid2(cdiv(maxatoms, EWF_TPB * EWF_APT), ns), dim3(EWF_TPB), 0, st, d, pairvir, fkeep);
+  else hipLaunchKernelGGL(k_ewald_force<64>, grid2(cdiv(maxatoms, 64 * EWF_APT), ns), dim3(64), 0, st, d, pairvir, fkeep);
 }
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
   if (maxclus <= 0) return;

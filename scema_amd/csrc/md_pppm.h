@@ -10,5 +10,6 @@ void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int m
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid);
 // after the forward transform of grid 0: energy, virial, field spectra into grids 1..3
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid);
-// after the inverse transforms of grids 1..3: forces added to SimDev::f
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms);
+// after the inverse transforms of the field grids: forces added to SimDev::f (add != 0) or stored there (the chain runs ahead of
+// the kernel that assembles the force of the step, which then adds them: mdk_ewald_force fkeep)
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_pppm_poisson(const SimDev *sims) {
 // (consecutive atoms in consecutive lanes: neighbours read the same grid points, which the LDS broadcasts); LDS = false reads
 // the grids through the caches.
 template <bool LDS>
-__global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int split) {
+__global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int split, int add) {
   const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
   if (nx == 0) return;
@@ -246,7 +246,10 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
   box_derive(S.sc->box, b);
   for (int a = a0 + (int)threadIdx.x; a < a1; a += 256) {
     const double qa = S.q[a];
-    if (qa == 0.0) continue;
+    if (qa == 0.0) {
+      if (!add) { S.f[3 * a] = 0.0; S.f[3 * a + 1] = 0.0; S.f[3 * a + 2] = 0.0; }
+      continue;
+    }
     double l0, l1, l2;
     atom_lamda(S, b, a, l0, l1, l2);
     double wx[PP_ORDER], wy[PP_ORDER], wz[PP_ORDER];
@@ -272,7 +275,8 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
       }
     }
     const double qf = MD_QQRD2E * qa;
-    S.f[3 * a] += qf * fx; S.f[3 * a + 1] += qf * fy; S.f[3 * a + 2] += qf * fz;
+    if (add) { S.f[3 * a] += qf * fx; S.f[3 * a + 1] += qf * fy; S.f[3 * a + 2] += qf * fz; }
+    else { S.f[3 * a] = qf * fx; S.f[3 * a + 1] = qf * fy; S.f[3 * a + 2] = qf * fz; }
   }
 }
 
@@ -297,15 +301,15 @@ void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int m
 }
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_gf, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_poisson, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms) {
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add) {
   const size_t lds = 3 * (size_t)maxgrid * sizeof(double);
   if (lds > mdk_pppm_lds_limit()) {
-    hipLaunchKernelGGL(k_pppm_force<false>, grid2(cdiv(maxatoms, 256), ns), dim3(256), 0, st, d, cdiv(maxatoms, 256));
+    hipLaunchKernelGGL(k_pppm_force<false>, grid2(cdiv(maxatoms, 256), ns), dim3(256), 0, st, d, cdiv(maxatoms, 256), add);
     return;
   }
   static size_t optin_tab[16] = {0};
   size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_force<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
   const int split = pppm_split(ns, maxatoms);
-  hipLaunchKernelGGL(k_pppm_force<true>, grid2(split, ns), dim3(256), lds, st, d, split);
+  hipLaunchKernelGGL(k_pppm_force<true>, grid2(split, ns), dim3(256), lds, st, d, split, add);
 }
