@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <ctime>
 #include <array>
@@ -211,7 +212,8 @@ struct scema_md_engine {
   std::map<std::string, std::unique_ptr<Topo>> topos;
   std::map<std::string, std::unique_ptr<State>> states;
   std::vector<std::unique_ptr<Slot>> slots;
-  DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair, d_pppm;
+  DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair, d_pppm, d_copytab;
+  std::vector<MdkCopy> h_copytab;
   std::map<std::array<int, 5>, hipfftHandle> pppm_plans;   // (nx, ny, nz, batch, stream) -> batched 3-d Z2Z plan over contiguous grids (a plan owns work space: one per stream)
   std::vector<int> h_kpack;   // host copy, alive until the stream has consumed the upload
   int local_stress_count = 0;
@@ -626,7 +628,7 @@ struct EwaldSetup {
   int kmaxd[3] = {0, 0, 0};
 };
 void ewald_tables(EwaldSetup &out);
-void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, EwaldSetup &out) {
+void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, EwaldSetup &out, bool g_only = false) {
   out = EwaldSetup();
   if (t.qsqsum == 0.0) return;
   HostBox b;
@@ -636,6 +638,7 @@ void ewald_setup(const scema_md_params &p, const Topo &t, const double *box, Ewa
   const double rc = p.cut_coul;
   const double tt = accuracy * std::sqrt((double)t.natoms * rc * b.h[0] * b.h[1] * b.h[2]) / (2.0 * q2);
   out.g = (tt >= 1.0) ? (1.35 - 0.15 * std::log(accuracy)) / rc : std::sqrt(-std::log(tt)) / rc;
+  if (g_only) return;   // PPPM starts from this g_ewald and has no use for the k list
   const double g = out.g;
   int kmax[3];
   double gsqmx = 0.0;
@@ -832,9 +835,10 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
 // accuracy, raised to a product of 2, 3, 5; then g_ewald by Newton's method on (real-space error - k-space error) = 0 ----
 static double pppm_ik_error(double h, double prd, double g, double q2, double natoms) {
   static const double ACONS5[5] = {1.0 / 23232.0, 7601.0 / 13628160.0, 143.0 / 69120.0, 517231.0 / 106536960.0, 106640677.0 / 11737571328.0};
-  double sum = 0.0;
-  for (int m = 0; m < 5; m++) sum += ACONS5[m] * std::pow(h * g, 2.0 * m);
-  return q2 * std::pow(h * g, 5.0) * std::sqrt(g * prd * std::sqrt(2.0 * MD_PI) * sum / natoms) / (prd * prd);
+  const double hg = h * g, hg2 = hg * hg;
+  double sum = 0.0, pw = 1.0;   // powers by multiplication: this runs a few hundred times per simulation and run
+  for (int m = 0; m < 5; m++) { sum += ACONS5[m] * pw; pw *= hg2; }
+  return q2 * (hg2 * hg2 * hg) * std::sqrt(g * prd * std::sqrt(2.0 * MD_PI) * sum / natoms) / (prd * prd);
 }
 static void pppm_setup_host(const scema_md_params &p, const Topo &t, const double *box, double &g, int pg[3]) {
   HostBox b;
@@ -1099,15 +1103,52 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   kpack.clear();
   std::vector<size_t> koff(ns, 0);
   int maxgrp = 0;
+  double t_lay[4] = {0, 0, 0, 0};   // host time of the layout loop by part (SCEMA_MD_TIMING): box range, cell grid, k-space set-up, the rest
+  auto t_now = [] { return std::chrono::steady_clock::now(); };
+  auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   std::vector<std::vector<FlipEvent>> flips(ns);   // per position: the box flips of this run (fix deform, flip yes)
   std::vector<EwaldSetup> ews(ns);
   int maxgrid = 0;   // PPPM: largest grid of the batch
+  // k-space set-up of every simulation first: g_ewald with the k list of the Ewald sum, or with the PPPM grid.  Pure functions
+  // of the box and by far the longest part of the layout (12 us per PE-10k replica, 7 of 8 ms for 576 while the GPU waits),
+  // so large batches spread them over a few host threads.
+  {
+    auto kspace_one = [&](int pos) {
+      const int i = order[pos];
+      const Topo &T = *sims[i].st->topo;
+      const SimScalars &hsc = e->h_sc[i];
+      EwaldSetup &ew = ews[pos];
+      const bool kept = spec.ew_keep && spec.keep;
+      const bool pppm = P.kspace_style == 1 && T.qsqsum > 0.0 && !kept;
+      if (kept && (int)spec.ew_keep->size() == ns) ew = (*spec.ew_keep)[pos];   // a run keeps the k-space setup of its start
+      else ewald_setup(P, T, hsc.box, ew, pppm);
+      if (pppm) {
+        // PPPM: the Ewald k list is not used; g_ewald is adjusted to the grid (and with it the real-space part)
+        int pgd[3];
+        double gp = ew.g;
+        pppm_setup_host(P, T, hsc.box, gp, pgd);
+        ew = EwaldSetup();
+        ew.g = gp;
+        for (int d = 0; d < 3; d++) ew.kmaxd[d] = -pgd[d];   // the grid travels in the set-up record (negative: not a k range)
+      }
+    };
+    const int nthr = ns >= 64 ? std::max(1, std::min(8, (int)std::thread::hardware_concurrency())) : 1;
+    if (nthr == 1) {
+      for (int pos = 0; pos < ns; pos++) kspace_one(pos);
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthr; t++)
+        pool.emplace_back([&, t] { for (int pos = t; pos < ns; pos += nthr) kspace_one(pos); });
+      for (auto &th : pool) th.join();
+    }
+  }
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
     ActiveSim &A = sims[i];
     Topo &T = *A.st->topo;
     const SimScalars &hsc = e->h_sc[i];
+    const auto tl0 = t_now();
     // box range over this run -> cell grid that stays valid while the box deforms (and flips: the tilt is largest just
     // before a flip, those boxes are kept as extremes)
     double box_end[9];
@@ -1165,6 +1206,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     // the half stencil within rlist of the cell, 28 B of LDS each) still fits two workgroups per CU.  PE-10k:
     // 5x6x4 cells of 8.9 x 7.4 x 10.1 A (22 clusters, 2 280 table entries) instead of 6x6x5 (14 clusters, 2 040):
     // k_pair -3.5 %, build +8 %, step -2.4 %.  Denser systems fall back to cells of rlist/3, rlist/4, ...
+    const auto tl1 = t_now();
     const double rho = T.natoms / vol_min;
     int capj = 0, maxneigh = 0;
     bool fits = false;
@@ -1241,22 +1283,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (!fits)
       return fail(e, SCEMA_MD_ERR_ARG, "the j table of a cell tile (%d entries) does not fit the LDS of the pair kernel (system too dense for the cutoff)", capj);
     S.ncells = S.nc[0] * S.nc[1] * S.nc[2];
-    EwaldSetup &ew = ews[pos];
-    if (spec.ew_keep && spec.keep && (int)spec.ew_keep->size() == ns) ew = (*spec.ew_keep)[pos];   // a run keeps the k-space setup of its start
-    else ewald_setup(P, T, hsc.box, ew);
-    if (P.kspace_style == 1 && T.qsqsum > 0.0 && !(spec.ew_keep && spec.keep)) {
-      // PPPM: the Ewald k list is not used; g_ewald is adjusted to the grid (and with it the real-space part)
-      int pgd[3];
-      double gp = ew.g;
-      pppm_setup_host(P, T, hsc.box, gp, pgd);
-      ew = EwaldSetup();
-      ew.g = gp;
-      for (int d = 0; d < 3; d++) ew.kmaxd[d] = -pgd[d];   // the grid travels in the set-up record (negative: not a k range)
-    }
+    const auto tl2 = t_now();
+    EwaldSetup &ew = ews[pos];   // from the pass above
     if (P.kspace_style == 1 && T.qsqsum > 0.0) {
       for (int d = 0; d < 3; d++) { S.pg[d] = -ew.kmaxd[d]; }
       maxgrid = std::max(maxgrid, S.pg[0] * S.pg[1] * S.pg[2]);
     }
+    const auto tl3 = t_now();
     S.nk = (int)ew.kn.size() / 3;
     for (int d = 0; d < 3; d++) S.kmaxd[d] = std::max(ew.kmaxd[d], 0);
     S.g_ewald = ew.g;
@@ -1348,6 +1381,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       maxgrp = std::max(maxgrp, S.ngrp);
     }
     e->h_sims[pos] = S;
+    { const auto tl4 = t_now(); t_lay[0] += t_ms(tl0, tl1); t_lay[1] += t_ms(tl1, tl2); t_lay[2] += t_ms(tl2, tl3); t_lay[3] += t_ms(tl3, tl4); }
     maxatoms = std::max(maxatoms, S.natoms); maxpad = std::max(maxpad, S.npad); maxcells = std::max(maxcells, S.ncells);
     maxk = std::max(maxk, S.nk);
     maxpoly = std::max(maxpoly, S.coul_npoly);
@@ -1702,8 +1736,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     fprintf(stderr, "[scema_md] sim 0: cells %dx%dx%d, j table max %d of %d, row max %d of %d, row entries/cluster %.1f, listed pairs/atom %.1f, builds %d\n",
             S0.nc[0], S0.nc[1], S0.nc[2], c.maxj_seen, S0.capj, c.maxneigh_seen, S0.maxneigh, (double)c.nrowent / (S0.npad / MD_CLUSTER),
             (double)c.nentries / S0.natoms, c.nbuilds);
-    fprintf(stderr, "[scema_md] host: %.2f ms laying out %d simulations before the first launch of this run\n",
-            std::chrono::duration<double, std::milli>(t_laid_out - t_enter).count(), ns);
+    fprintf(stderr, "[scema_md] host: %.2f ms laying out %d simulations before the first launch of this run (box range %.2f, cell grid %.2f, k-space set-up %.2f, rest of the loop %.2f)\n",
+            std::chrono::duration<double, std::milli>(t_laid_out - t_enter).count(), ns, t_lay[0], t_lay[1], t_lay[2], t_lay[3]);
     fprintf(stderr, "[scema_md] sim 0: far skin band walked on %d of %d steps; list skin %.2f A\n", c.nfar_steps, c.step, S0.skin);
 #ifdef PAIR_TIMING
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
@@ -1870,6 +1904,27 @@ struct EvalOpt {
   int shake_a = 1, shake_b = 1;
 };
 
+// positions and velocities of a chunk's states -> the slots' backups (restore: the other way), all in one launch
+static int backup_states(scema_md_engine *e, std::vector<ActiveSim> &chunk, bool restore) {
+  const int ns = (int)chunk.size();
+  e->h_copytab.resize(2 * (size_t)ns);
+  long long maxn = 0;
+  for (int i = 0; i < ns; i++) {
+    Slot &sl = *e->slots[i];
+    const long long n = 3 * (long long)chunk[i].st->topo->natoms;
+    HIPCHK(sl.xbak.ensure((size_t)n * 8));
+    HIPCHK(sl.vbak.ensure((size_t)n * 8));
+    double *x = chunk[i].st->x.as<double>(), *v = chunk[i].st->v.as<double>(), *xb = sl.xbak.as<double>(), *vb = sl.vbak.as<double>();
+    e->h_copytab[2 * i] = restore ? MdkCopy{xb, x, n} : MdkCopy{x, xb, n};
+    e->h_copytab[2 * i + 1] = restore ? MdkCopy{vb, v, n} : MdkCopy{v, vb, n};
+    maxn = std::max(maxn, n);
+  }
+  HIPCHK(e->d_copytab.ensure(2 * (size_t)std::max(ns, 1) * sizeof(MdkCopy)));
+  HIPCHK(hipMemcpyAsync(e->d_copytab.p, e->h_copytab.data(), 2 * (size_t)ns * sizeof(MdkCopy), hipMemcpyHostToDevice, e->stream));
+  mdk_copy_many(e->stream, e->d_copytab.as<MdkCopy>(), 2 * ns, maxn);
+  return SCEMA_MD_OK;
+}
+
 // full evaluation (phase A + phase B) of a chunk of simulations, with overflow retry
 int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt &opt = EvalOpt()) {
   const int ns = (int)chunk.size();
@@ -1877,14 +1932,8 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
     int rc = prepare_slots(e, chunk);
     if (rc) return rc;
     // backup for a retry after neighbour overflow
-    for (int i = 0; i < ns; i++) {
-      Slot &sl = *e->slots[i];
-      const size_t bytes = 3 * (size_t)chunk[i].st->topo->natoms * 8;
-      HIPCHK(sl.xbak.ensure(bytes));
-      HIPCHK(sl.vbak.ensure(bytes));
-      HIPCHK(hipMemcpyAsync(sl.xbak.p, chunk[i].st->x.p, bytes, hipMemcpyDeviceToDevice, e->stream));
-      HIPCHK(hipMemcpyAsync(sl.vbak.p, chunk[i].st->v.p, bytes, hipMemcpyDeviceToDevice, e->stream));
-    }
+    rc = backup_states(e, chunk, false);
+    if (rc) return rc;
     RunSpec A;
     A.deform = 1;
     A.use_shake = opt.shake_a;
@@ -1924,22 +1973,13 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
     if (rc != SCEMA_MD_ERR_OVERFLOW) {
       // instability, box error, non-finite stress, device error: the reference would have stopped before write_restart
       // (stmd_problem.h:258), so the stored states must not keep the half-advanced positions
-      for (int i = 0; i < ns; i++) {
-        Slot &sl = *e->slots[i];
-        const size_t bytes = 3 * (size_t)chunk[i].st->topo->natoms * 8;
-        (void)hipMemcpyAsync(chunk[i].st->x.p, sl.xbak.p, bytes, hipMemcpyDeviceToDevice, e->stream);
-        (void)hipMemcpyAsync(chunk[i].st->v.p, sl.vbak.p, bytes, hipMemcpyDeviceToDevice, e->stream);
-      }
+      (void)backup_states(e, chunk, true);
       (void)hipStreamSynchronize(e->stream);
       return rc;
     }
     // restore and grow
-    for (int i = 0; i < ns; i++) {
-      Slot &sl = *e->slots[i];
-      const size_t bytes = 3 * (size_t)chunk[i].st->topo->natoms * 8;
-      HIPCHK(hipMemcpyAsync(chunk[i].st->x.p, sl.xbak.p, bytes, hipMemcpyDeviceToDevice, e->stream));
-      HIPCHK(hipMemcpyAsync(chunk[i].st->v.p, sl.vbak.p, bytes, hipMemcpyDeviceToDevice, e->stream));
-    }
+    rc = backup_states(e, chunk, true);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->overflow_bits & 4) e->jtab_grow *= 1.25;
     if ((e->overflow_bits & 8) || !(e->overflow_bits & 4)) e->neigh_grow *= 1.5;

@@ -27,3 +27,6 @@ void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms);
 // triclinic box flip of ONE simulation between two steps (fix deform, flip yes): new tilts, forced list rebuild
 void mdk_flip(hipStream_t st, const SimDev *sim, double xy, double xz, double yz);
 void mdk_phase_end(hipStream_t st, const SimDev *d, int ns, int maxatoms);
+// ncopies device-to-device copies of doubles in one launch; the table lives in device memory, maxn = the longest copy
+struct MdkCopy { const double *src; double *dst; long long n; };
+void mdk_copy_many(hipStream_t st, const MdkCopy *tab, int ncopies, long long maxn);

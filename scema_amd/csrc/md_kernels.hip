@@ -1008,6 +1008,18 @@ void mdk_flip(hipStream_t st, const SimDev *sim, double xy, double xz, double yz
 void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
   hipLaunchKernelGGL(k_remap, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
 }
+// many device-to-device copies in one launch (the x / v backups of a batch: 2 x 576 separate copy calls cost 13 ms of
+// launch gaps per update); block row y serves descriptor y
+__global__ __launch_bounds__(256) void k_copy_many(const MdkCopy *tab) {
+  const MdkCopy c = tab[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < c.n; i += (long long)gridDim.x * 256) c.dst[i] = c.src[i];
+}
+void mdk_copy_many(hipStream_t st, const MdkCopy *tab, int ncopies, long long maxn) {
+  if (ncopies <= 0 || maxn <= 0) return;
+  const int bx = (int)std::min<long long>(cdiv((int)std::min<long long>(maxn, 1 << 30), 256 * 4), 64);
+  hipLaunchKernelGGL(k_copy_many, grid2(std::max(bx, 1), ncopies), dim3(256), 0, st, tab);
+}
+
 void mdk_phase_end(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
   hipLaunchKernelGGL(k_scale_v, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_phase_end, dim3(ns), dim3(64), 0, st, d);
