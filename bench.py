@@ -31,12 +31,12 @@ sys.path.insert(0, ROOT)
 EQ_QP = 1 << 30   # scratch quadrature-point id of the equilibration run
 
 
-def _cpu_eval(k, cells, strain, nss):
+def _cpu_eval(k, cells, strain, nss, pppm=1):
     """one oracle evaluation in a worker process (test infrastructure timed as the CPU baseline)"""
     from oracle import pyoracle as po
     from scema_amd.systems import build_pe
     d = build_pe(*cells, shake_project=True)
-    o = po.Oracle(d)
+    o = po.Oracle(d, po.default_params(kspace_pppm=pppm))
     t0 = time.time()
     _, nts = o.eval(strain, 2.0, 300.0, 1e-4, nss)
     t1 = time.time()
@@ -68,7 +68,7 @@ def _lammps_baseline(lmp, scripts, cells, strains, nss, ncore):
     return ncore / dt, dt
 
 
-def cpu_baseline(cells, strains, nss):
+def cpu_baseline(cells, strains, nss, pppm=1):
     """The CPU path timed on the host cores the way the reference runs it: one serial MD engine per core, one replica each
     (stmd_sync.h:189-278 with n_sims >= ranks).  If a LAMMPS executable and the reference's scripts ($SCEMA_SCRIPTS) are on
     this host, that IS the reference path ("kind": "reference"); otherwise the oracle (CPU restatement, NOT LAMMPS), one
@@ -89,7 +89,7 @@ def cpu_baseline(cells, strains, nss):
         except Exception as exc:
             print("bench.py: LAMMPS baseline failed, falling back to the CPU restatement:", exc, file=sys.stderr)
     with cf.ProcessPoolExecutor(max_workers=ncore, mp_context=mp.get_context("spawn")) as ex:
-        res = list(ex.map(_cpu_eval, range(ncore), [cells] * ncore, [strains[k] for k in range(ncore)], [nss] * ncore))
+        res = list(ex.map(_cpu_eval, range(ncore), [cells] * ncore, [strains[k] for k in range(ncore)], [nss] * ncore, [pppm] * ncore))
     t0 = min(r[1] for r in res)
     t1 = max(r[2] for r in res)
     dt = t1 - t0
@@ -132,8 +132,8 @@ def main():
     ap.add_argument("--equil-cache", default=None, help="npz file: load the equilibrated state from it if it exists, else write it (profiling runs: "
                     "keeps the 2 000 single-replica steps out of a PMC pass)")
     ap.add_argument("--monotonic", action="store_true", help="apply the tensile strain draws update after update (no unloading on odd updates)")
-    ap.add_argument("--kspace", default="ewald", choices=["ewald", "pppm"], help="reciprocal part: the Ewald sum (default, the reported configuration) "
-                    "or PPPM on hipFFT as `kspace_style pppm` asks for (SURVEY f-3; slower at this replica size)")
+    ap.add_argument("--kspace", default="pppm", choices=["pppm", "ewald"], help="reciprocal part: PPPM (order 5, ik, hipFFT) as the reference's "
+                    "`kspace_style pppm 0.0001` asks for (default, the reported configuration) or the plain Ewald sum at the same accuracy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
@@ -157,7 +157,7 @@ def main():
     # CPU baseline first: its worker processes start while nothing in this process has touched the GPU
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(tuple(args.cells), synthetic_strains(32, lens, seed=2026), args.nss)
+        cpu = cpu_baseline(tuple(args.cells), synthetic_strains(32, lens, seed=2026), args.nss, 1 if args.kspace == "pppm" else 0)
 
     import torch
     import torch.distributed as dist
@@ -175,8 +175,7 @@ def main():
     from scema_amd import capi
     # ablation knobs for kernel experiments only (never set in a reported run)
     extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
-    if args.kspace == "pppm":
-        extra["kspace_style"] = 1
+    extra["kspace_style"] = 1 if args.kspace == "pppm" else 0
     eng = capi.Engine(capi.default_params(device=device, profile=1, **extra))
     if world > 1:
         from scema_amd import comm

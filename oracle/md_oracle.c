@@ -56,7 +56,7 @@ void omd_default_params(omd_params *p) {
   p->shake_mass = 1.0;
   p->t_period = 100.0;
   p->t_chain = 3;
-  p->kspace_pppm = 0;
+  p->kspace_pppm = 1;   /* kspace_style pppm, as in.set.lammps:36 asks; 0: the plain Ewald sum */
 }
 
 #define MAXCHAIN 8
@@ -90,6 +90,8 @@ struct omd_sim {
   double g_ewald;
   int nk, *kn;
   int pg[3];      /* PPPM grid (kspace_pppm) */
+  double *pgf;    /* influence function of the box it was last computed for (pgf_key: box, g_ewald, grid): recomputed only when that changes */
+  double pgf_key[13];
   int nflips; /* box flips applied so far (fix deform flip yes) */
   int kspace_frozen;
   double qsqsum, qsum;
@@ -414,7 +416,7 @@ void omd_destroy(omd_sim *s) {
   free(s->x); free(s->v); free(s->f); free(s->wrapn); free(s->xhold);
   free(s->sp_i); free(s->sp_j); free(s->sp_flj); free(s->sp_fc); free(s->ex_start); free(s->ex_list);
   free(s->clus_n); free(s->clus_atom); free(s->clus_d); free(s->bond_shaken);
-  free(s->kn); free(s->pi); free(s->pj); free(s->psh);
+  free(s->kn); free(s->pi); free(s->pj); free(s->psh); free(s->pgf);
   free(s);
 }
 
@@ -600,7 +602,54 @@ static void pppm_compute(omd_sim *s, const boxq *b, double *f, double *eng, doub
     }
   }
   pppm_dft3(rr, ri, ng, -1);
-  /* poisson_ik: influence function, energy, virial, field spectra */
+  /* influence function (ik differentiation, alias sums |m| <= 2): a function of the box, g_ewald and the grid only */
+  {
+    double key[13];
+    for (int k = 0; k < 3; k++) { key[k] = b->lo[k]; key[3 + k] = b->h[k]; key[6 + k] = b->h[3 + k]; key[10 + k] = (double)ng[k]; }
+    key[9] = g;
+    if (!s->pgf || memcmp(key, s->pgf_key, sizeof key) != 0) {
+      free(s->pgf);
+      s->pgf = (double *)xcalloc(NG, sizeof(double));
+      memcpy(s->pgf_key, key, sizeof key);
+      /* squared transform of the assignment function: the grid lives in lamda space, so it factorises over the lattice indices */
+      double *w1 = (double *)xcalloc((size_t)5 * nx, sizeof(double)), *w2d = (double *)xcalloc((size_t)5 * ny, sizeof(double)), *w3 = (double *)xcalloc((size_t)5 * nz, sizeof(double));
+      for (int m = 0; m < nx; m++) for (int a = -2; a <= 2; a++) w1[5 * m + a + 2] = sinc_pow(MY_PI * (m - nx * (2 * m / nx) + nx * a) / nx, 2 * PPPM_ORDER);
+      for (int m = 0; m < ny; m++) for (int a = -2; a <= 2; a++) w2d[5 * m + a + 2] = sinc_pow(MY_PI * (m - ny * (2 * m / ny) + ny * a) / ny, 2 * PPPM_ORDER);
+      for (int m = 0; m < nz; m++) for (int a = -2; a <= 2; a++) w3[5 * m + a + 2] = sinc_pow(MY_PI * (m - nz * (2 * m / nz) + nz * a) / nz, 2 * PPPM_ORDER);
+      const double g2inv_ = 1.0 / (g * g);
+      for (int m3 = 0; m3 < nz; m3++) {
+        const int p3 = m3 - nz * (2 * m3 / nz);
+        for (int m2 = 0; m2 < ny; m2++) {
+          const int p2 = m2 - ny * (2 * m2 / ny);
+          for (int m1 = 0; m1 < nx; m1++) {
+            const int p1 = m1 - nx * (2 * m1 / nx);
+            const size_t idx = ((size_t)m3 * ny + m2) * nx + m1;
+            if (p1 == 0 && p2 == 0 && p3 == 0) continue;
+            const double kx = 2.0 * MY_PI * (b->hinv[0] * p1);
+            const double ky = 2.0 * MY_PI * (b->hinv[5] * p1 + b->hinv[1] * p2);
+            const double kz = 2.0 * MY_PI * (b->hinv[4] * p1 + b->hinv[3] * p2 + b->hinv[2] * p3);
+            const double sqk = kx * kx + ky * ky + kz * kz;
+            double num = 0.0, den = 0.0;
+            for (int a3 = -2; a3 <= 2; a3++)
+              for (int a2 = -2; a2 <= 2; a2++)
+                for (int a1 = -2; a1 <= 2; a1++) {
+                  const int q1 = p1 + nx * a1, q2_ = p2 + ny * a2, q3 = p3 + nz * a3;
+                  const double qx = 2.0 * MY_PI * (b->hinv[0] * q1);
+                  const double qy = 2.0 * MY_PI * (b->hinv[5] * q1 + b->hinv[1] * q2_);
+                  const double qz = 2.0 * MY_PI * (b->hinv[4] * q1 + b->hinv[3] * q2_ + b->hinv[2] * q3);
+                  const double dot2 = qx * qx + qy * qy + qz * qz;
+                  const double w2 = w1[5 * m1 + a1 + 2] * w2d[5 * m2 + a2 + 2] * w3[5 * m3 + a3 + 2];
+                  den += w2;
+                  num += (kx * qx + ky * qy + kz * qz) / dot2 * exp(-0.25 * dot2 * g2inv_) * w2;
+                }
+            s->pgf[idx] = 4.0 * MY_PI / sqk * num / (den * den);
+          }
+        }
+      }
+      free(w1); free(w2d); free(w3);
+    }
+  }
+  /* poisson_ik: energy, virial, field spectra */
   double *ex = (double *)xcalloc(NG, sizeof(double)), *exi = (double *)xcalloc(NG, sizeof(double));
   double *ey = (double *)xcalloc(NG, sizeof(double)), *eyi = (double *)xcalloc(NG, sizeof(double));
   double *ez = (double *)xcalloc(NG, sizeof(double)), *ezi = (double *)xcalloc(NG, sizeof(double));
@@ -618,21 +667,7 @@ static void pppm_compute(omd_sim *s, const boxq *b, double *f, double *eng, doub
         const double ky = 2.0 * MY_PI * (b->hinv[5] * p1 + b->hinv[1] * p2);
         const double kz = 2.0 * MY_PI * (b->hinv[4] * p1 + b->hinv[3] * p2 + b->hinv[2] * p3);
         const double sqk = kx * kx + ky * ky + kz * kz;
-        double num = 0.0, den = 0.0;
-        for (int a3 = -2; a3 <= 2; a3++)
-          for (int a2 = -2; a2 <= 2; a2++)
-            for (int a1 = -2; a1 <= 2; a1++) {
-              const int q1 = p1 + nx * a1, q2_ = p2 + ny * a2, q3 = p3 + nz * a3;
-              const double qx = 2.0 * MY_PI * (b->hinv[0] * q1);
-              const double qy = 2.0 * MY_PI * (b->hinv[5] * q1 + b->hinv[1] * q2_);
-              const double qz = 2.0 * MY_PI * (b->hinv[4] * q1 + b->hinv[3] * q2_ + b->hinv[2] * q3);
-              const double dot2 = qx * qx + qy * qy + qz * qz;
-              /* squared transform of the assignment function: the grid lives in lamda space, so it factorises over the lattice indices */
-              const double w2 = sinc_pow(MY_PI * q1 / nx, 2 * PPPM_ORDER) * sinc_pow(MY_PI * q2_ / ny, 2 * PPPM_ORDER) * sinc_pow(MY_PI * q3 / nz, 2 * PPPM_ORDER);
-              den += w2;
-              num += (kx * qx + ky * qy + kz * qz) / dot2 * exp(-0.25 * dot2 * g2inv) * w2;
-            }
-        const double gf = 4.0 * MY_PI / sqk * num / (den * den);
+        const double gf = s->pgf[idx];
         const double ar = rr[idx] * scaleinv, ai = ri[idx] * scaleinv;
         const double eg = gf * (ar * ar + ai * ai);
         e += eg;

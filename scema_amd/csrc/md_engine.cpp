@@ -1472,8 +1472,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // k_pair and the bonded kernel: its forces are stored in SimDev::f, and k_ewald_force, which assembles the force of the
   // step, adds them after the join.  Otherwise the chain follows the assembly and adds to it.  PE-10k, evaluations per second
   // with the chain on the side stream / inline: 8 replicas 210 / 183, 72: 336 / 333, 576: 369 / 368; a single replica 39.7 / 41.6
-  // (its k_pair does not fill the chip and the fork/join is pure latency), so batches below four stay inline.
-  const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= 4 && !getenv("SCEMA_MD_PPPM_INLINE");
+  // (its k_pair does not fill the chip and the fork/join is pure latency).  So: batches of 4 to 255 replicas; a batch that
+  // fills the chip many times over gains nothing, and inline its k_pair launches are timed and profiled undisturbed.
+  const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= 4 && ns < 256 && !getenv("SCEMA_MD_PPPM_INLINE");
   auto pppm_fork = [&](hipStream_t st, int pos0, int na, int full, bool new_box) -> int {
     if (!pppm_side) return SCEMA_MD_OK;
     HIPCHK(hipEventRecord(e->ev_fork, st));
@@ -2120,7 +2121,7 @@ void scema_md_default_params(scema_md_params *p) {
   p->device = 0;
   p->max_batch = 0;
   p->profile = 0;
-  p->kspace_style = 0;
+  p->kspace_style = 1;   // kspace_style pppm 0.0001 (in.set.lammps:36); 0: the plain Ewald sum at the same accuracy
 }
 
 int scema_md_create(const scema_md_params *p, scema_md_engine **out) {

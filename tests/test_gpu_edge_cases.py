@@ -395,10 +395,10 @@ def test_large_k_sets_stay_on_the_table_path(small_pe, acc, min_groups):
     from scema_amd import capi
     from oracle import pyoracle as po
     kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=acc)
-    e = capi.Engine(capi.default_params(**kw))
+    e = capi.Engine(capi.default_params(kspace_style=0, **kw))            # the Ewald sum (the default is PPPM)
     e.register_replica("pe", 1, small_pe)
     f, en, w, info = e.debug_compute("pe", 1, use_shake=False)
-    o = po.Oracle(small_pe, po.default_params(**kw))
+    o = po.Oracle(small_pe, po.default_params(kspace_pppm=0, **kw))
     o.setup(False)
     fo, eo, wo = o.compute()
     assert info["nk"] == o.nkvec and info["nk"] > 3.2 * min_groups        # about 4 k-vectors per group

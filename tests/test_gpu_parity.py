@@ -258,3 +258,26 @@ def test_shake_clusters_of_two_and_four_trajectory():
     assert relerr(v, vo) < 1e-8
     assert relerr(pavg, pavg_o) < 1e-8
     eng.close()
+
+
+@pytest.mark.parametrize("use_shake", [False, True])
+def test_the_ewald_sum_instead_of_pppm(small_pe, use_shake):
+    """kspace_style 0: the reciprocal part as the plain Ewald sum at the same accuracy (the default is PPPM, as in.set.lammps:36
+    asks): static parts and a full evaluation against the oracle's Ewald sum, tolerances as for the default above."""
+    from scema_amd import capi
+    e = capi.Engine(capi.default_params(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5, kspace_style=0))
+    e.register_replica("pe", 1, small_pe)
+    f, en, w, info = e.debug_compute("pe", 1, use_shake=use_shake)
+    o = oracle_small(small_pe, kspace_pppm=0)
+    o.setup(use_shake)
+    fo, eo, wo = o.compute()
+    assert info["nk"] == o.nkvec > 0
+    assert relerr(f, fo) < 1e-10 and relerr(en, eo) < 1e-10 and relerr(w, wo) < 1e-9
+    if use_shake:
+        lens = small_pe["box"][3:6] - small_pe["box"][:3]
+        strain = np.array([-0.3 * 1.2e-3 * lens[0], -0.3 * 1.2e-3 * lens[1], 1.2e-3 * lens[2], 5e-5 * lens[2], -3e-5 * lens[1], 2e-5 * lens[0]])
+        got = np.array(e.strain_batch([capi.make_sim(7, "pe", 1, strain, nss=20, most_recent=capi.QP_NONE)])[0].stress[:])
+        o2 = oracle_small(small_pe, kspace_pppm=0)
+        exp, nts = o2.eval(strain, 2.0, 300.0, 1e-4, 20)
+        assert nts == 10 and relerr(got, exp) < 1e-6
+    e.close()

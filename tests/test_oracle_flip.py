@@ -47,13 +47,14 @@ def _oracle(d, **kw):
 
 
 def test_the_two_representations_of_one_lattice_give_the_same_forces(small_pe):
-    """xy = +Lx/2 and xy = -Lx/2 span the same lattice: energies, forces and virials of every part agree."""
+    """xy = +Lx/2 and xy = -Lx/2 span the same lattice: energies, forces and virials of every part agree.  With the Ewald sum,
+    which sees the lattice only; the PPPM grid follows the box edges, so its 1e-5 discretisation error differs between the two."""
     d1 = dict(small_pe); d2 = dict(small_pe)
     lx = small_pe["box"][3] - small_pe["box"][0]
     b1 = np.array(small_pe["box"], float); b2 = b1.copy()
     b1[6] = 0.5 * lx; b2[6] = -0.5 * lx
     d1["box"] = b1; d2["box"] = b2
-    o1, o2 = _oracle(d1), _oracle(d2)
+    o1, o2 = _oracle(d1, kspace_pppm=0), _oracle(d2, kspace_pppm=0)
     o1.setup(True); o2.setup(True)
     f1, e1, w1 = o1.compute(); f2, e2, w2 = o2.compute()
     assert o1.npairs == o2.npairs

@@ -16,7 +16,8 @@ def small_params(**kw):
 
 
 def test_energy_force_consistency_per_term(small_pe):
-    o = po.Oracle(small_pe, small_params())
+    # with the Ewald sum: PPPM's ik differentiation gives forces that are not the exact gradient of its energy (1e-5 here)
+    o = po.Oracle(small_pe, small_params(kspace_pppm=0))
     o.setup(use_shake=False)
     f, e, w = o.compute()
     box, x, v = o.get_state()
