@@ -47,10 +47,10 @@ typedef struct {
   int32_t device;          /* HIP device ordinal */
   int32_t max_batch;       /* simulations advanced together per launch group; 0 = all that fit */
   int32_t profile;         /* !=0: HIP-event timing of every pair-kernel launch (scema_md_get_profile) */
-  int32_t kspace_style;    /* 0 (default): reciprocal part as the plain Ewald sum at kspace_accuracy (DESIGN.md deviation 1: more
-                            * exact than the mesh sum, and cheaper up to ~80 k atoms per replica on this hardware); 1: PPPM as
-                            * `kspace_style pppm` asks for (order 5, ik differentiation, hipFFT; grid and g_ewald by the rules of
-                            * pppm.cpp as restated in md_engine.cpp / oracle/md_oracle.c) */
+  int32_t kspace_style;    /* 1 (default): PPPM as `kspace_style pppm 0.0001` asks for (in.set.lammps:36; order 5, ik differentiation,
+                            * hipFFT; grid and g_ewald by the rules of pppm.cpp as restated in md_engine.cpp / oracle/md_oracle.c;
+                            * DESIGN.md 5c); 0: the reciprocal part as the plain Ewald sum PPPM approximates, at kspace_accuracy
+                            * (LAMMPS' initial g_ewald estimate, k-vectors by the RMS criterion of kspace_style ewald) */
 } scema_md_params;
 
 void scema_md_default_params(scema_md_params *p);
