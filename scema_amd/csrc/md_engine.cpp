@@ -214,7 +214,7 @@ struct scema_md_engine {
   std::vector<std::unique_ptr<Slot>> slots;
   DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair, d_pppm, d_copytab;
   std::vector<MdkCopy> h_copytab;
-  std::map<std::array<int, 5>, hipfftHandle> pppm_plans;   // (nx, ny, nz, batch, stream) -> batched 3-d Z2Z plan over contiguous grids (a plan owns work space: one per stream)
+  std::map<std::array<int, 6>, hipfftHandle> pppm_plans;   // (nx, ny, nz, batch, stream, distance between grids) -> batched 3-d Z2Z plan
   std::vector<int> h_kpack;   // host copy, alive until the stream has consumed the upload
   int local_stress_count = 0;
   std::vector<SimDev> h_sims;
@@ -1077,10 +1077,49 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const scema_md_params &P = e->p;
   const auto t_enter = std::chrono::steady_clock::now();
   const double cutmax_all = std::max(P.cut_lj, P.cut_coul);
-  // order: longest run first, so the active simulations are always a prefix
+  // k-space set-up of every simulation first (by simulation index, before the launch order exists): g_ewald with the k list of
+  // the Ewald sum, or with the PPPM grid.  Pure functions of the box and by far the longest part of the layout (12 us per PE-10k
+  // replica, 7 of 8 ms for 576 while the GPU waits), so large batches spread them over a few host threads.
+  std::vector<EwaldSetup> ews_i(ns);
+  {
+    auto kspace_one = [&](int i) {
+      const Topo &T = *sims[i].st->topo;
+      const SimScalars &hsc = e->h_sc[i];
+      EwaldSetup &ew = ews_i[i];
+      const bool kept = spec.ew_keep && spec.keep;
+      const bool pppm = P.kspace_style == 1 && T.qsqsum > 0.0 && !kept;
+      if (kept && (int)spec.ew_keep->size() == ns) ew = (*spec.ew_keep)[i];   // a run keeps the k-space setup of its start
+      else ewald_setup(P, T, hsc.box, ew, pppm);
+      if (pppm) {
+        // PPPM: the Ewald k list is not used; g_ewald is adjusted to the grid (and with it the real-space part)
+        int pgd[3];
+        double gp = ew.g;
+        pppm_setup_host(P, T, hsc.box, gp, pgd);
+        ew = EwaldSetup();
+        ew.g = gp;
+        for (int d = 0; d < 3; d++) ew.kmaxd[d] = -pgd[d];   // the grid travels in the set-up record (negative: not a k range)
+      }
+    };
+    const int nthr = ns >= 64 ? std::max(1, std::min(8, (int)std::thread::hardware_concurrency())) : 1;
+    if (nthr == 1) {
+      for (int i = 0; i < ns; i++) kspace_one(i);
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthr; t++)
+        pool.emplace_back([&, t] { for (int i = t; i < ns; i += nthr) kspace_one(i); });
+      for (auto &th : pool) th.join();
+    }
+  }
+  if (spec.ew_keep && !spec.keep) *spec.ew_keep = ews_i;
+  // order: longest run first, so the active simulations are always a prefix; among equally long runs the simulations that share
+  // a PPPM grid stand together (one batched transform per such group; a strained batch can straddle a grid size)
+  auto grid_key = [&](int i) { const int *k = ews_i[i].kmaxd; return k[0] < 0 ? ((long)(-k[0]) << 40) | ((long)(-k[1]) << 20) | (long)(-k[2]) : 0L; };
   std::vector<int> order(ns);
   for (int i = 0; i < ns; i++) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (sims[a].nsteps != sims[b].nsteps) return sims[a].nsteps > sims[b].nsteps;
+    return grid_key(a) < grid_key(b);
+  });
   // Two half batches on two streams (large batches only): every kernel but k_pair is latency bound and leaves most issue
   // slots idle, while k_pair saturates them and holds every wave slot of the chip; with two independent halves in flight
   // the small kernels of one half fill in as the pair workgroups of the other retire (the in-order streams fall half a
@@ -1107,41 +1146,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   auto t_now = [] { return std::chrono::steady_clock::now(); };
   auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   std::vector<std::vector<FlipEvent>> flips(ns);   // per position: the box flips of this run (fix deform, flip yes)
-  std::vector<EwaldSetup> ews(ns);
+  std::vector<EwaldSetup> ews(ns);   // by position
+  for (int pos = 0; pos < ns; pos++) ews[pos] = std::move(ews_i[order[pos]]);
   int maxgrid = 0;   // PPPM: largest grid of the batch
-  // k-space set-up of every simulation first: g_ewald with the k list of the Ewald sum, or with the PPPM grid.  Pure functions
-  // of the box and by far the longest part of the layout (12 us per PE-10k replica, 7 of 8 ms for 576 while the GPU waits),
-  // so large batches spread them over a few host threads.
-  {
-    auto kspace_one = [&](int pos) {
-      const int i = order[pos];
-      const Topo &T = *sims[i].st->topo;
-      const SimScalars &hsc = e->h_sc[i];
-      EwaldSetup &ew = ews[pos];
-      const bool kept = spec.ew_keep && spec.keep;
-      const bool pppm = P.kspace_style == 1 && T.qsqsum > 0.0 && !kept;
-      if (kept && (int)spec.ew_keep->size() == ns) ew = (*spec.ew_keep)[pos];   // a run keeps the k-space setup of its start
-      else ewald_setup(P, T, hsc.box, ew, pppm);
-      if (pppm) {
-        // PPPM: the Ewald k list is not used; g_ewald is adjusted to the grid (and with it the real-space part)
-        int pgd[3];
-        double gp = ew.g;
-        pppm_setup_host(P, T, hsc.box, gp, pgd);
-        ew = EwaldSetup();
-        ew.g = gp;
-        for (int d = 0; d < 3; d++) ew.kmaxd[d] = -pgd[d];   // the grid travels in the set-up record (negative: not a k range)
-      }
-    };
-    const int nthr = ns >= 64 ? std::max(1, std::min(8, (int)std::thread::hardware_concurrency())) : 1;
-    if (nthr == 1) {
-      for (int pos = 0; pos < ns; pos++) kspace_one(pos);
-    } else {
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nthr; t++)
-        pool.emplace_back([&, t] { for (int pos = t; pos < ns; pos += nthr) kspace_one(pos); });
-      for (auto &th : pool) th.join();
-    }
-  }
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
@@ -1405,7 +1412,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // PPPM: four complex grids and the influence function per simulation.  The charge grids of the batch are contiguous, and so
   // are the field grids (three per simulation, simulation-major): one batched transform forward and ONE back for a launch
   // group whose simulations share the grid, which they do for one material
-  bool pppm_uniform = true;
+  std::vector<std::pair<int, int>> pppm_runs;   // (first position, count) of neighbours in the launch order that share a grid; none crosses a half
   if (maxgrid > 0) {
     HIPCHK(e->d_pppm.ensure((size_t)ns * maxgrid * (4 * sizeof(double2) + sizeof(double))));
     double *gbase = e->d_pppm.as<double>(), *ebase = gbase + (size_t)ns * maxgrid * 2, *fbase = gbase + (size_t)ns * maxgrid * 8;
@@ -1415,17 +1422,22 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       S.pfield = ebase + (size_t)pos * maxgrid * 6;
       S.pgstride = (long long)maxgrid;
       S.pgf = fbase + (size_t)pos * maxgrid;
-      for (int d = 0; d < 3; d++) pppm_uniform = pppm_uniform && S.pg[d] == e->h_sims[0].pg[d];
+      const bool same = !pppm_runs.empty() && pos != hbeg[1] && S.pg[0] == e->h_sims[pos - 1].pg[0] && S.pg[1] == e->h_sims[pos - 1].pg[1] && S.pg[2] == e->h_sims[pos - 1].pg[2];
+      if (same) pppm_runs.back().second += 1;
+      else pppm_runs.push_back({pos, 1});
     }
   }
+  // Batched 3-d Z2Z plans over grids that lie maxgrid complex elements apart (the charge grids of neighbouring simulations, and
+  // all their field grids: three per simulation, simulation-major).  A plan owns work space, so each stream has its own.
   auto pppm_plan = [&](const int pg[3], int batch, hipStream_t st, hipfftHandle &plan) -> int {
-    const std::array<int, 5> key = {pg[0], pg[1], pg[2], batch, st == e->stream ? 0 : st == e->stream2 ? 1 : 2};
+    if ((long long)maxgrid > 0x7fffffffLL) return fail(e, SCEMA_MD_ERR_ARG, "PPPM grid of %d points is too large", maxgrid);
+    const std::array<int, 6> key = {pg[0], pg[1], pg[2], batch, st == e->stream ? 0 : st == e->stream2 ? 1 : 2, maxgrid};
     auto it = e->pppm_plans.find(key);
     if (it == e->pppm_plans.end()) {
       hipfftHandle h;
       int n[3] = {pg[2], pg[1], pg[0]};   // slowest dimension first
-      // batch > 1 only for simulations that share the grid: their grids are contiguous (maxgrid = nx ny nz apart)
-      if (hipfftPlanMany(&h, 3, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2Z, batch) != HIPFFT_SUCCESS)
+      // embed = the grid itself; the distance between consecutive grids is the batch's stride, not the grid's size
+      if (hipfftPlanMany(&h, 3, n, n, 1, maxgrid, n, 1, maxgrid, HIPFFT_Z2Z, batch) != HIPFFT_SUCCESS)
         return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftPlanMany failed for a %d x %d x %d grid, batch %d", pg[0], pg[1], pg[2], batch);
       it = e->pppm_plans.emplace(key, h).first;
     }
@@ -1439,24 +1451,19 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     mdk_pppm_spread(st, Dp, na, maxgrid, maxatoms);
     auto transform = [&](bool fields, int dir) -> int {   // the charge grids forward, or the three field grids of every simulation back
       static const bool serial_fft = getenv("SCEMA_MD_PPPM_SERIAL") != nullptr;   // debugging: one transform per simulation and grid
-      auto exec = [&](hipfftHandle plan, double *g) -> int {
-        if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS || hipfftExecZ2Z(plan, (hipfftDoubleComplex *)g, (hipfftDoubleComplex *)g, dir) != HIPFFT_SUCCESS)
-          return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftExecZ2Z failed");
-        return SCEMA_MD_OK;
-      };
-      const SimDev &S0 = e->h_sims[pos0];
-      int rc;
-      hipfftHandle plan;
-      if (!serial_fft && pppm_uniform && (size_t)S0.pg[0] * S0.pg[1] * S0.pg[2] == (size_t)maxgrid) {
-        if ((rc = pppm_plan(S0.pg, fields ? 3 * full : full, st, plan))) return rc;
-        return exec(plan, fields ? S0.pfield : S0.pgrid);
-      }
-      for (int k = 0; k < na; k++) {
-        const SimDev &S = e->h_sims[pos0 + k];
-        if (S.pg[0] == 0) continue;
-        if ((rc = pppm_plan(S.pg, 1, st, plan))) return rc;
-        for (int c = 0; c < (fields ? 3 : 1); c++)
-          if ((rc = exec(plan, fields ? S.pfield + 2 * (size_t)c * S.pgstride : S.pgrid))) return rc;
+      for (const auto &run : pppm_runs) {
+        if (run.first + run.second <= pos0 || run.first >= pos0 + na) continue;   // outside this launch group, or none of it is active any more
+        const SimDev &S0 = e->h_sims[run.first];
+        if (S0.pg[0] == 0) continue;
+        const int per = fields ? 3 : 1;
+        for (int k = 0; k < (serial_fft ? run.second * per : 1); k++) {
+          hipfftHandle plan;
+          const int rc = pppm_plan(S0.pg, serial_fft ? 1 : per * run.second, st, plan);
+          if (rc) return rc;
+          double *g = (fields ? S0.pfield : S0.pgrid) + (serial_fft ? 2 * (size_t)k * S0.pgstride : 0);
+          if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS || hipfftExecZ2Z(plan, (hipfftDoubleComplex *)g, (hipfftDoubleComplex *)g, dir) != HIPFFT_SUCCESS)
+            return fail(e, SCEMA_MD_ERR_DEVICE, "hipfftExecZ2Z failed");
+        }
       }
       return SCEMA_MD_OK;
     };
@@ -1511,7 +1518,6 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (spec.nh) mdk_setup_post_nh(st, Dh, nh);
     else mdk_setup_post(st, Dh, nh);
   }
-  if (spec.ew_keep && !spec.keep) *spec.ew_keep = ews;
   if (spec.minimize) {
     // min_style sd: every replica runs its own line search, decided on the device between two force evaluations; the host
     // only looks now and then whether all of them have stopped.  x0 and the search direction live in the slot's backup arrays.

@@ -450,8 +450,9 @@ def test_pppm_trajectory_with_deform_and_full_evaluation(small_pe):
 
 
 def test_pppm_grid_too_large_for_the_lds_and_mixed_grids(small_pe):
-    """a grid beyond the LDS (tight accuracy) takes the global-atomics spreading path; two replicas with different boxes (hence
-    different grids) in one batch take per-replica transforms"""
+    """a grid beyond the LDS (tight accuracy) takes the global-atomics spreading path; replicas with different boxes (hence different
+    grids) interleaved in one batch are regrouped by grid and take one batched transform per group (the smaller grid lies in a
+    buffer laid out for the larger one)"""
     from copy import deepcopy
     from scema_amd import capi
     from oracle import pyoracle as po
@@ -477,12 +478,14 @@ def test_pppm_grid_too_large_for_the_lds_and_mixed_grids(small_pe):
     e.register_replica("a", 1, small_pe)
     e.register_replica("b", 1, d2)
     st = np.array([1e-3, -5e-4, 2e-3, 0.0, 1e-3, 0.0])
-    out = e.strain_batch([capi.make_sim(0, "a", 1, st, nss=10, most_recent=capi.QP_NONE), capi.make_sim(1, "b", 1, st, nss=10, most_recent=capi.QP_NONE)])
-    grids = []
-    for q, d in enumerate((small_pe, d2)):
-        oq = po.Oracle(d, po.default_params(kspace_pppm=1, **kw))
-        exp, _ = oq.eval(st, 2.0, 300.0, 1e-4, 10)
-        grids.append(oq.pppm_grid)
+    mats = ["a", "b", "a", "b", "b"]                                          # interleaved: a a | b b b after the regrouping
+    scale = [1.0, 1.0, 0.7, -0.6, 1.3]
+    out = e.strain_batch([capi.make_sim(q, m, 1, st * scale[q], nss=10, most_recent=capi.QP_NONE) for q, m in enumerate(mats)])
+    grids = {}
+    for q, m in enumerate(mats):
+        oq = po.Oracle(small_pe if m == "a" else d2, po.default_params(kspace_pppm=1, **kw))
+        exp, _ = oq.eval(st * scale[q], 2.0, 300.0, 1e-4, 10)
+        grids[m] = oq.pppm_grid
         assert np.abs(np.array(out[q].stress[:]) - exp).max() < 1e-7 * np.abs(exp).max(), q
-    assert grids[0] != grids[1]
+    assert grids["a"] != grids["b"]
     e.close()
