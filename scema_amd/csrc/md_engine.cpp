@@ -1412,6 +1412,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // PPPM: four complex grids and the influence function per simulation.  The charge grids of the batch are contiguous, and so
   // are the field grids (three per simulation, simulation-major): one batched transform forward and ONE back for a launch
   // group whose simulations share the grid, which they do for one material
+  int maxdims = 0;              // largest nx + ny + nz
+  bool pppm_clean[2] = {false, false};   // per half: the charge grids hold zeros (the buffer is laid out anew for every run)
   std::vector<std::pair<int, int>> pppm_runs;   // (first position, count) of neighbours in the launch order that share a grid; none crosses a half
   if (maxgrid > 0) {
     HIPCHK(e->d_pppm.ensure((size_t)ns * maxgrid * (4 * sizeof(double2) + sizeof(double))));
@@ -1422,11 +1424,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       S.pfield = ebase + (size_t)pos * maxgrid * 6;
       S.pgstride = (long long)maxgrid;
       S.pgf = fbase + (size_t)pos * maxgrid;
+      maxdims = std::max(maxdims, S.pg[0] + S.pg[1] + S.pg[2]);
       const bool same = !pppm_runs.empty() && pos != hbeg[1] && S.pg[0] == e->h_sims[pos - 1].pg[0] && S.pg[1] == e->h_sims[pos - 1].pg[1] && S.pg[2] == e->h_sims[pos - 1].pg[2];
       if (same) pppm_runs.back().second += 1;
       else pppm_runs.push_back({pos, 1});
     }
   }
+  const bool pppm_in_lds = maxgrid > 0 && maxgrid <= mdk_pppm_solve_max() && (3 * (size_t)maxgrid + (size_t)maxdims) * 16 <= 150 * 1024 && !getenv("SCEMA_MD_PPPM_FFT");
   // Batched 3-d Z2Z plans over grids that lie maxgrid complex elements apart (the charge grids of neighbouring simulations, and
   // all their field grids: three per simulation, simulation-major).  A plan owns work space, so each stream has its own.
   auto pppm_plan = [&](const int pg[3], int batch, hipStream_t st, hipfftHandle &plan) -> int {
@@ -1448,7 +1452,16 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   auto pppm_stage = [&](hipStream_t st, int pos0, int na, int full, bool new_box, int add = 1) -> int {
     if (maxgrid <= 0 || na <= 0) return SCEMA_MD_OK;
     const SimDev *Dp = e->d_sims.as<SimDev>() + pos0;
-    mdk_pppm_spread(st, Dp, na, maxgrid, maxatoms);
+    bool &clean = pppm_clean[(nhalf == 2 && pos0 == hbeg[1]) ? 1 : 0];
+    mdk_pppm_spread(st, Dp, na, maxgrid, maxatoms, clean ? 1 : 0);
+    clean = false;
+    if (pppm_in_lds) {   // small grids: the whole solve in one launch, in LDS (md_pppm.hip k_pppm_solve); it leaves the charge grids zeroed
+      if (new_box) mdk_pppm_gf(st, Dp, na, maxgrid);
+      mdk_pppm_solve(st, Dp, na, maxgrid, maxdims);
+      clean = true;
+      mdk_pppm_force(st, Dp, na, maxgrid, maxatoms, add);
+      return SCEMA_MD_OK;
+    }
     auto transform = [&](bool fields, int dir) -> int {   // the charge grids forward, or the three field grids of every simulation back
       static const bool serial_fft = getenv("SCEMA_MD_PPPM_SERIAL") != nullptr;   // debugging: one transform per simulation and grid
       for (const auto &run : pppm_runs) {

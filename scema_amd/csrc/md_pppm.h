@@ -5,7 +5,12 @@
 struct SimDev;
 size_t mdk_pppm_lds_limit();
 // charges -> grid 0 (complex, imaginary part 0); maxgrid = largest nx*ny*nz of the batch
-void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms);
+// zeroed != 0: the charge grids are known to hold zeros (k_pppm_solve leaves them so)
+void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed);
+// small grids (maxgrid <= mdk_pppm_solve_max()): forward transform, energy / virial / field spectra and the three inverse transforms in one
+// launch, in LDS (replaces the transforms of the engine and mdk_pppm_poisson); maxdims = largest nx + ny + nz of the batch
+int mdk_pppm_solve_max();
+void mdk_pppm_solve(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxdims);
 // influence function of the current box into SimDev::pgf
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid);
 // after the forward transform of grid 0: energy, virial, field spectra into grids 1..3

@@ -24,6 +24,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 #define PP_ORDER 5
 #define PP_TPB 1024
+#define PP_SOLVE_MAX 2900   // grid points up to which k_pppm_solve keeps three complex grids and the twiddles in 144 KB of LDS
 
 // weights of the order-5 cardinal B-spline at the 5 grid points i-2 .. i+2 around u, i = floor(u + 1/2) (oracle: pppm_weights;
 // the divisions of the recursion are multiplications by the rounded reciprocals here: one unit in the last place)
@@ -181,6 +182,30 @@ __global__ __launch_bounds__(256) void k_pppm_gf(const SimDev *sims) {
   S.pgf[idx] = 4.0 * MD_PI / sqk * num / (den * den);
 }
 
+// one reciprocal mode: wave vector of grid index idx, and -- with the (unnormalised) transform r of the charge grid -- its share of
+// energy and virial; returns the potential G rho(k) / NG whose products with -i k are the field spectra
+__device__ __forceinline__ double2 pppm_mode(const SimDev &S, const BoxD &b, int idx, int nx, int ny, int nz, double2 r, double (&kv)[3], double (&v)[6], double &e) {
+  const int NG = nx * ny * nz;
+  const int m1 = idx % nx, m2 = (idx / nx) % ny, m3 = idx / (nx * ny);
+  const int p1 = m1 - nx * (2 * m1 / nx), p2 = m2 - ny * (2 * m2 / ny), p3 = m3 - nz * (2 * m3 / nz);
+  const double twopi = 2.0 * MD_PI;
+  const double kx = twopi * (b.hinv[0] * p1), ky = twopi * (b.hinv[5] * p1 + b.hinv[1] * p2), kz = twopi * (b.hinv[4] * p1 + b.hinv[3] * p2 + b.hinv[2] * p3);
+  kv[0] = kx; kv[1] = ky; kv[2] = kz;
+  const double gf = S.pgf[idx], scaleinv = 1.0 / (double)NG;
+  const double ar = r.x * scaleinv, ai = r.y * scaleinv;
+  if (gf != 0.0) {
+    const double sqk = kx * kx + ky * ky + kz * kz;
+    const double eg = 0.5 * b.vol * MD_QQRD2E * gf * (ar * ar + ai * ai);
+    const double vterm = -2.0 * (1.0 / sqk + 0.25 / (S.g_ewald * S.g_ewald));
+    e += eg;
+    v[0] += eg * (1.0 + vterm * kx * kx); v[1] += eg * (1.0 + vterm * ky * ky); v[2] += eg * (1.0 + vterm * kz * kz);
+    v[3] += eg * vterm * kx * ky; v[4] += eg * vterm * kx * kz; v[5] += eg * vterm * ky * kz;
+  }
+  if (idx == 0)   // self energy and neutralising background
+    e -= MD_QQRD2E * (S.g_ewald * S.qsqsum / sqrt(MD_PI) + 0.5 * MD_PI * S.qsum * S.qsum / (S.g_ewald * S.g_ewald * b.vol));
+  return make_double2(gf * ar, gf * ai);
+}
+
 // energy, virial and the three field spectra; the charge grid holds rho(k) (unnormalised), the field grids receive E_x, E_y, E_z (k)
 __global__ __launch_bounds__(256) void k_pppm_poisson(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
@@ -193,33 +218,83 @@ __global__ __launch_bounds__(256) void k_pppm_poisson(const SimDev *sims) {
   BoxD b;
   box_derive(S.sc->box, b);
   if (idx < NG) {
-    double2 *grid = (double2 *)S.pgrid;
-    const int m1 = idx % nx, m2 = (idx / nx) % ny, m3 = idx / (nx * ny);
-    const int p1 = m1 - nx * (2 * m1 / nx), p2 = m2 - ny * (2 * m2 / ny), p3 = m3 - nz * (2 * m3 / nz);
-    const double twopi = 2.0 * MD_PI;
-    const double kx = twopi * (b.hinv[0] * p1), ky = twopi * (b.hinv[5] * p1 + b.hinv[1] * p2), kz = twopi * (b.hinv[4] * p1 + b.hinv[3] * p2 + b.hinv[2] * p3);
-    const double gf = S.pgf[idx], scaleinv = 1.0 / (double)NG;
-    const double2 r = grid[idx];
-    const double ar = r.x * scaleinv, ai = r.y * scaleinv;
-    const double pr = gf * ar, pi = gf * ai;
+    double kv[3];
+    const double2 p = pppm_mode(S, b, idx, nx, ny, nz, ((const double2 *)S.pgrid)[idx], kv, v, e[0]);
     const size_t gs = (size_t)S.pgstride;
     double2 *field = (double2 *)S.pfield;
-    field[idx] = make_double2(kx * pi, -kx * pr);       // (a + i b)(-i k) = b k - i a k
-    field[gs + idx] = make_double2(ky * pi, -ky * pr);
-    field[2 * gs + idx] = make_double2(kz * pi, -kz * pr);
-    if (gf != 0.0) {
-      const double sqk = kx * kx + ky * ky + kz * kz;
-      const double eg = 0.5 * b.vol * MD_QQRD2E * gf * (ar * ar + ai * ai);
-      const double vterm = -2.0 * (1.0 / sqk + 0.25 / (S.g_ewald * S.g_ewald));
-      e[0] = eg;
-      v[0] = eg * (1.0 + vterm * kx * kx); v[1] = eg * (1.0 + vterm * ky * ky); v[2] = eg * (1.0 + vterm * kz * kz);
-      v[3] = eg * vterm * kx * ky; v[4] = eg * vterm * kx * kz; v[5] = eg * vterm * ky * kz;
-    }
-    if (idx == 0)   // self energy and neutralising background
-      e[0] -= MD_QQRD2E * (S.g_ewald * S.qsqsum / sqrt(MD_PI) + 0.5 * MD_PI * S.qsum * S.qsum / (S.g_ewald * S.g_ewald * b.vol));
+    field[idx] = make_double2(kv[0] * p.y, -kv[0] * p.x);       // (a + i b)(-i k) = b k - i a k
+    field[gs + idx] = make_double2(kv[1] * p.y, -kv[1] * p.x);
+    field[2 * gs + idx] = make_double2(kv[2] * p.y, -kv[2] * p.x);
   }
   block_atomic_add_n<6, 4>(v, S.sc->vir + P_KSPACE * 6, s_red);
   block_atomic_add_n<1, 4>(e, S.sc->eng + P_KSPACE, s_red);
+}
+
+// Small grids (3 NG complex numbers + the twiddles fit the LDS: NG <= PP_SOLVE_MAX): the whole solve of a replica -- forward
+// transform, energy / virial / field spectra, three inverse transforms -- in ONE launch, one workgroup per replica, the grid never
+// leaving the LDS.  The transforms are plain DFTs along one dimension at a time (a 10 x 10 x 9 grid is 29 multiply-adds per
+// point and pass; the twiddles exp(-2 pi i j / n) come from sincospi once per launch), ping-ponging between two LDS buffers;
+// a third keeps rho(k) while the three field components are transformed back.  Replaces eight to ten library launches of a few
+// microseconds each per step (what a single replica or a 72-replica share waits for) and leaves the charge grid zeroed for the
+// next spreading pass.  Replicas of one launch may have different grids.
+extern __shared__ double2 s_fft[];
+#define PP_SOLVE_TPB 1024   // one grid point per thread and pass for grids of up to 1 024 points: a single replica waits for this kernel
+__global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.x];
+  const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
+  if (nx == 0) return;
+  __shared__ double s_red[8 * (PP_SOLVE_TPB / 64)];
+  const int NG = nx * ny * nz;
+  double2 *A = s_fft, *B = A + NG, *C = B + NG, *tw = C + NG;   // twiddles: x at 0, y at nx, z at nx + ny
+  for (int k = threadIdx.x; k < nx + ny + nz; k += PP_SOLVE_TPB) {
+    const int n = k < nx ? nx : (k < nx + ny ? ny : nz), j = k < nx ? k : (k < nx + ny ? k - nx : k - nx - ny);
+    double sn, cs;
+    sincospi(2.0 * (double)j / (double)n, &sn, &cs);
+    tw[k] = make_double2(cs, -sn);
+  }
+  double2 *rho = (double2 *)S.pgrid;
+  for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) { A[k] = make_double2(rho[k].x, 0.0); rho[k] = make_double2(0.0, 0.0); }
+  __syncthreads();
+  // out[.., m, ..] = sum_k in[.., k, ..] w^(m k) along dimension dim (w = exp(-+2 pi i / n)); ends with a barrier
+  auto pass = [&](const double2 *in, double2 *out, int dim, bool inverse) {
+    const int n = dim == 0 ? nx : (dim == 1 ? ny : nz), stride = dim == 0 ? 1 : (dim == 1 ? nx : nx * ny);
+    const double2 *t = tw + (dim == 0 ? 0 : (dim == 1 ? nx : nx + ny));
+    for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) {
+      const int m = (idx / stride) % n, base = idx - m * stride;
+      double ar = 0.0, ai = 0.0;
+      int j = 0;   // (m k) mod n
+#pragma unroll 5
+      for (int k = 0; k < n; k++) {
+        const double2 vv = in[base + k * stride], w = t[j];
+        const double wi = inverse ? -w.y : w.y;
+        ar = fma(vv.x, w.x, fma(-vv.y, wi, ar));
+        ai = fma(vv.x, wi, fma(vv.y, w.x, ai));
+        j += m;
+        if (j >= n) j -= n;
+      }
+      out[idx] = make_double2(ar, ai);
+    }
+    __syncthreads();
+  };
+  pass(A, B, 0, false); pass(B, A, 1, false); pass(A, B, 2, false);   // B = rho(k)
+  BoxD b;
+  box_derive(S.sc->box, b);
+  double v[6] = {0, 0, 0, 0, 0, 0}, e[1] = {0};
+  const size_t gs = (size_t)S.pgstride;
+  double2 *field = (double2 *)S.pfield;
+  for (int c = 0; c < 3; c++) {
+    for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) {
+      double kv[3], vd[6] = {0, 0, 0, 0, 0, 0}, ed = 0.0;
+      const double2 p = (c == 0) ? pppm_mode(S, b, idx, nx, ny, nz, B[idx], kv, v, e[0]) : pppm_mode(S, b, idx, nx, ny, nz, B[idx], kv, vd, ed);
+      A[idx] = make_double2(kv[c] * p.y, -kv[c] * p.x);       // (a + i b)(-i k) = b k - i a k
+    }
+    __syncthreads();
+    pass(A, C, 0, true); pass(C, A, 1, true); pass(A, C, 2, true);
+    for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) field[c * gs + idx] = C[idx];
+    __syncthreads();
+  }
+  block_atomic_add_n<6, PP_SOLVE_TPB / 64>(v, S.sc->vir + P_KSPACE * 6, s_red);
+  block_atomic_add_n<1, PP_SOLVE_TPB / 64>(e, S.sc->eng + P_KSPACE, s_red);
 }
 
 // forces: the field (real parts of grids 1..3 after the inverse transforms) at the atom, by the assignment weights.  LDS = true:
@@ -284,11 +359,11 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
 size_t mdk_pppm_lds_limit() { return 144 * 1024; }
 // atom ranges per replica: enough workgroups to fill the 256 CUs several times over, none with fewer than 256 atoms
 static inline int pppm_split(int ns, int maxatoms) { return std::max(1, std::min(std::min(16, cdiv(2048, ns)), maxatoms / 256)); }
-void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms) {
+void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed) {
   const size_t lds = (size_t)maxgrid * sizeof(double);
   const bool use_lds = lds <= mdk_pppm_lds_limit();
   const int split = pppm_split(ns, maxatoms);
-  if (!use_lds || split > 1) hipLaunchKernelGGL(k_pppm_zero, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d);
+  if ((!use_lds || split > 1) && !zeroed) hipLaunchKernelGGL(k_pppm_zero, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d);
   if (!use_lds) {
     hipLaunchKernelGGL(k_pppm_spread<false>, grid2(split, ns), dim3(256), 0, st, d, split);
     return;
@@ -298,6 +373,14 @@ void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int m
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_spread<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
   // a small grid leaves room for several workgroups per CU; a large one gets the CU to itself and brings its own sixteen waves
   hipLaunchKernelGGL(k_pppm_spread<true>, grid2(split, ns), dim3(lds <= 36 * 1024 ? 256 : PP_TPB), lds, st, d, split);
+}
+int mdk_pppm_solve_max() { return PP_SOLVE_MAX; }
+void mdk_pppm_solve(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxdims) {
+  const size_t lds = (3 * (size_t)maxgrid + (size_t)maxdims) * sizeof(double2);
+  static size_t optin_tab[16] = {0};
+  size_t &optin = lds_optin_slot(optin_tab);
+  if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+  hipLaunchKernelGGL(k_pppm_solve, dim3(ns), dim3(PP_SOLVE_TPB), lds, st, d);
 }
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_gf, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_poisson, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }

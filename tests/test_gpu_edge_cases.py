@@ -407,13 +407,16 @@ def test_large_k_sets_stay_on_the_table_path(small_pe, acc, min_groups):
     e.close()
 
 
-@pytest.mark.parametrize("acc", [1e-4, 1e-6])
-def test_pppm_matches_the_oracle_pppm(small_pe, acc):
-    """kspace_style 1 (`kspace_style pppm`, in.set.lammps:36): charge assignment in LDS, hipFFT, influence function, field
+@pytest.mark.parametrize("acc,library", [(1e-4, False), (1e-4, True), (1e-6, False)])
+def test_pppm_matches_the_oracle_pppm(small_pe, acc, library, monkeypatch):
+    """kspace_style 1 (`kspace_style pppm`, in.set.lammps:36): charge assignment in LDS, transforms (small grids: the fused solve in
+    LDS, k_pppm_solve; larger ones, or SCEMA_MD_PPPM_FFT=1: batched hipFFT + k_pppm_poisson), influence function, field
     interpolation -- against the oracle's PPPM (plain sums per line instead of FFTs): same grid rule, same adjusted g_ewald,
     reciprocal energy, virial and forces to round-off; and, like the oracle's, close to the Ewald sum at the accuracy asked for."""
     from scema_amd import capi
     from oracle import pyoracle as po
+    if library:
+        monkeypatch.setenv("SCEMA_MD_PPPM_FFT", "1")
     kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=acc)
     e = capi.Engine(capi.default_params(kspace_style=1, **kw))
     e.register_replica("pe", 1, small_pe)
@@ -425,7 +428,7 @@ def test_pppm_matches_the_oracle_pppm(small_pe, acc):
     assert abs(en[6] - eo[6]) < 1e-10 * abs(eo[6]) and np.abs(w[6] - wo[6]).max() < 1e-10 * np.abs(wo[6]).max()
     assert abs(en[1] - eo[1]) < 1e-10 * abs(eo[1])                      # real-space part with the adjusted g_ewald
     assert np.abs(f - fo).max() < 1e-10 * np.abs(fo).max()
-    oe = po.Oracle(small_pe, po.default_params(**kw)); oe.setup(False)
+    oe = po.Oracle(small_pe, po.default_params(kspace_pppm=0, **kw)); oe.setup(False)
     fe = oe.compute()[0]
     assert np.sqrt(((f - fe) ** 2).sum(1).mean()) < 12.0 * acc * 332.06371
     e.close()
