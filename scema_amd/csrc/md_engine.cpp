@@ -1111,6 +1111,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     }
   }
   if (spec.ew_keep && !spec.keep) *spec.ew_keep = ews_i;
+  const double t_kspace_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
   // order: longest run first, so the active simulations are always a prefix; among equally long runs the simulations that share
   // a PPPM grid stand together (one batched transform per such group; a strained batch can straddle a grid size)
   auto grid_key = [&](int i) { const int *k = ews_i[i].kmaxd; return k[0] < 0 ? ((long)(-k[0]) << 40) | ((long)(-k[1]) << 20) | (long)(-k[2]) : 0L; };
@@ -1388,7 +1389,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       maxgrp = std::max(maxgrp, S.ngrp);
     }
     e->h_sims[pos] = S;
-    { const auto tl4 = t_now(); t_lay[0] += t_ms(tl0, tl1); t_lay[1] += t_ms(tl1, tl2); t_lay[2] += t_ms(tl2, tl3); t_lay[3] += t_ms(tl3, tl4); }
+    { const auto tl4 = t_now(); t_lay[0] += t_ms(tl0, tl1); t_lay[1] += t_ms(tl1, tl2); t_lay[3] += t_ms(tl2, tl3); t_lay[3] += t_ms(tl3, tl4); }
     maxatoms = std::max(maxatoms, S.natoms); maxpad = std::max(maxpad, S.npad); maxcells = std::max(maxcells, S.ncells);
     maxk = std::max(maxk, S.nk);
     maxpoly = std::max(maxpoly, S.coul_npoly);
@@ -1449,7 +1450,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     return SCEMA_MD_OK;
   };
   // reciprocal part by PPPM for the simulations [pos0, pos0 + na) of a launch group of `full` (md_pppm.hip); after force_stage
-  auto pppm_stage = [&](hipStream_t st, int pos0, int na, int full, bool new_box, int add = 1) -> int {
+  auto pppm_stage = [&](hipStream_t st, int pos0, int na, bool new_box, int add = 1) -> int {
     if (maxgrid <= 0 || na <= 0) return SCEMA_MD_OK;
     const SimDev *Dp = e->d_sims.as<SimDev>() + pos0;
     bool &clean = pppm_clean[(nhalf == 2 && pos0 == hbeg[1]) ? 1 : 0];
@@ -1495,11 +1496,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // (its k_pair does not fill the chip and the fork/join is pure latency).  So: batches of 4 to 255 replicas; a batch that
   // fills the chip many times over gains nothing, and inline its k_pair launches are timed and profiled undisturbed.
   const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= 4 && ns < 256 && !getenv("SCEMA_MD_PPPM_INLINE");
-  auto pppm_fork = [&](hipStream_t st, int pos0, int na, int full, bool new_box) -> int {
+  auto pppm_fork = [&](hipStream_t st, int pos0, int na, bool new_box) -> int {
     if (!pppm_side) return SCEMA_MD_OK;
     HIPCHK(hipEventRecord(e->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-    const int rc = pppm_stage(e->stream2, pos0, na, full, new_box, 0);
+    const int rc = pppm_stage(e->stream2, pos0, na, new_box, 0);
     if (rc) return rc;
     HIPCHK(hipEventRecord(e->ev_join, e->stream2));
     return SCEMA_MD_OK;
@@ -1522,10 +1523,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     const int nh = hcnt[h];
     mdk_phase_init(st, Dh, nh);
     mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
-    { const int rcp = pppm_fork(st, hbeg[h], nh, nh, true); if (rcp) return rcp; }
+    { const int rcp = pppm_fork(st, hbeg[h], nh, true); if (rcp) return rcp; }
     mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
     HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
-    if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], nh, nh, true); if (rcp) return rcp; }
+    if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], nh, true); if (rcp) return rcp; }
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
     mdk_final_integrate(st, Dh, nh, maxatoms, 0);
     if (spec.nh) mdk_setup_post_nh(st, Dh, nh);
@@ -1556,7 +1557,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
         mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
         mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly);
         HIPCHK(force_stage(e, st, false, D, ns, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, 1, 0));
-        { const int rcp = pppm_stage(st, 0, ns, ns, false); if (rcp) return rcp; }
+        { const int rcp = pppm_stage(st, 0, ns, false); if (rcp) return rcp; }
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
         mdk_min_decide(st, D, ns);
       }
@@ -1591,7 +1592,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (spec.nh) { mdk_pre_nh(st, Dh, na); mdk_initial_integrate_nh(st, Dh, na, maxatoms); }
     else { mdk_pre(st, Dh, na); mdk_initial_integrate(st, Dh, na, maxatoms); }
     mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj);
-    { const int rcp = pppm_fork(st, hbeg[h], na, hcnt[h], spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
+    { const int rcp = pppm_fork(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
     if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;
@@ -1609,7 +1610,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       launch_sims.push_back({hbeg[h], na});
     }
     HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
-    if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], na, hcnt[h], spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
+    if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
     mdk_shake(st, Dh, na, maxclus, 1.0);
     mdk_final_integrate(st, Dh, na, maxatoms, 1);
     if (spec.nh) mdk_post_nh(st, Dh, na);
@@ -1756,8 +1757,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     fprintf(stderr, "[scema_md] sim 0: cells %dx%dx%d, j table max %d of %d, row max %d of %d, row entries/cluster %.1f, listed pairs/atom %.1f, builds %d\n",
             S0.nc[0], S0.nc[1], S0.nc[2], c.maxj_seen, S0.capj, c.maxneigh_seen, S0.maxneigh, (double)c.nrowent / (S0.npad / MD_CLUSTER),
             (double)c.nentries / S0.natoms, c.nbuilds);
-    fprintf(stderr, "[scema_md] host: %.2f ms laying out %d simulations before the first launch of this run (box range %.2f, cell grid %.2f, k-space set-up %.2f, rest of the loop %.2f)\n",
-            std::chrono::duration<double, std::milli>(t_laid_out - t_enter).count(), ns, t_lay[0], t_lay[1], t_lay[2], t_lay[3]);
+    fprintf(stderr, "[scema_md] host: %.2f ms laying out %d simulations before the first launch of this run (k-space set-up on host threads %.2f, box range %.2f, cell grid %.2f, rest of the loop %.2f)\n",
+            std::chrono::duration<double, std::milli>(t_laid_out - t_enter).count(), ns, t_kspace_ms, t_lay[0], t_lay[1], t_lay[3]);
     fprintf(stderr, "[scema_md] sim 0: far skin band walked on %d of %d steps; list skin %.2f A\n", c.nfar_steps, c.step, S0.skin);
 #ifdef PAIR_TIMING
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
