@@ -18,6 +18,7 @@
 #include "md_types.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 static inline dim3 grid2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)ns, 1); }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256) void k_pppm_zero(const SimDev *sims) {
 // a private copy of the real grid in LDS (ds_add_f64), added to grid 0 at the end (the only global atomics: one per grid point
 // and workgroup; a direct store when the replica has one workgroup).  LDS = false (grid beyond the LDS): global atomics throughout.
 extern __shared__ double s_grid[];
-template <bool LDS>
-__global__ __launch_bounds__(PP_TPB) void k_pppm_spread(const SimDev *sims, int split) {
+template <bool LDS, int TPB_>
+__global__ __launch_bounds__(TPB_) void k_pppm_spread(const SimDev *sims, int split) {
   const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
   if (nx == 0) return;
@@ -96,30 +97,59 @@ __global__ __launch_bounds__(PP_TPB) void k_pppm_spread(const SimDev *sims, int 
   }
   const double delvolinv = (double)NG / b.vol;
   const int rows = (a1 - a0 + 63) >> 6, lane = threadIdx.x & 63;
-  for (int r = (int)threadIdx.x >> 6; r < rows; r += T >> 6) {
-    const int a = a0 + lane * rows + r;
-    if (a >= a1) continue;
-    const double z0 = delvolinv * S.q[a];
-    if (z0 == 0.0) continue;
+  // Two consecutive atoms per lane and turn.  Neighbours in the file are bonded neighbours: about half of such pairs have the same
+  // nearest grid point, hence the same 125 grid points, and then ONE atomic per point carries both contributions (the LDS
+  // atomics, at ~26 cycles per wave instruction, are what this kernel waits for).
+  for (int r = 2 * ((int)threadIdx.x >> 6); r < rows; r += 2 * (T >> 6)) {
+    const int aA = a0 + lane * rows + r, aB = aA + 1;
+    const bool vA = aA < a1, vB = r + 1 < rows && aB < a1;
+    if (!vA) continue;
+    double wxA[PP_ORDER], wyA[PP_ORDER], wzA[PP_ORDER], wxB[PP_ORDER], wyB[PP_ORDER], wzB[PP_ORDER];
+    int gxA[PP_ORDER], gyA[PP_ORDER], gzA[PP_ORDER], gxB[PP_ORDER], gyB[PP_ORDER], gzB[PP_ORDER];
     double l0, l1, l2;
-    atom_lamda(S, b, a, l0, l1, l2);
-    double wx[PP_ORDER], wy[PP_ORDER], wz[PP_ORDER];
-    int gx[PP_ORDER], gy[PP_ORDER], gz[PP_ORDER];
-    pppm_wrap(pppm_weights(l0 * nx, wx), nx, gx);
-    pppm_wrap(pppm_weights(l1 * ny, wy), ny, gy);
-    pppm_wrap(pppm_weights(l2 * nz, wz), nz, gz);
+    atom_lamda(S, b, aA, l0, l1, l2);
+    const int ixA = pppm_weights(l0 * nx, wxA), iyA = pppm_weights(l1 * ny, wyA), izA = pppm_weights(l2 * nz, wzA);
+    pppm_wrap(ixA, nx, gxA); pppm_wrap(iyA, ny, gyA); pppm_wrap(izA, nz, gzA);
+    const double zA = delvolinv * S.q[aA];
+    double zB = 0.0;
+    int ixB = -1000, iyB = 0, izB = 0;
+    if (vB) {
+      atom_lamda(S, b, aB, l0, l1, l2);
+      ixB = pppm_weights(l0 * nx, wxB); iyB = pppm_weights(l1 * ny, wyB); izB = pppm_weights(l2 * nz, wzB);
+      pppm_wrap(ixB, nx, gxB); pppm_wrap(iyB, ny, gyB); pppm_wrap(izB, nz, gzB);
+      zB = delvolinv * S.q[aB];
+    }
+    const bool merged = vB && ixA == ixB && iyA == iyB && izA == izB;
 #pragma unroll
-    for (int k = 0; k < PP_ORDER; k++) wx[k] *= z0;
+    for (int k = 0; k < PP_ORDER; k++) { wxA[k] *= zA; if (vB) wxB[k] *= zB; }
+    if (zA != 0.0 || (merged && zB != 0.0)) {
 #pragma unroll
-    for (int c = 0; c < PP_ORDER; c++) {
+      for (int c = 0; c < PP_ORDER; c++) {
 #pragma unroll
-      for (int bb = 0; bb < PP_ORDER; bb++) {
-        const double zy = wz[c] * wy[bb];
-        const int row = (gz[c] * ny + gy[bb]) * nx;
+        for (int bb = 0; bb < PP_ORDER; bb++) {
+          const double zyA = wzA[c] * wyA[bb], zyB = merged ? wzB[c] * wyB[bb] : 0.0;
+          const int row = (gzA[c] * ny + gyA[bb]) * nx;
 #pragma unroll
-        for (int k = 0; k < PP_ORDER; k++) {
-          if (LDS) (void)__hip_atomic_fetch_add(&s_grid[row + gx[k]], zy * wx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          else atomicAdd(&rho[row + gx[k]].x, zy * wx[k]);
+          for (int k = 0; k < PP_ORDER; k++) {
+            const double val = merged ? fma(zyB, wxB[k], zyA * wxA[k]) : zyA * wxA[k];
+            if (LDS) (void)__hip_atomic_fetch_add(&s_grid[row + gxA[k]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else atomicAdd(&rho[row + gxA[k]].x, val);
+          }
+        }
+      }
+    }
+    if (vB && !merged && zB != 0.0) {
+#pragma unroll
+      for (int c = 0; c < PP_ORDER; c++) {
+#pragma unroll
+        for (int bb = 0; bb < PP_ORDER; bb++) {
+          const double zyB = wzB[c] * wyB[bb];
+          const int row = (gzB[c] * ny + gyB[bb]) * nx;
+#pragma unroll
+          for (int k = 0; k < PP_ORDER; k++) {
+            if (LDS) (void)__hip_atomic_fetch_add(&s_grid[row + gxB[k]], zyB * wxB[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else atomicAdd(&rho[row + gxB[k]].x, zyB * wxB[k]);
+          }
         }
       }
     }
@@ -358,21 +388,25 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
 
 size_t mdk_pppm_lds_limit() { return 144 * 1024; }
 // atom ranges per replica: enough workgroups to fill the 256 CUs several times over, none with fewer than 256 atoms
-static inline int pppm_split(int ns, int maxatoms) { return std::max(1, std::min(std::min(16, cdiv(2048, ns)), maxatoms / 256)); }
+static inline int pppm_split(int ns, int maxatoms) {
+  if (const char *v = getenv("SCEMA_MD_PPPM_SPLIT")) return std::max(1, atoi(v));   // measurement only
+  return std::max(1, std::min(std::min(16, cdiv(2048, ns)), maxatoms / 256));
+}
 void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed) {
   const size_t lds = (size_t)maxgrid * sizeof(double);
   const bool use_lds = lds <= mdk_pppm_lds_limit();
   const int split = pppm_split(ns, maxatoms);
   if ((!use_lds || split > 1) && !zeroed) hipLaunchKernelGGL(k_pppm_zero, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d);
   if (!use_lds) {
-    hipLaunchKernelGGL(k_pppm_spread<false>, grid2(split, ns), dim3(256), 0, st, d, split);
+    hipLaunchKernelGGL((k_pppm_spread<false, 256>), grid2(split, ns), dim3(256), 0, st, d, split);
     return;
   }
   static size_t optin_tab[16] = {0};
   size_t &optin = lds_optin_slot(optin_tab);
-  if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_spread<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+  if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_spread<true, PP_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
   // a small grid leaves room for several workgroups per CU; a large one gets the CU to itself and brings its own sixteen waves
-  hipLaunchKernelGGL(k_pppm_spread<true>, grid2(split, ns), dim3(lds <= 36 * 1024 ? 256 : PP_TPB), lds, st, d, split);
+  if (lds <= 36 * 1024) hipLaunchKernelGGL((k_pppm_spread<true, 256>), grid2(split, ns), dim3(256), lds, st, d, split);
+  else hipLaunchKernelGGL((k_pppm_spread<true, PP_TPB>), grid2(split, ns), dim3(PP_TPB), lds, st, d, split);
 }
 int mdk_pppm_solve_max() { return PP_SOLVE_MAX; }
 void mdk_pppm_solve(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxdims) {
