@@ -154,52 +154,78 @@ __global__ __launch_bounds__(TPB) void k_initial_integrate(const SimDev *sims) {
 // ------------------------------------------------------------------------------------------
 // neighbour build pipeline (all early-exit unless sc->rebuild)
 // ------------------------------------------------------------------------------------------
+// A workgroup bins BIN_APT * TPB consecutive atoms and counts them per cell in LDS first: the per-cell counters of a replica are
+// hit by 86 atoms each, and global atomics on one address serialise at the memory side (0.65 ms per 576-replica rebuild with
+// one global atomic per atom).  Grids of more than BIN_MAXCELLS cells count in global memory directly.
+#define BIN_APT 4
+#define BIN_MAXCELLS 2048
 __global__ __launch_bounds__(TPB) void k_bin(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   SimScalars &sc = *S.sc;
   if (!sc.rebuild) return;
-  const int i = blockIdx.x * TPB + threadIdx.x;
+  if ((int)(blockIdx.x * TPB * BIN_APT) >= S.natoms) return;
+  __shared__ int s_cnt[BIN_MAXCELLS];
+  const bool in_lds = S.ncells <= BIN_MAXCELLS;
+  if (in_lds) {
+    for (int k = threadIdx.x; k < S.ncells; k += TPB) s_cnt[k] = 0;
+    __syncthreads();
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     box_corners(sc.box, sc.corners_hold);
     sc.far_dsq = 1.0e300;   // fresh list: every listed skin pair is outside the cutoff
     sc.need_far = 0;
   }
-  if (i >= S.natoms) return;
   BoxD b;
   box_derive(sc.box, b);
-  double x0 = S.x[3 * i], x1 = S.x[3 * i + 1], x2 = S.x[3 * i + 2];
-  S.xhold[3 * i] = x0; S.xhold[3 * i + 1] = x1; S.xhold[3 * i + 2] = x2;
-  double d0 = x0 - b.lo[0], d1 = x1 - b.lo[1], d2 = x2 - b.lo[2];
-  double l[3];
-  l[0] = b.hinv[0] * d0 + b.hinv[5] * d1 + b.hinv[4] * d2;
-  l[1] = b.hinv[1] * d1 + b.hinv[3] * d2;
-  l[2] = b.hinv[2] * d2;
-  int c[3];
-  int key = 0;
+  int nsub[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) {
-    double fl = floor(l[d]);
-    S.wrapn[3 * i + d] = (int)fl;
-    double w = l[d] - fl;
-    if (w >= 1.0) w = 0.0;
-    int cc = (int)(w * S.nc[d]);
-    if (cc >= S.nc[d]) cc = S.nc[d] - 1;
-    if (cc < 0) cc = 0;
-    c[d] = cc;
     // position inside the cell on a grid of ~1.1 A sub-cells (isotropic in Angstrom whatever the shape of the
     // cell, at most 16 per edge) -> Morton key: consecutive slots of a cell are spatial neighbours, which keeps the
     // 4-atom i-clusters of k_pair compact
     const double edge = (d == 0 ? b.h[0] : d == 1 ? b.h[1] : b.h[2]) / S.nc[d];
-    int nsub = (int)ceil(edge / 1.1);
-    nsub = nsub < 2 ? 2 : (nsub > 16 ? 16 : nsub);
-    int sub = (int)((w * S.nc[d] - cc) * nsub);
-    sub = sub < 0 ? 0 : (sub > nsub - 1 ? nsub - 1 : sub);
-    key |= ((sub & 1) << d) | ((sub & 2) << (d + 2)) | ((sub & 4) << (d + 4)) | ((sub & 8) << (d + 6));
+    const int n = (int)ceil(edge / 1.1);
+    nsub[d] = n < 2 ? 2 : (n > 16 ? 16 : n);
   }
-  S.ckey[i] = key;
-  const int cell = (c[2] * S.nc[1] + c[1]) * S.nc[0] + c[0];
-  S.cell_of[i] = cell;
-  atomicAdd(&S.cell_count[cell], 1);
+  for (int u = 0; u < BIN_APT; u++) {
+    const int i = (blockIdx.x * BIN_APT + u) * TPB + threadIdx.x;
+    if (i >= S.natoms) break;
+    double x0 = S.x[3 * i], x1 = S.x[3 * i + 1], x2 = S.x[3 * i + 2];
+    S.xhold[3 * i] = x0; S.xhold[3 * i + 1] = x1; S.xhold[3 * i + 2] = x2;
+    double d0 = x0 - b.lo[0], d1 = x1 - b.lo[1], d2 = x2 - b.lo[2];
+    double l[3];
+    l[0] = b.hinv[0] * d0 + b.hinv[5] * d1 + b.hinv[4] * d2;
+    l[1] = b.hinv[1] * d1 + b.hinv[3] * d2;
+    l[2] = b.hinv[2] * d2;
+    int c[3];
+    int key = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      double fl = floor(l[d]);
+      S.wrapn[3 * i + d] = (int)fl;
+      double w = l[d] - fl;
+      if (w >= 1.0) w = 0.0;
+      int cc = (int)(w * S.nc[d]);
+      if (cc >= S.nc[d]) cc = S.nc[d] - 1;
+      if (cc < 0) cc = 0;
+      c[d] = cc;
+      int sub = (int)((w * S.nc[d] - cc) * nsub[d]);
+      sub = sub < 0 ? 0 : (sub > nsub[d] - 1 ? nsub[d] - 1 : sub);
+      key |= ((sub & 1) << d) | ((sub & 2) << (d + 2)) | ((sub & 4) << (d + 4)) | ((sub & 8) << (d + 6));
+    }
+    S.ckey[i] = key;
+    const int cell = (c[2] * S.nc[1] + c[1]) * S.nc[0] + c[0];
+    S.cell_of[i] = cell;
+    if (in_lds) atomicAdd(&s_cnt[cell], 1);
+    else atomicAdd(&S.cell_count[cell], 1);
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < S.ncells; k += TPB) {
+      const int n = s_cnt[k];
+      if (n) atomicAdd(&S.cell_count[k], n);
+    }
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_cell_scan(const SimDev *sims) {
@@ -246,14 +272,41 @@ __global__ __launch_bounds__(TPB) void k_cell_scan(const SimDev *sims) {
   }
 }
 
+// slots of the cell's range are handed out in any order (k_cell_sort fixes the order afterwards): a workgroup counts its
+// BIN_APT * TPB atoms per cell in LDS, reserves one range per cell with a single global atomic, and numbers its atoms inside
 __global__ __launch_bounds__(TPB) void k_cell_fill(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   if (!S.sc->rebuild) return;
-  const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i >= S.natoms) return;
-  const int c = S.cell_of[i];
-  const int slot = S.cell_start[c] + atomicAdd(&S.cell_fill[c], 1);
-  S.slot_tmp[slot] = i;
+  if ((int)(blockIdx.x * TPB * BIN_APT) >= S.natoms) return;
+  __shared__ int s_cnt[BIN_MAXCELLS];
+  const bool in_lds = S.ncells <= BIN_MAXCELLS;
+  int cell[BIN_APT], rank[BIN_APT];
+  if (in_lds) {
+    for (int k = threadIdx.x; k < S.ncells; k += TPB) s_cnt[k] = 0;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < BIN_APT; u++) {
+    const int i = (blockIdx.x * BIN_APT + u) * TPB + threadIdx.x;
+    cell[u] = -1; rank[u] = 0;
+    if (i < S.natoms) {
+      cell[u] = S.cell_of[i];
+      rank[u] = in_lds ? atomicAdd(&s_cnt[cell[u]], 1) : atomicAdd(&S.cell_fill[cell[u]], 1);
+    }
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < S.ncells; k += TPB) {
+      const int n = s_cnt[k];
+      s_cnt[k] = n ? atomicAdd(&S.cell_fill[k], n) : 0;   // first slot of this workgroup's share of the cell
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < BIN_APT; u++) {
+    const int i = (blockIdx.x * BIN_APT + u) * TPB + threadIdx.x;
+    if (cell[u] >= 0) S.slot_tmp[S.cell_start[cell[u]] + (in_lds ? s_cnt[cell[u]] : 0) + rank[u]] = i;
+  }
 }
 
 // Deterministic order inside each cell, chosen so that 4 consecutive slots (one i-cluster of k_pair) are spatial
@@ -962,9 +1015,9 @@ void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms
   hipLaunchKernelGGL(k_initial_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
 }
 void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj) {
-  hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB * BIN_APT), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_scan, dim3(ns), dim3(TPB), 0, st, d);
-  hipLaunchKernelGGL(k_cell_fill, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
+  hipLaunchKernelGGL(k_cell_fill, grid2(cdiv(maxatoms, TPB * BIN_APT), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_sort, grid2(maxcells, ns), dim3(64), 0, st, d);
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
   mdk_neigh_build(st, d, ns, maxcells, maxrow, capj);
