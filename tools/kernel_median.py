@@ -16,4 +16,4 @@ for r in rows:
     if not want or any(w in n for w in want):
         d[n].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for n, v in sorted(d.items(), key=lambda x: -sum(x[1])):
-    print(f"{n[:40]:40s} calls {len(v):5d}  median {statistics.median(v):9.1f} us  mean {sum(v)/len(v):9.1f} us  max {max(v):9.1f} us")
+    print(f"{n[:40]:40s} calls {len(v):5d}  min {min(v):8.1f} us  median {statistics.median(v):9.1f} us  mean {sum(v)/len(v):9.1f} us  max {max(v):9.1f} us")
