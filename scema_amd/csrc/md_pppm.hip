@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_pppm_poisson(const SimDev *sims) {
 }
 
 // Small grids (3 NG complex numbers + the twiddles fit the LDS: NG <= PP_SOLVE_MAX): the whole solve of a replica -- forward
-// transform, energy / virial / field spectra, three inverse transforms -- in ONE launch, one workgroup per replica, the grid never
+// transform, energy / virial / field spectra, the inverse transforms (two: x and y ride together) -- in ONE launch, one workgroup per replica, the grid never
 // leaving the LDS.  The transforms are plain DFTs along one dimension at a time (a 10 x 10 x 9 grid is 29 multiply-adds per
 // point and pass; the twiddles exp(-2 pi i j / n) come from sincospi once per launch), ping-ponging between two LDS buffers;
 // a third keeps rho(k) while the three field components are transformed back.  Replaces eight to ten library launches of a few
@@ -312,15 +312,33 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
   double v[6] = {0, 0, 0, 0, 0, 0}, e[1] = {0};
   const size_t gs = (size_t)S.pgstride;
   double2 *field = (double2 *)S.pfield;
-  for (int c = 0; c < 3; c++) {
+  // Two transforms back instead of three: the fields are real, so E_x(k) + i E_y(k) comes back as e_x(r) + i e_y(r) -- if both
+  // spectra are Hermitian.  Modes with a Nyquist component are not (the grid index n/2 stands for -n/2 only), and taking the real
+  // part of each field, as the three-transform form does, is the same as transforming the Hermitian part (X(k) + conj X(-k)) / 2:
+  // that is what is packed here (for every other mode it equals X(k) to the last bit).
+  for (int c = 0; c < 2; c++) {
     for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) {
       double kv[3], vd[6] = {0, 0, 0, 0, 0, 0}, ed = 0.0;
       const double2 p = (c == 0) ? pppm_mode(S, b, idx, nx, ny, nz, B[idx], kv, v, e[0]) : pppm_mode(S, b, idx, nx, ny, nz, B[idx], kv, vd, ed);
-      A[idx] = make_double2(kv[c] * p.y, -kv[c] * p.x);       // (a + i b)(-i k) = b k - i a k
+      // spectrum of one component: (a + i b)(-i k) = b k - i a k
+      if (c == 0) {
+        const int m1 = idx % nx, m2 = (idx / nx) % ny, m3 = idx / (nx * ny);
+        const int mid = (((nz - m3) % nz) * ny + (ny - m2) % ny) * nx + (nx - m1) % nx;
+        double kw[3];
+        const double2 q = pppm_mode(S, b, mid, nx, ny, nz, B[mid], kw, vd, ed);
+        // Hermitian parts of X = (kx p.y, -kx p.x) and Y = (ky p.y, -ky p.x), with conj of the mirror mode's (kw q.y, -kw q.x)
+        const double xr = 0.5 * (kv[0] * p.y + kw[0] * q.y), xi = 0.5 * (-kv[0] * p.x + kw[0] * q.x);
+        const double yr = 0.5 * (kv[1] * p.y + kw[1] * q.y), yi = 0.5 * (-kv[1] * p.x + kw[1] * q.x);
+        A[idx] = make_double2(xr - yi, xi + yr);   // X_H + i Y_H
+      } else A[idx] = make_double2(kv[2] * p.y, -kv[2] * p.x);
     }
     __syncthreads();
     pass(A, C, 0, true); pass(C, A, 1, true); pass(A, C, 2, true);
-    for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) field[c * gs + idx] = C[idx];
+    for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) {
+      const double2 r = C[idx];
+      if (c == 0) { field[idx] = make_double2(r.x, 0.0); field[gs + idx] = make_double2(r.y, 0.0); }
+      else field[2 * gs + idx] = make_double2(r.x, 0.0);
+    }
     __syncthreads();
   }
   block_atomic_add_n<6, PP_SOLVE_TPB / 64>(v, S.sc->vir + P_KSPACE * 6, s_red);
@@ -390,7 +408,8 @@ size_t mdk_pppm_lds_limit() { return 144 * 1024; }
 // atom ranges per replica: enough workgroups to fill the 256 CUs several times over, none with fewer than 256 atoms
 static inline int pppm_split(int ns, int maxatoms) {
   if (const char *v = getenv("SCEMA_MD_PPPM_SPLIT")) return std::max(1, atoi(v));   // measurement only
-  return std::max(1, std::min(std::min(16, cdiv(2048, ns)), maxatoms / 256));
+  // small batches: down to one atom per thread (a single replica: spreading 27 -> 15 us, interpolation 27 -> 20 us)
+  return std::max(1, std::min(std::min(ns < 32 ? 64 : 16, cdiv(2048, ns)), maxatoms / 256));
 }
 void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed) {
   const size_t lds = (size_t)maxgrid * sizeof(double);
