@@ -313,8 +313,10 @@ __global__ __launch_bounds__(TPB) void k_cell_fill(const SimDev *sims) {
 // neighbours: a k-d ordering.  The cell's atoms are split recursively at the median of the longest extent of the
 // current group (left part = half of the group's clusters, a multiple of 4 atoms) until the groups are single
 // clusters; ties by atom index, so the result does not depend on the atomic fill order.  One wave per cell, O(n^2)
-// rank counting per level in LDS (n <= 256; larger cells fall back to the Morton key of k_bin).
-#define KD_MAX 256
+// rank counting per level in LDS (n <= KD_MAX; larger cells fall back to the Morton key of k_bin).
+// KD_MAX = 128 or 256 (the launch picks by the mean cell population: the smaller one doubles the waves a CU holds, and this kernel
+// is bound by the latency of its LDS loops); a cell beyond KD_MAX atoms takes the Morton order
+template <int KD_MAX>
 __global__ __launch_bounds__(64) void k_cell_sort(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
   if (!S.sc->rebuild) return;
@@ -344,20 +346,23 @@ __global__ __launch_bounds__(64) void k_cell_sort(const SimDev *sims) {
     }
     return;
   }
-  __shared__ double s_x[KD_MAX][3];
-  __shared__ int s_gid[KD_MAX];
-  __shared__ int s_k[2][KD_MAX], s_s[2][KD_MAX], s_e[2][KD_MAX];
+  // coordinates and atom ids travel with the order (two buffers, swapped per level): the loops over a group read consecutive LDS
+  // entries without a dependent index load in between (with an index array they waited for two LDS latencies per element:
+  // 2.5 ms per 576-replica rebuild)
+  __shared__ double s_x[2][KD_MAX][3];
+  __shared__ int s_gid[2][KD_MAX];
+  __shared__ int s_s[2][KD_MAX], s_e[2][KD_MAX];
   {
     BoxD bx;
     box_derive(S.sc->box, bx);
     for (int k = threadIdx.x; k < n; k += 64) {
       const int a = S.slot_tmp[b + k];
       const int w0 = S.wrapn[3 * a], w1 = S.wrapn[3 * a + 1], w2 = S.wrapn[3 * a + 2];
-      s_x[k][0] = S.x[3 * a] - (bx.h[0] * w0 + bx.h[5] * w1 + bx.h[4] * w2);
-      s_x[k][1] = S.x[3 * a + 1] - (bx.h[1] * w1 + bx.h[3] * w2);
-      s_x[k][2] = S.x[3 * a + 2] - (bx.h[2] * w2);
-      s_gid[k] = a;
-      s_k[0][k] = k; s_s[0][k] = 0; s_e[0][k] = n;
+      s_x[0][k][0] = S.x[3 * a] - (bx.h[0] * w0 + bx.h[5] * w1 + bx.h[4] * w2);
+      s_x[0][k][1] = S.x[3 * a + 1] - (bx.h[1] * w1 + bx.h[3] * w2);
+      s_x[0][k][2] = S.x[3 * a + 2] - (bx.h[2] * w2);
+      s_gid[0][k] = a;
+      s_s[0][k] = 0; s_e[0][k] = n;
     }
   }
   int cur = 0;
@@ -365,38 +370,40 @@ __global__ __launch_bounds__(64) void k_cell_sort(const SimDev *sims) {
     __syncthreads();
     bool split_any = false;
     for (int p = threadIdx.x; p < n; p += 64) {
-      const int s0 = s_s[cur][p], e0 = s_e[cur][p], cnt = e0 - s0, k = s_k[cur][p];
+      const int s0 = s_s[cur][p], e0 = s_e[cur][p], cnt = e0 - s0;
+      const double xp[3] = {s_x[cur][p][0], s_x[cur][p][1], s_x[cur][p][2]};
+      const int gp = s_gid[cur][p];
       int np = p, ns = s0, ne = e0;
       if (cnt > 4) {
         split_any = true;
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (int q = s0; q < e0; q++) {
-          const int kq = s_k[cur][q];
-          for (int d = 0; d < 3; d++) { lo[d] = fmin(lo[d], s_x[kq][d]); hi[d] = fmax(hi[d], s_x[kq][d]); }
-        }
+#pragma unroll 4
+        for (int q = s0; q < e0; q++)
+#pragma unroll
+          for (int d = 0; d < 3; d++) { const double xv = s_x[cur][q][d]; lo[d] = fmin(lo[d], xv); hi[d] = fmax(hi[d], xv); }
         const double ex0 = hi[0] - lo[0], ex1 = hi[1] - lo[1], ex2 = hi[2] - lo[2];
         const int axis = (ex0 >= ex1 && ex0 >= ex2) ? 0 : (ex1 >= ex2 ? 1 : 2);
-        const double xp = s_x[k][axis];
-        const int gp = s_gid[k];
+        const double xpa = axis == 0 ? xp[0] : (axis == 1 ? xp[1] : xp[2]);
         int rank = 0;
+#pragma unroll 4
         for (int q = s0; q < e0; q++) {
-          const int kq = s_k[cur][q];
-          const double xq_ = s_x[kq][axis];
-          rank += (xq_ < xp || (xq_ == xp && s_gid[kq] < gp)) ? 1 : 0;
+          const double xq_ = s_x[cur][q][axis];
+          rank += (xq_ < xpa || (xq_ == xpa && s_gid[cur][q] < gp)) ? 1 : 0;
         }
         const int nclus = (cnt + 3) / 4;
         const int left = ((nclus + 1) / 2) * 4;   // half of the group's clusters (rounded up), always < cnt
         np = s0 + rank;
         if (rank < left) { ns = s0; ne = s0 + left; } else { ns = s0 + left; ne = e0; }
       }
-      s_k[1 - cur][np] = k; s_s[1 - cur][np] = ns; s_e[1 - cur][np] = ne;
+      s_x[1 - cur][np][0] = xp[0]; s_x[1 - cur][np][1] = xp[1]; s_x[1 - cur][np][2] = xp[2];
+      s_gid[1 - cur][np] = gp; s_s[1 - cur][np] = ns; s_e[1 - cur][np] = ne;
     }
     cur = 1 - cur;
     if (!__any(split_any)) break;
   }
   __syncthreads();
   for (int p = threadIdx.x; p < n; p += 64) {
-    const int a = s_gid[s_k[cur][p]];
+    const int a = s_gid[cur][p];
     S.perm[b + p] = a;
     S.slot_of[a] = b + p;
   }
@@ -1018,7 +1025,8 @@ void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int max
   hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB * BIN_APT), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_scan, dim3(ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_cell_fill, grid2(cdiv(maxatoms, TPB * BIN_APT), ns), dim3(TPB), 0, st, d);
-  hipLaunchKernelGGL(k_cell_sort, grid2(maxcells, ns), dim3(64), 0, st, d);
+  if (maxatoms <= 100 * maxcells) hipLaunchKernelGGL(k_cell_sort<128>, grid2(maxcells, ns), dim3(64), 0, st, d);
+  else hipLaunchKernelGGL(k_cell_sort<256>, grid2(maxcells, ns), dim3(64), 0, st, d);
   hipLaunchKernelGGL(k_pack, grid2(cdiv(maxpad, TPB), ns), dim3(TPB), 0, st, d);
   mdk_neigh_build(st, d, ns, maxcells, maxrow, capj);
 }
