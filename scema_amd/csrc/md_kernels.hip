@@ -432,11 +432,13 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   r.x = S.x[3 * a] - (b.h[0] * w0 + b.h[5] * w1 + b.h[4] * w2);
   r.y = S.x[3 * a + 1] - (b.h[1] * w1 + b.h[3] * w2);
   r.z = S.x[3 * a + 2] - (b.h[2] * w2);
-  r.w = S.q[a];
   // two arrays of 16-byte halves: (x,y)[npad], (z,q)[npad]  (see md_pair.hip)
   double *xy = (double *)S.xq + 2 * (size_t)s, *zq = (double *)S.xq + 2 * (size_t)S.npad + 2 * (size_t)s;
-  xy[0] = r.x; xy[1] = r.y; zq[0] = r.z; zq[1] = r.w;
-  S.stype[s] = S.type[a];
+  xy[0] = r.x; xy[1] = r.y; zq[0] = r.z;
+  if (S.sc->rebuild) {   // charge and type of a slot change only when the slots are dealt anew: two scattered reads less on the other steps
+    zq[1] = S.q[a];
+    S.stype[s] = S.type[a];
+  }
 }
 
 // k_neigh_build and k_pair live in md_pair.hip, the bonded terms in md_bonded.hip
