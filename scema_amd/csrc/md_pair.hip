@@ -150,7 +150,8 @@ extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave li
                                   // [NQ][qcap] 16-bit table indices: the part of the table each quarter of the cell's clusters can reach
 #define NQ 4
 
-__global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap) {
+// (TT, 4): at most 128 registers, so that two workgroups share a CU -- at 129 the kernel ran 1.6 times longer
+__global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap) {
   int sim, cell;
   if (!xcd_map(ntiles, nsims, sim, cell)) return;
   const SimDev &S = sims[sim];
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
   const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2;
   const GLOBAL_AS int *stype = as_global(S.stype);
   unsigned long long npairs = 0, npairs_ref = 0, nrowent = 0;
+  const bool count_ref = S.rlist_ref2 < S.rlist2;   // only a list wider than the reference's needs the second count (uniform)
   int nmax = 0, over = 0;
   for (int cl = cs / NI + wave; cl < ce / NI; cl += TW) {
     const int s0slot = cl * NI;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
         const double cx = bx - xj, cy = by - yj, cz = bz - zj;
         if (__ballot(in && cx * cx + cy * cy + cz * cz < breach2) == 0ull) continue;   // nothing of this chunk is in reach
       }
-      int mask = 0, near = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
+      int mask = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
       double rmin = 1.0e300;
 #pragma unroll
       for (int a = 0; a < NI; a++) {
@@ -448,21 +450,25 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
         const double r2 = dx * dx + dy * dy + dz * dz;
         const bool acc = in && ci.atom[a] >= 0 && r2 < S.rlist2 && !(own && j <= s0slot + a);
         mask |= acc ? (1 << a) : 0;
-        refm |= (acc && r2 < S.rlist_ref2) ? (1 << a) : 0;
+        if (count_ref) refm |= (acc && r2 < S.rlist_ref2) ? (1 << a) : 0;
         rmin = acc ? fmin(rmin, r2) : rmin;
-        near |= (acc && r2 < S.excl_cut2) ? (1 << a) : 0;
       }
-      if (__ballot(near != 0) != 0ull) {
-        if (near) {
+      // candidates inside the exclusion gate (bonded neighbours: a few chunks per row) take the wave-uniform slow path, which
+      // looks at the four distances again and walks the exclusion lists
+      if (__ballot(mask != 0 && rmin < S.excl_cut2) != 0ull) {
+        if (mask != 0 && rmin < S.excl_cut2) {
           const int aj = S.perm[j];
 #pragma unroll
           for (int a = 0; a < NI; a++)
-            if (near & (1 << a)) {
-              bool keep = true;
-              const int nl = min(exn[a], 16);
-              for (int e = 0; e < nl; e++) keep = keep && (s_ex[wave][a * 16 + e] != aj);
-              for (int e = 16; e < exn[a]; e++) keep = keep && (S.ex_list[exb[a] + e] != aj);
-              if (!keep) { mask &= ~(1 << a); refm &= ~(1 << a); }   // rmin may stay too small: only the segment choice sees it, and a nearer segment is always allowed
+            if (mask & (1 << a)) {
+              const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
+              if (dx * dx + dy * dy + dz * dz < S.excl_cut2) {
+                bool keep = true;
+                const int nl = min(exn[a], 16);
+                for (int e = 0; e < nl; e++) keep = keep && (s_ex[wave][a * 16 + e] != aj);
+                for (int e = 16; e < exn[a]; e++) keep = keep && (S.ex_list[exb[a] + e] != aj);
+                if (!keep) { mask &= ~(1 << a); refm &= ~(1 << a); }   // rmin may stay too small: only the segment choice sees it, and a nearer segment is always allowed
+              }
             }
         }
       }
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(TT) void k_neigh_build(const SimDev *__restrict__ s
       }
       nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC); nD += __popcll(mD);
       npairs += __popc(mask);
-      npairs_ref += __popc(refm);
+      npairs_ref += __popc(count_ref ? refm : mask);
     }
     const int n = nA + nB + nC + nD;
     const bool bad = nB + nC > capB || n > maxrow;
