@@ -354,7 +354,8 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
   const int maxrow = S.maxneigh;
   const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2;
   const GLOBAL_AS int *stype = as_global(S.stype);
-  unsigned long long npairs = 0, npairs_ref = 0, nrowent = 0;
+  unsigned int npairs = 0, npairs_ref = 0;   // per lane and tile: far below 2^32
+  unsigned long long nrowent = 0;
   const bool count_ref = S.rlist_ref2 < S.rlist2;   // only a list wider than the reference's needs the second count (uniform)
   int nmax = 0, over = 0;
   for (int cl = cs / NI + wave; cl < ce / NI; cl += TW) {
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       }
       nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC); nD += __popcll(mD);
       npairs += __popc(mask);
-      npairs_ref += __popc(count_ref ? refm : mask);
+      if (count_ref) npairs_ref += __popc(refm);
     }
     const int n = nA + nB + nC + nD;
     const bool bad = nB + nC > capB || n > maxrow;
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     atomicAdd(&sc.dbg[5], tb1 - tb0); atomicAdd(&sc.dbg[6], tb2 - tb1); atomicAdd(&sc.dbg[7], tb3 - tb2);
   }
 #endif
-  const double cnt = wave_sum((double)npairs), cnt_ref = wave_sum((double)npairs_ref);
+  const double cnt = wave_sum((double)npairs), cnt_ref = count_ref ? wave_sum((double)npairs_ref) : cnt;
   if (lane == 0) {
     if (over) atomicOr(&sc.overflow, 1 | 8);   // 8: a cluster row (or its segment-B list)
     atomicMax(&sc.maxneigh_seen, nmax);
