@@ -204,7 +204,10 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     }
   }
   // own cell first: table index l <-> slot cs + l (pads included), so the cluster atoms know their own index
-  for (int l = threadIdx.x; l < nown && l < capj; l += TT) s_jtab[l] = (cs + l) | (CODE_HOME << 23);
+  // (inside this kernel the table entries also carry the type of j in bits 28..31: the rows need it per accepted candidate, and
+  // one load per table entry here replaces one per cluster and entry there; the copy that k_pair reads is written without it)
+  const GLOBAL_AS int *stype = as_global(S.stype);
+  for (int l = threadIdx.x; l < nown && l < capj; l += TT) s_jtab[l] = (cs + l) | (CODE_HOME << 23) | (stype[cs + l] << 28);
   __syncthreads();
   const double blo0 = s_box[0], blo1 = s_box[1], blo2 = s_box[2], bhi0 = s_box[3], bhi1 = s_box[4], bhi2 = s_box[5];
   const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
           }
           if (ok) {
             const int pos = nj + before + popc_below(m);
-            if (pos < capj) s_jtab[pos] = j | (code << 23);
+            if (pos < capj) s_jtab[pos] = j | (code << 23) | (stype[j] << 28);
           }
           nj += total;
           __syncthreads();
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
   }
   {
     GLOBAL_AS int *gj = as_global_w(S.tile_jtab) + (size_t)cell * S.capj;
-    for (int l = threadIdx.x; l < nj; l += TT) gj[l] = s_jtab[l];
+    for (int l = threadIdx.x; l < nj; l += TT) gj[l] = s_jtab[l] & 0x0FFFFFFF;
     if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
   }
   // ---- phase 1b: which table entries can each quarter of the cell's clusters reach at all? ----
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       if (l < nj) {
         const int jt = s_jtab[l];
         const size_t j = (size_t)(jt & MD_JMASK);
-        const int code = jt >> 23;
+        const int code = (jt >> 23) & 31;
         const double xj = xq[2 * j] + s_shift[3 * code], yj = xq[2 * j + 1] + s_shift[3 * code + 1], zj = zq[2 * j] + s_shift[3 * code + 2];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
@@ -353,7 +356,6 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 #endif
   const int maxrow = S.maxneigh;
   const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2;
-  const GLOBAL_AS int *stype = as_global(S.stype);
   unsigned int npairs = 0, npairs_ref = 0;   // per lane and tile: far below 2^32
   unsigned long long nrowent = 0;
   const bool count_ref = S.rlist_ref2 < S.rlist2;   // only a list wider than the reference's needs the second count (uniform)
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       // wave-uniform slow path that walks the exclusion lists.
       const bool in = l >= 0;
       const int j = jt & MD_JMASK;
-      const int code = jt >> 23;
+      const int code = (jt >> 23) & 31;
       const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
       const bool own = in && l < nown;   // same cell, same image: each pair once, by slot order
       {
@@ -449,10 +451,17 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       for (int a = 0; a < NI; a++) {
         const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
         const double r2 = dx * dx + dy * dy + dz * dz;
-        const bool acc = in && ci.atom[a] >= 0 && r2 < S.rlist2 && !(own && j <= s0slot + a);
+        const bool acc = in && ci.atom[a] >= 0 && r2 < S.rlist2;
         mask |= acc ? (1 << a) : 0;
         if (count_ref) refm |= (acc && r2 < S.rlist_ref2) ? (1 << a) : 0;
         rmin = acc ? fmin(rmin, r2) : rmin;
+      }
+      {
+        // same cell, same image: each pair once, by slot order -- atom a of the cluster keeps j only if j > s0slot + a.  One mask per
+        // candidate instead of a test per atom (rmin may then be too small: a nearer segment is always allowed)
+        const int d = j - s0slot;
+        const int drop = !own ? 0 : (d <= 0 ? 0xF : (d > 3 ? 0 : (0xF << d) & 0xF));
+        mask &= ~drop; refm &= ~drop;
       }
       // candidates inside the exclusion gate (bonded neighbours: a few chunks per row) take the wave-uniform slow path, which
       // looks at the four distances again and walks the exclusion lists
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       const bool isD = mask && !isA && !isB && !isC;
       const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC), mD = __ballot(isD);
       if (mask) {
-        const int entry = l | (stype[j] << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT);
+        const int entry = l | ((int)((unsigned)jt >> 28) << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT);
         if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) row[pos] = entry; }
         else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
         else if (isC) { const int pos = capB - 1 - (nC + popc_below(mC)); if (pos >= 0) lb[pos] = entry; }
