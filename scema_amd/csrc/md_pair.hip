@@ -447,15 +447,18 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       }
       int mask = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
       double rmin = 1.0e300;
+      // (pad atoms of the cluster sit at 1e15: never inside the list radius; lanes past the end of the list are cleared below; the
+      // nearest of the four distances stands for the nearest ACCEPTED one: beyond the list radius it decides nothing, and otherwise it
+      // can only be too small, which moves the entry to a nearer segment -- always allowed)
 #pragma unroll
       for (int a = 0; a < NI; a++) {
         const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
         const double r2 = dx * dx + dy * dy + dz * dz;
-        const bool acc = in && ci.atom[a] >= 0 && r2 < S.rlist2;
-        mask |= acc ? (1 << a) : 0;
-        if (count_ref) refm |= (acc && r2 < S.rlist_ref2) ? (1 << a) : 0;
-        rmin = acc ? fmin(rmin, r2) : rmin;
+        mask |= (r2 < S.rlist2) ? (1 << a) : 0;
+        if (count_ref) refm |= (r2 < S.rlist_ref2) ? (1 << a) : 0;
+        rmin = fmin(rmin, r2);
       }
+      if (!in) { mask = 0; refm = 0; }
       {
         // same cell, same image: each pair once, by slot order -- atom a of the cluster keeps j only if j > s0slot + a.  One mask per
         // candidate instead of a test per atom (rmin may then be too small: a nearer segment is always allowed)
