@@ -641,7 +641,8 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   // Row headers of this wave and the first two chunks of its entry stream are requested before the tile's table is
   // staged: none of that needs the LDS, so their latency runs under the table load and the barrier.
   const int p_begin = S.tile_wstart[(size_t)cell * (TW + 1) + wave], p_end = S.tile_wstart[(size_t)cell * (TW + 1) + wave + 1];
-  const int nrows = (nj > 0) ? min(p_end - p_begin, 64) : 0;
+  // (wave-uniform by construction; saying so lets the row cursors below live in scalar registers and branch on the scalar unit)
+  const int nrows = __builtin_amdgcn_readfirstlane((nj > 0) ? min(p_end - p_begin, 64) : 0);
   if (p_end - p_begin > 64 && lane == 0) atomicOr(&sc.overflow, 1 | 4);   // cannot happen after k_neigh_build's check; loud if it ever does
   int h_cl = 0, h_nab = 0, h_nn = 0;
   if (lane < nrows) {
