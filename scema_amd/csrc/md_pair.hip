@@ -686,7 +686,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   }
   double cp[NP];
 #pragma unroll
-  for (int m = 0; m < NP; m++) cp[m] = S.coul_poly[m];
+  for (int m = 0; m < NP; m++) cp[m] = S.coul_poly_g[m];   // g H(u), scaled on the host: x H = r (g H), one multiplication less per coulomb pair
   __syncthreads();
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);   // (x,y) halves
   const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;              // (z,q) halves
@@ -751,14 +751,14 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
             double fp = 0.0, flj = 0.0, fc = 0.0;
             if (rsq < cutc2) {
               // erfc(x) + 2x/sqrt(pi) exp(-x^2) = 1 - x H(u): Horner in t = u*uscale - 1
-              const double x = g * rsq * rinv;
+              const double rr = rsq * rinv;   // r
               const double t = fma(rsq, g2u, -1.0);
               double p = cp[NP - 1];
 #pragma unroll
               for (int m = NP - 2; m >= 0; m--) p = fma(p, t, cp[m]);
               const double pref = qi[a] * qj * rinv;
-              fp = pref * fma(-x, p, 1.0) * r2inv;
-              if (ENG) { fc = fp; ecoul += pref * erfc(x); }
+              fp = pref * fma(-rr, p, 1.0) * r2inv;
+              if (ENG) { fc = fp; ecoul += pref * erfc(g * rr); }
             }
             if (rsq < cutl2) {
               const double r6inv = r2inv * r2inv * r2inv;
