@@ -161,7 +161,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 #ifdef PAIR_TIMING
   const unsigned long long tb0 = __builtin_readcyclecounter();
 #endif
-  const int cs = S.cell_start[cell], ce = S.cell_start[cell + 1], nown = ce - cs;
+  const int cs = __builtin_amdgcn_readfirstlane(S.cell_start[cell]), ce = __builtin_amdgcn_readfirstlane(S.cell_start[cell + 1]), nown = ce - cs;   // uniform, and said so
   if (nown == 0) {
     if (threadIdx.x == 0) S.tile_nj[cell] = 0;
     return;
