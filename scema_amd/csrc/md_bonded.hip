@@ -65,7 +65,8 @@ __global__ __launch_bounds__(BT_TPB, BT_OCC) void k_bonded(const SimDev *__restr
   SimScalars &sc = *S.sc;
   __shared__ double s_red[8 * (BT_TPB / 64)];
   const int *desc = S.bt_desc + (size_t)blockIdx.x * BT_DESC;
-  const int nloc = desc[1], nown = desc[14], nchunk = desc[3];
+  // (wave-uniform: said so, so that the loops over them run on the scalar unit)
+  const int nloc = __builtin_amdgcn_readfirstlane(desc[1]), nown = __builtin_amdgcn_readfirstlane(desc[14]), nchunk = __builtin_amdgcn_readfirstlane(desc[3]);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // the wave's term descriptors first: nothing below depends on them until the positions are staged, so their latency
   // runs under the staging loads
