@@ -149,6 +149,7 @@ struct ClusterI {
 extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists (segment B from the front, C1 from the back), then
                                   // [NQ][qcap] 16-bit table indices: the part of the table each quarter of the cell's clusters can reach
 #define NQ 4
+#define SPLIT_OVH 160   // cost of starting one more row part in k_pair, in the units of the rows' cost estimate (k_neigh_build's schedule)
 
 // (TT, 4): at most 128 registers, so that two workgroups share a CU -- at 129 the kernel ran 1.6 times longer
 __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap) {
@@ -552,6 +553,44 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
           if (w == wmin) { pos = num[w]; num[w] += 1; load[w] += c; }
         if (lane == src) { my_w = wmin; my_pos = pos; }
       }
+      // Rows are few (about 22 per tile for 8 waves: some waves get three, some two, and the tile waits for the slowest: an eighth
+      // of k_pair's wave time was spent at its final barrier).  So the loads are evened out by handing the tail of a row of the
+      // fullest wave to the emptiest: an entry of tile_order is (cluster | a << 20 | b << 25) and stands for the chunks
+      // [C a / 16, C b / 16) of the cluster's row, C = its number of 64-entry chunks when k_pair runs; (0, 16) = the whole row.
+      // A part costs its share of the row plus the per-row work (i-cluster records, force reduction: ~SPLIT_OVH entries' worth).
+      int pa = 0, pb = 16, ecl = i;     // this lane's entry: part [pa, pb) of cluster ecl (lanes >= nclus: entries made by splits)
+      bool have = i < nclus;
+      int nextra = 0;
+      if (nclus >= TW && nclus + TW <= 64) {   // (a tile's share of tile_order is twice its clusters: room for TW more entries)
+        for (int it = 0; it < TW; it++) {
+          int wmax = 0, wmin = 0;
+#pragma unroll
+          for (int w = 1; w < TW; w++) {
+            if (load[w] > load[wmax]) wmax = w;
+            if (load[w] < load[wmin]) wmin = w;
+          }
+          const int diff = load[wmax] - load[wmin];
+          if (diff < 3 * SPLIT_OVH) break;
+          const unsigned long long sel = __ballot(have && i < nclus && my_w == wmax && pa == 0 && pb == 16);
+          if (sel == 0ull) break;
+          const int src = __ffsll((long long)sel) - 1;
+          const int c = __shfl(cnt_i, src, 64) - SPLIT_OVH;       // the part of the row's cost that scales with its length
+          if (c < 8 * SPLIT_OVH) break;
+          int m16 = (16 * (diff - SPLIT_OVH) + c) / (2 * c);      // sixteenths to move so that both waves end level
+          m16 = min(max(m16, 0), 12);
+          if (m16 < 2) break;
+          const int moved = (c * m16) / 16;
+          int pos = 0;
+#pragma unroll
+          for (int w = 0; w < TW; w++) {
+            if (w == wmax) load[w] -= moved;
+            if (w == wmin) { pos = num[w]; num[w] += 1; load[w] += moved + SPLIT_OVH; }
+          }
+          if (lane == src) pb = 16 - m16;
+          if (lane == nclus + nextra) { have = true; ecl = src; pa = 16 - m16; pb = 16; my_w = wmin; my_pos = pos; }
+          nextra++;
+        }
+      }
       int start = 0, my_start = 0;
 #pragma unroll
       for (int w = 0; w < TW; w++) {
@@ -560,7 +599,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
         start += num[w];
       }
       if (lane == TW) wst[TW] = start;
-      if (i < nclus) S.tile_order[c0i + my_start + my_pos] = c0i + i;
+      if (have) S.tile_order[2 * c0i + my_start + my_pos] = (c0i + ecl) | (pa << 20) | (pb << 25);
     } else {
       // very large cells: round robin
       for (int w = lane; w <= TW; w += 64) {
@@ -572,7 +611,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
         const int w = i % TW;
         int st = 0;
         for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
-        S.tile_order[c0i + st + i / TW] = c0i + i;
+        S.tile_order[2 * c0i + st + i / TW] = (c0i + i) | (16 << 25);
       }
     }
   }
@@ -646,9 +685,14 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   if (p_end - p_begin > 64 && lane == 0) atomicOr(&sc.overflow, 1 | 4);   // cannot happen after k_neigh_build's check; loud if it ever does
   int h_cl = 0, h_nab = 0, h_nn = 0;
   if (lane < nrows) {
-    h_cl = S.tile_order[cs / NI + p_begin + lane];
+    // an entry of the schedule: cluster | a << 20 | b << 25 = the chunks [C a / 16, C b / 16) of that cluster's row (k_neigh_build)
+    const int ent = S.tile_order[2 * (cs / NI) + p_begin + lane];
+    h_cl = ent & 0xFFFFF;
     h_nab = S.numneigh[2 * h_cl];
-    h_nn = (h_nab + (need_far ? S.numneigh[2 * h_cl + 1] : 0)) << 16;   // [A|B|C1] from the front, C2 reversed from the back
+    const int n = h_nab + (need_far ? S.numneigh[2 * h_cl + 1] : 0);   // [A|B|C1] from the front, C2 reversed from the back
+    const int C = (n + 63) >> 6, pa = (ent >> 20) & 31, pb = (ent >> 25) & 31;
+    const int kb = 64 * ((C * pa) >> 4), ke = min(n, 64 * ((C * pb) >> 4));
+    h_nn = (max(ke, kb) << 16) | kb;
   }
 #define H_KB(v) ((v) & 0xFFFF)
 #define H_KE(v) ((int)((unsigned)(v) >> 16))
