@@ -1306,6 +1306,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       const double perr = cached_coul_poly(e, ew.g, P.cut_coul, S.coul_poly, &S.coul_npoly, &S.coul_uscale);
       if (perr > 1e-12 && !getenv("SCEMA_MD_POLY_TOL")) return fail(e, SCEMA_MD_ERR_ARG, "real-space Ewald polynomial fit error %.3e too large (g*rc = %.3f)", perr, ew.g * P.cut_coul);
       for (int m = 0; m < MD_MAXPOLY; m++) S.coul_poly_g[m] = S.coul_poly[m] * ew.g;
+      static const int row_split = getenv("SCEMA_MD_ROW_SPLIT") ? atoi(getenv("SCEMA_MD_ROW_SPLIT")) : 1;
+      S.sched_split = row_split;
     }
     {
       const double m = 0.1 * P.skin;   // margin of the row segments over the cutoffs (scan 0 .. 0.6 skin: flat optimum at 0.05-0.15)

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       int pa = 0, pb = 16, ecl = i;     // this lane's entry: part [pa, pb) of cluster ecl (lanes >= nclus: entries made by splits)
       bool have = i < nclus;
       int nextra = 0;
-      if (nclus >= TW && nclus + TW <= 64) {   // (a tile's share of tile_order is twice its clusters: room for TW more entries)
+      if (S.sched_split && nclus >= TW && nclus + TW <= 64) {   // (a tile's share of tile_order is twice its clusters: room for TW more entries)
         for (int it = 0; it < TW; it++) {
           int wmax = 0, wmin = 0;
 #pragma unroll
