@@ -780,7 +780,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       }
       const int mask = (e >> E_MASK_SHIFT) & 0xF;  // 0 for the padding of a row's last chunk
       if (mask != 0) {
-        const int cs4 = 4 * (jt >> 23);
+        const int cs4 = (int)(((unsigned)jt >> 21) & 0x7Cu);   // 4 * image code (bits 23..27; the type bits above them are cleared in this copy)
         const double xs = xj + s_shift[cs4], ys = yj + s_shift[cs4 + 1], zs = zj + s_shift[cs4 + 2];
         const int tj = (e >> E_TYPE_SHIFT) & 0xF;
         double gx = 0.0, gy = 0.0, gz = 0.0;   // reaction force on j
