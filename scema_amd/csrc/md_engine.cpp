@@ -1527,7 +1527,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     mdk_phase_init(st, Dh, nh);
     mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
     { const int rcp = pppm_fork(st, hbeg[h], nh, true); if (rcp) return rcp; }
-    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
+    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
     HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
     if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], nh, true); if (rcp) return rcp; }
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
@@ -1558,7 +1558,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
         mdk_min_pre(st, D, ns);
         mdk_min_move(st, D, ns, maxatoms, x0s, hsd);
         mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
-        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly);
+        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly, P.cut_coul <= P.cut_lj);
         HIPCHK(force_stage(e, st, false, D, ns, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, 1, 0));
         { const int rcp = pppm_stage(st, 0, ns, false); if (rcp) return rcp; }
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
@@ -1606,7 +1606,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
-    mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly);
+    mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
     if (timed) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;

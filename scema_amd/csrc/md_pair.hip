@@ -620,7 +620,9 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 // NP = number of polynomial coefficients kept in scalar registers (>= fitted degree+1, 0-padded)
 extern __shared__ double s_pair[];  // [3][capj] reaction-force accumulators, then int [capj] j table
 
-template <bool VIR, bool ENG, int NP>
+// CLE: the coulomb cutoff does not exceed the LJ cutoff (the reference's 9 / 12): every interacting lane has an LJ term, which then
+// defines the force factor without a zero to start from, and the cutoff test is one instead of two
+template <bool VIR, bool ENG, int NP, bool CLE = false>
 __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj) {
   int sim, cell;
   if (!xcd_map(ntiles, nsims, sim, cell)) return;
@@ -770,7 +772,26 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
           if (!(mask & (1 << a))) continue;
           const double dx = xi[a] - xs, dy = yi[a] - ys, dz = zi[a] - zs;
           const double rsq = dx * dx + dy * dy + dz * dz;
-          if (rsq < cutmax2) {
+          if (CLE && !ENG) {
+            if (rsq < cutl2) {
+              const double rinv = rsqrt_f64(rsq);
+              const double r2inv = rinv * rinv;
+              const double r6inv = r2inv * r2inv * r2inv;
+              const double2 lj12 = ((const double2 *)s_lj)[ti[a] + tj];
+              double fp = r6inv * (lj12.x * r6inv - lj12.y) * r2inv;
+              if (rsq < cutc2) {
+                const double rr = rsq * rinv;   // r
+                const double t = fma(rsq, g2u, -1.0);
+                double p = cp[NP - 1];
+#pragma unroll
+                for (int m = NP - 2; m >= 0; m--) p = fma(p, t, cp[m]);
+                fp = fma(qi[a] * qj * rinv * fma(-rr, p, 1.0), r2inv, fp);
+              }
+              const double tx = dx * fp, ty = dy * fp, tz = dz * fp;
+              fx[a] += tx; fy[a] += ty; fz[a] += tz;
+              gx -= tx; gy -= ty; gz -= tz;
+            }
+          } else if (rsq < cutmax2) {
             const double rinv = rsqrt_f64(rsq);
             const double r2inv = rinv * rinv;
             double fp = 0.0, flj = 0.0, fc = 0.0;
@@ -937,33 +958,33 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
   hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB, neigh_qcap(capj));
 }
 
-template <bool VIR, bool ENG, int NP>
+template <bool VIR, bool ENG, int NP, bool CLE = false>
 static void launch_pair_v(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj) {
   const size_t lds = mdk_pair_lds_bytes(capj);
   static size_t optin_tab[16] = {0};
   size_t &optin = lds_optin_slot(optin_tab);
-  if (lds > 48 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pair<VIR, ENG, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  hipLaunchKernelGGL((k_pair<VIR, ENG, NP>), grid_xcd(ntiles, ns), dim3(TT), lds, st, d, ntiles, ns, capj);
+  if (lds > 48 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pair<VIR, ENG, NP, CLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+  hipLaunchKernelGGL((k_pair<VIR, ENG, NP, CLE>), grid_xcd(ntiles, ns), dim3(TT), lds, st, d, ntiles, ns, capj);
 }
 
 template <int NP>
-static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj, int vir, int eng) {
+static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj, int vir, int eng, int cle) {
   if (eng) launch_pair_v<true, true, NP>(st, d, ns, ntiles, capj);
-  else if (vir) launch_pair_v<true, false, NP>(st, d, ns, ntiles, capj);
-  else launch_pair_v<false, false, NP>(st, d, ns, ntiles, capj);
+  else if (vir) { if (cle) launch_pair_v<true, false, NP, true>(st, d, ns, ntiles, capj); else launch_pair_v<true, false, NP>(st, d, ns, ntiles, capj); }
+  else { if (cle) launch_pair_v<false, false, NP, true>(st, d, ns, ntiles, capj); else launch_pair_v<false, false, NP>(st, d, ns, ntiles, capj); }
 }
 
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly) {
-  if (npoly <= 6) launch_pair<6>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 8) launch_pair<8>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 10) launch_pair<10>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 14) launch_pair<14>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 15) launch_pair<15>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 16) launch_pair<16>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 18) launch_pair<18>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 20) launch_pair<20>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 24) launch_pair<24>(st, d, ns, maxcells, capj, vir, eng);
-  else if (npoly <= 32) launch_pair<32>(st, d, ns, maxcells, capj, vir, eng);
-  else launch_pair<MD_MAXPOLY>(st, d, ns, maxcells, capj, vir, eng);
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly, int cle) {
+  if (npoly <= 6) launch_pair<6>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 8) launch_pair<8>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 10) launch_pair<10>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 14) launch_pair<14>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 15) launch_pair<15>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 16) launch_pair<16>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 18) launch_pair<18>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 20) launch_pair<20>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 24) launch_pair<24>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 32) launch_pair<32>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else launch_pair<MD_MAXPOLY>(st, d, ns, maxcells, capj, vir, eng, cle);
 }
