@@ -281,3 +281,25 @@ def test_the_ewald_sum_instead_of_pppm(small_pe, use_shake):
         exp, nts = o2.eval(strain, 2.0, 300.0, 1e-4, 20)
         assert nts == 10 and relerr(got, exp) < 1e-6
     e.close()
+
+
+def test_coulomb_cutoff_beyond_the_lj_cutoff(small_pe):
+    """pair_style lj/cut/coul/long with the coulomb cutoff the LARGER of the two: the pair kernel's general form (the reference's
+    12 / 9 takes the form specialised for cut_coul <= cut_lj).  Static parts and a full evaluation against the oracle."""
+    from scema_amd import capi
+    kw = dict(cut_lj=4.0, cut_coul=5.0, skin=1.0, kspace_accuracy=1e-5)
+    e = capi.Engine(capi.default_params(**kw))
+    e.register_replica("pe", 1, small_pe)
+    f, en, w, info = e.debug_compute("pe", 1, use_shake=True)
+    o = oracle_small(small_pe, **kw)
+    o.setup(True)
+    fo, eo, wo = o.compute()
+    assert info["npairs"] == o.npairs
+    assert relerr(f, fo) < 1e-10 and relerr(en, eo) < 1e-10 and relerr(w, wo) < 1e-9
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    strain = np.array([-0.3 * 1.2e-3 * lens[0], -0.3 * 1.2e-3 * lens[1], 1.2e-3 * lens[2], 5e-5 * lens[2], -3e-5 * lens[1], 2e-5 * lens[0]])
+    got = np.array(e.strain_batch([capi.make_sim(7, "pe", 1, strain, nss=20, most_recent=capi.QP_NONE)])[0].stress[:])
+    o2 = oracle_small(small_pe, **kw)
+    exp, nts = o2.eval(strain, 2.0, 300.0, 1e-4, 20)
+    assert nts == 10 and relerr(got, exp) < 1e-6
+    e.close()
