@@ -714,6 +714,8 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   double cp[NP];
 #pragma unroll
   for (int m = 0; m < NP; m++) cp[m] = S.coul_poly_g[m];   // g H(u), scaled on the host: x H = r (g H), one multiplication less per coulomb pair
+  double cp_top = cp[NP - 1];   // the leading coefficient in a vector register: the first Horner step then needs no move (one scalar operand per instruction)
+  asm volatile("" : "+v"(cp_top));
   __syncthreads();
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);   // (x,y) halves
   const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;              // (z,q) halves
@@ -767,6 +769,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
         const double xs = xj + s_shift[cs4], ys = yj + s_shift[cs4 + 1], zs = zj + s_shift[cs4 + 2];
         const int tj = (e >> E_TYPE_SHIFT) & 0xF;
         double gx = 0.0, gy = 0.0, gz = 0.0;   // reaction force on j
+        asm volatile("" : "+v"(gx), "+v"(gy), "+v"(gz));   // one set of zeros here instead of one per nested branch of the first atom
 #pragma unroll
         for (int a = 0; a < NI; a++) {
           if (!(mask & (1 << a))) continue;
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
               if (rsq < cutc2) {
                 const double rr = rsq * rinv;   // r
                 const double t = fma(rsq, g2u, -1.0);
-                double p = cp[NP - 1];
+                double p = cp_top;
 #pragma unroll
                 for (int m = NP - 2; m >= 0; m--) p = fma(p, t, cp[m]);
                 fp = fma(qi[a] * qj * rinv * fma(-rr, p, 1.0), r2inv, fp);
