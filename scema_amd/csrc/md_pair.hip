@@ -783,12 +783,12 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
               const double2 lj12 = ((const double2 *)s_lj)[ti[a] + tj];
               double fp = r6inv * (lj12.x * r6inv - lj12.y) * r2inv;
               if (rsq < cutc2) {
-                const double rr = rsq * rinv;   // r
+                // qq (1 - x H(u)) / r^3 with x H = r (g H) = r P and r / r = 1:  qq (1/r - P) / r^2
                 const double t = fma(rsq, g2u, -1.0);
                 double p = cp_top;
 #pragma unroll
                 for (int m = NP - 2; m >= 0; m--) p = fma(p, t, cp[m]);
-                fp = fma(qi[a] * qj * rinv * fma(-rr, p, 1.0), r2inv, fp);
+                fp = fma(qi[a] * qj * (rinv - p), r2inv, fp);
               }
               const double tx = dx * fp, ty = dy * fp, tz = dz * fp;
               fx[a] += tx; fy[a] += ty; fz[a] += tz;
