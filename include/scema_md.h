@@ -153,12 +153,20 @@ int scema_md_write_lammps_restart(const char *path, const scema_md_system *sys, 
  * State branch rule of stmd_problem.h:116-138,185-207: load from most_recent_qp_id if != qp_id, else qp_id, else the
  * registered init state; always store under qp_id.  hooke != 0: sigma = C:eps (stmd_problem.h:479-483).
  *   - no communicator attached (world may still be > 1): only this rank's share is evaluated, the others are left
- *     untouched (stress_updated = 0) and the caller gathers (scema_md_local_stress_* + scema_md_scatter_gathered);
+ *     untouched (stress_updated = 0) and the caller gathers (scema_md_copy_local_stress + scema_md_scatter_gathered:
+ *     the result buffer carries this rank's status word, so the caller enters its collective even after a failed call);
  *     a request whose source state lives on another rank is an error (SCEMA_MD_ERR_NOSTATE);
- *   - communicator attached (scema_md_comm_init_*): the call is collective -- states that have to change GPU travel
- *     first, then ONE all-gather returns every stress to every rank (replaces STMDSync::share_stresses,
- *     stmd_sync.h:620-726): on return every sims[i].stress is set on every rank.
- * A failed call leaves the state store as it found it. */
+ *   - communicator attached (scema_md_comm_init_*): the call is collective -- the ranks first agree (a 16-byte
+ *     handshake per rank: status of the local pre-checks + hash of the plan each rank computed; a mismatch is an error
+ *     on every rank instead of a hang), states that have to change GPU travel, then ONE all-gather returns every stress
+ *     to every rank (replaces STMDSync::share_stresses, stmd_sync.h:620-726): on return every sims[i].stress is set on
+ *     every rank.  The all-gather carries a status word per rank: a share that failed on one rank (list overflow after
+ *     regrowth, a replica that blew up, a missing state) makes the call fail on EVERY rank, none is left waiting.
+ * Requests are validated on every rank before anything is planned, so a bad request is refused by all ranks alike.
+ * A failed call leaves the state store and the owner directory as it found them, on every rank: states that had
+ * already been advanced are put back from their backups (the reference stops the whole run at this point, exit(1)).
+ * What the ranks must share for their plans to agree: the same replicas registered, the same request vectors, and every
+ * call that edits the state store (set_state, drop_state, load_state_file, equilibrate) made on every rank. */
 int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims, int32_t hooke,
                           int32_t rank, int32_t world);
 /* literal per-simulation drop-in */
@@ -184,21 +192,28 @@ void scema_md_comm_destroy(scema_md_engine *e);
 int32_t scema_md_comm_world(const scema_md_engine *e);   /* 1 = no communicator */
 int32_t scema_md_comm_rank(const scema_md_engine *e);
 int scema_md_comm_stats(const scema_md_engine *e, int64_t *allgathers, int64_t *migrations);
+int64_t scema_md_comm_handshakes(const scema_md_engine *e);   /* agreement handshakes so far (one per update when world > 1) */
 /* rank recorded as the owner of a stored state, -1 = none recorded (held wherever it was set) */
 int32_t scema_md_state_owner(const scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica);
 
 /* Plan of the last scema_md_strain_batch: owner[i] = rank that ran simulation i, pos[i] = its slot in that rank's
  * result buffer, cap = slots per rank. */
 int scema_md_last_plan(const scema_md_engine *e, int32_t n_sims, int32_t *owner, int32_t *pos, int32_t *cap);
-/* Device-side result buffer of the last scema_md_strain_batch: 6*cap doubles in HBM, simulation i of this rank at
- * offset 6*pos[i]; the operand of the all-gather when the caller runs the collective itself. */
+/* Device-side result buffer of the last scema_md_strain_batch: 6*max(cap,1) doubles in HBM, simulation i of this rank
+ * at offset 6*pos[i], followed by SCEMA_MD_RESULT_TRAILER words: the status of this rank's share (0, or the error code
+ * scema_md_strain_batch returned) and the hash of the plan this rank computed.  The operand of the all-gather when the
+ * caller runs the collective itself: scema_md_local_result_doubles() doubles per rank. */
+#define SCEMA_MD_RESULT_TRAILER 2
 void *scema_md_local_stress_device_ptr(scema_md_engine *e);
 int32_t scema_md_local_stress_count(const scema_md_engine *e);   /* = cap */
-/* copy that buffer into caller memory (a device pointer, e.g. the send buffer of the all-gather, or host) */
+int32_t scema_md_local_result_doubles(const scema_md_engine *e); /* = 6*max(cap,1) + SCEMA_MD_RESULT_TRAILER */
+/* copy that buffer (all scema_md_local_result_doubles() of it) into caller memory (a device pointer, e.g. the send
+ * buffer of the all-gather, or host) */
 int scema_md_copy_local_stress(scema_md_engine *e, void *dst, int32_t dst_on_device);
-/* after the caller's all-gather into gathered[world][6*cap] (host memory): fill sims[i].stress / stress_updated for
- * every i by the plan of the last scema_md_strain_batch (rank-0 bookkeeping of stmd_sync.h:698-725) */
-int scema_md_scatter_gathered(const scema_md_engine *e, const double *gathered, scema_mdsim *sims, int32_t n_sims);
+/* after the caller's all-gather into gathered[world][scema_md_local_result_doubles()] (host memory): check every
+ * rank's status word and plan hash (an error here is an error on every rank), then fill sims[i].stress /
+ * stress_updated for every i by the plan of the last scema_md_strain_batch (rank-0 bookkeeping of stmd_sync.h:698-725) */
+int scema_md_scatter_gathered(scema_md_engine *e, const double *gathered, scema_mdsim *sims, int32_t n_sims);
 
 /* The planner alone (scema_amd/csrc/host/sim_plan.h; pure host arithmetic, no GPU): owner/pos/cap as above, moves =
  * (simulation, from, to) triples of the states that would travel; cost NULL = equal cost; commit != 0 records the

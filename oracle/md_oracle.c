@@ -57,6 +57,7 @@ void omd_default_params(omd_params *p) {
   p->t_period = 100.0;
   p->t_chain = 3;
   p->kspace_pppm = 1;   /* kspace_style pppm, as in.set.lammps:36 asks; 0: the plain Ewald sum */
+  p->pppm_mesh[0] = p->pppm_mesh[1] = p->pppm_mesh[2] = 0;
 }
 
 #define MAXCHAIN 8
@@ -110,6 +111,10 @@ struct omd_sim {
   /* last virial / energies */
   double vir[OMD_NPART * 6], eng[OMD_NPART];
   double timing[4];
+  /* force field supplied from outside (omd_set_external_force): replaces every force routine of this file */
+  omd_force_fn ext_fn;
+  void *ext_ctx;
+  int ext_calls;   /* force evaluations since the last omd_setup: 0 = the set-up evaluation of a run */
 };
 
 /* ------------------------------------------------------------------ box helpers */
@@ -463,9 +468,8 @@ void omd_last_timing(const omd_sim *s, double t[4]) {
  * UNPINNED]: order-5 charge assignment on a grid in lamda coordinates (so triclinic boxes need nothing special), optimal
  * influence function for ik differentiation with the alias sums taken directly (|m| <= 2 per dimension, numerator and
  * denominator alike; pppm.cpp has the denominator in closed form), energy and virial in reciprocal space, three inverse
- * transforms for the field, forces by the same weights.  Grid: smallest n per dimension whose estimated ik error
- * (estimate_ik_error with the acons table) is below the accuracy, raised to a product of 2, 3, 5; then g_ewald by Newton's
- * method on (real-space error - k-space error) = 0 (adjust_gewald).  Transforms are plain O(n^2) sums per line. */
+ * transforms for the field, forces by the same weights.  Grid and g_ewald: set_grid_global / adjust_gewald with the loop
+ * structure of pppm.cpp (see pppm_setup below).  Transforms are plain O(n^2) sums per line. */
 #define PPPM_ORDER 5
 static const double ACONS5[5] = {1.0 / 23232.0, 7601.0 / 13628160.0, 143.0 / 69120.0, 517231.0 / 106536960.0, 106640677.0 / 11737571328.0};
 
@@ -480,31 +484,71 @@ static int pppm_factorable(int n) {
   while (n % 5 == 0) n /= 5;
   return n == 1;
 }
-static double pppm_f(const omd_sim *s, const boxq *b, double g, double q2) {
+/* grid spacings h_x, h_y, h_z as set_grid_global leaves them: prd / n in an orthogonal box; in a triclinic one the
+ * reciprocal of x2lamdaT(n) (the tilts enter h_y and h_z).  b->h = xprd, yprd, zprd, yz, xz, xy. */
+static void pppm_spacings(const boxq *b, int triclinic, const int pg[3], double hh[3]) {
+  if (!triclinic) {
+    for (int d = 0; d < 3; d++) hh[d] = b->h[d] / pg[d];
+    return;
+  }
+  const double v0 = pg[0], v1 = pg[1], v2 = pg[2];
+  hh[0] = 1.0 / (b->hinv[0] * v0);
+  hh[1] = 1.0 / (b->hinv[5] * v0 + b->hinv[1] * v1);
+  hh[2] = 1.0 / (b->hinv[4] * v0 + b->hinv[3] * v1 + b->hinv[2] * v2);
+}
+/* newton_raphson_f: real-space error estimate minus compute_df_kspace (ik: RMS of the three per-dimension estimates) */
+static double pppm_f(const omd_sim *s, const boxq *b, double g, double q2, const double hh[3]) {
   const double rc = s->p.cut_coul, N = (double)s->n;
   const double df_r = 2.0 * q2 * exp(-g * g * rc * rc) / sqrt(N * rc * b->h[0] * b->h[1] * b->h[2]);
-  double sq = 0.0;
-  for (int d = 0; d < 3; d++) {
-    const double e = pppm_ik_error(b->h[d] / s->pg[d], b->h[d], g, q2, N);
-    sq += e * e;
-  }
-  return df_r - sqrt(sq) / sqrt(3.0);
+  const double lprx = pppm_ik_error(hh[0], b->h[0], g, q2, N), lpry = pppm_ik_error(hh[1], b->h[1], g, q2, N),
+               lprz = pppm_ik_error(hh[2], b->h[2], g, q2, N);
+  return df_r - sqrt(lprx * lprx + lpry * lpry + lprz * lprz) / sqrt(3.0);
 }
+/* PPPM::set_grid_global + adjust_gewald of pppm.cpp (17Nov16, ik differentiation, no stagger) with their loop structure:
+ *  - per dimension start at n = int(prd * g) + 1 with h = 1/g; `while (err > accuracy) { err = E(h); n++; h = prd/n; }`
+ *    -- the increment follows the evaluation, so the loop leaves n ONE PAST the first grid whose estimate is admissible
+ *    (or at the start value if E(1/g) already is);
+ *  - a triclinic box (the reference's replicas always are one: in.init.lammps:27 `change_box all triclinic`) rescales:
+ *    n = int(lamda2xT(n / prd)) + 1 -- with zero tilts that is n or n + 1 depending on how (n / prd) * prd rounds;
+ *  - raise each n to a product of 2, 3, 5;
+ *  - g_ewald: Newton steps with a forward-difference derivative of step 1e-6, stopping at the first iterate with
+ *    |f| < SMALL = 1e-5 (not at convergence). */
 static void pppm_setup(omd_sim *s, const boxq *b, double accuracy, double q2) {
   double g = s->g_ewald;
-  for (int d = 0; d < 3; d++) {
-    int n = 2;
-    while (pppm_ik_error(b->h[d] / n, b->h[d], g, q2, (double)s->n) > accuracy && n < 4096) n++;
-    while (!pppm_factorable(n)) n++;
-    s->pg[d] = n;
+  const double N = (double)s->n;
+  const int triclinic = 1;   /* the engine's box model (9 numbers with tilts) is LAMMPS' triclinic box, whatever the tilts are */
+  int n[3];
+  const int gridflag = s->p.pppm_mesh[0] > 0 && s->p.pppm_mesh[1] > 0 && s->p.pppm_mesh[2] > 0;
+  for (int d = 0; d < 3 && gridflag; d++) n[d] = s->p.pppm_mesh[d];
+  for (int d = 0; d < 3 && !gridflag; d++) {
+    const double prd = b->h[d];
+    double h = 1.0 / g;
+    n[d] = (int)(prd / h) + 1;
+    double err = pppm_ik_error(h, prd, g, q2, N);
+    while (err > accuracy) {
+      err = pppm_ik_error(h, prd, g, q2, N);
+      n[d]++;
+      h = prd / n[d];
+    }
   }
-  /* adjust_gewald: Newton-Raphson with a numerical derivative */
+  if (triclinic && !gridflag) {
+    const double t0 = n[0] / b->h[0], t1 = n[1] / b->h[1], t2 = n[2] / b->h[2];
+    const double u0 = b->h[0] * t0, u1 = b->h[5] * t0 + b->h[1] * t1, u2 = b->h[4] * t0 + b->h[3] * t1 + b->h[2] * t2;
+    n[0] = (int)u0 + 1; n[1] = (int)u1 + 1; n[2] = (int)u2 + 1;
+  }
+  for (int d = 0; d < 3; d++) {
+    while (!pppm_factorable(n[d])) n[d]++;
+    s->pg[d] = n[d];
+  }
+  double hh[3];
+  pppm_spacings(b, triclinic, s->pg, hh);
+  /* adjust_gewald */
   for (int it = 0; it < 10000; it++) {
-    const double hh = 1.0e-5;
-    const double f0 = pppm_f(s, b, g, q2), f1 = pppm_f(s, b, g + hh, q2);
-    const double dg = f0 / ((f1 - f0) / hh);
-    g -= dg;
-    if (fabs(f0) < 1.0e-5 * 1.0e-5 || fabs(dg) < 1.0e-5) break;   /* SMALL = 1e-5 on the step */
+    const double step = 0.000001;
+    const double f1 = pppm_f(s, b, g, q2, hh), f2 = pppm_f(s, b, g + step, q2, hh);
+    const double dx = f1 / ((f2 - f1) / step);
+    g -= dx;
+    if (fabs(pppm_f(s, b, g, q2, hh)) < 0.00001) break;
   }
   s->g_ewald = g;
 }
@@ -1301,6 +1345,11 @@ static void force_compute(omd_sim *s) {
   memset(s->f, 0, 3 * (size_t)s->n * sizeof(double));
   memset(s->eng, 0, sizeof(s->eng));
   memset(s->vir, 0, sizeof(s->vir));
+  if (s->ext_fn) {
+    const double box[9] = {s->lo[0], s->lo[1], s->lo[2], s->hi[0], s->hi[1], s->hi[2], s->xy, s->xz, s->yz};
+    s->ext_fn(s->ext_ctx, s->ext_calls++, s->n, box, s->x, s->f, &s->vir[OMD_LJ * 6], &s->eng[OMD_LJ]);
+    return;
+  }
   pair_compute(s, &b, s->f, s->eng, s->vir);
   bond_compute(s, &b, s->f, s->eng, s->vir);
   angle_compute(s, &b, s->f, s->eng, s->vir);
@@ -1311,9 +1360,17 @@ static void force_compute(omd_sim *s) {
 
 void omd_freeze_kspace(omd_sim *s, int frozen) { s->kspace_frozen = frozen; }
 
+void omd_set_external_force(omd_sim *s, omd_force_fn fn, void *ctx) {
+  s->ext_fn = fn;
+  s->ext_ctx = ctx;
+  s->ext_calls = 0;
+}
+
 void omd_setup(omd_sim *s, int use_shake) {
   s->use_shake = use_shake && s->nclus > 0;
   s->tdof = 3.0 * s->n - 3.0 - (s->use_shake ? s->ncons : 0);
+  s->ext_calls = 0;
+  if (s->ext_fn) return;   /* no lists, no k-space of this file */
   if (!s->kspace_frozen) ewald_setup(s);
   neigh_build(s);
 }
@@ -1614,8 +1671,8 @@ int omd_run(omd_sim *s, int nsteps, double dt, double temperature, int nvt, int 
       }
       flip_pending = 0;
       s->nflips++;
-      neigh_build(s);
-    } else if (s->ago >= s->p.neigh_delay && neigh_check(s))
+      if (!s->ext_fn) neigh_build(s);
+    } else if (!s->ext_fn && s->ago >= s->p.neigh_delay && neigh_check(s))
       neigh_build(s);
     /* forces + SHAKE */
     force_compute(s);

@@ -45,11 +45,20 @@ typedef struct {
   double shake_mass;    /* <= 0: no SHAKE */
   double t_period;      /* in.strain.lammps:80 fix nvt temp T T 100.0 */
   int    t_chain;       /* Nose-Hoover chain length (fix nvt default 3) */
-  int    kspace_pppm;   /* 0: the plain Ewald sum (default, DESIGN.md deviation 1); 1: PPPM as `kspace_style pppm` asks for
+  int    kspace_pppm;   /* 1 (default): PPPM as `kspace_style pppm` asks for; 0: the plain Ewald sum it approximates
                          * (order 5, ik differentiation; grid and g_ewald by the rules of pppm.cpp as restated in md_oracle.c) */
+  int    pppm_mesh[3];  /* all > 0: `kspace_modify mesh nx ny nz` (the grid is given, the search and the triclinic rescaling of
+                         * set_grid_global are skipped; still raised to products of 2, 3, 5); default 0 0 0 = the rule decides */
 } omd_params;
 
 void omd_default_params(omd_params *p);
+
+/* A force field from outside this file (the ReaxFF oracle, oracle/reax_md.py): fn fills f[3n] (kcal/mol/A), the virial
+ * vir[6] = sum r (x) f (xx,yy,zz,xy,xz,yz; kcal/mol) and the potential energy for the positions x in the box given; `call` is 0
+ * for the set-up evaluation of a run (omd_setup) and counts the evaluations after it.  With it set, omd_run / omd_eval are the
+ * integrator, thermostat, fix deform (with flips) and pressure average of this file around those forces: no lists, no k-space,
+ * no bonded terms of this file; SHAKE only if the system was created with constraints. */
+typedef void (*omd_force_fn)(void *ctx, int call, int natoms, const double box[9], const double *x, double *f, double vir[6], double *energy);
 
 typedef struct omd_sim omd_sim;
 
@@ -91,6 +100,7 @@ int omd_tilt_flip(const double tilt[3], double xprd, double yprd, double flipped
  * g_ewald and the k-vector set from the current box, neighbour list rebuild.
  * use_shake selects whether SHAKE'd bonds are removed from the bond list. */
 void omd_setup(omd_sim *s, int use_shake);
+void omd_set_external_force(omd_sim *s, omd_force_fn fn, void *ctx);
 /* test hook: keep g_ewald and the k-vector set of the last setup (for d/d(strain) tests) */
 void omd_freeze_kspace(omd_sim *s, int frozen);
 

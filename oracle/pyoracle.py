@@ -22,7 +22,7 @@ class OmdParams(C.Structure):
     _fields_ = [("cut_lj", C.c_double), ("cut_coul", C.c_double), ("skin", C.c_double),
                 ("neigh_delay", C.c_int), ("kspace_accuracy", C.c_double), ("shake_tol", C.c_double),
                 ("shake_maxiter", C.c_int), ("shake_mass", C.c_double), ("t_period", C.c_double),
-                ("t_chain", C.c_int), ("kspace_pppm", C.c_int)]
+                ("t_chain", C.c_int), ("kspace_pppm", C.c_int), ("pppm_mesh", C.c_int * 3)]
 
 
 def build(force: bool = False) -> str:

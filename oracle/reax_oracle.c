@@ -741,3 +741,48 @@ void rxo_forces_fd(const rxo_ff *ff, int n, const int *type, const double *x, co
   }
   free(xx);
 }
+
+/* ------------------------------------------------------------------ tables for a second implementation
+ * oracle/reax_torch.py restates the ENERGY of this file as one differentiable expression (reverse-mode differentiation then
+ * gives forces and virial at the cost of an energy evaluation instead of 6N of them); it reads the parameters through this
+ * export so that both work from the same reader.  Layouts (all double): gp[64]; sbp[nt][28] in the order of sbp_t with name
+ * skipped and p_hbond as a double; tbp[nt][nt][25] in the order of tbp_t; thbp[nt][nt][nt][1 + 4*7] = cnt, then prm[4];
+ * fbp[nt]^4[7] = cnt, specific, V1, V2, V3, p_tor1, p_cot1; hbp[nt]^3[4]; misc[11] = bo_cut, swa, swb, tap[0..7]. */
+int rxo_export(const rxo_ff *ff, double *gp, double *sbp, double *tbp, double *thbp, double *fbp, double *hbp, double *misc) {
+  const int nt = ff->nt;
+  for (int k = 0; k < 64; k++) gp[k] = ff->gp[k];
+  for (int i = 0; i < nt; i++) {
+    const sbp_t *s = &ff->sbp[i];
+    const double v[28] = {s->r_s, s->valency, s->mass, s->r_vdw, s->epsilon, s->gamma, s->r_pi, s->valency_e, s->nlp_opt, s->alpha, s->gamma_w,
+                          s->valency_boc, s->p_ovun5, s->chi, s->eta, (double)s->p_hbond, s->r_pi_pi, s->p_lp2, s->b_o_131, s->b_o_132, s->b_o_133,
+                          s->p_ovun2, s->p_val3, s->valency_val, s->p_val5, s->rcore2, s->ecore2, s->acore2};
+    memcpy(sbp + 28 * i, v, sizeof v);
+    for (int j = 0; j < nt; j++) {
+      const tbp_t *t = &ff->tbp[i][j];
+      const double u[25] = {t->De_s, t->De_p, t->De_pp, t->p_be1, t->p_bo5, t->v13cor, t->p_bo6, t->p_ovun1, t->p_be2, t->p_bo3, t->p_bo4, t->p_bo1, t->p_bo2,
+                            t->ovc, t->r_s, t->r_p, t->r_pp, t->p_boc3, t->p_boc4, t->p_boc5, t->D, t->alpha, t->r_vdW, t->gamma_w, t->gamma};
+      memcpy(tbp + 25 * (i * nt + j), u, sizeof u);
+      for (int k = 0; k < nt; k++) {
+        const thbp_t *th = &ff->thbp[i][j][k];
+        double *o = thbp + 29 * ((i * nt + j) * nt + k);
+        o[0] = th->cnt;
+        for (int c = 0; c < RX_MAXANG; c++) {
+          const thb_prm *p = &th->prm[c];
+          const double w[7] = {p->theta_00, p->p_val1, p->p_val2, p->p_coa1, p->p_val7, p->p_pen1, p->p_val4};
+          memcpy(o + 1 + 7 * c, w, sizeof w);
+        }
+        const hbp_t *h = &ff->hbp[i][j][k];
+        double *oh = hbp + 4 * ((i * nt + j) * nt + k);
+        oh[0] = h->r0_hb; oh[1] = h->p_hb1; oh[2] = h->p_hb2; oh[3] = h->p_hb3;
+        for (int l = 0; l < nt; l++) {
+          const fbp_t *f = &ff->fbp[i][j][k][l];
+          double *of = fbp + 7 * (((i * nt + j) * nt + k) * nt + l);
+          of[0] = f->cnt; of[1] = f->specific; of[2] = f->V1; of[3] = f->V2; of[4] = f->V3; of[5] = f->p_tor1; of[6] = f->p_cot1;
+        }
+      }
+    }
+  }
+  misc[0] = ff->bo_cut; misc[1] = ff->swa; misc[2] = ff->swb;
+  for (int k = 0; k < 8; k++) misc[3 + k] = ff->tap[k];
+  return nt;
+}

@@ -3,8 +3,11 @@
  * (reference lammps_scripts/lammps_scripts_reax/in.strain.lammps:10-12: `pair_style reax/c NULL safezone 50 mincap 100000`,
  * `pair_coeff * * ffield.reax.2 H C N O`, `fix qeq/reax 1 0.0 10.0 1e-6 reax/c`; SURVEY.md 8(f) row f-4, BASELINE config 5).
  *
- * TEST INFRASTRUCTURE ONLY, and the FIRST STEP of row f-4 only: there is no HIP path for this force field yet
- * (scema_md_strain_batch refuses force_field "reax").  Nothing in the product path may link, import or execute this code.
+ * TEST INFRASTRUCTURE ONLY: the checker of the HIP path for this force field (scema_amd/csrc/md_reax.hip, reax/rx_core.h;
+ * force_field "reax" of scema_md_strain_batch).  Nothing in the product path may link, import or execute this code.
+ * Dynamics (a whole strained evaluation with its expected stress): oracle/reax_md.py = the integrator, thermostat, fix deform
+ * and pressure average of oracle/md_oracle.c around the forces of oracle/reax_torch.py, which differentiates the energy
+ * expression of this file in reverse mode.
  *
  * PARITY UNPINNED: the arithmetic lives in LAMMPS 17Nov16, package USER-REAXC, which is neither vendored by the reference
  * nor installed here.  This file restates the published functional forms as that package implements them (van Duin et
@@ -52,6 +55,9 @@ int rxo_qeq(const rxo_ff *ff, int n, const int *type, const double *x, const dou
 /* central differences of the energy at fixed charges: f[3n] = -dE/dx, virial[6] = -dE/d(strain) (xx,yy,zz,xy,xz,yz; periodic only) */
 void rxo_forces_fd(const rxo_ff *ff, int n, const int *type, const double *x, const double *box, const double *q, double h,
                    double *f, double *virial);
+
+/* parameter tables as read (layouts in reax_oracle.c), for oracle/reax_torch.py; returns the number of types */
+int rxo_export(const rxo_ff *ff, double *gp, double *sbp, double *tbp, double *thbp, double *fbp, double *hbp, double *misc);
 
 #ifdef __cplusplus
 }

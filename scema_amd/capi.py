@@ -26,11 +26,11 @@ SYMBOLS = [
     "scema_md_probe_lammps_restart", "scema_md_read_lammps_restart_atoms", "scema_md_load_lammps_restart",
     "scema_md_convert_lammps_restart", "scema_md_write_lammps_restart",
     "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
-    "scema_md_local_stress_count", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
+    "scema_md_local_stress_count", "scema_md_local_result_doubles", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
     "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file", "scema_md_save_state_lammps",
     "scema_md_init_material", "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile",
     "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",
-    "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_state_owner", "scema_md_last_plan",
+    "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_comm_handshakes", "scema_md_state_owner", "scema_md_last_plan",
     "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update",
     "scema_md_save_state_dump", "scema_md_replica_natoms", "scema_md_save_replica_file", "scema_md_equilibrate", "scema_md_debug_minimize", "scema_md_debug_run_nh",
     "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_debug_compute", "scema_md_reax_stats",
@@ -278,6 +278,10 @@ class Engine:
     def local_stress_ptr(self):
         return lib().scema_md_local_stress_device_ptr(self.h), lib().scema_md_local_stress_count(self.h)
 
+    def local_result_doubles(self) -> int:
+        """doubles in the result buffer of the last strain_batch: 6*max(cap,1) stresses + status word + plan hash"""
+        return int(lib().scema_md_local_result_doubles(self.h))
+
     def copy_local_stress(self, dst_ptr: int, on_device: bool):
         self._chk(lib().scema_md_copy_local_stress(self.h, C.c_void_p(dst_ptr), C.c_int32(1 if on_device else 0)))
 
@@ -338,7 +342,9 @@ class Engine:
     def comm_stats(self) -> dict:
         a = C.c_int64(0); m = C.c_int64(0)
         self._chk(lib().scema_md_comm_stats(self.h, C.byref(a), C.byref(m)))
-        return dict(allgathers=a.value, migrations=m.value)
+        lib().scema_md_comm_handshakes.restype = C.c_int64
+        lib().scema_md_comm_handshakes.argtypes = [_P]
+        return dict(allgathers=a.value, migrations=m.value, handshakes=int(lib().scema_md_comm_handshakes(self.h)))
 
     def state_owner(self, qp, matid, replica) -> int:
         return int(lib().scema_md_state_owner(self.h, C.c_int32(qp), matid.encode(), C.c_int32(replica)))

@@ -33,6 +33,7 @@ struct PlanMove {
 struct SimPlan {
   int world = 1;
   std::vector<int> owner;  // per simulation: the rank that runs it
+  std::vector<int> home;   // per simulation: the rank recorded as holding its source state, -1 = none (the directory's view)
   std::vector<int> pos;    // per simulation: slot in its owner's result buffer (6 doubles each)
   std::vector<int> count;  // per rank: simulations it runs
   int cap = 0;             // max count = slots per rank in the one all-gather
@@ -65,7 +66,8 @@ class OwnerDirectory {
     P.owner.assign(n, 0);
     P.pos.assign(n, 0);
     P.count.assign(world, 0);
-    std::vector<int> home(n, -1);
+    std::vector<int> &home = P.home;
+    home.assign(n, -1);
     if (world > 1) {
       std::vector<double> load(world, 0.0);
       auto least = [&](int start) {   // least loaded rank, ties resolved round robin from `start`

@@ -58,7 +58,22 @@ class STMDProblem {
     std::vector<int> owner(n);
     for (int i = 0; i < n; i++) owner[i] = i % world;
     std::vector<int> mine;
-    if (hooke) {
+    if (hooke && engine_ && scema_md_comm_world(engine_) > 1) {
+      // the reference's fake backend with a communicator attached to the engine: dealt i % world and gathered by the
+      // engine's own collective, like an MD update
+      std::vector<scema_mdsim> c(n);
+      for (int i = 0; i < n; i++) c[i] = sims[i]->to_c();
+      const int rc = scema_md_strain_batch(engine_, c.data(), n, 1, rank, world);
+      if (rc != SCEMA_MD_OK) {
+        err_ = scema_md_last_error(engine_);
+        return rc;
+      }
+      for (int i = 0; i < n; i++) {
+        if (owner[i] == rank) mine.push_back(i);
+        for (int k = 0; k < 6; k++) sims[i]->stress.raw[k] = c[i].stress[k];
+        sims[i]->stress_updated = c[i].stress_updated != 0;
+      }
+    } else if (hooke) {
       // "approximate md with hookes law": the reference's own fake backend (stmd_problem.h:479-483)
       for (int i = 0; i < n; i++)
         if (owner[i] == rank) mine.push_back(i);

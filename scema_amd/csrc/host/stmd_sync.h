@@ -91,9 +91,11 @@ class STMDSync {
       std::cout << std::endl;
     }
     if (n_md > 0) {
+      // a rank whose share failed still enters the collective of share_stresses: its status word ends the update on
+      // every rank (the reference's exit(1) would take the whole MPI job down; a blocked collective would not)
+      const int rc_exec = execute_inside_md_simulations(md_simulations);
       int rc;
-      if ((rc = execute_inside_md_simulations(md_simulations))) return rc;
-      if ((rc = share_stresses(md_simulations))) return rc;
+      if ((rc = share_stresses(md_simulations, rc_exec))) return rc;
       // every rank holds every stress after the all-gather: the serial branch of the reference
       // (stmd_sync.h:1119-1123) runs everywhere, so no broadcast of the update_list is needed afterwards
       if ((rc = store_md_simulations(md_simulations, scale_bridging_data))) return rc;
@@ -273,33 +275,46 @@ class STMDSync {
   }
 
   // reference stmd_sync.h:620-726: 6 doubles per simulation to everybody, ONE collective.  With a communicator attached
-  // to the engine (scema_md_comm_init_rccl / _host) that all-gather already ran inside scema_md_strain_batch and every
-  // stress is here; otherwise it runs through the host program's callback, laid out by the engine's plan (MD) or by
-  // the round robin i % world (stateless Hooke mode).
-  int share_stresses(std::vector<MDSim> &md_simulations) {
+  // to the engine (scema_md_comm_init_rccl / _host) that all-gather already ran inside scema_md_strain_batch (MD and Hooke
+  // mode alike) and every stress -- or every rank's failure -- is here; otherwise it runs through the host program's
+  // callback, laid out by the engine's plan (MD) or by the round robin i % world (stateless Hooke mode).  Whether the
+  // callback runs is decided by what every rank knows (world, mode, communicator), never by this rank's own results;
+  // each rank's record ends with its status word and plan hash (SCEMA_MD_RESULT_TRAILER).
+  int share_stresses(std::vector<MDSim> &md_simulations, int rc_exec) {
     const int n = (int)md_simulations.size();
-    bool complete = true;
-    for (int i = 0; i < n; i++) complete = complete && md_simulations[i].stress_updated;
-    if (world_ > 1 && !complete) {
+    const bool engine_gathered = engine_ && scema_md_comm_world(engine_) > 1;
+    if (world_ > 1 && !engine_gathered) {
       if (!allgather_) return fail(SCEMA_MD_ERR_ARG, "world > 1 needs an all-gather: attach a communicator to the engine or pass a callback");
       const bool md = engine_ && !approx_md_with_hookes_law;
       std::vector<int> owner(n), pos(n);
       int per_rank = (n + world_ - 1) / world_;
       for (int i = 0; i < n; i++) { owner[i] = i % world_; pos[i] = i / world_; }
+      // no plan recorded: this rank's call failed before planning (a refused request: every rank refuses it alike)
       if (md && scema_md_last_plan(engine_, n, owner.data(), pos.data(), &per_rank) != SCEMA_MD_OK)
-        return fail(SCEMA_MD_ERR_ARG, "no plan recorded for this request vector");
-      std::vector<double> local(6 * (size_t)std::max(per_rank, 1), 0.0), gathered(6 * (size_t)std::max(per_rank, 1) * world_, 0.0);
+        return rc_exec ? rc_exec : fail(SCEMA_MD_ERR_ARG, "no plan recorded for this request vector");
+      const size_t cnt = 6 * (size_t)std::max(per_rank, 1) + SCEMA_MD_RESULT_TRAILER;
+      std::vector<double> local(cnt, 0.0), gathered(cnt * world_, 0.0);
       for (int i = 0; i < n; i++)
-        if (owner[i] == rank_)
+        if (owner[i] == rank_ && md_simulations[i].stress_updated)
           for (int k = 0; k < 6; k++) local[6 * (size_t)pos[i] + k] = md_simulations[i].stress.raw[k];
-      int rc = allgather_(ag_ctx_, md ? engine_ : nullptr, local.data(), 6 * per_rank, gathered.data());
+      local[cnt - 2] = (double)rc_exec;   // the MD path sends the engine's device buffer, which carries the same word
+      int rc = allgather_(ag_ctx_, md ? engine_ : nullptr, local.data(), (int)cnt, gathered.data());
       if (rc) return fail(SCEMA_MD_ERR_DEVICE, "all-gather of the stresses failed");
+      if (rc_exec) return rc_exec;   // err_ is set
+      for (int r = 0; r < world_; r++)
+        if (gathered[r * cnt + cnt - 2] != 0.0)
+          return fail((int)gathered[r * cnt + cnt - 2], "rank " + std::to_string(r) + " failed during the update (code " +
+                      std::to_string((int)gathered[r * cnt + cnt - 2]) + "): the update is abandoned on every rank");
+      for (int r = 1; r < world_; r++)
+        if (gathered[r * cnt + cnt - 1] != gathered[cnt - 1])
+          return fail(SCEMA_MD_ERR_ARG, "ranks 0 and " + std::to_string(r) + " computed different plans for this update");
       for (int i = 0; i < n; i++) {
-        const double *src = gathered.data() + ((size_t)owner[i] * per_rank + (size_t)pos[i]) * 6;
+        const double *src = gathered.data() + ((size_t)owner[i] * cnt + (size_t)pos[i] * 6);
         for (int k = 0; k < 6; k++) md_simulations[i].stress.raw[k] = src[k];
         md_simulations[i].stress_updated = true;
       }
     }
+    if (rc_exec) return rc_exec;   // single rank, or the engine's own collective already told every rank
     // reference stmd_sync.h:712-725
     for (int i = 0; i < n; i++)
       if (!md_simulations[i].stress_updated)

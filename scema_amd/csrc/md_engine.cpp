@@ -168,6 +168,7 @@ struct ActiveSim {
   double dt = 0, temperature = 0;
   int nts = 0, nss = 0;
   double pavg[6];
+  double box0[9], skin0 = 0.0;   // box and list skin of the state before the update (a failed update puts them back)
 };
 
 // One process per GPU: the communicator of the engine.  RCCL (xGMI) for the GPU box, or transport callbacks of the host
@@ -180,9 +181,9 @@ struct Comm {
   scema_md_host_send_fn send = nullptr;
   scema_md_host_recv_fn recv = nullptr;
   void *ctx = nullptr;
-  DevBuf d_gather, d_box;
+  DevBuf d_gather, d_box, d_word;
   std::vector<double> h_gather;
-  long long migrations = 0, allgathers = 0;
+  long long migrations = 0, allgathers = 0, handshakes = 0;
 };
 
 struct Profile {
@@ -214,6 +215,9 @@ struct scema_md_engine {
   std::vector<std::unique_ptr<Slot>> slots;
   DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair, d_pppm, d_copytab;
   std::vector<MdkCopy> h_copytab;
+  // x and v of every state an update advances, as they were before it: the retry after a list overflow restarts from
+  // them, and a failed update (on this rank or on another) puts them back
+  std::vector<std::unique_ptr<DevBuf>> bak_x, bak_v;
   std::map<std::array<int, 6>, hipfftHandle> pppm_plans;   // (nx, ny, nz, batch, stream, distance between grids) -> batched 3-d Z2Z plan
   std::vector<int> h_kpack;   // host copy, alive until the stream has consumed the upload
   int local_stress_count = 0;
@@ -830,37 +834,62 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
   return err;
 }
 
-// ---- PPPM set-up on the host (kspace_style 1): grid and g_ewald by the rules of LAMMPS' pppm.cpp as remembered [LAMMPS-ext],
-// the same arithmetic as oracle/md_oracle.c pppm_setup: per dimension the smallest n whose estimated ik error is below the
-// accuracy, raised to a product of 2, 3, 5; then g_ewald by Newton's method on (real-space error - k-space error) = 0 ----
+// ---- PPPM set-up on the host (kspace_style 1): PPPM::set_grid_global and adjust_gewald of LAMMPS' pppm.cpp (17Nov16; ik
+// differentiation, not staggered) with their loop structure [LAMMPS-ext: restated from the published source as remembered,
+// LAMMPS is not in the reference tree]:
+//   * per dimension the search starts at n = int(prd * g) + 1 with h = 1 / g and runs `while (err > accuracy) { err = E(h);
+//     n++; h = prd / n; }` -- the increment follows the evaluation, so it stops ONE PAST the first admissible grid;
+//   * the box is LAMMPS' triclinic box (in.init.lammps:27 `change_box all triclinic`; the engine's box always carries its
+//     three tilts), for which the grid is rescaled: n = int(lamda2xT(n / prd)) + 1;
+//   * each n is raised to a product of 2, 3, 5; the spacings are the reciprocals of x2lamdaT(n);
+//   * g_ewald by Newton steps on (real-space error - k-space error) with a forward difference of 1e-6, stopped at the first
+//     iterate with |f| < 1e-5.
+// The oracle restates the same routine on its own (oracle/md_oracle.c pppm_setup). ----
 static double pppm_ik_error(double h, double prd, double g, double q2, double natoms) {
   static const double ACONS5[5] = {1.0 / 23232.0, 7601.0 / 13628160.0, 143.0 / 69120.0, 517231.0 / 106536960.0, 106640677.0 / 11737571328.0};
   const double hg = h * g, hg2 = hg * hg;
-  double sum = 0.0, pw = 1.0;   // powers by multiplication: this runs a few hundred times per simulation and run
+  double sum = 0.0, pw = 1.0;   // powers by multiplication: this runs a few dozen times per simulation and run
   for (int m = 0; m < 5; m++) { sum += ACONS5[m] * pw; pw *= hg2; }
   return q2 * (hg2 * hg2 * hg) * std::sqrt(g * prd * std::sqrt(2.0 * MD_PI) * sum / natoms) / (prd * prd);
 }
 static void pppm_setup_host(const scema_md_params &p, const Topo &t, const double *box, double &g, int pg[3]) {
   HostBox b;
-  box_derive(box, b);
+  box_derive(box, b);   // b.h = xprd, yprd, zprd, yz, xz, xy
   const double accuracy = p.kspace_accuracy * MD_QQRD2E, q2 = t.qsqsum * MD_QQRD2E, rc = p.cut_coul, N = (double)t.natoms;
   auto factorable = [](int n) { while (n % 2 == 0) n /= 2; while (n % 3 == 0) n /= 3; while (n % 5 == 0) n /= 5; return n == 1; };
+  int n[3];
   for (int d = 0; d < 3; d++) {
-    int n = 2;
-    while (pppm_ik_error(b.h[d] / n, b.h[d], g, q2, N) > accuracy && n < 4096) n++;
-    while (!factorable(n)) n++;
-    pg[d] = n;
+    const double prd = b.h[d];
+    double h = 1.0 / g;
+    n[d] = (int)(prd / h) + 1;
+    double err = pppm_ik_error(h, prd, g, q2, N);
+    while (err > accuracy && n[d] < 4096) {
+      err = pppm_ik_error(h, prd, g, q2, N);
+      n[d]++;
+      h = prd / n[d];
+    }
   }
+  {
+    const double t0 = n[0] / b.h[0], t1 = n[1] / b.h[1], t2 = n[2] / b.h[2];
+    const double u0 = b.h[0] * t0, u1 = b.h[5] * t0 + b.h[1] * t1, u2 = b.h[4] * t0 + b.h[3] * t1 + b.h[2] * t2;
+    n[0] = (int)u0 + 1; n[1] = (int)u1 + 1; n[2] = (int)u2 + 1;
+  }
+  for (int d = 0; d < 3; d++) {
+    n[d] = std::max(n[d], 2);
+    while (!factorable(n[d])) n[d]++;
+    pg[d] = n[d];
+  }
+  const double hs[3] = {1.0 / (b.hinv[0] * pg[0]), 1.0 / (b.hinv[5] * pg[0] + b.hinv[1] * pg[1]), 1.0 / (b.hinv[4] * pg[0] + b.hinv[3] * pg[1] + b.hinv[2] * pg[2])};
   auto f = [&](double gg) {
     const double df_r = 2.0 * q2 * std::exp(-gg * gg * rc * rc) / std::sqrt(N * rc * b.h[0] * b.h[1] * b.h[2]);
     double sq = 0.0;
-    for (int d = 0; d < 3; d++) { const double e = pppm_ik_error(b.h[d] / pg[d], b.h[d], gg, q2, N); sq += e * e; }
+    for (int d = 0; d < 3; d++) { const double e = pppm_ik_error(hs[d], b.h[d], gg, q2, N); sq += e * e; }
     return df_r - std::sqrt(sq) / std::sqrt(3.0);
   };
   for (int it = 0; it < 10000; it++) {
-    const double hh = 1.0e-5, f0 = f(g), f1 = f(g + hh), dg = f0 / ((f1 - f0) / hh);
-    g -= dg;
-    if (std::fabs(f0) < 1.0e-10 || std::fabs(dg) < 1.0e-5) break;
+    const double step = 0.000001, f1 = f(g), f2 = f(g + step);
+    g -= f1 / ((f2 - f1) / step);
+    if (std::fabs(f(g)) < 0.00001) break;
   }
 }
 
@@ -1928,17 +1957,22 @@ struct EvalOpt {
   int shake_a = 1, shake_b = 1;
 };
 
-// positions and velocities of a chunk's states -> the slots' backups (restore: the other way), all in one launch
-static int backup_states(scema_md_engine *e, std::vector<ActiveSim> &chunk, bool restore) {
+// positions and velocities of a chunk's states -> the engine's backup pool from position `pool_off` on (restore: the other
+// way), all in one launch
+static int backup_states(scema_md_engine *e, std::vector<ActiveSim> &chunk, bool restore, size_t pool_off = 0) {
   const int ns = (int)chunk.size();
   e->h_copytab.resize(2 * (size_t)ns);
+  while (e->bak_x.size() < pool_off + (size_t)ns) {
+    e->bak_x.emplace_back(new DevBuf());
+    e->bak_v.emplace_back(new DevBuf());
+  }
   long long maxn = 0;
   for (int i = 0; i < ns; i++) {
-    Slot &sl = *e->slots[i];
+    DevBuf &bx = *e->bak_x[pool_off + i], &bv = *e->bak_v[pool_off + i];
     const long long n = 3 * (long long)chunk[i].st->topo->natoms;
-    HIPCHK(sl.xbak.ensure((size_t)n * 8));
-    HIPCHK(sl.vbak.ensure((size_t)n * 8));
-    double *x = chunk[i].st->x.as<double>(), *v = chunk[i].st->v.as<double>(), *xb = sl.xbak.as<double>(), *vb = sl.vbak.as<double>();
+    HIPCHK(bx.ensure((size_t)n * 8));
+    HIPCHK(bv.ensure((size_t)n * 8));
+    double *x = chunk[i].st->x.as<double>(), *v = chunk[i].st->v.as<double>(), *xb = bx.as<double>(), *vb = bv.as<double>();
     e->h_copytab[2 * i] = restore ? MdkCopy{xb, x, n} : MdkCopy{x, xb, n};
     e->h_copytab[2 * i + 1] = restore ? MdkCopy{vb, v, n} : MdkCopy{v, vb, n};
     maxn = std::max(maxn, n);
@@ -1946,17 +1980,27 @@ static int backup_states(scema_md_engine *e, std::vector<ActiveSim> &chunk, bool
   HIPCHK(e->d_copytab.ensure(2 * (size_t)std::max(ns, 1) * sizeof(MdkCopy)));
   HIPCHK(hipMemcpyAsync(e->d_copytab.p, e->h_copytab.data(), 2 * (size_t)ns * sizeof(MdkCopy), hipMemcpyHostToDevice, e->stream));
   mdk_copy_many(e->stream, e->d_copytab.as<MdkCopy>(), 2 * ns, maxn);
+  if (restore)
+    for (int i = 0; i < ns; i++) {
+      std::memcpy(chunk[i].st->box, chunk[i].box0, sizeof chunk[i].box0);
+      chunk[i].st->skin_extra = chunk[i].skin0;
+    }
+  else
+    for (int i = 0; i < ns; i++) {
+      std::memcpy(chunk[i].box0, chunk[i].st->box, sizeof chunk[i].box0);
+      chunk[i].skin0 = chunk[i].st->skin_extra;
+    }
   return SCEMA_MD_OK;
 }
 
 // full evaluation (phase A + phase B) of a chunk of simulations, with overflow retry
-int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt &opt = EvalOpt()) {
+int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt &opt = EvalOpt(), size_t pool_off = 0) {
   const int ns = (int)chunk.size();
   for (int attempt = 0; attempt < 6; attempt++) {
     int rc = prepare_slots(e, chunk);
     if (rc) return rc;
     // backup for a retry after neighbour overflow
-    rc = backup_states(e, chunk, false);
+    rc = backup_states(e, chunk, false, pool_off);
     if (rc) return rc;
     RunSpec A;
     A.deform = 1;
@@ -1997,12 +2041,12 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
     if (rc != SCEMA_MD_ERR_OVERFLOW) {
       // instability, box error, non-finite stress, device error: the reference would have stopped before write_restart
       // (stmd_problem.h:258), so the stored states must not keep the half-advanced positions
-      (void)backup_states(e, chunk, true);
+      (void)backup_states(e, chunk, true, pool_off);
       (void)hipStreamSynchronize(e->stream);
       return rc;
     }
     // restore and grow
-    rc = backup_states(e, chunk, true);
+    rc = backup_states(e, chunk, true, pool_off);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->overflow_bits & 4) e->jtab_grow *= 1.25;
@@ -2022,11 +2066,12 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
 // another quadrature point branches from it (most_recent_qp_id != qp_id); a state that merely moved is dropped there after
 // the update.  RCCL: one group of point-to-point sends/receives over xGMI on the engine's stream; host transport: the
 // moves in plan order, blocking send/recv pairs (every rank walks the same list, so the pairs cannot cross).
+constexpr int MIG_SIDE = 10;   // doubles that travel next to x and v of a migrating state: box[9], State::skin_extra
 int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, const std::vector<std::string> &src_keys,
                    std::map<int, std::unique_ptr<State>> &incoming) {
   Comm &c = e->comm;
   const int nm = (int)plan.moves.size();
-  std::vector<double> hbox(9 * (size_t)nm, 0.0);
+  std::vector<double> hbox(MIG_SIDE * (size_t)nm, 0.0);   // box[9] + the state's list skin (State::skin_extra)
   std::vector<State *> src(nm, nullptr);
   for (int k = 0; k < nm; k++) {
     const scema::PlanMove &m = plan.moves[k];
@@ -2037,7 +2082,8 @@ int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::Sim
       if (it == e->states.end())
         return fail(e, SCEMA_MD_ERR_NOSTATE, "rank %d is recorded as the owner of state %s but does not hold it", c.rank, src_keys[m.sim].c_str());
       src[k] = it->second.get();
-      std::memcpy(&hbox[9 * (size_t)k], src[k]->box, 9 * sizeof(double));
+      std::memcpy(&hbox[MIG_SIDE * (size_t)k], src[k]->box, 9 * sizeof(double));
+      hbox[MIG_SIDE * (size_t)k + 9] = src[k]->skin_extra;
     }
     if (c.rank == m.to) {
       int rc = make_empty_state(e, t, incoming[m.sim]);
@@ -2050,26 +2096,29 @@ int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::Sim
     NCCLCHK(ncclGroupStart());
     for (int k = 0; k < nm; k++) {
       const scema::PlanMove &m = plan.moves[k];
-      double *dbox = c.d_box.as<double>() + 9 * (size_t)k;
+      double *dbox = c.d_box.as<double>() + MIG_SIDE * (size_t)k;
       if (c.rank == m.from) {
         const size_t cnt = 3 * (size_t)src[k]->topo->natoms;
         NCCLCHK(ncclSend(src[k]->x.p, cnt, ncclDouble, m.to, c.nccl, e->stream));
         NCCLCHK(ncclSend(src[k]->v.p, cnt, ncclDouble, m.to, c.nccl, e->stream));
-        NCCLCHK(ncclSend(dbox, 9, ncclDouble, m.to, c.nccl, e->stream));
+        NCCLCHK(ncclSend(dbox, MIG_SIDE, ncclDouble, m.to, c.nccl, e->stream));
       }
       if (c.rank == m.to) {
         State *d = incoming[m.sim].get();
         const size_t cnt = 3 * (size_t)d->topo->natoms;
         NCCLCHK(ncclRecv(d->x.p, cnt, ncclDouble, m.from, c.nccl, e->stream));
         NCCLCHK(ncclRecv(d->v.p, cnt, ncclDouble, m.from, c.nccl, e->stream));
-        NCCLCHK(ncclRecv(dbox, 9, ncclDouble, m.from, c.nccl, e->stream));
+        NCCLCHK(ncclRecv(dbox, MIG_SIDE, ncclDouble, m.from, c.nccl, e->stream));
       }
     }
     NCCLCHK(ncclGroupEnd());
     HIPCHK(hipMemcpyAsync(hbox.data(), c.d_box.p, hbox.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int k = 0; k < nm; k++)
-      if (c.rank == plan.moves[k].to) std::memcpy(incoming[plan.moves[k].sim]->box, &hbox[9 * (size_t)k], 9 * sizeof(double));
+      if (c.rank == plan.moves[k].to) {
+        std::memcpy(incoming[plan.moves[k].sim]->box, &hbox[MIG_SIDE * (size_t)k], 9 * sizeof(double));
+        incoming[plan.moves[k].sim]->skin_extra = hbox[MIG_SIDE * (size_t)k + 9];
+      }
   } else {
     if (!c.send || !c.recv) return fail(e, SCEMA_MD_ERR_ARG, "the host communicator has no send/recv callbacks: replica states cannot move between ranks");
     std::vector<double> buf;
@@ -2078,12 +2127,13 @@ int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::Sim
       if (c.rank != m.from && c.rank != m.to) continue;
       State *st = (c.rank == m.from) ? src[k] : incoming[m.sim].get();
       const size_t n3 = 3 * (size_t)st->topo->natoms;
-      buf.resize(2 * n3 + 9);
+      buf.resize(2 * n3 + MIG_SIDE);
       if (c.rank == m.from) {
         HIPCHK(hipMemcpyAsync(buf.data(), st->x.p, n3 * 8, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipMemcpyAsync(buf.data() + n3, st->v.p, n3 * 8, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         std::memcpy(buf.data() + 2 * n3, st->box, 9 * sizeof(double));
+        buf[2 * n3 + 9] = st->skin_extra;
         if (c.send(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.to)) return fail(e, SCEMA_MD_ERR_DEVICE, "host send of a replica state to rank %d failed", m.to);
       } else {
         if (c.recv(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.from)) return fail(e, SCEMA_MD_ERR_DEVICE, "host receive of a replica state from rank %d failed", m.from);
@@ -2091,6 +2141,7 @@ int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::Sim
         HIPCHK(hipMemcpyAsync(st->v.p, buf.data() + n3, n3 * 8, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         std::memcpy(st->box, buf.data() + 2 * n3, 9 * sizeof(double));
+        st->skin_extra = buf[2 * n3 + 9];
       }
     }
   }
@@ -2098,23 +2149,85 @@ int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::Sim
   return SCEMA_MD_OK;
 }
 
-// ONE all-gather of 6*cap doubles per rank, then every rank fills every sims[i].stress (all ranks hold all stresses, so
-// the second share_scale_bridging_data broadcast of the caller, dealammps.cc:458, is not needed).
+// Result buffer of a rank: 6*cap stresses followed by SCEMA_MD_RESULT_TRAILER words -- [status of this rank's share
+// (0 = fine, else the error code), hash of the plan this rank computed].  Every rank enters the collective whatever
+// happened to its share, so that a rank-local failure (list overflow, a replica that blew up, a missing state) ends the
+// update on ALL ranks together instead of leaving the others blocked in the collective.
+static_assert(SCEMA_MD_RESULT_TRAILER == 2, "result trailer: status, plan hash");
+
+// 52 bits of an FNV-1a hash: exactly representable in the double it travels in
+double plan_hash(const scema::SimPlan &P, const std::vector<double> &cost) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) {
+    for (int k = 0; k < 8; k++) { h ^= (v >> (8 * k)) & 0xffull; h *= 1099511628211ull; }
+  };
+  mix((unsigned long long)P.world); mix((unsigned long long)P.cap); mix(P.owner.size());
+  for (size_t i = 0; i < P.owner.size(); i++) {
+    mix((unsigned long long)P.owner[i]); mix((unsigned long long)P.pos[i]); mix((unsigned long long)(long long)P.home[i]);
+    unsigned long long bits; std::memcpy(&bits, &cost[i], 8); mix(bits);
+  }
+  mix(P.moves.size());
+  for (const scema::PlanMove &m : P.moves) { mix((unsigned long long)m.sim); mix((unsigned long long)m.from); mix((unsigned long long)m.to); }
+  return (double)(h & ((1ull << 52) - 1));
+}
+
+// every rank contributes cnt doubles (host memory), out = world * cnt
+int comm_allgather(scema_md_engine *e, const double *local, size_t cnt, std::vector<double> &out, DevBuf &d_send) {
+  Comm &c = e->comm;
+  out.assign(cnt * c.world, 0.0);
+  if (c.kind == 1) {
+    HIPCHK(d_send.ensure(cnt * sizeof(double)));
+    HIPCHK(c.d_gather.ensure(cnt * c.world * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(d_send.p, local, cnt * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    NCCLCHK(ncclAllGather(d_send.p, c.d_gather.p, cnt, ncclDouble, c.nccl, e->stream));
+    HIPCHK(hipMemcpyAsync(out.data(), c.d_gather.p, cnt * c.world * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  } else {
+    if (!c.ag || c.ag(c.ctx, local, out.data(), (int64_t)(cnt * sizeof(double))))
+      return fail(e, SCEMA_MD_ERR_DEVICE, "host all-gather failed");
+  }
+  return SCEMA_MD_OK;
+}
+
+// what the ranks told each other: the first failing rank's code, or a plan mismatch
+int check_gathered_trailers(scema_md_engine *e, const double *gathered, size_t stride, size_t off, int world, int rank, const char *when) {
+  for (int r = 0; r < world; r++) {
+    const int st = (int)gathered[r * stride + off];
+    if (st != 0) {
+      if (r == rank) return st;   // this rank's own message is already in e->err
+      return fail(e, st, "rank %d failed %s (code %d): the update is abandoned on every rank", r, when, st);
+    }
+  }
+  for (int r = 1; r < world; r++)
+    if (gathered[r * stride + off + 1] != gathered[off + 1])
+      return fail(e, SCEMA_MD_ERR_ARG, "ranks 0 and %d computed different plans for this update: replicas, states and request vectors must be the same on every rank "
+                  "(scema_md_register_replica / set_state / drop_state / load_state_file / equilibrate are collective when a world > 1 is used)", r);
+  return SCEMA_MD_OK;
+}
+
+// Agreement before anything moves: 2 doubles per rank (status of the local pre-checks, plan hash).  A plan that differs
+// between ranks would pair sends with no receive, or give the all-gather different counts.
+int handshake(scema_md_engine *e, int local_status, double hash) {
+  Comm &c = e->comm;
+  const double word[2] = {(double)local_status, hash};
+  std::vector<double> all;
+  int rc = comm_allgather(e, word, 2, all, c.d_word);
+  if (rc) return rc;
+  c.handshakes += 1;
+  return check_gathered_trailers(e, all.data(), 2, 0, c.world, c.rank, "before the update started");
+}
+
+// ONE all-gather of 6*cap (+ trailer) doubles per rank, then every rank fills every sims[i].stress (all ranks hold all
+// stresses, so the second share_scale_bridging_data broadcast of the caller, dealammps.cc:458, is not needed).
 int allgather_stresses(scema_md_engine *e, const std::vector<double> &local, scema_mdsim *sims, int n_sims) {
   Comm &c = e->comm;
   const scema::SimPlan &plan = e->last_plan;
-  const size_t cnt = 6 * (size_t)std::max(plan.cap, 1);
-  c.h_gather.assign(cnt * c.world, 0.0);
-  if (c.kind == 1) {
-    HIPCHK(c.d_gather.ensure(cnt * c.world * sizeof(double)));
-    NCCLCHK(ncclAllGather(e->d_local_stress.p, c.d_gather.p, cnt, ncclDouble, c.nccl, e->stream));
-    HIPCHK(hipMemcpyAsync(c.h_gather.data(), c.d_gather.p, cnt * c.world * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-  } else {
-    if (!c.ag || c.ag(c.ctx, local.data(), c.h_gather.data(), (int64_t)(cnt * sizeof(double))))
-      return fail(e, SCEMA_MD_ERR_DEVICE, "host all-gather of the stresses failed");
-  }
+  const size_t cnt = local.size();
+  int rc = comm_allgather(e, local.data(), cnt, c.h_gather, e->d_local_stress);
+  if (rc) return rc;
   c.allgathers += 1;
+  rc = check_gathered_trailers(e, c.h_gather.data(), cnt, cnt - SCEMA_MD_RESULT_TRAILER, c.world, c.rank, "during the update");
+  if (rc) return rc;
   for (int i = 0; i < n_sims; i++) {
     const double *src = c.h_gather.data() + ((size_t)plan.owner[i] * cnt + 6 * (size_t)plan.pos[i]);
     for (int k = 0; k < 6; k++) sims[i].stress[k] = src[k];
@@ -2187,6 +2300,7 @@ void scema_md_destroy(scema_md_engine *e) {
   scema_md_comm_destroy(e);
   e->comm.d_gather.release();
   e->comm.d_box.release();
+  e->comm.d_word.release();
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -2318,7 +2432,9 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   if (e->comm.kind && (e->comm.rank != rank || e->comm.world != world))
     return fail(e, SCEMA_MD_ERR_ARG, "rank/world (%d/%d) differ from the attached communicator (%d/%d)", rank, world, e->comm.rank, e->comm.world);
   HIPCHK(hipSetDevice(e->p.device));
-  // ---- who runs what (host/sim_plan.h): identical on every rank ----
+  e->last_plan = scema::SimPlan();   // a call that ends before planning leaves no plan behind
+  // ---- the request itself: checked on every rank for every simulation, so that a request that cannot run is refused by
+  // all ranks together, before anything is planned or moved ----
   std::vector<std::string> src_keys(n_sims), dst_keys(n_sims);
   std::vector<double> cost(n_sims, 1.0);
   int n_reax = 0, n_md = 0;
@@ -2330,29 +2446,45 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
       return fail(e, SCEMA_MD_ERR_ARG, "Error: Force field is %s but only 'opls' and 'reax' are implemented... ", ff);
     if (hooke_mode) continue;   // sigma = C:eps has no state: the fresh-batch rule of the planner = i % world (stmd_sync.h:583)
     n_md++;
-    if (std::strcmp(ff, "reax") == 0) {
-      n_reax++;
-      if (!e->rx_ready) {
-        // the reference's scripts name the file and the elements: pair_coeff * * ${locs}/ffield.reax.2 H C N O
-        // (lammps_scripts_reax/in.strain.lammps:11, locs = MDSim.scripts_folder, stmd_problem.h:163)
-        static const char *hcno[4] = {"H", "C", "N", "O"};
-        const std::string path = std::string(sims[i].scripts_folder ? sims[i].scripts_folder : ".") + "/ffield.reax.2";
-        const int rc_cfg = scema_md_reax_configure(e, path.c_str(), hcno, 4, 1e-6, -1.0);
-        if (rc_cfg) return rc_cfg;
-      }
-    }
+    if (std::strcmp(ff, "reax") == 0) n_reax++;
+    // requests that cannot be run: LAMMPS would stop while parsing "variable ceeps_.. equal nan" or "timestep 0"
+    bool finite = true;
+    for (int k = 0; k < 6; k++) finite = finite && std::isfinite(sims[i].strain[k]);
+    if (!finite) return fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: non-finite strain", sims[i].qp_id);
+    if (!(sims[i].strain_rate > 0.0) || !std::isfinite(sims[i].strain_rate) || !(sims[i].timestep_length > 0.0) ||
+        !std::isfinite(sims[i].timestep_length) || !(sims[i].temperature > 0.0) || !std::isfinite(sims[i].temperature))
+      return fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: strain rate, time step and temperature must be positive and finite", sims[i].qp_id);
+    if (sims[i].nsteps_sample < 1) return fail(e, SCEMA_MD_ERR_ARG, "number of sampling steps must be >= 1");
+  }
+  if (n_reax != 0 && n_reax != n_md) return fail(e, SCEMA_MD_ERR_ARG, "one update mixes force fields (%d of %d simulations ask for 'reax'): md_force_field is one setting per run", n_reax, n_md);
+  if (n_reax && !e->rx_ready) {
+    // the reference's scripts name the file and the elements: pair_coeff * * ${locs}/ffield.reax.2 H C N O
+    // (lammps_scripts_reax/in.strain.lammps:11, locs = MDSim.scripts_folder, stmd_problem.h:163)
+    static const char *hcno[4] = {"H", "C", "N", "O"};
+    const std::string path = std::string(sims[0].scripts_folder ? sims[0].scripts_folder : ".") + "/ffield.reax.2";
+    const int rc_cfg = scema_md_reax_configure(e, path.c_str(), hcno, 4, 1e-6, -1.0);
+    if (rc_cfg) return rc_cfg;
+  }
+  // ---- who runs what (host/sim_plan.h): identical on every rank ----
+  int pre_status = SCEMA_MD_OK;   // rank-local findings before anything runs; exchanged in the handshake
+  for (int i = 0; i < n_sims && !hooke_mode; i++) {
     dst_keys[i] = state_key(sims[i].qp_id, sims[i].matid, sims[i].replica);
     // stmd_problem.h:116-120: the state is read under most_recent_qp_id ("none" -> init.<mat>_<rep>.bin)
     if (sims[i].most_recent_qp_id == sims[i].qp_id) src_keys[i] = dst_keys[i];
     else if (sims[i].most_recent_qp_id != SCEMA_MD_QP_NONE) src_keys[i] = state_key(sims[i].most_recent_qp_id, sims[i].matid, sims[i].replica);
-    // cost = MD steps of the evaluation, estimated with the replica's initial box (known to every rank)
-    if (Topo *t = find_topo(e, sims[i].matid, sims[i].replica)) {
-      const double lb0[3] = {t->init_box[3] - t->init_box[0], t->init_box[4] - t->init_box[1], t->init_box[5] - t->init_box[2]};
-      double eps0[6];
-      cost[i] = (double)nts_rule(sims[i], lb0, eps0, nullptr) + (double)std::max(sims[i].nsteps_sample, 1);
+    // cost = MD steps of the evaluation, estimated with the replica's registered box (the same on every rank: replicas
+    // are registered collectively; the plan hash of the handshake says so if they were not)
+    Topo *t = find_topo(e, sims[i].matid, sims[i].replica);
+    if (!t) {
+      if (world == 1 || !e->comm.kind)
+        return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered (init.%s_%d.bin missing)", sims[i].matid, sims[i].replica, sims[i].matid, sims[i].replica);
+      if (!pre_status) pre_status = fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered on rank %d (init.%s_%d.bin missing)", sims[i].matid, sims[i].replica, rank, sims[i].matid, sims[i].replica);
+      continue;
     }
+    const double lb0[3] = {t->init_box[3] - t->init_box[0], t->init_box[4] - t->init_box[1], t->init_box[5] - t->init_box[2]};
+    double eps0[6];
+    cost[i] = (double)nts_rule(sims[i], lb0, eps0, nullptr) + (double)std::max(sims[i].nsteps_sample, 1);
   }
-  if (n_reax != 0 && n_reax != n_md) return fail(e, SCEMA_MD_ERR_ARG, "one update mixes force fields (%d of %d simulations ask for 'reax'): md_force_field is one setting per run", n_reax, n_md);
   struct ReaxScope {   // the force field of this update; the debug entry points keep whatever scema_md_reax_activate chose
     scema_md_engine *e; bool saved;
     ReaxScope(scema_md_engine *e_, bool on) : e(e_), saved(e_->reax_active) { e->reax_active = on; }
@@ -2361,20 +2493,40 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   e->last_plan = e->dir.plan(src_keys, dst_keys, cost, world);
   const scema::SimPlan &plan = e->last_plan;
   const int per_rank = plan.cap;
+  const double hash = plan_hash(plan, cost);
   e->local_stress_count = per_rank;
-  HIPCHK(e->d_local_stress.ensure((size_t)std::max(per_rank, 1) * 6 * sizeof(double)));
-  std::vector<double> local(6 * (size_t)std::max(per_rank, 1), 0.0);
+  const size_t nres = 6 * (size_t)std::max(per_rank, 1) + SCEMA_MD_RESULT_TRAILER;
+  HIPCHK(e->d_local_stress.ensure(nres * sizeof(double)));
+  std::vector<double> local(nres, 0.0);
+  local[nres - 1] = hash;
+  const bool collective = e->comm.kind && world > 1;
+  // without a communicator the caller gathers this buffer: it must say what happened to this rank's share whenever a plan exists
+  auto publish = [&](int st) {
+    local[nres - 2] = (double)st;
+    (void)hipMemcpyAsync(e->d_local_stress.p, local.data(), local.size() * sizeof(double), hipMemcpyHostToDevice, e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    return st;
+  };
+  // a source state this rank is recorded to own but does not hold: found before any rank posts a receive for it
+  for (const scema::PlanMove &m : plan.moves)
+    if (m.from == rank && !pre_status && !e->states.count(src_keys[m.sim]))
+      pre_status = fail(e, SCEMA_MD_ERR_NOSTATE, "rank %d is recorded as the owner of state %s but does not hold it", rank, src_keys[m.sim].c_str());
+  if (collective) {
+    const int rc = handshake(e, pre_status, hash);
+    if (rc) return rc;
+  } else if (pre_status)
+    return publish(pre_status);
   // ---- states that have to change GPU first ----
   std::map<int, std::unique_ptr<State>> incoming;
   if (!hooke_mode && !plan.moves.empty()) {
     if (!e->comm.kind) {
       const scema::PlanMove &m = plan.moves[0];
-      return fail(e, SCEMA_MD_ERR_NOSTATE, "the state %s that quadrature point %d continues from lives on rank %d but the simulation is planned on rank %d: "
-                  "attach a communicator (scema_md_comm_init_rccl / scema_md_comm_init_host) so that states can move between GPUs",
-                  src_keys[m.sim].c_str(), sims[m.sim].qp_id, m.from, m.to);
+      return publish(fail(e, SCEMA_MD_ERR_NOSTATE, "the state %s that quadrature point %d continues from lives on rank %d but the simulation is planned on rank %d: "
+                          "attach a communicator (scema_md_comm_init_rccl / scema_md_comm_init_host) so that states can move between GPUs",
+                          src_keys[m.sim].c_str(), sims[m.sim].qp_id, m.from, m.to));
     }
     int rc = migrate_states(e, sims, plan, src_keys, incoming);
-    if (rc) return rc;
+    if (rc) return rc;   // a transport failure: nothing a status word could repair
   }
   // ---- this rank's share ----
   std::vector<ActiveSim> act;
@@ -2387,7 +2539,8 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     }
     created.clear();
   };
-  for (int i = 0; i < n_sims; i++) {
+  int status = SCEMA_MD_OK;   // of this rank's share; with a communicator it travels in the trailer of the all-gather
+  for (int i = 0; i < n_sims && !status; i++) {
     if (plan.owner[i] != rank) continue;
     if (hooke_mode) {
       hooke(sims[i].stiffness, sims[i].strain, sims[i].stress);
@@ -2398,25 +2551,19 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     bool was_created = false;
     std::unique_ptr<State> displaced;
     auto inc = incoming.find(i);
-    int rc = resolve_state(e, sims[i], &A.st, inc == incoming.end() ? nullptr : &inc->second, &was_created, &displaced);
-    if (rc) { undo(); return rc; }
+    status = resolve_state(e, sims[i], &A.st, inc == incoming.end() ? nullptr : &inc->second, &was_created, &displaced);
+    if (status) break;
     if (was_created) created.push_back({dst_keys[i], std::move(displaced)});
     A.user_index = i;
     // stmd_problem.h:213-225
     const double lb[3] = {A.st->box[3] - A.st->box[0], A.st->box[4] - A.st->box[1], A.st->box[5] - A.st->box[2]};
     double eps[6], nrm = 0.0;
     const int nts = nts_rule(sims[i], lb, eps, &nrm);
-    // requests that cannot be run: LAMMPS would stop while parsing "variable ceeps_.. equal nan" or "timestep 0"
-    int bad = 0;
-    if (!std::isfinite(nrm)) bad = fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: non-finite strain", sims[i].qp_id);
-    else if (!(sims[i].strain_rate > 0.0) || !std::isfinite(sims[i].strain_rate) || !(sims[i].timestep_length > 0.0) ||
-             !std::isfinite(sims[i].timestep_length) || !(sims[i].temperature > 0.0) || !std::isfinite(sims[i].temperature))
-      bad = fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: strain rate, time step and temperature must be positive and finite", sims[i].qp_id);
+    if (!std::isfinite(nrm)) status = fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: non-finite strain", sims[i].qp_id);
     else if (nrm / sims[i].strain_rate / sims[i].timestep_length > 1.0e7)
-      bad = fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: %.3g straining steps requested (strain norm %.3g at rate %.3g per fs)",
-                 sims[i].qp_id, nrm / sims[i].strain_rate / sims[i].timestep_length, nrm, sims[i].strain_rate);
-    else if (sims[i].nsteps_sample < 1) bad = fail(e, SCEMA_MD_ERR_ARG, "number of sampling steps must be >= 1");
-    if (bad) { undo(); return bad; }
+      status = fail(e, SCEMA_MD_ERR_ARG, "quadrature point %d: %.3g straining steps requested (strain norm %.3g at rate %.3g per fs)",
+                    sims[i].qp_id, nrm / sims[i].strain_rate / sims[i].timestep_length, nrm, sims[i].strain_rate);
+    if (status) break;
     A.nts = nts;
     A.nss = sims[i].nsteps_sample;
     A.dt = round_trip("%f", sims[i].timestep_length);
@@ -2439,23 +2586,57 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
       maxb = (int)std::max(1.0, std::min(1024.0, fit));
     }
   }
-  for (size_t off = 0; off < act.size(); off += maxb) {
+  size_t n_advanced = 0;   // simulations of `act` whose states have been advanced (their backups sit in the pool)
+  for (size_t off = 0; off < act.size() && !status; off += maxb) {
     std::vector<ActiveSim> chunk(act.begin() + off, act.begin() + std::min(act.size(), off + (size_t)maxb));
-    int rc = eval_chunk(e, chunk);
-    if (rc) { undo(); return rc; }
+    status = eval_chunk(e, chunk, EvalOpt(), off);   // a failed chunk has put its own states back
+    if (status) break;
+    for (size_t k = 0; k < chunk.size(); k++) { std::memcpy(act[off + k].box0, chunk[k].box0, sizeof chunk[k].box0); act[off + k].skin0 = chunk[k].skin0; }
+    n_advanced = off + chunk.size();
     for (auto &A : chunk) {
       scema_mdsim &m = sims[A.user_index];
       for (int k = 0; k < 6; k++) m.stress[k] = A.pavg[k] * (-1.0) * 1.01325e+05;  // stmd_problem.h:340
       // a replica that blew up (overlapping atoms, a time step far too long) must not hand NaN to the FE solver:
       // LAMMPS would stop with "lost atoms" / "bond atoms missing" at this point
-      for (int k = 0; k < 6; k++)
-        if (!std::isfinite(m.stress[k])) {
-          undo();
-          return fail(e, SCEMA_MD_ERR_ARG, "simulation of quadrature point %d (material %s, replica %d) produced a non-finite stress: unstable state or parameters",
-                      m.qp_id, m.matid ? m.matid : "?", m.replica);
-        }
+      for (int k = 0; k < 6 && !status; k++)
+        if (!std::isfinite(m.stress[k]))
+          status = fail(e, SCEMA_MD_ERR_ARG, "simulation of quadrature point %d (material %s, replica %d) produced a non-finite stress: unstable state or parameters",
+                        m.qp_id, m.matid ? m.matid : "?", m.replica);
+      if (status) break;
       m.stress_updated = 1;
     }
+  }
+  // ---- results of this rank: stresses, status word, plan hash ----
+  if (status)
+    for (int i = 0; i < n_sims; i++) sims[i].stress_updated = 0;
+  for (int i = 0; i < n_sims; i++)
+    if (plan.owner[i] == rank && sims[i].stress_updated)
+      for (int k = 0; k < 6; k++) local[6 * (size_t)plan.pos[i] + k] = sims[i].stress[k];
+  local[nres - 2] = (double)status;
+  // ---- the one collective of the update (replaces STMDSync::share_stresses, stmd_sync.h:620-726) ----
+  // (with a communicator attached it runs for a single rank too: one 48-byte-per-simulation collective costs microseconds
+  // and the one-GPU test box thereby exercises the RCCL calls).  A rank whose share failed enters it all the same: the
+  // status word in the trailer ends the update on every rank.
+  int rc = status;
+  if (e->comm.kind) {
+    const int rc_g = allgather_stresses(e, local, sims, n_sims);
+    if (!rc) rc = rc_g;
+  } else {
+    // the caller gathers (scema_md_copy_local_stress + scema_md_scatter_gathered): the buffer carries this rank's status
+    (void)publish(status);
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (rc) {
+    // every rank arrives here together (or the single rank alone): states that were advanced go back to their backups,
+    // new states go, the directory keeps the owners it had
+    if (n_advanced) {
+      std::vector<ActiveSim> done(act.begin(), act.begin() + n_advanced);
+      (void)backup_states(e, done, true, 0);
+      (void)hipStreamSynchronize(e->stream);
+    }
+    undo();
+    for (int i = 0; i < n_sims; i++) sims[i].stress_updated = 0;
+    return rc;
   }
   // ---- bookkeeping: every state now lives under its own key on the rank that ran it; stale copies elsewhere go ----
   if (!hooke_mode && world > 1) {
@@ -2463,18 +2644,6 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     for (int i = 0; i < n_sims; i++)
       if (plan.owner[i] != rank) e->states.erase(dst_keys[i]);
   }
-  for (int i = 0; i < n_sims; i++)
-    if (plan.owner[i] == rank && sims[i].stress_updated)
-      for (int k = 0; k < 6; k++) local[6 * (size_t)plan.pos[i] + k] = sims[i].stress[k];
-  HIPCHK(hipMemcpyAsync(e->d_local_stress.p, local.data(), local.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  // ---- the one collective of the update (replaces STMDSync::share_stresses, stmd_sync.h:620-726) ----
-  // (with a communicator attached it runs for a single rank too: one 48-byte-per-simulation collective costs microseconds
-  // and the one-GPU test box thereby exercises the RCCL calls)
-  if (e->comm.kind) {
-    int rc = allgather_stresses(e, local, sims, n_sims);
-    if (rc) return rc;
-  }
-  HIPCHK(hipStreamSynchronize(e->stream));
   return SCEMA_MD_OK;
 }
 
@@ -2486,12 +2655,14 @@ int32_t scema_md_local_stress_count(const scema_md_engine *e) { return e ? e->lo
 int scema_md_copy_local_stress(scema_md_engine *e, void *dst, int32_t dst_on_device) {
   if (!e || !dst) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
-  HIPCHK(hipMemcpyAsync(dst, e->d_local_stress.p, (size_t)std::max(e->local_stress_count, 0) * 6 * sizeof(double),
+  HIPCHK(hipMemcpyAsync(dst, e->d_local_stress.p, (size_t)scema_md_local_result_doubles(e) * sizeof(double),
                         dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
   // the caller hands dst to a collective on another stream
   HIPCHK(hipStreamSynchronize(e->stream));
   return SCEMA_MD_OK;
 }
+
+int32_t scema_md_local_result_doubles(const scema_md_engine *e) { return e ? 6 * std::max(e->local_stress_count, 1) + SCEMA_MD_RESULT_TRAILER : 0; }
 
 int scema_md_last_plan(const scema_md_engine *e, int32_t n_sims, int32_t *owner, int32_t *pos, int32_t *cap) {
   if (!e || n_sims != (int)e->last_plan.owner.size()) return SCEMA_MD_ERR_ARG;
@@ -2503,10 +2674,14 @@ int scema_md_last_plan(const scema_md_engine *e, int32_t n_sims, int32_t *owner,
   return SCEMA_MD_OK;
 }
 
-int scema_md_scatter_gathered(const scema_md_engine *e, const double *gathered, scema_mdsim *sims, int32_t n_sims) {
+int scema_md_scatter_gathered(scema_md_engine *e, const double *gathered, scema_mdsim *sims, int32_t n_sims) {
   if (!e || !gathered || !sims || n_sims != (int)e->last_plan.owner.size()) return SCEMA_MD_ERR_ARG;
   const scema::SimPlan &plan = e->last_plan;
-  const size_t cnt = 6 * (size_t)std::max(plan.cap, 0);
+  const size_t cnt = (size_t)scema_md_local_result_doubles(e);
+  for (int i = 0; i < n_sims; i++) sims[i].stress_updated = 0;
+  // this rank's own failure was reported by scema_md_strain_batch already; here: somebody else's, or a plan mismatch
+  const int rc = check_gathered_trailers(e, gathered, cnt, cnt - SCEMA_MD_RESULT_TRAILER, plan.world, -1, "during the update");
+  if (rc) return rc;
   for (int i = 0; i < n_sims; i++) {
     const double *src = gathered + ((size_t)plan.owner[i] * cnt + 6 * (size_t)plan.pos[i]);
     for (int k = 0; k < 6; k++) sims[i].stress[k] = src[k];
@@ -2566,6 +2741,8 @@ void scema_md_comm_destroy(scema_md_engine *e) {
 
 int32_t scema_md_comm_world(const scema_md_engine *e) { return (e && e->comm.kind) ? e->comm.world : 1; }
 int32_t scema_md_comm_rank(const scema_md_engine *e) { return (e && e->comm.kind) ? e->comm.rank : 0; }
+
+int64_t scema_md_comm_handshakes(const scema_md_engine *e) { return e ? e->comm.handshakes : 0; }
 
 int scema_md_comm_stats(const scema_md_engine *e, int64_t *allgathers, int64_t *migrations) {
   if (!e) return SCEMA_MD_ERR_ARG;

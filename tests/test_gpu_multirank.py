@@ -157,3 +157,85 @@ def test_rccl_calls_run_on_one_rank(tmp_path):
     script.write_text(_RCCL_ONE)
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+WORKER_EDGE = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+from scema_amd import capi, comm
+from scema_amd.systems import build_pe
+from test_gpu_multirank import KW
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+d = build_pe(2, 3, 5, jitter=0.05, seed=7)
+d["box"][6:9] = [0.7, -0.4, 0.5]
+eng = capi.Engine(capi.default_params(**KW))
+comm.attach_gloo(eng, rank, world)
+eng.register_replica("pe", 1, d)
+lens = d["box"][3:6] - d["box"][:3]
+st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+log = {}
+# (1) two fresh points, one per rank; then an update_list that holds only rank 0's point: rank 1 has nothing to run and
+#     must still take part in the collective (ADVICE r2 high: no rank decides on its own whether to enter)
+a = eng.strain_batch([capi.make_sim(q, "pe", 1, st, nss=10, most_recent=capi.QP_NONE) for q in (0, 1)], rank=rank, world=world)
+b = eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10)], rank=rank, world=world)
+log["one_owner"] = np.array(list(b[0].stress)); log["one_owner_plan"] = eng.last_plan(1)[0]
+# (2) a share that fails on ONE rank (qp 1 lives on rank 1; a 60 fs time step blows the replica up there): every rank gets
+#     the error, nobody is left in the collective, the directory and the stored states stay usable
+sims = [capi.make_sim(0, "pe", 1, st, nss=10), capi.make_sim(1, "pe", 1, st, nss=10)]
+sims[1].timestep_length = 60.0
+try:
+    eng.strain_batch(sims, rank=rank, world=world)
+    log["fail_msg"] = "no error"
+except capi.EngineError as exc:
+    log["fail_msg"] = str(exc)
+log["owners_after_failure"] = np.array([eng.state_owner(q, "pe", 1) for q in (0, 1)])
+c = eng.strain_batch([capi.make_sim(q, "pe", 1, st, nss=10) for q in (0, 1)], rank=rank, world=world)
+log["after_failure"] = np.array([list(x.stress) for x in c])
+# (3) a state-store edit made on ONE rank only changes that rank's plan: the handshake says so on every rank
+if rank == 1:
+    eng.drop_state(1, "pe", 1)
+try:
+    eng.strain_batch([capi.make_sim(q, "pe", 1, st, nss=10) for q in (1, 0, 2)], rank=rank, world=world)
+    log["mismatch_msg"] = "no error"
+except capi.EngineError as exc:
+    log["mismatch_msg"] = str(exc)
+st_ = eng.comm_stats()
+log["stats"] = np.array([st_["allgathers"], st_["handshakes"]])
+np.savez(sys.argv[2] + f".{rank}.npz", **log)
+dist.barrier(); eng.close(); dist.destroy_process_group()
+'''
+
+
+def test_collective_edge_cases_one_owner_one_failure_one_mismatch(tmp_path, small_pe):
+    """Two ranks over the host transport: an update that only one rank has work for, a share that fails on one rank, and
+    plans that differ between the ranks -- none of them may leave a rank blocked in a collective (ADVICE r2)."""
+    from scema_amd import capi
+    (tmp_path / "worker.py").write_text(WORKER_EDGE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", str(tmp_path / "worker.py"), ROOT, str(tmp_path / "out")]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = [np.load(str(tmp_path / "out") + f".{k}.npz") for k in range(2)]
+    # single-rank run of the same sequence (the failed update leaves no trace)
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+    eng.strain_batch([capi.make_sim(q, "pe", 1, st, nss=10, most_recent=capi.QP_NONE) for q in (0, 1)])
+    b = eng.strain_batch([capi.make_sim(0, "pe", 1, st, nss=10)])
+    c = eng.strain_batch([capi.make_sim(q, "pe", 1, st, nss=10) for q in (0, 1)])
+    ref_b = np.array(list(b[0].stress)); ref_c = np.array([list(x.stress) for x in c])
+    eng.close()
+    for k in range(2):
+        assert int(got[k]["one_owner_plan"][0]) == 0
+        assert np.abs(got[k]["one_owner"] - ref_b).max() < 1e-8 * np.abs(ref_b).max()
+        msg = str(got[k]["fail_msg"])
+        assert msg != "no error" and ("non-finite" in msg or "unstable" in msg or "rank 1 failed" in msg), msg
+        assert list(got[k]["owners_after_failure"]) == [0, 1]
+        assert np.abs(got[k]["after_failure"] - ref_c).max() < 1e-8 * np.abs(ref_c).max()
+        assert "different plans" in str(got[k]["mismatch_msg"]), str(got[k]["mismatch_msg"])
+        assert got[k]["stats"][0] == 4 and got[k]["stats"][1] == 5       # stress all-gathers: 4 updates got that far; handshakes: all 5
+    assert "rank 1 failed" in str(got[0]["fail_msg"])

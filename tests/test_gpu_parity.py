@@ -183,9 +183,12 @@ def test_ragged_world_sharding_leaves_other_ranks_untouched(small_pe, eng_small)
     assert [o.stress_updated for o in out] == [0, 1, 0, 0, 1]
     ptr, cnt = eng_small.local_stress_ptr()
     assert cnt == 2 and ptr
-    host = np.zeros(12)
+    # result buffer: 6*cap stresses, then this rank's status word and the hash of the plan it computed
+    assert eng_small.local_result_doubles() == 14
+    host = np.zeros(14)
     eng_small.copy_local_stress(host.ctypes.data, False)
-    assert np.allclose(host[:6], out[1].stress[:]) and np.allclose(host[6:], out[4].stress[:])
+    assert np.allclose(host[:6], out[1].stress[:]) and np.allclose(host[6:12], out[4].stress[:])
+    assert host[12] == 0.0 and host[13] > 0.0 and host[13] == np.floor(host[13])
 
 
 def test_impropers_match_oracle(small_pe, eng_small):
@@ -303,3 +306,40 @@ def test_coulomb_cutoff_beyond_the_lj_cutoff(small_pe):
     exp, nts = o2.eval(strain, 2.0, 300.0, 1e-4, 20)
     assert nts == 10 and relerr(got, exp) < 1e-6
     e.close()
+
+
+def test_launch_groups_smaller_than_the_batch(small_pe):
+    """max_batch = 2 over 5 simulations: three launch groups (2 + 2 + 1) give what one group gives, for two consecutive
+    updates on persistent states -- the path the dogbone_file3D mesh takes (4 864 points x replicas exceed one launch
+    group of 1 024, inputs_dogbone_file3D.json:36).  A failure in the LAST group puts the first groups' states back."""
+    from scema_amd import capi
+    KW = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    def strains(u):
+        return [np.array([-3e-4 * lens[0], -3e-4 * lens[1], (1.0e-3 + 2e-4 * k) * lens[2] * (1 if u == 0 else -1), 3e-5 * k * lens[2], 0.0, -2e-5 * k * lens[0]])
+                for k in range(5)]
+    res = {}
+    for mb in (0, 2):
+        eng = capi.Engine(capi.default_params(max_batch=mb, **KW))
+        eng.register_replica("pe", 1, small_pe)
+        out = []
+        for u in range(2):
+            sims = [capi.make_sim(300 + k, "pe", 1, s, nss=10, most_recent=capi.QP_NONE if u == 0 else None) for k, s in enumerate(strains(u))]
+            arr = eng.strain_batch(sims)
+            assert all(a.stress_updated for a in arr)
+            out.append(np.array([list(a.stress) for a in arr]))
+        if mb == 2:
+            # third update: the fifth simulation (alone in the last group) blows up -> the whole update fails and the four
+            # states advanced by the first two groups are put back: repeating update 2's continuation gives the same numbers
+            before = eng.get_state(300, "pe", 1)
+            sims = [capi.make_sim(300 + k, "pe", 1, s, nss=10) for k, s in enumerate(strains(0))]
+            sims[4].timestep_length = 60.0
+            with pytest.raises(capi.EngineError):
+                eng.strain_batch(sims)
+            after = eng.get_state(300, "pe", 1)
+            assert np.array_equal(before[1], after[1]) and np.array_equal(before[2], after[2]) and np.array_equal(before[0], after[0])
+        res[mb] = out
+        eng.close()
+    for u in range(2):
+        err = np.abs(res[0][u] - res[2][u]).max() / np.abs(res[0][u]).max()
+        assert err < 1e-9, (u, err)

@@ -11,8 +11,11 @@ from oracle import pyoracle as po
 KW = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0)
 
 
-def _run(d, acc, pppm):
-    o = po.Oracle(d, po.default_params(kspace_accuracy=acc, kspace_pppm=1 if pppm else 0, **KW))
+def _run(d, acc, pppm, mesh=None):
+    p = po.default_params(kspace_accuracy=acc, kspace_pppm=1 if pppm else 0, **KW)
+    if mesh is not None:
+        p.pppm_mesh[:] = list(mesh)
+    o = po.Oracle(d, p)
     o.setup(False)
     f, e, w = o.compute()
     return o, f, e, w
@@ -48,14 +51,17 @@ def _factorable(n):
 
 def test_pppm_in_a_triclinic_cell_equals_its_lattice_equivalent(small_pe):
     """xy = +lx/2 and xy = -lx/2 (atoms unchanged) are two representations of one lattice (what a box flip switches between): the
-    mesh sum, done in lamda coordinates, must not care beyond its own discretisation error (the two grids cut space differently)"""
+    mesh sum, done in lamda coordinates, must not care beyond its own discretisation error (the two grids cut space differently).
+    Both on the grid the rule gives the first one (`kspace_modify mesh`): set_grid_global's triclinic rescaling depends on the
+    SIGN of the tilt (int(xy nx / xprd + ny) + 1), so left to itself the second representation would get a much coarser grid."""
     from copy import deepcopy
     d1, d2 = deepcopy(small_pe), deepcopy(small_pe)
     lx = d1["box"][3] - d1["box"][0]
     d1["box"][6] = 0.5 * lx
     d2["box"][6] = -0.5 * lx
     o1, f1, e1, _ = _run(d1, 1e-6, True)
-    o2, f2, e2, _ = _run(d2, 1e-6, True)
+    o2, f2, e2, _ = _run(d2, 1e-6, True, mesh=o1.pppm_grid)
+    assert o2.pppm_grid == o1.pppm_grid
     frms = np.sqrt((f1 ** 2).sum(1).mean())
     assert np.sqrt(((f1 - f2) ** 2).sum(1).mean()) < 2e-5 * frms
     assert abs((e1[1] + e1[6]) - (e2[1] + e2[6])) < 2e-3
@@ -72,3 +78,50 @@ def test_pppm_short_trajectory_conserves_energy_like_the_ewald_run(small_pe):
         et = tr[:, 1] + tr[:, 2]
         res.append(np.abs(et - et[0]).max() / tr[:, 2].mean())
     assert res[1] < 5e-3 and res[1] < 5.0 * res[0] + 1e-3          # ik differentiation is not exactly conservative, but close
+
+
+def _estimate_ik_error(h, prd, g, q2, natoms):
+    acons = [1.0 / 23232.0, 7601.0 / 13628160.0, 143.0 / 69120.0, 517231.0 / 106536960.0, 106640677.0 / 11737571328.0]
+    s = sum(a * (h * g) ** (2.0 * m) for m, a in enumerate(acons))
+    return q2 * (h * g) ** 5.0 * np.sqrt(g * prd * np.sqrt(2.0 * np.pi) * s / natoms) / (prd * prd)
+
+
+def _set_grid_global(box, g, acc, q2, natoms):
+    """PPPM::set_grid_global of pppm.cpp (17Nov16, ik, triclinic) restated a second time, line by line, in Python: the search
+    starts at int(prd g) + 1 with h = 1 / g, the increment FOLLOWS the evaluation (one past the first admissible grid), the
+    triclinic rescaling int(lamda2xT(n / prd)) + 1, then products of 2, 3, 5."""
+    lo, hi, (xy, xz, yz) = box[:3], box[3:6], box[6:9]
+    prd = hi - lo
+    n = []
+    for d in range(3):
+        h = 1.0 / g
+        nd = int(prd[d] / h) + 1
+        err = _estimate_ik_error(h, prd[d], g, q2, natoms)
+        while err > acc:
+            err = _estimate_ik_error(h, prd[d], g, q2, natoms)
+            nd += 1
+            h = prd[d] / nd
+        n.append(nd)
+    t = [n[0] / prd[0], n[1] / prd[1], n[2] / prd[2]]
+    u = [prd[0] * t[0], xy * t[0] + prd[1] * t[1], xz * t[0] + yz * t[1] + prd[2] * t[2]]
+    n = [int(v) + 1 for v in u]
+    return tuple(next(m for m in range(v, 10 * v + 8) if _factorable(m)) for v in n)
+
+
+@pytest.mark.parametrize("tilt", [(0.0, 0.0, 0.0), (0.7, -0.4, 0.5), (-0.7, 0.4, -0.5), (3.0, 0.0, 0.0)])
+@pytest.mark.parametrize("acc", [1e-4, 1e-5])
+def test_grid_follows_set_grid_global(small_pe, tilt, acc):
+    """The oracle's C restatement against the Python one above, for boxes whose tilts push the triclinic rescaling both ways,
+    and one hand-checked property: the result is never below the first admissible grid + 1 per dimension when the search ran."""
+    from copy import deepcopy
+    d = deepcopy(small_pe)
+    d["box"][6:9] = tilt
+    o = po.Oracle(d, po.default_params(kspace_accuracy=acc, kspace_pppm=0, **KW))
+    o.setup(False)
+    g0 = o.g_ewald                                     # the initial estimate (the Ewald path keeps it)
+    q2 = float((np.asarray(d["charge"]) ** 2).sum()) * 332.06371
+    exp = _set_grid_global(np.asarray(d["box"], float), g0, acc * 332.06371, q2, d["natoms"])
+    op, *_ = _run(d, acc, True)
+    assert op.pppm_grid == exp, (op.pppm_grid, exp)
+    # adjust_gewald stops at the first Newton iterate with |f| < 1e-5: the residual is small but not converged to round-off
+    assert op.g_ewald != g0

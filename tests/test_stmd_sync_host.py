@@ -110,7 +110,8 @@ rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 nin = sys.argv[2]
 s = stmd.STMDSync(None, rank, world, stmd.torch_allgather(None, rank, world))
-s.init(nanostatelocin=nin, nrepl=2, approx_md_with_hookes_law=True)
+nrepl = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+s.init(nanostatelocin=nin, nrepl=nrepl, approx_md_with_hookes_law=True)
 strains = np.load(sys.argv[3])
 got = s.update(1, 0.0, 1, [(i, i, 0, strains[i]) for i in range(len(strains))])
 np.save(sys.argv[4] + f".{rank}.npy", got)
@@ -137,3 +138,20 @@ def test_ranks_share_stresses_with_one_allgather(tmp_path, world):
     for rank in range(world):
         got = np.load(str(tmp_path / "out") + f".{rank}.npy")
         assert np.allclose(got, exp, rtol=1e-13, atol=1e-6)
+
+
+def test_one_simulation_on_two_ranks_does_not_deadlock(tmp_path):
+    """an update whose every simulation lands on ONE rank (a one-point update_list with one replica)
+    must still be collective -- whether the all-gather runs is decided by (world, mode), never by a rank's own results."""
+    nin, reps = _setup(tmp_path, nrepl=1)
+    rng = np.random.default_rng(11)
+    strains = rng.normal(0, 1e-3, (1, 6))
+    np.save(tmp_path / "strains.npy", strains)
+    (tmp_path / "worker.py").write_text(WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(tmp_path / "worker.py"), ROOT, nin, str(tmp_path / "strains.npy"), str(tmp_path / "out"), "1"]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = _expected(reps, strains)
+    for rank in range(2):
+        assert np.allclose(np.load(str(tmp_path / "out") + f".{rank}.npy"), exp, rtol=1e-13, atol=1e-6)
