@@ -13,6 +13,10 @@ scema_md_strain_batch, so the total work per step is fixed ("strong" scaling).
 `python bench.py --gpus N` without RANK in the environment starts the N ranks itself (before anything
 touches a GPU) and fails if the node has fewer than N devices.
 
+`--force-field reax` runs BASELINE config 5 instead: 72 replicas of a 1 620-atom polyethylene cell with md_force_field "reax"
+(lammps_scripts_reax: ffield.reax.2, QEq to 1e-6 every step, dt 0.25 fs, 10 + 20 MD steps per evaluation), same JSON contract,
+with the roofline block of its HBM-bound kernel (the matrix sweep of the charge equilibration) and its own CPU baseline.
+
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
 import argparse
@@ -68,6 +72,51 @@ def _lammps_baseline(lmp, scripts, cells, strains, nss, ncore):
     return ncore / dt, dt
 
 
+def _host_cores(per_process_gb, cap=None):
+    """processes the CPU baseline may start: every host core, unless memory (or a cap) says fewer"""
+    n = os.cpu_count() or 1
+    try:
+        import psutil
+        n = min(n, max(1, int(psutil.virtual_memory().available / 2**30 / per_process_gb * 0.6)))
+    except Exception:
+        pass
+    return max(1, min(n, cap) if cap else n)
+
+
+def _cpu_eval_reax(k, cells, strain, nss, dt, rate):
+    """one evaluation of the ReaxFF oracle (oracle/reax_md.py) in a worker process, one thread"""
+    import torch
+    torch.set_num_threads(1)
+    from oracle import reax_md
+    from scema_amd.systems import build_pe
+    d = build_pe(*cells)
+    sym = ["C" if d["mass"][t] > 5 else "H" for t in d["type"]]
+    lt = np.array([1 if c == "C" else 0 for c in sym])
+    m = np.array([12.011 if c == "C" else 1.008 for c in sym])
+    v = np.random.default_rng(3).standard_normal((len(sym), 3)) * np.sqrt(0.0019872067 * 300.0 / (m[:, None] * 48.88821291 ** 2))
+    v -= (m[:, None] * v).sum(0) / m.sum()
+    M = reax_md.ReaxMD(os.path.join(ROOT, "tests", "golden", "ffield.reax.2"), ["H", "C", "N", "O"], lt, [1.008, 12.011, 14.007, 15.999], d["box"], d["x"], v)
+    t0 = time.time()
+    _, nts = M.eval(strain, dt, 300.0, rate, nss)
+    return k, t0, time.time(), int(nts), M.qeq_iters / max(M.qeq_solves, 1)
+
+
+def cpu_baseline_reax(cells, strains, nss, dt, rate):
+    """The ReaxFF oracle timed on the host cores, one single-threaded process per core (capped at 64: every process holds a
+    reverse-mode graph of ~0.6 GB): CPU restatement (oracle/reax_md.py: torch FP64 autograd forces + CG), NOT LAMMPS."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    ncore = min(_host_cores(1.0, cap=64), len(strains))
+    with cf.ProcessPoolExecutor(max_workers=ncore, mp_context=mp.get_context("spawn")) as ex:
+        res = list(ex.map(_cpu_eval_reax, range(ncore), [cells] * ncore, [strains[k] for k in range(ncore)], [nss] * ncore, [dt] * ncore, [rate] * ncore))
+    dtw = max(r[2] for r in res) - min(r[1] for r in res)
+    natoms = 12 * cells[0] * cells[1] * cells[2]
+    return {"value": ncore / dtw, "unit": "evals/s", "cores": ncore, "kind": "port", "lammps_on_this_host": None,
+            "sample": f"{ncore} PE-{natoms} ReaxFF evaluations ({res[0][3]}+{nss} MD steps each, {res[0][4]:.1f} CG iterations per solve), one single-threaded process "
+                      f"per host core on {ncore} of {os.cpu_count()} cores: {dtw:.1f} s wall, {np.mean([r[2] - r[1] for r in res]):.1f} s mean per evaluation; "
+                      "CPU restatement (oracle/reax_md.py), not LAMMPS USER-REAXC"}
+
+
 def cpu_baseline(cells, strains, nss, pppm=1):
     """The CPU path timed on the host cores the way the reference runs it: one serial MD engine per core, one replica each
     (stmd_sync.h:189-278 with n_sims >= ranks).  If a LAMMPS executable and the reference's scripts ($SCEMA_SCRIPTS) are on
@@ -76,7 +125,7 @@ def cpu_baseline(cells, strains, nss, pppm=1):
     import concurrent.futures as cf
     import multiprocessing as mp
     import shutil
-    ncore = max(1, min(len(strains), os.cpu_count() or 1, 32))
+    ncore = max(1, min(len(strains), _host_cores(0.4)))   # every host core (no cap), memory permitting
     lmp = next((shutil.which(n) for n in (os.environ.get("SCEMA_LAMMPS") or "lmp", "lmp_serial", "lmp_mpi", "lammps") if shutil.which(n)), None)
     scripts = os.environ.get("SCEMA_SCRIPTS", "")
     natoms = 12 * cells[0] * cells[1] * cells[2]
@@ -102,10 +151,26 @@ def cpu_baseline(cells, strains, nss, pppm=1):
                       f"kspace {tm['kspace']:.1f} s, neigh {tm['neigh']:.1f} s); CPU restatement (oracle/md_oracle.c), not LAMMPS"}
 
 
+def count_gpus_without_hip():
+    """GPUs of this node from the KFD topology in sysfs (nodes with SIMDs; CPUs have simd_count 0): the parent that forks the rank
+    launcher must not have opened /dev/kfd, and torch.cuda.device_count() falls back to hipGetDeviceCount where amdsmi is absent."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except OSError:
+            pass
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if vis:
+        n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args):
     """--gpus N from a plain shell: start N ranks (torch.distributed.run) BEFORE any GPU call in this process."""
-    import torch
-    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    have = count_gpus_without_hip()
     if have < args.gpus and not args.share_gpus:
         print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
         return 2
@@ -135,10 +200,20 @@ def main():
     ap.add_argument("--kspace", default="pppm", choices=["pppm", "ewald"], help="reciprocal part: PPPM (order 5, ik, hipFFT) as the reference's "
                     "`kspace_style pppm 0.0001` asks for (default, the reported configuration) or the plain Ewald sum at the same accuracy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-field", default="opls", choices=["opls", "reax"],
+                    help="opls: the headline workload (576 x PE-10k); reax: BASELINE config 5, 72 x PE-1620 ReaxFF replicas (--sims / --cells / --nss default to that)")
+    ap.add_argument("--monotonic-updates", type=int, default=4, help="after the timed loop, this many all-tensile updates (the SURVEY 8(d) set as written) are "
+                    "timed as well and reported as config.strain_set_monotonic_evals_per_s (0: skip; never part of `value`)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
     ap.add_argument("--share-gpus", action="store_true", help="tests: let several ranks share a GPU (needs --dist-backend gloo)")
     args = ap.parse_args()
+    if args.force_field == "reax":   # the replica set of BASELINE config 5, unless the command line says otherwise
+        given = " ".join(sys.argv[1:])
+        if "--sims" not in given: args.sims = 72
+        if "--cells" not in given: args.cells = [3, 5, 9]
+        if "--nss" not in given: args.nss = 20
+        if "--equil-steps" not in given: args.equil_steps = 200
 
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
@@ -150,14 +225,21 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     from scema_amd.systems import build_pe, synthetic_strains
-    d = build_pe(*args.cells, shake_project=True)   # seed 1234, 300 K, SHAKE-projected velocities
+    reax = args.force_field == "reax"
+    DT = 0.25 if reax else 2.0                      # fs; ReaxFF needs the short step (bond orders change within femtoseconds)
+    d = build_pe(*args.cells, shake_project=not reax)   # seed 1234, 300 K, SHAKE-projected velocities
     lens = d["box"][3:6] - d["box"][:3]
     n = args.sims
+    rate = 1e-3 if reax else (2e-4 if args.strain_set == "file3d" else 1e-4)
 
     # CPU baseline first: its worker processes start while nothing in this process has touched the GPU
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(tuple(args.cells), synthetic_strains(32, lens, seed=2026), args.nss, 1 if args.kspace == "pppm" else 0)
+        ncpu = os.cpu_count() or 1
+        if reax:
+            cpu = cpu_baseline_reax(tuple(args.cells), synthetic_strains(max(ncpu, 8), lens, seed=2026), args.nss, DT, rate)
+        else:
+            cpu = cpu_baseline(tuple(args.cells), synthetic_strains(max(ncpu, 32), lens, seed=2026), args.nss, 1 if args.kspace == "pppm" else 0)
 
     import torch
     import torch.distributed as dist
@@ -182,6 +264,15 @@ def main():
         (comm.attach_rccl if args.dist_backend == "nccl" else comm.attach_gloo)(eng, rank, world)
 
     # ---- equilibrated replica (outside the timed region): rank 0 runs it, every rank registers the same state ----
+    if reax:
+        # atom_style charge, types H C N O as pair_coeff names them; ffield.reax.2 is the reference's own parameter file
+        # (lammps_scripts_reax/ffield.reax.2; tests/golden holds it as a data fixture, the reference tree is not on the GPU box)
+        sym = ["C" if d["mass"][t] > 5 else "H" for t in d["type"]]
+        m = np.array([12.011 if c == "C" else 1.008 for c in sym])
+        v0 = np.random.default_rng(3).standard_normal((len(sym), 3)) * np.sqrt(0.0019872067 * 300.0 / (m[:, None] * 48.88821291 ** 2))
+        v0 -= (m[:, None] * v0).sum(0) / m.sum()
+        d = capi.reax_system(sym, d["x"], d["box"], v=v0)
+        eng.reax_configure(os.path.join(ROOT, "tests", "golden", "ffield.reax.2"), qeq_tol=1e-6)
     eng.register_replica("g0", 1, d)
     if args.equil_steps > 0:
         state = [None]
@@ -190,7 +281,7 @@ def main():
             state[0] = (z["box"], z["x"], z["v"])
         elif rank == 0:
             eng.set_state(EQ_QP, "g0", 1, d["box"], d["x"], d["v"])
-            eng.debug_run("g0", 1, args.equil_steps, 2.0, 300.0, qp=EQ_QP, nvt=True, use_shake=True)
+            eng.debug_run("g0", 1, args.equil_steps, DT, 300.0, qp=EQ_QP, nvt=True, use_shake=not reax)   # reax_configure selected the ReaxFF stage
             state[0] = eng.get_state(EQ_QP, "g0", 1)
             if args.equil_cache:
                 np.savez(args.equil_cache, box=state[0][0], x=state[0][1], v=state[0][2])
@@ -206,7 +297,7 @@ def main():
     # stmd_sync.h:491-568) is built once; every update only rewrites the strains and most_recent ids in place.
     import ctypes
     req = {"arr": None}
-    rate = 2e-4 if args.strain_set == "file3d" else 1e-4
+    mono = {"on": args.monotonic}
 
     def requests(istep):
         strains = synthetic_strains(n, lens, seed=2026 + istep, scale=(5.0 if args.strain_set == "file3d" else 1.0),
@@ -216,10 +307,11 @@ def main():
         # more often: a different workload at the end than at the start).  Odd updates therefore take the draw with the
         # opposite sign (a load/unload cycle): same magnitudes, same nts, and every update sees a replica within one
         # strain increment of the equilibrated state.
-        if istep % 2 == 1 and not args.monotonic:
+        if istep % 2 == 1 and not mono["on"]:
             strains = -strains
         if req["arr"] is None:
-            sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=capi.QP_NONE, strain_rate=rate) for q in range(n)]
+            sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=capi.QP_NONE, strain_rate=rate, dt=DT,
+                                  force_field=args.force_field) for q in range(n)]
             arr = (capi.MDSim * n)(*sims)
             raw = np.frombuffer(arr, dtype=np.uint8).reshape(n, ctypes.sizeof(capi.MDSim))
             o_s, o_m = capi.MDSim.strain.offset, capi.MDSim.most_recent_qp_id.offset
@@ -228,7 +320,7 @@ def main():
         # straining steps per replica (reference stmd_problem.h:222-232): nts = max(ceil(|eps|_F / rate / dt / 10) * 10, 10)
         true = np.asarray(strains, float) / np.array([lens[0], lens[1], lens[2], lens[2], lens[1], lens[0]])
         fro = np.sqrt((true[:, :3] ** 2).sum(1) + 2.0 * (true[:, 3:] ** 2).sum(1))
-        req["nts_mean"] = float(np.maximum(np.ceil(fro / rate / 2.0 / 10.0) * 10.0, 10.0).mean())
+        req["nts_mean"] = float(np.maximum(np.ceil(fro / rate / DT / 10.0) * 10.0, 10.0).mean())
         req["recent"][:, 0] = capi.QP_NONE if istep == 0 else np.arange(n, dtype=np.int32)
         return req["arr"]
 
@@ -262,6 +354,25 @@ def main():
     prof = eng.profile()
     comm = eng.comm_stats()
     owner, _, cap = eng.last_plan(n)
+    nts_mean = req.get("nts_mean", 10.0)
+    rstat = eng.reax_stats() if reax else None
+
+    # The SURVEY 8(d) strain set AS WRITTEN (every draw tensile, update after update) next to the load/unload cycle of the
+    # headline: a few more updates from the state the timed loop left, timed the same way, never part of `value`.
+    mono_rate = None
+    if args.monotonic_updates > 0 and not args.monotonic and args.strain_set == "balanced":
+        mono["on"] = True
+        fence()
+        tm0 = time.perf_counter()
+        for k in range(args.monotonic_updates):
+            update(args.warmup + args.steps + k)
+        fence()
+        tm = time.perf_counter() - tm0
+        if world > 1:
+            t = torch.tensor([tm], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tm = float(t.item())
+        mono_rate = n * args.monotonic_updates / tm
 
     if rank == 0:
         natoms = int(d["natoms"])
@@ -303,17 +414,47 @@ def main():
                             "issue_time_ms": 1e3 * insts * cyc / (nsimd * clk), "frac": insts * cyc / (nsimd * clk) / avg_launch_s if avg_launch_s > 0 else 0.0,
                             "note": "vector instructions of one launch (SQ_INSTS_VALU, PMC pass under profiles/) priced at the FP64 rate of 4 cycles per "
                                     "wave instruction on a SIMD-32, over the launch time measured here: the bound that binds (HBM does not)"}
+        workload = (f"{n} x PE-{natoms} OPLS replicas per update(), {nts_mean:.0f}+{args.nss} MD steps each "
+                    "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + " + ("PPPM" if args.kspace == "pppm" else "Ewald") + " 1e-4 + SHAKE + NVT), persistent per-QP state, "
+                    f"replica equilibrated for {args.equil_steps} steps before the timed region")
+        if reax:
+            # k_rx_qeq_sweep, the HBM-bound kernel of this path: per launch it reads, for every replica that still
+            # iterates, each stored matrix entry once (8 B value + 4 B column index) and per row 84 B (row length 4, own
+            # preconditioned residual pair 16, search direction and product pairs read + written 64); the gathered pairs of the
+            # columns are cache traffic by design and not counted.  Entries and rows are counted on the device per sweep taken part in.
+            sw_s = prof["rx_sweep_ms"] * 1e-3
+            sw_n = max(prof["rx_sweep_launches"], 1)
+            sw_bytes = 12.0 * prof["rx_sweep_entries"] + 84.0 * prof["rx_sweep_rows"]
+            achieved = sw_bytes / sw_s / 1e9 if sw_s > 0 else 0.0
+            pmc = None
+            ppath = os.path.join(ROOT, "profiles", "reax_pmc.json")
+            if os.path.exists(ppath):
+                pmc = json.load(open(ppath))
+            roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "traffic": (pmc or {}).get("hbm_bytes_per_full_sweep_corrected"), "traffic_source": (pmc or {}).get("source"),
+                    "kernel": "k_rx_qeq_sweep (charge equilibration: y = H z for both conjugate-gradient systems, one pass over the stored matrix rows)",
+                    "accounting": "achieved = (12 B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
+                                  "device) / HIP-event time of all launches of the kernel on the engine's stream (launches that find every replica converged "
+                                  "cost time and move nothing); traffic = counter bytes of ONE sweep over the whole batch (profiles/reax_pmc.json)",
+                    "launches": prof["rx_sweep_launches"], "avg_launch_ms": 1e3 * sw_s / sw_n, "alg_bytes_per_launch": sw_bytes / sw_n,
+                    "alg_bytes_per_full_sweep": sw_bytes / max(prof["rx_sweep_rows"] / natoms, 1.0) * per_rank,   # one sweep over every replica of this rank
+                    "stored_entries_per_row": prof["rx_sweep_entries"] / max(prof["rx_sweep_rows"], 1.0),
+                    "rank0_sweep_share_of_wall": sw_s / elapsed,
+                    "qeq_iterations_per_solve": rstat["qeq_iters"] / max(rstat["qeq_solves"], 1)}
+            workload = (f"{n} x PE-{natoms} ReaxFF replicas per update() (md_force_field reax: ffield.reax.2 with H C N O, fix qeq/reax to 1e-6 every step), "
+                        f"{nts_mean:.0f}+{args.nss} MD steps each (dt {DT} fs, 300 K, NVT, fix deform), persistent per-QP state, replica equilibrated for "
+                        f"{args.equil_steps} steps before the timed region")
         out = {
             "metric": "stress_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n} x PE-{natoms} OPLS replicas per update(), {req.get('nts_mean', 10.0):.0f}+{args.nss} MD steps each "
-                                   "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + " + ("PPPM" if args.kspace == "pppm" else "Ewald") + " 1e-4 + SHAKE + NVT), persistent per-QP state, "
-                                   f"replica equilibrated for {args.equil_steps} steps before the timed region",
-                       "strain_set": args.strain_set + (" (monotonic)" if args.monotonic else " (load/unload: odd updates take the draw with the opposite sign)"), "n_sims": n, "atoms_per_replica": natoms, "md_steps_per_eval": req.get("nts_mean", 10.0) + args.nss,
+            "config": {"workload": workload, "force_field": args.force_field,
+                       "strain_set": args.strain_set + (" (monotonic)" if args.monotonic else " (load/unload: odd updates take the draw with the opposite sign)"),
+                       "strain_set_monotonic_evals_per_s": mono_rate, "strain_set_monotonic_updates": args.monotonic_updates if mono_rate else 0,
+                       "n_sims": n, "atoms_per_replica": natoms, "md_steps_per_eval": nts_mean + args.nss,
                        "sharding": "engine planner (host/sim_plan.h): fresh batch i % N, then sticky to the GPU that holds the state, levelled by MD steps",
                        "sims_on_rank0": int((owner == 0).sum()), "collective": ("ncclAllGather inside scema_md_strain_batch" if args.dist_backend == "nccl" else "host transport (gloo)") if world > 1 else None,
-                       "allgathers": comm["allgathers"], "state_migrations": comm["migrations"],
+                       "allgathers": comm["allgathers"], "handshakes": comm["handshakes"], "state_migrations": comm["migrations"],
                        "stress_zz_checksum_Pa": checksum,
                        "list_skin_A": prof.get("list_skin_mean", 0.0),
                        "steps_per_list_rebuild": prof["md_steps"] / max(prof["neigh_builds"], 1)},

@@ -339,6 +339,12 @@ typedef struct {
   double list_skin_mean;      /* mean neighbour-list skin of those evaluations: params.skin + the adaptive extra (performance only) */
   int64_t pair_sims;          /* simulations summed over the timed pair launches (a large batch runs as two half batches) */
   int64_t box_flips;          /* triclinic box flips applied during straining runs (fix deform, default flip yes) */
+  /* force_field "reax": the matrix sweep of the charge equilibration (k_rx_qeq_sweep), the HBM-bound kernel of that path */
+  int64_t rx_sweep_launches;  /* timed launches */
+  double rx_sweep_ms;         /* sum of their HIP-event durations */
+  double rx_sweep_entries;    /* stored matrix entries those launches passed over (per replica: entries of its rows x sweeps it took
+                               * part in); algorithmic bytes = 12 per entry (8 value + 4 column) + 84 per row */
+  double rx_sweep_rows;       /* rows likewise */
 } scema_md_profile;
 int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset);
 

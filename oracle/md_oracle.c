@@ -471,6 +471,7 @@ void omd_last_timing(const omd_sim *s, double t[4]) {
  * transforms for the field, forces by the same weights.  Grid and g_ewald: set_grid_global / adjust_gewald with the loop
  * structure of pppm.cpp (see pppm_setup below).  Transforms are plain O(n^2) sums per line. */
 #define PPPM_ORDER 5
+#define PPPM_GRID_GUARD 1.0e-9
 static const double ACONS5[5] = {1.0 / 23232.0, 7601.0 / 13628160.0, 143.0 / 69120.0, 517231.0 / 106536960.0, 106640677.0 / 11737571328.0};
 
 static double pppm_ik_error(double h, double prd, double g, double q2, double natoms) {
@@ -509,7 +510,8 @@ static double pppm_f(const omd_sim *s, const boxq *b, double g, double q2, const
  *    -- the increment follows the evaluation, so the loop leaves n ONE PAST the first grid whose estimate is admissible
  *    (or at the start value if E(1/g) already is);
  *  - a triclinic box (the reference's replicas always are one: in.init.lammps:27 `change_box all triclinic`) rescales:
- *    n = int(lamda2xT(n / prd)) + 1 -- with zero tilts that is n or n + 1 depending on how (n / prd) * prd rounds;
+ *    n = int(lamda2xT(n / prd)) + 1 -- with zero tilts that is n or n + 1 depending on how (n / prd) * prd rounds (guarded
+ *    here, see below);
  *  - raise each n to a product of 2, 3, 5;
  *  - g_ewald: Newton steps with a forward-difference derivative of step 1e-6, stopping at the first iterate with
  *    |f| < SMALL = 1e-5 (not at convergence). */
@@ -534,7 +536,11 @@ static void pppm_setup(omd_sim *s, const boxq *b, double accuracy, double q2) {
   if (triclinic && !gridflag) {
     const double t0 = n[0] / b->h[0], t1 = n[1] / b->h[1], t2 = n[2] / b->h[2];
     const double u0 = b->h[0] * t0, u1 = b->h[5] * t0 + b->h[1] * t1, u2 = b->h[4] * t0 + b->h[3] * t1 + b->h[2] * t2;
-    n[0] = (int)u0 + 1; n[1] = (int)u1 + 1; n[2] = (int)u2 + 1;
+    /* (n / prd) * prd is n or one ulp beside it, so without a tilt contribution the truncation is a coin flip on the last bit
+     * of the box length (a 1e-12 change of the box moves a grid by one).  A guard of 1e-9 grid points decides such cases as
+     * exact arithmetic would (n + 1, also LAMMPS' answer whenever the product rounds to n or above): the one place where this
+     * restatement is deliberately not bit-faithful, because a checker cannot be a coin flip. */
+    n[0] = (int)(u0 + PPPM_GRID_GUARD) + 1; n[1] = (int)(u1 + PPPM_GRID_GUARD) + 1; n[2] = (int)(u2 + PPPM_GRID_GUARD) + 1;
   }
   for (int d = 0; d < 3; d++) {
     while (!pppm_factorable(n[d])) n[d]++;

@@ -421,7 +421,8 @@ class ReaxEnergy:
         tot, parts = self.energy(types, xt, box, qt, strain=eps, pairs=pairs)
         grads = torch.autograd.grad(tot, [xt] + ([eps] if virial else []))
         f = -grads[0].numpy()
-        parts = {k: float(v) for k, v in parts.items()}
+        parts = {k: float(v.detach()) for k, v in parts.items()}
+        tot = tot.detach()
         if not virial:
             return f, float(tot), parts
         g = grads[1].numpy()

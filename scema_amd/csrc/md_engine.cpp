@@ -195,6 +195,9 @@ struct Profile {
   double unique_pairs_sum = 0;
   long long unique_pairs_n = 0;
   double skin_sum = 0;
+  // ReaxFF: launches of k_rx_qeq_sweep
+  long long rx_sweep_launches = 0;
+  double rx_sweep_ms = 0, rx_sweep_entries = 0, rx_sweep_rows = 0;
 };
 
 }  // namespace
@@ -846,11 +849,12 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
 //     iterate with |f| < 1e-5.
 // The oracle restates the same routine on its own (oracle/md_oracle.c pppm_setup). ----
 static double pppm_ik_error(double h, double prd, double g, double q2, double natoms) {
+  // estimate_ik_error with the arithmetic of pppm.cpp (pow, not repeated multiplication): g_ewald comes out of a Newton step with
+  // a forward difference of 1e-6, which amplifies the last bits of this function a millionfold
   static const double ACONS5[5] = {1.0 / 23232.0, 7601.0 / 13628160.0, 143.0 / 69120.0, 517231.0 / 106536960.0, 106640677.0 / 11737571328.0};
-  const double hg = h * g, hg2 = hg * hg;
-  double sum = 0.0, pw = 1.0;   // powers by multiplication: this runs a few dozen times per simulation and run
-  for (int m = 0; m < 5; m++) { sum += ACONS5[m] * pw; pw *= hg2; }
-  return q2 * (hg2 * hg2 * hg) * std::sqrt(g * prd * std::sqrt(2.0 * MD_PI) * sum / natoms) / (prd * prd);
+  double sum = 0.0;
+  for (int m = 0; m < 5; m++) sum += ACONS5[m] * std::pow(h * g, 2.0 * m);
+  return q2 * std::pow(h * g, 5.0) * std::sqrt(g * prd * std::sqrt(2.0 * MD_PI) * sum / natoms) / (prd * prd);
 }
 static void pppm_setup_host(const scema_md_params &p, const Topo &t, const double *box, double &g, int pg[3]) {
   HostBox b;
@@ -872,7 +876,10 @@ static void pppm_setup_host(const scema_md_params &p, const Topo &t, const doubl
   {
     const double t0 = n[0] / b.h[0], t1 = n[1] / b.h[1], t2 = n[2] / b.h[2];
     const double u0 = b.h[0] * t0, u1 = b.h[5] * t0 + b.h[1] * t1, u2 = b.h[4] * t0 + b.h[3] * t1 + b.h[2] * t2;
-    n[0] = (int)u0 + 1; n[1] = (int)u1 + 1; n[2] = (int)u2 + 1;
+    // (n / prd) * prd is n or one ulp beside it: without a tilt contribution the truncation would be a coin flip on the last bit of
+    // the box length.  Decided as exact arithmetic would (the oracle carries the same guard; DESIGN.md section 2, deviation 1).
+    const double guard = 1.0e-9;
+    n[0] = (int)(u0 + guard) + 1; n[1] = (int)(u1 + guard) + 1; n[2] = (int)(u2 + guard) + 1;
   }
   for (int d = 0; d < 3; d++) {
     n[d] = std::max(n[d], 2);
@@ -3596,6 +3603,10 @@ int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t rese
   out->list_skin_mean = e->prof.evals ? e->prof.skin_sum / (double)e->prof.evals : 0.0;
   out->pair_sims = e->prof.pair_sims;
   out->box_flips = e->prof.box_flips;
+  out->rx_sweep_launches = e->prof.rx_sweep_launches;
+  out->rx_sweep_ms = e->prof.rx_sweep_ms;
+  out->rx_sweep_entries = e->prof.rx_sweep_entries;
+  out->rx_sweep_rows = e->prof.rx_sweep_rows;
   if (reset) e->prof = Profile();
   return SCEMA_MD_OK;
 }

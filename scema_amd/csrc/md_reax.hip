@@ -432,7 +432,15 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
     sh[3 * np + i] = sh[2 * np + i]; sh[2 * np + i] = sh[np + i]; sh[np + i] = sh[i]; sh[i] = s[i];
     th[2 * np + i] = th[np + i]; th[np + i] = th[i]; th[i] = t[i];
   }
+  // what the launched sweeps of this solve read: every stored entry of the replica's rows once per sweep it took part in
+  // (the launches counted by k_rx_qeq_update, plus the first product H x0)
+  double nent = 0.0, nrow = 0.0;
+  for (int i = tid; i < n; i += QEQ_TPB) { nent += (double)V.nb_cnt[i]; nrow += 1.0; }
+  qeq_reduce2(nent, nrow, s_red);
   if (tid == 0) {
+    const long long sweeps = (long long)(V.qstat[0] - V.qstat[4]) + 1;
+    V.sweep_acc[0] += sweeps * (long long)(nent + 0.5);
+    V.sweep_acc[1] += sweeps * (long long)n;
     const int total = V.qstat[0] + it;   // k_rx_qeq_update counted the launched iterations this replica took part in
     V.qstat[0] = total;
     V.qstat[1] += 1;
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(TPB) void k_rx_phase_init(const RxView *views) {
     for (int k = 0; k < 4; k++) V.s_hist[(size_t)k * V.npad + i] = 0.0;
     for (int k = 0; k < 3; k++) V.t_hist[(size_t)k * V.npad + i] = 0.0;
   }
-  if (i == 0) { for (int k = 0; k < 6; k++) V.qstat[k] = 0; *V.overflow = 0; }
+  if (i == 0) { for (int k = 0; k < 6; k++) V.qstat[k] = 0; *V.overflow = 0; V.sweep_acc[0] = 0; V.sweep_acc[1] = 0; }
 }
 
 static inline dim3 g2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)ns, 1); }
@@ -592,18 +600,28 @@ void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad) {
   hipLaunchKernelGGL(k_rx_phase_init, g2(cdv(maxpad, TPB), ns), dim3(TPB), 0, st, v);
 }
 void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int qeq_launch,
-                     int terms) {
+                     int terms, std::vector<hipEvent_t> *ev, size_t *ev_used) {
+  // a HIP-event pair around every launch of the matrix sweep when the caller profiles (bench.py's roofline block)
+  auto sweep = [&](int it) {
+    const dim3 gk = g2(cdv(maxatoms, 64), ns);
+    if (ev) {
+      while (*ev_used + 2 > ev->size()) { hipEvent_t a; if (hipEventCreate(&a) != hipSuccess) { ev = nullptr; break; } ev->push_back(a); }
+    }
+    if (ev) (void)hipEventRecord((*ev)[*ev_used], st);
+    hipLaunchKernelGGL(k_rx_qeq_sweep, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
+    if (ev) { (void)hipEventRecord((*ev)[*ev_used + 1], st); *ev_used += 2; }
+  };
   const dim3 ga = g2(cdv(maxatoms, TPB), ns), gr = g2(cdv(maxatoms, RX_TPB), ns), gk = g2(cdv(maxatoms, 64), ns), gu = g2(cdv(maxatoms, QEQ_UT), ns);
   hipLaunchKernelGGL(k_rx_prepare, dim3(ns), dim3(64), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_wrap, ga, dim3(TPB), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_neigh, ga, dim3(TPB), 0, st, d, v, rlist);
   hipLaunchKernelGGL(k_rx_hrow, gk, dim3(RX_KT), 0, st, d, v, P);
   hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v);
-  hipLaunchKernelGGL(k_rx_qeq_sweep, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, -1);
+  sweep(-1);
   hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, -1);
   const int nlaunch = qeq_launch < qeq_maxiter ? qeq_launch : qeq_maxiter;
   for (int it = 0; it < nlaunch; it++) {
-    hipLaunchKernelGGL(k_rx_qeq_sweep, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
+    sweep(it);
     hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, it);
   }
   hipLaunchKernelGGL(k_rx_qeq_finish, dim3(ns), dim3(QEQ_TPB), 0, st, d, v, P, qeq_tol, nlaunch, qeq_maxiter);

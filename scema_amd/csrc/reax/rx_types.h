@@ -102,4 +102,6 @@ typedef struct {
   double *eparts;         // [RX_NPART] energy parts of the step
   int mimg[3];            // neighbour search: 0,0,0 = minimum image (box at least two list radii wide), else images up to mimg[d] boxes away
   int *overflow;          // bit 1: neighbour row full, bit 2: bond row full, bit 4: charge equilibration did not converge
+  long long *sweep_acc;   // [2] since the start of the run: matrix entries and rows that launches of k_rx_qeq_sweep passed over for this
+                          // replica (stored entries of its rows x sweeps it took part in): the kernel's algorithmic traffic (bench.py)
 } RxView;

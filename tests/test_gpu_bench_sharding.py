@@ -10,7 +10,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--sims", "6", "--steps", "2", "--warmup", "1", "--nss", "10", "--cells", "4", "6", "12", "--equil-steps", "40", "--no-cpu-baseline"]
+COMMON = ["--sims", "6", "--steps", "2", "--warmup", "1", "--nss", "10", "--cells", "4", "6", "12", "--equil-steps", "40", "--no-cpu-baseline",
+          "--monotonic-updates", "0"]
 
 
 def _run(cmd, ok=True):
@@ -43,9 +44,38 @@ def test_more_gpus_than_devices_is_an_error_not_a_smaller_run():
 def test_two_rank_bench_over_rccl():
     import torch
     if torch.cuda.device_count() < 2:
-        pytest.skip("RCCL PATH NOT EXERCISED: this box has one GPU (ncclAllGather inside scema_md_strain_batch needs one device per rank)")
+        pytest.skip("RCCL PATH WITH 2 RANKS NOT EXERCISED: this box has one GPU, and this RCCL build refuses two ranks on one device ('Duplicate GPU "
+                    "detected : rank %d and rank %d both on CUDA device' is its own message; librccl of ROCm 7.2 exports no multi-rank-per-GPU entry point "
+                    "such as ncclCommInitRankMulti and has no environment switch for it).  The one-rank RCCL calls run in test_gpu_multirank.py")
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON)
     two = _run([sys.executable, "bench.py", "--gpus", "2"] + COMMON)
     assert two["n_gpus"] == 2 and two["config"]["collective"].startswith("ncclAllGather")
     c1, c2 = one["config"]["stress_zz_checksum_Pa"], two["config"]["stress_zz_checksum_Pa"]
     assert abs(c1 - c2) <= 1e-8 * abs(c1), (c1, c2)
+
+
+def test_imbalanced_batch_on_two_ranks_is_levelled_and_moves_states():
+    """the ragged strain set (nts 10..100) on two ranks: after the first update the planner levels the load by MD steps,
+    which makes replica states change rank (over the host transport here); the stresses equal the single-rank run's"""
+    common = ["--sims", "8", "--steps", "3", "--warmup", "1", "--nss", "10", "--cells", "4", "6", "12", "--equil-steps", "40", "--no-cpu-baseline",
+              "--monotonic-updates", "0", "--strain-set", "imbalanced"]
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common)
+    two = _run([sys.executable, "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--share-gpus"] + common)
+    c1, c2 = one["config"]["stress_zz_checksum_Pa"], two["config"]["stress_zz_checksum_Pa"]
+    assert abs(c1 - c2) <= 1e-8 * abs(c1), (c1, c2)
+    cfg = two["config"]
+    assert cfg["allgathers"] == 4 and cfg["handshakes"] == 4            # one of each per update
+    assert cfg["state_migrations"] >= 1, cfg                            # a fresh batch is dealt i % 2; levelling by cost then moves states
+    assert 1 <= cfg["sims_on_rank0"] <= 7
+    assert cfg["md_steps_per_eval"] > 25.0                              # ragged: more straining steps than the balanced set's 10
+
+
+def test_reax_replica_set_bench_line():
+    """bench.py --force-field reax (BASELINE config 5) at a reduced batch: the same JSON contract, roofline block of the matrix sweep"""
+    out = _run([sys.executable, "bench.py", "--force-field", "reax", "--sims", "6", "--steps", "1", "--warmup", "1", "--equil-steps", "20",
+                "--no-cpu-baseline", "--monotonic-updates", "0"])
+    assert out["metric"] == "stress_evals_per_sec" and out["value"] > 0 and out["dtype"] == "f64"
+    assert out["config"]["force_field"] == "reax" and out["config"]["atoms_per_replica"] == 1620 and "ReaxFF" in out["config"]["workload"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"].startswith("k_rx_qeq_sweep") and r["launches"] > 0 and 0.0 < r["frac"] < 1.0
+    assert 300 < r["stored_entries_per_row"] < 1100 and 2 < r["qeq_iterations_per_solve"] < 80

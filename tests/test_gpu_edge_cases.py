@@ -424,7 +424,7 @@ def test_pppm_matches_the_oracle_pppm(small_pe, acc, library, monkeypatch):
     o = po.Oracle(small_pe, po.default_params(kspace_pppm=1, **kw))
     o.setup(False)
     fo, eo, wo = o.compute()
-    assert info["nk"] == 0 and abs(info["g_ewald"] - o.g_ewald) < 1e-13
+    assert info["nk"] == 0 and abs(info["g_ewald"] - o.g_ewald) < 1e-12   # Newton step with a 1e-6 forward difference: last bits x 1e6
     assert abs(en[6] - eo[6]) < 1e-10 * abs(eo[6]) and np.abs(w[6] - wo[6]).max() < 1e-10 * np.abs(wo[6]).max()
     assert abs(en[1] - eo[1]) < 1e-10 * abs(eo[1])                      # real-space part with the adjusted g_ewald
     assert np.abs(f - fo).max() < 1e-10 * np.abs(fo).max()

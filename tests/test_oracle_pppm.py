@@ -104,7 +104,7 @@ def _set_grid_global(box, g, acc, q2, natoms):
         n.append(nd)
     t = [n[0] / prd[0], n[1] / prd[1], n[2] / prd[2]]
     u = [prd[0] * t[0], xy * t[0] + prd[1] * t[1], xz * t[0] + yz * t[1] + prd[2] * t[2]]
-    n = [int(v) + 1 for v in u]
+    n = [int(v + 1e-9) + 1 for v in u]          # guard: (n / prd) * prd must not decide the grid by its last bit (md_oracle.c)
     return tuple(next(m for m in range(v, 10 * v + 8) if _factorable(m)) for v in n)
 
 
@@ -123,5 +123,10 @@ def test_grid_follows_set_grid_global(small_pe, tilt, acc):
     exp = _set_grid_global(np.asarray(d["box"], float), g0, acc * 332.06371, q2, d["natoms"])
     op, *_ = _run(d, acc, True)
     assert op.pppm_grid == exp, (op.pppm_grid, exp)
+    # a box that differs in the 13th digit gets the same grid (without the guard the x grid, which no tilt touches, flips)
+    d2 = deepcopy(d)
+    d2["box"] = np.asarray(d["box"], float) * (1.0 + 3e-13)
+    op2, *_ = _run(d2, acc, True)
+    assert op2.pppm_grid == op.pppm_grid
     # adjust_gewald stops at the first Newton iterate with |f| < 1e-5: the residual is small but not converged to round-off
     assert op.g_ewald != g0
