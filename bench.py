@@ -431,7 +431,7 @@ def main():
             if os.path.exists(ppath):
                 pmc = json.load(open(ppath))
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": (pmc or {}).get("hbm_bytes_per_full_sweep_corrected"), "traffic_source": (pmc or {}).get("source"),
+                    "traffic": (pmc or {}).get("hbm_bytes_per_sweep_corrected"), "traffic_source": (pmc or {}).get("command"),
                     "kernel": "k_rx_qeq_sweep (charge equilibration: y = H z for both conjugate-gradient systems, one pass over the stored matrix rows)",
                     "accounting": "achieved = (12 B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
                                   "device) / HIP-event time of all launches of the kernel on the engine's stream (launches that find every replica converged "

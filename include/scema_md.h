@@ -48,7 +48,7 @@ typedef struct {
   int32_t max_batch;       /* simulations advanced together per launch group; 0 = all that fit */
   int32_t profile;         /* !=0: HIP-event timing of every pair-kernel launch (scema_md_get_profile) */
   int32_t kspace_style;    /* 1 (default): PPPM as `kspace_style pppm 0.0001` asks for (in.set.lammps:36; order 5, ik differentiation,
-                            * hipFFT; grid and g_ewald by the rules of pppm.cpp as restated in md_engine.cpp / oracle/md_oracle.c;
+                            * hipFFT; grid and g_ewald by the rules of pppm.cpp as restated in scema_amd/csrc/engine/engine_kspace.cpp / oracle/md_oracle.c;
                             * DESIGN.md 5c); 0: the reciprocal part as the plain Ewald sum PPPM approximates, at kspace_accuracy
                             * (LAMMPS' initial g_ewald estimate, k-vectors by the RMS criterion of kspace_style ewald) */
 } scema_md_params;

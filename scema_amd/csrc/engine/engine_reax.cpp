@@ -1,5 +1,8 @@
-// md_reax_engine.inc -- host side of the ReaxFF path, textually included by md_engine.cpp (it needs the engine's private types).
-//
+// engine_reax.cpp -- host side of the ReaxFF path (force_field "reax"): run_phase_reax and the ReaxFF entry points of the C ABI
+#include "engine.h"
+
+namespace scema_eng {
+
 // run_phase_reax is run_phase with another force stage: the same step sequence (k_pre, k_initial_integrate, forces,
 // k_final_integrate, k_post, k_remap), the same batch rules (longest run first, active prefix), the same box flips; no
 // cells, no Ewald tables, no SHAKE (lammps_scripts_reax/in.strain.lammps has no fix shake and no kspace_style).
@@ -322,3 +325,116 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   if (fault & 64) return SCEMA_MD_ERR_OVERFLOW;   // the barostat took the box out of the range this segment was laid out for
   return SCEMA_MD_OK;
 }
+
+}  // namespace scema_eng
+
+extern "C" {
+
+// ---- ReaxFF path ----
+int scema_md_reax_configure(scema_md_engine *e, const char *ffield_path, const char *const *elements, int32_t n_elements, double qeq_tol, double skin) {
+  if (!e || !ffield_path || !elements || n_elements <= 0) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(e->p.device));
+  std::vector<std::string> el(elements, elements + n_elements);
+  std::string err;
+  RxParams P;
+  std::vector<int> map;
+  if (!scema::read_reax_ffield(ffield_path, el, P, map, err)) return fail(e, SCEMA_MD_ERR_IO, "%s", err.c_str());
+  if (const char *x = getenv("SCEMA_REAX_DROP_DSBO2")) P.lammps_dsbo2 = atoi(x) ? 1 : 0;
+  e->rx_host = P;
+  e->rx_type_map = map;
+  if (qeq_tol > 0.0) e->rx_qeq_tol = qeq_tol;
+  if (skin >= 0.0) e->rx_skin = skin;
+  if (const char *x = getenv("SCEMA_REAX_SKIN")) e->rx_skin = atof(x);
+  if (const char *x = getenv("SCEMA_REAX_QEQ_LAUNCH")) { e->rx_qeq_launch = e->rx_qeq_launch_cold = std::max(0, atoi(x)); e->rx_qeq_launch_pinned = true; }
+  HIPCHK(e->d_rxparams.ensure(sizeof(RxParams)));
+  HIPCHK(hipMemcpyAsync(e->d_rxparams.p, &e->rx_host, sizeof(RxParams), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->rx_ready = true;
+  e->rx_stamp += 1;
+  e->reax_active = true;
+  return SCEMA_MD_OK;
+}
+int scema_md_reax_activate(scema_md_engine *e, int32_t on) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  if (on && !e->rx_ready) return fail(e, SCEMA_MD_ERR_ARG, "no ReaxFF force field loaded");
+  e->reax_active = on != 0;
+  return SCEMA_MD_OK;
+}
+int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms, int32_t qeq_maxiter) {
+  if (!e || !e->rx_ready) return fail(e, SCEMA_MD_ERR_ARG, "no ReaxFF force field loaded");
+  HIPCHK(hipSetDevice(e->p.device));
+  if (exact_gradient >= 0) {
+    e->rx_host.lammps_dsbo2 = exact_gradient ? 0 : 1;
+    HIPCHK(hipMemcpyAsync(e->d_rxparams.p, &e->rx_host, sizeof(RxParams), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  if (terms >= 0) e->rx_terms = terms;
+  if (qeq_maxiter > 0) e->rx_qeq_maxiter = qeq_maxiter;
+  return SCEMA_MD_OK;
+}
+// static evaluation of a state (qp_id SCEMA_MD_QP_NONE: the registered replica): forces, the 13 energy parts, virial, charges
+int scema_md_reax_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double *f, double *eparts, double *virial,
+                                double *q, double *info) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  if (!e->rx_ready) return fail(e, SCEMA_MD_ERR_ARG, "no ReaxFF force field loaded");
+  HIPCHK(hipSetDevice(e->p.device));
+  State *s = nullptr;
+  std::unique_ptr<State> tmp;
+  int rc = debug_state(e, qp_id, matid, replica, &s, tmp);
+  if (rc) return rc;
+  std::vector<ActiveSim> sims(1);
+  sims[0].st = s;
+  sims[0].nsteps = 0;
+  sims[0].dt = 1.0;
+  sims[0].temperature = 300.0;
+  const bool saved = e->reax_active;
+  e->reax_active = true;
+  const long long it0 = e->rx_qeq_iters;
+  for (int attempt = 0; attempt < 6; attempt++) {
+    if ((rc = prepare_slots(e, sims))) break;
+    RunSpec R;
+    R.nvt = 0;
+    R.static_only = 1;
+    rc = run_phase(e, sims, R);
+    if (rc != SCEMA_MD_ERR_OVERFLOW) break;
+    e->neigh_grow *= 1.5;
+  }
+  e->reax_active = saved;
+  if (rc) return rc;
+  const int n = s->topo->natoms;
+  const SimScalars &sc = e->h_sc[0];
+  const RxView &V = e->h_rxviews[0];
+  if (f) HIPCHK(hipMemcpy(f, e->slots[0]->f.p, 3 * (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (eparts) HIPCHK(hipMemcpy(eparts, V.eparts, RX_NPART * 8, hipMemcpyDeviceToHost));
+  if (q) HIPCHK(hipMemcpy(q, V.q, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (virial)
+    for (int k = 0; k < 6; k++) {
+      virial[k] = 0.0;
+      for (int p = 0; p < MD_NPART; p++) virial[k] += sc.vir[p * 6 + k];
+    }
+  if (info) {
+    info[0] = sc.maxneigh_seen;
+    info[1] = V.maxnb;
+    info[2] = V.maxbd;
+    info[3] = (double)(e->rx_qeq_iters - it0);
+    info[4] = V.mimg[0] + V.mimg[1] + V.mimg[2];
+    std::vector<int> bc(n);
+    HIPCHK(hipMemcpy(bc.data(), V.bd_cnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int mb = 0;
+    for (int v : bc) mb = std::max(mb, v);
+    info[5] = mb;
+  }
+  return SCEMA_MD_OK;
+}
+int scema_md_reax_stats(const scema_md_engine *e, double *out) {
+  if (!e || !out) return SCEMA_MD_ERR_ARG;
+  out[0] = (double)e->rx_qeq_iters;
+  out[1] = (double)e->rx_qeq_solves;
+  out[2] = e->rx_skin;
+  out[3] = e->rx_qeq_tol;
+  out[4] = (double)e->rx_qeq_slow;
+  out[5] = (double)e->rx_qeq_launch;
+  return SCEMA_MD_OK;
+}
+
+}  // extern "C"

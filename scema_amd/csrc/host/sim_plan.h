@@ -15,7 +15,7 @@
 //     loaded one, the best such simulation moves (its state travels: PlanMove).  Cost = MD steps (nts + nss), so a
 //     ragged batch (nts 10..100) is balanced, a balanced one never migrates.
 //
-// Pure host C++ (no HIP): the engine (md_engine.cpp) and the Hooke-mode path of STMDSync use the same planner, and
+// Pure host C++ (no HIP): the engine (engine/engine_batch.cpp) and the Hooke-mode path of STMDSync use the same planner, and
 // the CPU tests drive it through the C ABI (scema_plan_* in include/scema_md.h).
 #pragma once
 #include <algorithm>

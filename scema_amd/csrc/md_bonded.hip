@@ -7,7 +7,7 @@
 // global FP64 atomics were bound by those atomics once the batch outgrew the caches (they execute at the memory
 // side: 1.56 ms per 576-replica step against 0.11 ms per 72).  Now:
 //   * a tile = BT_OWNERS atoms that are consecutive in a breadth-first ranking of the bond graph (its owners); it
-//     evaluates every term that touches an owner (built once per topology, md_engine.cpp build_topo), so a term
+//     evaluates every term that touches an owner (built once per topology, engine/engine_topo.cpp build_topo), so a term
 //     that spans two tiles is evaluated twice -- a few per cent of the terms of a chain molecule -- and NO force
 //     ever crosses a tile: the owners' forces leave with plain coalesced stores into fb (indexed by rank), nothing
 //     is zeroed beforehand, no global atomic is issued;

@@ -695,7 +695,7 @@ __global__ __launch_bounds__(EWF_T) void k_ewald_force(const SimDev *sims, int p
       }
       m1 = n1; m2 = n2; m3 = n3;
       // rest of the row: n3 -> n3 +- 1 = one complex multiplication each, no scalar control; the row's direction is the
-      // sign of its run length (snake order of the k list, md_engine.cpp ewald_tables)
+      // sign of its run length (snake order of the k list, engine/engine_kspace.cpp ewald_tables)
       const int srun = __builtin_amdgcn_readfirstlane(s_run[kk]);
       const int run = min(srun < 0 ? -srun : srun, kc - 1 - kk);   // rows are cut at chunk ends
       double s3d[EWF_APT];
@@ -944,7 +944,7 @@ __global__ void k_post(const SimDev *sims) {
   }
   // fix deform 1 ... erate ... : box(t) linear in t about the box centre, raw tilt targets by Ly0/Lz0, then moved by whole
   // box lengths to the value closest to the current tilt ratio (LAMMPS fix_deform end_of_step; after a flip the tilt
-  // continues from the flipped value).  The flip itself is decided and enqueued by the host (md_engine.cpp run_phase).
+  // continues from the flipped value).  The flip itself is decided and enqueued by the host (engine/engine_run.cpp run_phase).
   if (S.deform) {
     for (int k = 0; k < 9; k++) sc.box_prev[k] = sc.box[k];
     const double t = sc.step * S.dt;

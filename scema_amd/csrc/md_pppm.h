@@ -1,5 +1,5 @@
 // md_pppm.h -- host-callable launch wrappers of the PPPM kernels (md_pppm.hip); the transforms between them are hipFFT calls
-// issued by the engine (md_engine.cpp pppm_stage)
+// issued by the engine (engine/engine_run.cpp pppm_stage)
 #pragma once
 #include <hip/hip_runtime.h>
 struct SimDev;
