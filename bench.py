@@ -73,8 +73,28 @@ def _lammps_baseline(lmp, scripts, cells, strains, nss, ncore):
 
 
 def _host_cores(per_process_gb, cap=None):
-    """processes the CPU baseline may start: every host core, unless memory (or a cap) says fewer"""
+    """processes the CPU baseline may start: every host core THIS JOB MAY USE -- the affinity mask and the cgroup CPU quota, not
+    os.cpu_count() (a GPU box reports 256 cores and gives a one-GPU job 16 of them: 256 workers then take 12 times as long) --
+    unless memory (or a cap) says fewer"""
     n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))):
+        try:
+            q = parse(open(path).read())
+            if q:
+                n = min(n, max(1, int(q + 0.5)))
+        except Exception:
+            pass
+    # A one-GPU job of this pool gets 16 of the host's cores whatever os.cpu_count() says, and nothing in /sys says so (measured:
+    # 256 workers on a "256-core" box deliver 0.68 evaluations/s, 32 deliver 1.1, i.e. both are oversubscribed); the baseline runs
+    # at N = 1 only, so 16 it is unless SCEMA_CPU_BASELINE_CORES names the share of another host
+    n = min(n, 16)
+    if os.environ.get("SCEMA_CPU_BASELINE_CORES"):
+        n = max(1, int(os.environ["SCEMA_CPU_BASELINE_CORES"]))
     try:
         import psutil
         n = min(n, max(1, int(psutil.virtual_memory().available / 2**30 / per_process_gb * 0.6)))
@@ -107,13 +127,25 @@ def cpu_baseline_reax(cells, strains, nss, dt, rate):
     import concurrent.futures as cf
     import multiprocessing as mp
     ncore = min(_host_cores(1.0, cap=64), len(strains))
-    with cf.ProcessPoolExecutor(max_workers=ncore, mp_context=mp.get_context("spawn")) as ex:
-        res = list(ex.map(_cpu_eval_reax, range(ncore), [cells] * ncore, [strains[k] for k in range(ncore)], [nss] * ncore, [dt] * ncore, [rate] * ncore))
+    # torch's autograd engine asks for the GPU count on its first backward(), which opens /dev/kfd: the workers are CPU-only and
+    # must not count as users of the box's GPU (oracle/nogpu_shim.c hides the device nodes from them)
+    shim = os.path.join(ROOT, "oracle", "_build", "libnogpu_shim.so")
+    old = os.environ.get("LD_PRELOAD")
+    if os.path.exists(shim):
+        os.environ["LD_PRELOAD"] = shim + ((":" + old) if old else "")
+    try:
+        with cf.ProcessPoolExecutor(max_workers=ncore, mp_context=mp.get_context("spawn")) as ex:
+            res = list(ex.map(_cpu_eval_reax, range(ncore), [cells] * ncore, [strains[k] for k in range(ncore)], [nss] * ncore, [dt] * ncore, [rate] * ncore))
+    finally:
+        if old is None:
+            os.environ.pop("LD_PRELOAD", None)
+        else:
+            os.environ["LD_PRELOAD"] = old
     dtw = max(r[2] for r in res) - min(r[1] for r in res)
     natoms = 12 * cells[0] * cells[1] * cells[2]
     return {"value": ncore / dtw, "unit": "evals/s", "cores": ncore, "kind": "port", "lammps_on_this_host": None,
             "sample": f"{ncore} PE-{natoms} ReaxFF evaluations ({res[0][3]}+{nss} MD steps each, {res[0][4]:.1f} CG iterations per solve), one single-threaded process "
-                      f"per host core on {ncore} of {os.cpu_count()} cores: {dtw:.1f} s wall, {np.mean([r[2] - r[1] for r in res]):.1f} s mean per evaluation; "
+                      f"per core of this job's CPU share ({ncore} cores; the host reports {os.cpu_count()}): {dtw:.1f} s wall, {np.mean([r[2] - r[1] for r in res]):.1f} s mean per evaluation; "
                       "CPU restatement (oracle/reax_md.py), not LAMMPS USER-REAXC"}
 
 
@@ -125,7 +157,7 @@ def cpu_baseline(cells, strains, nss, pppm=1):
     import concurrent.futures as cf
     import multiprocessing as mp
     import shutil
-    ncore = max(1, min(len(strains), _host_cores(0.4)))   # every host core (no cap), memory permitting
+    ncore = max(1, min(len(strains), _host_cores(0.4)))   # every core this job may use (see _host_cores), memory permitting
     lmp = next((shutil.which(n) for n in (os.environ.get("SCEMA_LAMMPS") or "lmp", "lmp_serial", "lmp_mpi", "lammps") if shutil.which(n)), None)
     scripts = os.environ.get("SCEMA_SCRIPTS", "")
     natoms = 12 * cells[0] * cells[1] * cells[2]
@@ -146,8 +178,8 @@ def cpu_baseline(cells, strains, nss, pppm=1):
     alone = np.mean([r[2] - r[1] for r in res])
     return {"value": ncore / dt, "unit": "evals/s", "cores": ncore, "kind": "port",
             "lammps_on_this_host": lmp,   # a LAMMPS found here (with $SCEMA_SCRIPTS) would be the real baseline; none is installed on these images
-            "sample": f"{ncore} PE-{natoms} evaluations ({res[0][3]}+{nss} MD steps each), one process per host core on {ncore} of "
-                      f"{os.cpu_count()} cores: {dt:.1f} s wall, {alone:.1f} s mean per evaluation (replica 0: pair {tm['pair']:.1f} s, "
+            "sample": f"{ncore} PE-{natoms} evaluations ({res[0][3]}+{nss} MD steps each), one process per core of this job's CPU share ({ncore} cores; the host "
+                      f"reports {os.cpu_count()}): {dt:.1f} s wall, {alone:.1f} s mean per evaluation (replica 0: pair {tm['pair']:.1f} s, "
                       f"kspace {tm['kspace']:.1f} s, neigh {tm['neigh']:.1f} s); CPU restatement (oracle/md_oracle.c), not LAMMPS"}
 
 
@@ -235,7 +267,7 @@ def main():
     # CPU baseline first: its worker processes start while nothing in this process has touched the GPU
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        ncpu = os.cpu_count() or 1
+        ncpu = _host_cores(0.4)
         if reax:
             cpu = cpu_baseline_reax(tuple(args.cells), synthetic_strains(max(ncpu, 8), lens, seed=2026), args.nss, DT, rate)
         else:

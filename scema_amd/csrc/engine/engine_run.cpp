@@ -782,6 +782,12 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     fprintf(stderr, "[scema_md] host: %.2f ms laying out %d simulations before the first launch of this run (k-space set-up on host threads %.2f, box range %.2f, cell grid %.2f, rest of the loop %.2f)\n",
             std::chrono::duration<double, std::milli>(t_laid_out - t_enter).count(), ns, t_kspace_ms, t_lay[0], t_lay[1], t_lay[3]);
     fprintf(stderr, "[scema_md] sim 0: far skin band walked on %d of %d steps; list skin %.2f A\n", c.nfar_steps, c.step, S0.skin);
+#ifdef PAIR_COUNT
+    fprintf(stderr, "[scema_md] k_pair lanes (sim 0, this run): %llu wave-chunks (%llu with work); atom blocks run %llu = %.2f per working chunk, %.1f lanes of 64 in them; "
+            "LJ block run in %llu of them with %.1f lanes; coulomb block in %llu with %.1f lanes; pairs inside the LJ cutoff %llu, inside the coulomb cutoff %llu\n",
+            c.dbg[0], c.dbg[1], c.dbg[2], (double)c.dbg[2] / std::max(1ull, c.dbg[1]), (double)c.dbg[3] / std::max(1ull, c.dbg[2]), c.dbg[5],
+            (double)c.dbg[4] / std::max(1ull, c.dbg[5]), c.dbg[7], (double)c.dbg[6] / std::max(1ull, c.dbg[7]), c.dbg[4], c.dbg[6]);
+#endif
 #ifdef PAIR_TIMING
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
             (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);

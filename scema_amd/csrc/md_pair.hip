@@ -732,6 +732,11 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   // ahead) runs straight across row boundaries; a boundary only swaps the i-cluster (reduce its forces, load the next
   // cluster's records).  Row headers (cluster, counts) sit in one VGPR triple, lane r = r-th row of the wave, and are
   // read with v_readlane: no memory latency on the row switch.
+#ifdef PAIR_COUNT
+  // diagnostic build (make HIPFLAGS+=-DPAIR_COUNT): where the lanes of the row loop are -- per wave-chunk and per atom block, how many
+  // lanes reach the distance test, the LJ block and the coulomb block (SimScalars::dbg, printed with SCEMA_MD_TIMING=1)
+  unsigned pc_chunk = 0, pc_chunk_nz = 0, pc_blk = 0, pc_dist = 0, pc_lj = 0, pc_ljblk = 0, pc_coul = 0, pc_coulblk = 0;
+#endif
   if (nrows > 0) {
     int jt_n = s_jtab[e_n & E_LMASK];
     double xn0, xn1, xn2, xn3;
@@ -764,6 +769,9 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
         e_nn = fetch();
       }
       const int mask = (e >> E_MASK_SHIFT) & 0xF;  // 0 for the padding of a row's last chunk
+#ifdef PAIR_COUNT
+      if (lane == 0) { pc_chunk += 1; pc_chunk_nz += (__ballot(mask != 0) != 0ull) ? 1 : 0; }
+#endif
       if (mask != 0) {
         const int cs4 = (int)(((unsigned)jt >> 21) & 0x7Cu);   // 4 * image code (bits 23..27; the type bits above them are cleared in this copy)
         const double xs = xj + s_shift[cs4], ys = yj + s_shift[cs4 + 1], zs = zj + s_shift[cs4 + 2];
@@ -775,6 +783,11 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
           if (!(mask & (1 << a))) continue;
           const double dx = xi[a] - xs, dy = yi[a] - ys, dz = zi[a] - zs;
           const double rsq = dx * dx + dy * dy + dz * dz;
+#ifdef PAIR_COUNT
+          { const unsigned long long b = __ballot(true); pc_dist += 1; if (lane == __ffsll((long long)b) - 1) pc_blk += 1; }
+          if (rsq < cutl2) { const unsigned long long b = __ballot(true); pc_lj += 1; if (lane == __ffsll((long long)b) - 1) pc_ljblk += 1; }
+          if (rsq < cutc2) { const unsigned long long b = __ballot(true); pc_coul += 1; if (lane == __ffsll((long long)b) - 1) pc_coulblk += 1; }
+#endif
           if (CLE && !ENG) {
             if (rsq < cutl2) {
               const double rinv = rsqrt_f64(rsq);
@@ -875,6 +888,15 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       }
     }
   }
+#ifdef PAIR_COUNT
+  {
+    const double v[8] = {(double)pc_chunk, (double)pc_chunk_nz, (double)pc_blk, (double)pc_dist, (double)pc_lj, (double)pc_ljblk, (double)pc_coul, (double)pc_coulblk};
+    for (int k = 0; k < 8; k++) {
+      const double t = wave_sum(v[k]);
+      if (lane == 0 && t != 0.0) atomicAdd(&sc.dbg[k], (unsigned long long)t);
+    }
+  }
+#endif
 #ifdef PAIR_TIMING
   const unsigned long long tm2 = __builtin_readcyclecounter();
 #endif
