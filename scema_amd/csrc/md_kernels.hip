@@ -49,7 +49,7 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.far_dsq = 1.0e300;
     sc.need_far = 0;
     sc.nfar_steps = 0;
-#ifdef PAIR_TIMING
+#if defined(PAIR_TIMING) || defined(PAIR_COUNT)
     for (int k = 0; k < 8; k++) sc.dbg[k] = 0;
 #endif
   }

@@ -361,12 +361,8 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
   if (a0 >= a1) return;
   const size_t gs = (size_t)S.pgstride;
   const double2 *ex = (const double2 *)S.pfield, *ey = ex + gs, *ez = ey + gs;
-  // LDS layout: (E_x, E_y) of a grid point side by side, E_z behind them: one 16-byte and one 8-byte read per point instead of three
-  // 8-byte reads (a wave's ds_read_b64 and ds_read_b128 both take 8 clocks of the LDS: 375 -> 250 LDS instructions per atom)
-  double2 *s_xy = (double2 *)s_grid;
-  double *s_z = s_grid + 2 * (size_t)NG;
   if (LDS) {
-    for (int k = threadIdx.x; k < NG; k += 256) { s_xy[k] = make_double2(ex[k].x, ey[k].x); s_z[k] = ez[k].x; }
+    for (int k = threadIdx.x; k < NG; k += 256) { s_grid[k] = ex[k].x; s_grid[NG + k] = ey[k].x; s_grid[2 * NG + k] = ez[k].x; }
     __syncthreads();
   }
   BoxD b;
@@ -395,7 +391,7 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
 #pragma unroll
         for (int k = 0; k < PP_ORDER; k++) {
           const int g = row + gx[k];
-          if (LDS) { const double2 exy = s_xy[g]; rx = fma(wx[k], exy.x, rx); ry = fma(wx[k], exy.y, ry); rz = fma(wx[k], s_z[g], rz); }
+          if (LDS) { rx = fma(wx[k], s_grid[g], rx); ry = fma(wx[k], s_grid[NG + g], ry); rz = fma(wx[k], s_grid[2 * NG + g], rz); }
           else { rx = fma(wx[k], ex[g].x, rx); ry = fma(wx[k], ey[g].x, ry); rz = fma(wx[k], ez[g].x, rz); }
         }
         fx = fma(zy, rx, fx); fy = fma(zy, ry, fy); fz = fma(zy, rz, fz);

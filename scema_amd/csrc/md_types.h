@@ -88,7 +88,7 @@ struct SimScalars {
   double min_alpha_now, min_alpha_next;   // where x sits on the current search line before / after the move of this evaluation (min_incremental)
   double min_alpha, min_alphamax, min_fdothall, min_eorig, min_eprev, min_fhprev, min_engprev, min_alphaprev, min_fh_trial, min_ecur, min_einit;
   double min_dots[4];  // f.h, f.f, max |f| of the last evaluation (+ spare)
-#ifdef PAIR_TIMING
+#if defined(PAIR_TIMING) || defined(PAIR_COUNT)
   unsigned long long dbg[8];
 #endif
 };
