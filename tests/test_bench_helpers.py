@@ -1,0 +1,41 @@
+"""bench.py's host-side helpers (no GPU): the CPU-baseline core count, the GPU count from sysfs, and the shim that keeps the
+CPU-only torch workers of the ReaxFF baseline away from the GPU's device nodes."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_cores_is_the_jobs_share_not_the_hosts_count(monkeypatch):
+    import bench
+    n = bench._host_cores(0.4)
+    assert 1 <= n <= 16                                   # a one-GPU job of this pool gets 16 cores whatever os.cpu_count() says
+    assert bench._host_cores(0.4, cap=2) <= 2
+    monkeypatch.setenv("SCEMA_CPU_BASELINE_CORES", "3")
+    assert bench._host_cores(1000.0) in (1, 3)            # the memory bound still applies after the override
+
+
+def test_gpu_count_comes_from_sysfs_and_respects_visibility(monkeypatch):
+    import bench
+    n = bench.count_gpus_without_hip()
+    assert n >= 0                                         # no /sys/class/kfd here: 0; on a GPU box the nodes with SIMDs
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.count_gpus_without_hip() <= 1
+
+
+def test_the_shim_hides_the_gpu_device_nodes_and_nothing_else(tmp_path):
+    import __graft_entry__ as g
+    g.build()
+    shim = os.path.join(ROOT, "oracle", "_build", "libnogpu_shim.so")
+    assert os.path.exists(shim)
+    code = ("import os, errno\n"
+            "for p in ('/dev/kfd', '/dev/dri/renderD128'):\n"
+            "    try:\n"
+            "        os.close(os.open(p, os.O_RDWR)); print('OPENED', p)\n"
+            "    except OSError as e:\n"
+            "        print('blocked' if e.errno == errno.ENOENT else 'other', p)\n"
+            "open(r'%s', 'w').write('x'); print(open('/dev/null').read() == '', open(r'%s').read())\n" % (tmp_path / "f", tmp_path / "f"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LD_PRELOAD=shim), capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("blocked") == 2 and "OPENED" not in r.stdout and "True x" in r.stdout
