@@ -203,6 +203,9 @@ def count_gpus_without_hip():
 def spawn_ranks(args):
     """--gpus N from a plain shell: start N ranks (torch.distributed.run) BEFORE any GPU call in this process."""
     have = count_gpus_without_hip()
+    if have == 0:   # no KFD topology in this container's sysfs: ask torch (amdsmi where present; otherwise this does open the device)
+        import torch
+        have = torch.cuda.device_count()
     if have < args.gpus and not args.share_gpus:
         print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
         return 2

@@ -325,7 +325,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       const double perr = cached_coul_poly(e, ew.g, P.cut_coul, S.coul_poly, &S.coul_npoly, &S.coul_uscale);
       if (perr > 1e-12 && !getenv("SCEMA_MD_POLY_TOL")) return fail(e, SCEMA_MD_ERR_ARG, "real-space Ewald polynomial fit error %.3e too large (g*rc = %.3f)", perr, ew.g * P.cut_coul);
       for (int m = 0; m < MD_MAXPOLY; m++) S.coul_poly_g[m] = S.coul_poly[m] * ew.g;
-      static const int row_split = getenv("SCEMA_MD_ROW_SPLIT") ? atoi(getenv("SCEMA_MD_ROW_SPLIT")) : 1;
+      // rows of a tile over its waves: 2 = round robin by cluster index (default since round 3: in a same-box A/B it beats the
+      // longest-first deal with or without row splitting -- 398.0 / 399.4 against 395.2 / 394.4 (1) and 396.2 (0) evaluations/s; the
+      // rows of a cell cost about the same, and the schedule itself was 5 % of k_neigh_build)
+      static const int row_split = getenv("SCEMA_MD_ROW_SPLIT") ? atoi(getenv("SCEMA_MD_ROW_SPLIT")) : 2;
       S.sched_split = row_split;
     }
     {

@@ -152,9 +152,17 @@ extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave li
 #define SPLIT_OVH 160   // cost of starting one more row part in k_pair, in the units of the rows' cost estimate (k_neigh_build's schedule)
 
 // (TT, 4): at most 128 registers, so that two workgroups share a CU -- at 129 the kernel ran 1.6 times longer
-__global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap) {
+__global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap, int spread) {
   int sim, cell;
-  if (!xcd_map(ntiles, nsims, sim, cell)) return;
+  // Which replicas rebuild in a given step is random (one in ~16 of them, each at its own time).  With the tiles of a replica pinned
+  // to one XCD (k_pair's map) the XCD that happens to hold the most rebuilding replicas sets the launch time; consecutive blocks =
+  // consecutive tiles of one replica instead deals every rebuilding replica's tiles over all eight XCDs (its 332 KB of positions
+  // are then read by each of them: nothing next to the 10 MB of rows it writes).
+  if (spread) {
+    sim = blockIdx.x / ntiles;
+    cell = blockIdx.x % ntiles;
+    if (sim >= nsims) return;
+  } else if (!xcd_map(ntiles, nsims, sim, cell)) return;
   const SimDev &S = sims[sim];
   SimScalars &sc = *S.sc;
   if (!sc.rebuild) return;
@@ -502,6 +510,25 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
   // Schedule of k_pair, fixed here: longest-processing-time-first list scheduling of the tile's rows over the TW
   // waves.  tile_order holds the tile's clusters grouped by wave (longest row first), tile_wstart the TW+1 group
   // boundaries.  Rows were written by other waves -> barrier + own-workgroup visibility first.
+  if (S.sched_split == 2) {
+    // round robin (the default): the schedule does not look at the rows, so nothing waits for them -- a wave that has written its
+    // rows is done (the longest-first deal below has to wait for the slowest wave of the tile first)
+    if (wave == 0) {
+      const int c0i = cs / NI, nclus = nown / NI;
+      int *wst = S.tile_wstart + (size_t)cell * (TW + 1);
+      for (int w = lane; w <= TW; w += 64) {
+        int st = 0;
+        for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
+        wst[w] = st;
+      }
+      for (int i = lane; i < nclus; i += 64) {
+        const int w = i % TW;
+        int st = 0;
+        for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
+        S.tile_order[2 * c0i + st + i / TW] = (c0i + i) | (16 << 25);
+      }
+    }
+  } else {
   __threadfence_block();
   __syncthreads();
   if (wave == 0) {
@@ -542,7 +569,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       int pa = 0, pb = 16, ecl = i;     // this lane's entry: part [pa, pb) of cluster ecl (lanes >= nclus: entries made by splits)
       bool have = i < nclus;
       int nextra = 0;
-      if (S.sched_split && nclus >= TW && nclus + TW <= 64) {   // (a tile's share of tile_order is twice its clusters: room for TW more entries)
+      if (S.sched_split == 1 && nclus >= TW && nclus + TW <= 64) {   // (a tile's share of tile_order is twice its clusters: room for TW more entries)
         for (int it = 0; it < TW; it++) {
           int wmax = 0, wmin = 0;
 #pragma unroll
@@ -595,6 +622,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
         S.tile_order[2 * c0i + st + i / TW] = (c0i + i) | (16 << 25);
       }
     }
+  }
   }
 #ifdef PAIR_TIMING
   if (lane == 0) {
@@ -980,7 +1008,8 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
   static size_t optin_tab[16] = {0};  // more than 64 KB of dynamic LDS needs an explicit opt-in
   size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_neigh_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB, neigh_qcap(capj));
+  static const int spread = getenv("SCEMA_MD_NEIGH_SPREAD") ? atoi(getenv("SCEMA_MD_NEIGH_SPREAD")) : 1;   // measurement switch (0: k_pair's XCD map)
+  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB, neigh_qcap(capj), spread);
 }
 
 template <bool VIR, bool ENG, int NP, bool CLE = false>
