@@ -325,11 +325,6 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       const double perr = cached_coul_poly(e, ew.g, P.cut_coul, S.coul_poly, &S.coul_npoly, &S.coul_uscale);
       if (perr > 1e-12 && !getenv("SCEMA_MD_POLY_TOL")) return fail(e, SCEMA_MD_ERR_ARG, "real-space Ewald polynomial fit error %.3e too large (g*rc = %.3f)", perr, ew.g * P.cut_coul);
       for (int m = 0; m < MD_MAXPOLY; m++) S.coul_poly_g[m] = S.coul_poly[m] * ew.g;
-      // rows of a tile over its waves: 2 = round robin by cluster index (default since round 3: in a same-box A/B it beats the
-      // longest-first deal with or without row splitting -- 398.0 / 399.4 against 395.2 / 394.4 (1) and 396.2 (0) evaluations/s; the
-      // rows of a cell cost about the same, and the schedule itself was 5 % of k_neigh_build)
-      static const int row_split = getenv("SCEMA_MD_ROW_SPLIT") ? atoi(getenv("SCEMA_MD_ROW_SPLIT")) : 2;
-      S.sched_split = row_split;
     }
     {
       const double m = 0.1 * P.skin;   // margin of the row segments over the cutoffs (scan 0 .. 0.6 skin: flat optimum at 0.05-0.15)
@@ -796,8 +791,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
             (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);
     if (c.nbuilds > 0) {
       const double nw = (double)c.nbuilds * S0.ncells * MD_TILE_WAVES;
-      fprintf(stderr, "[scema_md] k_neigh_build wave clocks (sim 0, mean per wave and build): table %.0f, rows %.0f, schedule %.0f\n",
-              (double)c.dbg[5] / nw, (double)c.dbg[6] / nw, (double)c.dbg[7] / nw);
+      fprintf(stderr, "[scema_md] k_neigh_build wave clocks (sim 0, mean per wave and build): table %.0f (boxes and runs %.0f, candidates %.0f), rows %.0f, schedule %.0f; %llu waves of %.0f; %.2f rows per wave of %.1f chunks\n",
+              (double)c.dbg[5] / nw, (double)c.dbg[8] / nw, (double)(c.dbg[5] - c.dbg[8]) / nw, (double)c.dbg[6] / nw, (double)c.dbg[7] / nw, c.dbg[9], nw,
+              (double)c.dbg[11] / nw, (double)c.dbg[10] / std::max(1ull, c.dbg[11]));
     }
 #endif
   }

@@ -50,7 +50,7 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.need_far = 0;
     sc.nfar_steps = 0;
 #if defined(PAIR_TIMING) || defined(PAIR_COUNT)
-    for (int k = 0; k < 8; k++) sc.dbg[k] = 0;
+    for (int k = 0; k < 12; k++) sc.dbg[k] = 0;
 #endif
   }
   for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;
@@ -420,7 +420,9 @@ __global__ __launch_bounds__(TPB) void k_pack(const SimDev *sims) {
   if (a < 0) {  // pad slot: a record no real atom is ever within the list cutoff of
     if (S.sc->rebuild) {
       double *xy = (double *)S.xq + 2 * (size_t)s, *zq = (double *)S.xq + 2 * (size_t)S.npad + 2 * (size_t)s;
-      xy[0] = 1.0e15; xy[1] = 1.0e15; zq[0] = 1.0e15; zq[1] = 0.0;
+      // (every pad slot at its own place, 10^6 A from the next: two pads of one cell must not list each other either -- the
+      // whole-table walk of k_neigh_build, taken when a quarter list overflows, tests pads against pads)
+      xy[0] = 1.0e15 + 1.0e6 * (double)s; xy[1] = 1.0e15; zq[0] = 1.0e15; zq[1] = 0.0;
       S.stype[s] = 0;
     }
     return;

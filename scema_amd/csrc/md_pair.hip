@@ -25,6 +25,8 @@
 // (in.set.lammps:27); special_bonds 0 0 1 pairs are excluded here and handled in k_bonded (md_bonded.hip).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "md_device.h"
 #include "md_kernels.h"
 
@@ -88,15 +90,18 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
 __device__ __forceinline__ int popc_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+// wave-wide max on the DPP path (row shifts, then row broadcasts; lanes without a source keep their own value), result from lane 63
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_keep(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  return v;
+__device__ __forceinline__ double wave_max_dpp(double v) {
+  v = fmax(v, dpp_keep<0x111, 0xF>(v)); v = fmax(v, dpp_keep<0x112, 0xF>(v)); v = fmax(v, dpp_keep<0x114, 0xF>(v)); v = fmax(v, dpp_keep<0x118, 0xF>(v));
+  v = fmax(v, dpp_keep<0x142, 0xA>(v));   // row_bcast:15 -> rows 1, 3
+  v = fmax(v, dpp_keep<0x143, 0xC>(v));   // row_bcast:31 -> rows 2, 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 // cross-lane move through the DPP path of the VALU (no LDS traffic): every lane reads the lane selected by CTRL
 // inside its row of 16 (quad_perm / row_shr), lanes without a source read 0
@@ -111,6 +116,16 @@ __device__ __forceinline__ double dpp_mov(double v) {
 #define DPP_ROW_SHR4 0x114
 #define DPP_ROW_SHR8 0x118
 
+// inclusive prefix sum over the first 32 lanes of a wave on the DPP path (row shifts inside the rows of 16, then lane 15 broadcast
+// into row 1): 5 VALU instructions instead of 5 LDS round trips
+__device__ __forceinline__ int scan32_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1 and 3
+  return v;
+}
 // LDS FP64 atomic add without return value (ds_add_f64)
 __device__ __forceinline__ void lds_add(double *p, double v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -148,8 +163,10 @@ struct ClusterI {
 
 extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists (segment B from the front, C1 from the back), then
                                   // [NQ][qcap] 16-bit table indices: the part of the table each quarter of the cell's clusters can reach
-#define NQ 4
-#define SPLIT_OVH 160   // cost of starting one more row part in k_pair, in the units of the rows' cost estimate (k_neigh_build's schedule)
+#define NQ 4      // groups of a cell's clusters with their own candidate list (<= TW: one wave takes each group's bounding box)
+#define NB_MAXRUN 128    // slot runs of one tile's candidates (own cell + half stencil; 20 for PE-10k)
+#define NB_MAXUNIT 1024  // 64-candidate units of one tile (85 for PE-10k)
+#define NB_UPW 4         // units per wave and round (TW * NB_UPW = 32: scan32_incl)
 
 // (TT, 4): at most 128 registers, so that two workgroups share a CU -- at 129 the kernel ran 1.6 times longer
 __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap, int spread) {
@@ -176,18 +193,18 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     return;
   }
   __shared__ double s_shift[27 * 3];
-  __shared__ double s_box[6];   // bounding box of the cell's real atoms
-  __shared__ int s_wcnt[TW];
-  __shared__ int s_cost[64];
+  __shared__ int s_rjb[NB_MAXRUN], s_rlen[NB_MAXRUN], s_rcode[NB_MAXRUN], s_ub[NB_MAXRUN + 1];   // slot runs of the candidates, first unit of each
+  __shared__ unsigned char s_urun[NB_MAXUNIT];                                                    // run of each 64-candidate unit
+  __shared__ int s_ucnt[2][1 + NQ][TW * NB_UPW];                                                  // accepted per unit of a round: table, group lists
   __shared__ int s_ex[TW][NI * 16];   // exclusion lists of the cluster a wave is working on (first 16 per atom)
   __shared__ double s_qbox[NQ][6];    // bounding boxes of the quarters of the cell's clusters (k-d order: quarters are compact)
-  __shared__ int s_qcnt[NQ][TW];
   __shared__ int s_qn[NQ];            // entries of a quarter's list; -1: list overflowed, the quarter walks the whole table
   int *s_jtab = s_build;
   unsigned short *s_qlist = (unsigned short *)(s_build + capj + TW * capB);
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int *lb = s_build + capj + wave * capB;
+
   BoxD b;
   box_derive(sc.box, b);
   if (threadIdx.x < 27) {
@@ -198,98 +215,11 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
   }
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);               // (x,y) halves
   const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;                          // (z,q) halves
-  if (wave == 0) {
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int s = cs + lane; s < ce; s += 64)
-      if (S.perm[s] >= 0) {
-        const double x = xq[2 * (size_t)s], y = xq[2 * (size_t)s + 1], z = zq[2 * (size_t)s];
-        lo[0] = fmin(lo[0], x); hi[0] = fmax(hi[0], x);
-        lo[1] = fmin(lo[1], y); hi[1] = fmax(hi[1], y);
-        lo[2] = fmin(lo[2], z); hi[2] = fmax(hi[2], z);
-      }
-    for (int d = 0; d < 3; d++) {
-      const double l = wave_min(lo[d]), h = wave_max(hi[d]);
-      if (lane == 0) { s_box[d] = l; s_box[3 + d] = h; }
-    }
-  }
-  // own cell first: table index l <-> slot cs + l (pads included), so the cluster atoms know their own index
-  // (inside this kernel the table entries also carry the type of j in bits 28..31: the rows need it per accepted candidate, and
-  // one load per table entry here replaces one per cluster and entry there; the copy that k_pair reads is written without it)
-  const GLOBAL_AS int *stype = as_global(S.stype);
-  for (int l = threadIdx.x; l < nown && l < capj; l += TT) s_jtab[l] = (cs + l) | (CODE_HOME << 23) | (stype[cs + l] << 28);
-  __syncthreads();
-  const double blo0 = s_box[0], blo1 = s_box[1], blo2 = s_box[2], bhi0 = s_box[3], bhi1 = s_box[4], bhi2 = s_box[5];
-  const int c0 = cell % S.nc[0], c1 = (cell / S.nc[0]) % S.nc[1], c2 = cell / (S.nc[0] * S.nc[1]);
-  int nj = nown;
-  for (int o2 = 0; o2 <= S.mst[2]; o2++) {
-    int a2 = c2 + o2, s2 = 0;
-    while (a2 >= S.nc[2]) { a2 -= S.nc[2]; s2 += 1; }
-    if (s2 > 1) continue;
-    for (int o1 = (o2 == 0 ? 0 : -S.mst[1]); o1 <= S.mst[1]; o1++) {
-      int a1 = c1 + o1, s1 = 0;
-      while (a1 < 0) { a1 += S.nc[1]; s1 -= 1; }
-      while (a1 >= S.nc[1]) { a1 -= S.nc[1]; s1 += 1; }
-      if (s1 < -1 || s1 > 1) continue;
-      // the x range of cells is one or more contiguous slot runs, one per image
-      int o0 = (o2 == 0 && o1 == 0) ? 1 : -S.mst[0];
-      while (o0 <= S.mst[0]) {
-        int a0 = c0 + o0, s0 = 0;
-        while (a0 < 0) { a0 += S.nc[0]; s0 -= 1; }
-        while (a0 >= S.nc[0]) { a0 -= S.nc[0]; s0 += 1; }
-        int len = 1;
-        while (o0 + len <= S.mst[0] && a0 + len < S.nc[0]) len++;
-        o0 += len;
-        if (s0 < -1 || s0 > 1) continue;
-        const int code = (s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1);
-        const double sx = s_shift[3 * code], sy = s_shift[3 * code + 1], sz = s_shift[3 * code + 2];
-        const int cj = (a2 * S.nc[1] + a1) * S.nc[0] + a0;
-        const int jb = S.cell_start[cj], je = S.cell_start[cj + len];
-        for (int base = jb; base < je; base += TT) {
-          const int j = base + threadIdx.x;
-          bool ok = false;
-          if (j < je) {
-            const double xj = xq[2 * (size_t)j] + sx, yj = xq[2 * (size_t)j + 1] + sy, zj = zq[2 * (size_t)j] + sz;
-            const double ex = fmax(0.0, fmax(blo0 - xj, xj - bhi0)), ey = fmax(0.0, fmax(blo1 - yj, yj - bhi1)),
-                         ez = fmax(0.0, fmax(blo2 - zj, zj - bhi2));
-            ok = ex * ex + ey * ey + ez * ez < S.rlist2;
-          }
-          const unsigned long long m = __ballot(ok);
-          if (lane == 0) s_wcnt[wave] = __popcll(m);
-          __syncthreads();
-          int before = 0, total = 0;
-#pragma unroll
-          for (int w = 0; w < TW; w++) {
-            const int cw = s_wcnt[w];
-            before += (w < wave) ? cw : 0;
-            total += cw;
-          }
-          if (ok) {
-            const int pos = nj + before + popc_below(m);
-            if (pos < capj) s_jtab[pos] = j | (code << 23) | (stype[j] << 28);
-          }
-          nj += total;
-          __syncthreads();
-        }
-      }
-    }
-  }
-  // k_pair keeps a wave's row headers in one VGPR triple (lane r = r-th row): at most 64 rows per wave, 64*TW clusters
-  // per cell.  A denser cell is reported like a table overflow (the engine retries with smaller cells), never dropped.
-  if (nj > capj || nj > S.capj || nown / NI > 64 * TW) {   // uniform: table overflow -> the engine regrows and retries
-    if (threadIdx.x == 0) { S.tile_nj[cell] = 0; atomicOr(&sc.overflow, 1 | 4); atomicMax(&sc.maxj_seen, nj); }   // 4: table
-    for (int cl = cs / NI + threadIdx.x; cl < ce / NI; cl += TT) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
-    return;
-  }
-  {
-    GLOBAL_AS int *gj = as_global_w(S.tile_jtab) + (size_t)cell * S.capj;
-    for (int l = threadIdx.x; l < nj; l += TT) gj[l] = s_jtab[l] & 0x0FFFFFFF;
-    if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
-  }
-  // ---- phase 1b: which table entries can each quarter of the cell's clusters reach at all? ----
-  // A cluster tests the table with 4 atoms x 64 lanes per chunk whatever the outcome; 61 % of a cell's table is out of reach
-  // of a given cluster.  The clusters of a cell are in k-d order, so a quarter of them is a compact region: entries farther
-  // than rlist from its bounding box are left out of its list (conservative: no atom of the quarter can list them) and its
-  // clusters walk the list instead of the table.  Lists keep table order, so rows come out exactly as before.
+  // ---- phase 0: bounding boxes of the groups of the cell's clusters; slot runs of the half stencil ----
+  // The clusters of a cell are in k-d order, so a group of consecutive clusters (a quarter of the cell's) is a compact region: a
+  // candidate farther than rlist from the group's box is left out of the group's list (conservative: no atom of the group can list
+  // it) and the group's clusters walk the list instead of the table (a cluster tests its candidates with 4 atoms x 64 lanes per
+  // chunk whatever the outcome).  Lists keep table order, so rows do not depend on them.
   const int nclus_cell = nown / NI;
   if (wave < NQ) {
     const int c_lo = (wave * nclus_cell) / NQ, c_hi = ((wave + 1) * nclus_cell) / NQ;
@@ -302,69 +232,192 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
         lo[2] = fmin(lo[2], z); hi[2] = fmax(hi[2], z);
       }
     for (int d = 0; d < 3; d++) {
-      const double l = wave_min(lo[d]), h = wave_max(hi[d]);
-      if (lane == 0) { s_qbox[wave][d] = l; s_qbox[wave][3 + d] = h; }
+      const double l = -wave_max_dpp(-lo[d]), h = wave_max_dpp(hi[d]);
+      if (lane == 0) { s_qbox[wave][d] = l; s_qbox[wave][3 + d] = h; }   // (an empty group keeps an inverted box: nothing passes)
+    }
+  }
+  // Candidates = the slots of the own cell (run 0: table index l <-> slot cs + l, pads included, so that the cluster atoms know their
+  // own index) and of the cells of the half stencil, as runs of consecutive slots (the x range of cells at fixed (o2, o1) is one run
+  // per periodic image).  The loop below is scalar arithmetic and names the runs by their cells; lane r of wave 0 then fetches the two
+  // cell boundaries of run r, so that the loads of all runs are in flight together.
+  // (scalars of the replica that the loops below use, read once: behind the LDS stores the compiler reloads them at every use)
+  const int nc0 = S.nc[0], nc1 = S.nc[1], nc2 = S.nc[2], mst0 = S.mst[0], mst1 = S.mst[1], mst2 = S.mst[2];
+  const double rl2 = S.rlist2;
+  const int c0 = cell % nc0, c1 = (cell / nc0) % nc1, c2 = cell / (nc0 * nc1);
+  int nrun = 1;
+  if (threadIdx.x == 0) { s_rjb[0] = cs; s_rlen[0] = nown; s_rcode[0] = CODE_HOME; }
+  for (int o2 = 0; o2 <= mst2; o2++) {
+    int a2 = c2 + o2, s2 = 0;
+    while (a2 >= nc2) { a2 -= nc2; s2 += 1; }
+    if (s2 > 1) continue;
+    for (int o1 = (o2 == 0 ? 0 : -mst1); o1 <= mst1; o1++) {
+      int a1 = c1 + o1, s1 = 0;
+      while (a1 < 0) { a1 += nc1; s1 -= 1; }
+      while (a1 >= nc1) { a1 -= nc1; s1 += 1; }
+      if (s1 < -1 || s1 > 1) continue;
+      int o0 = (o2 == 0 && o1 == 0) ? 1 : -mst0;
+      while (o0 <= mst0) {
+        int a0 = c0 + o0, s0 = 0;
+        while (a0 < 0) { a0 += nc0; s0 -= 1; }
+        while (a0 >= nc0) { a0 -= nc0; s0 += 1; }
+        int len = 1;
+        while (o0 + len <= mst0 && a0 + len < nc0) len++;
+        o0 += len;
+        if (s0 < -1 || s0 > 1) continue;
+        if (threadIdx.x == 0 && nrun < NB_MAXRUN) {   // (cells for now; wave 0 turns them into slots below, all runs' loads in flight together)
+          s_rjb[nrun] = (a2 * nc1 + a1) * nc0 + a0; s_rlen[nrun] = len;
+          s_rcode[nrun] = (s2 + 1) * 9 + (s1 + 1) * 3 + (s0 + 1);
+        }
+        nrun++;
+      }
     }
   }
   __syncthreads();
-  {
-    int qn[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) qn[q] = 0;
-    for (int base = 0; base < nj; base += TT) {
-      const int l = base + threadIdx.x;
-      bool ok[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; q++) ok[q] = false;
-      if (l < nj) {
-        const int jt = s_jtab[l];
-        const size_t j = (size_t)(jt & MD_JMASK);
-        const int code = (jt >> 23) & 31;
-        const double xj = xq[2 * j] + s_shift[3 * code], yj = xq[2 * j + 1] + s_shift[3 * code + 1], zj = zq[2 * j] + s_shift[3 * code + 2];
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const double ex = fmax(0.0, fmax(s_qbox[q][0] - xj, xj - s_qbox[q][3])), ey = fmax(0.0, fmax(s_qbox[q][1] - yj, yj - s_qbox[q][4])),
-                       ez = fmax(0.0, fmax(s_qbox[q][2] - zj, zj - s_qbox[q][5]));
-          ok[q] = ex * ex + ey * ey + ez * ez < S.rlist2;   // an empty quarter has an inverted box: nothing passes
-        }
+  // units of 64 consecutive candidates of one run, numbered in run order: s_ub[r] = first unit of run r, s_urun[u] = run of unit u
+  if (wave == 0) {
+    int carry = 0;
+    for (int r0 = 0; r0 < min(nrun, NB_MAXRUN); r0 += 64) {
+      const int r = r0 + lane;
+      if (r > 0 && r < min(nrun, NB_MAXRUN)) {
+        const int cj = s_rjb[r], jb = S.cell_start[cj];
+        s_rlen[r] = S.cell_start[cj + s_rlen[r]] - jb;
+        s_rjb[r] = jb;
       }
-      unsigned long long m[NQ];
+      const int nu = (r < min(nrun, NB_MAXRUN)) ? (s_rlen[r] + 63) >> 6 : 0;
+      int incl = nu;
 #pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        m[q] = __ballot(ok[q]);
-        if (lane == 0) s_qcnt[q][wave] = __popcll(m[q]);
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      const int first = carry + incl - nu;
+      if (r < min(nrun, NB_MAXRUN)) {
+        s_ub[r] = first;
+        for (int k = 0; k < nu; k++) if (first + k < NB_MAXUNIT) s_urun[first + k] = (unsigned char)r;
       }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < TW; w++) {
-          const int cw = s_qcnt[q][w];
-          before += (w < wave) ? cw : 0;
-          total += cw;
-        }
-        if (ok[q]) {
-          const int pos = qn[q] + before + popc_below(m[q]);
-          if (pos < qcap) s_qlist[q * qcap + pos] = (unsigned short)l;
-        }
-        qn[q] += total;
-      }
-      __syncthreads();
+      carry += __shfl(incl, 63, 64);
     }
-    if (threadIdx.x < NQ) {
-      const int q = threadIdx.x;
-      const int n = (q == 0) ? qn[0] : (q == 1) ? qn[1] : (q == 2) ? qn[2] : qn[3];
-      s_qn[q] = (n > qcap) ? -1 : n;
+    if (lane == 0) s_ub[NB_MAXRUN] = carry;
+  }
+  __syncthreads();
+  const int nunit = s_ub[NB_MAXRUN];
+#ifdef PAIR_TIMING
+  const unsigned long long tb05 = __builtin_readcyclecounter();
+#endif
+  // the cell's box = union of its groups' boxes
+  double blo0 = 1e300, blo1 = 1e300, blo2 = 1e300, bhi0 = -1e300, bhi1 = -1e300, bhi2 = -1e300;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    blo0 = fmin(blo0, s_qbox[q][0]); blo1 = fmin(blo1, s_qbox[q][1]); blo2 = fmin(blo2, s_qbox[q][2]);
+    bhi0 = fmax(bhi0, s_qbox[q][3]); bhi1 = fmax(bhi1, s_qbox[q][4]); bhi2 = fmax(bhi2, s_qbox[q][5]);
+  }
+  // ---- phase 1: candidates -> j table (pruned against the cell's box) and group lists (against the groups' boxes), one pass ----
+  // Rounds of TW * NB_UPW units: a wave takes NB_UPW units per round (their loads in flight together), ballots give each unit's
+  // counts, ONE barrier per round, then every wave takes the prefix over the round's units and writes its accepted entries: table and
+  // lists come out in candidate order whatever wave handled what.
+  // (inside this kernel the table entries also carry the type of j in bits 28..31: the rows need it per accepted candidate, and
+  // one load per table entry here replaces one per cluster and entry there; the copy that k_pair reads is written without it)
+  const GLOBAL_AS int *stype = as_global(S.stype);
+  int nj = 0;
+  int qn[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) qn[q] = 0;
+  const bool runs_ok = nrun <= NB_MAXRUN && nunit <= NB_MAXUNIT;   // (uniform; otherwise reported as a table overflow below)
+  for (int u0 = 0, par = 0; runs_ok && u0 < nunit; u0 += TW * NB_UPW, par ^= 1) {
+    int jv[NB_UPW], cv[NB_UPW];
+    double px[NB_UPW], py[NB_UPW], pz[NB_UPW];
+    int tv[NB_UPW];
+    bool valid[NB_UPW], home[NB_UPW];
+#pragma unroll
+    for (int i = 0; i < NB_UPW; i++) {
+      const int u = u0 + wave * NB_UPW + i;
+      valid[i] = false; home[i] = false; jv[i] = 0; cv[i] = CODE_HOME;
+      if (u < nunit) {
+        const int r = s_urun[u];
+        const int off = ((u - s_ub[r]) << 6) + lane;
+        valid[i] = off < s_rlen[r];
+        home[i] = r == 0;
+        jv[i] = valid[i] ? s_rjb[r] + off : cs;
+        cv[i] = s_rcode[r];
+      }
+      const size_t j = (size_t)jv[i];
+      px[i] = xq[2 * j]; py[i] = xq[2 * j + 1]; pz[i] = zq[2 * j];
+      tv[i] = stype[j];
+    }
+    bool ok[NB_UPW];
+    unsigned okq[NB_UPW];
+    unsigned long long m[NB_UPW];
+#pragma unroll
+    for (int i = 0; i < NB_UPW; i++) {
+      const double xj = px[i] + s_shift[3 * cv[i]], yj = py[i] + s_shift[3 * cv[i] + 1], zj = pz[i] + s_shift[3 * cv[i] + 2];
+      {
+        const double ex = fmax(0.0, fmax(blo0 - xj, xj - bhi0)), ey = fmax(0.0, fmax(blo1 - yj, yj - bhi1)), ez = fmax(0.0, fmax(blo2 - zj, zj - bhi2));
+        ok[i] = valid[i] && (home[i] || ex * ex + ey * ey + ez * ez < rl2);
+      }
+      okq[i] = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const double ex = fmax(0.0, fmax(s_qbox[q][0] - xj, xj - s_qbox[q][3])), ey = fmax(0.0, fmax(s_qbox[q][1] - yj, yj - s_qbox[q][4])),
+                     ez = fmax(0.0, fmax(s_qbox[q][2] - zj, zj - s_qbox[q][5]));
+        okq[i] |= (ok[i] && ex * ex + ey * ey + ez * ez < rl2) ? (1u << q) : 0u;
+      }
+      m[i] = __ballot(ok[i]);
+      const int ui = wave * NB_UPW + i;
+      if (lane == 0) s_ucnt[par][0][ui] = __popcll(m[i]);
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const unsigned long long mq = __ballot((okq[i] >> q) & 1u);
+        if (lane == 0) s_ucnt[par][1 + q][ui] = __popcll(mq);
+      }
     }
     __syncthreads();
+    // prefix over the round's units, per counter: lane u holds unit u's counts
+    int ex_c[1 + NQ], tot_c[1 + NQ];
+#pragma unroll
+    for (int c = 0; c <= NQ; c++) {
+      const int v = (lane < TW * NB_UPW) ? s_ucnt[par][c][lane] : 0;
+      const int incl = scan32_incl(v);
+      ex_c[c] = incl - v;
+      tot_c[c] = __builtin_amdgcn_readlane(incl, TW * NB_UPW - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < NB_UPW; i++) {
+      const int ui = wave * NB_UPW + i;
+      const int pos = nj + __builtin_amdgcn_readlane(ex_c[0], ui) + popc_below(m[i]);
+      if (ok[i] && pos < capj) s_jtab[pos] = jv[i] | (cv[i] << 23) | (tv[i] << 28);
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const bool in_q = (okq[i] >> q) & 1u;
+        const unsigned long long mq = __ballot(in_q);
+        const int lp = qn[q] + __builtin_amdgcn_readlane(ex_c[1 + q], ui) + popc_below(mq);
+        if (in_q && lp < qcap) s_qlist[q * qcap + lp] = (unsigned short)pos;
+      }
+    }
+    nj += tot_c[0];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) qn[q] += tot_c[1 + q];
   }
+  __syncthreads();
+  // k_pair keeps a wave's row headers in one VGPR triple (lane r = r-th row): at most 64 rows per wave, 64*TW clusters
+  // per cell.  A denser cell is reported like a table overflow (the engine retries with smaller cells), never dropped.
+  if (!runs_ok || nj > capj || nj > S.capj || nown / NI > 64 * TW) {   // uniform: table overflow -> the engine regrows and retries
+    if (threadIdx.x == 0) { S.tile_nj[cell] = 0; atomicOr(&sc.overflow, 1 | 4); atomicMax(&sc.maxj_seen, runs_ok ? nj : 2 * S.capj); }   // 4: table
+    for (int cl = cs / NI + threadIdx.x; cl < ce / NI; cl += TT) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
+    return;
+  }
+  {
+    GLOBAL_AS int *gj = as_global_w(S.tile_jtab) + (size_t)cell * S.capj;
+    for (int l = threadIdx.x; l < nj; l += TT) gj[l] = s_jtab[l] & 0x0FFFFFFF;
+    if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+    if ((int)threadIdx.x == q) s_qn[q] = (qn[q] > qcap) ? -1 : qn[q];
+  __syncthreads();
+
   // ---- phase 2 ----
 #ifdef PAIR_TIMING
   const unsigned long long tb1 = __builtin_readcyclecounter();
 #endif
   const int maxrow = S.maxneigh;
-  const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2;
+  const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2, excl2 = S.excl_cut2;
   unsigned int npairs = 0, npairs_ref = 0;   // per lane and tile: far below 2^32
   unsigned long long nrowent = 0;
   const bool count_ref = S.rlist_ref2 < S.rlist2;   // only a list wider than the reference's needs the second count (uniform)
@@ -378,7 +431,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       ci.x[a] = XQ_X(S, s0slot + a); ci.y[a] = XQ_Y(S, s0slot + a); ci.z[a] = XQ_Z(S, s0slot + a);
     }
     if (ci.atom[0] < 0) {  // empty cluster (pad only)
-      if (lane == 0) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; if (cl - cs / NI < 64) s_cost[cl - cs / NI] = 0; }
+      if (lane == 0) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
       continue;
     }
     GLOBAL_AS int *row = as_global_w(S.neigh) + (size_t)cl * maxrow;
@@ -396,7 +449,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       const int a = lane >> 4, e = lane & 15;
       const int na = (a == 0) ? exn[0] : (a == 1) ? exn[1] : (a == 2) ? exn[2] : exn[3];
       const int ba = (a == 0) ? exb[0] : (a == 1) ? exb[1] : (a == 2) ? exb[2] : exb[3];
-      s_ex[wave][lane] = (e < na) ? S.ex_list[ba + e] : -1;
+      s_ex[wave][lane] = (e < na) ? S.slot_of[S.ex_list[ba + e]] : -1;   // as slots: what the table entries name (no perm[] lookup per candidate)
     }
     int nA = 0, nB = 0, nC = 0, nD = 0;   // segments A, B, C1 (near skin band), C2 (far skin band)
     // the part of the table this cluster's quarter can reach (or the whole table if that list overflowed)
@@ -415,6 +468,9 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       const size_t jn = (size_t)(jt_n & MD_JMASK);
       pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
     }
+#ifdef PAIR_TIMING
+    if (lane == 0) { atomicAdd(&sc.dbg[10], (unsigned long long)((nl + 63) >> 6)); atomicAdd(&sc.dbg[11], 1ull); }
+#endif
     for (int base = 0; base < nl; base += 64) {
       const int l = l_n;
       const int jt = jt_n;
@@ -437,7 +493,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 
       int mask = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
       double rmin = 1.0e300;
-      // (pad atoms of the cluster sit at 1e15: never inside the list radius; lanes past the end of the list are cleared below; the
+      // (pad atoms of the cluster sit beyond 1e15, each pad slot at its own place: never inside the list radius of anything; lanes past the end of the list are cleared below; the
       // nearest of the four distances stands for the nearest ACCEPTED one: beyond the list radius it decides nothing, and otherwise it
       // can only be too small, which moves the entry to a nearer segment -- always allowed)
 #pragma unroll
@@ -458,18 +514,17 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       }
       // candidates inside the exclusion gate (bonded neighbours: a few chunks per row) take the wave-uniform slow path, which
       // looks at the four distances again and walks the exclusion lists
-      if (__ballot(mask != 0 && rmin < S.excl_cut2) != 0ull) {
-        if (mask != 0 && rmin < S.excl_cut2) {
-          const int aj = S.perm[j];
+      if (__ballot(mask != 0 && rmin < excl2) != 0ull) {
+        if (mask != 0 && rmin < excl2) {
 #pragma unroll
           for (int a = 0; a < NI; a++)
             if (mask & (1 << a)) {
               const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
-              if (dx * dx + dy * dy + dz * dz < S.excl_cut2) {
+              if (dx * dx + dy * dy + dz * dz < excl2) {
                 bool keep = true;
                 const int nl = min(exn[a], 16);
-                for (int e = 0; e < nl; e++) keep = keep && (s_ex[wave][a * 16 + e] != aj);
-                for (int e = 16; e < exn[a]; e++) keep = keep && (S.ex_list[exb[a] + e] != aj);
+                for (int e = 0; e < nl; e++) keep = keep && (s_ex[wave][a * 16 + e] != j);
+                for (int e = 16; e < exn[a]; e++) keep = keep && (S.slot_of[S.ex_list[exb[a] + e]] != j);
                 if (!keep) { mask &= ~(1 << a); refm &= ~(1 << a); }   // rmin may stay too small: only the segment choice sees it, and a nearer segment is always allowed
               }
             }
@@ -498,8 +553,6 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     for (int k = lane; k < mC_; k += 64) row[nA + nB + k] = lb[capB - 1 - k];
     if (lane == 0) {
       S.numneigh[2 * cl] = bad ? 0 : nA + nB + nC; S.numneigh[2 * cl + 1] = bad ? 0 : nD;
-      // cost of the row in k_pair (FP64 instructions per entry of the segments + per-row overhead)
-      if (cl - cs / NI < 64) s_cost[cl - cs / NI] = bad ? 0 : 5 * nA + 3 * nB + (3 * nC) / 2 + nD + 96;
     }
     nmax = max(nmax, n);
     nrowent += n;
@@ -507,127 +560,31 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 #ifdef PAIR_TIMING
   const unsigned long long tb2 = __builtin_readcyclecounter();
 #endif
-  // Schedule of k_pair, fixed here: longest-processing-time-first list scheduling of the tile's rows over the TW
-  // waves.  tile_order holds the tile's clusters grouped by wave (longest row first), tile_wstart the TW+1 group
-  // boundaries.  Rows were written by other waves -> barrier + own-workgroup visibility first.
-  if (S.sched_split == 2) {
-    // round robin (the default): the schedule does not look at the rows, so nothing waits for them -- a wave that has written its
-    // rows is done (the longest-first deal below has to wait for the slowest wave of the tile first)
-    if (wave == 0) {
-      const int c0i = cs / NI, nclus = nown / NI;
-      int *wst = S.tile_wstart + (size_t)cell * (TW + 1);
-      for (int w = lane; w <= TW; w += 64) {
-        int st = 0;
-        for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
-        wst[w] = st;
-      }
-      for (int i = lane; i < nclus; i += 64) {
-        const int w = i % TW;
-        int st = 0;
-        for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
-        S.tile_order[2 * c0i + st + i / TW] = (c0i + i) | (16 << 25);
-      }
-    }
-  } else {
-  __threadfence_block();
-  __syncthreads();
+  // Schedule of k_pair, fixed here: the tile's rows are dealt round robin to its TW waves.  tile_order holds the tile's clusters
+  // grouped by wave, tile_wstart the TW+1 group boundaries; an entry is (cluster | a << 20 | b << 25) and stands for the chunks
+  // [C a / 16, C b / 16) of the cluster's row, (0, 16) = the whole row.  The deal does not look at the rows, so nothing waits for
+  // them: a wave that has written its rows is done.  (Measured against longest-row-first list scheduling with and without splitting
+  // long rows, which have to wait for the tile's slowest wave first: 398 against 395 and 396 evaluations/s, profiles/HISTORY.md.)
   if (wave == 0) {
     const int c0i = cs / NI, nclus = nown / NI;
     int *wst = S.tile_wstart + (size_t)cell * (TW + 1);
-    if (nclus <= 64) {
-      const int i = lane;
-      const int cnt_i = (i < nclus) ? s_cost[i] : -1;
-      int rank = 0;
-      for (int j = 0; j < nclus; j++) {
-        const int cj = __shfl(cnt_i, j, 64);
-        rank += (cj > cnt_i || (cj == cnt_i && j < i)) ? 1 : 0;
-      }
-      if (i >= nclus) rank = -1;
-      int load[TW], num[TW];
-#pragma unroll
-      for (int w = 0; w < TW; w++) { load[w] = 0; num[w] = 0; }
-      int my_w = 0, my_pos = 0;
-      for (int r = 0; r < nclus; r++) {            // wave-uniform greedy
-        const unsigned long long m = __ballot(rank == r);
-        const int src = __ffsll((long long)m) - 1;
-        const int c = __shfl(cnt_i, src, 64);
-        int wmin = 0, lmin = load[0];
-#pragma unroll
-        for (int w = 1; w < TW; w++)
-          if (load[w] < lmin) { lmin = load[w]; wmin = w; }
-        int pos = 0;
-#pragma unroll
-        for (int w = 0; w < TW; w++)
-          if (w == wmin) { pos = num[w]; num[w] += 1; load[w] += c; }
-        if (lane == src) { my_w = wmin; my_pos = pos; }
-      }
-      // Rows are few (about 22 per tile for 8 waves: some waves get three, some two, and the tile waits for the slowest: an eighth
-      // of k_pair's wave time was spent at its final barrier).  So the loads are evened out by handing the tail of a row of the
-      // fullest wave to the emptiest: an entry of tile_order is (cluster | a << 20 | b << 25) and stands for the chunks
-      // [C a / 16, C b / 16) of the cluster's row, C = its number of 64-entry chunks when k_pair runs; (0, 16) = the whole row.
-      // A part costs its share of the row plus the per-row work (i-cluster records, force reduction: ~SPLIT_OVH entries' worth).
-      int pa = 0, pb = 16, ecl = i;     // this lane's entry: part [pa, pb) of cluster ecl (lanes >= nclus: entries made by splits)
-      bool have = i < nclus;
-      int nextra = 0;
-      if (S.sched_split == 1 && nclus >= TW && nclus + TW <= 64) {   // (a tile's share of tile_order is twice its clusters: room for TW more entries)
-        for (int it = 0; it < TW; it++) {
-          int wmax = 0, wmin = 0;
-#pragma unroll
-          for (int w = 1; w < TW; w++) {
-            if (load[w] > load[wmax]) wmax = w;
-            if (load[w] < load[wmin]) wmin = w;
-          }
-          const int diff = load[wmax] - load[wmin];
-          if (diff < 3 * SPLIT_OVH) break;
-          const unsigned long long sel = __ballot(have && i < nclus && my_w == wmax && pa == 0 && pb == 16);
-          if (sel == 0ull) break;
-          const int src = __ffsll((long long)sel) - 1;
-          const int c = __shfl(cnt_i, src, 64) - SPLIT_OVH;       // the part of the row's cost that scales with its length
-          if (c < 8 * SPLIT_OVH) break;
-          int m16 = (16 * (diff - SPLIT_OVH) + c) / (2 * c);      // sixteenths to move so that both waves end level
-          m16 = min(max(m16, 0), 12);
-          if (m16 < 2) break;
-          const int moved = (c * m16) / 16;
-          int pos = 0;
-#pragma unroll
-          for (int w = 0; w < TW; w++) {
-            if (w == wmax) load[w] -= moved;
-            if (w == wmin) { pos = num[w]; num[w] += 1; load[w] += moved + SPLIT_OVH; }
-          }
-          if (lane == src) pb = 16 - m16;
-          if (lane == nclus + nextra) { have = true; ecl = src; pa = 16 - m16; pb = 16; my_w = wmin; my_pos = pos; }
-          nextra++;
-        }
-      }
-      int start = 0, my_start = 0;
-#pragma unroll
-      for (int w = 0; w < TW; w++) {
-        if (lane == w) wst[w] = start;
-        if (my_w == w) my_start = start;
-        start += num[w];
-      }
-      if (lane == TW) wst[TW] = start;
-      if (have) S.tile_order[2 * c0i + my_start + my_pos] = (c0i + ecl) | (pa << 20) | (pb << 25);
-    } else {
-      // very large cells: round robin
-      for (int w = lane; w <= TW; w += 64) {
-        int st = 0;
-        for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
-        wst[w] = st;
-      }
-      for (int i = lane; i < nclus; i += 64) {
-        const int w = i % TW;
-        int st = 0;
-        for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
-        S.tile_order[2 * c0i + st + i / TW] = (c0i + i) | (16 << 25);
-      }
+    for (int w = lane; w <= TW; w += 64) {
+      int st = 0;
+      for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
+      wst[w] = st;
     }
-  }
+    for (int i = lane; i < nclus; i += 64) {
+      const int w = i % TW;
+      int st = 0;
+      for (int u = 0; u < w; u++) st += (nclus - u + TW - 1) / TW;
+      S.tile_order[2 * c0i + st + i / TW] = (c0i + i) | (16 << 25);
+    }
   }
 #ifdef PAIR_TIMING
   if (lane == 0) {
     const unsigned long long tb3 = __builtin_readcyclecounter();
     atomicAdd(&sc.dbg[5], tb1 - tb0); atomicAdd(&sc.dbg[6], tb2 - tb1); atomicAdd(&sc.dbg[7], tb3 - tb2);
+    atomicAdd(&sc.dbg[8], tb05 - tb0); atomicAdd(&sc.dbg[9], 1ull);
   }
 #endif
   const double cnt = wave_sum((double)npairs), cnt_ref = count_ref ? wave_sum((double)npairs_ref) : cnt;
@@ -995,8 +952,11 @@ static inline dim3 grid_xcd(int ntiles, int ns) { return dim3((unsigned)(ns * nt
 
 size_t mdk_pair_lds_bytes(int capj) { return (size_t)capj * (3 * sizeof(double) + sizeof(int)); }
 int mdk_neigh_capB(int maxrow) { return (int)(0.6 * maxrow) / 64 * 64 + 64; }
-// capacity of one quarter list (16-bit table indices): 3/4 of the table; a denser quarter walks the whole table instead
-static int neigh_qcap(int capj) { return (3 * capj / 4 + 63) / 64 * 64; }
+// capacity of one group's list (16-bit table indices): 3/4 of the table (a quarter of PE-10k's clusters reaches 72 %); a group that reaches more walks the whole table instead.  (The kernel's LDS must stay below 80 KB for two workgroups per CU: at 83 KB it ran 1.75 times longer.)
+static int neigh_qcap(int capj) {
+  static const int n16 = getenv("SCEMA_MD_QCAP16") ? atoi(getenv("SCEMA_MD_QCAP16")) : 12;   // (test switch: small values force the whole-table path)
+  return (n16 * capj / 16 + 63) / 64 * 64;
+}
 size_t mdk_neigh_lds_bytes(int capj, int maxrow) {
   return ((size_t)capj + (size_t)TW * mdk_neigh_capB(maxrow)) * sizeof(int) + (size_t)NQ * neigh_qcap(capj) * sizeof(unsigned short);
 }

@@ -89,7 +89,7 @@ struct SimScalars {
   double min_alpha, min_alphamax, min_fdothall, min_eorig, min_eprev, min_fhprev, min_engprev, min_alphaprev, min_fh_trial, min_ecur, min_einit;
   double min_dots[4];  // f.h, f.f, max |f| of the last evaluation (+ spare)
 #if defined(PAIR_TIMING) || defined(PAIR_COUNT)
-  unsigned long long dbg[8];
+  unsigned long long dbg[12];
 #endif
 };
 
@@ -124,7 +124,7 @@ struct SimDev {
   double coul_uscale;
   double coul_poly[MD_MAXPOLY];
   double coul_poly_g[MD_MAXPOLY];   // the same coefficients times g_ewald (k_pair)
-  int sched_split, pad_sched_;      // k_neigh_build evens out the waves of a tile by splitting rows (0: whole rows only; SCEMA_MD_ROW_SPLIT=0)
+  int pad_sched_[2];
   double rlist_ref2;      // (cutoff + the reference's skin)^2: pairs inside it are what the roofline accounting prices
   double seg_a2, seg_b2;  // row segments by build-time distance: (cut_coul+m)^2, (cut_lj+m)^2
   double far_band;        // width (A) of the near skin band C1

@@ -492,3 +492,30 @@ def test_pppm_grid_too_large_for_the_lds_and_mixed_grids(small_pe):
         assert np.abs(np.array(out[q].stress[:]) - exp).max() < 1e-7 * np.abs(exp).max(), q
     assert grids["a"] != grids["b"]
     e.close()
+
+
+def test_quarter_list_overflow_walks_the_whole_table():
+    """k_neigh_build: a quarter of a cell's clusters whose reach exceeds its list capacity walks the whole j table instead (never seen
+    at the default capacity).  Forced here by a tiny capacity (SCEMA_MD_QCAP16, read once per process -> a child process): same
+    pairs, forces and energies as the default run -- pad slots of a cell must not list each other on that path."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "d = build_pe(4, 6, 12, jitter=0.03, seed=11)\n"
+            "d['box'][6:9] = [0.4, -0.3, 0.2]\n"
+            "e = capi.Engine()\n"
+            "e.register_replica('g0', 1, d)\n"
+            "f, en, w, info = e.debug_compute('g0', 1, use_shake=True)\n"
+            "print(json.dumps({'npairs': float(info['npairs']), 'f': np.asarray(f).ravel().tolist(), 'en': np.asarray(en)[:7].tolist(), 'w': np.asarray(w)[:7].ravel().tolist()}))\n")
+    out = {}
+    for q in ("12", "2"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, SCEMA_MD_QCAP16=q))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[q] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = out["12"], out["2"]
+    assert a["npairs"] == b["npairs"]
+    assert np.all(np.isfinite(b["en"])) and np.all(np.isfinite(b["w"]))
+    assert np.abs(np.array(a["f"]) - np.array(b["f"])).max() < 1e-11 * np.abs(np.array(a["f"])).max()
+    assert np.abs(np.array(a["en"]) - np.array(b["en"])).max() < 1e-11 * np.abs(np.array(a["en"])).max()
