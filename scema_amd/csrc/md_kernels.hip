@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TPB) void k_cell_scan(const SimDev *sims) {
     sc.ago = 0;
     sc.nbuilds += 1;
     sc.nentries = 0ull;
-    sc.nentries_ref = 0ull;
+    if (!(S.rlist_ref2 < S.rlist2) || sc.step == 0) sc.nentries_ref = 0ull;   // (a wider list counts the reference's pairs at the first build of a run only)
     sc.nrowent = 0ull;
   }
 }
