@@ -606,12 +606,16 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   size_t ev_used = 0;
   std::vector<std::pair<int, int>> launch_sims;   // per timed pair launch: (first position, simulations)
   // one MD step of the first `na` simulations of half h, as a sequence of launches on that half's stream
+  // Small batches are launch-bound (a single replica: ~20 launches of 5-35 us per step), so there k_initial_integrate also writes the
+  // slot-ordered records that k_pack would (scattered 16-byte stores: for 576 replicas that costs what the separate, coalesced
+  // k_pack costs -- 304 against 170 + 125 us -- so large batches keep k_pack)
+  const bool fuse_pack = ns <= 32;
   auto launch_step = [&](int h, int na, bool timed) -> int {
     hipStream_t st = hs[h];
     const SimDev *Dh = D + hbeg[h];
     if (spec.nh) { mdk_pre_nh(st, Dh, na); mdk_initial_integrate_nh(st, Dh, na, maxatoms); }
-    else { mdk_pre(st, Dh, na); mdk_initial_integrate(st, Dh, na, maxatoms); }
-    mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj);
+    else mdk_initial_integrate(st, Dh, na, maxatoms, fuse_pack);   // (its k_pre: at the end of the step before, in k_post; for step 1 below)
+    mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack);
     { const int rcp = pppm_fork(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
     if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
@@ -634,7 +638,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     mdk_shake(st, Dh, na, maxclus, 1.0);
     mdk_final_integrate(st, Dh, na, maxatoms, 1);
     if (spec.nh) mdk_post_nh(st, Dh, na);
-    else mdk_post(st, Dh, na);
+    else mdk_post(st, Dh, na, 1);
     if (spec.deform) mdk_remap(st, Dh, na, maxatoms);
     return SCEMA_MD_OK;
   };
@@ -658,6 +662,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   std::vector<std::unique_ptr<DevBuf>> flip_bufs;          // k-vector tables in the new reciprocal basis, alive until the run has drained
   std::vector<std::unique_ptr<std::vector<int>>> flip_host;
   std::vector<std::unique_ptr<SimDev>> flip_desc;
+  if (!spec.nh)   // the k_pre of step 1, for the simulations that have a step 1; every later one rides on the k_post of the step before
+    for (int h = 0; h < nhalf; h++) {
+      const int n1 = active(h, 1);
+      if (n1 > 0) mdk_pre(hs[h], D + hbeg[h], n1);
+    }
   for (int step = 1; step <= maxsteps;) {
     const int na = active(0, step);
     if (na == 0) break;

@@ -5,8 +5,8 @@ struct SimDev;
 void mdk_phase_init(hipStream_t st, const SimDev *d, int ns);
 void mdk_setup_post(hipStream_t st, const SimDev *d, int ns);
 void mdk_pre(hipStream_t st, const SimDev *d, int ns);
-void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms);
-void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj);
+void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, bool pack = false);   // pack: also the slot records of k_pair (then no k_pack)
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj, bool pack = true);
 void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int maxrow, int capj);
 // dynamic LDS of the tile kernels for a j-table capacity (the engine sizes the cell grid so that these fit)
 size_t mdk_pair_lds_bytes(int capj);
@@ -22,7 +22,7 @@ void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax
 void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir, int fkeep = 0);   // fkeep: add to the forces a PPPM chain left in f
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);
-void mdk_post(hipStream_t st, const SimDev *d, int ns);
+void mdk_post(hipStream_t st, const SimDev *d, int ns, int next_pre = 0);
 void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms);
 // triclinic box flip of ONE simulation between two steps (fix deform, flip yes): new tilts, forced list rebuild
 void mdk_flip(hipStream_t st, const SimDev *sim, double xy, double xz, double yz);

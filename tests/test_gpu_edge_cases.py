@@ -494,7 +494,7 @@ def test_pppm_grid_too_large_for_the_lds_and_mixed_grids(small_pe):
     e.close()
 
 
-def test_quarter_list_overflow_walks_the_whole_table():
+def test_rarely_taken_list_build_paths_give_the_same_lists():
     """k_neigh_build: a quarter of a cell's clusters whose reach exceeds its list capacity walks the whole j table instead (never seen
     at the default capacity).  Forced here by a tiny capacity (SCEMA_MD_QCAP16, read once per process -> a child process): same
     pairs, forces and energies as the default run -- pad slots of a cell must not list each other on that path."""
@@ -510,12 +510,15 @@ def test_quarter_list_overflow_walks_the_whole_table():
             "f, en, w, info = e.debug_compute('g0', 1, use_shake=True)\n"
             "print(json.dumps({'npairs': float(info['npairs']), 'f': np.asarray(f).ravel().tolist(), 'en': np.asarray(en)[:7].tolist(), 'w': np.asarray(w)[:7].ravel().tolist()}))\n")
     out = {}
-    for q in ("12", "2"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, SCEMA_MD_QCAP16=q))
+    # (the third run takes the three-kernel cell binning of replicas too large for the one-launch k_cell_build)
+    for name, env in (("default", {}), ("whole_table", {"SCEMA_MD_QCAP16": "2"}), ("three_kernel_binning", {"SCEMA_MD_CELL_BUILD": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
-        out[q] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    a, b = out["12"], out["2"]
-    assert a["npairs"] == b["npairs"]
-    assert np.all(np.isfinite(b["en"])) and np.all(np.isfinite(b["w"]))
-    assert np.abs(np.array(a["f"]) - np.array(b["f"])).max() < 1e-11 * np.abs(np.array(a["f"])).max()
-    assert np.abs(np.array(a["en"]) - np.array(b["en"])).max() < 1e-11 * np.abs(np.array(a["en"])).max()
+        out[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a = out["default"]
+    for name in ("whole_table", "three_kernel_binning"):
+        b = out[name]
+        assert a["npairs"] == b["npairs"], name
+        assert np.all(np.isfinite(b["en"])) and np.all(np.isfinite(b["w"])), name
+        assert np.abs(np.array(a["f"]) - np.array(b["f"])).max() < 1e-11 * np.abs(np.array(a["f"])).max(), name
+        assert np.abs(np.array(a["en"]) - np.array(b["en"])).max() < 1e-11 * np.abs(np.array(a["en"])).max(), name
