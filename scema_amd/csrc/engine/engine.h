@@ -120,14 +120,14 @@ struct Topo {
   SysCopy original;
   std::vector<int> type;
   std::vector<double> q, mass_atom, lj;
-  int nbonds = 0, nbonds_noshake = 0, nangles = 0, ndihedrals = 0, nimpropers = 0, nspecial = 0, nclus = 0, ncons = 0;
+  int nbonds = 0, nbonds_noshake = 0, nangles = 0, ndihedrals = 0, nimpropers = 0, nspecial = 0, nclus = 0, ncons = 0, nfree = 0;
   double qsqsum = 0, qsum = 0, excl_cut = 0;
   double init_box[9];
   std::vector<double> init_x, init_v;
   // device copies
   DevBuf d_rtype;          // ReaxFF: force-field type per atom (element of the LAMMPS type), valid for rtype_stamp
   int rtype_stamp = -1;
-  DevBuf d_type, d_q, d_mass, d_lj, d_bt_terms, d_bt_coef, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_bt_desc, d_bt_atoms, d_bt_rank;
+  DevBuf d_type, d_q, d_mass, d_lj, d_bt_terms, d_bt_coef, d_ex_start, d_ex_list, d_clus_at, d_clus_n, d_clus_d, d_free_at, d_bt_desc, d_bt_atoms, d_bt_rank;
   int bt_ntile = 0, bt_maxloc = 1, bt_maxchunk = 1, bt_ncoef = 0, bt_cf_off[4] = {0, 0, 0, 0};
   double sp_w[6] = {0, 0, 0, 0, 0, 0};   // special_bonds weights: lj 1-2, 1-3, 1-4, coul 1-2, 1-3, 1-4
 };

@@ -156,7 +156,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const int hbeg[2] = {0, nhalf == 2 ? (ns + 1) / 2 : ns}, hcnt[2] = {nhalf == 2 ? (ns + 1) / 2 : ns, nhalf == 2 ? ns / 2 : 0};
   e->h_sims.assign(ns, SimDev());
   int maxbt = 1, maxloc = 1, maxcoef = 0;
-  int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxsteps = 0;
+  int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxunits = 0, maxsteps = 0;
   // k-vector tables of all simulations (indices, row run lengths, groups), packed into one upload
   std::vector<int> &kpack = e->h_kpack;
   kpack.clear();
@@ -390,6 +390,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     maxbt = std::max(maxbt, T.bt_ntile); maxloc = std::max(maxloc, T.bt_maxloc);
     maxcoef = std::max(maxcoef, T.bt_ncoef);
     S.clus_at = T.d_clus_at.as<int>(); S.clus_n = T.d_clus_n.as<int>(); S.clus_d = T.d_clus_d.as<double>();
+    S.free_at = T.d_free_at.as<int>(); S.nfree = T.nfree;
     S.x = A.st->x.as<double>(); S.v = A.st->v.as<double>(); S.f = sl.f.as<double>();
     S.xq = sl.xq.as<double4>(); S.stype = sl.stype.as<int>(); S.perm = sl.perm.as<int>(); S.slot_tmp = sl.slot_tmp.as<int>();
     S.wrapn = sl.wrapn.as<int>(); S.xhold = sl.xhold.as<double>();
@@ -416,6 +417,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     for (int d = 0; d < 3; d++) mmax = std::max(mmax, S.kmaxd[d] + 1);
     maxb = std::max(maxb, S.nbonds); maxa = std::max(maxa, S.nangles); maxd = std::max(maxd, S.ndihedrals);
     maxi = std::max(maxi, S.nimpropers); maxs = std::max(maxs, S.nspecial); maxclus = std::max(maxclus, S.use_shake ? S.nclus : 0);
+    maxunits = std::max(maxunits, S.use_shake ? S.nclus + S.nfree : S.natoms);
     maxsteps = std::max(maxsteps, A.nsteps);
   }
   if ((size_t)64 * 3 * mmax * 16 + 4096 > 160 * 1024)
@@ -610,6 +612,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // slot-ordered records that k_pack would (scattered 16-byte stores: for 576 replicas that costs what the separate, coalesced
   // k_pack costs -- 304 against 170 + 125 us -- so large batches keep k_pack)
   const bool fuse_pack = ns <= 32;
+  // Steps without a per-atom reciprocal sum (PPPM or no k-space), Verlet / fix nvt, production virial: the tail of the force stage in
+  // one pass (k_finish) instead of k_ewald_force + k_shake + k_final_integrate (SCEMA_MD_FUSED_TAIL=0: the three kernels)
+  static const bool fused_tail_on = !(getenv("SCEMA_MD_FUSED_TAIL") && atoi(getenv("SCEMA_MD_FUSED_TAIL")) == 0);
+  const bool fused_tail = fused_tail_on && !spec.nh && maxk == 0 && !spec.ev_always;
   auto launch_step = [&](int h, int na, bool timed) -> int {
     hipStream_t st = hs[h];
     const SimDev *Dh = D + hbeg[h];
@@ -633,10 +639,19 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       ev_used += 2;
       launch_sims.push_back({hbeg[h], na});
     }
-    HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
-    if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
-    mdk_shake(st, Dh, na, maxclus, 1.0);
-    mdk_final_integrate(st, Dh, na, maxatoms, 1);
+    if (fused_tail) {
+      // no per-atom reciprocal sum: the bonded kernel, the PPPM chain (its forces stored in f, from the side stream or here), then
+      // assembly of f, fix shake and the second half-kick in one pass (k_finish)
+      mdk_bonded(st, Dh, na, maxbt, maxloc, maxcoef, 0);
+      if (pppm_side) HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
+      else { const int rcp = pppm_stage(st, hbeg[h], na, spec.deform, 0); if (rcp) return rcp; }
+      mdk_finish(st, Dh, na, maxunits, ev, maxgrid > 0 ? 1 : 0);
+    } else {
+      HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
+      if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
+      mdk_shake(st, Dh, na, maxclus, 1.0);
+      mdk_final_integrate(st, Dh, na, maxatoms, 1);
+    }
     if (spec.nh) mdk_post_nh(st, Dh, na);
     else mdk_post(st, Dh, na, 1);
     if (spec.deform) mdk_remap(st, Dh, na, maxatoms);

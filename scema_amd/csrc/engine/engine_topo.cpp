@@ -144,6 +144,16 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
     t.ncons++;
   }
   t.nclus = (int)clus_n.size();
+  // the atoms outside the clusters (k_finish walks clusters, then these)
+  std::vector<int> free_at;
+  {
+    std::vector<char> in_cl(n, 0);
+    for (int cl = 0; cl < t.nclus; cl++)
+      for (int k = 0; k < clus_n[cl]; k++) in_cl[clus_at[4 * cl + k]] = 1;
+    for (int i = 0; i < n; i++)
+      if (!in_cl[i]) free_at.push_back(i);
+  }
+  t.nfree = (int)free_at.size();
   // ---- per-term coefficient expansion; unconstrained bonds first ----
   std::vector<int> bond_at, angle_at(s->angle_atoms, s->angle_atoms + 3 * (size_t)s->nangles),
       dih_at(s->dihedral_atoms, s->dihedral_atoms + 4 * (size_t)s->ndihedrals),
@@ -344,6 +354,7 @@ int build_topo(scema_md_engine *e, const scema_md_system *s, Topo &t) {
   if ((rc = upload(e, t.d_clus_at, clus_at))) return rc;
   if ((rc = upload(e, t.d_clus_n, clus_n))) return rc;
   if ((rc = upload(e, t.d_clus_d, clus_d))) return rc;
+  if ((rc = upload(e, t.d_free_at, free_at))) return rc;
   return SCEMA_MD_OK;
 }
 

@@ -21,6 +21,8 @@ void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxlo
 void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax, int maxgrp);
 void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir, int fkeep = 0);   // fkeep: add to the forces a PPPM chain left in f
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);
+// assembly of f + fix shake + second half-kick in one pass (steps without a per-atom reciprocal sum); fkeep: PPPM forces wait in f
+void mdk_finish(hipStream_t st, const SimDev *d, int ns, int maxunits, int pairvir, int fkeep);
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);
 void mdk_post(hipStream_t st, const SimDev *d, int ns, int next_pre = 0);
 void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms);

@@ -884,27 +884,13 @@ __global__ __launch_bounds__(EWF_T) void k_ewald_force(const SimDev *sims, int p
 // k_shake : fix shake, one thread per star cluster (central atom + 1..3 satellites)
 // ------------------------------------------------------------------------------------------
 // One star cluster with NB satellites (NB a compile-time constant: every array below lives in registers, every loop is
-// unrolled; the generic form with run-time bounds put its arrays into scratch memory and ran at 192 VGPRs)
+// unrolled; the generic form with run-time bounds put its arrays into scratch memory and ran at 192 VGPRs).
+// shake_lambda: the multipliers of the NB constraints.  xc = positions at the start of the step (constraint directions), xs = the
+// unconstrained positions after it, dist = bond lengths; r[k] = xc[0] - xc[k+1] by minimum image is returned with them.
 template <int NB>
-__device__ __forceinline__ void shake_cluster(const SimDev &S, const BoxD &b, int cl, double dtfsq_scale, double (&v)[6]) {
-  const double dtv = S.dt, dtfsq = dtfsq_scale * S.dt * S.dt * MD_FTM2V;
-  const int *at = S.clus_at + 4 * cl;
-  const double *dist = S.clus_d + 3 * cl;
-  int ia[NB + 1];
-  double invm[NB + 1], xs[NB + 1][3], xc[NB + 1][3];
-  // v is exact here: k_initial_integrate folded the deferred NH factor in before the drift
-#pragma unroll
-  for (int a = 0; a <= NB; a++) {
-    const int i = at[a];
-    ia[a] = i;
-    invm[a] = 1.0 / S.mass[i];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      xc[a][k] = S.x[3 * i + k];
-      xs[a][k] = xc[a][k] + dtv * S.v[3 * i + k] + dtfsq * invm[a] * S.f[3 * i + k];
-    }
-  }
-  double r[NB][3], sv[NB][3];
+__device__ __forceinline__ void shake_lambda(const SimDev &S, const BoxD &b, const double *dist, const double (&invm)[NB + 1], const double (&xc)[NB + 1][3],
+                                             const double (&xs)[NB + 1][3], double (&lam)[NB], double (&r)[NB][3]) {
+  double sv[NB][3];
 #pragma unroll
   for (int k = 0; k < NB; k++) {
 #pragma unroll
@@ -912,7 +898,6 @@ __device__ __forceinline__ void shake_cluster(const SimDev &S, const BoxD &b, in
     minimg(b, r[k][0], r[k][1], r[k][2]);
     minimg(b, sv[k][0], sv[k][1], sv[k][2]);
   }
-  double lam[NB];
 #pragma unroll
   for (int k = 0; k < NB; k++) lam[k] = 0.0;
   if (NB == 1) {
@@ -984,6 +969,29 @@ __device__ __forceinline__ void shake_cluster(const SimDev &S, const BoxD &b, in
       iter++;
     }
   }
+}
+
+template <int NB>
+__device__ __forceinline__ void shake_cluster(const SimDev &S, const BoxD &b, int cl, double dtfsq_scale, double (&v)[6]) {
+  const double dtv = S.dt, dtfsq = dtfsq_scale * S.dt * S.dt * MD_FTM2V;
+  const int *at = S.clus_at + 4 * cl;
+  const double *dist = S.clus_d + 3 * cl;
+  int ia[NB + 1];
+  double invm[NB + 1], xs[NB + 1][3], xc[NB + 1][3];
+  // v is exact here: k_initial_integrate folded the deferred NH factor in before the drift
+#pragma unroll
+  for (int a = 0; a <= NB; a++) {
+    const int i = at[a];
+    ia[a] = i;
+    invm[a] = 1.0 / S.mass[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      xc[a][k] = S.x[3 * i + k];
+      xs[a][k] = xc[a][k] + dtv * S.v[3 * i + k] + dtfsq * invm[a] * S.f[3 * i + k];
+    }
+  }
+  double lam[NB], r[NB][3];
+  shake_lambda<NB>(S, b, dist, invm, xc, xs, lam, r);
   double f0[3] = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < NB; k++) {
@@ -1040,6 +1048,115 @@ __global__ __launch_bounds__(TPB) void k_final_integrate(const SimDev *sims, int
     ke[0] = mm * v[0] * v[0]; ke[1] = mm * v[1] * v[1]; ke[2] = mm * v[2] * v[2];
     ke[3] = mm * v[0] * v[1]; ke[4] = mm * v[0] * v[2]; ke[5] = mm * v[1] * v[2];
   }
+  block_atomic_add<6>(ke, sc.ke, s_red);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finish : end of the force stage of a step in ONE pass over the atoms, for the steps that need no per-atom reciprocal sum (PPPM or no
+// k-space; Verlet / fix nvt): what k_ewald_force (assembly of f from the slot-ordered pair forces, the rank-ordered bonded forces
+// and the PPPM forces left in f; pair virial), k_shake and k_final_integrate do in three.  One thread per SHAKE cluster, then one
+// per atom outside the clusters (all atoms of a replica that runs without fix shake).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void assemble_atom(const SimDev &S, int a, bool keep, int pairvir, double (&f)[3], double (&pv)[6]) {
+  const size_t sl = (size_t)S.slot_of[a], np = (size_t)S.npad, r = (size_t)S.bt_rank[a];
+  const double px = S.fs[sl], py = S.fs[np + sl], pz = S.fs[2 * np + sl];
+  f[0] = px + S.fb[3 * r] + (keep ? S.f[3 * a] : 0.0);
+  f[1] = py + S.fb[3 * r + 1] + (keep ? S.f[3 * a + 1] : 0.0);
+  f[2] = pz + S.fb[3 * r + 2] + (keep ? S.f[3 * a + 2] : 0.0);
+  if (pairvir) {
+    // pair virial, part 1: wrapped slot position (x) total pair force of the slot (part 2 = k_pair's partials)
+    const double *xy = (const double *)S.xq + 2 * sl, *zq = (const double *)S.xq + 2 * np + 2 * sl;
+    const double x = xy[0], y = xy[1], z = zq[0];
+    pv[0] += x * px; pv[1] += y * py; pv[2] += z * pz; pv[3] += x * py; pv[4] += x * pz; pv[5] += y * pz;
+  }
+}
+__device__ __forceinline__ void kick_atom(const SimDev &S, int a, double invm, const double (&f)[3], const double (&v0)[3], double (&ke)[6]) {
+  const double dtfm = 0.5 * S.dt * MD_FTM2V * invm;
+  double v[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    v[k] = v0[k] + dtfm * f[k];
+    S.v[3 * a + k] = v[k];
+    S.f[3 * a + k] = f[k];
+  }
+  const double mm = MD_MVV2E / invm;
+  ke[0] += mm * v[0] * v[0]; ke[1] += mm * v[1] * v[1]; ke[2] += mm * v[2] * v[2];
+  ke[3] += mm * v[0] * v[1]; ke[4] += mm * v[0] * v[2]; ke[5] += mm * v[1] * v[2];
+}
+template <int NB>
+__device__ __forceinline__ void finish_cluster(const SimDev &S, const BoxD &b, int cl, bool keep, int pairvir, double (&pv)[6], double (&sv)[6], double (&ke)[6]) {
+  const double dtv = S.dt, dtfsq = S.dt * S.dt * MD_FTM2V;
+  const int *at = S.clus_at + 4 * cl;
+  const double *dist = S.clus_d + 3 * cl;
+  int ia[NB + 1];
+  double invm[NB + 1], xs[NB + 1][3], xc[NB + 1][3], f[NB + 1][3], v0[NB + 1][3];
+#pragma unroll
+  for (int a = 0; a <= NB; a++) {
+    const int i = at[a];
+    ia[a] = i;
+    invm[a] = 1.0 / S.mass[i];
+    assemble_atom(S, i, keep, pairvir, f[a], pv);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      xc[a][k] = S.x[3 * i + k];
+      v0[a][k] = S.v[3 * i + k];
+      xs[a][k] = xc[a][k] + dtv * v0[a][k] + dtfsq * invm[a] * f[a][k];
+    }
+  }
+  double lam[NB], r[NB][3];
+  shake_lambda<NB>(S, b, dist, invm, xc, xs, lam, r);
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const double l = lam[k] / dtfsq;
+    const double ff[3] = {l * r[k][0], l * r[k][1], l * r[k][2]};
+#pragma unroll
+    for (int c = 0; c < 3; c++) { f[0][c] += ff[c]; f[k + 1][c] -= ff[c]; }
+    vt(sv, r[k][0], r[k][1], r[k][2], ff[0], ff[1], ff[2]);
+  }
+#pragma unroll
+  for (int a = 0; a <= NB; a++) kick_atom(S, ia[a], invm[a], f[a], v0[a], ke);
+}
+__global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairvir, int fkeep) {
+  const SimDev &S = sims[blockIdx.y];
+  SimScalars &sc = *S.sc;
+  const int nunits = S.use_shake ? S.nclus + S.nfree : S.natoms;
+  if ((int)(blockIdx.x * TPB) >= nunits) return;
+  __shared__ double s_red[6 * (TPB / 64)];
+  const int u = blockIdx.x * TPB + threadIdx.x;
+  const bool keep = fkeep && S.pg[0] > 0;
+  double pv[6] = {0, 0, 0, 0, 0, 0}, sv[6] = {0, 0, 0, 0, 0, 0}, ke[6] = {0, 0, 0, 0, 0, 0};
+  if (u < nunits) {
+    if (S.use_shake && u < S.nclus) {
+      BoxD b;
+      box_derive(sc.box, b);
+      const int nb = S.clus_n[u] - 1;
+      if (nb == 2) finish_cluster<2>(S, b, u, keep, pairvir, pv, sv, ke);        // CH2
+      else if (nb == 1) finish_cluster<1>(S, b, u, keep, pairvir, pv, sv, ke);
+      else if (nb == 3) finish_cluster<3>(S, b, u, keep, pairvir, pv, sv, ke);   // CH3
+    } else {
+      const int a = S.use_shake ? S.free_at[u - S.nclus] : u;
+      double f[3];
+      assemble_atom(S, a, keep, pairvir, f, pv);
+      const double v0[3] = {S.v[3 * a], S.v[3 * a + 1], S.v[3 * a + 2]};
+      kick_atom(S, a, 1.0 / S.mass[a], f, v0, ke);
+    }
+  }
+  if (pairvir) {
+    const int nblk = (nunits + TPB - 1) / TPB;   // blocks of this simulation that got this far
+    const int nrows = S.ncells * MD_TILE_WAVES;  // one row of 6 per cell and wave of k_pair
+    for (int r = blockIdx.x * TPB + threadIdx.x; r < nrows; r += nblk * TPB) {
+      const double *vp = S.virp + (size_t)r * 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) pv[k] += vp[k];
+    }
+    for (int r = blockIdx.x * TPB + threadIdx.x; r < S.bt_ntile; r += nblk * TPB) {   // the lumped bonded virial: one row of 6 per bonded tile
+      const double *vp = S.virb + (size_t)r * 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) pv[k] += vp[k];
+    }
+    block_atomic_add<6>(pv, sc.vir + P_LJ * 6, s_red);
+  }
+  if (S.use_shake) block_atomic_add<6>(sv, sc.vir + P_SHAKE * 6, s_red);
   block_atomic_add<6>(ke, sc.ke, s_red);
 }
 
@@ -1207,6 +1324,9 @@ void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int 
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale) {
   if (maxclus <= 0) return;
   hipLaunchKernelGGL(k_shake, grid2(cdiv(maxclus, TPB), ns), dim3(TPB), 0, st, d, dtfsq_scale);
+}
+void mdk_finish(hipStream_t st, const SimDev *d, int ns, int maxunits, int pairvir, int fkeep) {
+  hipLaunchKernelGGL(k_finish, grid2(cdiv(maxunits, TPB), ns), dim3(TPB), 0, st, d, pairvir, fkeep);
 }
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick) {
   hipLaunchKernelGGL(k_final_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d, kick);

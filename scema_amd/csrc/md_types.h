@@ -124,7 +124,7 @@ struct SimDev {
   double coul_uscale;
   double coul_poly[MD_MAXPOLY];
   double coul_poly_g[MD_MAXPOLY];   // the same coefficients times g_ewald (k_pair)
-  int pad_sched_[2];
+  int nfree, pad_free_;
   double rlist_ref2;      // (cutoff + the reference's skin)^2: pairs inside it are what the roofline accounting prices
   double seg_a2, seg_b2;  // row segments by build-time distance: (cut_coul+m)^2, (cut_lj+m)^2
   double far_band;        // width (A) of the near skin band C1
@@ -144,6 +144,7 @@ struct SimDev {
   const int *bt_rank;              // atom -> breadth-first rank in the bond graph (index into fb)
   int bt_ntile;
   const int *clus_at, *clus_n; const double *clus_d;
+  const int *free_at;              // the atoms outside the SHAKE clusters (nfree of them)
   // state
   double *x, *v, *f;
   double *fs;       // pair forces in slot order, [3][npad] (zeroed by k_pack, accumulated by k_pair, folded into f by k_ewald_force)

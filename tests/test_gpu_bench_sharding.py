@@ -79,3 +79,18 @@ def test_reax_replica_set_bench_line():
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["kernel"].startswith("k_rx_qeq_sweep") and r["launches"] > 0 and 0.0 < r["frac"] < 1.0
     assert 300 < r["stored_entries_per_row"] < 1100 and 2 < r["qeq_iterations_per_solve"] < 80
+
+
+def test_one_pass_step_tail_equals_the_three_kernels():
+    """k_finish (assembly of f + fix shake + second half-kick in one pass, the default for PPPM / no k-space steps) against
+    k_ewald_force + k_shake + k_final_integrate (SCEMA_MD_FUSED_TAIL=0), and the one-launch cell binning against the three-kernel
+    one, on the bench's small replica set: the same stresses (FP64 atomics: summation order differs from run to run)"""
+    def run(env):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + COMMON, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                           env=dict(os.environ, MASTER_ADDR="127.0.0.1", **env))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["config"]["stress_zz_checksum_Pa"]
+    a = run({})
+    for env in ({"SCEMA_MD_FUSED_TAIL": "0"}, {"SCEMA_MD_CELL_BUILD": "0"}):
+        b = run(env)
+        assert abs(a - b) <= 1e-8 * abs(a), (env, a, b)
