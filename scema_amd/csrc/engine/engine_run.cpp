@@ -612,10 +612,12 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // slot-ordered records that k_pack would (scattered 16-byte stores: for 576 replicas that costs what the separate, coalesced
   // k_pack costs -- 304 against 170 + 125 us -- so large batches keep k_pack)
   const bool fuse_pack = ns <= 32;
-  // Steps without a per-atom reciprocal sum (PPPM or no k-space), Verlet / fix nvt, production virial: the tail of the force stage in
-  // one pass (k_finish) instead of k_ewald_force + k_shake + k_final_integrate (SCEMA_MD_FUSED_TAIL=0: the three kernels)
-  static const bool fused_tail_on = !(getenv("SCEMA_MD_FUSED_TAIL") && atoi(getenv("SCEMA_MD_FUSED_TAIL")) == 0);
-  const bool fused_tail = fused_tail_on && !spec.nh && maxk == 0 && !spec.ev_always;
+  // Likewise the tail of the force stage of steps without a per-atom reciprocal sum (PPPM or no k-space; Verlet / fix nvt, production
+  // virial): one pass (k_finish) instead of k_ewald_force + k_shake + k_final_integrate -- two launches less for a small batch
+  // (a single replica: 14.2 against 17.4 us); a thread per SHAKE cluster gathers less well than the three kernels stream, so large
+  // batches keep them (576 replicas: 452 against 426 us).  SCEMA_MD_FUSED_TAIL = 0 / 1 forces either.
+  static const int fused_tail_env = getenv("SCEMA_MD_FUSED_TAIL") ? atoi(getenv("SCEMA_MD_FUSED_TAIL")) : -1;
+  const bool fused_tail = (fused_tail_env < 0 ? ns <= 32 : fused_tail_env != 0) && !spec.nh && maxk == 0 && !spec.ev_always;
   auto launch_step = [&](int h, int na, bool timed) -> int {
     hipStream_t st = hs[h];
     const SimDev *Dh = D + hbeg[h];

@@ -82,7 +82,7 @@ def test_reax_replica_set_bench_line():
 
 
 def test_one_pass_step_tail_equals_the_three_kernels():
-    """k_finish (assembly of f + fix shake + second half-kick in one pass, the default for PPPM / no k-space steps) against
+    """k_finish (assembly of f + fix shake + second half-kick in one pass, the default for small batches of PPPM / no k-space steps) against
     k_ewald_force + k_shake + k_final_integrate (SCEMA_MD_FUSED_TAIL=0), and the one-launch cell binning against the three-kernel
     one, on the bench's small replica set: the same stresses (FP64 atomics: summation order differs from run to run)"""
     def run(env):
