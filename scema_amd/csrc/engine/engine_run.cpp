@@ -482,7 +482,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       if (new_box) mdk_pppm_gf(st, Dp, na, maxgrid);
       mdk_pppm_solve(st, Dp, na, maxgrid, maxdims);
       clean = true;
-      mdk_pppm_force(st, Dp, na, maxgrid, maxatoms, add);
+      mdk_pppm_force(st, Dp, na, maxgrid, maxatoms, add, 1);
       return SCEMA_MD_OK;
     }
     auto transform = [&](bool fields, int dir) -> int {   // the charge grids forward, or the three field grids of every simulation back
@@ -813,6 +813,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
             (double)c.dbg[4] / std::max(1ull, c.dbg[5]), c.dbg[7], (double)c.dbg[6] / std::max(1ull, c.dbg[7]), c.dbg[4], c.dbg[6]);
 #endif
 #ifdef PAIR_TIMING
+    if (c.dbg2[7])
+      fprintf(stderr, "[scema_md] k_pppm_solve clocks (sim 0, thread 0, mean per launch): grid in %.0f, forward passes %.0f, spectra %.0f + %.0f, inverse passes %.0f + %.0f, out + sums %.0f\n",
+              (double)c.dbg2[0] / c.dbg2[7], (double)c.dbg2[1] / c.dbg2[7], (double)c.dbg2[2] / c.dbg2[7], (double)c.dbg2[4] / c.dbg2[7], (double)c.dbg2[3] / c.dbg2[7],
+              (double)c.dbg2[5] / c.dbg2[7], (double)c.dbg2[6] / c.dbg2[7]);
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
             (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);
     if (c.nbuilds > 0) {

@@ -31,10 +31,24 @@ __device__ __forceinline__ void minimg(const BoxD &b, double &dx, double &dy, do
   dz = b.h[2] * l2;
 }
 
+// Sum over the 64 lanes of a wave, returned in every lane.  On the DPP path of the VALU (quad permutes, row mirrors, then the row
+// broadcasts of gfx9): 12 cross-lane moves that cost an instruction each -- as `__shfl_down` steps they were 12 LDS round trips
+// (ds_bpermute), which is what the tails of the small kernels waited for (a single replica's k_pppm_solve: 11 of its 71 thousand cycles).
+// All lanes of the wave must be active.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_read0(double v) {   // the lane CTRL selects; 0 where there is none or the row is not in ROWMASK
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v += dpp_read0<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_read0<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_read0<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_read0<0x140, 0xF>(v);   // row_mirror: every lane of a row of 16 holds the row's sum
+  v += dpp_read0<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_read0<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // block-wide sum of NV values per thread over NW waves, result atomically added to dst[0..NV)

@@ -52,6 +52,7 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.nfar_steps = 0;
 #if defined(PAIR_TIMING) || defined(PAIR_COUNT)
     for (int k = 0; k < 12; k++) sc.dbg[k] = 0;
+    for (int k = 0; k < 8; k++) sc.dbg2[k] = 0;
 #endif
   }
   for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;

@@ -151,10 +151,14 @@ __device__ __forceinline__ void tile_atomic_add(double (&vals)[NV], double *dst,
 
 // ------------------------------------------------------------------------------------------
 // k_neigh_build : workgroup per cell.
-//   phase 1 (all threads): candidate j images of the half stencil, pruned against the bounding box
-//            of the cell's atoms, numbered into the tile's j table (deterministic order)
-//   phase 2 (wave per cluster): the table is tested against the cluster's 4 atoms; ballots compact
-//            the accepted entries into the three row segments
+//   phase 0: bounding boxes of the four groups of the cell's clusters; slot runs of the half stencil (own cell first)
+//   phase 1 (all waves, units of 64 candidates): candidate j images pruned against the bounding box of the cell's
+//            atoms and numbered into the tile's j table, and against the groups' boxes into the groups' candidate
+//            lists -- one pass, candidate order (deterministic)
+//   phase 2 (wave per cluster): the group's list is tested against the cluster's 4 atoms; ballots compact
+//            the accepted entries into the row segments
+//   the rows are dealt round robin to the waves of k_pair
+// SCEMA_MD_QCAP16 (test switch) shrinks the group lists so that they overflow: the whole-table walk of phase 2.
 // ------------------------------------------------------------------------------------------
 struct ClusterI {
   double x[NI], y[NI], z[NI];
@@ -162,7 +166,7 @@ struct ClusterI {
 };
 
 extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists (segment B from the front, C1 from the back), then
-                                  // [NQ][qcap] 16-bit table indices: the part of the table each quarter of the cell's clusters can reach
+                                  // [NQ][qcap] 16-bit table indices: the part of the table each group (quarter) of the cell's clusters can reach
 #define NQ 4      // groups of a cell's clusters with their own candidate list (<= TW: one wave takes each group's bounding box)
 #define NB_MAXRUN 128    // slot runs of one tile's candidates (own cell + half stencil; 20 for PE-10k)
 #define NB_MAXUNIT 1024  // 64-candidate units of one tile (85 for PE-10k)

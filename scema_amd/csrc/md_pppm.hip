@@ -276,6 +276,13 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
   __shared__ double s_red[8 * (PP_SOLVE_TPB / 64)];
   const int NG = nx * ny * nz;
   double2 *A = s_fft, *B = A + NG, *C = B + NG, *tw = C + NG;   // twiddles: x at 0, y at nx, z at nx + ny
+#ifdef PAIR_TIMING
+  unsigned long long tq[8]; int ntq = 0;
+#define PP_CLK() tq[ntq++] = __builtin_readcyclecounter()
+#else
+#define PP_CLK()
+#endif
+  PP_CLK();
   for (int k = threadIdx.x; k < nx + ny + nz; k += PP_SOLVE_TPB) {
     const int n = k < nx ? nx : (k < nx + ny ? ny : nz), j = k < nx ? k : (k < nx + ny ? k - nx : k - nx - ny);
     double sn, cs;
@@ -285,28 +292,51 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
   double2 *rho = (double2 *)S.pgrid;
   for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) { A[k] = make_double2(rho[k].x, 0.0); rho[k] = make_double2(0.0, 0.0); }
   __syncthreads();
-  // out[.., m, ..] = sum_k in[.., k, ..] w^(m k) along dimension dim (w = exp(-+2 pi i / n)); ends with a barrier
+  PP_CLK();   // 1: twiddles + charge grid in
+  // out[.., m, ..] = sum_k in[.., k, ..] w^(m k) along dimension dim (w = exp(-+2 pi i / n)); ends with a barrier.  A work item is one
+  // line of the grid and one m in 0 .. n/2: it also produces the output n - m, whose twiddles are the complex conjugates (8 multiply-adds
+  // and two LDS reads per k for two outputs; one output per item took 4 and two: 7 / 12 of the items, and a 12 x 12 x 12 grid is one
+  // round of the 1 024 threads instead of two).  The items of a thread are the same in the three passes of a dimension: their line
+  // offsets and m come from integer divisions done once.
+  int it_m[3][2], it_base[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int n = d == 0 ? nx : (d == 1 ? ny : nz), stride = d == 0 ? 1 : (d == 1 ? nx : nx * ny), nh = n / 2 + 1;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int it = (int)threadIdx.x + r * PP_SOLVE_TPB, L = it / nh;
+      it_m[d][r] = it - L * nh;
+      it_base[d][r] = (L / stride) * stride * n + (L % stride);
+    }
+  }
   auto pass = [&](const double2 *in, double2 *out, int dim, bool inverse) {
-    const int n = dim == 0 ? nx : (dim == 1 ? ny : nz), stride = dim == 0 ? 1 : (dim == 1 ? nx : nx * ny);
+    const int n = dim == 0 ? nx : (dim == 1 ? ny : nz), stride = dim == 0 ? 1 : (dim == 1 ? nx : nx * ny), nh = n / 2 + 1;
+    const int nitems = (NG / n) * nh;
     const double2 *t = tw + (dim == 0 ? 0 : (dim == 1 ? nx : nx + ny));
-    for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) {
-      const int m = (idx / stride) % n, base = idx - m * stride;
-      double ar = 0.0, ai = 0.0;
+    for (int it = threadIdx.x, r = 0; it < nitems; it += PP_SOLVE_TPB, r++) {
+      int m, base;
+      if (r < 2) { m = r == 0 ? it_m[dim][0] : it_m[dim][1]; base = r == 0 ? it_base[dim][0] : it_base[dim][1]; }
+      else { const int L = it / nh; m = it - L * nh; base = (L / stride) * stride * n + (L % stride); }
+      double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
       int j = 0;   // (m k) mod n
-#pragma unroll 5
+#pragma unroll 4
       for (int k = 0; k < n; k++) {
         const double2 vv = in[base + k * stride], w = t[j];
         const double wi = inverse ? -w.y : w.y;
         ar = fma(vv.x, w.x, fma(-vv.y, wi, ar));
         ai = fma(vv.x, wi, fma(vv.y, w.x, ai));
+        br = fma(vv.x, w.x, fma(vv.y, wi, br));      // conj(w): output n - m
+        bi = fma(-vv.x, wi, fma(vv.y, w.x, bi));
         j += m;
         if (j >= n) j -= n;
       }
-      out[idx] = make_double2(ar, ai);
+      out[base + m * stride] = make_double2(ar, ai);
+      if (m != 0 && 2 * m != n) out[base + (n - m) * stride] = make_double2(br, bi);
     }
     __syncthreads();
   };
   pass(A, B, 0, false); pass(B, A, 1, false); pass(A, B, 2, false);   // B = rho(k)
+  PP_CLK();   // 2: forward passes
   BoxD b;
   box_derive(S.sc->box, b);
   double v[6] = {0, 0, 0, 0, 0, 0}, e[1] = {0};
@@ -333,23 +363,37 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
       } else A[idx] = make_double2(kv[2] * p.y, -kv[2] * p.x);
     }
     __syncthreads();
+    PP_CLK();   // 3, 5: spectra
     pass(A, C, 0, true); pass(C, A, 1, true); pass(A, C, 2, true);
+    PP_CLK();   // 4, 6: inverse passes
+    // (the fields leave as three REAL arrays at a spacing of gs doubles inside the buffer of the three complex grids: k_pppm_force
+    // then stages 8 instead of 16 bytes per point)
     for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) {
       const double2 r = C[idx];
-      if (c == 0) { field[idx] = make_double2(r.x, 0.0); field[gs + idx] = make_double2(r.y, 0.0); }
-      else field[2 * gs + idx] = make_double2(r.x, 0.0);
+      double *fr = (double *)field;
+      if (c == 0) { fr[idx] = r.x; fr[gs + idx] = r.y; }
+      else fr[2 * gs + idx] = r.x;
     }
     __syncthreads();
   }
   block_atomic_add_n<6, PP_SOLVE_TPB / 64>(v, S.sc->vir + P_KSPACE * 6, s_red);
   block_atomic_add_n<1, PP_SOLVE_TPB / 64>(e, S.sc->eng + P_KSPACE, s_red);
+#ifdef PAIR_TIMING
+  PP_CLK();   // 7: field stores of the second round + sums
+  if (threadIdx.x == 0 && blockIdx.x == 0 && ntq == 8) {
+    for (int k = 1; k < 8; k++) atomicAdd(&S.sc->dbg2[k - 1], tq[k] - tq[k - 1]);
+    atomicAdd(&S.sc->dbg2[7], 1ull);
+  }
+#endif
+#undef PP_CLK
 }
 
 // forces: the field (real parts of grids 1..3 after the inverse transforms) at the atom, by the assignment weights.  LDS = true:
 // workgroup (s, r) stages the three real field grids of replica r in LDS once and serves the s-th of `split` atom ranges
 // (consecutive atoms in consecutive lanes: neighbours read the same grid points, which the LDS broadcasts); LDS = false reads
 // the grids through the caches.
-template <bool LDS>
+// REALF: the fields are three real arrays at a spacing of gs doubles (written by k_pppm_solve) instead of the real parts of three complex grids
+template <bool LDS, bool REALF = false>
 __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int split, int add) {
   const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
@@ -362,7 +406,12 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
   const size_t gs = (size_t)S.pgstride;
   const double2 *ex = (const double2 *)S.pfield, *ey = ex + gs, *ez = ey + gs;
   if (LDS) {
-    for (int k = threadIdx.x; k < NG; k += 256) { s_grid[k] = ex[k].x; s_grid[NG + k] = ey[k].x; s_grid[2 * NG + k] = ez[k].x; }
+    if (REALF) {
+      const double *fr = (const double *)S.pfield;
+      for (int k = threadIdx.x; k < NG; k += 256) { s_grid[k] = fr[k]; s_grid[NG + k] = fr[gs + k]; s_grid[2 * NG + k] = fr[2 * gs + k]; }
+    } else {
+      for (int k = threadIdx.x; k < NG; k += 256) { s_grid[k] = ex[k].x; s_grid[NG + k] = ey[k].x; s_grid[2 * NG + k] = ez[k].x; }
+    }
     __syncthreads();
   }
   BoxD b;
@@ -437,15 +486,20 @@ void mdk_pppm_solve(hipStream_t st, const SimDev *d, int ns, int maxgrid, int ma
 }
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_gf, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_poisson, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add) {
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields) {
   const size_t lds = 3 * (size_t)maxgrid * sizeof(double);
   if (lds > mdk_pppm_lds_limit()) {
-    hipLaunchKernelGGL(k_pppm_force<false>, grid2(cdiv(maxatoms, 256), ns), dim3(256), 0, st, d, cdiv(maxatoms, 256), add);
+    hipLaunchKernelGGL((k_pppm_force<false, false>), grid2(cdiv(maxatoms, 256), ns), dim3(256), 0, st, d, cdiv(maxatoms, 256), add);
     return;
   }
   static size_t optin_tab[16] = {0};
   size_t &optin = lds_optin_slot(optin_tab);
-  if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_force<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+  if (lds > 64 * 1024 && lds > optin) {
+    (void)hipFuncSetAttribute((const void *)k_pppm_force<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_pppm_force<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    optin = lds;
+  }
   const int split = pppm_split(ns, maxatoms);
-  hipLaunchKernelGGL(k_pppm_force<true>, grid2(split, ns), dim3(256), lds, st, d, split, add);
+  if (real_fields) hipLaunchKernelGGL((k_pppm_force<true, true>), grid2(split, ns), dim3(256), lds, st, d, split, add);
+  else hipLaunchKernelGGL((k_pppm_force<true, false>), grid2(split, ns), dim3(256), lds, st, d, split, add);
 }

@@ -90,6 +90,7 @@ struct SimScalars {
   double min_dots[4];  // f.h, f.f, max |f| of the last evaluation (+ spare)
 #if defined(PAIR_TIMING) || defined(PAIR_COUNT)
   unsigned long long dbg[12];
+  unsigned long long dbg2[8];   // k_pppm_solve phase clocks
 #endif
 };
 
