@@ -97,6 +97,7 @@ __global__ __launch_bounds__(BT_TPB, BT_OCC) void k_bonded(const SimDev *__restr
   }
   BoxD b;
   box_derive(sc.box, b);
+  box_uniform(b);
   const double g = S.g_ewald, g2u = g * g * S.coul_uscale;
   const int np = S.coul_npoly;
   const double *cf_bond = s_cf + S.bt_cf_off[0], *cf_angle = s_cf + S.bt_cf_off[1], *cf_dih = s_cf + S.bt_cf_off[2], *cf_imp = s_cf + S.bt_cf_off[3];

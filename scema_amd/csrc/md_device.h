@@ -21,6 +21,18 @@ __device__ __forceinline__ void box_derive(const double *b, BoxD &o) {
   o.vol = o.h[0] * o.h[1] * o.h[2];
 }
 
+// The box is the same for every lane of a workgroup; said so (v_readfirstlane), its derived quantities live in scalar registers
+// instead of 2 x 15 vector registers per lane (k_bonded spilled 21 registers around its torsion code with the box in VGPRs).
+__device__ __forceinline__ double wave_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ void box_uniform(BoxD &b) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) b.lo[k] = wave_uniform(b.lo[k]);
+#pragma unroll
+  for (int k = 0; k < 6; k++) { b.h[k] = wave_uniform(b.h[k]); b.hinv[k] = wave_uniform(b.hinv[k]); }
+  b.vol = wave_uniform(b.vol);
+}
 __device__ __forceinline__ void minimg(const BoxD &b, double &dx, double &dy, double &dz) {
   double l0 = b.hinv[0] * dx + b.hinv[5] * dy + b.hinv[4] * dz;
   double l1 = b.hinv[1] * dy + b.hinv[3] * dz;

@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(TPB, 4) void k_shake(const SimDev *sims, double dtf
   if (cl < S.nclus) {
     BoxD b;
     box_derive(sc.box, b);
+    box_uniform(b);
     const int nb = S.clus_n[cl] - 1;
     if (nb == 2) shake_cluster<2>(S, b, cl, dtfsq_scale, v);        // CH2
     else if (nb == 1) shake_cluster<1>(S, b, cl, dtfsq_scale, v);
@@ -1130,6 +1131,7 @@ __global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairv
     if (S.use_shake && u < S.nclus) {
       BoxD b;
       box_derive(sc.box, b);
+      box_uniform(b);
       const int nb = S.clus_n[u] - 1;
       if (nb == 2) finish_cluster<2>(S, b, u, keep, pairvir, pv, sv, ke);        // CH2
       else if (nb == 1) finish_cluster<1>(S, b, u, keep, pairvir, pv, sv, ke);

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(TPB_) void k_pppm_spread(const SimDev *sims, int sp
   if (a0 >= a1) return;
   BoxD b;
   box_derive(S.sc->box, b);
+  box_uniform(b);
   double2 *rho = (double2 *)S.pgrid;
   if (LDS) {
     for (int k = threadIdx.x; k < NG; k += T) s_grid[k] = 0.0;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
   }
   BoxD b;
   box_derive(S.sc->box, b);
+  box_uniform(b);
   for (int a = a0 + (int)threadIdx.x; a < a1; a += 256) {
     const double qa = S.q[a];
     if (qa == 0.0) {
