@@ -454,12 +454,13 @@ def main():
                     f"replica equilibrated for {args.equil_steps} steps before the timed region")
         if reax:
             # k_rx_qeq_sweep, the HBM-bound kernel of this path: per launch it reads, for every replica that still
-            # iterates, each stored matrix entry once (8 B value + 4 B column index) and per row 84 B (row length 4, own
-            # preconditioned residual pair 16, search direction and product pairs read + written 64); the gathered pairs of the
-            # columns are cache traffic by design and not counted.  Entries and rows are counted on the device per sweep taken part in.
+            # iterates, each stored matrix entry once (8 B value + a 2-byte column index; 4 bytes for replicas beyond 65 536 atoms; only the
+            # entries inside the taper radius are stored) and per row 84 B (row length 4, own preconditioned residual
+            # pair 16, search direction and product pairs read + written 64); the gathered pairs of the columns are cache traffic by design
+            # and not counted.  Entries and rows are counted on the device per sweep taken part in.
             sw_s = prof["rx_sweep_ms"] * 1e-3
             sw_n = max(prof["rx_sweep_launches"], 1)
-            sw_bytes = 12.0 * prof["rx_sweep_entries"] + 84.0 * prof["rx_sweep_rows"]
+            sw_bytes = (8.0 + prof["rx_sweep_col_bytes"]) * prof["rx_sweep_entries"] + 84.0 * prof["rx_sweep_rows"]
             achieved = sw_bytes / sw_s / 1e9 if sw_s > 0 else 0.0
             pmc = None
             ppath = os.path.join(ROOT, "profiles", "reax_pmc.json")
@@ -468,7 +469,7 @@ def main():
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": (pmc or {}).get("hbm_bytes_per_sweep_corrected"), "traffic_source": (pmc or {}).get("command"),
                     "kernel": "k_rx_qeq_sweep (charge equilibration: y = H z for both conjugate-gradient systems, one pass over the stored matrix rows)",
-                    "accounting": "achieved = (12 B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
+                    "accounting": f"achieved = ({8 + int(prof['rx_sweep_col_bytes'])} B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
                                   "device) / HIP-event time of all launches of the kernel on the engine's stream (launches that find every replica converged "
                                   "cost time and move nothing); traffic = counter bytes of ONE sweep over the whole batch (profiles/reax_pmc.json)",
                     "launches": prof["rx_sweep_launches"], "avg_launch_ms": 1e3 * sw_s / sw_n, "alg_bytes_per_launch": sw_bytes / sw_n,

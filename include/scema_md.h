@@ -343,8 +343,9 @@ typedef struct {
   int64_t rx_sweep_launches;  /* timed launches */
   double rx_sweep_ms;         /* sum of their HIP-event durations */
   double rx_sweep_entries;    /* stored matrix entries those launches passed over (per replica: entries of its rows x sweeps it took
-                               * part in); algorithmic bytes = 12 per entry (8 value + 4 column) + 84 per row */
+                               * part in); algorithmic bytes = (8 value + rx_sweep_col_bytes) per entry + 84 per row */
   double rx_sweep_rows;       /* rows likewise */
+  int64_t rx_sweep_col_bytes; /* bytes of a stored column index: 2 (replicas of up to 65 536 atoms) or 4 */
 } scema_md_profile;
 int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset);
 

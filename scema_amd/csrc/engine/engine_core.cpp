@@ -128,6 +128,7 @@ int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t rese
   out->rx_sweep_ms = e->prof.rx_sweep_ms;
   out->rx_sweep_entries = e->prof.rx_sweep_entries;
   out->rx_sweep_rows = e->prof.rx_sweep_rows;
+  out->rx_sweep_col_bytes = e->prof.rx_sweep_col_bytes;
   if (reset) e->prof = Profile();
   return SCEMA_MD_OK;
 }

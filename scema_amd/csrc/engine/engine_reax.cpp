@@ -23,6 +23,7 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
     HIPCHK(r.qwork.ensure(8 * (size_t)npad * 8));
     HIPCHK(r.qpart.ensure((6 * (size_t)((npad + 255) / 256) + 2 * (size_t)(npad / 64)) * 8));   // layout: md_reax.hip
     HIPCHK(r.nbn_cnt.ensure((size_t)npad * 4));
+    HIPCHK(r.hlen.ensure((size_t)npad * 4));
     HIPCHK(r.misc.ensure(256));
     r.cap_pad = npad;
     r.cap_nb = 0;
@@ -36,6 +37,8 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
   if (maxnb > r.cap_nb) {
     HIPCHK(r.nb.ensure((size_t)maxnb * npad * 4));
     HIPCHK(r.hval.ensure((size_t)maxnb * npad * 8));
+    HIPCHK(r.hcol.ensure((size_t)maxnb * npad * 4));   // (16-bit columns use half of it)
+    HIPCHK(r.nbT.ensure((size_t)maxnb * npad * 4));
     r.cap_nb = maxnb;
   }
   if (maxbd > r.cap_bd) {
@@ -81,6 +84,9 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   e->h_rxviews.assign(ns, RxView());
   std::vector<std::vector<FlipEvent>> flips(ns);
   int maxatoms = 0, maxpad = 0, maxsteps = 0;
+  // columns of the charge-equilibration matrix as 16-bit atom indices when every replica of the batch has at most 65 536 atoms
+  bool col16 = true;
+  for (int i = 0; i < ns; i++) col16 = col16 && sims[i].st->topo->natoms <= 65536;
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
     ActiveSim &A = sims[i];
@@ -179,6 +185,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     V.bd_bop = R.bd_bop.as<double>(); V.bd_c = R.bd_c.as<double>(); V.bd_bo = R.bd_bo.as<double>(); V.bd_g = R.bd_g.as<double>(); V.bd_cb = R.bd_cb.as<double>();
     V.deltap = R.deltap.as<double>(); V.total_bo = R.total_bo.as<double>(); V.cd_delta = R.cd_delta.as<double>(); V.hd = R.hd.as<double>();
     V.f = S.f; V.hval = R.hval.as<double>(); V.s = R.s.as<double>(); V.t = R.t.as<double>();
+    V.hcol16 = col16 ? R.hcol.as<unsigned short>() : nullptr; V.hcol32 = col16 ? nullptr : R.hcol.as<int>(); V.hlen = R.hlen.as<int>(); V.nbT = R.nbT.as<int>();
     V.s_hist = R.s_hist.as<double>(); V.t_hist = R.t_hist.as<double>(); V.qwork = R.qwork.as<double>();
     V.eparts = R.misc.as<double>();                         // [0, 13) doubles
     V.qstat = (int *)(R.misc.as<char>() + 128);             // 6 ints
@@ -204,7 +211,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   std::vector<hipEvent_t> *evp = prof ? &e->ev_pool : nullptr;
   mdk_phase_init(st, D, ns);
   mdk_reax_phase_init(st, VV, ns, maxpad);
-  mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, e->rx_qeq_launch_cold, terms, evp, &ev_used);
+  mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, e->rx_qeq_launch_cold, terms, col16, evp, &ev_used);
   mdk_final_integrate(st, D, ns, maxatoms, 0);
   if (spec.nh) mdk_setup_post_nh(st, D, ns);
   else mdk_setup_post(st, D, ns);
@@ -228,7 +235,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       for (int r = 0; r < 16; r++, ev_n++) {
         mdk_min_pre(st, D, ns);
         mdk_min_move(st, D, ns, maxatoms, x0s, hsd);
-        mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, e->rx_qeq_launch_cold, terms);
+        mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, e->rx_qeq_launch_cold, terms, col16);
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
         mdk_min_decide(st, D, ns);
       }
@@ -264,7 +271,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     if (spec.nh) { mdk_pre_nh(st, D, na); mdk_initial_integrate_nh(st, D, na, maxatoms); }
     else { mdk_pre(st, D, na); mdk_initial_integrate(st, D, na, maxatoms); }
     // the first solves of a run start from an empty history (RX_QEQ_COLD in md_reax.hip: setup is solve 1)
-    mdk_reax_forces(st, D, VV, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, step < 4 ? e->rx_qeq_launch_cold : e->rx_qeq_launch, terms, evp, &ev_used);
+    mdk_reax_forces(st, D, VV, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, step < 4 ? e->rx_qeq_launch_cold : e->rx_qeq_launch, terms, col16, evp, &ev_used);
     mdk_final_integrate(st, D, na, maxatoms, 1);
     if (spec.nh) mdk_post_nh(st, D, na);
     else mdk_post(st, D, na);
@@ -301,6 +308,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     for (int pos = 0; pos < ns; pos++) {
       e->prof.rx_sweep_entries += (double)acc[2 * pos];
       e->prof.rx_sweep_rows += (double)acc[2 * pos + 1];
+      e->prof.rx_sweep_col_bytes = col16 ? 2 : 4;
     }
   }
   int fault = 0, most = 0, most_cold = 0;

@@ -13,5 +13,5 @@ void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad);
 // qeq_launch: conjugate-gradient iterations issued as launches over the batch (replicas that need more finish inside k_rx_qeq_finish)
 // terms: bit 0 bond/lone pair/over/under, 1 angles, 2 torsions, 3 hydrogen bonds, 4 non-bonded (31 = all; parity hook)
 void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int qeq_launch, int terms,
-                     std::vector<hipEvent_t> *sweep_events = nullptr, size_t *sweep_events_used = nullptr);
+                     bool col16, std::vector<hipEvent_t> *sweep_events = nullptr, size_t *sweep_events_used = nullptr);
 // sweep_events: when given, a HIP-event pair is recorded around every launch of k_rx_qeq_sweep (pool grown on demand)

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *vi
         if (cnt >= V.maxnb) { full = true; continue; }
         const int code = (2 - (int)n0) + 5 * (2 - (int)n1) + 25 * (2 - (int)n2);
         V.nb[(size_t)cnt * np + i] = j | (code << 24);
+        V.nbT[(size_t)i * V.maxnb + cnt] = j | (code << 24);
         cnt++;
         if (r2 <= rn2) {
           if (cntn >= V.maxnbn) { full = true; continue; }
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *vi
               if (cnt >= V.maxnb) { full = true; continue; }
               const int ent = j | (((sx + 2) + 5 * (sy + 2) + 25 * (sz + 2)) << 24);
               V.nb[(size_t)cnt * np + i] = ent;
+              V.nbT[(size_t)i * V.maxnb + cnt] = ent;
               cnt++;
               if (r2 <= rn2) {
                 if (cntn >= V.maxnbn) { full = true; continue; }
@@ -156,14 +158,38 @@ __global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *vi
 // Row walks are shared by RX_KS waves: a workgroup owns 64 consecutive atoms (lane = atom), wave w takes the entries
 // k = w, w + RX_KS, ... of their rows and the partial results meet in LDS.  With one lane per atom alone a replica of a few
 // thousand atoms gives the chip a few dozen waves; this gives it RX_KS times as many, each with a short row walk.
-#define RX_KS 8
 #define RX_KT (64 * RX_KS)
 
+// The matrix rows of this step: a workgroup owns 64 consecutive atoms, wave w the rows 8 w .. 8 w + 7 of them, one after the other with its
+// lanes over the entries of the list row (read from the row-major copy of the list: contiguous); the entries inside the taper radius
+// are compacted with a ballot and leave as contiguous stores (RxView::hval).  (Lanes over rows and the entries in [k][row] planes, as the
+// other passes have them, made the compacted stores scatter over the planes: 1.30 against 0.70 ms per 72-replica step.)
 __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
   (void)sims;
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  if (i < V.n) rx_qeq_row_part(P, &V, i, threadIdx.x >> 6, RX_KS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = 0; r < 64 / RX_KS; r++) {
+    const int i = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
+    if (i >= V.n) return;   // (wave-uniform)
+    const int cnt = V.nb_cnt[i];
+    const size_t base = (size_t)i * V.maxnb;
+    int len = 0;
+    for (int k0 = 0; k0 < cnt; k0 += 64) {
+      const int k = k0 + lane;
+      int col = 0;
+      double h = -1.0;
+      if (k < cnt) h = rx_qeq_entry(P, &V, i, V.nbT[base + k], &col);
+      const unsigned long long m = __ballot(h >= 0.0);
+      if (h >= 0.0) {
+        const size_t o = base + len + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        V.hval[o] = h;
+        if (V.hcol16) V.hcol16[o] = (unsigned short)col;
+        else V.hcol32[o] = col;
+      }
+      len += __popcll(m);
+    }
+    if (lane == 0) V.hlen[i] = len;
+  }
 }
 
 // fix qeq/reax: H s = -chi and H t = -1 by Jacobi-preconditioned conjugate gradients from the extrapolated previous solutions
@@ -223,6 +249,7 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views) {
 }
 
 // it < 0: the first product H x0 of the solve (x0 sits in z), stored in q
+template <bool COL16>
 __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, const RxParams *P, double tol, int it) {
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -241,33 +268,51 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   }
   const size_t np = V.npad;
   const double2 *z = (const double2 *)(V.qwork + 6 * np);
-  const int cnt = (i < n) ? V.nb_cnt[i] : 0;
-  // wave-uniform trip count, loads predicated: the compiler can keep several entries in flight
-  int cmax = cnt;
+  // the products of this workgroup's 64 rows: wave w takes the rows 8 w .. 8 w + 7, lanes over the entries of a row
+  __shared__ double s_y[2][64];
+  const unsigned short *c16 = V.hcol16;
+  const int *c32 = V.hcol32;
+  // (two rows at a time: their loads are independent)
+#define RX_SWEEP_RG 2
+  for (int r0 = 0; r0 < 64 / RX_KS; r0 += RX_SWEEP_RG) {
+    const int lr0 = wave * (64 / RX_KS) + r0, row0 = blockIdx.x * 64 + lr0;
+    int len[RX_SWEEP_RG], lmax = 0;
+    size_t base[RX_SWEEP_RG];
+    double ps[RX_SWEEP_RG], pt[RX_SWEEP_RG];
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) cmax = max(cmax, __shfl_xor(cmax, m));
-  double ys = 0.0, yt = 0.0;
-  const int *nb = V.nb + i;
-  const double *hv = V.hval + i;
-#pragma unroll 4
-  for (int k = wave; k < cmax; k += RX_KS) {
-    const bool on = k < cnt;
-    const size_t o = on ? (size_t)k * np : 0;
-    const int j = on ? (nb[o] & RX_JMASK) : 0;
-    const double h = on ? hv[o] : 0.0;
-    const double2 zj = z[j];
-    ys = fma(h, zj.x, ys);
-    yt = fma(h, zj.y, yt);
+    for (int q = 0; q < RX_SWEEP_RG; q++) {
+      const int row = row0 + q;
+      len[q] = (row < n) ? V.hlen[row] : 0;   // (wave-uniform)
+      base[q] = (size_t)min(row, n - 1) * V.maxnb;
+      lmax = max(lmax, len[q]);
+      ps[q] = 0.0; pt[q] = 0.0;
+    }
+#pragma unroll 2
+    for (int c0 = 0; c0 < lmax; c0 += 64) {
+      const int c = c0 + lane;
+#pragma unroll
+      for (int q = 0; q < RX_SWEEP_RG; q++) {
+        const bool on = c < len[q];
+        const size_t o = base[q] + (on ? c : 0);
+        const int j = COL16 ? (int)c16[o] : c32[o];
+        const double h = on ? V.hval[o] : 0.0;
+        const double2 zj = z[j];
+        ps[q] = fma(h, zj.x, ps[q]);
+        pt[q] = fma(h, zj.y, pt[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RX_SWEEP_RG; q++) {
+      const double a = wave_sum(ps[q]), bsum = wave_sum(pt[q]);
+      if (lane == 0) { s_y[0][lr0 + q] = a; s_y[1][lr0 + q] = bsum; }
+    }
   }
-  __shared__ double s_y[2][RX_KS][64];
-  s_y[0][wave][lane] = ys; s_y[1][wave][lane] = yt;
   __syncthreads();
+  double ys = 0.0, yt = 0.0;
   if (wave != 0) return;
   double dq_s = 0.0, dq_t = 0.0;
   if (i < n) {
-    ys = 0.0; yt = 0.0;
-#pragma unroll
-    for (int w = 0; w < RX_KS; w++) { ys += s_y[0][w][lane]; yt += s_y[1][w][lane]; }
+    ys = s_y[0][lane]; yt = s_y[1][lane];
     const double eta = P->sbp[V.rtype[i]].eta;
     const double2 zi = z[i];
     ys = fma(eta, zi.x, ys); yt = fma(eta, zi.y, yt);
@@ -386,23 +431,28 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
     for (; done + it < maxiter && (run_s || run_t); it++) {
       const double be_s = (done + it > 0) ? sig_s / prev_s : 0.0, be_t = (done + it > 0) ? sig_t / prev_t : 0.0;
       double dq_s = 0.0, dq_t = 0.0;
-      for (int i = tid; i < n; i += QEQ_TPB) {
-        const double eta = P->sbp[V.rtype[i]].eta;
-        const double2 zi = z[i];
+      // (a wave per row, lanes over its entries: the matrix is row-major)
+      for (int i = tid >> 6; i < n; i += QEQ_TPB / 64) {
+        const int len = V.hlen[i], lane = tid & 63;
         double ys = 0.0, yt = 0.0;
-        const int cnt = V.nb_cnt[i];
-        for (int k = 0; k < cnt; k++) {
-          const size_t o = (size_t)k * np + i;
-          const double2 zj = z[V.nb[o] & RX_JMASK];
-          const double hv = V.hval[o];
+        for (int c0 = 0; c0 < len; c0 += 64) {
+          const bool on = c0 + lane < len;
+          const size_t o = (size_t)i * V.maxnb + (on ? c0 + lane : 0);
+          const double2 zj = z[V.hcol16 ? (int)V.hcol16[o] : V.hcol32[o]];
+          const double hv = on ? V.hval[o] : 0.0;
           ys = fma(hv, zj.x, ys);
           yt = fma(hv, zj.y, yt);
         }
-        ys = fma(eta, zi.x, ys); yt = fma(eta, zi.y, yt);
-        double2 di = d[i], qi = q[i];
-        if (run_s) { di.x = fma(be_s, di.x, zi.x); qi.x = fma(be_s, qi.x, ys); dq_s += di.x * qi.x; }
-        if (run_t) { di.y = fma(be_t, di.y, zi.y); qi.y = fma(be_t, qi.y, yt); dq_t += di.y * qi.y; }
-        d[i] = di; q[i] = qi;
+        ys = wave_sum(ys); yt = wave_sum(yt);
+        if (lane == 0) {
+          const double eta = P->sbp[V.rtype[i]].eta;
+          const double2 zi = z[i];
+          ys = fma(eta, zi.x, ys); yt = fma(eta, zi.y, yt);
+          double2 di = d[i], qi = q[i];
+          if (run_s) { di.x = fma(be_s, di.x, zi.x); qi.x = fma(be_s, qi.x, ys); dq_s += di.x * qi.x; }
+          if (run_t) { di.y = fma(be_t, di.y, zi.y); qi.y = fma(be_t, qi.y, yt); dq_t += di.y * qi.y; }
+          d[i] = di; q[i] = qi;
+        }
       }
       qeq_reduce2(dq_s, dq_t, s_red);   // its barriers also order the sweep (reads z) before the update (writes z)
       const double al_s = run_s ? sig_s / dq_s : 0.0, al_t = run_t ? sig_t / dq_t : 0.0;
@@ -435,7 +485,7 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
   // what the launched sweeps of this solve read: every stored entry of the replica's rows once per sweep it took part in
   // (the launches counted by k_rx_qeq_update, plus the first product H x0)
   double nent = 0.0, nrow = 0.0;
-  for (int i = tid; i < n; i += QEQ_TPB) { nent += (double)V.nb_cnt[i]; nrow += 1.0; }
+  for (int i = tid; i < n; i += QEQ_TPB) { nent += (double)V.hlen[i]; nrow += 1.0; }
   qeq_reduce2(nent, nrow, s_red);
   if (tid == 0) {
     const long long sweeps = (long long)(V.qstat[0] - V.qstat[4]) + 1;
@@ -600,7 +650,7 @@ void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad) {
   hipLaunchKernelGGL(k_rx_phase_init, g2(cdv(maxpad, TPB), ns), dim3(TPB), 0, st, v);
 }
 void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int qeq_launch,
-                     int terms, std::vector<hipEvent_t> *ev, size_t *ev_used) {
+                     int terms, bool col16, std::vector<hipEvent_t> *ev, size_t *ev_used) {
   // a HIP-event pair around every launch of the matrix sweep when the caller profiles (bench.py's roofline block)
   auto sweep = [&](int it) {
     const dim3 gk = g2(cdv(maxatoms, 64), ns);
@@ -608,7 +658,8 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
       while (*ev_used + 2 > ev->size()) { hipEvent_t a; if (hipEventCreate(&a) != hipSuccess) { ev = nullptr; break; } ev->push_back(a); }
     }
     if (ev) (void)hipEventRecord((*ev)[*ev_used], st);
-    hipLaunchKernelGGL(k_rx_qeq_sweep, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
+    if (col16) hipLaunchKernelGGL(k_rx_qeq_sweep<true>, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
+    else hipLaunchKernelGGL(k_rx_qeq_sweep<false>, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
     if (ev) { (void)hipEventRecord((*ev)[*ev_used + 1], st); *ev_used += 2; }
   };
   const dim3 ga = g2(cdv(maxatoms, TPB), ns), gr = g2(cdv(maxatoms, RX_TPB), ns), gk = g2(cdv(maxatoms, 64), ns), gu = g2(cdv(maxatoms, QEQ_UT), ns);

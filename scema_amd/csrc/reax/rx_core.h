@@ -773,31 +773,15 @@ RX_FN void rx_back_force(const RxParams *P, const RxView *V, int i, double *vir)
 // ------------------------------------------------------------------------------------------------------------------
 // charge equilibration (fix qeq/reax): matrix entries of atom i's row, H_ij = Tap(r) 14.4 / (r^3 + gamma_ij)^(1/3)
 // ------------------------------------------------------------------------------------------------------------------
-RX_FN void rx_qeq_row_part(const RxParams *P, const RxView *V, int i, int k0, int kstep) {
-  const int np = V->npad, ti = V->rtype[i], cnt = V->nb_cnt[i];
-  const double swb2 = P->swb * P->swb;
-  for (int k = k0; k < cnt; k += kstep) {
-    const size_t o = (size_t)k * np + i;
-    double d[3];
-    const int j = rx_partner(V, i, V->nb[o], d);
-    const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    double hv = 0.0;
-    if (r2 <= swb2) {
-      const double r = sqrt(r2);
-      double dTap;
-      const double Tap = rx_taper(P, r, &dTap);
-      hv = Tap * RX_EV_TO_KCALPMOL / cbrt(r2 * r + P->tbp[ti * RX_MAXT + V->rtype[j]].gamma);
-    }
-    V->hval[o] = hv;
-  }
-}
-RX_FN void rx_qeq_row(const RxParams *P, const RxView *V, int i) { rx_qeq_row_part(P, V, i, 0, 1); }
-RX_FN double rx_qeq_matvec_row(const RxParams *P, const RxView *V, int i, const double *x) {
-  const int np = V->npad, cnt = V->nb_cnt[i];
-  double y = P->sbp[V->rtype[i]].eta * x[i];
-  for (int k = 0; k < cnt; k++) {
-    const size_t o = (size_t)k * np + i;
-    y += V->hval[o] * x[V->nb[o] & RX_JMASK];
-  }
-  return y;
+// H_ij of list entry e of row i, or a negative number when the pair is outside the taper radius; *col = j
+RX_FN double rx_qeq_entry(const RxParams *P, const RxView *V, int i, int e, int *col) {
+  double d[3];
+  const int j = rx_partner(V, i, e, d);
+  *col = j;
+  const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  if (r2 > P->swb * P->swb) return -1.0;
+  const double r = sqrt(r2);
+  double dTap;
+  const double Tap = rx_taper(P, r, &dTap);
+  return Tap * RX_EV_TO_KCALPMOL / cbrt(r2 * r + P->tbp[V->rtype[i] * RX_MAXT + V->rtype[j]].gamma);
 }

@@ -13,6 +13,7 @@
 #define RX_MAXT 6            /* force-field types kept (elements named by pair_coeff) */
 #define RX_MAXANG 4          /* parameter sets per valence-angle triple */
 #define RX_NGP 40
+#define RX_KS 8               /* waves of a workgroup of the charge-equilibration kernels: 64 rows per workgroup, 8 per wave */
 #define RX_JMASK 0x00FFFFFF  /* row entry: [23:0] atom, [30:24] image code (sx+2) + 5 (sy+2) + 25 (sz+2) */
 #define RX_CODE0 62          /* code of the zero shift */
 
@@ -91,7 +92,14 @@ typedef struct {
   double *hd;             // [n] dE/d(Delta'_i)
   double *f;              // [n][3]
   // charge equilibration
-  double *hval;           // [maxnb][npad] H_ij of the row entries inside the taper radius (0 beyond)
+  // the matrix of the charge equilibration, rebuilt every step, ROW-MAJOR (row i at i * maxnb): only the row entries inside the taper
+  // radius (about 70 % of a row of the list), in list order; the kernels that walk it put the lanes of a wave over the entries of one
+  // row (contiguous loads) and reduce across the wave
+  double *hval;           // [npad][maxnb] H_ij
+  unsigned short *hcol16; // [npad][maxnb] column (atom index) of the entry; replicas of up to 65 536 atoms (else NULL and hcol32)
+  int *hcol32;
+  int *hlen;              // [npad] entries of the row
+  int *nbT;               // [npad][maxnb] the list rows once more, row-major (written with the list; read by the matrix build)
   double *s, *t;          // [npad] the two solutions
   double *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)
   double *qwork;          // [8][npad]: four arrays of (s-system, t-system) pairs per atom: residual r, search direction d,
