@@ -785,3 +785,25 @@ RX_FN double rx_qeq_entry(const RxParams *P, const RxView *V, int i, int e, int 
   const double Tap = rx_taper(P, r, &dTap);
   return Tap * RX_EV_TO_KCALPMOL / cbrt(r2 * r + P->tbp[V->rtype[i] * RX_MAXT + V->rtype[j]].gamma);
 }
+// row i of the matrix, serially (host checks: tests/reax_host_driver.cpp; the kernels put a wave on the row): the entries inside the
+// taper radius, in list order, at i * maxnb
+RX_FN void rx_qeq_row(const RxParams *P, const RxView *V, int i) {
+  const size_t base = (size_t)i * V->maxnb;
+  int len = 0;
+  for (int k = 0; k < V->nb_cnt[i]; k++) {
+    int col;
+    const double h = rx_qeq_entry(P, V, i, V->nb[(size_t)k * V->npad + i], &col);
+    if (h < 0.0) continue;
+    V->hval[base + len] = h;
+    if (V->hcol16) V->hcol16[base + len] = (unsigned short)col;
+    else V->hcol32[base + len] = col;
+    len++;
+  }
+  V->hlen[i] = len;
+}
+RX_FN double rx_qeq_matvec_row(const RxParams *P, const RxView *V, int i, const double *x) {
+  const size_t base = (size_t)i * V->maxnb;
+  double y = P->sbp[V->rtype[i]].eta * x[i];
+  for (int c = 0; c < V->hlen[i]; c++) y += V->hval[base + c] * x[V->hcol16 ? (int)V->hcol16[base + c] : V->hcol32[base + c]];
+  return y;
+}

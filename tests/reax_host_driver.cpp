@@ -101,11 +101,12 @@ int rxh_compute(void *h, int n, const int *lmp_type0, const double *x_in, const 
   }
   std::vector<double> bop(4 * V.maxbd * np), bc(3 * V.maxbd * np), bo(3 * V.maxbd * np), bg(3 * V.maxbd * np), cb(V.maxbd * np);
   std::vector<double> deltap(n), total_bo(n), cd_delta(n), hd(n), ff(3 * (size_t)n), q(n, 0.0), hval((size_t)maxnb * np);
+  std::vector<int> hcol32((size_t)maxnb * np), hlen(np);
   int overflow = 0;
   V.nb_cnt = nb_cnt.data(); V.nb = nb.data(); V.bd_cnt = bd_cnt.data(); V.bd = bd.data(); V.bd_rev = bd_rev.data();
   V.bd_bop = bop.data(); V.bd_c = bc.data(); V.bd_bo = bo.data(); V.bd_g = bg.data(); V.bd_cb = cb.data();
   V.deltap = deltap.data(); V.total_bo = total_bo.data(); V.cd_delta = cd_delta.data(); V.hd = hd.data(); V.f = ff.data();
-  V.q = q.data(); V.hval = hval.data(); V.overflow = &overflow;
+  V.q = q.data(); V.hval = hval.data(); V.hcol16 = nullptr; V.hcol32 = hcol32.data(); V.hlen = hlen.data(); V.overflow = &overflow;
   int qeq_iters = 0;
   if (q_in) {
     for (int i = 0; i < n; i++) q[i] = q_in[i];
