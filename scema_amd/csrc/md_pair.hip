@@ -479,6 +479,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 #ifdef PAIR_TIMING
     if (lane == 0) { atomicAdd(&sc.dbg[10], (unsigned long long)((nl + 63) >> 6)); atomicAdd(&sc.dbg[11], 1ull); }
 #endif
+    bool own_chunks = true;
     for (int base = 0; base < nl; base += 64) {
       const int l = l_n;
       const int jt = jt_n;
@@ -497,7 +498,6 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       const int j = jt & MD_JMASK;
       const int code = (jt >> 23) & 31;
       const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
-      const bool own = in && l < nown;   // same cell, same image: each pair once, by slot order
 
       int mask = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
       double rmin = 1.0e300;
@@ -513,12 +513,14 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
         rmin = fmin(rmin, r2);
       }
       if (!in) { mask = 0; refm = 0; }
-      {
+      if (own_chunks) {   // (wave-uniform: the entries of the own cell come first in the table and in every list)
         // same cell, same image: each pair once, by slot order -- atom a of the cluster keeps j only if j > s0slot + a.  One mask per
         // candidate instead of a test per atom (rmin may then be too small: a nearer segment is always allowed)
+        const bool own = in && l < nown;
         const int d = j - s0slot;
         const int drop = !own ? 0 : (d <= 0 ? 0xF : (d > 3 ? 0 : (0xF << d) & 0xF));
         mask &= ~drop; refm &= ~drop;
+        own_chunks = __ballot(own) != 0ull;
       }
       // candidates inside the exclusion gate (bonded neighbours: a few chunks per row) take the wave-uniform slow path, which
       // looks at the four distances again and walks the exclusion lists
