@@ -24,6 +24,7 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
     HIPCHK(r.qpart.ensure((6 * (size_t)((npad + 255) / 256) + 2 * (size_t)(npad / 64)) * 8));   // layout: md_reax.hip
     HIPCHK(r.nbn_cnt.ensure((size_t)npad * 4));
     HIPCHK(r.hlen.ensure((size_t)npad * 4));
+    HIPCHK(r.hownlen.ensure((size_t)npad * 4));
     HIPCHK(r.misc.ensure(256));
     r.cap_pad = npad;
     r.cap_nb = 0;
@@ -39,6 +40,7 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
     HIPCHK(r.hval.ensure((size_t)maxnb * npad * 8));
     HIPCHK(r.hcol.ensure((size_t)maxnb * npad * 4));   // (16-bit columns use half of it)
     HIPCHK(r.nbT.ensure((size_t)maxnb * npad * 4));
+    HIPCHK(r.hown.ensure((size_t)maxnb * npad * 4));
     r.cap_nb = maxnb;
   }
   if (maxbd > r.cap_bd) {
@@ -186,6 +188,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     V.deltap = R.deltap.as<double>(); V.total_bo = R.total_bo.as<double>(); V.cd_delta = R.cd_delta.as<double>(); V.hd = R.hd.as<double>();
     V.f = S.f; V.hval = R.hval.as<double>(); V.s = R.s.as<double>(); V.t = R.t.as<double>();
     V.hcol16 = col16 ? R.hcol.as<unsigned short>() : nullptr; V.hcol32 = col16 ? nullptr : R.hcol.as<int>(); V.hlen = R.hlen.as<int>(); V.nbT = R.nbT.as<int>();
+    V.hown = R.hown.as<int>(); V.hownlen = R.hownlen.as<int>();
     V.s_hist = R.s_hist.as<double>(); V.t_hist = R.t_hist.as<double>(); V.qwork = R.qwork.as<double>();
     V.eparts = R.misc.as<double>();                         // [0, 13) doubles
     V.qstat = (int *)(R.misc.as<char>() + 128);             // 6 ints

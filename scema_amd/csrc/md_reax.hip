@@ -15,6 +15,8 @@
 //   k_rx_bonds ... k_rx_back2  bond orders, energy terms, reverse-mode forces (reax/rx_core.h)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "md_device.h"
 #include "md_kernels.h"
 #include "md_reax.h"
@@ -173,12 +175,12 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
     if (i >= V.n) return;   // (wave-uniform)
     const int cnt = V.nb_cnt[i];
     const size_t base = (size_t)i * V.maxnb;
-    int len = 0;
+    int len = 0, lown = 0;
     for (int k0 = 0; k0 < cnt; k0 += 64) {
       const int k = k0 + lane;
-      int col = 0;
+      int col = 0, ent = 0;
       double h = -1.0;
-      if (k < cnt) h = rx_qeq_entry(P, &V, i, V.nbT[base + k], &col);
+      if (k < cnt) { ent = V.nbT[base + k]; h = rx_qeq_entry(P, &V, i, ent, &col); }
       const unsigned long long m = __ballot(h >= 0.0);
       if (h >= 0.0) {
         const size_t o = base + len + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -187,8 +189,13 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
         else V.hcol32[o] = col;
       }
       len += __popcll(m);
+      // the pairs of the row that this end owns, for the non-bonded pass (each pair once)
+      const bool mine = h >= 0.0 && rx_owns(i, ent);
+      const unsigned long long mo = __ballot(mine);
+      if (mine) V.hown[base + lown + __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0))] = ent;
+      lown += __popcll(mo);
     }
-    if (lane == 0) V.hlen[i] = len;
+    if (lane == 0) { V.hlen[i] = len; V.hownlen[i] = lown; }
   }
 }
 
@@ -602,6 +609,74 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded(const SimDev *sims, cons
   }
   rx_flush_block<RX_KS>(e, w, V, *sims[blockIdx.y].sc, P_LJ);
 }
+// The same terms with every pair evaluated ONCE: a workgroup owns 64 consecutive atoms, wave w their rows 8 w .. 8 w + 7 with its lanes over
+// the row's OWNED pairs (RxView::hown, compacted by k_rx_hrow: no skin entries, no lane idling behind the ownership test); the
+// force on the partner goes into a table of the replica's forces in LDS (ds_add_f64; replicas of up to RX_NB1_MAXPAD atoms), flushed
+// once per workgroup.  Half the transcendental arithmetic of the both-ends form (three exp, two log, a cube root per pair).
+#define RX_NB1_MAXPAD 6000
+extern __shared__ double s_nbf[];   // [3][npad]
+__global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims, const RxView *views, const RxParams *P) {
+  const RxView V = views[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = V.n;
+  if ((int)(blockIdx.x * 64) >= n) return;
+  const size_t np = V.npad;
+  for (int k = threadIdx.x; k < 3 * (int)np; k += RX_KT) s_nbf[k] = 0.0;
+  __syncthreads();
+  double e[RX_NPART], w[6];
+#pragma unroll
+  for (int k = 0; k < RX_NPART; k++) e[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) w[k] = 0.0;
+  for (int r = 0; r < 64 / RX_KS; r++) {
+    const int i = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
+    if (i >= n) break;   // (wave-uniform)
+    const int len = V.hownlen[i], ti = V.rtype[i];
+    const size_t base = (size_t)i * V.maxnb;
+    const double qi = RX_C_ELE * V.q[i];
+    const double xi0 = V.x[3 * i], xi1 = V.x[3 * i + 1], xi2 = V.x[3 * i + 2];
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+    for (int c0 = 0; c0 < len; c0 += 64) {
+      const int c = c0 + lane;
+      if (c < len) {
+        const int ent = V.hown[base + c], j = ent & RX_JMASK;
+        double sh[3];
+        rx_shift(&V, ent, sh);
+        const double d0 = V.x[3 * j] - xi0 + sh[0], d1 = V.x[3 * j + 1] - xi1 + sh[1], d2 = V.x[3 * j + 2] - xi2 + sh[2];
+        double ev, ec, sc_;
+        rx_nonbonded_pair(P, &P->tbp[ti * RX_MAXT + V.rtype[j]], qi * V.q[j], d0 * d0 + d1 * d1 + d2 * d2, &ev, &ec, &sc_);
+        e[RX_E_VDW] += ev; e[RX_E_COUL] += ec;
+        const double g0 = sc_ * d0, g1 = sc_ * d1, g2 = sc_ * d2;   // force on i; the partner takes the opposite
+        f0 += g0; f1 += g1; f2 += g2;
+        (void)__hip_atomic_fetch_add(&s_nbf[j], -g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_add(&s_nbf[np + j], -g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_add(&s_nbf[2 * np + j], -g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // pair virial d (x) f_j = -s d (x) d
+        w[0] -= g0 * d0; w[1] -= g1 * d1; w[2] -= g2 * d2; w[3] -= g0 * d1; w[4] -= g0 * d2; w[5] -= g1 * d2;
+      }
+    }
+    f0 = wave_sum(f0); f1 = wave_sum(f1); f2 = wave_sum(f2);
+    if (lane == 0) {
+      (void)__hip_atomic_fetch_add(&s_nbf[i], f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add(&s_nbf[np + i], f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add(&s_nbf[2 * np + i], f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 3 * n; k += RX_KT) {
+    const int a = k / 3, c = k - 3 * a;
+    const double v = s_nbf[(size_t)c * np + a];
+    if (v != 0.0) atomicAdd(&V.f[k], v);
+  }
+  {
+    const int i = blockIdx.x * 64 + lane;
+    if (wave == 0 && i < n) {
+      const double qi = V.q[i];
+      const int ti = V.rtype[i];
+      e[RX_E_POL] += RX_KCALPMOL_TO_EV * (P->sbp[ti].chi * qi + 0.5 * P->sbp[ti].eta * qi * qi);
+    }
+  }
+  rx_flush_block<RX_KS>(e, w, V, *sims[blockIdx.y].sc, P_LJ);
+}
 __global__ __launch_bounds__(TPB) void k_rx_back1(const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * TPB + threadIdx.x;
@@ -683,7 +758,17 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   if (terms & 2) hipLaunchKernelGGL(k_rx_terms<1>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 4) hipLaunchKernelGGL(k_rx_terms<2>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, st, d, v, P);
-  if (terms & 16) hipLaunchKernelGGL(k_rx_nonbonded, gk, dim3(RX_KT), 0, st, d, v, P);
+  if (terms & 16) {
+    static const bool once_off = getenv("SCEMA_MD_RX_NB_ONCE") && atoi(getenv("SCEMA_MD_RX_NB_ONCE")) == 0;   // (test switch: the both-ends kernel)
+    const int maxpad = (maxatoms + 63) / 64 * 64;
+    if (!once_off && maxpad <= RX_NB1_MAXPAD) {
+      const size_t lds = 3 * (size_t)maxpad * sizeof(double);
+      static size_t optin_tab[16] = {0};
+      size_t &optin = lds_optin_slot(optin_tab);
+      if (lds > 48 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_rx_nonbonded_once, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+      hipLaunchKernelGGL(k_rx_nonbonded_once, gk, dim3(RX_KT), lds, st, d, v, P);
+    } else hipLaunchKernelGGL(k_rx_nonbonded, gk, dim3(RX_KT), 0, st, d, v, P);
+  }
   hipLaunchKernelGGL(k_rx_back1, ga, dim3(TPB), 0, st, v, P);
   hipLaunchKernelGGL(k_rx_back2, ga, dim3(TPB), 0, st, d, v, P);
   hipLaunchKernelGGL(k_rx_finish, dim3(ns), dim3(64), 0, st, d, v);

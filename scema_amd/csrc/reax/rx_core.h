@@ -666,9 +666,30 @@ RX_FN void rx_hbond_terms(const RxParams *P, const RxView *V, int j, double *eng
 // i only, half of each pair's energy and virial (the partner's lane does the same pair from its side) + polarisation energy
 // ------------------------------------------------------------------------------------------------------------------
 // entries k0, k0 + kstep, ... of the row: several waves may share a row; fi = force on i from these entries
+// one non-bonded pair (tapered van der Waals with the shielded distance + shielded Coulomb) at distance r = sqrt(r2) <= swb:
+// energies and s = (dE/dr) / r, so that dE/dd = s d
+RX_FN void rx_nonbonded_pair(const RxParams *P, const RxTbp *t, double qq, double r2, double *evdw, double *ecoul, double *s_out) {
+  const double p_vdW1 = P->gp[28], p_vdW1i = 1.0 / p_vdW1;
+  const double r = sqrt(r2), rinv = 1.0 / r;
+  double dTap;
+  const double Tap = rx_taper(P, r, &dTap);
+  // shielded distance fn13 = (r^p + gamma_w^-p)^(1/p); d(fn13)/dr = fn13 / (r^p + gamma_w^-p) * r^(p-1)
+  const double powr = exp(p_vdW1 * log(r));
+  const double sum = powr + t->powgw;
+  const double fn13 = exp(p_vdW1i * log(sum));
+  const double dfn13 = fn13 / sum * powr * rinv;
+  const double ex2 = exp(0.5 * t->alpha * (1.0 - fn13 / t->r_vdW)), ex1 = ex2 * ex2;
+  const double e_v = t->D * (ex1 - 2.0 * ex2);
+  double dE = dTap * e_v - Tap * t->D * (t->alpha / t->r_vdW) * (ex1 - ex2) * dfn13;
+  *evdw = Tap * e_v;
+  const double r3g = r2 * r + t->gamma, c13i = 1.0 / cbrt(r3g);
+  *ecoul = Tap * qq * c13i;
+  dE += qq * c13i * (dTap - Tap * r2 / r3g);
+  *s_out = dE * rinv;
+}
+// atom i's end of its pairs: the entries k0, k0 + kstep, ... of its list row (every pair is seen from both ends, half the energy each)
 RX_FN void rx_nonbonded_part(const RxParams *P, const RxView *V, int i, int k0, int kstep, double *fi, double *eng, double *vir) {
   const int np = V->npad, ti = V->rtype[i], cnt = V->nb_cnt[i];
-  const double p_vdW1 = P->gp[28], p_vdW1i = 1.0 / p_vdW1;
   const double qi = RX_C_ELE * V->q[i];
   const double swb2 = P->swb * P->swb;
   const double xi0 = V->x[3 * i], xi1 = V->x[3 * i + 1], xi2 = V->x[3 * i + 2];
@@ -681,24 +702,10 @@ RX_FN void rx_nonbonded_part(const RxParams *P, const RxView *V, int i, int k0, 
     const double d0 = V->x[3 * j] - xi0 + sh[0], d1 = V->x[3 * j + 1] - xi1 + sh[1], d2 = V->x[3 * j + 2] - xi2 + sh[2];
     const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
     if (r2 > swb2) continue;
-    const double r = sqrt(r2), rinv = 1.0 / r;
-    const RxTbp *t = &P->tbp[ti * RX_MAXT + V->rtype[j]];
-    double dTap;
-    const double Tap = rx_taper(P, r, &dTap);
-    // shielded distance fn13 = (r^p + gamma_w^-p)^(1/p); d(fn13)/dr = fn13 / (r^p + gamma_w^-p) * r^(p-1)
-    const double powr = exp(p_vdW1 * log(r));
-    const double sum = powr + t->powgw;
-    const double fn13 = exp(p_vdW1i * log(sum));
-    const double dfn13 = fn13 / sum * powr * rinv;
-    const double ex2 = exp(0.5 * t->alpha * (1.0 - fn13 / t->r_vdW)), ex1 = ex2 * ex2;
-    const double e_v = t->D * (ex1 - 2.0 * ex2);
-    double dE = dTap * e_v - Tap * t->D * (t->alpha / t->r_vdW) * (ex1 - ex2) * dfn13;
-    evdw += Tap * e_v;
-    const double r3g = r2 * r + t->gamma, c13i = 1.0 / cbrt(r3g);
-    const double qq = qi * V->q[j];
-    ecoul += Tap * qq * c13i;
-    dE += qq * c13i * (dTap - Tap * r2 / r3g);
-    const double s = dE * rinv;   // dE/dd = s d ; force on i = +s d
+    double ev, ec, s;
+    rx_nonbonded_pair(P, &P->tbp[ti * RX_MAXT + V->rtype[j]], qi * V->q[j], r2, &ev, &ec, &s);
+    evdw += ev;
+    ecoul += ec;
     fi[0] += s * d0; fi[1] += s * d1; fi[2] += s * d2;
     // pair virial d (x) f_j = -s d (x) d, half per end
     w[0] += s * d0 * d0; w[1] += s * d1 * d1; w[2] += s * d2 * d2;

@@ -99,6 +99,9 @@ typedef struct {
   unsigned short *hcol16; // [npad][maxnb] column (atom index) of the entry; replicas of up to 65 536 atoms (else NULL and hcol32)
   int *hcol32;
   int *hlen;              // [npad] entries of the row
+  int *hown;              // [npad][maxnb] the list entries (atom | image code) of the row's pairs inside the taper radius that this
+                          // end owns (rx_owns: each pair once), compacted; the non-bonded pass walks these
+  int *hownlen;           // [npad]
   int *nbT;               // [npad][maxnb] the list rows once more, row-major (written with the list; read by the matrix build)
   double *s, *t;          // [npad] the two solutions
   double *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)

@@ -287,3 +287,35 @@ def test_strain_batch_with_reax_force_field(ff, tmp_path):
         e.strain_batch(bad)
     e.close()
     e2.close()
+
+
+def test_both_ends_nonbonded_kernel_equals_the_once_per_pair_one():
+    """k_rx_nonbonded_once (every pair once, partner forces in an LDS table: the default for replicas of up to 6 000 atoms) against
+    k_rx_nonbonded (both ends of every pair, no table: larger replicas; SCEMA_MD_RX_NB_ONCE=0 forces it, read once per process ->
+    child processes) on the triclinic cell with several images inside the list radius: same forces, energies and virial"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys, numpy as np\n"
+            "sys.path.insert(0, 'tests')\n"
+            "from oracle import pyreax as pr\n"
+            "from scema_amd import capi\n"
+            "from test_oracle_reax import FFIELD\n"
+            "from test_reax_host import _pe_cell\n"
+            "ff = pr.ForceField(FFIELD)\n"
+            "sym, x, box = _pe_cell(ff, tilt=(3.0, -2.0, 1.5), amp=0.12)\n"
+            "e = capi.Engine()\n"
+            "e.reax_configure(FFIELD, qeq_tol=1e-10)\n"
+            "e.register_replica('m', 1, capi.reax_system(sym, x, box))\n"
+            "r = e.reax_compute('m', 1)\n"
+            "print(json.dumps({'f': np.asarray(r['f']).ravel().tolist(), 'w': np.asarray(r['w']).ravel().tolist(), 'vdw': float(r['e']['vdw']), 'coul': float(r['e']['coul']), 'pol': float(r['e']['pol'])}))\n")
+    out = {}
+    for name, env in (("once", {}), ("both_ends", {"SCEMA_MD_RX_NB_ONCE": "0"})):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = out["once"], out["both_ends"]
+    fa, fb = np.array(a["f"]), np.array(b["f"])
+    assert np.abs(fa - fb).max() < 1e-10 * np.abs(fa).max()
+    assert np.abs(np.array(a["w"]) - np.array(b["w"])).max() < 1e-10 * np.abs(np.array(a["w"])).max()
+    for k in ("vdw", "coul", "pol"):
+        assert abs(a[k] - b[k]) < 1e-10 * max(1.0, abs(a[k])), k
