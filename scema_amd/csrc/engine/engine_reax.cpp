@@ -87,7 +87,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   std::vector<std::vector<FlipEvent>> flips(ns);
   int maxatoms = 0, maxpad = 0, maxsteps = 0;
   // columns of the charge-equilibration matrix as 16-bit atom indices when every replica of the batch has at most 65 536 atoms
-  bool col16 = true;
+  bool col16 = !(getenv("SCEMA_MD_RX_COL32") && atoi(getenv("SCEMA_MD_RX_COL32")) != 0);   // (test switch: 32-bit columns for any size)
   for (int i = 0; i < ns; i++) col16 = col16 && sims[i].st->topo->natoms <= 65536;
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];

@@ -289,7 +289,7 @@ def test_strain_batch_with_reax_force_field(ff, tmp_path):
     e2.close()
 
 
-def test_both_ends_nonbonded_kernel_equals_the_once_per_pair_one():
+def test_fallback_kernels_of_large_replicas_equal_the_default_ones():
     """k_rx_nonbonded_once (every pair once, partner forces in an LDS table: the default for replicas of up to 6 000 atoms) against
     k_rx_nonbonded (both ends of every pair, no table: larger replicas; SCEMA_MD_RX_NB_ONCE=0 forces it, read once per process ->
     child processes) on the triclinic cell with several images inside the list radius: same forces, energies and virial"""
@@ -309,13 +309,16 @@ def test_both_ends_nonbonded_kernel_equals_the_once_per_pair_one():
             "r = e.reax_compute('m', 1)\n"
             "print(json.dumps({'f': np.asarray(r['f']).ravel().tolist(), 'w': np.asarray(r['w']).ravel().tolist(), 'vdw': float(r['e']['vdw']), 'coul': float(r['e']['coul']), 'pol': float(r['e']['pol'])}))\n")
     out = {}
-    for name, env in (("once", {}), ("both_ends", {"SCEMA_MD_RX_NB_ONCE": "0"})):
+    for name, env in (("once", {}), ("both_ends", {"SCEMA_MD_RX_NB_ONCE": "0"}), ("col32", {"SCEMA_MD_RX_COL32": "1"})):
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr[-2000:]
         out[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    a, b = out["once"], out["both_ends"]
-    fa, fb = np.array(a["f"]), np.array(b["f"])
-    assert np.abs(fa - fb).max() < 1e-10 * np.abs(fa).max()
-    assert np.abs(np.array(a["w"]) - np.array(b["w"])).max() < 1e-10 * np.abs(np.array(a["w"])).max()
-    for k in ("vdw", "coul", "pol"):
-        assert abs(a[k] - b[k]) < 1e-10 * max(1.0, abs(a[k])), k
+    a = out["once"]
+    fa = np.array(a["f"])
+    # (the third run stores the columns of the charge-equilibration matrix as 32-bit indices, as replicas beyond 65 536 atoms do)
+    for name in ("both_ends", "col32"):
+        b = out[name]
+        assert np.abs(fa - np.array(b["f"])).max() < 1e-10 * np.abs(fa).max(), name
+        assert np.abs(np.array(a["w"]) - np.array(b["w"])).max() < 1e-10 * np.abs(np.array(a["w"])).max(), name
+        for k in ("vdw", "coul", "pol"):
+            assert abs(a[k] - b[k]) < 1e-10 * max(1.0, abs(a[k])), (name, k)
