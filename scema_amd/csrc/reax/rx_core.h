@@ -54,6 +54,18 @@ RX_FN int rx_owns(int i, int e) { const int j = e & RX_JMASK; return j > i || (j
 RX_FN void rx_vt(double *v, const double *a, const double *f) {
   v[0] += a[0] * f[0]; v[1] += a[1] * f[1]; v[2] += a[2] * f[2]; v[3] += a[0] * f[1]; v[4] += a[0] * f[2]; v[5] += a[1] * f[2];
 }
+// x^(-1/3), x > 0.  On the device: the FP32 estimate exp2(-log2(x) / 3) (two hardware transcendentals) and two Newton steps
+// y <- y (4 - x y^3) / 3 (quadratic: 1e-6 -> 2e-12 -> below the rounding of FP64) instead of the library's cbrt and a division.
+RX_FN double rx_icbrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = (double)__builtin_amdgcn_exp2f(-0.33333334f * __builtin_amdgcn_logf((float)x));
+  y = y * fma(-x * y, y * y, 4.0) * 0.33333333333333331;
+  y = y * fma(-x * y, y * y, 4.0) * 0.33333333333333331;
+  return y;
+#else
+  return 1.0 / cbrt(x);
+#endif
+}
 RX_FN double rx_taper(const RxParams *P, double r, double *dtap) {
   double t = P->tap[7], dt = 7.0 * P->tap[7];
   for (int m = 6; m >= 0; m--) t = t * r + P->tap[m];
@@ -682,7 +694,7 @@ RX_FN void rx_nonbonded_pair(const RxParams *P, const RxTbp *t, double qq, doubl
   const double e_v = t->D * (ex1 - 2.0 * ex2);
   double dE = dTap * e_v - Tap * t->D * (t->alpha / t->r_vdW) * (ex1 - ex2) * dfn13;
   *evdw = Tap * e_v;
-  const double r3g = r2 * r + t->gamma, c13i = 1.0 / cbrt(r3g);
+  const double r3g = r2 * r + t->gamma, c13i = rx_icbrt(r3g);
   *ecoul = Tap * qq * c13i;
   dE += qq * c13i * (dTap - Tap * r2 / r3g);
   *s_out = dE * rinv;
@@ -790,7 +802,7 @@ RX_FN double rx_qeq_entry(const RxParams *P, const RxView *V, int i, int e, int 
   const double r = sqrt(r2);
   double dTap;
   const double Tap = rx_taper(P, r, &dTap);
-  return Tap * RX_EV_TO_KCALPMOL / cbrt(r2 * r + P->tbp[V->rtype[i] * RX_MAXT + V->rtype[j]].gamma);
+  return Tap * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * r + P->tbp[V->rtype[i] * RX_MAXT + V->rtype[j]].gamma);
 }
 // row i of the matrix, serially (host checks: tests/reax_host_driver.cpp; the kernels put a wave on the row): the entries inside the
 // taper radius, in list order, at i * maxnb
