@@ -146,7 +146,7 @@ struct State {
 // work arrays of the ReaxFF path for one batch position (reax/rx_types.h RxView points into these)
 struct RxSlot {
   int cap_pad = 0, cap_nb = 0, cap_bd = 0, cap_nbn = 0;
-  DevBuf nbn_cnt, nbn, qpart;
+  DevBuf nbn_cnt, nbn, nbnT, qpart;
   DevBuf nb_cnt, nb, nbT, hval, hcol, hlen, hown, hownlen, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
 };
 

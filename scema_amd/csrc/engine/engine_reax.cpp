@@ -33,6 +33,7 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
   }
   if (maxnbn > r.cap_nbn) {
     HIPCHK(r.nbn.ensure((size_t)maxnbn * npad * 4));
+    HIPCHK(r.nbnT.ensure((size_t)maxnbn * npad * 4));
     r.cap_nbn = maxnbn;
   }
   if (maxnb > r.cap_nb) {
@@ -181,7 +182,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     S.sc = e->d_sc.as<SimScalars>() + i;
     V.n = n; V.npad = npad; V.maxnb = maxnb; V.maxbd = maxbd;
     V.rtype = T.d_rtype.as<int>(); V.x = S.x; V.q = R.q.as<double>();
-    V.nbn_cnt = R.nbn_cnt.as<int>(); V.nbn = R.nbn.as<int>(); V.maxnbn = maxnbn; V.rnear2 = rnear * rnear;
+    V.nbn_cnt = R.nbn_cnt.as<int>(); V.nbn = R.nbn.as<int>(); V.nbnT = R.nbnT.as<int>(); V.maxnbn = maxnbn; V.rnear2 = rnear * rnear;
     V.qpart = R.qpart.as<double>();
     V.nb_cnt = R.nb_cnt.as<int>(); V.nb = R.nb.as<int>(); V.bd_cnt = R.bd_cnt.as<int>(); V.bd = R.bd.as<int>(); V.bd_rev = R.bd_rev.as<int>();
     V.bd_bop = R.bd_bop.as<double>(); V.bd_c = R.bd_c.as<double>(); V.bd_bo = R.bd_bo.as<double>(); V.bd_g = R.bd_g.as<double>(); V.bd_cb = R.bd_cb.as<double>();

@@ -99,6 +99,40 @@ RX_FN void rx_atom_deltas(const RxParams *P, int type, double total_bo, RxAtomD 
 // ------------------------------------------------------------------------------------------------------------------
 // pass 1: uncorrected bond orders of atom i from its neighbour row (BOp of reaxc_bond_orders.cpp)
 // ------------------------------------------------------------------------------------------------------------------
+// uncorrected bond order of atom i with the partner of near-row entry e: BO' (total, cutoff NOT yet taken off), its pi parts, r and
+// the coefficients of d in dBO'/dd; returns 0 when the pair is beyond the bond cutoff or BO' below the threshold
+RX_FN int rx_bond_prime_entry(const RxParams *P, const RxView *V, int i, int e, double *bo, double *bp, double *bpp, double *r_out, double *cs, double *cp, double *cpp) {
+  const int ti = V->rtype[i];
+  const RxSbp *si = &P->sbp[ti];
+  double d[3];
+  const int j = rx_partner(V, i, e, d);
+  const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  if (r2 > RX_BOND_CUT * RX_BOND_CUT) return 0;
+  const double r = sqrt(r2);
+  const int tj = V->rtype[j];
+  const RxSbp *sj = &P->sbp[tj];
+  const RxTbp *t = &P->tbp[ti * RX_MAXT + tj];
+  double bs = 0;
+  *bp = 0; *bpp = 0; *cs = 0; *cp = 0; *cpp = 0;
+  if (si->r_s > 0.0 && sj->r_s > 0.0) {
+    const double c12 = t->p_bo1 * pow(r / t->r_s, t->p_bo2);
+    bs = (1.0 + P->bo_cut) * exp(c12);
+    *cs = bs * t->p_bo2 * c12 / r2;
+  }
+  if (si->r_pi > 0.0 && sj->r_pi > 0.0) {
+    const double c34 = t->p_bo3 * pow(r / t->r_p, t->p_bo4);
+    *bp = exp(c34);
+    *cp = *bp * t->p_bo4 * c34 / r2;
+  }
+  if (si->r_pi_pi > 0.0 && sj->r_pi_pi > 0.0) {
+    const double c56 = t->p_bo5 * pow(r / t->r_pp, t->p_bo6);
+    *bpp = exp(c56);
+    *cpp = *bpp * t->p_bo6 * c56 / r2;
+  }
+  *bo = bs + *bp + *bpp;
+  *r_out = r;
+  return *bo >= P->bo_cut;
+}
 RX_FN void rx_bonds_prime(const RxParams *P, const RxView *V, int i) {
   const int np = V->npad, ti = V->rtype[i];
   const RxSbp *si = &P->sbp[ti];

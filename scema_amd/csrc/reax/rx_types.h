@@ -75,6 +75,7 @@ typedef struct {
   // near rows: the entries of nb inside the bond cutoff + skin, same order (the bond-order pass walks these; NULL: walk nb)
   int *nbn_cnt;           // [n]
   int *nbn;               // [maxnbn][npad]
+  int *nbnT;              // [npad][maxnbn] the near rows once more, row-major (the bond-order pass puts a wave on a row)
   int maxnbn, pad0_;
   double rnear2;          // (bond cutoff + skin)^2
   // bond rows: pairs with BO' >= cutoff (full)
