@@ -21,7 +21,7 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
     HIPCHK(r.s_hist.ensure(4 * (size_t)npad * 8));
     HIPCHK(r.t_hist.ensure(3 * (size_t)npad * 8));
     HIPCHK(r.qwork.ensure(8 * (size_t)npad * 8));
-    HIPCHK(r.qpart.ensure((6 * (size_t)((npad + 255) / 256) + 2 * (size_t)(npad / 64)) * 8));   // layout: md_reax.hip
+    HIPCHK(r.qpart.ensure((6 * (size_t)((npad + 255) / 256) + 2 * (size_t)(npad / RX_SWR + 1)) * 8));   // layout: md_reax.hip
     HIPCHK(r.nbn_cnt.ensure((size_t)npad * 4));
     HIPCHK(r.hlen.ensure((size_t)npad * 4));
     HIPCHK(r.hownlen.ensure((size_t)npad * 4));

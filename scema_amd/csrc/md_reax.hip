@@ -216,7 +216,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
 // then forms the charges and shifts the history.
 //
 // qpart layout (doubles): [0, 2 NV) and [2 NV, 4 NV): r.z partials of even / odd iterations; [4 NV, 6 NV): b.b partials;
-// [6 NV, 6 NV + 2 NB): d.q partials.  NV = RX_QNV (update workgroups, padded), NB = sweep workgroups = npad / 64.
+// [6 NV, 6 NV + 2 NB): d.q partials.  NV = RX_QNV (update workgroups, padded), NB = sweep workgroups = npad / RX_SWR.
 #define QEQ_TPB 1024
 #define RX_QEQ_COLD 4   /* solves of a run that count as cold (the extrapolation uses four past solutions) */
 #define QEQ_UT 256
@@ -262,8 +262,8 @@ template <bool COL16>
 __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, const RxParams *P, double tol, int it) {
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane, n = V.n;
-  if (blockIdx.x * 64 >= n) return;
+  const int i = blockIdx.x * RX_SWR + lane, n = V.n;   // (the row of lane < RX_SWR of wave 0 in the row-local part below)
+  if (blockIdx.x * RX_SWR >= n) return;
   QeqScal Q;
   double beta_s = 0.0, beta_t = 0.0;
   if (it >= 0) {
@@ -278,13 +278,13 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   const size_t np = V.npad;
   const double2 *z = (const double2 *)(V.qwork + 6 * np);
   // the products of this workgroup's 64 rows: wave w takes the rows 8 w .. 8 w + 7, lanes over the entries of a row
-  __shared__ double s_y[2][64];
+  __shared__ double s_y[2][RX_SWR];
   const unsigned short *c16 = V.hcol16;
   const int *c32 = V.hcol32;
   // (two rows at a time: their loads are independent)
 #define RX_SWEEP_RG 2
-  for (int r0 = 0; r0 < 64 / RX_KS; r0 += RX_SWEEP_RG) {
-    const int lr0 = wave * (64 / RX_KS) + r0, row0 = blockIdx.x * 64 + lr0;
+  for (int r0 = 0; r0 < RX_SWR / RX_KS; r0 += RX_SWEEP_RG) {
+    const int lr0 = wave * (RX_SWR / RX_KS) + r0, row0 = blockIdx.x * RX_SWR + lr0;
     int len[RX_SWEEP_RG], lmax = 0;
     size_t base[RX_SWEEP_RG];
     double ps[RX_SWEEP_RG], pt[RX_SWEEP_RG];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   double ys = 0.0, yt = 0.0;
   if (wave != 0) return;
   double dq_s = 0.0, dq_t = 0.0;
-  if (i < n) {
+  if (lane < RX_SWR && i < n) {
     ys = s_y[0][lane]; yt = s_y[1][lane];
     const double eta = P->sbp[V.rtype[i]].eta;
     const double2 zi = z[i];
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, c
       return;
     }
     double dq_s, dq_t;
-    qeq_fold(V.qpart + 6 * nv, (V.n + 63) / 64, dq_s, dq_t);
+    qeq_fold(V.qpart + 6 * nv, (V.n + RX_SWR - 1) / RX_SWR, dq_s, dq_t);
     const double al_s = Q.run[0] ? Q.sig[0] / dq_s : 0.0, al_t = Q.run[1] ? Q.sig[1] / dq_t : 0.0;
     if (i < n) {
       const double eta = P->sbp[V.rtype[i]].eta;
@@ -771,7 +771,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
                      int terms, bool col16, std::vector<hipEvent_t> *ev, size_t *ev_used) {
   // a HIP-event pair around every launch of the matrix sweep when the caller profiles (bench.py's roofline block)
   auto sweep = [&](int it) {
-    const dim3 gk = g2(cdv(maxatoms, 64), ns);
+    const dim3 gk = g2(cdv(maxatoms, RX_SWR), ns);
     if (ev) {
       while (*ev_used + 2 > ev->size()) { hipEvent_t a; if (hipEventCreate(&a) != hipSuccess) { ev = nullptr; break; } ev->push_back(a); }
     }

@@ -14,6 +14,7 @@
 #define RX_MAXANG 4          /* parameter sets per valence-angle triple */
 #define RX_NGP 40
 #define RX_KS 8               /* waves of a workgroup of the charge-equilibration kernels: 64 rows per workgroup, 8 per wave */
+#define RX_SWR 32             /* rows per workgroup of the matrix sweep (4 per wave): small workgroups, so that the tail of a launch is short */
 #define RX_JMASK 0x00FFFFFF  /* row entry: [23:0] atom, [30:24] image code (sx+2) + 5 (sy+2) + 25 (sz+2) */
 #define RX_CODE0 62          /* code of the zero shift */
 
