@@ -172,17 +172,22 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
   const RxView V = views[blockIdx.y];
   (void)sims;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the type-pair constants of the kernel in LDS: one dependent global load less per entry
+  __shared__ double s_gamma[RX_MAXT * RX_MAXT];
+  if (threadIdx.x < RX_MAXT * RX_MAXT) s_gamma[threadIdx.x] = P->tbp[threadIdx.x].gamma;
+  __syncthreads();
   for (int r = 0; r < 64 / RX_KS; r++) {
     const int i = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
-    if (i >= V.n) return;   // (wave-uniform)
+    if (i >= V.n) return;   // (wave-uniform; no barrier below)
     const int cnt = V.nb_cnt[i];
     const size_t base = (size_t)i * V.maxnb;
+    const double *grow = s_gamma + V.rtype[i] * RX_MAXT;
     int len = 0, lown = 0;
     for (int k0 = 0; k0 < cnt; k0 += 64) {
       const int k = k0 + lane;
       int col = 0, ent = 0;
       double h = -1.0;
-      if (k < cnt) { ent = V.nbT[base + k]; h = rx_qeq_entry(P, &V, i, ent, &col); }
+      if (k < cnt) { ent = V.nbT[base + k]; h = rx_qeq_entry(P, &V, i, ent, &col, grow); }
       const unsigned long long m = __ballot(h >= 0.0);
       if (h >= 0.0) {
         const size_t o = base + len + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -561,9 +566,15 @@ __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxP
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t np = V.npad, plane = (size_t)V.maxbd * np;
+  // the type tables in LDS: the parameters of a pair are two dependent global loads away otherwise
+  __shared__ RxSbp s_sbp[RX_MAXT];
+  __shared__ RxTbp s_tbp[RX_MAXT * RX_MAXT];
+  for (int k = threadIdx.x; k < (int)(sizeof(s_sbp) / 8); k += TPB) ((double *)s_sbp)[k] = ((const double *)P->sbp)[k];
+  for (int k = threadIdx.x; k < (int)(sizeof(s_tbp) / 8); k += TPB) ((double *)s_tbp)[k] = ((const double *)P->tbp)[k];
+  __syncthreads();
   for (int r = 0; r < 8; r++) {
     const int i = blockIdx.x * (8 * (TPB / 64)) + wave * 8 + r;
-    if (i >= V.n) return;   // (wave-uniform)
+    if (i >= V.n) return;   // (wave-uniform; no barrier below)
     const int cnt = V.nbn_cnt[i];
     const size_t base = (size_t)i * V.maxnbn;
     int nb = 0;
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxP
       const int k = k0 + lane;
       int e = 0, ok = 0;
       double bo = 0, bp = 0, bpp = 0, rr = 0, cs = 0, cp = 0, cpp = 0;
-      if (k < cnt) { e = V.nbnT[base + k]; ok = rx_bond_prime_entry(P, &V, i, e, &bo, &bp, &bpp, &rr, &cs, &cp, &cpp); }
+      if (k < cnt) { e = V.nbnT[base + k]; ok = rx_bond_prime_entry(P, &V, i, e, &bo, &bp, &bpp, &rr, &cs, &cp, &cpp, s_sbp, s_tbp); }
       const unsigned long long m = __ballot(ok);
       if (ok) {
         const int pos = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -663,6 +674,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = V.n;
   if ((int)(blockIdx.x * 64) >= n) return;
   const size_t np = V.npad;
+  __shared__ RxTbp s_tbp[RX_MAXT * RX_MAXT];   // the pair parameters in LDS (a dependent global load less per pair)
+  for (int k = threadIdx.x; k < (int)(sizeof(s_tbp) / 8); k += RX_KT) ((double *)s_tbp)[k] = ((const double *)P->tbp)[k];
   for (int k = threadIdx.x; k < 3 * (int)np; k += RX_KT) s_nbf[k] = 0.0;
   __syncthreads();
   double e[RX_NPART], w[6];
@@ -686,7 +699,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims,
         rx_shift(&V, ent, sh);
         const double d0 = V.x[3 * j] - xi0 + sh[0], d1 = V.x[3 * j + 1] - xi1 + sh[1], d2 = V.x[3 * j + 2] - xi2 + sh[2];
         double ev, ec, sc_;
-        rx_nonbonded_pair(P, &P->tbp[ti * RX_MAXT + V.rtype[j]], qi * V.q[j], d0 * d0 + d1 * d1 + d2 * d2, &ev, &ec, &sc_);
+        rx_nonbonded_pair(P, &s_tbp[ti * RX_MAXT + V.rtype[j]], qi * V.q[j], d0 * d0 + d1 * d1 + d2 * d2, &ev, &ec, &sc_);
         e[RX_E_VDW] += ev; e[RX_E_COUL] += ec;
         const double g0 = sc_ * d0, g1 = sc_ * d1, g2 = sc_ * d2;   // force on i; the partner takes the opposite
         f0 += g0; f1 += g1; f2 += g2;

@@ -24,6 +24,11 @@
 #define RX_ATOMIC_OR(p, v) atomicOr((p), (v))
 #endif
 
+#ifdef __cplusplus
+#define RX_DEFAULT_NULL = nullptr
+#else
+#define RX_DEFAULT_NULL
+#endif
 #define RX_SQR(x) ((x) * (x))
 #define RX_PI 3.14159265358979323846
 
@@ -101,17 +106,21 @@ RX_FN void rx_atom_deltas(const RxParams *P, int type, double total_bo, RxAtomD 
 // ------------------------------------------------------------------------------------------------------------------
 // uncorrected bond order of atom i with the partner of near-row entry e: BO' (total, cutoff NOT yet taken off), its pi parts, r and
 // the coefficients of d in dBO'/dd; returns 0 when the pair is beyond the bond cutoff or BO' below the threshold
-RX_FN int rx_bond_prime_entry(const RxParams *P, const RxView *V, int i, int e, double *bo, double *bp, double *bpp, double *r_out, double *cs, double *cp, double *cpp) {
+// (sbp, tbp: the type tables, e.g. staged in LDS; NULL: the ones of P)
+RX_FN int rx_bond_prime_entry(const RxParams *P, const RxView *V, int i, int e, double *bo, double *bp, double *bpp, double *r_out, double *cs, double *cp, double *cpp,
+                              const RxSbp *sbp RX_DEFAULT_NULL, const RxTbp *tbp RX_DEFAULT_NULL) {
+  if (!sbp) sbp = P->sbp;
+  if (!tbp) tbp = P->tbp;
   const int ti = V->rtype[i];
-  const RxSbp *si = &P->sbp[ti];
+  const RxSbp *si = &sbp[ti];
   double d[3];
   const int j = rx_partner(V, i, e, d);
   const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
   if (r2 > RX_BOND_CUT * RX_BOND_CUT) return 0;
   const double r = sqrt(r2);
   const int tj = V->rtype[j];
-  const RxSbp *sj = &P->sbp[tj];
-  const RxTbp *t = &P->tbp[ti * RX_MAXT + tj];
+  const RxSbp *sj = &sbp[tj];
+  const RxTbp *t = &tbp[ti * RX_MAXT + tj];
   double bs = 0;
   *bp = 0; *bpp = 0; *cs = 0; *cp = 0; *cpp = 0;
   if (si->r_s > 0.0 && sj->r_s > 0.0) {
@@ -827,7 +836,8 @@ RX_FN void rx_back_force(const RxParams *P, const RxView *V, int i, double *vir)
 // charge equilibration (fix qeq/reax): matrix entries of atom i's row, H_ij = Tap(r) 14.4 / (r^3 + gamma_ij)^(1/3)
 // ------------------------------------------------------------------------------------------------------------------
 // H_ij of list entry e of row i, or a negative number when the pair is outside the taper radius; *col = j
-RX_FN double rx_qeq_entry(const RxParams *P, const RxView *V, int i, int e, int *col) {
+// (gamma_row: the gamma_ij of atom i's type against every type, e.g. staged in LDS; NULL: read from the parameter tables)
+RX_FN double rx_qeq_entry(const RxParams *P, const RxView *V, int i, int e, int *col, const double *gamma_row RX_DEFAULT_NULL) {
   double d[3];
   const int j = rx_partner(V, i, e, d);
   *col = j;
@@ -836,7 +846,8 @@ RX_FN double rx_qeq_entry(const RxParams *P, const RxView *V, int i, int e, int 
   const double r = sqrt(r2);
   double dTap;
   const double Tap = rx_taper(P, r, &dTap);
-  return Tap * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * r + P->tbp[V->rtype[i] * RX_MAXT + V->rtype[j]].gamma);
+  const double gamma = gamma_row ? gamma_row[V->rtype[j]] : P->tbp[V->rtype[i] * RX_MAXT + V->rtype[j]].gamma;
+  return Tap * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * r + gamma);
 }
 // row i of the matrix, serially (host checks: tests/reax_host_driver.cpp; the kernels put a wave on the row): the entries inside the
 // taper radius, in list order, at i * maxnb
