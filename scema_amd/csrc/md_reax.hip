@@ -231,10 +231,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
 __device__ __forceinline__ void qeq_fold(const double *part, int count, double &a, double &b) {
   double sa = 0.0, sb = 0.0;
   for (int k = threadIdx.x & 63; k < count; k += 64) { sa += part[2 * k]; sb += part[2 * k + 1]; }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { sa += __shfl_xor(sa, m); sb += __shfl_xor(sb, m); }   // butterfly: every lane holds the same sum
-  a = sa;
-  b = sb;
+  a = wave_sum(sa);   // (DPP: every lane holds the same sum; as shuffles these were 24 LDS round trips per fold, at the head of every launch)
+  b = wave_sum(sb);
 }
 struct QeqScal { double sig[2], bn[2]; bool run[2]; };
 // scalars of iteration `it` from the partial sums of the launches before it
