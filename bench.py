@@ -72,35 +72,47 @@ def _lammps_baseline(lmp, scripts, cells, strains, nss, ncore):
     return ncore / dt, dt
 
 
+CORES_RULE = {"rule": None}
+
+
 def _host_cores(per_process_gb, cap=None):
     """processes the CPU baseline may start: every host core THIS JOB MAY USE -- the affinity mask and the cgroup CPU quota, not
     os.cpu_count() (a GPU box reports 256 cores and gives a one-GPU job 16 of them: 256 workers then take 12 times as long) --
-    unless memory (or a cap) says fewer"""
-    n = os.cpu_count() or 1
+    unless memory (or a cap) says fewer.  Which rule decided is recorded (CORES_RULE) and printed with the baseline."""
+    total = os.cpu_count() or 1
+    n, rule = total, "os.cpu_count"
     try:
-        n = min(n, len(os.sched_getaffinity(0)))
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, rule = a, "affinity mask"
     except Exception:
         pass
     for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
                         ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))):
         try:
             q = parse(open(path).read())
-            if q:
-                n = min(n, max(1, int(q + 0.5)))
+            if q and max(1, int(q + 0.5)) < n:
+                n, rule = max(1, int(q + 0.5)), "cgroup cpu quota"
         except Exception:
             pass
-    # A one-GPU job of this pool gets 16 of the host's cores whatever os.cpu_count() says, and nothing in /sys says so (measured:
-    # 256 workers on a "256-core" box deliver 0.68 evaluations/s, 32 deliver 1.1, i.e. both are oversubscribed); the baseline runs
-    # at N = 1 only, so 16 it is unless SCEMA_CPU_BASELINE_CORES names the share of another host
-    n = min(n, 16)
+    # Neither the affinity mask nor a cgroup quota constrains this job: a one-GPU job of this pool still gets only 16 of the host's
+    # cores and nothing in /sys says so (measured: 256 workers on a "256-core" box deliver 0.68 evaluations/s, 32 deliver 1.1, i.e.
+    # both are oversubscribed), so 16 is the pool default for an unconstrained job; a constraint found above is used as it is
+    if rule == "os.cpu_count" and n > 16:
+        n, rule = 16, "pool default (no affinity or cgroup constraint found; a one-GPU job's share of the host)"
     if os.environ.get("SCEMA_CPU_BASELINE_CORES"):
-        n = max(1, int(os.environ["SCEMA_CPU_BASELINE_CORES"]))
+        n, rule = max(1, int(os.environ["SCEMA_CPU_BASELINE_CORES"])), "SCEMA_CPU_BASELINE_CORES"
     try:
         import psutil
-        n = min(n, max(1, int(psutil.virtual_memory().available / 2**30 / per_process_gb * 0.6)))
+        m = max(1, int(psutil.virtual_memory().available / 2**30 / per_process_gb * 0.6))
+        if m < n:
+            n, rule = m, "available memory"
     except Exception:
         pass
-    return max(1, min(n, cap) if cap else n)
+    if cap and cap < n:
+        n, rule = cap, f"cap of {cap} workers"
+    CORES_RULE["rule"] = rule
+    return max(1, n)
 
 
 def _cpu_eval_reax(k, cells, strain, nss, dt, rate):
@@ -115,18 +127,18 @@ def _cpu_eval_reax(k, cells, strain, nss, dt, rate):
     m = np.array([12.011 if c == "C" else 1.008 for c in sym])
     v = np.random.default_rng(3).standard_normal((len(sym), 3)) * np.sqrt(0.0019872067 * 300.0 / (m[:, None] * 48.88821291 ** 2))
     v -= (m[:, None] * v).sum(0) / m.sum()
-    M = reax_md.ReaxMD(os.path.join(ROOT, "tests", "golden", "ffield.reax.2"), ["H", "C", "N", "O"], lt, [1.008, 12.011, 14.007, 15.999], d["box"], d["x"], v)
+    M = reax_md.ReaxMD(os.path.join(ROOT, "examples", "ffield.reax.2"), ["H", "C", "N", "O"], lt, [1.008, 12.011, 14.007, 15.999], d["box"], d["x"], v)
     t0 = time.time()
     _, nts = M.eval(strain, dt, 300.0, rate, nss)
     return k, t0, time.time(), int(nts), M.qeq_iters / max(M.qeq_solves, 1)
 
 
-def cpu_baseline_reax(cells, strains, nss, dt, rate):
+def cpu_baseline_reax(cells, strains, nss, dt, rate, cap=64):
     """The ReaxFF oracle timed on the host cores, one single-threaded process per core (capped at 64: every process holds a
     reverse-mode graph of ~0.6 GB): CPU restatement (oracle/reax_md.py: torch FP64 autograd forces + CG), NOT LAMMPS."""
     import concurrent.futures as cf
     import multiprocessing as mp
-    ncore = min(_host_cores(1.0, cap=64), len(strains))
+    ncore = min(_host_cores(1.0, cap=cap), len(strains))
     # torch's autograd engine asks for the GPU count on its first backward(), which opens /dev/kfd: the workers are CPU-only and
     # must not count as users of the box's GPU (oracle/nogpu_shim.c hides the device nodes from them)
     shim = os.path.join(ROOT, "oracle", "_build", "libnogpu_shim.so")
@@ -217,78 +229,40 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sims", type=int, default=576, help="quadrature-point replicas per update()")
-    ap.add_argument("--nss", type=int, default=100)
-    ap.add_argument("--cells", type=int, nargs=3, default=[6, 9, 16], help="PE supercell (6 9 16 = PE-10k)")
-    ap.add_argument("--strain-set", default="balanced", choices=["balanced", "file3d", "imbalanced"],
-                    help="balanced: nts=10 for every replica (default, SURVEY 8d); file3d: x5 strains at rate 2e-4 (nts=30); "
-                         "imbalanced: eps_zz log-uniform in [1e-3,2e-2] (nts 10..100)")
-    ap.add_argument("--equil-steps", type=int, default=2000, help="NVT+SHAKE steps that equilibrate the synthetic crystal before anything is timed")
-    ap.add_argument("--equil-cache", default=None, help="npz file: load the equilibrated state from it if it exists, else write it (profiling runs: "
-                    "keeps the 2 000 single-replica steps out of a PMC pass)")
-    ap.add_argument("--monotonic", action="store_true", help="apply the tensile strain draws update after update (no unloading on odd updates)")
-    ap.add_argument("--kspace", default="pppm", choices=["pppm", "ewald"], help="reciprocal part: PPPM (order 5, ik, hipFFT) as the reference's "
-                    "`kspace_style pppm 0.0001` asks for (default, the reported configuration) or the plain Ewald sum at the same accuracy")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-field", default="opls", choices=["opls", "reax"],
-                    help="opls: the headline workload (576 x PE-10k); reax: BASELINE config 5, 72 x PE-1620 ReaxFF replicas (--sims / --cells / --nss default to that)")
-    ap.add_argument("--monotonic-updates", type=int, default=4, help="after the timed loop, this many all-tensile updates (the SURVEY 8(d) set as written) are "
-                    "timed as well and reported as config.strain_set_monotonic_evals_per_s (0: skip; never part of `value`)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
-    ap.add_argument("--share-gpus", action="store_true", help="tests: let several ranks share a GPU (needs --dist-backend gloo)")
-    args = ap.parse_args()
-    if args.force_field == "reax":   # the replica set of BASELINE config 5, unless the command line says otherwise
-        given = " ".join(sys.argv[1:])
-        if "--sims" not in given: args.sims = 72
-        if "--cells" not in given: args.cells = [3, 5, 9]
-        if "--nss" not in given: args.nss = 20
-        if "--equil-steps" not in given: args.equil_steps = 200
-
-    if "RANK" not in os.environ and args.gpus > 1:
-        raise SystemExit(spawn_ranks(args))
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-
-    from scema_amd.systems import build_pe, synthetic_strains
+def _workload(args):
+    """what a leg needs before the GPU is touched: the replica, its box lengths, time step and strain rate"""
+    from scema_amd.systems import build_pe
     reax = args.force_field == "reax"
     DT = 0.25 if reax else 2.0                      # fs; ReaxFF needs the short step (bond orders change within femtoseconds)
     d = build_pe(*args.cells, shake_project=not reax)   # SURVEY 8(d): seed 1234, 300 K, SHAKE-projected velocities
     lens = d["box"][3:6] - d["box"][:3]
-    n = args.sims
     rate = 1e-3 if reax else (2e-4 if args.strain_set == "file3d" else 1e-4)
+    return d, lens, DT, rate
 
-    # CPU baseline first: its worker processes start while nothing in this process has touched the GPU
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        ncpu = _host_cores(0.4)
-        if reax:
-            cpu = cpu_baseline_reax(tuple(args.cells), synthetic_strains(max(ncpu, 8), lens, seed=2026), args.nss, DT, rate)
-        else:
-            cpu = cpu_baseline(tuple(args.cells), synthetic_strains(max(ncpu, 32), lens, seed=2026), args.nss, 1 if args.kspace == "pppm" else 0)
 
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    if world > ndev and not args.share_gpus:
-        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s)")
-    device = local_rank % ndev
-    torch.cuda.set_device(device)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")   # control plane only (id exchange, barrier, max of the timings); the data path is RCCL
+def _reax_leg_args(args):
+    """BASELINE config 5 as a short second leg of the default run: 72 x PE-1620 ReaxFF replicas, 2 warm-up + 4 timed updates"""
+    import copy
+    r = copy.copy(args)
+    r.force_field, r.sims, r.cells, r.nss, r.equil_steps = "reax", 72, [3, 5, 9], 20, 200
+    r.steps, r.warmup, r.monotonic_updates, r.monotonic, r.strain_set, r.equil_cache = 4, 2, 0, False, "balanced", None
+    return r
 
+
+def env_overrides():
+    """every SCEMA_* variable of this process's environment that the engine or this program reads: a reported run has none"""
+    from scema_amd import capi
+    eng_side = capi.env_overrides()
+    mine = [f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("SCEMA_BENCH_") or k in ("SCEMA_CPU_BASELINE_CORES", "SCEMA_LAMMPS", "SCEMA_SCRIPTS")]
+    return eng_side + mine
+
+
+def run_leg(args, rank, world, device, cpu, torch, dist):
+    """one workload through the engine: equilibrate (untimed), warm up, time `steps` updates; rank 0 returns the JSON record"""
+    from scema_amd.systems import synthetic_strains
+    reax = args.force_field == "reax"
+    d, lens, DT, rate = _workload(args)
+    n = args.sims
     from scema_amd import capi
     # ablation knobs for kernel experiments only (never set in a reported run)
     extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
@@ -307,7 +281,7 @@ def main():
         v0 = np.random.default_rng(3).standard_normal((len(sym), 3)) * np.sqrt(0.0019872067 * 300.0 / (m[:, None] * 48.88821291 ** 2))
         v0 -= (m[:, None] * v0).sum(0) / m.sum()
         d = capi.reax_system(sym, d["x"], d["box"], v=v0)
-        eng.reax_configure(os.path.join(ROOT, "tests", "golden", "ffield.reax.2"), qeq_tol=1e-6)
+        eng.reax_configure(args.ffield, qeq_tol=1e-6)
     eng.register_replica("g0", 1, d)
     if args.equil_steps > 0:
         state = [None]
@@ -382,6 +356,7 @@ def main():
         update(args.warmup + k)
     fence()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -409,6 +384,14 @@ def main():
             tm = float(t.item())
         mono_rate = n * args.monotonic_updates / tm
 
+    # N > 1: what every rank did in the timed loop (its own clock), so that a scaling line explains itself
+    per_rank_stats = None
+    if world > 1:
+        mine = {"rank": rank, "sims": int((owner == rank).sum()), "elapsed_s": own_elapsed, "pair_ms": prof["pair_ms"], "md_steps": prof["md_steps"]}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        per_rank_stats = [dict(r, evals_per_s=r["sims"] * args.steps / r["elapsed_s"] if r["elapsed_s"] > 0 else 0.0) for r in allr]
+    out = None
     if rank == 0:
         natoms = int(d["natoms"])
         per_rank = int(cap)
@@ -497,11 +480,115 @@ def main():
             "roofline": roof,
         }
         if cpu is not None:
-            out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = dict(cpu, cores_rule=cpu.get("cores_rule") or CORES_RULE["rule"])
+        if world > 1:
+            out["config"]["per_rank"] = per_rank_stats
+        out["config"]["env_overrides"] = env_overrides()
     if world > 1:
         dist.barrier()
     eng.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sims", type=int, default=576, help="quadrature-point replicas per update()")
+    ap.add_argument("--nss", type=int, default=100)
+    ap.add_argument("--cells", type=int, nargs=3, default=[6, 9, 16], help="PE supercell (6 9 16 = PE-10k)")
+    ap.add_argument("--strain-set", default="balanced", choices=["balanced", "file3d", "imbalanced"],
+                    help="balanced: nts=10 for every replica (default, SURVEY 8d); file3d: x5 strains at rate 2e-4 (nts=30); "
+                         "imbalanced: eps_zz log-uniform in [1e-3,2e-2] (nts 10..100)")
+    ap.add_argument("--equil-steps", type=int, default=2000, help="NVT+SHAKE steps that equilibrate the synthetic crystal before anything is timed")
+    ap.add_argument("--equil-cache", default=None, help="npz file: load the equilibrated state from it if it exists, else write it (profiling runs: "
+                    "keeps the 2 000 single-replica steps out of a PMC pass)")
+    ap.add_argument("--monotonic", action="store_true", help="apply the tensile strain draws update after update (no unloading on odd updates)")
+    ap.add_argument("--kspace", default="pppm", choices=["pppm", "ewald"], help="reciprocal part: PPPM (order 5, ik, hipFFT) as the reference's "
+                    "`kspace_style pppm 0.0001` asks for (default, the reported configuration) or the plain Ewald sum at the same accuracy")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-field", default="opls", choices=["opls", "reax"],
+                    help="opls: the headline workload (576 x PE-10k); reax: BASELINE config 5, 72 x PE-1620 ReaxFF replicas (--sims / --cells / --nss default to that)")
+    ap.add_argument("--monotonic-updates", type=int, default=4, help="after the timed loop, this many all-tensile updates (the SURVEY 8(d) set as written) are "
+                    "timed as well and reported as config.strain_set_monotonic_evals_per_s (0: skip; never part of `value`)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
+    ap.add_argument("--share-gpus", action="store_true", help="tests: let several ranks share a GPU (needs --dist-backend gloo)")
+    ap.add_argument("--reax-leg", default="auto", choices=["auto", "on", "off"],
+                    help="after the OPLS loop, outside `value`: a short ReaxFF replica-set leg (BASELINE config 5: 72 x PE-1620, 2 warm-up + 4 timed updates) "
+                         "reported as config.reax in the same JSON line.  auto: for the default workload (576 x PE-10k) on one GPU")
+    ap.add_argument("--ffield", default=os.path.join(ROOT, "examples", "ffield.reax.2"),
+                    help="ReaxFF parameter file (the reference's lammps_scripts_reax/ffield.reax.2; the tree keeps a copy as data under examples/)")
+    args = ap.parse_args()
+    if args.force_field == "reax":   # the replica set of BASELINE config 5, unless the command line says otherwise
+        given = " ".join(sys.argv[1:])
+        if "--sims" not in given: args.sims = 72
+        if "--cells" not in given: args.cells = [3, 5, 9]
+        if "--nss" not in given: args.nss = 20
+        if "--equil-steps" not in given: args.equil_steps = 200
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    d, lens, DT, rate = _workload(args)
+    from scema_amd.systems import synthetic_strains
+    reax = args.force_field == "reax"
+    want_reax_leg = (not reax) and world == 1 and (args.reax_leg == "on" or (args.reax_leg == "auto" and args.sims == 576 and list(args.cells) == [6, 9, 16]))
+    rargs = _reax_leg_args(args) if want_reax_leg else None
+
+    # CPU baselines first: their worker processes start while nothing in this process has touched the GPU
+    cpu = cpu_rx = None
+    if world == 1 and not args.no_cpu_baseline:
+        ncpu = _host_cores(0.4)
+        if reax:
+            cpu = cpu_baseline_reax(tuple(args.cells), synthetic_strains(max(ncpu, 8), lens, seed=2026), args.nss, DT, rate)
+        else:
+            cpu = cpu_baseline(tuple(args.cells), synthetic_strains(max(ncpu, 32), lens, seed=2026), args.nss, 1 if args.kspace == "pppm" else 0)
+        cpu["cores_rule"] = CORES_RULE["rule"]
+        if rargs is not None:   # a few workers only: every one holds a reverse-mode graph, and the leg must stay short
+            _, rl, rdt, rrate = _workload(rargs)
+            cpu_rx = cpu_baseline_reax(tuple(rargs.cells), synthetic_strains(8, rl, seed=2026), rargs.nss, rdt, rrate, cap=4)
+            cpu_rx["cores_rule"] = CORES_RULE["rule"]
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if world > ndev and not args.share_gpus:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s)")
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")   # control plane only (id exchange, barrier, max of the timings); the data path is RCCL
+
+    out = run_leg(args, rank, world, device, cpu, torch, dist)
+    if rargs is not None:
+        try:
+            r = run_leg(rargs, rank, world, device, cpu_rx, torch, dist)
+        except Exception as exc:   # the headline line must not depend on the second leg
+            r = None
+            if rank == 0:
+                out["config"]["reax"] = {"error": repr(exc)}
+        if rank == 0 and r is not None:
+            c = r["config"]
+            out["config"]["reax"] = {
+                "workload": c["workload"], "evals_per_s": r["value"], "ms_per_update": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
+                "md_steps_per_eval": c["md_steps_per_eval"], "replica_steps_per_s": r["value"] * c["md_steps_per_eval"],
+                "atoms_per_replica": c["atoms_per_replica"], "n_sims": c["n_sims"], "stress_zz_checksum_Pa": c["stress_zz_checksum_Pa"],
+                "roofline": r["roofline"], "cpu_baseline": r.get("cpu_baseline"),
+                "note": "BASELINE config 5 as a second leg of this run, after the OPLS loop and outside `value`; an evaluation here is "
+                        f"{c['md_steps_per_eval']:.0f} MD steps of 0.25 fs on 1 620 atoms (the OPLS line's: 110 steps of 2 fs on 10 368 atoms): compare replica_steps_per_s, not evals_per_s"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

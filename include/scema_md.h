@@ -349,6 +349,12 @@ typedef struct {
 } scema_md_profile;
 int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset);
 
+/* The library reads its environment through ONE table of declared switches (scema_amd/csrc/md_env.h, engine/engine_core.cpp:
+ * performance A/B switches with measured defaults, test hooks, diagnostics; the reference has no counterpart -- its knobs are the
+ * LAMMPS scripts).  This returns the declared switches that are set in the calling process's environment as "NAME=value" lines,
+ * and their number: a reported run shows an empty list (bench.py: config.env_overrides). */
+int scema_md_env_overrides(char *buf, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_build", "libmd_oracle.so")
+_SAN = os.environ.get("SCEMA_SANITIZE") == "1"   # tools/run_asan.sh: the AddressSanitizer + UBSan build
+_LIB = os.path.join(_HERE, "_build_asan" if _SAN else "_build", "libmd_oracle.so")
 
 NPART = 8
 PARTS = ["lj", "coul", "bond", "angle", "dihedral", "improper", "kspace", "shake"]
@@ -28,7 +29,7 @@ class OmdParams(C.Structure):
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("md_oracle.c", "md_oracle.h", "host_oracle.c", "host_oracle.h")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _SAN else []))
     return _LIB
 
 

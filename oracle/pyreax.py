@@ -11,14 +11,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_build", "libreax_oracle.so")
+_SAN = os.environ.get("SCEMA_SANITIZE") == "1"   # tools/run_asan.sh: the AddressSanitizer + UBSan build
+_LIB = os.path.join(_HERE, "_build_asan" if _SAN else "_build", "libreax_oracle.so")
 PARTS = ["bond", "lp", "over", "under", "angle", "pen", "coa", "tors", "conj", "hb", "vdw", "coul", "pol"]
 
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("reax_oracle.c", "reax_oracle.h")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _SAN else []))
     return _LIB
 
 

@@ -64,6 +64,8 @@ struct rxo_ff {
 };
 
 /* ------------------------------------------------------------------ force-field file */
+/* a count or a 1-based index read as a double: a damaged file may hold NaN, 1e300 or -7 there, and (int) of those is undefined */
+static int as_int(double d) { return (d == d && d > -1.0e9 && d < 1.0e9) ? (int)d : -1000000; }
 static int next_vals(FILE *fp, double *v, int maxv, char *first_word) {
   char line[1024];
   if (!fgets(line, sizeof line, fp)) return -1;
@@ -91,12 +93,12 @@ rxo_ff *rxo_read_ffield(const char *path) {
   double v[16];
   int ok = fgets(line, sizeof line, fp) != NULL;             /* header comment */
   ok = ok && next_vals(fp, v, 16, NULL) >= 1;
-  ff->ngp = ok ? (int)v[0] : 0;
+  ff->ngp = ok ? as_int(v[0]) : 0;
   for (int k = 0; ok && k < ff->ngp; k++) { ok = next_vals(fp, v, 16, NULL) >= 1; if (k < 64) ff->gp[k] = v[0]; }
   /* atoms: count line + three header lines, four lines per atom */
   ok = ok && next_vals(fp, v, 16, NULL) >= 1;
-  ff->nt = ok ? (int)v[0] : 0;
-  if (ff->nt > RX_MAXT) ok = 0;
+  ff->nt = ok ? as_int(v[0]) : 0;
+  if (ff->nt > RX_MAXT || ff->nt < 0) { ok = 0; ff->nt = 0; }   /* (nt sizes the loops below: found by tests/test_corrupt_files.py under UBSan) */
   for (int k = 0; ok && k < 3; k++) ok = fgets(line, sizeof line, fp) != NULL;
   for (int i = 0; ok && i < ff->nt; i++) {
     sbp_t *s = &ff->sbp[i];
@@ -108,7 +110,7 @@ rxo_ff *rxo_read_ffield(const char *path) {
     s->nlp_opt = 0.5 * (s->valency_e - s->valency);
     ok = next_vals(fp, v, 16, NULL) >= 8;
     if (!ok) break;
-    s->alpha = v[0]; s->gamma_w = v[1]; s->valency_boc = v[2]; s->p_ovun5 = v[3]; s->chi = v[5]; s->eta = 2.0 * v[6]; s->p_hbond = (int)v[7];
+    s->alpha = v[0]; s->gamma_w = v[1]; s->valency_boc = v[2]; s->p_ovun5 = v[3]; s->chi = v[5]; s->eta = 2.0 * v[6]; s->p_hbond = as_int(v[7]);
     ok = next_vals(fp, v, 16, NULL) >= 8;
     if (!ok) break;
     s->r_pi_pi = v[0]; s->p_lp2 = v[1]; s->b_o_131 = v[3]; s->b_o_132 = v[4]; s->b_o_133 = v[5];
@@ -129,12 +131,12 @@ rxo_ff *rxo_read_ffield(const char *path) {
     }
   /* bonds: count line + one header line, two lines per bond */
   ok = ok && next_vals(fp, v, 16, NULL) >= 1;
-  int nb = ok ? (int)v[0] : 0;
+  int nb = ok ? as_int(v[0]) : 0;
   ok = ok && fgets(line, sizeof line, fp) != NULL;
   for (int m = 0; ok && m < nb; m++) {
     ok = next_vals(fp, v, 16, NULL) >= 10;
     if (!ok) break;
-    const int j = (int)v[0] - 1, k = (int)v[1] - 1;
+    const int j = as_int(v[0]) - 1, k = as_int(v[1]) - 1;
     double u[16];
     ok = next_vals(fp, u, 16, NULL) >= 8;
     if (!ok) break;
@@ -147,11 +149,11 @@ rxo_ff *rxo_read_ffield(const char *path) {
   }
   /* off-diagonal terms */
   ok = ok && next_vals(fp, v, 16, NULL) >= 1;
-  int no = ok ? (int)v[0] : 0;
+  int no = ok ? as_int(v[0]) : 0;
   for (int m = 0; ok && m < no; m++) {
     ok = next_vals(fp, v, 16, NULL) >= 8;
     if (!ok) break;
-    const int j = (int)v[0] - 1, k = (int)v[1] - 1;
+    const int j = as_int(v[0]) - 1, k = as_int(v[1]) - 1;
     if (j < 0 || k < 0 || j >= ff->nt || k >= ff->nt) continue;
     for (int s = 0; s < 2; s++) {
       tbp_t *t = s ? &ff->tbp[k][j] : &ff->tbp[j][k];
@@ -165,11 +167,11 @@ rxo_ff *rxo_read_ffield(const char *path) {
   }
   /* valence angles */
   ok = ok && next_vals(fp, v, 16, NULL) >= 1;
-  int na = ok ? (int)v[0] : 0;
+  int na = ok ? as_int(v[0]) : 0;
   for (int m = 0; ok && m < na; m++) {
     ok = next_vals(fp, v, 16, NULL) >= 10;
     if (!ok) break;
-    const int j = (int)v[0] - 1, k = (int)v[1] - 1, l = (int)v[2] - 1;
+    const int j = as_int(v[0]) - 1, k = as_int(v[1]) - 1, l = as_int(v[2]) - 1;
     if (j < 0 || k < 0 || l < 0 || j >= ff->nt || k >= ff->nt || l >= ff->nt) continue;
     thbp_t *t1 = &ff->thbp[j][k][l], *t2 = &ff->thbp[l][k][j];
     if (t1->cnt >= RX_MAXANG) continue;
@@ -180,11 +182,11 @@ rxo_ff *rxo_read_ffield(const char *path) {
   }
   /* torsions: specific quadruples win over the 0-j-k-0 wildcards, whatever their order in the file */
   ok = ok && next_vals(fp, v, 16, NULL) >= 1;
-  int ntor = ok ? (int)v[0] : 0;
+  int ntor = ok ? as_int(v[0]) : 0;
   for (int m = 0; ok && m < ntor; m++) {
     ok = next_vals(fp, v, 16, NULL) >= 9;
     if (!ok) break;
-    const int j = (int)v[0] - 1, k = (int)v[1] - 1, l = (int)v[2] - 1, n = (int)v[3] - 1;
+    const int j = as_int(v[0]) - 1, k = as_int(v[1]) - 1, l = as_int(v[2]) - 1, n = as_int(v[3]) - 1;
     if (k < 0 || l < 0 || k >= ff->nt || l >= ff->nt) continue;
     if (j >= 0 && n >= 0) {
       if (j >= ff->nt || n >= ff->nt) continue;
@@ -204,10 +206,10 @@ rxo_ff *rxo_read_ffield(const char *path) {
   }
   /* hydrogen bonds (donor, hydrogen, acceptor) */
   ok = ok && next_vals(fp, v, 16, NULL) >= 1;
-  int nh = ok ? (int)v[0] : 0;
+  int nh = ok ? as_int(v[0]) : 0;
   for (int m = 0; ok && m < nh; m++) {
     if (next_vals(fp, v, 16, NULL) < 7) break;
-    const int j = (int)v[0] - 1, k = (int)v[1] - 1, l = (int)v[2] - 1;
+    const int j = as_int(v[0]) - 1, k = as_int(v[1]) - 1, l = as_int(v[2]) - 1;
     if (j < 0 || k < 0 || l < 0 || j >= ff->nt || k >= ff->nt || l >= ff->nt) continue;
     hbp_t *h = &ff->hbp[j][k][l];
     h->r0_hb = v[3]; h->p_hb1 = v[4]; h->p_hb2 = v[5]; h->p_hb3 = v[6];

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscema_md.so")
+# tools/run_asan.sh (CPU tests only): the build whose host layer is compiled with AddressSanitizer + UBSan
+LIB_PATH = os.path.join(_HERE, "libscema_md_asan.so" if os.environ.get("SCEMA_SANITIZE") == "1" else "libscema_md.so")
 
 NPART = 8
 PARTS = ["lj", "coul", "bond", "angle", "dihedral", "improper", "kspace", "shake"]
@@ -28,7 +29,7 @@ SYMBOLS = [
     "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
     "scema_md_local_stress_count", "scema_md_local_result_doubles", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
     "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file", "scema_md_save_state_lammps",
-    "scema_md_init_material", "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile",
+    "scema_md_init_material", "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile", "scema_md_env_overrides",
     "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_comm_handshakes", "scema_md_state_owner", "scema_md_last_plan",
     "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update",
@@ -462,6 +463,14 @@ class Engine:
         p = Profile()
         self._chk(lib().scema_md_get_profile(self.h, C.byref(p), C.c_int32(1 if reset else 0)))
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+def env_overrides() -> list:
+    """the library's declared environment switches that are set in this process ("NAME=value"); empty in a clean run"""
+    buf = C.create_string_buffer(4096)
+    lib().scema_md_env_overrides.restype = C.c_int
+    n = lib().scema_md_env_overrides(buf, C.c_int(len(buf)))
+    return [l for l in buf.value.decode().split("\n") if l] if n else []
 
 
 def make_sim(qp_id: int, matid: str, replica: int, strain_len, *, most_recent: int | None = None, material: int = 0,

@@ -266,7 +266,6 @@ struct scema_md_engine {
   double neigh_grow = 1.0;   // headroom factor of the cluster rows, x1.5 per overflow
   double jtab_grow = 1.0;    // headroom factor of the tile j tables, x1.25 per overflow (-> smaller cells)
   int overflow_bits = 0;     // what overflowed in the last run: 4 = a tile's j table, 8 = a cluster row
-  bool use_graphs = false;  // hipGraph replay of the MD step loop: opt-in (SCEMA_MD_GRAPH=1), measured slower on ROCm 7.2
   // ReaxFF path (force_field "reax"): the force-field tables, settings of fix qeq/reax, list skin
   bool rx_ready = false, reax_active = false;
   int rx_stamp = 0;                    // bumped by every scema_md_reax_configure

@@ -14,6 +14,7 @@
 //   Hooke fallback ................... stmd_problem.h:386-392,479-483
 //   force-field check ................ stmd_problem.h:462-467
 #include "engine.h"
+#include "../md_env.h"
 
 namespace scema_eng {
 
@@ -92,7 +93,7 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
       B.use_shake = opt.shake_b;
       for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nss;
       rc = run_phase(e, chunk, B);
-      if (getenv("SCEMA_MD_TIMING")) fprintf(stderr, "[scema_md] chunk of %d: phase A %.1f ms, phase B %.1f ms (attempt %d)\n", ns, 1e3 * (t_a1 - t_a0), 1e3 * (wall_s() - t_a1), attempt);
+      if (scema_env("SCEMA_MD_TIMING")) fprintf(stderr, "[scema_md] chunk of %d: phase A %.1f ms, phase B %.1f ms (attempt %d)\n", ns, 1e3 * (t_a1 - t_a0), 1e3 * (wall_s() - t_a1), attempt);
     }
     if (rc == SCEMA_MD_OK) {
       for (int i = 0; i < ns; i++) {

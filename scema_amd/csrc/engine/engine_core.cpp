@@ -1,5 +1,6 @@
 // engine_core.cpp -- the engine object: creation, destruction, replica registration, counters
 #include "engine.h"
+#include "../md_env.h"
 
 namespace scema_eng {
 
@@ -18,7 +19,51 @@ std::string state_key(int qp, const char *matid, int replica) { return std::to_s
 
 }  // namespace scema_eng
 
+// ---- the environment switches of the library (md_env.h): name, what it does ----
+namespace {
+struct EnvSwitch { const char *name, *what; };
+const EnvSwitch k_env[] = {
+    // performance switches with a measured default; a reported run sets none of them
+    {"SCEMA_MD_SPLIT", "0: never run a launch group of 32-199 simulations as two half batches on two streams"},
+    {"SCEMA_MD_ONE_STREAM", "no side stream (bonded / k-space chain beside the pair kernel)"},
+    {"SCEMA_MD_SKIN_EXTRA", "list skin = params.skin + this many Angstrom (results do not depend on it)"},
+    {"SCEMA_MD_SKIN_ADAPT", "1: per-state adaptation of the extra skin from the rebuild interval (round-1 behaviour)"},
+    {"SCEMA_MD_PPPM_FFT", "hipFFT for every PPPM grid (default: grids of up to 2 900 points are solved in LDS)"},
+    {"SCEMA_MD_FUSED_TAIL", "0 / 1: force assembly + SHAKE + second kick as three kernels / as k_finish (default: by batch size)"},
+    {"SCEMA_MD_CELL_BUILD", "0: cell binning as k_bin + k_cell_scan + k_cell_fill instead of the one-launch k_cell_build"},
+    {"SCEMA_MD_POLY_TOL", "fit target of the real-space Ewald polynomial (default 2e-13); parity tolerances assume the default"},
+    {"SCEMA_REAX_DROP_DSBO2", "ReaxFF valence-angle gradient without the dSBO2 term, as USER-REAXC is believed to compute it"},
+    {"SCEMA_REAX_SKIN", "ReaxFF list skin in Angstrom"},
+    {"SCEMA_REAX_QEQ_LAUNCH", "conjugate-gradient iterations issued as launches per charge solve (default: adaptive)"},
+    // test hooks: force rarely-taken paths
+    {"SCEMA_MD_NEIGH_GROW0", "start with undersized neighbour capacities: overflow -> restore -> regrow"},
+    {"SCEMA_MD_QCAP16", "capacity of k_neigh_build's group lists in sixteenths of the table: small values force the whole-table walk"},
+    {"SCEMA_MD_RX_COL32", "32-bit column indices in the ReaxFF charge matrix whatever the replica size"},
+    {"SCEMA_MD_RX_NB_ONCE", "0: the both-ends ReaxFF non-bonded kernel"},
+    // diagnostics: print, never change a result
+    {"SCEMA_MD_TIMING", "per-chunk wall times and the PAIR_TIMING / PAIR_COUNT counters on stderr"},
+};
+}  // namespace
+
+const char *scema_env(const char *name) {
+  for (const EnvSwitch &s : k_env)
+    if (strcmp(s.name, name) == 0) return getenv(name);
+  fprintf(stderr, "[scema_md] environment switch %s is not declared in engine_core.cpp\n", name);
+  abort();
+}
+
 extern "C" {
+
+/* the declared switches that are set in this process's environment, as "NAME=value" separated by newlines; returns the
+ * number of switches set (the text is truncated to cap - 1 characters) */
+int scema_md_env_overrides(char *buf, int cap) {
+  std::string out;
+  int n = 0;
+  for (const EnvSwitch &s : k_env)
+    if (const char *v = getenv(s.name)) { out += (n ? "\n" : ""); out += s.name; out += "="; out += v; n++; }
+  if (buf && cap > 0) { strncpy(buf, out.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+  return n;
+}
 
 void scema_md_default_params(scema_md_params *p) {
   p->cut_lj = 12.0;
@@ -51,21 +96,19 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     delete e;
     return SCEMA_MD_ERR_DEVICE;
   }
-  if (getenv("SCEMA_MD_GRAPH")) e->use_graphs = true;
-  if (const char *sp = getenv("SCEMA_MD_SPLIT")) e->split_streams = atoi(sp) != 0;
-  if (const char *sp = getenv("SCEMA_MD_SPLIT_MIN")) e->split_min = std::max(2, atoi(sp));
+  if (const char *sp = scema_env("SCEMA_MD_SPLIT")) e->split_streams = atoi(sp) != 0;
   if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess)
     e->stream3 = nullptr;   // an optimisation only
-  if (const char *sx = getenv("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(-0.75 * e->p.skin, atof(sx));
-  if (const char *sx = getenv("SCEMA_MD_SKIN_ADAPT")) e->skin_adapt = atoi(sx) != 0;
-  if (!getenv("SCEMA_MD_ONE_STREAM")) {
+  if (const char *sx = scema_env("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(-0.75 * e->p.skin, atof(sx));
+  if (const char *sx = scema_env("SCEMA_MD_SKIN_ADAPT")) e->skin_adapt = atoi(sx) != 0;
+  if (!scema_env("SCEMA_MD_ONE_STREAM")) {
     if (hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)
       e->stream2 = nullptr;   // side stream is an optimisation only
   }
   // test hook: start with undersized neighbour capacities, so that the overflow -> restore -> regrow path runs
-  if (const char *g0 = getenv("SCEMA_MD_NEIGH_GROW0")) e->neigh_grow = e->jtab_grow = std::max(0.05, atof(g0));
+  if (const char *g0 = scema_env("SCEMA_MD_NEIGH_GROW0")) e->neigh_grow = e->jtab_grow = std::max(0.05, atof(g0));
   *out = e;
   return SCEMA_MD_OK;
 }

@@ -1,5 +1,6 @@
 // engine_kspace.cpp -- what a LAMMPS `run` sets up on the host: g_ewald and the k-vector set, the PPPM grid, the polynomial of the real-space factor, fix deform's box path
 #include "engine.h"
+#include "../md_env.h"
 
 namespace scema_eng {
 
@@ -200,7 +201,7 @@ static double fit_coul_poly(double g, double rc, double *poly, int *npoly, doubl
   *uscale = (double)(2.0L / umax);
   double err = 0.0, target = 2e-13;
   // measurement knob: what the precision of this factor costs (LAMMPS' own table is good to ~1e-6); parity tests run at the default
-  if (const char *tv = getenv("SCEMA_MD_POLY_TOL")) target = std::min(1e-3, std::max(1e-15, atof(tv)));
+  if (const char *tv = scema_env("SCEMA_MD_POLY_TOL")) target = std::min(1e-3, std::max(1e-15, atof(tv)));
   for (int N = 6; N <= MD_MAXPOLY; N++) {   // k_pair<.., 16> and beyond spill registers: an odd count that suffices is worth having
     err = fit_coul_poly_n(umax, N, poly);
     *npoly = N;

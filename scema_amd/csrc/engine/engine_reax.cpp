@@ -1,5 +1,6 @@
 // engine_reax.cpp -- host side of the ReaxFF path (force_field "reax"): run_phase_reax and the ReaxFF entry points of the C ABI
 #include "engine.h"
+#include "../md_env.h"
 
 namespace scema_eng {
 
@@ -88,7 +89,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   std::vector<std::vector<FlipEvent>> flips(ns);
   int maxatoms = 0, maxpad = 0, maxsteps = 0;
   // columns of the charge-equilibration matrix as 16-bit atom indices when every replica of the batch has at most 65 536 atoms
-  bool col16 = !(getenv("SCEMA_MD_RX_COL32") && atoi(getenv("SCEMA_MD_RX_COL32")) != 0);   // (test switch: 32-bit columns for any size)
+  bool col16 = !(scema_env("SCEMA_MD_RX_COL32") && atoi(scema_env("SCEMA_MD_RX_COL32")) != 0);   // (test switch: 32-bit columns for any size)
   for (int i = 0; i < ns; i++) col16 = col16 && sims[i].st->topo->natoms <= 65536;
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
@@ -351,13 +352,13 @@ int scema_md_reax_configure(scema_md_engine *e, const char *ffield_path, const c
   RxParams P;
   std::vector<int> map;
   if (!scema::read_reax_ffield(ffield_path, el, P, map, err)) return fail(e, SCEMA_MD_ERR_IO, "%s", err.c_str());
-  if (const char *x = getenv("SCEMA_REAX_DROP_DSBO2")) P.lammps_dsbo2 = atoi(x) ? 1 : 0;
+  if (const char *x = scema_env("SCEMA_REAX_DROP_DSBO2")) P.lammps_dsbo2 = atoi(x) ? 1 : 0;
   e->rx_host = P;
   e->rx_type_map = map;
   if (qeq_tol > 0.0) e->rx_qeq_tol = qeq_tol;
   if (skin >= 0.0) e->rx_skin = skin;
-  if (const char *x = getenv("SCEMA_REAX_SKIN")) e->rx_skin = atof(x);
-  if (const char *x = getenv("SCEMA_REAX_QEQ_LAUNCH")) { e->rx_qeq_launch = e->rx_qeq_launch_cold = std::max(0, atoi(x)); e->rx_qeq_launch_pinned = true; }
+  if (const char *x = scema_env("SCEMA_REAX_SKIN")) e->rx_skin = atof(x);
+  if (const char *x = scema_env("SCEMA_REAX_QEQ_LAUNCH")) { e->rx_qeq_launch = e->rx_qeq_launch_cold = std::max(0, atoi(x)); e->rx_qeq_launch_pinned = true; }
   HIPCHK(e->d_rxparams.ensure(sizeof(RxParams)));
   HIPCHK(hipMemcpyAsync(e->d_rxparams.p, &e->rx_host, sizeof(RxParams), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -1,5 +1,6 @@
 // engine_run.cpp -- one "run" of a batch with the OPLS force stage: slots, launch sequence of the MD steps, what comes back
 #include "engine.h"
+#include "../md_env.h"
 
 namespace scema_eng {
 
@@ -271,8 +272,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     };
     // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
     // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
-    static const int small_max = getenv("SCEMA_MD_SMALL_CELLS_MAX") ? atoi(getenv("SCEMA_MD_SMALL_CELLS_MAX")) : 8;   // replicas up to which the most-cells grid is taken
-    const bool small_batch = ns <= small_max && !getenv("SCEMA_MD_BIG_CELLS");
+    const bool small_batch = ns <= 8;   // replicas up to which the most-cells grid is taken (scanned in round 2: tools/small_batch_scan.sh)
     for (int pass = 0; pass < 2 && !fits; pass++) {
       int lo[3], hi[3];
       for (int d = 0; d < 3; d++) {
@@ -323,7 +323,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     {
       // H depends on u only: fit once per (rounded-up) range and share it between simulations
       const double perr = cached_coul_poly(e, ew.g, P.cut_coul, S.coul_poly, &S.coul_npoly, &S.coul_uscale);
-      if (perr > 1e-12 && !getenv("SCEMA_MD_POLY_TOL")) return fail(e, SCEMA_MD_ERR_ARG, "real-space Ewald polynomial fit error %.3e too large (g*rc = %.3f)", perr, ew.g * P.cut_coul);
+      if (perr > 1e-12 && !scema_env("SCEMA_MD_POLY_TOL")) return fail(e, SCEMA_MD_ERR_ARG, "real-space Ewald polynomial fit error %.3e too large (g*rc = %.3f)", perr, ew.g * P.cut_coul);
       for (int m = 0; m < MD_MAXPOLY; m++) S.coul_poly_g[m] = S.coul_poly[m] * ew.g;
     }
     {
@@ -332,7 +332,6 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       S.seg_b2 = (P.cut_lj + m) * (P.cut_lj + m);
       // skin pairs listed beyond cutmax + far_band sit at the back of the rows and are skipped until an atom has moved far_band/2
       double frac = 0.65;   // scan 0.25 .. 0.85 on PE-10k (rebuild every ~33 steps, the largest displacement passes 0.5 A after ~8): optimum 0.65-0.75
-      if (const char *fv = getenv("SCEMA_MD_FAR_FRAC")) frac = atof(fv);
       S.far_band = frac * skin_i;
       const double cm = std::max(P.cut_coul, P.cut_lj) + S.far_band;
       S.seg_c2 = cm * cm;
@@ -453,7 +452,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       else pppm_runs.push_back({pos, 1});
     }
   }
-  const bool pppm_in_lds = maxgrid > 0 && maxgrid <= mdk_pppm_solve_max() && (3 * (size_t)maxgrid + (size_t)maxdims) * 16 <= 150 * 1024 && !getenv("SCEMA_MD_PPPM_FFT");
+  const bool pppm_in_lds = maxgrid > 0 && maxgrid <= mdk_pppm_solve_max() && (3 * (size_t)maxgrid + (size_t)maxdims) * 16 <= 150 * 1024 && !scema_env("SCEMA_MD_PPPM_FFT");
   // Batched 3-d Z2Z plans over grids that lie maxgrid complex elements apart (the charge grids of neighbouring simulations, and
   // all their field grids: three per simulation, simulation-major).  A plan owns work space, so each stream has its own.
   auto pppm_plan = [&](const int pg[3], int batch, hipStream_t st, hipfftHandle &plan) -> int {
@@ -486,7 +485,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       return SCEMA_MD_OK;
     }
     auto transform = [&](bool fields, int dir) -> int {   // the charge grids forward, or the three field grids of every simulation back
-      static const bool serial_fft = getenv("SCEMA_MD_PPPM_SERIAL") != nullptr;   // debugging: one transform per simulation and grid
+      const bool serial_fft = false;
       for (const auto &run : pppm_runs) {
         if (run.first + run.second <= pos0 || run.first >= pos0 + na) continue;   // outside this launch group, or none of it is active any more
         const SimDev &S0 = e->h_sims[run.first];
@@ -517,7 +516,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // with the chain on the side stream / inline: 8 replicas 210 / 183, 72: 336 / 333, 576: 369 / 368; a single replica 39.7 / 41.6
   // (its k_pair does not fill the chip and the fork/join is pure latency).  So: batches of 4 to 255 replicas; a batch that
   // fills the chip many times over gains nothing, and inline its k_pair launches are timed and profiled undisturbed.
-  const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= 4 && ns < 256 && !getenv("SCEMA_MD_PPPM_INLINE");
+  const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= 4 && ns < 256;
   auto pppm_fork = [&](hipStream_t st, int pos0, int na, bool new_box) -> int {
     if (!pppm_side) return SCEMA_MD_OK;
     HIPCHK(hipEventRecord(e->ev_fork, st));
@@ -616,7 +615,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // virial): one pass (k_finish) instead of k_ewald_force + k_shake + k_final_integrate -- two launches less for a small batch
   // (a single replica: 14.2 against 17.4 us); a thread per SHAKE cluster gathers less well than the three kernels stream, so large
   // batches keep them (576 replicas: 452 against 426 us).  SCEMA_MD_FUSED_TAIL = 0 / 1 forces either.
-  static const int fused_tail_env = getenv("SCEMA_MD_FUSED_TAIL") ? atoi(getenv("SCEMA_MD_FUSED_TAIL")) : -1;
+  static const int fused_tail_env = scema_env("SCEMA_MD_FUSED_TAIL") ? atoi(scema_env("SCEMA_MD_FUSED_TAIL")) : -1;
   const bool fused_tail = (fused_tail_env < 0 ? ns <= 32 : fused_tail_env != 0) && !spec.nh && maxk == 0 && !spec.ev_always;
   auto launch_step = [&](int h, int na, bool timed) -> int {
     hipStream_t st = hs[h];
@@ -664,13 +663,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     while (na < hcnt[h] && e->h_sims[hbeg[h] + na].nsteps >= step) na++;
     return na;
   };
-  // The step loop is launch-bound for small batches (about 20 kernels of a few microseconds each per step of a
-  // single replica): the steps that share an active count can be captured once into a hipGraph and replayed.
-  // Measured on ROCm 7.2 / MI355X (tools/graph_cmp.py, ms per update of 1 / 72 PE-10k replicas): plain launches
-  // 25.8 / 236.7 on one stream, 28.3 / 232.2 with the side stream; graph replay 26.4 / 236.9 on one stream and
-  // 55.2 / 251.3 with the side stream inside the graph -- no gain, so replay is opt-in (SCEMA_MD_GRAPH=1).  Not
-  // with per-launch event timing (profile mode), which needs the individual launches.
-  const bool use_graph = !prof && e->use_graphs && nhalf == 1 && maxgrid == 0;
+  // (hipGraph replay of the steps that share an active count was measured on ROCm 7.2 / MI355X -- ms per update of 1 / 72 PE-10k
+  // replicas: plain launches 25.8 / 236.7, replay 26.4 / 236.9, with the side stream inside the graph 55.2 / 251.3 -- and removed in
+  // round 4: profiles/HISTORY.md)
   // box flips (fix deform, flip yes): step -> positions that flip after it
   std::map<int, std::vector<std::pair<int, int>>> flip_at;
   for (int pos = 0; pos < ns; pos++)
@@ -694,34 +689,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       auto nxt = flip_at.lower_bound(step);
       if (nxt != flip_at.end()) run_len = std::min(run_len, nxt->first - step + 1);   // the launch group ends with the flipping step
     }
-    bool replayed = false;
-    if (use_graph && run_len >= 4) {
-      hipStream_t st = hs[0];
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t gexec = nullptr;
-      bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      if (ok) {
-        const int rc_l = launch_step(0, na, false);
-        ok = (hipStreamEndCapture(st, &graph) == hipSuccess) && rc_l == SCEMA_MD_OK && graph != nullptr;
-      }
-      if (ok) ok = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
-      if (ok) {
-        for (int r = 0; r < run_len && ok; r++) ok = hipGraphLaunch(gexec, st) == hipSuccess;
-        if (!ok) return fail(e, SCEMA_MD_ERR_DEVICE, "hipGraphLaunch failed");
-        replayed = true;
-      } else {
-        (void)hipGetLastError();
-        e->use_graphs = false;   // capture is not available here: plain launches from now on
-      }
-      if (gexec) (void)hipGraphExecDestroy(gexec);
-      if (graph) (void)hipGraphDestroy(graph);
+    for (int r = 0; r < run_len; r++) {
+      int rc_l = launch_step(0, na, prof);
+      if (rc_l) return rc_l;
+      if (nb > 0 && (rc_l = launch_step(1, nb, prof))) return rc_l;
     }
-    if (!replayed)
-      for (int r = 0; r < run_len; r++) {
-        int rc_l = launch_step(0, na, prof);
-        if (rc_l) return rc_l;
-        if (nb > 0 && (rc_l = launch_step(1, nb, prof))) return rc_l;
-      }
     e->prof.md_steps += (long long)(na + nb) * run_len;
     step += run_len;
     // flips detected at the end of step - 1: between the two steps the box takes its flipped tilts, the list rebuild of
@@ -797,7 +769,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       for (int pos = launch_sims[l].first; pos < launch_sims[l].first + launch_sims[l].second; pos++) e->prof.pair_alg_bytes += simbytes[pos];
     }
   }
-  if (getenv("SCEMA_MD_TIMING") && ns > 0) {
+  if (scema_env("SCEMA_MD_TIMING") && ns > 0) {
     const SimScalars &c = e->h_sc[0];
     const SimDev &S0 = e->h_sims[0];
     fprintf(stderr, "[scema_md] sim 0: cells %dx%dx%d, j table max %d of %d, row max %d of %d, row entries/cluster %.1f, listed pairs/atom %.1f, builds %d\n",

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -88,6 +89,15 @@ static int parse_lammps_data(const char *path, const double special_lj[3], const
     else if (w.size() >= 6 && w[3] == "xy" && w[4] == "xz" && w[5] == "yz") { box[6] = atof(w[0].c_str()); box[7] = atof(w[1].c_str()); box[8] = atof(w[2].c_str()); }
   }
   if (natoms <= 0 || ntypes <= 0) return SCEMA_MD_ERR_IO;
+  // Every counted item is a line of the file: a count beyond the number of lines (or a negative one) is a damaged header, and it must
+  // be refused BEFORE it sizes an allocation (a header that says 999 999 999 atoms used to end in std::bad_alloc -> terminate; found
+  // by tests/test_corrupt_files.py).  Atom ids index a 32-bit table downstream.
+  {
+    const long nl = (long)lines.size();
+    const long counts[] = {natoms, nbonds, nangles, ndih, nimp, ntypes, nbt, nat, ndt, nit};
+    for (long c : counts)
+      if (c < 0 || c > nl) return SCEMA_MD_ERR_IO;
+  }
   std::vector<double> mass(ntypes, 0.0), eps1(ntypes, 0.0), sig1(ntypes, 0.0), eps((size_t)ntypes * ntypes, -1.0), sig((size_t)ntypes * ntypes, 0.0);
   std::vector<double> bc(2 * (size_t)nbt), ac(2 * (size_t)nat), dc(4 * (size_t)ndt), ic(2 * (size_t)nit);
   std::vector<int32_t> type(natoms), bat(2 * (size_t)nbonds), btp(nbonds), aat(3 * (size_t)nangles), atp(nangles), dat(4 * (size_t)ndih), dtp(ndih),
@@ -231,12 +241,20 @@ extern "C" {
 int scema_md_load_lammps_data(scema_md_engine *e, const char *matid, int32_t replica, const char *path, const double special_lj[3],
                               const double special_coul[3]) {
   if (!e || !matid) return SCEMA_MD_ERR_ARG;
-  return parse_lammps_data(path, special_lj, special_coul, [&](const scema_md_system &s) { return scema_md_register_replica(e, matid, replica, &s); });
+  try {
+    return parse_lammps_data(path, special_lj, special_coul, [&](const scema_md_system &s) { return scema_md_register_replica(e, matid, replica, &s); });
+  } catch (const std::exception &) {   // (allocation failure on a damaged file: an error code, never an exception across the C ABI)
+    return SCEMA_MD_ERR_IO;
+  }
 }
 
 int scema_md_convert_lammps_data(const char *data_path, const char *replica_path, const double special_lj[3], const double special_coul[3]) {
   if (!replica_path) return SCEMA_MD_ERR_ARG;
-  return parse_lammps_data(data_path, special_lj, special_coul, [&](const scema_md_system &s) { return scema_md_write_replica_file(replica_path, &s); });
+  try {
+    return parse_lammps_data(data_path, special_lj, special_coul, [&](const scema_md_system &s) { return scema_md_write_replica_file(replica_path, &s); });
+  } catch (const std::exception &) {
+    return SCEMA_MD_ERR_IO;
+  }
 }
 
 }  // extern "C"

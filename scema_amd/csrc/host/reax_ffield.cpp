@@ -50,17 +50,26 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
     if (l.v.size() < need) { err = path + ": line " + std::to_string(at) + " has too few numbers"; return false; }
     return true;
   };
+  // a count read as a double: it must be a whole number of lines that the file still has (a damaged file may hold NaN, 1e300 or -7
+  // there; (int) of those is undefined, and the atom count sizes an allocation)
+  auto count = [&](double d, int &out) -> bool {
+    if (!(d >= 0.0) || d > (double)lines.size()) { err = path + ": line " + std::to_string(at) + " holds a count that the file cannot contain"; return false; }
+    out = (int)d;
+    return true;
+  };
   Line l;
   std::memset(&P, 0, sizeof(P));
   P.lammps_dsbo2 = 0;
   if (!next(l, 1)) return false;
-  const int ngp = (int)l.v[0];
+  int ngp = 0;
+  if (!count(l.v[0], ngp)) return false;
   for (int k = 0; k < ngp; k++) {
     if (!next(l, 1)) return false;
     if (k < RX_NGP) P.gp[k] = l.v[0];
   }
   if (!next(l, 1)) return false;
-  const int nat = (int)l.v[0];
+  int nat = 0;
+  if (!count(l.v[0], nat)) return false;
   at += 3;   // the rest of the atom block's header
   std::vector<AtomRec> atoms(nat);
   for (int i = 0; i < nat; i++) {
@@ -96,7 +105,7 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
     RxSbp &s = P.sbp[c];
     s.r_s = r.a[0]; s.valency = r.a[1]; s.mass = r.a[2]; s.r_vdw = r.a[3]; s.epsilon = r.a[4]; s.gamma = r.a[5]; s.r_pi = r.a[6]; s.valency_e = r.a[7];
     s.nlp_opt = 0.5 * (s.valency_e - s.valency);
-    s.alpha = r.b[0]; s.gamma_w = r.b[1]; s.valency_boc = r.b[2]; s.p_ovun5 = r.b[3]; s.chi = r.b[5]; s.eta = 2.0 * r.b[6]; s.p_hbond = (int)r.b[7];
+    s.alpha = r.b[0]; s.gamma_w = r.b[1]; s.valency_boc = r.b[2]; s.p_ovun5 = r.b[3]; s.chi = r.b[5]; s.eta = 2.0 * r.b[6]; s.p_hbond = (r.b[7] >= 0.0 && r.b[7] < 100.0) ? (int)r.b[7] : 0;
     s.r_pi_pi = r.c[0]; s.p_lp2 = r.c[1]; s.b_o_131 = r.c[3]; s.b_o_132 = r.c[4]; s.b_o_133 = r.c[5];
     s.p_ovun2 = r.d[0]; s.p_val3 = r.d[1]; s.valency_val = r.d[3]; s.p_val5 = r.d[4];
     if (r.d[5] > 0.0 || r.d[6] > 0.0) { err = "inner-wall van der Waals parameters (rcore, ecore) are not supported"; return false; }
@@ -113,10 +122,11 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
       t.D = std::sqrt(x.epsilon * y.epsilon); t.alpha = std::sqrt(x.alpha * y.alpha); t.r_vdW = 2.0 * std::sqrt(x.r_vdw * y.r_vdw);
       t.gamma_w = std::sqrt(x.gamma_w * y.gamma_w); t.gamma = std::pow(x.gamma * y.gamma, -1.5);
     }
-  auto C = [&](double v) -> int { const int f = (int)v - 1; return (f >= 0 && f < nat) ? compact[f] : -1; };
+  auto C = [&](double v) -> int { if (!(v >= 1.0) || v > (double)nat) return -1; return compact[(int)v - 1]; };
   // bonds
   if (!next(l, 1)) return false;
-  const int nbond = (int)l.v[0];
+  int nbond = 0;
+  if (!count(l.v[0], nbond)) return false;
   at += 1;
   for (int m = 0; m < nbond; m++) {
     Line l1, l2;
@@ -131,7 +141,8 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
   }
   // off-diagonal
   if (!next(l, 1)) return false;
-  const int noff = (int)l.v[0];
+  int noff = 0;
+  if (!count(l.v[0], noff)) return false;
   for (int m = 0; m < noff; m++) {
     if (!next(l, 8)) return false;
     const int a = C(l.v[0]), b = C(l.v[1]);
@@ -148,7 +159,8 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
   }
   // valence angles
   if (!next(l, 1)) return false;
-  const int nang = (int)l.v[0];
+  int nang = 0;
+  if (!count(l.v[0], nang)) return false;
   for (int m = 0; m < nang; m++) {
     if (!next(l, 10)) return false;
     const int a = C(l.v[0]), b = C(l.v[1]), c = C(l.v[2]);
@@ -162,12 +174,13 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
   }
   // torsions
   if (!next(l, 1)) return false;
-  const int ntor = (int)l.v[0];
+  int ntor = 0;
+  if (!count(l.v[0], ntor)) return false;
   std::vector<char> specific((size_t)RX_MAXT * RX_MAXT * RX_MAXT * RX_MAXT, 0);
   auto Q = [&](int a, int b, int c, int d) -> size_t { return ((size_t)(a * RX_MAXT + b) * RX_MAXT + c) * RX_MAXT + d; };
   for (int m = 0; m < ntor; m++) {
     if (!next(l, 9)) return false;
-    const int fa = (int)l.v[0], fd = (int)l.v[3];
+    const int fa = (l.v[0] >= 1.0 && l.v[0] <= (double)nat) ? (int)l.v[0] : (l.v[0] == 0.0 ? 0 : -1), fd = (l.v[3] >= 1.0 && l.v[3] <= (double)nat) ? (int)l.v[3] : (l.v[3] == 0.0 ? 0 : -1);
     const int b = C(l.v[1]), c = C(l.v[2]);
     if (b < 0 || c < 0) continue;
     auto set = [&](size_t q) { RxFbp &f = P.fbp[q]; f.cnt = 1; f.V1 = l.v[4]; f.V2 = l.v[5]; f.V3 = l.v[6]; f.p_tor1 = l.v[7]; f.p_cot1 = l.v[8]; };
@@ -186,7 +199,8 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
   }
   // hydrogen bonds
   if (!next(l, 1)) return false;
-  const int nhb = (int)l.v[0];
+  int nhb = 0;
+  if (!count(l.v[0], nhb)) return false;
   for (int m = 0; m < nhb; m++) {
     if (!next(l, 7)) return false;
     const int a = C(l.v[0]), b = C(l.v[1]), c = C(l.v[2]);

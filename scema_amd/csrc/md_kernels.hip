@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "md_device.h"
+#include "md_env.h"
 #include "md_kernels.h"
 #include "md_types.h"
 
@@ -1285,7 +1286,7 @@ void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms
   else hipLaunchKernelGGL(k_initial_integrate<false>, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
 }
 void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj, bool pack) {
-  static const bool one_launch = !(getenv("SCEMA_MD_CELL_BUILD") && atoi(getenv("SCEMA_MD_CELL_BUILD")) == 0);
+  static const bool one_launch = !(scema_env("SCEMA_MD_CELL_BUILD") && atoi(scema_env("SCEMA_MD_CELL_BUILD")) == 0);
   if (one_launch && maxatoms <= CB_MAXATOMS && maxcells <= BIN_MAXCELLS) hipLaunchKernelGGL(k_cell_build, dim3(ns), dim3(CB_TPB), 0, st, d);
   else {
     hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB * BIN_APT), ns), dim3(TPB), 0, st, d);

@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "md_device.h"
+#include "md_env.h"
 #include "md_kernels.h"
 
 #define TW MD_TILE_WAVES    // waves per tile workgroup
@@ -173,17 +174,16 @@ extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave li
 #define NB_UPW 4         // units per wave and round (TW * NB_UPW = 32: scan32_incl)
 
 // (TT, 4): at most 128 registers, so that two workgroups share a CU -- at 129 the kernel ran 1.6 times longer
-__global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap, int spread) {
+__global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap) {
   int sim, cell;
   // Which replicas rebuild in a given step is random (one in ~16 of them, each at its own time).  With the tiles of a replica pinned
   // to one XCD (k_pair's map) the XCD that happens to hold the most rebuilding replicas sets the launch time; consecutive blocks =
   // consecutive tiles of one replica instead deals every rebuilding replica's tiles over all eight XCDs (its 332 KB of positions
   // are then read by each of them: nothing next to the 10 MB of rows it writes).
-  if (spread) {
-    sim = blockIdx.x / ntiles;
-    cell = blockIdx.x % ntiles;
-    if (sim >= nsims) return;
-  } else if (!xcd_map(ntiles, nsims, sim, cell)) return;
+  // (measured against k_pair's map in round 3: -75 us per 576-replica step)
+  sim = blockIdx.x / ntiles;
+  cell = blockIdx.x % ntiles;
+  if (sim >= nsims) return;
   const SimDev &S = sims[sim];
   SimScalars &sc = *S.sc;
   if (!sc.rebuild) return;
@@ -964,7 +964,7 @@ size_t mdk_pair_lds_bytes(int capj) { return (size_t)capj * (3 * sizeof(double) 
 int mdk_neigh_capB(int maxrow) { return (int)(0.6 * maxrow) / 64 * 64 + 64; }
 // capacity of one group's list (16-bit table indices): 3/4 of the table (a quarter of PE-10k's clusters reaches 72 %); a group that reaches more walks the whole table instead.  (The kernel's LDS must stay below 80 KB for two workgroups per CU: at 83 KB it ran 1.75 times longer.)
 static int neigh_qcap(int capj) {
-  static const int n16 = getenv("SCEMA_MD_QCAP16") ? atoi(getenv("SCEMA_MD_QCAP16")) : 12;   // (test switch: small values force the whole-table path)
+  static const int n16 = scema_env("SCEMA_MD_QCAP16") ? atoi(scema_env("SCEMA_MD_QCAP16")) : 12;   // (test switch: small values force the whole-table path)
   return (n16 * capj / 16 + 63) / 64 * 64;
 }
 size_t mdk_neigh_lds_bytes(int capj, int maxrow) {
@@ -978,8 +978,7 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
   static size_t optin_tab[16] = {0};  // more than 64 KB of dynamic LDS needs an explicit opt-in
   size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_neigh_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  static const int spread = getenv("SCEMA_MD_NEIGH_SPREAD") ? atoi(getenv("SCEMA_MD_NEIGH_SPREAD")) : 1;   // measurement switch (0: k_pair's XCD map)
-  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB, neigh_qcap(capj), spread);
+  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB, neigh_qcap(capj));
 }
 
 template <bool VIR, bool ENG, int NP, bool CLE = false>

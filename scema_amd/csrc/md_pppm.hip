@@ -458,7 +458,6 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
 size_t mdk_pppm_lds_limit() { return 144 * 1024; }
 // atom ranges per replica: enough workgroups to fill the 256 CUs several times over, none with fewer than 256 atoms
 static inline int pppm_split(int ns, int maxatoms) {
-  if (const char *v = getenv("SCEMA_MD_PPPM_SPLIT")) return std::max(1, atoi(v));   // measurement only
   // small batches: down to one atom per thread (a single replica: spreading 27 -> 15 us, interpolation 27 -> 20 us)
   return std::max(1, std::min(std::min(ns < 32 ? 64 : 16, cdiv(2048, ns)), maxatoms / 256));
 }

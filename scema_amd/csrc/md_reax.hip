@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "md_device.h"
+#include "md_env.h"
 #include "md_kernels.h"
 #include "md_reax.h"
 #include "md_types.h"
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
       for (int q = 0; q < RX_SWEEP_RG; q++) {
         const bool on = c < len[q];
         const size_t o = base[q] + (on ? c : 0);
-        const int j = COL16 ? (int)c16[o] : c32[o];
+        // (a masked lane must not trust entry 0 of the row either: a row without neighbours inside the taper radius was never written)
+        const int j = on ? (COL16 ? (int)c16[o] : c32[o]) : 0;
         const double h = on ? V.hval[o] : 0.0;
         const double2 zj = z[j];
         ps[q] = fma(h, zj.x, ps[q]);
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
         for (int c0 = 0; c0 < len; c0 += 64) {
           const bool on = c0 + lane < len;
           const size_t o = (size_t)i * V.maxnb + (on ? c0 + lane : 0);
-          const double2 zj = z[V.hcol16 ? (int)V.hcol16[o] : V.hcol32[o]];
+          const double2 zj = z[on ? (V.hcol16 ? (int)V.hcol16[o] : V.hcol32[o]) : 0];
           const double hv = on ? V.hval[o] : 0.0;
           ys = fma(hv, zj.x, ys);
           yt = fma(hv, zj.y, yt);
@@ -813,7 +815,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   if (terms & 4) hipLaunchKernelGGL(k_rx_terms<2>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 16) {
-    static const bool once_off = getenv("SCEMA_MD_RX_NB_ONCE") && atoi(getenv("SCEMA_MD_RX_NB_ONCE")) == 0;   // (test switch: the both-ends kernel)
+    static const bool once_off = scema_env("SCEMA_MD_RX_NB_ONCE") && atoi(scema_env("SCEMA_MD_RX_NB_ONCE")) == 0;   // (test switch: the both-ends kernel)
     const int maxpad = (maxatoms + 63) / 64 * 64;
     if (!once_off && maxpad <= RX_NB1_MAXPAD) {
       const size_t lds = 3 * (size_t)maxpad * sizeof(double);

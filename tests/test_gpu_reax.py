@@ -74,6 +74,26 @@ def test_isolated_molecule_all_terms(ff, eng):
     assert all(abs(po[k]) > 1e-6 for k in ("bond", "lp", "over", "under", "angle", "tors", "conj", "hb", "vdw", "coul", "pol"))
 
 
+def test_atoms_without_any_neighbour_inside_the_taper_radius(ff, eng):
+    """gas-phase case: a row of the charge matrix with no entry at all, walked in the same wave pass as a full one --
+    the masked lanes must not read a column index out of the unwritten row.  Two lone hydrogens 40 A from a molecule, one of them
+    between the molecule's atoms in the file so that its row is paired with a non-empty one."""
+    t, x = _glycine_like(ff)
+    sym = _sym(ff, t)
+    sym = sym[:1] + ["H"] + sym[1:] + ["H"]
+    x = np.vstack([x[:1], [[24.0, 23.0, 25.0]], x[1:], [[-24.0, 22.0, -23.0]]])
+    box = np.array([-30.0, -30.0, -30.0, 30.0, 30.0, 30.0, 0.0, 0.0, 0.0])
+    # the scratch memory the rows live in is not zeroed by the allocator: poison it first with a denser system of the same name
+    from scema_amd.systems import build_pe
+    d = build_pe(2, 3, 5)
+    eng.register_replica("poison", 1, capi.reax_system(["C" if d["mass"][k] > 5 else "H" for k in d["type"]], d["x"], d["box"]))
+    eng.reax_compute("poison", 1)
+    r, po = _compare_static(ff, eng, sym, x, box, name="lone", full_fd=True)
+    assert np.all(np.isfinite(r["q"])) and np.all(np.isfinite(r["f"]))
+    # a lone atom keeps the charge the constraint leaves it and feels nothing
+    assert np.abs(r["f"][1]).max() < 1e-9 and np.abs(r["f"][-1]).max() < 1e-9
+
+
 def test_each_term_group_alone(ff, eng):
     """the parity switch `terms` isolates a launch: its forces are the central differences of just those energy parts"""
     t, x = _glycine_like(ff)

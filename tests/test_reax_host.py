@@ -34,11 +34,13 @@ def ff():
 def drv():
     out = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out, exist_ok=True)
-    so = os.path.join(out, "libreax_host.so")
+    san = os.environ.get("SCEMA_SANITIZE") == "1"       # tools/run_asan.sh: the driver and the parameter reader under ASan + UBSan
+    so = os.path.join(out, "libreax_host_asan.so" if san else "libreax_host.so")
     srcs = [os.path.join(ROOT, "tests", "reax_host_driver.cpp"), os.path.join(ROOT, "scema_amd", "csrc", "host", "reax_ffield.cpp")]
     deps = srcs + [os.path.join(ROOT, "scema_amd", "csrc", "reax", f) for f in ("rx_core.h", "rx_types.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in deps):
-        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so] + srcs)
+        flags = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if san else ["-O2"]
+        subprocess.check_call(["g++"] + flags + ["-fPIC", "-shared", "-std=c++17", "-o", so] + srcs)
     L = C.CDLL(so)
     L.rxh_create.restype = C.c_void_p
     L.rxh_create.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]
