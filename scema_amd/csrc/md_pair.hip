@@ -37,6 +37,7 @@
 #define E_LMASK 0x1FFF
 #define E_TYPE_SHIFT 13
 #define E_MASK_SHIFT 17
+#define E_FAR (1 << 21)    // (inside k_neigh_build only: a skin-band entry of the far part, C2)
 #define CODE_HOME 13       // image code of (0,0,0)
 
 // slot records are stored as two arrays of 16-byte halves, (x,y)[npad] then (z,q)[npad]: a wave's gather
@@ -540,27 +541,39 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
             }
         }
       }
-      const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isC = mask && !isA && !isB && rmin < rc2;
-      const bool isD = mask && !isA && !isB && !isC;
-      const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC), mD = __ballot(isD);
+      // segments: A straight into the row; B from the front of the wave's LDS list; the skin band -- C1 (near) and C2 (far, flagged) --
+      // from its back, one ballot for both; the end of the row sorts the band into C1 | C2 so that the row leaves CONTIGUOUS
+      // ([A|B|C1|C2]: k_pair's prefetch then indexes row[k] and nothing else)
+      const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isS = mask && !isA && !isB;
+      const bool isD = isS && !(rmin < rc2);
+      const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mS = __ballot(isS), mD = __ballot(isD);
       if (mask) {
         const int entry = l | ((int)((unsigned)jt >> 28) << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT);
         if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) row[pos] = entry; }
         else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
-        else if (isC) { const int pos = capB - 1 - (nC + popc_below(mC)); if (pos >= 0) lb[pos] = entry; }
-        else { const int pos = maxrow - 1 - (nD + popc_below(mD)); if (pos >= 0) row[pos] = entry; }
+        else { const int pos = capB - 1 - (nC + nD + popc_below(mS)); if (pos >= 0) lb[pos] = entry | (isD ? E_FAR : 0); }
       }
-      nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC); nD += __popcll(mD);
+      { const int ns = __popcll(mS), nd = __popcll(mD); nA += __popcll(mA); nB += __popcll(mB); nC += ns - nd; nD += nd; }
       npairs += __popc(mask);
       if (count_ref) npairs_ref += __popc(refm);
     }
     const int n = nA + nB + nC + nD;
-    const bool bad = nB + nC > capB || n > maxrow;
+    const bool bad = nB + nC + nD > capB || n > maxrow;
     if (bad) over = 1;
-    // B, C1: LDS lists -> behind A (same-wave LDS traffic is processed in order)
-    const int mB_ = bad ? 0 : nB, mC_ = bad ? 0 : nC;
-    for (int k = lane; k < mB_; k += 64) row[nA + k] = lb[k];
-    for (int k = lane; k < mC_; k += 64) row[nA + nB + k] = lb[capB - 1 - k];
+    // B, skin band: LDS lists -> behind A (same-wave LDS traffic is processed in order)
+    if (!bad) {
+      for (int k = lane; k < nB; k += 64) row[nA + k] = lb[k];
+      int cC = nA + nB, cD = nA + nB + nC;
+      for (int k0 = 0; k0 < nC + nD; k0 += 64) {
+        const int k = k0 + lane;
+        const bool in = k < nC + nD;
+        const int e = in ? lb[capB - 1 - k] : 0;
+        const bool far = in && (e & E_FAR);
+        const unsigned long long mN = __ballot(in && !far), mF = __ballot(far);
+        if (in) row[far ? cD + popc_below(mF) : cC + popc_below(mN)] = e & ~E_FAR;
+        cC += __popcll(mN); cD += __popcll(mF);
+      }
+    }
     if (lane == 0) {
       S.numneigh[2 * cl] = bad ? 0 : nA + nB + nC; S.numneigh[2 * cl + 1] = bad ? 0 : nD;
     }
@@ -661,13 +674,12 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   // (wave-uniform by construction; saying so lets the row cursors below live in scalar registers and branch on the scalar unit)
   const int nrows = __builtin_amdgcn_readfirstlane((nj > 0) ? min(p_end - p_begin, 64) : 0);
   if (p_end - p_begin > 64 && lane == 0) atomicOr(&sc.overflow, 1 | 4);   // cannot happen after k_neigh_build's check; loud if it ever does
-  int h_cl = 0, h_nab = 0, h_nn = 0;
+  int h_cl = 0, h_nn = 0;
   if (lane < nrows) {
     // an entry of the schedule: cluster | a << 20 | b << 25 = the chunks [C a / 16, C b / 16) of that cluster's row (k_neigh_build)
     const int ent = S.tile_order[2 * (cs / NI) + p_begin + lane];
     h_cl = ent & 0xFFFFF;
-    h_nab = S.numneigh[2 * h_cl];
-    const int n = h_nab + (need_far ? S.numneigh[2 * h_cl + 1] : 0);   // [A|B|C1] from the front, C2 reversed from the back
+    const int n = S.numneigh[2 * h_cl] + (need_far ? S.numneigh[2 * h_cl + 1] : 0);   // [A|B|C1], then C2
     const int C = (n + 63) >> 6, pa = (ent >> 20) & 31, pb = (ent >> 25) & 31;
     const int kb = 64 * ((C * pa) >> 4), ke = min(n, 64 * ((C * pb) >> 4));
     h_nn = (max(ke, kb) << 16) | kb;
@@ -677,20 +689,22 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   const GLOBAL_AS int *neigh = as_global(S.neigh);
   // prefetch cursor: the chunk two ahead of the one being evaluated
   int pr = 0;
-  int pcl = __builtin_amdgcn_readlane(h_cl, 0), pnab = __builtin_amdgcn_readlane(h_nab, 0), pnn = __builtin_amdgcn_readlane(h_nn, 0);
+  int pcl = __builtin_amdgcn_readlane(h_cl, 0), pnn = __builtin_amdgcn_readlane(h_nn, 0);
   int pk = H_KB(pnn);
   pnn = H_KE(pnn);
+  const unsigned lane4 = 4u * (unsigned)lane;
   auto fetch = [&]() -> int {
     int v = 0;
     if (pr < nrows) {
-      const int k = pk + lane;
-      const GLOBAL_AS int *row = neigh + (size_t)pcl * maxrow;
-      if (k < pnn) v = row[(k < pnab) ? k : (maxrow - 1 - (k - pnab))];
+      // the row is contiguous ([A|B|C1|C2], k_neigh_build): scalar row base + a 32-bit byte offset per lane
+      const GLOBAL_AS char *row = (const GLOBAL_AS char *)(neigh + (size_t)pcl * maxrow);
+      const unsigned off = 4u * (unsigned)pk + lane4;
+      if (off < 4u * (unsigned)pnn) v = *(const GLOBAL_AS int *)(row + off);
       pk += 64;
       if (pk >= pnn) {
         pr += 1;
         const int q = min(pr, nrows - 1);
-        pcl = __builtin_amdgcn_readlane(h_cl, q); pnab = __builtin_amdgcn_readlane(h_nab, q); pnn = __builtin_amdgcn_readlane(h_nn, q);
+        pcl = __builtin_amdgcn_readlane(h_cl, q); pnn = __builtin_amdgcn_readlane(h_nn, q);
         pk = H_KB(pnn);
         pnn = H_KE(pnn);
       }
@@ -733,12 +747,6 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   unsigned pc_chunk = 0, pc_chunk_nz = 0, pc_blk = 0, pc_dist = 0, pc_lj = 0, pc_ljblk = 0, pc_coul = 0, pc_coulblk = 0;
 #endif
   if (nrows > 0) {
-    int jt_n = s_jtab[e_n & E_LMASK];
-    double xn0, xn1, xn2, xn3;
-    {
-      const size_t j = (size_t)(jt_n & MD_JMASK);
-      xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
-    }
     // evaluation cursor
     int r = 0;
     int s0 = __builtin_amdgcn_readlane(h_cl, 0) * NI, nn = __builtin_amdgcn_readlane(h_nn, 0);
@@ -753,16 +761,9 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
       ti[a] = S.stype[s0 + a] * nt;
       fx[a] = fy[a] = fz[a] = 0.0;
     }
-    while (r < nrows) {
-      const int e = e_n, jt = jt_n;
-      const double xj = xn0, yj = xn1, zj = xn2, qj = xn3;
-      {
-        e_n = e_nn;
-        jt_n = s_jtab[e_n & E_LMASK];
-        const size_t j = (size_t)(jt_n & MD_JMASK);
-        xn0 = xq[2 * j]; xn1 = xq[2 * j + 1]; xn2 = zq[2 * j]; xn3 = zq[2 * j + 1];
-        e_nn = fetch();
-      }
+    // One chunk: the entries `e` (one per lane), their table entries `jt` and records (xj, yj, zj, qj) against the wave's current
+    // i-cluster; then the row cursor moves on.
+    auto chunk = [&](const int e, const int jt, const double xj, const double yj, const double zj, const double qj) __attribute__((always_inline)) {
       const int mask = (e >> E_MASK_SHIFT) & 0xF;  // 0 for the padding of a row's last chunk
 #ifdef PAIR_COUNT
       if (lane == 0) { pc_chunk += 1; pc_chunk_nz += (__ballot(mask != 0) != 0ull) ? 1 : 0; }
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
         lds_add(&s_fx[l], gx); lds_add(&s_fy[l], gy); lds_add(&s_fz[l], gz);
       }
       k0 += 64;
-      if (k0 >= nn) {
+      if (r < nrows && k0 >= nn) {
         // Row finished.  Forces on the cluster's own atoms: 12 per-lane partial sums -> the atoms' own table entries
         // (own cell first).  Transposing butterfly over the quad (lane i ends up with component c of atom i&3), then
         // a row scan: lanes 12..15 of each row of 16 hold the row totals and add them to LDS.  81 VALU instructions
@@ -881,7 +882,32 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
           }
         }
       }
-    }
+    };
+    // The pipeline is three deep in the entries (evaluated | table entry read and record requested | row entry requested) and two deep
+    // in the records.  Written as ONE loop body, every chunk paid seven register moves to shift the stages along (three entries, a
+    // table entry, four 64-bit record words: 4 % of the kernel's vector instructions); the body below is two chunks with the roles
+    // of the two record sets swapped, which leaves one exchange of the entry names per pair of chunks.
+    struct Rec { double x, y, z, q; };
+    auto deref = [&](const int e, int &jt, Rec &R) __attribute__((always_inline)) {
+      jt = s_jtab[e & E_LMASK];
+      const size_t j = (size_t)(jt & MD_JMASK);
+      R.x = xq[2 * j]; R.y = xq[2 * j + 1]; R.z = zq[2 * j]; R.q = zq[2 * j + 1];
+    };
+    int eA = e_n, eB = e_nn, eC, jtX, jtY;
+    Rec X, Y;
+    deref(eA, jtX, X);
+    // (one exit, at the end of the pair: with a second exit between the chunks the compiler moved the prefetch cursor into vector
+    // registers; a wave whose stream ends after the first chunk of a pair runs the second one on empty entries -- mask 0, nothing
+    // evaluated, and the row cursor stands still once the last row is done)
+    do {
+      deref(eB, jtY, Y);
+      eC = fetch();
+      chunk(eA, jtX, X.x, X.y, X.z, X.q);
+      deref(eC, jtX, X);
+      eA = fetch();
+      chunk(eB, jtY, Y.x, Y.y, Y.z, Y.q);
+      { const int t = eA; eA = eC; eB = t; }   // evaluated next: eC (its record is in X), then the entry just requested
+    } while (r < nrows);
   }
 #ifdef PAIR_COUNT
   {
