@@ -253,7 +253,7 @@ def env_overrides():
     """every SCEMA_* variable of this process's environment that the engine or this program reads: a reported run has none"""
     from scema_amd import capi
     eng_side = capi.env_overrides()
-    mine = [f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("SCEMA_BENCH_") or k in ("SCEMA_CPU_BASELINE_CORES", "SCEMA_LAMMPS", "SCEMA_SCRIPTS")]
+    mine = [f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("SCEMA_BENCH_") or k in ("SCEMA_CPU_BASELINE_CORES", "SCEMA_LAMMPS", "SCEMA_SCRIPTS", "SCEMA_MD_LIB", "SCEMA_SANITIZE")]
     return eng_side + mine
 
 

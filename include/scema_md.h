@@ -163,8 +163,12 @@ int scema_md_write_lammps_restart(const char *path, const scema_md_system *sys, 
  *     every rank.  The all-gather carries a status word per rank: a share that failed on one rank (list overflow after
  *     regrowth, a replica that blew up, a missing state) makes the call fail on EVERY rank, none is left waiting.
  * Requests are validated on every rank before anything is planned, so a bad request is refused by all ranks alike.
- * A failed call leaves the state store and the owner directory as it found them, on every rank: states that had
- * already been advanced are put back from their backups (the reference stops the whole run at this point, exit(1)).
+ * A failed call leaves the state store and the owner directory as it found them -- ON EVERY RANK when a communicator is
+ * attached (the ranks learn of each other's failure inside the call and all roll back): states that had already been
+ * advanced are put back from their backups (the reference stops the whole run at this point, exit(1)).  Without a
+ * communicator the guarantee is this rank's only: a rank whose own share succeeded has committed it by the time the
+ * caller's collective (scema_md_scatter_gathered) reports that another rank failed; such a run must be treated as the
+ * reference treats it -- stopped -- or restarted from its last checkpoint files, not retried.
  * What the ranks must share for their plans to agree: the same replicas registered, the same request vectors, and every
  * call that edits the state store (set_state, drop_state, load_state_file, equilibrate) made on every rank. */
 int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims, int32_t hooke,

@@ -13,7 +13,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/run_asan.sh (CPU tests only): the build whose host layer is compiled with AddressSanitizer + UBSan
-LIB_PATH = os.path.join(_HERE, "libscema_md_asan.so" if os.environ.get("SCEMA_SANITIZE") == "1" else "libscema_md.so")
+# SCEMA_MD_LIB=<file name in this directory>: an A/B build of the library for same-box kernel comparisons (csrc/Makefile: LIBNAME);
+# bench.py lists the variable under config.env_overrides
+LIB_PATH = os.path.join(_HERE, os.environ.get("SCEMA_MD_LIB") or ("libscema_md_asan.so" if os.environ.get("SCEMA_SANITIZE") == "1" else "libscema_md.so"))
 
 NPART = 8
 PARTS = ["lj", "coul", "bond", "angle", "dihedral", "improper", "kspace", "shake"]

@@ -141,6 +141,11 @@ struct State {
   // reference's 2.0 A; once thermalised it rebuilds every ~14 steps and 0.5 A more (one rebuild in ~22 steps, the far
   // band of the rows mostly skipped) is 6 % faster.
   double skin_extra = 0.0;
+  // ReaxFF, performance only (the solver's tolerance fixes the charges, not its starting point): the last solutions of the charge
+  // equilibration of this state's latest run, [4][npad] s then [3][npad] t, newest first -- the next run of the state extrapolates
+  // its first guesses from them instead of starting from zeros (RxView::warm)
+  DevBuf qhist;
+  bool qhist_valid = false;
 };
 
 // work arrays of the ReaxFF path for one batch position (reax/rx_types.h RxView points into these)
@@ -224,6 +229,8 @@ struct RunSpec {
   std::vector<EwaldSetup> *ew_keep = nullptr;   // k-space setup of the run's first segment, reused by the later ones
   int minimize = 0, min_maxiter = 0, min_maxeval = 0;
   double min_etol = 0, min_ftol = 0;
+  int qeq_continue = 0;   // ReaxFF: this run follows another one of the same simulations on the same slots (phase B after phase A): the
+                          // charge-equilibration history is still in place
 };
 
 // which phases an evaluation runs and with which constraints (the hot path: strain with SHAKE, sample with SHAKE;

@@ -58,6 +58,7 @@ static int backup_states(scema_md_engine *e, std::vector<ActiveSim> &chunk, bool
     for (int i = 0; i < ns; i++) {
       std::memcpy(chunk[i].st->box, chunk[i].box0, sizeof chunk[i].box0);
       chunk[i].st->skin_extra = chunk[i].skin0;
+      chunk[i].st->qhist_valid = false;   // (what it holds belongs to the positions that were just taken back)
     }
   else
     for (int i = 0; i < ns; i++) {
@@ -91,6 +92,7 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
       RunSpec B;
       B.sample = 1;
       B.use_shake = opt.shake_b;
+      B.qeq_continue = opt.phase_a ? 1 : 0;   // same simulations, same slots: the ReaxFF solver history of phase A is in place
       for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nss;
       rc = run_phase(e, chunk, B);
       if (scema_env("SCEMA_MD_TIMING")) fprintf(stderr, "[scema_md] chunk of %d: phase A %.1f ms, phase B %.1f ms (attempt %d)\n", ns, 1e3 * (t_a1 - t_a0), 1e3 * (wall_s() - t_a1), attempt);
@@ -154,7 +156,15 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   if (!e || (!sims && n_sims > 0) || n_sims < 0 || world <= 0 || rank < 0 || rank >= world) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
   if (e->comm.kind && (e->comm.rank != rank || e->comm.world != world))
     return fail(e, SCEMA_MD_ERR_ARG, "rank/world (%d/%d) differ from the attached communicator (%d/%d)", rank, world, e->comm.rank, e->comm.world);
-  HIPCHK(hipSetDevice(e->p.device));
+  // Rank-local findings before anything runs are collected in pre_status and exchanged in the handshake: with a communicator a rank
+  // that cannot go on (device error, force-field file unreadable here, replica not registered here) still enters the handshake, so
+  // that every rank ends the call with the same error instead of the others waiting in it
+  int pre_status = SCEMA_MD_OK;
+  const bool collective_call = e->comm.kind && world > 1;
+  if (hipSetDevice(e->p.device) != hipSuccess) {
+    if (!collective_call) return fail(e, SCEMA_MD_ERR_DEVICE, "hipSetDevice(%d) failed", e->p.device);
+    pre_status = fail(e, SCEMA_MD_ERR_DEVICE, "hipSetDevice(%d) failed on rank %d", e->p.device, rank);
+  }
   e->last_plan = scema::SimPlan();   // a call that ends before planning leaves no plan behind
   // ---- the request itself: checked on every rank for every simulation, so that a request that cannot run is refused by
   // all ranks together, before anything is planned or moved ----
@@ -186,10 +196,10 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     static const char *hcno[4] = {"H", "C", "N", "O"};
     const std::string path = std::string(sims[0].scripts_folder ? sims[0].scripts_folder : ".") + "/ffield.reax.2";
     const int rc_cfg = scema_md_reax_configure(e, path.c_str(), hcno, 4, 1e-6, -1.0);
-    if (rc_cfg) return rc_cfg;
+    if (rc_cfg && !collective_call) return rc_cfg;
+    if (rc_cfg && !pre_status) pre_status = rc_cfg;   // (a file one rank cannot read: the others must hear of it)
   }
   // ---- who runs what (host/sim_plan.h): identical on every rank ----
-  int pre_status = SCEMA_MD_OK;   // rank-local findings before anything runs; exchanged in the handshake
   for (int i = 0; i < n_sims && !hooke_mode; i++) {
     dst_keys[i] = state_key(sims[i].qp_id, sims[i].matid, sims[i].replica);
     // stmd_problem.h:116-120: the state is read under most_recent_qp_id ("none" -> init.<mat>_<rep>.bin)
@@ -219,10 +229,13 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   const double hash = plan_hash(plan, cost);
   e->local_stress_count = per_rank;
   const size_t nres = 6 * (size_t)std::max(per_rank, 1) + SCEMA_MD_RESULT_TRAILER;
-  HIPCHK(e->d_local_stress.ensure(nres * sizeof(double)));
+  if (e->d_local_stress.ensure(nres * sizeof(double)) != hipSuccess) {
+    if (!collective_call) return fail(e, SCEMA_MD_ERR_DEVICE, "out of device memory for the result buffer");
+    if (!pre_status) pre_status = fail(e, SCEMA_MD_ERR_DEVICE, "out of device memory for the result buffer on rank %d", rank);
+  }
   std::vector<double> local(nres, 0.0);
   local[nres - 1] = hash;
-  const bool collective = e->comm.kind && world > 1;
+  const bool collective = collective_call;
   // without a communicator the caller gathers this buffer: it must say what happened to this rank's share whenever a plan exists
   auto publish = [&](int st) {
     local[nres - 2] = (double)st;

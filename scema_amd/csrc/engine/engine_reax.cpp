@@ -189,6 +189,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     V.bd_bop = R.bd_bop.as<double>(); V.bd_c = R.bd_c.as<double>(); V.bd_bo = R.bd_bo.as<double>(); V.bd_g = R.bd_g.as<double>(); V.bd_cb = R.bd_cb.as<double>();
     V.deltap = R.deltap.as<double>(); V.total_bo = R.total_bo.as<double>(); V.cd_delta = R.cd_delta.as<double>(); V.hd = R.hd.as<double>();
     V.f = S.f; V.hval = R.hval.as<double>(); V.s = R.s.as<double>(); V.t = R.t.as<double>();
+    V.warm = (spec.qeq_continue || A.st->qhist_valid) ? 1 : 0;
     V.hcol16 = col16 ? R.hcol.as<unsigned short>() : nullptr; V.hcol32 = col16 ? nullptr : R.hcol.as<int>(); V.hlen = R.hlen.as<int>(); V.nbT = R.nbT.as<int>();
     V.hown = R.hown.as<int>(); V.hownlen = R.hownlen.as<int>();
     V.s_hist = R.s_hist.as<double>(); V.t_hist = R.t_hist.as<double>(); V.qwork = R.qwork.as<double>();
@@ -215,8 +216,39 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   size_t ev_used = 0;
   std::vector<hipEvent_t> *evp = prof ? &e->ev_pool : nullptr;
   mdk_phase_init(st, D, ns);
+  // Charge-equilibration history: kept in place when this run follows another one on the same slots; else a state that has run
+  // before brings its own (one copy launch for the batch); the rest start from zeros like a new fix qeq/reax
+  bool any_cold = false;
+  {
+    std::vector<MdkCopy> tab;
+    long long maxn = 0;
+    for (int pos = 0; pos < ns; pos++) {
+      ActiveSim &A = sims[order[pos]];
+      const RxView &V = e->h_rxviews[pos];
+      if (!V.warm) any_cold = true;
+      if (spec.qeq_continue || !A.st->qhist_valid) continue;
+      const long long np = V.npad;
+      tab.push_back(MdkCopy{A.st->qhist.as<double>(), V.s_hist, 4 * np});
+      tab.push_back(MdkCopy{A.st->qhist.as<double>() + 4 * np, V.t_hist, 3 * np});
+      maxn = std::max(maxn, 4 * np);
+    }
+    if (!tab.empty()) {
+      HIPCHK(e->d_copytab.ensure(tab.size() * sizeof(MdkCopy)));
+      HIPCHK(hipMemcpyAsync(e->d_copytab.p, tab.data(), tab.size() * sizeof(MdkCopy), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));   // (the table is a local)
+      mdk_copy_many(st, e->d_copytab.as<MdkCopy>(), (int)tab.size(), maxn);
+    }
+  }
+  // how a solve is issued (md_reax.h): as many iterations as the slowest solve of the last run took plus a margin; the first
+  // solves of a run that has replicas without a history take longer
+  auto plan_for = [&](int step) {
+    RxQeqPlan pl;
+    pl.launch = (step < 4 && any_cold) ? e->rx_qeq_launch_cold : e->rx_qeq_launch;
+    pl.setup = step == 0 ? 1 : 0;
+    return pl;
+  };
   mdk_reax_phase_init(st, VV, ns, maxpad);
-  mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, e->rx_qeq_launch_cold, terms, col16, evp, &ev_used);
+  mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(0), terms, col16, evp, &ev_used);
   mdk_final_integrate(st, D, ns, maxatoms, 0);
   if (spec.nh) mdk_setup_post_nh(st, D, ns);
   else mdk_setup_post(st, D, ns);
@@ -240,7 +272,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       for (int r = 0; r < 16; r++, ev_n++) {
         mdk_min_pre(st, D, ns);
         mdk_min_move(st, D, ns, maxatoms, x0s, hsd);
-        mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, e->rx_qeq_launch_cold, terms, col16);
+        mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(1), terms, col16);
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
         mdk_min_decide(st, D, ns);
       }
@@ -276,7 +308,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     if (spec.nh) { mdk_pre_nh(st, D, na); mdk_initial_integrate_nh(st, D, na, maxatoms); }
     else { mdk_pre(st, D, na); mdk_initial_integrate(st, D, na, maxatoms); }
     // the first solves of a run start from an empty history (RX_QEQ_COLD in md_reax.hip: setup is solve 1)
-    mdk_reax_forces(st, D, VV, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, step < 4 ? e->rx_qeq_launch_cold : e->rx_qeq_launch, terms, col16, evp, &ev_used);
+    mdk_reax_forces(st, D, VV, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(step), terms, col16, evp, &ev_used);
     mdk_final_integrate(st, D, na, maxatoms, 1);
     if (spec.nh) mdk_post_nh(st, D, na);
     else mdk_post(st, D, na);
@@ -291,6 +323,24 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       }
   }
   mdk_phase_end(st, D, ns, maxatoms);
+  {  // the states keep the history for their next run (a failed update drops it: backup_states)
+    std::vector<MdkCopy> tab;
+    long long maxn = 0;
+    for (int pos = 0; pos < ns; pos++) {
+      ActiveSim &A = sims[order[pos]];
+      const RxView &V = e->h_rxviews[pos];
+      const long long np = V.npad;
+      HIPCHK(A.st->qhist.ensure(7 * (size_t)np * 8));
+      tab.push_back(MdkCopy{V.s_hist, A.st->qhist.as<double>(), 4 * np});
+      tab.push_back(MdkCopy{V.t_hist, A.st->qhist.as<double>() + 4 * np, 3 * np});
+      maxn = std::max(maxn, 4 * np);
+      A.st->qhist_valid = true;
+    }
+    HIPCHK(e->d_copytab.ensure(tab.size() * sizeof(MdkCopy)));
+    HIPCHK(hipMemcpyAsync(e->d_copytab.p, tab.data(), tab.size() * sizeof(MdkCopy), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    mdk_copy_many(st, e->d_copytab.as<MdkCopy>(), (int)tab.size(), maxn);
+  }
   HIPCHK(hipMemcpyAsync(e->h_sc.data(), e->d_sc.p, (size_t)ns * sizeof(SimScalars), hipMemcpyDeviceToHost, st));
   std::vector<int> qs(6 * (size_t)ns, 0);
   std::vector<long long> acc(2 * (size_t)ns, 0);
@@ -321,7 +371,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     fault |= e->h_sc[i].overflow;
     e->prof.neigh_builds += e->h_sc[i].nbuilds;
     e->rx_qeq_iters += qs[6 * i];
-    e->rx_qeq_solves += qs[6 * i + 1];
+    e->rx_qeq_solves += qs[6 * i + 1] - (e->h_rxviews[i].warm ? RX_QEQ_COLD_SOLVES : 0);   // (a warm run starts its solve count past the cold ones)
     most = std::max(most, qs[6 * i + 2]);
     most_cold = std::max(most_cold, qs[6 * i + 5]);
     e->rx_qeq_slow += qs[6 * i + 3];

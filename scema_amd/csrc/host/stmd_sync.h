@@ -289,9 +289,21 @@ class STMDSync {
       std::vector<int> owner(n), pos(n);
       int per_rank = (n + world_ - 1) / world_;
       for (int i = 0; i < n; i++) { owner[i] = i % world_; pos[i] = i / world_; }
-      // no plan recorded: this rank's call failed before planning (a refused request: every rank refuses it alike)
-      if (md && scema_md_last_plan(engine_, n, owner.data(), pos.data(), &per_rank) != SCEMA_MD_OK)
-        return rc_exec ? rc_exec : fail(SCEMA_MD_ERR_ARG, "no plan recorded for this request vector");
+      if (md) {
+        // A rank whose call ended before planning (a replica it has not registered, a device error) has no plan and so does not know
+        // the record size of the stress collective; the others may have one.  Whether everybody has a plan is therefore agreed on
+        // first, in a collective of ONE word per rank that every rank enters whatever happened to it (such a rank used to
+        // return here and leave the others in the all-gather below).
+        const bool have_plan = scema_md_last_plan(engine_, n, owner.data(), pos.data(), &per_rank) == SCEMA_MD_OK;
+        double mine = have_plan ? 0.0 : (double)(rc_exec ? rc_exec : SCEMA_MD_ERR_ARG);
+        std::vector<double> all(world_, 0.0);
+        if (allgather_(ag_ctx_, nullptr, &mine, 1, all.data())) return fail(SCEMA_MD_ERR_DEVICE, "all-gather of the plan status failed");
+        for (int r = 0; r < world_; r++)
+          if (all[r] != 0.0) {
+            if (r == rank_ && rc_exec) return rc_exec;   // err_ is set
+            return fail((int)all[r], "rank " + std::to_string(r) + " could not plan this update (code " + std::to_string((int)all[r]) + "): the update is abandoned on every rank");
+          }
+      }
       const size_t cnt = 6 * (size_t)std::max(per_rank, 1) + SCEMA_MD_RESULT_TRAILER;
       std::vector<double> local(cnt, 0.0), gathered(cnt * world_, 0.0);
       for (int i = 0; i < n; i++)

@@ -46,7 +46,16 @@ __device__ __forceinline__ void minimg(const BoxD &b, double &dx, double &dy, do
 // Sum over the 64 lanes of a wave, returned in every lane.  On the DPP path of the VALU (quad permutes, row mirrors, then the row
 // broadcasts of gfx9): 12 cross-lane moves that cost an instruction each -- as `__shfl_down` steps they were 12 LDS round trips
 // (ds_bpermute), which is what the tails of the small kernels waited for (a single replica's k_pppm_solve: 11 of its 71 thousand cycles).
-// All lanes of the wave must be active.
+// All lanes of the wave must be active (a debug build, -DSCEMA_DEVICE_ASSERTS, traps otherwise), and the row broadcasts exist on
+// gfx9 only: the library is built for gfx950 and refuses other targets here instead of returning garbage sums there.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "md_device.h: the DPP reductions (row_bcast) are written for gfx9 / CDNA: build with --offload-arch=gfx950"
+#endif
+#ifdef SCEMA_DEVICE_ASSERTS
+#define SCEMA_ASSERT_FULL_WAVE() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define SCEMA_ASSERT_FULL_WAVE() do { } while (0)
+#endif
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_read0(double v) {   // the lane CTRL selects; 0 where there is none or the row is not in ROWMASK
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, true);
@@ -54,6 +63,7 @@ __device__ __forceinline__ double dpp_read0(double v) {   // the lane CTRL selec
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v) {
+  SCEMA_ASSERT_FULL_WAVE();
   v += dpp_read0<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
   v += dpp_read0<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
   v += dpp_read0<0x141, 0xF>(v);   // row_half_mirror

@@ -100,6 +100,7 @@ __device__ __forceinline__ double dpp_keep(double v) {
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_max_dpp(double v) {
+  SCEMA_ASSERT_FULL_WAVE();   // (md_device.h: all 64 lanes active, gfx9 row broadcasts)
   v = fmax(v, dpp_keep<0x111, 0xF>(v)); v = fmax(v, dpp_keep<0x112, 0xF>(v)); v = fmax(v, dpp_keep<0x114, 0xF>(v)); v = fmax(v, dpp_keep<0x118, 0xF>(v));
   v = fmax(v, dpp_keep<0x142, 0xA>(v));   // row_bcast:15 -> rows 1, 3
   v = fmax(v, dpp_keep<0x143, 0xC>(v));   // row_bcast:31 -> rows 2, 3
@@ -121,6 +122,7 @@ __device__ __forceinline__ double dpp_mov(double v) {
 // inclusive prefix sum over the first 32 lanes of a wave on the DPP path (row shifts inside the rows of 16, then lane 15 broadcast
 // into row 1): 5 VALU instructions instead of 5 LDS round trips
 __device__ __forceinline__ int scan32_incl(int v) {
+  SCEMA_ASSERT_FULL_WAVE();
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
@@ -573,6 +575,11 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
         if (in) row[far ? cD + popc_below(mF) : cC + popc_below(mN)] = e & ~E_FAR;
         cC += __popcll(mN); cD += __popcll(mF);
       }
+      // the row's last chunk is filled up with empty entries (mask 0): k_pair reads whole chunks and masks no lane.  (maxrow is a
+      // multiple of 64.)  On steps without the far band it reads up to the end of the chunk that holds the last C1 entry: what
+      // follows there are C2 entries, whose pairs are outside the cutoff on such a step -- evaluated to nothing in lanes that
+      // would otherwise idle
+      if (n + lane < ((n + 63) & ~63)) row[n + lane] = 0;
     }
     if (lane == 0) {
       S.numneigh[2 * cl] = bad ? 0 : nA + nB + nC; S.numneigh[2 * cl + 1] = bad ? 0 : nD;
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 // k_pair
 // ------------------------------------------------------------------------------------------
 // NP = number of polynomial coefficients kept in scalar registers (>= fitted degree+1, 0-padded)
-extern __shared__ double s_pair[];  // [3][capj] reaction-force accumulators, then int [capj] j table
+extern __shared__ double s_pair[];  // [capj][3] reaction-force accumulators, then int [capj] j table
 
 // CLE: the coulomb cutoff does not exceed the LJ cutoff (the reference's 9 / 12): every interacting lane has an LJ term, which then
 // defines the force factor without a zero to start from, and the cutoff test is one instead of two
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   __shared__ double s_shift[27 * 4];
   __shared__ __attribute__((aligned(16))) double s_lj[2 * MD_MAXTYPES * MD_MAXTYPES];
   __shared__ double s_red[8 * TW];
-  double *s_fx = s_pair, *s_fy = s_pair + capj, *s_fz = s_pair + 2 * (size_t)capj;
+  double *s_f = s_pair;   // [capj][3]: the three components of an entry side by side -- one address per entry for the three LDS atomics of a chunk
   int *s_jtab = (int *)(s_pair + 3 * (size_t)capj);
   if (threadIdx.x < 27) {
     BoxD b;
@@ -681,7 +688,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     h_cl = ent & 0xFFFFF;
     const int n = S.numneigh[2 * h_cl] + (need_far ? S.numneigh[2 * h_cl + 1] : 0);   // [A|B|C1], then C2
     const int C = (n + 63) >> 6, pa = (ent >> 20) & 31, pb = (ent >> 25) & 31;
-    const int kb = 64 * ((C * pa) >> 4), ke = min(n, 64 * ((C * pb) >> 4));
+    const int kb = 64 * ((C * pa) >> 4), ke = 64 * ((C * pb) >> 4);   // whole chunks: the row's last one is padded with empty entries
     h_nn = (max(ke, kb) << 16) | kb;
   }
 #define H_KB(v) ((v) & 0xFFFF)
@@ -698,8 +705,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     if (pr < nrows) {
       // the row is contiguous ([A|B|C1|C2], k_neigh_build): scalar row base + a 32-bit byte offset per lane
       const GLOBAL_AS char *row = (const GLOBAL_AS char *)(neigh + (size_t)pcl * maxrow);
-      const unsigned off = 4u * (unsigned)pk + lane4;
-      if (off < 4u * (unsigned)pnn) v = *(const GLOBAL_AS int *)(row + off);
+      v = *(const GLOBAL_AS int *)(row + (4u * (unsigned)pk + lane4));
       pk += 64;
       if (pk >= pnn) {
         pr += 1;
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     const GLOBAL_AS int *gj = as_global(S.tile_jtab) + (size_t)cell * S.capj;
     for (int l = threadIdx.x; l < nj; l += TT) {
       s_jtab[l] = gj[l];
-      s_fx[l] = 0.0; s_fy[l] = 0.0; s_fz[l] = 0.0;
+      s_f[3 * l] = 0.0; s_f[3 * l + 1] = 0.0; s_f[3 * l + 2] = 0.0;
     }
   }
   double cp[NP];
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
           }
         }
         const int l = e & E_LMASK;
-        lds_add(&s_fx[l], gx); lds_add(&s_fy[l], gy); lds_add(&s_fz[l], gz);
+        lds_add(&s_f[3 * l], gx); lds_add(&s_f[3 * l + 1], gy); lds_add(&s_f[3 * l + 2], gz);
       }
       k0 += 64;
       if (r < nrows && k0 >= nn) {
@@ -866,7 +872,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
         }
         if ((lane & 12) == 12) {
           const int l = s0 - cs + (lane & 3);
-          lds_add(&s_fx[l], u[0]); lds_add(&s_fy[l], u[1]); lds_add(&s_fz[l], u[2]);
+          lds_add(&s_f[3 * l], u[0]); lds_add(&s_f[3 * l + 1], u[1]); lds_add(&s_f[3 * l + 2], u[2]);
         }
         r += 1;
         if (r < nrows) {
@@ -935,7 +941,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     for (int l = threadIdx.x; l < nj; l += TT) {
       const int code = s_jtab[l] >> 23;
       if (code != CODE_HOME) {
-        const double ax = s_fx[l], ay = s_fy[l], az = s_fz[l];
+        const double ax = s_f[3 * l], ay = s_f[3 * l + 1], az = s_f[3 * l + 2];
         const double px = s_shift[4 * code], py = s_shift[4 * code + 1], pz = s_shift[4 * code + 2];
         vl[0] = fma(px, ax, vl[0]); vl[1] = fma(py, ay, vl[1]); vl[2] = fma(pz, az, vl[2]);
         vl[3] = fma(px, ay, vl[3]); vl[4] = fma(px, az, vl[4]); vl[5] = fma(py, az, vl[5]);
@@ -946,7 +952,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     double *fs = S.fs;
     const size_t np = (size_t)S.npad;
     for (int l = threadIdx.x; l < nj; l += TT) {
-      const double ax = s_fx[l], ay = s_fy[l], az = s_fz[l];
+      const double ax = s_f[3 * l], ay = s_f[3 * l + 1], az = s_f[3 * l + 2];
       if (ax != 0.0 || ay != 0.0 || az != 0.0) {
         const size_t slot = (size_t)(s_jtab[l] & MD_JMASK);
         atomicAdd(fs + slot, ax); atomicAdd(fs + np + slot, ay); atomicAdd(fs + 2 * np + slot, az);

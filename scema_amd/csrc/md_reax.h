@@ -6,12 +6,16 @@
 
 #include "reax/rx_types.h"
 struct SimDev;
-// zero the charge-equilibration history and the flags at the start of a run
+// start of a run: flags and counters; the charge-equilibration history is zeroed for the replicas that do not keep theirs (RxView::warm)
 void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad);
+// how a solve of the charge equilibration is issued as launches over the batch
+struct RxQeqPlan {
+  int launch = 0;  // conjugate-gradient iterations issued as launches over the batch (replicas that need more finish inside k_rx_qeq_finish)
+  int setup = 0;   // the solve of a run's step 0 (a replica that kept its history starts from the newest solution)
+};
 // the whole force stage of one step for the first ns replicas: (neighbour rows if the rebuild flag of the step is set,)
 // charge equilibration, bond orders, energy terms, forces into SimDev::f, virial and energies into SimScalars.
-// qeq_launch: conjugate-gradient iterations issued as launches over the batch (replicas that need more finish inside k_rx_qeq_finish)
 // terms: bit 0 bond/lone pair/over/under, 1 angles, 2 torsions, 3 hydrogen bonds, 4 non-bonded (31 = all; parity hook)
-void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int qeq_launch, int terms,
+void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, const RxQeqPlan &plan, int terms,
                      bool col16, std::vector<hipEvent_t> *sweep_events = nullptr, size_t *sweep_events_used = nullptr);
 // sweep_events: when given, a HIP-event pair is recorded around every launch of k_rx_qeq_sweep (pool grown on demand)

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
 // qpart layout (doubles): [0, 2 NV) and [2 NV, 4 NV): r.z partials of even / odd iterations; [4 NV, 6 NV): b.b partials;
 // [6 NV, 6 NV + 2 NB): d.q partials.  NV = RX_QNV (update workgroups, padded), NB = sweep workgroups = npad / RX_SWR.
 #define QEQ_TPB 1024
-#define RX_QEQ_COLD 4   /* solves of a run that count as cold (the extrapolation uses four past solutions) */
+#define RX_QEQ_COLD RX_QEQ_COLD_SOLVES
 #define QEQ_UT 256
 #define RX_QNV(npad) (((npad) + QEQ_UT - 1) / QEQ_UT)
 
@@ -248,21 +248,28 @@ __device__ __forceinline__ QeqScal qeq_scalars(const RxView &V, int it, double t
   return Q;
 }
 
-__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views) {
+// setup != 0: the solve of a run's step 0.  A replica whose history was kept from the run before (RxView::warm) stands where that
+// run's last solve stood: its guess is the newest stored solution, not the extrapolation one step ahead
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views, int setup) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * QEQ_UT + threadIdx.x;
   if (i >= V.n) return;
   const size_t np = V.npad;
   const double *sh = V.s_hist, *th = V.t_hist;
-  const double s0 = 4.0 * (sh[i] + sh[2 * np + i]) - (6.0 * sh[np + i] + sh[3 * np + i]);
-  const double t0 = 3.0 * (th[i] - th[np + i]) + th[2 * np + i];
+  const bool same_place = setup && V.warm;
+  const double s0 = same_place ? sh[i] : 4.0 * (sh[i] + sh[2 * np + i]) - (6.0 * sh[np + i] + sh[3 * np + i]);
+  const double t0 = same_place ? th[i] : 3.0 * (th[i] - th[np + i]) + th[2 * np + i];
   V.s[i] = s0; V.t[i] = t0;
   double2 *z = (double2 *)(V.qwork + 6 * np);
   z[i] = make_double2(s0, t0);
 }
 
 // it < 0: the first product H x0 of the solve (x0 sits in z), stored in q
-template <bool COL16>
+// ZLDS: the vector the rows gather from (one (s, t) pair per atom, 16 bytes) is staged in LDS first.  A workgroup's rows gather
+// ~17 000 pairs from a vector of 1 620 (PE-1620): through the caches every gather is an L2 round trip (the workgroups of a replica
+// sit on different CUs, so no L1 holds a replica's vector for long), and the kernel waited for those, not for the matrix stream.
+extern __shared__ double2 s_zl[];
+template <bool COL16, bool ZLDS>
 __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, const RxParams *P, double tol, int it) {
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -281,6 +288,10 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   }
   const size_t np = V.npad;
   const double2 *z = (const double2 *)(V.qwork + 6 * np);
+  if (ZLDS) {
+    for (int k = threadIdx.x; k < n; k += RX_KT) s_zl[k] = z[k];
+    __syncthreads();
+  }
   // the products of this workgroup's 64 rows: wave w takes the rows 8 w .. 8 w + 7, lanes over the entries of a row
   __shared__ double s_y[2][RX_SWR];
   const unsigned short *c16 = V.hcol16;
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
         // (a masked lane must not trust entry 0 of the row either: a row without neighbours inside the taper radius was never written)
         const int j = on ? (COL16 ? (int)c16[o] : c32[o]) : 0;
         const double h = on ? V.hval[o] : 0.0;
-        const double2 zj = z[j];
+        const double2 zj = ZLDS ? s_zl[j] : z[j];
         ps[q] = fma(h, zj.x, ps[q]);
         pt[q] = fma(h, zj.y, pt[q]);
       }
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   if (lane < RX_SWR && i < n) {
     ys = s_y[0][lane]; yt = s_y[1][lane];
     const double eta = P->sbp[V.rtype[i]].eta;
-    const double2 zi = z[i];
+    const double2 zi = ZLDS ? s_zl[i] : z[i];
     ys = fma(eta, zi.x, ys); yt = fma(eta, zi.y, yt);
     double2 *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np);
     if (it < 0) {
@@ -428,7 +439,7 @@ __device__ __forceinline__ void qeq_reduce2(double &a, double &b, double *lds) {
 // One workgroup per replica after `done` iterations of the launches above: a replica that has not converged yet goes on here
 // with the same recurrences on the same arrays (the result does not depend on how many iterations were issued as launches, only
 // the summation order of the scalar products differs), then q = s - (sum s / sum t) t and the history.
-__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, const RxView *views, const RxParams *P, double tol, int done, int maxiter) {
+__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, const RxView *views, const RxParams *P, double tol, int done, int maxiter, int setup) {
   const RxView V = views[blockIdx.x];
   (void)sims;
   __shared__ double s_red[32];
@@ -490,11 +501,16 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
   for (int i = tid; i < n; i += QEQ_TPB) { ss += s[i]; st += t[i]; }
   qeq_reduce2(ss, st, s_red);
   const double u = ss / st;
+  const bool same_place = setup && V.warm;   // the atoms stand where the newest stored solution was taken: it is replaced, not pushed down
   for (int i = tid; i < n; i += QEQ_TPB) {
     V.q[i] = s[i] - u * t[i];
     double *sh = V.s_hist, *th = V.t_hist;
-    sh[3 * np + i] = sh[2 * np + i]; sh[2 * np + i] = sh[np + i]; sh[np + i] = sh[i]; sh[i] = s[i];
-    th[2 * np + i] = th[np + i]; th[np + i] = th[i]; th[i] = t[i];
+    if (!same_place) {
+      sh[3 * np + i] = sh[2 * np + i]; sh[2 * np + i] = sh[np + i]; sh[np + i] = sh[i];
+      th[2 * np + i] = th[np + i]; th[np + i] = th[i];
+    }
+    sh[i] = s[i];
+    th[i] = t[i];
   }
   // what the launched sweeps of this solve read: every stored entry of the replica's rows once per sweep it took part in
   // (the launches counted by k_rx_qeq_update, plus the first product H x0)
@@ -502,15 +518,15 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
   for (int i = tid; i < n; i += QEQ_TPB) { nent += (double)V.hlen[i]; nrow += 1.0; }
   qeq_reduce2(nent, nrow, s_red);
   if (tid == 0) {
-    const long long sweeps = (long long)(V.qstat[0] - V.qstat[4]) + 1;
+    const long long sweeps = (long long)(V.qstat[0] - V.qstat[4]) + 1;   // k_rx_qeq_update counted the launched iterations; plus the first product
     V.sweep_acc[0] += sweeps * (long long)(nent + 0.5);
     V.sweep_acc[1] += sweeps * (long long)n;
-    const int total = V.qstat[0] + it;   // k_rx_qeq_update counted the launched iterations this replica took part in
+    const int total = V.qstat[0] + it;
     V.qstat[0] = total;
     V.qstat[1] += 1;
     const int mine = total - V.qstat[4];
     V.qstat[4] = total;
-    // the first solves of a run start from an empty history and take longer: their own record
+    // the first solves of a run that starts from an empty history take longer: their own record
     const int rec = (V.qstat[1] <= RX_QEQ_COLD) ? 5 : 2;
     if (mine > V.qstat[rec]) V.qstat[rec] = mine;
     if (it > 0) V.qstat[3] += 1;
@@ -763,15 +779,22 @@ __global__ void k_rx_finish(const SimDev *sims, const RxView *views) {
   sc.eng[P_COUL] = e[RX_E_COUL] + e[RX_E_POL];
   if (*V.overflow) atomicOr(&sc.overflow, (*V.overflow & 3) ? 1 : 32);
 }
-// zero the charge-equilibration history at the start of a run (a new fix qeq/reax starts from zeros)
+// Start of a run: a new fix qeq/reax starts from zeros (the reference's two LAMMPS lifetimes per evaluation each do).  The history
+// only decides where the conjugate gradients START -- the answer is fixed by the tolerance -- so a replica that continues a run
+// of the same state (RxView::warm: phase B after phase A, or the state's previous evaluation) keeps it and none of its solves
+// counts as cold.
 __global__ __launch_bounds__(TPB) void k_rx_phase_init(const RxView *views) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i < V.npad) {
+  if (i < V.npad && !V.warm) {
     for (int k = 0; k < 4; k++) V.s_hist[(size_t)k * V.npad + i] = 0.0;
     for (int k = 0; k < 3; k++) V.t_hist[(size_t)k * V.npad + i] = 0.0;
   }
-  if (i == 0) { for (int k = 0; k < 6; k++) V.qstat[k] = 0; *V.overflow = 0; V.sweep_acc[0] = 0; V.sweep_acc[1] = 0; }
+  if (i == 0) {
+    for (int k = 0; k < 6; k++) V.qstat[k] = 0;
+    if (V.warm) V.qstat[1] = RX_QEQ_COLD;
+    *V.overflow = 0; V.sweep_acc[0] = 0; V.sweep_acc[1] = 0;
+  }
 }
 
 static inline dim3 g2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)ns, 1); }
@@ -780,7 +803,7 @@ static inline int cdv(int a, int b) { return (a + b - 1) / b; }
 void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad) {
   hipLaunchKernelGGL(k_rx_phase_init, g2(cdv(maxpad, TPB), ns), dim3(TPB), 0, st, v);
 }
-void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, int qeq_launch,
+void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, const RxQeqPlan &plan,
                      int terms, bool col16, std::vector<hipEvent_t> *ev, size_t *ev_used) {
   // a HIP-event pair around every launch of the matrix sweep when the caller profiles (bench.py's roofline block)
   auto sweep = [&](int it) {
@@ -789,8 +812,12 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
       while (*ev_used + 2 > ev->size()) { hipEvent_t a; if (hipEventCreate(&a) != hipSuccess) { ev = nullptr; break; } ev->push_back(a); }
     }
     if (ev) (void)hipEventRecord((*ev)[*ev_used], st);
-    if (col16) hipLaunchKernelGGL(k_rx_qeq_sweep<true>, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
-    else hipLaunchKernelGGL(k_rx_qeq_sweep<false>, gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
+    // replicas of up to 4 096 atoms: the gathered vector in LDS (64 KB)
+    static const bool zlds_off = scema_env("SCEMA_REAX_QEQ_ZLDS") && atoi(scema_env("SCEMA_REAX_QEQ_ZLDS")) == 0;
+    const size_t lds = (size_t)((maxatoms + 63) / 64 * 64) * sizeof(double2);
+    if (col16 && lds <= 64 * 1024 && !zlds_off) hipLaunchKernelGGL((k_rx_qeq_sweep<true, true>), gk, dim3(RX_KT), lds, st, v, P, qeq_tol, it);
+    else if (col16) hipLaunchKernelGGL((k_rx_qeq_sweep<true, false>), gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
+    else hipLaunchKernelGGL((k_rx_qeq_sweep<false, false>), gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
     if (ev) { (void)hipEventRecord((*ev)[*ev_used + 1], st); *ev_used += 2; }
   };
   const dim3 ga = g2(cdv(maxatoms, TPB), ns), gr = g2(cdv(maxatoms, RX_TPB), ns), gk = g2(cdv(maxatoms, 64), ns), gu = g2(cdv(maxatoms, QEQ_UT), ns);
@@ -798,15 +825,15 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   hipLaunchKernelGGL(k_rx_wrap, ga, dim3(TPB), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_neigh, ga, dim3(TPB), 0, st, d, v, rlist);
   hipLaunchKernelGGL(k_rx_hrow, gk, dim3(RX_KT), 0, st, d, v, P);
-  hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v);
+  hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v, plan.setup);
   sweep(-1);
   hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, -1);
-  const int nlaunch = qeq_launch < qeq_maxiter ? qeq_launch : qeq_maxiter;
+  const int nlaunch = plan.launch < qeq_maxiter ? plan.launch : qeq_maxiter;
   for (int it = 0; it < nlaunch; it++) {
     sweep(it);
     hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, it);
   }
-  hipLaunchKernelGGL(k_rx_qeq_finish, dim3(ns), dim3(QEQ_TPB), 0, st, d, v, P, qeq_tol, nlaunch, qeq_maxiter);
+  hipLaunchKernelGGL(k_rx_qeq_finish, dim3(ns), dim3(QEQ_TPB), 0, st, d, v, P, qeq_tol, nlaunch, qeq_maxiter, plan.setup);
   hipLaunchKernelGGL(k_rx_bonds, g2(cdv(maxatoms, 8 * (TPB / 64)), ns), dim3(TPB), 0, st, v, P);
   hipLaunchKernelGGL(k_rx_rev, ga, dim3(TPB), 0, st, v);
   hipLaunchKernelGGL(k_rx_corr, ga, dim3(TPB), 0, st, v, P);

@@ -14,7 +14,10 @@
 #define RX_MAXANG 4          /* parameter sets per valence-angle triple */
 #define RX_NGP 40
 #define RX_KS 8               /* waves of a workgroup of the charge-equilibration kernels: 64 rows per workgroup, 8 per wave */
-#define RX_SWR 32             /* rows per workgroup of the matrix sweep (4 per wave): small workgroups, so that the tail of a launch is short */
+#define RX_QEQ_COLD_SOLVES 4   /* solves of a run that starts from an empty history which count as cold (the extrapolation uses four past solutions) */
+#ifndef RX_SWR   /* (at most 64: one wave does the row-local part of the sweep, a row per lane) */
+#define RX_SWR 64             /* rows per workgroup of the matrix sweep (8 per wave): the workgroup stages the gathered vector in LDS once for all of them (32: 400 against 410 evaluations/s, profiles/r04_e_*) */
+#endif
 #define RX_JMASK 0x00FFFFFF  /* row entry: [23:0] atom, [30:24] image code (sx+2) + 5 (sy+2) + 25 (sz+2) */
 #define RX_CODE0 62          /* code of the zero shift */
 
@@ -112,6 +115,7 @@ typedef struct {
   double *qpart;          // per-block partial sums of the solver's scalar products (layout: md_reax.hip)
   int *qstat;             // [6] since the start of the run: iterations, solves, most iterations in one solve (cold solves aside), solves
                           // finished by the single-workgroup loop, (scratch), most iterations in one of the run's first (cold) solves
+  int warm;               // the history arrays hold the solutions of the run this one continues (kept, not zeroed, at the start)
   double *eparts;         // [RX_NPART] energy parts of the step
   int mimg[3];            // neighbour search: 0,0,0 = minimum image (box at least two list radii wide), else images up to mimg[d] boxes away
   int *overflow;          // bit 1: neighbour row full, bit 2: bond row full, bit 4: charge equilibration did not converge
