@@ -174,6 +174,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
   (void)sims;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // the type-pair constants of the kernel in LDS: one dependent global load less per entry
+  // (positions and types staged in LDS as well, as the sweep does with its vector: 418.5 against 416.5 evaluations/s, not kept)
   __shared__ double s_gamma[RX_MAXT * RX_MAXT];
   if (threadIdx.x < RX_MAXT * RX_MAXT) s_gamma[threadIdx.x] = P->tbp[threadIdx.x].gamma;
   __syncthreads();

@@ -37,6 +37,34 @@ def test_exported_case_issues_the_references_command_sequence(small_pe, tmp_path
     assert "Atoms # full" in open(tmp_path / "replica.data").read()
 
 
+def test_exported_reax_case_follows_the_reax_branch(tmp_path):
+    """md_force_field "reax" (stmd_problem.h:190-194,261-264,297-302): atom_style charge data, the state as a text dump that comes
+    back through read_restart init.bin + rerun, the reax script folder"""
+    import export_lammps_case as x
+    from scema_amd import capi
+    from scema_amd.systems import synthetic_strains
+    r = x.reax_replica((2, 3, 5))
+    lens = r["box"][3:6] - r["box"][:3]
+    case = x.export_reax(str(tmp_path), r, synthetic_strains(1, lens, seed=2026)[0], "/ref/lammps_scripts_reax")
+    assert case["force_field"] == "reax" and case["dt"] == 0.25 and case["nss"] == 20 and case["nts"] % 10 == 0
+    a = open(tmp_path / "phase_a.lammps").read().splitlines()
+    want = ["include /ref/lammps_scripts_reax/in.set.lammps", "read_restart init.g0_1.bin", "variable dts equal 0.250000",
+            "include /ref/lammps_scripts_reax/in.strain.lammps", "write_dump all custom last.0.g0_1.dump id type xs ys zs vx vy vz ix iy iz"]
+    pos = [a.index(w) for w in want]
+    assert pos == sorted(pos)
+    b = open(tmp_path / "phase_b.lammps").read().splitlines()
+    want = ["read_restart init.g0_1.bin", "rerun last.0.g0_1.dump dump x y z vx vy vz ix iy iz box yes scaled yes wrapped yes format native",
+            "reset_timestep 0", "include /ref/lammps_scripts_reax/ELASTIC/in.homogenization.lammps"]
+    pos = [b.index(w) for w in want]
+    assert pos == sorted(pos)
+    # the data file is one the engine's own reader takes (atom_style charge, types H C N O = 1..4)
+    out = str(tmp_path / "o.bin")
+    assert capi.lib().scema_md_convert_lammps_data(str(tmp_path / "replica.data").encode(), out.encode(), None, None) == 0
+    from scema_amd.systems import read_replica_file
+    d = read_replica_file(out)
+    assert d["natoms"] == r["natoms"] and d["ntypes"] == 4 and sorted(set(d["type"].tolist())) == [0, 1]
+
+
 @pytest.mark.gpu
 def test_closure_verdict_on_this_host(small_pe, tmp_path):
     """runs LAMMPS where there is one ("LAMMPS-verified", 1e-4 demanded); says "invariant-verified" where there is none"""
@@ -51,3 +79,22 @@ def test_closure_verdict_on_this_host(small_pe, tmp_path):
         assert res["verdict"].startswith("invariant-verified")
     else:
         assert res["rel_err_vs_lammps"]["gpu"] < 1e-4, res["verdict"]
+
+
+@pytest.mark.gpu
+def test_reax_closure_verdict_on_this_host(tmp_path):
+    """the reax case: both variants of the valence-angle gradient are evaluated; with a LAMMPS (USER-REAXC) the closer one is named and
+    1e-4 is demanded of it, without one the verdict says so"""
+    import export_lammps_case as x
+    from scema_amd.systems import synthetic_strains
+    r = x.reax_replica((3, 5, 9))
+    lens = r["box"][3:6] - r["box"][:3]
+    res = x.verify_reax(str(tmp_path), r, synthetic_strains(1, lens, seed=2026)[0], os.environ.get("SCEMA_SCRIPTS_REAX", "/root/reference/lammps_scripts/lammps_scripts_reax"))
+    print(res["verdict"])
+    assert res["gpu_exact"] is not None and res["gpu_drop_dsbo2"] is not None
+    dev = np.abs(np.array(res["gpu_exact"]) - np.array(res["gpu_drop_dsbo2"])).max() / np.abs(np.array(res["gpu_exact"])).max()
+    assert dev > 1e-6          # the two variants are different answers: only LAMMPS can say which is the reference's
+    if res["lammps"] is None:
+        assert res["verdict"].startswith("invariant-verified")
+    else:
+        assert min(res["rel_err_vs_lammps"][k] for k in ("gpu_exact", "gpu_drop_dsbo2")) < 1e-4, res["verdict"]
