@@ -83,6 +83,22 @@ def kd_order(idx, x):
     return kd_order(o[:nl], x) + kd_order(o[nl:], x)
 
 
+def greedy_order(idx, x):
+    """alternative cluster formation (--clusters greedy): the remaining atom farthest from the others' centroid and its three nearest"""
+    out, rem = [], set(int(i) for i in idx)
+    while len(rem) > 4:
+        arr = np.array(sorted(rem)); P = x[arr]
+        s = arr[((P - P.mean(0)) ** 2).sum(1).argmax()]
+        grp = arr[np.argsort(((P - x[s]) ** 2).sum(1), kind="stable")[:4]]
+        out += [int(g) for g in grp]
+        rem -= set(int(g) for g in grp)
+    return out + sorted(rem)
+
+
+ORDER_IN_CELL = {"kd": kd_order, "greedy": greedy_order}
+CLUSTERS = {"how": "kd"}
+
+
 def build_rows(box, x0, ei, ej):
     """-> per cluster: atoms[4] (-1 pad), and row = (jatom, shift[3], mask) arrays in table order, plus segment ids"""
     lo, hi = box[:3], box[3:6]
@@ -101,7 +117,7 @@ def build_rows(box, x0, ei, ej):
     slot_atoms, cell_start = [], [0]
     for cc in range(ncell):
         idx = np.nonzero(cell == cc)[0]
-        o = kd_order(idx, xw)
+        o = ORDER_IN_CELL[CLUSTERS["how"]](idx, xw)
         o += [-1] * ((-len(o)) % 4)
         slot_atoms += o
         cell_start.append(len(slot_atoms))
@@ -240,7 +256,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--therm", type=int, default=300)
     ap.add_argument("--cache", default="/tmp/gate_traj.npz")
+    ap.add_argument("--clusters", default="kd", choices=["kd", "greedy"], help="how a cell's atoms are grouped into 4-atom clusters (kd: as k_cell_sort does)")
     args = ap.parse_args()
+    CLUSTERS["how"] = args.clusters
     life = [0, 5, 10, 15]
     box, snaps, ei, ej = trajectory(args.therm, life, args.cache)
     t0 = time.time()
