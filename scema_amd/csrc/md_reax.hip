@@ -185,11 +185,38 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
     const size_t base = (size_t)i * V.maxnb;
     const double *grow = s_gamma + V.rtype[i] * RX_MAXT;
     int len = 0, lown = 0;
+    // The row walk as a pipeline: the list entries two chunks ahead, the partner's position and type one chunk ahead, the arithmetic
+    // of rx_qeq_entry (reax/rx_core.h, same operations in the same order) on the chunk whose operands have arrived.  Written as
+    // load -> gather -> compute per chunk, every chunk waited for two dependent memory round trips (12 chunks per row).
+    const double xi0 = V.x[3 * i], xi1 = V.x[3 * i + 1], xi2 = V.x[3 * i + 2];
+    const double swb2 = P->swb * P->swb;
+    auto load_ent = [&](int k0) -> int { const int k = k0 + lane; return (k < cnt) ? V.nbT[base + k] : -1; };
+    int e1 = load_ent(0), e2 = load_ent(64);
+    double p0, p1, p2;
+    int tjn;
+    { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
     for (int k0 = 0; k0 < cnt; k0 += 64) {
-      const int k = k0 + lane;
-      int col = 0, ent = 0;
+      const int ent = e1;
+      const double q0 = p0, q1 = p1, q2 = p2;
+      const int tj = tjn;
+      e1 = e2;
+      { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
+      e2 = load_ent(k0 + 128);
+      int col = 0;
       double h = -1.0;
-      if (k < cnt) { ent = V.nbT[base + k]; h = rx_qeq_entry(P, &V, i, ent, &col, grow); }
+      if (ent >= 0) {
+        double sh[3];
+        rx_shift(&V, ent, sh);
+        col = ent & RX_JMASK;
+        const double d0 = q0 - xi0 + sh[0], d1 = q1 - xi1 + sh[1], d2 = q2 - xi2 + sh[2];
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+        if (!(r2 > swb2)) {
+          const double rr = sqrt(r2);
+          double dTap;
+          const double Tap = rx_taper(P, rr, &dTap);
+          h = Tap * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * rr + grow[tj]);
+        }
+      }
       const unsigned long long m = __ballot(h >= 0.0);
       if (h >= 0.0) {
         const size_t o = base + len + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -655,6 +682,44 @@ __global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims,
   }
   rx_flush(e, w, V, *sims[blockIdx.y].sc, PASS == 4 ? P_LJ : (PASS == 1 ? P_ANGLE : (PASS == 2 ? P_DIHEDRAL : (PASS == 3 ? P_IMPROPER : P_BOND))));
 }
+// The torsion pass with a lane per WORK ITEM (first leg j-i, central bond j-k; reax/rx_core.h rx_torsion_item) instead of a lane per atom:
+// with a lane per atom only the atoms that own a central bond work -- a third of the lanes of a hydrocarbon, each walking its nine
+// torsions one after the other at 256 registers.  A workgroup takes RX_TORS_ATOMS atoms, lists their items in LDS (an LDS counter; the
+// order of the list, and with it the order of the atomic sums, varies from run to run as every atomic sum here does) and then
+// puts its lanes over the list.  Items beyond the list's capacity (a denser system than any tested) are done where they are found.
+#define RX_TORS_ATOMS 256
+#define RX_TORS_CAP 2048
+__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const SimDev *sims, const RxView *views, const RxParams *P) {
+  const RxView V = views[blockIdx.y];
+  if ((int)(blockIdx.x * RX_TORS_ATOMS) >= V.n) return;
+  __shared__ int s_items[RX_TORS_CAP];
+  __shared__ int s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  double e[RX_NPART], w[6];
+#pragma unroll
+  for (int k = 0; k < RX_NPART; k++) e[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) w[k] = 0.0;
+  const int j0 = blockIdx.x * RX_TORS_ATOMS, j = j0 + threadIdx.x;
+  if (j < V.n) {
+    const int cnt = V.bd_cnt[j];
+    for (int ak = 0; ak < cnt; ak++)
+      for (int ai = 0; ai < cnt; ai++)
+        if (rx_torsion_item_valid(&V, j, ak, ai)) {
+          const int pos = atomicAdd(&s_n, 1);
+          if (pos < RX_TORS_CAP) s_items[pos] = (int)(((unsigned)threadIdx.x << 24) | ((unsigned)ak << 12) | (unsigned)ai);   // (rows hold far fewer than 4 096 bonds)
+          else rx_torsion_item(P, &V, j, ak, ai, e, w);
+        }
+  }
+  __syncthreads();
+  const int nitems = min(s_n, RX_TORS_CAP);
+  for (int it = threadIdx.x; it < nitems; it += RX_TORS_ATOMS) {
+    const unsigned c = (unsigned)s_items[it];
+    rx_torsion_item(P, &V, j0 + (int)(c >> 24), (int)((c >> 12) & 0xFFF), (int)(c & 0xFFF), e, w);
+  }
+  rx_flush(e, w, V, *sims[blockIdx.y].sc, P_DIHEDRAL);
+}
 // tapered van der Waals + shielded Coulomb over the full neighbour rows, RX_KS waves per row
 __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded(const SimDev *sims, const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
@@ -708,15 +773,25 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims,
     const double qi = RX_C_ELE * V.q[i];
     const double xi0 = V.x[3 * i], xi1 = V.x[3 * i + 1], xi2 = V.x[3 * i + 2];
     double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+    // (the same pipeline as the matrix build: entries two chunks ahead, the partner's record one chunk ahead)
+    auto load_ent = [&](int c0) -> int { const int c = c0 + lane; return (c < len) ? V.hown[base + c] : -1; };
+    int e1 = load_ent(0), e2 = load_ent(64);
+    double p0, p1, p2, pq;
+    int ptj;
+    { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; pq = V.q[j]; ptj = V.rtype[j]; }
     for (int c0 = 0; c0 < len; c0 += 64) {
-      const int c = c0 + lane;
-      if (c < len) {
-        const int ent = V.hown[base + c], j = ent & RX_JMASK;
+      const int ent = e1, tj = ptj;
+      const double x0 = p0, x1 = p1, x2 = p2, qj = pq;
+      e1 = e2;
+      { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; pq = V.q[j]; ptj = V.rtype[j]; }
+      e2 = load_ent(c0 + 128);
+      if (ent >= 0) {
+        const int j = ent & RX_JMASK;
         double sh[3];
         rx_shift(&V, ent, sh);
-        const double d0 = V.x[3 * j] - xi0 + sh[0], d1 = V.x[3 * j + 1] - xi1 + sh[1], d2 = V.x[3 * j + 2] - xi2 + sh[2];
+        const double d0 = x0 - xi0 + sh[0], d1 = x1 - xi1 + sh[1], d2 = x2 - xi2 + sh[2];
         double ev, ec, sc_;
-        rx_nonbonded_pair(P, &s_tbp[ti * RX_MAXT + V.rtype[j]], qi * V.q[j], d0 * d0 + d1 * d1 + d2 * d2, &ev, &ec, &sc_);
+        rx_nonbonded_pair(P, &s_tbp[ti * RX_MAXT + tj], qi * qj, d0 * d0 + d1 * d1 + d2 * d2, &ev, &ec, &sc_);
         e[RX_E_VDW] += ev; e[RX_E_COUL] += ec;
         const double g0 = sc_ * d0, g1 = sc_ * d1, g2 = sc_ * d2;   // force on i; the partner takes the opposite
         f0 += g0; f1 += g1; f2 += g2;
@@ -840,7 +915,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   hipLaunchKernelGGL(k_rx_corr, ga, dim3(TPB), 0, st, v, P);
   if (terms & 1) hipLaunchKernelGGL(k_rx_terms<0>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 2) hipLaunchKernelGGL(k_rx_terms<1>, gr, dim3(RX_TPB), 0, st, d, v, P);
-  if (terms & 4) hipLaunchKernelGGL(k_rx_terms<2>, gr, dim3(RX_TPB), 0, st, d, v, P);
+  if (terms & 4) hipLaunchKernelGGL(k_rx_torsions, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P);
   if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 16) {
     static const bool once_off = scema_env("SCEMA_MD_RX_NB_ONCE") && atoi(scema_env("SCEMA_MD_RX_NB_ONCE")) == 0;   // (test switch: the both-ends kernel)

@@ -510,38 +510,45 @@ RX_FN void rx_angle_terms(const RxParams *P, const RxView *V, int j, double *eng
 RX_FN void rx_cross(const double *a, const double *b, double *c) {
   c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
 }
-RX_FN void rx_torsion_terms(const RxParams *P, const RxView *V, int j, double *eng, double *vir) {
-  const int np = V->npad, tj = V->rtype[j], cnt = V->bd_cnt[j];
+// Whether (j, ak, ai) is a work item of the torsion pass: ak a bond j-k that j owns with a partner row to come back through, ai another
+// bond j-i of j, both above the bond-order cutoff
+RX_FN int rx_torsion_item_valid(const RxView *V, int j, int ak, int ai) {
+  const int np = V->npad;
+  if (ai == ak) return 0;
+  const size_t ojk = (size_t)ak * np + j, oij = (size_t)ai * np + j;
+  if (!rx_owns(j, V->bd[ojk]) || !(V->bd_bo[ojk] > RX_THB_CUT) || V->bd_rev[ojk] < 0) return 0;
+  return V->bd_bo[oij] > RX_THB_CUT;
+}
+// One work item: the torsions i-j-k-l over all bonds k-l of k, for the first leg j-i (ai) and the central bond j-k (ak) of atom j.
+// Everything it adds to shared places is atomic (other items reach the same bonds and atoms); the sums over a central bond's items
+// (dE/dBO_jk, dE/dBO_pi_jk, dE/dDelta, forces on j and k) therefore leave per item.  The GPU puts a lane on an item
+// (k_rx_torsions compacts the items of a block of atoms first); rx_torsion_terms below is the same work atom by atom.
+RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, int ai, double *eng, double *vir) {
+  const int np = V->npad, tj = V->rtype[j];
   const size_t plane = (size_t)V->maxbd * np;
   const double p_tor2 = P->gp[23], p_tor3 = P->gp[24], p_tor4 = P->gp[25], p_cot2 = P->gp[27];
   RxAtomD J;
   rx_atom_deltas(P, tj, V->total_bo[j], &J);
-  for (int ak = 0; ak < cnt; ak++) {
-    const size_t ojk = (size_t)ak * np + j;
-    const int ejk = V->bd[ojk];
-    if (!rx_owns(j, ejk)) continue;
-    const double bo_jk = V->bd_bo[ojk];
-    if (!(bo_jk > RX_THB_CUT)) continue;
-    double q[3];   // j -> k
-    const int k = rx_partner(V, j, ejk, q);
-    const int tk = V->rtype[k], cntk = V->bd_cnt[k], rev = V->bd_rev[ojk];
-    if (rev < 0) continue;
-    const double r_jk = V->bd_bop[3 * plane + ojk], bpi_jk = V->bd_bo[plane + ojk];
-    RxAtomD K;
-    rx_atom_deltas(P, tk, V->total_bo[k], &K);
-    const double BOA_jk = bo_jk - RX_THB_CUT;
-    const double exp_tor2_jk = exp(-p_tor2 * BOA_jk), exp_cot2_jk = exp(-p_cot2 * RX_SQR(BOA_jk - 1.5));
-    const double DjDk = J.Delta_boc + K.Delta_boc;
-    const double exp_tor3 = exp(-p_tor3 * DjDk), exp_tor4 = exp(p_tor4 * DjDk), trm34 = 1.0 + exp_tor3 + exp_tor4;
-    const double f11 = (2.0 + exp_tor3) / trm34;
-    const double Cf11 = (-p_tor3 * exp_tor3 * trm34 - (2.0 + exp_tor3) * (-p_tor3 * exp_tor3 + p_tor4 * exp_tor4)) / (trm34 * trm34);
-    const double mq[3] = {-q[0], -q[1], -q[2]};
-    double g_jk = 0.0, gpi_jk = 0.0, cdd = 0.0, fj[3] = {0, 0, 0}, fk[3] = {0, 0, 0};
-    for (int ai = 0; ai < cnt; ai++) {
-      if (ai == ak) continue;
+  const size_t ojk = (size_t)ak * np + j;
+  const int ejk = V->bd[ojk];
+  const double bo_jk = V->bd_bo[ojk];
+  double q[3];   // j -> k
+  const int k = rx_partner(V, j, ejk, q);
+  const int tk = V->rtype[k], cntk = V->bd_cnt[k], rev = V->bd_rev[ojk];
+  const double r_jk = V->bd_bop[3 * plane + ojk], bpi_jk = V->bd_bo[plane + ojk];
+  RxAtomD K;
+  rx_atom_deltas(P, tk, V->total_bo[k], &K);
+  const double BOA_jk = bo_jk - RX_THB_CUT;
+  const double exp_tor2_jk = exp(-p_tor2 * BOA_jk), exp_cot2_jk = exp(-p_cot2 * RX_SQR(BOA_jk - 1.5));
+  const double DjDk = J.Delta_boc + K.Delta_boc;
+  const double exp_tor3 = exp(-p_tor3 * DjDk), exp_tor4 = exp(p_tor4 * DjDk), trm34 = 1.0 + exp_tor3 + exp_tor4;
+  const double f11 = (2.0 + exp_tor3) / trm34;
+  const double Cf11 = (-p_tor3 * exp_tor3 * trm34 - (2.0 + exp_tor3) * (-p_tor3 * exp_tor3 + p_tor4 * exp_tor4)) / (trm34 * trm34);
+  const double mq[3] = {-q[0], -q[1], -q[2]};
+  double g_jk = 0.0, gpi_jk = 0.0, cdd = 0.0, fj[3] = {0, 0, 0}, fk[3] = {0, 0, 0};
+  {
       const size_t oij = (size_t)ai * np + j;
       const double bo_ij = V->bd_bo[oij];
-      if (!(bo_ij > RX_THB_CUT)) continue;
       double p[3];   // j -> i
       const int eij = V->bd[oij];
       const int i = rx_partner(V, j, eij, p);
@@ -642,15 +649,19 @@ RX_FN void rx_torsion_terms(const RxParams *P, const RxView *V, int j, double *e
         rx_vt(vir, q, fkk);
         rx_vt(vir, qs, fl);
       }
-      RX_ATOMIC_ADD(&V->bd_g[oij], g_ij);   // other lanes reach this row as their far bond in the same pass
+      RX_ATOMIC_ADD(&V->bd_g[oij], g_ij);   // other items reach this row as their far bond in the same pass
       for (int m = 0; m < 3; m++) RX_ATOMIC_ADD(&V->f[3 * i + m], fi[m]);
-    }
-    RX_ATOMIC_ADD(&V->bd_g[ojk], g_jk);
-    RX_ATOMIC_ADD(&V->bd_g[plane + ojk], gpi_jk);
-    RX_ATOMIC_ADD(&V->cd_delta[j], cdd);
-    RX_ATOMIC_ADD(&V->cd_delta[k], cdd);
-    for (int m = 0; m < 3; m++) { RX_ATOMIC_ADD(&V->f[3 * j + m], fj[m]); RX_ATOMIC_ADD(&V->f[3 * k + m], fk[m]); }
   }
+  if (g_jk != 0.0) RX_ATOMIC_ADD(&V->bd_g[ojk], g_jk);
+  if (gpi_jk != 0.0) RX_ATOMIC_ADD(&V->bd_g[plane + ojk], gpi_jk);
+  if (cdd != 0.0) { RX_ATOMIC_ADD(&V->cd_delta[j], cdd); RX_ATOMIC_ADD(&V->cd_delta[k], cdd); }
+  for (int m = 0; m < 3; m++) { RX_ATOMIC_ADD(&V->f[3 * j + m], fj[m]); RX_ATOMIC_ADD(&V->f[3 * k + m], fk[m]); }
+}
+RX_FN void rx_torsion_terms(const RxParams *P, const RxView *V, int j, double *eng, double *vir) {
+  const int cnt = V->bd_cnt[j];
+  for (int ak = 0; ak < cnt; ak++)
+    for (int ai = 0; ai < cnt; ai++)
+      if (rx_torsion_item_valid(V, j, ak, ai)) rx_torsion_item(P, V, j, ak, ai, eng, vir);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
