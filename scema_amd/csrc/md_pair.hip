@@ -784,7 +784,16 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
         for (int a = 0; a < NI; a++) {
           if (!(mask & (1 << a))) continue;
           const double dx = xi[a] - xs, dy = yi[a] - ys, dz = zi[a] - zs;
+#if defined(PAIR_WHATIF_FMA)    // sensitivity experiment (never in a product build): eight more dependent FP64 FMAs per distance block
+          double rsq = dx * dx + dy * dy + dz * dz;
+          { double t_ = rsq; _Pragma("unroll") for (int q_ = 0; q_ < 8; q_++) t_ = fma(t_, 1.0e-300, rsq); asm volatile("" : "+v"(t_)); rsq = t_; }
+#elif defined(PAIR_WHATIF_INT)  // ... or eight more dependent 32-bit integer operations
+          double rsq = dx * dx + dy * dy + dz * dz;
+          { int t_ = __double2loint(rsq); _Pragma("unroll") for (int q_ = 0; q_ < 8; q_++) { t_ = (t_ ^ 0x5bd1e995) + q_; asm volatile("" : "+v"(t_)); }
+            int lo_ = __double2loint(rsq); asm volatile("" : "+v"(lo_) : "v"(t_)); rsq = __hiloint2double(__double2hiint(rsq), lo_); }   // (a dependency, not a change)
+#else
           const double rsq = dx * dx + dy * dy + dz * dz;
+#endif
 #ifdef PAIR_COUNT
           { const unsigned long long b = __ballot(true); pc_dist += 1; if (lane == __ffsll((long long)b) - 1) pc_blk += 1; }
           if (rsq < cutl2) { const unsigned long long b = __ballot(true); pc_lj += 1; if (lane == __ffsll((long long)b) - 1) pc_ljblk += 1; }
@@ -851,6 +860,9 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
         }
         const int l = e & E_LMASK;
         lds_add(&s_f[3 * l], gx); lds_add(&s_f[3 * l + 1], gy); lds_add(&s_f[3 * l + 2], gz);
+#ifdef PAIR_WHATIF_ATOMICS   // sensitivity experiment (never in a product build): every LDS atomic of the row loop issued twice
+        lds_add(&s_f[3 * l], 0.0); lds_add(&s_f[3 * l + 1], 0.0); lds_add(&s_f[3 * l + 2], 0.0);
+#endif
       }
       k0 += 64;
       if (r < nrows && k0 >= nn) {

@@ -24,6 +24,8 @@
 #include "md_types.h"
 #include "reax/rx_core.h"
 
+// LDS FP64 atomic add without return value (ds_add_f64)
+__device__ __forceinline__ void lds_add_f64(double *p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define RX_TPB 128
 #ifndef RX_OCC
 #define RX_OCC 2   /* waves per SIMD the term kernels are compiled for (the torsion pass would take 300 VGPRs unbounded: one wave per SIMD) */
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(TPB) void k_rx_corr(const RxView *views, const RxPa
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i < V.n) rx_bonds_corrected(P, &V, i);
 }
-// pass: 0 atom terms, 1 angles, 2 torsions, 3 hydrogen bonds (4, non-bonded: k_rx_nonbonded)
+// pass: 0 atom terms, 3 hydrogen bonds (angles: k_rx_angles, torsions: k_rx_torsions, non-bonded: k_rx_nonbonded_once / k_rx_nonbonded)
 template <int PASS>
 __global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims, const RxView *views, const RxParams *P) {
   const RxView V = views[blockIdx.y];
@@ -676,8 +678,6 @@ __global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims,
   for (int k = 0; k < 6; k++) w[k] = 0.0;
   if (i < V.n) {
     if (PASS == 0) rx_atom_terms(P, &V, i, e);
-    if (PASS == 1) rx_angle_terms(P, &V, i, e, w);
-    if (PASS == 2) rx_torsion_terms(P, &V, i, e, w);
     if (PASS == 3) rx_hbond_terms(P, &V, i, e, w);
   }
   rx_flush(e, w, V, *sims[blockIdx.y].sc, PASS == 4 ? P_LJ : (PASS == 1 ? P_ANGLE : (PASS == 2 ? P_DIHEDRAL : (PASS == 3 ? P_IMPROPER : P_BOND))));
@@ -719,6 +719,62 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const Sim
     rx_torsion_item(P, &V, j0 + (int)(c >> 24), (int)((c >> 12) & 0xFFF), (int)(c & 0xFFF), e, w);
   }
   rx_flush(e, w, V, *sims[blockIdx.y].sc, P_DIHEDRAL);
+}
+// The valence-angle pass the same way: a lane per ANGLE (reax/rx_core.h rx_angle_item).  What an atom's angles share (rx_angle_pre) is
+// computed by the atom's thread first and read from LDS by the items; what they sum for the atom (force on it, dE/dDelta, dE/dSBO)
+// meets in LDS accumulators and is fed back by the atom's thread (rx_angle_post) after a barrier.
+__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDev *sims, const RxView *views, const RxParams *P) {
+  const RxView V = views[blockIdx.y];
+  if ((int)(blockIdx.x * RX_TORS_ATOMS) >= V.n) return;
+  __shared__ int s_items[RX_TORS_CAP];
+  __shared__ int s_n;
+  __shared__ double s_sbo[2][RX_TORS_ATOMS];   // SBO2, CSBO2 of the block's atoms
+  __shared__ double s_sum[5][RX_TORS_ATOMS];   // cdd, f[3], dE/dSBO
+  if (threadIdx.x == 0) s_n = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) s_sum[k][threadIdx.x] = 0.0;
+  __syncthreads();
+  double e[RX_NPART], w[6];
+#pragma unroll
+  for (int k = 0; k < RX_NPART; k++) e[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) w[k] = 0.0;
+  const int j0 = blockIdx.x * RX_TORS_ATOMS, j = j0 + threadIdx.x;
+  RxAnglePre A;
+  const bool has = j < V.n && rx_angle_pre(P, &V, j, &A);
+  if (has) {
+    s_sbo[0][threadIdx.x] = A.SBO2; s_sbo[1][threadIdx.x] = A.CSBO2;
+    const int cnt = V.bd_cnt[j];
+    for (int ai = 0; ai < cnt; ai++)
+      for (int ak = ai + 1; ak < cnt; ak++)
+        if (rx_angle_item_valid(&V, j, ai, ak)) {
+          const int pos = atomicAdd(&s_n, 1);
+          if (pos < RX_TORS_CAP) s_items[pos] = (int)(((unsigned)threadIdx.x << 24) | ((unsigned)ai << 12) | (unsigned)ak);
+          else {   // (a denser system than any tested: done where it is found)
+            RxAngleSum S = {0.0, {0.0, 0.0, 0.0}, 0.0};
+            rx_angle_item(P, &V, j, ai, ak, A.SBO2, A.CSBO2, &S, e, w);
+            lds_add_f64(&s_sum[0][threadIdx.x], S.cdd); lds_add_f64(&s_sum[1][threadIdx.x], S.f[0]); lds_add_f64(&s_sum[2][threadIdx.x], S.f[1]);
+            lds_add_f64(&s_sum[3][threadIdx.x], S.f[2]); lds_add_f64(&s_sum[4][threadIdx.x], S.dE_dSBO);
+          }
+        }
+  }
+  __syncthreads();
+  const int nitems = min(s_n, RX_TORS_CAP);
+  for (int it = threadIdx.x; it < nitems; it += RX_TORS_ATOMS) {
+    const unsigned c = (unsigned)s_items[it];
+    const int jl = (int)(c >> 24);
+    RxAngleSum S = {0.0, {0.0, 0.0, 0.0}, 0.0};
+    rx_angle_item(P, &V, j0 + jl, (int)((c >> 12) & 0xFFF), (int)(c & 0xFFF), s_sbo[0][jl], s_sbo[1][jl], &S, e, w);
+    lds_add_f64(&s_sum[0][jl], S.cdd); lds_add_f64(&s_sum[1][jl], S.f[0]); lds_add_f64(&s_sum[2][jl], S.f[1]);
+    lds_add_f64(&s_sum[3][jl], S.f[2]); lds_add_f64(&s_sum[4][jl], S.dE_dSBO);
+  }
+  __syncthreads();
+  if (has) {
+    RxAngleSum S;
+    S.cdd = s_sum[0][threadIdx.x]; S.f[0] = s_sum[1][threadIdx.x]; S.f[1] = s_sum[2][threadIdx.x]; S.f[2] = s_sum[3][threadIdx.x]; S.dE_dSBO = s_sum[4][threadIdx.x];
+    rx_angle_post(&V, j, &A, &S);
+  }
+  rx_flush(e, w, V, *sims[blockIdx.y].sc, P_ANGLE);
 }
 // tapered van der Waals + shielded Coulomb over the full neighbour rows, RX_KS waves per row
 __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded(const SimDev *sims, const RxView *views, const RxParams *P) {
@@ -914,7 +970,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   hipLaunchKernelGGL(k_rx_rev, ga, dim3(TPB), 0, st, v);
   hipLaunchKernelGGL(k_rx_corr, ga, dim3(TPB), 0, st, v, P);
   if (terms & 1) hipLaunchKernelGGL(k_rx_terms<0>, gr, dim3(RX_TPB), 0, st, d, v, P);
-  if (terms & 2) hipLaunchKernelGGL(k_rx_terms<1>, gr, dim3(RX_TPB), 0, st, d, v, P);
+  if (terms & 2) hipLaunchKernelGGL(k_rx_angles, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P);
   if (terms & 4) hipLaunchKernelGGL(k_rx_torsions, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P);
   if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 16) {

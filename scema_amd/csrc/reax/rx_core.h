@@ -365,14 +365,18 @@ RX_FN void rx_dcos(const double *a, double ra, const double *b, double rb, doubl
 // ------------------------------------------------------------------------------------------------------------------
 // pass 3b: valence angle, penalty and three-body conjugation with central atom j (Valence_Angles)
 // ------------------------------------------------------------------------------------------------------------------
-RX_FN void rx_angle_terms(const RxParams *P, const RxView *V, int j, double *eng, double *vir) {
+// The valence-angle pass in three parts, so that the GPU can put a lane on every ANGLE (k_rx_angles lists the (first bond, second bond)
+// items of a block of atoms) instead of walking a central atom's angles on one lane: what the angles of an atom share (rx_angle_pre),
+// one angle i-j-k (rx_angle_item), and what the sums over an atom's angles feed back (rx_angle_post).  rx_angle_terms is the same
+// work atom by atom (host driver, and the reference for the split).
+typedef struct { double SBO2, CSBO2, dSBO1, dSBO_dDelta; } RxAnglePre;
+typedef struct { double cdd, f[3], dE_dSBO; } RxAngleSum;   // over the angles of one central atom
+RX_FN int rx_angle_pre(const RxParams *P, const RxView *V, int j, RxAnglePre *A) {
   const int np = V->npad, tj = V->rtype[j], cnt = V->bd_cnt[j];
   const size_t plane = (size_t)V->maxbd * np;
-  if (cnt < 2) return;
-  const RxSbp *sj = &P->sbp[tj];
+  if (cnt < 2) return 0;
   const double *gp = P->gp;
-  const double p_val6 = gp[14], p_val8 = gp[33], p_val9 = gp[16], p_val10 = gp[17];
-  const double p_pen2 = gp[19], p_pen3 = gp[20], p_pen4 = gp[21], p_coa2 = gp[2], p_coa3 = gp[38], p_coa4 = gp[30];
+  const double p_val8 = gp[33], p_val9 = gp[16];
   RxAtomD J;
   rx_atom_deltas(P, tj, V->total_bo[j], &J);
   double SBOp = 0.0, prod = 1.0;
@@ -383,41 +387,59 @@ RX_FN void rx_angle_terms(const RxParams *P, const RxView *V, int j, double *eng
     double t8 = bo * bo; t8 *= t8; t8 *= t8;
     prod *= exp(-t8);
   }
-  double vlpadj, dSBO_dDelta;   // d(SBO)/d(Delta_j)
+  double vlpadj;
   if (J.vlpex >= 0.0) {
     vlpadj = 0.0;
-    dSBO_dDelta = P->lammps_dsbo2 ? 0.0 : (prod - 1.0);
+    A->dSBO_dDelta = P->lammps_dsbo2 ? 0.0 : (prod - 1.0);
   } else {
     vlpadj = J.nlp;
-    dSBO_dDelta = (prod - 1.0) * (1.0 - p_val8 * J.dDelta_lp);
+    A->dSBO_dDelta = (prod - 1.0) * (1.0 - p_val8 * J.dDelta_lp);
   }
   const double SBO = SBOp + (1.0 - prod) * (-J.Delta_boc - p_val8 * vlpadj);
-  const double dSBO1 = -8.0 * prod * (J.Delta_boc + p_val8 * vlpadj);   // d(SBO)/d(BO_n) = dSBO1 BO_n^7
-  double SBO2, CSBO2;
-  if (SBO <= 0.0) { SBO2 = 0.0; CSBO2 = 0.0; }
-  else if (SBO <= 1.0) { SBO2 = pow(SBO, p_val9); CSBO2 = p_val9 * pow(SBO, p_val9 - 1.0); }
-  else if (SBO < 2.0) { SBO2 = 2.0 - pow(2.0 - SBO, p_val9); CSBO2 = p_val9 * pow(2.0 - SBO, p_val9 - 1.0); }
-  else { SBO2 = 2.0; CSBO2 = 0.0; }
+  A->dSBO1 = -8.0 * prod * (J.Delta_boc + p_val8 * vlpadj);   // d(SBO)/d(BO_n) = dSBO1 BO_n^7
+  if (SBO <= 0.0) { A->SBO2 = 0.0; A->CSBO2 = 0.0; }
+  else if (SBO <= 1.0) { A->SBO2 = pow(SBO, p_val9); A->CSBO2 = p_val9 * pow(SBO, p_val9 - 1.0); }
+  else if (SBO < 2.0) { A->SBO2 = 2.0 - pow(2.0 - SBO, p_val9); A->CSBO2 = p_val9 * pow(2.0 - SBO, p_val9 - 1.0); }
+  else { A->SBO2 = 2.0; A->CSBO2 = 0.0; }
+  return 1;
+}
+// (ai < ak) is an angle of atom j when both bond orders pass the cutoffs of Valence_Angles
+RX_FN int rx_angle_item_valid(const RxView *V, int j, int ai, int ak) {
+  const int np = V->npad;
+  if (!(ai < ak)) return 0;
+  const double bo_i = V->bd_bo[(size_t)ai * np + j], bo_k = V->bd_bo[(size_t)ak * np + j];
+  return bo_i - RX_THB_CUT > 0.0 && bo_k - RX_THB_CUT > 0.0 && bo_i > RX_THB_CUT && bo_k > RX_THB_CUT && bo_i * bo_k > RX_THB_CUTSQ;
+}
+// one angle i-j-k: energies, dE/dBO of its two bonds (atomic: the items of an atom run on different lanes), forces on i and k, the
+// virial; what it adds to the central atom's sums comes back in S (added to, not set)
+RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int ak, double SBO2, double CSBO2, RxAngleSum *S, double *eng, double *vir) {
+  const int np = V->npad, tj = V->rtype[j];
+  const size_t plane = (size_t)V->maxbd * np;
+  const RxSbp *sj = &P->sbp[tj];
+  const double *gp = P->gp;
+  const double p_val6 = gp[14], p_val10 = gp[17];
+  const double p_pen2 = gp[19], p_pen3 = gp[20], p_pen4 = gp[21], p_coa2 = gp[2], p_coa3 = gp[38], p_coa4 = gp[30];
+  RxAtomD J;
+  rx_atom_deltas(P, tj, V->total_bo[j], &J);
   const double expval6 = exp(p_val6 * J.Delta_boc);
-  double cdd_j = 0.0, fj[3] = {0, 0, 0}, dE_dSBO = 0.0;
-  for (int ai = 0; ai < cnt; ai++) {
+  double cdd_j = 0.0, dE_dSBO = 0.0;
+  double *fj = S->f;
+  {
     const size_t oi = (size_t)ai * np + j;
     const double bo_i = V->bd_bo[oi], BOA_ij = bo_i - RX_THB_CUT;
-    if (!(BOA_ij > 0.0)) continue;
     double dji[3];
     const int i = rx_partner(V, j, V->bd[oi], dji);
     const double r_ij = V->bd_bop[3 * plane + oi];
     const int ti = V->rtype[i];
-    for (int ak = ai + 1; ak < cnt; ak++) {
+    {
       const size_t ok = (size_t)ak * np + j;
       const double bo_k = V->bd_bo[ok], BOA_jk = bo_k - RX_THB_CUT;
-      if (!(BOA_jk > 0.0 && bo_i > RX_THB_CUT && bo_k > RX_THB_CUT && bo_i * bo_k > RX_THB_CUTSQ)) continue;
       double djk[3];
       const int k = rx_partner(V, j, V->bd[ok], djk);
       const double r_jk = V->bd_bop[3 * plane + ok];
       const int tk = V->rtype[k];
       const RxThbp *th = &P->thbp[(ti * RX_MAXT + tj) * RX_MAXT + tk];
-      if (th->cnt == 0) continue;
+      if (th->cnt == 0) return;
       double cos_t;
       const double theta = rx_angle(dji, r_ij, djk, r_jk, &cos_t);
       double sin_t = sin(theta);
@@ -472,8 +494,8 @@ RX_FN void rx_angle_terms(const RxParams *P, const RxView *V, int j, double *eng
         RX_ATOMIC_ADD(&V->cd_delta[i], -2.0 * p_coa3 * (tbi - BOA_ij) * e_coa);
         RX_ATOMIC_ADD(&V->cd_delta[k], -2.0 * p_coa3 * (tbk - BOA_jk) * e_coa);
       }
-      V->bd_g[oi] += g_i;
-      V->bd_g[ok] += g_k;
+      RX_ATOMIC_ADD(&V->bd_g[oi], g_i);
+      RX_ATOMIC_ADD(&V->bd_g[ok], g_k);
       // geometry: dE/dtheta -> forces on i, j, k
       const double ce = -dE_dtheta / sin_t;   // dE/dcos
       double da[3], db[3], fi[3], fk[3];
@@ -488,20 +510,37 @@ RX_FN void rx_angle_terms(const RxParams *P, const RxView *V, int j, double *eng
       rx_vt(vir, djk, fk);
     }
   }
-  // SBO feeds every bond of j and Delta_j
-  if (dE_dSBO != 0.0) {
+  S->cdd += cdd_j;
+  S->dE_dSBO += dE_dSBO;
+}
+// SBO feeds every bond of j and Delta_j; the force on j
+RX_FN void rx_angle_post(const RxView *V, int j, const RxAnglePre *A, const RxAngleSum *S) {
+  const int np = V->npad, cnt = V->bd_cnt[j];
+  const size_t plane = (size_t)V->maxbd * np;
+  double cdd_j = S->cdd;
+  if (S->dE_dSBO != 0.0) {
     for (int a = 0; a < cnt; a++) {
       const size_t o = (size_t)a * np + j;
       const double bo = V->bd_bo[o];
       double b7 = bo * bo * bo; b7 = b7 * b7 * bo;
-      V->bd_g[o] += dE_dSBO * dSBO1 * b7;
-      V->bd_g[plane + o] += dE_dSBO;
-      V->bd_g[2 * plane + o] += dE_dSBO;
+      RX_ATOMIC_ADD(&V->bd_g[o], S->dE_dSBO * A->dSBO1 * b7);
+      RX_ATOMIC_ADD(&V->bd_g[plane + o], S->dE_dSBO);
+      RX_ATOMIC_ADD(&V->bd_g[2 * plane + o], S->dE_dSBO);
     }
-    cdd_j += dE_dSBO * dSBO_dDelta;
+    cdd_j += S->dE_dSBO * A->dSBO_dDelta;
   }
   RX_ATOMIC_ADD(&V->cd_delta[j], cdd_j);
-  for (int m = 0; m < 3; m++) RX_ATOMIC_ADD(&V->f[3 * j + m], fj[m]);
+  for (int m = 0; m < 3; m++) RX_ATOMIC_ADD(&V->f[3 * j + m], S->f[m]);
+}
+RX_FN void rx_angle_terms(const RxParams *P, const RxView *V, int j, double *eng, double *vir) {
+  RxAnglePre A;
+  if (!rx_angle_pre(P, V, j, &A)) return;
+  RxAngleSum S = {0.0, {0.0, 0.0, 0.0}, 0.0};
+  const int cnt = V->bd_cnt[j];
+  for (int ai = 0; ai < cnt; ai++)
+    for (int ak = ai + 1; ak < cnt; ak++)
+      if (rx_angle_item_valid(V, j, ai, ak)) rx_angle_item(P, V, j, ai, ak, A.SBO2, A.CSBO2, &S, eng, vir);
+  rx_angle_post(V, j, &A, &S);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
