@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "md_device.h"
 #include "md_env.h"
@@ -135,6 +136,19 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// min of two finite doubles as ONE instruction (fmin() quiets signalling NaNs first: a v_max_f64 x, x per operand)
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// distance of a coordinate from an interval [lo, hi] (0 inside): max(0, lo - x, x - hi)
+__device__ __forceinline__ double box_excess(double lo, double hi, double x) { return vmax_f64(0.0, vmax_f64(lo - x, x - hi)); }
 // block-wide sum of NV values per thread over the TW waves of a tile workgroup, atomically added to dst[0..NV)
 template <int NV>
 __device__ __forceinline__ void tile_atomic_add(double (&vals)[NV], double *dst, double *lds /* >= NV*TW */) {
@@ -355,14 +369,13 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     for (int i = 0; i < NB_UPW; i++) {
       const double xj = px[i] + s_shift[3 * cv[i]], yj = py[i] + s_shift[3 * cv[i] + 1], zj = pz[i] + s_shift[3 * cv[i] + 2];
       {
-        const double ex = fmax(0.0, fmax(blo0 - xj, xj - bhi0)), ey = fmax(0.0, fmax(blo1 - yj, yj - bhi1)), ez = fmax(0.0, fmax(blo2 - zj, zj - bhi2));
+        const double ex = box_excess(blo0, bhi0, xj), ey = box_excess(blo1, bhi1, yj), ez = box_excess(blo2, bhi2, zj);
         ok[i] = valid[i] && (home[i] || ex * ex + ey * ey + ez * ez < rl2);
       }
       okq[i] = 0;
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
-        const double ex = fmax(0.0, fmax(s_qbox[q][0] - xj, xj - s_qbox[q][3])), ey = fmax(0.0, fmax(s_qbox[q][1] - yj, yj - s_qbox[q][4])),
-                     ez = fmax(0.0, fmax(s_qbox[q][2] - zj, zj - s_qbox[q][5]));
+        const double ex = box_excess(s_qbox[q][0], s_qbox[q][3], xj), ey = box_excess(s_qbox[q][1], s_qbox[q][4], yj), ez = box_excess(s_qbox[q][2], s_qbox[q][5], zj);
         okq[i] |= (ok[i] && ex * ex + ey * ey + ez * ez < rl2) ? (1u << q) : 0u;
       }
       m[i] = __ballot(ok[i]);
@@ -483,6 +496,8 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     if (lane == 0) { atomicAdd(&sc.dbg[10], (unsigned long long)((nl + 63) >> 6)); atomicAdd(&sc.dbg[11], 1ull); }
 #endif
     bool own_chunks = true;
+    auto row_loop = [&](auto cref_tag) __attribute__((always_inline)) {
+    constexpr bool CREF = decltype(cref_tag)::value;
     for (int base = 0; base < nl; base += 64) {
       const int l = l_n;
       const int jt = jt_n;
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
 
       int mask = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
-      double rmin = 1.0e300;
+      double r2a[NI];
       // (pad atoms of the cluster sit beyond 1e15, each pad slot at its own place: never inside the list radius of anything; lanes past the end of the list are cleared below; the
       // nearest of the four distances stands for the nearest ACCEPTED one: beyond the list radius it decides nothing, and otherwise it
       // can only be too small, which moves the entry to a nearer segment -- always allowed)
@@ -512,9 +527,10 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
         const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
         const double r2 = dx * dx + dy * dy + dz * dz;
         mask |= (r2 < S.rlist2) ? (1 << a) : 0;
-        if (count_ref) refm |= (r2 < S.rlist_ref2) ? (1 << a) : 0;
-        rmin = fmin(rmin, r2);
+        if (CREF) refm |= (r2 < S.rlist_ref2) ? (1 << a) : 0;
+        r2a[a] = r2;
       }
+      const double rmin = vmin_f64(vmin_f64(r2a[0], r2a[1]), vmin_f64(r2a[2], r2a[3]));
       if (!in) { mask = 0; refm = 0; }
       if (own_chunks) {   // (wave-uniform: the entries of the own cell come first in the table and in every list)
         // same cell, same image: each pair once, by slot order -- atom a of the cluster keeps j only if j > s0slot + a.  One mask per
@@ -557,8 +573,12 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       }
       { const int ns = __popcll(mS), nd = __popcll(mD); nA += __popcll(mA); nB += __popcll(mB); nC += ns - nd; nD += nd; }
       npairs += __popc(mask);
-      if (count_ref) npairs_ref += __popc(refm);
+      if (CREF) npairs_ref += __popc(refm);
     }
+    };
+    // (the second count is a statistic of a run's first build: its own copy of the loop, so that every other build does not pay for
+    // four compares per candidate that the compiler would otherwise keep as predicated code)
+    if (count_ref) row_loop(std::true_type{}); else row_loop(std::false_type{});
     const int n = nA + nB + nC + nD;
     const bool bad = nB + nC + nD > capB || n > maxrow;
     if (bad) over = 1;
