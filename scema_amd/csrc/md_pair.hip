@@ -821,6 +821,8 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
 #endif
           if (CLE && !ENG) {
             if (rsq < cutl2) {
+              // (1/r^2 from the reciprocal estimate + one Newton step in the blocks no lane of which is inside the coulomb cutoff -- 3 FP64
+              // instructions instead of 7 in half of the LJ blocks -- was measured a third time in round 4: 8.34 / 8.37 against 8.32 / 8.26 ms)
               const double rinv = rsqrt_f64(rsq);
               const double r2inv = rinv * rinv;
               const double r6inv = r2inv * r2inv * r2inv;
