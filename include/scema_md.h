@@ -166,9 +166,8 @@ int scema_md_write_lammps_restart(const char *path, const scema_md_system *sys, 
  * A failed call leaves the state store and the owner directory as it found them -- ON EVERY RANK when a communicator is
  * attached (the ranks learn of each other's failure inside the call and all roll back): states that had already been
  * advanced are put back from their backups (the reference stops the whole run at this point, exit(1)).  Without a
- * communicator the guarantee is this rank's only: a rank whose own share succeeded has committed it by the time the
- * caller's collective (scema_md_scatter_gathered) reports that another rank failed; such a run must be treated as the
- * reference treats it -- stopped -- or restarted from its last checkpoint files, not retried.
+ * communicator a rank whose own share succeeded learns of another rank's failure only in the caller's collective: its share
+ * waits for that (scema_md_settle_update below) and is taken back there.
  * What the ranks must share for their plans to agree: the same replicas registered, the same request vectors, and every
  * call that edits the state store (set_state, drop_state, load_state_file, equilibrate) made on every rank. */
 int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims, int32_t hooke,
@@ -218,6 +217,11 @@ int scema_md_copy_local_stress(scema_md_engine *e, void *dst, int32_t dst_on_dev
  * rank's status word and plan hash (an error here is an error on every rank), then fill sims[i].stress /
  * stress_updated for every i by the plan of the last scema_md_strain_batch (rank-0 bookkeeping of stmd_sync.h:698-725) */
 int scema_md_scatter_gathered(scema_md_engine *e, const double *gathered, scema_mdsim *sims, int32_t n_sims);
+/* Without a communicator an update of a world of several ranks WAITS after scema_md_strain_batch (backups kept, owner directory
+ * uncommitted) until the caller's collective has shown every rank's status word: scema_md_scatter_gathered settles it (an error
+ * there takes this rank's share back too); a host that scatters the gathered buffer itself calls this with failed != 0 / 0.  The
+ * next scema_md_strain_batch lets an unsettled update stand. */
+int scema_md_settle_update(scema_md_engine *e, int32_t failed);
 
 /* The planner alone (scema_amd/csrc/host/sim_plan.h; pure host arithmetic, no GPU): owner/pos/cap as above, moves =
  * (simulation, from, to) triples of the states that would travel; cost NULL = equal cost; commit != 0 records the

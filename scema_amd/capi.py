@@ -29,7 +29,7 @@ SYMBOLS = [
     "scema_md_probe_lammps_restart", "scema_md_read_lammps_restart_atoms", "scema_md_load_lammps_restart",
     "scema_md_convert_lammps_restart", "scema_md_write_lammps_restart",
     "scema_md_strain_batch", "scema_md_strain", "scema_md_local_stress_device_ptr",
-    "scema_md_local_stress_count", "scema_md_local_result_doubles", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_has_state", "scema_md_get_state",
+    "scema_md_local_stress_count", "scema_md_local_result_doubles", "scema_md_copy_local_stress", "scema_md_scatter_gathered", "scema_md_settle_update", "scema_md_has_state", "scema_md_get_state",
     "scema_md_set_state", "scema_md_drop_state", "scema_md_save_state_file", "scema_md_load_state_file", "scema_md_save_state_lammps",
     "scema_md_init_material", "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile", "scema_md_env_overrides",
     "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",

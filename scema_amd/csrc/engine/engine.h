@@ -175,6 +175,20 @@ struct ActiveSim {
   double box0[9], skin0 = 0.0;   // box and list skin of the state before the update (a failed update puts them back)
 };
 
+// A state object that an update stored under a key, with what it displaced (undone if the update fails)
+struct CreatedState { std::string key; std::unique_ptr<State> displaced; };
+// An update that ran on this rank WITHOUT a communicator in a world of several ranks: whether it stands is only known once the caller's
+// collective has shown every rank's status word (scema_md_scatter_gathered / scema_md_settle_update).  Until then the advanced states keep
+// their backups and the owner directory stays uncommitted.
+struct PendingUpdate {
+  bool active = false;
+  std::vector<ActiveSim> act;         // the simulations whose states were advanced (backups at pool offsets 0 .. act.size() - 1)
+  std::vector<CreatedState> created;
+  scema::SimPlan plan;
+  std::vector<std::string> dst_keys;
+  int rank = 0;
+};
+
 // One process per GPU: the communicator of the engine.  RCCL (xGMI) for the GPU box, or transport callbacks of the host
 // program (MPI in SCEMa, gloo in the CPU tests).  Replaces the MPI calls of stmd_sync.h:620-726.
 struct Comm {
@@ -289,6 +303,7 @@ struct scema_md_engine {
   Comm comm;
   scema::OwnerDirectory dir;   // state key -> owning rank, identical on every rank (host/sim_plan.h)
   scema::SimPlan last_plan;
+  PendingUpdate pending;
 };
 
 namespace scema_eng {
@@ -330,6 +345,7 @@ bool deform_trajectory(const double *box0, const double *rates, double dt, int n
 double wall_s();
 double round_trip(const char *fmt, double v);
 // engine_run.cpp / engine_reax.cpp
+int settle_pending(scema_md_engine *e, bool failed);
 int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncells, int nk, int capj);
 int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &spec);
 int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &spec);

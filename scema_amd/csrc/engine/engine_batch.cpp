@@ -131,9 +131,43 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
   return fail(e, SCEMA_MD_ERR_OVERFLOW, "neighbour capacity exceeded after regrowth");
 }
 
+// the update that is waiting for the caller's collective (PendingUpdate): it stands (owners committed, stale copies dropped) or it
+// never happened (states back to their backups, new states gone, directory as it was)
+int settle_pending(scema_md_engine *e, bool failed) {
+  PendingUpdate &P = e->pending;
+  if (!P.active) return SCEMA_MD_OK;
+  P.active = false;
+  if (failed) {
+    if (!P.act.empty()) {
+      (void)backup_states(e, P.act, true, 0);
+      (void)hipStreamSynchronize(e->stream);
+    }
+    for (auto it = P.created.rbegin(); it != P.created.rend(); ++it) {
+      if (it->displaced) e->states[it->key] = std::move(it->displaced);
+      else e->states.erase(it->key);
+    }
+  } else {
+    e->dir.commit(P.plan, P.dst_keys);
+    for (size_t i = 0; i < P.dst_keys.size(); i++)
+      if (P.plan.owner[i] != P.rank) e->states.erase(P.dst_keys[i]);
+  }
+  P.act.clear();
+  P.created.clear();
+  P.dst_keys.clear();
+  return SCEMA_MD_OK;
+}
+
 }  // namespace scema_eng
 
 extern "C" {
+
+/* The caller's collective has shown the status words of every rank (scema_md_scatter_gathered calls this itself; a host that
+ * scatters on its own -- STMDSync::share_stresses over its callback -- says so here): failed != 0 takes this rank's share of the last
+ * update back, 0 lets it stand.  Without a pending update (communicator attached, single rank, Hooke mode) nothing happens. */
+int scema_md_settle_update(scema_md_engine *e, int32_t failed) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  return settle_pending(e, failed != 0);
+}
 
 // ---- the hot path ----
 // straining steps of a request (stmd_problem.h:213-232) for a box of the given lengths
@@ -165,6 +199,7 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     if (!collective_call) return fail(e, SCEMA_MD_ERR_DEVICE, "hipSetDevice(%d) failed", e->p.device);
     pre_status = fail(e, SCEMA_MD_ERR_DEVICE, "hipSetDevice(%d) failed on rank %d", e->p.device, rank);
   }
+  (void)settle_pending(e, false);    // an update nobody objected to stands
   e->last_plan = scema::SimPlan();   // a call that ends before planning leaves no plan behind
   // ---- the request itself: checked on every rank for every simulation, so that a request that cannot run is refused by
   // all ranks together, before anything is planned or moved ----
@@ -266,8 +301,7 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   }
   // ---- this rank's share ----
   std::vector<ActiveSim> act;
-  struct Created { std::string key; std::unique_ptr<State> displaced; };
-  std::vector<Created> created;
+  std::vector<CreatedState> created;
   auto undo = [&]() {   // a failed update leaves the state store as it found it (the reference stops before write_restart)
     for (auto it = created.rbegin(); it != created.rend(); ++it) {
       if (it->displaced) e->states[it->key] = std::move(it->displaced);
@@ -376,6 +410,19 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   }
   // ---- bookkeeping: every state now lives under its own key on the rank that ran it; stale copies elsewhere go ----
   if (!hooke_mode && world > 1) {
+    if (!e->comm.kind) {
+      // no communicator: whether the other ranks' shares succeeded is only known after the caller's collective.  The update waits
+      // (backups kept, directory uncommitted) for scema_md_scatter_gathered / scema_md_settle_update -- or for the next call, which
+      // lets it stand (only the failing rank used to roll back on this transport)
+      PendingUpdate &P = e->pending;
+      P.active = true;
+      P.act.assign(act.begin(), act.begin() + n_advanced);
+      P.created = std::move(created);
+      P.plan = plan;
+      P.dst_keys = dst_keys;
+      P.rank = rank;
+      return SCEMA_MD_OK;
+    }
     e->dir.commit(plan, dst_keys);
     for (int i = 0; i < n_sims; i++)
       if (plan.owner[i] != rank) e->states.erase(dst_keys[i]);
@@ -417,6 +464,7 @@ int scema_md_scatter_gathered(scema_md_engine *e, const double *gathered, scema_
   for (int i = 0; i < n_sims; i++) sims[i].stress_updated = 0;
   // this rank's own failure was reported by scema_md_strain_batch already; here: somebody else's, or a plan mismatch
   const int rc = check_gathered_trailers(e, gathered, cnt, cnt - SCEMA_MD_RESULT_TRAILER, plan.world, -1, "during the update");
+  (void)settle_pending(e, rc != 0);   // another rank failed (or the plans differ): this rank's share goes back as well
   if (rc) return rc;
   for (int i = 0; i < n_sims; i++) {
     const double *src = gathered + ((size_t)plan.owner[i] * cnt + 6 * (size_t)plan.pos[i]);

@@ -301,6 +301,7 @@ class STMDSync {
         for (int r = 0; r < world_; r++)
           if (all[r] != 0.0) {
             if (r == rank_ && rc_exec) return rc_exec;   // err_ is set
+            (void)scema_md_settle_update(engine_, 1);   // this rank may have run its share: it did not happen
             return fail((int)all[r], "rank " + std::to_string(r) + " could not plan this update (code " + std::to_string((int)all[r]) + "): the update is abandoned on every rank");
           }
       }
@@ -311,15 +312,22 @@ class STMDSync {
           for (int k = 0; k < 6; k++) local[6 * (size_t)pos[i] + k] = md_simulations[i].stress.raw[k];
       local[cnt - 2] = (double)rc_exec;   // the MD path sends the engine's device buffer, which carries the same word
       int rc = allgather_(ag_ctx_, md ? engine_ : nullptr, local.data(), (int)cnt, gathered.data());
-      if (rc) return fail(SCEMA_MD_ERR_DEVICE, "all-gather of the stresses failed");
-      if (rc_exec) return rc_exec;   // err_ is set
+      if (rc) { if (md) (void)scema_md_settle_update(engine_, 1); return fail(SCEMA_MD_ERR_DEVICE, "all-gather of the stresses failed"); }
+      if (rc_exec) return rc_exec;   // err_ is set (and the engine has taken this rank's share back already)
+      // the engine's share of this rank is waiting for the verdict of the collective (scema_md_settle_update): it is taken back
+      // when any rank failed or the plans differ, and stands otherwise
       for (int r = 0; r < world_; r++)
-        if (gathered[r * cnt + cnt - 2] != 0.0)
+        if (gathered[r * cnt + cnt - 2] != 0.0) {
+          if (md) (void)scema_md_settle_update(engine_, 1);
           return fail((int)gathered[r * cnt + cnt - 2], "rank " + std::to_string(r) + " failed during the update (code " +
                       std::to_string((int)gathered[r * cnt + cnt - 2]) + "): the update is abandoned on every rank");
+        }
       for (int r = 1; r < world_; r++)
-        if (gathered[r * cnt + cnt - 1] != gathered[cnt - 1])
+        if (gathered[r * cnt + cnt - 1] != gathered[cnt - 1]) {
+          if (md) (void)scema_md_settle_update(engine_, 1);
           return fail(SCEMA_MD_ERR_ARG, "ranks 0 and " + std::to_string(r) + " computed different plans for this update");
+        }
+      if (md) (void)scema_md_settle_update(engine_, 0);
       for (int i = 0; i < n; i++) {
         const double *src = gathered.data() + ((size_t)owner[i] * cnt + (size_t)pos[i] * 6);
         for (int k = 0; k < 6; k++) md_simulations[i].stress.raw[k] = src[k];

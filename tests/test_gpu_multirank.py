@@ -114,6 +114,51 @@ def test_without_a_communicator_a_remote_source_state_is_an_error(small_pe):
     eng.close()
 
 
+def test_callback_transport_takes_this_ranks_share_back_when_another_rank_failed(small_pe):
+    """rank 0 of 2 without a communicator runs its share successfully; the caller's collective then shows that rank 1
+    failed.  scema_md_scatter_gathered reports it AND this rank's share did not happen: the states it created are gone, the state it
+    advanced stands where it stood, and the owner directory is uncommitted -- a retry of the same update then gives the same stresses."""
+    import ctypes as C
+    from scema_amd import capi
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+
+    def gathered_with(status_of_rank1):
+        n = eng.local_result_doubles()
+        mine = np.zeros(n)
+        eng.copy_local_stress(mine.ctypes.data, False)
+        g = np.stack([mine, mine.copy()])
+        g[1, -2] = status_of_rank1
+        return g
+
+    # update 1: fresh batch; rank 1 "succeeds": the update stands
+    sims = [capi.make_sim(q, "pe", 1, st, nss=10, most_recent=capi.QP_NONE) for q in range(4)]
+    out = eng.strain_batch(sims, rank=0, world=2)
+    eng.scatter_gathered(gathered_with(0.0), out)
+    assert eng.has_state(0, "pe", 1) and eng.has_state(2, "pe", 1)
+    x_before = eng.get_state(0, "pe", 1)[1].copy()
+    first = np.array(list(out[0].stress))
+    # update 2: rank 0's share runs, rank 1 "fails" (status 7): this rank's share goes back
+    sims2 = [capi.make_sim(q, "pe", 1, st, nss=10, most_recent=q) for q in range(4)] + [capi.make_sim(8, "pe", 1, st, nss=10, most_recent=capi.QP_NONE)]
+    out2 = eng.strain_batch(sims2, rank=0, world=2)
+    mine_new = eng.last_plan(5)[0][4] == 0                                          # does the planner give the new point to this rank?
+    assert out2[0].stress_updated and eng.has_state(8, "pe", 1) == mine_new         # (done, and waiting for the verdict)
+    second = np.array(list(out2[0].stress))
+    with pytest.raises(capi.EngineError, match="rank 1"):
+        eng.scatter_gathered(gathered_with(7.0), out2)
+    assert not eng.has_state(8, "pe", 1)                                            # the state the update created is gone
+    assert np.array_equal(eng.get_state(0, "pe", 1)[1], x_before)                   # the state it advanced is where it was
+    # the retry is the same update again: same stresses (to the FP64 atomics' summation noise), and it stands this time
+    out3 = eng.strain_batch(sims2, rank=0, world=2)
+    eng.scatter_gathered(gathered_with(0.0), out3)
+    third = np.array(list(out3[0].stress))
+    assert np.abs(third - second).max() < 1e-8 * np.abs(second).max() and np.abs(second - first).max() > 1e-6 * np.abs(first).max()
+    assert eng.has_state(8, "pe", 1) == mine_new and not np.array_equal(eng.get_state(0, "pe", 1)[1], x_before)
+    eng.close()
+
+
 _RCCL_ONE = r"""
 import sys
 import numpy as np
