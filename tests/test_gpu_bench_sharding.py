@@ -116,6 +116,22 @@ def test_reax_replica_set_bench_line():
     assert 300 < r["stored_entries_per_row"] < 1100 and 2 < r["qeq_iterations_per_solve"] < 80
 
 
+def test_default_run_carries_the_reax_leg_and_reports_environment_switches():
+    """the default line's second leg (BASELINE config 5 as config.reax, outside `value`), forced on for a small OPLS batch; and a run
+    with a declared switch set says so in config.env_overrides (a clean run: an empty list)"""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--reax-leg", "on"] + COMMON, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", SCEMA_MD_SPLIT="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["env_overrides"] == ["SCEMA_MD_SPLIT=0"]
+    x = out["config"]["reax"]
+    assert "error" not in x, x
+    assert x["n_sims"] == 72 and x["atoms_per_replica"] == 1620 and x["md_steps_per_eval"] == 30.0 and x["evals_per_s"] > 0
+    assert abs(x["replica_steps_per_s"] - 30.0 * x["evals_per_s"]) < 1e-6 * x["replica_steps_per_s"]
+    assert x["roofline"]["kernel"].startswith("k_rx_qeq_sweep") and 0.0 < x["roofline"]["frac"] < 1.0
+    assert out["value"] > 0 and out["config"]["force_field"] == "opls"          # the headline is the OPLS loop's, untouched by the leg
+
+
 def test_one_pass_step_tail_equals_the_three_kernels():
     """k_finish (assembly of f + fix shake + second half-kick in one pass, the default for small batches of PPPM / no k-space steps) against
     k_ewald_force + k_shake + k_final_integrate (SCEMA_MD_FUSED_TAIL=0), and the one-launch cell binning against the three-kernel
