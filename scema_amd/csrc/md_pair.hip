@@ -807,6 +807,11 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
 #if defined(PAIR_WHATIF_FMA)    // sensitivity experiment (never in a product build): eight more dependent FP64 FMAs per distance block
           double rsq = dx * dx + dy * dy + dz * dz;
           { double t_ = rsq; _Pragma("unroll") for (int q_ = 0; q_ < 8; q_++) t_ = fma(t_, 1.0e-300, rsq); asm volatile("" : "+v"(t_)); rsq = t_; }
+#elif defined(PAIR_WHATIF_FMA_ILP)   // ... the same eight FMAs as four independent chains of two
+          double rsq = dx * dx + dy * dy + dz * dz;
+          { double t0_ = rsq, t1_ = dx, t2_ = dy, t3_ = dz;
+            _Pragma("unroll") for (int q_ = 0; q_ < 2; q_++) { t0_ = fma(t0_, 1.0e-300, rsq); t1_ = fma(t1_, 1.0e-300, rsq); t2_ = fma(t2_, 1.0e-300, rsq); t3_ = fma(t3_, 1.0e-300, rsq); }
+            asm volatile("" : "+v"(t0_), "+v"(t1_), "+v"(t2_), "+v"(t3_)); rsq = t0_; }
 #elif defined(PAIR_WHATIF_INT)  // ... or eight more dependent 32-bit integer operations
           double rsq = dx * dx + dy * dy + dz * dz;
           { int t_ = __double2loint(rsq); _Pragma("unroll") for (int q_ = 0; q_ < 8; q_++) { t_ = (t_ ^ 0x5bd1e995) + q_; asm volatile("" : "+v"(t_)); }
