@@ -41,6 +41,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_QCAP16", "capacity of k_neigh_build's group lists in sixteenths of the table: small values force the whole-table walk"},
     {"SCEMA_MD_RX_COL32", "32-bit column indices in the ReaxFF charge matrix whatever the replica size"},
     {"SCEMA_MD_RX_NB_ONCE", "0: the both-ends ReaxFF non-bonded kernel"},
+    {"SCEMA_MD_RX_ITEMCAP", "capacity of the work-item lists of the ReaxFF angle and torsion kernels: small values force their in-place path"},
     // diagnostics: print, never change a result
     {"SCEMA_MD_TIMING", "per-chunk wall times and the PAIR_TIMING / PAIR_COUNT counters on stderr"},
 };

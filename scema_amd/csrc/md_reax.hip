@@ -15,6 +15,8 @@
 //   k_rx_bonds ... k_rx_back2  bond orders, energy terms, reverse-mode forces (reax/rx_core.h)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdlib>
 
 #include "md_device.h"
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims,
 // puts its lanes over the list.  Items beyond the list's capacity (a denser system than any tested) are done where they are found.
 #define RX_TORS_ATOMS 256
 #define RX_TORS_CAP 2048
-__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const SimDev *sims, const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const SimDev *sims, const RxView *views, const RxParams *P, int cap) {
   const RxView V = views[blockIdx.y];
   if ((int)(blockIdx.x * RX_TORS_ATOMS) >= V.n) return;
   __shared__ int s_items[RX_TORS_CAP];
@@ -708,12 +710,12 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const Sim
       for (int ai = 0; ai < cnt; ai++)
         if (rx_torsion_item_valid(&V, j, ak, ai)) {
           const int pos = atomicAdd(&s_n, 1);
-          if (pos < RX_TORS_CAP) s_items[pos] = (int)(((unsigned)threadIdx.x << 24) | ((unsigned)ak << 12) | (unsigned)ai);   // (rows hold far fewer than 4 096 bonds)
+          if (pos < cap) s_items[pos] = (int)(((unsigned)threadIdx.x << 24) | ((unsigned)ak << 12) | (unsigned)ai);   // (rows hold far fewer than 4 096 bonds)
           else rx_torsion_item(P, &V, j, ak, ai, e, w);
         }
   }
   __syncthreads();
-  const int nitems = min(s_n, RX_TORS_CAP);
+  const int nitems = min(s_n, cap);
   for (int it = threadIdx.x; it < nitems; it += RX_TORS_ATOMS) {
     const unsigned c = (unsigned)s_items[it];
     rx_torsion_item(P, &V, j0 + (int)(c >> 24), (int)((c >> 12) & 0xFFF), (int)(c & 0xFFF), e, w);
@@ -723,7 +725,7 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const Sim
 // The valence-angle pass the same way: a lane per ANGLE (reax/rx_core.h rx_angle_item).  What an atom's angles share (rx_angle_pre) is
 // computed by the atom's thread first and read from LDS by the items; what they sum for the atom (force on it, dE/dDelta, dE/dSBO)
 // meets in LDS accumulators and is fed back by the atom's thread (rx_angle_post) after a barrier.
-__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDev *sims, const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDev *sims, const RxView *views, const RxParams *P, int cap) {
   const RxView V = views[blockIdx.y];
   if ((int)(blockIdx.x * RX_TORS_ATOMS) >= V.n) return;
   __shared__ int s_items[RX_TORS_CAP];
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDe
       for (int ak = ai + 1; ak < cnt; ak++)
         if (rx_angle_item_valid(&V, j, ai, ak)) {
           const int pos = atomicAdd(&s_n, 1);
-          if (pos < RX_TORS_CAP) s_items[pos] = (int)(((unsigned)threadIdx.x << 24) | ((unsigned)ai << 12) | (unsigned)ak);
+          if (pos < cap) s_items[pos] = (int)(((unsigned)threadIdx.x << 24) | ((unsigned)ai << 12) | (unsigned)ak);
           else {   // (a denser system than any tested: done where it is found)
             RxAngleSum S = {0.0, {0.0, 0.0, 0.0}, 0.0};
             rx_angle_item(P, &V, j, ai, ak, A.SBO2, A.CSBO2, &S, e, w);
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDe
         }
   }
   __syncthreads();
-  const int nitems = min(s_n, RX_TORS_CAP);
+  const int nitems = min(s_n, cap);
   for (int it = threadIdx.x; it < nitems; it += RX_TORS_ATOMS) {
     const unsigned c = (unsigned)s_items[it];
     const int jl = (int)(c >> 24);
@@ -970,8 +972,10 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   hipLaunchKernelGGL(k_rx_rev, ga, dim3(TPB), 0, st, v);
   hipLaunchKernelGGL(k_rx_corr, ga, dim3(TPB), 0, st, v, P);
   if (terms & 1) hipLaunchKernelGGL(k_rx_terms<0>, gr, dim3(RX_TPB), 0, st, d, v, P);
-  if (terms & 2) hipLaunchKernelGGL(k_rx_angles, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P);
-  if (terms & 4) hipLaunchKernelGGL(k_rx_torsions, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P);
+  // (test hook: a small item list forces the in-place path of the two item kernels)
+  static const int item_cap = scema_env("SCEMA_MD_RX_ITEMCAP") ? std::max(0, std::min(RX_TORS_CAP, atoi(scema_env("SCEMA_MD_RX_ITEMCAP")))) : RX_TORS_CAP;
+  if (terms & 2) hipLaunchKernelGGL(k_rx_angles, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P, item_cap);
+  if (terms & 4) hipLaunchKernelGGL(k_rx_torsions, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P, item_cap);
   if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, st, d, v, P);
   if (terms & 16) {
     static const bool once_off = scema_env("SCEMA_MD_RX_NB_ONCE") && atoi(scema_env("SCEMA_MD_RX_NB_ONCE")) == 0;   // (test switch: the both-ends kernel)

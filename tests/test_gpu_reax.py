@@ -327,18 +327,21 @@ def test_fallback_kernels_of_large_replicas_equal_the_default_ones():
             "e.reax_configure(FFIELD, qeq_tol=1e-10)\n"
             "e.register_replica('m', 1, capi.reax_system(sym, x, box))\n"
             "r = e.reax_compute('m', 1)\n"
-            "print(json.dumps({'f': np.asarray(r['f']).ravel().tolist(), 'w': np.asarray(r['w']).ravel().tolist(), 'vdw': float(r['e']['vdw']), 'coul': float(r['e']['coul']), 'pol': float(r['e']['pol'])}))\n")
+            "print(json.dumps(dict({'f': np.asarray(r['f']).ravel().tolist(), 'w': np.asarray(r['w']).ravel().tolist()}, **{k: float(v) for k, v in r['e'].items()})))\n")
     out = {}
-    for name, env in (("once", {}), ("both_ends", {"SCEMA_MD_RX_NB_ONCE": "0"}), ("col32", {"SCEMA_MD_RX_COL32": "1"})):
+    for name, env in (("once", {}), ("both_ends", {"SCEMA_MD_RX_NB_ONCE": "0"}), ("col32", {"SCEMA_MD_RX_COL32": "1"}),
+                      ("items_in_place", {"SCEMA_MD_RX_ITEMCAP": "0"}), ("items_mixed", {"SCEMA_MD_RX_ITEMCAP": "100"})):
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr[-2000:]
         out[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     a = out["once"]
     fa = np.array(a["f"])
     # (the third run stores the columns of the charge-equilibration matrix as 32-bit indices, as replicas beyond 65 536 atoms do)
-    for name in ("both_ends", "col32"):
+    # (the last two give the angle and torsion kernels an item list of 0 / 100 entries per 256 atoms, so that their work items are
+    # done where they are found -- the path of a system denser than any tested -- entirely / for the items beyond the list)
+    for name in ("both_ends", "col32", "items_in_place", "items_mixed"):
         b = out[name]
         assert np.abs(fa - np.array(b["f"])).max() < 1e-10 * np.abs(fa).max(), name
         assert np.abs(np.array(a["w"]) - np.array(b["w"])).max() < 1e-10 * np.abs(np.array(a["w"])).max(), name
-        for k in ("vdw", "coul", "pol"):
+        for k in ("vdw", "coul", "pol", "angle", "pen", "coa", "tors", "conj"):
             assert abs(a[k] - b[k]) < 1e-10 * max(1.0, abs(a[k])), (name, k)
