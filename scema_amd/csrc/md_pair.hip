@@ -725,7 +725,9 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     if (pr < nrows) {
       // the row is contiguous ([A|B|C1|C2], k_neigh_build): scalar row base + a 32-bit byte offset per lane
       const GLOBAL_AS char *row = (const GLOBAL_AS char *)(neigh + (size_t)pcl * maxrow);
-      v = *(const GLOBAL_AS int *)(row + (4u * (unsigned)pk + lane4));
+      // (an EMPTY row -- a cluster without a listed neighbour: a lone molecule in a large box -- still takes one turn of the stream; its
+      // memory holds whatever an earlier build left there, so it reads nothing.  The test is on the scalar unit.)
+      if (pk < pnn) v = *(const GLOBAL_AS int *)(row + (4u * (unsigned)pk + lane4));
       pk += 64;
       if (pk >= pnn) {
         pr += 1;

@@ -75,6 +75,32 @@ def test_uncharged_atomic_system_no_kspace_no_shake():
     eng.close()
 
 
+def test_lone_atom_has_an_empty_row_and_feels_nothing():
+    """A cluster WITHOUT a listed neighbour (an atom 43 A from the others, alone in its cell): its row is empty, and k_pair must read
+    nothing of the memory the row sits in -- which, in a reused slot, holds a crystal's entries (round 4: the prefetch reads whole chunks
+    without lane masks; an empty row's one turn of the stream is guarded on the scalar unit)."""
+    from scema_amd import capi
+    from scema_amd.systems import build_pe
+    from oracle import pyoracle as po
+    z = lambda *s: np.zeros(s, np.int32)
+    d = dict(natoms=3, ntypes=1, type=z(3), charge=np.array([0.3, -0.3, 0.0]), mass=np.array([12.0]), eps=np.array([[0.1]]), sigma=np.array([[3.4]]),
+             bonds=z(0, 2), bond_type=z(0), bond_coeff=np.zeros((0, 2)), angles=z(0, 3), angle_type=z(0), angle_coeff=np.zeros((0, 2)),
+             dihedrals=z(0, 4), dihedral_type=z(0), dihedral_coeff=np.zeros((0, 4)), impropers=z(0, 4), improper_type=z(0),
+             improper_coeff=np.zeros((0, 2)), special_lj=np.ones(3), special_coul=np.ones(3),
+             box=np.array([0, 0, 0, 60, 60, 60, 0, 0, 0.0]), x=np.array([[30.0, 30, 30], [34.2, 30, 30], [5.0, 5.0, 5.0]]), v=np.zeros((3, 3)))
+    eng = capi.Engine(capi.default_params(shake_mass=0.0, kspace_style=0))
+    eng.register_replica("dense", 1, build_pe(4, 6, 12))          # fills the engine's work arrays with a crystal's rows first
+    eng.debug_compute("dense", 1)
+    eng.register_replica("lone", 1, d)
+    f, e, w, info = eng.debug_compute("lone", 1)
+    o = po.Oracle(d, po.default_params(shake_mass=0.0, kspace_pppm=0)); o.setup(False)
+    fo, eo, wo = o.compute()
+    assert np.abs(f - fo).max() < 1e-11 * np.abs(fo).max() and info["npairs"] == o.npairs
+    assert np.abs(f[2]).max() < 1e-12 * np.abs(f[0]).max()                # the lone, uncharged atom: no pair force, no reciprocal force
+    assert np.abs(f[0] + f[1]).max() < 1e-9 * np.abs(f[0]).max()
+    eng.close()
+
+
 def test_two_atoms_closed_form():
     """Smallest possible system: two LJ+coulomb atoms in a 60 A box; force equals the analytic pair force."""
     from scema_amd import capi
@@ -86,6 +112,12 @@ def test_two_atoms_closed_form():
              improper_coeff=np.zeros((0, 2)), special_lj=np.ones(3), special_coul=np.ones(3),
              box=np.array([0, 0, 0, 60, 60, 60, 0, 0, 0.0]), x=np.array([[30.0, 30, 30], [30 + r, 30, 30]]), v=np.zeros((2, 3)))
     eng = capi.Engine(capi.default_params(shake_mass=0.0))
+    # the work arrays of the engine are reused: a dense replica first, so that the rows of the two-atom system (one of its two
+    # clusters lists the pair, the other lists NOTHING) sit in memory that holds a crystal's entries -- an empty row must read none of it
+    from scema_amd.systems import build_pe
+    dense = build_pe(4, 6, 12)        # 3 456 atoms, 29.6 A wide: the default cutoffs fit
+    eng.register_replica("dense", 1, dense)
+    eng.debug_compute("dense", 1)
     eng.register_replica("two", 1, d)
     f, e, w, info = eng.debug_compute("two", 1)
     from oracle import pyoracle as po
