@@ -139,6 +139,7 @@ void scema_md_destroy(scema_md_engine *e) {
 const char *scema_md_last_error(const scema_md_engine *e) { return e ? e->err.c_str() : "null engine"; }
 
 int scema_md_register_replica(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_system *sys) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e || !matid || !sys) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
   std::unique_ptr<Topo> t(new Topo());

@@ -26,6 +26,7 @@ extern "C" {
 
 int scema_md_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t use_shake, double *f,
                            double *energies, double *virials, double *info) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
   State *s = nullptr;
@@ -70,6 +71,7 @@ int scema_md_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid,
 
 int scema_md_debug_run(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t nsteps, double dt,
                        double temperature, int32_t nvt, int32_t use_shake, const double *rates, double *press_avg) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e || nsteps < 0) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
   if (qp_id == SCEMA_MD_QP_NONE) return fail(e, SCEMA_MD_ERR_ARG, "debug_run needs a stored state (scema_md_set_state first)");

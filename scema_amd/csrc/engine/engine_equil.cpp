@@ -202,6 +202,7 @@ int scema_md_debug_minimize(scema_md_engine *e, int32_t qp_id, const char *matid
 }
 int scema_md_debug_run_nh(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, int32_t nsteps, double dt, double t_start,
                           double t_stop, int32_t npt, double p_target, double p_period, double *lavg) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e || nsteps < 0) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
   if (qp_id == SCEMA_MD_QP_NONE) return fail(e, SCEMA_MD_ERR_ARG, "debug_run_nh needs a stored state (scema_md_set_state first)");
@@ -212,6 +213,7 @@ int scema_md_debug_run_nh(scema_md_engine *e, int32_t qp_id, const char *matid, 
 }
 
 int scema_md_equilibrate(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_equilparams *p, double length[3], double *info) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e || !p || !length) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
   Topo *t = find_topo(e, matid, replica);
@@ -255,6 +257,7 @@ int scema_md_equilibrate(scema_md_engine *e, const char *matid, int32_t replica,
 // ---- init_material: what EQMDProblem::lammps_equilibration computes once the replica is equilibrated ----
 int scema_md_init_material(scema_md_engine *e, const char *matid, int32_t replica, const scema_md_eqparams *p, double length[3],
                            double stress[6], double stiff[36]) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e || !p || !length || !stress || !stiff) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
   Topo *t = find_topo(e, matid, replica);

@@ -223,6 +223,7 @@ int scema_md_get_state(scema_md_engine *e, int32_t qp_id, const char *matid, int
 }
 
 int scema_md_set_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const double box[9], const double *x, const double *v) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e || !box || !x || !v) return SCEMA_MD_ERR_ARG;
   HIPCHK(hipSetDevice(e->p.device));
   Topo *t = find_topo(e, matid, replica);
@@ -238,6 +239,7 @@ int scema_md_set_state(scema_md_engine *e, int32_t qp_id, const char *matid, int
 }
 
 int scema_md_drop_state(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e) return SCEMA_MD_ERR_ARG;
   (void)hipSetDevice(e->p.device);
   e->states.erase(state_key(qp_id, matid, replica));
@@ -376,6 +378,7 @@ int scema_md_save_state_dump(scema_md_engine *e, int32_t qp_id, const char *mati
 }
 
 int scema_md_load_state_file(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, const char *path) {
+  if (e) (void)settle_pending(e, false);   // an update that waits for its verdict (no communicator) stands once the engine is used for something else
   if (!e || !path) return SCEMA_MD_ERR_ARG;
   Topo *t = find_topo(e, matid, replica);
   if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d not registered", matid, replica);
