@@ -208,8 +208,15 @@ bool read_reax_ffield(const std::string &path, const std::vector<std::string> &e
     RxHbp &h = P.hbp[(a * RX_MAXT + b) * RX_MAXT + c];
     h.r0_hb = l.v[3]; h.p_hb1 = l.v[4]; h.p_hb2 = l.v[5]; h.p_hb3 = l.v[6];
   }
-  for (int a = 0; a < RX_MAXT * RX_MAXT; a++)
-    P.tbp[a].powgw = (P.tbp[a].gamma_w > 0.0) ? std::pow(1.0 / P.tbp[a].gamma_w, P.gp[28]) : 0.0;
+  for (int a = 0; a < RX_MAXT * RX_MAXT; a++) {
+    RxTbp &t = P.tbp[a];
+    t.powgw = (t.gamma_w > 0.0) ? std::pow(1.0 / t.gamma_w, P.gp[28]) : 0.0;
+    t.lr_s = (t.r_s > 0.0) ? std::log(t.r_s) : 0.0;
+    t.lr_p = (t.r_p > 0.0) ? std::log(t.r_p) : 0.0;
+    t.lr_pp = (t.r_pp > 0.0) ? std::log(t.r_pp) : 0.0;
+    t.inv_rvdw = (t.r_vdW > 0.0) ? 1.0 / t.r_vdW : 0.0;
+  }
+  P.inv_pvdw1 = 1.0 / P.gp[28];
   P.bo_cut = 0.01 * P.gp[29];
   P.swa = P.gp[11];
   P.swb = P.gp[12];

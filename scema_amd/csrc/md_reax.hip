@@ -215,7 +215,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
         const double d0 = q0 - xi0 + sh[0], d1 = q1 - xi1 + sh[1], d2 = q2 - xi2 + sh[2];
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
         if (!(r2 > swb2)) {
-          const double rr = sqrt(r2);
+          const double rr = r2 * rx_rsqrt(r2);
           double dTap;
           const double Tap = rx_taper(P, rr, &dTap);
           h = Tap * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * rr + grow[tj]);

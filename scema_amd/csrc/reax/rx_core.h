@@ -71,6 +71,82 @@ RX_FN double rx_icbrt(double x) {
   return 1.0 / cbrt(x);
 #endif
 }
+// ---- FP64 elementary functions at the accuracy this path needs (a few ulp), for positive finite normal arguments only ----------------
+// The library's log / pow / division / sqrt carry the IEEE corner cases and, for log and pow, double-double arithmetic: 85 and ~200
+// instructions a call on the device, more than a third of the non-bonded pair and most of a bond-order entry.  Every argument here is a
+// distance, a bond order above its threshold or a sum of positive terms, so: reciprocal and reciprocal square root from the hardware
+// estimate (2^-26) and one third-order correction; log x by the classical reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)),
+// log m = 2 atanh(s), s = (m - 1)/(m + 1), written f - f^2/2 + s (f^2/2 + R(s^2)) with the series R(z) = sum 2 z^n/(2n+1) cut
+// after n = 10 (z <= 0.0295: remainder 1e-18); x^p = exp(p log x).  The host build (tests/reax_host_driver.cpp) takes the library
+// functions unless RX_DEVICE_MATH_ON_HOST asks for these algorithms with single-precision seeds in place of the hardware estimates, so
+// that the formulas themselves are checked against the oracle without a GPU (tests/test_reax_host.py).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RX_DEVICE_MATH 1
+#define RX_RCP_SEED(x) __builtin_amdgcn_rcp(x)
+#define RX_RSQ_SEED(x) __builtin_amdgcn_rsq(x)
+#elif defined(RX_DEVICE_MATH_ON_HOST)
+#define RX_DEVICE_MATH 1
+#define RX_RCP_SEED(x) ((double)(1.0f / (float)(x)))
+#define RX_RSQ_SEED(x) ((double)(1.0f / sqrtf((float)(x))))
+#endif
+RX_FN double rx_rcp(double x) {
+#ifdef RX_DEVICE_MATH
+  const double y = RX_RCP_SEED(x);
+  const double e = fma(-x, y, 1.0);
+  return fma(y, fma(e, e, e), y);     // y (1 + e + e^2)
+#else
+  return 1.0 / x;
+#endif
+}
+RX_FN double rx_rsqrt(double x) {
+#ifdef RX_DEVICE_MATH
+  const double y = RX_RSQ_SEED(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y, e * fma(0.375, e, 0.5), y);   // y (1 + e/2 + 3 e^2/8)
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+RX_FN double rx_log(double x) {
+#ifdef RX_DEVICE_MATH
+#if defined(__HIP_DEVICE_COMPILE__)
+  double m = __builtin_amdgcn_frexp_mant(x);
+  int k = __builtin_amdgcn_frexp_exp(x);
+#else
+  int k;
+  double m = frexp(x, &k);
+#endif
+  if (m < 0.70710678118654752) { m += m; k -= 1; }
+  const double f = m - 1.0;
+  const double s = f * rx_rcp(2.0 + f), z = s * s;
+  double R = 2.0 / 21.0;
+  R = fma(R, z, 2.0 / 19.0); R = fma(R, z, 2.0 / 17.0); R = fma(R, z, 2.0 / 15.0); R = fma(R, z, 2.0 / 13.0); R = fma(R, z, 2.0 / 11.0);
+  R = fma(R, z, 2.0 / 9.0); R = fma(R, z, 2.0 / 7.0); R = fma(R, z, 2.0 / 5.0); R = fma(R, z, 2.0 / 3.0);
+  R *= z;
+  const double hfsq = 0.5 * f * f, dk = (double)k;
+  // ln 2 in two parts: the first has 21 trailing zero bits, so its product with dk is exact
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+#else
+  return log(x);
+#endif
+}
+RX_FN double rx_pow(double x, double p) {
+#ifdef RX_DEVICE_MATH
+  return exp(p * rx_log(x));
+#else
+  return pow(x, p);
+#endif
+}
+// sqrt(x) for x >= 0 that is zero or a normal number
+RX_FN double rx_sqrt(double x) {
+#ifdef RX_DEVICE_MATH
+  return (x > 0.0) ? x * rx_rsqrt(x) : 0.0;
+#else
+  return sqrt(x);
+#endif
+}
+// sin(theta) of an angle in [0, pi] from its (clamped) cosine: sqrt((1 - c)(1 + c)) -- no acos, no sin
+RX_FN double rx_sin_of_cos(double c) { return rx_sqrt((1.0 - c) * (1.0 + c)); }
 RX_FN double rx_taper(const RxParams *P, double r, double *dtap) {
   double t = P->tap[7], dt = 7.0 * P->tap[7];
   for (int m = 6; m >= 0; m--) t = t * r + P->tap[m];
@@ -117,26 +193,27 @@ RX_FN int rx_bond_prime_entry(const RxParams *P, const RxView *V, int i, int e, 
   const int j = rx_partner(V, i, e, d);
   const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
   if (r2 > RX_BOND_CUT * RX_BOND_CUT) return 0;
-  const double r = sqrt(r2);
+  // (r / r_x)^p = exp(p (log r - log r_x)): ONE logarithm for the three bond orders of the entry (RxTbp::lr_*)
+  const double rinv = rx_rsqrt(r2), r = r2 * rinv, r2inv = rinv * rinv, lr = 0.5 * rx_log(r2);
   const int tj = V->rtype[j];
   const RxSbp *sj = &sbp[tj];
   const RxTbp *t = &tbp[ti * RX_MAXT + tj];
   double bs = 0;
   *bp = 0; *bpp = 0; *cs = 0; *cp = 0; *cpp = 0;
   if (si->r_s > 0.0 && sj->r_s > 0.0) {
-    const double c12 = t->p_bo1 * pow(r / t->r_s, t->p_bo2);
+    const double c12 = t->p_bo1 * exp(t->p_bo2 * (lr - t->lr_s));
     bs = (1.0 + P->bo_cut) * exp(c12);
-    *cs = bs * t->p_bo2 * c12 / r2;
+    *cs = bs * t->p_bo2 * c12 * r2inv;
   }
   if (si->r_pi > 0.0 && sj->r_pi > 0.0) {
-    const double c34 = t->p_bo3 * pow(r / t->r_p, t->p_bo4);
+    const double c34 = t->p_bo3 * exp(t->p_bo4 * (lr - t->lr_p));
     *bp = exp(c34);
-    *cp = *bp * t->p_bo4 * c34 / r2;
+    *cp = *bp * t->p_bo4 * c34 * r2inv;
   }
   if (si->r_pi_pi > 0.0 && sj->r_pi_pi > 0.0) {
-    const double c56 = t->p_bo5 * pow(r / t->r_pp, t->p_bo6);
+    const double c56 = t->p_bo5 * exp(t->p_bo6 * (lr - t->lr_pp));
     *bpp = exp(c56);
-    *cpp = *bpp * t->p_bo6 * c56 / r2;
+    *cpp = *bpp * t->p_bo6 * c56 * r2inv;
   }
   *bo = bs + *bp + *bpp;
   *r_out = r;
@@ -157,25 +234,25 @@ RX_FN void rx_bonds_prime(const RxParams *P, const RxView *V, int i) {
     const int j = rx_partner(V, i, e, d);
     const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
     if (r2 > RX_BOND_CUT * RX_BOND_CUT) continue;
-    const double r = sqrt(r2);
+    const double rinv = rx_rsqrt(r2), r = r2 * rinv, r2inv = rinv * rinv, lr = 0.5 * rx_log(r2);
     const int tj = V->rtype[j];
     const RxSbp *sj = &P->sbp[tj];
     const RxTbp *t = &P->tbp[ti * RX_MAXT + tj];
     double bs = 0, bp = 0, bpp = 0, cs = 0, cp = 0, cpp = 0;
     if (si->r_s > 0.0 && sj->r_s > 0.0) {
-      const double c12 = t->p_bo1 * pow(r / t->r_s, t->p_bo2);
+      const double c12 = t->p_bo1 * exp(t->p_bo2 * (lr - t->lr_s));
       bs = (1.0 + P->bo_cut) * exp(c12);
-      cs = bs * t->p_bo2 * c12 / r2;
+      cs = bs * t->p_bo2 * c12 * r2inv;
     }
     if (si->r_pi > 0.0 && sj->r_pi > 0.0) {
-      const double c34 = t->p_bo3 * pow(r / t->r_p, t->p_bo4);
+      const double c34 = t->p_bo3 * exp(t->p_bo4 * (lr - t->lr_p));
       bp = exp(c34);
-      cp = bp * t->p_bo4 * c34 / r2;
+      cp = bp * t->p_bo4 * c34 * r2inv;
     }
     if (si->r_pi_pi > 0.0 && sj->r_pi_pi > 0.0) {
-      const double c56 = t->p_bo5 * pow(r / t->r_pp, t->p_bo6);
+      const double c56 = t->p_bo5 * exp(t->p_bo6 * (lr - t->lr_pp));
       bpp = exp(c56);
-      cpp = bpp * t->p_bo6 * c56 / r2;
+      cpp = bpp * t->p_bo6 * c56 * r2inv;
     }
     const double bo = bs + bp + bpp;
     if (bo < P->bo_cut) continue;
@@ -220,19 +297,19 @@ RX_FN void rx_corr(const RxParams *P, int ti, int tj, double Di, double Dj, doub
   if (t->ovc >= 0.001) {
     const double p1 = P->gp[0], p2 = P->gp[1];
     const double e1i = exp(-p1 * Di), e1j = exp(-p1 * Dj), e2i = exp(-p2 * Di), e2j = exp(-p2 * Dj);
-    const double f2 = e1i + e1j, f3 = -1.0 / p2 * log(0.5 * (e2i + e2j));
+    const double f2 = e1i + e1j, f3 = -1.0 / p2 * rx_log(0.5 * (e2i + e2j));
     const double vi = si->valency, vj = sj->valency;
-    const double ui = 1.0 / (vi + f2 + f3), uj = 1.0 / (vj + f2 + f3);
+    const double ui = rx_rcp(vi + f2 + f3), uj = rx_rcp(vj + f2 + f3);
     c->Y = 0.5 * ((vi + f2) * ui + (vj + f2) * uj);
     // d/dD of (v + f2)/(v + f2 + f3) = (f2' f3 - (v + f2) f3') / (v + f2 + f3)^2
-    const double f2i = -p1 * e1i, f2j = -p1 * e1j, f3i = e2i / (e2i + e2j), f3j = e2j / (e2i + e2j);
+    const double f2i = -p1 * e1i, f2j = -p1 * e1j, ie2 = rx_rcp(e2i + e2j), f3i = e2i * ie2, f3j = e2j * ie2;
     c->Yi = 0.5 * ((f2i * f3 - (vi + f2) * f3i) * ui * ui + (f2i * f3 - (vj + f2) * f3i) * uj * uj);
     c->Yj = 0.5 * ((f2j * f3 - (vi + f2) * f3j) * ui * ui + (f2j * f3 - (vj + f2) * f3j) * uj * uj);
   }
   if (t->v13cor >= 0.001) {
     const double Dbi = Di + si->valency - si->valency_boc, Dbj = Dj + sj->valency - sj->valency_boc;
     const double E4 = exp(-(t->p_boc4 * B * B - Dbi) * t->p_boc3 + t->p_boc5), E5 = exp(-(t->p_boc4 * B * B - Dbj) * t->p_boc3 + t->p_boc5);
-    const double f4 = 1.0 / (1.0 + E4), f5 = 1.0 / (1.0 + E5);
+    const double f4 = rx_rcp(1.0 + E4), f5 = rx_rcp(1.0 + E5);
     c->X = f4 * f5;
     const double f4i = -t->p_boc3 * E4 * f4 * f4, f5j = -t->p_boc3 * E5 * f5 * f5;
     c->Xi = f4i * f5;
@@ -296,7 +373,7 @@ RX_FN void rx_atom_terms(const RxParams *P, const RxView *V, int i, double *eng)
     const double bo = V->bd_bo[o], bpi = V->bd_bo[plane + o], bpi2 = V->bd_bo[2 * plane + o];
     if (rx_owns(i, e)) {   // bond energy, once per bond
       const double bs = bo - bpi - bpi2;
-      const double pw = (bs > 0.0) ? pow(bs, t->p_be2) : 0.0;
+      const double pw = (bs > 0.0) ? rx_pow(bs, t->p_be2) : 0.0;
       const double ex = exp(t->p_be1 * (1.0 - pw));
       eng[RX_E_BOND] += -t->De_s * bs * ex - t->De_p * bpi - t->De_pp * bpi2;
       const double CEbo = -t->De_s * ex * (1.0 - t->p_be1 * t->p_be2 * pw);
@@ -346,16 +423,20 @@ RX_FN void rx_atom_terms(const RxParams *P, const RxView *V, int i, double *eng)
 // rx_torsion_terms reaches other atoms' rows (the far bond k-l), so all its updates are atomic.  Per-atom sums are atomic
 // everywhere.  The kernels therefore run 3a, 3b, 3c, 3d as separate launches.
 
-RX_FN double rx_angle(const double *a, double ra, const double *b, double rb, double *cosv) {
-  double c = (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) / (ra * rb);
+RX_FN double rx_cos_angle(const double *a, double ra, const double *b, double rb) {
+  double c = (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) * rx_rcp(ra * rb);
   if (c > 1.0) c = 1.0;
   if (c < -1.0) c = -1.0;
+  return c;
+}
+RX_FN double rx_angle(const double *a, double ra, const double *b, double rb, double *cosv) {
+  const double c = rx_cos_angle(a, ra, b, rb);
   *cosv = c;
   return acos(c);
 }
 // d(cos theta)/da and /db for cos = a.b/(|a||b|)
 RX_FN void rx_dcos(const double *a, double ra, const double *b, double rb, double c, double *da, double *db) {
-  const double iab = 1.0 / (ra * rb), ia2 = 1.0 / (ra * ra), ib2 = 1.0 / (rb * rb);
+  const double ia = rx_rcp(ra), ib = rx_rcp(rb), iab = ia * ib, ia2 = ia * ia, ib2 = ib * ib;
   for (int m = 0; m < 3; m++) {
     da[m] = b[m] * iab - c * a[m] * ia2;
     db[m] = a[m] * iab - c * b[m] * ib2;
@@ -398,8 +479,8 @@ RX_FN int rx_angle_pre(const RxParams *P, const RxView *V, int j, RxAnglePre *A)
   const double SBO = SBOp + (1.0 - prod) * (-J.Delta_boc - p_val8 * vlpadj);
   A->dSBO1 = -8.0 * prod * (J.Delta_boc + p_val8 * vlpadj);   // d(SBO)/d(BO_n) = dSBO1 BO_n^7
   if (SBO <= 0.0) { A->SBO2 = 0.0; A->CSBO2 = 0.0; }
-  else if (SBO <= 1.0) { A->SBO2 = pow(SBO, p_val9); A->CSBO2 = p_val9 * pow(SBO, p_val9 - 1.0); }
-  else if (SBO < 2.0) { A->SBO2 = 2.0 - pow(2.0 - SBO, p_val9); A->CSBO2 = p_val9 * pow(2.0 - SBO, p_val9 - 1.0); }
+  else if (SBO <= 1.0) { const double w = rx_pow(SBO, p_val9); A->SBO2 = w; A->CSBO2 = p_val9 * w * rx_rcp(SBO); }   // x^(p-1) = x^p / x
+  else if (SBO < 2.0) { const double w = rx_pow(2.0 - SBO, p_val9); A->SBO2 = 2.0 - w; A->CSBO2 = p_val9 * w * rx_rcp(2.0 - SBO); }
   else { A->SBO2 = 2.0; A->CSBO2 = 0.0; }
   return 1;
 }
@@ -442,20 +523,21 @@ RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int 
       if (th->cnt == 0) return;
       double cos_t;
       const double theta = rx_angle(dji, r_ij, djk, r_jk, &cos_t);
-      double sin_t = sin(theta);
+      double sin_t = rx_sin_of_cos(cos_t);
       if (sin_t < 1.0e-5) sin_t = 1.0e-5;
       double dE_dtheta = 0.0, g_i = 0.0, g_k = 0.0;   // dE/dtheta, dE/dBO_ij, dE/dBO_jk
       for (int c = 0; c < th->cnt; c++) {
         const RxThbPrm *p = &th->prm[c];
         if (fabs(p->p_val1) <= 0.001) continue;
         // angle energy
-        const double pw_i = pow(BOA_ij, p->p_val4), pw_k = pow(BOA_jk, p->p_val4);
-        const double exp3ij = exp(-sj->p_val3 * pw_i), f7_ij = 1.0 - exp3ij, Cf7ij = sj->p_val3 * p->p_val4 * pow(BOA_ij, p->p_val4 - 1.0) * exp3ij;
-        const double exp3jk = exp(-sj->p_val3 * pw_k), f7_jk = 1.0 - exp3jk, Cf7jk = sj->p_val3 * p->p_val4 * pow(BOA_jk, p->p_val4 - 1.0) * exp3jk;
+        const double pw_i = rx_pow(BOA_ij, p->p_val4), pw_k = rx_pow(BOA_jk, p->p_val4);   // (x^(p-1) = x^p / x below)
+        const double exp3ij = exp(-sj->p_val3 * pw_i), f7_ij = 1.0 - exp3ij, Cf7ij = sj->p_val3 * p->p_val4 * (pw_i * rx_rcp(BOA_ij)) * exp3ij;
+        const double exp3jk = exp(-sj->p_val3 * pw_k), f7_jk = 1.0 - exp3jk, Cf7jk = sj->p_val3 * p->p_val4 * (pw_k * rx_rcp(BOA_jk)) * exp3jk;
         const double expval7 = exp(-p->p_val7 * J.Delta_boc);
         const double trm8 = 1.0 + expval6 + expval7;
-        const double f8_Dj = sj->p_val5 - (sj->p_val5 - 1.0) * (2.0 + expval6) / trm8;
-        const double Cf8j = ((1.0 - sj->p_val5) / (trm8 * trm8)) * (p_val6 * expval6 * trm8 - (2.0 + expval6) * (p_val6 * expval6 - p->p_val7 * expval7));
+        const double itrm8 = rx_rcp(trm8);
+        const double f8_Dj = sj->p_val5 - (sj->p_val5 - 1.0) * (2.0 + expval6) * itrm8;
+        const double Cf8j = ((1.0 - sj->p_val5) * (itrm8 * itrm8)) * (p_val6 * expval6 * trm8 - (2.0 + expval6) * (p_val6 * expval6 - p->p_val7 * expval7));
         const double theta_00 = p->theta_00 * RX_PI / 180.0;
         const double ex10 = exp(-p_val10 * (2.0 - SBO2));
         const double theta_0 = RX_PI - theta_00 * (1.0 - ex10);
@@ -475,8 +557,9 @@ RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int 
         const double exp_pen2ij = exp(-p_pen2 * RX_SQR(BOA_ij - 2.0)), exp_pen2jk = exp(-p_pen2 * RX_SQR(BOA_jk - 2.0));
         const double exp_pen3 = exp(-p_pen3 * J.Delta), exp_pen4 = exp(p_pen4 * J.Delta);
         const double trm_pen34 = 1.0 + exp_pen3 + exp_pen4;
-        const double f9_Dj = (2.0 + exp_pen3) / trm_pen34;
-        const double Cf9j = (-p_pen3 * exp_pen3 * trm_pen34 - (2.0 + exp_pen3) * (-p_pen3 * exp_pen3 + p_pen4 * exp_pen4)) / (trm_pen34 * trm_pen34);
+        const double itrm_pen34 = rx_rcp(trm_pen34);
+        const double f9_Dj = (2.0 + exp_pen3) * itrm_pen34;
+        const double Cf9j = (-p_pen3 * exp_pen3 * trm_pen34 - (2.0 + exp_pen3) * (-p_pen3 * exp_pen3 + p_pen4 * exp_pen4)) * (itrm_pen34 * itrm_pen34);
         const double e_pen = p->p_pen1 * f9_Dj * exp_pen2ij * exp_pen2jk;
         eng[RX_E_PEN] += e_pen;
         cdd_j += p->p_pen1 * Cf9j * exp_pen2ij * exp_pen2jk;
@@ -485,10 +568,11 @@ RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int 
         // three-body conjugation
         const double exp_coa2 = exp(p_coa2 * J.Delta_val);
         const double tbi = V->total_bo[i], tbk = V->total_bo[k];
-        const double e_coa = p->p_coa1 / (1.0 + exp_coa2) * exp(-p_coa3 * RX_SQR(tbi - BOA_ij)) * exp(-p_coa3 * RX_SQR(tbk - BOA_jk)) *
+        const double icoa2 = rx_rcp(1.0 + exp_coa2);
+        const double e_coa = p->p_coa1 * icoa2 * exp(-p_coa3 * RX_SQR(tbi - BOA_ij)) * exp(-p_coa3 * RX_SQR(tbk - BOA_jk)) *
                              exp(-p_coa4 * RX_SQR(BOA_ij - 1.5)) * exp(-p_coa4 * RX_SQR(BOA_jk - 1.5));
         eng[RX_E_COA] += e_coa;
-        cdd_j += -p_coa2 * exp_coa2 / (1.0 + exp_coa2) * e_coa;
+        cdd_j += -p_coa2 * exp_coa2 * icoa2 * e_coa;
         g_i += (2.0 * p_coa3 * (tbi - BOA_ij) - 2.0 * p_coa4 * (BOA_ij - 1.5)) * e_coa;
         g_k += (2.0 * p_coa3 * (tbk - BOA_jk) - 2.0 * p_coa4 * (BOA_jk - 1.5)) * e_coa;
         RX_ATOMIC_ADD(&V->cd_delta[i], -2.0 * p_coa3 * (tbi - BOA_ij) * e_coa);
@@ -497,7 +581,7 @@ RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int 
       RX_ATOMIC_ADD(&V->bd_g[oi], g_i);
       RX_ATOMIC_ADD(&V->bd_g[ok], g_k);
       // geometry: dE/dtheta -> forces on i, j, k
-      const double ce = -dE_dtheta / sin_t;   // dE/dcos
+      const double ce = -dE_dtheta * rx_rcp(sin_t);   // dE/dcos
       double da[3], db[3], fi[3], fk[3];
       rx_dcos(dji, r_ij, djk, r_jk, cos_t, da, db);
       for (int m = 0; m < 3; m++) {
@@ -581,8 +665,9 @@ RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, in
   const double exp_tor2_jk = exp(-p_tor2 * BOA_jk), exp_cot2_jk = exp(-p_cot2 * RX_SQR(BOA_jk - 1.5));
   const double DjDk = J.Delta_boc + K.Delta_boc;
   const double exp_tor3 = exp(-p_tor3 * DjDk), exp_tor4 = exp(p_tor4 * DjDk), trm34 = 1.0 + exp_tor3 + exp_tor4;
-  const double f11 = (2.0 + exp_tor3) / trm34;
-  const double Cf11 = (-p_tor3 * exp_tor3 * trm34 - (2.0 + exp_tor3) * (-p_tor3 * exp_tor3 + p_tor4 * exp_tor4)) / (trm34 * trm34);
+  const double itrm34 = rx_rcp(trm34);
+  const double f11 = (2.0 + exp_tor3) * itrm34;
+  const double Cf11 = (-p_tor3 * exp_tor3 * trm34 - (2.0 + exp_tor3) * (-p_tor3 * exp_tor3 + p_tor4 * exp_tor4)) * (itrm34 * itrm34);
   const double mq[3] = {-q[0], -q[1], -q[2]};
   double g_jk = 0.0, gpi_jk = 0.0, cdd = 0.0, fj[3] = {0, 0, 0}, fk[3] = {0, 0, 0};
   {
@@ -593,9 +678,8 @@ RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, in
       const int i = rx_partner(V, j, eij, p);
       const int ti = V->rtype[i];
       const double r_ij = V->bd_bop[3 * plane + oij], BOA_ij = bo_ij - RX_THB_CUT;
-      double cos_ijk;
-      const double th_ijk = rx_angle(p, r_ij, q, r_jk, &cos_ijk);
-      double sin_ijk = sin(th_ijk);
+      const double cos_ijk = rx_cos_angle(p, r_ij, q, r_jk);
+      double sin_ijk = rx_sin_of_cos(cos_ijk);
       if (sin_ijk >= 0 && sin_ijk <= RX_MIN_SINE) sin_ijk = RX_MIN_SINE;
       const double exp_tor2_ij = exp(-p_tor2 * BOA_ij), exp_cot2_ij = exp(-p_cot2 * RX_SQR(BOA_ij - 1.5));
       double g_ij = 0.0, fi[3] = {0, 0, 0};
@@ -612,19 +696,19 @@ RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, in
         const double bo_kl = V->bd_bo[okl];
         if (!(fb->cnt && bo_kl > RX_THB_CUT && bo_ij * bo_jk * bo_kl > RX_THB_CUT)) continue;
         const double r_kl = V->bd_bop[3 * plane + okl], BOA_kl = bo_kl - RX_THB_CUT;
-        double cos_jkl;
-        const double th_jkl = rx_angle(mq, r_jk, s, r_kl, &cos_jkl);
-        double sin_jkl = sin(th_jkl);
+        const double cos_jkl = rx_cos_angle(mq, r_jk, s, r_kl);
+        double sin_jkl = rx_sin_of_cos(cos_jkl);
         if (sin_jkl >= 0 && sin_jkl <= RX_MIN_SINE) sin_jkl = RX_MIN_SINE;
         // dihedral from the plane normals n1 = p x q, n2 = s x q
         double n1[3], n2[3];
         rx_cross(p, q, n1);
         rx_cross(s, q, n2);
-        const double l1 = sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]), l2 = sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
+        const double l1 = rx_sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]), l2 = rx_sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
         // (n2 = (k->l) x (j->k) = (k->j) x (k->l): parallel normals for the cis arrangement, cos(omega) = +1 there)
         double co = 1.0;
         const int ok_n = l1 > 0.0 && l2 > 0.0;
-        if (ok_n) co = (n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2]) / (l1 * l2);
+        const double i12 = ok_n ? rx_rcp(l1 * l2) : 0.0;
+        if (ok_n) co = (n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2]) * i12;
         if (co > 1.0) co = 1.0;
         if (co < -1.0) co = -1.0;
         const double cos2 = 2.0 * co * co - 1.0, cos3 = co * (4.0 * co * co - 3.0);
@@ -652,7 +736,7 @@ RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, in
         const double dE_dsin_jkl = fn10 * sin_ijk * CV + fb->p_cot1 * fn12 * (co * co - 1.0) * sin_ijk;
         const double dE_dco = fn10 * ss * 0.5 * (fb->V1 - 4.0 * fb->V2 * exp_tor1 * co + fb->V3 * (12.0 * co * co - 3.0)) + fb->p_cot1 * fn12 * 2.0 * co * ss;
         // sin(theta) = sqrt(1 - cos^2): dsin/dcos = -cos/sin
-        const double ce_ijk = dE_dsin_ijk * (-cos_ijk / sin_ijk), ce_jkl = dE_dsin_jkl * (-cos_jkl / sin_jkl);
+        const double ce_ijk = dE_dsin_ijk * (-cos_ijk * rx_rcp(sin_ijk)), ce_jkl = dE_dsin_jkl * (-cos_jkl * rx_rcp(sin_jkl));
         double dp[3] = {0, 0, 0}, dq[3] = {0, 0, 0}, ds[3] = {0, 0, 0};   // dE/dp, dE/dq, dE/ds
         double da[3], db[3];
         rx_dcos(p, r_ij, q, r_jk, cos_ijk, da, db);
@@ -662,10 +746,10 @@ RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, in
         if (ok_n && co > -1.0 && co < 1.0) {
           // c = n1.n2/(|n1||n2|): g1 = dc/dn1, g2 = dc/dn2; n1 = p x q, n2 = s x q
           double g1[3], g2[3], t1[3], t2[3], t3[3], t4[3];
-          const double i12 = 1.0 / (l1 * l2);
+          const double c11 = co * (i12 * i12) * (l2 * l2), c22 = co * (i12 * i12) * (l1 * l1);   // co / l1^2, co / l2^2
           for (int m = 0; m < 3; m++) {
-            g1[m] = n2[m] * i12 - co * n1[m] / (l1 * l1);
-            g2[m] = n1[m] * i12 - co * n2[m] / (l2 * l2);
+            g1[m] = n2[m] * i12 - c11 * n1[m];
+            g2[m] = n1[m] * i12 - c22 * n2[m];
           }
           rx_cross(q, g1, t1);   // dc/dp
           rx_cross(g1, p, t2);   // dc/dq (through n1)
@@ -739,8 +823,7 @@ RX_FN void rx_hbond_terms(const RxParams *P, const RxView *V, int j, double *eng
       double dji[3];
       rx_partner(V, j, ei, dji);
       const double r_ij = V->bd_bop[3 * plane + o];
-      double cos_t;
-      (void)rx_angle(dji, r_ij, djk, r_jk, &cos_t);
+      const double cos_t = rx_cos_angle(dji, r_ij, djk, r_jk);
       const double s4 = 0.25 * RX_SQR(1.0 - cos_t);   // sin^4(theta/2)
       const double ex2 = exp(-h->p_hb2 * bo_ij), ex3 = exp(-h->p_hb3 * (h->r0_hb / r_jk + r_jk / h->r0_hb - 2.0));
       const double e_hb = h->p_hb1 * (1.0 - ex2) * ex3 * s4;
@@ -774,22 +857,22 @@ RX_FN void rx_hbond_terms(const RxParams *P, const RxView *V, int j, double *eng
 // one non-bonded pair (tapered van der Waals with the shielded distance + shielded Coulomb) at distance r = sqrt(r2) <= swb:
 // energies and s = (dE/dr) / r, so that dE/dd = s d
 RX_FN void rx_nonbonded_pair(const RxParams *P, const RxTbp *t, double qq, double r2, double *evdw, double *ecoul, double *s_out) {
-  const double p_vdW1 = P->gp[28], p_vdW1i = 1.0 / p_vdW1;
-  const double r = sqrt(r2), rinv = 1.0 / r;
+  const double p_vdW1 = P->gp[28], p_vdW1i = P->inv_pvdw1;
+  const double rinv = rx_rsqrt(r2), r = r2 * rinv;
   double dTap;
   const double Tap = rx_taper(P, r, &dTap);
   // shielded distance fn13 = (r^p + gamma_w^-p)^(1/p); d(fn13)/dr = fn13 / (r^p + gamma_w^-p) * r^(p-1)
-  const double powr = exp(p_vdW1 * log(r));
+  const double powr = exp(0.5 * p_vdW1 * rx_log(r2));
   const double sum = powr + t->powgw;
-  const double fn13 = exp(p_vdW1i * log(sum));
-  const double dfn13 = fn13 / sum * powr * rinv;
-  const double ex2 = exp(0.5 * t->alpha * (1.0 - fn13 / t->r_vdW)), ex1 = ex2 * ex2;
+  const double fn13 = exp(p_vdW1i * rx_log(sum));
+  const double dfn13 = fn13 * rx_rcp(sum) * powr * rinv;
+  const double ex2 = exp(0.5 * t->alpha * (1.0 - fn13 * t->inv_rvdw)), ex1 = ex2 * ex2;
   const double e_v = t->D * (ex1 - 2.0 * ex2);
-  double dE = dTap * e_v - Tap * t->D * (t->alpha / t->r_vdW) * (ex1 - ex2) * dfn13;
+  double dE = dTap * e_v - Tap * t->D * (t->alpha * t->inv_rvdw) * (ex1 - ex2) * dfn13;
   *evdw = Tap * e_v;
   const double r3g = r2 * r + t->gamma, c13i = rx_icbrt(r3g);
   *ecoul = Tap * qq * c13i;
-  dE += qq * c13i * (dTap - Tap * r2 / r3g);
+  dE += qq * c13i * (dTap - Tap * r2 * (c13i * c13i * c13i));   // 1 / (r^3 + gamma) = c13i^3
   *s_out = dE * rinv;
 }
 // atom i's end of its pairs: the entries k0, k0 + kstep, ... of its list row (every pair is seen from both ends, half the energy each)
@@ -893,7 +976,7 @@ RX_FN double rx_qeq_entry(const RxParams *P, const RxView *V, int i, int e, int 
   *col = j;
   const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
   if (r2 > P->swb * P->swb) return -1.0;
-  const double r = sqrt(r2);
+  const double r = r2 * rx_rsqrt(r2);
   double dTap;
   const double Tap = rx_taper(P, r, &dTap);
   const double gamma = gamma_row ? gamma_row[V->rtype[j]] : P->tbp[V->rtype[i] * RX_MAXT + V->rtype[j]].gamma;

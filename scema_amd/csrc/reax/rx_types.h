@@ -45,6 +45,8 @@ typedef struct {
   double De_s, De_p, De_pp, p_be1, p_bo5, v13cor, p_bo6, p_ovun1, p_be2, p_bo3, p_bo4, p_bo1, p_bo2, ovc;
   double r_s, r_p, r_pp, p_boc3, p_boc4, p_boc5, D, alpha, r_vdW, gamma_w, gamma;
   double powgw;           // (1/gamma_w)^p_vdW1: the shielding constant of the van der Waals term (derived by the reader)
+  double lr_s, lr_p, lr_pp;   // log r_s, log r_p, log r_pp: (r / r_x)^p = exp(p (log r - log r_x)), one logarithm per bond-order entry (derived by the reader)
+  double inv_rvdw;        // 1 / r_vdW (derived by the reader)
 } RxTbp;
 typedef struct { double theta_00, p_val1, p_val2, p_coa1, p_val7, p_pen1, p_val4; } RxThbPrm;
 typedef struct { int cnt, pad_; RxThbPrm prm[RX_MAXANG]; } RxThbp;
@@ -57,6 +59,7 @@ typedef struct {
                           // could not be checked and breaks energy conservation; off by default)
   double gp[RX_NGP];
   double bo_cut, swa, swb;
+  double inv_pvdw1;       // 1 / gp[28] (derived by the reader)
   double tap[8];
   RxSbp sbp[RX_MAXT];
   RxTbp tbp[RX_MAXT * RX_MAXT];

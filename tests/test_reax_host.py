@@ -30,17 +30,21 @@ def ff():
     f.close()
 
 
-@pytest.fixture(scope="module")
-def drv():
+# "library": the host build as the product's host tools see it (libm).  "device_math": the same functions with the device's own log / pow /
+# reciprocal / reciprocal-square-root algorithms (rx_core.h, RX_DEVICE_MATH_ON_HOST: single-precision seeds stand in for the hardware
+# estimates), so that what the kernels compute is held against the oracle here as well, term by term and derivative by derivative.
+@pytest.fixture(scope="module", params=["library", "device_math"])
+def drv(request):
     out = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out, exist_ok=True)
     san = os.environ.get("SCEMA_SANITIZE") == "1"       # tools/run_asan.sh: the driver and the parameter reader under ASan + UBSan
-    so = os.path.join(out, "libreax_host_asan.so" if san else "libreax_host.so")
+    dm = request.param == "device_math"
+    so = os.path.join(out, "libreax_host" + ("_dm" if dm else "") + ("_asan" if san else "") + ".so")
     srcs = [os.path.join(ROOT, "tests", "reax_host_driver.cpp"), os.path.join(ROOT, "scema_amd", "csrc", "host", "reax_ffield.cpp")]
     deps = srcs + [os.path.join(ROOT, "scema_amd", "csrc", "reax", f) for f in ("rx_core.h", "rx_types.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in deps):
         flags = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if san else ["-O2"]
-        subprocess.check_call(["g++"] + flags + ["-fPIC", "-shared", "-std=c++17", "-o", so] + srcs)
+        subprocess.check_call(["g++"] + flags + (["-DRX_DEVICE_MATH_ON_HOST"] if dm else []) + ["-fPIC", "-shared", "-std=c++17", "-o", so] + srcs)
     L = C.CDLL(so)
     L.rxh_create.restype = C.c_void_p
     L.rxh_create.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]
