@@ -4,6 +4,23 @@
 
 #include "md_types.h"
 
+// A pointer read from a structure in memory is a generic ("flat") pointer to the compiler: its loads and stores are FLAT instructions, which may
+// hit LDS, tick BOTH memory counters and return out of order with everything else -- so every use of a flat load's result waits with
+// s_waitcnt vmcnt(0) lgkmcnt(0): no load stays in flight across an LDS read, a prefetch written in the source is waited for at once.
+// Saying that the pointer is in global memory gives global_load / global_store: vmcnt only, counted in order, prefetches stay in flight.
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const GLOBAL_AS T *as_global(const T *p) {
+  return (const GLOBAL_AS T *)p;
+}
+template <class T>
+__device__ __forceinline__ GLOBAL_AS T *as_global_w(T *p) {
+  return (GLOBAL_AS T *)p;
+}
+// (double2 is a class: it cannot be read through an address-space pointer; the native vector type can)
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ldg2(const GLOBAL_AS dvec2 *p, size_t k) { const dvec2 v = p[k]; return make_double2(v.x, v.y); }
+
 #define TPB 256
 
 struct BoxD {

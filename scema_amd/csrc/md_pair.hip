@@ -48,15 +48,6 @@
 #define XQ_Z(S, s) (((const double *)(S).xq)[2 * (size_t)(S).npad + 2 * (size_t)(s)])
 #define XQ_Q(S, s) (((const double *)(S).xq)[2 * (size_t)(S).npad + 2 * (size_t)(s) + 1])
 
-#define GLOBAL_AS __attribute__((address_space(1)))
-template <class T>
-__device__ __forceinline__ const GLOBAL_AS T *as_global(const T *p) {
-  return (const GLOBAL_AS T *)p;
-}
-template <class T>
-__device__ __forceinline__ GLOBAL_AS T *as_global_w(T *p) {
-  return (GLOBAL_AS T *)p;
-}
 
 // XCD-aware block -> (simulation, tile) map.  Workgroups are dealt round-robin over the 8 XCDs
 // (block L lands on XCD L % 8), each with its own 4 MiB L2.  A simulation's j gathers touch its

@@ -319,15 +319,24 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
     }
   }
   const size_t np = V.npad;
-  const double2 *z = (const double2 *)(V.qwork + 6 * np);
+  const GLOBAL_AS dvec2 *z = as_global((const dvec2 *)(V.qwork + 6 * np));
   if (ZLDS) {
-    for (int k = threadIdx.x; k < n; k += RX_KT) s_zl[k] = z[k];
+    // (four loads in flight per thread: one at a time, every element waited a memory round trip before its LDS write)
+    for (int k0 = threadIdx.x; k0 < n; k0 += 4 * RX_KT) {
+      double2 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = k0 + u * RX_KT; t[u] = ldg2(z, k < n ? k : n - 1); }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = k0 + u * RX_KT; if (k < n) s_zl[k] = t[u]; }
+    }
     __syncthreads();
   }
   // the products of this workgroup's 64 rows: wave w takes the rows 8 w .. 8 w + 7, lanes over the entries of a row
   __shared__ double s_y[2][RX_SWR];
-  const unsigned short *c16 = V.hcol16;
-  const int *c32 = V.hcol32;
+  const GLOBAL_AS unsigned short *c16 = as_global(V.hcol16);
+  const GLOBAL_AS int *c32 = as_global(V.hcol32);
+  const GLOBAL_AS double *hv = as_global(V.hval);
+  const GLOBAL_AS int *hlen = as_global(V.hlen);
   // (two rows at a time: their loads are independent)
 #define RX_SWEEP_RG 2
   for (int r0 = 0; r0 < RX_SWR / RX_KS; r0 += RX_SWEEP_RG) {
@@ -338,24 +347,37 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
 #pragma unroll
     for (int q = 0; q < RX_SWEEP_RG; q++) {
       const int row = row0 + q;
-      len[q] = (row < n) ? V.hlen[row] : 0;   // (wave-uniform)
+      len[q] = (row < n) ? hlen[row] : 0;   // (wave-uniform)
       base[q] = (size_t)min(row, n - 1) * V.maxnb;
       lmax = max(lmax, len[q]);
       ps[q] = 0.0; pt[q] = 0.0;
     }
-#pragma unroll 2
-    for (int c0 = 0; c0 < lmax; c0 += 64) {
+    // the matrix stream one chunk ahead of the products (global loads: they stay in flight across the LDS gathers, md_device.h)
+    int jn[RX_SWEEP_RG];
+    double hn[RX_SWEEP_RG];
+    auto load = [&](int c0) {
       const int c = c0 + lane;
 #pragma unroll
       for (int q = 0; q < RX_SWEEP_RG; q++) {
         const bool on = c < len[q];
         const size_t o = base[q] + (on ? c : 0);
         // (a masked lane must not trust entry 0 of the row either: a row without neighbours inside the taper radius was never written)
-        const int j = on ? (COL16 ? (int)c16[o] : c32[o]) : 0;
-        const double h = on ? V.hval[o] : 0.0;
-        const double2 zj = ZLDS ? s_zl[j] : z[j];
-        ps[q] = fma(h, zj.x, ps[q]);
-        pt[q] = fma(h, zj.y, pt[q]);
+        jn[q] = on ? (COL16 ? (int)c16[o] : c32[o]) : 0;
+        hn[q] = on ? hv[o] : 0.0;
+      }
+    };
+    load(0);
+    for (int c0 = 0; c0 < lmax; c0 += 64) {
+      int j[RX_SWEEP_RG];
+      double h[RX_SWEEP_RG];
+#pragma unroll
+      for (int q = 0; q < RX_SWEEP_RG; q++) { j[q] = jn[q]; h[q] = hn[q]; }
+      load(c0 + 64);
+#pragma unroll
+      for (int q = 0; q < RX_SWEEP_RG; q++) {
+        const double2 zj = ZLDS ? s_zl[j[q]] : ldg2(z, j[q]);
+        ps[q] = fma(h[q], zj.x, ps[q]);
+        pt[q] = fma(h[q], zj.y, pt[q]);
       }
     }
 #pragma unroll
@@ -371,7 +393,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   if (lane < RX_SWR && i < n) {
     ys = s_y[0][lane]; yt = s_y[1][lane];
     const double eta = P->sbp[V.rtype[i]].eta;
-    const double2 zi = ZLDS ? s_zl[i] : z[i];
+    const double2 zi = ZLDS ? s_zl[i] : ldg2(z, i);
     ys = fma(eta, zi.x, ys); yt = fma(eta, zi.y, yt);
     double2 *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np);
     if (it < 0) {
