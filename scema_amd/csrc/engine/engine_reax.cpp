@@ -8,6 +8,8 @@ namespace scema_eng {
 // k_final_integrate, k_post, k_remap), the same batch rules (longest run first, active prefix), the same box flips; no
 // cells, no Ewald tables, no SHAKE (lammps_scripts_reax/in.strain.lammps has no fix shake and no kspace_style).
 
+// (the pointers of RxView are qualified as global-memory pointers in device code, reax/rx_types.h: a cast in both passes of the compiler)
+#define RXSET(dst, src) dst = (decltype(dst))(src)
 static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int maxnb, int maxbd, int maxnbn) {
   if (npad > r.cap_pad) {
     HIPCHK(r.nb_cnt.ensure((size_t)npad * 4));
@@ -182,21 +184,21 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     S.sfac = sl.sfac.as<double>(); S.cell_count = sl.cell_count.as<int>();
     S.sc = e->d_sc.as<SimScalars>() + i;
     V.n = n; V.npad = npad; V.maxnb = maxnb; V.maxbd = maxbd;
-    V.rtype = T.d_rtype.as<int>(); V.x = S.x; V.q = R.q.as<double>();
-    V.nbn_cnt = R.nbn_cnt.as<int>(); V.nbn = R.nbn.as<int>(); V.nbnT = R.nbnT.as<int>(); V.maxnbn = maxnbn; V.rnear2 = rnear * rnear;
-    V.qpart = R.qpart.as<double>();
-    V.nb_cnt = R.nb_cnt.as<int>(); V.nb = R.nb.as<int>(); V.bd_cnt = R.bd_cnt.as<int>(); V.bd = R.bd.as<int>(); V.bd_rev = R.bd_rev.as<int>();
-    V.bd_bop = R.bd_bop.as<double>(); V.bd_c = R.bd_c.as<double>(); V.bd_bo = R.bd_bo.as<double>(); V.bd_g = R.bd_g.as<double>(); V.bd_cb = R.bd_cb.as<double>();
-    V.deltap = R.deltap.as<double>(); V.total_bo = R.total_bo.as<double>(); V.cd_delta = R.cd_delta.as<double>(); V.hd = R.hd.as<double>();
-    V.f = S.f; V.hval = R.hval.as<double>(); V.s = R.s.as<double>(); V.t = R.t.as<double>();
+    RXSET(V.rtype, T.d_rtype.as<int>()); RXSET(V.x, S.x); RXSET(V.q, R.q.as<double>());
+    RXSET(V.nbn_cnt, R.nbn_cnt.as<int>()); RXSET(V.nbn, R.nbn.as<int>()); RXSET(V.nbnT, R.nbnT.as<int>()); V.maxnbn = maxnbn; V.rnear2 = rnear * rnear;
+    RXSET(V.qpart, R.qpart.as<double>());
+    RXSET(V.nb_cnt, R.nb_cnt.as<int>()); RXSET(V.nb, R.nb.as<int>()); RXSET(V.bd_cnt, R.bd_cnt.as<int>()); RXSET(V.bd, R.bd.as<int>()); RXSET(V.bd_rev, R.bd_rev.as<int>());
+    RXSET(V.bd_bop, R.bd_bop.as<double>()); RXSET(V.bd_c, R.bd_c.as<double>()); RXSET(V.bd_bo, R.bd_bo.as<double>()); RXSET(V.bd_g, R.bd_g.as<double>()); RXSET(V.bd_cb, R.bd_cb.as<double>());
+    RXSET(V.deltap, R.deltap.as<double>()); RXSET(V.total_bo, R.total_bo.as<double>()); RXSET(V.cd_delta, R.cd_delta.as<double>()); RXSET(V.hd, R.hd.as<double>());
+    RXSET(V.f, S.f); RXSET(V.hval, R.hval.as<double>()); RXSET(V.s, R.s.as<double>()); RXSET(V.t, R.t.as<double>());
     V.warm = (spec.qeq_continue || A.st->qhist_valid) ? 1 : 0;
-    V.hcol16 = col16 ? R.hcol.as<unsigned short>() : nullptr; V.hcol32 = col16 ? nullptr : R.hcol.as<int>(); V.hlen = R.hlen.as<int>(); V.nbT = R.nbT.as<int>();
-    V.hown = R.hown.as<int>(); V.hownlen = R.hownlen.as<int>();
-    V.s_hist = R.s_hist.as<double>(); V.t_hist = R.t_hist.as<double>(); V.qwork = R.qwork.as<double>();
-    V.eparts = R.misc.as<double>();                         // [0, 13) doubles
-    V.qstat = (int *)(R.misc.as<char>() + 128);             // 6 ints
-    V.overflow = (int *)(R.misc.as<char>() + 160);
-    V.sweep_acc = (long long *)(R.misc.as<char>() + 168);   // 2 x 8 bytes
+    RXSET(V.hcol16, col16 ? R.hcol.as<unsigned short>() : nullptr); RXSET(V.hcol32, col16 ? nullptr : R.hcol.as<int>()); RXSET(V.hlen, R.hlen.as<int>()); RXSET(V.nbT, R.nbT.as<int>());
+    RXSET(V.hown, R.hown.as<int>()); RXSET(V.hownlen, R.hownlen.as<int>());
+    RXSET(V.s_hist, R.s_hist.as<double>()); RXSET(V.t_hist, R.t_hist.as<double>()); RXSET(V.qwork, R.qwork.as<double>());
+    RXSET(V.eparts, R.misc.as<double>());                         // [0, 13) doubles
+    RXSET(V.qstat, (int *)(R.misc.as<char>() + 128));             // 6 ints
+    RXSET(V.overflow, (int *)(R.misc.as<char>() + 160));
+    RXSET(V.sweep_acc, (long long *)(R.misc.as<char>() + 168));   // 2 x 8 bytes
     HIPCHK(hipMemsetAsync(sl.wrapn.p, 0, 3 * (size_t)n * 4, e->stream));
     e->h_sims[pos] = S;
     e->h_rxviews[pos] = V;

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *vi
 // lanes over the entries of the list row (read from the row-major copy of the list: contiguous); the entries inside the taper radius
 // are compacted with a ballot and leave as contiguous stores (RxView::hval).  (Lanes over rows and the entries in [k][row] planes, as the
 // other passes have them, made the compacted stores scatter over the planes: 1.30 against 0.70 ms per 72-replica step.)
-__global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   (void)sims;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,6 +182,9 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
   __shared__ double s_gamma[RX_MAXT * RX_MAXT];
   if (threadIdx.x < RX_MAXT * RX_MAXT) s_gamma[threadIdx.x] = P->tbp[threadIdx.x].gamma;
   __syncthreads();
+  double tap[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) tap[m] = P->tap[m];
   for (int r = 0; r < 64 / RX_KS; r++) {
     const int i = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
     if (i >= V.n) return;   // (wave-uniform; no barrier below)
@@ -192,49 +195,63 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
     // The row walk as a pipeline: the list entries two chunks ahead, the partner's position and type one chunk ahead, the arithmetic
     // of rx_qeq_entry (reax/rx_core.h, same operations in the same order) on the chunk whose operands have arrived.  Written as
     // load -> gather -> compute per chunk, every chunk waited for two dependent memory round trips (12 chunks per row).
-    const double xi0 = V.x[3 * i], xi1 = V.x[3 * i + 1], xi2 = V.x[3 * i + 2];
+    // (the row's own position: the same for every lane; as scalars -- and waited for here, not inside the loop behind the stores)
+    const double xi0 = wave_uniform(V.x[3 * i]), xi1 = wave_uniform(V.x[3 * i + 1]), xi2 = wave_uniform(V.x[3 * i + 2]);
     const double swb2 = P->swb * P->swb;
     auto load_ent = [&](int k0) -> int { const int k = k0 + lane; return (k < cnt) ? V.nbT[base + k] : -1; };
+    // One turn of the loop: (1) the STORES of the chunk computed in the turn before, (2) the requests of the turn after (partner records of
+    // the next chunk, list entries of the one after it), (3) the arithmetic of this chunk.  The stores come first because the memory
+    // counter counts in order and the compiler cannot count stores that sit behind a branch: a wait for any load issued before them
+    // becomes a wait for everything, the stores' own round trip included -- with the stores last in the turn every turn ended on that
+    // (80 % of the waves' cycles waiting, rocprofv3 SQ_WAIT_ANY).  Issued first, they have the whole turn to complete.
     int e1 = load_ent(0), e2 = load_ent(64);
     double p0, p1, p2;
     int tjn;
     { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
+    // (the first record is waited for HERE: a wait left to the first use inside the loop stays in the loop, behind the stores of every turn)
+    asm volatile("" : : "v"(p0), "v"(p1), "v"(p2), "v"(tjn), "v"(e2));
+    double h_prev = -1.0;
+    int ent_prev = -1;
+    auto flush = [&]() __attribute__((always_inline)) {
+      const unsigned long long m = __ballot(h_prev >= 0.0);
+      if (h_prev >= 0.0) {
+        const size_t o = base + len + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        V.hval[o] = h_prev;
+        if (V.hcol16) V.hcol16[o] = (unsigned short)(ent_prev & RX_JMASK);
+        else V.hcol32[o] = ent_prev & RX_JMASK;
+      }
+      len += __popcll(m);
+      // the pairs of the row that this end owns, for the non-bonded pass (each pair once)
+      const bool mine = h_prev >= 0.0 && rx_owns(i, ent_prev);
+      const unsigned long long mo = __ballot(mine);
+      if (mine) V.hown[base + lown + __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0))] = ent_prev;
+      lown += __popcll(mo);
+    };
     for (int k0 = 0; k0 < cnt; k0 += 64) {
       const int ent = e1;
       const double q0 = p0, q1 = p1, q2 = p2;
       const int tj = tjn;
       e1 = e2;
+      flush();
       { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
       e2 = load_ent(k0 + 128);
-      int col = 0;
       double h = -1.0;
       if (ent >= 0) {
         double sh[3];
         rx_shift(&V, ent, sh);
-        col = ent & RX_JMASK;
         const double d0 = q0 - xi0 + sh[0], d1 = q1 - xi1 + sh[1], d2 = q2 - xi2 + sh[2];
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
         if (!(r2 > swb2)) {
           const double rr = r2 * rx_rsqrt(r2);
-          double dTap;
-          const double Tap = rx_taper(P, rr, &dTap);
-          h = Tap * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * rr + grow[tj]);
+          double tp = tap[7];
+#pragma unroll
+          for (int m = 6; m >= 0; m--) tp = tp * rr + tap[m];      // rx_taper (value only)
+          h = tp * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * rr + grow[tj]);
         }
       }
-      const unsigned long long m = __ballot(h >= 0.0);
-      if (h >= 0.0) {
-        const size_t o = base + len + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        V.hval[o] = h;
-        if (V.hcol16) V.hcol16[o] = (unsigned short)col;
-        else V.hcol32[o] = col;
-      }
-      len += __popcll(m);
-      // the pairs of the row that this end owns, for the non-bonded pass (each pair once)
-      const bool mine = h >= 0.0 && rx_owns(i, ent);
-      const unsigned long long mo = __ballot(mine);
-      if (mine) V.hown[base + lown + __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0))] = ent;
-      lown += __popcll(mo);
+      h_prev = h; ent_prev = ent;
     }
+    flush();
     if (lane == 0) { V.hlen[i] = len; V.hownlen[i] = lown; }
   }
 }
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views, in
 // sit on different CUs, so no L1 holds a replica's vector for long), and the kernel waited for those, not for the matrix stream.
 extern __shared__ double2 s_zl[];
 template <bool COL16, bool ZLDS>
-__global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, const RxParams *P, double tol, int it) {
+__global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, const RxParams *__restrict__ P, double tol, int it) {
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * RX_SWR + lane, n = V.n;   // (the row of lane < RX_SWR of wave 0 in the row-local part below)
@@ -415,7 +432,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
 }
 
 // it < 0: r = b - H x0, z = r / eta, d = q = 0, partial sums of r.z (slot of iteration 0) and b.b
-__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, const RxParams *P, double tol, int it) {
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, const RxParams *__restrict__ P, double tol, int it) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * QEQ_UT + threadIdx.x, n = V.n;
   if (blockIdx.x * QEQ_UT >= n) return;
@@ -493,7 +510,7 @@ __device__ __forceinline__ void qeq_reduce2(double &a, double &b, double *lds) {
 // One workgroup per replica after `done` iterations of the launches above: a replica that has not converged yet goes on here
 // with the same recurrences on the same arrays (the result does not depend on how many iterations were issued as launches, only
 // the summation order of the scalar products differs), then q = s - (sum s / sum t) t and the history.
-__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, const RxView *views, const RxParams *P, double tol, int done, int maxiter, int setup) {
+__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P, double tol, int done, int maxiter, int setup) {
   const RxView V = views[blockIdx.x];
   (void)sims;
   __shared__ double s_red[32];
@@ -632,7 +649,7 @@ __device__ __forceinline__ void rx_flush_block(double (&e)[RX_NPART], double (&w
 // with its lanes over the entries (read from the row-major copy of the near rows); the few entries that are bonds are compacted with a
 // ballot into the atom's bond row in list order, the sum of their orders by a wave sum.  (One lane per atom walked its 118 near
 // entries serially with three pow and three exp each, 1 822 waves for 72 replicas: 0.63 ms per step.)
-__global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t np = V.npad, plane = (size_t)V.maxbd * np;
@@ -685,14 +702,14 @@ __global__ __launch_bounds__(TPB) void k_rx_rev(const RxView *views) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i < V.n) rx_bonds_rev(&V, i);
 }
-__global__ __launch_bounds__(TPB) void k_rx_corr(const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(TPB) void k_rx_corr(const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i < V.n) rx_bonds_corrected(P, &V, i);
 }
 // pass: 0 atom terms, 3 hydrogen bonds (angles: k_rx_angles, torsions: k_rx_torsions, non-bonded: k_rx_nonbonded_once / k_rx_nonbonded)
 template <int PASS>
-__global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims, const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * RX_TPB + threadIdx.x;
   double e[RX_NPART], w[6];
@@ -713,7 +730,7 @@ __global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims,
 // puts its lanes over the list.  Items beyond the list's capacity (a denser system than any tested) are done where they are found.
 #define RX_TORS_ATOMS 256
 #define RX_TORS_CAP 2048
-__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const SimDev *sims, const RxView *views, const RxParams *P, int cap) {
+__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P, int cap) {
   const RxView V = views[blockIdx.y];
   if ((int)(blockIdx.x * RX_TORS_ATOMS) >= V.n) return;
   __shared__ int s_items[RX_TORS_CAP];
@@ -747,7 +764,7 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const Sim
 // The valence-angle pass the same way: a lane per ANGLE (reax/rx_core.h rx_angle_item).  What an atom's angles share (rx_angle_pre) is
 // computed by the atom's thread first and read from LDS by the items; what they sum for the atom (force on it, dE/dDelta, dE/dSBO)
 // meets in LDS accumulators and is fed back by the atom's thread (rx_angle_post) after a barrier.
-__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDev *sims, const RxView *views, const RxParams *P, int cap) {
+__global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P, int cap) {
   const RxView V = views[blockIdx.y];
   if ((int)(blockIdx.x * RX_TORS_ATOMS) >= V.n) return;
   __shared__ int s_items[RX_TORS_CAP];
@@ -801,7 +818,7 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDe
   rx_flush(e, w, V, *sims[blockIdx.y].sc, P_ANGLE);
 }
 // tapered van der Waals + shielded Coulomb over the full neighbour rows, RX_KS waves per row
-__global__ __launch_bounds__(RX_KT) void k_rx_nonbonded(const SimDev *sims, const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(RX_KT) void k_rx_nonbonded(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
@@ -831,7 +848,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded(const SimDev *sims, cons
 // once per workgroup.  Half the transcendental arithmetic of the both-ends form (three exp, two log, a cube root per pair).
 #define RX_NB1_MAXPAD 6000
 extern __shared__ double s_nbf[];   // [3][npad]
-__global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims, const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = V.n;
   if ((int)(blockIdx.x * 64) >= n) return;
@@ -905,12 +922,12 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims,
   }
   rx_flush_block<RX_KS>(e, w, V, *sims[blockIdx.y].sc, P_LJ);
 }
-__global__ __launch_bounds__(TPB) void k_rx_back1(const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(TPB) void k_rx_back1(const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i < V.n) rx_back_corr(P, &V, i);
 }
-__global__ __launch_bounds__(TPB) void k_rx_back2(const SimDev *sims, const RxView *views, const RxParams *P) {
+__global__ __launch_bounds__(TPB) void k_rx_back2(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * TPB + threadIdx.x;
   double e[RX_NPART], w[6];

@@ -20,8 +20,9 @@
 #define RX_ATOMIC_OR(p, v) (*(p) |= (v))
 #else
 #define RX_FN __device__ __forceinline__
-#define RX_ATOMIC_ADD(p, v) atomicAdd((p), (v))
-#define RX_ATOMIC_OR(p, v) atomicOr((p), (v))
+// (the builtins take pointers of any address space: global_atomic_* through the qualified pointers of RxView; relaxed, device scope, as atomicAdd / atomicOr)
+#define RX_ATOMIC_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#define RX_ATOMIC_OR(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 #endif
 
 #ifdef __cplusplus

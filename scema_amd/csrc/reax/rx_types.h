@@ -68,60 +68,68 @@ typedef struct {
   RxHbp hbp[RX_MAXT * RX_MAXT * RX_MAXT];
 } RxParams;
 
+// Every pointer of the work set is a pointer to GLOBAL memory, and says so in device code: the kernels read this structure from memory, and a
+// pointer read from memory is a generic one to the compiler -- FLAT loads and stores, each waited for with both memory counters at zero
+// (md_device.h).  With the qualifier every access through the view is a global_load / global_store / global_atomic.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RX_G __attribute__((address_space(1)))
+#else
+#define RX_G
+#endif
 // one replica's ReaxFF work set
 typedef struct {
   int n, npad;            // atoms, row stride (n rounded up to 64)
   int maxnb, maxbd;       // row capacities (entries)
   double h[6], lo[3];     // box: lx, ly, lz, yz, xz, xy (LAMMPS h order) and origin
-  const int *rtype;       // [n] force-field type of every atom
-  const double *x;        // [n][3] positions (unwrapped)
-  double *q;              // [n] charges (charge equilibration)
+  const int RX_G *rtype;       // [n] force-field type of every atom
+  const double RX_G *x;        // [n][3] positions (unwrapped)
+  double RX_G *q;              // [n] charges (charge equilibration)
   // neighbour rows inside the list radius (full: j appears in i's row and i in j's)
-  int *nb_cnt;            // [n]
-  int *nb;                // [maxnb][npad]
+  int RX_G *nb_cnt;            // [n]
+  int RX_G *nb;                // [maxnb][npad]
   // near rows: the entries of nb inside the bond cutoff + skin, same order (the bond-order pass walks these; NULL: walk nb)
-  int *nbn_cnt;           // [n]
-  int *nbn;               // [maxnbn][npad]
-  int *nbnT;              // [npad][maxnbn] the near rows once more, row-major (the bond-order pass puts a wave on a row)
+  int RX_G *nbn_cnt;           // [n]
+  int RX_G *nbn;               // [maxnbn][npad]
+  int RX_G *nbnT;              // [npad][maxnbn] the near rows once more, row-major (the bond-order pass puts a wave on a row)
   int maxnbn, pad0_;
   double rnear2;          // (bond cutoff + skin)^2
   // bond rows: pairs with BO' >= cutoff (full)
-  int *bd_cnt;            // [n]
-  int *bd;                // [maxbd][npad] atom | image code
-  int *bd_rev;            // [maxbd][npad] slot of this atom in the partner's row
-  double *bd_bop;         // [4][maxbd][npad] uncorrected: BO' (total, cutoff taken off), BO'_pi, BO'_pi2, r
-  double *bd_c;           // [3][maxbd][npad] dBO'_s/dd = c_s d, dBO'_pi/dd = c_pi d, dBO'_pi2/dd = c_pi2 d
-  double *bd_bo;          // [3][maxbd][npad] corrected: BO, BO_pi, BO_pi2
-  double *bd_g;           // [3][maxbd][npad] dE/d(BO, BO_pi, BO_pi2) gathered by the energy terms (each end into its own or the partner's row)
-  double *bd_cb;          // [maxbd][npad] after the back-propagation: coefficient of d in the bond force, Delta' part aside
-  double *deltap;         // [n] Delta'_i = sum BO' - valency
-  double *total_bo;       // [n] sum of corrected bond orders
-  double *cd_delta;       // [n] dE/d(Delta_i)
-  double *hd;             // [n] dE/d(Delta'_i)
-  double *f;              // [n][3]
+  int RX_G *bd_cnt;            // [n]
+  int RX_G *bd;                // [maxbd][npad] atom | image code
+  int RX_G *bd_rev;            // [maxbd][npad] slot of this atom in the partner's row
+  double RX_G *bd_bop;         // [4][maxbd][npad] uncorrected: BO' (total, cutoff taken off), BO'_pi, BO'_pi2, r
+  double RX_G *bd_c;           // [3][maxbd][npad] dBO'_s/dd = c_s d, dBO'_pi/dd = c_pi d, dBO'_pi2/dd = c_pi2 d
+  double RX_G *bd_bo;          // [3][maxbd][npad] corrected: BO, BO_pi, BO_pi2
+  double RX_G *bd_g;           // [3][maxbd][npad] dE/d(BO, BO_pi, BO_pi2) gathered by the energy terms (each end into its own or the partner's row)
+  double RX_G *bd_cb;          // [maxbd][npad] after the back-propagation: coefficient of d in the bond force, Delta' part aside
+  double RX_G *deltap;         // [n] Delta'_i = sum BO' - valency
+  double RX_G *total_bo;       // [n] sum of corrected bond orders
+  double RX_G *cd_delta;       // [n] dE/d(Delta_i)
+  double RX_G *hd;             // [n] dE/d(Delta'_i)
+  double RX_G *f;              // [n][3]
   // charge equilibration
   // the matrix of the charge equilibration, rebuilt every step, ROW-MAJOR (row i at i * maxnb): only the row entries inside the taper
   // radius (about 70 % of a row of the list), in list order; the kernels that walk it put the lanes of a wave over the entries of one
   // row (contiguous loads) and reduce across the wave
-  double *hval;           // [npad][maxnb] H_ij
-  unsigned short *hcol16; // [npad][maxnb] column (atom index) of the entry; replicas of up to 65 536 atoms (else NULL and hcol32)
-  int *hcol32;
-  int *hlen;              // [npad] entries of the row
-  int *hown;              // [npad][maxnb] the list entries (atom | image code) of the row's pairs inside the taper radius that this
+  double RX_G *hval;           // [npad][maxnb] H_ij
+  unsigned short RX_G *hcol16; // [npad][maxnb] column (atom index) of the entry; replicas of up to 65 536 atoms (else NULL and hcol32)
+  int RX_G *hcol32;
+  int RX_G *hlen;              // [npad] entries of the row
+  int RX_G *hown;              // [npad][maxnb] the list entries (atom | image code) of the row's pairs inside the taper radius that this
                           // end owns (rx_owns: each pair once), compacted; the non-bonded pass walks these
-  int *hownlen;           // [npad]
-  int *nbT;               // [npad][maxnb] the list rows once more, row-major (written with the list; read by the matrix build)
-  double *s, *t;          // [npad] the two solutions
-  double *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)
-  double *qwork;          // [8][npad]: four arrays of (s-system, t-system) pairs per atom: residual r, search direction d,
+  int RX_G *hownlen;           // [npad]
+  int RX_G *nbT;               // [npad][maxnb] the list rows once more, row-major (written with the list; read by the matrix build)
+  double RX_G *s, *t;          // [npad] the two solutions
+  double RX_G *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)
+  double RX_G *qwork;          // [8][npad]: four arrays of (s-system, t-system) pairs per atom: residual r, search direction d,
                           // matrix-vector product q = H d, preconditioned residual z = r / eta (the vector the matrix sweeps gather)
-  double *qpart;          // per-block partial sums of the solver's scalar products (layout: md_reax.hip)
-  int *qstat;             // [6] since the start of the run: iterations, solves, most iterations in one solve (cold solves aside), solves
+  double RX_G *qpart;          // per-block partial sums of the solver's scalar products (layout: md_reax.hip)
+  int RX_G *qstat;             // [6] since the start of the run: iterations, solves, most iterations in one solve (cold solves aside), solves
                           // finished by the single-workgroup loop, (scratch), most iterations in one of the run's first (cold) solves
   int warm;               // the history arrays hold the solutions of the run this one continues (kept, not zeroed, at the start)
-  double *eparts;         // [RX_NPART] energy parts of the step
+  double RX_G *eparts;         // [RX_NPART] energy parts of the step
   int mimg[3];            // neighbour search: 0,0,0 = minimum image (box at least two list radii wide), else images up to mimg[d] boxes away
-  int *overflow;          // bit 1: neighbour row full, bit 2: bond row full, bit 4: charge equilibration did not converge
-  long long *sweep_acc;   // [2] since the start of the run: matrix entries and rows that launches of k_rx_qeq_sweep passed over for this
+  int RX_G *overflow;          // bit 1: neighbour row full, bit 2: bond row full, bit 4: charge equilibration did not converge
+  long long RX_G *sweep_acc;   // [2] since the start of the run: matrix entries and rows that launches of k_rx_qeq_sweep passed over for this
                           // replica (stored entries of its rows x sweeps it took part in): the kernel's algorithmic traffic (bench.py)
 } RxView;
