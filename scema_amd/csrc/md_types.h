@@ -94,6 +94,13 @@ struct SimScalars {
 #endif
 };
 
+// Every pointer of SimDev points to GLOBAL memory and says so in device code (the kernels read this structure from memory; a pointer read from
+// memory is a generic one to the compiler: FLAT loads and stores, each waited for with both memory counters at zero -- md_device.h).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MD_G __attribute__((address_space(1)))
+#else
+#define MD_G
+#endif
 struct SimDev {
   // sizes
   int natoms, npad, ntypes;
@@ -131,54 +138,54 @@ struct SimDev {
   double far_band;        // width (A) of the near skin band C1
   double seg_c2;          // skin band split: (cutmax + skin/2)^2, beyond it segment C2 (skipped while nothing moved far enough)
   // topology (shared by all simulations of one (material, replica))
-  const int *type;
-  const double *q, *mass;       // per atom
-  const double *lj;             // 4 * ntypes^2 : lj1,lj2,lj3,lj4
+  const int MD_G *type;
+  const double MD_G *q, *mass;       // per atom
+  const double MD_G *lj;             // 4 * ntypes^2 : lj1,lj2,lj3,lj4
   // bonded terms: one 64-bit descriptor per term in tile order (BT_D_*), coefficient tables by type
-  const unsigned long long *bt_terms;
-  const double *bt_coef;          // bonds (K,r0) | angles (K,theta0) | dihedrals (K1..K4) | impropers (K,chi0)
+  const unsigned long long MD_G *bt_terms;
+  const double MD_G *bt_coef;          // bonds (K,r0) | angles (K,theta0) | dihedrals (K1..K4) | impropers (K,chi0)
   int bt_ncoef, bt_cf_off[4];
   int nbonds_noshake;
   double sp_w[6];                 // special_bonds weights: lj 1-2,1-3,1-4, coul 1-2,1-3,1-4
-  const int *ex_start, *ex_list;
-  const int *bt_desc, *bt_atoms;   // tile descriptors, local atom lists
-  const int *bt_rank;              // atom -> breadth-first rank in the bond graph (index into fb)
+  const int MD_G *ex_start, *ex_list;
+  const int MD_G *bt_desc, *bt_atoms;   // tile descriptors, local atom lists
+  const int MD_G *bt_rank;              // atom -> breadth-first rank in the bond graph (index into fb)
   int bt_ntile;
-  const int *clus_at, *clus_n; const double *clus_d;
-  const int *free_at;              // the atoms outside the SHAKE clusters (nfree of them)
+  const int MD_G *clus_at, *clus_n; const double MD_G *clus_d;
+  const int MD_G *free_at;              // the atoms outside the SHAKE clusters (nfree of them)
   // state
-  double *x, *v, *f;
-  double *fs;       // pair forces in slot order, [3][npad] (zeroed by k_pack, accumulated by k_pair, folded into f by k_ewald_force)
-  double *fb;       // bonded forces in breadth-first-rank order, [natoms][3] (every entry written by the tile that owns it, k_bonded)
-  double *virb;     // per bonded tile: 6 partial sums of the lumped bonded virial (no atomics; folded by k_ewald_force)
-  int *slot_of;     // atom -> slot
-  int *tile_nj;     // per cell: entries of its j table
-  int *tile_order;  // per cell, at its cluster range: the cell's clusters grouped by the wave of k_pair that takes them
-  double *virp;     // per cell and wave of k_pair: 6 partial sums of the pair virial's image-shift part (no atomics)
-  int *tile_wstart; // per cell: 9 group boundaries into tile_order (k_pair's schedule, fixed at build time)
-  int *tile_jtab;   // per cell: capj entries (image code | slot), own cell first
+  double MD_G *x, *v, *f;
+  double MD_G *fs;       // pair forces in slot order, [3][npad] (zeroed by k_pack, accumulated by k_pair, folded into f by k_ewald_force)
+  double MD_G *fb;       // bonded forces in breadth-first-rank order, [natoms][3] (every entry written by the tile that owns it, k_bonded)
+  double MD_G *virb;     // per bonded tile: 6 partial sums of the lumped bonded virial (no atomics; folded by k_ewald_force)
+  int MD_G *slot_of;     // atom -> slot
+  int MD_G *tile_nj;     // per cell: entries of its j table
+  int MD_G *tile_order;  // per cell, at its cluster range: the cell's clusters grouped by the wave of k_pair that takes them
+  double MD_G *virp;     // per cell and wave of k_pair: 6 partial sums of the pair virial's image-shift part (no atomics)
+  int MD_G *tile_wstart; // per cell: 9 group boundaries into tile_order (k_pair's schedule, fixed at build time)
+  int MD_G *tile_jtab;   // per cell: capj entries (image code | slot), own cell first
   // pair structures
-  double4 *xq;      // slot records as two arrays of 16-byte halves: (x,y)[npad] then (z,q)[npad] (wrapped positions, charge)
-  int *stype;       // slot-ordered type
-  int *perm;        // slot -> atom
-  int *slot_tmp;    // unsorted cell fill
-  int *wrapn;       // atom -> integer wrap (3)
-  double *xhold;
-  int *cell_of, *ckey, *cell_count, *cell_start, *cell_fill;
-  int *numneigh, *neigh;  // per cluster: {entries in segments A+B+C1 (front), entries in segment C2 (back)}; rows of maxneigh entries
+  double4 MD_G *xq;      // slot records as two arrays of 16-byte halves: (x,y)[npad] then (z,q)[npad] (wrapped positions, charge)
+  int MD_G *stype;       // slot-ordered type
+  int MD_G *perm;        // slot -> atom
+  int MD_G *slot_tmp;    // unsorted cell fill
+  int MD_G *wrapn;       // atom -> integer wrap (3)
+  double MD_G *xhold;
+  int MD_G *cell_of, *ckey, *cell_count, *cell_start, *cell_fill;
+  int MD_G *numneigh, *neigh;  // per cluster: {entries in segments A+B+C1 (front), entries in segment C2 (back)}; rows of maxneigh entries
   // ewald
-  const int *kn;    // 3 ints per k
-  const int *krun;  // per k: +-(number of following k-vectors that continue its row: same n1, n2; n3 + 1 or n3 - 1 each), sign = direction
-  const int *kgrp;  // 8 ints per group of k-vectors (n1, +-n2, +-n3): n1, |n2|, |n3|, k index of (+,+), (-,+), (+,-), (-,-) or -1
+  const int MD_G *kn;    // 3 ints per k
+  const int MD_G *krun;  // per k: +-(number of following k-vectors that continue its row: same n1, n2; n3 + 1 or n3 - 1 each), sign = direction
+  const int MD_G *kgrp;  // 8 ints per group of k-vectors (n1, +-n2, +-n3): n1, |n2|, |n3|, k index of (+,+), (-,+), (+,-), (-,-) or -1
   int ngrp;
-  double *sfac;     // 2 per k
-  double *kvec;     // 4 per k : kx,ky,kz,ug
+  double MD_G *sfac;     // 2 per k
+  double MD_G *kvec;     // 4 per k : kx,ky,kz,ug
   // PPPM (md_pppm.hip; pg[0] == 0: the Ewald sum above is used)
   int pg[3], pad_pg_;
-  double *pgrid;    // complex grid [nz][ny][nx] (x fastest) of this simulation: charge density / its transform
-  double *pfield;   // the three complex field grids of this simulation, pgstride complex elements apart (the batch keeps the charge
+  double MD_G *pgrid;    // complex grid [nz][ny][nx] (x fastest) of this simulation: charge density / its transform
+  double MD_G *pfield;   // the three complex field grids of this simulation, pgstride complex elements apart (the batch keeps the charge
                     // grids of all simulations together, and all field grids: one batched, contiguous transform per direction)
   long long pgstride;
-  double *pgf;      // influence function [nz][ny][nx]
-  SimScalars *sc;
+  double MD_G *pgf;      // influence function [nz][ny][nx]
+  SimScalars MD_G *sc;
 };
