@@ -489,10 +489,17 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     bool own_chunks = true;
     auto row_loop = [&](auto cref_tag) __attribute__((always_inline)) {
     constexpr bool CREF = decltype(cref_tag)::value;
+    // (segment-A entries of a chunk are STORED at the top of the next turn, before that turn's requests: the memory counter counts in
+    // order and the compiler cannot count a store behind a branch, so a store at the end of the turn made the wait for the records
+    // requested at its top -- due at the start of the next turn -- a wait for the store's own round trip as well.  Issued first, it has
+    // the whole turn.)
+    int posA_prev = -1, entA_prev = 0;
     for (int base = 0; base < nl; base += 64) {
       const int l = l_n;
       const int jt = jt_n;
       const double px = pn0, py = pn1, pz = pn2;
+      if (posA_prev >= 0) row[posA_prev] = entA_prev;
+      posA_prev = -1;
       {
         const int in_ = base + 64 + lane;
         l_n = (in_ < nl) ? (qall ? in_ : (int)ql[in_]) : -1;
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mS = __ballot(isS), mD = __ballot(isD);
       if (mask) {
         const int entry = l | ((int)((unsigned)jt >> 28) << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT);
-        if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) row[pos] = entry; }
+        if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) { posA_prev = pos; entA_prev = entry; } }
         else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
         else { const int pos = capB - 1 - (nC + nD + popc_below(mS)); if (pos >= 0) lb[pos] = entry | (isD ? E_FAR : 0); }
       }
@@ -566,6 +573,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       npairs += __popc(mask);
       if (CREF) npairs_ref += __popc(refm);
     }
+    if (posA_prev >= 0) row[posA_prev] = entA_prev;
     };
     // (the second count is a statistic of a run's first build: its own copy of the loop, so that every other build does not pay for
     // four compares per candidate that the compiler would otherwise keep as predicated code)

@@ -666,29 +666,54 @@ __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxP
     const size_t base = (size_t)i * V.maxnbn;
     int nb = 0;
     double sum = 0.0;
-    for (int k0 = 0; k0 < cnt; k0 += 64) {
-      const int k = k0 + lane;
-      int e = 0, ok = 0;
-      double bo = 0, bp = 0, bpp = 0, rr = 0, cs = 0, cp = 0, cpp = 0;
-      if (k < cnt) { e = V.nbnT[base + k]; ok = rx_bond_prime_entry(P, &V, i, e, &bo, &bp, &bpp, &rr, &cs, &cp, &cpp, s_sbp, s_tbp); }
-      const unsigned long long m = __ballot(ok);
-      if (ok) {
+    // the row walk as in k_rx_hrow: the stores of the chunk before, the requests of the chunks after (partner records one chunk ahead, near-row
+    // entries two), the arithmetic of this one
+    const int ti = V.rtype[i];
+    const double xi0 = wave_uniform(V.x[3 * i]), xi1 = wave_uniform(V.x[3 * i + 1]), xi2 = wave_uniform(V.x[3 * i + 2]);
+    auto load_ent = [&](int k0) -> int { const int k = k0 + lane; return (k < cnt) ? V.nbnT[base + k] : -1; };
+    int e1 = load_ent(0), e2 = load_ent(64);
+    double p0, p1, p2;
+    int tjn;
+    { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
+    asm volatile("" : : "v"(p0), "v"(p1), "v"(p2), "v"(tjn), "v"(e2));   // (waited for here, not inside the loop)
+    int ok_prev = 0, e_prev = 0;
+    double bo_p = 0, bp_p = 0, bpp_p = 0, rr_p = 0, cs_p = 0, cp_p = 0, cpp_p = 0;
+    auto flush = [&]() __attribute__((always_inline)) {
+      const unsigned long long m = __ballot(ok_prev);
+      if (ok_prev) {
         const int pos = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if (pos < V.maxbd) {
           const size_t o = (size_t)pos * np + i;
-          V.bd[o] = e;
-          V.bd_bop[o] = bo - P->bo_cut;
-          V.bd_bop[plane + o] = bp;
-          V.bd_bop[2 * plane + o] = bpp;
-          V.bd_bop[3 * plane + o] = rr;
-          V.bd_c[o] = cs;
-          V.bd_c[plane + o] = cp;
-          V.bd_c[2 * plane + o] = cpp;
-          sum += bo - P->bo_cut;
+          V.bd[o] = e_prev;
+          V.bd_bop[o] = bo_p - P->bo_cut;
+          V.bd_bop[plane + o] = bp_p;
+          V.bd_bop[2 * plane + o] = bpp_p;
+          V.bd_bop[3 * plane + o] = rr_p;
+          V.bd_c[o] = cs_p;
+          V.bd_c[plane + o] = cp_p;
+          V.bd_c[2 * plane + o] = cpp_p;
+          sum += bo_p - P->bo_cut;
         }
       }
       nb += __popcll(m);
+    };
+    for (int k0 = 0; k0 < cnt; k0 += 64) {
+      const int ent = e1, tj = tjn;
+      const double q0 = p0, q1 = p1, q2 = p2;
+      e1 = e2;
+      flush();
+      { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
+      e2 = load_ent(k0 + 128);
+      ok_prev = 0;
+      if (ent >= 0) {
+        double sh[3];
+        rx_shift(&V, ent, sh);
+        const double d0 = q0 - xi0 + sh[0], d1 = q1 - xi1 + sh[1], d2 = q2 - xi2 + sh[2];
+        ok_prev = rx_bond_prime_pair(P, s_sbp, s_tbp, ti, tj, d0 * d0 + d1 * d1 + d2 * d2, &bo_p, &bp_p, &bpp_p, &rr_p, &cs_p, &cp_p, &cpp_p);
+      }
+      e_prev = ent;
     }
+    flush();
     sum = wave_sum(sum);
     if (lane == 0) {
       if (nb > V.maxbd) { atomicOr(V.overflow, 2); nb = V.maxbd; }

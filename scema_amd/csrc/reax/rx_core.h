@@ -184,21 +184,16 @@ RX_FN void rx_atom_deltas(const RxParams *P, int type, double total_bo, RxAtomD 
 // uncorrected bond order of atom i with the partner of near-row entry e: BO' (total, cutoff NOT yet taken off), its pi parts, r and
 // the coefficients of d in dBO'/dd; returns 0 when the pair is beyond the bond cutoff or BO' below the threshold
 // (sbp, tbp: the type tables, e.g. staged in LDS; NULL: the ones of P)
-RX_FN int rx_bond_prime_entry(const RxParams *P, const RxView *V, int i, int e, double *bo, double *bp, double *bpp, double *r_out, double *cs, double *cp, double *cpp,
-                              const RxSbp *sbp RX_DEFAULT_NULL, const RxTbp *tbp RX_DEFAULT_NULL) {
-  if (!sbp) sbp = P->sbp;
-  if (!tbp) tbp = P->tbp;
-  const int ti = V->rtype[i];
-  const RxSbp *si = &sbp[ti];
-  double d[3];
-  const int j = rx_partner(V, i, e, d);
-  const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+// ... the arithmetic alone: types ti, tj, squared distance r2 (the kernel gathers the partner's record a chunk ahead); the type tables are
+// the caller's (staged in LDS by k_rx_bonds, P's own for everyone else)
+template <class SBP, class TBP>
+RX_FN int rx_bond_prime_pair(const RxParams *P, const SBP *sbp, const TBP *tbp, int ti, int tj, double r2, double *bo, double *bp, double *bpp, double *r_out,
+                             double *cs, double *cp, double *cpp) {
   if (r2 > RX_BOND_CUT * RX_BOND_CUT) return 0;
+  const SBP *si = &sbp[ti], *sj = &sbp[tj];
+  const TBP *t = &tbp[ti * RX_MAXT + tj];
   // (r / r_x)^p = exp(p (log r - log r_x)): ONE logarithm for the three bond orders of the entry (RxTbp::lr_*)
   const double rinv = rx_rsqrt(r2), r = r2 * rinv, r2inv = rinv * rinv, lr = 0.5 * rx_log(r2);
-  const int tj = V->rtype[j];
-  const RxSbp *sj = &sbp[tj];
-  const RxTbp *t = &tbp[ti * RX_MAXT + tj];
   double bs = 0;
   *bp = 0; *bpp = 0; *cs = 0; *cp = 0; *cpp = 0;
   if (si->r_s > 0.0 && sj->r_s > 0.0) {
@@ -233,30 +228,8 @@ RX_FN void rx_bonds_prime(const RxParams *P, const RxView *V, int i) {
     const int e = row[(size_t)k * np + i];
     double d[3];
     const int j = rx_partner(V, i, e, d);
-    const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    if (r2 > RX_BOND_CUT * RX_BOND_CUT) continue;
-    const double rinv = rx_rsqrt(r2), r = r2 * rinv, r2inv = rinv * rinv, lr = 0.5 * rx_log(r2);
-    const int tj = V->rtype[j];
-    const RxSbp *sj = &P->sbp[tj];
-    const RxTbp *t = &P->tbp[ti * RX_MAXT + tj];
-    double bs = 0, bp = 0, bpp = 0, cs = 0, cp = 0, cpp = 0;
-    if (si->r_s > 0.0 && sj->r_s > 0.0) {
-      const double c12 = t->p_bo1 * exp(t->p_bo2 * (lr - t->lr_s));
-      bs = (1.0 + P->bo_cut) * exp(c12);
-      cs = bs * t->p_bo2 * c12 * r2inv;
-    }
-    if (si->r_pi > 0.0 && sj->r_pi > 0.0) {
-      const double c34 = t->p_bo3 * exp(t->p_bo4 * (lr - t->lr_p));
-      bp = exp(c34);
-      cp = bp * t->p_bo4 * c34 * r2inv;
-    }
-    if (si->r_pi_pi > 0.0 && sj->r_pi_pi > 0.0) {
-      const double c56 = t->p_bo5 * exp(t->p_bo6 * (lr - t->lr_pp));
-      bpp = exp(c56);
-      cpp = bpp * t->p_bo6 * c56 * r2inv;
-    }
-    const double bo = bs + bp + bpp;
-    if (bo < P->bo_cut) continue;
+    double bo, bp, bpp, r, cs, cp, cpp;
+    if (!rx_bond_prime_pair(P, P->sbp, P->tbp, ti, V->rtype[j], d[0] * d[0] + d[1] * d[1] + d[2] * d[2], &bo, &bp, &bpp, &r, &cs, &cp, &cpp)) continue;
     if (nb >= V->maxbd) { RX_ATOMIC_OR(V->overflow, 2); break; }
     const size_t o = (size_t)nb * np + i;
     V->bd[o] = e;
