@@ -173,6 +173,17 @@ __global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *vi
 // lanes over the entries of the list row (read from the row-major copy of the list: contiguous); the entries inside the taper radius
 // are compacted with a ballot and leave as contiguous stores (RxView::hval).  (Lanes over rows and the entries in [k][row] planes, as the
 // other passes have them, made the compacted stores scatter over the planes: 1.30 against 0.70 ms per 72-replica step.)
+// The image shift of a row entry (rx_shift: two integer divisions by 5, nine multiplications) from a table of the 125 codes in LDS -- the box
+// is one per replica, and a workgroup works on one replica.  Same products in the same order as rx_shift: bitwise the same shifts.
+#define RX_NSHIFT 125
+__device__ __forceinline__ void rx_shift_table(const RxView &V, double *s_sh) {
+  for (int code = threadIdx.x; code < RX_NSHIFT; code += blockDim.x) {
+    const int sx = code % 5 - 2, sy = (code / 5) % 5 - 2, sz = code / 25 - 2;
+    s_sh[3 * code] = sx * V.h[0] + sy * V.h[5] + sz * V.h[4];
+    s_sh[3 * code + 1] = sy * V.h[1] + sz * V.h[3];
+    s_sh[3 * code + 2] = sz * V.h[2];
+  }
+}
 __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   (void)sims;
@@ -181,6 +192,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
   // (positions and types staged in LDS as well, as the sweep does with its vector: 418.5 against 416.5 evaluations/s, not kept)
   __shared__ double s_gamma[RX_MAXT * RX_MAXT];
   if (threadIdx.x < RX_MAXT * RX_MAXT) s_gamma[threadIdx.x] = P->tbp[threadIdx.x].gamma;
+  __shared__ double s_sh[3 * RX_NSHIFT];
+  rx_shift_table(V, s_sh);
   __syncthreads();
   double tap[8];
 #pragma unroll
@@ -237,8 +250,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
       e2 = load_ent(k0 + 128);
       double h = -1.0;
       if (ent >= 0) {
-        double sh[3];
-        rx_shift(&V, ent, sh);
+        const double *sh = s_sh + 3 * ((ent >> 24) & 0x7F);
         const double d0 = q0 - xi0 + sh[0], d1 = q1 - xi1 + sh[1], d2 = q2 - xi2 + sh[2];
         const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
         if (!(r2 > swb2)) {
@@ -658,6 +670,8 @@ __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxP
   __shared__ RxTbp s_tbp[RX_MAXT * RX_MAXT];
   for (int k = threadIdx.x; k < (int)(sizeof(s_sbp) / 8); k += TPB) ((double *)s_sbp)[k] = ((const double *)P->sbp)[k];
   for (int k = threadIdx.x; k < (int)(sizeof(s_tbp) / 8); k += TPB) ((double *)s_tbp)[k] = ((const double *)P->tbp)[k];
+  __shared__ double s_sh[3 * RX_NSHIFT];
+  rx_shift_table(V, s_sh);
   __syncthreads();
   for (int r = 0; r < 8; r++) {
     const int i = blockIdx.x * (8 * (TPB / 64)) + wave * 8 + r;
@@ -706,8 +720,7 @@ __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxP
       e2 = load_ent(k0 + 128);
       ok_prev = 0;
       if (ent >= 0) {
-        double sh[3];
-        rx_shift(&V, ent, sh);
+        const double *sh = s_sh + 3 * ((ent >> 24) & 0x7F);
         const double d0 = q0 - xi0 + sh[0], d1 = q1 - xi1 + sh[1], d2 = q2 - xi2 + sh[2];
         ok_prev = rx_bond_prime_pair(P, s_sbp, s_tbp, ti, tj, d0 * d0 + d1 * d1 + d2 * d2, &bo_p, &bp_p, &bpp_p, &rr_p, &cs_p, &cp_p, &cpp_p);
       }
@@ -881,6 +894,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims,
   __shared__ RxTbp s_tbp[RX_MAXT * RX_MAXT];   // the pair parameters in LDS (a dependent global load less per pair)
   for (int k = threadIdx.x; k < (int)(sizeof(s_tbp) / 8); k += RX_KT) ((double *)s_tbp)[k] = ((const double *)P->tbp)[k];
   for (int k = threadIdx.x; k < 3 * (int)np; k += RX_KT) s_nbf[k] = 0.0;
+  __shared__ double s_sh[3 * RX_NSHIFT];
+  rx_shift_table(V, s_sh);
   __syncthreads();
   double e[RX_NPART], w[6];
 #pragma unroll
@@ -909,8 +924,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims,
       e2 = load_ent(c0 + 128);
       if (ent >= 0) {
         const int j = ent & RX_JMASK;
-        double sh[3];
-        rx_shift(&V, ent, sh);
+        const double *sh = s_sh + 3 * ((ent >> 24) & 0x7F);
         const double d0 = x0 - xi0 + sh[0], d1 = x1 - xi1 + sh[1], d2 = x2 - xi2 + sh[2];
         double ev, ec, sc_;
         rx_nonbonded_pair(P, &s_tbp[ti * RX_MAXT + tj], qi * qj, d0 * d0 + d1 * d1 + d2 * d2, &ev, &ec, &sc_);
