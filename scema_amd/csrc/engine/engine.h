@@ -273,6 +273,9 @@ struct scema_md_engine {
   std::vector<std::unique_ptr<Slot>> slots;
   DevBuf d_sims, d_sc, d_local_stress, d_kpack, d_minptr, d_boxpair, d_pppm, d_copytab;
   std::vector<MdkCopy> h_copytab;
+  DevBuf d_zerotab, d_rxstat;            // zero-fill descriptors; the solver statistics of a ReaxFF batch, gathered for one read-back
+  std::vector<MdkZero> h_zerotab;
+  std::vector<long long> h_rxstat;
   // x and v of every state an update advances, as they were before it: the retry after a list overflow restarts from
   // them, and a failed update (on this rank or on another) puts them back
   std::vector<std::unique_ptr<DevBuf>> bak_x, bak_v;

@@ -93,6 +93,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   // columns of the charge-equilibration matrix as 16-bit atom indices when every replica of the batch has at most 65 536 atoms
   bool col16 = !(scema_env("SCEMA_MD_RX_COL32") && atoi(scema_env("SCEMA_MD_RX_COL32")) != 0);   // (test switch: 32-bit columns for any size)
   for (int i = 0; i < ns; i++) col16 = col16 && sims[i].st->topo->natoms <= 65536;
+  e->h_zerotab.clear();
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
     ActiveSim &A = sims[i];
@@ -199,7 +200,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     RXSET(V.qstat, (int *)(R.misc.as<char>() + 128));             // 6 ints
     RXSET(V.overflow, (int *)(R.misc.as<char>() + 160));
     RXSET(V.sweep_acc, (long long *)(R.misc.as<char>() + 168));   // 2 x 8 bytes
-    HIPCHK(hipMemsetAsync(sl.wrapn.p, 0, 3 * (size_t)n * 4, e->stream));
+    e->h_zerotab.push_back(MdkZero{sl.wrapn.as<int>(), 3 * (long long)n});
     e->h_sims[pos] = S;
     e->h_rxviews[pos] = V;
     maxatoms = std::max(maxatoms, n); maxpad = std::max(maxpad, npad); maxsteps = std::max(maxsteps, A.nsteps);
@@ -208,6 +209,11 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   HIPCHK(e->d_rxviews.ensure((size_t)ns * sizeof(RxView)));
   HIPCHK(hipMemcpyAsync(e->d_sims.p, e->h_sims.data(), (size_t)ns * sizeof(SimDev), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->d_rxviews.p, e->h_rxviews.data(), (size_t)ns * sizeof(RxView), hipMemcpyHostToDevice, e->stream));
+  if (!e->h_zerotab.empty()) {   // the wrap counters of every replica start from zero: one launch
+    HIPCHK(e->d_zerotab.ensure(e->h_zerotab.size() * sizeof(MdkZero)));
+    HIPCHK(hipMemcpyAsync(e->d_zerotab.p, e->h_zerotab.data(), e->h_zerotab.size() * sizeof(MdkZero), hipMemcpyHostToDevice, e->stream));
+    mdk_zero_many(e->stream, e->d_zerotab.as<MdkZero>(), (int)e->h_zerotab.size(), 3 * (long long)maxatoms);
+  }
   const SimDev *D = e->d_sims.as<SimDev>();
   RxView *VV = e->d_rxviews.as<RxView>();
   const RxParams *RP = e->d_rxparams.as<RxParams>();
@@ -344,13 +350,18 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     mdk_copy_many(st, e->d_copytab.as<MdkCopy>(), (int)tab.size(), maxn);
   }
   HIPCHK(hipMemcpyAsync(e->h_sc.data(), e->d_sc.p, (size_t)ns * sizeof(SimScalars), hipMemcpyDeviceToHost, st));
+  // (the solver statistics of all replicas in ONE read-back: two small copies per replica were 2 x 72 launch gaps of 24 us per run)
   std::vector<int> qs(6 * (size_t)ns, 0);
   std::vector<long long> acc(2 * (size_t)ns, 0);
-  for (int pos = 0; pos < ns; pos++) {
-    HIPCHK(hipMemcpyAsync(&qs[6 * pos], e->h_rxviews[pos].qstat, 24, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&acc[2 * pos], e->h_rxviews[pos].sweep_acc, 16, hipMemcpyDeviceToHost, st));
-  }
+  HIPCHK(e->d_rxstat.ensure(8 * (size_t)ns * sizeof(long long)));
+  e->h_rxstat.assign(8 * (size_t)ns, 0);
+  mdk_reax_collect_stats(st, e->d_rxviews.as<RxView>(), ns, e->d_rxstat.as<long long>());
+  HIPCHK(hipMemcpyAsync(e->h_rxstat.data(), e->d_rxstat.p, 8 * (size_t)ns * sizeof(long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  for (int pos = 0; pos < ns; pos++) {
+    for (int k = 0; k < 6; k++) qs[6 * pos + k] = (int)e->h_rxstat[8 * pos + k];
+    acc[2 * pos] = e->h_rxstat[8 * pos + 6]; acc[2 * pos + 1] = e->h_rxstat[8 * pos + 7];
+  }
   HIPCHK(hipGetLastError());
   if (prof) {
     // the matrix sweep of the charge equilibration, the HBM-bound kernel of this path: HIP-event time of every launch, and what

@@ -32,3 +32,6 @@ void mdk_phase_end(hipStream_t st, const SimDev *d, int ns, int maxatoms);
 // ncopies device-to-device copies of doubles in one launch; the table lives in device memory, maxn = the longest copy
 struct MdkCopy { const double *src; double *dst; long long n; };
 void mdk_copy_many(hipStream_t st, const MdkCopy *tab, int ncopies, long long maxn);
+// many zero fills in one launch (n 32-bit words each): a hipMemsetAsync per replica costs a launch gap each
+struct MdkZero { int *p; long long n; };
+void mdk_zero_many(hipStream_t st, const MdkZero *tab, int nfills, long long maxn);

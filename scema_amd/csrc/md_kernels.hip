@@ -1352,6 +1352,16 @@ void mdk_copy_many(hipStream_t st, const MdkCopy *tab, int ncopies, long long ma
   hipLaunchKernelGGL(k_copy_many, grid2(std::max(bx, 1), ncopies), dim3(256), 0, st, tab);
 }
 
+__global__ __launch_bounds__(256) void k_zero_many(const MdkZero *tab) {
+  const MdkZero c = tab[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < c.n; i += (long long)gridDim.x * 256) c.p[i] = 0;
+}
+void mdk_zero_many(hipStream_t st, const MdkZero *tab, int nfills, long long maxn) {
+  if (nfills <= 0 || maxn <= 0) return;
+  const int bx = (int)std::min<long long>(cdiv((int)std::min<long long>(maxn, 1 << 30), 256 * 4), 64);
+  hipLaunchKernelGGL(k_zero_many, grid2(std::max(bx, 1), nfills), dim3(256), 0, st, tab);
+}
+
 void mdk_phase_end(hipStream_t st, const SimDev *d, int ns, int maxatoms) {
   hipLaunchKernelGGL(k_scale_v, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   hipLaunchKernelGGL(k_phase_end, dim3(ns), dim3(64), 0, st, d);

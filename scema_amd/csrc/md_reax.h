@@ -19,3 +19,5 @@ struct RxQeqPlan {
 void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, const RxQeqPlan &plan, int terms,
                      bool col16, std::vector<hipEvent_t> *sweep_events = nullptr, size_t *sweep_events_used = nullptr);
 // sweep_events: when given, a HIP-event pair is recorded around every launch of k_rx_qeq_sweep (pool grown on demand)
+// the solver statistics of the batch in one array (8 words per replica: RxView::qstat[0..5], RxView::sweep_acc[0..1]) for ONE read-back
+void mdk_reax_collect_stats(hipStream_t st, const RxView *v, int ns, long long *out);

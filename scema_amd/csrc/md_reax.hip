@@ -1012,6 +1012,16 @@ __global__ __launch_bounds__(TPB) void k_rx_phase_init(const RxView *views) {
 static inline dim3 g2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)ns, 1); }
 static inline int cdv(int a, int b) { return (a + b - 1) / b; }
 
+__global__ void k_rx_collect_stats(const RxView *views, int ns, long long *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const RxView &V = views[i];
+  for (int k = 0; k < 6; k++) out[8 * i + k] = V.qstat[k];
+  out[8 * i + 6] = V.sweep_acc[0]; out[8 * i + 7] = V.sweep_acc[1];
+}
+void mdk_reax_collect_stats(hipStream_t st, const RxView *v, int ns, long long *out) {
+  if (ns > 0) hipLaunchKernelGGL(k_rx_collect_stats, dim3((ns + 63) / 64), dim3(64), 0, st, v, ns, out);
+}
 void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad) {
   hipLaunchKernelGGL(k_rx_phase_init, g2(cdv(maxpad, TPB), ns), dim3(TPB), 0, st, v);
 }
