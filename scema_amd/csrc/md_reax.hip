@@ -198,73 +198,94 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
   double tap[8];
 #pragma unroll
   for (int m = 0; m < 8; m++) tap[m] = P->tap[m];
-  for (int r = 0; r < 64 / RX_KS; r++) {
-    const int i = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
-    if (i >= V.n) return;   // (wave-uniform; no barrier below)
-    const int cnt = V.nb_cnt[i];
-    const size_t base = (size_t)i * V.maxnb;
-    const double *grow = s_gamma + V.rtype[i] * RX_MAXT;
-    int len = 0, lown = 0;
-    // The row walk as a pipeline: the list entries two chunks ahead, the partner's position and type one chunk ahead, the arithmetic
-    // of rx_qeq_entry (reax/rx_core.h, same operations in the same order) on the chunk whose operands have arrived.  Written as
-    // load -> gather -> compute per chunk, every chunk waited for two dependent memory round trips (12 chunks per row).
-    // (the row's own position: the same for every lane; as scalars -- and waited for here, not inside the loop behind the stores)
-    const double xi0 = wave_uniform(V.x[3 * i]), xi1 = wave_uniform(V.x[3 * i + 1]), xi2 = wave_uniform(V.x[3 * i + 2]);
-    const double swb2 = P->swb * P->swb;
-    auto load_ent = [&](int k0) -> int { const int k = k0 + lane; return (k < cnt) ? V.nbT[base + k] : -1; };
-    // One turn of the loop: (1) the STORES of the chunk computed in the turn before, (2) the requests of the turn after (partner records of
-    // the next chunk, list entries of the one after it), (3) the arithmetic of this chunk.  The stores come first because the memory
-    // counter counts in order and the compiler cannot count stores that sit behind a branch: a wait for any load issued before them
-    // becomes a wait for everything, the stores' own round trip included -- with the stores last in the turn every turn ended on that
-    // (80 % of the waves' cycles waiting, rocprofv3 SQ_WAIT_ANY).  Issued first, they have the whole turn to complete.
-    int e1 = load_ent(0), e2 = load_ent(64);
-    double p0, p1, p2;
-    int tjn;
-    { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
-    // (the first record is waited for HERE: a wait left to the first use inside the loop stays in the loop, behind the stores of every turn)
-    asm volatile("" : : "v"(p0), "v"(p1), "v"(p2), "v"(tjn), "v"(e2));
-    double h_prev = -1.0;
-    int ent_prev = -1;
-    auto flush = [&]() __attribute__((always_inline)) {
-      const unsigned long long m = __ballot(h_prev >= 0.0);
-      if (h_prev >= 0.0) {
-        const size_t o = base + len + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        V.hval[o] = h_prev;
-        if (V.hcol16) V.hcol16[o] = (unsigned short)(ent_prev & RX_JMASK);
-        else V.hcol32[o] = ent_prev & RX_JMASK;
-      }
-      len += __popcll(m);
-      // the pairs of the row that this end owns, for the non-bonded pass (each pair once)
-      const bool mine = h_prev >= 0.0 && rx_owns(i, ent_prev);
-      const unsigned long long mo = __ballot(mine);
-      if (mine) V.hown[base + lown + __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0))] = ent_prev;
-      lown += __popcll(mo);
-    };
-    for (int k0 = 0; k0 < cnt; k0 += 64) {
-      const int ent = e1;
-      const double q0 = p0, q1 = p1, q2 = p2;
-      const int tj = tjn;
-      e1 = e2;
-      flush();
-      { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
-      e2 = load_ent(k0 + 128);
-      double h = -1.0;
-      if (ent >= 0) {
-        const double *sh = s_sh + 3 * ((ent >> 24) & 0x7F);
-        const double d0 = q0 - xi0 + sh[0], d1 = q1 - xi1 + sh[1], d2 = q2 - xi2 + sh[2];
-        const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-        if (!(r2 > swb2)) {
-          const double rr = r2 * rx_rsqrt(r2);
-          double tp = tap[7];
+  const double swb2 = P->swb * P->swb;
+  // A wave walks TWO of its rows at a time (RG): their requests are independent, so a record has two chunks of arithmetic to arrive in
+  // instead of one.  Per row, one turn of the loop is: (1) the STORES of the chunk computed in the turn before, (2) the requests of the
+  // turn after (partner records of the next chunk, list entries of the one after it), (3) the arithmetic of this chunk (rx_qeq_entry of
+  // reax/rx_core.h, same operations in the same order).  The stores come first because the memory counter counts in order and the
+  // compiler cannot count stores that sit behind a branch: a wait for any load issued before them becomes a wait for everything, the
+  // stores' own round trip included -- with the stores last in the turn every turn ended on that (80 % of the waves' cycles waiting,
+  // rocprofv3 SQ_WAIT_ANY).  Issued first, they have the whole turn to complete.
+  constexpr int RG = 2;
+  for (int r = 0; r < 64 / RX_KS; r += RG) {
+    const int ifirst = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
+    if (ifirst >= V.n) return;   // (wave-uniform; no barrier below)
+    int row[RG], cnt[RG], len[RG], lown[RG], e1[RG], e2[RG], tjn[RG], ent_prev[RG];
+    size_t base[RG];
+    const double *grow[RG];
+    double xi0[RG], xi1[RG], xi2[RG], p0[RG], p1[RG], p2[RG], h_prev[RG];
+    int cmax = 0;
 #pragma unroll
-          for (int m = 6; m >= 0; m--) tp = tp * rr + tap[m];      // rx_taper (value only)
-          h = tp * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * rr + grow[tj]);
-        }
-      }
-      h_prev = h; ent_prev = ent;
+    for (int g = 0; g < RG; g++) {
+      const bool live = ifirst + g < V.n;
+      row[g] = live ? ifirst + g : ifirst;
+      cnt[g] = live ? V.nb_cnt[row[g]] : 0;
+      cmax = max(cmax, cnt[g]);
+      base[g] = (size_t)row[g] * V.maxnb;
+      grow[g] = s_gamma + V.rtype[row[g]] * RX_MAXT;
+      // (the row's own position: the same for every lane; as scalars -- and waited for here, not inside the loop behind the stores)
+      xi0[g] = wave_uniform(V.x[3 * row[g]]); xi1[g] = wave_uniform(V.x[3 * row[g] + 1]); xi2[g] = wave_uniform(V.x[3 * row[g] + 2]);
+      len[g] = 0; lown[g] = 0; h_prev[g] = -1.0; ent_prev[g] = -1;
     }
-    flush();
-    if (lane == 0) { V.hlen[i] = len; V.hownlen[i] = lown; }
+    auto load_ent = [&](int g, int k0) -> int { const int k = k0 + lane; return (k < cnt[g]) ? V.nbT[base[g] + k] : -1; };
+    auto gather = [&](int g) __attribute__((always_inline)) {
+      const int j = (e1[g] >= 0) ? (e1[g] & RX_JMASK) : 0;
+      p0[g] = V.x[3 * j]; p1[g] = V.x[3 * j + 1]; p2[g] = V.x[3 * j + 2]; tjn[g] = V.rtype[j];
+    };
+    auto flush = [&](int g) __attribute__((always_inline)) {
+      const unsigned long long m = __ballot(h_prev[g] >= 0.0);
+      if (h_prev[g] >= 0.0) {
+        const size_t o = base[g] + len[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        V.hval[o] = h_prev[g];
+        if (V.hcol16) V.hcol16[o] = (unsigned short)(ent_prev[g] & RX_JMASK);
+        else V.hcol32[o] = ent_prev[g] & RX_JMASK;
+      }
+      len[g] += __popcll(m);
+      // the pairs of the row that this end owns, for the non-bonded pass (each pair once)
+      const bool mine = h_prev[g] >= 0.0 && rx_owns(row[g], ent_prev[g]);
+      const unsigned long long mo = __ballot(mine);
+      if (mine) V.hown[base[g] + lown[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0))] = ent_prev[g];
+      lown[g] += __popcll(mo);
+    };
+#pragma unroll
+    for (int g = 0; g < RG; g++) { e1[g] = load_ent(g, 0); e2[g] = load_ent(g, 64); }
+#pragma unroll
+    for (int g = 0; g < RG; g++) gather(g);
+    // (the first records are waited for HERE: a wait left to the first use inside the loop stays in the loop, behind the stores of every turn)
+#pragma unroll
+    for (int g = 0; g < RG; g++) asm volatile("" : : "v"(p0[g]), "v"(p1[g]), "v"(p2[g]), "v"(tjn[g]), "v"(e2[g]));
+    for (int k0 = 0; k0 < cmax; k0 += 64) {
+      int ent[RG], tj[RG];
+      double q0[RG], q1[RG], q2[RG];
+#pragma unroll
+      for (int g = 0; g < RG; g++) { ent[g] = e1[g]; q0[g] = p0[g]; q1[g] = p1[g]; q2[g] = p2[g]; tj[g] = tjn[g]; e1[g] = e2[g]; }
+#pragma unroll
+      for (int g = 0; g < RG; g++) flush(g);
+#pragma unroll
+      for (int g = 0; g < RG; g++) { gather(g); e2[g] = load_ent(g, k0 + 128); }
+#pragma unroll
+      for (int g = 0; g < RG; g++) {
+        double h = -1.0;
+        if (ent[g] >= 0) {
+          const double *sh = s_sh + 3 * ((ent[g] >> 24) & 0x7F);
+          const double d0 = q0[g] - xi0[g] + sh[0], d1 = q1[g] - xi1[g] + sh[1], d2 = q2[g] - xi2[g] + sh[2];
+          const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+          if (!(r2 > swb2)) {
+            const double rr = r2 * rx_rsqrt(r2);
+            double tp = tap[7];
+#pragma unroll
+            for (int m = 6; m >= 0; m--) tp = tp * rr + tap[m];      // rx_taper (value only)
+            h = tp * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * rr + grow[g][tj[g]]);
+          }
+        }
+        h_prev[g] = h; ent_prev[g] = ent[g];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < RG; g++) {
+      flush(g);
+      if (lane == 0 && ifirst + g < V.n) { V.hlen[row[g]] = len[g]; V.hownlen[row[g]] = lown[g]; }
+    }
   }
 }
 
