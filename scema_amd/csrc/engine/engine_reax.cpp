@@ -389,10 +389,13 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     most_cold = std::max(most_cold, qs[6 * i + 5]);
     e->rx_qeq_slow += qs[6 * i + 3];
   }
-  // iterations issued as launches in the next run: what the slowest solve of this one needed, plus a margin
+  // iterations issued as launches in the next run: what the slowest solve of this one needed (of all replicas and steps), plus one.  A launch
+  // that finds every replica converged still costs its two kernels and their gaps (28 us); a replica that needs more than was issued
+  // finishes in one workgroup (80 us per iteration).  Scan on the 72-replica set, slowest solve 15: 13 launches 543, 14: 591, 15: 603,
+  // 16: 598, 18: 590 evaluations/s (tools/reax_launch_scan.sh, profiles/r04_zh_launch_scan.txt)
   if (!e->rx_qeq_launch_pinned) {
-    if (most > 0) e->rx_qeq_launch = std::max(8, most + 3);
-    if (most_cold > 0) e->rx_qeq_launch_cold = std::max(8, most_cold + 3);
+    if (most > 0) e->rx_qeq_launch = std::max(8, most + 1);
+    if (most_cold > 0) e->rx_qeq_launch_cold = std::max(8, most_cold + 1);
   }
   if (fault & 16) return fail(e, SCEMA_MD_ERR_ARG, "a simulation became unstable (non-finite or runaway atom positions): overlapping atoms or a time step too long for ReaxFF");
   if (fault & 32) return fail(e, SCEMA_MD_ERR_ARG, "charge equilibration did not converge to %.1e in %d iterations", e->rx_qeq_tol, e->rx_qeq_maxiter);
