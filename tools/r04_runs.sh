@@ -25,7 +25,11 @@ python bench.py --force-field reax --steps 6 --warmup 2 > gpurun_out/${T}_bench_
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_rprof -- python bench.py --force-field reax --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_rprof_bench.json.log 2>&1
 cp gpurun_out/${T}_rprof/*/*kernel_stats.csv gpurun_out/${T}_kernel_stats_bench_reax_72sims.csv
 python tools/kernel_table.py gpurun_out/${T}_rprof > gpurun_out/${T}_kernel_table_bench_reax_72sims.txt 2>/dev/null || python tools/kernel_median.py gpurun_out/${T}_rprof > gpurun_out/${T}_kernel_table_bench_reax_72sims.txt
+python tools/kernel_gaps.py gpurun_out/${T}_rprof 10 k_rx_hrow > gpurun_out/${T}_kernel_gaps_bench_reax_72sims.txt
 rm -rf gpurun_out/${T}_rprof
 for f in gpurun_out/${T}_bench_72sims_10updates.json.log gpurun_out/${T}_bench_576sims_imbalanced.json.log gpurun_out/${T}_bench_1sim.json.log gpurun_out/${T}_bench_4864sims.json.log gpurun_out/${T}_bench_reax_72sims.json.log; do
   python -c "import sys,json; d=json.loads([l for l in open('$f') if l.startswith('{')][-1]); r=d['roofline']; print('$f', round(d['value'],1), round(d['ms_per_step'],2), d['config']['md_steps_per_eval'], r['bound'], round(r['frac'],3), round(r['avg_launch_ms'],3), (d.get('cpu_baseline') or {}).get('value'))"
 done
+# 6. the ReaxFF set at the size of the headline batch, and the PMC passes behind roofline.traffic of both kernels
+python bench.py --force-field reax --sims 576 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/${T}_bench_reax_576sims.json.log
+python -c "import json; d=json.loads(open(\"gpurun_out/${T}_bench_reax_576sims.json.log\").read()); print(\"reax 576\", round(d[\"value\"],1), round(d[\"roofline\"][\"frac\"],3))"
