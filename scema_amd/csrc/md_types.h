@@ -189,3 +189,4 @@ struct SimDev {
   double MD_G *pgf;      // influence function [nz][ny][nx]
   SimScalars MD_G *sc;
 };
+static_assert(sizeof(double MD_G *) == sizeof(double *), "the qualified pointers of SimDev have the size of plain ones: host and device passes see one layout");

@@ -133,3 +133,6 @@ typedef struct {
   long long RX_G *sweep_acc;   // [2] since the start of the run: matrix entries and rows that launches of k_rx_qeq_sweep passed over for this
                           // replica (stored entries of its rows x sweeps it took part in): the kernel's algorithmic traffic (bench.py)
 } RxView;
+#ifdef __cplusplus
+static_assert(sizeof(double RX_G *) == sizeof(double *), "the qualified pointers of RxView have the size of plain ones: host and device passes see one layout");
+#endif
