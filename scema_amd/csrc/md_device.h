@@ -90,6 +90,20 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// the first four steps of wave_sum: every lane of a row of 16 lanes holds the sum over its row (the same additions in the same order as
+// wave_sum makes inside a row: a value that lives in one row only has the same sum bit for bit either way)
+__device__ __forceinline__ double row_sum(double v) {
+  SCEMA_ASSERT_FULL_WAVE();
+  v += dpp_read0<0xB1, 0xF>(v);
+  v += dpp_read0<0x4E, 0xF>(v);
+  v += dpp_read0<0x141, 0xF>(v);
+  v += dpp_read0<0x140, 0xF>(v);
+  return v;
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
 // block-wide sum of NV values per thread over NW waves, result atomically added to dst[0..NV)
 template <int NV, int NW>
 __device__ __forceinline__ void block_atomic_add_n(double (&vals)[NV], double *dst, double *lds /* >= NV*NW */) {

@@ -330,6 +330,34 @@ __device__ __forceinline__ QeqScal qeq_scalars(const RxView &V, int it, double t
   return Q;
 }
 
+// The same scalars, and up to two more folds, from ONE round of loads: a launch used to open with three folds one after the other (three dependent
+// memory round trips at the head of every workgroup of a 90 us kernel -- and of the 6 us update).  Partial sums of different kinds go to
+// different rows of 16 lanes; the row sums are the additions wave_sum makes inside a row, so every scalar is the same bit for bit as folded
+// alone (run flags agree between kernels whichever form they use).  For at most 16 partial pairs per kind (32 for `wide`, which takes two rows).
+//   rows 0, 1: r.z of iteration it, b.b;  row 2 (+ 3): `extra`, `nextra` pairs (r.z of iteration it - 1, or the d.q partials)
+__device__ __forceinline__ QeqScal qeq_scalars_with(const RxView &V, int it, double tol, const double *extra, int nextra, double &xs, double &xt) {
+  const int nv = RX_QNV(V.npad), nvl = (V.n + QEQ_UT - 1) / QEQ_UT;
+  QeqScal Q;
+  if (nvl > 16 || nextra > 32) {   // (uniform) large replicas: one fold after the other
+    Q = qeq_scalars(V, it, tol);
+    xs = 0.0; xt = 0.0;
+    if (extra) qeq_fold(extra, nextra, xs, xt);
+    return Q;
+  }
+  const int lane = threadIdx.x & 63, row = lane >> 4, k = lane & 15;
+  const double *src = (row == 0) ? V.qpart + 2 * nv * (it & 1) : (row == 1) ? V.qpart + 4 * nv : extra;
+  const int cnt = (row < 2) ? nvl : nextra, kk = (row < 2) ? k : lane - 32;
+  double a = 0.0, b = 0.0;
+  if (src && kk < cnt) { a = src[2 * kk]; b = src[2 * kk + 1]; }
+  a = row_sum(a); b = row_sum(b);
+  Q.sig[0] = lane_value(a, 0); Q.sig[1] = lane_value(b, 0);
+  Q.bn[0] = sqrt(lane_value(a, 16)); Q.bn[1] = sqrt(lane_value(b, 16));
+  xs = lane_value(a, 48) + lane_value(a, 32); xt = lane_value(b, 48) + lane_value(b, 32);   // (row 3 + row 2: the order of wave_sum)
+  Q.run[0] = sqrt(Q.sig[0]) / Q.bn[0] > tol;
+  Q.run[1] = sqrt(Q.sig[1]) / Q.bn[1] > tol;
+  return Q;
+}
+
 // setup != 0: the solve of a run's step 0.  A replica whose history was kept from the run before (RxView::warm) stands where that
 // run's last solve stood: its guess is the newest stored solution, not the extrapolation one step ahead
 __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views, int setup) {
@@ -360,13 +388,10 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   QeqScal Q;
   double beta_s = 0.0, beta_t = 0.0;
   if (it >= 0) {
-    Q = qeq_scalars(V, it, tol);
+    double ps, pt;
+    Q = qeq_scalars_with(V, it, tol, (it > 0) ? V.qpart + 2 * RX_QNV(V.npad) * ((it - 1) & 1) : nullptr, (V.n + QEQ_UT - 1) / QEQ_UT, ps, pt);
     if (!Q.run[0] && !Q.run[1]) return;
-    if (it > 0) {
-      double ps, pt;
-      qeq_fold(V.qpart + 2 * RX_QNV(V.npad) * ((it - 1) & 1), (V.n + QEQ_UT - 1) / QEQ_UT, ps, pt);
-      beta_s = Q.sig[0] / ps; beta_t = Q.sig[1] / pt;
-    }
+    if (it > 0) { beta_s = Q.sig[0] / ps; beta_t = Q.sig[1] / pt; }
   }
   const size_t np = V.npad;
   const GLOBAL_AS dvec2 *z = as_global((const dvec2 *)(V.qwork + 6 * np));
@@ -488,7 +513,8 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, c
       p0 = r1 * z1; p1 = r2 * z2; p2 = chi * chi; p3 = 1.0;
     }
   } else {
-    const QeqScal Q = qeq_scalars(V, it, tol);
+    double dq_s, dq_t;
+    const QeqScal Q = qeq_scalars_with(V, it, tol, V.qpart + 6 * nv, (V.n + RX_SWR - 1) / RX_SWR, dq_s, dq_t);
     if (!Q.run[0] && !Q.run[1]) {
       // converged: the scalar products travel on unchanged, so that every later launch sees the same (converged) state
       if (threadIdx.x == 0) {
@@ -498,8 +524,6 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, c
       }
       return;
     }
-    double dq_s, dq_t;
-    qeq_fold(V.qpart + 6 * nv, (V.n + RX_SWR - 1) / RX_SWR, dq_s, dq_t);
     const double al_s = Q.run[0] ? Q.sig[0] / dq_s : 0.0, al_t = Q.run[1] ? Q.sig[1] / dq_t : 0.0;
     if (i < n) {
       const double eta = P->sbp[V.rtype[i]].eta;
