@@ -454,7 +454,9 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                     "kernel": "k_rx_qeq_sweep (charge equilibration: y = H z for both conjugate-gradient systems, one pass over the stored matrix rows)",
                     "accounting": f"achieved = ({8 + int(prof['rx_sweep_col_bytes'])} B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
                                   "device) / HIP-event time of all launches of the kernel on the engine's stream (launches that find every replica converged "
-                                  "cost time and move nothing); traffic = counter bytes of ONE sweep over the whole batch (profiles/reax_pmc.json)",
+                                  "cost time and move nothing); traffic = counter bytes of ONE sweep over the whole batch (profiles/reax_pmc.json).  "
+                                  "The time is the kernel's AS RUN: the bond-order chain of the step runs next to the charge chain on a second stream, so some "
+                                  "launches share the GPU with it (SCEMA_REAX_OVERLAP=0 runs the sweep alone: a seventh faster per launch, 3.6 % fewer evaluations/s)",
                     "launches": prof["rx_sweep_launches"], "avg_launch_ms": 1e3 * sw_s / sw_n, "alg_bytes_per_launch": sw_bytes / sw_n,
                     "alg_bytes_per_full_sweep": sw_bytes / max(prof["rx_sweep_rows"] / natoms, 1.0) * per_rank,   # one sweep over every replica of this rank
                     "stored_entries_per_row": prof["rx_sweep_entries"] / max(prof["rx_sweep_rows"], 1.0),

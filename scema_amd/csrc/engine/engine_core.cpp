@@ -34,6 +34,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_POLY_TOL", "fit target of the real-space Ewald polynomial (default 2e-13); parity tolerances assume the default"},
     {"SCEMA_REAX_DROP_DSBO2", "ReaxFF valence-angle gradient without the dSBO2 term, as USER-REAXC is believed to compute it"},
     {"SCEMA_REAX_SKIN", "ReaxFF list skin in Angstrom"},
+    {"SCEMA_REAX_OVERLAP", "0: the bond-order chain of the ReaxFF force stage on the same stream as the charge chain instead of next to it"},
     {"SCEMA_REAX_QEQ_ZLDS", "0: the matrix sweep of the charge equilibration gathers through the caches instead of from an LDS copy"},
     {"SCEMA_REAX_QEQ_LAUNCH", "conjugate-gradient iterations issued as launches per charge solve (default: adaptive)"},
     // test hooks: force rarely-taken paths

@@ -249,6 +249,10 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   }
   // how a solve is issued (md_reax.h): as many iterations as the slowest solve of the last run took plus a margin; the first
   // solves of a run that has replicas without a history take longer
+  // the bond-order chain of the force stage on the engine's side stream, next to the charge chain (md_reax.hip); SCEMA_REAX_OVERLAP=0: one stream
+  static const bool overlap_off = scema_env("SCEMA_REAX_OVERLAP") && atoi(scema_env("SCEMA_REAX_OVERLAP")) == 0;
+  const RxSide side = {e->stream2, e->ev_fork, e->ev_up, e->ev_join};
+  const RxSide *sidep = (e->stream2 && e->ev_up && !overlap_off) ? &side : nullptr;
   auto plan_for = [&](int step) {
     RxQeqPlan pl;
     pl.launch = (step < 4 && any_cold) ? e->rx_qeq_launch_cold : e->rx_qeq_launch;
@@ -256,7 +260,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     return pl;
   };
   mdk_reax_phase_init(st, VV, ns, maxpad);
-  mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(0), terms, col16, evp, &ev_used);
+  mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(0), terms, col16, evp, &ev_used, sidep);
   mdk_final_integrate(st, D, ns, maxatoms, 0);
   if (spec.nh) mdk_setup_post_nh(st, D, ns);
   else mdk_setup_post(st, D, ns);
@@ -280,7 +284,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       for (int r = 0; r < 16; r++, ev_n++) {
         mdk_min_pre(st, D, ns);
         mdk_min_move(st, D, ns, maxatoms, x0s, hsd);
-        mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(1), terms, col16);
+        mdk_reax_forces(st, D, VV, RP, ns, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(1), terms, col16, nullptr, nullptr, sidep);
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
         mdk_min_decide(st, D, ns);
       }
@@ -316,7 +320,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     if (spec.nh) { mdk_pre_nh(st, D, na); mdk_initial_integrate_nh(st, D, na, maxatoms); }
     else { mdk_pre(st, D, na); mdk_initial_integrate(st, D, na, maxatoms); }
     // the first solves of a run start from an empty history (RX_QEQ_COLD in md_reax.hip: setup is solve 1)
-    mdk_reax_forces(st, D, VV, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(step), terms, col16, evp, &ev_used);
+    mdk_reax_forces(st, D, VV, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(step), terms, col16, evp, &ev_used, sidep);
     mdk_final_integrate(st, D, na, maxatoms, 1);
     if (spec.nh) mdk_post_nh(st, D, na);
     else mdk_post(st, D, na);

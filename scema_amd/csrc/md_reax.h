@@ -16,8 +16,11 @@ struct RxQeqPlan {
 // the whole force stage of one step for the first ns replicas: (neighbour rows if the rebuild flag of the step is set,)
 // charge equilibration, bond orders, energy terms, forces into SimDev::f, virial and energies into SimScalars.
 // terms: bit 0 bond/lone pair/over/under, 1 angles, 2 torsions, 3 hydrogen bonds, 4 non-bonded (31 = all; parity hook)
+// side: when given, the bond-order chain (bond orders, corrections, bonded terms, back-propagation) runs on a second stream next to the charge chain
+// (matrix rows, conjugate gradients, non-bonded pairs): neither reads what the other writes until the forces are summed (see md_reax.hip)
+struct RxSide { hipStream_t st2; hipEvent_t fork, mid, join; };
 void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, const RxQeqPlan &plan, int terms,
-                     bool col16, std::vector<hipEvent_t> *sweep_events = nullptr, size_t *sweep_events_used = nullptr);
+                     bool col16, std::vector<hipEvent_t> *sweep_events = nullptr, size_t *sweep_events_used = nullptr, const RxSide *side = nullptr);
 // sweep_events: when given, a HIP-event pair is recorded around every launch of k_rx_qeq_sweep (pool grown on demand)
 // the solver statistics of the batch in one array (8 words per replica: RxView::qstat[0..5], RxView::sweep_acc[0..1]) for ONE read-back
 void mdk_reax_collect_stats(hipStream_t st, const RxView *v, int ns, long long *out);

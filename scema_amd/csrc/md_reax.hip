@@ -1071,7 +1071,7 @@ void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad) {
   hipLaunchKernelGGL(k_rx_phase_init, g2(cdv(maxpad, TPB), ns), dim3(TPB), 0, st, v);
 }
 void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams *P, int ns, int maxatoms, double rlist, double qeq_tol, int qeq_maxiter, const RxQeqPlan &plan,
-                     int terms, bool col16, std::vector<hipEvent_t> *ev, size_t *ev_used) {
+                     int terms, bool col16, std::vector<hipEvent_t> *ev, size_t *ev_used, const RxSide *side) {
   // a HIP-event pair around every launch of the matrix sweep when the caller profiles (bench.py's roofline block)
   auto sweep = [&](int it) {
     const dim3 gk = g2(cdv(maxatoms, RX_SWR), ns);
@@ -1091,6 +1091,25 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   hipLaunchKernelGGL(k_rx_prepare, dim3(ns), dim3(64), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_wrap, ga, dim3(TPB), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_neigh, ga, dim3(TPB), 0, st, d, v, rlist);
+  // Two chains from here to the sum of the forces.  CHARGES: matrix rows, conjugate gradients, charges, non-bonded pairs.  BOND ORDERS: bond
+  // orders, corrections, bonded terms, back-propagation.  Neither reads what the other writes, except that k_rx_corr zeroes the force array the
+  // non-bonded pass adds to (one event).  The second is a chain of latency-bound kernels (two waves per SIMD waiting on dependent loads, a tenth
+  // of the issue rate) and the first spends half of its time in launches that find most replicas converged: side by side on two streams.
+  hipStream_t sb = side ? side->st2 : st;
+  if (side) { (void)hipEventRecord(side->fork, st); (void)hipStreamWaitEvent(sb, side->fork, 0); }
+  hipLaunchKernelGGL(k_rx_bonds, g2(cdv(maxatoms, 8 * (TPB / 64)), ns), dim3(TPB), 0, sb, v, P);
+  hipLaunchKernelGGL(k_rx_rev, ga, dim3(TPB), 0, sb, v);
+  hipLaunchKernelGGL(k_rx_corr, ga, dim3(TPB), 0, sb, v, P);
+  if (side) (void)hipEventRecord(side->mid, sb);
+  if (terms & 1) hipLaunchKernelGGL(k_rx_terms<0>, gr, dim3(RX_TPB), 0, sb, d, v, P);
+  // (test hook: a small item list forces the in-place path of the two item kernels)
+  static const int item_cap = scema_env("SCEMA_MD_RX_ITEMCAP") ? std::max(0, std::min(RX_TORS_CAP, atoi(scema_env("SCEMA_MD_RX_ITEMCAP")))) : RX_TORS_CAP;
+  if (terms & 2) hipLaunchKernelGGL(k_rx_angles, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, sb, d, v, P, item_cap);
+  if (terms & 4) hipLaunchKernelGGL(k_rx_torsions, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, sb, d, v, P, item_cap);
+  if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, sb, d, v, P);
+  hipLaunchKernelGGL(k_rx_back1, ga, dim3(TPB), 0, sb, v, P);
+  hipLaunchKernelGGL(k_rx_back2, ga, dim3(TPB), 0, sb, d, v, P);
+  if (side) (void)hipEventRecord(side->join, sb);
   hipLaunchKernelGGL(k_rx_hrow, gk, dim3(RX_KT), 0, st, d, v, P);
   hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v, plan.setup);
   sweep(-1);
@@ -1101,15 +1120,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
     hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, it);
   }
   hipLaunchKernelGGL(k_rx_qeq_finish, dim3(ns), dim3(QEQ_TPB), 0, st, d, v, P, qeq_tol, nlaunch, qeq_maxiter, plan.setup);
-  hipLaunchKernelGGL(k_rx_bonds, g2(cdv(maxatoms, 8 * (TPB / 64)), ns), dim3(TPB), 0, st, v, P);
-  hipLaunchKernelGGL(k_rx_rev, ga, dim3(TPB), 0, st, v);
-  hipLaunchKernelGGL(k_rx_corr, ga, dim3(TPB), 0, st, v, P);
-  if (terms & 1) hipLaunchKernelGGL(k_rx_terms<0>, gr, dim3(RX_TPB), 0, st, d, v, P);
-  // (test hook: a small item list forces the in-place path of the two item kernels)
-  static const int item_cap = scema_env("SCEMA_MD_RX_ITEMCAP") ? std::max(0, std::min(RX_TORS_CAP, atoi(scema_env("SCEMA_MD_RX_ITEMCAP")))) : RX_TORS_CAP;
-  if (terms & 2) hipLaunchKernelGGL(k_rx_angles, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P, item_cap);
-  if (terms & 4) hipLaunchKernelGGL(k_rx_torsions, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, st, d, v, P, item_cap);
-  if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, st, d, v, P);
+  if (side) (void)hipStreamWaitEvent(st, side->mid, 0);
   if (terms & 16) {
     static const bool once_off = scema_env("SCEMA_MD_RX_NB_ONCE") && atoi(scema_env("SCEMA_MD_RX_NB_ONCE")) == 0;   // (test switch: the both-ends kernel)
     const int maxpad = (maxatoms + 63) / 64 * 64;
@@ -1121,7 +1132,6 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
       hipLaunchKernelGGL(k_rx_nonbonded_once, gk, dim3(RX_KT), lds, st, d, v, P);
     } else hipLaunchKernelGGL(k_rx_nonbonded, gk, dim3(RX_KT), 0, st, d, v, P);
   }
-  hipLaunchKernelGGL(k_rx_back1, ga, dim3(TPB), 0, st, v, P);
-  hipLaunchKernelGGL(k_rx_back2, ga, dim3(TPB), 0, st, d, v, P);
+  if (side) (void)hipStreamWaitEvent(st, side->join, 0);
   hipLaunchKernelGGL(k_rx_finish, dim3(ns), dim3(64), 0, st, d, v);
 }
