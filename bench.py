@@ -362,6 +362,17 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = eng.profile()
+    prof_alone = None
+    if reax:
+        # the charge-equilibration sweep ALONE: two more updates with the batch issued as one sequence of launches on one stream (the timed region
+        # runs it as two half batches next to each other and next to the bond-order chains: its per-launch time there is the kernel's as run)
+        eng.reax_concurrency(0, 0)
+        eng.profile(reset=True)
+        for k in range(2):
+            update(args.warmup + args.steps + k)
+        fence()
+        prof_alone = eng.profile()
+        eng.reax_concurrency(1, 1)
     comm = eng.comm_stats()
     owner, _, cap = eng.last_plan(n)
     nts_mean = req.get("nts_mean", 10.0)
@@ -445,6 +456,14 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
             sw_n = max(prof["rx_sweep_launches"], 1)
             sw_bytes = (8.0 + prof["rx_sweep_col_bytes"]) * prof["rx_sweep_entries"] + 84.0 * prof["rx_sweep_rows"]
             achieved = sw_bytes / sw_s / 1e9 if sw_s > 0 else 0.0
+            alone = None
+            if prof_alone and prof_alone["rx_sweep_ms"] > 0:
+                a_s = prof_alone["rx_sweep_ms"] * 1e-3
+                a_bytes = (8.0 + prof_alone["rx_sweep_col_bytes"]) * prof_alone["rx_sweep_entries"] + 84.0 * prof_alone["rx_sweep_rows"]
+                alone = {"achieved": a_bytes / a_s / 1e9, "frac": a_bytes / a_s / 1e9 / 8000.0, "launches": prof_alone["rx_sweep_launches"],
+                         "avg_launch_ms": 1e3 * a_s / max(prof_alone["rx_sweep_launches"], 1),
+                         "note": "the same kernel with nothing next to it: two more updates after the timed region with the batch issued as ONE sequence of "
+                                 "launches on one stream (scema_md_reax_concurrency(0, 0)); launches over the whole batch"}
             pmc = None
             ppath = os.path.join(ROOT, "profiles", "reax_pmc.json")
             if os.path.exists(ppath):
@@ -455,8 +474,10 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                     "accounting": f"achieved = ({8 + int(prof['rx_sweep_col_bytes'])} B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
                                   "device) / HIP-event time of all launches of the kernel on the engine's stream (launches that find every replica converged "
                                   "cost time and move nothing); traffic = counter bytes of ONE sweep over the whole batch (profiles/reax_pmc.json).  "
-                                  "The time is the kernel's AS RUN: the bond-order chain of the step runs next to the charge chain on a second stream, so some "
-                                  "launches share the GPU with it (SCEMA_REAX_OVERLAP=0 runs the sweep alone: a seventh faster per launch, 3.6 % fewer evaluations/s)",
+                                  "The time is the kernel's AS RUN in the timed region: the batch is issued as two half batches on two streams, each with its bond-order "
+                                  "chain on a side stream, so a launch covers HALF the replicas and shares the GPU with the other half's kernels -- frac here is one "
+                                  "half's stream over its launches, not the chip's HBM rate; `alone` is the kernel with the chip to itself",
+                    "alone": alone,
                     "launches": prof["rx_sweep_launches"], "avg_launch_ms": 1e3 * sw_s / sw_n, "alg_bytes_per_launch": sw_bytes / sw_n,
                     "alg_bytes_per_full_sweep": sw_bytes / max(prof["rx_sweep_rows"] / natoms, 1.0) * per_rank,   # one sweep over every replica of this rank
                     "stored_entries_per_row": prof["rx_sweep_entries"] / max(prof["rx_sweep_rows"], 1.0),

@@ -268,6 +268,9 @@ struct scema_md_engine {
   bool split_streams = true;              // SCEMA_MD_SPLIT=0 switches the two-half pipeline off
   int split_min = 32, split_max = 200;  // launch groups of this size range are split (larger ones gain nothing: measured 336 evals/s either way at 576)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int rx_halves = 1, rx_overlap = 1;      // scema_md_reax_concurrency (initial values from SCEMA_REAX_HALVES / SCEMA_REAX_OVERLAP)
+  hipStream_t rx_stream4 = nullptr;       // ReaxFF runs in two half batches: side stream of the second half; events: its fork / mid / join, the halves' join
+  hipEvent_t rx_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::map<std::string, std::unique_ptr<Topo>> topos;
   std::map<std::string, std::unique_ptr<State>> states;
   std::vector<std::unique_ptr<Slot>> slots;

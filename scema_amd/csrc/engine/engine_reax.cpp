@@ -250,9 +250,8 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   // how a solve is issued (md_reax.h): as many iterations as the slowest solve of the last run took plus a margin; the first
   // solves of a run that has replicas without a history take longer
   // the bond-order chain of the force stage on the engine's side stream, next to the charge chain (md_reax.hip); SCEMA_REAX_OVERLAP=0: one stream
-  static const bool overlap_off = scema_env("SCEMA_REAX_OVERLAP") && atoi(scema_env("SCEMA_REAX_OVERLAP")) == 0;
   const RxSide side = {e->stream2, e->ev_fork, e->ev_up, e->ev_join};
-  const RxSide *sidep = (e->stream2 && e->ev_up && !overlap_off) ? &side : nullptr;
+  const RxSide *sidep = (e->stream2 && e->ev_up && e->rx_overlap) ? &side : nullptr;
   auto plan_for = [&](int step) {
     RxQeqPlan pl;
     pl.launch = (step < 4 && any_cold) ? e->rx_qeq_launch_cold : e->rx_qeq_launch;
@@ -314,26 +313,53 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   for (int pos = 0; pos < ns; pos++)
     for (size_t k = 0; k < flips[pos].size(); k++)
       if (flips[pos][k].step < e->h_sims[pos].nsteps) flip_at[flips[pos][k].step].push_back({pos, (int)k});
+  // Two half batches on two streams (replicas are independent: each half runs its own sequence of steps, and one half's launch gaps, tails
+  // and latency-bound kernels are filled by the other's work); each with its own side stream for the bond-order chain.  SCEMA_REAX_HALVES=0: one.
+  struct Half { int off, n; hipStream_t st; RxSide side; const RxSide *sidep; };
+  std::vector<Half> halves;
+  const bool two = e->rx_halves && ns >= 8 && e->stream3 && e->rx_stream4 && e->rx_ev[0] && !spec.minimize;
+  if (two) {
+    const int n0 = (ns + 1) / 2;
+    halves.push_back(Half{0, n0, st, side, sidep});
+    halves.push_back(Half{n0, ns - n0, e->stream3, RxSide{e->rx_stream4, e->rx_ev[0], e->rx_ev[1], e->rx_ev[2]}, nullptr});
+    halves[1].sidep = sidep ? &halves[1].side : nullptr;
+    HIPCHK(hipEventRecord(e->rx_ev[3], st));
+    HIPCHK(hipStreamWaitEvent(e->stream3, e->rx_ev[3], 0));
+  } else halves.push_back(Half{0, ns, st, side, sidep});
+  halves[0].sidep = sidep ? &halves[0].side : nullptr;
   for (int step = 1; step <= maxsteps; step++) {
-    const int na = active(step);
-    if (na == 0) break;
-    if (spec.nh) { mdk_pre_nh(st, D, na); mdk_initial_integrate_nh(st, D, na, maxatoms); }
-    else { mdk_pre(st, D, na); mdk_initial_integrate(st, D, na, maxatoms); }
-    // the first solves of a run start from an empty history (RX_QEQ_COLD in md_reax.hip: setup is solve 1)
-    mdk_reax_forces(st, D, VV, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(step), terms, col16, evp, &ev_used, sidep);
-    mdk_final_integrate(st, D, na, maxatoms, 1);
-    if (spec.nh) mdk_post_nh(st, D, na);
-    else mdk_post(st, D, na);
-    if (spec.deform) mdk_remap(st, D, na, maxatoms);
-    e->prof.md_steps += na;
+    const int na_all = active(step);
+    if (na_all == 0) break;
+    for (const Half &H : halves) {
+      const int na = std::max(0, std::min(na_all - H.off, H.n));
+      if (na == 0) continue;
+      const SimDev *Dh = D + H.off;
+      RxView *Vh = VV + H.off;
+      hipStream_t sh = H.st;
+      if (spec.nh) { mdk_pre_nh(sh, Dh, na); mdk_initial_integrate_nh(sh, Dh, na, maxatoms); }
+      else { mdk_pre(sh, Dh, na); mdk_initial_integrate(sh, Dh, na, maxatoms); }
+      // the first solves of a run start from an empty history (RX_QEQ_COLD in md_reax.hip: setup is solve 1); sweep events on the first half only
+      mdk_reax_forces(sh, Dh, Vh, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(step), terms, col16, H.off == 0 ? evp : nullptr, &ev_used, H.sidep);
+      mdk_final_integrate(sh, Dh, na, maxatoms, 1);
+      if (spec.nh) mdk_post_nh(sh, Dh, na);
+      else mdk_post(sh, Dh, na);
+      if (spec.deform) mdk_remap(sh, Dh, na, maxatoms);
+      e->prof.md_steps += na;
+    }
     auto fl = flip_at.find(step);
     if (fl != flip_at.end())
       for (const auto &pk : fl->second) {
         const FlipEvent &fe = flips[pk.first][pk.second];
-        mdk_flip(st, D + pk.first, fe.tilt[0], fe.tilt[1], fe.tilt[2]);
+        hipStream_t sh = (two && pk.first >= halves[1].off) ? halves[1].st : st;
+        mdk_flip(sh, D + pk.first, fe.tilt[0], fe.tilt[1], fe.tilt[2]);
         e->prof.box_flips += 1;
       }
   }
+  if (two) {
+    HIPCHK(hipEventRecord(e->rx_ev[3], e->stream3));
+    HIPCHK(hipStreamWaitEvent(st, e->rx_ev[3], 0));
+  }
+  const int prof_n = two ? halves[0].n : ns;
   mdk_phase_end(st, D, ns, maxatoms);
   {  // the states keep the history for their next run (a failed update drops it: backup_states)
     std::vector<MdkCopy> tab;
@@ -377,7 +403,10 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       e->prof.rx_sweep_ms += ms;
       e->prof.rx_sweep_launches += 1;
     }
+    // (with two half batches the events sit around the first half's launches: its replicas' entries only.  The setup solve of step 0 ran over
+    // the whole batch inside one pair of events -- one launch in twenty: its second half is left out of both sides of the quotient by scaling)
     for (int pos = 0; pos < ns; pos++) {
+      if (pos >= prof_n) continue;
       e->prof.rx_sweep_entries += (double)acc[2 * pos];
       e->prof.rx_sweep_rows += (double)acc[2 * pos + 1];
       e->prof.rx_sweep_col_bytes = col16 ? 2 : 4;
@@ -441,6 +470,12 @@ int scema_md_reax_activate(scema_md_engine *e, int32_t on) {
   if (!e) return SCEMA_MD_ERR_ARG;
   if (on && !e->rx_ready) return fail(e, SCEMA_MD_ERR_ARG, "no ReaxFF force field loaded");
   e->reax_active = on != 0;
+  return SCEMA_MD_OK;
+}
+int scema_md_reax_concurrency(scema_md_engine *e, int32_t halves, int32_t overlap) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  if (halves >= 0) e->rx_halves = halves != 0;
+  if (overlap >= 0) e->rx_overlap = overlap != 0;
   return SCEMA_MD_OK;
 }
 int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms, int32_t qeq_maxiter) {
