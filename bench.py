@@ -366,13 +366,14 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
     if reax:
         # the charge-equilibration sweep ALONE: two more updates with the batch issued as one sequence of launches on one stream (the timed region
         # runs it as two half batches next to each other and next to the bond-order chains: its per-launch time there is the kernel's as run)
+        parts_default = int(os.environ.get("SCEMA_REAX_HALVES", "2"))
         eng.reax_concurrency(0, 0)
         eng.profile(reset=True)
         for k in range(2):
             update(args.warmup + args.steps + k)
         fence()
         prof_alone = eng.profile()
-        eng.reax_concurrency(1, 1)
+        eng.reax_concurrency(parts_default, 1)
     comm = eng.comm_stats()
     owner, _, cap = eng.last_plan(n)
     nts_mean = req.get("nts_mean", 10.0)

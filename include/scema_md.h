@@ -327,8 +327,8 @@ int scema_md_reax_activate(scema_md_engine *e, int32_t on);
  * vlpex >= 0, as USER-REAXC's Valence_Angles is remembered to do (unverifiable here, not energy conserving: DESIGN.md;
  * default 1 = the exact gradient); terms = bit mask of energy-term groups evaluated (31 = all) */
 int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms, int32_t qeq_maxiter);
-/* How a ReaxFF batch is issued on the device -- results do not depend on it.  halves: 1 = two half batches on two streams (default; batches of
-   8 replicas and more), 0 = one sequence of launches.  overlap: 1 = the bond-order chain of the force stage on a side stream next to the charge
+/* How a ReaxFF batch is issued on the device -- results do not depend on it.  halves: the number of part batches, each on its own stream (default 2; batches of
+   at least four replicas per part), 0 or 1 = one sequence of launches.  overlap: 1 = the bond-order chain of the force stage on a side stream next to the charge
    chain (default), 0 = one after the other.  -1 leaves a setting as it is.  A measurement aid: bench.py times the charge-equilibration sweep
    alone with both off.  (The reference has no counterpart: its LAMMPS ranks run one replica each, stmd_sync.h:583.) */
 int scema_md_reax_concurrency(scema_md_engine *e, int32_t halves, int32_t overlap);

@@ -268,9 +268,12 @@ struct scema_md_engine {
   bool split_streams = true;              // SCEMA_MD_SPLIT=0 switches the two-half pipeline off
   int split_min = 32, split_max = 200;  // launch groups of this size range are split (larger ones gain nothing: measured 336 evals/s either way at 576)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int rx_halves = 1, rx_overlap = 1;      // scema_md_reax_concurrency (initial values from SCEMA_REAX_HALVES / SCEMA_REAX_OVERLAP)
-  hipStream_t rx_stream4 = nullptr;       // ReaxFF runs in two half batches: side stream of the second half; events: its fork / mid / join, the halves' join
-  hipEvent_t rx_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int rx_halves = 2, rx_overlap = 1;      // scema_md_reax_concurrency: part batches (1 = one sequence of launches) and side streams (initial values from SCEMA_REAX_HALVES / SCEMA_REAX_OVERLAP)
+  // ReaxFF runs as rx_halves part batches on as many streams (part 0: stream + stream2), each with a side stream for its bond-order chain and
+  // four events (fork / mid / join of the side stream, the part's join with the main stream); created on first use
+  struct RxPart { hipStream_t main = nullptr, side = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; };
+  std::vector<RxPart> rx_parts;
+  hipEvent_t rx_fork = nullptr;           // main stream -> the parts' streams at the start of the step loop
   std::map<std::string, std::unique_ptr<Topo>> topos;
   std::map<std::string, std::unique_ptr<State>> states;
   std::vector<std::unique_ptr<Slot>> slots;

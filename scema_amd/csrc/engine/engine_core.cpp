@@ -34,7 +34,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_POLY_TOL", "fit target of the real-space Ewald polynomial (default 2e-13); parity tolerances assume the default"},
     {"SCEMA_REAX_DROP_DSBO2", "ReaxFF valence-angle gradient without the dSBO2 term, as USER-REAXC is believed to compute it"},
     {"SCEMA_REAX_SKIN", "ReaxFF list skin in Angstrom"},
-    {"SCEMA_REAX_HALVES", "0: a ReaxFF batch runs as one sequence of launches instead of two half batches on two streams"},
+    {"SCEMA_REAX_HALVES", "number of part batches a ReaxFF batch runs as, each on its own stream (default 2; 0 or 1: one sequence of launches)"},
     {"SCEMA_REAX_OVERLAP", "0: the bond-order chain of the ReaxFF force stage on the same stream as the charge chain instead of next to it"},
     {"SCEMA_REAX_QEQ_ZLDS", "0: the matrix sweep of the charge equilibration gathers through the caches instead of from an LDS copy"},
     {"SCEMA_REAX_QEQ_LAUNCH", "conjugate-gradient iterations issued as launches per charge solve (default: adaptive)"},
@@ -111,13 +111,8 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
         hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)
       e->stream2 = nullptr;   // side stream is an optimisation only
   }
-  if (const char *sx = scema_env("SCEMA_REAX_HALVES")) e->rx_halves = atoi(sx) != 0;
+  if (const char *sx = scema_env("SCEMA_REAX_HALVES")) e->rx_halves = std::max(0, std::min(8, atoi(sx)));
   if (const char *sx = scema_env("SCEMA_REAX_OVERLAP")) e->rx_overlap = atoi(sx) != 0;
-  if (e->stream2 && e->stream3) {
-    bool ok = hipStreamCreateWithFlags(&e->rx_stream4, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 4 && ok; k++) ok = hipEventCreateWithFlags(&e->rx_ev[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { if (e->rx_stream4) (void)hipStreamDestroy(e->rx_stream4); e->rx_stream4 = nullptr; }   // an optimisation only
-  }
   // test hook: start with undersized neighbour capacities, so that the overflow -> restore -> regrow path runs
   if (const char *g0 = scema_env("SCEMA_MD_NEIGH_GROW0")) e->neigh_grow = e->jtab_grow = std::max(0.05, atof(g0));
   *out = e;
@@ -135,8 +130,12 @@ void scema_md_destroy(scema_md_engine *e) {
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-  if (e->rx_stream4) (void)hipStreamDestroy(e->rx_stream4);
-  for (int k = 0; k < 4; k++) if (e->rx_ev[k]) (void)hipEventDestroy(e->rx_ev[k]);
+  if (e->rx_fork) (void)hipEventDestroy(e->rx_fork);
+  for (auto &pt : e->rx_parts) {
+    if (pt.main) (void)hipStreamDestroy(pt.main);
+    if (pt.side) (void)hipStreamDestroy(pt.side);
+    for (int k = 0; k < 4; k++) if (pt.ev[k]) (void)hipEventDestroy(pt.ev[k]);
+  }
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->stream3) (void)hipStreamDestroy(e->stream3);
   if (e->ev_up) (void)hipEventDestroy(e->ev_up);

@@ -315,18 +315,34 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       if (flips[pos][k].step < e->h_sims[pos].nsteps) flip_at[flips[pos][k].step].push_back({pos, (int)k});
   // Two half batches on two streams (replicas are independent: each half runs its own sequence of steps, and one half's launch gaps, tails
   // and latency-bound kernels are filled by the other's work); each with its own side stream for the bond-order chain.  SCEMA_REAX_HALVES=0: one.
-  struct Half { int off, n; hipStream_t st; RxSide side; const RxSide *sidep; };
+  struct Half { int off, n; hipStream_t st; RxSide side; const RxSide *sidep; hipEvent_t done; };
   std::vector<Half> halves;
-  const bool two = e->rx_halves && ns >= 8 && e->stream3 && e->rx_stream4 && e->rx_ev[0] && !spec.minimize;
+  int nparts = (e->rx_halves >= 2 && ns >= 4 * e->rx_halves && !spec.minimize) ? e->rx_halves : 1;
+  // (streams and events of the parts beyond the first: created once, kept)
+  while (nparts > 1 && (int)e->rx_parts.size() < nparts - 1) {
+    scema_md_engine::RxPart pt;
+    bool ok = hipStreamCreateWithFlags(&pt.main, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&pt.side, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 4 && ok; k++) ok = hipEventCreateWithFlags(&pt.ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { nparts = 1; break; }   // an optimisation only
+    e->rx_parts.push_back(pt);
+  }
+  const bool two = nparts > 1;
+  halves.reserve(nparts);
+  for (int k = 0, off = 0; k < nparts; k++) {
+    const int nk = (ns - off) / (nparts - k) + (((ns - off) % (nparts - k)) ? 1 : 0);
+    if (k == 0) halves.push_back(Half{0, nk, st, side, nullptr, nullptr});
+    else {
+      const auto &pt = e->rx_parts[k - 1];
+      halves.push_back(Half{off, nk, pt.main, RxSide{pt.side, pt.ev[0], pt.ev[1], pt.ev[2]}, nullptr, pt.ev[3]});
+    }
+    off += nk;
+  }
+  for (auto &H : halves) H.sidep = sidep ? &H.side : nullptr;
   if (two) {
-    const int n0 = (ns + 1) / 2;
-    halves.push_back(Half{0, n0, st, side, sidep});
-    halves.push_back(Half{n0, ns - n0, e->stream3, RxSide{e->rx_stream4, e->rx_ev[0], e->rx_ev[1], e->rx_ev[2]}, nullptr});
-    halves[1].sidep = sidep ? &halves[1].side : nullptr;
-    HIPCHK(hipEventRecord(e->rx_ev[3], st));
-    HIPCHK(hipStreamWaitEvent(e->stream3, e->rx_ev[3], 0));
-  } else halves.push_back(Half{0, ns, st, side, sidep});
-  halves[0].sidep = sidep ? &halves[0].side : nullptr;
+    if (!e->rx_fork) HIPCHK(hipEventCreateWithFlags(&e->rx_fork, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->rx_fork, st));
+    for (size_t k = 1; k < halves.size(); k++) HIPCHK(hipStreamWaitEvent(halves[k].st, e->rx_fork, 0));
+  }
   for (int step = 1; step <= maxsteps; step++) {
     const int na_all = active(step);
     if (na_all == 0) break;
@@ -350,14 +366,15 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     if (fl != flip_at.end())
       for (const auto &pk : fl->second) {
         const FlipEvent &fe = flips[pk.first][pk.second];
-        hipStream_t sh = (two && pk.first >= halves[1].off) ? halves[1].st : st;
+        hipStream_t sh = st;
+        for (const Half &H : halves) if (pk.first >= H.off && pk.first < H.off + H.n) sh = H.st;
         mdk_flip(sh, D + pk.first, fe.tilt[0], fe.tilt[1], fe.tilt[2]);
         e->prof.box_flips += 1;
       }
   }
-  if (two) {
-    HIPCHK(hipEventRecord(e->rx_ev[3], e->stream3));
-    HIPCHK(hipStreamWaitEvent(st, e->rx_ev[3], 0));
+  for (size_t k = 1; k < halves.size(); k++) {
+    HIPCHK(hipEventRecord(halves[k].done, halves[k].st));
+    HIPCHK(hipStreamWaitEvent(st, halves[k].done, 0));
   }
   const int prof_n = two ? halves[0].n : ns;
   mdk_phase_end(st, D, ns, maxatoms);
@@ -474,7 +491,7 @@ int scema_md_reax_activate(scema_md_engine *e, int32_t on) {
 }
 int scema_md_reax_concurrency(scema_md_engine *e, int32_t halves, int32_t overlap) {
   if (!e) return SCEMA_MD_ERR_ARG;
-  if (halves >= 0) e->rx_halves = halves != 0;
+  if (halves >= 0) e->rx_halves = std::min(halves, 8);
   if (overlap >= 0) e->rx_overlap = overlap != 0;
   return SCEMA_MD_OK;
 }
