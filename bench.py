@@ -417,22 +417,31 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         pair_s = prof["pair_ms"] * 1e-3
         launches = max(prof["pair_launches"], 1)
         avg_launch_s = pair_s / launches
+        # a batch runs as two half batches on two streams: their launches are in flight together part of the time.  union = the time during which
+        # at least one timed launch ran (HIP events of both streams on the device clock); without overlap it equals the sum of the durations
+        union_s = prof.get("pair_union_ms", 0.0) * 1e-3 or pair_s
+        in_flight = pair_s / union_s if union_s > 0 else 1.0
         # algorithmic bytes: N*(4*nbar + 56) + 48 per replica and launch.  full = nbar of a FULL per-atom list
         # inside cutoff + the reference's skin (what the engine counts at build time); stored = every pair once (half of it)
         full = prof["pair_alg_bytes"]
         fixed = prof["pair_sims"] * (56.0 * natoms + 48.0)
         stored = 0.5 * (full - fixed) + fixed
-        achieved = stored / pair_s / 1e9 if pair_s > 0 else 0.0
+        achieved = stored / union_s / 1e9 if union_s > 0 else 0.0
         roof = {"bound": "fp64_valu", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": None, "traffic_source": None,
                 "kernel": "k_pair (lj/cut/coul/long force+virial; every pair once, 4-atom cluster rows, LDS reaction-force tiles)",
                 "accounting": "achieved = SURVEY 8(d) bytes N*(4*n_stored+56)+48 with n_stored = the neighbours the kernel stores per atom "
                               "(each pair once = half of the full list inside cutoff + the reference's 2 A skin, counted at build time) / "
-                              "HIP-event time of the launches on the engine's stream; frac_full_list_equiv prices the full list instead",
-                "frac_full_list_equiv": full / pair_s / 1e9 / 8000.0 if pair_s > 0 else 0.0,
+                              "the time during which the timed launches ran (HIP events).  A batch of 200 replicas and more runs as two half batches on two "
+                              "streams, so launches are in flight together part of the time: the time is the UNION of their intervals (= the sum of the "
+                              "durations when nothing overlaps; launches_in_flight = sum / union), i.e. frac = bytes of all launches / time with at least one "
+                              "of them running.  Per launch (what a rocprofv3 kernel table shows): alg_bytes_per_launch / avg_launch_ms = frac / "
+                              "launches_in_flight.  frac_full_list_equiv prices the full list instead",
+                "frac_full_list_equiv": full / union_s / 1e9 / 8000.0 if union_s > 0 else 0.0,
+                "launches_in_flight": in_flight, "frac_per_launch": stored / pair_s / 1e9 / 8000.0 if pair_s > 0 else 0.0,
                 "launches": prof["pair_launches"], "avg_launch_ms": 1e3 * avg_launch_s,
                 "alg_bytes_per_launch": stored / launches, "sims_per_launch": prof["pair_sims"] / launches,
-                "rank0_pair_share_of_wall": pair_s / elapsed}
+                "rank0_pair_share_of_wall": union_s / elapsed}
         if pmc:
             scale = prof["pair_sims"] / launches   # PMC figures are per replica and launch
             roof["traffic"] = pmc["hbm_bytes_per_sim_step_corrected"] * scale
@@ -441,9 +450,9 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
             cyc = pmc.get("cycles_per_valu_inst", 4.0)
             nsimd, clk = 256 * 4, 2.4e9
             roof["fp64"] = {"valu_insts": insts, "cycles_per_inst": cyc, "simds": nsimd, "clock_hz": clk,
-                            "issue_time_ms": 1e3 * insts * cyc / (nsimd * clk), "frac": insts * cyc / (nsimd * clk) / avg_launch_s if avg_launch_s > 0 else 0.0,
+                            "issue_time_ms": 1e3 * insts * cyc / (nsimd * clk), "frac": insts * cyc / (nsimd * clk) / (avg_launch_s / in_flight) if avg_launch_s > 0 else 0.0,
                             "note": "vector instructions of one launch (SQ_INSTS_VALU, PMC pass under profiles/) priced at the FP64 rate of 4 cycles per "
-                                    "wave instruction on a SIMD-32, over the launch time measured here: the bound that binds (HBM does not)"}
+                                    "wave instruction on a SIMD-32, over the launch time measured here (divided by launches_in_flight): the bound that binds (HBM does not)"}
         workload = (f"{n} x PE-{natoms} OPLS replicas per update(), {nts_mean:.0f}+{args.nss} MD steps each "
                     "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + " + ("PPPM" if args.kspace == "pppm" else "Ewald") + " 1e-4 + SHAKE + NVT), persistent per-QP state, "
                     f"replica equilibrated for {args.equil_steps} steps before the timed region")
@@ -456,7 +465,8 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
             sw_s = prof["rx_sweep_ms"] * 1e-3
             sw_n = max(prof["rx_sweep_launches"], 1)
             sw_bytes = (8.0 + prof["rx_sweep_col_bytes"]) * prof["rx_sweep_entries"] + 84.0 * prof["rx_sweep_rows"]
-            achieved = sw_bytes / sw_s / 1e9 if sw_s > 0 else 0.0
+            sw_union = prof.get("rx_sweep_union_ms", 0.0) * 1e-3 or sw_s
+            achieved = sw_bytes / sw_union / 1e9 if sw_union > 0 else 0.0
             alone = None
             if prof_alone and prof_alone["rx_sweep_ms"] > 0:
                 a_s = prof_alone["rx_sweep_ms"] * 1e-3
@@ -475,10 +485,11 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                     "accounting": f"achieved = ({8 + int(prof['rx_sweep_col_bytes'])} B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
                                   "device) / HIP-event time of all launches of the kernel on the engine's stream (launches that find every replica converged "
                                   "cost time and move nothing); traffic = counter bytes of ONE sweep over the whole batch (profiles/reax_pmc.json).  "
-                                  "The time is the kernel's AS RUN in the timed region: the batch is issued as two half batches on two streams, each with its bond-order "
-                                  "chain on a side stream, so a launch covers HALF the replicas and shares the GPU with the other half's kernels -- frac here is one "
-                                  "half's stream over its launches, not the chip's HBM rate; `alone` is the kernel with the chip to itself",
-                    "alone": alone,
+                                  "The batch is issued as two half batches on two streams, each with its bond-order chain on a side stream: a launch covers HALF the "
+                                  "replicas and launches of the two halves are in flight together part of the time.  The time is the UNION of the launches' intervals "
+                                  "(time with at least one sweep running; launches_in_flight = sum of durations / union) -- and during it the sweep shares the chip "
+                                  "with the other kernels of both halves; `alone` is the kernel with the chip to itself",
+                    "alone": alone, "launches_in_flight": sw_s / sw_union if sw_union > 0 else 1.0, "frac_per_launch": sw_bytes / sw_s / 1e9 / 8000.0 if sw_s > 0 else 0.0,
                     "launches": prof["rx_sweep_launches"], "avg_launch_ms": 1e3 * sw_s / sw_n, "alg_bytes_per_launch": sw_bytes / sw_n,
                     "alg_bytes_per_full_sweep": sw_bytes / max(prof["rx_sweep_rows"] / natoms, 1.0) * per_rank,   # one sweep over every replica of this rank
                     "stored_entries_per_row": prof["rx_sweep_entries"] / max(prof["rx_sweep_rows"], 1.0),

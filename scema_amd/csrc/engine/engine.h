@@ -204,10 +204,13 @@ struct Comm {
   long long migrations = 0, allgathers = 0, handshakes = 0;
 };
 
+// union of the intervals [ev[2l], ev[2l+1]), l < n, on the device clock (ms); events of several streams
+double event_union_ms(const std::vector<hipEvent_t> &ev, size_t n);
 struct Profile {
   long long pair_launches = 0;
   double pair_ms = 0, pair_alg_bytes = 0;
   long long pair_sims = 0;   // simulations summed over the timed pair launches
+  double pair_union_ms = 0.0, rx_sweep_union_ms = 0.0;   // time with at least one timed launch in flight (launches of two half batches overlap)
   long long box_flips = 0;   // triclinic box flips applied (fix deform, flip yes)
   long long md_steps = 0, neigh_builds = 0, evals = 0;
   double unique_pairs_sum = 0;
@@ -266,7 +269,8 @@ struct scema_md_engine {
   hipStream_t stream3 = nullptr;          // second half batch of a large launch group (run_phase)
   hipEvent_t ev_up = nullptr;
   bool split_streams = true;              // SCEMA_MD_SPLIT=0 switches the two-half pipeline off
-  int split_min = 32, split_max = 200;  // launch groups of this size range are split (larger ones gain nothing: measured 336 evals/s either way at 576)
+  int split_min = 32, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
+                                         // at 576 and left large groups whole; with round 4's kernels the halves give 437 against 429, profiles/r04_zs_*)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int rx_halves = 2, rx_overlap = 1;      // scema_md_reax_concurrency: part batches (1 = one sequence of launches) and side streams (initial values from SCEMA_REAX_HALVES / SCEMA_REAX_OVERLAP)
   // ReaxFF runs as rx_halves part batches on as many streams (part 0: stream + stream2), each with a side stream for its bond-order chain and

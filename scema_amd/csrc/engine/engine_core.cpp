@@ -1,4 +1,5 @@
 // engine_core.cpp -- the engine object: creation, destruction, replica registration, counters
+#include <algorithm>
 #include "engine.h"
 #include "../md_env.h"
 
@@ -19,12 +20,33 @@ std::string state_key(int qp, const char *matid, int replica) { return std::to_s
 
 }  // namespace scema_eng
 
+namespace scema_eng {
+double event_union_ms(const std::vector<hipEvent_t> &ev, size_t n) {
+  if (n == 0) return 0.0;
+  std::vector<std::pair<float, float>> iv(n);
+  for (size_t l = 0; l < n; l++) {
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, ev[0], ev[2 * l]) != hipSuccess || hipEventElapsedTime(&b, ev[0], ev[2 * l + 1]) != hipSuccess) return 0.0;
+    iv[l] = {a, b};
+  }
+  std::sort(iv.begin(), iv.end());
+  double total = 0.0;
+  float lo = iv[0].first, hi = iv[0].second;
+  for (size_t l = 1; l < n; l++) {
+    if (iv[l].first > hi) { total += hi - lo; lo = iv[l].first; hi = iv[l].second; }
+    else hi = std::max(hi, iv[l].second);
+  }
+  return total + (hi - lo);
+}
+}  // namespace scema_eng
+
 // ---- the environment switches of the library (md_env.h): name, what it does ----
 namespace {
 struct EnvSwitch { const char *name, *what; };
 const EnvSwitch k_env[] = {
     // performance switches with a measured default; a reported run sets none of them
-    {"SCEMA_MD_SPLIT", "0: never run a launch group of 32-199 simulations as two half batches on two streams"},
+    {"SCEMA_MD_SPLIT_MAX", "launch groups of this many replicas and more run whole instead of as two half batches (default: none)"},
+    {"SCEMA_MD_SPLIT", "0: never run a launch group of 32 simulations and more as two half batches on two streams"},
     {"SCEMA_MD_ONE_STREAM", "no side stream (bonded / k-space chain beside the pair kernel)"},
     {"SCEMA_MD_SKIN_EXTRA", "list skin = params.skin + this many Angstrom (results do not depend on it)"},
     {"SCEMA_MD_SKIN_ADAPT", "1: per-state adaptation of the extra skin from the rebuild interval (round-1 behaviour)"},
@@ -101,6 +123,7 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     return SCEMA_MD_ERR_DEVICE;
   }
   if (const char *sp = scema_env("SCEMA_MD_SPLIT")) e->split_streams = atoi(sp) != 0;
+  if (const char *sp = scema_env("SCEMA_MD_SPLIT_MAX")) e->split_max = std::max(0, atoi(sp));
   if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess)
     e->stream3 = nullptr;   // an optimisation only
   if (const char *sx = scema_env("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(-0.75 * e->p.skin, atof(sx));
@@ -168,6 +191,7 @@ int scema_md_register_replica(scema_md_engine *e, const char *matid, int32_t rep
 }
 
 
+
 int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset) {
   if (!e || !out) return SCEMA_MD_ERR_ARG;
   out->pair_launches = e->prof.pair_launches;
@@ -185,6 +209,8 @@ int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t rese
   out->rx_sweep_entries = e->prof.rx_sweep_entries;
   out->rx_sweep_rows = e->prof.rx_sweep_rows;
   out->rx_sweep_col_bytes = e->prof.rx_sweep_col_bytes;
+  out->pair_union_ms = e->prof.pair_union_ms;
+  out->rx_sweep_union_ms = e->prof.rx_sweep_union_ms;
   if (reset) e->prof = Profile();
   return SCEMA_MD_OK;
 }

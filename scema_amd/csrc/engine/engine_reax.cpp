@@ -354,8 +354,8 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       hipStream_t sh = H.st;
       if (spec.nh) { mdk_pre_nh(sh, Dh, na); mdk_initial_integrate_nh(sh, Dh, na, maxatoms); }
       else { mdk_pre(sh, Dh, na); mdk_initial_integrate(sh, Dh, na, maxatoms); }
-      // the first solves of a run start from an empty history (RX_QEQ_COLD in md_reax.hip: setup is solve 1); sweep events on the first half only
-      mdk_reax_forces(sh, Dh, Vh, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(step), terms, col16, H.off == 0 ? evp : nullptr, &ev_used, H.sidep);
+      // the first solves of a run start from an empty history (RX_QEQ_COLD in md_reax.hip: setup is solve 1)
+      mdk_reax_forces(sh, Dh, Vh, RP, na, maxatoms, rlist, e->rx_qeq_tol, e->rx_qeq_maxiter, plan_for(step), terms, col16, evp, &ev_used, H.sidep);
       mdk_final_integrate(sh, Dh, na, maxatoms, 1);
       if (spec.nh) mdk_post_nh(sh, Dh, na);
       else mdk_post(sh, Dh, na);
@@ -376,7 +376,6 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     HIPCHK(hipEventRecord(halves[k].done, halves[k].st));
     HIPCHK(hipStreamWaitEvent(st, halves[k].done, 0));
   }
-  const int prof_n = two ? halves[0].n : ns;
   mdk_phase_end(st, D, ns, maxatoms);
   {  // the states keep the history for their next run (a failed update drops it: backup_states)
     std::vector<MdkCopy> tab;
@@ -420,10 +419,9 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       e->prof.rx_sweep_ms += ms;
       e->prof.rx_sweep_launches += 1;
     }
-    // (with two half batches the events sit around the first half's launches: its replicas' entries only.  The setup solve of step 0 ran over
-    // the whole batch inside one pair of events -- one launch in twenty: its second half is left out of both sides of the quotient by scaling)
+    e->prof.rx_sweep_union_ms += event_union_ms(e->ev_pool, ev_used / 2);
+    // (the launches of both half batches are timed, each on its stream; rx_sweep_union_ms is the time with at least one of them in flight)
     for (int pos = 0; pos < ns; pos++) {
-      if (pos >= prof_n) continue;
       e->prof.rx_sweep_entries += (double)acc[2 * pos];
       e->prof.rx_sweep_rows += (double)acc[2 * pos + 1];
       e->prof.rx_sweep_col_bytes = col16 ? 2 : 4;

@@ -768,6 +768,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       e->prof.pair_sims += launch_sims[l].second;
       for (int pos = launch_sims[l].first; pos < launch_sims[l].first + launch_sims[l].second; pos++) e->prof.pair_alg_bytes += simbytes[pos];
     }
+    e->prof.pair_union_ms += event_union_ms(e->ev_pool, launch_sims.size());
   }
   if (scema_env("SCEMA_MD_TIMING") && ns > 0) {
     const SimScalars &c = e->h_sc[0];
