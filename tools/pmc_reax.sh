@@ -5,6 +5,7 @@
 # told from full sweeps by their fetch size.  Writes gpurun_out/reax_pmc.json.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+export SCEMA_REAX_HALVES=1 SCEMA_REAX_OVERLAP=0   # whole batch per launch, one stream: the counters are per launch over all replicas
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD"; do
   t=$(echo $P | cut -d" " -f1)
   timeout 400 rocprofv3 --pmc $P --kernel-include-regex "k_rx_qeq_sweep" --output-format csv -d gpurun_out/pmcrx_$t -- python tools/reax_bench.py --updates 1 --warmup 0 --equil-steps 0 > gpurun_out/pmcrx_$t.log 2>&1
