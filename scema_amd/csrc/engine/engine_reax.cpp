@@ -86,6 +86,16 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   std::vector<int> order(ns);
   for (int i = 0; i < ns; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
+  // The batch runs as part batches on as many streams (the step loop below).  Part p takes the ranks p, p + P, ... of the length order and sits at
+  // consecutive positions: each part is itself sorted longest first, and the parts carry the same mix of run lengths.
+  const int nparts_plan = (e->rx_halves >= 2 && ns >= 4 * e->rx_halves && !spec.minimize) ? e->rx_halves : 1;
+  if (nparts_plan > 1) {
+    std::vector<int> o2;
+    o2.reserve(ns);
+    for (int p = 0; p < nparts_plan; p++)
+      for (int r = p; r < ns; r += nparts_plan) o2.push_back(order[r]);
+    order.swap(o2);
+  }
   e->h_sims.assign(ns, SimDev());
   e->h_rxviews.assign(ns, RxView());
   std::vector<std::vector<FlipEvent>> flips(ns);
@@ -304,11 +314,6 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     return SCEMA_MD_OK;
   }
   // ---- steps ----
-  auto active = [&](int step) {
-    int na = 0;
-    while (na < ns && e->h_sims[na].nsteps >= step) na++;
-    return na;
-  };
   std::map<int, std::vector<std::pair<int, int>>> flip_at;
   for (int pos = 0; pos < ns; pos++)
     for (size_t k = 0; k < flips[pos].size(); k++)
@@ -317,13 +322,13 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   // and latency-bound kernels are filled by the other's work); each with its own side stream for the bond-order chain.  SCEMA_REAX_HALVES=0: one.
   struct Half { int off, n; hipStream_t st; RxSide side; const RxSide *sidep; hipEvent_t done; };
   std::vector<Half> halves;
-  int nparts = (e->rx_halves >= 2 && ns >= 4 * e->rx_halves && !spec.minimize) ? e->rx_halves : 1;
+  int nparts = nparts_plan;
   // (streams and events of the parts beyond the first: created once, kept)
   while (nparts > 1 && (int)e->rx_parts.size() < nparts - 1) {
     scema_md_engine::RxPart pt;
     bool ok = hipStreamCreateWithFlags(&pt.main, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&pt.side, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 4 && ok; k++) ok = hipEventCreateWithFlags(&pt.ev[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { nparts = 1; break; }   // an optimisation only
+    if (!ok) return fail(e, SCEMA_MD_ERR_DEVICE, "could not create the streams of the ReaxFF part batches");
     e->rx_parts.push_back(pt);
   }
   const bool two = nparts > 1;
@@ -344,11 +349,12 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     for (size_t k = 1; k < halves.size(); k++) HIPCHK(hipStreamWaitEvent(halves[k].st, e->rx_fork, 0));
   }
   for (int step = 1; step <= maxsteps; step++) {
-    const int na_all = active(step);
-    if (na_all == 0) break;
+    bool any = false;
     for (const Half &H : halves) {
-      const int na = std::max(0, std::min(na_all - H.off, H.n));
+      int na = 0;   // (a part is sorted longest first: its active replicas are a prefix)
+      while (na < H.n && e->h_sims[H.off + na].nsteps >= step) na++;
       if (na == 0) continue;
+      any = true;
       const SimDev *Dh = D + H.off;
       RxView *Vh = VV + H.off;
       hipStream_t sh = H.st;
@@ -362,6 +368,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       if (spec.deform) mdk_remap(sh, Dh, na, maxatoms);
       e->prof.md_steps += na;
     }
+    if (!any) break;
     auto fl = flip_at.find(step);
     if (fl != flip_at.end())
       for (const auto &pk : fl->second) {

@@ -133,3 +133,30 @@ def test_the_replica_set_at_its_batch_size(gold, scripts):
     scale = np.abs(res[0]).max()
     assert np.abs(res[0][70] - res[0][0]).max() < 1e-6 * scale and np.abs(res[0][71] - res[0][5]).max() < 1e-6 * scale
     assert np.abs(res[0] - res[1]).max() < 1e-6 * scale
+
+
+def test_stresses_do_not_depend_on_how_the_batch_is_issued(gold, scripts):
+    """a batch runs as part batches on several streams, each with the bond-order chain of its force stage on a side stream (the parts take
+    every P-th rank of the run-length order); issued as ONE sequence of launches on one stream the same requests give the same stresses
+    (to the order of FP64 atomic sums), whatever the run lengths -- the draw below has evaluations of 10 to 30 straining steps."""
+    from scema_amd.systems import synthetic_strains
+    sym, x, box, v = _mixture(gold)
+    lens = box[3:6] - box[:3]
+    draw = synthetic_strains(13, lens, seed=7)
+    strains = [draw[k] * (0.4 + 0.2 * (k % 5)) for k in range(13)]
+    res = []
+    for parts, overlap in ((2, 1), (1, 0), (3, 1)):
+        e = capi.Engine()
+        e.reax_configure(FFIELD)
+        e.reax_concurrency(parts, overlap)
+        e.register_replica("g0", 1, capi.reax_system(sym, x, box, v=v))
+        sims = [_sim(k, st, gold, scripts, capi.QP_NONE) for k, st in enumerate(strains)]
+        out = e.strain_batch(sims)
+        assert all(o.stress_updated for o in out)
+        res.append(np.array([list(o.stress) for o in out]))
+        e.close()
+    scale = np.abs(res[0]).max()
+    assert np.isfinite(res[0]).all() and scale > 0
+    assert np.abs(res[0] - res[1]).max() < 1e-6 * scale
+    assert np.abs(res[2] - res[1]).max() < 1e-6 * scale
+
