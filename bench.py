@@ -436,7 +436,9 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                               "streams, so launches are in flight together part of the time: the time is the UNION of their intervals (= the sum of the "
                               "durations when nothing overlaps; launches_in_flight = sum / union), i.e. frac = bytes of all launches / time with at least one "
                               "of them running.  Per launch (what a rocprofv3 kernel table shows): alg_bytes_per_launch / avg_launch_ms = frac / "
-                              "launches_in_flight.  frac_full_list_equiv prices the full list instead",
+                              "launches_in_flight (a launch's event interval begins when its stream reaches it, so it includes the time its first workgroups wait for "
+                              "slots the other half's kernels hold: with two half batches the intervals average a tenth longer than the kernel durations of a "
+                              "rocprofv3 trace of the same command; with the batch whole, SCEMA_MD_SPLIT=0, the two agree).  frac_full_list_equiv prices the full list instead",
                 "frac_full_list_equiv": full / union_s / 1e9 / 8000.0 if union_s > 0 else 0.0,
                 "launches_in_flight": in_flight, "frac_per_launch": stored / pair_s / 1e9 / 8000.0 if pair_s > 0 else 0.0,
                 "launches": prof["pair_launches"], "avg_launch_ms": 1e3 * avg_launch_s,
