@@ -136,6 +136,11 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
   }
   if (const char *sx = scema_env("SCEMA_REAX_HALVES")) e->rx_halves = std::max(0, std::min(8, atoi(sx)));
   if (const char *sx = scema_env("SCEMA_REAX_OVERLAP")) e->rx_overlap = atoi(sx) != 0;
+  if (e->stream2 && e->stream3) {   // (fourth and last stream of an engine: see engine.h)
+    bool ok = hipStreamCreateWithFlags(&e->rx_side1, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 4 && ok; k++) ok = hipEventCreateWithFlags(&e->rx_side1_ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok && e->rx_side1) { (void)hipStreamDestroy(e->rx_side1); e->rx_side1 = nullptr; }
+  }
   // test hook: start with undersized neighbour capacities, so that the overflow -> restore -> regrow path runs
   if (const char *g0 = scema_env("SCEMA_MD_NEIGH_GROW0")) e->neigh_grow = e->jtab_grow = std::max(0.05, atof(g0));
   *out = e;
@@ -154,6 +159,8 @@ void scema_md_destroy(scema_md_engine *e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->rx_fork) (void)hipEventDestroy(e->rx_fork);
+  if (e->rx_side1) (void)hipStreamDestroy(e->rx_side1);
+  for (int k = 0; k < 4; k++) if (e->rx_side1_ev[k]) (void)hipEventDestroy(e->rx_side1_ev[k]);
   for (auto &pt : e->rx_parts) {
     if (pt.main) (void)hipStreamDestroy(pt.main);
     if (pt.side) (void)hipStreamDestroy(pt.side);

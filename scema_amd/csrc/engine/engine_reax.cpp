@@ -324,7 +324,9 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   std::vector<Half> halves;
   int nparts = nparts_plan;
   // (streams and events of the parts beyond the first: created once, kept)
-  while (nparts > 1 && (int)e->rx_parts.size() < nparts - 1) {
+  // (the second part runs on stream3 and the engine's fourth stream; further parts -- a measurement aid, two is the optimum -- get streams of their own)
+  const int pool0 = (e->stream3 && e->rx_side1) ? 2 : 1;   // parts served without the pool
+  while (nparts > pool0 && (int)e->rx_parts.size() < nparts - pool0) {
     scema_md_engine::RxPart pt;
     bool ok = hipStreamCreateWithFlags(&pt.main, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&pt.side, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 4 && ok; k++) ok = hipEventCreateWithFlags(&pt.ev[k], hipEventDisableTiming) == hipSuccess;
@@ -336,8 +338,9 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   for (int k = 0, off = 0; k < nparts; k++) {
     const int nk = (ns - off) / (nparts - k) + (((ns - off) % (nparts - k)) ? 1 : 0);
     if (k == 0) halves.push_back(Half{0, nk, st, side, nullptr, nullptr});
+    else if (k == 1 && pool0 == 2) halves.push_back(Half{off, nk, e->stream3, RxSide{e->rx_side1, e->rx_side1_ev[0], e->rx_side1_ev[1], e->rx_side1_ev[2]}, nullptr, e->rx_side1_ev[3]});
     else {
-      const auto &pt = e->rx_parts[k - 1];
+      const auto &pt = e->rx_parts[k - pool0];
       halves.push_back(Half{off, nk, pt.main, RxSide{pt.side, pt.ev[0], pt.ev[1], pt.ev[2]}, nullptr, pt.ev[3]});
     }
     off += nk;
