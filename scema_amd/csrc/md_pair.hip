@@ -320,6 +320,11 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     blo0 = fmin(blo0, s_qbox[q][0]); blo1 = fmin(blo1, s_qbox[q][1]); blo2 = fmin(blo2, s_qbox[q][2]);
     bhi0 = fmax(bhi0, s_qbox[q][3]); bhi1 = fmax(bhi1, s_qbox[q][4]); bhi2 = fmax(bhi2, s_qbox[q][5]);
   }
+#if defined(NEIGH_WHATIF_BOX32)
+  __shared__ float s_qboxf[NQ][6];
+  if (threadIdx.x < NQ * 6) { const int q = threadIdx.x / 6, k = threadIdx.x % 6; s_qboxf[q][k] = (float)(s_qbox[q][k] - (k % 3 == 0 ? blo0 : k % 3 == 1 ? blo1 : blo2)); }
+  __syncthreads();
+#endif
   // ---- phase 1: candidates -> j table (pruned against the cell's box) and group lists (against the groups' boxes), one pass ----
   // Rounds of TW * NB_UPW units: a wave takes NB_UPW units per round (their loads in flight together), ballots give each unit's
   // counts, ONE barrier per round, then every wave takes the prefix over the round's units and writes its accepted entries: table and
@@ -359,16 +364,31 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 #pragma unroll
     for (int i = 0; i < NB_UPW; i++) {
       const double xj = px[i] + s_shift[3 * cv[i]], yj = py[i] + s_shift[3 * cv[i] + 1], zj = pz[i] + s_shift[3 * cv[i] + 2];
+      okq[i] = 0;
+#if defined(NEIGH_WHATIF_BOX32)   // sensitivity experiment (never in a product build): the five box tests of a candidate in FP32
+      {
+        const float xf = (float)(xj - blo0), yf = (float)(yj - blo1), zf = (float)(zj - blo2);
+        const float hx = (float)(bhi0 - blo0), hy = (float)(bhi1 - blo1), hz = (float)(bhi2 - blo2), rl2f = (float)rl2;
+        const float ex = fmaxf(0.f, fmaxf(-xf, xf - hx)), ey = fmaxf(0.f, fmaxf(-yf, yf - hy)), ez = fmaxf(0.f, fmaxf(-zf, zf - hz));
+        ok[i] = valid[i] && (home[i] || ex * ex + ey * ey + ez * ez < rl2f);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const float *bq = s_qboxf[q];
+          const float fx = fmaxf(0.f, fmaxf(bq[0] - xf, xf - bq[3])), fy = fmaxf(0.f, fmaxf(bq[1] - yf, yf - bq[4])), fz = fmaxf(0.f, fmaxf(bq[2] - zf, zf - bq[5]));
+          okq[i] |= (ok[i] && fx * fx + fy * fy + fz * fz < rl2f) ? (1u << q) : 0u;
+        }
+      }
+#else
       {
         const double ex = box_excess(blo0, bhi0, xj), ey = box_excess(blo1, bhi1, yj), ez = box_excess(blo2, bhi2, zj);
         ok[i] = valid[i] && (home[i] || ex * ex + ey * ey + ez * ez < rl2);
       }
-      okq[i] = 0;
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const double ex = box_excess(s_qbox[q][0], s_qbox[q][3], xj), ey = box_excess(s_qbox[q][1], s_qbox[q][4], yj), ez = box_excess(s_qbox[q][2], s_qbox[q][5], zj);
         okq[i] |= (ok[i] && ex * ex + ey * ey + ez * ez < rl2) ? (1u << q) : 0u;
       }
+#endif
       m[i] = __ballot(ok[i]);
       const int ui = wave * NB_UPW + i;
       if (lane == 0) s_ucnt[par][0][ui] = __popcll(m[i]);
@@ -520,15 +540,32 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
       // (pad atoms of the cluster sit beyond 1e15, each pad slot at its own place: never inside the list radius of anything; lanes past the end of the list are cleared below; the
       // nearest of the four distances stands for the nearest ACCEPTED one: beyond the list radius it decides nothing, and otherwise it
       // can only be too small, which moves the entry to a nearer segment -- always allowed)
+#if defined(NEIGH_WHATIF_F32)   // sensitivity experiment (never in a product build): the four distance tests in FP32 on cluster-relative coordinates, no exact fallback
+      const float xjf = (float)(xj - ci.x[0]), yjf = (float)(yj - ci.y[0]), zjf = (float)(zj - ci.z[0]);
+      float r2f[NI];
+#pragma unroll
+      for (int a = 0; a < NI; a++) {
+        const float dx = (float)(ci.x[a] - ci.x[0]) - xjf, dy = (float)(ci.y[a] - ci.y[0]) - yjf, dz = (float)(ci.z[a] - ci.z[0]) - zjf;   // (the i side is loop-invariant)
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        mask |= (r2 < (float)S.rlist2) ? (1 << a) : 0;
+        r2f[a] = r2; r2a[a] = 0.0;
+      }
+      const double rmin = (double)fminf(fminf(r2f[0], r2f[1]), fminf(r2f[2], r2f[3]));
+#else
 #pragma unroll
       for (int a = 0; a < NI; a++) {
         const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
-        const double r2 = dx * dx + dy * dy + dz * dz;
+        double r2 = dx * dx + dy * dy + dz * dz;
+#if defined(NEIGH_WHATIF_DIST2)   // ... or the FP64 distance arithmetic of the row loop issued twice (+28 FP64 instructions per chunk)
+        { double ex = xj, ey = yj, ez = zj; asm volatile("" : "+v"(ex), "+v"(ey), "+v"(ez));
+          const double ux = ci.x[a] - ex, uy = ci.y[a] - ey, uz = ci.z[a] - ez; r2 = vmin_f64(r2, ux * ux + uy * uy + uz * uz); }
+#endif
         mask |= (r2 < S.rlist2) ? (1 << a) : 0;
         if (CREF) refm |= (r2 < S.rlist_ref2) ? (1 << a) : 0;
         r2a[a] = r2;
       }
       const double rmin = vmin_f64(vmin_f64(r2a[0], r2a[1]), vmin_f64(r2a[2], r2a[3]));
+#endif
       if (!in) { mask = 0; refm = 0; }
       if (own_chunks) {   // (wave-uniform: the entries of the own cell come first in the table and in every list)
         // same cell, same image: each pair once, by slot order -- atom a of the cluster keeps j only if j > s0slot + a.  One mask per
