@@ -214,11 +214,11 @@ def count_gpus_without_hip():
 
 def spawn_ranks(args):
     """--gpus N from a plain shell: start N ranks (torch.distributed.run) BEFORE any GPU call in this process."""
-    have = count_gpus_without_hip()
+    have = args.gpus if args.dry_run_ranks else count_gpus_without_hip()
     if have == 0:   # no KFD topology in this container's sysfs: ask torch (amdsmi where present; otherwise this does open the device)
         import torch
         have = torch.cuda.device_count()
-    if have < args.gpus and not args.share_gpus:
+    if have < args.gpus and not args.share_gpus and not args.dry_run_ranks:
         print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -255,6 +255,103 @@ def env_overrides():
     eng_side = capi.env_overrides()
     mine = [f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("SCEMA_BENCH_") or k in ("SCEMA_CPU_BASELINE_CORES", "SCEMA_LAMMPS", "SCEMA_SCRIPTS", "SCEMA_MD_LIB", "SCEMA_SANITIZE")]
     return eng_side + mine
+
+
+class Requests:
+    """The request vector of an update (one MDSim per quadrature point, what prepare_md_simulations fills in C++ in the reference,
+    stmd_sync.h:491-568), built once; every update only rewrites the strains and most_recent ids in place.  Host code only: the
+    dry run of the control plane (--dry-run-ranks) builds exactly the requests the engine would get."""
+
+    def __init__(self, args, n, lens, rate, DT):
+        self.args, self.n, self.lens, self.rate, self.DT = args, n, lens, rate, DT
+        self.mono = {"on": args.monotonic}
+        self.arr = None
+        self.nts_mean = 10.0
+
+    def build(self, istep):
+        import ctypes
+        from scema_amd import capi
+        from scema_amd.systems import synthetic_strains
+        args, n, lens, rate, DT = self.args, self.n, self.lens, self.rate, self.DT
+        strains = synthetic_strains(n, lens, seed=2026 + istep, scale=(5.0 if args.strain_set == "file3d" else 1.0),
+                                    mode=("imbalanced" if args.strain_set == "imbalanced" else "balanced"))
+        # The SURVEY 8(d) strains are all tensile: applied update after update to persistent states they would pull the
+        # replica 3.5 % out of its equilibrium within the 25 updates of a driver run (5 GPa of tension, lists rebuilt 40 %
+        # more often: a different workload at the end than at the start).  Odd updates therefore take the draw with the
+        # opposite sign (a load/unload cycle): same magnitudes, same nts, and every update sees a replica within one
+        # strain increment of the equilibrated state.
+        if istep % 2 == 1 and not self.mono["on"]:
+            strains = -strains
+        if self.arr is None:
+            sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=capi.QP_NONE, strain_rate=rate, dt=DT,
+                                  force_field=args.force_field) for q in range(n)]
+            arr = (capi.MDSim * n)(*sims)
+            raw = np.frombuffer(arr, dtype=np.uint8).reshape(n, ctypes.sizeof(capi.MDSim))
+            o_s, o_m = capi.MDSim.strain.offset, capi.MDSim.most_recent_qp_id.offset
+            self.arr, self.keep = arr, sims
+            self.strain, self.recent = raw[:, o_s:o_s + 48].view(np.float64), raw[:, o_m:o_m + 4].view(np.int32)
+        self.strain[:, :] = strains
+        # straining steps per replica (reference stmd_problem.h:222-232): nts = max(ceil(|eps|_F / rate / dt / 10) * 10, 10)
+        true = np.asarray(strains, float) / np.array([lens[0], lens[1], lens[2], lens[2], lens[1], lens[0]])
+        fro = np.sqrt((true[:, :3] ** 2).sum(1) + 2.0 * (true[:, 3:] ** 2).sum(1))
+        self.nts = np.maximum(np.ceil(fro / rate / DT / 10.0) * 10.0, 10.0)
+        self.nts_mean = float(self.nts.mean())
+        self.recent[:, 0] = capi.QP_NONE if istep == 0 else np.arange(n, dtype=np.int32)
+        return self.arr
+
+
+def dry_run_ranks(args, rank, world, dist):
+    """--dry-run-ranks N: the control plane that `--gpus N` takes, with no engine and no GPU -- ranks spawned the same way, gloo
+    rendezvous, the 128-byte communicator id from rank 0 to all, the planner (scema_plan_update, the very code the engine plans with)
+    over the same request vectors update after update, max-over-ranks of a clock, per-rank records gathered, one JSON line from rank 0.
+    What it cannot show: RCCL itself and the MD.  `value` is null: nothing was measured."""
+    import hashlib
+    import torch
+    from scema_amd import capi
+    d, lens, DT, rate = _workload(args)
+    n = args.sims
+    uid = [os.urandom(capi.COMM_ID_BYTES) if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    assert len(uid[0]) == capi.COMM_ID_BYTES
+    digests = [None] * world
+    dist.all_gather_object(digests, hashlib.sha256(uid[0]).hexdigest())
+    assert len(set(digests)) == 1, "the communicator id differs between ranks"
+    req = Requests(args, n, lens, rate, DT)
+    plan = capi.PlanDir()
+    mine_total, moves_total, owners_digest = 0, 0, []
+    t0 = time.perf_counter()
+    for istep in range(args.warmup + args.steps):
+        arr = req.build(istep)
+        owner, pos, cap, moves = plan.update(arr, world, cost=req.nts + args.nss, commit=True)
+        assert cap == int(np.bincount(owner, minlength=world).max())
+        # within a rank the result positions are dense and unique: the all-gather's compaction map is well defined
+        for r in range(world):
+            pr = np.sort(pos[owner == r])
+            assert (pr == np.arange(len(pr))).all(), (istep, r)
+        if istep == 0 and args.strain_set != "imbalanced":
+            assert (owner == np.arange(n) % world).all(), "a fresh balanced batch is dealt i % N (stmd_sync.h:583)"
+        moves_total += len(moves)
+        mine_total = int((owner == rank).sum())   # (as run_leg reports it: the last update's share)
+        owners_digest.append(hashlib.sha256(owner.tobytes() + pos.tobytes()).hexdigest())
+    elapsed = time.perf_counter() - t0
+    plans = [None] * world
+    dist.all_gather_object(plans, owners_digest)
+    assert all(p == plans[0] for p in plans), "ranks computed different plans"
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    mine = {"rank": rank, "sims": mine_total, "elapsed_s": elapsed, "pair_ms": 0.0, "md_steps": 0}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    out = None
+    if rank == 0:
+        out = {"metric": "stress_evals_per_sec", "value": None, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "dry_run": True,
+               "config": {"workload": f"DRY RUN of the control plane of --gpus {world}: {n} requests per update(), planner only, no engine, no GPU",
+                          "n_sims": n, "sims_on_rank0": int(allr[0]["sims"]), "state_migrations": moves_total,
+                          "per_rank": allr, "plan_digest": owners_digest[-1][:16], "max_rank_elapsed_s": float(t.item())}}
+    dist.barrier()
+    return out
 
 
 def run_leg(args, rank, world, device, cpu, torch, dist):
@@ -302,36 +399,9 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         lens = d["box"][3:6] - d["box"][:3]
     checksum = 0.0
 
-    # The request vector (one MDSim per quadrature point, what prepare_md_simulations fills in C++ in the reference,
-    # stmd_sync.h:491-568) is built once; every update only rewrites the strains and most_recent ids in place.
-    import ctypes
-    req = {"arr": None}
-    mono = {"on": args.monotonic}
-
-    def requests(istep):
-        strains = synthetic_strains(n, lens, seed=2026 + istep, scale=(5.0 if args.strain_set == "file3d" else 1.0),
-                                    mode=("imbalanced" if args.strain_set == "imbalanced" else "balanced"))
-        # The SURVEY 8(d) strains are all tensile: applied update after update to persistent states they would pull the
-        # replica 3.5 % out of its equilibrium within the 25 updates of a driver run (5 GPa of tension, lists rebuilt 40 %
-        # more often: a different workload at the end than at the start).  Odd updates therefore take the draw with the
-        # opposite sign (a load/unload cycle): same magnitudes, same nts, and every update sees a replica within one
-        # strain increment of the equilibrated state.
-        if istep % 2 == 1 and not mono["on"]:
-            strains = -strains
-        if req["arr"] is None:
-            sims = [capi.make_sim(q, "g0", 1, strains[q], nss=args.nss, most_recent=capi.QP_NONE, strain_rate=rate, dt=DT,
-                                  force_field=args.force_field) for q in range(n)]
-            arr = (capi.MDSim * n)(*sims)
-            raw = np.frombuffer(arr, dtype=np.uint8).reshape(n, ctypes.sizeof(capi.MDSim))
-            o_s, o_m = capi.MDSim.strain.offset, capi.MDSim.most_recent_qp_id.offset
-            req.update(arr=arr, keep=sims, strain=raw[:, o_s:o_s + 48].view(np.float64), recent=raw[:, o_m:o_m + 4].view(np.int32))
-        req["strain"][:, :] = strains
-        # straining steps per replica (reference stmd_problem.h:222-232): nts = max(ceil(|eps|_F / rate / dt / 10) * 10, 10)
-        true = np.asarray(strains, float) / np.array([lens[0], lens[1], lens[2], lens[2], lens[1], lens[0]])
-        fro = np.sqrt((true[:, :3] ** 2).sum(1) + 2.0 * (true[:, 3:] ** 2).sum(1))
-        req["nts_mean"] = float(np.maximum(np.ceil(fro / rate / DT / 10.0) * 10.0, 10.0).mean())
-        req["recent"][:, 0] = capi.QP_NONE if istep == 0 else np.arange(n, dtype=np.int32)
-        return req["arr"]
+    req = Requests(args, n, lens, rate, DT)
+    mono = req.mono
+    requests = req.build
 
     def update(istep):
         nonlocal checksum
@@ -376,7 +446,7 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         eng.reax_concurrency(parts_default, 1)
     comm = eng.comm_stats()
     owner, _, cap = eng.last_plan(n)
-    nts_mean = req.get("nts_mean", 10.0)
+    nts_mean = req.nts_mean
     rstat = eng.reax_stats() if reax else None
 
     # The SURVEY 8(d) strain set AS WRITTEN (every draw tensile, update after update) next to the load/unload cycle of the
@@ -551,6 +621,8 @@ def main():
                     "timed as well and reported as config.strain_set_monotonic_evals_per_s (0: skip; never part of `value`)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
+    ap.add_argument("--dry-run-ranks", type=int, default=0, help="N: run the control plane of --gpus N (rank spawn, rendezvous, id exchange, planner, "
+                    "per-rank JSON assembly) with no engine and no GPU; prints a line with \"dry_run\": true and no value")
     ap.add_argument("--share-gpus", action="store_true", help="tests: let several ranks share a GPU (needs --dist-backend gloo)")
     ap.add_argument("--reax-leg", default="auto", choices=["auto", "on", "off"],
                     help="after the OPLS loop, outside `value`: a short ReaxFF replica-set leg (BASELINE config 5: 72 x PE-1620, 2 warm-up + 4 timed updates) "
@@ -565,6 +637,8 @@ def main():
         if "--nss" not in given: args.nss = 20
         if "--equil-steps" not in given: args.equil_steps = 200
 
+    if args.dry_run_ranks:
+        args.gpus = args.dry_run_ranks
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
 
@@ -573,6 +647,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    if args.dry_run_ranks:
+        import torch.distributed as dist
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        else:
+            raise SystemExit("bench.py: --dry-run-ranks needs N > 1")
+        out = dry_run_ranks(args, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dist.destroy_process_group()
+        return
 
     d, lens, DT, rate = _workload(args)
     from scema_amd.systems import synthetic_strains

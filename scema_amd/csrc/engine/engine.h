@@ -378,6 +378,7 @@ int resolve_state(scema_md_engine *e, const scema_mdsim &m, State **out, std::un
 // engine_batch.cpp
 int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt &opt = EvalOpt(), size_t pool_off = 0);
 // engine_comm.cpp
+int prepare_incoming(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, std::map<int, std::unique_ptr<State>> &incoming);
 int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, const std::vector<std::string> &src_keys,
                    std::map<int, std::unique_ptr<State>> &incoming);
 double plan_hash(const scema::SimPlan &P, const std::vector<double> &cost);

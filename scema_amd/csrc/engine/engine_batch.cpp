@@ -282,13 +282,17 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
   for (const scema::PlanMove &m : plan.moves)
     if (m.from == rank && !pre_status && !e->states.count(src_keys[m.sim]))
       pre_status = fail(e, SCEMA_MD_ERR_NOSTATE, "rank %d is recorded as the owner of state %s but does not hold it", rank, src_keys[m.sim].c_str());
+  // the states that migrate to this rank are allocated BEFORE the handshake: a rank that cannot take them says so in its status word
+  // instead of leaving the sending rank inside the exchange
+  std::map<int, std::unique_ptr<State>> incoming;
+  if (collective && !hooke_mode && !pre_status) pre_status = prepare_incoming(e, sims, plan, incoming);
   if (collective) {
     const int rc = handshake(e, pre_status, hash);
     if (rc) return rc;
   } else if (pre_status)
     return publish(pre_status);
   // ---- states that have to change GPU first ----
-  std::map<int, std::unique_ptr<State>> incoming;
+  int status = SCEMA_MD_OK;   // of this rank's share; with a communicator it travels in the trailer of the all-gather
   if (!hooke_mode && !plan.moves.empty()) {
     if (!e->comm.kind) {
       const scema::PlanMove &m = plan.moves[0];
@@ -296,8 +300,9 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
                           "attach a communicator (scema_md_comm_init_rccl / scema_md_comm_init_host) so that states can move between GPUs",
                           src_keys[m.sim].c_str(), sims[m.sim].qp_id, m.from, m.to));
     }
-    int rc = migrate_states(e, sims, plan, src_keys, incoming);
-    if (rc) return rc;   // a transport failure: nothing a status word could repair
+    if (!collective) status = prepare_incoming(e, sims, plan, incoming);   // (a communicator with world 1 plans no moves; kept for symmetry)
+    // an error of the exchange becomes this rank's status: it still enters the stress all-gather, where every rank learns of it
+    if (!status) status = migrate_states(e, sims, plan, src_keys, incoming);
   }
   // ---- this rank's share ----
   std::vector<ActiveSim> act;
@@ -309,7 +314,6 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     }
     created.clear();
   };
-  int status = SCEMA_MD_OK;   // of this rank's share; with a communicator it travels in the trailer of the all-gather
   for (int i = 0; i < n_sims && !status; i++) {
     if (plan.owner[i] != rank) continue;
     if (hooke_mode) {

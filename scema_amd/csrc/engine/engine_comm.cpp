@@ -1,5 +1,6 @@
 // engine_comm.cpp -- one process per GPU: communicator, agreement handshake, state migration, the stress all-gather (replaces stmd_sync.h:620-726), the planner's C face
 #include "engine.h"
+#include "../md_env.h"
 
 namespace scema_eng {
 
@@ -9,7 +10,31 @@ namespace scema_eng {
 // another quadrature point branches from it (most_recent_qp_id != qp_id); a state that merely moved is dropped there after
 // the update.  RCCL: one group of point-to-point sends/receives over xGMI on the engine's stream; host transport: the
 // moves in plan order, blocking send/recv pairs (every rank walks the same list, so the pairs cannot cross).
+//
+// Everything that can fail on ONE rank alone happens before the handshake (prepare_incoming: the receiving rank's allocations;
+// scema_md_strain_batch: the source states a rank must hold), where its status word ends the call on every rank.  What is left
+// here runs after the ranks agreed to exchange, so a rank that meets an error keeps to the protocol: the RCCL group it opened is
+// ended whatever happened inside it, the host transport still posts every send and receive of its moves, and the error is
+// RETURNED for the status word of the stress all-gather -- the other ranks are never left inside a collective this rank skipped.
 constexpr int MIG_SIDE = 10;   // doubles that travel next to x and v of a migrating state: box[9], State::skin_extra
+
+// the states this rank receives, allocated (before the handshake: a failure here must travel in its status word)
+int prepare_incoming(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, std::map<int, std::unique_ptr<State>> &incoming) {
+  const int rank = e->comm.rank;
+  for (const scema::PlanMove &m : plan.moves) {
+    if (m.to != rank) continue;
+    Topo *t = find_topo(e, sims[m.sim].matid, sims[m.sim].replica);
+    if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered on rank %d", sims[m.sim].matid, sims[m.sim].replica, rank);
+    if (const char *fr = scema_env("SCEMA_MD_TEST_FAIL_INCOMING"))   // test hook: the allocation fails on that rank
+      if (atoi(fr) == rank || atoi(fr) < 0) return fail(e, SCEMA_MD_ERR_DEVICE, "out of device memory for a replica state that migrates to rank %d (injected: SCEMA_MD_TEST_FAIL_INCOMING)", rank);
+    if (int rc = make_empty_state(e, t, incoming[m.sim])) {
+      (void)hipGetLastError();   // (the allocation's error is reported, not left for the next launch to find)
+      return fail(e, rc, "out of device memory for a replica state that migrates to rank %d", rank);
+    }
+  }
+  return SCEMA_MD_OK;
+}
+
 int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, const std::vector<std::string> &src_keys,
                    std::map<int, std::unique_ptr<State>> &incoming) {
   Comm &c = e->comm;
@@ -18,43 +43,47 @@ int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::Sim
   std::vector<State *> src(nm, nullptr);
   for (int k = 0; k < nm; k++) {
     const scema::PlanMove &m = plan.moves[k];
-    Topo *t = find_topo(e, sims[m.sim].matid, sims[m.sim].replica);
-    if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered on rank %d", sims[m.sim].matid, sims[m.sim].replica, c.rank);
     if (c.rank == m.from) {
-      auto it = e->states.find(src_keys[m.sim]);
+      auto it = e->states.find(src_keys[m.sim]);   // (held: scema_md_strain_batch looked before the handshake)
       if (it == e->states.end())
         return fail(e, SCEMA_MD_ERR_NOSTATE, "rank %d is recorded as the owner of state %s but does not hold it", c.rank, src_keys[m.sim].c_str());
       src[k] = it->second.get();
       std::memcpy(&hbox[MIG_SIDE * (size_t)k], src[k]->box, 9 * sizeof(double));
       hbox[MIG_SIDE * (size_t)k + 9] = src[k]->skin_extra;
     }
-    if (c.rank == m.to) {
-      int rc = make_empty_state(e, t, incoming[m.sim]);
-      if (rc) return rc;
-    }
+    if (c.rank == m.to && !incoming.count(m.sim))
+      return fail(e, SCEMA_MD_ERR_ARG, "internal: no state was prepared for the one simulation %d receives from rank %d", m.sim, m.from);
   }
+  int err = SCEMA_MD_OK;
   if (c.kind == 1) {
     HIPCHK(c.d_box.ensure(hbox.size() * sizeof(double)));
     HIPCHK(hipMemcpyAsync(c.d_box.p, hbox.data(), hbox.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
     NCCLCHK(ncclGroupStart());
-    for (int k = 0; k < nm; k++) {
+    // inside the group nothing returns: a failing call ends the queueing, the group is ended all the same
+    auto q = [&](ncclResult_t r, const char *what, int peer) {
+      if (r != ncclSuccess && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "%s with rank %d failed while replica states migrate: %s", what, peer, ncclGetErrorString(r));
+      return r == ncclSuccess;
+    };
+    for (int k = 0; k < nm && !err; k++) {
       const scema::PlanMove &m = plan.moves[k];
       double *dbox = c.d_box.as<double>() + MIG_SIDE * (size_t)k;
       if (c.rank == m.from) {
         const size_t cnt = 3 * (size_t)src[k]->topo->natoms;
-        NCCLCHK(ncclSend(src[k]->x.p, cnt, ncclDouble, m.to, c.nccl, e->stream));
-        NCCLCHK(ncclSend(src[k]->v.p, cnt, ncclDouble, m.to, c.nccl, e->stream));
-        NCCLCHK(ncclSend(dbox, MIG_SIDE, ncclDouble, m.to, c.nccl, e->stream));
+        (void)(q(ncclSend(src[k]->x.p, cnt, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to) &&
+               q(ncclSend(src[k]->v.p, cnt, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to) &&
+               q(ncclSend(dbox, MIG_SIDE, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to));
       }
-      if (c.rank == m.to) {
+      if (c.rank == m.to && !err) {
         State *d = incoming[m.sim].get();
         const size_t cnt = 3 * (size_t)d->topo->natoms;
-        NCCLCHK(ncclRecv(d->x.p, cnt, ncclDouble, m.from, c.nccl, e->stream));
-        NCCLCHK(ncclRecv(d->v.p, cnt, ncclDouble, m.from, c.nccl, e->stream));
-        NCCLCHK(ncclRecv(dbox, MIG_SIDE, ncclDouble, m.from, c.nccl, e->stream));
+        (void)(q(ncclRecv(d->x.p, cnt, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from) &&
+               q(ncclRecv(d->v.p, cnt, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from) &&
+               q(ncclRecv(dbox, MIG_SIDE, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from));
       }
     }
-    NCCLCHK(ncclGroupEnd());
+    const ncclResult_t ge = ncclGroupEnd();
+    if (ge != ncclSuccess && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "ncclGroupEnd failed while replica states migrate: %s", ncclGetErrorString(ge));
+    if (err) return err;
     HIPCHK(hipMemcpyAsync(hbox.data(), c.d_box.p, hbox.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int k = 0; k < nm; k++)
@@ -64,29 +93,34 @@ int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::Sim
       }
   } else {
     if (!c.send || !c.recv) return fail(e, SCEMA_MD_ERR_ARG, "the host communicator has no send/recv callbacks: replica states cannot move between ranks");
+    // a device copy that fails does not stop the walk: the peer of every move is waiting in its own send or receive
+    auto dev = [&](hipError_t r, const char *what) {
+      if (r != hipSuccess && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "%s failed while replica states migrate: %s", what, hipGetErrorString(r));
+    };
     std::vector<double> buf;
     for (int k = 0; k < nm; k++) {
       const scema::PlanMove &m = plan.moves[k];
       if (c.rank != m.from && c.rank != m.to) continue;
       State *st = (c.rank == m.from) ? src[k] : incoming[m.sim].get();
       const size_t n3 = 3 * (size_t)st->topo->natoms;
-      buf.resize(2 * n3 + MIG_SIDE);
+      buf.assign(2 * n3 + MIG_SIDE, 0.0);
       if (c.rank == m.from) {
-        HIPCHK(hipMemcpyAsync(buf.data(), st->x.p, n3 * 8, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipMemcpyAsync(buf.data() + n3, st->v.p, n3 * 8, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        dev(hipMemcpyAsync(buf.data(), st->x.p, n3 * 8, hipMemcpyDeviceToHost, e->stream), "copy of a state to the host");
+        dev(hipMemcpyAsync(buf.data() + n3, st->v.p, n3 * 8, hipMemcpyDeviceToHost, e->stream), "copy of a state to the host");
+        dev(hipStreamSynchronize(e->stream), "copy of a state to the host");
         std::memcpy(buf.data() + 2 * n3, st->box, 9 * sizeof(double));
         buf[2 * n3 + 9] = st->skin_extra;
-        if (c.send(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.to)) return fail(e, SCEMA_MD_ERR_DEVICE, "host send of a replica state to rank %d failed", m.to);
+        if (c.send(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.to) && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "host send of a replica state to rank %d failed", m.to);
       } else {
-        if (c.recv(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.from)) return fail(e, SCEMA_MD_ERR_DEVICE, "host receive of a replica state from rank %d failed", m.from);
-        HIPCHK(hipMemcpyAsync(st->x.p, buf.data(), n3 * 8, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(st->v.p, buf.data() + n3, n3 * 8, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        if (c.recv(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.from) && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "host receive of a replica state from rank %d failed", m.from);
+        dev(hipMemcpyAsync(st->x.p, buf.data(), n3 * 8, hipMemcpyHostToDevice, e->stream), "copy of a state to the device");
+        dev(hipMemcpyAsync(st->v.p, buf.data() + n3, n3 * 8, hipMemcpyHostToDevice, e->stream), "copy of a state to the device");
+        dev(hipStreamSynchronize(e->stream), "copy of a state to the device");
         std::memcpy(st->box, buf.data() + 2 * n3, 9 * sizeof(double));
         st->skin_extra = buf[2 * n3 + 9];
       }
     }
+    if (err) return err;
   }
   c.migrations += nm;
   return SCEMA_MD_OK;

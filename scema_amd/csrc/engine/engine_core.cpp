@@ -62,6 +62,8 @@ const EnvSwitch k_env[] = {
     {"SCEMA_REAX_QEQ_LAUNCH", "conjugate-gradient iterations issued as launches per charge solve (default: adaptive)"},
     // test hooks: force rarely-taken paths
     {"SCEMA_MD_NEIGH_GROW0", "start with undersized neighbour capacities: overflow -> restore -> regrow"},
+    {"SCEMA_MD_NEIGH_EXACT", "1: every list build tests its candidates in FP64 at the exact list radius; 0: none does (default: the first build of a run)"},
+    {"SCEMA_MD_TEST_FAIL_INCOMING", "rank on which the allocation of a state that migrates in fails (-1: on whichever rank receives one); the failure must reach every rank through the handshake"},
     {"SCEMA_MD_QCAP16", "capacity of k_neigh_build's group lists in sixteenths of the table: small values force the whole-table walk"},
     {"SCEMA_MD_RX_COL32", "32-bit column indices in the ReaxFF charge matrix whatever the replica size"},
     {"SCEMA_MD_RX_NB_ONCE", "0: the both-ends ReaxFF non-bonded kernel"},

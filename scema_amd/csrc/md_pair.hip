@@ -163,10 +163,19 @@ __device__ __forceinline__ void tile_atomic_add(double (&vals)[NV], double *dst,
 //   phase 0: bounding boxes of the four groups of the cell's clusters; slot runs of the half stencil (own cell first)
 //   phase 1 (all waves, units of 64 candidates): candidate j images pruned against the bounding box of the cell's
 //            atoms and numbered into the tile's j table, and against the groups' boxes into the groups' candidate
-//            lists -- one pass, candidate order (deterministic)
+//            lists -- one pass, candidate order (deterministic).  An accepted candidate leaves its position as an FP32
+//            record RELATIVE TO THE TILE'S ORIGIN in LDS (the table entry itself goes straight to global memory).
 //   phase 2 (wave per cluster): the group's list is tested against the cluster's 4 atoms; ballots compact
 //            the accepted entries into the row segments
 //   the rows are dealt round robin to the waves of k_pair
+// What has to be exact and what has not: k_pair tests every r^2 in FP64 against the cutoffs, so a row only has to be a SUPERSET of
+// the pairs inside the list radius.  Every build but the first of a run therefore tests its candidates in FP32 on tile-relative
+// coordinates (|coordinate| <= M = half the cell's extent + list radius) against a radius widened by the error bound of that
+// arithmetic, eps = 2^-24 (96 M r + 8 r^2) in r^2 (derivation at nb_eps): FP32 instructions issue at twice the FP64 rate, the
+// records come out of LDS instead of two gathers, an image shift and three FP64 additions per candidate.  The first build of a
+// run (sc.step == 0: also every static evaluation of the parity hook) keeps the FP64 test at the exact radius and takes the
+// statistics there (pairs inside the list radius, the count the tests compare with the oracle's; the reference-radius count of a
+// wider list); SCEMA_MD_NEIGH_EXACT=1 makes every build exact, =0 none (test switches).
 // SCEMA_MD_QCAP16 (test switch) shrinks the group lists so that they overflow: the whole-table walk of phase 2.
 // ------------------------------------------------------------------------------------------
 struct ClusterI {
@@ -174,15 +183,31 @@ struct ClusterI {
   int atom[NI];   // real atom index or -1 (pad)
 };
 
-extern __shared__ int s_build[];  // [capj] j table, then [TW][capB] per-wave lists (segment B from the front, C1 from the back), then
+extern __shared__ int s_build[];  // [3][capj + 64] FP32 records of the j table (x, y, z relative to the tile's origin; entry capj: a far dummy), then
+                                  // [TW][capB] per-wave lists (segment B from the front, the skin band from the back), then
                                   // [NQ][qcap] 16-bit table indices: the part of the table each group (quarter) of the cell's clusters can reach
 #define NQ 4      // groups of a cell's clusters with their own candidate list (<= TW: one wave takes each group's bounding box)
 #define NB_MAXRUN 128    // slot runs of one tile's candidates (own cell + half stencil; 20 for PE-10k)
 #define NB_MAXUNIT 1024  // 64-candidate units of one tile (85 for PE-10k)
 #define NB_UPW 4         // units per wave and round (TW * NB_UPW = 32: scan32_incl)
+#define NB_RECPAD 64     // records behind the table: [capj] is the dummy the lanes past the end of a list read
+#define NB_FAR 1.0e18f   // FP32 place of the dummy record and (negated) of the pad atoms of an i-cluster: (2e18)^2 * 3 is finite
+
+// Error bound of the FP32 tests.  u = 2^-24.  A tile-relative coordinate X, |X| <= M, is stored as fl(X): off by <= u M.  A difference
+// of two stored coordinates is exact up to its own rounding, so d = fl(xi - xj) is off the true difference by <= 2 u M + u |d| <= 3 u M;
+// r^2 = fl(dx^2 + dy^2 + dz^2) carries at most 4 roundings, relative 4 u.  |r2_f - r^2| <= 2 (|dx| + |dy| + |dz|) 3 u M + 4 u r^2
+// <= 6 sqrt(3) u M r + 4 u r^2 < u (11 M r + 4 r^2) for pairs at the radius r.  The box tests of phase 1 (distance of a point from a
+// box whose FP32 edges are off by <= u M as well) obey the same bound.  The kernel uses u (96 M r + 8 r^2): an order of magnitude of
+// slack, and the band it adds to a 14 A list is 1e-4 A wide.
+__device__ __forceinline__ float nb_eps(double M, double r2) {
+  const double r = sqrt(r2);
+  return (float)(1.0001 * 5.9604644775390625e-8 * (96.0 * M * r + 8.0 * r2));
+}
+// v < t, rounded so that the FP32 test can only err towards "inside"
+__device__ __forceinline__ float nb_up(double t, float eps) { return (float)(t * (1.0 + 2.4e-7)) + eps; }
 
 // (TT, 4): at most 128 registers, so that two workgroups share a CU -- at 129 the kernel ran 1.6 times longer
-__global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap) {
+__global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int capB, int qcap, int exact_mode) {
   int sim, cell;
   // Which replicas rebuild in a given step is random (one in ~16 of them, each at its own time).  With the tiles of a replica pinned
   // to one XCD (k_pair's map) the XCD that happens to hold the most rebuilding replicas sets the launch time; consecutive blocks =
@@ -204,18 +229,20 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     if (threadIdx.x == 0) S.tile_nj[cell] = 0;
     return;
   }
-  __shared__ double s_shift[27 * 3];
+  __shared__ double s_shift[27 * 3];  // image shifts (the exact row loop and the candidates of phase 1, which subtract the tile's origin themselves)
   __shared__ int s_rjb[NB_MAXRUN], s_rlen[NB_MAXRUN], s_rcode[NB_MAXRUN], s_ub[NB_MAXRUN + 1];   // slot runs of the candidates, first unit of each
   __shared__ unsigned char s_urun[NB_MAXUNIT];                                                    // run of each 64-candidate unit
   __shared__ int s_ucnt[2][1 + NQ][TW * NB_UPW];                                                  // accepted per unit of a round: table, group lists
   __shared__ int s_ex[TW][NI * 16];   // exclusion lists of the cluster a wave is working on (first 16 per atom)
   __shared__ double s_qbox[NQ][6];    // bounding boxes of the quarters of the cell's clusters (k-d order: quarters are compact)
+  __shared__ float s_qboxf[NQ][6];    // the same relative to the tile's origin, FP32
   __shared__ int s_qn[NQ];            // entries of a quarter's list; -1: list overflowed, the quarter walks the whole table
-  int *s_jtab = s_build;
-  unsigned short *s_qlist = (unsigned short *)(s_build + capj + TW * capB);
+  const int capr = capj + NB_RECPAD;
+  float *s_rx = (float *)s_build, *s_ry = s_rx + capr, *s_rz = s_ry + capr;
+  unsigned short *s_qlist = (unsigned short *)(s_build + 3 * capr) + TW * capB;   // (capB is a multiple of 64)
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int *lb = s_build + capj + wave * capB;
+  unsigned short *lb = (unsigned short *)(s_build + 3 * capr) + wave * capB;   // this wave's staging list (phase 2)
 
   BoxD b;
   box_derive(sc.box, b);
@@ -225,6 +252,11 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     s_shift[3 * threadIdx.x + 1] = b.h[1] * s1 + b.h[3] * s2;
     s_shift[3 * threadIdx.x + 2] = b.h[2] * s2;
   }
+  // (capj, the kernel's argument, is the largest table of the launch and lays out the LDS; a replica's own capacity S.capj <= capj bounds
+  // what is written to ITS table in memory, and entry S.capj -- never a valid one -- is the dummy that lanes past the end of a list
+  // name: a far record in LDS, and in memory the first word behind this tile's table: the next tile's, or the buffer's slack)
+  const int capjs = S.capj;
+  if (threadIdx.x == 32) { s_rx[capjs] = NB_FAR; s_ry[capjs] = NB_FAR; s_rz[capjs] = NB_FAR; }
   const GLOBAL_AS double *xq = as_global((const double *)S.xq);               // (x,y) halves
   const GLOBAL_AS double *zq = xq + 2 * (size_t)S.npad;                          // (z,q) halves
   // ---- phase 0: bounding boxes of the groups of the cell's clusters; slot runs of the half stencil ----
@@ -308,30 +340,36 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     }
     if (lane == 0) s_ub[NB_MAXRUN] = carry;
   }
-  __syncthreads();
-  const int nunit = s_ub[NB_MAXRUN];
-#ifdef PAIR_TIMING
-  const unsigned long long tb05 = __builtin_readcyclecounter();
-#endif
-  // the cell's box = union of its groups' boxes
+  // the cell's box = union of its groups' boxes; its centre is the tile's origin; the groups' boxes relative to it in FP32
   double blo0 = 1e300, blo1 = 1e300, blo2 = 1e300, bhi0 = -1e300, bhi1 = -1e300, bhi2 = -1e300;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
     blo0 = fmin(blo0, s_qbox[q][0]); blo1 = fmin(blo1, s_qbox[q][1]); blo2 = fmin(blo2, s_qbox[q][2]);
     bhi0 = fmax(bhi0, s_qbox[q][3]); bhi1 = fmax(bhi1, s_qbox[q][4]); bhi2 = fmax(bhi2, s_qbox[q][5]);
   }
-#if defined(NEIGH_WHATIF_BOX32)
-  __shared__ float s_qboxf[NQ][6];
-  if (threadIdx.x < NQ * 6) { const int q = threadIdx.x / 6, k = threadIdx.x % 6; s_qboxf[q][k] = (float)(s_qbox[q][k] - (k % 3 == 0 ? blo0 : k % 3 == 1 ? blo1 : blo2)); }
+  const double ox = wave_uniform(0.5 * (blo0 + bhi0)), oy = wave_uniform(0.5 * (blo1 + bhi1)), oz = wave_uniform(0.5 * (blo2 + bhi2));
+  // (a cell always holds a real atom here -- nown > 0 and pads only fill the last cluster -- so the box is a proper one)
+  const double Mrel = wave_uniform(0.5 * fmax(bhi0 - blo0, fmax(bhi1 - blo1, bhi2 - blo2)) + sqrt(rl2));
+  const float eps = nb_eps(Mrel, rl2);
+  const float rl2e = nb_up(rl2, eps);
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + NQ * 6) {
+    const int q = (threadIdx.x - 64) / 6, k = (threadIdx.x - 64) % 6;
+    s_qboxf[q][k] = (float)(s_qbox[q][k] - (k % 3 == 0 ? ox : k % 3 == 1 ? oy : oz));
+  }
+  const float hx = (float)(bhi0 - ox), hy = (float)(bhi1 - oy), hz = (float)(bhi2 - oz);   // half extents of the cell's box (the origin is its centre)
   __syncthreads();
+  const int nunit = s_ub[NB_MAXRUN];
+#ifdef PAIR_TIMING
+  const unsigned long long tb05 = __builtin_readcyclecounter();
 #endif
   // ---- phase 1: candidates -> j table (pruned against the cell's box) and group lists (against the groups' boxes), one pass ----
   // Rounds of TW * NB_UPW units: a wave takes NB_UPW units per round (their loads in flight together), ballots give each unit's
   // counts, ONE barrier per round, then every wave takes the prefix over the round's units and writes its accepted entries: table and
   // lists come out in candidate order whatever wave handled what.
   // (inside this kernel the table entries also carry the type of j in bits 28..31: the rows need it per accepted candidate, and
-  // one load per table entry here replaces one per cluster and entry there; the copy that k_pair reads is written without it)
+  // one load per table entry here replaces one per cluster and entry there; k_pair masks its reads of the table)
   const GLOBAL_AS int *stype = as_global(S.stype);
+  GLOBAL_AS int *gj = as_global_w(S.tile_jtab) + (size_t)cell * S.capj;
   int nj = 0;
   int qn[NQ];
 #pragma unroll
@@ -361,34 +399,22 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     bool ok[NB_UPW];
     unsigned okq[NB_UPW];
     unsigned long long m[NB_UPW];
+    float xf[NB_UPW], yf[NB_UPW], zf[NB_UPW];
 #pragma unroll
     for (int i = 0; i < NB_UPW; i++) {
-      const double xj = px[i] + s_shift[3 * cv[i]], yj = py[i] + s_shift[3 * cv[i] + 1], zj = pz[i] + s_shift[3 * cv[i] + 2];
+      // the candidate's image relative to the tile's origin, FP64 up to the conversion (a pad's 1e15 stays a finite FP32 number)
+      xf[i] = (float)(px[i] + (s_shift[3 * cv[i]] - ox)); yf[i] = (float)(py[i] + (s_shift[3 * cv[i] + 1] - oy)); zf[i] = (float)(pz[i] + (s_shift[3 * cv[i] + 2] - oz));
+      {
+        const float ex = fmaxf(0.f, fabsf(xf[i]) - hx), ey = fmaxf(0.f, fabsf(yf[i]) - hy), ez = fmaxf(0.f, fabsf(zf[i]) - hz);
+        ok[i] = valid[i] && (home[i] || ex * ex + ey * ey + ez * ez < rl2e);
+      }
       okq[i] = 0;
-#if defined(NEIGH_WHATIF_BOX32)   // sensitivity experiment (never in a product build): the five box tests of a candidate in FP32
-      {
-        const float xf = (float)(xj - blo0), yf = (float)(yj - blo1), zf = (float)(zj - blo2);
-        const float hx = (float)(bhi0 - blo0), hy = (float)(bhi1 - blo1), hz = (float)(bhi2 - blo2), rl2f = (float)rl2;
-        const float ex = fmaxf(0.f, fmaxf(-xf, xf - hx)), ey = fmaxf(0.f, fmaxf(-yf, yf - hy)), ez = fmaxf(0.f, fmaxf(-zf, zf - hz));
-        ok[i] = valid[i] && (home[i] || ex * ex + ey * ey + ez * ez < rl2f);
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const float *bq = s_qboxf[q];
-          const float fx = fmaxf(0.f, fmaxf(bq[0] - xf, xf - bq[3])), fy = fmaxf(0.f, fmaxf(bq[1] - yf, yf - bq[4])), fz = fmaxf(0.f, fmaxf(bq[2] - zf, zf - bq[5]));
-          okq[i] |= (ok[i] && fx * fx + fy * fy + fz * fz < rl2f) ? (1u << q) : 0u;
-        }
-      }
-#else
-      {
-        const double ex = box_excess(blo0, bhi0, xj), ey = box_excess(blo1, bhi1, yj), ez = box_excess(blo2, bhi2, zj);
-        ok[i] = valid[i] && (home[i] || ex * ex + ey * ey + ez * ez < rl2);
-      }
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
-        const double ex = box_excess(s_qbox[q][0], s_qbox[q][3], xj), ey = box_excess(s_qbox[q][1], s_qbox[q][4], yj), ez = box_excess(s_qbox[q][2], s_qbox[q][5], zj);
-        okq[i] |= (ok[i] && ex * ex + ey * ey + ez * ez < rl2) ? (1u << q) : 0u;
+        const float *bq = s_qboxf[q];
+        const float ex = fmaxf(0.f, fmaxf(bq[0] - xf[i], xf[i] - bq[3])), ey = fmaxf(0.f, fmaxf(bq[1] - yf[i], yf[i] - bq[4])), ez = fmaxf(0.f, fmaxf(bq[2] - zf[i], zf[i] - bq[5]));
+        okq[i] |= (ok[i] && ex * ex + ey * ey + ez * ez < rl2e) ? (1u << q) : 0u;
       }
-#endif
       m[i] = __ballot(ok[i]);
       const int ui = wave * NB_UPW + i;
       if (lane == 0) s_ucnt[par][0][ui] = __popcll(m[i]);
@@ -412,35 +438,36 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     for (int i = 0; i < NB_UPW; i++) {
       const int ui = wave * NB_UPW + i;
       const int pos = nj + __builtin_amdgcn_readlane(ex_c[0], ui) + popc_below(m[i]);
-      if (ok[i] && pos < capj) s_jtab[pos] = jv[i] | (cv[i] << 23) | (tv[i] << 28);
+      if (ok[i] && pos < capjs) {
+        gj[pos] = jv[i] | (cv[i] << 23) | (tv[i] << 28);
+        s_rx[pos] = xf[i]; s_ry[pos] = yf[i]; s_rz[pos] = zf[i];
+      }
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const bool in_q = (okq[i] >> q) & 1u;
         const unsigned long long mq = __ballot(in_q);
         const int lp = qn[q] + __builtin_amdgcn_readlane(ex_c[1 + q], ui) + popc_below(mq);
-        if (in_q && lp < qcap) s_qlist[q * qcap + lp] = (unsigned short)pos;
+        if (in_q && lp < qcap) s_qlist[q * qcap + lp] = (unsigned short)(pos | (tv[i] << 12));   // (pos < capj <= 4032)
       }
     }
     nj += tot_c[0];
 #pragma unroll
     for (int q = 0; q < NQ; q++) qn[q] += tot_c[1 + q];
   }
-  __syncthreads();
   // k_pair keeps a wave's row headers in one VGPR triple (lane r = r-th row): at most 64 rows per wave, 64*TW clusters
   // per cell.  A denser cell is reported like a table overflow (the engine retries with smaller cells), never dropped.
-  if (!runs_ok || nj > capj || nj > S.capj || nown / NI > 64 * TW) {   // uniform: table overflow -> the engine regrows and retries
+  if (!runs_ok || nj > capjs || nown / NI > 64 * TW) {   // uniform: table overflow -> the engine regrows and retries
     if (threadIdx.x == 0) { S.tile_nj[cell] = 0; atomicOr(&sc.overflow, 1 | 4); atomicMax(&sc.maxj_seen, runs_ok ? nj : 2 * S.capj); }   // 4: table
     for (int cl = cs / NI + threadIdx.x; cl < ce / NI; cl += TT) { S.numneigh[2 * cl] = 0; S.numneigh[2 * cl + 1] = 0; }
     return;
   }
-  {
-    GLOBAL_AS int *gj = as_global_w(S.tile_jtab) + (size_t)cell * S.capj;
-    for (int l = threadIdx.x; l < nj; l += TT) gj[l] = s_jtab[l] & 0x0FFFFFFF;
-    if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
-  }
+  if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
 #pragma unroll
   for (int q = 0; q < NQ; q++)
     if ((int)threadIdx.x == q) s_qn[q] = (qn[q] > qcap) ? -1 : qn[q];
+  // (the table entries of this tile written above are read back by this workgroup's row loops: stores and loads of one workgroup to
+  // global memory are ordered by the barrier once the stores have left the waves)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
 
   // ---- phase 2 ----
@@ -448,14 +475,20 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
   const unsigned long long tb1 = __builtin_readcyclecounter();
 #endif
   const int maxrow = S.maxneigh;
-  const double ra2 = S.seg_a2, rb2 = S.seg_b2, rc2 = S.seg_c2, excl2 = S.excl_cut2;
+  const double ra2 = S.seg_a2, rb2 = fmax(S.seg_a2, S.seg_b2), rc2 = fmax(rb2, S.seg_c2), excl2 = S.excl_cut2;
   unsigned int npairs = 0, npairs_ref = 0;   // per lane and tile: far below 2^32
   unsigned long long nrowent = 0;
-  // Only a list wider than the reference's needs the second count (uniform), and it is a statistic (the algorithmic bytes of the
-  // roofline): taken at the first build of a run, kept until the next run (it moves by < 0.1 % between the builds of a run, and the
-  // per-atom compares were 6 % of this loop's instructions)
+  // The first build of a run is the exact one (header).  Only a list wider than the reference's needs the second count (uniform),
+  // and it is a statistic (the algorithmic bytes of the roofline): taken at that build, kept until the next run (it moves by < 0.1 %
+  // between the builds of a run).
   const bool wider = S.rlist_ref2 < S.rlist2;
-  const bool count_ref = wider && sc.step == 0;
+  const bool exact = exact_mode == 1 || (exact_mode != 0 && sc.step == 0);
+  const bool count_ref = wider && exact && sc.step == 0;
+  const float ra2e = nb_up(ra2, eps), rb2e = nb_up(rb2, eps), rc2e = nb_up(rc2, eps), excl2e = nb_up(excl2, eps);
+  const GLOBAL_AS int *gjr = (const GLOBAL_AS int *)gj;
+  // The wave's staging list, 16-bit entries (position in the group's list | i-mask << 12): segment B from the front of [0, capBC),
+  // the near skin band C1 from its back, the far band C2 in [capBC, capB).  (32-bit entries were 41 KB of LDS for the eight waves.)
+  const int capD = capB >> 2, capBC = capB - capD;
   int nmax = 0, over = 0;
   for (int cl = cs / NI + wave; cl < ce / NI; cl += TW) {
     const int s0slot = cl * NI;
@@ -495,142 +528,173 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     const bool qall = qnl < 0;
     const int nl = qall ? nj : qnl;
     const unsigned short *ql = s_qlist + qq * qcap;
-    // one chunk of the list ahead: entry + record of chunk r+1 are in flight while chunk r is tested
-    int l_n = (lane < nl) ? (qall ? lane : (int)ql[lane]) : -1;
-    int jt_n = (l_n >= 0) ? s_jtab[l_n] : 0;
-    double pn0, pn1, pn2;
-    {
-      const size_t jn = (size_t)(jt_n & MD_JMASK);
-      pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
-    }
+    // entry k of the cluster's candidate list as (table index | type of j << 12); past the end: the dummy record behind the table.
+    // (A group list holds exactly that; the whole-table walk of an overflowed list takes the type from the table entry.)
+    auto list_at = [&](int k) -> int { return (k < nl) ? (qall ? k : (int)ql[k]) : capjs; };
 #ifdef PAIR_TIMING
     if (lane == 0) { atomicAdd(&sc.dbg[10], (unsigned long long)((nl + 63) >> 6)); atomicAdd(&sc.dbg[11], 1ull); }
 #endif
     bool own_chunks = true;
-    auto row_loop = [&](auto cref_tag) __attribute__((always_inline)) {
-    constexpr bool CREF = decltype(cref_tag)::value;
-    // (segment-A entries of a chunk are STORED at the top of the next turn, before that turn's requests: the memory counter counts in
-    // order and the compiler cannot count a store behind a branch, so a store at the end of the turn made the wait for the records
-    // requested at its top -- due at the start of the next turn -- a wait for the store's own round trip as well.  Issued first, it has
-    // the whole turn.)
     int posA_prev = -1, entA_prev = 0;
-    for (int base = 0; base < nl; base += 64) {
-      const int l = l_n;
-      const int jt = jt_n;
-      const double px = pn0, py = pn1, pz = pn2;
-      if (posA_prev >= 0) row[posA_prev] = entA_prev;
-      posA_prev = -1;
+    // What both row loops do with a chunk once the i-mask of every candidate is known: own-cell rule, exclusions, segments, stores.
+    // (lt: list entry; jt: table entry; R2X(a): the candidate's squared distance from atom a in the loop's arithmetic)
+#define NB_CHUNK_TAIL(RMIN, R2X, RA, RB, RC, EXCL)                                                                                       \
+      const int l = lt & 0xFFF;                                                                                                           \
+      const int j = jt & MD_JMASK;                                                                                                        \
+      if (own_chunks) {   /* (wave-uniform: the entries of the own cell come first in the table and in every list) */                     \
+        /* same cell, same image: each pair once, by slot order -- atom a of the cluster keeps j only if j > s0slot + a.  One mask per */ \
+        /* candidate instead of a test per atom (rmin may then be too small: a nearer segment is always allowed) */                       \
+        const bool own = l < nown;                                                                                                        \
+        const int d = j - s0slot;                                                                                                         \
+        const int drop = !own ? 0 : (d <= 0 ? 0xF : (d > 3 ? 0 : (0xF << d) & 0xF));                                                      \
+        mask &= ~drop; refm &= ~drop;                                                                                                     \
+        own_chunks = __ballot(own) != 0ull;                                                                                               \
+      }                                                                                                                                   \
+      /* candidates inside the exclusion gate (bonded neighbours: a few chunks per row) take the wave-uniform slow path, which */        \
+      /* looks at the four distances again and walks the exclusion lists */                                                               \
+      if (__ballot(mask != 0 && RMIN < EXCL) != 0ull) {                                                                                   \
+        if (mask != 0 && RMIN < EXCL) {                                                                                                   \
+          _Pragma("unroll") for (int a = 0; a < NI; a++)                                                                                  \
+            if ((mask & (1 << a)) && R2X(a) < EXCL) {                                                                                     \
+              bool keep = true;                                                                                                           \
+              const int nl16 = min(exn[a], 16);                                                                                           \
+              for (int e = 0; e < nl16; e++) keep = keep && (s_ex[wave][a * 16 + e] != j);                                                \
+              for (int e = 16; e < exn[a]; e++) keep = keep && (S.slot_of[S.ex_list[exb[a] + e]] != j);                                   \
+              if (!keep) { mask &= ~(1 << a); refm &= ~(1 << a); }   /* rmin may stay too small: only the segment choice sees it */       \
+            }                                                                                                                             \
+        }                                                                                                                                 \
+      }                                                                                                                                   \
+      /* segments: A straight into the row (the store itself at the top of the next turn); B, C1, C2 into the wave's staging list */     \
+      {                                                                                                                                   \
+        const bool isA = mask && RMIN < RA, isB = mask && !isA && RMIN < RB, isS = mask && !isA && !isB;                                  \
+        const bool isD = isS && !(RMIN < RC), isC = isS && !isD;                                                                          \
+        const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC), mD = __ballot(isD);                          \
+        if (mask) {                                                                                                                       \
+          const unsigned short e16 = (unsigned short)((base + lane) | (mask << 12));                                                      \
+          if (isA) {                                                                                                                      \
+            const int pos = nA + popc_below(mA);                                                                                          \
+            const int ty = qall ? (int)((unsigned)jt >> 28) : (lt >> 12);                                                                 \
+            if (pos < maxrow) { posA_prev = pos; entA_prev = l | (ty << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT); }                         \
+          } else if (isB) { const int pos = nB + popc_below(mB); if (pos < capBC) lb[pos] = e16; }                                        \
+          else if (isC) { const int pos = capBC - 1 - (nC + popc_below(mC)); if (pos >= 0) lb[pos] = e16; }                               \
+          else { const int pos = nD + popc_below(mD); if (pos < capD) lb[capBC + pos] = e16; }                                            \
+        }                                                                                                                                 \
+        nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC); nD += __popcll(mD);                                                   \
+      }                                                                                                                                   \
+      npairs += __popc(mask);
+
+    if (exact) {
+      // ---- the exact row loop (first build of a run): FP64 distances at the exact radius, positions gathered from memory ----
+      // one chunk of the list ahead: entry + record of chunk r+1 are in flight while chunk r is tested
+      int lt_n = list_at(lane);
+      int jt_n = gjr[lt_n & 0xFFF];
+      double pn0, pn1, pn2;
       {
-        const int in_ = base + 64 + lane;
-        l_n = (in_ < nl) ? (qall ? in_ : (int)ql[in_]) : -1;
-        jt_n = (l_n >= 0) ? s_jtab[l_n] : 0;
         const size_t jn = (size_t)(jt_n & MD_JMASK);
         pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
       }
-      // Branch-free test of the candidate against the four atoms (lanes past the end of the list read entry 0 and are
-      // masked out); only candidates inside the exclusion gate -- bonded neighbours, a few chunks per row -- take the
-      // wave-uniform slow path that walks the exclusion lists.
-      const bool in = l >= 0;
-      const int j = jt & MD_JMASK;
-      const int code = (jt >> 23) & 31;
-      const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
-
-      int mask = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
-      double r2a[NI];
-      // (pad atoms of the cluster sit beyond 1e15, each pad slot at its own place: never inside the list radius of anything; lanes past the end of the list are cleared below; the
-      // nearest of the four distances stands for the nearest ACCEPTED one: beyond the list radius it decides nothing, and otherwise it
-      // can only be too small, which moves the entry to a nearer segment -- always allowed)
-#if defined(NEIGH_WHATIF_F32)   // sensitivity experiment (never in a product build): the four distance tests in FP32 on cluster-relative coordinates, no exact fallback
-      const float xjf = (float)(xj - ci.x[0]), yjf = (float)(yj - ci.y[0]), zjf = (float)(zj - ci.z[0]);
-      float r2f[NI];
+      auto row_loop = [&](auto cref_tag) __attribute__((always_inline)) {
+        constexpr bool CREF = decltype(cref_tag)::value;
+        // (segment-A entries of a chunk are STORED at the top of the next turn, before that turn's requests: the memory counter counts in
+        // order and the compiler cannot count a store behind a branch, so a store at the end of the turn made the wait for the records
+        // requested at its top -- due at the start of the next turn -- a wait for the store's own round trip as well.  Issued first, it has
+        // the whole turn.)
+        for (int base = 0; base < nl; base += 64) {
+          const int lt = lt_n;
+          const int jt = jt_n;
+          const double px = pn0, py = pn1, pz = pn2;
+          if (posA_prev >= 0) row[posA_prev] = entA_prev;
+          posA_prev = -1;
+          {
+            lt_n = list_at(base + 64 + lane);
+            jt_n = gjr[lt_n & 0xFFF];   // (past the end of the list: the word behind the table -- the next tile's, or the buffer's slack; never used)
+            const size_t jn = (size_t)(jt_n & MD_JMASK);
+            pn0 = xq[2 * jn]; pn1 = xq[2 * jn + 1]; pn2 = zq[2 * jn];
+          }
+          // Branch-free test of the candidate against the four atoms (lanes past the end of the list are masked out); only
+          // candidates inside the exclusion gate -- bonded neighbours, a few chunks per row -- take the wave-uniform slow path
+          // that walks the exclusion lists.
+          const bool in = base + lane < nl;
+          const int code = (jt >> 23) & 31;
+          const double xj = px + s_shift[3 * code], yj = py + s_shift[3 * code + 1], zj = pz + s_shift[3 * code + 2];
+          int mask = 0, refm = 0;   // refm: the accepted pairs that the reference's list radius would hold too
+          double r2a[NI];
+          // (pad atoms of the cluster sit beyond 1e15, each pad slot at its own place: never inside the list radius of anything; the
+          // nearest of the four distances stands for the nearest ACCEPTED one: beyond the list radius it decides nothing, and otherwise it
+          // can only be too small, which moves the entry to a nearer segment -- always allowed)
 #pragma unroll
-      for (int a = 0; a < NI; a++) {
-        const float dx = (float)(ci.x[a] - ci.x[0]) - xjf, dy = (float)(ci.y[a] - ci.y[0]) - yjf, dz = (float)(ci.z[a] - ci.z[0]) - zjf;   // (the i side is loop-invariant)
-        const float r2 = dx * dx + dy * dy + dz * dz;
-        mask |= (r2 < (float)S.rlist2) ? (1 << a) : 0;
-        r2f[a] = r2; r2a[a] = 0.0;
-      }
-      const double rmin = (double)fminf(fminf(r2f[0], r2f[1]), fminf(r2f[2], r2f[3]));
-#else
-#pragma unroll
-      for (int a = 0; a < NI; a++) {
-        const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
-        double r2 = dx * dx + dy * dy + dz * dz;
-#if defined(NEIGH_WHATIF_DIST2)   // ... or the FP64 distance arithmetic of the row loop issued twice (+28 FP64 instructions per chunk)
-        { double ex = xj, ey = yj, ez = zj; asm volatile("" : "+v"(ex), "+v"(ey), "+v"(ez));
-          const double ux = ci.x[a] - ex, uy = ci.y[a] - ey, uz = ci.z[a] - ez; r2 = vmin_f64(r2, ux * ux + uy * uy + uz * uz); }
-#endif
-        mask |= (r2 < S.rlist2) ? (1 << a) : 0;
-        if (CREF) refm |= (r2 < S.rlist_ref2) ? (1 << a) : 0;
-        r2a[a] = r2;
-      }
-      const double rmin = vmin_f64(vmin_f64(r2a[0], r2a[1]), vmin_f64(r2a[2], r2a[3]));
-#endif
-      if (!in) { mask = 0; refm = 0; }
-      if (own_chunks) {   // (wave-uniform: the entries of the own cell come first in the table and in every list)
-        // same cell, same image: each pair once, by slot order -- atom a of the cluster keeps j only if j > s0slot + a.  One mask per
-        // candidate instead of a test per atom (rmin may then be too small: a nearer segment is always allowed)
-        const bool own = in && l < nown;
-        const int d = j - s0slot;
-        const int drop = !own ? 0 : (d <= 0 ? 0xF : (d > 3 ? 0 : (0xF << d) & 0xF));
-        mask &= ~drop; refm &= ~drop;
-        own_chunks = __ballot(own) != 0ull;
-      }
-      // candidates inside the exclusion gate (bonded neighbours: a few chunks per row) take the wave-uniform slow path, which
-      // looks at the four distances again and walks the exclusion lists
-      if (__ballot(mask != 0 && rmin < excl2) != 0ull) {
-        if (mask != 0 && rmin < excl2) {
-#pragma unroll
-          for (int a = 0; a < NI; a++)
-            if (mask & (1 << a)) {
-              const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
-              if (dx * dx + dy * dy + dz * dz < excl2) {
-                bool keep = true;
-                const int nl = min(exn[a], 16);
-                for (int e = 0; e < nl; e++) keep = keep && (s_ex[wave][a * 16 + e] != j);
-                for (int e = 16; e < exn[a]; e++) keep = keep && (S.slot_of[S.ex_list[exb[a] + e]] != j);
-                if (!keep) { mask &= ~(1 << a); refm &= ~(1 << a); }   // rmin may stay too small: only the segment choice sees it, and a nearer segment is always allowed
-              }
-            }
+          for (int a = 0; a < NI; a++) {
+            const double dx = ci.x[a] - xj, dy = ci.y[a] - yj, dz = ci.z[a] - zj;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            mask |= (r2 < S.rlist2) ? (1 << a) : 0;
+            if (CREF) refm |= (r2 < S.rlist_ref2) ? (1 << a) : 0;
+            r2a[a] = r2;
+          }
+          const double rmin = vmin_f64(vmin_f64(r2a[0], r2a[1]), vmin_f64(r2a[2], r2a[3]));
+          if (!in) { mask = 0; refm = 0; }
+#define NB_R2X(a) r2a[a]
+          NB_CHUNK_TAIL(rmin, NB_R2X, ra2, rb2, rc2, excl2)
+          if (CREF) npairs_ref += __popc(refm);
         }
+      };
+      // (the second count has its own copy of the loop, so that the builds without it do not pay for four compares per candidate that
+      // the compiler would otherwise keep as predicated code)
+      if (count_ref) row_loop(std::true_type{}); else row_loop(std::false_type{});
+    } else {
+      // ---- the row loop of every other build: FP32, records from LDS, a superset of the list radius by eps ----
+      // the cluster's atoms relative to the tile's origin, in scalar registers; pads far on the other side from every record
+      float cx[NI], cy[NI], cz[NI];
+#pragma unroll
+      for (int a = 0; a < NI; a++) {
+        const bool real = ci.atom[a] >= 0;
+        cx[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(real ? (float)(ci.x[a] - ox) : -NB_FAR)));
+        cy[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(real ? (float)(ci.y[a] - oy) : -NB_FAR)));
+        cz[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(real ? (float)(ci.z[a] - oz) : -NB_FAR)));
       }
-      // segments: A straight into the row; B from the front of the wave's LDS list; the skin band -- C1 (near) and C2 (far, flagged) --
-      // from its back, one ballot for both; the end of the row sorts the band into C1 | C2 so that the row leaves CONTIGUOUS
-      // ([A|B|C1|C2]: k_pair's prefetch then indexes row[k] and nothing else)
-      const bool isA = mask && rmin < ra2, isB = mask && !isA && rmin < rb2, isS = mask && !isA && !isB;
-      const bool isD = isS && !(rmin < rc2);
-      const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mS = __ballot(isS), mD = __ballot(isD);
-      if (mask) {
-        const int entry = l | ((int)((unsigned)jt >> 28) << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT);
-        if (isA) { const int pos = nA + popc_below(mA); if (pos < maxrow) { posA_prev = pos; entA_prev = entry; } }
-        else if (isB) { const int pos = nB + popc_below(mB); if (pos < capB) lb[pos] = entry; }
-        else { const int pos = capB - 1 - (nC + nD + popc_below(mS)); if (pos >= 0) lb[pos] = entry | (isD ? E_FAR : 0); }
+      // list entries two chunks ahead, record and table entry one chunk ahead (a record's address needs its list entry: that is there
+      // when the requests of the next chunk go out)
+      int lt_c = list_at(lane), lt_n = list_at(64 + lane);
+      float x_c = s_rx[lt_c & 0xFFF], y_c = s_ry[lt_c & 0xFFF], z_c = s_rz[lt_c & 0xFFF];
+      int jt_c = gjr[lt_c & 0xFFF];
+      for (int base = 0; base < nl; base += 64) {
+        const int lt = lt_c;
+        const int jt = jt_c;
+        const float xf = x_c, yf = y_c, zf = z_c;
+        if (posA_prev >= 0) row[posA_prev] = entA_prev;
+        posA_prev = -1;
+        lt_c = lt_n;
+        x_c = s_rx[lt_c & 0xFFF]; y_c = s_ry[lt_c & 0xFFF]; z_c = s_rz[lt_c & 0xFFF];
+        jt_c = gjr[lt_c & 0xFFF];
+        lt_n = list_at(base + 128 + lane);
+        int mask = 0, refm = 0;   // (refm: the exact loop's second count; dead here)
+        (void)refm;
+        float r2a[NI];
+#pragma unroll
+        for (int a = 0; a < NI; a++) {
+          const float dx = cx[a] - xf, dy = cy[a] - yf, dz = cz[a] - zf;
+          const float r2 = dx * dx + dy * dy + dz * dz;
+          mask |= (r2 < rl2e) ? (1 << a) : 0;
+          r2a[a] = r2;
+        }
+        const float rmin = fminf(fminf(r2a[0], r2a[1]), fminf(r2a[2], r2a[3]));
+        NB_CHUNK_TAIL(rmin, NB_R2X, ra2e, rb2e, rc2e, excl2e)
       }
-      { const int ns = __popcll(mS), nd = __popcll(mD); nA += __popcll(mA); nB += __popcll(mB); nC += ns - nd; nD += nd; }
-      npairs += __popc(mask);
-      if (CREF) npairs_ref += __popc(refm);
     }
+#undef NB_R2X
     if (posA_prev >= 0) row[posA_prev] = entA_prev;
-    };
-    // (the second count is a statistic of a run's first build: its own copy of the loop, so that every other build does not pay for
-    // four compares per candidate that the compiler would otherwise keep as predicated code)
-    if (count_ref) row_loop(std::true_type{}); else row_loop(std::false_type{});
     const int n = nA + nB + nC + nD;
-    const bool bad = nB + nC + nD > capB || n > maxrow;
+    const bool bad = nB + nC > capBC || nD > capD || n > maxrow;
     if (bad) over = 1;
-    // B, skin band: LDS lists -> behind A (same-wave LDS traffic is processed in order)
+    // B, C1, C2: staging list -> behind A, with the table index and the type of j back in place (same-wave LDS traffic is processed in order)
     if (!bad) {
-      for (int k = lane; k < nB; k += 64) row[nA + k] = lb[k];
-      int cC = nA + nB, cD = nA + nB + nC;
-      for (int k0 = 0; k0 < nC + nD; k0 += 64) {
-        const int k = k0 + lane;
-        const bool in = k < nC + nD;
-        const int e = in ? lb[capB - 1 - k] : 0;
-        const bool far = in && (e & E_FAR);
-        const unsigned long long mN = __ballot(in && !far), mF = __ballot(far);
-        if (in) row[far ? cD + popc_below(mF) : cC + popc_below(mN)] = e & ~E_FAR;
-        cC += __popcll(mN); cD += __popcll(mF);
-      }
+      auto expand = [&](int e16) -> int {
+        const int lt = list_at(e16 & 0xFFF), l = lt & 0xFFF;
+        const int ty = qall ? (int)((unsigned)gjr[l] >> 28) : (lt >> 12);
+        return l | (ty << E_TYPE_SHIFT) | ((e16 >> 12) << E_MASK_SHIFT);
+      };
+      for (int k = lane; k < nB; k += 64) row[nA + k] = expand(lb[k]);
+      for (int k = lane; k < nC; k += 64) row[nA + nB + k] = expand(lb[capBC - 1 - k]);
+      for (int k = lane; k < nD; k += 64) row[nA + nB + nC + k] = expand(lb[capBC + k]);
       // the row's last chunk is filled up with empty entries (mask 0): k_pair reads whole chunks and masks no lane.  (maxrow is a
       // multiple of 64.)  On steps without the far band it reads up to the end of the chunk that holds the last C1 entry: what
       // follows there are C2 entries, whose pairs are outside the cutoff on such a step -- evaluated to nothing in lanes that
@@ -643,6 +707,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     nmax = max(nmax, n);
     nrowent += n;
   }
+#undef NB_CHUNK_TAIL
 #ifdef PAIR_TIMING
   const unsigned long long tb2 = __builtin_readcyclecounter();
 #endif
@@ -673,13 +738,20 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     atomicAdd(&sc.dbg[8], tb05 - tb0); atomicAdd(&sc.dbg[9], 1ull);
   }
 #endif
-  const double cnt = wave_sum((double)npairs), cnt_ref = count_ref ? wave_sum((double)npairs_ref) : (wider ? 0.0 : cnt);
+  // Statistics: the pairs listed (what a full per-atom list would store: every unordered pair from both ends) -- at an exact build
+  // the pairs inside the list radius, the count the tests compare with the oracle's; an FP32 build also counts the few pairs of its
+  // eps band (1e-5 of the list) -- and, for a list wider than the reference's, the pairs inside the reference's radius, taken at the
+  // first build of a run.
+  {
+    const double cnt = wave_sum((double)npairs), cnt_ref = count_ref ? wave_sum((double)npairs_ref) : (wider ? 0.0 : cnt);
+    if (lane == 0) {
+      atomicAdd(&sc.nentries, 2ull * (unsigned long long)cnt);
+      atomicAdd(&sc.nentries_ref, 2ull * (unsigned long long)cnt_ref);
+    }
+  }
   if (lane == 0) {
     if (over) atomicOr(&sc.overflow, 1 | 8);   // 8: a cluster row (or its segment-B list)
     atomicMax(&sc.maxneigh_seen, nmax);
-    // nentries counts what a full per-atom list would store: every unordered pair from both ends
-    atomicAdd(&sc.nentries, 2ull * (unsigned long long)cnt);
-    atomicAdd(&sc.nentries_ref, 2ull * (unsigned long long)cnt_ref);
     atomicAdd(&sc.nrowent, nrowent);
   }
 }
@@ -1016,7 +1088,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   // non-home entries (shift from LDS, no position gathers), one partial sum per wave, stored without atomics.
   if (VIR && !ENG) {
     for (int l = threadIdx.x; l < nj; l += TT) {
-      const int code = s_jtab[l] >> 23;
+      const int code = (s_jtab[l] >> 23) & 31;   // (bits 28..31: the type of j, k_neigh_build's)
       if (code != CODE_HOME) {
         const double ax = s_f[3 * l], ay = s_f[3 * l + 1], az = s_f[3 * l + 2];
         const double px = s_shift[4 * code], py = s_shift[4 * code + 1], pz = s_shift[4 * code + 2];
@@ -1077,7 +1149,13 @@ static int neigh_qcap(int capj) {
   return (n16 * capj / 16 + 63) / 64 * 64;
 }
 size_t mdk_neigh_lds_bytes(int capj, int maxrow) {
-  return ((size_t)capj + (size_t)TW * mdk_neigh_capB(maxrow)) * sizeof(int) + (size_t)NQ * neigh_qcap(capj) * sizeof(unsigned short);
+  if (capj > 4032) return (size_t)1 << 30;   // group-list and staging entries hold a 12-bit table index (k_pair's own LDS bound keeps tables below 2 707 entries)
+  return 3 * ((size_t)capj + NB_RECPAD) * sizeof(float) + ((size_t)TW * mdk_neigh_capB(maxrow) + (size_t)NQ * neigh_qcap(capj)) * sizeof(unsigned short);
+}
+// which builds test their candidates in FP64 at the exact list radius: -1 (default) the first build of a run, 1 all, 0 none
+static int neigh_exact_mode() {
+  static const int m = scema_env("SCEMA_MD_NEIGH_EXACT") ? atoi(scema_env("SCEMA_MD_NEIGH_EXACT")) : -1;
+  return m;
 }
 
 void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int maxrow, int capj) {
@@ -1087,7 +1165,7 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
   static size_t optin_tab[16] = {0};  // more than 64 KB of dynamic LDS needs an explicit opt-in
   size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_neigh_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB, neigh_qcap(capj));
+  hipLaunchKernelGGL(k_neigh_build, grid_xcd(maxcells, ns), dim3(TT), lds, st, d, maxcells, ns, capj, capB, neigh_qcap(capj), neigh_exact_mode());
 }
 
 template <bool VIR, bool ENG, int NP, bool CLE = false>

@@ -39,3 +39,32 @@ def test_the_shim_hides_the_gpu_device_nodes_and_nothing_else(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LD_PRELOAD=shim), capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     assert r.stdout.count("blocked") == 2 and "OPENED" not in r.stdout and "True x" in r.stdout
+
+
+def _dry(extra, port):
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-ranks", "8", "--steps", "2", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_the_control_plane_of_gpus_8_runs_without_a_gpu():
+    """everything `bench.py --gpus 8` does around the engine -- the spawn of 8 ranks, the gloo rendezvous, the id
+    exchange, the planner over the request vectors of every update, the max over ranks and the per-rank JSON assembly -- at world 8,
+    which no GPU test of this pool can reach (process guard: 6).  Balanced set: 72 simulations per rank, no state moves."""
+    out = _dry([], 0)
+    assert out["dry_run"] is True and out["value"] is None and out["n_gpus"] == 8
+    pr = out["config"]["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8)) and all(r["sims"] == 72 for r in pr)
+    assert out["config"]["state_migrations"] == 0 and out["config"]["sims_on_rank0"] == 72
+
+
+def test_the_ragged_strain_set_is_levelled_over_8_ranks_in_the_dry_run():
+    """the imbalanced set (nts 10..100): the planner levels MD steps, so simulations per rank differ and states move between updates"""
+    out = _dry(["--strain-set", "imbalanced"], 1)
+    sims = [r["sims"] for r in out["config"]["per_rank"]]
+    assert sum(sims) == 576 and max(sims) - min(sims) >= 1 and min(sims) > 40
+    assert out["config"]["state_migrations"] >= 1

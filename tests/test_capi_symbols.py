@@ -52,3 +52,17 @@ def test_no_gpu_means_loud_failure():
     from scema_amd import capi
     with pytest.raises(capi.EngineError):
         capi.Engine()
+
+
+def test_every_environment_switch_the_sources_read_is_declared():
+    """md_env.h: an undeclared name passed to scema_env() aborts the process the first time that line runs -- which may be on the
+    GPU box only.  Every literal name in the sources must be in the table of engine_core.cpp, and every table entry must be read."""
+    import glob
+    src = os.path.join(ROOT, "scema_amd", "csrc")
+    table = set(re.findall(r'^\s*\{"(SCEMA_[A-Z0-9_]+)",', open(os.path.join(src, "engine", "engine_core.cpp")).read(), flags=re.M))
+    used = set()
+    for f in glob.glob(os.path.join(src, "**", "*"), recursive=True):
+        if f.endswith((".cpp", ".hip", ".h")) and "_obj" not in f:
+            used |= set(re.findall(r'scema_env\("(SCEMA_[A-Z0-9_]+)"\)', open(f).read()))
+    assert used <= table, used - table
+    assert table <= used, table - used

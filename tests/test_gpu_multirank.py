@@ -284,3 +284,73 @@ def test_collective_edge_cases_one_owner_one_failure_one_mismatch(tmp_path, smal
         assert "different plans" in str(got[k]["mismatch_msg"]), str(got[k]["mismatch_msg"])
         assert got[k]["stats"][0] == 4 and got[k]["stats"][1] == 5       # stress all-gathers: 4 updates got that far; handshakes: all 5
     assert "rank 1 failed" in str(got[0]["fail_msg"])
+
+
+WORKER_ALLOC = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+from scema_amd import capi, comm
+from scema_amd.systems import build_pe
+from test_gpu_multirank import KW, sequence
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+d = build_pe(2, 3, 5, jitter=0.05, seed=7)
+d["box"][6:9] = [0.7, -0.4, 0.5]
+eng = capi.Engine(capi.default_params(**KW))
+comm.attach_gloo(eng, rank, world)
+eng.register_replica("pe", 1, d)
+lens = d["box"][3:6] - d["box"][:3]
+u1, u2, _ = sequence(lens)
+def run(u):
+    qps, recent, strains = u
+    arr = eng.strain_batch([capi.make_sim(q, "pe", 1, s, nss=10, most_recent=r) for q, r, s in zip(qps, recent, strains)], rank=rank, world=world)
+    return np.array([list(a.stress) for a in arr])
+log = {"u1": run(u1)}
+# the ragged second update moves a state; the rank that receives it cannot allocate it (injected): EVERY rank must get the error,
+# before anything was sent, and nobody may be left inside the exchange or the collective
+os.environ["SCEMA_MD_TEST_FAIL_INCOMING"] = "-1"
+try:
+    run(u2)
+    log["msg"] = "no error"
+except capi.EngineError as exc:
+    log["msg"] = str(exc); log["code"] = exc.code if hasattr(exc, "code") else -1
+del os.environ["SCEMA_MD_TEST_FAIL_INCOMING"]
+st = eng.comm_stats()
+log["stats_after_failure"] = np.array([st["allgathers"], st["handshakes"], st["migrations"]])
+log["owners_after_failure"] = np.array([eng.state_owner(q, "pe", 1) for q in range(6)])
+# the same update again: it runs, moves the state, and equals the single-rank run
+log["u2"] = run(u2)
+st = eng.comm_stats()
+log["stats"] = np.array([st["allgathers"], st["handshakes"], st["migrations"]])
+np.savez(sys.argv[2] + f".{rank}.npz", **log)
+dist.barrier(); eng.close(); dist.destroy_process_group()
+'''
+
+
+def test_a_rank_that_cannot_take_a_migrating_state_fails_the_update_on_every_rank(tmp_path, small_pe):
+    """VERDICT r4: the states that migrate in are allocated BEFORE the handshake, so the receiving rank's allocation failure travels in
+    its status word: both ranks end the call with the same error, nothing was sent, the directory is unchanged and the retry works."""
+    from scema_amd import capi
+    (tmp_path / "worker.py").write_text(WORKER_ALLOC)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29583", str(tmp_path / "worker.py"), ROOT, str(tmp_path / "out")]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = [np.load(str(tmp_path / "out") + f".{k}.npz") for k in range(2)]
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    ref = run_sequence(eng, lens)
+    eng.close()
+    msgs = [str(g["msg"]) for g in got]
+    assert all(m != "no error" for m in msgs), msgs
+    # one rank reports its own injected failure, the other hears of it through the handshake
+    assert sum("injected" in m for m in msgs) == 1 and sum("before the update started" in m for m in msgs) == 1, msgs
+    for k in range(2):
+        assert list(got[k]["stats_after_failure"]) == [1, 2, 0]          # the failed update: a handshake, no exchange, no stress collective
+        assert list(got[k]["owners_after_failure"]) == [0, 1, 0, 1, 0, 1]  # the directory of the first update stands
+        assert got[k]["stats"][2] >= 1                                     # the retry moved the state
+        for u, name in enumerate(("u1", "u2")):
+            assert np.abs(got[k][name] - ref[u]).max() < 1e-8 * np.abs(ref[u]).max(), (k, name)
