@@ -372,6 +372,14 @@ int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t rese
  * and their number: a reported run shows an empty list (bench.py: config.env_overrides). */
 int scema_md_env_overrides(char *buf, int cap);
 
+/* The k-space set-up a run would use for this box, as a pure host function (no GPU, no engine): LAMMPS' initial g_ewald estimate
+ * from the accuracy asked for (what `kspace_style ewald` keeps), and for kspace_style 1 the PPPM grid and the adjusted g_ewald by
+ * PPPM::set_grid_global / adjust_gewald as restated in engine/engine_kspace.cpp (in.set.lammps:36 `kspace_style pppm 0.0001`).
+ * grid = 0 0 0 for the Ewald sum or an uncharged system.  For checks against an independent restatement of those rules
+ * (tests/test_oracle_pppm.py) and against LAMMPS' own log line "G vector ... grid = ..." (tools/export_lammps_case.py --run). */
+int scema_md_kspace_setup(const scema_md_params *p, const double *box /* 9: lo[3] hi[3] xy xz yz */, double qsqsum /* sum q_i^2, e^2 */,
+                          int32_t natoms, double *g_initial, double *g_ewald, int32_t *grid /* 3 */);
+
 #ifdef __cplusplus
 }
 #endif

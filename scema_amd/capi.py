@@ -34,7 +34,7 @@ SYMBOLS = [
     "scema_md_init_material", "scema_md_debug_compute", "scema_md_debug_run", "scema_md_get_profile", "scema_md_env_overrides",
     "scema_md_comm_unique_id", "scema_md_comm_init_rccl", "scema_md_comm_init_host", "scema_md_comm_destroy",
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_comm_handshakes", "scema_md_state_owner", "scema_md_last_plan",
-    "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update",
+    "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update", "scema_md_kspace_setup",
     "scema_md_save_state_dump", "scema_md_replica_natoms", "scema_md_save_replica_file", "scema_md_equilibrate", "scema_md_debug_minimize", "scema_md_debug_run_nh",
     "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_concurrency", "scema_md_reax_debug_compute", "scema_md_reax_stats",
 ]
@@ -478,6 +478,19 @@ def env_overrides() -> list:
     lib().scema_md_env_overrides.restype = C.c_int
     n = lib().scema_md_env_overrides(buf, C.c_int(len(buf)))
     return [l for l in buf.value.decode().split("\n") if l] if n else []
+
+
+def kspace_setup(params, box, qsqsum: float, natoms: int):
+    """(g_initial, g_ewald, grid) a run would use for this box: scema_md_kspace_setup, a pure host function (no GPU)"""
+    L = lib()
+    L.scema_md_kspace_setup.restype = C.c_int
+    b = np.ascontiguousarray(box, np.float64)
+    g0, g1 = C.c_double(0.0), C.c_double(0.0)
+    grid = (C.c_int32 * 3)()
+    rc = L.scema_md_kspace_setup(C.byref(params), _p(b), C.c_double(qsqsum), C.c_int32(natoms), C.byref(g0), C.byref(g1), grid)
+    if rc != 0:
+        raise EngineError(f"scema_md_kspace_setup rc={rc}")
+    return g0.value, g1.value, tuple(grid)
 
 
 def make_sim(qp_id: int, matid: str, replica: int, strain_len, *, most_recent: int | None = None, material: int = 0,

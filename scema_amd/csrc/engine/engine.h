@@ -155,8 +155,16 @@ struct RxSlot {
   DevBuf nb_cnt, nb, nbT, hval, hcol, hlen, hown, hownlen, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
 };
 
+// what the neighbour rows of a slot were built for: a run that follows on the same slot keeps them if all of it still holds
+struct ListSig {
+  bool valid = false;
+  const void *topo = nullptr;
+  int nc[3] = {0, 0, 0}, capj = 0, maxneigh = 0, npad = 0;
+  double rlist = 0.0, cut_lj = 0.0, cut_coul = 0.0;
+};
 struct Slot {
   std::unique_ptr<RxSlot> rx;
+  ListSig sig;
   int cap_atoms = 0, cap_pad = 0, cap_neigh = 0, cap_cells = 0, cap_k = 0;
   size_t cap_jtab = 0;
   DevBuf virp, virb, fb, fs, slot_of, tile_nj, tile_jtab, tile_order, tile_wstart;
@@ -246,6 +254,8 @@ struct RunSpec {
   std::vector<EwaldSetup> *ew_keep = nullptr;   // k-space setup of the run's first segment, reused by the later ones
   int minimize = 0, min_maxiter = 0, min_maxeval = 0;
   double min_etol = 0, min_ftol = 0;
+  int keep_list = 0;      // this run follows another one of the same simulations on the same slots (phase B after phase A): the neighbour rows on the
+                          // device stand where the cell grid of the new run can be the old one (SimDev::keep_list)
   int qeq_continue = 0;   // ReaxFF: this run follows another one of the same simulations on the same slots (phase B after phase A): the
                           // charge-equilibration history is still in place
 };

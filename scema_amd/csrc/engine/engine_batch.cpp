@@ -92,6 +92,7 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
       RunSpec B;
       B.sample = 1;
       B.use_shake = opt.shake_b;
+      B.keep_list = opt.phase_a ? 1 : 0;      // ... and so are the cell grids and neighbour rows (run_phase keeps them where the grid can stay)
       B.qeq_continue = opt.phase_a ? 1 : 0;   // same simulations, same slots: the ReaxFF solver history of phase A is in place
       for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nss;
       rc = run_phase(e, chunk, B);

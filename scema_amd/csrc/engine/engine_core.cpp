@@ -48,6 +48,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_SPLIT_MAX", "launch groups of this many replicas and more run whole instead of as two half batches (default: none)"},
     {"SCEMA_MD_SPLIT", "0: never run a launch group of 32 simulations and more as two half batches on two streams"},
     {"SCEMA_MD_ONE_STREAM", "no side stream (bonded / k-space chain beside the pair kernel)"},
+    {"SCEMA_MD_KEEP_LIST", "0: the sampling run of an evaluation rebuilds its neighbour rows at its start even where those of the straining run still hold"},
     {"SCEMA_MD_SKIN_EXTRA", "list skin = params.skin + this many Angstrom (results do not depend on it)"},
     {"SCEMA_MD_SKIN_ADAPT", "1: per-state adaptation of the extra skin from the rebuild interval (round-1 behaviour)"},
     {"SCEMA_MD_PPPM_FFT", "hipFFT for every PPPM grid (default: grids of up to 2 900 points are solved in LDS)"},

@@ -375,3 +375,24 @@ double round_trip(const char *fmt, double v) {
 }
 
 }  // namespace scema_eng
+
+// ---- the k-space set-up as a pure host function of the C ABI (no GPU, no engine): what a run would use for this box ----
+// The parity tests compare the engine with the C oracle, whose PPPM set-up was written by the same hand as pppm_setup_host above;
+// this entry lets a line-by-line Python restatement of PPPM::set_grid_global / adjust_gewald (tests/test_oracle_pppm.py) check the
+// PRODUCT's answer directly (the chain product -> C oracle -> Python was circular in its 43 shared lines).
+extern "C" int scema_md_kspace_setup(const scema_md_params *p, const double *box, double qsqsum, int32_t natoms, double *g_initial,
+                                     double *g_ewald, int32_t *grid) {
+  if (!p || !box || natoms <= 0 || !(qsqsum >= 0.0)) return SCEMA_MD_ERR_ARG;
+  scema_eng::Topo t;
+  t.natoms = natoms;
+  t.qsqsum = qsqsum;
+  scema_eng::EwaldSetup ew;
+  scema_eng::ewald_setup(*p, t, box, ew, true);   // LAMMPS' initial estimate (the Ewald sum keeps it)
+  if (g_initial) *g_initial = ew.g;
+  double g = ew.g;
+  int pg[3] = {0, 0, 0};
+  if (p->kspace_style == 1 && qsqsum > 0.0) scema_eng::pppm_setup_host(*p, t, box, g, pg);
+  if (g_ewald) *g_ewald = g;
+  if (grid) { grid[0] = pg[0]; grid[1] = pg[1]; grid[2] = pg[2]; }
+  return SCEMA_MD_OK;
+}

@@ -267,9 +267,27 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       // row capacity of one i-cluster: the union of 4 half neighbour spheres whose centres are within a cell, plus
       // headroom; regrown on overflow
       mn_out = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.25 * e->neigh_grow) + 128;
-      mn_out = (std::min(mn_out, cj_out) + 63) / 64 * 64;
+      mn_out = (std::min(mn_out, cj_out) + 63) / 64 * 64 + 64;   // (+ 64: the last 64 words of a row's capacity are k_neigh_build's dump zone, md_pair.hip)
       return cj_out <= MD_MAXJTAB && mdk_pair_lds_bytes(cj_out) <= 74 * 1024 && mdk_neigh_lds_bytes(cj_out, mn_out) <= 150 * 1024;
     };
+    // A run that follows another one on the same slot (the sampling run of an evaluation behind its straining run) keeps that run's
+    // cell grid where it is a valid one for the new box, and with it the neighbour rows on the device: one list build in seven of an
+    // evaluation less.  (Capacities are strides of the stored tables: they stay what they were.)
+    static const bool keep_lists = !(scema_env("SCEMA_MD_KEEP_LIST") && atoi(scema_env("SCEMA_MD_KEEP_LIST")) == 0);
+    bool keep = false;
+    {
+      const ListSig &g = e->slots[i]->sig;
+      if (spec.keep_list && keep_lists && g.valid && g.topo == (const void *)&T && g.rlist == rlist && g.cut_lj == P.cut_lj && g.cut_coul == P.cut_coul &&
+          !hsc.force_rebuild && !hsc.overflow) {
+        int mst[3], cj = 0, mn = 0;
+        if (size_grid(g.nc, mst, cj, mn) && cj <= g.capj && mn <= g.maxneigh && padded_slots(T.natoms, g.nc[0] * g.nc[1] * g.nc[2]) == g.npad) {
+          keep = fits = true;
+          capj = g.capj; maxneigh = g.maxneigh;
+          for (int d = 0; d < 3; d++) { S.nc[d] = g.nc[d]; S.mst[d] = mst[d]; }
+        }
+      }
+    }
+    S.keep_list = keep ? 1 : 0;
     // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
     // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
     const bool small_batch = ns <= 8;   // replicas up to which the most-cells grid is taken (scanned in round 2: tools/small_batch_scan.sh)
@@ -344,6 +362,14 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (rc) return rc;
     S.maxneigh = maxneigh;
     S.capj = capj;
+    {
+      ListSig &g = sl.sig;   // what this run's rows are built for; valid once the run has ended without a fault
+      g.valid = false;
+      g.topo = (const void *)&T;
+      for (int d = 0; d < 3; d++) g.nc[d] = S.nc[d];
+      g.capj = capj; g.maxneigh = maxneigh; g.npad = S.npad;
+      g.rlist = rlist; g.cut_lj = P.cut_lj; g.cut_coul = P.cut_coul;
+    }
     maxrow = std::max(maxrow, maxneigh);
     maxcapj = std::max(maxcapj, capj);
     S.nbonds = T.nbonds; S.nbonds_noshake = T.nbonds_noshake; S.nangles = T.nangles; S.ndihedrals = T.ndihedrals;
@@ -797,6 +823,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       fprintf(stderr, "[scema_md] k_neigh_build wave clocks (sim 0, mean per wave and build): table %.0f (boxes and runs %.0f, candidates %.0f), rows %.0f, schedule %.0f; %llu waves of %.0f; %.2f rows per wave of %.1f chunks\n",
               (double)c.dbg[5] / nw, (double)c.dbg[8] / nw, (double)(c.dbg[5] - c.dbg[8]) / nw, (double)c.dbg[6] / nw, (double)c.dbg[7] / nw, c.dbg[9], nw,
               (double)c.dbg[11] / nw, (double)c.dbg[10] / std::max(1ull, c.dbg[11]));
+      const double nr = (double)std::max(1ull, c.dbg[11]);
+      fprintf(stderr, "[scema_md] k_neigh_build per row (sim 0, cycles): set-up %.0f, chunk loop %.0f = %.0f per chunk, row end %.0f; of %.1f chunks %.2f walk exclusion lists, %.2f are own-cell chunks\n",
+              (double)c.dbg[12] / nr, (double)c.dbg[13] / nr, (double)c.dbg[13] / std::max(1ull, c.dbg[10]), (double)c.dbg[14] / nr, (double)c.dbg[10] / nr,
+              (double)c.dbg[15] / nr, (double)c.dbg[16] / nr);
     }
 #endif
   }
@@ -812,6 +842,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   e->overflow_bits = fault;
   if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
   if (fault & 64) return SCEMA_MD_ERR_OVERFLOW;   // the barostat took the box out of the range this segment was laid out for
+  for (int i = 0; i < ns; i++) e->slots[i]->sig.valid = true;   // the rows on the device hold for the positions this run ended at
   return SCEMA_MD_OK;
 }
 

@@ -43,16 +43,22 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.vscale = 1.0;
     sc.nsamples = 0;
     sc.step = 0;
-    sc.ago = 0;
+    // A LAMMPS run begins with a list build (Verlet::setup), and so does a run here -- unless it continues one that has just ended on
+    // this slot with the same cell grid (the sampling run behind the straining run of an evaluation): positions and box are those of
+    // the last force evaluation, for which the rows on the device were checked, so they stand, with their age and reference positions.
+    // The far band is walked in the set-up evaluation (what moved since the build is only looked at from step 1 on).  A box flip that
+    // is still pending forces the build as it would between two steps.  Results do not depend on when a list is built.
+    const int keep = S.keep_list && !sc.force_rebuild;
+    if (!keep) sc.ago = 0;
     sc.check = 1;
-    sc.rebuild = 1;
+    sc.rebuild = keep ? 0 : 1;
     sc.force_rebuild = 0;
     sc.deltasq = 0.0;
     sc.far_dsq = 1.0e300;
-    sc.need_far = 0;
+    sc.need_far = keep ? 1 : 0;
     sc.nfar_steps = 0;
 #if defined(PAIR_TIMING) || defined(PAIR_COUNT)
-    for (int k = 0; k < 12; k++) sc.dbg[k] = 0;
+    for (int k = 0; k < 20; k++) sc.dbg[k] = 0;
     for (int k = 0; k < 8; k++) sc.dbg2[k] = 0;
 #endif
   }

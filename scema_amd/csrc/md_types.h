@@ -89,7 +89,7 @@ struct SimScalars {
   double min_alpha, min_alphamax, min_fdothall, min_eorig, min_eprev, min_fhprev, min_engprev, min_alphaprev, min_fh_trial, min_ecur, min_einit;
   double min_dots[4];  // f.h, f.f, max |f| of the last evaluation (+ spare)
 #if defined(PAIR_TIMING) || defined(PAIR_COUNT)
-  unsigned long long dbg[12];
+  unsigned long long dbg[20];   // [12..17]: k_neigh_build per row: set-up, chunk loop, row end (cycles); chunks through the exclusion walk, own-cell chunks, chunks
   unsigned long long dbg2[8];   // k_pppm_solve phase clocks
 #endif
 };
@@ -132,7 +132,8 @@ struct SimDev {
   double coul_uscale;
   double coul_poly[MD_MAXPOLY];
   double coul_poly_g[MD_MAXPOLY];   // the same coefficients times g_ewald (k_pair)
-  int nfree, pad_free_;
+  int nfree;
+  int keep_list;            // this run continues one that has just ended on the same slot: its cell grid and neighbour rows stand (k_phase_init)
   double rlist_ref2;      // (cutoff + the reference's skin)^2: pairs inside it are what the roofline accounting prices
   double seg_a2, seg_b2;  // row segments by build-time distance: (cut_coul+m)^2, (cut_lj+m)^2
   double far_band;        // width (A) of the near skin band C1

@@ -130,3 +130,81 @@ def test_grid_follows_set_grid_global(small_pe, tilt, acc):
     assert op2.pppm_grid == op.pppm_grid
     # adjust_gewald stops at the first Newton iterate with |f| < 1e-5: the residual is small but not converged to round-off
     assert op.g_ewald != g0
+
+
+# ---- the PRODUCT's set-up (scema_md_kspace_setup: engine/engine_kspace.cpp, a pure host function of the C ABI) against the Python
+# restatement, with no C oracle in between (product and C oracle share a hand; this chain does not pass through it) ----
+def _initial_g(acc, rc, prd, q2, natoms):
+    """KSpace g_ewald estimate of pppm.cpp init(): accuracy*sqrt(N rc V)/(2 q2) -> sqrt(-log)/rc, or the fallback"""
+    t = acc * np.sqrt(natoms * rc * prd[0] * prd[1] * prd[2]) / (2.0 * q2)
+    return (1.35 - 0.15 * np.log(acc)) / rc if t >= 1.0 else np.sqrt(-np.log(t)) / rc
+
+
+def _adjust_gewald(box, grid, g, acc, rc, q2, natoms):
+    """PPPM::adjust_gewald / newton_raphson_f / compute_qopt-free ik branch of pppm.cpp (17Nov16), line by line: Newton steps on
+    f(g) = real-space error - k-space error with a forward difference of 1e-6, at most 10 000, stopped at the first iterate with
+    |f| < 1e-5; the grid spacings of a triclinic box are the reciprocals of x2lamdaT(n)."""
+    lo, hi, (xy, xz, yz) = box[:3], box[3:6], box[6:9]
+    prd = hi - lo
+    # h_inv of domain.cpp (triclinic): [1/xprd, 1/yprd, 1/zprd, -yz/(yprd zprd), (yz xy - yprd xz)/(xprd yprd zprd), -xy/(xprd yprd)]
+    hinv = [1.0 / prd[0], 1.0 / prd[1], 1.0 / prd[2], -yz / (prd[1] * prd[2]), (yz * xy - prd[1] * xz) / (prd[0] * prd[1] * prd[2]), -xy / (prd[0] * prd[1])]
+    # x2lamdaT(v) = (h_inv[0] v0, h_inv[5] v0 + h_inv[1] v1, h_inv[4] v0 + h_inv[3] v1 + h_inv[2] v2)
+    t = [hinv[0] * grid[0], hinv[5] * grid[0] + hinv[1] * grid[1], hinv[4] * grid[0] + hinv[3] * grid[1] + hinv[2] * grid[2]]
+    hs = [1.0 / t[0], 1.0 / t[1], 1.0 / t[2]]
+
+    def f(gg):
+        df_r = 2.0 * q2 * np.exp(-gg * gg * rc * rc) / np.sqrt(natoms * rc * prd[0] * prd[1] * prd[2])
+        e = [_estimate_ik_error(hs[d], prd[d], gg, q2, natoms) for d in range(3)]
+        return df_r - np.sqrt(e[0] ** 2 + e[1] ** 2 + e[2] ** 2) / np.sqrt(3.0)
+
+    for _ in range(10000):
+        dx = 0.000001
+        f1, f2 = f(g), f(g + dx)
+        g -= f1 / ((f2 - f1) / dx)
+        if abs(f(g)) < 0.00001:
+            break
+    return g
+
+
+@pytest.mark.parametrize("tilt", [(0.0, 0.0, 0.0), (0.7, -0.4, 0.5), (-0.7, 0.4, -0.5), (3.0, 0.0, 0.0)])
+@pytest.mark.parametrize("acc", [1e-4, 1e-5])
+def test_the_products_pppm_setup_follows_the_python_restatement(small_pe, tilt, acc):
+    from copy import deepcopy
+    from scema_amd import capi
+    d = deepcopy(small_pe)
+    d["box"][6:9] = tilt
+    box = np.asarray(d["box"], float)
+    qsq = float((np.asarray(d["charge"]) ** 2).sum())
+    q2 = qsq * 332.06371
+    P = capi.default_params(kspace_accuracy=acc, **KW)
+    g0, g1, grid = capi.kspace_setup(P, box, qsq, d["natoms"])
+    a = acc * 332.06371
+    g0_py = _initial_g(a, KW["cut_coul"], box[3:6] - box[:3], q2, d["natoms"])
+    assert abs(g0 - g0_py) < 1e-14 * g0_py
+    grid_py = _set_grid_global(box, g0_py, a, q2, d["natoms"])
+    assert grid == grid_py, (grid, grid_py)
+    g1_py = _adjust_gewald(box, grid_py, g0_py, a, KW["cut_coul"], q2, d["natoms"])
+    # (a Newton step with a 1e-6 forward difference multiplies the last bits of f by a million: 1e-9 is what two correct
+    # implementations in different arithmetic libraries agree to; a wrong rule is off in the second digit)
+    assert abs(g1 - g1_py) < 1e-9 * g1_py and g1 != g0
+    # the 13th-digit box gets the same grid from the product too
+    g0b, g1b, gridb = capi.kspace_setup(P, box * (1.0 + 3e-13), qsq, d["natoms"])
+    assert gridb == grid
+    # Ewald sum: the initial estimate stands, no grid; an uncharged system: nothing
+    assert capi.kspace_setup(capi.default_params(kspace_accuracy=acc, kspace_style=0, **KW), box, qsq, d["natoms"])[1:] == (g0, (0, 0, 0))
+    assert capi.kspace_setup(P, box, 0.0, d["natoms"]) == (0.0, 0.0, (0, 0, 0))
+
+
+def test_the_products_pppm_setup_at_the_reference_size():
+    """PE-10k at the reference's settings (12/9 A, 1e-4): the grid DESIGN.md quotes (12 x 12 x 10..12) is what both restatements give"""
+    from scema_amd import capi
+    from scema_amd.systems import build_pe
+    d = build_pe(6, 9, 16)
+    box = np.asarray(d["box"], float)
+    qsq = float((np.asarray(d["charge"]) ** 2).sum())
+    g0, g1, grid = capi.kspace_setup(capi.default_params(), box, qsq, d["natoms"])
+    a, q2 = 1e-4 * 332.06371, qsq * 332.06371
+    g0_py = _initial_g(a, 9.0, box[3:6] - box[:3], q2, d["natoms"])
+    grid_py = _set_grid_global(box, g0_py, a, q2, d["natoms"])
+    assert grid == grid_py and grid[0] == 12 and grid[1] == 12 and grid[2] in (10, 12)
+    assert abs(g1 - _adjust_gewald(box, grid_py, g0_py, a, 9.0, q2, d["natoms"])) < 1e-9 * g1 and 0.20 < g1 < 0.23

@@ -14,6 +14,13 @@ with the KSPACE, MOLECULE and RIGID packages (the reference pins 17Nov16, README
                                reset_timestep 0, locbe / nssample0, include ELASTIC/in.homogenization.lammps, print pp11..pp23
   <out>/case.json              strain (Angstrom-valued MDSim.strain), nts, rates, and -- when they can be computed here --
                                the stresses of the CPU oracle and of the GPU engine for the same request
+  <out>/static.lammps          the STATIC case: in.set.lammps, read_restart init.*, `run 0` with LAMMPS' per-style energies
+                               (pe evdwl ecoul elong ebond eangle edihed eimp), the six pressure components with and without the
+                               kinetic part, and a force dump -- once as the scripts stand (pair_modify table 12, the 17Nov16 default)
+  <out>/static_table0.lammps   ... and once with `pair_modify table 0` (analytic erfc, what the engine computes).  `--run` compares both
+                               term by term with scema_md_debug_compute and names the FIRST term that differs: a miss of the
+                               time-averaged stress then says whether the force field, the PPPM set-up, the erfc table or the
+                               dynamics (SHAKE, thermostat, fix deform) is where the two part ways.
 
 `--force-field reax` exports BASELINE config 5's case instead (lammps_scripts_reax: `atom_style charge` data file with types H C N O,
 `pair_style reax/c` + `fix qeq/reax 1 0.0 10.0 1e-6`, no SHAKE, no k-space; dt 0.25 fs): the state travels between the two LAMMPS
@@ -137,8 +144,9 @@ variable nssample  equal {nss}
 include {scripts}/ELASTIC/in.homogenization.lammps
 print "SCEMA_PP ${{pp11}} ${{pp22}} ${{pp33}} ${{pp12}} ${{pp13}} ${{pp23}}" file pp.out
 """)
+    static = export_static_reax(out, scripts, mat, rep, temperature)
     case = dict(force_field="reax", strain_len=[float(v) for v in strain_len], nts=nts, rates=rates, dt=dt, temperature=temperature, strain_rate=rate,
-                nss=nss, natoms=int(r["natoms"]), scripts=scripts,
+                nss=nss, natoms=int(r["natoms"]), scripts=scripts, static_inputs=static,
                 note="lammps_scripts_reax/ELASTIC/in.homogenization.lammps:61-62 is shipped with a line broken inside c_thermo_press[6] (SURVEY Appendix C 9): "
                      "join the two lines in a copy of the scripts before running")
     json.dump(case, open(os.path.join(out, "case.json"), "w"), indent=1)
@@ -191,8 +199,11 @@ def verify_reax(out, r, strain_len, scripts, lmp=None, **kw):
         errs = {k: float(np.abs(np.array(res[k]) - s).max() / np.abs(s).max()) for k in ("oracle", "gpu_exact", "gpu_drop_dsbo2") if res[k] is not None}
         res["rel_err_vs_lammps"] = errs
         closer = min((k for k in ("gpu_exact", "gpu_drop_dsbo2") if k in errs), key=lambda k: errs[k], default=None)
+        res["static"] = run_static_reax(lmp, out, r, scripts)
+        firsts = {k: v.get("first_term_that_differs") for k, v in (res["static"] or {}).items() if isinstance(v, dict)}
         res["verdict"] = ("LAMMPS-verified: " + ", ".join(f"{k} max rel err {v:.3e}" for k, v in errs.items()) + f" ({lmp})" +
-                          (f"; the reference's valence-angle gradient is the '{closer}' variant" if closer else ""))
+                          (f"; the reference's valence-angle gradient is the '{closer}' variant" if closer else "") +
+                          f"; static case, first term that differs: {firsts}")
     json.dump(res, open(os.path.join(out, "verdict.json"), "w"), indent=1)
     return res
 
@@ -244,10 +255,206 @@ variable nssample  equal {nss}
 include {scripts}/ELASTIC/in.homogenization.lammps
 print "SCEMA_PP ${{pp11}} ${{pp22}} ${{pp33}} ${{pp12}} ${{pp13}} ${{pp23}}" file pp.out
 """)
+    static = export_static(out, scripts, mat, rep, temperature)
     case = dict(strain_len=[float(v) for v in strain_len], nts=nts, rates=rates, dt=dt, temperature=temperature, strain_rate=rate, nss=nss,
-                natoms=int(d["natoms"]), scripts=scripts)
+                natoms=int(d["natoms"]), scripts=scripts, static_inputs=static)
     json.dump(case, open(os.path.join(out, "case.json"), "w"), indent=1)
     return case
+
+
+# ---- the static case: one force evaluation, term by term (SURVEY 7 (iii); lammps_scripts_opls/in.set.lammps:36,42) ----
+STATIC_TERMS = ["ebond", "eangle", "edihed", "eimp", "evdwl", "ecoul", "elong", "pe"]
+STATIC_PRESS = ["pxx", "pyy", "pzz", "pxy", "pxz", "pyz"]
+
+
+def export_static(out, scripts, mat="g0", rep=1, temperature=300.0):
+    """static.lammps / static_table0.lammps: the reference's settings (in.set.lammps by path), the init restart, `run 0`"""
+    state = f"{mat}_{rep}"
+    cols = " ".join(STATIC_TERMS) + " " + " ".join(STATIC_PRESS) + " " + " ".join(f"c_vir[{k}]" for k in range(1, 7))
+    prn = " ".join(f"$({t})" for t in STATIC_TERMS) + " " + " ".join(f"$({t})" for t in STATIC_PRESS) + " " + " ".join(f"$(c_vir[{k}])" for k in range(1, 7))
+    for tag, extra in (("static", ""), ("static_table0", "pair_modify table 0   # analytic erfc instead of the 4096-entry table (after read_restart: the file carries the table bits)\n")):
+        with open(os.path.join(out, tag + ".lammps"), "w") as f:
+            f.write(f"""# one force evaluation of init.{state}.bin under the reference's settings, LAMMPS' own terms printed (no fix: no SHAKE force, no thermostat)
+variable mdt string {mat}
+variable locs string {scripts}
+variable tempt equal {temperature:f}
+include {scripts}/in.set.lammps
+read_restart init.{state}.bin
+{extra}compute vir all pressure NULL virial
+thermo_style custom step {cols}
+thermo_modify format float %.15g
+run 0
+print "SCEMA_STATIC {prn}" file {tag}.out
+write_dump all custom {tag}.forces id fx fy fz modify sort id format float %.15g
+""")
+    return ["static.lammps", "static_table0.lammps"]
+
+
+def export_static_reax(out, scripts, mat="g0", rep=1, temperature=300.0):
+    """the ReaxFF static case: per-term energies of `compute pair reax/c` (c_reax[1..14]: eb ea elp emol ev epen ecoa ehb et eco ew ep efi eqeq),
+    the charges fix qeq/reax settles on (lammps_scripts_reax/in.strain.lammps:12), virial pressure, forces"""
+    state = f"{mat}_{rep}"
+    cols = "pe " + " ".join(f"c_reax[{k}]" for k in range(1, 15)) + " " + " ".join(f"c_vir[{k}]" for k in range(1, 7))
+    prn = "$(pe) " + " ".join(f"$(c_reax[{k}])" for k in range(1, 15)) + " " + " ".join(f"$(c_vir[{k}])" for k in range(1, 7))
+    with open(os.path.join(out, "static.lammps"), "w") as f:
+        f.write(f"""# one force evaluation of init.{state}.bin with pair reax/c + fix qeq/reax as the reference's scripts set them
+variable mdt string {mat}
+variable locs string {scripts}
+variable tempt equal {temperature:f}
+include {scripts}/in.set.lammps
+read_restart init.{state}.bin
+pair_style reax/c NULL safezone 50.0 mincap 100000
+pair_coeff * * {scripts}/ffield.reax.2 H C N O
+fix qeq all qeq/reax 1 0.0 10.0 1e-6 reax/c
+compute reax all pair reax/c
+compute vir all pressure NULL virial
+thermo_style custom step {cols}
+thermo_modify format float %.15g
+run 0
+print "SCEMA_STATIC {prn}" file static.out
+write_dump all custom static.forces id q fx fy fz modify sort id format float %.15g
+""")
+    return ["static.lammps"]
+
+
+def read_static(out, tag, ncol_dump=3):
+    """-> (numbers of the SCEMA_STATIC line, per-atom array of the dump sorted by id)"""
+    vals = [float(v) for v in open(os.path.join(out, tag + ".out")).read().split()[1:]]
+    rows, on = [], False
+    for line in open(os.path.join(out, tag + ".forces")):
+        if line.startswith("ITEM: ATOMS"):
+            on = True
+        elif line.startswith("ITEM:"):
+            on = False
+        elif on:
+            rows.append([float(v) for v in line.split()[1:1 + ncol_dump]])
+    return vals, np.array(rows)
+
+
+def static_ours(d):
+    """the same terms from the engine's parity hook (scema_md_debug_compute on the registered init state): kcal/mol, atm, kcal/mol/A"""
+    import torch
+    if not torch.cuda.is_available():
+        return None
+    from scema_amd import capi
+    e = capi.Engine()
+    e.register_replica("g0", 1, d)
+    f, en, w, info = e.debug_compute("g0", 1)
+    e.close()
+    b = np.asarray(d["box"], float)
+    vol = float(np.prod(b[3:6] - b[:3]))
+    m = np.asarray(d["mass"])[np.asarray(d["type"])]
+    v = np.asarray(d["v"])
+    mvv2e, nktv2p = 48.88821291 ** 2, 68568.415
+    ke = np.array([(m * v[:, a] * v[:, c]).sum() * mvv2e for a, c in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))])
+    wsum = w.sum(0)   # every part: pair, bonded, k-space (no SHAKE in a static evaluation)
+    terms = dict(ebond=en[2], eangle=en[3], edihed=en[4], eimp=en[5], evdwl=en[0], ecoul=en[1], elong=en[6], pe=float(en[:7].sum()))
+    press = dict(zip(STATIC_PRESS, (ke + wsum) / vol * nktv2p))
+    vir = dict(zip([f"c_vir[{k}]" for k in range(1, 7)], wsum / vol * nktv2p))
+    return dict(terms=terms, press=press, vir=vir, forces=f, g_ewald=info["g_ewald"])
+
+
+def compare_static(lmp_vals, lmp_forces, mine, tol):
+    """term by term, in the order a difference would propagate (bonded terms, pair terms, k-space, sums, virial, forces): -> rows and
+    the name of the first term whose relative difference exceeds tol (None: all agree)"""
+    names = STATIC_TERMS + STATIC_PRESS + [f"c_vir[{k}]" for k in range(1, 7)]
+    L = dict(zip(names, lmp_vals))
+    ours = dict(mine["terms"]); ours.update(mine["press"]); ours.update(mine["vir"])
+    rows, first = [], None
+    scale_e = max(abs(L["pe"]), 1e-12)
+    scale_p = max(max(abs(L[k]) for k in STATIC_PRESS), 1e-12)
+    for n in names:
+        ref = scale_e if n in STATIC_TERMS else scale_p   # relative to the total: a term that is zero in both is not "different"
+        rel = abs(L[n] - ours[n]) / max(abs(L[n]), 1e-3 * ref)
+        rows.append((n, L[n], float(ours[n]), float(rel)))
+        if first is None and rel > tol:
+            first = n
+    ff = np.abs(lmp_forces - mine["forces"]).max() / np.abs(lmp_forces).max()
+    rows.append(("forces (max over atoms / max |f|)", float(np.abs(lmp_forces).max()), float(np.abs(mine["forces"]).max()), float(ff)))
+    if first is None and ff > tol:
+        first = "forces"
+    return rows, first
+
+
+def run_static(lmp, out, d, scripts):
+    """run both static inputs and compare: as the scripts stand the erfc table limits the agreement to ~1e-6, with table 0 the
+    force field must agree to ~1e-9 and what is left is the PPPM set-up"""
+    mine = static_ours(d)
+    if mine is None:
+        return None
+    res = {}
+    for tag, tol in (("static", 1e-5), ("static_table0", 1e-7)):
+        r = subprocess.run([lmp, "-in", tag + ".lammps", "-log", tag + ".log", "-screen", "none"], cwd=out)
+        if r.returncode != 0:
+            res[tag] = dict(error=f"{lmp} -in {tag}.lammps failed (rc={r.returncode})")
+            continue
+        vals, forces = read_static(out, tag)
+        rows, first = compare_static(vals, forces, mine, tol)
+        res[tag] = dict(tolerance=tol, first_term_that_differs=first, rows=rows, pppm_lammps=pppm_from_log(os.path.join(out, tag + ".log")))
+    return res
+
+
+REAX_TERMS = ["eb", "ea", "elp", "emol", "ev", "epen", "ecoa", "ehb", "et", "eco", "ew", "ep", "efi", "eqeq"]   # compute pair reax/c, c_reax[1..14]
+
+
+def static_ours_reax(r, scripts, exact):
+    """the engine's static ReaxFF evaluation in LAMMPS' term order (scema_md_reax_debug_compute: bond, lone pair, over, under, angle,
+    penalty, 3-body conj., torsion, 4-body conj., hydrogen bond, van der Waals, Coulomb, polarisation)"""
+    import torch
+    if not torch.cuda.is_available():
+        return None
+    from scema_amd import capi
+    ff = os.path.join(scripts, "ffield.reax.2")
+    if not os.path.exists(ff):
+        ff = os.path.join(ROOT, "examples", "ffield.reax.2")
+    e = capi.Engine()
+    e.reax_configure(ff, qeq_tol=1e-6)
+    e.reax_set(exact_gradient=exact)
+    e.register_replica("g0", 1, capi.reax_system(r["sym"], r["x"], r["box"], v=r["v"]))
+    c = e.reax_compute("g0", 1)
+    e.close()
+    ep = list(c["e"].values())   # in the order of the C ABI's eparts[13]
+    b = np.asarray(r["box"], float)
+    vol = float(np.prod(b[3:6] - b[:3]))
+    t = dict(eb=ep[0], elp=ep[1], ea=ep[2] + ep[3], emol=0.0, ev=ep[4], epen=ep[5], ecoa=ep[6], et=ep[7], eco=ep[8], ehb=ep[9], ew=ep[10], ep=ep[11],
+             efi=0.0, eqeq=ep[12])
+    return dict(terms=t, pe=float(np.sum(ep)), vir=np.asarray(c["w"]) / vol * 68568.415, q=np.asarray(c["q"]), forces=np.asarray(c["f"]))
+
+
+def run_static_reax(lmp, out, r, scripts, tol=1e-6):
+    """the ReaxFF static case against both gradient variants of the engine: energies and charges do not depend on the variant, forces and
+    virial do -- the first place where 'exact' and 'drop dSBO2' can be told apart without any dynamics"""
+    rr = subprocess.run([lmp, "-in", "static.lammps", "-log", "static.log", "-screen", "none"], cwd=out)
+    if rr.returncode != 0:
+        return dict(error=f"{lmp} -in static.lammps failed (rc={rr.returncode})")
+    vals, per_atom = read_static(out, "static", ncol_dump=4)
+    L = dict(zip(["pe"] + REAX_TERMS + [f"c_vir[{k}]" for k in range(1, 7)], vals))
+    res = {}
+    for key, exact in (("gpu_exact", 1), ("gpu_drop_dsbo2", 0)):
+        mine = static_ours_reax(r, scripts, exact)
+        if mine is None:
+            return None
+        rows, first = [], None
+        scale = max(abs(L["pe"]), 1e-12)
+        for n in REAX_TERMS + ["pe"]:
+            o = mine["pe"] if n == "pe" else mine["terms"][n]
+            rel = abs(L[n] - o) / max(abs(L[n]), 1e-3 * scale)
+            rows.append((n, L[n], float(o), float(rel)))
+            if first is None and rel > tol:
+                first = n
+        dq = float(np.abs(per_atom[:, 0] - mine["q"]).max())
+        rows.append(("charges (max |dq|, e)", float(np.abs(per_atom[:, 0]).max()), float(np.abs(mine["q"]).max()), dq))
+        if first is None and dq > 1e-5:   # the solver's tolerance is 1e-6 on the residual norm
+            first = "charges"
+        pv = np.array([L[f"c_vir[{k}]"] for k in range(1, 7)])
+        rv = float(np.abs(pv - mine["vir"]).max() / np.abs(pv).max())
+        rows.append(("virial pressure (max rel of 6)", float(np.abs(pv).max()), float(np.abs(mine["vir"]).max()), rv))
+        ff = float(np.abs(per_atom[:, 1:4] - mine["forces"]).max() / np.abs(per_atom[:, 1:4]).max())
+        rows.append(("forces (max over atoms / max |f|)", float(np.abs(per_atom[:, 1:4]).max()), float(np.abs(mine["forces"]).max()), ff))
+        if first is None and max(rv, ff) > 1e-5:
+            first = "forces / virial"
+        res[key] = dict(first_term_that_differs=first, rows=rows)
+    return res
 
 
 def run_lammps(lmp, out, log=True):
@@ -283,6 +490,18 @@ def pppm_ours(d):
         return dict(g_ewald=float(o.g_ewald), grid=[int(v) for v in o.pppm_grid])
     except Exception as exc:
         print("oracle not available:", exc)
+        return None
+
+
+def pppm_product(d):
+    """the same from the PRODUCT (scema_md_kspace_setup: a host function of the C ABI, no GPU needed) or None"""
+    try:
+        from scema_amd import capi
+        q = np.asarray(d["charge"], float)
+        g0, g1, grid = capi.kspace_setup(capi.default_params(), np.asarray(d["box"], float), float((q ** 2).sum()), int(d["natoms"]))
+        return dict(g_ewald=g1, grid=list(grid), g_initial=g0)
+    except Exception as exc:
+        print("library not available:", exc)
         return None
 
 
@@ -325,8 +544,11 @@ def verify(out, d, strain_len, scripts, lmp=None, **kw):
         res["lammps"] = [float(v) for v in s]
         errs = {k: float(np.abs(np.array(v) - s).max() / np.abs(s).max()) for k, v in (("oracle", res["oracle"]), ("gpu", res["gpu"])) if v is not None}
         res["rel_err_vs_lammps"] = errs
-        res["pppm"] = dict(lammps=pppm_from_log(os.path.join(out, "phase_a.log")), ours=pppm_ours(d))
-        res["verdict"] = "LAMMPS-verified: " + ", ".join(f"{k} max rel err {v:.3e}" for k, v in errs.items()) + f" ({lmp}); PPPM set-up {res['pppm']}"
+        res["pppm"] = dict(lammps=pppm_from_log(os.path.join(out, "phase_a.log")), ours=pppm_ours(d), product=pppm_product(d))
+        res["static"] = run_static(lmp, out, d, scripts)
+        firsts = {k: v.get("first_term_that_differs") for k, v in (res["static"] or {}).items()}
+        res["verdict"] = ("LAMMPS-verified: " + ", ".join(f"{k} max rel err {v:.3e}" for k, v in errs.items()) + f" ({lmp}); PPPM set-up {res['pppm']}; "
+                          f"static case, first term that differs (as the scripts stand / pair_modify table 0): {firsts.get('static')} / {firsts.get('static_table0')}")
     json.dump(res, open(os.path.join(out, "verdict.json"), "w"), indent=1)
     return res
 
