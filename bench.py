@@ -100,6 +100,8 @@ def _host_cores(per_process_gb, cap=None):
     # both are oversubscribed), so 16 is the pool default for an unconstrained job; a constraint found above is used as it is
     if rule == "os.cpu_count" and n > 16:
         n, rule = 16, "pool default (no affinity or cgroup constraint found; a one-GPU job's share of the host)"
+    elif n > 16:   # a mask or quota wider than that share: 32 workers were measured oversubscribed here; SCEMA_CPU_BASELINE_CORES overrides
+        n, rule = 16, rule + " of more than 16, capped at the pool's 16-core share"
     if os.environ.get("SCEMA_CPU_BASELINE_CORES"):
         n, rule = max(1, int(os.environ["SCEMA_CPU_BASELINE_CORES"])), "SCEMA_CPU_BASELINE_CORES"
     try:
@@ -432,18 +434,22 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = eng.profile()
-    prof_alone = None
+    # The roofline kernel WITH THE CHIP TO ITSELF: two more updates after the timed region with the batch issued as one sequence of launches on
+    # one stream (the timed region runs it as two half batches whose launches overlap each other and the other kernels of both halves: a
+    # per-launch time there is not a chip-exclusive time).  The engine's settings are put back exactly as they were found.
+    found = eng.concurrency()
     if reax:
-        # the charge-equilibration sweep ALONE: two more updates with the batch issued as one sequence of launches on one stream (the timed region
-        # runs it as two half batches next to each other and next to the bond-order chains: its per-launch time there is the kernel's as run)
-        parts_default = int(os.environ.get("SCEMA_REAX_HALVES", "2"))
         eng.reax_concurrency(0, 0)
-        eng.profile(reset=True)
-        for k in range(2):
-            update(args.warmup + args.steps + k)
-        fence()
-        prof_alone = eng.profile()
-        eng.reax_concurrency(parts_default, 1)
+    else:
+        eng.batch_split(0)
+    eng.profile(reset=True)
+    for k in range(2):
+        update(args.warmup + args.steps + k)
+    fence()
+    prof_alone = eng.profile()
+    eng.reax_concurrency(found["reax_halves"], found["reax_overlap"])
+    eng.batch_split(found["split"])
+    assert eng.concurrency() == found
     comm = eng.comm_stats()
     owner, _, cap = eng.last_plan(n)
     nts_mean = req.nts_mean
@@ -457,7 +463,7 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         fence()
         tm0 = time.perf_counter()
         for k in range(args.monotonic_updates):
-            update(args.warmup + args.steps + k)
+            update(args.warmup + args.steps + 2 + k)
         fence()
         tm = time.perf_counter() - tm0
         if world > 1:
@@ -484,47 +490,56 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         if os.path.exists(ppath) and natoms == 10368:
             pmc = json.load(open(ppath))
         value = n * args.steps / elapsed
+        # ---- the roofline record of k_pair (schema 2, round 5; every figure reproduces from a table under profiles/) ----
+        # The kernel is bound by vector-instruction ISSUE, not by HBM: `bound`, `achieved`, `peak`, `frac` describe THAT
+        # bound, measured with the batch whole (the chip to itself); the byte-based figures of SURVEY 8(d) stand beside them as frac_hbm*.
+        #   bytes: N*(4*nbar + 56) + 48 per replica and launch; `stored` = every pair once = half the full per-atom list inside
+        #   cutoff + the reference's skin (counted by the exact list build of each run)
+        def bytes_of(pf):
+            full = pf["pair_alg_bytes"]
+            fixed = pf["pair_sims"] * (56.0 * natoms + 48.0)
+            return 0.5 * (full - fixed) + fixed, full
+        stored, full = bytes_of(prof)
         pair_s = prof["pair_ms"] * 1e-3
         launches = max(prof["pair_launches"], 1)
-        avg_launch_s = pair_s / launches
-        # a batch runs as two half batches on two streams: their launches are in flight together part of the time.  union = the time during which
-        # at least one timed launch ran (HIP events of both streams on the device clock); without overlap it equals the sum of the durations
-        union_s = prof.get("pair_union_ms", 0.0) * 1e-3 or pair_s
+        union_s = prof.get("pair_union_ms", 0.0) * 1e-3 or pair_s     # time with at least one timed launch running (= the sum when nothing overlaps)
         in_flight = pair_s / union_s if union_s > 0 else 1.0
-        # algorithmic bytes: N*(4*nbar + 56) + 48 per replica and launch.  full = nbar of a FULL per-atom list
-        # inside cutoff + the reference's skin (what the engine counts at build time); stored = every pair once (half of it)
-        full = prof["pair_alg_bytes"]
-        fixed = prof["pair_sims"] * (56.0 * natoms + 48.0)
-        stored = 0.5 * (full - fixed) + fixed
-        achieved = stored / union_s / 1e9 if union_s > 0 else 0.0
-        roof = {"bound": "fp64_valu", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+        w_stored, w_full = bytes_of(prof_alone)
+        w_s = prof_alone["pair_ms"] * 1e-3
+        w_launches = max(prof_alone["pair_launches"], 1)
+        w_avg = w_s / w_launches
+        w_sims = prof_alone["pair_sims"] / w_launches
+        nsimd, clk, cyc = 256 * 4, 2.4e9, 4.0
+        peak_issue = nsimd * clk / cyc / 1e9                         # G wave-instructions/s the chip can issue at 4 cycles each
+        insts_per_sim_step = pmc["valu_insts_per_sim_step"] if pmc else None
+        pairs_per_sim_step = 0.5 * (w_full - prof_alone["pair_sims"] * (56.0 * natoms + 48.0)) / 4.0 / max(prof_alone["pair_sims"], 1)   # listed pairs (inside cutoff + skin)
+        roof = {"schema": 2, "bound": "fp64_valu", "unit": "G wave-instr/s", "peak": peak_issue,
+                "achieved": (insts_per_sim_step * w_sims / w_avg / 1e9) if insts_per_sim_step and w_avg > 0 else None,
+                "frac": (insts_per_sim_step * w_sims / w_avg / 1e9 / peak_issue) if insts_per_sim_step and w_avg > 0 else None,
+                "frac_hbm": w_stored / w_s / 1e9 / 8000.0 if w_s > 0 else None,
+                "frac_hbm_full_list": w_full / w_s / 1e9 / 8000.0 if w_s > 0 else None,
+                "whole_avg_launch_ms": 1e3 * w_avg, "whole_launches": prof_alone["pair_launches"], "whole_sims_per_launch": w_sims,
+                "whole_alg_bytes_per_launch": w_stored / w_launches, "whole_hbm_gbps": w_stored / w_s / 1e9 if w_s > 0 else None,
+                # 55 flop per pair inside the LJ cutoff (4.876 M of the ~7.7 M listed pairs of a PE-10k replica-step) over the FP64 vector peak
+                "useful_flop_frac": (55.0 * 4.876e6 / 7.725e6 * pairs_per_sim_step * w_sims / w_avg / 78.6e12) if w_avg > 0 else None,
                 "traffic": None, "traffic_source": None,
+                "timed_avg_launch_ms": 1e3 * pair_s / launches, "timed_launches": prof["pair_launches"], "timed_sims_per_launch": prof["pair_sims"] / launches,
+                "avg_launch_ms": 1e3 * pair_s / launches, "launches": prof["pair_launches"], "sims_per_launch": prof["pair_sims"] / launches,   # (names of schema 1: the timed region)
+                "timed_launches_in_flight": in_flight,
+                "frac_hbm_timed_union": stored / union_s / 1e9 / 8000.0 if union_s > 0 else None,
+                "frac_hbm_timed_per_launch": stored / pair_s / 1e9 / 8000.0 if pair_s > 0 else None,
+                "rank0_pair_share_of_wall": union_s / elapsed,
                 "kernel": "k_pair (lj/cut/coul/long force+virial; every pair once, 4-atom cluster rows, LDS reaction-force tiles)",
-                "accounting": "achieved = SURVEY 8(d) bytes N*(4*n_stored+56)+48 with n_stored = the neighbours the kernel stores per atom "
-                              "(each pair once = half of the full list inside cutoff + the reference's 2 A skin, counted at build time) / "
-                              "the time during which the timed launches ran (HIP events).  A batch of 200 replicas and more runs as two half batches on two "
-                              "streams, so launches are in flight together part of the time: the time is the UNION of their intervals (= the sum of the "
-                              "durations when nothing overlaps; launches_in_flight = sum / union), i.e. frac = bytes of all launches / time with at least one "
-                              "of them running.  Per launch (what a rocprofv3 kernel table shows): alg_bytes_per_launch / avg_launch_ms = frac / "
-                              "launches_in_flight (a launch's event interval begins when its stream reaches it, so it includes the time its first workgroups wait for "
-                              "slots the other half's kernels hold: with two half batches the intervals average a tenth longer than the kernel durations of a "
-                              "rocprofv3 trace of the same command; with the batch whole, SCEMA_MD_SPLIT=0, the two agree).  frac_full_list_equiv prices the full list instead",
-                "frac_full_list_equiv": full / union_s / 1e9 / 8000.0 if union_s > 0 else 0.0,
-                "launches_in_flight": in_flight, "frac_per_launch": stored / pair_s / 1e9 / 8000.0 if pair_s > 0 else 0.0,
-                "launches": prof["pair_launches"], "avg_launch_ms": 1e3 * avg_launch_s,
-                "alg_bytes_per_launch": stored / launches, "sims_per_launch": prof["pair_sims"] / launches,
-                "rank0_pair_share_of_wall": union_s / elapsed}
+                "accounting": "bound = vector-instruction issue: frac = SQ_INSTS_VALU of a launch (profiles/pair_pmc.json, per replica-step x replicas per launch) / "
+                              "whole_avg_launch_ms / (1 024 SIMDs x 2.4 GHz / 4 cycles per wave instruction).  whole_* = two updates after the timed region with the "
+                              "batch as ONE sequence of launches (scema_md_batch_split(0)): HIP-event time per launch with the chip to itself -- what a rocprofv3 "
+                              "kernel table of a SCEMA_MD_SPLIT=0 run shows.  frac_hbm = SURVEY 8(d) bytes of the stored list (each pair once) / that time / 8 TB/s.  "
+                              "timed_* = the timed region, where the batch runs as two half batches on two streams: launches overlap, so a per-launch event "
+                              "interval is not a chip-exclusive time; frac_hbm_timed_union = bytes / time with at least one pair launch running"}
         if pmc:
-            scale = prof["pair_sims"] / launches   # PMC figures are per replica and launch
-            roof["traffic"] = pmc["hbm_bytes_per_sim_step_corrected"] * scale
+            roof["traffic"] = pmc["hbm_bytes_per_sim_step_corrected"] * w_sims
             roof["traffic_source"] = pmc.get("source", "profiles/pair_pmc.json")
-            insts = pmc["valu_insts_per_sim_step"] * scale
-            cyc = pmc.get("cycles_per_valu_inst", 4.0)
-            nsimd, clk = 256 * 4, 2.4e9
-            roof["fp64"] = {"valu_insts": insts, "cycles_per_inst": cyc, "simds": nsimd, "clock_hz": clk,
-                            "issue_time_ms": 1e3 * insts * cyc / (nsimd * clk), "frac": insts * cyc / (nsimd * clk) / (avg_launch_s / in_flight) if avg_launch_s > 0 else 0.0,
-                            "note": "vector instructions of one launch (SQ_INSTS_VALU, PMC pass under profiles/) priced at the FP64 rate of 4 cycles per "
-                                    "wave instruction on a SIMD-32, over the launch time measured here (divided by launches_in_flight): the bound that binds (HBM does not)"}
+            roof["valu_insts_per_launch"] = insts_per_sim_step * w_sims
         workload = (f"{n} x PE-{natoms} OPLS replicas per update(), {nts_mean:.0f}+{args.nss} MD steps each "
                     "(dt 2 fs, 300 K, lj/cut/coul/long 12/9 + " + ("PPPM" if args.kspace == "pppm" else "Ewald") + " 1e-4 + SHAKE + NVT), persistent per-QP state, "
                     f"replica equilibrated for {args.equil_steps} steps before the timed region")
@@ -534,35 +549,35 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
             # entries inside the taper radius are stored) and per row 84 B (row length 4, own preconditioned residual
             # pair 16, search direction and product pairs read + written 64); the gathered pairs of the columns are cache traffic by design
             # and not counted.  Entries and rows are counted on the device per sweep taken part in.
-            sw_s = prof["rx_sweep_ms"] * 1e-3
-            sw_n = max(prof["rx_sweep_launches"], 1)
-            sw_bytes = (8.0 + prof["rx_sweep_col_bytes"]) * prof["rx_sweep_entries"] + 84.0 * prof["rx_sweep_rows"]
+            def sweep_of(pf):
+                t = pf["rx_sweep_ms"] * 1e-3
+                by = (8.0 + pf["rx_sweep_col_bytes"]) * pf["rx_sweep_entries"] + 84.0 * pf["rx_sweep_rows"]
+                return t, by, max(pf["rx_sweep_launches"], 1)
+            sw_s, sw_bytes, sw_n = sweep_of(prof)
             sw_union = prof.get("rx_sweep_union_ms", 0.0) * 1e-3 or sw_s
-            achieved = sw_bytes / sw_union / 1e9 if sw_union > 0 else 0.0
-            alone = None
-            if prof_alone and prof_alone["rx_sweep_ms"] > 0:
-                a_s = prof_alone["rx_sweep_ms"] * 1e-3
-                a_bytes = (8.0 + prof_alone["rx_sweep_col_bytes"]) * prof_alone["rx_sweep_entries"] + 84.0 * prof_alone["rx_sweep_rows"]
-                alone = {"achieved": a_bytes / a_s / 1e9, "frac": a_bytes / a_s / 1e9 / 8000.0, "launches": prof_alone["rx_sweep_launches"],
-                         "avg_launch_ms": 1e3 * a_s / max(prof_alone["rx_sweep_launches"], 1),
-                         "note": "the same kernel with nothing next to it: two more updates after the timed region with the batch issued as ONE sequence of "
-                                 "launches on one stream (scema_md_reax_concurrency(0, 0)); launches over the whole batch"}
+            a_s, a_bytes, a_n = sweep_of(prof_alone)
             pmc = None
             ppath = os.path.join(ROOT, "profiles", "reax_pmc.json")
             if os.path.exists(ppath):
                 pmc = json.load(open(ppath))
-            roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            # schema 2 (round 5): `achieved` / `frac` = the kernel with the chip to itself (two updates after the timed region with the batch as ONE
+            # sequence of launches on one stream: what a rocprofv3 table of such a run shows); the timed region's figures beside them
+            roof = {"schema": 2, "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                    "achieved": a_bytes / a_s / 1e9 if a_s > 0 else None, "frac": a_bytes / a_s / 1e9 / 8000.0 if a_s > 0 else None,
+                    "whole_avg_launch_ms": 1e3 * a_s / a_n, "whole_launches": prof_alone["rx_sweep_launches"], "whole_alg_bytes_per_launch": a_bytes / a_n,
                     "traffic": (pmc or {}).get("hbm_bytes_per_sweep_corrected"), "traffic_source": (pmc or {}).get("command"),
+                    "timed_avg_launch_ms": 1e3 * sw_s / sw_n, "timed_launches": prof["rx_sweep_launches"], "timed_launches_in_flight": sw_s / sw_union if sw_union > 0 else 1.0,
+                    "frac_timed_union": sw_bytes / sw_union / 1e9 / 8000.0 if sw_union > 0 else None,
+                    "frac_timed_per_launch": sw_bytes / sw_s / 1e9 / 8000.0 if sw_s > 0 else None,
+                    "avg_launch_ms": 1e3 * sw_s / sw_n, "launches": prof["rx_sweep_launches"],   # (names of schema 1: the timed region)
+                    "alone": {"frac": a_bytes / a_s / 1e9 / 8000.0 if a_s > 0 else None},       # (schema 1 kept this nested; = frac now)
                     "kernel": "k_rx_qeq_sweep (charge equilibration: y = H z for both conjugate-gradient systems, one pass over the stored matrix rows)",
-                    "accounting": f"achieved = ({8 + int(prof['rx_sweep_col_bytes'])} B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
-                                  "device) / HIP-event time of all launches of the kernel on the engine's stream (launches that find every replica converged "
-                                  "cost time and move nothing); traffic = counter bytes of ONE sweep over the whole batch (profiles/reax_pmc.json).  "
-                                  "The batch is issued as two half batches on two streams, each with its bond-order chain on a side stream: a launch covers HALF the "
-                                  "replicas and launches of the two halves are in flight together part of the time.  The time is the UNION of the launches' intervals "
-                                  "(time with at least one sweep running; launches_in_flight = sum of durations / union) -- and during it the sweep shares the chip "
-                                  "with the other kernels of both halves; `alone` is the kernel with the chip to itself",
-                    "alone": alone, "launches_in_flight": sw_s / sw_union if sw_union > 0 else 1.0, "frac_per_launch": sw_bytes / sw_s / 1e9 / 8000.0 if sw_s > 0 else 0.0,
-                    "launches": prof["rx_sweep_launches"], "avg_launch_ms": 1e3 * sw_s / sw_n, "alg_bytes_per_launch": sw_bytes / sw_n,
+                    "accounting": f"bytes = ({8 + int(prof['rx_sweep_col_bytes'])} B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
+                                  "device) / HIP-event time of the kernel's launches (launches that find every replica converged cost time and move nothing); traffic = counter "
+                                  "bytes of ONE sweep over the whole batch (profiles/reax_pmc.json).  whole_* / frac: the batch as one sequence of launches on one stream "
+                                  "(scema_md_reax_concurrency(0, 0)), the chip to itself.  timed_*: the timed region, where the batch runs as two half batches on two "
+                                  "streams, each with its bond-order chain on a side stream -- a launch covers HALF the replicas, launches overlap, and "
+                                  "frac_timed_union = bytes / time with at least one sweep running, next to the other kernels of both halves",
                     "alg_bytes_per_full_sweep": sw_bytes / max(prof["rx_sweep_rows"] / natoms, 1.0) * per_rank,   # one sweep over every replica of this rank
                     "stored_entries_per_row": prof["rx_sweep_entries"] / max(prof["rx_sweep_rows"], 1.0),
                     "rank0_sweep_share_of_wall": sw_s / elapsed,
@@ -712,6 +727,13 @@ def main():
                 "note": "BASELINE config 5 as a second leg of this run, after the OPLS loop and outside `value`; an evaluation here is "
                         f"{c['md_steps_per_eval']:.0f} MD steps of 0.25 fs on 1 620 atoms (the OPLS line's: 110 steps of 2 fs on 10 368 atoms): compare replica_steps_per_s, not evals_per_s"}
     if rank == 0:
+        rx = out["config"].get("reax") or {}
+        if "evals_per_s" in rx:   # the second leg once more in flat keys (a parser that keeps one level of nesting keeps these)
+            out["reax_evals_per_s"] = rx["evals_per_s"]
+            out["reax_replica_steps_per_s"] = rx["replica_steps_per_s"]
+            out["reax_frac"] = rx["roofline"]["frac"]
+            out["reax_frac_timed_union"] = rx["roofline"]["frac_timed_union"]
+            out["reax_whole_avg_launch_ms"] = rx["roofline"]["whole_avg_launch_ms"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

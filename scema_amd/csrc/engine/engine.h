@@ -151,7 +151,7 @@ struct State {
 // work arrays of the ReaxFF path for one batch position (reax/rx_types.h RxView points into these)
 struct RxSlot {
   int cap_pad = 0, cap_nb = 0, cap_bd = 0, cap_nbn = 0;
-  DevBuf nbn_cnt, nbn, nbnT, qpart;
+  DevBuf nbn_cnt, nbn, nbnT, qpart, pm_len, pm_col, pm_raw, pm_val;
   DevBuf nb_cnt, nb, nbT, hval, hcol, hlen, hown, hownlen, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
 };
 
@@ -282,6 +282,7 @@ struct scema_md_engine {
   int split_min = 32, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
                                          // at 576 and left large groups whole; with round 4's kernels the halves give 437 against 429, profiles/r04_zs_*)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool rx_precond = true;                 // bonded-pattern sparse approximate inverse as the preconditioner of the charge equilibration (SCEMA_REAX_QEQ_PRECOND=0: the reference's Jacobi one)
   int rx_halves = 2, rx_overlap = 1;      // scema_md_reax_concurrency: part batches (1 = one sequence of launches) and side streams (initial values from SCEMA_REAX_HALVES / SCEMA_REAX_OVERLAP)
   // ReaxFF runs as rx_halves part batches on as many streams (part 0: stream + stream2), each with a side stream for its bond-order chain and
   // four events (fork / mid / join of the side stream, the part's join with the main stream); created on first use

@@ -23,8 +23,12 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
     HIPCHK(r.t.ensure((size_t)npad * 8));
     HIPCHK(r.s_hist.ensure(4 * (size_t)npad * 8));
     HIPCHK(r.t_hist.ensure(3 * (size_t)npad * 8));
-    HIPCHK(r.qwork.ensure(8 * (size_t)npad * 8));
-    HIPCHK(r.qpart.ensure((6 * (size_t)((npad + 255) / 256) + 2 * (size_t)(npad / RX_SWR + 1)) * 8));   // layout: md_reax.hip
+    HIPCHK(r.qwork.ensure(10 * (size_t)npad * 8));
+    HIPCHK(r.qpart.ensure((10 * (size_t)((npad + 255) / 256) + 2 * (size_t)(npad / RX_SWR + 1)) * 8));   // layout: md_reax.hip
+    HIPCHK(r.pm_len.ensure((size_t)npad * 4));
+    HIPCHK(r.pm_col.ensure((size_t)RX_PM_MAX * npad * 4));
+    HIPCHK(r.pm_raw.ensure((size_t)RX_PM_MAX * npad * 8));
+    HIPCHK(r.pm_val.ensure((size_t)RX_PM_MAX * npad * 8));
     HIPCHK(r.nbn_cnt.ensure((size_t)npad * 4));
     HIPCHK(r.hlen.ensure((size_t)npad * 4));
     HIPCHK(r.hownlen.ensure((size_t)npad * 4));
@@ -104,6 +108,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   bool col16 = !(scema_env("SCEMA_MD_RX_COL32") && atoi(scema_env("SCEMA_MD_RX_COL32")) != 0);   // (test switch: 32-bit columns for any size)
   for (int i = 0; i < ns; i++) col16 = col16 && sims[i].st->topo->natoms <= 65536;
   e->h_zerotab.clear();
+  bool any_precond = false;
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
     ActiveSim &A = sims[i];
@@ -206,6 +211,10 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     RXSET(V.hcol16, col16 ? R.hcol.as<unsigned short>() : nullptr); RXSET(V.hcol32, col16 ? nullptr : R.hcol.as<int>()); RXSET(V.hlen, R.hlen.as<int>()); RXSET(V.nbT, R.nbT.as<int>());
     RXSET(V.hown, R.hown.as<int>()); RXSET(V.hownlen, R.hownlen.as<int>());
     RXSET(V.s_hist, R.s_hist.as<double>()); RXSET(V.t_hist, R.t_hist.as<double>()); RXSET(V.qwork, R.qwork.as<double>());
+    // the bonded-pattern preconditioner needs one image per neighbour (boxes at least two list radii wide: every production replica)
+    V.pm_on = (e->rx_precond && V.mimg[0] == 0 && V.mimg[1] == 0 && V.mimg[2] == 0) ? 1 : 0;
+    any_precond = any_precond || V.pm_on;
+    RXSET(V.pm_len, R.pm_len.as<int>()); RXSET(V.pm_col, R.pm_col.as<int>()); RXSET(V.pm_raw, R.pm_raw.as<double>()); RXSET(V.pm_val, R.pm_val.as<double>());
     RXSET(V.eparts, R.misc.as<double>());                         // [0, 13) doubles
     RXSET(V.qstat, (int *)(R.misc.as<char>() + 128));             // 6 ints
     RXSET(V.overflow, (int *)(R.misc.as<char>() + 160));
@@ -266,6 +275,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     RxQeqPlan pl;
     pl.launch = (step < 4 && any_cold) ? e->rx_qeq_launch_cold : e->rx_qeq_launch;
     pl.setup = step == 0 ? 1 : 0;
+    pl.precond = any_precond ? 1 : 0;
     return pl;
   };
   mdk_reax_phase_init(st, VV, ns, maxpad);
@@ -501,6 +511,18 @@ int scema_md_reax_concurrency(scema_md_engine *e, int32_t halves, int32_t overla
   if (!e) return SCEMA_MD_ERR_ARG;
   if (halves >= 0) e->rx_halves = std::min(halves, 8);
   if (overlap >= 0) e->rx_overlap = overlap != 0;
+  return SCEMA_MD_OK;
+}
+int scema_md_batch_split(scema_md_engine *e, int32_t on) {
+  if (!e) return SCEMA_MD_ERR_ARG;
+  if (on >= 0) e->split_streams = on != 0;
+  return SCEMA_MD_OK;
+}
+int scema_md_get_concurrency(const scema_md_engine *e, int32_t *out) {
+  if (!e || !out) return SCEMA_MD_ERR_ARG;
+  out[0] = e->split_streams ? 1 : 0;
+  out[1] = e->rx_halves;
+  out[2] = e->rx_overlap ? 1 : 0;
   return SCEMA_MD_OK;
 }
 int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms, int32_t qeq_maxiter) {

@@ -12,6 +12,7 @@ void mdk_reax_phase_init(hipStream_t st, const RxView *v, int ns, int maxpad);
 struct RxQeqPlan {
   int launch = 0;  // conjugate-gradient iterations issued as launches over the batch (replicas that need more finish inside k_rx_qeq_finish)
   int setup = 0;   // the solve of a run's step 0 (a replica that kept its history starts from the newest solution)
+  int precond = 0; // the batch's views have pm_on set: build the sparse approximate inverse before the solve
 };
 // the whole force stage of one step for the first ns replicas: (neighbour rows if the rebuild flag of the step is set,)
 // charge equilibration, bond orders, energy terms, forces into SimDev::f, virial and energies into SimScalars.

@@ -304,7 +304,14 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
 // then forms the charges and shifts the history.
 //
 // qpart layout (doubles): [0, 2 NV) and [2 NV, 4 NV): r.z partials of even / odd iterations; [4 NV, 6 NV): b.b partials;
-// [6 NV, 6 NV + 2 NB): d.q partials.  NV = RX_QNV (update workgroups, padded), NB = sweep workgroups = npad / RX_SWR.
+// [6 NV, 6 NV + 2 NB'): d.q partials; then [.., + 2 NV) and [.., + 2 NV): r.D^-1 r partials of even / odd iterations (the reference's
+// convergence measure: the same sums as r.z while the preconditioner is the Jacobi one).  NV = RX_QNV (update workgroups, padded),
+// NB' = npad / RX_SWR + 1 >= the sweep workgroups.
+//
+// Preconditioner (round 5): `fix qeq/reax 1 0.0 10.0 1e-6` (in.strain.lammps:12) fixes the answer -- stop when sqrt(r.D^-1 r) / |b| <= 1e-6 --
+// not the way there.  z = M r with M a sparse approximate inverse on the bonded pattern (k_rx_qeq_pm_rows / _sym; RX_PM_RADIUS) instead of
+// D^-1 takes 5.1 instead of 12.4 iterations per solve on PE-1620 (tools/qeq_precond_gate.py, gated offline before it was built), for a
+// product with ~4 entries per row next to the matrix's ~545.  The stop is still taken on the reference's measure.
 #define QEQ_TPB 1024
 #define RX_QEQ_COLD RX_QEQ_COLD_SOLVES
 #define QEQ_UT 256
@@ -318,6 +325,17 @@ __device__ __forceinline__ void qeq_fold(const double *part, int count, double &
   b = wave_sum(sb);
 }
 struct QeqScal { double sig[2], bn[2]; bool run[2]; };
+// where the r.D^-1 r partials of an iteration's parity sit in qpart
+__device__ __forceinline__ double RX_G *qeq_conv_part(const RxView &V, int parity) {
+  return V.qpart + 6 * RX_QNV(V.npad) + 2 * (V.npad / RX_SWR + 1) + 2 * RX_QNV(V.npad) * parity;
+}
+// the run flags of iteration `it`: the reference's measure sqrt(r.D^-1 r) / |b| against the tolerance (r.z itself under the Jacobi preconditioner)
+__device__ __forceinline__ void qeq_run_flags(const RxView &V, int it, double tol, QeqScal &Q) {
+  double c0 = Q.sig[0], c1 = Q.sig[1];
+  if (V.pm_on) qeq_fold((const double *)qeq_conv_part(V, it & 1), (V.n + QEQ_UT - 1) / QEQ_UT, c0, c1);
+  Q.run[0] = sqrt(c0) / Q.bn[0] > tol;
+  Q.run[1] = sqrt(c1) / Q.bn[1] > tol;
+}
 // scalars of iteration `it` from the partial sums of the launches before it
 __device__ __forceinline__ QeqScal qeq_scalars(const RxView &V, int it, double tol) {
   const int nv = RX_QNV(V.npad), nvl = (V.n + QEQ_UT - 1) / QEQ_UT;   // slots, slots in use
@@ -325,8 +343,7 @@ __device__ __forceinline__ QeqScal qeq_scalars(const RxView &V, int it, double t
   qeq_fold(V.qpart + 2 * nv * (it & 1), nvl, Q.sig[0], Q.sig[1]);
   qeq_fold(V.qpart + 4 * nv, nvl, Q.bn[0], Q.bn[1]);
   Q.bn[0] = sqrt(Q.bn[0]); Q.bn[1] = sqrt(Q.bn[1]);
-  Q.run[0] = sqrt(Q.sig[0]) / Q.bn[0] > tol;
-  Q.run[1] = sqrt(Q.sig[1]) / Q.bn[1] > tol;
+  qeq_run_flags(V, it, tol, Q);
   return Q;
 }
 
@@ -353,8 +370,7 @@ __device__ __forceinline__ QeqScal qeq_scalars_with(const RxView &V, int it, dou
   Q.sig[0] = lane_value(a, 0); Q.sig[1] = lane_value(b, 0);
   Q.bn[0] = sqrt(lane_value(a, 16)); Q.bn[1] = sqrt(lane_value(b, 16));
   xs = lane_value(a, 48) + lane_value(a, 32); xt = lane_value(b, 48) + lane_value(b, 32);   // (row 3 + row 2: the order of wave_sum)
-  Q.run[0] = sqrt(Q.sig[0]) / Q.bn[0] > tol;
-  Q.run[1] = sqrt(Q.sig[1]) / Q.bn[1] > tol;
+  qeq_run_flags(V, it, tol, Q);
   return Q;
 }
 
@@ -474,7 +490,9 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
     if (it < 0) {
       q[i] = make_double2(ys, yt);
     } else {
-      double2 di = d[i], qi = q[i];
+      // (iteration 0: d = z, q = y -- the arrays hold what the solve before left, and q the first product H x0 that the update of
+      // it < 0 and its preconditioner read)
+      double2 di = (it > 0) ? d[i] : make_double2(0.0, 0.0), qi = (it > 0) ? q[i] : make_double2(0.0, 0.0);
       if (Q.run[0]) { di.x = fma(beta_s, di.x, zi.x); qi.x = fma(beta_s, qi.x, ys); dq_s = di.x * qi.x; }
       if (Q.run[1]) { di.y = fma(beta_t, di.y, zi.y); qi.y = fma(beta_t, qi.y, yt); dq_t = di.y * qi.y; }
       d[i] = di; q[i] = qi;
@@ -489,28 +507,125 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   }
 }
 
-// it < 0: r = b - H x0, z = r / eta, d = q = 0, partial sums of r.z (slot of iteration 0) and b.b
+// ---- the preconditioner: a sparse approximate inverse on the bonded pattern ----
+// Row i of M = row i of (H[P, P])^-1 with P = {i} + its neighbours within RX_PM_RADIUS (from the near rows, a superset), then M := (M + M^T) / 2
+// in a second launch (a row needs its neighbours' rows).  H[P, P] is a handful of shielded Coulomb terms: a dense solve of at most 8 x 8 per
+// atom (symmetric positive definite: elimination without pivoting).  Rebuilt every step: 0.2 % of it.
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_pm_rows(const RxView *views, const RxParams *__restrict__ P) {
+  const RxView V = views[blockIdx.y];
+  if (!V.pm_on) return;
+  const int i = blockIdx.x * QEQ_UT + threadIdx.x;
+  if (i >= V.n) return;
+  const size_t np = V.npad;
+  int col[RX_PM_MAX], ty[RX_PM_MAX];
+  double px[RX_PM_MAX][3];
+  int m = 1;
+  col[0] = i; ty[0] = V.rtype[i]; px[0][0] = px[0][1] = px[0][2] = 0.0;
+  const int cnt = V.nbn_cnt[i];
+  for (int k = 0; k < cnt && m < RX_PM_MAX; k++) {
+    const int e = V.nbn[(size_t)k * np + i];
+    double d[3];
+    const int j = rx_partner(&V, i, e, d);
+    if (j == i) continue;
+    if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] <= RX_PM_RADIUS * RX_PM_RADIUS) {
+      col[m] = j; ty[m] = V.rtype[j]; px[m][0] = d[0]; px[m][1] = d[1]; px[m][2] = d[2];
+      m++;
+    }
+  }
+  double A[RX_PM_MAX][RX_PM_MAX], rhs[RX_PM_MAX];
+  for (int a = 0; a < m; a++) {
+    rhs[a] = (a == 0) ? 1.0 : 0.0;
+    A[a][a] = P->sbp[ty[a]].eta;
+    for (int b2 = a + 1; b2 < m; b2++) {
+      const double d0 = px[a][0] - px[b2][0], d1 = px[a][1] - px[b2][1], d2 = px[a][2] - px[b2][2];
+      const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+      double h = 0.0;
+      if (!(r2 > P->swb * P->swb)) {
+        const double r = r2 * rx_rsqrt(r2);
+        double tp = P->tap[7];
+        for (int q = 6; q >= 0; q--) tp = tp * r + P->tap[q];
+        h = tp * RX_EV_TO_KCALPMOL * rx_icbrt(r2 * r + P->tbp[ty[a] * RX_MAXT + ty[b2]].gamma);
+      }
+      A[a][b2] = h; A[b2][a] = h;
+    }
+  }
+  for (int c = 0; c < m; c++) {          // elimination
+    const double inv = 1.0 / A[c][c];
+    for (int a = c + 1; a < m; a++) {
+      const double f = A[a][c] * inv;
+      for (int b2 = c; b2 < m; b2++) A[a][b2] -= f * A[c][b2];
+      rhs[a] -= f * rhs[c];
+    }
+  }
+  for (int a = m - 1; a >= 0; a--) {     // back substitution
+    double v = rhs[a];
+    for (int b2 = a + 1; b2 < m; b2++) v -= A[a][b2] * rhs[b2];
+    rhs[a] = v / A[a][a];
+  }
+  V.pm_len[i] = m;
+  for (int k = 0; k < m; k++) { V.pm_col[(size_t)k * np + i] = col[k]; V.pm_raw[(size_t)k * np + i] = rhs[k]; }
+}
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_pm_sym(const RxView *views) {
+  const RxView V = views[blockIdx.y];
+  if (!V.pm_on) return;
+  const int i = blockIdx.x * QEQ_UT + threadIdx.x;
+  if (i >= V.n) return;
+  const size_t np = V.npad;
+  const int m = V.pm_len[i];
+  V.pm_val[i] = V.pm_raw[i];
+  for (int k = 1; k < m; k++) {
+    const int j = V.pm_col[(size_t)k * np + i];
+    double other = 0.0;
+    bool found = false;
+    const int mj = V.pm_len[j];
+    for (int kk = 1; kk < mj; kk++)
+      if (V.pm_col[(size_t)kk * np + j] == i) { other = V.pm_raw[(size_t)kk * np + j]; found = true; }
+    // (a neighbour whose own row was full and left this atom out: the pair is dropped from both rows)
+    V.pm_val[(size_t)k * np + i] = found ? 0.5 * (V.pm_raw[(size_t)k * np + i] + other) : 0.0;
+  }
+}
+// z_i = sum_k M_ik r_k for both systems, the residuals r_k handed in by a functor (the update launches compute a neighbour's NEW residual
+// from arrays that no workgroup writes in that launch)
+template <class F>
+__device__ __forceinline__ double2 qeq_pm_apply(const RxView &V, int i, F &&res) {
+  const size_t np = V.npad;
+  const int m = V.pm_len[i];
+  double z0 = 0.0, z1 = 0.0;
+  for (int k = 0; k < m; k++) {
+    const double w = V.pm_val[(size_t)k * np + i];
+    const double2 rk = res(V.pm_col[(size_t)k * np + i]);
+    z0 = fma(w, rk.x, z0); z1 = fma(w, rk.y, z1);
+  }
+  return make_double2(z0, z1);
+}
+// the residual array of an iteration's parity (rx_types.h: qwork)
+__device__ __forceinline__ double2 *qeq_rbuf(const RxView &V, int parity) { return (double2 *)(V.qwork + (parity ? 8 * (size_t)V.npad : 0)); }
+
+// it < 0: r = b - H x0 (into the residual array of parity 0), z = M r, partial sums of r.z and r.D^-1 r (slots of iteration 0) and b.b
 __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, const RxParams *__restrict__ P, double tol, int it) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * QEQ_UT + threadIdx.x, n = V.n;
   if (blockIdx.x * QEQ_UT >= n) return;
   const size_t np = V.npad;
   const int nv = RX_QNV(V.npad);
-  double2 *r = (double2 *)V.qwork, *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np), *z = (double2 *)(V.qwork + 6 * np);
-  __shared__ double s_red[4][QEQ_UT / 64];
-  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+  const double2 *r_in = qeq_rbuf(V, it < 0 ? 0 : (it & 1));
+  double2 *r_out = qeq_rbuf(V, it < 0 ? 0 : ((it + 1) & 1));
+  const double2 *d = (const double2 *)(V.qwork + 2 * np), *q = (const double2 *)(V.qwork + 4 * np);
+  double2 *z = (double2 *)(V.qwork + 6 * np);
+  __shared__ double s_red[6][QEQ_UT / 64];
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, c0 = 0.0, c1 = 0.0;
   if (it < 0) {
     if (i < n) {
+      // (q holds the first product H x0, which this launch leaves alone: the neighbours' residuals come from it)
+      auto res0 = [&](int k) { const int tk = V.rtype[k]; const double2 y = q[k]; return make_double2(-P->sbp[tk].chi - y.x, -1.0 - y.y); };
       const int ti = V.rtype[i];
       const double eta = P->sbp[ti].eta, chi = P->sbp[ti].chi;
-      const double2 y = q[i];
-      const double r1 = -chi - y.x, r2 = -1.0 - y.y;
-      const double z1 = r1 / eta, z2 = r2 / eta;
-      r[i] = make_double2(r1, r2);
-      z[i] = make_double2(z1, z2);
-      d[i] = make_double2(0.0, 0.0);
-      q[i] = make_double2(0.0, 0.0);
-      p0 = r1 * z1; p1 = r2 * z2; p2 = chi * chi; p3 = 1.0;
+      const double2 ri = res0(i);
+      const double2 zi = V.pm_on ? qeq_pm_apply(V, i, res0) : make_double2(ri.x / eta, ri.y / eta);
+      r_out[i] = ri;
+      z[i] = zi;
+      p0 = ri.x * zi.x; p1 = ri.y * zi.y; p2 = chi * chi; p3 = 1.0;
+      c0 = ri.x * ri.x / eta; c1 = ri.y * ri.y / eta;
     }
   } else {
     double dq_s, dq_t;
@@ -521,33 +636,52 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, c
         const double *pf = V.qpart + 2 * nv * (it & 1) + 2 * blockIdx.x;
         double *pa = V.qpart + 2 * nv * ((it + 1) & 1) + 2 * blockIdx.x;
         pa[0] = pf[0]; pa[1] = pf[1];
+        if (V.pm_on) {
+          const double RX_G *cf = qeq_conv_part(V, it & 1) + 2 * blockIdx.x;
+          double RX_G *ca = qeq_conv_part(V, (it + 1) & 1) + 2 * blockIdx.x;
+          ca[0] = cf[0]; ca[1] = cf[1];
+        }
       }
       return;
     }
     const double al_s = Q.run[0] ? Q.sig[0] / dq_s : 0.0, al_t = Q.run[1] ? Q.sig[1] / dq_t : 0.0;
     if (i < n) {
+      // a converged system keeps r (alpha = 0), z and with them its scalar products: it stays converged
+      auto res1 = [&](int k) { const double2 rk = r_in[k], qk = q[k]; return make_double2(fma(-al_s, qk.x, rk.x), fma(-al_t, qk.y, rk.y)); };
       const double eta = P->sbp[V.rtype[i]].eta;
-      const double2 di = d[i], qi = q[i];
-      double2 ri = r[i], zi = z[i];
-      // a converged system keeps r, z and with them its scalar product: it stays converged
-      if (Q.run[0]) { V.s[i] = fma(al_s, di.x, V.s[i]); ri.x = fma(-al_s, qi.x, ri.x); zi.x = ri.x / eta; }
-      if (Q.run[1]) { V.t[i] = fma(al_t, di.y, V.t[i]); ri.y = fma(-al_t, qi.y, ri.y); zi.y = ri.y / eta; }
-      r[i] = ri; z[i] = zi;
+      const double2 di = d[i];
+      const double2 ri = res1(i);
+      double2 zi = z[i];
+      if (V.pm_on) {
+        const double2 zn = qeq_pm_apply(V, i, res1);
+        if (Q.run[0]) zi.x = zn.x;
+        if (Q.run[1]) zi.y = zn.y;
+      } else {
+        if (Q.run[0]) zi.x = ri.x / eta;
+        if (Q.run[1]) zi.y = ri.y / eta;
+      }
+      if (Q.run[0]) V.s[i] = fma(al_s, di.x, V.s[i]);
+      if (Q.run[1]) V.t[i] = fma(al_t, di.y, V.t[i]);
+      r_out[i] = ri; z[i] = zi;
       p0 = ri.x * zi.x; p1 = ri.y * zi.y;
+      c0 = ri.x * ri.x / eta; c1 = ri.y * ri.y / eta;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) V.qstat[0] += 1;
   }
   p0 = wave_sum(p0); p1 = wave_sum(p1);
   if (it < 0) { p2 = wave_sum(p2); p3 = wave_sum(p3); }
+  if (V.pm_on) { c0 = wave_sum(c0); c1 = wave_sum(c1); }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { s_red[0][wave] = p0; s_red[1][wave] = p1; s_red[2][wave] = p2; s_red[3][wave] = p3; }
+  if (lane == 0) { s_red[0][wave] = p0; s_red[1][wave] = p1; s_red[2][wave] = p2; s_red[3][wave] = p3; s_red[4][wave] = c0; s_red[5][wave] = c1; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int w = 0; w < QEQ_UT / 64; w++) { a0 += s_red[0][w]; a1 += s_red[1][w]; a2 += s_red[2][w]; a3 += s_red[3][w]; }
-    double *pa = V.qpart + 2 * nv * ((it < 0) ? 0 : ((it + 1) & 1)) + 2 * blockIdx.x;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+    for (int w = 0; w < QEQ_UT / 64; w++) { a0 += s_red[0][w]; a1 += s_red[1][w]; a2 += s_red[2][w]; a3 += s_red[3][w]; a4 += s_red[4][w]; a5 += s_red[5][w]; }
+    const int par = (it < 0) ? 0 : ((it + 1) & 1);
+    double *pa = V.qpart + 2 * nv * par + 2 * blockIdx.x;
     pa[0] = a0; pa[1] = a1;
     if (it < 0) { double *pc = V.qpart + 4 * nv + 2 * blockIdx.x; pc[0] = a2; pc[1] = a3; }
+    if (V.pm_on) { double RX_G *ca = qeq_conv_part(V, par) + 2 * blockIdx.x; ca[0] = a4; ca[1] = a5; }
   }
 }
 
@@ -578,7 +712,7 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
   bool run_s = Q.run[0], run_t = Q.run[1];
   int it = 0;
   if (run_s || run_t) {
-    double2 *r = (double2 *)V.qwork, *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np), *z = (double2 *)(V.qwork + 6 * np);
+    double2 *r = qeq_rbuf(V, done & 1), *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np), *z = (double2 *)(V.qwork + 6 * np);
     double sig_s = Q.sig[0], sig_t = Q.sig[1], prev_s = 1.0, prev_t = 1.0;
     if (done > 0) qeq_fold(V.qpart + 2 * RX_QNV(V.npad) * ((done - 1) & 1), (n + QEQ_UT - 1) / QEQ_UT, prev_s, prev_t);
     for (; done + it < maxiter && (run_s || run_t); it++) {
@@ -601,7 +735,8 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
           const double eta = P->sbp[V.rtype[i]].eta;
           const double2 zi = z[i];
           ys = fma(eta, zi.x, ys); yt = fma(eta, zi.y, yt);
-          double2 di = d[i], qi = q[i];
+          const bool first = done + it == 0;   // (d = z, q = y: the arrays hold what the solve before left)
+          double2 di = first ? make_double2(0.0, 0.0) : d[i], qi = first ? make_double2(0.0, 0.0) : q[i];
           if (run_s) { di.x = fma(be_s, di.x, zi.x); qi.x = fma(be_s, qi.x, ys); dq_s += di.x * qi.x; }
           if (run_t) { di.y = fma(be_t, di.y, zi.y); qi.y = fma(be_t, qi.y, yt); dq_t += di.y * qi.y; }
           d[i] = di; q[i] = qi;
@@ -609,19 +744,33 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
       }
       qeq_reduce2(dq_s, dq_t, s_red);   // its barriers also order the sweep (reads z) before the update (writes z)
       const double al_s = run_s ? sig_s / dq_s : 0.0, al_t = run_t ? sig_t / dq_t : 0.0;
-      double sn_s = 0.0, sn_t = 0.0;
+      double sn_s = 0.0, sn_t = 0.0, cv_s = 0.0, cv_t = 0.0;
       for (int i = tid; i < n; i += QEQ_TPB) {
         const double eta = P->sbp[V.rtype[i]].eta;
         const double2 di = d[i], qi = q[i];
         double2 ri = r[i], zi = z[i];
         if (run_s) { s[i] = fma(al_s, di.x, s[i]); ri.x = fma(-al_s, qi.x, ri.x); zi.x = ri.x / eta; }
         if (run_t) { t[i] = fma(al_t, di.y, t[i]); ri.y = fma(-al_t, qi.y, ri.y); zi.y = ri.y / eta; }
-        r[i] = ri; z[i] = zi;
-        sn_s += ri.x * zi.x; sn_t += ri.y * zi.y;
+        r[i] = ri;
+        if (!V.pm_on) { z[i] = zi; sn_s += ri.x * zi.x; sn_t += ri.y * zi.y; }
+        cv_s += ri.x * ri.x / eta; cv_t += ri.y * ri.y / eta;
+      }
+      if (V.pm_on) {
+        __syncthreads();   // the residuals of the whole replica are in place: z = M r gathers the neighbours'
+        for (int i = tid; i < n; i += QEQ_TPB) {
+          const double2 ri = r[i];
+          const double2 zn = qeq_pm_apply(V, i, [&](int k) { return r[k]; });
+          double2 zi = z[i];
+          if (run_s) zi.x = zn.x;
+          if (run_t) zi.y = zn.y;
+          z[i] = zi;
+          sn_s += ri.x * zi.x; sn_t += ri.y * zi.y;
+        }
       }
       qeq_reduce2(sn_s, sn_t, s_red);
-      if (run_s) { prev_s = sig_s; sig_s = sn_s; run_s = sqrt(sig_s) / Q.bn[0] > tol; }
-      if (run_t) { prev_t = sig_t; sig_t = sn_t; run_t = sqrt(sig_t) / Q.bn[1] > tol; }
+      if (V.pm_on) qeq_reduce2(cv_s, cv_t, s_red); else { cv_s = sn_s; cv_t = sn_t; }
+      if (run_s) { prev_s = sig_s; sig_s = sn_s; run_s = sqrt(cv_s) / Q.bn[0] > tol; }
+      if (run_t) { prev_t = sig_t; sig_t = sn_t; run_t = sqrt(cv_t) / Q.bn[1] > tol; }
       __syncthreads();
     }
   }
@@ -1082,7 +1231,12 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
     // replicas of up to 4 096 atoms: the gathered vector in LDS (64 KB)
     static const bool zlds_off = scema_env("SCEMA_REAX_QEQ_ZLDS") && atoi(scema_env("SCEMA_REAX_QEQ_ZLDS")) == 0;
     const size_t lds = (size_t)((maxatoms + 63) / 64 * 64) * sizeof(double2);
-    if (col16 && lds <= 64 * 1024 && !zlds_off) hipLaunchKernelGGL((k_rx_qeq_sweep<true, true>), gk, dim3(RX_KT), lds, st, v, P, qeq_tol, it);
+    // (the kernel has 1 KB of static LDS besides; beyond 48 KB of dynamic LDS a launch needs the opt-in, as the other large-LDS kernels take it)
+    static size_t optin_tab[16] = {0};
+    size_t &optin = lds_optin_slot(optin_tab);
+    const bool zlds = col16 && lds + 2048 <= 64 * 1024 && !zlds_off;
+    if (zlds && lds > 47 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_rx_qeq_sweep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+    if (zlds) hipLaunchKernelGGL((k_rx_qeq_sweep<true, true>), gk, dim3(RX_KT), lds, st, v, P, qeq_tol, it);
     else if (col16) hipLaunchKernelGGL((k_rx_qeq_sweep<true, false>), gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
     else hipLaunchKernelGGL((k_rx_qeq_sweep<false, false>), gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
     if (ev) { (void)hipEventRecord((*ev)[*ev_used + 1], st); *ev_used += 2; }
@@ -1111,6 +1265,10 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   hipLaunchKernelGGL(k_rx_back2, ga, dim3(TPB), 0, sb, d, v, P);
   if (side) (void)hipEventRecord(side->join, sb);
   hipLaunchKernelGGL(k_rx_hrow, gk, dim3(RX_KT), 0, st, d, v, P);
+  if (plan.precond) {
+    hipLaunchKernelGGL(k_rx_qeq_pm_rows, gu, dim3(QEQ_UT), 0, st, v, P);
+    hipLaunchKernelGGL(k_rx_qeq_pm_sym, gu, dim3(QEQ_UT), 0, st, v);
+  }
   hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v, plan.setup);
   sweep(-1);
   hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, -1);

@@ -18,6 +18,9 @@
 #ifndef RX_SWR   /* (at most 64: one wave does the row-local part of the sweep, a row per lane) */
 #define RX_SWR 64             /* rows per workgroup of the matrix sweep (8 per wave): the workgroup stages the gathered vector in LDS once for all of them (32: 400 against 410 evaluations/s, profiles/r04_e_*) */
 #endif
+#define RX_PM_MAX 8            /* entries of a preconditioner row: the atom and up to 7 neighbours within RX_PM_RADIUS (the nearest in list order) */
+#define RX_PM_RADIUS 2.0       /* Angstrom: the bonded neighbours; gated offline (tools/qeq_precond_gate.py, profiles/r05_qeq_precond_gate.txt):
+                                  1.7 .. 2.5 A save 58 .. 62 % of the iterations of the Jacobi preconditioner on PE-1620, 3.0 A only 17 % */
 #define RX_JMASK 0x00FFFFFF  /* row entry: [23:0] atom, [30:24] image code (sx+2) + 5 (sy+2) + 25 (sz+2) */
 #define RX_CODE0 62          /* code of the zero shift */
 
@@ -121,8 +124,17 @@ typedef struct {
   int RX_G *nbT;               // [npad][maxnb] the list rows once more, row-major (written with the list; read by the matrix build)
   double RX_G *s, *t;          // [npad] the two solutions
   double RX_G *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)
-  double RX_G *qwork;          // [8][npad]: four arrays of (s-system, t-system) pairs per atom: residual r, search direction d,
-                          // matrix-vector product q = H d, preconditioned residual z = r / eta (the vector the matrix sweeps gather)
+  double RX_G *qwork;          // [10][npad]: five arrays of (s-system, t-system) pairs per atom: residual r, search direction d,
+                          // matrix-vector product q = H d, preconditioned residual z = M r (the vector the matrix sweeps gather), and a
+                          // second residual array (the update of iteration `it` reads r of parity it & 1 and writes the other one: the
+                          // preconditioner gathers the NEW residuals of an atom's bonded neighbours, which other workgroups own)
+  // preconditioner of the conjugate gradients (round 5): a sparse approximate inverse on the bonded pattern -- row i of M = row i of
+  // the inverse of H restricted to i and its neighbours within RX_PM_RADIUS, symmetrised; pm_on = 0: the Jacobi one of fix qeq/reax
+  int pm_on, pm_pad_;
+  int RX_G *pm_len;            // [npad] entries of the row (the atom itself first)
+  int RX_G *pm_col;            // [RX_PM_MAX][npad]
+  double RX_G *pm_raw;         // [RX_PM_MAX][npad] rows of the local inverses
+  double RX_G *pm_val;         // [RX_PM_MAX][npad] symmetrised: the preconditioner
   double RX_G *qpart;          // per-block partial sums of the solver's scalar products (layout: md_reax.hip)
   int RX_G *qstat;             // [6] since the start of the run: iterations, solves, most iterations in one solve (cold solves aside), solves
                           // finished by the single-workgroup loop, (scratch), most iterations in one of the run's first (cold) solves

@@ -1,22 +1,66 @@
 #!/usr/bin/env python3
-"""usage: tools/kernel_table.py <rocprofv3 output dir> -- per-kernel table of the batch launches (largest grid per kernel name only)."""
+"""usage: tools/kernel_table.py <rocprofv3 output dir> [--min-grid-frac 0.25] -- per-kernel table of the BATCH launches of a bench run.
+
+A launch counts as a batch launch when its grid is at least `min-grid-frac` of the largest grid seen for that kernel name: the whole batch
+and its half / part batches are in, the single-replica launches of the equilibration run are out.  (Until round 4 only the launches with
+the LARGEST grid were kept, which for a run issued as part batches showed the two whole-batch "alone" updates and nothing of the timed
+loop: VERDICT r4.)  Launches of part batches overlap, so besides the per-launch statistics the table gives, per kernel, the UNION of its
+launch intervals (time with at least one launch of it running), and one union-based line for the whole run: busy time per step.  With
+more than one stream in use the same table follows per stream."""
 import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+frac = 0.25
+for i, a in enumerate(sys.argv):
+    if a == "--min-grid-frac":
+        frac = float(sys.argv[i + 1]); args = [x for x in args if x != sys.argv[i + 1]]
+f = glob.glob(args[0] + '/*/*kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
+grid = lambda r: int(r['Grid_Size_X']) * int(r.get('Grid_Size_Y', 1) or 1) * int(r.get('Grid_Size_Z', 1) or 1)
 gmax = collections.defaultdict(int)
 for r in rows:
-    g = int(r['Grid_Size_X']) * int(r['Grid_Size_Y'])
-    gmax[r['Kernel_Name']] = max(gmax[r['Kernel_Name']], g)
-agg = collections.defaultdict(lambda: [0, 0.0, 0])
-for r in rows:
-    if int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) != gmax[r['Kernel_Name']]:
-        continue
-    n = r['Kernel_Name'].split('(')[0]
-    d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
-    agg[n][0] += 1; agg[n][1] += d; agg[n][2] = max(agg[n][2], d)
-tot = sum(v[1] for v in agg.values())
-nstep = (sum(v[0] for n, v in agg.items() if 'k_pair' in n) or sum(v[0] for n, v in agg.items() if n.strip().endswith('k_rx_bonds'))
-         or max(v[0] for v in agg.values()))   # one k_pair (OPLS) or k_rx_bonds (ReaxFF) launch per MD step of the batch
-print(f"kernel time {tot/1e9:.3f} s over {nstep} steps = {tot/nstep/1e3:.1f} us per step")
-for n, v in sorted(agg.items(), key=lambda x: -x[1][1]):
-    print(f"{n[:44]:44s} calls {v[0]:5d}  avg {v[1]/v[0]/1e3:9.1f} us  max {v[2]/1e3:9.1f} us  share {100*v[1]/tot:5.1f}%  per-step {v[1]/nstep/1e3:8.1f} us")
+    gmax[r['Kernel_Name']] = max(gmax[r['Kernel_Name']], grid(r))
+batch = [r for r in rows if grid(r) >= frac * gmax[r['Kernel_Name']]]
+stream_of = lambda r: r.get('Stream_Id') or r.get('Queue_Id') or '0'
+
+
+def union(iv):
+    iv = sorted(iv)
+    tot, lo, hi = 0, None, None
+    for a, b in iv:
+        if hi is None or a > hi:
+            if hi is not None: tot += hi - lo
+            lo, hi = a, b
+        else:
+            hi = max(hi, b)
+    return tot + ((hi - lo) if hi is not None else 0)
+
+
+def table(rs, title):
+    agg = collections.defaultdict(lambda: [0, 0, 0, []])
+    for r in rs:
+        n = r['Kernel_Name'].split('(')[0]
+        a, b = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        v = agg[n]
+        v[0] += 1; v[1] += b - a; v[2] = max(v[2], b - a); v[3].append((a, b))
+    if not agg:
+        return
+    per_stream = collections.defaultdict(lambda: collections.defaultdict(int))
+    for r in rs:
+        per_stream[stream_of(r)][r['Kernel_Name'].split('(')[0]] += 1
+    step_kernel = next((n for n in agg if 'k_pair' in n), None) or next((n for n in agg if n.strip().endswith('k_rx_bonds')), None) or max(agg, key=lambda n: agg[n][0])
+    nstep = max(c[step_kernel] for c in per_stream.values() if step_kernel in c)   # one such launch per MD step on each stream that runs a part of the batch
+    tot = sum(v[1] for v in agg.values())
+    busy = union([iv for v in agg.values() for iv in v[3]])
+    print(f"== {title}: {len(rs)} batch launches on {len(per_stream)} stream(s); {nstep} steps (launches of {step_kernel.strip()[:40]} per stream)")
+    print(f"kernel time (sum of launch durations) {tot/1e9:.3f} s = {tot/nstep/1e3:.1f} us per step; busy time (union of all launch intervals) {busy/1e9:.3f} s = {busy/nstep/1e3:.1f} us per step")
+    for n, v in sorted(agg.items(), key=lambda x: -x[1][1]):
+        u = union(v[3])
+        print(f"{n[:44]:44s} calls {v[0]:6d}  avg {v[1]/v[0]/1e3:9.1f} us  max {v[2]/1e3:9.1f} us  share {100*v[1]/tot:5.1f}%  sum/step {v[1]/nstep/1e3:8.1f} us  union/step {u/nstep/1e3:8.1f} us  in flight {v[1]/max(u,1):4.2f}")
+
+
+table(batch, "all streams")
+streams = sorted({stream_of(r) for r in batch})
+if len(streams) > 1:
+    for s in streams:
+        table([r for r in batch if stream_of(r) == s], f"stream {s}")
