@@ -510,10 +510,12 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
 // ---- the preconditioner: a sparse approximate inverse on the bonded pattern ----
 // Row i of M = row i of (H[P, P])^-1 with P = {i} + its neighbours within RX_PM_RADIUS (from the near rows, a superset), then M := (M + M^T) / 2
 // in a second launch (a row needs its neighbours' rows).  H[P, P] is a handful of shielded Coulomb terms: a dense solve of at most 8 x 8 per
-// atom (symmetric positive definite: elimination without pivoting).  Rebuilt every step: 0.2 % of it.
-__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_pm_rows(const RxView *views, const RxParams *__restrict__ P) {
+// atom (symmetric positive definite: elimination without pivoting).  Rebuilt with the neighbour rows.
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_pm_rows(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
-  if (!V.pm_on) return;
+  // (built with the neighbour rows: a preconditioner may be stale -- one built at the first step of an evaluation and kept for all 31 saves the
+  // same 59 % of the iterations as one rebuilt every step, profiles/r05_qeq_precond_gate.txt -- and every run starts with a list build)
+  if (!V.pm_on || !sims[blockIdx.y].sc->rebuild) return;
   const int i = blockIdx.x * QEQ_UT + threadIdx.x;
   if (i >= V.n) return;
   const size_t np = V.npad;
@@ -565,9 +567,9 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_pm_rows(const RxView *views, 
   V.pm_len[i] = m;
   for (int k = 0; k < m; k++) { V.pm_col[(size_t)k * np + i] = col[k]; V.pm_raw[(size_t)k * np + i] = rhs[k]; }
 }
-__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_pm_sym(const RxView *views) {
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_pm_sym(const SimDev *sims, const RxView *views) {
   const RxView V = views[blockIdx.y];
-  if (!V.pm_on) return;
+  if (!V.pm_on || !sims[blockIdx.y].sc->rebuild) return;
   const int i = blockIdx.x * QEQ_UT + threadIdx.x;
   if (i >= V.n) return;
   const size_t np = V.npad;
@@ -1266,8 +1268,8 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   if (side) (void)hipEventRecord(side->join, sb);
   hipLaunchKernelGGL(k_rx_hrow, gk, dim3(RX_KT), 0, st, d, v, P);
   if (plan.precond) {
-    hipLaunchKernelGGL(k_rx_qeq_pm_rows, gu, dim3(QEQ_UT), 0, st, v, P);
-    hipLaunchKernelGGL(k_rx_qeq_pm_sym, gu, dim3(QEQ_UT), 0, st, v);
+    hipLaunchKernelGGL(k_rx_qeq_pm_rows, gu, dim3(QEQ_UT), 0, st, d, v, P);
+    hipLaunchKernelGGL(k_rx_qeq_pm_sym, gu, dim3(QEQ_UT), 0, st, d, v);
   }
   hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v, plan.setup);
   sweep(-1);

@@ -179,6 +179,36 @@ def test_charges_do_not_depend_on_how_the_solver_is_launched(ff, monkeypatch):
     assert np.abs(q0).max() > 0.05
 
 
+def test_the_preconditioner_changes_the_iteration_count_not_the_charges(ff, monkeypatch):
+    """fix qeq/reax's tolerance fixes the charges; the preconditioner only decides how many iterations it takes to get there.  The bonded-pattern
+    approximate inverse (default) and the reference's Jacobi preconditioner stop on the same measure, sqrt(r.D^-1 r) / |b|: same charges to the
+    tolerance's order, in well under half the iterations (gated offline first: profiles/r05_qeq_precond_gate.txt)."""
+    from scema_amd.systems import build_pe
+    d = build_pe(3, 5, 9, jitter=0.08, seed=5)      # PE-1620, the replica of BASELINE config 5: wide enough for one image per neighbour,
+    sym = ["C" if d["mass"][t] > 5 else "H" for t in d["type"]]   # which the bonded pattern needs (smaller boxes keep the Jacobi preconditioner)
+    x, box = d["x"], d["box"]
+    res = {}
+    for name, env in (("sai", None), ("jacobi", "0")):
+        if env is None:
+            monkeypatch.delenv("SCEMA_REAX_QEQ_PRECOND", raising=False)
+        else:
+            monkeypatch.setenv("SCEMA_REAX_QEQ_PRECOND", env)
+        for tol in (1e-6, 1e-10):
+            e = capi.Engine()
+            e.reax_configure(FFIELD, qeq_tol=tol)
+            e.register_replica("m", 1, capi.reax_system(sym, x, box))
+            r = e.reax_compute("m", 1)
+            res[(name, tol)] = (r["q"].copy(), r["qeq_iters"], r["f"].copy())
+            e.close()
+    q_ref = res[("jacobi", 1e-10)][0]
+    assert np.abs(res[("sai", 1e-10)][0] - q_ref).max() < 2e-8                      # the same linear systems (measured: 3.5e-9)
+    for name in ("sai", "jacobi"):
+        assert np.abs(res[(name, 1e-6)][0] - q_ref).max() < 5e-5, name              # the reference's tolerance: the same order of error either way
+    assert res[("sai", 1e-6)][1] < 0.6 * res[("jacobi", 1e-6)][1] and res[("sai", 1e-10)][1] < 0.6 * res[("jacobi", 1e-10)][1]
+    f_ref = res[("jacobi", 1e-10)][2]
+    assert np.abs(res[("sai", 1e-6)][2] - f_ref).max() < 1e-4 * np.abs(f_ref).max()
+
+
 def test_verlet_step_and_energy_conservation(ff, eng):
     sym, x, box = _pe_cell(ff, amp=0.02)
     n = len(sym)
