@@ -222,6 +222,9 @@ int scema_md_scatter_gathered(scema_md_engine *e, const double *gathered, scema_
  * there takes this rank's share back too); a host that scatters the gathered buffer itself calls this with failed != 0 / 0.  The
  * next scema_md_strain_batch lets an unsettled update stand. */
 int scema_md_settle_update(scema_md_engine *e, int32_t failed);
+/* How many updates the NEXT call found unsettled and let stand (world > 1, no communicator attached, neither scema_md_scatter_gathered nor
+ * scema_md_settle_update called in between): 0 in a host that follows the protocol; a warning is printed the first time. */
+int64_t scema_md_unsettled_updates(const scema_md_engine *e);
 
 /* The planner alone (scema_amd/csrc/host/sim_plan.h; pure host arithmetic, no GPU): owner/pos/cap as above, moves =
  * (simulation, from, to) triples of the states that would travel; cost NULL = equal cost; commit != 0 records the

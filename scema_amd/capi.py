@@ -36,7 +36,7 @@ SYMBOLS = [
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_comm_handshakes", "scema_md_state_owner", "scema_md_last_plan",
     "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update", "scema_md_kspace_setup",
     "scema_md_save_state_dump", "scema_md_replica_natoms", "scema_md_save_replica_file", "scema_md_equilibrate", "scema_md_debug_minimize", "scema_md_debug_run_nh",
-    "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_concurrency", "scema_md_batch_split", "scema_md_get_concurrency", "scema_md_reax_debug_compute", "scema_md_reax_stats",
+    "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_concurrency", "scema_md_batch_split", "scema_md_get_concurrency", "scema_md_unsettled_updates", "scema_md_reax_debug_compute", "scema_md_reax_stats",
 ]
 COMM_ID_BYTES = 128
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -432,6 +432,10 @@ class Engine:
     def reax_concurrency(self, halves: int = -1, overlap: int = -1):
         """how a ReaxFF batch is issued (two half batches on two streams; bond-order chain next to the charge chain): 1 / 0, -1 leaves it"""
         self._chk(lib().scema_md_reax_concurrency(self.h, C.c_int32(halves), C.c_int32(overlap)))
+
+    def unsettled_updates(self) -> int:
+        lib().scema_md_unsettled_updates.restype = C.c_int64
+        return int(lib().scema_md_unsettled_updates(self.h))
 
     def batch_split(self, on: int = -1):
         self._chk(lib().scema_md_batch_split(self.h, C.c_int32(on)))

@@ -200,6 +200,17 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     if (!collective_call) return fail(e, SCEMA_MD_ERR_DEVICE, "hipSetDevice(%d) failed", e->p.device);
     pre_status = fail(e, SCEMA_MD_ERR_DEVICE, "hipSetDevice(%d) failed on rank %d", e->p.device, rank);
   }
+  if (e->pending.active) {
+    // An update of a world > 1 without a communicator that nobody settled (scema_md_scatter_gathered / scema_md_settle_update): it is taken
+    // to stand.  A host written against the round-3 interface, which scatters the gathered buffer itself, ends up here after every update:
+    // if another rank's share had failed, that rank has rolled back and this one commits -- the directories part ways and the next plan hash
+    // says so.  Counted (scema_md_unsettled_updates) and said once.
+    e->unsettled_updates += 1;
+    if (e->unsettled_updates == 1)
+      fprintf(stderr, "[scema_md] warning: the previous update (rank %d of %d, no communicator attached) was never settled -- call scema_md_scatter_gathered or "
+                      "scema_md_settle_update once the stresses of all ranks are known; it is taken to stand (INTEGRATION.md, \"Settling an update\")\n",
+              e->pending.rank, e->pending.plan.world);
+  }
   (void)settle_pending(e, false);    // an update nobody objected to stands
   e->last_plan = scema::SimPlan();   // a call that ends before planning leaves no plan behind
   // ---- the request itself: checked on every rank for every simulation, so that a request that cannot run is refused by
@@ -436,6 +447,8 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
 }
 
 int scema_md_strain(scema_md_engine *e, scema_mdsim *sim, int32_t hooke_mode) { return scema_md_strain_batch(e, sim, 1, hooke_mode, 0, 1); }
+
+int64_t scema_md_unsettled_updates(const scema_md_engine *e) { return e ? e->unsettled_updates : 0; }
 
 void *scema_md_local_stress_device_ptr(scema_md_engine *e) { return e ? e->d_local_stress.p : nullptr; }
 int32_t scema_md_local_stress_count(const scema_md_engine *e) { return e ? e->local_stress_count : 0; }

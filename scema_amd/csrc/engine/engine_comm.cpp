@@ -230,6 +230,7 @@ int scema_md_comm_unique_id(void *id) {
 int scema_md_comm_init_rccl(scema_md_engine *e, const void *id, int32_t rank, int32_t world) {
   if (!e || !id || world <= 0 || rank < 0 || rank >= world) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
   if (e->comm.kind) return fail(e, SCEMA_MD_ERR_ARG, "a communicator is already attached");
+  (void)settle_pending(e, false);   // (an update of the communicator-less transport that is still waiting for its verdict stands)
   HIPCHK(hipSetDevice(e->p.device));
   ncclUniqueId u;
   std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
@@ -244,6 +245,7 @@ int scema_md_comm_init_host(scema_md_engine *e, int32_t rank, int32_t world, sce
                             scema_md_host_recv_fn recv, void *ctx) {
   if (!e || !allgather || world <= 0 || rank < 0 || rank >= world) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
   if (e->comm.kind) return fail(e, SCEMA_MD_ERR_ARG, "a communicator is already attached");
+  (void)settle_pending(e, false);
   e->comm.kind = 2;
   e->comm.rank = rank;
   e->comm.world = world;

@@ -111,6 +111,8 @@ def test_without_a_communicator_a_remote_source_state_is_an_error(small_pe):
     # the failed call left the store as it was: qp 0 continues normally
     out3 = eng.strain_batch([capi.make_sim(0, "pe", 1, st), capi.make_sim(1, "pe", 1, st)], rank=0, world=2)
     assert [o.stress_updated for o in out3] == [1, 0]
+    # this caller never settled its updates (no scatter_gathered, no settle_update): each next call let the one before stand -- and counted it
+    assert eng.unsettled_updates() >= 1
     eng.close()
 
 
@@ -156,6 +158,7 @@ def test_callback_transport_takes_this_ranks_share_back_when_another_rank_failed
     third = np.array(list(out3[0].stress))
     assert np.abs(third - second).max() < 1e-8 * np.abs(second).max() and np.abs(second - first).max() > 1e-6 * np.abs(first).max()
     assert eng.has_state(8, "pe", 1) == mine_new and not np.array_equal(eng.get_state(0, "pe", 1)[1], x_before)
+    assert eng.unsettled_updates() == 0      # every update of this caller was settled by scatter_gathered
     eng.close()
 
 

@@ -48,8 +48,10 @@ def table(rs, title):
     per_stream = collections.defaultdict(lambda: collections.defaultdict(int))
     for r in rs:
         per_stream[stream_of(r)][r['Kernel_Name'].split('(')[0]] += 1
-    step_kernel = next((n for n in agg if 'k_pair' in n), None) or next((n for n in agg if n.strip().endswith('k_rx_bonds')), None) or max(agg, key=lambda n: agg[n][0])
-    nstep = max(c[step_kernel] for c in per_stream.values() if step_kernel in c)   # one such launch per MD step on each stream that runs a part of the batch
+    step_kernel = max((n for n in agg if 'k_pair' in n), key=lambda n: agg[n][0], default=None) or next((n for n in agg if n.strip().endswith('k_rx_bonds')), None) or max(agg, key=lambda n: agg[n][0])
+    # one launch of the step kernel per MD step on each stream that runs a part of the batch (k_pair has a variant per virial setting: all count)
+    fam = [n for n in agg if 'k_pair' in n] if 'k_pair' in step_kernel else [step_kernel]
+    nstep = max(sum(c[n] for n in fam) for c in per_stream.values())
     tot = sum(v[1] for v in agg.values())
     busy = union([iv for v in agg.values() for iv in v[3]])
     print(f"== {title}: {len(rs)} batch launches on {len(per_stream)} stream(s); {nstep} steps (launches of {step_kernel.strip()[:40]} per stream)")
