@@ -48,6 +48,7 @@ extern __shared__ int s_build[];  // [3][capj + 64] FP32 records of the j table 
 #define NB_MAXRUN 128    // slot runs of one tile's candidates (own cell + half stencil; 20 for PE-10k)
 #define NB_MAXUNIT 1024  // 64-candidate units of one tile (85 for PE-10k)
 #define NB_UPW 4         // units per wave and round (TW * NB_UPW = 32: scan32_incl)
+#define NB_LISTPAD 256   // dummy entries behind a group list (the fast loop reads up to 192 + 63 entries past the end)
 #define NB_RECPAD 64     // records behind the table: [capj] is the dummy the lanes past the end of a list read
 #define NB_FAR 1.0e18f   // FP32 place of the dummy record and (negated) of the pad atoms of an i-cluster: (2e18)^2 * 3 is finite
 
@@ -319,9 +320,14 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     return;
   }
   if (threadIdx.x == 0) { S.tile_nj[cell] = nj; atomicMax(&sc.maxj_seen, nj); }
+  // A group list is followed by NB_LISTPAD dummy entries (the record behind the table): the row loops read their list entries two chunks
+  // ahead without a bounds test.  A list that has no room for them counts as overflowed (the group walks the whole table).
 #pragma unroll
-  for (int q = 0; q < NQ; q++)
-    if ((int)threadIdx.x == q) s_qn[q] = (qn[q] > qcap) ? -1 : qn[q];
+  for (int q = 0; q < NQ; q++) {
+    const bool fits = qn[q] + NB_LISTPAD <= qcap;
+    if ((int)threadIdx.x == q) s_qn[q] = fits ? qn[q] : -1;
+    if (fits && threadIdx.x < NB_LISTPAD) s_qlist[q * qcap + qn[q] + threadIdx.x] = (unsigned short)capjs;
+  }
   // (the table entries of this tile written above are read back by this workgroup's row loops: stores and loads of one workgroup to
   // global memory are ordered by the barrier once the stores have left the waves)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     const unsigned short *ql = s_qlist + qq * qcap;
     // entry k of the cluster's candidate list as (table index | type of j << 12); past the end: the dummy record behind the table.
     // (A group list holds exactly that; the whole-table walk of an overflowed list takes the type from the table entry.)
-    auto list_at = [&](int k) -> int { return (k < nl) ? (qall ? k : (int)ql[k]) : capjs; };
+    auto list_at = [&](int k) -> int { return qall ? ((k < nl) ? k : capjs) : (int)ql[k]; };
 #ifdef PAIR_TIMING
     if (lane == 0) { atomicAdd(&sc.dbg[10], (unsigned long long)((nl + 63) >> 6)); atomicAdd(&sc.dbg[11], 1ull); }
     __builtin_amdgcn_s_waitcnt(0);
@@ -451,20 +457,23 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
               if (S.slot_of[S.ex_list[exb[a] + e]] == j) { mask &= ~(1 << a); refm &= ~(1 << a); }                                        \
         }                                                                                                                                 \
       }                                                                                                                                   \
-      /* segments: A straight into the row (the store itself at the top of the next turn); B, C1, C2 into the wave's staging list */     \
+      /* Segments: A straight into the row (the store itself at the top of the next turn); B, C1, C2 into the wave's staging list with ONE store. */ \
+      /* Lanes without an entry get a distance beyond every threshold, so that the four class masks are four plain compares (a ballot of a */      \
+      /* composed condition costs two more vector instructions each), and the staging index is selected, clamped into the list (an index that */  \
+      /* leaves its region means an overflow, which `bad` reports below) and used by one predicated store instead of three. */                    \
       {                                                                                                                                   \
-        const bool isA = mask && RMIN < RA, isB = mask && !isA && RMIN < RB, isS = mask && !isA && !isB;                                  \
-        const bool isD = isS && !(RMIN < RC), isC = isS && !isD;                                                                          \
-        const unsigned long long mA = __ballot(isA), mB = __ballot(isB), mC = __ballot(isC), mD = __ballot(isD);                          \
-        if (mask) {                                                                                                                       \
-          const unsigned short e16 = (unsigned short)((base + lane) | (mask << 12));                                                      \
-          if (isA) {                                                                                                                      \
-            const int pos = nA + popc_below(mA);                                                                                          \
-            const int ty = qall ? (int)((unsigned)jt >> 28) : (lt >> 12);                                                                 \
-            if (pos < maxrow - 64) { posA_prev = pos; entA_prev = l | (ty << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT); }                    \
-          } else if (isB) { const int pos = nB + popc_below(mB); if (pos < capBC) lb[pos] = e16; }                                        \
-          else if (isC) { const int pos = capBC - 1 - (nC + popc_below(mC)); if (pos >= 0) lb[pos] = e16; }                               \
-          else { const int pos = nD + popc_below(mD); if (pos < capD) lb[capBC + pos] = e16; }                                            \
+        typedef decltype(RMIN) nb_rm_t;                                                                                                   \
+        const nb_rm_t rmx = mask ? RMIN : (nb_rm_t)3.0e38f;                                                                               \
+        const bool inA = rmx < RA, inAB = rmx < RB, inABC = rmx < RC, inAll = mask != 0;                                                  \
+        const unsigned long long mA = __ballot(inA), mAB = __ballot(inAB), mABC = __ballot(inABC), mAll = __ballot(inAll);                \
+        const unsigned long long mB = mAB & ~mA, mC = mABC & ~mAB, mD = mAll & ~mABC;                                                     \
+        const int pB = nB + popc_below(mB), pC = capBC - 1 - (nC + popc_below(mC)), pD = capBC + nD + popc_below(mD);                     \
+        const int idx = min(max(inAB ? pB : (inABC ? pC : pD), 0), capB - 1);                                                             \
+        if (inAll && !inA) lb[idx] = (unsigned short)((base + lane) | (mask << 12));                                                      \
+        if (inA) {                                                                                                                        \
+          const int pos = nA + popc_below(mA);                                                                                            \
+          const int ty = qall ? (int)((unsigned)jt >> 28) : (lt >> 12);                                                                   \
+          if (pos < maxrow - 64) { posA_prev = pos; entA_prev = l | (ty << E_TYPE_SHIFT) | (mask << E_MASK_SHIFT); }                      \
         }                                                                                                                                 \
         nA += __popcll(mA); nB += __popcll(mB); nC += __popcll(mC); nD += __popcll(mD);                                                   \
       }                                                                                                                                   \
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
           mask |= (r2 < rl2e) ? (1 << a) : 0;
           r2a[a] = r2;
         }
-        const float rmin = fminf(fminf(r2a[0], r2a[1]), fminf(r2a[2], r2a[3]));
+        const float rmin = vmin3_f32(vmin_f32(r2a[0], r2a[1]), r2a[2], r2a[3]);
         NB_CHUNK_TAIL(rmin, ra2e, rb2e, rc2e, excl2e)
       };
       // The pipeline: list entries two chunks ahead, record and table entry one chunk ahead (a record's address needs its list entry:
@@ -663,9 +672,9 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
 
 
 int mdk_neigh_capB(int maxrow) { return (int)(0.6 * maxrow) / 64 * 64 + 64; }
-// capacity of one group's list (16-bit table indices): 3/4 of the table (a quarter of PE-10k's clusters reaches 72 %); a group that reaches more walks the whole table instead.  (The kernel's LDS must stay below 80 KB for two workgroups per CU: at 83 KB it ran 1.75 times longer.)
+// capacity of one group's list (16-bit entries): 13/16 of the table (a quarter of PE-10k's clusters reaches 72 %, and NB_LISTPAD dummy entries follow the list); a group that reaches more walks the whole table instead.  (The kernel's LDS must stay below 80 KB for two workgroups per CU: at 83 KB it ran 1.75 times longer.)
 static int neigh_qcap(int capj) {
-  static const int n16 = scema_env("SCEMA_MD_QCAP16") ? atoi(scema_env("SCEMA_MD_QCAP16")) : 12;   // (test switch: small values force the whole-table path)
+  static const int n16 = scema_env("SCEMA_MD_QCAP16") ? atoi(scema_env("SCEMA_MD_QCAP16")) : 13;   // (test switch: small values force the whole-table path)
   return (n16 * capj / 16 + 63) / 64 * 64;
 }
 size_t mdk_neigh_lds_bytes(int capj, int maxrow) {

@@ -106,6 +106,16 @@ __device__ __forceinline__ double vmin_f64(double a, double b) {
   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ float vmin_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin3_f32(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ double vmax_f64(double a, double b) {
   double r;
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
