@@ -462,8 +462,10 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   // finishes in one workgroup (80 us per iteration).  Scan on the 72-replica set, slowest solve 15: 13 launches 543, 14: 591, 15: 603,
   // 16: 598, 18: 590 evaluations/s (tools/reax_launch_scan.sh, profiles/r04_zh_launch_scan.txt)
   if (!e->rx_qeq_launch_pinned) {
-    if (most > 0) e->rx_qeq_launch = std::max(8, most + 1);
-    if (most_cold > 0) e->rx_qeq_launch_cold = std::max(8, most_cold + 1);
+    // (the floor of 8 dated from the Jacobi preconditioner's 11 iterations per solve; with 3.9 per solve -- slowest 5 -- it issued 8: scan
+    // with the round-5 preconditioner, 72 replicas: 3 launches 577, 4: 747, 5: 978, 6: 969, 7: 965, 8: 959 evaluations/s)
+    if (most > 0) e->rx_qeq_launch = std::max(4, most + 1);
+    if (most_cold > 0) e->rx_qeq_launch_cold = std::max(4, most_cold + 1);
   }
   if (fault & 16) return fail(e, SCEMA_MD_ERR_ARG, "a simulation became unstable (non-finite or runaway atom positions): overlapping atoms or a time step too long for ReaxFF");
   if (fault & 32) return fail(e, SCEMA_MD_ERR_ARG, "charge equilibration did not converge to %.1e in %d iterations", e->rx_qeq_tol, e->rx_qeq_maxiter);

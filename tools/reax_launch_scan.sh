@@ -1,5 +1,5 @@
 #!/bin/bash
-for L in 0 12 13 14 15 16 18; do
+for L in ${@:-0 12 13 14 15 16 18}; do
   if [ $L = 0 ]; then envs=""; else envs="SCEMA_REAX_QEQ_LAUNCH=$L"; fi
   env $envs python bench.py --force-field reax --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
