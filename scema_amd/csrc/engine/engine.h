@@ -159,8 +159,13 @@ struct RxSlot {
 struct ListSig {
   bool valid = false;
   const void *topo = nullptr;
+  const void *state = nullptr;   // the state the rows were last built for (a hint: whether they still hold is decided on the device)
   int nc[3] = {0, 0, 0}, capj = 0, maxneigh = 0, npad = 0;
   double rlist = 0.0, cut_lj = 0.0, cut_coul = 0.0;
+  // the list's scalars at the end of the run that left it: what the displacement test of the next run needs, and the statistics
+  double corners_hold[24];
+  int ago = 0, maxj_seen = 0;
+  unsigned long long nentries = 0, nentries_ref = 0, nrowent = 0;
 };
 struct Slot {
   std::unique_ptr<RxSlot> rx;
@@ -254,8 +259,10 @@ struct RunSpec {
   std::vector<EwaldSetup> *ew_keep = nullptr;   // k-space setup of the run's first segment, reused by the later ones
   int minimize = 0, min_maxiter = 0, min_maxeval = 0;
   double min_etol = 0, min_ftol = 0;
-  int keep_list = 0;      // this run follows another one of the same simulations on the same slots (phase B after phase A): the neighbour rows on the
-                          // device stand where the cell grid of the new run can be the old one (SimDev::keep_list)
+  int keep_list = 0;      // 1: this run follows another one of the same simulations on the same slots (phase B after phase A): the neighbour rows on the
+                          // device stand where the cell grid of the new run can be the old one (SimDev::keep_list).  2: the slots may still hold the rows
+                          // of these states from the update before: kept where the device finds every atom within half the skin of the positions
+                          // the rows were built for (k_keep_validate)
   int qeq_continue = 0;   // ReaxFF: this run follows another one of the same simulations on the same slots (phase B after phase A): the
                           // charge-equilibration history is still in place
 };

@@ -80,6 +80,7 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
     RunSpec A;
     A.deform = 1;
     A.use_shake = opt.shake_a;
+    A.keep_list = (attempt == 0) ? 2 : 0;   // the slots may hold these states' rows from the update before (a retry after an overflow rebuilds)
     for (int i = 0; i < ns; i++) chunk[i].nsteps = chunk[i].nts;
     const double t_a0 = wall_s();
     rc = opt.phase_a ? run_phase(e, chunk, A) : SCEMA_MD_OK;

@@ -166,6 +166,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     int maxnbn = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rnear * rnear * rnear * 1.5 * e->neigh_grow) + 32;
     maxnbn = (maxnbn + 7) / 8 * 8;
     Slot &sl = *e->slots[i];
+    sl.sig.valid = false;   // (this run overwrites xhold and wrapn of the slot: cell rows of an OPLS run that it may still hold are void)
     rc = ensure_slot(e, sl, n, 64, 1, 0, 64);
     if (rc) return rc;
     if (!sl.rx) sl.rx.reset(new RxSlot());

@@ -157,6 +157,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const int hbeg[2] = {0, nhalf == 2 ? (ns + 1) / 2 : ns}, hcnt[2] = {nhalf == 2 ? (ns + 1) / 2 : ns, nhalf == 2 ? ns / 2 : 0};
   e->h_sims.assign(ns, SimDev());
   int maxbt = 1, maxloc = 1, maxcoef = 0;
+  bool any_validate = false;   // some simulation may keep the rows its slot holds from the update before (SimDev::keep_list == 2)
   int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxunits = 0, maxsteps = 0;
   // k-vector tables of all simulations (indices, row run lengths, groups), packed into one upload
   std::vector<int> &kpack = e->h_kpack;
@@ -278,7 +279,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     {
       const ListSig &g = e->slots[i]->sig;
       if (spec.keep_list && keep_lists && g.valid && g.topo == (const void *)&T && g.rlist == rlist && g.cut_lj == P.cut_lj && g.cut_coul == P.cut_coul &&
-          !hsc.force_rebuild && !hsc.overflow) {
+          (spec.keep_list == 1 || g.state == (const void *)A.st) && !hsc.force_rebuild && !hsc.overflow) {
         int mst[3], cj = 0, mn = 0;
         if (size_grid(g.nc, mst, cj, mn) && cj <= g.capj && mn <= g.maxneigh && padded_slots(T.natoms, g.nc[0] * g.nc[1] * g.nc[2]) == g.npad) {
           keep = fits = true;
@@ -287,7 +288,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
         }
       }
     }
-    S.keep_list = keep ? 1 : 0;
+    S.keep_list = keep ? spec.keep_list : 0;
+    any_validate = any_validate || S.keep_list == 2;
     // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
     // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
     const bool small_batch = ns <= 8;   // replicas up to which the most-cells grid is taken (scanned in round 2: tools/small_batch_scan.sh)
@@ -569,6 +571,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     const SimDev *Dh = D + hbeg[h];
     const int nh = hcnt[h];
     mdk_phase_init(st, Dh, nh);
+    if (any_validate) mdk_keep_validate(st, Dh, nh, maxatoms);
     mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
     { const int rcp = pppm_fork(st, hbeg[h], nh, true); if (rcp) return rcp; }
     mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
@@ -842,7 +845,14 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   e->overflow_bits = fault;
   if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
   if (fault & 64) return SCEMA_MD_ERR_OVERFLOW;   // the barostat took the box out of the range this segment was laid out for
-  for (int i = 0; i < ns; i++) e->slots[i]->sig.valid = true;   // the rows on the device hold for the positions this run ended at
+  for (int i = 0; i < ns; i++) {   // the rows on the device hold for the positions this run ended at
+    ListSig &g = e->slots[i]->sig;
+    const SimScalars &c = e->h_sc[i];
+    g.valid = true;
+    g.state = (const void *)sims[i].st;
+    std::memcpy(g.corners_hold, c.corners_hold, sizeof g.corners_hold);
+    g.ago = c.ago; g.maxj_seen = c.maxj_seen; g.nentries = c.nentries; g.nentries_ref = c.nentries_ref; g.nrowent = c.nrowent;
+  }
   return SCEMA_MD_OK;
 }
 
@@ -855,6 +865,14 @@ int prepare_slots(scema_md_engine *e, std::vector<ActiveSim> &sims) {
     std::memset(&e->h_sc[i], 0, sizeof(SimScalars));
     std::memcpy(e->h_sc[i].box, sims[i].st->box, 9 * sizeof(double));
     e->h_sc[i].vscale = 1.0;
+    // the slot may still hold this state's neighbour rows from the update before: their scalars come back with them (run_phase and the
+    // device decide whether the rows are kept; a slot that last served another state leaves the zeros, which force the build)
+    const ListSig &g = e->slots[i]->sig;
+    if (g.valid && g.state == (const void *)sims[i].st) {
+      std::memcpy(e->h_sc[i].corners_hold, g.corners_hold, sizeof g.corners_hold);
+      e->h_sc[i].ago = g.ago; e->h_sc[i].maxj_seen = g.maxj_seen;
+      e->h_sc[i].nentries = g.nentries; e->h_sc[i].nentries_ref = g.nentries_ref; e->h_sc[i].nrowent = g.nrowent;
+    }
   }
   HIPCHK(hipMemcpyAsync(e->d_sc.p, e->h_sc.data(), (size_t)ns * sizeof(SimScalars), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

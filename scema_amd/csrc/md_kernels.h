@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 struct SimDev;
 void mdk_phase_init(hipStream_t st, const SimDev *d, int ns);
+void mdk_keep_validate(hipStream_t st, const SimDev *d, int ns, int maxatoms);
 void mdk_setup_post(hipStream_t st, const SimDev *d, int ns);
 void mdk_pre(hipStream_t st, const SimDev *d, int ns);
 void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, bool pack = false);   // pack: also the slot records of k_pair (then no k_pack)

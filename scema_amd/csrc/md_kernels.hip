@@ -48,12 +48,29 @@ __global__ void k_phase_init(const SimDev *sims) {
     // the last force evaluation, for which the rows on the device were checked, so they stand, with their age and reference positions.
     // The far band is walked in the set-up evaluation (what moved since the build is only looked at from step 1 on).  A box flip that
     // is still pending forces the build as it would between two steps.  Results do not depend on when a list is built.
-    const int keep = S.keep_list && !sc.force_rebuild;
+    int keep = S.keep_list && !sc.force_rebuild;
+    sc.deltasq = 0.0;
+    if (keep && S.keep_list == 2) {
+      // rows from the update before: they stand only if the list's own test says so -- every atom within half the skin (less the motion of
+      // the box corners) of the position the rows were built for.  The box part here, the atoms in k_keep_validate.  A slot that last
+      // served another state arrives with zeroed reference corners: the corner motion then exceeds any skin and the build is made.
+      double c[24];
+      box_corners(sc.box, c);
+      double d1 = 0.0, d2 = 0.0;
+      for (int k = 0; k < 8; k++) {
+        const double dx = c[3 * k] - sc.corners_hold[3 * k], dy = c[3 * k + 1] - sc.corners_hold[3 * k + 1], dz = c[3 * k + 2] - sc.corners_hold[3 * k + 2];
+        const double d = sqrt(dx * dx + dy * dy + dz * dz);
+        if (d > d1) { d2 = d1; d1 = d; }
+        else if (d > d2) d2 = d;
+      }
+      const double delta = 0.5 * (S.skin - (d1 + d2));
+      if (delta > 0.0) sc.deltasq = delta * delta;
+      else keep = 0;
+    }
     if (!keep) sc.ago = 0;
     sc.check = 1;
     sc.rebuild = keep ? 0 : 1;
     sc.force_rebuild = 0;
-    sc.deltasq = 0.0;
     sc.far_dsq = 1.0e300;
     sc.need_far = keep ? 1 : 0;
     sc.nfar_steps = 0;
@@ -64,6 +81,19 @@ __global__ void k_phase_init(const SimDev *sims) {
   }
   for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;
   for (int k = threadIdx.x; k < S.ncells; k += blockDim.x) S.cell_count[k] = 0;
+}
+
+// k_keep_validate : rows kept from the update before (SimDev::keep_list == 2) stand only while every atom is within the list's displacement
+// bound of its reference position -- the test k_initial_integrate makes every step, here for the positions the run starts from
+__global__ __launch_bounds__(TPB) void k_keep_validate(const SimDev *sims) {
+  const SimDev &S = sims[blockIdx.y];
+  if (S.keep_list != 2) return;
+  SimScalars &sc = *S.sc;
+  if (sc.rebuild) return;
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= S.natoms) return;
+  const double dx = S.x[3 * i] - S.xhold[3 * i], dy = S.x[3 * i + 1] - S.xhold[3 * i + 1], dz = S.x[3 * i + 2] - S.xhold[3 * i + 2];
+  if (!(dx * dx + dy * dy + dz * dz <= sc.deltasq)) sc.rebuild = 1;   // (NaN-safe)
 }
 
 // k_setup_post : after the step-0 force evaluation: fix nvt setup (t_current, chain masses)
@@ -1285,6 +1315,7 @@ static inline dim3 grid2(int nx, int ns) { return dim3((unsigned)nx, (unsigned)n
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void mdk_phase_init(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_phase_init, dim3(ns), dim3(64), 0, st, d); }
+void mdk_keep_validate(hipStream_t st, const SimDev *d, int ns, int maxatoms) { hipLaunchKernelGGL(k_keep_validate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d); }
 void mdk_setup_post(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_setup_post, dim3(ns), dim3(64), 0, st, d); }
 void mdk_pre(hipStream_t st, const SimDev *d, int ns) { hipLaunchKernelGGL(k_pre, dim3(ns), dim3(64), 0, st, d); }
 void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, bool pack) {
