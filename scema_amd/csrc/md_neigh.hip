@@ -214,7 +214,6 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     const int q = (threadIdx.x - 64) / 6, k = (threadIdx.x - 64) % 6;
     s_qboxf[q][k] = (float)(s_qbox[q][k] - (k % 3 == 0 ? ox : k % 3 == 1 ? oy : oz));
   }
-  const float hx = (float)(bhi0 - ox), hy = (float)(bhi1 - oy), hz = (float)(bhi2 - oz);   // half extents of the cell's box (the origin is its centre)
   __syncthreads();
   const int nunit = s_ub[NB_MAXRUN];
 #ifdef PAIR_TIMING
@@ -262,17 +261,16 @@ __global__ __launch_bounds__(TT, 4) void k_neigh_build(const SimDev *__restrict_
     for (int i = 0; i < NB_UPW; i++) {
       // the candidate's image relative to the tile's origin, FP64 up to the conversion (a pad's 1e15 stays a finite FP32 number)
       xf[i] = (float)(px[i] + (s_shift[3 * cv[i]] - ox)); yf[i] = (float)(py[i] + (s_shift[3 * cv[i] + 1] - oy)); zf[i] = (float)(pz[i] + (s_shift[3 * cv[i] + 2] - oz));
-      {
-        const float ex = fmaxf(0.f, fabsf(xf[i]) - hx), ey = fmaxf(0.f, fabsf(yf[i]) - hy), ez = fmaxf(0.f, fabsf(zf[i]) - hz);
-        ok[i] = valid[i] && (home[i] || ex * ex + ey * ey + ez * ez < rl2e);
-      }
+      // a candidate enters the table if some GROUP can reach it (the groups' boxes lie inside the cell's: a test against the cell's box would
+      // only admit candidates that no cluster can list); the own cell's slots all enter (table index l <-> slot cs + l)
       okq[i] = 0;
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const float *bq = s_qboxf[q];
         const float ex = fmaxf(0.f, fmaxf(bq[0] - xf[i], xf[i] - bq[3])), ey = fmaxf(0.f, fmaxf(bq[1] - yf[i], yf[i] - bq[4])), ez = fmaxf(0.f, fmaxf(bq[2] - zf[i], zf[i] - bq[5]));
-        okq[i] |= (ok[i] && ex * ex + ey * ey + ez * ez < rl2e) ? (1u << q) : 0u;
+        okq[i] |= (valid[i] && ex * ex + ey * ey + ez * ez < rl2e) ? (1u << q) : 0u;
       }
+      ok[i] = valid[i] && (home[i] || okq[i] != 0u);
       m[i] = __ballot(ok[i]);
       const int ui = wave * NB_UPW + i;
       if (lane == 0) s_ucnt[par][0][ui] = __popcll(m[i]);
