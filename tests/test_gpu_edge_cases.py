@@ -554,3 +554,75 @@ def test_rarely_taken_list_build_paths_give_the_same_lists():
         assert np.all(np.isfinite(b["en"])) and np.all(np.isfinite(b["w"])), name
         assert np.abs(np.array(a["f"]) - np.array(b["f"])).max() < 1e-11 * np.abs(np.array(a["f"])).max(), name
         assert np.abs(np.array(a["en"]) - np.array(b["en"])).max() < 1e-11 * np.abs(np.array(a["en"])).max(), name
+
+
+def _child(code, env):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, **env))
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_fp32_list_builds_list_a_superset_and_change_no_force():
+    """k_neigh_build tests its candidates in FP32 on tile-relative coordinates against a radius widened by the error bound of that arithmetic
+    (every build but the first of a run; SCEMA_MD_NEIGH_EXACT=0: the first too, =1: none -- read once per process, hence child processes).  The
+    rows are then a superset of the exact ones by a band of ~1e-5 of the pairs, k_pair tests every r^2 in FP64: same forces, same trajectory."""
+    code = ("import json, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "d = build_pe(4, 6, 12, jitter=0.05, seed=11, shake_project=True)\n"
+            "e = capi.Engine()\n"
+            "e.register_replica('g0', 1, d)\n"
+            "f, en, w, info = e.debug_compute('g0', 1, use_shake=True)\n"
+            "e.set_state(5, 'g0', 1, d['box'], d['x'], d['v'])\n"
+            "e.debug_run('g0', 1, 40, 2.0, 300.0, qp=5, nvt=True, use_shake=True, rates=[2e-5, -1e-5, 1e-5, 3e-6, -2e-6, 1e-6])\n"
+            "x = e.get_state(5, 'g0', 1)[1]\n"
+            "print(json.dumps({'f': np.asarray(f).ravel().tolist(), 'npairs': float(info['npairs']), 'x': np.asarray(x).ravel().tolist(), 'e': np.asarray(en)[:7].tolist()}))\n")
+    exact = _child(code, {"SCEMA_MD_NEIGH_EXACT": "1"})
+    dflt = _child(code, {})
+    fp32 = _child(code, {"SCEMA_MD_NEIGH_EXACT": "0"})
+    fe = np.array(exact["f"])
+    assert dflt["npairs"] == exact["npairs"]                                    # the first build of a run is the exact one
+    assert exact["npairs"] <= fp32["npairs"] <= exact["npairs"] * (1 + 1e-4)    # the eps band: a few pairs in a hundred thousand
+    for other in (dflt, fp32):
+        assert np.abs(np.array(other["f"]) - fe).max() < 1e-11 * np.abs(fe).max()
+        assert np.abs(np.array(other["e"]) - np.array(exact["e"])).max() < 1e-10 * np.abs(exact["e"]).max()
+        # 40 steps of NVT + SHAKE + deform with list rebuilds: the same trajectory to the noise of the FP64 atomics
+        assert np.abs(np.array(other["x"]) - np.array(exact["x"])).max() < 1e-8
+
+
+def test_kept_neighbour_rows_equal_rebuilt_ones(small_pe):
+    """Neighbour rows survive from the straining run to the sampling run and from one update to the next where the device finds every atom
+    within the list's displacement bound of its reference position (k_keep_validate); SCEMA_MD_KEEP_LIST=0 rebuilds at every run start.  An
+    update sequence in which one state is REPLACED between two updates (its rows no longer fit: the build must be made) and another continues:
+    same stresses either way."""
+    code = ("import json, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "d = build_pe(2, 3, 5, jitter=0.05, seed=7); d['box'][6:9] = [0.7, -0.4, 0.5]\n"
+            "kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)\n"
+            "e = capi.Engine(capi.default_params(**kw))\n"
+            "e.register_replica('pe', 1, d)\n"
+            "L = d['box'][3:6] - d['box'][:3]\n"
+            "st = np.array([-3e-4 * L[0], -3e-4 * L[1], 1e-3 * L[2], 2e-5 * L[2], 0, 0])\n"
+            "out = []\n"
+            "a = e.strain_batch([capi.make_sim(q, 'pe', 1, st * (1 + 0.2 * q), nss=20, most_recent=capi.QP_NONE) for q in (0, 1)])\n"
+            "out += [list(o.stress) for o in a]\n"
+            "a = e.strain_batch([capi.make_sim(q, 'pe', 1, -st, nss=20) for q in (0, 1)])\n"
+            "out += [list(o.stress) for o in a]\n"
+            "box, x, v = e.get_state(1, 'pe', 1)\n"
+            "rng = np.random.default_rng(3)\n"
+            "e.set_state(0, 'pe', 1, box, x + rng.normal(0, 0.02, x.shape), v)      # qp 0 becomes (a perturbed copy of) qp 1's state\n"
+            "a = e.strain_batch([capi.make_sim(q, 'pe', 1, st, nss=20) for q in (0, 1)])\n"
+            "out += [list(o.stress) for o in a]\n"
+            "p = e.profile()\n"
+            "print(json.dumps({'s': out, 'builds': p['neigh_builds'], 'steps': p['md_steps']}))\n")
+    keep = _child(code, {})
+    nokeep = _child(code, {"SCEMA_MD_KEEP_LIST": "0"})
+    a, b = np.array(keep["s"]), np.array(nokeep["s"])
+    assert np.abs(a - b).max() < 1e-9 * np.abs(b).max()
+    assert keep["steps"] == nokeep["steps"]
+    # 6 evaluations x 2 runs rebuild at their start without the kept rows; with them only the very first run of each state and the run
+    # that follows the replaced state do
+    assert keep["builds"] <= nokeep["builds"] - 6, (keep["builds"], nokeep["builds"])
