@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "md_device.h"
+#include "md_env.h"
 #include "md_pppm.h"
 #include "md_types.h"
 
@@ -268,15 +269,20 @@ __global__ __launch_bounds__(256) void k_pppm_poisson(const SimDev *sims) {
 // a third keeps rho(k) while the three field components are transformed back.  Replaces eight to ten library launches of a few
 // microseconds each per step (what a single replica or a 72-replica share waits for) and leaves the charge grid zeroed for the
 // next spreading pass.  Replicas of one launch may have different grids.
+// Two shapes (round 5).  <1 024, false>: sixteen waves and rho(k) in a third LDS buffer -- one grid point per thread and pass for grids of up
+// to 1 024 points: what a single replica or a handful waits for.  <512, true>: eight waves, two LDS buffers, rho(k) in the replica's charge
+// grid in memory (written once, read three times: cache traffic) -- 56 KB and 512 threads for a 12 x 12 x 12 grid, which is what ONE retiring
+// k_pair workgroup leaves free on a CU.  The first shape (83 KB, 1 024 threads) needs both of a CU's k_pair workgroups gone, so beside a pair
+// launch it only ever started in that launch's tail: 899 instead of 90 us per step at 72 replicas, the k-space chain behind it stalled.
 extern __shared__ double2 s_fft[];
-#define PP_SOLVE_TPB 1024   // one grid point per thread and pass for grids of up to 1 024 points: a single replica waits for this kernel
+template <int PP_SOLVE_TPB, bool BGLOBAL>
 __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.x];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
   if (nx == 0) return;
   __shared__ double s_red[8 * (PP_SOLVE_TPB / 64)];
   const int NG = nx * ny * nz;
-  double2 *A = s_fft, *B = A + NG, *C = B + NG, *tw = C + NG;   // twiddles: x at 0, y at nx, z at nx + ny
+  double2 *A = s_fft, *C = A + NG, *B = BGLOBAL ? (double2 *)S.pgrid : C + NG, *tw = (BGLOBAL ? C : B) + NG;   // twiddles: x at 0, y at nx, z at nx + ny
 #ifdef PAIR_TIMING
   unsigned long long tq[8]; int ntq = 0;
 #define PP_CLK() tq[ntq++] = __builtin_readcyclecounter()
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
     tw[k] = make_double2(cs, -sn);
   }
   double2 *rho = (double2 *)S.pgrid;
-  for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) { A[k] = make_double2(rho[k].x, 0.0); rho[k] = make_double2(0.0, 0.0); }
+  for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) { A[k] = make_double2(rho[k].x, 0.0); if (!BGLOBAL) rho[k] = make_double2(0.0, 0.0); }
   __syncthreads();
   PP_CLK();   // 1: twiddles + charge grid in
   // out[.., m, ..] = sum_k in[.., k, ..] w^(m k) along dimension dim (w = exp(-+2 pi i / n)); ends with a barrier.  A work item is one
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
     }
     __syncthreads();
   };
-  pass(A, B, 0, false); pass(B, A, 1, false); pass(A, B, 2, false);   // B = rho(k)
+  pass(A, C, 0, false); pass(C, A, 1, false); pass(A, B, 2, false);   // B = rho(k) (BGLOBAL: in the charge grid's memory; the barrier that ends a pass orders it for the workgroup)
   PP_CLK();   // 2: forward passes
   BoxD b;
   box_derive(S.sc->box, b);
@@ -377,6 +383,8 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
     }
     __syncthreads();
   }
+  if (BGLOBAL)   // the charge grid leaves zeroed for the next spreading pass, as in the other shape
+    for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) rho[k] = make_double2(0.0, 0.0);
   block_atomic_add_n<6, PP_SOLVE_TPB / 64>(v, S.sc->vir + P_KSPACE * 6, s_red);
   block_atomic_add_n<1, PP_SOLVE_TPB / 64>(e, S.sc->eng + P_KSPACE, s_red);
 #ifdef PAIR_TIMING
@@ -479,11 +487,19 @@ void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int m
 }
 int mdk_pppm_solve_max() { return PP_SOLVE_MAX; }
 void mdk_pppm_solve(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxdims) {
-  const size_t lds = (3 * (size_t)maxgrid + (size_t)maxdims) * sizeof(double2);
-  static size_t optin_tab[16] = {0};
-  size_t &optin = lds_optin_slot(optin_tab);
-  if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  hipLaunchKernelGGL(k_pppm_solve, dim3(ns), dim3(PP_SOLVE_TPB), lds, st, d);
+  // batches: the shape that fits beside a pair workgroup; a few replicas: the one with the most threads per replica
+  static const int shape_env = scema_env("SCEMA_MD_PPPM_SOLVE_WIDE") ? atoi(scema_env("SCEMA_MD_PPPM_SOLVE_WIDE")) : -1;
+  const bool wide = shape_env < 0 ? ns < 8 : shape_env != 0;
+  const size_t lds = ((wide ? 3 : 2) * (size_t)maxgrid + (size_t)maxdims) * sizeof(double2);
+  static size_t optin_tab[2][16] = {{0}, {0}};
+  size_t &optin = lds_optin_slot(optin_tab[wide ? 1 : 0]);
+  if (wide) {
+    if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_solve<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+    hipLaunchKernelGGL((k_pppm_solve<1024, false>), dim3(ns), dim3(1024), lds, st, d);
+  } else {
+    if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_solve<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
+    hipLaunchKernelGGL((k_pppm_solve<512, true>), dim3(ns), dim3(512), lds, st, d);
+  }
 }
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_gf, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_poisson, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
