@@ -356,6 +356,68 @@ def dry_run_ranks(args, rank, world, dist):
     return out
 
 
+_RCCL_FAILED = []
+_ABANDONED = []   # engines whose RCCL attach never came back: kept alive, and the process leaves through os._exit
+
+
+def attach_comm(eng, new_engine, args, rank, world, device, dist):
+    """The data path of --gpus N: RCCL inside the engine, proved before anything depends on it by ONE empty collective update (the
+    agreement handshake and the stress all-gather with no request) under a watchdog.  If any rank fails or does not come back in time,
+    EVERY rank moves -- together, agreed over the gloo control plane -- to the engine's host transport on a fresh engine (same protocol,
+    the all-gather of a few kB on the host) and the JSON line says so in config.collective: a scaling run then still produces numbers.
+    Returns (engine, description, comm_stats after the probe)."""
+    import threading
+    import torch
+    from scema_amd import comm
+    timeout_s = float(args.comm_timeout)
+    why = _RCCL_FAILED[0] if _RCCL_FAILED else None   # (a later leg of the same run does not wait for the same failure again: every rank saw it)
+    if args.dist_backend == "nccl" and why is None:
+        uid = [None]
+        if rank == 0:
+            try:
+                uid[0] = eng.comm_unique_id()
+            except Exception as exc:
+                uid[0] = None
+                why = f"rank 0: {exc!r}"
+        dist.broadcast_object_list(uid, src=0)   # (on the main thread: the watchdog below must never leave a gloo collective half entered)
+        err, done = [None], threading.Event()
+        if uid[0] is not None:
+            def work():
+                try:
+                    torch.cuda.set_device(device)
+                    eng.comm_init_rccl(uid[0], rank, world)
+                    eng.strain_batch([], rank=rank, world=world)
+                except BaseException as exc:
+                    err[0] = repr(exc)
+                done.set()
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            if not done.wait(timeout_s):
+                err[0] = f"no answer from RCCL within {timeout_s:.0f} s"
+                _ABANDONED.append(eng)
+            if err[0]:
+                why = f"rank {rank}: {err[0]}"
+        flag = torch.tensor([0 if why else 1], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return eng, "ncclAllGather inside scema_md_strain_batch", eng.comm_stats()
+        whys = [None] * world
+        dist.all_gather_object(whys, why)
+        why = "; ".join(w for w in whys if w) or "unknown"
+        _RCCL_FAILED.append(why)
+        if rank == 0:
+            print(f"[bench] RCCL attach failed ({why}): every rank moves to the host transport over gloo", file=sys.stderr, flush=True)
+        if eng not in _ABANDONED:
+            try:
+                eng.comm_destroy()
+            except Exception:
+                pass
+        eng = new_engine()
+    comm.attach_gloo(eng, rank, world)
+    eng.strain_batch([], rank=rank, world=world)
+    return eng, "host transport (gloo)" + (f" -- RCCL attach failed: {why}" if why else ""), eng.comm_stats()
+
+
 def run_leg(args, rank, world, device, cpu, torch, dist):
     """one workload through the engine: equilibrate (untimed), warm up, time `steps` updates; rank 0 returns the JSON record"""
     from scema_amd.systems import synthetic_strains
@@ -367,9 +429,9 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
     extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
     extra["kspace_style"] = 1 if args.kspace == "pppm" else 0
     eng = capi.Engine(capi.default_params(device=device, profile=1, **extra))
+    collective, comm0 = None, {"allgathers": 0, "handshakes": 0, "migrations": 0}
     if world > 1:
-        from scema_amd import comm
-        (comm.attach_rccl if args.dist_backend == "nccl" else comm.attach_gloo)(eng, rank, world)
+        eng, collective, comm0 = attach_comm(eng, lambda: capi.Engine(capi.default_params(device=device, profile=1, **extra)), args, rank, world, device, dist)
 
     # ---- equilibrated replica (outside the timed region): rank 0 runs it, every rank registers the same state ----
     if reax:
@@ -434,7 +496,7 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = eng.profile()
-    comm = eng.comm_stats()          # (collectives and checksum of warm-up + timed region: what follows is measurement aid)
+    comm = {k: v - comm0.get(k, 0) for k, v in eng.comm_stats().items()}   # (without attach_comm's probe; collectives and checksum of warm-up + timed region: what follows is measurement aid)
     checksum_timed = checksum
     # The roofline kernel WITH THE CHIP TO ITSELF: two more updates after the timed region with the batch issued as one sequence of launches on
     # one stream (the timed region runs it as two half batches whose launches overlap each other and the other kernels of both halves: a
@@ -595,7 +657,7 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                        "strain_set_monotonic_evals_per_s": mono_rate, "strain_set_monotonic_updates": args.monotonic_updates if mono_rate else 0,
                        "n_sims": n, "atoms_per_replica": natoms, "md_steps_per_eval": nts_mean + args.nss,
                        "sharding": "engine planner (host/sim_plan.h): fresh batch i % N, then sticky to the GPU that holds the state, levelled by MD steps",
-                       "sims_on_rank0": int((owner == 0).sum()), "collective": ("ncclAllGather inside scema_md_strain_batch" if args.dist_backend == "nccl" else "host transport (gloo)") if world > 1 else None,
+                       "sims_on_rank0": int((owner == 0).sum()), "collective": collective,
                        "allgathers": comm["allgathers"], "handshakes": comm["handshakes"], "state_migrations": comm["migrations"],
                        "stress_zz_checksum_Pa": checksum_timed,
                        "list_skin_A": prof.get("list_skin_mean", 0.0),
@@ -639,6 +701,8 @@ def main():
                     help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
     ap.add_argument("--dry-run-ranks", type=int, default=0, help="N: run the control plane of --gpus N (rank spawn, rendezvous, id exchange, planner, "
                     "per-rank JSON assembly) with no engine and no GPU; prints a line with \"dry_run\": true and no value")
+    ap.add_argument("--comm-timeout", type=float, default=300.0,
+                    help="seconds the RCCL attach + its one-update probe may take before every rank moves to the host transport")
     ap.add_argument("--share-gpus", action="store_true", help="tests: let several ranks share a GPU (needs --dist-backend gloo)")
     ap.add_argument("--reax-leg", default="auto", choices=["auto", "on", "off"],
                     help="after the OPLS loop, outside `value`: a short ReaxFF replica-set leg (BASELINE config 5: 72 x PE-1620, 2 warm-up + 4 timed updates) "
@@ -738,6 +802,9 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if _ABANDONED:   # a thread is still inside RCCL: no interpreter shutdown through it
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -54,6 +54,21 @@ def test_two_rank_bench_over_rccl():
     assert abs(c1 - c2) <= 1e-8 * abs(c1), (c1, c2)
 
 
+def test_rccl_attach_failure_moves_every_rank_to_the_host_transport():
+    """two ranks on ONE device with the RCCL data path asked for: RCCL refuses (duplicate GPU) on every rank; bench.py's attach_comm notices in its
+    probe, the ranks agree over the control plane, and the run completes over the host transport with the same stresses -- and says so"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box where two ranks must share a device")
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON)
+    two = _run([sys.executable, "bench.py", "--gpus", "2", "--share-gpus", "--comm-timeout", "120"] + COMMON)
+    coll = two["config"]["collective"]
+    assert coll.startswith("host transport (gloo) -- RCCL attach failed"), coll
+    c1, c2 = one["config"]["stress_zz_checksum_Pa"], two["config"]["stress_zz_checksum_Pa"]
+    assert abs(c1 - c2) <= 1e-8 * abs(c1), (c1, c2)
+    assert two["config"]["allgathers"] == 3 and two["config"]["handshakes"] == 3     # (the probe's own collective is not counted)
+
+
 def test_imbalanced_batch_on_two_ranks_is_levelled_and_moves_states():
     """the ragged strain set (nts 10..100) on two ranks: after the first update the planner levels the load by MD steps,
     which makes replica states change rank (over the host transport here); the stresses equal the single-rank run's"""
