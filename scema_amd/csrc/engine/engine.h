@@ -152,7 +152,7 @@ struct State {
 struct RxSlot {
   int cap_pad = 0, cap_nb = 0, cap_bd = 0, cap_nbn = 0;
   DevBuf nbn_cnt, nbn, nbnT, qpart, pm_len, pm_col, pm_raw, pm_val;
-  DevBuf nb_cnt, nb, nbT, hval, hcol, hlen, hown, hownlen, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
+  DevBuf nb_cnt, nbT, hval, hcol, hlen, hown, hownlen, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
 };
 
 // what the neighbour rows of a slot were built for: a run that follows on the same slot keeps them if all of it still holds

@@ -44,7 +44,6 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
     r.cap_nbn = maxnbn;
   }
   if (maxnb > r.cap_nb) {
-    HIPCHK(r.nb.ensure((size_t)maxnb * npad * 4));
     HIPCHK(r.hval.ensure((size_t)maxnb * npad * 8));
     HIPCHK(r.hcol.ensure((size_t)maxnb * npad * 4));   // (16-bit columns use half of it)
     HIPCHK(r.nbT.ensure((size_t)maxnb * npad * 4));
@@ -204,7 +203,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     RXSET(V.rtype, T.d_rtype.as<int>()); RXSET(V.x, S.x); RXSET(V.q, R.q.as<double>());
     RXSET(V.nbn_cnt, R.nbn_cnt.as<int>()); RXSET(V.nbn, R.nbn.as<int>()); RXSET(V.nbnT, R.nbnT.as<int>()); V.maxnbn = maxnbn; V.rnear2 = rnear * rnear;
     RXSET(V.qpart, R.qpart.as<double>());
-    RXSET(V.nb_cnt, R.nb_cnt.as<int>()); RXSET(V.nb, R.nb.as<int>()); RXSET(V.bd_cnt, R.bd_cnt.as<int>()); RXSET(V.bd, R.bd.as<int>()); RXSET(V.bd_rev, R.bd_rev.as<int>());
+    RXSET(V.nb_cnt, R.nb_cnt.as<int>()); RXSET(V.nb, (int *)nullptr); RXSET(V.bd_cnt, R.bd_cnt.as<int>()); RXSET(V.bd, R.bd.as<int>()); RXSET(V.bd_rev, R.bd_rev.as<int>());
     RXSET(V.bd_bop, R.bd_bop.as<double>()); RXSET(V.bd_c, R.bd_c.as<double>()); RXSET(V.bd_bo, R.bd_bo.as<double>()); RXSET(V.bd_g, R.bd_g.as<double>()); RXSET(V.bd_cb, R.bd_cb.as<double>());
     RXSET(V.deltap, R.deltap.as<double>()); RXSET(V.total_bo, R.total_bo.as<double>()); RXSET(V.cd_delta, R.cd_delta.as<double>()); RXSET(V.hd, R.hd.as<double>());
     RXSET(V.f, S.f); RXSET(V.hval, R.hval.as<double>()); RXSET(V.s, R.s.as<double>()); RXSET(V.t, R.t.as<double>());

@@ -80,84 +80,99 @@ __global__ __launch_bounds__(TPB) void k_rx_wrap(const SimDev *sims, RxView *vie
   S.wrapn[3 * i] += (int)w0; S.wrapn[3 * i + 1] += (int)w1; S.wrapn[3 * i + 2] += (int)w2;
 }
 
-// Neighbour rows by tiles: every lane owns an atom and walks all atoms of the replica, staged 256 at a time through LDS.
-// O(N^2) distance tests per rebuild (about 25 FP64 operations each), rebuilt every some tens of steps: a few per cent of the
-// step next to the force kernels, any box shape, and rows that come out sorted by partner index (deterministic).
+// Neighbour rows, a wave per row (round 5; until then a lane per atom walked all atoms of the replica: 2 000 waves for 72 replicas, 2.0 ms per
+// rebuild of all of them, and two stores of four bytes per entry that no neighbour lane shared a cache line with): a workgroup owns 64
+// consecutive atoms, wave w their rows 8 w .. 8 w + 7 (as the matrix build has them), its lanes over the replica's atoms as partners, 64 at a
+// time.  A chunk's accepted partners leave as one contiguous store into the row (ballot + lane rank): rows come out sorted by partner index as
+// before (deterministic; with several images per partner, image-major inside a chunk).  O(N^2) distance tests per rebuild, any box shape.
+// Only the row-major rows are written (RxView::nbT): the entry-major copy of the FULL rows had two readers left, the hydrogen-bond pass and the
+// both-ends non-bonded kernel of the tests, which read rows now (rx_nb_entry); the NEAR rows keep both copies (a dozen entries per row).
 // mimg = 0: boxes at least two list radii wide, minimum image; otherwise all images up to mimg[d] boxes away.
-__global__ __launch_bounds__(TPB) void k_rx_neigh(const SimDev *sims, RxView *views, double rlist) {
+#define RX_NBR 8   /* rows per wave */
+__global__ __launch_bounds__(64 * (64 / RX_NBR)) void k_rx_neigh(const SimDev *sims, RxView *views, double rlist) {
   const SimDev &S = sims[blockIdx.y];
   if (!S.sc->rebuild) return;
   const RxView &V = views[blockIdx.y];
-  __shared__ double s_x[TPB], s_y[TPB], s_z[TPB];
-  const int i = blockIdx.x * TPB + threadIdx.x, n = V.n, np = V.npad;
-  const bool live = i < n;
-  const double xi = live ? S.x[3 * i] : 0.0, yi = live ? S.x[3 * i + 1] : 0.0, zi = live ? S.x[3 * i + 2] : 0.0;
-  const double rl2 = rlist * rlist;
-  const double ih0 = 1.0 / V.h[0], ih1 = 1.0 / V.h[1], ih2 = 1.0 / V.h[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = V.n, np = V.npad, maxnb = V.maxnb, maxnbn = V.maxnbn;
+  const int r0 = blockIdx.x * 64 + wave * RX_NBR;
+  if (r0 >= n) return;   // (wave-uniform; the kernel has no barrier)
+  const int nr = min(RX_NBR, n - r0);
+  const double rl2 = rlist * rlist, rn2 = V.rnear2;
+  const double h0 = wave_uniform(V.h[0]), h1 = wave_uniform(V.h[1]), h2 = wave_uniform(V.h[2]), h3 = wave_uniform(V.h[3]), h4 = wave_uniform(V.h[4]),
+               h5 = wave_uniform(V.h[5]);
+  const double ih0 = 1.0 / h0, ih1 = 1.0 / h1, ih2 = 1.0 / h2;
   const int m0 = V.mimg[0], m1 = V.mimg[1], m2 = V.mimg[2];
   const bool minimage = (m0 | m1 | m2) == 0;
-  int cnt = 0, cntn = 0;
-  bool full = false;
-  const double rn2 = V.rnear2;
-  for (int j0 = 0; j0 < n; j0 += TPB) {
-    __syncthreads();
-    const int jl = j0 + threadIdx.x;
-    if (jl < n) { s_x[threadIdx.x] = S.x[3 * jl]; s_y[threadIdx.x] = S.x[3 * jl + 1]; s_z[threadIdx.x] = S.x[3 * jl + 2]; }
-    __syncthreads();
-    if (!live) continue;
-    const int jn = min(TPB, n - j0);
-    for (int jj = 0; jj < jn; jj++) {
-      const int j = j0 + jj;
-      double dx = s_x[jj] - xi, dy = s_y[jj] - yi, dz = s_z[jj] - zi;
+  double xr[RX_NBR], yr[RX_NBR], zr[RX_NBR];
+  int len[RX_NBR], lenn[RX_NBR];
+#pragma unroll
+  for (int g = 0; g < RX_NBR; g++) {
+    const int row = min(r0 + g, n - 1);
+    xr[g] = wave_uniform(S.x[3 * row]); yr[g] = wave_uniform(S.x[3 * row + 1]); zr[g] = wave_uniform(S.x[3 * row + 2]);
+    len[g] = 0; lenn[g] = 0;
+  }
+  // one accepted (partner, image) per lane -> the row's next entries
+  auto append = [&](int g, bool ok, bool near, int ent) __attribute__((always_inline)) {
+    const unsigned long long m = __ballot(ok);
+    if (m == 0) return;
+    const int row = r0 + g;
+    const int pos = len[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    if (ok && pos < maxnb) V.nbT[(size_t)row * maxnb + pos] = ent;
+    len[g] += __popcll(m);
+    const unsigned long long mn = __ballot(ok && near);
+    if (mn == 0) return;
+    const int posn = lenn[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(mn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mn, 0));
+    if (ok && near && posn < maxnbn) {
+      V.nbnT[(size_t)row * maxnbn + posn] = ent;
+      V.nbn[(size_t)posn * np + row] = ent;
+    }
+    lenn[g] += __popcll(mn);
+  };
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const bool jl = j < n;
+    const int jc = jl ? j : n - 1;
+    const double xj = S.x[3 * jc], yj = S.x[3 * jc + 1], zj = S.x[3 * jc + 2];
+#pragma unroll
+    for (int g = 0; g < RX_NBR; g++) {
+      if (g >= nr) break;   // (wave-uniform)
+      double dx = xj - xr[g], dy = yj - yr[g], dz = zj - zr[g];
       if (minimage) {
-        if (j == i) continue;
         const double n2 = rint(dz * ih2);
-        dz -= n2 * V.h[2]; dy -= n2 * V.h[3]; dx -= n2 * V.h[4];
+        dz -= n2 * h2; dy -= n2 * h3; dx -= n2 * h4;
         const double n1 = rint(dy * ih1);
-        dy -= n1 * V.h[1]; dx -= n1 * V.h[5];
+        dy -= n1 * h1; dx -= n1 * h5;
         const double n0 = rint(dx * ih0);
-        dx -= n0 * V.h[0];
+        dx -= n0 * h0;
         const double r2 = dx * dx + dy * dy + dz * dz;
-        if (r2 > rl2) continue;
-        if (cnt >= V.maxnb) { full = true; continue; }
         const int code = (2 - (int)n0) + 5 * (2 - (int)n1) + 25 * (2 - (int)n2);
-        V.nb[(size_t)cnt * np + i] = j | (code << 24);
-        V.nbT[(size_t)i * V.maxnb + cnt] = j | (code << 24);
-        cnt++;
-        if (r2 <= rn2) {
-          if (cntn >= V.maxnbn) { full = true; continue; }
-          V.nbn[(size_t)cntn * np + i] = j | (code << 24);
-          V.nbnT[(size_t)i * V.maxnbn + cntn] = j | (code << 24);
-          cntn++;
-        }
+        append(g, jl && j != r0 + g && !(r2 > rl2), r2 <= rn2, j | (code << 24));
       } else {
         for (int sz = -m2; sz <= m2; sz++)
           for (int sy = -m1; sy <= m1; sy++)
             for (int sx = -m0; sx <= m0; sx++) {
-              if (j == i && sx == 0 && sy == 0 && sz == 0) continue;
-              const double ex = dx + sx * V.h[0] + sy * V.h[5] + sz * V.h[4], ey = dy + sy * V.h[1] + sz * V.h[3], ez = dz + sz * V.h[2];
+              const double ex = dx + sx * h0 + sy * h5 + sz * h4, ey = dy + sy * h1 + sz * h3, ez = dz + sz * h2;
               const double r2 = ex * ex + ey * ey + ez * ez;
-              if (r2 > rl2) continue;
-              if (cnt >= V.maxnb) { full = true; continue; }
-              const int ent = j | (((sx + 2) + 5 * (sy + 2) + 25 * (sz + 2)) << 24);
-              V.nb[(size_t)cnt * np + i] = ent;
-              V.nbT[(size_t)i * V.maxnb + cnt] = ent;
-              cnt++;
-              if (r2 <= rn2) {
-                if (cntn >= V.maxnbn) { full = true; continue; }
-                V.nbn[(size_t)cntn * np + i] = ent;
-                V.nbnT[(size_t)i * V.maxnbn + cntn] = ent;
-                cntn++;
-              }
+              const bool self = j == r0 + g && sx == 0 && sy == 0 && sz == 0;
+              append(g, jl && !self && !(r2 > rl2), r2 <= rn2, j | (((sx + 2) + 5 * (sy + 2) + 25 * (sz + 2)) << 24));
             }
       }
     }
   }
-  if (live) {
-    V.nb_cnt[i] = cnt;
-    V.nbn_cnt[i] = cntn;
+  bool full = false;
+  int most = 0;
+#pragma unroll
+  for (int g = 0; g < RX_NBR; g++) {
+    if (g >= nr) break;
+    full |= len[g] > maxnb || lenn[g] > maxnbn;
+    const int c = min(len[g], maxnb);
+    most = max(most, c);
+    if (lane == 0) { V.nb_cnt[r0 + g] = c; V.nbn_cnt[r0 + g] = min(lenn[g], maxnbn); }
+  }
+  if (lane == 0) {
     if (full) atomicOr(V.overflow, 1);
-    atomicMax(&S.sc->maxneigh_seen, cnt);
+    atomicMax(&S.sc->maxneigh_seen, most);
   }
 }
 
@@ -1246,7 +1261,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   const dim3 ga = g2(cdv(maxatoms, TPB), ns), gr = g2(cdv(maxatoms, RX_TPB), ns), gk = g2(cdv(maxatoms, 64), ns), gu = g2(cdv(maxatoms, QEQ_UT), ns);
   hipLaunchKernelGGL(k_rx_prepare, dim3(ns), dim3(64), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_wrap, ga, dim3(TPB), 0, st, d, v);
-  hipLaunchKernelGGL(k_rx_neigh, ga, dim3(TPB), 0, st, d, v, rlist);
+  hipLaunchKernelGGL(k_rx_neigh, gk, dim3(64 * (64 / RX_NBR)), 0, st, d, v, rlist);
   // Two chains from here to the sum of the forces.  CHARGES: matrix rows, conjugate gradients, charges, non-bonded pairs.  BOND ORDERS: bond
   // orders, corrections, bonded terms, back-propagation.  Neither reads what the other writes, except that k_rx_corr zeroes the force array the
   // non-bonded pass adds to (one event).  The second is a chain of latency-bound kernels (two waves per SIMD waiting on dependent loads, a tenth

@@ -45,6 +45,8 @@ RX_FN void rx_shift(const RxView *V, int e, double s[3]) {
   s[2] = sz * V->h[2];
 }
 // vector from atom i to the partner named by row entry e
+// entry k of atom i's full neighbour row: the device keeps the rows row-major only (nbT), the host test driver entry-major (nb)
+RX_FN int rx_nb_entry(const RxView *V, int i, int k) { return V->nbT ? V->nbT[(size_t)i * V->maxnb + k] : V->nb[(size_t)k * V->npad + i]; }
 RX_FN int rx_partner(const RxView *V, int i, int e, double d[3]) {
   const int j = e & RX_JMASK;
   double s[3];
@@ -777,7 +779,7 @@ RX_FN void rx_hbond_terms(const RxParams *P, const RxView *V, int j, double *eng
   if (ndon == 0) return;
   double fj[3] = {0, 0, 0};
   for (int n = 0; n < nn; n++) {
-    const int ek = V->nb[(size_t)n * np + j];
+    const int ek = rx_nb_entry(V, j, n);
     const int k = ek & RX_JMASK, tk = V->rtype[k];
     if (P->sbp[tk].p_hbond != 2) continue;
     double djk[3];
@@ -851,13 +853,13 @@ RX_FN void rx_nonbonded_pair(const RxParams *P, const RxTbp *t, double qq, doubl
 }
 // atom i's end of its pairs: the entries k0, k0 + kstep, ... of its list row (every pair is seen from both ends, half the energy each)
 RX_FN void rx_nonbonded_part(const RxParams *P, const RxView *V, int i, int k0, int kstep, double *fi, double *eng, double *vir) {
-  const int np = V->npad, ti = V->rtype[i], cnt = V->nb_cnt[i];
+  const int ti = V->rtype[i], cnt = V->nb_cnt[i];
   const double qi = RX_C_ELE * V->q[i];
   const double swb2 = P->swb * P->swb;
   const double xi0 = V->x[3 * i], xi1 = V->x[3 * i + 1], xi2 = V->x[3 * i + 2];
   double evdw = 0.0, ecoul = 0.0, w[6] = {0, 0, 0, 0, 0, 0};
   for (int k = k0; k < cnt; k += kstep) {
-    const int e = V->nb[(size_t)k * np + i];
+    const int e = rx_nb_entry(V, i, k);
     const int j = e & RX_JMASK;
     double sh[3];
     rx_shift(V, e, sh);
@@ -963,7 +965,7 @@ RX_FN void rx_qeq_row(const RxParams *P, const RxView *V, int i) {
   int len = 0;
   for (int k = 0; k < V->nb_cnt[i]; k++) {
     int col;
-    const double h = rx_qeq_entry(P, V, i, V->nb[(size_t)k * V->npad + i], &col);
+    const double h = rx_qeq_entry(P, V, i, rx_nb_entry(V, i, k), &col);
     if (h < 0.0) continue;
     V->hval[base + len] = h;
     if (V->hcol16) V->hcol16[base + len] = (unsigned short)col;

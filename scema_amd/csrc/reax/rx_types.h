@@ -89,7 +89,7 @@ typedef struct {
   double RX_G *q;              // [n] charges (charge equilibration)
   // neighbour rows inside the list radius (full: j appears in i's row and i in j's)
   int RX_G *nb_cnt;            // [n]
-  int RX_G *nb;                // [maxnb][npad]
+  int RX_G *nb;                // [maxnb][npad] entry-major rows: the host test driver only (NULL on the device, which keeps nbT; rx_nb_entry)
   // near rows: the entries of nb inside the bond cutoff + skin, same order (the bond-order pass walks these; NULL: walk nb)
   int RX_G *nbn_cnt;           // [n]
   int RX_G *nbn;               // [maxnbn][npad]
@@ -121,7 +121,7 @@ typedef struct {
   int RX_G *hown;              // [npad][maxnb] the list entries (atom | image code) of the row's pairs inside the taper radius that this
                           // end owns (rx_owns: each pair once), compacted; the non-bonded pass walks these
   int RX_G *hownlen;           // [npad]
-  int RX_G *nbT;               // [npad][maxnb] the list rows once more, row-major (written with the list; read by the matrix build)
+  int RX_G *nbT;               // [npad][maxnb] the list rows, row-major (a wave per row writes and reads them)
   double RX_G *s, *t;          // [npad] the two solutions
   double RX_G *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)
   double RX_G *qwork;          // [10][npad]: five arrays of (s-system, t-system) pairs per atom: residual r, search direction d,
