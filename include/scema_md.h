@@ -367,7 +367,7 @@ typedef struct {
   double rx_sweep_entries;    /* stored matrix entries those launches passed over (per replica: entries of its rows x sweeps it took
                                * part in); algorithmic bytes = (8 value + rx_sweep_col_bytes) per entry + 84 per row */
   double rx_sweep_rows;       /* rows likewise */
-  int64_t rx_sweep_col_bytes; /* bytes of a stored column index: 2 (replicas of up to 65 536 atoms) or 4 */
+  int64_t rx_sweep_col_bytes; /* bytes of a stored column index beside the 8-byte value: 0 (replicas of up to 65 536 atoms: it rides in the value's word) or 4 */
   /* Launches on different streams may be in flight together (a batch runs as two half batches): the time during which AT LEAST ONE of the
    * timed launches ran -- the union of their HIP-event intervals on the device's common clock.  Equal to the sums above when nothing overlaps. */
   double pair_union_ms;

@@ -151,6 +151,7 @@ struct State {
 // work arrays of the ReaxFF path for one batch position (reax/rx_types.h RxView points into these)
 struct RxSlot {
   int cap_pad = 0, cap_nb = 0, cap_bd = 0, cap_nbn = 0;
+  size_t cap_col = 0;
   DevBuf nbn_cnt, nbn, nbnT, qpart, pm_len, pm_col, pm_raw, pm_val;
   DevBuf nb_cnt, nbT, hval, hcol, hlen, hown, hownlen, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
 };

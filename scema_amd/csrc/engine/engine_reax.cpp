@@ -10,7 +10,7 @@ namespace scema_eng {
 
 // (the pointers of RxView are qualified as global-memory pointers in device code, reax/rx_types.h: a cast in both passes of the compiler)
 #define RXSET(dst, src) dst = (decltype(dst))(src)
-static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int maxnb, int maxbd, int maxnbn) {
+static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int maxnb, int maxbd, int maxnbn, bool col16) {
   if (npad > r.cap_pad) {
     HIPCHK(r.nb_cnt.ensure((size_t)npad * 4));
     HIPCHK(r.bd_cnt.ensure((size_t)npad * 4));
@@ -45,10 +45,13 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
   }
   if (maxnb > r.cap_nb) {
     HIPCHK(r.hval.ensure((size_t)maxnb * npad * 8));
-    HIPCHK(r.hcol.ensure((size_t)maxnb * npad * 4));   // (16-bit columns use half of it)
     HIPCHK(r.nbT.ensure((size_t)maxnb * npad * 4));
     HIPCHK(r.hown.ensure((size_t)maxnb * npad * 4));
     r.cap_nb = maxnb;
+  }
+  if (!col16 && (size_t)r.cap_nb * npad > r.cap_col) {   // (32-bit columns beside the values: replicas of more than 65 536 atoms only)
+    HIPCHK(r.hcol.ensure((size_t)r.cap_nb * npad * 4));
+    r.cap_col = (size_t)r.cap_nb * npad;
   }
   if (maxbd > r.cap_bd) {
     const size_t plane = (size_t)maxbd * npad;
@@ -170,7 +173,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     if (rc) return rc;
     if (!sl.rx) sl.rx.reset(new RxSlot());
     RxSlot &R = *sl.rx;
-    if ((rc = ensure_rx_slot(e, R, n, npad, maxnb, maxbd, maxnbn))) return rc;
+    if ((rc = ensure_rx_slot(e, R, n, npad, maxnb, maxbd, maxnbn, col16))) return rc;
     S.natoms = n; S.npad = npad; S.ntypes = T.ntypes;
     S.nsteps = A.nsteps;
     if (spec.sample) {
@@ -206,9 +209,9 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     RXSET(V.nb_cnt, R.nb_cnt.as<int>()); RXSET(V.nb, (int *)nullptr); RXSET(V.bd_cnt, R.bd_cnt.as<int>()); RXSET(V.bd, R.bd.as<int>()); RXSET(V.bd_rev, R.bd_rev.as<int>());
     RXSET(V.bd_bop, R.bd_bop.as<double>()); RXSET(V.bd_c, R.bd_c.as<double>()); RXSET(V.bd_bo, R.bd_bo.as<double>()); RXSET(V.bd_g, R.bd_g.as<double>()); RXSET(V.bd_cb, R.bd_cb.as<double>());
     RXSET(V.deltap, R.deltap.as<double>()); RXSET(V.total_bo, R.total_bo.as<double>()); RXSET(V.cd_delta, R.cd_delta.as<double>()); RXSET(V.hd, R.hd.as<double>());
-    RXSET(V.f, S.f); RXSET(V.hval, R.hval.as<double>()); RXSET(V.s, R.s.as<double>()); RXSET(V.t, R.t.as<double>());
+    RXSET(V.f, S.f); RXSET(V.hval, col16 ? nullptr : R.hval.as<double>()); RXSET(V.hpk, col16 ? R.hval.as<unsigned long long>() : nullptr); RXSET(V.s, R.s.as<double>()); RXSET(V.t, R.t.as<double>());
     V.warm = (spec.qeq_continue || A.st->qhist_valid) ? 1 : 0;
-    RXSET(V.hcol16, col16 ? R.hcol.as<unsigned short>() : nullptr); RXSET(V.hcol32, col16 ? nullptr : R.hcol.as<int>()); RXSET(V.hlen, R.hlen.as<int>()); RXSET(V.nbT, R.nbT.as<int>());
+    RXSET(V.hcol16, (unsigned short *)nullptr); RXSET(V.hcol32, col16 ? nullptr : R.hcol.as<int>()); RXSET(V.hlen, R.hlen.as<int>()); RXSET(V.nbT, R.nbT.as<int>());
     RXSET(V.hown, R.hown.as<int>()); RXSET(V.hownlen, R.hownlen.as<int>());
     RXSET(V.s_hist, R.s_hist.as<double>()); RXSET(V.t_hist, R.t_hist.as<double>()); RXSET(V.qwork, R.qwork.as<double>());
     // the bonded-pattern preconditioner needs one image per neighbour (boxes at least two list radii wide: every production replica)
@@ -431,7 +434,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   HIPCHK(hipGetLastError());
   if (prof) {
     // the matrix sweep of the charge equilibration, the HBM-bound kernel of this path: HIP-event time of every launch, and what
-    // the launches read by the algorithm: 12 bytes per stored matrix entry (8 value + 4 column) and RX_SWEEP_ROW_BYTES per row,
+    // the launches read by the algorithm: 8 bytes per stored matrix entry (value and 16-bit column in one word, RxView::hpk; 8 + 4 with 32-bit columns) and RX_SWEEP_ROW_BYTES per row,
     // for every replica and sweep it took part in (counted on the device, k_rx_qeq_finish)
     for (size_t l = 0; 2 * l + 1 < ev_used; l++) {
       float ms = 0.f;
@@ -444,7 +447,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     for (int pos = 0; pos < ns; pos++) {
       e->prof.rx_sweep_entries += (double)acc[2 * pos];
       e->prof.rx_sweep_rows += (double)acc[2 * pos + 1];
-      e->prof.rx_sweep_col_bytes = col16 ? 2 : 4;
+      e->prof.rx_sweep_col_bytes = col16 ? 0 : 4;   // (packed entries: the column rides in the value's word)
     }
   }
   int fault = 0, most = 0, most_cold = 0;

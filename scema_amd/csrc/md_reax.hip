@@ -251,9 +251,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
       const unsigned long long m = __ballot(h_prev[g] >= 0.0);
       if (h_prev[g] >= 0.0) {
         const size_t o = base[g] + len[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        V.hval[o] = h_prev[g];
-        if (V.hcol16) V.hcol16[o] = (unsigned short)(ent_prev[g] & RX_JMASK);
-        else V.hcol32[o] = ent_prev[g] & RX_JMASK;
+        if (V.hpk) V.hpk[o] = rx_hpack(h_prev[g], ent_prev[g] & RX_JMASK);
+        else { V.hval[o] = h_prev[g]; V.hcol32[o] = ent_prev[g] & RX_JMASK; }
       }
       len[g] += __popcll(m);
       // the pairs of the row that this end owns, for the non-bonded pass (each pair once)
@@ -309,7 +308,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
 //
 // The iteration runs as launches over all replicas, two per iteration (a conjugate-gradient step has two scalar products that
 // every row needs before it can go on):
-//   k_rx_qeq_sweep   y = H z (the only pass over the matrix: 12 bytes per stored entry, both systems per entry), then row-local
+//   k_rx_qeq_sweep   y = H z (the only pass over the matrix: 8 bytes per stored entry -- RxView::hpk -- both systems per entry), then row-local
 //                    d = z + beta d,  q = y + beta q  (H d by linearity: only z is ever gathered),  partial sums of d.q
 //   k_rx_qeq_update  alpha = sigma / d.q;  s += alpha d;  r -= alpha q;  z = r / eta;  partial sums of r.z
 // Scalars never sit in one memory word: every workgroup writes its partial sums with plain stores and every workgroup of the
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
   }
   // the products of this workgroup's 64 rows: wave w takes the rows 8 w .. 8 w + 7, lanes over the entries of a row
   __shared__ double s_y[2][RX_SWR];
-  const GLOBAL_AS unsigned short *c16 = as_global(V.hcol16);
+  const GLOBAL_AS unsigned long long *pk = as_global(V.hpk);
   const GLOBAL_AS int *c32 = as_global(V.hcol32);
   const GLOBAL_AS double *hv = as_global(V.hval);
   const GLOBAL_AS int *hlen = as_global(V.hlen);
@@ -468,8 +467,13 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep(const RxView *views, con
         const bool on = c < len[q];
         const size_t o = base[q] + (on ? c : 0);
         // (a masked lane must not trust entry 0 of the row either: a row without neighbours inside the taper radius was never written)
-        jn[q] = on ? (COL16 ? (int)c16[o] : c32[o]) : 0;
-        hn[q] = on ? hv[o] : 0.0;
+        if (COL16) {
+          const unsigned long long b = on ? pk[o] : 0ull;
+          hn[q] = rx_hunpack(b, &jn[q]);
+        } else {
+          jn[q] = on ? c32[o] : 0;
+          hn[q] = on ? hv[o] : 0.0;
+        }
       }
     };
     load(0);
@@ -742,8 +746,11 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
         for (int c0 = 0; c0 < len; c0 += 64) {
           const bool on = c0 + lane < len;
           const size_t o = (size_t)i * V.maxnb + (on ? c0 + lane : 0);
-          const double2 zj = z[on ? (V.hcol16 ? (int)V.hcol16[o] : V.hcol32[o]) : 0];
-          const double hv = on ? V.hval[o] : 0.0;
+          int col;
+          double hv;
+          if (V.hpk) hv = rx_hunpack(on ? V.hpk[o] : 0ull, &col);
+          else { col = on ? V.hcol32[o] : 0; hv = on ? V.hval[o] : 0.0; }
+          const double2 zj = z[col];
           ys = fma(hv, zj.x, ys);
           yt = fma(hv, zj.y, yt);
         }

@@ -11,6 +11,7 @@
 // O(bonds x neighbours) Add_dBond_to_Forces.
 #pragma once
 #include <math.h>
+#include <string.h>
 
 #include "rx_types.h"
 
@@ -47,6 +48,19 @@ RX_FN void rx_shift(const RxView *V, int e, double s[3]) {
 // vector from atom i to the partner named by row entry e
 // entry k of atom i's full neighbour row: the device keeps the rows row-major only (nbT), the host test driver entry-major (nb)
 RX_FN int rx_nb_entry(const RxView *V, int i, int k) { return V->nbT ? V->nbT[(size_t)i * V->maxnb + k] : V->nb[(size_t)k * V->npad + i]; }
+// one packed matrix entry (RxView::hpk)
+RX_FN unsigned long long rx_hpack(double h, int col) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &h, 8);
+  return ((b + 0x8000ull) & ~0xFFFFull) | (unsigned long long)(col & 0xFFFF);
+}
+RX_FN double rx_hunpack(unsigned long long b, int *col) {
+  *col = (int)(b & 0xFFFFull);
+  b &= ~0xFFFFull;
+  double h;
+  __builtin_memcpy(&h, &b, 8);
+  return h;
+}
 RX_FN int rx_partner(const RxView *V, int i, int e, double d[3]) {
   const int j = e & RX_JMASK;
   double s[3];

@@ -114,6 +114,10 @@ typedef struct {
   // the matrix of the charge equilibration, rebuilt every step, ROW-MAJOR (row i at i * maxnb): only the row entries inside the taper
   // radius (about 70 % of a row of the list), in list order; the kernels that walk it put the lanes of a wave over the entries of one
   // row (contiguous loads) and reduce across the wave
+  // Replicas of up to 65 536 atoms keep an entry in ONE 64-bit word (hpk): the column in bits 0-15, the value's upper 48 bits (rounded to
+  // nearest: relative error <= 2^-37 = 7e-12, five orders below the 1e-6 the solve stops at) in bits 16-63 -- 8 instead of 10 bytes per entry
+  // for the HBM-bound matrix sweep, one load instead of two.  Larger replicas (and the host checks): hval + hcol32 (hpk NULL).
+  unsigned long long RX_G *hpk; // [npad][maxnb]
   double RX_G *hval;           // [npad][maxnb] H_ij
   unsigned short RX_G *hcol16; // [npad][maxnb] column (atom index) of the entry; replicas of up to 65 536 atoms (else NULL and hcol32)
   int RX_G *hcol32;

@@ -1,5 +1,5 @@
 // Accuracy of the FP64 elementary functions that the ReaxFF kernels use instead of the library's (reax/rx_core.h: rx_log, rx_pow, rx_rcp,
-// rx_rsqrt, rx_sqrt), compiled for the host with the device algorithms (RX_DEVICE_MATH_ON_HOST: single-precision seeds stand in for the
+// rx_rsqrt, rx_sqrt) and of the packed matrix entry, compiled for the host with the device algorithms (RX_DEVICE_MATH_ON_HOST: single-precision seeds stand in for the
 // hardware estimates v_rcp_f64 / v_rsq_f64, which are at least as accurate).  Prints the worst errors over n pseudo-random arguments
 // against long double references; tests/test_reax_math.py holds them against the bounds DESIGN.md states.
 #define RX_HOST_TEST
@@ -34,6 +34,18 @@ int main(int argc, char **argv) {
     w_pow = fmax(w_pow, fabs((double)(((long double)rx_pow(b, p) - powl((long double)b, (long double)p)) / powl((long double)b, (long double)p))));
     (void)w_icbrt;
   }
-  printf("{\"n\": %ld, \"log_ulp\": %.3f, \"rcp_ulp\": %.3f, \"rsqrt_ulp\": %.3f, \"sqrt_ulp\": %.3f, \"pow_rel\": %.3e}\n", n, w_log, w_rcp, w_rsq, w_sqrt, w_pow);
+  // the packed matrix entry (rx_hpack / rx_hunpack): the column comes back, the value within 2^-37 of itself (round to nearest of the upper 48 bits)
+  double w_pack = 0;
+  long pack_bad = 0;
+  for (long i = 0; i < n / 4; i++) {
+    const double h = exp((rnd() - 0.5) * 20.0);   // shielded Coulomb terms: 1e-4 .. 1e4 kcal/mol/e^2
+    const int col = (int)(rnd() * 65536.0) & 0xFFFF;
+    int c2;
+    const double h2 = rx_hunpack(rx_hpack(h, col), &c2);
+    if (c2 != col) pack_bad++;
+    w_pack = fmax(w_pack, fabs(h2 - h) / h);
+  }
+  { int c2; if (rx_hunpack(rx_hpack(1.9999999999999998, 65535), &c2) != 2.0 || c2 != 65535) pack_bad++; }   // (a rounding that carries into the exponent)
+  printf("{\"n\": %ld, \"pack_rel\": %.3e, \"pack_bad\": %ld, \"log_ulp\": %.3f, \"rcp_ulp\": %.3f, \"rsqrt_ulp\": %.3f, \"sqrt_ulp\": %.3f, \"pow_rel\": %.3e}\n", n, w_pack, pack_bad, w_log, w_rcp, w_rsq, w_sqrt, w_pow);
   return 0;
 }

@@ -366,7 +366,8 @@ def test_fallback_kernels_of_large_replicas_equal_the_default_ones():
         out[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     a = out["once"]
     fa = np.array(a["f"])
-    # (the third run stores the columns of the charge-equilibration matrix as 32-bit indices, as replicas beyond 65 536 atoms do)
+    # (the third run stores the columns of the charge-equilibration matrix as 32-bit indices beside full FP64 values, as replicas beyond 65 536
+    # atoms do: the default packs a value's upper 48 bits and a 16-bit column into one word -- this comparison bounds what that rounding does)
     # (the last two give the angle and torsion kernels an item list of 0 / 100 entries per 256 atoms, so that their work items are
     # done where they are found -- the path of a system denser than any tested -- entirely / for the items beyond the list)
     for name in ("both_ends", "col32", "items_in_place", "items_mixed"):

@@ -15,3 +15,5 @@ def test_device_elementary_functions_are_within_a_few_ulp(tmp_path):
     assert out["log_ulp"] < 1.0          # the series is cut where its remainder is 1e-18
     assert out["rcp_ulp"] <= 1.0 and out["rsqrt_ulp"] <= 1.5 and out["sqrt_ulp"] <= 2.0   # (sqrt as x * rsqrt(x): two roundings)
     assert out["pow_rel"] < 1e-14        # exp(p log x): |p log x| times the error of the logarithm
+    # the 64-bit matrix entry of the charge equilibration (value's upper 48 bits + 16-bit column): 2^-37 = 7.3e-12, five orders below the solver's 1e-6
+    assert out["pack_bad"] == 0 and out["pack_rel"] <= 2.0 ** -37
