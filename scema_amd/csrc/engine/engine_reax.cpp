@@ -164,7 +164,8 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     int maxnb = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rlist * rlist * rlist * 1.2 * e->neigh_grow) + 32;
     maxnb = (maxnb + 7) / 8 * 8;
     const int maxbd = (int)std::ceil(24 * e->neigh_grow);
-    const double rnear = RX_BOND_CUT + e->rx_skin;
+    double rnear = 0.0;   // (the widest near row of the force field sizes the rows)
+    for (int k = 0; k < RX_MAXT * RX_MAXT; k++) rnear = std::max(rnear, std::sqrt(e->rx_host.rnear2[k]));
     int maxnbn = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rnear * rnear * rnear * 1.5 * e->neigh_grow) + 32;
     maxnbn = (maxnbn + 7) / 8 * 8;
     Slot &sl = *e->slots[i];
@@ -483,6 +484,45 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
 extern "C" {
 
 // ---- ReaxFF path ----
+// The reach of the uncorrected bond order of a type pair (rx_bond_prime_pair, reax/rx_core.h: three terms exp(p_a (r / r_x)^p_b) with p_a < 0 < p_b, each
+// falling with r): the r at which it passes bo_cut, plus a margin that covers the difference between this libm evaluation and the kernels' own
+// exp / log by orders of magnitude.  The exact test stays in the kernel; this only keeps hopeless candidates out of the near rows
+// (a row of 105 candidates within 5 + 1 A of a polyethylene atom holds 30 within reach + 1 A).  Parameters that do not fall with r: no cut.
+static double rx_bond_reach(const RxParams &P, int ti, int tj) {
+  const RxSbp &si = P.sbp[ti], &sj = P.sbp[tj];
+  const RxTbp &t = P.tbp[ti * RX_MAXT + tj];
+  const bool on_s = si.r_s > 0.0 && sj.r_s > 0.0, on_p = si.r_pi > 0.0 && sj.r_pi > 0.0, on_pp = si.r_pi_pi > 0.0 && sj.r_pi_pi > 0.0;
+  if ((on_s && !(t.p_bo1 < 0.0 && t.p_bo2 > 0.0)) || (on_p && !(t.p_bo3 < 0.0 && t.p_bo4 > 0.0)) || (on_pp && !(t.p_bo5 < 0.0 && t.p_bo6 > 0.0))) return RX_BOND_CUT;
+  auto bo = [&](double r) {
+    const double lr = std::log(r);
+    double b = 0.0;
+    if (on_s) b += (1.0 + P.bo_cut) * std::exp(t.p_bo1 * std::exp(t.p_bo2 * (lr - t.lr_s)));
+    if (on_p) b += std::exp(t.p_bo3 * std::exp(t.p_bo4 * (lr - t.lr_p)));
+    if (on_pp) b += std::exp(t.p_bo5 * std::exp(t.p_bo6 * (lr - t.lr_pp)));
+    return b;
+  };
+  if (!(P.bo_cut > 0.0) || bo(RX_BOND_CUT) >= P.bo_cut) return RX_BOND_CUT;
+  double lo = 1e-3, hi = RX_BOND_CUT;
+  if (bo(lo) < P.bo_cut) return lo;
+  for (int it = 0; it < 200 && hi - lo > 1e-12; it++) {
+    const double mid = 0.5 * (lo + hi);
+    (bo(mid) >= P.bo_cut ? lo : hi) = mid;
+  }
+  return std::min((double)RX_BOND_CUT, hi * (1.0 + 1e-6) + 1e-6);
+}
+static void rx_near_radii(RxParams &P, double skin) {
+  const bool full = scema_env("SCEMA_MD_RX_NEAR_FULL") && atoi(scema_env("SCEMA_MD_RX_NEAR_FULL")) != 0;   // (test hook: every pair inside the bond cutoff)
+  for (int a = 0; a < RX_MAXT; a++)
+    for (int b = 0; b < RX_MAXT; b++) {
+      const bool used = a < P.nt && b < P.nt;
+      const double reach = !used ? 0.0 : full ? (double)RX_BOND_CUT : std::max(rx_bond_reach(P, a, b), rx_bond_reach(P, b, a));
+      if (used && b >= a && scema_env("SCEMA_MD_TIMING")) fprintf(stderr, "[scema_md] reax types %d-%d: bond order below bo_cut beyond %.4f A\n", a, b, reach);
+      P.rbond[a * RX_MAXT + b] = reach;
+      const double rn = std::max(reach, (double)RX_PM_RADIUS) + skin;
+      P.rnear2[a * RX_MAXT + b] = used ? rn * rn : 0.0;
+    }
+}
+
 int scema_md_reax_configure(scema_md_engine *e, const char *ffield_path, const char *const *elements, int32_t n_elements, double qeq_tol, double skin) {
   if (!e || !ffield_path || !elements || n_elements <= 0) return fail(e, SCEMA_MD_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(e->p.device));
@@ -498,6 +538,7 @@ int scema_md_reax_configure(scema_md_engine *e, const char *ffield_path, const c
   if (skin >= 0.0) e->rx_skin = skin;
   if (const char *x = scema_env("SCEMA_REAX_SKIN")) e->rx_skin = atof(x);
   if (const char *x = scema_env("SCEMA_REAX_QEQ_LAUNCH")) { e->rx_qeq_launch = e->rx_qeq_launch_cold = std::max(0, atoi(x)); e->rx_qeq_launch_pinned = true; }
+  rx_near_radii(e->rx_host, e->rx_skin);
   HIPCHK(e->d_rxparams.ensure(sizeof(RxParams)));
   HIPCHK(hipMemcpyAsync(e->d_rxparams.p, &e->rx_host, sizeof(RxParams), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -89,27 +89,31 @@ __global__ __launch_bounds__(TPB) void k_rx_wrap(const SimDev *sims, RxView *vie
 // both-ends non-bonded kernel of the tests, which read rows now (rx_nb_entry); the NEAR rows keep both copies (a dozen entries per row).
 // mimg = 0: boxes at least two list radii wide, minimum image; otherwise all images up to mimg[d] boxes away.
 #define RX_NBR 8   /* rows per wave */
-__global__ __launch_bounds__(64 * (64 / RX_NBR)) void k_rx_neigh(const SimDev *sims, RxView *views, double rlist) {
+__global__ __launch_bounds__(64 * (64 / RX_NBR)) void k_rx_neigh(const SimDev *sims, RxView *views, const RxParams *__restrict__ P, double rlist) {
   const SimDev &S = sims[blockIdx.y];
   if (!S.sc->rebuild) return;
   const RxView &V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double s_rn2[RX_MAXT * RX_MAXT];   // the near-row radius of every type pair (RxParams::rnear2)
+  if (threadIdx.x < RX_MAXT * RX_MAXT) s_rn2[threadIdx.x] = P->rnear2[threadIdx.x];
+  __syncthreads();
   const int n = V.n, np = V.npad, maxnb = V.maxnb, maxnbn = V.maxnbn;
   const int r0 = blockIdx.x * 64 + wave * RX_NBR;
-  if (r0 >= n) return;   // (wave-uniform; the kernel has no barrier)
+  if (r0 >= n) return;   // (wave-uniform; no barrier below)
   const int nr = min(RX_NBR, n - r0);
-  const double rl2 = rlist * rlist, rn2 = V.rnear2;
+  const double rl2 = rlist * rlist;
   const double h0 = wave_uniform(V.h[0]), h1 = wave_uniform(V.h[1]), h2 = wave_uniform(V.h[2]), h3 = wave_uniform(V.h[3]), h4 = wave_uniform(V.h[4]),
                h5 = wave_uniform(V.h[5]);
   const double ih0 = 1.0 / h0, ih1 = 1.0 / h1, ih2 = 1.0 / h2;
   const int m0 = V.mimg[0], m1 = V.mimg[1], m2 = V.mimg[2];
   const bool minimage = (m0 | m1 | m2) == 0;
   double xr[RX_NBR], yr[RX_NBR], zr[RX_NBR];
-  int len[RX_NBR], lenn[RX_NBR];
+  int len[RX_NBR], lenn[RX_NBR], trow[RX_NBR];
 #pragma unroll
   for (int g = 0; g < RX_NBR; g++) {
     const int row = min(r0 + g, n - 1);
     xr[g] = wave_uniform(S.x[3 * row]); yr[g] = wave_uniform(S.x[3 * row + 1]); zr[g] = wave_uniform(S.x[3 * row + 2]);
+    trow[g] = __builtin_amdgcn_readfirstlane(V.rtype[row]) * RX_MAXT;
     len[g] = 0; lenn[g] = 0;
   }
   // one accepted (partner, image) per lane -> the row's next entries
@@ -134,9 +138,11 @@ __global__ __launch_bounds__(64 * (64 / RX_NBR)) void k_rx_neigh(const SimDev *s
     const bool jl = j < n;
     const int jc = jl ? j : n - 1;
     const double xj = S.x[3 * jc], yj = S.x[3 * jc + 1], zj = S.x[3 * jc + 2];
+    const int tj = V.rtype[jc];
 #pragma unroll
     for (int g = 0; g < RX_NBR; g++) {
       if (g >= nr) break;   // (wave-uniform)
+      const double rn2 = s_rn2[trow[g] + tj];
       double dx = xj - xr[g], dy = yj - yr[g], dz = zj - zr[g];
       if (minimage) {
         const double n2 = rint(dz * ih2);
@@ -1268,7 +1274,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   const dim3 ga = g2(cdv(maxatoms, TPB), ns), gr = g2(cdv(maxatoms, RX_TPB), ns), gk = g2(cdv(maxatoms, 64), ns), gu = g2(cdv(maxatoms, QEQ_UT), ns);
   hipLaunchKernelGGL(k_rx_prepare, dim3(ns), dim3(64), 0, st, d, v);
   hipLaunchKernelGGL(k_rx_wrap, ga, dim3(TPB), 0, st, d, v);
-  hipLaunchKernelGGL(k_rx_neigh, gk, dim3(64 * (64 / RX_NBR)), 0, st, d, v, rlist);
+  hipLaunchKernelGGL(k_rx_neigh, gk, dim3(64 * (64 / RX_NBR)), 0, st, d, v, P, rlist);
   // Two chains from here to the sum of the forces.  CHARGES: matrix rows, conjugate gradients, charges, non-bonded pairs.  BOND ORDERS: bond
   // orders, corrections, bonded terms, back-propagation.  Neither reads what the other writes, except that k_rx_corr zeroes the force array the
   // non-bonded pass adds to (one event).  The second is a chain of latency-bound kernels (two waves per SIMD waiting on dependent loads, a tenth

@@ -66,6 +66,10 @@ typedef struct {
   double tap[8];
   RxSbp sbp[RX_MAXT];
   RxTbp tbp[RX_MAXT * RX_MAXT];
+  // per type pair: the distance beyond which the uncorrected bond order is below bo_cut for certain (it falls with the distance: found by
+  // bisection when the force field is loaded, never above RX_BOND_CUT), and (that or RX_PM_RADIUS, whichever is larger, + list skin)^2 --
+  // the radius of the NEAR rows, which hold the candidates of the bond-order pass and of the preconditioner's pattern
+  double rbond[RX_MAXT * RX_MAXT], rnear2[RX_MAXT * RX_MAXT];
   RxThbp thbp[RX_MAXT * RX_MAXT * RX_MAXT];
   RxFbp fbp[RX_MAXT * RX_MAXT * RX_MAXT * RX_MAXT];
   RxHbp hbp[RX_MAXT * RX_MAXT * RX_MAXT];
@@ -95,7 +99,7 @@ typedef struct {
   int RX_G *nbn;               // [maxnbn][npad]
   int RX_G *nbnT;              // [npad][maxnbn] the near rows once more, row-major (the bond-order pass puts a wave on a row)
   int maxnbn, pad0_;
-  double rnear2;          // (bond cutoff + skin)^2
+  double rnear2;          // the largest near-row radius of the force field, squared (RxParams::rnear2 holds the one of each type pair)
   // bond rows: pairs with BO' >= cutoff (full)
   int RX_G *bd_cnt;            // [n]
   int RX_G *bd;                // [maxbd][npad] atom | image code
