@@ -57,6 +57,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_CELL_BUILD", "0: cell binning as k_bin + k_cell_scan + k_cell_fill instead of the one-launch k_cell_build"},
     {"SCEMA_MD_POLY_TOL", "fit target of the real-space Ewald polynomial (default 2e-13); parity tolerances assume the default"},
     {"SCEMA_REAX_DROP_DSBO2", "ReaxFF valence-angle gradient without the dSBO2 term, as USER-REAXC is believed to compute it"},
+    {"SCEMA_MD_RX_ITEM_LDS", "0 (test hook): the ReaxFF angle and torsion items add forces and dE/dDelta to the work set with device-wide atomics instead of through a workgroup's LDS tables (replicas too large for the tables do)"},
     {"SCEMA_MD_RX_NEAR_FULL", "1 (test hook): the ReaxFF near rows hold every pair within the 5 A bond cutoff + skin instead of the pairs within reach of their type pair's bond order"},
     {"SCEMA_REAX_SKIN", "ReaxFF list skin in Angstrom"},
     {"SCEMA_REAX_HALVES", "number of part batches a ReaxFF batch runs as, each on its own stream (default 2; 0 or 1: one sequence of launches)"},

@@ -992,12 +992,33 @@ __global__ __launch_bounds__(RX_TPB, RX_OCC) void k_rx_terms(const SimDev *sims,
 // puts its lanes over the list.  Items beyond the list's capacity (a denser system than any tested) are done where they are found.
 #define RX_TORS_ATOMS 256
 #define RX_TORS_CAP 2048
+// LACC: the forces and dE/dDelta sums of the items meet in LDS tables of the replica (s_acc: [3][npad] + [npad]; replicas of up to RX_NB1_MAXPAD
+// atoms) and reach the work set once per workgroup (rx_core.h, rx_add_f): 20 of an item's 26 device-wide atomics, which bounded the pass.
+extern __shared__ double s_acc[];
+__device__ __forceinline__ void rx_acc_zero(int np) {
+  for (int k = threadIdx.x; k < 4 * np; k += RX_TORS_ATOMS) s_acc[k] = 0.0;
+}
+__device__ __forceinline__ void rx_acc_flush(const RxView &V) {
+  const int n = V.n, np = V.npad;
+  for (int k = threadIdx.x; k < 3 * n; k += RX_TORS_ATOMS) {
+    const int a = k / 3, c = k - 3 * a;
+    const double v = s_acc[(size_t)c * np + a];
+    if (v != 0.0) atomicAdd(&V.f[k], v);
+  }
+  for (int a = threadIdx.x; a < n; a += RX_TORS_ATOMS) {
+    const double v = s_acc[(size_t)3 * np + a];
+    if (v != 0.0) atomicAdd(&V.cd_delta[a], v);
+  }
+}
+template <bool LACC>
 __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P, int cap) {
   const RxView V = views[blockIdx.y];
   if ((int)(blockIdx.x * RX_TORS_ATOMS) >= V.n) return;
   __shared__ int s_items[RX_TORS_CAP];
   __shared__ int s_n;
+  double *lf = LACC ? s_acc : nullptr, *lcd = LACC ? s_acc + 3 * (size_t)V.npad : nullptr;
   if (threadIdx.x == 0) s_n = 0;
+  if (LACC) rx_acc_zero(V.npad);
   __syncthreads();
   double e[RX_NPART], w[6];
 #pragma unroll
@@ -1012,20 +1033,25 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_torsions(const Sim
         if (rx_torsion_item_valid(&V, j, ak, ai)) {
           const int pos = atomicAdd(&s_n, 1);
           if (pos < cap) s_items[pos] = (int)(((unsigned)threadIdx.x << 24) | ((unsigned)ak << 12) | (unsigned)ai);   // (rows hold far fewer than 4 096 bonds)
-          else rx_torsion_item(P, &V, j, ak, ai, e, w);
+          else rx_torsion_item<LACC>(P, &V, j, ak, ai, e, w, lf, lcd);
         }
   }
   __syncthreads();
   const int nitems = min(s_n, cap);
   for (int it = threadIdx.x; it < nitems; it += RX_TORS_ATOMS) {
     const unsigned c = (unsigned)s_items[it];
-    rx_torsion_item(P, &V, j0 + (int)(c >> 24), (int)((c >> 12) & 0xFFF), (int)(c & 0xFFF), e, w);
+    rx_torsion_item<LACC>(P, &V, j0 + (int)(c >> 24), (int)((c >> 12) & 0xFFF), (int)(c & 0xFFF), e, w, lf, lcd);
+  }
+  if (LACC) {
+    __syncthreads();
+    rx_acc_flush(V);
   }
   rx_flush(e, w, V, *sims[blockIdx.y].sc, P_DIHEDRAL);
 }
 // The valence-angle pass the same way: a lane per ANGLE (reax/rx_core.h rx_angle_item).  What an atom's angles share (rx_angle_pre) is
 // computed by the atom's thread first and read from LDS by the items; what they sum for the atom (force on it, dE/dDelta, dE/dSBO)
 // meets in LDS accumulators and is fed back by the atom's thread (rx_angle_post) after a barrier.
+template <bool LACC>
 __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P, int cap) {
   const RxView V = views[blockIdx.y];
   if ((int)(blockIdx.x * RX_TORS_ATOMS) >= V.n) return;
@@ -1033,6 +1059,8 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDe
   __shared__ int s_n;
   __shared__ double s_sbo[2][RX_TORS_ATOMS];   // SBO2, CSBO2 of the block's atoms
   __shared__ double s_sum[5][RX_TORS_ATOMS];   // cdd, f[3], dE/dSBO
+  double *lf = LACC ? s_acc : nullptr, *lcd = LACC ? s_acc + 3 * (size_t)V.npad : nullptr;
+  if (LACC) rx_acc_zero(V.npad);
   if (threadIdx.x == 0) s_n = 0;
 #pragma unroll
   for (int k = 0; k < 5; k++) s_sum[k][threadIdx.x] = 0.0;
@@ -1055,7 +1083,7 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDe
           if (pos < cap) s_items[pos] = (int)(((unsigned)threadIdx.x << 24) | ((unsigned)ai << 12) | (unsigned)ak);
           else {   // (a denser system than any tested: done where it is found)
             RxAngleSum S = {0.0, {0.0, 0.0, 0.0}, 0.0};
-            rx_angle_item(P, &V, j, ai, ak, A.SBO2, A.CSBO2, &S, e, w);
+            rx_angle_item<LACC>(P, &V, j, ai, ak, A.SBO2, A.CSBO2, &S, e, w, lf, lcd);
             lds_add_f64(&s_sum[0][threadIdx.x], S.cdd); lds_add_f64(&s_sum[1][threadIdx.x], S.f[0]); lds_add_f64(&s_sum[2][threadIdx.x], S.f[1]);
             lds_add_f64(&s_sum[3][threadIdx.x], S.f[2]); lds_add_f64(&s_sum[4][threadIdx.x], S.dE_dSBO);
           }
@@ -1067,7 +1095,7 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDe
     const unsigned c = (unsigned)s_items[it];
     const int jl = (int)(c >> 24);
     RxAngleSum S = {0.0, {0.0, 0.0, 0.0}, 0.0};
-    rx_angle_item(P, &V, j0 + jl, (int)((c >> 12) & 0xFFF), (int)(c & 0xFFF), s_sbo[0][jl], s_sbo[1][jl], &S, e, w);
+    rx_angle_item<LACC>(P, &V, j0 + jl, (int)((c >> 12) & 0xFFF), (int)(c & 0xFFF), s_sbo[0][jl], s_sbo[1][jl], &S, e, w, lf, lcd);
     lds_add_f64(&s_sum[0][jl], S.cdd); lds_add_f64(&s_sum[1][jl], S.f[0]); lds_add_f64(&s_sum[2][jl], S.f[1]);
     lds_add_f64(&s_sum[3][jl], S.f[2]); lds_add_f64(&s_sum[4][jl], S.dE_dSBO);
   }
@@ -1075,7 +1103,11 @@ __global__ __launch_bounds__(RX_TORS_ATOMS, RX_OCC) void k_rx_angles(const SimDe
   if (has) {
     RxAngleSum S;
     S.cdd = s_sum[0][threadIdx.x]; S.f[0] = s_sum[1][threadIdx.x]; S.f[1] = s_sum[2][threadIdx.x]; S.f[2] = s_sum[3][threadIdx.x]; S.dE_dSBO = s_sum[4][threadIdx.x];
-    rx_angle_post(&V, j, &A, &S);
+    rx_angle_post<LACC>(&V, j, &A, &S, lf, lcd);
+  }
+  if (LACC) {
+    __syncthreads();
+    rx_acc_flush(V);
   }
   rx_flush(e, w, V, *sims[blockIdx.y].sc, P_ANGLE);
 }
@@ -1288,8 +1320,31 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   if (terms & 1) hipLaunchKernelGGL(k_rx_terms<0>, gr, dim3(RX_TPB), 0, sb, d, v, P);
   // (test hook: a small item list forces the in-place path of the two item kernels)
   static const int item_cap = scema_env("SCEMA_MD_RX_ITEMCAP") ? std::max(0, std::min(RX_TORS_CAP, atoi(scema_env("SCEMA_MD_RX_ITEMCAP")))) : RX_TORS_CAP;
-  if (terms & 2) hipLaunchKernelGGL(k_rx_angles, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, sb, d, v, P, item_cap);
-  if (terms & 4) hipLaunchKernelGGL(k_rx_torsions, g2(cdv(maxatoms, RX_TORS_ATOMS), ns), dim3(RX_TORS_ATOMS), 0, sb, d, v, P, item_cap);
+  {
+    // (replicas whose force table fits in LDS next to the item list: the items' atom sums meet there)
+    static const bool lacc_off = scema_env("SCEMA_MD_RX_ITEM_LDS") && atoi(scema_env("SCEMA_MD_RX_ITEM_LDS")) == 0;
+    const int mp = (maxatoms + 63) / 64 * 64;
+    const size_t acc_lds = 4 * (size_t)mp * sizeof(double);
+    const bool lacc = !lacc_off && mp <= RX_NB1_MAXPAD / 2;
+    if (lacc) {
+      static size_t optin_tab[16] = {0};
+      size_t &optin = lds_optin_slot(optin_tab);
+      if (acc_lds > 32 * 1024 && acc_lds > optin) {
+        (void)hipFuncSetAttribute((const void *)k_rx_angles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
+        (void)hipFuncSetAttribute((const void *)k_rx_torsions<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
+        optin = acc_lds;
+      }
+    }
+    const dim3 gi = g2(cdv(maxatoms, RX_TORS_ATOMS), ns);
+    if (terms & 2) {
+      if (lacc) hipLaunchKernelGGL(k_rx_angles<true>, gi, dim3(RX_TORS_ATOMS), acc_lds, sb, d, v, P, item_cap);
+      else hipLaunchKernelGGL(k_rx_angles<false>, gi, dim3(RX_TORS_ATOMS), 0, sb, d, v, P, item_cap);
+    }
+    if (terms & 4) {
+      if (lacc) hipLaunchKernelGGL(k_rx_torsions<true>, gi, dim3(RX_TORS_ATOMS), acc_lds, sb, d, v, P, item_cap);
+      else hipLaunchKernelGGL(k_rx_torsions<false>, gi, dim3(RX_TORS_ATOMS), 0, sb, d, v, P, item_cap);
+    }
+  }
   if (terms & 8) hipLaunchKernelGGL(k_rx_terms<3>, gr, dim3(RX_TPB), 0, sb, d, v, P);
   hipLaunchKernelGGL(k_rx_back1, ga, dim3(TPB), 0, sb, v, P);
   hipLaunchKernelGGL(k_rx_back2, ga, dim3(TPB), 0, sb, d, v, P);

@@ -26,6 +26,14 @@
 #define RX_ATOMIC_OR(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 #endif
 
+// Atom-indexed sums of the angle and torsion items (forces, dE/dDelta): with LACC they go to a workgroup's tables in LDS -- lf[3][npad], lcd[npad],
+// added to the work set once per workgroup by the kernel -- instead of one device-wide atomic each (a torsion item has 26 of them, 20 of these two
+// kinds; the pass was bound by them: 310 us per 72-replica launch against 106 us with the atomics compiled out, round 5).
+#if defined(RX_HOST_TEST)
+#define RX_LDS_ADD(p, v) (*(p) += (v))
+#else
+#define RX_LDS_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#endif
 #ifdef __cplusplus
 #define RX_DEFAULT_NULL = nullptr
 #else
@@ -164,6 +172,16 @@ RX_FN double rx_sqrt(double x) {
 }
 // sin(theta) of an angle in [0, pi] from its (clamped) cosine: sqrt((1 - c)(1 + c)) -- no acos, no sin
 RX_FN double rx_sin_of_cos(double c) { return rx_sqrt((1.0 - c) * (1.0 + c)); }
+template <bool LACC>
+RX_FN void rx_add_f(const RxView *V, double *lf, int atom, int m, double v) {
+  if (LACC) RX_LDS_ADD(&lf[(size_t)m * V->npad + atom], v);
+  else RX_ATOMIC_ADD(&V->f[3 * atom + m], v);
+}
+template <bool LACC>
+RX_FN void rx_add_cd(const RxView *V, double *lcd, int atom, double v) {
+  if (LACC) RX_LDS_ADD(&lcd[atom], v);
+  else RX_ATOMIC_ADD(&V->cd_delta[atom], v);
+}
 RX_FN double rx_taper(const RxParams *P, double r, double *dtap) {
   double t = P->tap[7], dt = 7.0 * P->tap[7];
   for (int m = 6; m >= 0; m--) t = t * r + P->tap[m];
@@ -483,7 +501,9 @@ RX_FN int rx_angle_item_valid(const RxView *V, int j, int ai, int ak) {
 }
 // one angle i-j-k: energies, dE/dBO of its two bonds (atomic: the items of an atom run on different lanes), forces on i and k, the
 // virial; what it adds to the central atom's sums comes back in S (added to, not set)
-RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int ak, double SBO2, double CSBO2, RxAngleSum *S, double *eng, double *vir) {
+template <bool LACC = false>
+RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int ak, double SBO2, double CSBO2, RxAngleSum *S, double *eng, double *vir,
+                         double *lf = nullptr, double *lcd = nullptr) {
   const int np = V->npad, tj = V->rtype[j];
   const size_t plane = (size_t)V->maxbd * np;
   const RxSbp *sj = &P->sbp[tj];
@@ -565,8 +585,8 @@ RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int 
         cdd_j += -p_coa2 * exp_coa2 * icoa2 * e_coa;
         g_i += (2.0 * p_coa3 * (tbi - BOA_ij) - 2.0 * p_coa4 * (BOA_ij - 1.5)) * e_coa;
         g_k += (2.0 * p_coa3 * (tbk - BOA_jk) - 2.0 * p_coa4 * (BOA_jk - 1.5)) * e_coa;
-        RX_ATOMIC_ADD(&V->cd_delta[i], -2.0 * p_coa3 * (tbi - BOA_ij) * e_coa);
-        RX_ATOMIC_ADD(&V->cd_delta[k], -2.0 * p_coa3 * (tbk - BOA_jk) * e_coa);
+        rx_add_cd<LACC>(V, lcd, i, -2.0 * p_coa3 * (tbi - BOA_ij) * e_coa);
+        rx_add_cd<LACC>(V, lcd, k, -2.0 * p_coa3 * (tbk - BOA_jk) * e_coa);
       }
       RX_ATOMIC_ADD(&V->bd_g[oi], g_i);
       RX_ATOMIC_ADD(&V->bd_g[ok], g_k);
@@ -579,7 +599,7 @@ RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int 
         fk[m] = -ce * db[m];
         fj[m] -= fi[m] + fk[m];
       }
-      for (int m = 0; m < 3; m++) { RX_ATOMIC_ADD(&V->f[3 * i + m], fi[m]); RX_ATOMIC_ADD(&V->f[3 * k + m], fk[m]); }
+      for (int m = 0; m < 3; m++) { rx_add_f<LACC>(V, lf, i, m, fi[m]); rx_add_f<LACC>(V, lf, k, m, fk[m]); }
       rx_vt(vir, dji, fi);
       rx_vt(vir, djk, fk);
     }
@@ -588,7 +608,8 @@ RX_FN void rx_angle_item(const RxParams *P, const RxView *V, int j, int ai, int 
   S->dE_dSBO += dE_dSBO;
 }
 // SBO feeds every bond of j and Delta_j; the force on j
-RX_FN void rx_angle_post(const RxView *V, int j, const RxAnglePre *A, const RxAngleSum *S) {
+template <bool LACC = false>
+RX_FN void rx_angle_post(const RxView *V, int j, const RxAnglePre *A, const RxAngleSum *S, double *lf = nullptr, double *lcd = nullptr) {
   const int np = V->npad, cnt = V->bd_cnt[j];
   const size_t plane = (size_t)V->maxbd * np;
   double cdd_j = S->cdd;
@@ -603,8 +624,8 @@ RX_FN void rx_angle_post(const RxView *V, int j, const RxAnglePre *A, const RxAn
     }
     cdd_j += S->dE_dSBO * A->dSBO_dDelta;
   }
-  RX_ATOMIC_ADD(&V->cd_delta[j], cdd_j);
-  for (int m = 0; m < 3; m++) RX_ATOMIC_ADD(&V->f[3 * j + m], S->f[m]);
+  rx_add_cd<LACC>(V, lcd, j, cdd_j);
+  for (int m = 0; m < 3; m++) rx_add_f<LACC>(V, lf, j, m, S->f[m]);
 }
 RX_FN void rx_angle_terms(const RxParams *P, const RxView *V, int j, double *eng, double *vir) {
   RxAnglePre A;
@@ -636,7 +657,8 @@ RX_FN int rx_torsion_item_valid(const RxView *V, int j, int ak, int ai) {
 // Everything it adds to shared places is atomic (other items reach the same bonds and atoms); the sums over a central bond's items
 // (dE/dBO_jk, dE/dBO_pi_jk, dE/dDelta, forces on j and k) therefore leave per item.  The GPU puts a lane on an item
 // (k_rx_torsions compacts the items of a block of atoms first); rx_torsion_terms below is the same work atom by atom.
-RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, int ai, double *eng, double *vir) {
+template <bool LACC = false>
+RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, int ai, double *eng, double *vir, double *lf = nullptr, double *lcd = nullptr) {
   const int np = V->npad, tj = V->rtype[j];
   const size_t plane = (size_t)V->maxbd * np;
   const double p_tor2 = P->gp[23], p_tor3 = P->gp[24], p_tor4 = P->gp[25], p_cot2 = P->gp[27];
@@ -755,7 +777,7 @@ RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, in
           fk[m] += -dq[m] + ds[m];
           fl[m] = -ds[m];
         }
-        for (int m = 0; m < 3; m++) RX_ATOMIC_ADD(&V->f[3 * l + m], fl[m]);
+        for (int m = 0; m < 3; m++) rx_add_f<LACC>(V, lf, l, m, fl[m]);
         // virial about j: positions p (i), 0 (j), q (k), q + s (l)
         const double mdp[3] = {-dp[0], -dp[1], -dp[2]}, fkk[3] = {-dq[0] + ds[0], -dq[1] + ds[1], -dq[2] + ds[2]}, qs[3] = {q[0] + s[0], q[1] + s[1], q[2] + s[2]};
         rx_vt(vir, p, mdp);
@@ -763,12 +785,12 @@ RX_FN void rx_torsion_item(const RxParams *P, const RxView *V, int j, int ak, in
         rx_vt(vir, qs, fl);
       }
       RX_ATOMIC_ADD(&V->bd_g[oij], g_ij);   // other items reach this row as their far bond in the same pass
-      for (int m = 0; m < 3; m++) RX_ATOMIC_ADD(&V->f[3 * i + m], fi[m]);
+      for (int m = 0; m < 3; m++) rx_add_f<LACC>(V, lf, i, m, fi[m]);
   }
   if (g_jk != 0.0) RX_ATOMIC_ADD(&V->bd_g[ojk], g_jk);
   if (gpi_jk != 0.0) RX_ATOMIC_ADD(&V->bd_g[plane + ojk], gpi_jk);
-  if (cdd != 0.0) { RX_ATOMIC_ADD(&V->cd_delta[j], cdd); RX_ATOMIC_ADD(&V->cd_delta[k], cdd); }
-  for (int m = 0; m < 3; m++) { RX_ATOMIC_ADD(&V->f[3 * j + m], fj[m]); RX_ATOMIC_ADD(&V->f[3 * k + m], fk[m]); }
+  if (cdd != 0.0) { rx_add_cd<LACC>(V, lcd, j, cdd); rx_add_cd<LACC>(V, lcd, k, cdd); }
+  for (int m = 0; m < 3; m++) { rx_add_f<LACC>(V, lf, j, m, fj[m]); rx_add_f<LACC>(V, lf, k, m, fk[m]); }
 }
 RX_FN void rx_torsion_terms(const RxParams *P, const RxView *V, int j, double *eng, double *vir) {
   const int cnt = V->bd_cnt[j];
