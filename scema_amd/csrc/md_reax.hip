@@ -1142,10 +1142,13 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded(const SimDev *sims, cons
 // once per workgroup.  Half the transcendental arithmetic of the both-ends form (three exp, two log, a cube root per pair).
 #define RX_NB1_MAXPAD 6000
 extern __shared__ double s_nbf[];   // [3][npad]
+#ifndef RX_NB1_ROWS
+#define RX_NB1_ROWS 64   /* rows of a workgroup (a multiple of 64) */
+#endif
 __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = V.n;
-  if ((int)(blockIdx.x * 64) >= n) return;
+  if ((int)(blockIdx.x * RX_NB1_ROWS) >= n) return;
   const size_t np = V.npad;
   __shared__ RxTbp s_tbp[RX_MAXT * RX_MAXT];   // the pair parameters in LDS (a dependent global load less per pair)
   for (int k = threadIdx.x; k < (int)(sizeof(s_tbp) / 8); k += RX_KT) ((double *)s_tbp)[k] = ((const double *)P->tbp)[k];
@@ -1158,8 +1161,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims,
   for (int k = 0; k < RX_NPART; k++) e[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; k++) w[k] = 0.0;
-  for (int r = 0; r < 64 / RX_KS; r++) {
-    const int i = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
+  for (int r = 0; r < RX_NB1_ROWS / RX_KS; r++) {
+    const int i = blockIdx.x * RX_NB1_ROWS + wave * (RX_NB1_ROWS / RX_KS) + r;
     if (i >= n) break;   // (wave-uniform)
     const int len = V.hownlen[i], ti = V.rtype[i];
     const size_t base = (size_t)i * V.maxnb;
@@ -1207,9 +1210,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_nonbonded_once(const SimDev *sims,
     const double v = s_nbf[(size_t)c * np + a];
     if (v != 0.0) atomicAdd(&V.f[k], v);
   }
-  {
-    const int i = blockIdx.x * 64 + lane;
-    if (wave == 0 && i < n) {
+  for (int i = blockIdx.x * RX_NB1_ROWS + threadIdx.x; i < min(n, (int)(blockIdx.x + 1) * RX_NB1_ROWS); i += RX_KT) {
+    {
       const double qi = V.q[i];
       const int ti = V.rtype[i];
       e[RX_E_POL] += RX_KCALPMOL_TO_EV * (P->sbp[ti].chi * qi + 0.5 * P->sbp[ti].eta * qi * qi);
@@ -1372,7 +1374,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
       static size_t optin_tab[16] = {0};
       size_t &optin = lds_optin_slot(optin_tab);
       if (lds > 48 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_rx_nonbonded_once, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-      hipLaunchKernelGGL(k_rx_nonbonded_once, gk, dim3(RX_KT), lds, st, d, v, P);
+      hipLaunchKernelGGL(k_rx_nonbonded_once, g2(cdv(maxatoms, RX_NB1_ROWS), ns), dim3(RX_KT), lds, st, d, v, P);
     } else hipLaunchKernelGGL(k_rx_nonbonded, gk, dim3(RX_KT), 0, st, d, v, P);
   }
   if (side) (void)hipStreamWaitEvent(st, side->join, 0);
