@@ -153,7 +153,7 @@ struct RxSlot {
   int cap_pad = 0, cap_nb = 0, cap_bd = 0, cap_nbn = 0;
   size_t cap_col = 0;
   DevBuf nbn_cnt, nbn, nbnT, qpart, pm_len, pm_col, pm_raw, pm_val;
-  DevBuf nb_cnt, nbT, hval, hcol, hlen, hown, hownlen, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
+  DevBuf nb_cnt, nb_own0, nbT, hval, hcol, hlen, hown, hownlen, bd_cnt, bd, bd_rev, bd_bop, bd_c, bd_bo, bd_g, bd_cb, deltap, total_bo, cd_delta, hd, q, s, t, s_hist, t_hist, qwork, misc;
 };
 
 // what the neighbour rows of a slot were built for: a run that follows on the same slot keeps them if all of it still holds
@@ -334,6 +334,7 @@ struct scema_md_engine {
   double rx_skin = 0.75, rx_qeq_tol = 1e-6;   // (list skin in A, performance only.  1.0 until the wave-per-row list build of round 5 made a rebuild a fifth as dear:
                                               // 0.3: 1 177, 0.5: 1 191, 0.75: 1 193, 1.0: 1 177 evaluations/s on the 72-replica set, same box)
   int rx_qeq_maxiter = 200, rx_terms = 31;
+  bool rx_sym = true;                  // the symmetric form of the charge solve where a batch allows it (SCEMA_REAX_QEQ_SYM=0: full rows)
   long long rx_qeq_iters = 0, rx_qeq_solves = 0, rx_qeq_slow = 0;
   int rx_qeq_launch_cold = 48;        // the same for the first solves of a run (empty history)
   int rx_qeq_launch = 32;             // conjugate-gradient iterations issued as batch launches per solve (follows what the last run needed)

@@ -63,6 +63,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_REAX_HALVES", "number of part batches a ReaxFF batch runs as, each on its own stream (default 2; 0 or 1: one sequence of launches)"},
     {"SCEMA_REAX_OVERLAP", "0: the bond-order chain of the ReaxFF force stage on the same stream as the charge chain instead of next to it"},
     {"SCEMA_REAX_QEQ_PRECOND", "0: the conjugate gradients of the charge equilibration with the Jacobi preconditioner of fix qeq/reax instead of the bonded-pattern approximate inverse"},
+    {"SCEMA_REAX_QEQ_SYM", "0: the matrix of the charge equilibration as full rows (every pair in both rows) instead of each pair once in its owner's row"},
     {"SCEMA_REAX_QEQ_ZLDS", "0: the matrix sweep of the charge equilibration gathers through the caches instead of from an LDS copy"},
     {"SCEMA_REAX_QEQ_LAUNCH", "conjugate-gradient iterations issued as launches per charge solve (default: adaptive)"},
     // test hooks: force rarely-taken paths
@@ -144,6 +145,7 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
   if (const char *sx = scema_env("SCEMA_REAX_HALVES")) e->rx_halves = std::max(0, std::min(8, atoi(sx)));
   if (const char *sx = scema_env("SCEMA_REAX_OVERLAP")) e->rx_overlap = atoi(sx) != 0;
   if (const char *sx = scema_env("SCEMA_REAX_QEQ_PRECOND")) e->rx_precond = atoi(sx) != 0;
+  if (const char *sx = scema_env("SCEMA_REAX_QEQ_SYM")) e->rx_sym = atoi(sx) != 0;
   if (e->stream2 && e->stream3) {   // (fourth and last stream of an engine: see engine.h)
     bool ok = hipStreamCreateWithFlags(&e->rx_side1, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 4 && ok; k++) ok = hipEventCreateWithFlags(&e->rx_side1_ev[k], hipEventDisableTiming) == hipSuccess;

@@ -32,6 +32,7 @@ static int ensure_rx_slot(scema_md_engine *e, RxSlot &r, int n, int npad, int ma
     HIPCHK(r.nbn_cnt.ensure((size_t)npad * 4));
     HIPCHK(r.hlen.ensure((size_t)npad * 4));
     HIPCHK(r.hownlen.ensure((size_t)npad * 4));
+    HIPCHK(r.nb_own0.ensure((size_t)npad * 4));
     HIPCHK(r.misc.ensure(256));
     r.cap_pad = npad;
     r.cap_nb = 0;
@@ -111,6 +112,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   for (int i = 0; i < ns; i++) col16 = col16 && sims[i].st->topo->natoms <= 65536;
   e->h_zerotab.clear();
   bool any_precond = false;
+  bool all_sym = col16 && e->rx_sym;
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
     ActiveSim &A = sims[i];
@@ -213,11 +215,13 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     RXSET(V.f, S.f); RXSET(V.hval, col16 ? nullptr : R.hval.as<double>()); RXSET(V.hpk, col16 ? R.hval.as<unsigned long long>() : nullptr); RXSET(V.s, R.s.as<double>()); RXSET(V.t, R.t.as<double>());
     V.warm = (spec.qeq_continue || A.st->qhist_valid) ? 1 : 0;
     RXSET(V.hcol16, (unsigned short *)nullptr); RXSET(V.hcol32, col16 ? nullptr : R.hcol.as<int>()); RXSET(V.hlen, R.hlen.as<int>()); RXSET(V.nbT, R.nbT.as<int>());
-    RXSET(V.hown, R.hown.as<int>()); RXSET(V.hownlen, R.hownlen.as<int>());
+    RXSET(V.hown, R.hown.as<int>()); RXSET(V.hownlen, R.hownlen.as<int>()); RXSET(V.nb_own0, R.nb_own0.as<int>());
     RXSET(V.s_hist, R.s_hist.as<double>()); RXSET(V.t_hist, R.t_hist.as<double>()); RXSET(V.qwork, R.qwork.as<double>());
     // the bonded-pattern preconditioner needs one image per neighbour (boxes at least two list radii wide: every production replica)
     V.pm_on = (e->rx_precond && V.mimg[0] == 0 && V.mimg[1] == 0 && V.mimg[2] == 0) ? 1 : 0;
     any_precond = any_precond || V.pm_on;
+    // the symmetric form of the solve: rows sorted by partner (one image per neighbour), both vectors of the replica in a workgroup's LDS
+    all_sym = all_sym && V.mimg[0] == 0 && V.mimg[1] == 0 && V.mimg[2] == 0 && 2 * (size_t)npad * 16 + 4096 <= 128 * 1024;
     RXSET(V.pm_len, R.pm_len.as<int>()); RXSET(V.pm_col, R.pm_col.as<int>()); RXSET(V.pm_raw, R.pm_raw.as<double>()); RXSET(V.pm_val, R.pm_val.as<double>());
     RXSET(V.eparts, R.misc.as<double>());                         // [0, 13) doubles
     RXSET(V.qstat, (int *)(R.misc.as<char>() + 128));             // 6 ints
@@ -280,6 +284,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     pl.launch = (step < 4 && any_cold) ? e->rx_qeq_launch_cold : e->rx_qeq_launch;
     pl.setup = step == 0 ? 1 : 0;
     pl.precond = any_precond ? 1 : 0;
+    pl.sym = all_sym ? 1 : 0;
     return pl;
   };
   mdk_reax_phase_init(st, VV, ns, maxpad);

@@ -13,6 +13,7 @@ struct RxQeqPlan {
   int launch = 0;  // conjugate-gradient iterations issued as launches over the batch (replicas that need more finish inside k_rx_qeq_finish)
   int setup = 0;   // the solve of a run's step 0 (a replica that kept its history starts from the newest solution)
   int precond = 0; // the batch's views have pm_on set: build the sparse approximate inverse before the solve
+  int sym = 0;     // the symmetric form of the solve (every replica of the batch: minimum image, 16-bit columns, two vectors of the replica in LDS)
 };
 // the whole force stage of one step for the first ns replicas: (neighbour rows if the rebuild flag of the step is set,)
 // charge equilibration, bond orders, energy terms, forces into SimDev::f, virial and energies into SimScalars.

@@ -108,13 +108,13 @@ __global__ __launch_bounds__(64 * (64 / RX_NBR)) void k_rx_neigh(const SimDev *s
   const int m0 = V.mimg[0], m1 = V.mimg[1], m2 = V.mimg[2];
   const bool minimage = (m0 | m1 | m2) == 0;
   double xr[RX_NBR], yr[RX_NBR], zr[RX_NBR];
-  int len[RX_NBR], lenn[RX_NBR], trow[RX_NBR];
+  int len[RX_NBR], lenn[RX_NBR], trow[RX_NBR], lown0[RX_NBR];
 #pragma unroll
   for (int g = 0; g < RX_NBR; g++) {
     const int row = min(r0 + g, n - 1);
     xr[g] = wave_uniform(S.x[3 * row]); yr[g] = wave_uniform(S.x[3 * row + 1]); zr[g] = wave_uniform(S.x[3 * row + 2]);
     trow[g] = __builtin_amdgcn_readfirstlane(V.rtype[row]) * RX_MAXT;
-    len[g] = 0; lenn[g] = 0;
+    len[g] = 0; lenn[g] = 0; lown0[g] = 0;
   }
   // one accepted (partner, image) per lane -> the row's next entries
   auto append = [&](int g, bool ok, bool near, int ent) __attribute__((always_inline)) {
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64 * (64 / RX_NBR)) void k_rx_neigh(const SimDev *s
     const int pos = len[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
     if (ok && pos < maxnb) V.nbT[(size_t)row * maxnb + pos] = ent;
     len[g] += __popcll(m);
+    lown0[g] += __popcll(__ballot(ok && !rx_owns(row, ent)));   // (minimum image: these all come before the owned ones)
     const unsigned long long mn = __ballot(ok && near);
     if (mn == 0) return;
     const int posn = lenn[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(mn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mn, 0));
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64 * (64 / RX_NBR)) void k_rx_neigh(const SimDev *s
     full |= len[g] > maxnb || lenn[g] > maxnbn;
     const int c = min(len[g], maxnb);
     most = max(most, c);
-    if (lane == 0) { V.nb_cnt[r0 + g] = c; V.nbn_cnt[r0 + g] = min(lenn[g], maxnbn); }
+    if (lane == 0) { V.nb_cnt[r0 + g] = c; V.nbn_cnt[r0 + g] = min(lenn[g], maxnbn); V.nb_own0[r0 + g] = min(lown0[g], c); }
   }
   if (lane == 0) {
     if (full) atomicOr(V.overflow, 1);
@@ -205,6 +206,9 @@ __device__ __forceinline__ void rx_shift_table(const RxView &V, double *s_sh) {
     s_sh[3 * code + 2] = sz * V.h[2];
   }
 }
+// SYM (round 5, the symmetric form of the charge solve): only the pairs a row OWNS are computed -- the tail of the row from nb_own0 on -- and stored,
+// matrix entry (hpk) and list entry (hown) at the same position; hlen = hownlen.  Half the arithmetic and half the stores of the full rows.
+template <bool SYM>
 __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
   (void)sims;
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
   for (int r = 0; r < 64 / RX_KS; r += RG) {
     const int ifirst = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
     if (ifirst >= V.n) return;   // (wave-uniform; no barrier below)
-    int row[RG], cnt[RG], len[RG], lown[RG], e1[RG], e2[RG], tjn[RG], ent_prev[RG];
+    int row[RG], cnt[RG], own0[RG], len[RG], lown[RG], e1[RG], e2[RG], tjn[RG], ent_prev[RG];
     size_t base[RG];
     const double *grow[RG];
     double xi0[RG], xi1[RG], xi2[RG], p0[RG], p1[RG], p2[RG], h_prev[RG];
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
     for (int g = 0; g < RG; g++) {
       const bool live = ifirst + g < V.n;
       row[g] = live ? ifirst + g : ifirst;
-      cnt[g] = live ? V.nb_cnt[row[g]] : 0;
+      own0[g] = (SYM && live) ? V.nb_own0[row[g]] : 0;
+      cnt[g] = live ? V.nb_cnt[row[g]] - own0[g] : 0;   // (entries this walk takes: all of the row, or its owned tail)
       cmax = max(cmax, cnt[g]);
       base[g] = (size_t)row[g] * V.maxnb;
       grow[g] = s_gamma + V.rtype[row[g]] * RX_MAXT;
@@ -248,13 +253,23 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
       xi0[g] = wave_uniform(V.x[3 * row[g]]); xi1[g] = wave_uniform(V.x[3 * row[g] + 1]); xi2[g] = wave_uniform(V.x[3 * row[g] + 2]);
       len[g] = 0; lown[g] = 0; h_prev[g] = -1.0; ent_prev[g] = -1;
     }
-    auto load_ent = [&](int g, int k0) -> int { const int k = k0 + lane; return (k < cnt[g]) ? V.nbT[base[g] + k] : -1; };
+    auto load_ent = [&](int g, int k0) -> int { const int k = k0 + lane; return (k < cnt[g]) ? V.nbT[base[g] + own0[g] + k] : -1; };
     auto gather = [&](int g) __attribute__((always_inline)) {
       const int j = (e1[g] >= 0) ? (e1[g] & RX_JMASK) : 0;
       p0[g] = V.x[3 * j]; p1[g] = V.x[3 * j + 1]; p2[g] = V.x[3 * j + 2]; tjn[g] = V.rtype[j];
     };
     auto flush = [&](int g) __attribute__((always_inline)) {
       const unsigned long long m = __ballot(h_prev[g] >= 0.0);
+      if (SYM) {
+        if (h_prev[g] >= 0.0) {
+          const size_t o = base[g] + len[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+          V.hpk[o] = rx_hpack(h_prev[g], ent_prev[g] & RX_JMASK);
+          V.hown[o] = ent_prev[g];
+        }
+        len[g] += __popcll(m);
+        lown[g] = len[g];
+        return;
+      }
       if (h_prev[g] >= 0.0) {
         const size_t o = base[g] + len[g] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if (V.hpk) V.hpk[o] = rx_hpack(h_prev[g], ent_prev[g] & RX_JMASK);
@@ -396,7 +411,7 @@ __device__ __forceinline__ QeqScal qeq_scalars_with(const RxView &V, int it, dou
 
 // setup != 0: the solve of a run's step 0.  A replica whose history was kept from the run before (RxView::warm) stands where that
 // run's last solve stood: its guess is the newest stored solution, not the extrapolation one step ahead
-__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views, int setup) {
+__global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views, int setup, int sym) {
   const RxView V = views[blockIdx.y];
   const int i = blockIdx.x * QEQ_UT + threadIdx.x;
   if (i >= V.n) return;
@@ -408,6 +423,7 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views, in
   V.s[i] = s0; V.t[i] = t0;
   double2 *z = (double2 *)(V.qwork + 6 * np);
   z[i] = make_double2(s0, t0);
+  if (sym) ((double2 *)(V.qwork + 8 * np))[i] = make_double2(0.0, 0.0);   // (the product vector the symmetric sweeps add to)
 }
 
 // it < 0: the first product H x0 of the solve (x0 sits in z), stored in q
@@ -725,6 +741,48 @@ __device__ __forceinline__ void qeq_reduce2(double &a, double &b, double *lds) {
   a = sa;
   b = sb;
 }
+// the end of a solve, one workgroup per replica: charges q = s - (sum s / sum t) t, the history pushed down, the solver's statistics
+// (`it`: iterations made by the single-workgroup loop after the launched ones; `unconverged`: the iteration limit was reached)
+__device__ __forceinline__ void qeq_finish_tail(const RxView &V, int setup, int it, bool unconverged, double *s_red) {
+  const int n = V.n, tid = threadIdx.x;
+  const size_t np = V.npad;
+  double *s = V.s, *t = V.t;
+  double ss = 0.0, st = 0.0;
+  for (int i = tid; i < n; i += QEQ_TPB) { ss += s[i]; st += t[i]; }
+  qeq_reduce2(ss, st, s_red);
+  const double u = ss / st;
+  const bool same_place = setup && V.warm;   // the atoms stand where the newest stored solution was taken: it is replaced, not pushed down
+  for (int i = tid; i < n; i += QEQ_TPB) {
+    V.q[i] = s[i] - u * t[i];
+    double *sh = V.s_hist, *th = V.t_hist;
+    if (!same_place) {
+      sh[3 * np + i] = sh[2 * np + i]; sh[2 * np + i] = sh[np + i]; sh[np + i] = sh[i];
+      th[2 * np + i] = th[np + i]; th[np + i] = th[i];
+    }
+    sh[i] = s[i];
+    th[i] = t[i];
+  }
+  // what the launched sweeps of this solve read: every stored entry of the replica's rows once per sweep it took part in
+  // (the launches counted by k_rx_qeq_update, plus the first product H x0)
+  double nent = 0.0, nrow = 0.0;
+  for (int i = tid; i < n; i += QEQ_TPB) { nent += (double)V.hlen[i]; nrow += 1.0; }
+  qeq_reduce2(nent, nrow, s_red);
+  if (tid == 0) {
+    const long long sweeps = (long long)(V.qstat[0] - V.qstat[4]) + 1;   // k_rx_qeq_update counted the launched iterations; plus the first product
+    V.sweep_acc[0] += sweeps * (long long)(nent + 0.5);
+    V.sweep_acc[1] += sweeps * (long long)n;
+    const int total = V.qstat[0] + it;
+    V.qstat[0] = total;
+    V.qstat[1] += 1;
+    const int mine = total - V.qstat[4];
+    V.qstat[4] = total;
+    // the first solves of a run that starts from an empty history take longer: their own record
+    const int rec = (V.qstat[1] <= RX_QEQ_COLD) ? 5 : 2;
+    if (mine > V.qstat[rec]) V.qstat[rec] = mine;
+    if (it > 0) V.qstat[3] += 1;
+    if (unconverged) atomicOr(V.overflow, 4);
+  }
+}
 // One workgroup per replica after `done` iterations of the launches above: a replica that has not converged yet goes on here
 // with the same recurrences on the same arrays (the result does not depend on how many iterations were issued as launches, only
 // the summation order of the scalar products differs), then q = s - (sum s / sum t) t and the history.
@@ -804,41 +862,232 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
       __syncthreads();
     }
   }
-  double ss = 0.0, st = 0.0;
-  for (int i = tid; i < n; i += QEQ_TPB) { ss += s[i]; st += t[i]; }
-  qeq_reduce2(ss, st, s_red);
-  const double u = ss / st;
-  const bool same_place = setup && V.warm;   // the atoms stand where the newest stored solution was taken: it is replaced, not pushed down
-  for (int i = tid; i < n; i += QEQ_TPB) {
-    V.q[i] = s[i] - u * t[i];
-    double *sh = V.s_hist, *th = V.t_hist;
-    if (!same_place) {
-      sh[3 * np + i] = sh[2 * np + i]; sh[2 * np + i] = sh[np + i]; sh[np + i] = sh[i];
-      th[2 * np + i] = th[np + i]; th[np + i] = th[i];
+  qeq_finish_tail(V, setup, it, run_s || run_t, s_red);
+}
+
+// ---- the symmetric form of the solve (round 5) ----
+// H is symmetric and every pair is OWNED by one of its ends (rx_owns): k_rx_hrow<true> stores each pair once, in its owner's row, and a sweep makes both
+// products of an entry -- y_i += h z_j summed over the row by the wave as before, y_j += h z_i through LDS atomics into a copy of the replica's
+// vector -- for half the bytes and half the matrix arithmetic of the full rows.  A workgroup's part of y meets the others' in memory (coalesced
+// atomics, once per workgroup), so y is complete only when the sweep has ENDED: what followed the product inside the full-row sweep (d, q, d.q)
+// moves to the launch after it, which is one workgroup per replica and keeps every scalar of the recurrences itself:
+//   k_rx_qeq_sweep_sym  y += H z (both triangles), workgroups of a converged replica leave at once
+//   k_rx_qeq_step       y complete: d = z + beta d, q = y + beta q, alpha = sigma / d.q, s += alpha d, r -= alpha q, z = M r, sigma' = r.z, the stop
+// The scalars of a replica's solve sit in qpart[0 .. QS_N) (no partial sums in this form).  y: the fifth array of qwork.
+enum { QS_SIG = 0, QS_PREV = 2, QS_BN = 4, QS_RUN = 6, QS_N = 8 };
+struct QeqState { double sig[2], prev[2], bn[2]; bool run[2]; };
+__device__ __forceinline__ QeqState qeq_state_load(const RxView &V) {
+  QeqState S;
+  const double RX_G *q = V.qpart;
+  S.sig[0] = q[QS_SIG]; S.sig[1] = q[QS_SIG + 1]; S.prev[0] = q[QS_PREV]; S.prev[1] = q[QS_PREV + 1];
+  S.bn[0] = q[QS_BN]; S.bn[1] = q[QS_BN + 1]; S.run[0] = q[QS_RUN] != 0.0; S.run[1] = q[QS_RUN + 1] != 0.0;
+  return S;
+}
+__device__ __forceinline__ void qeq_state_store(const RxView &V, const QeqState &S) {
+  double RX_G *q = V.qpart;
+  q[QS_SIG] = S.sig[0]; q[QS_SIG + 1] = S.sig[1]; q[QS_PREV] = S.prev[0]; q[QS_PREV + 1] = S.prev[1];
+  q[QS_BN] = S.bn[0]; q[QS_BN + 1] = S.bn[1]; q[QS_RUN] = S.run[0] ? 1.0 : 0.0; q[QS_RUN + 1] = S.run[1] ? 1.0 : 0.0;
+}
+__device__ __forceinline__ double2 *qeq_ybuf(const RxView &V) { return (double2 *)(V.qwork + 8 * (size_t)V.npad); }
+extern __shared__ double2 s_sym[];   // [0, npad): z of the replica; [npad, 2 npad): this workgroup's part of y
+// the products of the rows [row0, row1) with NW waves, two rows of a wave at a time (their loads are independent); s_z read, s_y added to
+template <int NW>
+__device__ __forceinline__ void qeq_sym_product(const RxView &V, int row0, int row1, const double2 *s_z, double2 *s_y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const GLOBAL_AS unsigned long long *pk = as_global(V.hpk);
+  const GLOBAL_AS int *hlen = as_global(V.hownlen);
+  for (int ra = row0 + 2 * wave; ra < row1; ra += 2 * NW) {
+    int len[2], lmax = 0;
+    size_t base[2];
+    double2 zi[2];
+    double ps[2], pt[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int row = ra + q;
+      const bool live = row < row1;
+      len[q] = live ? hlen[row] : 0;   // (wave-uniform)
+      base[q] = (size_t)(live ? row : ra) * V.maxnb;
+      zi[q] = s_z[live ? row : ra];
+      lmax = max(lmax, len[q]);
+      ps[q] = 0.0; pt[q] = 0.0;
     }
-    sh[i] = s[i];
-    th[i] = t[i];
+    unsigned long long bn[2];
+    auto load = [&](int c0) {
+      const int c = c0 + lane;
+#pragma unroll
+      for (int q = 0; q < 2; q++) bn[q] = (c < len[q]) ? pk[base[q] + c] : ~0ull;
+    };
+    load(0);
+    for (int c0 = 0; c0 < lmax; c0 += 64) {
+      unsigned long long b[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) b[q] = bn[q];
+      load(c0 + 64);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (b[q] != ~0ull) {   // (a stored value is positive and finite: no entry has this pattern)
+          int j;
+          const double h = rx_hunpack(b[q], &j);
+          const double2 zj = s_z[j];
+          ps[q] = fma(h, zj.x, ps[q]);
+          pt[q] = fma(h, zj.y, pt[q]);
+          lds_add_f64(&s_y[j].x, h * zi[q].x);
+          lds_add_f64(&s_y[j].y, h * zi[q].y);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const double a = wave_sum(ps[q]), bsum = wave_sum(pt[q]);
+      if (lane == 0 && ra + q < row1) { lds_add_f64(&s_y[ra + q].x, a); lds_add_f64(&s_y[ra + q].y, bsum); }
+    }
   }
-  // what the launched sweeps of this solve read: every stored entry of the replica's rows once per sweep it took part in
-  // (the launches counted by k_rx_qeq_update, plus the first product H x0)
-  double nent = 0.0, nrow = 0.0;
-  for (int i = tid; i < n; i += QEQ_TPB) { nent += (double)V.hlen[i]; nrow += 1.0; }
-  qeq_reduce2(nent, nrow, s_red);
+}
+// it < 0: the first product H x0 of a solve (x0 sits in z)
+__global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep_sym(const RxView *views, int it) {
+  const RxView V = views[blockIdx.y];
+  const int n = V.n, row0 = blockIdx.x * RX_SWR;
+  if (row0 >= n) return;
+  if (it >= 0 && V.qpart[QS_RUN] == 0.0 && V.qpart[QS_RUN + 1] == 0.0) return;   // (uniform) both systems have converged
+  const size_t np = V.npad;
+  double2 *s_z = s_sym, *s_y = s_sym + np;
+  const GLOBAL_AS dvec2 *z = as_global((const dvec2 *)(V.qwork + 6 * np));
+  for (int k0 = threadIdx.x; k0 < n; k0 += 4 * RX_KT) {
+    double2 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int k = k0 + u * RX_KT; t[u] = ldg2(z, k < n ? k : n - 1); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int k = k0 + u * RX_KT; if (k < n) { s_z[k] = t[u]; s_y[k] = make_double2(0.0, 0.0); } }
+  }
+  __syncthreads();
+  qeq_sym_product<RX_KS>(V, row0, min(row0 + RX_SWR, n), s_z, s_y);
+  __syncthreads();
+  double *yg = (double *)qeq_ybuf(V);
+  const double *yl = (const double *)s_y;
+  for (int k = threadIdx.x; k < 2 * n; k += RX_KT) {
+    const double v = yl[k];
+    if (v != 0.0) atomicAdd(&yg[k], v);
+  }
+}
+// One iteration's vector work for a replica with NT threads of ONE workgroup; y (the finished product H z without the diagonal; read, and
+// zeroed for the next sweep if `zero_y`) in memory or in LDS.  first: d = z, q = y.  The recurrences and their order are k_rx_qeq_finish's.
+template <int NT>
+__device__ __forceinline__ void qeq_sym_step(const RxView &V, const RxParams *__restrict__ P, double tol, bool first, QeqState &S, double2 *y, bool zero_y, double *s_red) {
+  const int n = V.n, tid = threadIdx.x;
+  const size_t np = V.npad;
+  double *s = V.s, *t = V.t;
+  double2 *r = qeq_rbuf(V, 0), *d = (double2 *)(V.qwork + 2 * np), *q = (double2 *)(V.qwork + 4 * np), *z = (double2 *)(V.qwork + 6 * np);
+  const bool run_s = S.run[0], run_t = S.run[1];
+  const double be_s = first ? 0.0 : S.sig[0] / S.prev[0], be_t = first ? 0.0 : S.sig[1] / S.prev[1];
+  double dq_s = 0.0, dq_t = 0.0;
+  for (int i = tid; i < n; i += NT) {
+    const double eta = P->sbp[V.rtype[i]].eta;
+    const double2 zi = z[i], yi = y[i];
+    if (zero_y) y[i] = make_double2(0.0, 0.0);
+    const double ys = fma(eta, zi.x, yi.x), yt = fma(eta, zi.y, yi.y);
+    double2 di = first ? make_double2(0.0, 0.0) : d[i], qi = first ? make_double2(0.0, 0.0) : q[i];
+    if (run_s) { di.x = fma(be_s, di.x, zi.x); qi.x = fma(be_s, qi.x, ys); dq_s += di.x * qi.x; }
+    if (run_t) { di.y = fma(be_t, di.y, zi.y); qi.y = fma(be_t, qi.y, yt); dq_t += di.y * qi.y; }
+    d[i] = di; q[i] = qi;
+  }
+  qeq_reduce2(dq_s, dq_t, s_red);
+  const double al_s = run_s ? S.sig[0] / dq_s : 0.0, al_t = run_t ? S.sig[1] / dq_t : 0.0;
+  double sn_s = 0.0, sn_t = 0.0, cv_s = 0.0, cv_t = 0.0;
+  for (int i = tid; i < n; i += NT) {
+    const double eta = P->sbp[V.rtype[i]].eta;
+    const double2 di = d[i], qi = q[i];
+    double2 ri = r[i], zi = z[i];
+    if (run_s) { s[i] = fma(al_s, di.x, s[i]); ri.x = fma(-al_s, qi.x, ri.x); zi.x = ri.x / eta; }
+    if (run_t) { t[i] = fma(al_t, di.y, t[i]); ri.y = fma(-al_t, qi.y, ri.y); zi.y = ri.y / eta; }
+    r[i] = ri;
+    if (!V.pm_on) { z[i] = zi; sn_s += ri.x * zi.x; sn_t += ri.y * zi.y; }
+    cv_s += ri.x * ri.x / eta; cv_t += ri.y * ri.y / eta;
+  }
+  if (V.pm_on) {
+    __syncthreads();   // the residuals of the whole replica are in place: z = M r gathers the neighbours'
+    for (int i = tid; i < n; i += NT) {
+      const double2 ri = r[i];
+      const double2 zn = qeq_pm_apply(V, i, [&](int k) { return r[k]; });
+      double2 zi = z[i];
+      if (run_s) zi.x = zn.x;
+      if (run_t) zi.y = zn.y;
+      z[i] = zi;
+      sn_s += ri.x * zi.x; sn_t += ri.y * zi.y;
+    }
+  }
+  qeq_reduce2(sn_s, sn_t, s_red);
+  if (V.pm_on) qeq_reduce2(cv_s, cv_t, s_red); else { cv_s = sn_s; cv_t = sn_t; }
+  if (run_s) { S.prev[0] = S.sig[0]; S.sig[0] = sn_s; S.run[0] = sqrt(cv_s) / S.bn[0] > tol; }
+  if (run_t) { S.prev[1] = S.sig[1]; S.sig[1] = sn_t; S.run[1] = sqrt(cv_t) / S.bn[1] > tol; }
+  __syncthreads();
+}
+// The launch between two sweeps (one workgroup per replica).  it < 0: r = b - H x0 from the first product (x0 sits in z), z = M r, the scalars
+// of the solve; it >= 0: iteration it of the conjugate gradients (qeq_sym_step).  A converged replica leaves at once.
+__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_step(const RxView *views, const RxParams *__restrict__ P, double tol, int it) {
+  const RxView V = views[blockIdx.x];
+  __shared__ double s_red[32];
+  const int n = V.n, tid = threadIdx.x;
+  const size_t np = V.npad;
+  double2 *y = qeq_ybuf(V);
+  if (it >= 0) {
+    QeqState S = qeq_state_load(V);
+    if (!S.run[0] && !S.run[1]) return;
+    __syncthreads();   // (every thread has read the state before thread 0 stores the next one)
+    qeq_sym_step<QEQ_TPB>(V, P, tol, it == 0, S, y, true, s_red);
+    if (tid == 0) { qeq_state_store(V, S); V.qstat[0] += 1; }
+    return;
+  }
+  double2 *r = qeq_rbuf(V, 0), *z = (double2 *)(V.qwork + 6 * np);
+  double p0 = 0.0, p1 = 0.0, b0 = 0.0, b1 = 0.0, c0 = 0.0, c1 = 0.0;
+  for (int i = tid; i < n; i += QEQ_TPB) {
+    const int ti = V.rtype[i];
+    const double eta = P->sbp[ti].eta, chi = P->sbp[ti].chi;
+    const double2 x0 = z[i], yi = y[i];
+    y[i] = make_double2(0.0, 0.0);
+    const double2 ri = make_double2(-chi - fma(eta, x0.x, yi.x), -1.0 - fma(eta, x0.y, yi.y));
+    r[i] = ri;
+    b0 += chi * chi; b1 += 1.0;
+    c0 += ri.x * ri.x / eta; c1 += ri.y * ri.y / eta;
+    if (!V.pm_on) { const double2 zi = make_double2(ri.x / eta, ri.y / eta); z[i] = zi; p0 += ri.x * zi.x; p1 += ri.y * zi.y; }
+  }
+  if (V.pm_on) {
+    __syncthreads();
+    for (int i = tid; i < n; i += QEQ_TPB) {
+      const double2 ri = r[i];
+      const double2 zi = qeq_pm_apply(V, i, [&](int k) { return r[k]; });
+      z[i] = zi;
+      p0 += ri.x * zi.x; p1 += ri.y * zi.y;
+    }
+  }
+  qeq_reduce2(p0, p1, s_red);
+  qeq_reduce2(b0, b1, s_red);
+  qeq_reduce2(c0, c1, s_red);
   if (tid == 0) {
-    const long long sweeps = (long long)(V.qstat[0] - V.qstat[4]) + 1;   // k_rx_qeq_update counted the launched iterations; plus the first product
-    V.sweep_acc[0] += sweeps * (long long)(nent + 0.5);
-    V.sweep_acc[1] += sweeps * (long long)n;
-    const int total = V.qstat[0] + it;
-    V.qstat[0] = total;
-    V.qstat[1] += 1;
-    const int mine = total - V.qstat[4];
-    V.qstat[4] = total;
-    // the first solves of a run that starts from an empty history take longer: their own record
-    const int rec = (V.qstat[1] <= RX_QEQ_COLD) ? 5 : 2;
-    if (mine > V.qstat[rec]) V.qstat[rec] = mine;
-    if (it > 0) V.qstat[3] += 1;
-    if (run_s || run_t) atomicOr(V.overflow, 4);
+    QeqState S;
+    S.sig[0] = p0; S.sig[1] = p1; S.prev[0] = 1.0; S.prev[1] = 1.0; S.bn[0] = sqrt(b0); S.bn[1] = sqrt(b1);
+    S.run[0] = sqrt(c0) / S.bn[0] > tol; S.run[1] = sqrt(c1) / S.bn[1] > tol;
+    qeq_state_store(V, S);
   }
+}
+// after `done` launched iterations: a replica that has not converged goes on in its one workgroup -- product into LDS, then the same step -- and
+// every replica ends its solve (charges, history, statistics)
+__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish_sym(const RxView *views, const RxParams *__restrict__ P, double tol, int done, int maxiter, int setup) {
+  const RxView V = views[blockIdx.x];
+  __shared__ double s_red[32];
+  const int n = V.n, tid = threadIdx.x;
+  const size_t np = V.npad;
+  QeqState S = qeq_state_load(V);
+  int it = 0;
+  double2 *s_z = s_sym, *s_y = s_sym + np;
+  const double2 *z = (const double2 *)(V.qwork + 6 * np);
+  for (; done + it < maxiter && (S.run[0] || S.run[1]); it++) {
+    for (int k = tid; k < n; k += QEQ_TPB) { s_z[k] = z[k]; s_y[k] = make_double2(0.0, 0.0); }
+    __syncthreads();
+    qeq_sym_product<QEQ_TPB / 64>(V, 0, n, s_z, s_y);
+    __syncthreads();
+    qeq_sym_step<QEQ_TPB>(V, P, tol, done + it == 0, S, s_y, false, s_red);
+  }
+  qeq_finish_tail(V, setup, it, S.run[0] || S.run[1], s_red);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1299,8 +1548,15 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
     static size_t optin_tab[16] = {0};
     size_t &optin = lds_optin_slot(optin_tab);
     const bool zlds = col16 && lds + 2048 <= 64 * 1024 && !zlds_off;
+    if (plan.sym) {
+      static size_t optin_sym[16] = {0};
+      size_t &os = lds_optin_slot(optin_sym);
+      if (2 * lds > 47 * 1024 && 2 * lds > os) { (void)hipFuncSetAttribute((const void *)k_rx_qeq_sweep_sym, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)); os = 2 * lds; }
+      hipLaunchKernelGGL(k_rx_qeq_sweep_sym, gk, dim3(RX_KT), 2 * lds, st, v, it);
+    } else
     if (zlds && lds > 47 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_rx_qeq_sweep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-    if (zlds) hipLaunchKernelGGL((k_rx_qeq_sweep<true, true>), gk, dim3(RX_KT), lds, st, v, P, qeq_tol, it);
+    if (plan.sym) {}
+    else if (zlds) hipLaunchKernelGGL((k_rx_qeq_sweep<true, true>), gk, dim3(RX_KT), lds, st, v, P, qeq_tol, it);
     else if (col16) hipLaunchKernelGGL((k_rx_qeq_sweep<true, false>), gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
     else hipLaunchKernelGGL((k_rx_qeq_sweep<false, false>), gk, dim3(RX_KT), 0, st, v, P, qeq_tol, it);
     if (ev) { (void)hipEventRecord((*ev)[*ev_used + 1], st); *ev_used += 2; }
@@ -1351,20 +1607,36 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   hipLaunchKernelGGL(k_rx_back1, ga, dim3(TPB), 0, sb, v, P);
   hipLaunchKernelGGL(k_rx_back2, ga, dim3(TPB), 0, sb, d, v, P);
   if (side) (void)hipEventRecord(side->join, sb);
-  hipLaunchKernelGGL(k_rx_hrow, gk, dim3(RX_KT), 0, st, d, v, P);
+  if (plan.sym) hipLaunchKernelGGL(k_rx_hrow<true>, gk, dim3(RX_KT), 0, st, d, v, P);
+  else hipLaunchKernelGGL(k_rx_hrow<false>, gk, dim3(RX_KT), 0, st, d, v, P);
   if (plan.precond) {
     hipLaunchKernelGGL(k_rx_qeq_pm_rows, gu, dim3(QEQ_UT), 0, st, d, v, P);
     hipLaunchKernelGGL(k_rx_qeq_pm_sym, gu, dim3(QEQ_UT), 0, st, d, v);
   }
-  hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v, plan.setup);
-  sweep(-1);
-  hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, -1);
+  hipLaunchKernelGGL(k_rx_qeq_guess, gu, dim3(QEQ_UT), 0, st, v, plan.setup, plan.sym);
   const int nlaunch = plan.launch < qeq_maxiter ? plan.launch : qeq_maxiter;
-  for (int it = 0; it < nlaunch; it++) {
-    sweep(it);
-    hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, it);
+  if (plan.sym) {
+    // the symmetric form: a sweep, then the replica's one-workgroup step (the product is complete only when the sweep has ended)
+    sweep(-1);
+    hipLaunchKernelGGL(k_rx_qeq_step, dim3(ns), dim3(QEQ_TPB), 0, st, v, P, qeq_tol, -1);
+    for (int it = 0; it < nlaunch; it++) {
+      sweep(it);
+      hipLaunchKernelGGL(k_rx_qeq_step, dim3(ns), dim3(QEQ_TPB), 0, st, v, P, qeq_tol, it);
+    }
+    const size_t lds2 = 2 * (size_t)((maxatoms + 63) / 64 * 64) * sizeof(double2);
+    static size_t optin_fin[16] = {0};
+    size_t &of = lds_optin_slot(optin_fin);
+    if (lds2 > 47 * 1024 && lds2 > of) { (void)hipFuncSetAttribute((const void *)k_rx_qeq_finish_sym, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); of = lds2; }
+    hipLaunchKernelGGL(k_rx_qeq_finish_sym, dim3(ns), dim3(QEQ_TPB), lds2, st, v, P, qeq_tol, nlaunch, qeq_maxiter, plan.setup);
+  } else {
+    sweep(-1);
+    hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, -1);
+    for (int it = 0; it < nlaunch; it++) {
+      sweep(it);
+      hipLaunchKernelGGL(k_rx_qeq_update, gu, dim3(QEQ_UT), 0, st, v, P, qeq_tol, it);
+    }
+    hipLaunchKernelGGL(k_rx_qeq_finish, dim3(ns), dim3(QEQ_TPB), 0, st, d, v, P, qeq_tol, nlaunch, qeq_maxiter, plan.setup);
   }
-  hipLaunchKernelGGL(k_rx_qeq_finish, dim3(ns), dim3(QEQ_TPB), 0, st, d, v, P, qeq_tol, nlaunch, qeq_maxiter, plan.setup);
   if (side) (void)hipStreamWaitEvent(st, side->mid, 0);
   if (terms & 16) {
     static const bool once_off = scema_env("SCEMA_MD_RX_NB_ONCE") && atoi(scema_env("SCEMA_MD_RX_NB_ONCE")) == 0;   // (test switch: the both-ends kernel)

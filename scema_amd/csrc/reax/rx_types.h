@@ -130,6 +130,7 @@ typedef struct {
                           // end owns (rx_owns: each pair once), compacted; the non-bonded pass walks these
   int RX_G *hownlen;           // [npad]
   int RX_G *nbT;               // [npad][maxnb] the list rows, row-major (a wave per row writes and reads them)
+  int RX_G *nb_own0;           // [npad] minimum-image rows are sorted by partner: the entries from here on are the pairs this end owns (rx_owns)
   double RX_G *s, *t;          // [npad] the two solutions
   double RX_G *s_hist, *t_hist;  // [4][npad] and [3][npad]: previous solutions, newest first (initial guesses are extrapolated from them)
   double RX_G *qwork;          // [10][npad]: five arrays of (s-system, t-system) pairs per atom: residual r, search direction d,

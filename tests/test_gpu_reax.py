@@ -359,7 +359,7 @@ def test_fallback_kernels_of_large_replicas_equal_the_default_ones():
             "r = e.reax_compute('m', 1)\n"
             "print(json.dumps(dict({'f': np.asarray(r['f']).ravel().tolist(), 'w': np.asarray(r['w']).ravel().tolist()}, **{k: float(v) for k, v in r['e'].items()})))\n")
     out = {}
-    for name, env in (("once", {}), ("both_ends", {"SCEMA_MD_RX_NB_ONCE": "0"}), ("col32", {"SCEMA_MD_RX_COL32": "1"}), ("near_full", {"SCEMA_MD_RX_NEAR_FULL": "1"}), ("item_atomics", {"SCEMA_MD_RX_ITEM_LDS": "0"}),
+    for name, env in (("once", {}), ("both_ends", {"SCEMA_MD_RX_NB_ONCE": "0"}), ("col32", {"SCEMA_MD_RX_COL32": "1"}), ("near_full", {"SCEMA_MD_RX_NEAR_FULL": "1"}), ("item_atomics", {"SCEMA_MD_RX_ITEM_LDS": "0"}), ("full_rows", {"SCEMA_REAX_QEQ_SYM": "0"}),
                       ("items_in_place", {"SCEMA_MD_RX_ITEMCAP": "0"}), ("items_mixed", {"SCEMA_MD_RX_ITEMCAP": "100"})):
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr[-2000:]
@@ -373,7 +373,9 @@ def test_fallback_kernels_of_large_replicas_equal_the_default_ones():
     # (near_full: the near rows with every pair inside 5 A + skin, as until round 5; the default keeps a type pair's candidates within the reach of
     # its bond order -- the bond rows, and everything after them, must not notice)
     # (item_atomics: the angle and torsion items add their forces and dE/dDelta with device-wide atomics, as replicas too large for the LDS tables do)
-    for name in ("both_ends", "col32", "near_full", "item_atomics", "items_in_place", "items_mixed"):
+    # (full_rows: the matrix of the charge equilibration with every pair in both rows and the two-launch iteration that goes with it; the default
+    # stores a pair once and makes both of its products in one sweep)
+    for name in ("both_ends", "col32", "near_full", "item_atomics", "full_rows", "items_in_place", "items_mixed"):
         b = out[name]
         assert np.abs(fa - np.array(b["f"])).max() < 1e-10 * np.abs(fa).max(), name
         assert np.abs(np.array(a["w"]) - np.array(b["w"])).max() < 1e-10 * np.abs(np.array(a["w"])).max(), name
