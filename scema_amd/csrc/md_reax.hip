@@ -423,7 +423,7 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_guess(const RxView *views, in
   V.s[i] = s0; V.t[i] = t0;
   double2 *z = (double2 *)(V.qwork + 6 * np);
   z[i] = make_double2(s0, t0);
-  if (sym) ((double2 *)(V.qwork + 8 * np))[i] = make_double2(0.0, 0.0);   // (the product vector the symmetric sweeps add to)
+  if (sym) { V.qwork[8 * np + i] = 0.0; V.qwork[9 * np + i] = 0.0; }   // (the product vector the symmetric sweeps add to)
 }
 
 // it < 0: the first product H x0 of the solve (x0 sits in z), stored in q
@@ -888,14 +888,16 @@ __device__ __forceinline__ void qeq_state_store(const RxView &V, const QeqState 
   q[QS_SIG] = S.sig[0]; q[QS_SIG + 1] = S.sig[1]; q[QS_PREV] = S.prev[0]; q[QS_PREV + 1] = S.prev[1];
   q[QS_BN] = S.bn[0]; q[QS_BN + 1] = S.bn[1]; q[QS_RUN] = S.run[0] ? 1.0 : 0.0; q[QS_RUN + 1] = S.run[1] ? 1.0 : 0.0;
 }
-__device__ __forceinline__ double2 *qeq_ybuf(const RxView &V) { return (double2 *)(V.qwork + 8 * (size_t)V.npad); }
+__device__ __forceinline__ double *qeq_ybuf(const RxView &V) { return V.qwork + 8 * (size_t)V.npad; }   // [2][npad]: the s system's part, then the t system's
 extern __shared__ double2 s_sym[];   // [0, npad): z of the replica; [npad, 2 npad): this workgroup's part of y
 // the products of the rows [row0, row1) with NW waves, two rows of a wave at a time (their loads are independent); s_z read, s_y added to
+// (s_y: the two systems' parts one after the other, [2][npad] -- the atomics of a chunk's consecutive columns fall into consecutive banks)
 template <int NW>
-__device__ __forceinline__ void qeq_sym_product(const RxView &V, int row0, int row1, const double2 *s_z, double2 *s_y) {
+__device__ __forceinline__ void qeq_sym_product(const RxView &V, int row0, int row1, const double2 *s_z, double *s_y) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const GLOBAL_AS unsigned long long *pk = as_global(V.hpk);
   const GLOBAL_AS int *hlen = as_global(V.hownlen);
+  const size_t np = V.npad;
   for (int ra = row0 + 2 * wave; ra < row1; ra += 2 * NW) {
     int len[2], lmax = 0;
     size_t base[2];
@@ -931,15 +933,15 @@ __device__ __forceinline__ void qeq_sym_product(const RxView &V, int row0, int r
           const double2 zj = s_z[j];
           ps[q] = fma(h, zj.x, ps[q]);
           pt[q] = fma(h, zj.y, pt[q]);
-          lds_add_f64(&s_y[j].x, h * zi[q].x);
-          lds_add_f64(&s_y[j].y, h * zi[q].y);
+          lds_add_f64(&s_y[j], h * zi[q].x);
+          lds_add_f64(&s_y[np + j], h * zi[q].y);
         }
       }
     }
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const double a = wave_sum(ps[q]), bsum = wave_sum(pt[q]);
-      if (lane == 0 && ra + q < row1) { lds_add_f64(&s_y[ra + q].x, a); lds_add_f64(&s_y[ra + q].y, bsum); }
+      if (lane == 0 && ra + q < row1) { lds_add_f64(&s_y[ra + q], a); lds_add_f64(&s_y[np + ra + q], bsum); }
     }
   }
 }
@@ -950,29 +952,30 @@ __global__ __launch_bounds__(RX_KT) void k_rx_qeq_sweep_sym(const RxView *views,
   if (row0 >= n) return;
   if (it >= 0 && V.qpart[QS_RUN] == 0.0 && V.qpart[QS_RUN + 1] == 0.0) return;   // (uniform) both systems have converged
   const size_t np = V.npad;
-  double2 *s_z = s_sym, *s_y = s_sym + np;
+  double2 *s_z = s_sym;
+  double *s_y = (double *)(s_sym + np);
   const GLOBAL_AS dvec2 *z = as_global((const dvec2 *)(V.qwork + 6 * np));
   for (int k0 = threadIdx.x; k0 < n; k0 += 4 * RX_KT) {
     double2 t[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int k = k0 + u * RX_KT; t[u] = ldg2(z, k < n ? k : n - 1); }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const int k = k0 + u * RX_KT; if (k < n) { s_z[k] = t[u]; s_y[k] = make_double2(0.0, 0.0); } }
+    for (int u = 0; u < 4; u++) { const int k = k0 + u * RX_KT; if (k < n) { s_z[k] = t[u]; s_y[k] = 0.0; s_y[np + k] = 0.0; } }
   }
   __syncthreads();
   qeq_sym_product<RX_KS>(V, row0, min(row0 + RX_SWR, n), s_z, s_y);
   __syncthreads();
-  double *yg = (double *)qeq_ybuf(V);
-  const double *yl = (const double *)s_y;
-  for (int k = threadIdx.x; k < 2 * n; k += RX_KT) {
-    const double v = yl[k];
-    if (v != 0.0) atomicAdd(&yg[k], v);
+  double *yg = qeq_ybuf(V);   // [2][npad] as well
+  for (int k = threadIdx.x; k < n; k += RX_KT) {
+    const double a = s_y[k], b = s_y[np + k];
+    if (a != 0.0) atomicAdd(&yg[k], a);
+    if (b != 0.0) atomicAdd(&yg[np + k], b);
   }
 }
 // One iteration's vector work for a replica with NT threads of ONE workgroup; y (the finished product H z without the diagonal; read, and
 // zeroed for the next sweep if `zero_y`) in memory or in LDS.  first: d = z, q = y.  The recurrences and their order are k_rx_qeq_finish's.
 template <int NT>
-__device__ __forceinline__ void qeq_sym_step(const RxView &V, const RxParams *__restrict__ P, double tol, bool first, QeqState &S, double2 *y, bool zero_y, double *s_red) {
+__device__ __forceinline__ void qeq_sym_step(const RxView &V, const RxParams *__restrict__ P, double tol, bool first, QeqState &S, double *y, bool zero_y, double *s_red) {
   const int n = V.n, tid = threadIdx.x;
   const size_t np = V.npad;
   double *s = V.s, *t = V.t;
@@ -982,9 +985,10 @@ __device__ __forceinline__ void qeq_sym_step(const RxView &V, const RxParams *__
   double dq_s = 0.0, dq_t = 0.0;
   for (int i = tid; i < n; i += NT) {
     const double eta = P->sbp[V.rtype[i]].eta;
-    const double2 zi = z[i], yi = y[i];
-    if (zero_y) y[i] = make_double2(0.0, 0.0);
-    const double ys = fma(eta, zi.x, yi.x), yt = fma(eta, zi.y, yi.y);
+    const double2 zi = z[i];
+    const double y0 = y[i], y1 = y[np + i];
+    if (zero_y) { y[i] = 0.0; y[np + i] = 0.0; }
+    const double ys = fma(eta, zi.x, y0), yt = fma(eta, zi.y, y1);
     double2 di = first ? make_double2(0.0, 0.0) : d[i], qi = first ? make_double2(0.0, 0.0) : q[i];
     if (run_s) { di.x = fma(be_s, di.x, zi.x); qi.x = fma(be_s, qi.x, ys); dq_s += di.x * qi.x; }
     if (run_t) { di.y = fma(be_t, di.y, zi.y); qi.y = fma(be_t, qi.y, yt); dq_t += di.y * qi.y; }
@@ -1028,7 +1032,7 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_step(const RxView *views, co
   __shared__ double s_red[32];
   const int n = V.n, tid = threadIdx.x;
   const size_t np = V.npad;
-  double2 *y = qeq_ybuf(V);
+  double *y = qeq_ybuf(V);
   if (it >= 0) {
     QeqState S = qeq_state_load(V);
     if (!S.run[0] && !S.run[1]) return;
@@ -1042,9 +1046,10 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_step(const RxView *views, co
   for (int i = tid; i < n; i += QEQ_TPB) {
     const int ti = V.rtype[i];
     const double eta = P->sbp[ti].eta, chi = P->sbp[ti].chi;
-    const double2 x0 = z[i], yi = y[i];
-    y[i] = make_double2(0.0, 0.0);
-    const double2 ri = make_double2(-chi - fma(eta, x0.x, yi.x), -1.0 - fma(eta, x0.y, yi.y));
+    const double2 x0 = z[i];
+    const double y0 = y[i], y1 = y[np + i];
+    y[i] = 0.0; y[np + i] = 0.0;
+    const double2 ri = make_double2(-chi - fma(eta, x0.x, y0), -1.0 - fma(eta, x0.y, y1));
     r[i] = ri;
     b0 += chi * chi; b1 += 1.0;
     c0 += ri.x * ri.x / eta; c1 += ri.y * ri.y / eta;
@@ -1078,10 +1083,11 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish_sym(const RxView *vie
   const size_t np = V.npad;
   QeqState S = qeq_state_load(V);
   int it = 0;
-  double2 *s_z = s_sym, *s_y = s_sym + np;
+  double2 *s_z = s_sym;
+  double *s_y = (double *)(s_sym + np);
   const double2 *z = (const double2 *)(V.qwork + 6 * np);
   for (; done + it < maxiter && (S.run[0] || S.run[1]); it++) {
-    for (int k = tid; k < n; k += QEQ_TPB) { s_z[k] = z[k]; s_y[k] = make_double2(0.0, 0.0); }
+    for (int k = tid; k < n; k += QEQ_TPB) { s_z[k] = z[k]; s_y[k] = 0.0; s_y[np + k] = 0.0; }
     __syncthreads();
     qeq_sym_product<QEQ_TPB / 64>(V, 0, n, s_z, s_y);
     __syncthreads();
