@@ -208,6 +208,9 @@ __device__ __forceinline__ void rx_shift_table(const RxView &V, double *s_sh) {
 }
 // SYM (round 5, the symmetric form of the charge solve): only the pairs a row OWNS are computed -- the tail of the row from nb_own0 on -- and stored,
 // matrix entry (hpk) and list entry (hown) at the same position; hlen = hownlen.  Half the arithmetic and half the stores of the full rows.
+#ifndef RX_HROW_RG
+#define RX_HROW_RG 2   /* rows of a wave in flight */
+#endif
 template <bool SYM>
 __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(RX_KT) void k_rx_hrow(const SimDev *sims, const RxV
   // compiler cannot count stores that sit behind a branch: a wait for any load issued before them becomes a wait for everything, the
   // stores' own round trip included -- with the stores last in the turn every turn ended on that (80 % of the waves' cycles waiting,
   // rocprofv3 SQ_WAIT_ANY).  Issued first, they have the whole turn to complete.
-  constexpr int RG = 2;
+  constexpr int RG = RX_HROW_RG;
   for (int r = 0; r < 64 / RX_KS; r += RG) {
     const int ifirst = blockIdx.x * 64 + wave * (64 / RX_KS) + r;
     if (ifirst >= V.n) return;   // (wave-uniform; no barrier below)
@@ -875,6 +878,9 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_finish(const SimDev *sims, c
 //   k_rx_qeq_step       y complete: d = z + beta d, q = y + beta q, alpha = sigma / d.q, s += alpha d, r -= alpha q, z = M r, sigma' = r.z, the stop
 // The scalars of a replica's solve sit in qpart[0 .. QS_N) (no partial sums in this form).  y: the fifth array of qwork.
 enum { QS_SIG = 0, QS_PREV = 2, QS_BN = 4, QS_RUN = 6, QS_N = 8 };
+#ifndef RX_SYM_RG
+#define RX_SYM_RG 4   /* rows of a wave in flight in the symmetric sweep */
+#endif
 struct QeqState { double sig[2], prev[2], bn[2]; bool run[2]; };
 __device__ __forceinline__ QeqState qeq_state_load(const RxView &V) {
   QeqState S;
@@ -898,35 +904,39 @@ __device__ __forceinline__ void qeq_sym_product(const RxView &V, int row0, int r
   const GLOBAL_AS unsigned long long *pk = as_global(V.hpk);
   const GLOBAL_AS int *hlen = as_global(V.hownlen);
   const size_t np = V.npad;
-  for (int ra = row0 + 2 * wave; ra < row1; ra += 2 * NW) {
-    int len[2], lmax = 0;
-    size_t base[2];
-    double2 zi[2];
-    double ps[2], pt[2];
+  // RG rows of a wave at a time: an owned row is three or four chunks long, so a row's header (its length, a dependent memory round trip before
+  // the first entry can be masked) weighs as much as its entries; with four rows in flight the wave waits for half as many of them
+  constexpr int RG = RX_SYM_RG;
+  for (int ra = row0 + RG * wave; ra < row1; ra += RG * NW) {
+    int len[RG], lmax = 0;
+    size_t base[RG];
+    double2 zi[RG];
+    double ps[RG], pt[RG];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < RG; q++) {
       const int row = ra + q;
       const bool live = row < row1;
       len[q] = live ? hlen[row] : 0;   // (wave-uniform)
       base[q] = (size_t)(live ? row : ra) * V.maxnb;
       zi[q] = s_z[live ? row : ra];
-      lmax = max(lmax, len[q]);
       ps[q] = 0.0; pt[q] = 0.0;
     }
-    unsigned long long bn[2];
+#pragma unroll
+    for (int q = 0; q < RG; q++) lmax = max(lmax, len[q]);
+    unsigned long long bn[RG];
     auto load = [&](int c0) {
       const int c = c0 + lane;
 #pragma unroll
-      for (int q = 0; q < 2; q++) bn[q] = (c < len[q]) ? pk[base[q] + c] : ~0ull;
+      for (int q = 0; q < RG; q++) bn[q] = (c < len[q]) ? pk[base[q] + c] : ~0ull;
     };
     load(0);
     for (int c0 = 0; c0 < lmax; c0 += 64) {
-      unsigned long long b[2];
+      unsigned long long b[RG];
 #pragma unroll
-      for (int q = 0; q < 2; q++) b[q] = bn[q];
+      for (int q = 0; q < RG; q++) b[q] = bn[q];
       load(c0 + 64);
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < RG; q++) {
         if (b[q] != ~0ull) {   // (a stored value is positive and finite: no entry has this pattern)
           int j;
           const double h = rx_hunpack(b[q], &j);
@@ -939,7 +949,7 @@ __device__ __forceinline__ void qeq_sym_product(const RxView &V, int row0, int r
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < RG; q++) {
       const double a = wave_sum(ps[q]), bsum = wave_sum(pt[q]);
       if (lane == 0 && ra + q < row1) { lds_add_f64(&s_y[ra + q], a); lds_add_f64(&s_y[np + ra + q], bsum); }
     }
