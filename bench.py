@@ -636,7 +636,11 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                     "frac_timed_per_launch": sw_bytes / sw_s / 1e9 / 8000.0 if sw_s > 0 else None,
                     "avg_launch_ms": 1e3 * sw_s / sw_n, "launches": prof["rx_sweep_launches"],   # (names of schema 1: the timed region)
                     "alone": {"frac": a_bytes / a_s / 1e9 / 8000.0 if a_s > 0 else None},       # (schema 1 kept this nested; = frac now)
-                    "kernel": "k_rx_qeq_sweep (charge equilibration: y = H z for both conjugate-gradient systems, one pass over the stored matrix rows)",
+                    "kernel": ("k_rx_qeq_sweep_sym (charge equilibration: y = H z for both conjugate-gradient systems; each pair of the symmetric matrix stored ONCE, "
+                               "both of its products in one pass -- the transposed one through LDS atomics: half the bytes of the full rows, and no longer "
+                               "a pure stream)") if prof.get("rx_sweep_symmetric") else
+                              "k_rx_qeq_sweep (charge equilibration: y = H z for both conjugate-gradient systems, one pass over the stored matrix rows)",
+                    "symmetric": bool(prof.get("rx_sweep_symmetric")),
                     "accounting": f"bytes = ({8 + int(prof['rx_sweep_col_bytes'])} B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
                                   "device) / HIP-event time of the kernel's launches (launches that find every replica converged cost time and move nothing); traffic = counter "
                                   "bytes of ONE sweep over the whole batch (profiles/reax_pmc.json).  whole_* / frac: the batch as one sequence of launches on one stream "

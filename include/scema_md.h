@@ -372,6 +372,8 @@ typedef struct {
    * timed launches ran -- the union of their HIP-event intervals on the device's common clock.  Equal to the sums above when nothing overlaps. */
   double pair_union_ms;
   double rx_sweep_union_ms;
+  int64_t rx_sweep_symmetric; /* 1: the timed sweeps ran in the symmetric form (each pair of the matrix stored once, in its owner's row: rx_sweep_entries
+                               * counts stored entries, half of the full rows'); 0: full rows */
 } scema_md_profile;
 int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t reset);
 

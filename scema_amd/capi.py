@@ -93,7 +93,7 @@ class Profile(C.Structure):
                 ("md_steps", C.c_int64), ("neigh_builds", C.c_int64), ("unique_pairs_per_sim", C.c_double),
                 ("evals", C.c_int64), ("list_skin_mean", C.c_double), ("pair_sims", C.c_int64), ("box_flips", C.c_int64),
                 ("rx_sweep_launches", C.c_int64), ("rx_sweep_ms", C.c_double), ("rx_sweep_entries", C.c_double), ("rx_sweep_rows", C.c_double), ("rx_sweep_col_bytes", C.c_int64),
-                ("pair_union_ms", C.c_double), ("rx_sweep_union_ms", C.c_double)]
+                ("pair_union_ms", C.c_double), ("rx_sweep_union_ms", C.c_double), ("rx_sweep_symmetric", C.c_int64)]
 
 
 _lib = None

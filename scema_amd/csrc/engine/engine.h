@@ -233,7 +233,7 @@ struct Profile {
   // ReaxFF: launches of k_rx_qeq_sweep
   long long rx_sweep_launches = 0;
   double rx_sweep_ms = 0, rx_sweep_entries = 0, rx_sweep_rows = 0;
-  long long rx_sweep_col_bytes = 0;
+  long long rx_sweep_col_bytes = 0, rx_sweep_symmetric = 0;
 };
 
 struct EwaldSetup {

@@ -226,6 +226,7 @@ int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t rese
   out->rx_sweep_entries = e->prof.rx_sweep_entries;
   out->rx_sweep_rows = e->prof.rx_sweep_rows;
   out->rx_sweep_col_bytes = e->prof.rx_sweep_col_bytes;
+  out->rx_sweep_symmetric = e->prof.rx_sweep_symmetric;
   out->pair_union_ms = e->prof.pair_union_ms;
   out->rx_sweep_union_ms = e->prof.rx_sweep_union_ms;
   if (reset) e->prof = Profile();

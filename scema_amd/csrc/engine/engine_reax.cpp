@@ -454,6 +454,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       e->prof.rx_sweep_entries += (double)acc[2 * pos];
       e->prof.rx_sweep_rows += (double)acc[2 * pos + 1];
       e->prof.rx_sweep_col_bytes = col16 ? 0 : 4;   // (packed entries: the column rides in the value's word)
+      e->prof.rx_sweep_symmetric = all_sym ? 1 : 0;
     }
   }
   int fault = 0, most = 0, most_cold = 0;
