@@ -731,7 +731,8 @@ __global__ __launch_bounds__(QEQ_UT) void k_rx_qeq_update(const RxView *views, c
   }
 }
 
-__device__ __forceinline__ void qeq_reduce2(double &a, double &b, double *lds) {
+template <int NT>
+__device__ __forceinline__ void qeq_reduce2t(double &a, double &b, double *lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   a = wave_sum(a);
   b = wave_sum(b);
@@ -740,10 +741,11 @@ __device__ __forceinline__ void qeq_reduce2(double &a, double &b, double *lds) {
   __syncthreads();
   double sa = 0.0, sb = 0.0;
 #pragma unroll
-  for (int w = 0; w < QEQ_TPB / 64; w++) { sa += lds[w]; sb += lds[16 + w]; }
+  for (int w = 0; w < NT / 64; w++) { sa += lds[w]; sb += lds[16 + w]; }
   a = sa;
   b = sb;
 }
+__device__ __forceinline__ void qeq_reduce2(double &a, double &b, double *lds) { qeq_reduce2t<QEQ_TPB>(a, b, lds); }
 // the end of a solve, one workgroup per replica: charges q = s - (sum s / sum t) t, the history pushed down, the solver's statistics
 // (`it`: iterations made by the single-workgroup loop after the launched ones; `unconverged`: the iteration limit was reached)
 __device__ __forceinline__ void qeq_finish_tail(const RxView &V, int setup, int it, bool unconverged, double *s_red) {
@@ -1004,7 +1006,7 @@ __device__ __forceinline__ void qeq_sym_step(const RxView &V, const RxParams *__
     if (run_t) { di.y = fma(be_t, di.y, zi.y); qi.y = fma(be_t, qi.y, yt); dq_t += di.y * qi.y; }
     d[i] = di; q[i] = qi;
   }
-  qeq_reduce2(dq_s, dq_t, s_red);
+  qeq_reduce2t<NT>(dq_s, dq_t, s_red);
   const double al_s = run_s ? S.sig[0] / dq_s : 0.0, al_t = run_t ? S.sig[1] / dq_t : 0.0;
   double sn_s = 0.0, sn_t = 0.0, cv_s = 0.0, cv_t = 0.0;
   for (int i = tid; i < n; i += NT) {
@@ -1029,15 +1031,20 @@ __device__ __forceinline__ void qeq_sym_step(const RxView &V, const RxParams *__
       sn_s += ri.x * zi.x; sn_t += ri.y * zi.y;
     }
   }
-  qeq_reduce2(sn_s, sn_t, s_red);
-  if (V.pm_on) qeq_reduce2(cv_s, cv_t, s_red); else { cv_s = sn_s; cv_t = sn_t; }
+  qeq_reduce2t<NT>(sn_s, sn_t, s_red);
+  if (V.pm_on) qeq_reduce2t<NT>(cv_s, cv_t, s_red); else { cv_s = sn_s; cv_t = sn_t; }
   if (run_s) { S.prev[0] = S.sig[0]; S.sig[0] = sn_s; S.run[0] = sqrt(cv_s) / S.bn[0] > tol; }
   if (run_t) { S.prev[1] = S.sig[1]; S.sig[1] = sn_t; S.run[1] = sqrt(cv_t) / S.bn[1] > tol; }
   __syncthreads();
 }
 // The launch between two sweeps (one workgroup per replica).  it < 0: r = b - H x0 from the first product (x0 sits in z), z = M r, the scalars
 // of the solve; it >= 0: iteration it of the conjugate gradients (qeq_sym_step).  A converged replica leaves at once.
-__global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_step(const RxView *views, const RxParams *__restrict__ P, double tol, int it) {
+// (RX_STEP_TPB threads: the launch sits between two sweeps of a serial chain on a chip that other streams keep full, and a workgroup of 1 024 threads
+// needs four free wave slots on EVERY SIMD of one CU before it starts)
+#ifndef RX_STEP_TPB
+#define RX_STEP_TPB 1024
+#endif
+__global__ __launch_bounds__(RX_STEP_TPB) void k_rx_qeq_step(const RxView *views, const RxParams *__restrict__ P, double tol, int it) {
   const RxView V = views[blockIdx.x];
   __shared__ double s_red[32];
   const int n = V.n, tid = threadIdx.x;
@@ -1047,13 +1054,13 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_step(const RxView *views, co
     QeqState S = qeq_state_load(V);
     if (!S.run[0] && !S.run[1]) return;
     __syncthreads();   // (every thread has read the state before thread 0 stores the next one)
-    qeq_sym_step<QEQ_TPB>(V, P, tol, it == 0, S, y, true, s_red);
+    qeq_sym_step<RX_STEP_TPB>(V, P, tol, it == 0, S, y, true, s_red);
     if (tid == 0) { qeq_state_store(V, S); V.qstat[0] += 1; }
     return;
   }
   double2 *r = qeq_rbuf(V, 0), *z = (double2 *)(V.qwork + 6 * np);
   double p0 = 0.0, p1 = 0.0, b0 = 0.0, b1 = 0.0, c0 = 0.0, c1 = 0.0;
-  for (int i = tid; i < n; i += QEQ_TPB) {
+  for (int i = tid; i < n; i += RX_STEP_TPB) {
     const int ti = V.rtype[i];
     const double eta = P->sbp[ti].eta, chi = P->sbp[ti].chi;
     const double2 x0 = z[i];
@@ -1067,16 +1074,16 @@ __global__ __launch_bounds__(QEQ_TPB) void k_rx_qeq_step(const RxView *views, co
   }
   if (V.pm_on) {
     __syncthreads();
-    for (int i = tid; i < n; i += QEQ_TPB) {
+    for (int i = tid; i < n; i += RX_STEP_TPB) {
       const double2 ri = r[i];
       const double2 zi = qeq_pm_apply(V, i, [&](int k) { return r[k]; });
       z[i] = zi;
       p0 += ri.x * zi.x; p1 += ri.y * zi.y;
     }
   }
-  qeq_reduce2(p0, p1, s_red);
-  qeq_reduce2(b0, b1, s_red);
-  qeq_reduce2(c0, c1, s_red);
+  qeq_reduce2t<RX_STEP_TPB>(p0, p1, s_red);
+  qeq_reduce2t<RX_STEP_TPB>(b0, b1, s_red);
+  qeq_reduce2t<RX_STEP_TPB>(c0, c1, s_red);
   if (tid == 0) {
     QeqState S;
     S.sig[0] = p0; S.sig[1] = p1; S.prev[0] = 1.0; S.prev[1] = 1.0; S.bn[0] = sqrt(b0); S.bn[1] = sqrt(b1);
@@ -1634,10 +1641,10 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   if (plan.sym) {
     // the symmetric form: a sweep, then the replica's one-workgroup step (the product is complete only when the sweep has ended)
     sweep(-1);
-    hipLaunchKernelGGL(k_rx_qeq_step, dim3(ns), dim3(QEQ_TPB), 0, st, v, P, qeq_tol, -1);
+    hipLaunchKernelGGL(k_rx_qeq_step, dim3(ns), dim3(RX_STEP_TPB), 0, st, v, P, qeq_tol, -1);
     for (int it = 0; it < nlaunch; it++) {
       sweep(it);
-      hipLaunchKernelGGL(k_rx_qeq_step, dim3(ns), dim3(QEQ_TPB), 0, st, v, P, qeq_tol, it);
+      hipLaunchKernelGGL(k_rx_qeq_step, dim3(ns), dim3(RX_STEP_TPB), 0, st, v, P, qeq_tol, it);
     }
     const size_t lds2 = 2 * (size_t)((maxatoms + 63) / 64 * 64) * sizeof(double2);
     static size_t optin_fin[16] = {0};
