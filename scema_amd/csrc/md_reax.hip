@@ -1153,13 +1153,13 @@ __device__ __forceinline__ void rx_flush_block(double (&e)[RX_NPART], double (&w
   }
 }
 
-// Uncorrected bond orders (rx_bonds_prime): a workgroup of 4 waves owns 32 consecutive atoms, a wave their near rows one after the other
-// with its lanes over the entries (read from the row-major copy of the near rows); the few entries that are bonds are compacted with a
-// ballot into the atom's bond row in list order, the sum of their orders by a wave sum.  (One lane per atom walked its 118 near
-// entries serially with three pow and three exp each, 1 822 waves for 72 replicas: 0.63 ms per step.)
+// Uncorrected bond orders (rx_bonds_prime): a workgroup of 4 waves owns 32 consecutive atoms, a wave eight of them, TWO at a time -- a half wave
+// per near row with its lanes over the entries (row-major copy of the near rows).  Since the near rows hold a type pair's candidates within reach of its
+// bond order (round 5) a row has some thirty of them: a wave per row left half its lanes idle.  The few entries that are bonds are compacted with a
+// ballot (each half's own 32 bits) into the atom's bond row in list order, the sum of their orders by a half-wave sum.
 __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
   const size_t np = V.npad, plane = (size_t)V.maxbd * np;
   // the type tables in LDS: the parameters of a pair are two dependent global loads away otherwise
   __shared__ RxSbp s_sbp[RX_MAXT];
@@ -1169,29 +1169,34 @@ __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxP
   __shared__ double s_sh[3 * RX_NSHIFT];
   rx_shift_table(V, s_sh);
   __syncthreads();
-  for (int r = 0; r < 8; r++) {
-    const int i = blockIdx.x * (8 * (TPB / 64)) + wave * 8 + r;
-    if (i >= V.n) return;   // (wave-uniform; no barrier below)
-    const int cnt = V.nbn_cnt[i];
+  const unsigned below = (1u << hl) - 1u;
+  for (int r = 0; r < 8; r += 2) {
+    const int i0 = blockIdx.x * (8 * (TPB / 64)) + wave * 8 + r;
+    if (i0 >= V.n) return;   // (wave-uniform; no barrier below)
+    const bool live = i0 + half < V.n;
+    const int i = live ? i0 + half : i0;
+    const int cnt = live ? V.nbn_cnt[i] : 0;
+    const int cmax = max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 32));
     const size_t base = (size_t)i * V.maxnbn;
     int nb = 0;
     double sum = 0.0;
     // the row walk as in k_rx_hrow: the stores of the chunk before, the requests of the chunks after (partner records one chunk ahead, near-row
     // entries two), the arithmetic of this one
     const int ti = V.rtype[i];
-    const double xi0 = wave_uniform(V.x[3 * i]), xi1 = wave_uniform(V.x[3 * i + 1]), xi2 = wave_uniform(V.x[3 * i + 2]);
-    auto load_ent = [&](int k0) -> int { const int k = k0 + lane; return (k < cnt) ? V.nbnT[base + k] : -1; };
-    int e1 = load_ent(0), e2 = load_ent(64);
+    const double xi0 = V.x[3 * i], xi1 = V.x[3 * i + 1], xi2 = V.x[3 * i + 2];
+    auto load_ent = [&](int k0) -> int { const int k = k0 + hl; return (k < cnt) ? V.nbnT[base + k] : -1; };
+    int e1 = load_ent(0), e2 = load_ent(32);
     double p0, p1, p2;
     int tjn;
     { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
-    asm volatile("" : : "v"(p0), "v"(p1), "v"(p2), "v"(tjn), "v"(e2));   // (waited for here, not inside the loop)
+    asm volatile("" : : "v"(p0), "v"(p1), "v"(p2), "v"(tjn), "v"(e2), "v"(xi0), "v"(xi1), "v"(xi2), "v"(ti));   // (waited for here, not inside the loop)
     int ok_prev = 0, e_prev = 0;
     double bo_p = 0, bp_p = 0, bpp_p = 0, rr_p = 0, cs_p = 0, cp_p = 0, cpp_p = 0;
     auto flush = [&]() __attribute__((always_inline)) {
       const unsigned long long m = __ballot(ok_prev);
+      const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;
       if (ok_prev) {
-        const int pos = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        const int pos = nb + __popc(mh & below);
         if (pos < V.maxbd) {
           const size_t o = (size_t)pos * np + i;
           V.bd[o] = e_prev;
@@ -1205,15 +1210,15 @@ __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxP
           sum += bo_p - P->bo_cut;
         }
       }
-      nb += __popcll(m);
+      nb += __popc(mh);
     };
-    for (int k0 = 0; k0 < cnt; k0 += 64) {
+    for (int k0 = 0; k0 < cmax; k0 += 32) {
       const int ent = e1, tj = tjn;
       const double q0 = p0, q1 = p1, q2 = p2;
       e1 = e2;
       flush();
       { const int j = (e1 >= 0) ? (e1 & RX_JMASK) : 0; p0 = V.x[3 * j]; p1 = V.x[3 * j + 1]; p2 = V.x[3 * j + 2]; tjn = V.rtype[j]; }
-      e2 = load_ent(k0 + 128);
+      e2 = load_ent(k0 + 64);
       ok_prev = 0;
       if (ent >= 0) {
         const double *sh = s_sh + 3 * ((ent >> 24) & 0x7F);
@@ -1223,11 +1228,13 @@ __global__ __launch_bounds__(TPB) void k_rx_bonds(const RxView *views, const RxP
       e_prev = ent;
     }
     flush();
-    sum = wave_sum(sum);
-    if (lane == 0) {
+    // the half's sum: the rows of 16 lanes, then row 0 into row 1 and row 2 into row 3 (the last lane of each half holds it)
+    sum = row_sum(sum);
+    sum += dpp_read0<0x142, 0xA>(sum);
+    if (hl == 31 && live) {
       if (nb > V.maxbd) { atomicOr(V.overflow, 2); nb = V.maxbd; }
       V.bd_cnt[i] = nb;
-      V.deltap[i] = sum - P->sbp[V.rtype[i]].valency;
+      V.deltap[i] = sum - P->sbp[ti].valency;
     }
   }
 }
