@@ -381,3 +381,40 @@ def test_fallback_kernels_of_large_replicas_equal_the_default_ones():
         assert np.abs(np.array(a["w"]) - np.array(b["w"])).max() < 1e-10 * np.abs(np.array(a["w"])).max(), name
         for k in ("vdw", "coul", "pol", "angle", "pen", "coa", "tors", "conj"):
             assert abs(a[k] - b[k]) < 1e-10 * max(1.0, abs(a[k])), (name, k)
+
+
+def test_symmetric_solve_and_lds_tables_on_minimum_image_replicas():
+    """The forms that need one image per neighbour, on the replicas that have it -- PE-1620 (BASELINE config 5) and PE-2880, whose tables (two vectors of
+    the replica for the symmetric sweep: 92 kB; forces + dE/dDelta of the angle / torsion items: 92 kB; partner forces of the non-bonded pass: 69 kB) are
+    past the 64 kB a launch gets without the opt-in: the symmetric form of the charge solve (each pair stored once, one workgroup per replica between
+    two sweeps) against full rows, and the item sums through LDS against device-wide atomics.  Same systems solved to 1e-10: same charges and forces.
+    (The switches are read once per process: child processes.)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "cells = tuple(int(c) for c in sys.argv[1:4])\n"
+            "d = build_pe(*cells, jitter=0.08, seed=5)\n"
+            "sym = ['C' if d['mass'][t] > 5 else 'H' for t in d['type']]\n"
+            "e = capi.Engine()\n"
+            "e.reax_configure(sys.argv[4], qeq_tol=1e-10)\n"
+            "e.register_replica('m', 1, capi.reax_system(sym, d['x'], d['box']))\n"
+            "r = e.reax_compute('m', 1)\n"
+            "print(json.dumps({'f': np.asarray(r['f']).ravel().tolist(), 'q': np.asarray(r['q']).ravel().tolist(), 'w': np.asarray(r['w']).ravel().tolist(), 'iters': int(r['qeq_iters']), 'n': len(sym)}))\n")
+    for cells in ((3, 5, 9), (4, 6, 10)):
+        out = {}
+        for name, env in (("default", {}), ("full_rows", {"SCEMA_REAX_QEQ_SYM": "0"}), ("item_atomics", {"SCEMA_MD_RX_ITEM_LDS": "0"})):
+            p = subprocess.run([sys.executable, "-c", code] + [str(c) for c in cells] + [FFIELD], capture_output=True, text=True, timeout=600, cwd=root,
+                               env=dict(os.environ, **env))
+            assert p.returncode == 0, p.stderr[-2000:]
+            out[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        a = out["default"]
+        assert a["n"] == 12 * cells[0] * cells[1] * cells[2]
+        fa, qa, wa = np.array(a["f"]), np.array(a["q"]), np.array(a["w"])
+        for name in ("full_rows", "item_atomics"):
+            b = out[name]
+            assert np.abs(qa - np.array(b["q"])).max() < 2e-8, (cells, name)                       # (two solves of one system to 1e-10)
+            assert np.abs(fa - np.array(b["f"])).max() < 1e-7 * np.abs(fa).max(), (cells, name)
+            assert np.abs(wa - np.array(b["w"])).max() < 1e-7 * np.abs(wa).max(), (cells, name)
+        assert abs(a["iters"] - out["full_rows"]["iters"]) <= 2, (a["iters"], out["full_rows"]["iters"])   # the same recurrences
