@@ -1,6 +1,6 @@
 #!/bin/bash
-# kernel table + gaps of a single replica (BASELINE config 2) (usage on the GPU box: tools/r04_1_prof.sh <tag>)
-T=${1:-r04_x}
+# kernel table + gaps of a single replica (BASELINE config 2) (usage on the GPU box: tools/r05_1_prof.sh <tag>)
+T=${1:-r05_x}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 C=gpurun_out/equil_pe10k.npz

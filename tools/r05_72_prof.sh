@@ -1,6 +1,6 @@
 #!/bin/bash
-# kernel table + gaps of one GPU's share of the 8-GPU run (72 replicas) (usage on the GPU box: tools/r04_72_prof.sh <tag>)
-T=${1:-r04_x}
+# kernel table + gaps of one GPU's share of the 8-GPU run (72 replicas) (usage on the GPU box: tools/r05_72_prof.sh <tag>)
+T=${1:-r05_x}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 C=gpurun_out/equil_pe10k.npz

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel table of the ReaxFF replica set (usage on the GPU box: tools/r04_reax_prof.sh <tag>)
+# kernel table of the ReaxFF replica set (usage on the GPU box: tools/r05_reax_prof.sh <tag>)
 T=${1:-r05_x}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
