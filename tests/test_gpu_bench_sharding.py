@@ -132,6 +132,16 @@ def test_reax_replica_set_bench_line():
     assert r["symmetric"] is True and 150 < r["stored_entries_per_row"] < 550 and 2 < r["qeq_iterations_per_solve"] < 80
 
 
+def test_reax_replica_set_on_two_ranks_matches_one_rank():
+    """BASELINE config 5 names 8 GPUs: the ReaxFF set sharded over two ranks (sharing the one device here, host transport) gives the stresses of one rank"""
+    common = ["--force-field", "reax", "--sims", "6", "--steps", "1", "--warmup", "1", "--equil-steps", "20", "--no-cpu-baseline", "--monotonic-updates", "0"]
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common)
+    two = _run([sys.executable, "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--share-gpus"] + common)
+    assert two["n_gpus"] == 2 and two["config"]["sims_on_rank0"] == 3 and two["config"]["allgathers"] == 2
+    c1, c2 = one["config"]["stress_zz_checksum_Pa"], two["config"]["stress_zz_checksum_Pa"]
+    assert abs(c1 - c2) <= 1e-6 * abs(c1), (c1, c2)      # (the charge solve stops at 1e-6; summation orders differ)
+
+
 def test_default_run_carries_the_reax_leg_and_reports_environment_switches():
     """the default line's second leg (BASELINE config 5 as config.reax, outside `value`), forced on for a small OPLS batch; and a run
     with a declared switch set says so in config.env_overrides (a clean run: an empty list)"""
