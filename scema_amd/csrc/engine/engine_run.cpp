@@ -542,9 +542,12 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // k_pair and the bonded kernel: its forces are stored in SimDev::f, and k_ewald_force, which assembles the force of the
   // step, adds them after the join.  Otherwise the chain follows the assembly and adds to it.  PE-10k, evaluations per second
   // with the chain on the side stream / inline: 8 replicas 210 / 183, 72: 336 / 333, 576: 369 / 368; a single replica 39.7 / 41.6
-  // (its k_pair does not fill the chip and the fork/join is pure latency).  So: batches of 4 to 255 replicas; a batch that
-  // fills the chip many times over gains nothing, and inline its k_pair launches are timed and profiled undisturbed.
-  const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= 4 && ns < 256;
+  // (round 2: its k_pair does not fill the chip and the fork/join is pure latency -- with round 5's kernels, where the chain is 67 us of
+  // dependent launches beside 45 us of k_pair + k_bonded, 16.7 against 18.3 ms per evaluation).  So: batches of up to 255 replicas
+  // (SCEMA_MD_PPPM_SIDE_MIN: the smallest); a batch that fills the chip many times over gains nothing, and inline its k_pair launches
+  // are timed and profiled undisturbed.
+  static const int side_min = scema_env("SCEMA_MD_PPPM_SIDE_MIN") ? atoi(scema_env("SCEMA_MD_PPPM_SIDE_MIN")) : 1;
+  const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= side_min && ns < 256;
   auto pppm_fork = [&](hipStream_t st, int pos0, int na, bool new_box) -> int {
     if (!pppm_side) return SCEMA_MD_OK;
     HIPCHK(hipEventRecord(e->ev_fork, st));
