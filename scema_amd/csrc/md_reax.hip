@@ -5,14 +5,18 @@
 // The integrator, thermostat, fix deform, pressure sampling and the batch machinery are the ones of the OPLS path
 // (md_kernels.hip); only the force stage differs.
 //
-// Layout: all per-atom lists are entry-major rows ([k][i], reax/rx_types.h), one lane per atom: a wave reads 64 consecutive
-// entries at every step of its row walk.  One launch covers every replica of the batch (blockIdx.y).
+// Layout: the per-atom lists of the lane-per-atom passes (bond rows, near rows) are entry-major ([k][i], reax/rx_types.h): a wave reads 64
+// consecutive entries at every step of its row walk; the lists a wave walks ROW by row (neighbour rows, owned pairs, matrix rows) are row-major.
+// One launch covers every replica of the batch (blockIdx.y).
 //   k_rx_prepare ........ box -> view, rebuild bookkeeping, zero the energy parts
-//   k_rx_wrap, k_rx_neigh  neighbour rows inside cutoff + skin, rebuilt when an atom has moved half the skin
+//   k_rx_wrap, k_rx_neigh  neighbour rows inside cutoff + skin (a wave per row), rebuilt when an atom has moved half the skin
 //                         (LAMMPS rebuilds every step, `neigh_modify every 1 delay 0 check no`: same pairs inside the cutoff)
-//   k_rx_hrow, k_rx_qeq .. charge equilibration: matrix rows in HBM, the two conjugate-gradient solves of one replica in
-//                         one workgroup (no host round trips), both right-hand sides per sweep over the matrix
-//   k_rx_bonds ... k_rx_back2  bond orders, energy terms, reverse-mode forces (reax/rx_core.h)
+//   k_rx_hrow ........... the matrix of the charge equilibration: each pair once in its owner's row (<true>) or every pair in both rows
+//   k_rx_qeq_* .......... the two conjugate-gradient solves, both right-hand sides per sweep over the matrix, no host round trips:
+//                         sweep_sym + step (symmetric form: one workgroup per replica between two sweeps) or sweep + update (full rows),
+//                         finish / finish_sym (stragglers, charges, history)
+//   k_rx_bonds ... k_rx_back2  bond orders, energy terms (a lane per angle / torsion item), reverse-mode forces (reax/rx_core.h)
+//   k_rx_nonbonded_once . tapered van der Waals + shielded Coulomb, every owned pair once
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
