@@ -631,6 +631,8 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                     # (counters taken with 72 replicas per launch: per replica x the replicas of a whole-batch launch here, as the OPLS block scales its own)
                     "traffic": (pmc["hbm_bytes_per_sweep_corrected"] * per_rank / 72.0) if pmc and "hbm_bytes_per_sweep_corrected" in pmc else None,
                     "traffic_source": ((pmc or {}).get("command", "") + "; 72 replicas per launch, scaled by replicas per launch") if pmc else None,
+                    # (the symmetric sweep is not a pure stream any more: its vector-instruction count beside its bytes, same counters, same scaling)
+                    "frac_valu_issue": (pmc["SQ_INSTS_VALU"] * per_rank / 72.0 / (a_s / a_n) / 614.4e9) if pmc and "SQ_INSTS_VALU" in pmc and a_s > 0 else None,
                     "timed_avg_launch_ms": 1e3 * sw_s / sw_n, "timed_launches": prof["rx_sweep_launches"], "timed_launches_in_flight": sw_s / sw_union if sw_union > 0 else 1.0,
                     "frac_timed_union": sw_bytes / sw_union / 1e9 / 8000.0 if sw_union > 0 else None,
                     "frac_timed_per_launch": sw_bytes / sw_s / 1e9 / 8000.0 if sw_s > 0 else None,
