@@ -418,3 +418,26 @@ def test_symmetric_solve_and_lds_tables_on_minimum_image_replicas():
             assert np.abs(fa - np.array(b["f"])).max() < 1e-7 * np.abs(fa).max(), (cells, name)
             assert np.abs(wa - np.array(b["w"])).max() < 1e-7 * np.abs(wa).max(), (cells, name)
         assert abs(a["iters"] - out["full_rows"]["iters"]) <= 2, (a["iters"], out["full_rows"]["iters"])   # the same recurrences
+
+
+def test_undersized_neighbour_rows_overflow_and_regrow(monkeypatch):
+    """SCEMA_MD_NEIGH_GROW0 starts the engine with row capacities at 0.4 of their estimate: the wave-per-row list build must flag full rows (full and
+    near rows, bond rows) instead of writing past them, and the engine regrows and repeats -- same forces as the run that never overflowed"""
+    from scema_amd.systems import build_pe
+    d = build_pe(3, 5, 9, jitter=0.08, seed=5)
+    sym = ["C" if d["mass"][t] > 5 else "H" for t in d["type"]]
+    res = []
+    for grow0 in (None, "0.4"):
+        if grow0 is None:
+            monkeypatch.delenv("SCEMA_MD_NEIGH_GROW0", raising=False)
+        else:
+            monkeypatch.setenv("SCEMA_MD_NEIGH_GROW0", grow0)
+        e = capi.Engine()
+        e.reax_configure(FFIELD, qeq_tol=1e-10)
+        e.register_replica("m", 1, capi.reax_system(sym, d["x"], d["box"]))
+        r = e.reax_compute("m", 1)
+        res.append((np.asarray(r["f"]).copy(), r["maxnb"], r["maxneigh_seen"]))
+        e.close()
+    f0, f1 = res[0][0], res[1][0]
+    assert np.abs(f0 - f1).max() < 1e-8 * np.abs(f0).max()
+    assert res[1][2] == res[0][2] and res[1][1] >= res[1][2]   # the same longest row, inside the regrown capacity
