@@ -167,6 +167,8 @@ struct ListSig {
   double corners_hold[24];
   int ago = 0, maxj_seen = 0;
   unsigned long long nentries = 0, nentries_ref = 0, nrowent = 0;
+  long long rx_stamp = 0;        // != 0: the rows are ReaxFF rows (RxSlot), built under this force-field stamp; capj holds the near rows' stride
+  int rx_mimg[3] = {0, 0, 0};
 };
 struct Slot {
   std::unique_ptr<RxSlot> rx;

@@ -111,7 +111,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   bool col16 = !(scema_env("SCEMA_MD_RX_COL32") && atoi(scema_env("SCEMA_MD_RX_COL32")) != 0);   // (test switch: 32-bit columns for any size)
   for (int i = 0; i < ns; i++) col16 = col16 && sims[i].st->topo->natoms <= 65536;
   e->h_zerotab.clear();
-  bool any_precond = false;
+  bool any_precond = false, any_validate = false;
   bool all_sym = col16 && e->rx_sym;
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
@@ -171,7 +171,32 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     int maxnbn = (int)std::ceil(rho * 4.0 / 3.0 * MD_PI * rnear * rnear * rnear * 1.5 * e->neigh_grow) + 32;
     maxnbn = (maxnbn + 7) / 8 * 8;
     Slot &sl = *e->slots[i];
-    sl.sig.valid = false;   // (this run overwrites xhold and wrapn of the slot: cell rows of an OPLS run that it may still hold are void)
+    // A run that follows another ReaxFF run of the same state on the same slot (the sampling run behind the straining run of an evaluation; the
+    // straining run of the next update) keeps that run's neighbour rows, as the OPLS path does (run_phase): rows, near rows, reference positions
+    // and the preconditioner live in the slot, the list's scalars come back through the slot's signature (prepare_slots), and k_phase_init /
+    // k_keep_validate decide on the device whether they still hold.  The rows keep the strides they were built with.
+    static const bool keep_lists = !(scema_env("SCEMA_MD_KEEP_LIST") && atoi(scema_env("SCEMA_MD_KEEP_LIST")) == 0);
+    bool keep = false;
+    {
+      const ListSig &g = sl.sig;
+      const SimScalars &hsc = e->h_sc[i];
+      if (spec.keep_list && keep_lists && g.valid && g.rx_stamp != 0 && g.rx_stamp == e->rx_stamp && g.topo == (const void *)&T && g.rlist == rlist && g.npad == npad &&
+          (spec.keep_list == 1 || g.state == (const void *)A.st) && !hsc.force_rebuild && !hsc.overflow && maxnb <= g.maxneigh && maxnbn <= g.capj &&
+          g.rx_mimg[0] == V.mimg[0] && g.rx_mimg[1] == V.mimg[1] && g.rx_mimg[2] == V.mimg[2] && sl.rx) {
+        keep = true;
+        maxnb = g.maxneigh; maxnbn = g.capj;
+      }
+    }
+    S.keep_list = keep ? spec.keep_list : 0;
+    any_validate = any_validate || S.keep_list == 2;
+    {
+      ListSig &g = sl.sig;   // what this run's rows are built for; valid once the run has ended without a fault
+      g.valid = false;
+      g.rx_stamp = e->rx_stamp;
+      g.topo = (const void *)&T;
+      g.rlist = rlist; g.npad = npad; g.maxneigh = maxnb; g.capj = maxnbn;
+      for (int d = 0; d < 3; d++) g.rx_mimg[d] = V.mimg[d];
+    }
     rc = ensure_slot(e, sl, n, 64, 1, 0, 64);
     if (rc) return rc;
     if (!sl.rx) sl.rx.reset(new RxSlot());
@@ -251,6 +276,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   size_t ev_used = 0;
   std::vector<hipEvent_t> *evp = prof ? &e->ev_pool : nullptr;
   mdk_phase_init(st, D, ns);
+  if (any_validate) mdk_keep_validate(st, D, ns, maxatoms);
   // Charge-equilibration history: kept in place when this run follows another one on the same slots; else a state that has run
   // before brings its own (one copy launch for the batch); the rest start from zeros like a new fix qeq/reax
   bool any_cold = false;
@@ -482,6 +508,14 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   e->overflow_bits = ((fault & 1) ? (1 | 8) : 0) | (fault & 64);
   if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
   if (fault & 64) return SCEMA_MD_ERR_OVERFLOW;   // the barostat took the box out of the range this segment was laid out for
+  for (int i = 0; i < ns; i++) {   // the rows on the device hold for the positions this run ended at
+    ListSig &g = e->slots[i]->sig;
+    const SimScalars &c = e->h_sc[i];
+    g.valid = !spec.minimize;
+    g.state = (const void *)sims[i].st;
+    std::memcpy(g.corners_hold, c.corners_hold, sizeof g.corners_hold);
+    g.ago = c.ago;
+  }
   return SCEMA_MD_OK;
 }
 

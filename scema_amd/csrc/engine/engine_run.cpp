@@ -278,7 +278,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     bool keep = false;
     {
       const ListSig &g = e->slots[i]->sig;
-      if (spec.keep_list && keep_lists && g.valid && g.topo == (const void *)&T && g.rlist == rlist && g.cut_lj == P.cut_lj && g.cut_coul == P.cut_coul &&
+      if (spec.keep_list && keep_lists && g.valid && g.rx_stamp == 0 && g.topo == (const void *)&T && g.rlist == rlist && g.cut_lj == P.cut_lj && g.cut_coul == P.cut_coul &&
           (spec.keep_list == 1 || g.state == (const void *)A.st) && !hsc.force_rebuild && !hsc.overflow) {
         int mst[3], cj = 0, mn = 0;
         if (size_grid(g.nc, mst, cj, mn) && cj <= g.capj && mn <= g.maxneigh && padded_slots(T.natoms, g.nc[0] * g.nc[1] * g.nc[2]) == g.npad) {
@@ -367,6 +367,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     {
       ListSig &g = sl.sig;   // what this run's rows are built for; valid once the run has ended without a fault
       g.valid = false;
+      g.rx_stamp = 0;
       g.topo = (const void *)&T;
       for (int d = 0; d < 3; d++) g.nc[d] = S.nc[d];
       g.capj = capj; g.maxneigh = maxneigh; g.npad = S.npad;

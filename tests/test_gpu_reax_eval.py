@@ -160,3 +160,49 @@ def test_stresses_do_not_depend_on_how_the_batch_is_issued(gold, scripts):
     assert np.abs(res[0] - res[1]).max() < 1e-6 * scale
     assert np.abs(res[2] - res[1]).max() < 1e-6 * scale
 
+
+def test_kept_reax_neighbour_rows_equal_rebuilt_ones(tmp_path):
+    """ReaxFF rows (full and near rows, reference positions, the preconditioner) survive from the straining run to the sampling run and from one update to
+    the next on the same slot where the device finds every atom within the list's displacement bound (as the OPLS rows do); SCEMA_MD_KEEP_LIST=0 rebuilds at
+    every run start.  A sequence in which one state is REPLACED between two updates and another continues: same stresses either way, fewer builds."""
+    import json, subprocess, sys
+    root = os.path.dirname(HERE)
+    d = tmp_path / "lammps_scripts_reax"
+    d.mkdir()
+    shutil.copy(FFIELD, d / "ffield.reax.2")
+    code = ("import json, sys, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "d = build_pe(3, 5, 9, jitter=0.05, seed=7)\n"
+            "sym = ['C' if d['mass'][t] > 5 else 'H' for t in d['type']]\n"
+            "m = np.array([12.011 if c == 'C' else 1.008 for c in sym])\n"
+            "v = np.random.default_rng(3).standard_normal((len(sym), 3)) * np.sqrt(0.0019872067 * 300.0 / (m[:, None] * 48.88821291 ** 2))\n"
+            "v -= (m[:, None] * v).sum(0) / m.sum()\n"
+            "e = capi.Engine()\n"
+            "e.reax_configure(sys.argv[1] + '/ffield.reax.2', qeq_tol=1e-10)\n"
+            "e.register_replica('g0', 1, capi.reax_system(sym, d['x'], d['box'], v=v))\n"
+            "L = d['box'][3:6] - d['box'][:3]\n"
+            "st = np.array([-3e-4 * L[0], -3e-4 * L[1], 1e-3 * L[2], 2e-5 * L[2], 0, 0])\n"
+            "mk = lambda q, s, recent: capi.make_sim(q, 'g0', 1, s, nss=20, dt=0.25, temperature=300.0, strain_rate=1e-4, most_recent=recent, force_field='reax', scripts_folder=sys.argv[1])\n"
+            "out = []\n"
+            "a = e.strain_batch([mk(q, st * (1 + 0.2 * q), capi.QP_NONE) for q in (0, 1)])\n"
+            "out += [list(o.stress) for o in a]\n"
+            "a = e.strain_batch([mk(q, -st, q) for q in (0, 1)])\n"
+            "out += [list(o.stress) for o in a]\n"
+            "box, x, vv = e.get_state(1, 'g0', 1)\n"
+            "rng = np.random.default_rng(3)\n"
+            "e.set_state(0, 'g0', 1, box, x + rng.normal(0, 0.02, x.shape), vv)      # qp 0 becomes (a perturbed copy of) qp 1's state\n"
+            "a = e.strain_batch([mk(q, st, q) for q in (0, 1)])\n"
+            "out += [list(o.stress) for o in a]\n"
+            "p = e.profile()\n"
+            "print(json.dumps({'s': out, 'builds': p['neigh_builds'], 'steps': p['md_steps']}))\n")
+    res = {}
+    for name, env in (("keep", {}), ("nokeep", {"SCEMA_MD_KEEP_LIST": "0"})):
+        pr = subprocess.run([sys.executable, "-c", code, str(d)], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **env))
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        res[name] = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = np.array(res["keep"]["s"]), np.array(res["nokeep"]["s"])
+    # (the charge solve to 1e-10: what is left is the order of FP64 sums and the age of the preconditioner)
+    assert np.abs(a - b).max() < 1e-7 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+    assert res["keep"]["steps"] == res["nokeep"]["steps"]
+    assert res["keep"]["builds"] <= res["nokeep"]["builds"] - 4, (res["keep"]["builds"], res["nokeep"]["builds"])
