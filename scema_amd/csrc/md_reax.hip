@@ -1247,10 +1247,43 @@ __global__ __launch_bounds__(TPB) void k_rx_rev(const RxView *views) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i < V.n) rx_bonds_rev(&V, i);
 }
+// Corrected bond orders (rx_bonds_corrected) with FOUR lanes per atom, one per bond slot (a carbon has four bonds): a lane-per-atom pass is a chain
+// of dependent round trips per bond -- entry, partner's Delta', the correction's exponentials -- and nothing else (2 % of the issue slots); a wave takes
+// 16 atoms, row r of its 16 lanes the bond slots r, r + 4, ...; the entry-major rows make every row's loads 16 consecutive words.
 __global__ __launch_bounds__(TPB) void k_rx_corr(const RxView *views, const RxParams *__restrict__ P) {
   const RxView V = views[blockIdx.y];
-  const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i < V.n) rx_bonds_corrected(P, &V, i);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, a = lane & 15, k4 = lane >> 4;
+  const int i = blockIdx.x * (TPB / 4) + wave * 16 + a;
+  const bool live = i < V.n;
+  const int ii = live ? i : 0;
+  const int np = V.npad, ti = V.rtype[ii], cnt = live ? V.bd_cnt[ii] : 0;
+  const size_t plane = (size_t)V.maxbd * np;
+  const double Di = V.deltap[ii];
+  double sum = 0.0;
+  for (int k = k4; k < cnt; k += 4) {
+    const size_t o = (size_t)k * np + i;
+    const int j = V.bd[o] & RX_JMASK;
+    const double B = V.bd_bop[o], Bp = V.bd_bop[plane + o], Bpp = V.bd_bop[2 * plane + o];
+    RxCorr c;
+    rx_corr(P, ti, V.rtype[j], Di, V.deltap[j], B, &c);
+    const double A0 = c.Y * c.X, A1 = A0 * c.Y;
+    double bo = B * A0, bp = Bp * A1, bpp = Bpp * A1;
+    if (bo < 1e-10) bo = 0.0;
+    if (bp < 1e-10) bp = 0.0;
+    if (bpp < 1e-10) bpp = 0.0;
+    V.bd_bo[o] = bo; V.bd_bo[plane + o] = bp; V.bd_bo[2 * plane + o] = bpp;
+    V.bd_g[o] = 0.0; V.bd_g[plane + o] = 0.0; V.bd_g[2 * plane + o] = 0.0;
+    sum += bo;
+  }
+  // the atom's four lanes sit in the four rows of the wave (the order of this sum differs from the serial pass for atoms of more than two bonds)
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  if (k4 == 0 && live) {
+    V.total_bo[i] = sum;
+    V.cd_delta[i] = 0.0;
+    V.hd[i] = 0.0;
+    V.f[3 * i] = 0.0; V.f[3 * i + 1] = 0.0; V.f[3 * i + 2] = 0.0;
+  }
 }
 // pass: 0 atom terms, 3 hydrogen bonds (angles: k_rx_angles, torsions: k_rx_torsions, non-bonded: k_rx_nonbonded_once / k_rx_nonbonded)
 template <int PASS>
@@ -1607,7 +1640,7 @@ void mdk_reax_forces(hipStream_t st, const SimDev *d, RxView *v, const RxParams 
   if (side) { (void)hipEventRecord(side->fork, st); (void)hipStreamWaitEvent(sb, side->fork, 0); }
   hipLaunchKernelGGL(k_rx_bonds, g2(cdv(maxatoms, 8 * (TPB / 64)), ns), dim3(TPB), 0, sb, v, P);
   hipLaunchKernelGGL(k_rx_rev, ga, dim3(TPB), 0, sb, v);
-  hipLaunchKernelGGL(k_rx_corr, ga, dim3(TPB), 0, sb, v, P);
+  hipLaunchKernelGGL(k_rx_corr, g2(cdv(maxatoms, TPB / 4), ns), dim3(TPB), 0, sb, v, P);
   if (side) (void)hipEventRecord(side->mid, sb);
   if (terms & 1) hipLaunchKernelGGL(k_rx_terms<0>, gr, dim3(RX_TPB), 0, sb, d, v, P);
   // (test hook: a small item list forces the in-place path of the two item kernels)
