@@ -171,6 +171,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   std::vector<EwaldSetup> ews(ns);   // by position
   for (int pos = 0; pos < ns; pos++) ews[pos] = std::move(ews_i[order[pos]]);
   int maxgrid = 0;   // PPPM: largest grid of the batch
+  int maxgridp = 0;  // ... with five more points per x row
+  bool padx_ok = true;
   // NOTE: slot index == position in `sims` (not in `order`): scalars stay attached to their slot
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
@@ -335,6 +337,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (P.kspace_style == 1 && T.qsqsum > 0.0) {
       for (int d = 0; d < 3; d++) { S.pg[d] = -ew.kmaxd[d]; }
       maxgrid = std::max(maxgrid, S.pg[0] * S.pg[1] * S.pg[2]);
+      if (S.pg[0] < 5) padx_ok = false;   // (the padded LDS copies of the spreading and interpolation kernels fold five distinct pad columns per row)
+      maxgridp = std::max(maxgridp, (S.pg[0] + 5) * S.pg[1] * S.pg[2]);
     }
     const auto tl3 = t_now();
     S.nk = (int)ew.kn.size() / 3;
@@ -504,13 +508,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (maxgrid <= 0 || na <= 0) return SCEMA_MD_OK;
     const SimDev *Dp = e->d_sims.as<SimDev>() + pos0;
     bool &clean = pppm_clean[(nhalf == 2 && pos0 == hbeg[1]) ? 1 : 0];
-    mdk_pppm_spread(st, Dp, na, maxgrid, maxatoms, clean ? 1 : 0);
+    mdk_pppm_spread(st, Dp, na, maxgrid, maxatoms, clean ? 1 : 0, padx_ok ? maxgridp : 0);
     clean = false;
     if (pppm_in_lds) {   // small grids: the whole solve in one launch, in LDS (md_pppm.hip k_pppm_solve); it leaves the charge grids zeroed
       if (new_box) mdk_pppm_gf(st, Dp, na, maxgrid);
       mdk_pppm_solve(st, Dp, na, maxgrid, maxdims);
       clean = true;
-      mdk_pppm_force(st, Dp, na, maxgrid, maxatoms, add, 1);
+      mdk_pppm_force(st, Dp, na, maxgrid, maxatoms, add, 1, padx_ok ? maxgridp : 0);
       return SCEMA_MD_OK;
     }
     auto transform = [&](bool fields, int dir) -> int {   // the charge grids forward, or the three field grids of every simulation back

@@ -6,7 +6,7 @@ struct SimDev;
 size_t mdk_pppm_lds_limit();
 // charges -> grid 0 (complex, imaginary part 0); maxgrid = largest nx*ny*nz of the batch
 // zeroed != 0: the charge grids are known to hold zeros (k_pppm_solve leaves them so)
-void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed);
+void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed, int maxgridp = 0);   // maxgridp: largest grid with 5 more points per x row (0: no padded LDS copy)
 // small grids (maxgrid <= mdk_pppm_solve_max()): forward transform, energy / virial / field spectra and the three inverse transforms in one
 // launch, in LDS (replaces the transforms of the engine and mdk_pppm_poisson); maxdims = largest nx + ny + nz of the batch
 int mdk_pppm_solve_max();
@@ -17,4 +17,4 @@ void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid);
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid);
 // after the inverse transforms of the field grids: forces added to SimDev::f (add != 0) or stored there (the chain runs ahead of
 // the kernel that assembles the force of the step, which then adds them: mdk_ewald_force fkeep)
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields = 0);   // real_fields: after mdk_pppm_solve
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields = 0, int maxgridp = 0);   // real_fields: after mdk_pppm_solve

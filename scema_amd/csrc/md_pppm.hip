@@ -76,13 +76,17 @@ __global__ __launch_bounds__(256) void k_pppm_zero(const SimDev *sims) {
 // neighbours share their 125 grid points, and 64 lanes adding to the same addresses would be serialised by the LDS.  LDS = true:
 // a private copy of the real grid in LDS (ds_add_f64), added to grid 0 at the end (the only global atomics: one per grid point
 // and workgroup; a direct store when the replica has one workgroup).  LDS = false (grid beyond the LDS): global atomics throughout.
+// PADX (LDS only, nx >= 5): the LDS copy has nx + 5 points per x row -- an atom's five x points are columns i .. i + 4 of the padded row, never
+// wrapped, so the address of a point is the row's plus a CONSTANT (the offset field of ds_add_f64) instead of an addition per point; the five
+// pad columns are folded back onto the points they alias before the copy leaves.
 extern __shared__ double s_grid[];
-template <bool LDS, int TPB_>
+template <bool LDS, int TPB_, bool PADX = false>
 __global__ __launch_bounds__(TPB_) void k_pppm_spread(const SimDev *sims, int split) {
   const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
   if (nx == 0) return;
   const int NG = nx * ny * nz, T = (int)blockDim.x;
+  const int nxp = PADX ? nx + 5 : nx, NGP = nxp * ny * nz;
   const int chunk = (S.natoms + split - 1) / split, a0 = (int)blockIdx.x * chunk, a1 = min(S.natoms, a0 + chunk);
   if (a0 >= a1) return;
   BoxD b;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(TPB_) void k_pppm_spread(const SimDev *sims, int sp
   box_uniform(b);
   double2 *rho = (double2 *)S.pgrid;
   if (LDS) {
-    for (int k = threadIdx.x; k < NG; k += T) s_grid[k] = 0.0;
+    for (int k = threadIdx.x; k < NGP; k += T) s_grid[k] = 0.0;
     __syncthreads();
   }
   const double delvolinv = (double)NG / b.vol;
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(TPB_) void k_pppm_spread(const SimDev *sims, int sp
     const int aA = a0 + lane * rows + r, aB = aA + 1;
     const bool vA = aA < a1, vB = r + 1 < rows && aB < a1;
     if (!vA) continue;
-    double wxA[PP_ORDER], wyA[PP_ORDER], wzA[PP_ORDER], wxB[PP_ORDER], wyB[PP_ORDER], wzB[PP_ORDER];
-    int gxA[PP_ORDER], gyA[PP_ORDER], gzA[PP_ORDER], gxB[PP_ORDER], gyB[PP_ORDER], gzB[PP_ORDER];
+    double wxA[PP_ORDER], wyA[PP_ORDER], wzA[PP_ORDER], wxB[PP_ORDER] = {0, 0, 0, 0, 0}, wyB[PP_ORDER] = {0, 0, 0, 0, 0}, wzB[PP_ORDER] = {0, 0, 0, 0, 0};
+    int gxA[PP_ORDER], gyA[PP_ORDER], gzA[PP_ORDER], gxB[PP_ORDER] = {0, 0, 0, 0, 0}, gyB[PP_ORDER] = {0, 0, 0, 0, 0}, gzB[PP_ORDER] = {0, 0, 0, 0, 0};
     double l0, l1, l2;
     atom_lamda(S, b, aA, l0, l1, l2);
     const int ixA = pppm_weights(l0 * nx, wxA), iyA = pppm_weights(l1 * ny, wyA), izA = pppm_weights(l2 * nz, wzA);
@@ -125,12 +129,14 @@ __global__ __launch_bounds__(TPB_) void k_pppm_spread(const SimDev *sims, int sp
       for (int c = 0; c < PP_ORDER; c++) {
 #pragma unroll
         for (int bb = 0; bb < PP_ORDER; bb++) {
-          const double zyA = wzA[c] * wyA[bb], zyB = merged ? wzB[c] * wyB[bb] : 0.0;
-          const int row = (gzA[c] * ny + gyA[bb]) * nx;
+          const double zyA = wzA[c] * wyA[bb], zyB = merged ? wzB[c] * wyB[bb] : 0.0;   // (B's weights are zeros where there is no B)
+          const int row = (gzA[c] * ny + gyA[bb]) * nxp;
+          double *prow = s_grid + row + ixA;   // PADX
 #pragma unroll
           for (int k = 0; k < PP_ORDER; k++) {
-            const double val = merged ? fma(zyB, wxB[k], zyA * wxA[k]) : zyA * wxA[k];
-            if (LDS) (void)__hip_atomic_fetch_add(&s_grid[row + gxA[k]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const double val = fma(zyB, wxB[k], zyA * wxA[k]);
+            if (LDS && PADX) (void)__hip_atomic_fetch_add(prow + k, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (LDS) (void)__hip_atomic_fetch_add(&s_grid[row + gxA[k]], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else atomicAdd(&rho[row + gxA[k]].x, val);
           }
         }
@@ -142,10 +148,12 @@ __global__ __launch_bounds__(TPB_) void k_pppm_spread(const SimDev *sims, int sp
 #pragma unroll
         for (int bb = 0; bb < PP_ORDER; bb++) {
           const double zyB = wzB[c] * wyB[bb];
-          const int row = (gzB[c] * ny + gyB[bb]) * nx;
+          const int row = (gzB[c] * ny + gyB[bb]) * nxp;
+          double *prow = s_grid + row + ixB;   // PADX
 #pragma unroll
           for (int k = 0; k < PP_ORDER; k++) {
-            if (LDS) (void)__hip_atomic_fetch_add(&s_grid[row + gxB[k]], zyB * wxB[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (LDS && PADX) (void)__hip_atomic_fetch_add(prow + k, zyB * wxB[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (LDS) (void)__hip_atomic_fetch_add(&s_grid[row + gxB[k]], zyB * wxB[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else atomicAdd(&rho[row + gxB[k]].x, zyB * wxB[k]);
           }
         }
@@ -154,7 +162,23 @@ __global__ __launch_bounds__(TPB_) void k_pppm_spread(const SimDev *sims, int sp
   }
   if (LDS) {
     __syncthreads();
-    if (split == 1) {
+    if (PADX) {
+      // column c of a padded row holds grid point c - 2: columns 0, 1 belong to nx - 2, nx - 1 and columns nx + 2 .. nx + 4 to 0, 1, 2
+      // (five distinct targets per row as nx >= 5: plain additions, one thread each)
+      const int nrow = ny * nz;
+      for (int k = threadIdx.x; k < 5 * nrow; k += T) {
+        const int row = k / 5, pc = k - 5 * row;
+        const int src = pc < 2 ? pc : nx + pc, dst = (pc < 2 ? nx - 2 + pc : pc - 2) + 2;
+        s_grid[row * nxp + dst] += s_grid[row * nxp + src];
+      }
+      __syncthreads();
+      for (int k = threadIdx.x; k < NG; k += T) {
+        const int row = k / nx, x = k - row * nx;
+        const double v = s_grid[row * nxp + x + 2];
+        if (split == 1) rho[k] = make_double2(v, 0.0);
+        else if (v != 0.0) atomicAdd(&rho[k].x, v);
+      }
+    } else if (split == 1) {
       for (int k = threadIdx.x; k < NG; k += T) rho[k] = make_double2(s_grid[k], 0.0);
     } else {
       for (int k = threadIdx.x; k < NG; k += T) {
@@ -398,19 +422,37 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
 // (consecutive atoms in consecutive lanes: neighbours read the same grid points, which the LDS broadcasts); LDS = false reads
 // the grids through the caches.
 // REALF: the fields are three real arrays at a spacing of gs doubles (written by k_pppm_solve) instead of the real parts of three complex grids
-template <bool LDS, bool REALF = false>
+// PADX (LDS only, nx >= 5): the staged fields as ONE array of (Ex, Ey, Ez) triples with nx + 5 points per x row (the pad columns repeat the points
+// they alias): the 15 values of an x row of an atom's stencil sit at constant offsets from one address.
+template <bool LDS, bool REALF = false, bool PADX = false>
 __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int split, int add) {
   const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
   if (nx == 0) return;
   const int NG = nx * ny * nz;
+  const int nxp = PADX ? nx + 5 : nx;
   int chunk = (S.natoms + split - 1) / split;
   chunk = (chunk + 255) & ~255;
   const int a0 = (int)blockIdx.x * chunk, a1 = min(S.natoms, a0 + chunk);
   if (a0 >= a1) return;
   const size_t gs = (size_t)S.pgstride;
   const double2 *ex = (const double2 *)S.pfield, *ey = ex + gs, *ez = ey + gs;
-  if (LDS) {
+  if (LDS && PADX) {
+    const int NGP = nxp * ny * nz;
+    for (int k = threadIdx.x; k < NGP; k += 256) {
+      const int row = k / nxp, c = k - row * nxp;
+      int x = c - 2;
+      x = x < 0 ? x + nx : (x >= nx ? x - nx : x);
+      const int g = row * nx + x;
+      if (REALF) {
+        const double *fr = (const double *)S.pfield;
+        s_grid[3 * k] = fr[g]; s_grid[3 * k + 1] = fr[gs + g]; s_grid[3 * k + 2] = fr[2 * gs + g];
+      } else {
+        s_grid[3 * k] = ex[g].x; s_grid[3 * k + 1] = ey[g].x; s_grid[3 * k + 2] = ez[g].x;
+      }
+    }
+    __syncthreads();
+  } else if (LDS) {
     if (REALF) {
       const double *fr = (const double *)S.pfield;
       for (int k = threadIdx.x; k < NG; k += 256) { s_grid[k] = fr[k]; s_grid[NG + k] = fr[gs + k]; s_grid[2 * NG + k] = fr[2 * gs + k]; }
@@ -432,7 +474,8 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
     atom_lamda(S, b, a, l0, l1, l2);
     double wx[PP_ORDER], wy[PP_ORDER], wz[PP_ORDER];
     int gx[PP_ORDER], gy[PP_ORDER], gz[PP_ORDER];
-    pppm_wrap(pppm_weights(l0 * nx, wx), nx, gx);
+    const int ix = pppm_weights(l0 * nx, wx);
+    pppm_wrap(ix, nx, gx);
     pppm_wrap(pppm_weights(l1 * ny, wy), ny, gy);
     pppm_wrap(pppm_weights(l2 * nz, wz), nz, gz);
     double fx = 0.0, fy = 0.0, fz = 0.0;
@@ -441,12 +484,14 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
 #pragma unroll
       for (int bb = 0; bb < PP_ORDER; bb++) {
         const double zy = wz[c] * wy[bb];
-        const int row = (gz[c] * ny + gy[bb]) * nx;
+        const int row = (gz[c] * ny + gy[bb]) * nxp;
+        const double *prow = s_grid + 3 * (row + ix);   // PADX
         double rx = 0.0, ry = 0.0, rz = 0.0;
 #pragma unroll
         for (int k = 0; k < PP_ORDER; k++) {
           const int g = row + gx[k];
-          if (LDS) { rx = fma(wx[k], s_grid[g], rx); ry = fma(wx[k], s_grid[NG + g], ry); rz = fma(wx[k], s_grid[2 * NG + g], rz); }
+          if (LDS && PADX) { rx = fma(wx[k], prow[3 * k], rx); ry = fma(wx[k], prow[3 * k + 1], ry); rz = fma(wx[k], prow[3 * k + 2], rz); }
+          else if (LDS) { rx = fma(wx[k], s_grid[g], rx); ry = fma(wx[k], s_grid[NG + g], ry); rz = fma(wx[k], s_grid[2 * NG + g], rz); }
           else { rx = fma(wx[k], ex[g].x, rx); ry = fma(wx[k], ey[g].x, ry); rz = fma(wx[k], ez[g].x, rz); }
         }
         fx = fma(zy, rx, fx); fy = fma(zy, ry, fy); fz = fma(zy, rz, fz);
@@ -465,8 +510,11 @@ static inline int pppm_split(int ns, int maxatoms) {
   // small batches: down to one atom per thread (a single replica: spreading 27 -> 15 us, interpolation 27 -> 20 us)
   return std::max(1, std::min(std::min(ns < 32 ? 64 : 16, cdiv(2048, ns)), maxatoms / 256));
 }
-void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed) {
-  const size_t lds = (size_t)maxgrid * sizeof(double);
+void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed, int maxgridp) {
+  // maxgridp: the largest grid with five more points per x row (0: a grid of the batch has fewer than five points in x): the padded LDS copy
+  static const bool padx_off = scema_env("SCEMA_MD_PPPM_PADX") && atoi(scema_env("SCEMA_MD_PPPM_PADX")) == 0;
+  const bool padx = maxgridp > 0 && !padx_off && (size_t)maxgridp * sizeof(double) <= 36 * 1024;
+  const size_t lds = (size_t)(padx ? maxgridp : maxgrid) * sizeof(double);
   const bool use_lds = lds <= mdk_pppm_lds_limit();
   const int split = pppm_split(ns, maxatoms);
   if ((!use_lds || split > 1) && !zeroed) hipLaunchKernelGGL(k_pppm_zero, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d);
@@ -478,7 +526,8 @@ void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int m
   size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_spread<true, PP_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
   // a small grid leaves room for several workgroups per CU; a large one gets the CU to itself and brings its own sixteen waves
-  if (lds <= 36 * 1024) hipLaunchKernelGGL((k_pppm_spread<true, 256>), grid2(split, ns), dim3(256), lds, st, d, split);
+  if (padx) hipLaunchKernelGGL((k_pppm_spread<true, 256, true>), grid2(split, ns), dim3(256), lds, st, d, split);
+  else if (lds <= 36 * 1024) hipLaunchKernelGGL((k_pppm_spread<true, 256>), grid2(split, ns), dim3(256), lds, st, d, split);
   else hipLaunchKernelGGL((k_pppm_spread<true, PP_TPB>), grid2(split, ns), dim3(PP_TPB), lds, st, d, split);
 }
 int mdk_pppm_solve_max() { return PP_SOLVE_MAX; }
@@ -499,8 +548,10 @@ void mdk_pppm_solve(hipStream_t st, const SimDev *d, int ns, int maxgrid, int ma
 }
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_gf, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_poisson, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields) {
-  const size_t lds = 3 * (size_t)maxgrid * sizeof(double);
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields, int maxgridp) {
+  static const bool padx_off = scema_env("SCEMA_MD_PPPM_PADX") && atoi(scema_env("SCEMA_MD_PPPM_PADX")) == 0;
+  const bool padx = maxgridp > 0 && !padx_off && real_fields && 3 * (size_t)maxgridp * sizeof(double) <= mdk_pppm_lds_limit();
+  const size_t lds = 3 * (size_t)(padx ? maxgridp : maxgrid) * sizeof(double);
   if (lds > mdk_pppm_lds_limit()) {
     hipLaunchKernelGGL((k_pppm_force<false, false>), grid2(cdiv(maxatoms, 256), ns), dim3(256), 0, st, d, cdiv(maxatoms, 256), add);
     return;
@@ -510,9 +561,11 @@ void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int ma
   if (lds > 64 * 1024 && lds > optin) {
     (void)hipFuncSetAttribute((const void *)k_pppm_force<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)k_pppm_force<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_pppm_force<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     optin = lds;
   }
   const int split = pppm_split(ns, maxatoms);
-  if (real_fields) hipLaunchKernelGGL((k_pppm_force<true, true>), grid2(split, ns), dim3(256), lds, st, d, split, add);
+  if (padx) hipLaunchKernelGGL((k_pppm_force<true, true, true>), grid2(split, ns), dim3(256), lds, st, d, split, add);
+  else if (real_fields) hipLaunchKernelGGL((k_pppm_force<true, true>), grid2(split, ns), dim3(256), lds, st, d, split, add);
   else hipLaunchKernelGGL((k_pppm_force<true, false>), grid2(split, ns), dim3(256), lds, st, d, split, add);
 }
