@@ -53,7 +53,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_SKIN_EXTRA", "list skin = params.skin + this many Angstrom (results do not depend on it)"},
     {"SCEMA_MD_SKIN_ADAPT", "1: per-state adaptation of the extra skin from the rebuild interval (round-1 behaviour)"},
     {"SCEMA_MD_PPPM_SOLVE_WIDE", "1 / 0: the in-LDS PPPM solve with 1 024 threads and three LDS grids / 512 threads and two (default: by batch size)"},
-    {"SCEMA_MD_PPPM_PADX", "0: the LDS grids of the PPPM spreading and interpolation kernels without the five pad points per x row (an address addition per stencil point instead of a constant offset)"},
+    {"SCEMA_MD_PPPM_PADX", "0: the LDS grid of the PPPM spreading kernel without the five pad points per x row (an address addition per stencil point instead of a constant offset)"},
     {"SCEMA_MD_PPPM_FFT", "hipFFT for every PPPM grid (default: grids of up to 2 900 points are solved in LDS)"},
     {"SCEMA_MD_FUSED_TAIL", "0 / 1: force assembly + SHAKE + second kick as three kernels / as k_finish (default: by batch size)"},
     {"SCEMA_MD_CELL_BUILD", "0: cell binning as k_bin + k_cell_scan + k_cell_fill instead of the one-launch k_cell_build"},

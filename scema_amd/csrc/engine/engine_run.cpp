@@ -514,7 +514,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       if (new_box) mdk_pppm_gf(st, Dp, na, maxgrid);
       mdk_pppm_solve(st, Dp, na, maxgrid, maxdims);
       clean = true;
-      mdk_pppm_force(st, Dp, na, maxgrid, maxatoms, add, 1, padx_ok ? maxgridp : 0);
+      mdk_pppm_force(st, Dp, na, maxgrid, maxatoms, add, 1);
       return SCEMA_MD_OK;
     }
     auto transform = [&](bool fields, int dir) -> int {   // the charge grids forward, or the three field grids of every simulation back

@@ -17,4 +17,4 @@ void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid);
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid);
 // after the inverse transforms of the field grids: forces added to SimDev::f (add != 0) or stored there (the chain runs ahead of
 // the kernel that assembles the force of the step, which then adds them: mdk_ewald_force fkeep)
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields = 0, int maxgridp = 0);   // real_fields: after mdk_pppm_solve
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields = 0);   // real_fields: after mdk_pppm_solve

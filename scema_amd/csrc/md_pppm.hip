@@ -422,37 +422,19 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
 // (consecutive atoms in consecutive lanes: neighbours read the same grid points, which the LDS broadcasts); LDS = false reads
 // the grids through the caches.
 // REALF: the fields are three real arrays at a spacing of gs doubles (written by k_pppm_solve) instead of the real parts of three complex grids
-// PADX (LDS only, nx >= 5): the staged fields as ONE array of (Ex, Ey, Ez) triples with nx + 5 points per x row (the pad columns repeat the points
-// they alias): the 15 values of an x row of an atom's stencil sit at constant offsets from one address.
-template <bool LDS, bool REALF = false, bool PADX = false>
+template <bool LDS, bool REALF = false>
 __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int split, int add) {
   const SimDev &S = sims[blockIdx.y];
   const int nx = S.pg[0], ny = S.pg[1], nz = S.pg[2];
   if (nx == 0) return;
   const int NG = nx * ny * nz;
-  const int nxp = PADX ? nx + 5 : nx;
   int chunk = (S.natoms + split - 1) / split;
   chunk = (chunk + 255) & ~255;
   const int a0 = (int)blockIdx.x * chunk, a1 = min(S.natoms, a0 + chunk);
   if (a0 >= a1) return;
   const size_t gs = (size_t)S.pgstride;
   const double2 *ex = (const double2 *)S.pfield, *ey = ex + gs, *ez = ey + gs;
-  if (LDS && PADX) {
-    const int NGP = nxp * ny * nz;
-    for (int k = threadIdx.x; k < NGP; k += 256) {
-      const int row = k / nxp, c = k - row * nxp;
-      int x = c - 2;
-      x = x < 0 ? x + nx : (x >= nx ? x - nx : x);
-      const int g = row * nx + x;
-      if (REALF) {
-        const double *fr = (const double *)S.pfield;
-        s_grid[3 * k] = fr[g]; s_grid[3 * k + 1] = fr[gs + g]; s_grid[3 * k + 2] = fr[2 * gs + g];
-      } else {
-        s_grid[3 * k] = ex[g].x; s_grid[3 * k + 1] = ey[g].x; s_grid[3 * k + 2] = ez[g].x;
-      }
-    }
-    __syncthreads();
-  } else if (LDS) {
+  if (LDS) {
     if (REALF) {
       const double *fr = (const double *)S.pfield;
       for (int k = threadIdx.x; k < NG; k += 256) { s_grid[k] = fr[k]; s_grid[NG + k] = fr[gs + k]; s_grid[2 * NG + k] = fr[2 * gs + k]; }
@@ -474,8 +456,7 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
     atom_lamda(S, b, a, l0, l1, l2);
     double wx[PP_ORDER], wy[PP_ORDER], wz[PP_ORDER];
     int gx[PP_ORDER], gy[PP_ORDER], gz[PP_ORDER];
-    const int ix = pppm_weights(l0 * nx, wx);
-    pppm_wrap(ix, nx, gx);
+    pppm_wrap(pppm_weights(l0 * nx, wx), nx, gx);
     pppm_wrap(pppm_weights(l1 * ny, wy), ny, gy);
     pppm_wrap(pppm_weights(l2 * nz, wz), nz, gz);
     double fx = 0.0, fy = 0.0, fz = 0.0;
@@ -484,14 +465,12 @@ __global__ __launch_bounds__(256) void k_pppm_force(const SimDev *sims, int spli
 #pragma unroll
       for (int bb = 0; bb < PP_ORDER; bb++) {
         const double zy = wz[c] * wy[bb];
-        const int row = (gz[c] * ny + gy[bb]) * nxp;
-        const double *prow = s_grid + 3 * (row + ix);   // PADX
+        const int row = (gz[c] * ny + gy[bb]) * nx;
         double rx = 0.0, ry = 0.0, rz = 0.0;
 #pragma unroll
         for (int k = 0; k < PP_ORDER; k++) {
           const int g = row + gx[k];
-          if (LDS && PADX) { rx = fma(wx[k], prow[3 * k], rx); ry = fma(wx[k], prow[3 * k + 1], ry); rz = fma(wx[k], prow[3 * k + 2], rz); }
-          else if (LDS) { rx = fma(wx[k], s_grid[g], rx); ry = fma(wx[k], s_grid[NG + g], ry); rz = fma(wx[k], s_grid[2 * NG + g], rz); }
+          if (LDS) { rx = fma(wx[k], s_grid[g], rx); ry = fma(wx[k], s_grid[NG + g], ry); rz = fma(wx[k], s_grid[2 * NG + g], rz); }
           else { rx = fma(wx[k], ex[g].x, rx); ry = fma(wx[k], ey[g].x, ry); rz = fma(wx[k], ez[g].x, rz); }
         }
         fx = fma(zy, rx, fx); fy = fma(zy, ry, fy); fz = fma(zy, rz, fz);
@@ -513,7 +492,7 @@ static inline int pppm_split(int ns, int maxatoms) {
 void mdk_pppm_spread(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int zeroed, int maxgridp) {
   // maxgridp: the largest grid with five more points per x row (0: a grid of the batch has fewer than five points in x): the padded LDS copy
   static const bool padx_off = scema_env("SCEMA_MD_PPPM_PADX") && atoi(scema_env("SCEMA_MD_PPPM_PADX")) == 0;
-  const bool padx = maxgridp > 0 && !padx_off && (size_t)maxgridp * sizeof(double) <= 36 * 1024;
+  const bool padx = maxgridp > 0 && !padx_off && (size_t)maxgridp * sizeof(double) <= 36 * 1024;   // (7 / 19 kB of LDS for 12 x 12 x 12 points: no workgroup fewer)
   const size_t lds = (size_t)(padx ? maxgridp : maxgrid) * sizeof(double);
   const bool use_lds = lds <= mdk_pppm_lds_limit();
   const int split = pppm_split(ns, maxatoms);
@@ -548,10 +527,8 @@ void mdk_pppm_solve(hipStream_t st, const SimDev *d, int ns, int maxgrid, int ma
 }
 void mdk_pppm_gf(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_gf, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
 void mdk_pppm_poisson(hipStream_t st, const SimDev *d, int ns, int maxgrid) { hipLaunchKernelGGL(k_pppm_poisson, grid2(cdiv(maxgrid, 256), ns), dim3(256), 0, st, d); }
-void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields, int maxgridp) {
-  static const bool padx_off = scema_env("SCEMA_MD_PPPM_PADX") && atoi(scema_env("SCEMA_MD_PPPM_PADX")) == 0;
-  const bool padx = maxgridp > 0 && !padx_off && real_fields && 3 * (size_t)maxgridp * sizeof(double) <= mdk_pppm_lds_limit();
-  const size_t lds = 3 * (size_t)(padx ? maxgridp : maxgrid) * sizeof(double);
+void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int maxatoms, int add, int real_fields) {
+  const size_t lds = 3 * (size_t)maxgrid * sizeof(double);
   if (lds > mdk_pppm_lds_limit()) {
     hipLaunchKernelGGL((k_pppm_force<false, false>), grid2(cdiv(maxatoms, 256), ns), dim3(256), 0, st, d, cdiv(maxatoms, 256), add);
     return;
@@ -561,11 +538,9 @@ void mdk_pppm_force(hipStream_t st, const SimDev *d, int ns, int maxgrid, int ma
   if (lds > 64 * 1024 && lds > optin) {
     (void)hipFuncSetAttribute((const void *)k_pppm_force<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)k_pppm_force<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void *)k_pppm_force<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     optin = lds;
   }
   const int split = pppm_split(ns, maxatoms);
-  if (padx) hipLaunchKernelGGL((k_pppm_force<true, true, true>), grid2(split, ns), dim3(256), lds, st, d, split, add);
-  else if (real_fields) hipLaunchKernelGGL((k_pppm_force<true, true>), grid2(split, ns), dim3(256), lds, st, d, split, add);
+  if (real_fields) hipLaunchKernelGGL((k_pppm_force<true, true>), grid2(split, ns), dim3(256), lds, st, d, split, add);
   else hipLaunchKernelGGL((k_pppm_force<true, false>), grid2(split, ns), dim3(256), lds, st, d, split, add);
 }
