@@ -197,6 +197,16 @@ def cpu_baseline(cells, strains, nss, pppm=1):
                       f"kspace {tm['kspace']:.1f} s, neigh {tm['neigh']:.1f} s); CPU restatement (oracle/md_oracle.c), not LAMMPS"}
 
 
+def kernel_source_hashes():
+    """git blob hashes (sha1 of "blob <size>\\0" + content: what `git hash-object` prints) of the sources k_pair is compiled from"""
+    import hashlib
+    out = {}
+    for f in ("md_pair.hip", "md_pair_dev.h", "md_device.h", "md_types.h"):
+        data = open(os.path.join(ROOT, "scema_amd", "csrc", f), "rb").read()
+        out[f] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
 def count_gpus_without_hip():
     """GPUs of this node from the KFD topology in sysfs (nodes with SIMDs; CPUs have simd_count 0): the parent that forks the rank
     launcher must not have opened /dev/kfd, and torch.cuda.device_count() falls back to hipGetDeviceCount where amdsmi is absent."""
@@ -247,7 +257,7 @@ def _reax_leg_args(args):
     import copy
     r = copy.copy(args)
     r.force_field, r.sims, r.cells, r.nss, r.equil_steps = "reax", 72, [3, 5, 9], 20, 200
-    r.steps, r.warmup, r.monotonic_updates, r.monotonic, r.strain_set, r.equil_cache = 4, 2, 0, False, "balanced", None
+    r.steps, r.warmup, r.monotonic_updates, r.monotonic, r.strain_set, r.equil_cache, r.share8_updates = 4, 2, 0, False, "balanced", None, 0
     return r
 
 
@@ -535,6 +545,39 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
             tm = float(t.item())
         mono_rate = n * args.monotonic_updates / tm
 
+    # The 8-GPU operating point on THIS GPU (SCALE is skipped on pools without an 8-GPU node): the share rank 0 of 8
+    # gets of the same requests -- quadrature points i % 8 == 0 (stmd_sync.h:583), 72 of 576 -- continued from the states the loop left,
+    # one warm-up and three timed updates; never part of `value`.  projected_8gpu_x = 8 x that rate / value (the stress all-gather of 27 kB
+    # and the 16-byte handshake are microseconds against 170 ms of MD).
+    share8 = None
+    if world == 1 and n >= 64 and n % 8 == 0 and args.share8_updates > 0 and not args.monotonic:
+        import ctypes
+        mono["on"] = False
+        idx = np.arange(0, n, 8)
+        base = args.warmup + args.steps + 2 + (args.monotonic_updates if mono_rate else 0)
+        def share_update(k):
+            full = requests(base + k)
+            sub = (capi.MDSim * len(idx))()
+            for j, i in enumerate(idx):
+                ctypes.memmove(ctypes.byref(sub[j]), ctypes.byref(full[int(i)]), ctypes.sizeof(capi.MDSim))
+            out8 = eng.strain_batch(sub, rank=0, world=1)
+            assert all(a.stress_updated for a in out8)
+        share_update(0)
+        fence()
+        ts0 = time.perf_counter()
+        for k in range(args.share8_updates):
+            share_update(1 + k)
+        fence()
+        ts = time.perf_counter() - ts0
+        share8 = {"sims": int(len(idx)), "updates": args.share8_updates, "evals_per_s": len(idx) * args.share8_updates / ts, "ms_per_update": 1e3 * ts / args.share8_updates}
+    # calibration of the box (the boxes of a pool differ by 4-6 % under this FP64 load): its FP64 FMA ceiling, measured now (0.2 s)
+    box_tflops = None
+    if rank == 0:
+        try:
+            box_tflops = capi.box_fp64_tflops(device)
+        except Exception as exc:   # (an A/B library of an older tree has no such entry)
+            print("bench.py: no box calibration:", exc, file=sys.stderr)
+
     # N > 1: what every rank did in the timed loop (its own clock), so that a scaling line explains itself
     per_rank_stats = None
     if world > 1:
@@ -548,10 +591,18 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         per_rank = int(cap)
         # PMC figures cannot be collected inside a timed run: tools/pmc_pair.sh measures them per replica-step on the same
         # kernel (separate rocprofv3 --pmc passes; gfx950 x2 correction on FETCH_SIZE) and commits profiles/pair_pmc.json
-        pmc = None
+        pmc, pmc_stale = None, None
         ppath = os.path.join(ROOT, "profiles", "pair_pmc.json")
         if os.path.exists(ppath) and natoms == 10368:
             pmc = json.load(open(ppath))
+            # the counters belong to ONE build of the kernel: the file records the git blob hashes of its sources, and a tree whose
+            # sources differ gets no instruction-issue figure (null + this note) instead of an old count under a new time
+            have = kernel_source_hashes()
+            if pmc.get("kernel_sources") != have:
+                pmc_stale = {"recorded": pmc.get("kernel_sources"), "tree": have}
+                print("bench.py: profiles/pair_pmc.json was taken on other sources of k_pair (re-run tools/pmc_pair.sh): frac_valu_issue and traffic are null",
+                      file=sys.stderr)
+                pmc = None
         value = n * args.steps / elapsed
         # ---- the roofline record of k_pair (schema 2, round 5; every figure reproduces from a table under profiles/) ----
         # The kernel is bound by vector-instruction ISSUE, not by HBM: `bound`, `achieved`, `peak`, `frac` describe THAT
@@ -576,16 +627,24 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
         peak_issue = nsimd * clk / cyc / 1e9                         # G wave-instructions/s the chip can issue at 4 cycles each
         insts_per_sim_step = pmc["valu_insts_per_sim_step"] if pmc else None
         pairs_per_sim_step = 0.5 * (w_full - prof_alone["pair_sims"] * (56.0 * natoms + 48.0)) / 4.0 / max(prof_alone["pair_sims"], 1)   # listed pairs (inside cutoff + skin)
-        roof = {"schema": 2, "bound": "fp64_valu", "unit": "G wave-instr/s", "peak": peak_issue,
-                "achieved": (insts_per_sim_step * w_sims / w_avg / 1e9) if insts_per_sim_step and w_avg > 0 else None,
-                "frac": (insts_per_sim_step * w_sims / w_avg / 1e9 / peak_issue) if insts_per_sim_step and w_avg > 0 else None,
+        frac_issue = (insts_per_sim_step * w_sims / w_avg / 1e9 / peak_issue) if insts_per_sim_step and w_avg > 0 else None
+        # schema 3 (round 6): the top-level achieved / peak / frac are the SURVEY 8(d) byte figures against 8 TB/s -- the yardstick
+        # north_star names --; the bound that actually binds the kernel (vector-instruction issue) stands beside them as frac_valu_issue
+        roof = {"schema": 3, "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                "achieved": w_stored / w_s / 1e9 if w_s > 0 else None,
+                "frac": w_stored / w_s / 1e9 / 8000.0 if w_s > 0 else None,
+                "frac_of": "hbm: SURVEY 8(d) bytes of the list the kernel stores (each pair once) / chip-exclusive launch time / 8 TB/s",
+                "binding_bound": "fp64_valu_issue",
+                "frac_valu_issue": frac_issue,
+                "valu_issue_achieved_ginstr_s": (insts_per_sim_step * w_sims / w_avg / 1e9) if insts_per_sim_step and w_avg > 0 else None,
+                "valu_issue_peak_ginstr_s": peak_issue,
                 "frac_hbm": w_stored / w_s / 1e9 / 8000.0 if w_s > 0 else None,
                 "frac_hbm_full_list": w_full / w_s / 1e9 / 8000.0 if w_s > 0 else None,
                 "whole_avg_launch_ms": 1e3 * w_avg, "whole_launches": prof_alone["pair_launches"], "whole_sims_per_launch": w_sims,
                 "whole_alg_bytes_per_launch": w_stored / w_launches, "whole_hbm_gbps": w_stored / w_s / 1e9 if w_s > 0 else None,
                 # 55 flop per pair inside the LJ cutoff (4.876 M of the ~7.7 M listed pairs of a PE-10k replica-step) over the FP64 vector peak
                 "useful_flop_frac": (55.0 * 4.876e6 / 7.725e6 * pairs_per_sim_step * w_sims / w_avg / 78.6e12) if w_avg > 0 else None,
-                "traffic": None, "traffic_source": None,
+                "traffic": None, "traffic_source": None, "pmc_stale": pmc_stale,
                 "timed_avg_launch_ms": 1e3 * pair_s / launches, "timed_launches": prof["pair_launches"], "timed_sims_per_launch": prof["pair_sims"] / launches,
                 "avg_launch_ms": 1e3 * pair_s / launches, "launches": prof["pair_launches"], "sims_per_launch": prof["pair_sims"] / launches,   # (names of schema 1: the timed region)
                 "timed_launches_in_flight": in_flight,
@@ -593,12 +652,15 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                 "frac_hbm_timed_per_launch": stored / pair_s / 1e9 / 8000.0 if pair_s > 0 else None,
                 "rank0_pair_share_of_wall": union_s / elapsed,
                 "kernel": "k_pair (lj/cut/coul/long force+virial; every pair once, 4-atom cluster rows, LDS reaction-force tiles)",
-                "accounting": "bound = vector-instruction issue: frac = SQ_INSTS_VALU of a launch (profiles/pair_pmc.json, per replica-step x replicas per launch) / "
-                              "whole_avg_launch_ms / (1 024 SIMDs x 2.4 GHz / 4 cycles per wave instruction).  whole_* = two updates after the timed region with the "
-                              "batch as ONE sequence of launches (scema_md_batch_split(0)): HIP-event time per launch with the chip to itself -- what a rocprofv3 "
-                              "kernel table of a SCEMA_MD_SPLIT=0 run shows.  frac_hbm = SURVEY 8(d) bytes of the stored list (each pair once) / that time / 8 TB/s.  "
-                              "timed_* = the timed region, where the batch runs as two half batches on two streams: launches overlap, so a per-launch event "
-                              "interval is not a chip-exclusive time; frac_hbm_timed_union = bytes / time with at least one pair launch running"}
+                "accounting": "achieved = SURVEY 8(d) algorithmic bytes of a launch -- sum over its replicas of N (4 nbar_stored + 56) + 48, nbar_stored = listed pairs "
+                              "per atom with each pair stored once, counted by the exact list build of every run -- / whole_avg_launch_ms; peak 8 TB/s; frac = "
+                              "achieved / peak (= frac_hbm).  The kernel is NOT bound by HBM but by vector-instruction issue (DESIGN.md 4, 5.3): frac_valu_issue = "
+                              "SQ_INSTS_VALU of a launch (profiles/pair_pmc.json, per replica-step x replicas per launch; null when that file was taken on other "
+                              "sources of the kernel) / whole_avg_launch_ms / (1 024 SIMDs x 2.4 GHz / 4 cycles per wave instruction).  whole_* = two updates after "
+                              "the timed region with the batch as ONE sequence of launches (scema_md_batch_split(0)): HIP-event time per launch with the chip to "
+                              "itself -- what a rocprofv3 kernel table of a SCEMA_MD_SPLIT=0 run shows.  timed_* = the timed region, where the batch runs as two "
+                              "half batches on two streams: launches overlap, so a per-launch event interval is not a chip-exclusive time; frac_hbm_timed_union = "
+                              "bytes / time with at least one pair launch running"}
         if pmc:
             roof["traffic"] = pmc["hbm_bytes_per_sim_step_corrected"] * w_sims
             roof["traffic_source"] = pmc.get("source", "profiles/pair_pmc.json")
@@ -643,6 +705,11 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                                "a pure stream)") if prof.get("rx_sweep_symmetric") else
                               "k_rx_qeq_sweep (charge equilibration: y = H z for both conjugate-gradient systems, one pass over the stored matrix rows)",
                     "symmetric": bool(prof.get("rx_sweep_symmetric")),
+                    # the stored entry: the upper 48 bits of the FP64 value (rounded to nearest, <= 2^-37 relative = 7e-12, five orders under the
+                    # solver's 1e-6) + a 16-bit column in one 64-bit word -- narrower storage than the reference's FP64 matrix, said here
+                    "matrix_entry_bits": 48 if int(prof["rx_sweep_col_bytes"]) == 0 else 64,
+                    "frac_clock": "HIP events around every sweep launch on its stream (includes the launch-to-launch gap the event pair sees: 13-30 % above "
+                                  "a rocprofv3 kernel duration at these 40-50 us launches; the conservative reading)",
                     "accounting": f"bytes = ({8 + int(prof['rx_sweep_col_bytes'])} B x stored matrix entries + 84 B x rows, summed over the replicas and sweeps that took part, counted on the "
                                   "device) / HIP-event time of the kernel's launches (launches that find every replica converged cost time and move nothing); traffic = counter "
                                   "bytes of ONE sweep over the whole batch (profiles/reax_pmc.json).  whole_* / frac: the batch as one sequence of launches on one stream "
@@ -660,6 +727,11 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
             "metric": "stress_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "replica_steps_per_s": value * (nts_mean + args.nss),
+            "box_fp64_tflops": box_tflops,
+            "share8_evals_per_s": share8["evals_per_s"] if share8 else None,
+            "projected_8gpu_x": (8.0 * share8["evals_per_s"] / value) if share8 and value > 0 else None,
+            "rccl_fallback": bool(collective and "RCCL attach failed" in collective),
             "config": {"workload": workload, "force_field": args.force_field,
                        "strain_set": args.strain_set + (" (monotonic)" if args.monotonic else " (load/unload: odd updates take the draw with the opposite sign)"),
                        "strain_set_monotonic_evals_per_s": mono_rate, "strain_set_monotonic_updates": args.monotonic_updates if mono_rate else 0,
@@ -668,6 +740,8 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
                        "sims_on_rank0": int((owner == 0).sum()), "collective": collective,
                        "allgathers": comm["allgathers"], "handshakes": comm["handshakes"], "state_migrations": comm["migrations"],
                        "stress_zz_checksum_Pa": checksum_timed,
+                       "share_of_8": (dict(share8, note="quadrature points i % 8 == 0 of the same requests (rank 0's share on 8 GPUs, stmd_sync.h:583), continued from the "
+                                                        "states of the timed loop on this one GPU; outside `value`") if share8 else None),
                        "list_skin_A": prof.get("list_skin_mean", 0.0),
                        "steps_per_list_rebuild": prof["md_steps"] / max(prof["neigh_builds"], 1)},
             "roofline": roof,
@@ -705,6 +779,8 @@ def main():
                     help="opls: the headline workload (576 x PE-10k); reax: BASELINE config 5, 72 x PE-1620 ReaxFF replicas (--sims / --cells / --nss default to that)")
     ap.add_argument("--monotonic-updates", type=int, default=4, help="after the timed loop, this many all-tensile updates (the SURVEY 8(d) set as written) are "
                     "timed as well and reported as config.strain_set_monotonic_evals_per_s (0: skip; never part of `value`)")
+    ap.add_argument("--share8-updates", type=int, default=3, help="after the timed loop (one GPU, batches of 64 and more): this many updates of the share rank 0 of 8 "
+                    "would run (requests i %% 8 == 0) -> share8_evals_per_s, projected_8gpu_x (0: skip; never part of `value`)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI inside the engine (default); gloo = the engine's host transport over gloo (tests)")
     ap.add_argument("--dry-run-ranks", type=int, default=0, help="N: run the control plane of --gpus N (rank spawn, rendezvous, id exchange, planner, "

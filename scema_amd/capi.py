@@ -36,7 +36,7 @@ SYMBOLS = [
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_comm_handshakes", "scema_md_state_owner", "scema_md_last_plan",
     "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update", "scema_md_kspace_setup",
     "scema_md_save_state_dump", "scema_md_replica_natoms", "scema_md_save_replica_file", "scema_md_equilibrate", "scema_md_debug_minimize", "scema_md_debug_run_nh",
-    "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_concurrency", "scema_md_batch_split", "scema_md_get_concurrency", "scema_md_unsettled_updates", "scema_md_reax_debug_compute", "scema_md_reax_stats",
+    "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_concurrency", "scema_md_batch_split", "scema_md_get_concurrency", "scema_md_unsettled_updates", "scema_md_reax_debug_compute", "scema_md_reax_stats", "scema_md_box_fma_tflops",
 ]
 COMM_ID_BYTES = 128
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -491,6 +491,16 @@ def env_overrides() -> list:
     lib().scema_md_env_overrides.restype = C.c_int
     n = lib().scema_md_env_overrides(buf, C.c_int(len(buf)))
     return [l for l in buf.value.decode().split("\n") if l] if n else []
+
+
+def box_fp64_tflops(device: int = 0) -> float:
+    """FP64 FMA ceiling of the device as measured now (scema_md_box_fma_tflops): the calibration bench.py prints beside its rates"""
+    out = C.c_double(0.0)
+    lib().scema_md_box_fma_tflops.restype = C.c_int
+    rc = lib().scema_md_box_fma_tflops(C.c_int32(device), C.byref(out))
+    if rc:
+        raise EngineError(f"scema_md_box_fma_tflops failed with code {rc} (no HIP device?)")
+    return float(out.value)
 
 
 def kspace_setup(params, box, qsqsum: float, natoms: int):

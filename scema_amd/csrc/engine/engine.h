@@ -25,6 +25,7 @@
 #include <cstring>
 #include <ctime>
 #include <array>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -115,7 +116,12 @@ struct SysCopy {
   }
 };
 
+// Identity of a State / Topo object for the list signatures (ListSig): a number no other object of the process ever gets.  (Until round 6 the
+// signatures held raw pointers: states are erased and re-created every update -- migration, branching, undo -- and a new object can land
+// on a freed address, where the device's displacement test was the only guard left: ADVICE r5.)
+inline unsigned long long next_object_id() { static std::atomic<unsigned long long> n{0}; return ++n; }
 struct Topo {
+  const unsigned long long id = next_object_id();
   int natoms = 0, ntypes = 0;
   SysCopy original;
   std::vector<int> type;
@@ -133,6 +139,7 @@ struct Topo {
 };
 
 struct State {
+  const unsigned long long id = next_object_id();
   Topo *topo = nullptr;
   double box[9];
   DevBuf x, v;
@@ -159,8 +166,8 @@ struct RxSlot {
 // what the neighbour rows of a slot were built for: a run that follows on the same slot keeps them if all of it still holds
 struct ListSig {
   bool valid = false;
-  const void *topo = nullptr;
-  const void *state = nullptr;   // the state the rows were last built for (a hint: whether they still hold is decided on the device)
+  unsigned long long topo = 0;    // Topo::id the rows were built for
+  unsigned long long state = 0;   // State::id the rows were last built for (a hint: whether they still hold is decided on the device)
   int nc[3] = {0, 0, 0}, capj = 0, maxneigh = 0, npad = 0;
   double rlist = 0.0, cut_lj = 0.0, cut_coul = 0.0;
   // the list's scalars at the end of the run that left it: what the displacement test of the next run needs, and the statistics
@@ -217,6 +224,10 @@ struct Comm {
   void *ctx = nullptr;
   DevBuf d_gather, d_box, d_word;
   std::vector<double> h_gather;
+  // the exchange of states of the current update, resolved before the handshake (prepare_incoming): per move of the plan the source
+  // state this rank sends / the state it receives into (else null), and the boxes that travel beside x and v
+  std::vector<State *> mig_src, mig_dst;
+  std::vector<double> h_box;
   long long migrations = 0, allgathers = 0, handshakes = 0;
 };
 
@@ -292,6 +303,7 @@ struct scema_md_engine {
   int split_min = 32, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
                                          // at 576 and left large groups whole; with round 4's kernels the halves give 437 against 429, profiles/r04_zs_*)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_nb_fork = nullptr, ev_nb_join = nullptr;   // main stream -> stream3 -> main stream around the list kernels of a small launch group (run_phase: nb_side)
   bool rx_precond = true;                 // bonded-pattern sparse approximate inverse as the preconditioner of the charge equilibration (SCEMA_REAX_QEQ_PRECOND=0: the reference's Jacobi one)
   int rx_halves = 2, rx_overlap = 1;      // scema_md_reax_concurrency: part batches (1 = one sequence of launches) and side streams (initial values from SCEMA_REAX_HALVES / SCEMA_REAX_OVERLAP)
   // ReaxFF runs as rx_halves part batches on as many streams (part 0: stream + stream2), each with a side stream for its bond-order chain and
@@ -402,9 +414,9 @@ int resolve_state(scema_md_engine *e, const scema_mdsim &m, State **out, std::un
 // engine_batch.cpp
 int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt &opt = EvalOpt(), size_t pool_off = 0);
 // engine_comm.cpp
-int prepare_incoming(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, std::map<int, std::unique_ptr<State>> &incoming);
-int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, const std::vector<std::string> &src_keys,
-                   std::map<int, std::unique_ptr<State>> &incoming);
+int prepare_incoming(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, const std::vector<std::string> &src_keys,
+                     std::map<int, std::unique_ptr<State>> &incoming);
+int migrate_states(scema_md_engine *e, const scema::SimPlan &plan);
 double plan_hash(const scema::SimPlan &P, const std::vector<double> &cost);
 int check_gathered_trailers(scema_md_engine *e, const double *gathered, size_t stride, size_t off, int world, int rank, const char *when);
 int handshake(scema_md_engine *e, int local_status, double hash);

@@ -272,6 +272,13 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     ~ReaxScope() { e->reax_active = saved; }
   } reax_scope(e, n_reax > 0);
   e->last_plan = e->dir.plan(src_keys, dst_keys, cost, world);
+  if (e->comm.kind == 1 && world == 1 && !hooke_mode && scema_env("SCEMA_MD_TEST_SELF_MOVE")) {
+    // test hook: with one rank no state ever changes GPU, so ncclSend / ncclRecv would never run on a one-GPU box.  Every simulation
+    // that continues from a state held here gets a move from this rank to itself: the state travels through the RCCL group of
+    // migrate_states like any other and the simulation continues from the received copy (results do not change)
+    for (int i = 0; i < n_sims; i++)
+      if (!src_keys[i].empty() && e->states.count(src_keys[i])) e->last_plan.moves.push_back({i, rank, rank});
+  }
   const scema::SimPlan &plan = e->last_plan;
   const int per_rank = plan.cap;
   const double hash = plan_hash(plan, cost);
@@ -291,14 +298,12 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
     (void)hipStreamSynchronize(e->stream);
     return st;
   };
-  // a source state this rank is recorded to own but does not hold: found before any rank posts a receive for it
-  for (const scema::PlanMove &m : plan.moves)
-    if (m.from == rank && !pre_status && !e->states.count(src_keys[m.sim]))
-      pre_status = fail(e, SCEMA_MD_ERR_NOSTATE, "rank %d is recorded as the owner of state %s but does not hold it", rank, src_keys[m.sim].c_str());
-  // the states that migrate to this rank are allocated BEFORE the handshake: a rank that cannot take them says so in its status word
-  // instead of leaving the sending rank inside the exchange
+  // Everything the exchange of states needs on this rank is made BEFORE the handshake (prepare_incoming): the source states it is
+  // recorded to own are looked up (one it does not hold is found before any rank posts a receive for it), the states that migrate to it
+  // are allocated, the boxes that travel beside them are on the device -- a rank that cannot do its part says so in its status word
+  // instead of leaving its peers inside the exchange
   std::map<int, std::unique_ptr<State>> incoming;
-  if (collective && !hooke_mode && !pre_status) pre_status = prepare_incoming(e, sims, plan, incoming);
+  if (collective && !hooke_mode && !pre_status) pre_status = prepare_incoming(e, sims, plan, src_keys, incoming);
   if (collective) {
     const int rc = handshake(e, pre_status, hash);
     if (rc) return rc;
@@ -313,9 +318,9 @@ int scema_md_strain_batch(scema_md_engine *e, scema_mdsim *sims, int32_t n_sims,
                           "attach a communicator (scema_md_comm_init_rccl / scema_md_comm_init_host) so that states can move between GPUs",
                           src_keys[m.sim].c_str(), sims[m.sim].qp_id, m.from, m.to));
     }
-    if (!collective) status = prepare_incoming(e, sims, plan, incoming);   // (a communicator with world 1 plans no moves; kept for symmetry)
+    if (!collective) status = prepare_incoming(e, sims, plan, src_keys, incoming);   // (a communicator with world 1 plans no moves of its own: the self-move test hook)
     // an error of the exchange becomes this rank's status: it still enters the stress all-gather, where every rank learns of it
-    if (!status) status = migrate_states(e, sims, plan, src_keys, incoming);
+    if (!status) status = migrate_states(e, plan);
   }
   // ---- this rank's share ----
   std::vector<ActiveSim> act;

@@ -11,17 +11,54 @@ namespace scema_eng {
 // the update.  RCCL: one group of point-to-point sends/receives over xGMI on the engine's stream; host transport: the
 // moves in plan order, blocking send/recv pairs (every rank walks the same list, so the pairs cannot cross).
 //
-// Everything that can fail on ONE rank alone happens before the handshake (prepare_incoming: the receiving rank's allocations;
-// scema_md_strain_batch: the source states a rank must hold), where its status word ends the call on every rank.  What is left
-// here runs after the ranks agreed to exchange, so a rank that meets an error keeps to the protocol: the RCCL group it opened is
-// ended whatever happened inside it, the host transport still posts every send and receive of its moves, and the error is
-// RETURNED for the status word of the stress all-gather -- the other ranks are never left inside a collective this rank skipped.
+// An update is TWO collectives: the 16-byte agreement handshake and the stress all-gather (with the exchange of states between
+// them where the plan has moves).  Everything that can fail on ONE rank alone happens before the handshake, in prepare_incoming:
+// the receiving rank's allocations, the look-up of every source state this rank must hold, the device buffer of the boxes that
+// travel beside x and v and its upload -- a failure there is the rank's status word in the handshake and ends the call on every
+// rank before anything is posted.  migrate_states runs after the ranks agreed to exchange and works on what prepare_incoming
+// resolved (pointers, no look-ups, no allocations): no path returns between the agreement and the end of the exchange.  A call
+// that fails inside the RCCL group does not stop the queueing -- every remaining send and receive of this rank is still posted,
+// so every operation a peer has posted finds its partner --, the group is ended whatever happened inside it, the host transport
+// posts every send and receive of its moves, and the error is RETURNED for the status word of the stress all-gather: the other
+// ranks are never left inside a collective this rank skipped.
 constexpr int MIG_SIDE = 10;   // doubles that travel next to x and v of a migrating state: box[9], State::skin_extra
 
-// the states this rank receives, allocated (before the handshake: a failure here must travel in its status word)
-int prepare_incoming(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, std::map<int, std::unique_ptr<State>> &incoming) {
-  const int rank = e->comm.rank;
-  for (const scema::PlanMove &m : plan.moves) {
+// test hook SCEMA_MD_TEST_FAIL_MIGRATE = "<what>[:<rank>]" (rank omitted or negative: every rank): what = dbox (the device buffer of
+// the boxes cannot be allocated: before the handshake), upload (its host-to-device copy fails: before the handshake), enqueue (the
+// first point-to-point call of the exchange reports a failure -- it is posted all the same, as a call that failed AFTER being
+// queued would be, so that the peers can finish --), group (ncclGroupEnd reports a failure), hostcopy (the first device copy of
+// the host transport fails)
+static bool inject_migrate_failure(const char *what, int rank) {
+  const char *v = scema_env("SCEMA_MD_TEST_FAIL_MIGRATE");
+  if (!v) return false;
+  const size_t n = std::strlen(what);
+  if (std::strncmp(v, what, n) != 0 || (v[n] != 0 && v[n] != ':')) return false;
+  if (v[n] == 0) return true;
+  const int r = atoi(v + n + 1);
+  return r < 0 || r == rank;
+}
+
+// what this rank needs for the exchange, made (and checked) before the handshake: a failure here must travel in its status word
+int prepare_incoming(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, const std::vector<std::string> &src_keys,
+                     std::map<int, std::unique_ptr<State>> &incoming) {
+  Comm &c = e->comm;
+  const int rank = c.rank;
+  const int nm = (int)plan.moves.size();
+  c.mig_src.assign(nm, nullptr);
+  c.mig_dst.assign(nm, nullptr);
+  c.h_box.assign(MIG_SIDE * (size_t)nm, 0.0);   // box[9] + the state's list skin (State::skin_extra)
+  if (c.kind == 2 && nm > 0 && (!c.send || !c.recv))
+    return fail(e, SCEMA_MD_ERR_ARG, "the host communicator has no send/recv callbacks: replica states cannot move between ranks");
+  for (int k = 0; k < nm; k++) {
+    const scema::PlanMove &m = plan.moves[k];
+    if (m.from == rank) {
+      auto it = e->states.find(src_keys[m.sim]);
+      if (it == e->states.end())
+        return fail(e, SCEMA_MD_ERR_NOSTATE, "rank %d is recorded as the owner of state %s but does not hold it", rank, src_keys[m.sim].c_str());
+      c.mig_src[k] = it->second.get();
+      std::memcpy(&c.h_box[MIG_SIDE * (size_t)k], c.mig_src[k]->box, 9 * sizeof(double));
+      c.h_box[MIG_SIDE * (size_t)k + 9] = c.mig_src[k]->skin_extra;
+    }
     if (m.to != rank) continue;
     Topo *t = find_topo(e, sims[m.sim].matid, sims[m.sim].replica);
     if (!t) return fail(e, SCEMA_MD_ERR_NOSTATE, "replica %s_%d is not registered on rank %d", sims[m.sim].matid, sims[m.sim].replica, rank);
@@ -31,77 +68,91 @@ int prepare_incoming(scema_md_engine *e, const scema_mdsim *sims, const scema::S
       (void)hipGetLastError();   // (the allocation's error is reported, not left for the next launch to find)
       return fail(e, rc, "out of device memory for a replica state that migrates to rank %d", rank);
     }
+    c.mig_dst[k] = incoming[m.sim].get();
+  }
+  if (c.kind == 1 && nm > 0) {
+    // the boxes travel through a device buffer: allocated and filled here, where a failure still reaches every rank
+    hipError_t rc = inject_migrate_failure("dbox", rank) ? hipErrorOutOfMemory : c.d_box.ensure(2 * c.h_box.size() * sizeof(double));   // (second half: where a state sent to this very rank receives its box)
+    if (rc != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e, SCEMA_MD_ERR_DEVICE, "out of device memory for the boxes of the replica states that migrate (rank %d): %s", rank, hipGetErrorString(rc));
+    }
+    rc = inject_migrate_failure("upload", rank) ? hipErrorInvalidValue : hipMemcpyAsync(c.d_box.p, c.h_box.data(), c.h_box.size() * sizeof(double), hipMemcpyHostToDevice, e->stream);
+    if (rc != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e, SCEMA_MD_ERR_DEVICE, "upload of the boxes of the replica states that migrate failed on rank %d: %s", rank, hipGetErrorString(rc));
+    }
   }
   return SCEMA_MD_OK;
 }
 
-int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::SimPlan &plan, const std::vector<std::string> &src_keys,
-                   std::map<int, std::unique_ptr<State>> &incoming) {
+int migrate_states(scema_md_engine *e, const scema::SimPlan &plan) {
   Comm &c = e->comm;
   const int nm = (int)plan.moves.size();
-  std::vector<double> hbox(MIG_SIDE * (size_t)nm, 0.0);   // box[9] + the state's list skin (State::skin_extra)
-  std::vector<State *> src(nm, nullptr);
-  for (int k = 0; k < nm; k++) {
-    const scema::PlanMove &m = plan.moves[k];
-    if (c.rank == m.from) {
-      auto it = e->states.find(src_keys[m.sim]);   // (held: scema_md_strain_batch looked before the handshake)
-      if (it == e->states.end())
-        return fail(e, SCEMA_MD_ERR_NOSTATE, "rank %d is recorded as the owner of state %s but does not hold it", c.rank, src_keys[m.sim].c_str());
-      src[k] = it->second.get();
-      std::memcpy(&hbox[MIG_SIDE * (size_t)k], src[k]->box, 9 * sizeof(double));
-      hbox[MIG_SIDE * (size_t)k + 9] = src[k]->skin_extra;
-    }
-    if (c.rank == m.to && !incoming.count(m.sim))
-      return fail(e, SCEMA_MD_ERR_ARG, "internal: no state was prepared for the one simulation %d receives from rank %d", m.sim, m.from);
-  }
   int err = SCEMA_MD_OK;
+  if ((int)c.mig_src.size() != nm || (int)c.mig_dst.size() != nm)   // (prepare_incoming ran for this plan: a broken call order is a bug of the library, found on every rank alike)
+    return fail(e, SCEMA_MD_ERR_ARG, "internal: the exchange of replica states was not prepared for this plan");
   if (c.kind == 1) {
-    HIPCHK(c.d_box.ensure(hbox.size() * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(c.d_box.p, hbox.data(), hbox.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    NCCLCHK(ncclGroupStart());
-    // inside the group nothing returns: a failing call ends the queueing, the group is ended all the same
+    bool first = true;
+    // inside the group nothing returns and nothing stops the queueing: a failing call is noted, the rest is posted all the same
     auto q = [&](ncclResult_t r, const char *what, int peer) {
+      if (first && inject_migrate_failure("enqueue", c.rank)) r = ncclInternalError;
+      first = false;
       if (r != ncclSuccess && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "%s with rank %d failed while replica states migrate: %s", what, peer, ncclGetErrorString(r));
-      return r == ncclSuccess;
     };
-    for (int k = 0; k < nm && !err; k++) {
+    ncclResult_t gs = ncclGroupStart();
+    if (gs != ncclSuccess) err = fail(e, SCEMA_MD_ERR_DEVICE, "ncclGroupStart failed while replica states migrate: %s", ncclGetErrorString(gs));
+    for (int k = 0; k < nm; k++) {
       const scema::PlanMove &m = plan.moves[k];
       double *dbox = c.d_box.as<double>() + MIG_SIDE * (size_t)k;
-      if (c.rank == m.from) {
-        const size_t cnt = 3 * (size_t)src[k]->topo->natoms;
-        (void)(q(ncclSend(src[k]->x.p, cnt, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to) &&
-               q(ncclSend(src[k]->v.p, cnt, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to) &&
-               q(ncclSend(dbox, MIG_SIDE, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to));
+      if (c.rank == m.from && c.mig_src[k]) {
+        State *s = c.mig_src[k];
+        const size_t cnt = 3 * (size_t)s->topo->natoms;
+        q(ncclSend(s->x.p, cnt, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to);
+        q(ncclSend(s->v.p, cnt, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to);
+        q(ncclSend(dbox, MIG_SIDE, ncclDouble, m.to, c.nccl, e->stream), "ncclSend", m.to);
       }
-      if (c.rank == m.to && !err) {
-        State *d = incoming[m.sim].get();
+      if (c.rank == m.to && c.mig_dst[k]) {
+        State *d = c.mig_dst[k];
         const size_t cnt = 3 * (size_t)d->topo->natoms;
-        (void)(q(ncclRecv(d->x.p, cnt, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from) &&
-               q(ncclRecv(d->v.p, cnt, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from) &&
-               q(ncclRecv(dbox, MIG_SIDE, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from));
+        // (a state sent to this very rank -- the one-rank test of these calls -- receives its box behind the sent ones)
+        double *rbox = (m.from == m.to) ? c.d_box.as<double>() + MIG_SIDE * (size_t)(nm + k) : dbox;
+        q(ncclRecv(d->x.p, cnt, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from);
+        q(ncclRecv(d->v.p, cnt, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from);
+        q(ncclRecv(rbox, MIG_SIDE, ncclDouble, m.from, c.nccl, e->stream), "ncclRecv", m.from);
       }
     }
-    const ncclResult_t ge = ncclGroupEnd();
-    if (ge != ncclSuccess && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "ncclGroupEnd failed while replica states migrate: %s", ncclGetErrorString(ge));
+    if (gs == ncclSuccess) {
+      ncclResult_t ge = ncclGroupEnd();
+      if (inject_migrate_failure("group", c.rank)) ge = ncclInternalError;
+      if (ge != ncclSuccess && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "ncclGroupEnd failed while replica states migrate: %s", ncclGetErrorString(ge));
+    }
+    // (from here on the exchange is over for the peers: what fails now is this rank's own business and travels in its status word)
     if (err) return err;
-    HIPCHK(hipMemcpyAsync(hbox.data(), c.d_box.p, hbox.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    std::vector<double> hb(2 * c.h_box.size(), 0.0);
+    HIPCHK(hipMemcpyAsync(hb.data(), c.d_box.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int k = 0; k < nm; k++)
-      if (c.rank == plan.moves[k].to) {
-        std::memcpy(incoming[plan.moves[k].sim]->box, &hbox[MIG_SIDE * (size_t)k], 9 * sizeof(double));
-        incoming[plan.moves[k].sim]->skin_extra = hbox[MIG_SIDE * (size_t)k + 9];
+      if (c.rank == plan.moves[k].to && c.mig_dst[k]) {
+        const double *b = &hb[MIG_SIDE * (size_t)(plan.moves[k].from == plan.moves[k].to ? nm + k : k)];
+        std::memcpy(c.mig_dst[k]->box, b, 9 * sizeof(double));
+        c.mig_dst[k]->skin_extra = b[9];
       }
   } else {
-    if (!c.send || !c.recv) return fail(e, SCEMA_MD_ERR_ARG, "the host communicator has no send/recv callbacks: replica states cannot move between ranks");
+    // (the callbacks are checked when the communicator is attached and again before the handshake, scema_md_strain_batch)
     // a device copy that fails does not stop the walk: the peer of every move is waiting in its own send or receive
+    bool first = true;
     auto dev = [&](hipError_t r, const char *what) {
+      if (first && inject_migrate_failure("hostcopy", c.rank)) r = hipErrorInvalidValue;
+      first = false;
       if (r != hipSuccess && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "%s failed while replica states migrate: %s", what, hipGetErrorString(r));
     };
     std::vector<double> buf;
     for (int k = 0; k < nm; k++) {
       const scema::PlanMove &m = plan.moves[k];
       if (c.rank != m.from && c.rank != m.to) continue;
-      State *st = (c.rank == m.from) ? src[k] : incoming[m.sim].get();
+      State *st = (c.rank == m.from) ? c.mig_src[k] : c.mig_dst[k];
+      if (!st) continue;
       const size_t n3 = 3 * (size_t)st->topo->natoms;
       buf.assign(2 * n3 + MIG_SIDE, 0.0);
       if (c.rank == m.from) {
@@ -110,9 +161,9 @@ int migrate_states(scema_md_engine *e, const scema_mdsim *sims, const scema::Sim
         dev(hipStreamSynchronize(e->stream), "copy of a state to the host");
         std::memcpy(buf.data() + 2 * n3, st->box, 9 * sizeof(double));
         buf[2 * n3 + 9] = st->skin_extra;
-        if (c.send(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.to) && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "host send of a replica state to rank %d failed", m.to);
+        if ((!c.send || c.send(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.to)) && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "host send of a replica state to rank %d failed", m.to);
       } else {
-        if (c.recv(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.from) && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "host receive of a replica state from rank %d failed", m.from);
+        if ((!c.recv || c.recv(c.ctx, buf.data(), (int64_t)(buf.size() * 8), m.from)) && !err) err = fail(e, SCEMA_MD_ERR_DEVICE, "host receive of a replica state from rank %d failed", m.from);
         dev(hipMemcpyAsync(st->x.p, buf.data(), n3 * 8, hipMemcpyHostToDevice, e->stream), "copy of a state to the device");
         dev(hipMemcpyAsync(st->v.p, buf.data() + n3, n3 * 8, hipMemcpyHostToDevice, e->stream), "copy of a state to the device");
         dev(hipStreamSynchronize(e->stream), "copy of a state to the device");

@@ -48,14 +48,22 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_SPLIT_MAX", "launch groups of this many replicas and more run whole instead of as two half batches (default: none)"},
     {"SCEMA_MD_SPLIT", "0: never run a launch group of 32 simulations and more as two half batches on two streams"},
     {"SCEMA_MD_PPPM_SIDE_MIN", "smallest batch whose PPPM chain runs on the side stream next to the pair kernel (default 1; 4 until round 5)"},
+    {"SCEMA_MD_PAIR_PARTS", "workgroups per tile of the pair kernel (1, 2, 4, 8; default: by the size of the launch group -- groups that do not fill the chip split their tiles)"},
+    {"SCEMA_MD_PAIR_FILL", "workgroups of a pair launch up to which its tiles are split once more (default 1536 = three rounds of the chip's 512 slots)"},
+    {"SCEMA_MD_NB_SIDE", "0 / 1: the cell and list kernels of a step on the main stream before the pair kernel / on a stream of their own beside the pair forces of the replicas that do not rebuild (default: off -- measured and lost, DESIGN.md 5.4)"},
+    {"SCEMA_MD_NB_SIDE_MAX", "batch size below which the list kernels run beside the pair kernel (default 0: never)"},
+    {"SCEMA_MD_CELLS_TARGET", "what-if: take the cell grid (= tiling of the pair kernel) whose number of cells is closest to this among the grids that fit"},
     {"SCEMA_MD_ONE_STREAM", "no side stream (bonded / k-space chain beside the pair kernel)"},
     {"SCEMA_MD_KEEP_LIST", "0: the sampling run of an evaluation rebuilds its neighbour rows at its start even where those of the straining run still hold"},
     {"SCEMA_MD_SKIN_EXTRA", "list skin = params.skin + this many Angstrom (results do not depend on it)"},
     {"SCEMA_MD_SKIN_ADAPT", "1: per-state adaptation of the extra skin from the rebuild interval (round-1 behaviour)"},
     {"SCEMA_MD_PPPM_SOLVE_WIDE", "1 / 0: the in-LDS PPPM solve with 1 024 threads and three LDS grids / 512 threads and two (default: by batch size)"},
+    {"SCEMA_MD_PPPM_SOLVE_TWO", "0 / 1: the in-LDS PPPM solve of the 1 024-thread shape as one / two workgroups per replica, one per transform back (default: two for batches under 8 replicas)"},
     {"SCEMA_MD_PPPM_PADX", "0: the LDS grid of the PPPM spreading kernel without the five pad points per x row (an address addition per stencil point instead of a constant offset)"},
     {"SCEMA_MD_PPPM_FFT", "hipFFT for every PPPM grid (default: grids of up to 2 900 points are solved in LDS)"},
     {"SCEMA_MD_FUSED_TAIL", "0 / 1: force assembly + SHAKE + second kick as three kernels / as k_finish (default: by batch size)"},
+    {"SCEMA_MD_FUSED_POST", "0: the end of the step (k_post) as a launch of its own behind k_finish instead of in k_finish's last workgroup of a replica"},
+    {"SCEMA_MD_BONDED_SIDE", "0: the bonded kernel of a small batch always on the main stream behind the pair kernel (default: behind the PPPM chain on the side stream on steps without a new influence function)"},
     {"SCEMA_MD_CELL_BUILD", "0: cell binning as k_bin + k_cell_scan + k_cell_fill instead of the one-launch k_cell_build"},
     {"SCEMA_MD_POLY_TOL", "fit target of the real-space Ewald polynomial (default 2e-13); parity tolerances assume the default"},
     {"SCEMA_REAX_DROP_DSBO2", "ReaxFF valence-angle gradient without the dSBO2 term, as USER-REAXC is believed to compute it"},
@@ -72,6 +80,8 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_NEIGH_GROW0", "start with undersized neighbour capacities: overflow -> restore -> regrow"},
     {"SCEMA_MD_NEIGH_EXACT", "1: every list build tests its candidates in FP64 at the exact list radius; 0: none does (default: the first build of a run)"},
     {"SCEMA_MD_TEST_FAIL_INCOMING", "rank on which the allocation of a state that migrates in fails (-1: on whichever rank receives one); the failure must reach every rank through the handshake"},
+    {"SCEMA_MD_TEST_FAIL_MIGRATE", "<what>[:<rank>] -- an injected failure of the exchange of replica states: dbox / upload (before the handshake: every rank ends the call, nothing is posted), enqueue / group / hostcopy (after it: the exchange is completed, the error travels in the status word of the stress all-gather)"},
+    {"SCEMA_MD_TEST_SELF_MOVE", "1 (RCCL, one rank): every simulation that continues from a state held here receives it through ncclSend / ncclRecv from this very rank"},
     {"SCEMA_MD_QCAP16", "capacity of k_neigh_build's group lists in sixteenths of the table: small values force the whole-table walk"},
     {"SCEMA_MD_RX_COL32", "32-bit column indices in the ReaxFF charge matrix whatever the replica size"},
     {"SCEMA_MD_RX_NB_ONCE", "0: the both-ends ReaxFF non-bonded kernel"},
@@ -136,6 +146,10 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
   if (const char *sp = scema_env("SCEMA_MD_SPLIT_MAX")) e->split_max = std::max(0, atoi(sp));
   if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess)
     e->stream3 = nullptr;   // an optimisation only
+  if (e->stream3 && (hipEventCreateWithFlags(&e->ev_nb_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_nb_join, hipEventDisableTiming) != hipSuccess)) {
+    if (e->ev_nb_fork) (void)hipEventDestroy(e->ev_nb_fork);
+    e->ev_nb_fork = e->ev_nb_join = nullptr;
+  }
   if (const char *sx = scema_env("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(-0.75 * e->p.skin, atof(sx));
   if (const char *sx = scema_env("SCEMA_MD_SKIN_ADAPT")) e->skin_adapt = atoi(sx) != 0;
   if (!scema_env("SCEMA_MD_ONE_STREAM")) {
@@ -170,6 +184,8 @@ void scema_md_destroy(scema_md_engine *e) {
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_nb_fork) (void)hipEventDestroy(e->ev_nb_fork);
+  if (e->ev_nb_join) (void)hipEventDestroy(e->ev_nb_join);
   if (e->rx_fork) (void)hipEventDestroy(e->rx_fork);
   if (e->rx_side1) (void)hipStreamDestroy(e->rx_side1);
   for (int k = 0; k < 4; k++) if (e->rx_side1_ev[k]) (void)hipEventDestroy(e->rx_side1_ev[k]);

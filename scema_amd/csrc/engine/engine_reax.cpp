@@ -180,8 +180,8 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     {
       const ListSig &g = sl.sig;
       const SimScalars &hsc = e->h_sc[i];
-      if (spec.keep_list && keep_lists && g.valid && g.rx_stamp != 0 && g.rx_stamp == e->rx_stamp && g.topo == (const void *)&T && g.rlist == rlist && g.npad == npad &&
-          (spec.keep_list == 1 || g.state == (const void *)A.st) && !hsc.force_rebuild && !hsc.overflow && maxnb <= g.maxneigh && maxnbn <= g.capj &&
+      if (spec.keep_list && keep_lists && g.valid && g.rx_stamp != 0 && g.rx_stamp == e->rx_stamp && g.topo == T.id && g.rlist == rlist && g.npad == npad &&
+          (spec.keep_list == 1 || g.state == A.st->id) && !hsc.force_rebuild && !hsc.overflow && maxnb <= g.maxneigh && maxnbn <= g.capj &&
           g.rx_mimg[0] == V.mimg[0] && g.rx_mimg[1] == V.mimg[1] && g.rx_mimg[2] == V.mimg[2] && sl.rx) {
         keep = true;
         maxnb = g.maxneigh; maxnbn = g.capj;
@@ -193,7 +193,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
       ListSig &g = sl.sig;   // what this run's rows are built for; valid once the run has ended without a fault
       g.valid = false;
       g.rx_stamp = e->rx_stamp;
-      g.topo = (const void *)&T;
+      g.topo = T.id;
       g.rlist = rlist; g.npad = npad; g.maxneigh = maxnb; g.capj = maxnbn;
       for (int d = 0; d < 3; d++) g.rx_mimg[d] = V.mimg[d];
     }
@@ -512,7 +512,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     ListSig &g = e->slots[i]->sig;
     const SimScalars &c = e->h_sc[i];
     g.valid = !spec.minimize;
-    g.state = (const void *)sims[i].st;
+    g.state = sims[i].st->id;
     std::memcpy(g.corners_hold, c.corners_hold, sizeof g.corners_hold);
     g.ago = c.ago;
   }

@@ -8,6 +8,7 @@ namespace scema_eng {
 // one "run" of a batch
 // -------------------------------------------------------------------------------------------
 // slots: every cell is padded to a multiple of MD_CLUSTER slots (i-clusters never straddle cells)
+static const int PAIR_MAXPARTS = 8;   // workgroups a tile of k_pair may run as (SimDev::pair_lparts <= 3)
 static int padded_slots(int natoms, int ncells) { return (natoms + (MD_CLUSTER - 1) * ncells + 255) / 256 * 256; }
 
 int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncells, int nk, int capj) {
@@ -45,7 +46,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.cell_fill.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.tile_nj.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.tile_wstart.ensure((size_t)(ncells + 1) * 9 * 4));
-    HIPCHK(sl.virp.ensure((size_t)(ncells + 1) * MD_TILE_WAVES * 6 * 8));
+    HIPCHK(sl.virp.ensure((size_t)(ncells + 1) * PAIR_MAXPARTS * MD_TILE_WAVES * 6 * 8));   // a row of 6 per (cell, part, wave) of k_pair
     sl.cap_cells = ncells + 1;
   }
   if ((size_t)ncells * capj > sl.cap_jtab || sl.cap_jtab == 0) {
@@ -280,8 +281,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     bool keep = false;
     {
       const ListSig &g = e->slots[i]->sig;
-      if (spec.keep_list && keep_lists && g.valid && g.rx_stamp == 0 && g.topo == (const void *)&T && g.rlist == rlist && g.cut_lj == P.cut_lj && g.cut_coul == P.cut_coul &&
-          (spec.keep_list == 1 || g.state == (const void *)A.st) && !hsc.force_rebuild && !hsc.overflow) {
+      if (spec.keep_list && keep_lists && g.valid && g.rx_stamp == 0 && g.topo == T.id && g.rlist == rlist && g.cut_lj == P.cut_lj && g.cut_coul == P.cut_coul &&
+          (spec.keep_list == 1 || g.state == A.st->id) && !hsc.force_rebuild && !hsc.overflow) {
         int mst[3], cj = 0, mn = 0;
         if (size_grid(g.nc, mst, cj, mn) && cj <= g.capj && mn <= g.maxneigh && padded_slots(T.natoms, g.nc[0] * g.nc[1] * g.nc[2]) == g.npad) {
           keep = fits = true;
@@ -295,6 +296,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
     // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
     const bool small_batch = ns <= 8;   // replicas up to which the most-cells grid is taken (scanned in round 2: tools/small_batch_scan.sh)
+    static const int cells_target = scema_env("SCEMA_MD_CELLS_TARGET") ? atoi(scema_env("SCEMA_MD_CELLS_TARGET")) : 0;
     for (int pass = 0; pass < 2 && !fits; pass++) {
       int lo[3], hi[3];
       for (int d = 0; d < 3; d++) {
@@ -302,7 +304,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
         lo[d] = std::max(2, std::min(64, (int)std::floor(w / (rlist * 1.0001))));
         hi[d] = std::max(lo[d], std::min(64, (int)std::floor(w / ((pass == 0 ? 0.5 : 0.25) * rlist * 1.0001))));
       }
-      double best = -1.0;
+      double best = -1.0e300;
       for (int n0 = lo[0]; n0 <= hi[0]; n0++)
         for (int n1 = lo[1]; n1 <= hi[1]; n1++)
           for (int n2 = lo[2]; n2 <= hi[2]; n2++) {
@@ -311,7 +313,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
             if (!size_grid(nc, mst, cj, mn)) continue;
             // batches that fill the chip take the largest cells (per-tile phases amortised over more rows); small ones the
             // most cells: a single replica on 120 tiles leaves half of the 512 workgroup slots empty and waits for one tile
-            const double vol = small_batch ? (double)n0 * n1 * n2 : 1.0 / ((double)n0 * n1 * n2);
+            // (SCEMA_MD_CELLS_TARGET: the fitting grid whose number of cells is closest to the target -- what-if runs of the tile size)
+            const double vol = cells_target > 0 ? -std::fabs((double)n0 * n1 * n2 - cells_target) - 1e-3 * n2 : small_batch ? (double)n0 * n1 * n2 : 1.0 / ((double)n0 * n1 * n2);
             if (vol > best) {
               best = vol;
               fits = true;
@@ -372,7 +375,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       ListSig &g = sl.sig;   // what this run's rows are built for; valid once the run has ended without a fault
       g.valid = false;
       g.rx_stamp = 0;
-      g.topo = (const void *)&T;
+      g.topo = T.id;
       for (int d = 0; d < 3; d++) g.nc[d] = S.nc[d];
       g.capj = capj; g.maxneigh = maxneigh; g.npad = S.npad;
       g.rlist = rlist; g.cut_lj = P.cut_lj; g.cut_coul = P.cut_coul;
@@ -452,6 +455,22 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     maxunits = std::max(maxunits, S.use_shake ? S.nclus + S.nfree : S.natoms);
     maxsteps = std::max(maxsteps, A.nsteps);
   }
+  // Workgroups per tile of k_pair: every tile as 2, 4 or 8 workgroups, each with a part of every row (md_pair.hip) -- the what-if of
+  // VERDICT r5 item 1c for launch groups that do not fill the chip's 512 workgroup slots.  Measured in round 6: it LOSES at
+  // every batch size from 1 to 18 replicas (a single replica: k_pair 40.3 -> 38.1 us with four parts, but the update 14.6 -> 15.9 ms) -- the
+  // rows are a small part of a lone tile's life next to its table load and its flush, whose memory-side atomics grow with the parts, and
+  // the extra workgroups take the CUs the PPPM chain beside it runs on.  So the default is one workgroup per tile whatever the size;
+  // SCEMA_MD_PAIR_PARTS forces a number, SCEMA_MD_PAIR_FILL a fill target.
+  int pair_lp = 0;
+  {
+    static const int parts_env = scema_env("SCEMA_MD_PAIR_PARTS") ? atoi(scema_env("SCEMA_MD_PAIR_PARTS")) : 0;
+    static const int parts_fill = scema_env("SCEMA_MD_PAIR_FILL") ? atoi(scema_env("SCEMA_MD_PAIR_FILL")) : 0;
+    const long wgs = (long)hcnt[0] * std::max(maxcells, 1);
+    if (parts_env > 0) { while ((2 << pair_lp) <= std::min(parts_env, PAIR_MAXPARTS)) pair_lp++; }
+    else while (pair_lp < 2 && (wgs << (pair_lp + 1)) <= parts_fill) pair_lp++;
+    for (int pos = 0; pos < ns; pos++) e->h_sims[pos].pair_lparts = pair_lp;
+  }
+  const int pair_parts = 1 << pair_lp;
   if ((size_t)64 * 3 * mmax * 16 + 4096 > 160 * 1024)
     return fail(e, SCEMA_MD_ERR_ARG, "k-space index range (|n| up to %d) too large for the LDS phase tables; raise cut_coul or loosen kspace_accuracy", mmax - 1);
   HIPCHK(e->d_kpack.ensure(kpack.size() * sizeof(int) + 64));
@@ -553,12 +572,13 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // are timed and profiled undisturbed.
   static const int side_min = scema_env("SCEMA_MD_PPPM_SIDE_MIN") ? atoi(scema_env("SCEMA_MD_PPPM_SIDE_MIN")) : 1;
   const bool pppm_side = maxgrid > 0 && nhalf == 1 && e->stream2 != nullptr && ns >= side_min && ns < 256;
-  auto pppm_fork = [&](hipStream_t st, int pos0, int na, bool new_box) -> int {
+  auto pppm_fork = [&](hipStream_t st, int pos0, int na, bool new_box, bool with_bonded = false) -> int {
     if (!pppm_side) return SCEMA_MD_OK;
     HIPCHK(hipEventRecord(e->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     const int rc = pppm_stage(e->stream2, pos0, na, new_box, 0);
     if (rc) return rc;
+    if (with_bonded) mdk_bonded(e->stream2, e->d_sims.as<SimDev>() + pos0, na, maxbt, maxloc, maxcoef, 0);   // (needs the positions only, like the chain before it)
     HIPCHK(hipEventRecord(e->ev_join, e->stream2));
     return SCEMA_MD_OK;
   };
@@ -582,7 +602,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (any_validate) mdk_keep_validate(st, Dh, nh, maxatoms);
     mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
     { const int rcp = pppm_fork(st, hbeg[h], nh, true); if (rcp) return rcp; }
-    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
+    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts);
     HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
     if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], nh, true); if (rcp) return rcp; }
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
@@ -613,7 +633,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
         mdk_min_pre(st, D, ns);
         mdk_min_move(st, D, ns, maxatoms, x0s, hsd);
         mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
-        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly, P.cut_coul <= P.cut_lj);
+        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly, P.cut_coul <= P.cut_lj, pair_parts);
         HIPCHK(force_stage(e, st, false, D, ns, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, 1, 0));
         { const int rcp = pppm_stage(st, 0, ns, false); if (rcp) return rcp; }
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
@@ -654,13 +674,39 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // batches keep them (576 replicas: 452 against 426 us).  SCEMA_MD_FUSED_TAIL = 0 / 1 forces either.
   static const int fused_tail_env = scema_env("SCEMA_MD_FUSED_TAIL") ? atoi(scema_env("SCEMA_MD_FUSED_TAIL")) : -1;
   const bool fused_tail = (fused_tail_env < 0 ? ns <= 32 : fused_tail_env != 0) && !spec.nh && maxk == 0 && !spec.ev_always;
+  // List rebuilds beside the pair kernel (round 6; a what-if that LOST and is off unless SCEMA_MD_NB_SIDE=1 asks for it): a step of 9 replicas
+  // spends 67 of its 290 us in the cell / list kernels of the ONE replica that rebuilds, on a quarter of the chip, while the other eight
+  // wait.  With those kernels on a stream of their own beside a first pair launch for the replicas whose rows stand, and a second pair
+  // launch for the others: 228 against 238-248 evaluations/s at 9 replicas, 295 against 308 at 18, 70 against 73 for a single one
+  // (profiles/r06_b_ab.log).  The trace says why (profiles/r06_c_nb_timeline_9sims.txt): the list kernel's 1 080 workgroups of 80 kB of LDS
+  // each, which leave at once on a step without a rebuild, cannot start while the pair launch holds every CU's LDS -- 44 us instead of 4 --,
+  // the pair launch beside them runs 177 instead of 157 us, and the second pair launch and its event edges add 19 us to every step.
+  static const int nb_side_env = scema_env("SCEMA_MD_NB_SIDE") ? atoi(scema_env("SCEMA_MD_NB_SIDE")) : -1;
+  static const int nb_side_max = scema_env("SCEMA_MD_NB_SIDE_MAX") ? atoi(scema_env("SCEMA_MD_NB_SIDE_MAX")) : 0;
+  const bool nb_side = nhalf == 1 && e->stream3 != nullptr && e->ev_nb_fork != nullptr && !spec.nh && !spec.ev_always &&
+                       (nb_side_env < 0 ? ns < nb_side_max : nb_side_env != 0);
+  // ... and the end of the step inside that pass (k_finish's last workgroup of a replica does k_post's work: one launch less again), and the
+  // bonded kernel behind the PPPM chain on the side stream on steps whose chain is short (no new influence function): a single replica's step
+  // is two chains of dependent launches, the pair chain the longer one on those steps.  SCEMA_MD_FUSED_POST / SCEMA_MD_BONDED_SIDE = 0: off.
+  static const bool fused_post = !(scema_env("SCEMA_MD_FUSED_POST") && atoi(scema_env("SCEMA_MD_FUSED_POST")) == 0);
+  static const bool bonded_side_on = !(scema_env("SCEMA_MD_BONDED_SIDE") && atoi(scema_env("SCEMA_MD_BONDED_SIDE")) == 0);
   auto launch_step = [&](int h, int na, bool timed) -> int {
     hipStream_t st = hs[h];
     const SimDev *Dh = D + hbeg[h];
     if (spec.nh) { mdk_pre_nh(st, Dh, na); mdk_initial_integrate_nh(st, Dh, na, maxatoms); }
     else mdk_initial_integrate(st, Dh, na, maxatoms, fuse_pack);   // (its k_pre: at the end of the step before, in k_post; for step 1 below)
-    mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack);
-    { const int rcp = pppm_fork(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
+    // the PPPM chain needs the new positions only: it leaves for its side stream before the list kernels are issued, not behind them
+    const bool bonded_side = bonded_side_on && pppm_side && fused_tail && !(spec.deform || (spec.nh && spec.npt));
+    { const int rcp = pppm_fork(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt), bonded_side); if (rcp) return rcp; }
+    if (nb_side) {
+      // the cell / list kernels (which leave at once for a replica that does not rebuild: the usual case) on a stream of their own, beside
+      // the pair forces of the replicas whose rows stand; the replicas that do rebuild get their pair forces in a second launch behind it
+      HIPCHK(hipEventRecord(e->ev_nb_fork, st));
+      HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_nb_fork, 0));
+      mdk_neighbor(e->stream3, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack);
+      HIPCHK(hipEventRecord(e->ev_nb_join, e->stream3));
+    } else
+      mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack);
     if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;
@@ -671,7 +717,12 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
-    mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
+    if (nb_side) {
+      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, 0);
+      HIPCHK(hipStreamWaitEvent(st, e->ev_nb_join, 0));
+      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, 1);
+    } else
+      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts);
     if (timed) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;
@@ -680,10 +731,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (fused_tail) {
       // no per-atom reciprocal sum: the bonded kernel, the PPPM chain (its forces stored in f, from the side stream or here), then
       // assembly of f, fix shake and the second half-kick in one pass (k_finish)
-      mdk_bonded(st, Dh, na, maxbt, maxloc, maxcoef, 0);
+      if (!bonded_side) mdk_bonded(st, Dh, na, maxbt, maxloc, maxcoef, 0);
       if (pppm_side) HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
       else { const int rcp = pppm_stage(st, hbeg[h], na, spec.deform, 0); if (rcp) return rcp; }
-      mdk_finish(st, Dh, na, maxunits, ev, maxgrid > 0 ? 1 : 0);
+      mdk_finish(st, Dh, na, maxunits, ev, maxgrid > 0 ? 1 : 0, fused_post ? 2 : 0);
     } else {
       HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
       if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
@@ -691,7 +742,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       mdk_final_integrate(st, Dh, na, maxatoms, 1);
     }
     if (spec.nh) mdk_post_nh(st, Dh, na);
-    else mdk_post(st, Dh, na, 1);
+    else if (!(fused_tail && fused_post)) mdk_post(st, Dh, na, 1);
     if (spec.deform) mdk_remap(st, Dh, na, maxatoms);
     return SCEMA_MD_OK;
   };
@@ -857,7 +908,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     ListSig &g = e->slots[i]->sig;
     const SimScalars &c = e->h_sc[i];
     g.valid = true;
-    g.state = (const void *)sims[i].st;
+    g.state = sims[i].st->id;
     std::memcpy(g.corners_hold, c.corners_hold, sizeof g.corners_hold);
     g.ago = c.ago; g.maxj_seen = c.maxj_seen; g.nentries = c.nentries; g.nentries_ref = c.nentries_ref; g.nrowent = c.nrowent;
   }
@@ -876,7 +927,7 @@ int prepare_slots(scema_md_engine *e, std::vector<ActiveSim> &sims) {
     // the slot may still hold this state's neighbour rows from the update before: their scalars come back with them (run_phase and the
     // device decide whether the rows are kept; a slot that last served another state leaves the zeros, which force the build)
     const ListSig &g = e->slots[i]->sig;
-    if (g.valid && g.state == (const void *)sims[i].st) {
+    if (g.valid && g.state == sims[i].st->id) {
       std::memcpy(e->h_sc[i].corners_hold, g.corners_hold, sizeof g.corners_hold);
       e->h_sc[i].ago = g.ago; e->h_sc[i].maxj_seen = g.maxj_seen;
       e->h_sc[i].nentries = g.nentries; e->h_sc[i].nentries_ref = g.nentries_ref; e->h_sc[i].nrowent = g.nrowent;

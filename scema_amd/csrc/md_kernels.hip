@@ -901,7 +901,7 @@ __global__ __launch_bounds__(EWF_T) void k_ewald_force(const SimDev *sims, int p
       }
     }
   if (pairvir) {
-    const int nrows = S.ncells * MD_TILE_WAVES;   // one row of 6 per cell and wave of k_pair
+    const int nrows = (S.ncells << S.pair_lparts) * MD_TILE_WAVES;   // one row of 6 per cell, part and wave of k_pair
     const int nblk = (S.natoms + EWF_T * EWF_APT - 1) / (EWF_T * EWF_APT);   // blocks of this simulation that got this far
     for (int r = blockIdx.x * EWF_T + threadIdx.x; r < nrows; r += nblk * EWF_T) {
       const double *vp = S.virp + (size_t)r * 6;
@@ -1155,7 +1155,11 @@ __device__ __forceinline__ void finish_cluster(const SimDev &S, const BoxD &b, i
 #pragma unroll
   for (int a = 0; a <= NB; a++) kick_atom(S, ia[a], invm[a], f[a], v0[a], ke);
 }
-__global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairvir, int fkeep) {
+__device__ __forceinline__ void post_scalars(const SimDev &S, SimScalars &sc);
+// post: the end of the step (k_post's work, and the k_pre of the next step where `post` is 2) is done by the LAST workgroup of the replica to
+// have added its sums -- a ticket per replica, taken behind the workgroup's atomics with release/acquire at device scope -- instead of by a
+// launch of its own: a batch of a few replicas is a chain of dependent launches 6-7 us apart, and k_post is 10 us of one thread (round 6)
+__global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairvir, int fkeep, int post) {
   const SimDev &S = sims[blockIdx.y];
   SimScalars &sc = *S.sc;
   const int nunits = S.use_shake ? S.nclus + S.nfree : S.natoms;
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairv
   }
   if (pairvir) {
     const int nblk = (nunits + TPB - 1) / TPB;   // blocks of this simulation that got this far
-    const int nrows = S.ncells * MD_TILE_WAVES;  // one row of 6 per cell and wave of k_pair
+    const int nrows = (S.ncells << S.pair_lparts) * MD_TILE_WAVES;  // one row of 6 per cell, part and wave of k_pair
     for (int r = blockIdx.x * TPB + threadIdx.x; r < nrows; r += nblk * TPB) {
       const double *vp = S.virp + (size_t)r * 6;
 #pragma unroll
@@ -1198,6 +1202,29 @@ __global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairv
   }
   if (S.use_shake) block_atomic_add<6>(sv, sc.vir + P_SHAKE * 6, s_red);
   block_atomic_add<6>(ke, sc.ke, s_red);
+  if (post) {
+    __shared__ int s_last, s_more;
+    __threadfence();   // this thread's atomics are performed at device scope ...
+    __syncthreads();   // ... for every thread of the workgroup, before its ticket is taken
+    if (threadIdx.x == 0) {
+      const int nblk = (nunits + TPB - 1) / TPB;
+      const int t = __hip_atomic_fetch_add(&sc.post_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == nblk - 1);
+      s_more = 0;
+      if (s_last) {
+        __hip_atomic_store(&sc.post_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the sums of all workgroups, not what this CU's caches may hold of them
+        post_scalars(S, sc);
+        s_more = post == 2 && sc.step < S.nsteps;
+        if (s_more) pre_scalars(S, sc);
+      }
+    }
+    __syncthreads();
+    if (s_last && s_more) {
+      for (int k = threadIdx.x; k < 2 * S.nk; k += TPB) S.sfac[k] = 0.0;
+      for (int k = threadIdx.x; k < S.ncells; k += TPB) S.cell_count[k] = 0;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1205,7 +1232,6 @@ __global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairv
 // ------------------------------------------------------------------------------------------
 // next_pre: a simulation with steps left also does the k_pre of its next step here (one launch less per step; the first step of a run
 // has its own k_pre)
-__device__ __forceinline__ void post_scalars(const SimDev &S, SimScalars &sc);
 __global__ void k_post(const SimDev *sims, int next_pre) {
   const SimDev &S = sims[blockIdx.x];
   SimScalars &sc = *S.sc;
@@ -1366,8 +1392,8 @@ void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfs
   if (maxclus <= 0) return;
   hipLaunchKernelGGL(k_shake, grid2(cdiv(maxclus, TPB), ns), dim3(TPB), 0, st, d, dtfsq_scale);
 }
-void mdk_finish(hipStream_t st, const SimDev *d, int ns, int maxunits, int pairvir, int fkeep) {
-  hipLaunchKernelGGL(k_finish, grid2(cdiv(maxunits, TPB), ns), dim3(TPB), 0, st, d, pairvir, fkeep);
+void mdk_finish(hipStream_t st, const SimDev *d, int ns, int maxunits, int pairvir, int fkeep, int post) {
+  hipLaunchKernelGGL(k_finish, grid2(cdiv(maxunits, TPB), ns), dim3(TPB), 0, st, d, pairvir, fkeep, post);
 }
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick) {
   hipLaunchKernelGGL(k_final_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d, kick);

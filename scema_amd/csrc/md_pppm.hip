@@ -316,9 +316,26 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
     sincospi(2.0 * (double)j / (double)n, &sn, &cs);
     tw[k] = make_double2(cs, -sn);
   }
+  // Two workgroups per replica (gridDim.y == 2; the shape with rho(k) in LDS only): each makes the forward transform and ONE of the two
+  // transforms back -- six one-dimensional passes instead of nine on the critical path of a batch of a few replicas, which waits for
+  // this kernel.  Energy and virial are taken by the first.  The charge grid must leave zeroed but not before both
+  // have read it: each takes a ticket once its copy is in LDS, the last one zeroes.
+  const bool two = !BGLOBAL && gridDim.y == 2;
+  const int c_lo = two ? (int)blockIdx.y : 0, c_hi = two ? (int)blockIdx.y + 1 : 2;
   double2 *rho = (double2 *)S.pgrid;
-  for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) { A[k] = make_double2(rho[k].x, 0.0); if (!BGLOBAL) rho[k] = make_double2(0.0, 0.0); }
+  for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) { A[k] = make_double2(rho[k].x, 0.0); if (!BGLOBAL && !two) rho[k] = make_double2(0.0, 0.0); }
   __syncthreads();
+  if (two) {
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+      const int t = __hip_atomic_fetch_add(&S.sc->pppm_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == 1);
+      if (t == 1) __hip_atomic_store(&S.sc->pppm_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_last)
+      for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) rho[k] = make_double2(0.0, 0.0);
+  }
   PP_CLK();   // 1: twiddles + charge grid in
   // out[.., m, ..] = sum_k in[.., k, ..] w^(m k) along dimension dim (w = exp(-+2 pi i / n)); ends with a barrier.  A work item is one
   // line of the grid and one m in 0 .. n/2: it also produces the output n - m, whose twiddles are the complex conjugates (8 multiply-adds
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
   // spectra are Hermitian.  Modes with a Nyquist component are not (the grid index n/2 stands for -n/2 only), and taking the real
   // part of each field, as the three-transform form does, is the same as transforming the Hermitian part (X(k) + conj X(-k)) / 2:
   // that is what is packed here (for every other mode it equals X(k) to the last bit).
-  for (int c = 0; c < 2; c++) {
+  for (int c = c_lo; c < c_hi; c++) {
     for (int idx = threadIdx.x; idx < NG; idx += PP_SOLVE_TPB) {
       double kv[3], vd[6] = {0, 0, 0, 0, 0, 0}, ed = 0.0;
       const double2 p = (c == 0) ? pppm_mode(S, b, idx, nx, ny, nz, B[idx], kv, v, e[0]) : pppm_mode(S, b, idx, nx, ny, nz, B[idx], kv, vd, ed);
@@ -405,11 +422,13 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
   }
   if (BGLOBAL)   // the charge grid leaves zeroed for the next spreading pass, as in the other shape
     for (int k = threadIdx.x; k < NG; k += PP_SOLVE_TPB) rho[k] = make_double2(0.0, 0.0);
-  block_atomic_add_n<6, PP_SOLVE_TPB / 64>(v, S.sc->vir + P_KSPACE * 6, s_red);
-  block_atomic_add_n<1, PP_SOLVE_TPB / 64>(e, S.sc->eng + P_KSPACE, s_red);
+  if (c_lo == 0) {   // (uniform over the workgroup)
+    block_atomic_add_n<6, PP_SOLVE_TPB / 64>(v, S.sc->vir + P_KSPACE * 6, s_red);
+    block_atomic_add_n<1, PP_SOLVE_TPB / 64>(e, S.sc->eng + P_KSPACE, s_red);
+  }
 #ifdef PAIR_TIMING
   PP_CLK();   // 7: field stores of the second round + sums
-  if (threadIdx.x == 0 && blockIdx.x == 0 && ntq == 8) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && ntq == 8) {
     for (int k = 1; k < 8; k++) atomicAdd(&S.sc->dbg2[k - 1], tq[k] - tq[k - 1]);
     atomicAdd(&S.sc->dbg2[7], 1ull);
   }
@@ -514,12 +533,14 @@ void mdk_pppm_solve(hipStream_t st, const SimDev *d, int ns, int maxgrid, int ma
   // batches: the shape that fits beside a pair workgroup; a few replicas: the one with the most threads per replica
   static const int shape_env = scema_env("SCEMA_MD_PPPM_SOLVE_WIDE") ? atoi(scema_env("SCEMA_MD_PPPM_SOLVE_WIDE")) : -1;
   const bool wide = shape_env < 0 ? ns < 8 : shape_env != 0;
+  static const int two_env = scema_env("SCEMA_MD_PPPM_SOLVE_TWO") ? atoi(scema_env("SCEMA_MD_PPPM_SOLVE_TWO")) : -1;
+  const bool two = wide && (two_env < 0 ? ns < 8 : two_env != 0);   // two workgroups per replica, one per transform back (the shape with rho(k) in LDS)
   const size_t lds = ((wide ? 3 : 2) * (size_t)maxgrid + (size_t)maxdims) * sizeof(double2);
   static size_t optin_tab[2][16] = {{0}, {0}};
   size_t &optin = lds_optin_slot(optin_tab[wide ? 1 : 0]);
   if (wide) {
     if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_solve<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-    hipLaunchKernelGGL((k_pppm_solve<1024, false>), dim3(ns), dim3(1024), lds, st, d);
+    hipLaunchKernelGGL((k_pppm_solve<1024, false>), dim3(ns, two ? 2 : 1), dim3(1024), lds, st, d);
   } else {
     if (lds > 64 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pppm_solve<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
     hipLaunchKernelGGL((k_pppm_solve<512, true>), dim3(ns), dim3(512), lds, st, d);

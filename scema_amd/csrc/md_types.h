@@ -82,9 +82,11 @@ struct SimScalars {
   double cen[3];       // centre of the dilation (box centre)
   double len0[3];      // box lengths at the start of the segment (the cell grid holds for +-box_margin around them)
   double lsum[3], lrun[3];   // fix ave/time of the box lengths: window sum, sum of window means
-  int nlwin, pad1_;
+  int nlwin;
+  int pppm_ticket;     // k_pppm_solve as two workgroups per replica: how many of them have read the charge grid (the last one zeroes it)
   // minimiser state (one line search at a time, decided on the device between two force evaluations)
-  int min_phase, min_stop, min_iter, min_neval, min_newdir, pad2_;
+  int min_phase, min_stop, min_iter, min_neval, min_newdir;
+  int post_ticket;     // k_finish with the end of the step inside: workgroups of this replica that have added their sums (the last one does k_post's work)
   double min_alpha_now, min_alpha_next;   // where x sits on the current search line before / after the move of this evaluation (min_incremental)
   double min_alpha, min_alphamax, min_fdothall, min_eorig, min_eprev, min_fhprev, min_engprev, min_alphaprev, min_fh_trial, min_ecur, min_einit;
   double min_dots[4];  // f.h, f.f, max |f| of the last evaluation (+ spare)
@@ -162,7 +164,7 @@ struct SimDev {
   int MD_G *slot_of;     // atom -> slot
   int MD_G *tile_nj;     // per cell: entries of its j table
   int MD_G *tile_order;  // per cell, at its cluster range: the cell's clusters grouped by the wave of k_pair that takes them
-  double MD_G *virp;     // per cell and wave of k_pair: 6 partial sums of the pair virial's image-shift part (no atomics)
+  double MD_G *virp;     // per cell, part (pair_lparts) and wave of k_pair: 6 partial sums of the pair virial's image-shift part (no atomics)
   int MD_G *tile_wstart; // per cell: 9 group boundaries into tile_order (k_pair's schedule, fixed at build time)
   int MD_G *tile_jtab;   // per cell: capj entries (image code | slot), own cell first
   // pair structures
@@ -182,7 +184,8 @@ struct SimDev {
   double MD_G *sfac;     // 2 per k
   double MD_G *kvec;     // 4 per k : kx,ky,kz,ug
   // PPPM (md_pppm.hip; pg[0] == 0: the Ewald sum above is used)
-  int pg[3], pad_pg_;
+  int pg[3];
+  int pair_lparts;         // k_pair runs every tile of this replica as 2^pair_lparts workgroups (launch groups too small to fill the chip); virp has a row of 6 per (cell, part, wave)
   double MD_G *pgrid;    // complex grid [nz][ny][nx] (x fastest) of this simulation: charge density / its transform
   double MD_G *pfield;   // the three complex field grids of this simulation, pgstride complex elements apart (the batch keeps the charge
                     // grids of all simulations together, and all field grids: one batched, contiguous transform per direction)

@@ -357,3 +357,135 @@ def test_a_rank_that_cannot_take_a_migrating_state_fails_the_update_on_every_ran
         assert got[k]["stats"][2] >= 1                                     # the retry moved the state
         for u, name in enumerate(("u1", "u2")):
             assert np.abs(got[k][name] - ref[u]).max() < 1e-8 * np.abs(ref[u]).max(), (k, name)
+
+
+WORKER_MIG = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+from scema_amd import capi, comm
+from scema_amd.systems import build_pe
+from test_gpu_multirank import KW, sequence
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+what = sys.argv[3]
+dist.init_process_group("gloo")
+d = build_pe(2, 3, 5, jitter=0.05, seed=7)
+d["box"][6:9] = [0.7, -0.4, 0.5]
+eng = capi.Engine(capi.default_params(**KW))
+comm.attach_gloo(eng, rank, world)
+eng.register_replica("pe", 1, d)
+lens = d["box"][3:6] - d["box"][:3]
+u1, u2, _ = sequence(lens)
+def run(u):
+    qps, recent, strains = u
+    arr = eng.strain_batch([capi.make_sim(q, "pe", 1, s, nss=10, most_recent=r) for q, r, s in zip(qps, recent, strains)], rank=rank, world=world)
+    return np.array([list(a.stress) for a in arr])
+log = {"u1": run(u1)}
+# the ragged second update moves a state; AFTER the handshake a device copy of the exchange fails on the rank that sends (injected): the
+# exchange must still be completed (the peer is inside its receive), and both ranks must learn of the error in the stress all-gather
+os.environ["SCEMA_MD_TEST_FAIL_MIGRATE"] = what
+try:
+    run(u2)
+    log["msg"] = "no error"
+except capi.EngineError as exc:
+    log["msg"] = str(exc)
+del os.environ["SCEMA_MD_TEST_FAIL_MIGRATE"]
+st = eng.comm_stats()
+log["stats_after_failure"] = np.array([st["allgathers"], st["handshakes"], st["migrations"]])
+log["owners_after_failure"] = np.array([eng.state_owner(q, "pe", 1) for q in range(6)])
+log["u2"] = run(u2)
+st = eng.comm_stats()
+log["stats"] = np.array([st["allgathers"], st["handshakes"], st["migrations"]])
+np.savez(sys.argv[2] + f".{rank}.npz", **log)
+dist.barrier(); eng.close(); dist.destroy_process_group()
+'''
+
+
+def test_an_error_inside_the_exchange_of_states_keeps_to_the_protocol_on_the_host_transport(tmp_path, small_pe):
+    """VERDICT r5 item 3, host transport, world 2: a device copy fails on ONE rank after the ranks agreed to exchange.  That rank still posts
+    every send and receive of its moves, enters the stress all-gather with the error as its status word, and both ranks end the update
+    with an error; nothing is committed and the retry moves the state and equals the single-rank run."""
+    from scema_amd import capi
+    (tmp_path / "worker.py").write_text(WORKER_MIG)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29589", str(tmp_path / "worker.py"), ROOT, str(tmp_path / "out"), "hostcopy"]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = [np.load(str(tmp_path / "out") + f".{k}.npz") for k in range(2)]
+    eng = capi.Engine(capi.default_params(**KW))
+    eng.register_replica("pe", 1, small_pe)
+    lens = small_pe["box"][3:6] - small_pe["box"][:3]
+    ref = run_sequence(eng, lens)
+    eng.close()
+    msgs = [str(g["msg"]) for g in got]
+    assert all(m != "no error" for m in msgs), msgs
+    # at least one rank reports its own failed copy; a rank that took no part in a move hears of it in the stress all-gather
+    assert any("while replica states migrate" in m for m in msgs), msgs
+    assert all("while replica states migrate" in m or "during the update" in m for m in msgs), msgs
+    for k in range(2):
+        assert list(got[k]["stats_after_failure"][:2]) == [2, 2]          # the failed update: handshake AND stress collective, on both ranks
+        assert list(got[k]["owners_after_failure"]) == [0, 1, 0, 1, 0, 1]  # the directory of the first update stands
+        assert got[k]["stats"][2] >= 1                                     # the retry moved the state
+        for u, name in enumerate(("u1", "u2")):
+            assert np.abs(got[k][name] - ref[u]).max() < 1e-8 * np.abs(ref[u]).max(), (k, name)
+
+
+_RCCL_SELF_MOVE = r"""
+import os, sys
+import numpy as np
+import torch
+assert torch.cuda.is_available()
+torch.zeros(4, device="cuda").sum().item()
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from scema_amd import capi
+from scema_amd.systems import build_pe
+from test_gpu_multirank import KW
+d = build_pe(2, 3, 5, jitter=0.05, seed=7); d["box"][6:9] = [0.7, -0.4, 0.5]
+lens = d["box"][3:6] - d["box"][:3]
+st = np.array([-4e-4 * lens[0], -4e-4 * lens[1], 1.2e-3 * lens[2], 0, 0, 0])
+def first(eng):
+    return eng.strain_batch([capi.make_sim(q, "pe", 1, st * (1 + 0.1 * q), nss=10, most_recent=capi.QP_NONE) for q in range(3)])
+def second(eng):   # qp 0 and 1 continue from their own states, qp 5 branches from qp 2's
+    out = eng.strain_batch([capi.make_sim(0, "pe", 1, st), capi.make_sim(1, "pe", 1, 0.5 * st), capi.make_sim(5, "pe", 1, st, most_recent=2)])
+    return np.array([list(o.stress) for o in out])
+# reference: no communicator
+eng = capi.Engine(capi.default_params(**KW)); eng.register_replica("pe", 1, d); first(eng); ref = second(eng); ref3 = second(eng); eng.close()
+# RCCL with one rank; every continued state travels through ncclSend / ncclRecv to this very rank
+os.environ["SCEMA_MD_TEST_SELF_MOVE"] = "1"
+eng = capi.Engine(capi.default_params(**KW))
+eng.comm_init_rccl(eng.comm_unique_id(), 0, 1)
+eng.register_replica("pe", 1, d)
+first(eng)
+assert eng.comm_stats()["migrations"] == 0          # fresh states: nothing to move
+# every injected failure ends the update with an error and leaves no trace: the update after it equals the reference
+for what, where in (("dbox", "out of device memory for the boxes"), ("upload", "upload of the boxes"), ("enqueue", "ncclSend"), ("group", "ncclGroupEnd")):
+    os.environ["SCEMA_MD_TEST_FAIL_MIGRATE"] = what
+    n_ag = eng.comm_stats()["allgathers"]
+    try:
+        second(eng)
+        raise SystemExit(f"{what}: no error")
+    except capi.EngineError as exc:
+        assert where in str(exc), (what, str(exc))
+    assert eng.comm_stats()["allgathers"] == n_ag + 1, what    # the rank entered the stress collective with its status word
+    del os.environ["SCEMA_MD_TEST_FAIL_MIGRATE"]
+got = second(eng)
+assert eng.comm_stats()["migrations"] == 3, eng.comm_stats()
+assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max(), np.abs(got - ref).max()
+got3 = second(eng)
+assert np.abs(got3 - ref3).max() < 1e-9 * np.abs(ref3).max()
+eng.comm_destroy(); eng.close()
+print("RCCL-SELF-MOVE-OK", float(np.abs(got - ref).max() / np.abs(ref).max()))
+"""
+
+
+def test_rccl_point_to_point_calls_and_their_error_paths_on_one_rank(tmp_path):
+    """VERDICT r5 item 3, RCCL: with one rank no state ever changes GPU, so migrate_states' ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd
+    had never run on the one-GPU test box.  SCEMA_MD_TEST_SELF_MOVE sends every continued state from this rank to itself through that very
+    group: the stresses equal the run without a communicator, and each injected failure -- two before the exchange (device buffer, its
+    upload), two inside it (a point-to-point call, the end of the group) -- ends the update with its error AFTER the rank has entered the
+    stress all-gather, and leaves no trace."""
+    script = tmp_path / "rccl_self.py"
+    script.write_text(_RCCL_SELF_MOVE)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-SELF-MOVE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

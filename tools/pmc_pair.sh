@@ -18,7 +18,9 @@ for P in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
   timeout 400 rocprofv3 --pmc $P --kernel-include-regex "$RE" --output-format csv -d gpurun_out/pmc_${TAG}_$t -- python bench.py --sims $SIMS --steps 1 --warmup 0 --nss 10 --no-cpu-baseline --equil-cache $CACHE > gpurun_out/pmc_${TAG}_$t.log 2>&1
 done
 python - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, sys
+sys.path.insert(0, '.')
+from bench import kernel_source_hashes
 out = collections.defaultdict(dict)
 for d in sorted(glob.glob('gpurun_out/pmc_${TAG}_*/*/*_counter_collection.csv')):
     rows = list(csv.DictReader(open(d)))
@@ -42,6 +44,7 @@ if kp and 'FETCH_SIZE' in out[kp] and 'WRITE_SIZE' in out[kp] and 'SQ_INSTS_VALU
                "hbm_bytes_per_launch_corrected": hbm, "hbm_bytes_per_sim_step_corrected": hbm / $SIMS,
                "valu_insts_per_launch": o['SQ_INSTS_VALU'], "valu_insts_per_sim_step": o['SQ_INSTS_VALU'] / $SIMS,
                "cycles_per_valu_inst": 4.0,
+               "kernel_sources": kernel_source_hashes(),   # git blob hashes of the kernel's sources: bench.py drops these counters when the tree's differ
                "SQ_WAVE_CYCLES": o.get('SQ_WAVE_CYCLES'), "SQ_ACTIVE_INST_VALU": o.get('SQ_ACTIVE_INST_VALU'), "SQ_WAIT_ANY": o.get('SQ_WAIT_ANY'),
                "GRBM_GUI_ACTIVE": o.get('GRBM_GUI_ACTIVE'),
                "correction": "gfx950: FETCH_SIZE x2 for coalesced streams (MI355X_MICROARCH.md, HBM); WRITE_SIZE as read",
