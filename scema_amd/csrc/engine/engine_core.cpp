@@ -49,6 +49,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_SPLIT", "0: never run a launch group of 32 simulations and more as two half batches on two streams"},
     {"SCEMA_MD_PPPM_SIDE_MIN", "smallest batch whose PPPM chain runs on the side stream next to the pair kernel (default 1; 4 until round 5)"},
     {"SCEMA_MD_PAIR_PARTS", "workgroups per tile of the pair kernel (1, 2, 4, 8; default: by the size of the launch group -- groups that do not fill the chip split their tiles)"},
+    {"SCEMA_MD_PAIR_TAIL", "n:parts -- only the last n replicas of every pair launch run their tiles as `parts` workgroups (what-if: shorter workgroups while the launch drains)"},
     {"SCEMA_MD_PAIR_FILL", "workgroups of a pair launch up to which its tiles are split once more (default 1536 = three rounds of the chip's 512 slots)"},
     {"SCEMA_MD_NB_SIDE", "0 / 1: the cell and list kernels of a step on the main stream before the pair kernel / on a stream of their own beside the pair forces of the replicas that do not rebuild (default: off -- measured and lost, DESIGN.md 5.4)"},
     {"SCEMA_MD_NB_SIDE_MAX", "batch size below which the list kernels run beside the pair kernel (default 0: never)"},
@@ -62,8 +63,10 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_PPPM_PADX", "0: the LDS grid of the PPPM spreading kernel without the five pad points per x row (an address addition per stencil point instead of a constant offset)"},
     {"SCEMA_MD_PPPM_FFT", "hipFFT for every PPPM grid (default: grids of up to 2 900 points are solved in LDS)"},
     {"SCEMA_MD_FUSED_TAIL", "0 / 1: force assembly + SHAKE + second kick as three kernels / as k_finish (default: by batch size)"},
-    {"SCEMA_MD_FUSED_POST", "0: the end of the step (k_post) as a launch of its own behind k_finish instead of in k_finish's last workgroup of a replica"},
     {"SCEMA_MD_BONDED_SIDE", "0: the bonded kernel of a small batch always on the main stream behind the pair kernel (default: behind the PPPM chain on the side stream on steps without a new influence function)"},
+    {"SCEMA_MD_BONDED_SIDE_MIN", "smallest batch whose bonded kernel follows the PPPM chain on the side stream (default 8: below, that chain is the longer one)"},
+    {"SCEMA_MD_SMALL_BATCH_MAX", "largest batch that takes the cell grid with the most cells instead of the largest cells (default 31: every launch group that runs whole)"},
+    {"SCEMA_MD_REBUILD_TOGETHER", "0: every replica rebuilds its neighbour rows on its own trigger (default: the replicas of a launch rebuild together as soon as one asks for it)"},
     {"SCEMA_MD_CELL_BUILD", "0: cell binning as k_bin + k_cell_scan + k_cell_fill instead of the one-launch k_cell_build"},
     {"SCEMA_MD_POLY_TOL", "fit target of the real-space Ewald polynomial (default 2e-13); parity tolerances assume the default"},
     {"SCEMA_REAX_DROP_DSBO2", "ReaxFF valence-angle gradient without the dSBO2 term, as USER-REAXC is believed to compute it"},

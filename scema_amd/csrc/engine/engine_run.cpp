@@ -295,7 +295,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     any_validate = any_validate || S.keep_list == 2;
     // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
     // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
-    const bool small_batch = ns <= 8;   // replicas up to which the most-cells grid is taken (scanned in round 2: tools/small_batch_scan.sh)
+    // replicas up to which the most-cells grid is taken: every launch group that runs whole (scanned again in round 6, profiles/r06_d_cells_scan.txt:
+    // 180 instead of 120 cells +5.4 % at 9 replicas, +2.4 % at 18; batches of 32 and more run as two half batches that fill the chip together and
+    // are fastest with the largest cells: 120 against 180 cells 378 / 372 evaluations/s at 36, 422 / 417 at 72, 441 / 429 at 144)
+    static const int small_max = scema_env("SCEMA_MD_SMALL_BATCH_MAX") ? atoi(scema_env("SCEMA_MD_SMALL_BATCH_MAX")) : 31;
+    const bool small_batch = ns <= small_max;
     static const int cells_target = scema_env("SCEMA_MD_CELLS_TARGET") ? atoi(scema_env("SCEMA_MD_CELLS_TARGET")) : 0;
     for (int pass = 0; pass < 2 && !fits; pass++) {
       int lo[3], hi[3];
@@ -470,7 +474,21 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     else while (pair_lp < 2 && (wgs << (pair_lp + 1)) <= parts_fill) pair_lp++;
     for (int pos = 0; pos < ns; pos++) e->h_sims[pos].pair_lparts = pair_lp;
   }
-  const int pair_parts = 1 << pair_lp;
+  // ... or only the LAST replicas of every launch (SCEMA_MD_PAIR_TAIL="n:parts"): the workgroups that run while the launch drains are shorter
+  int tail_n = 0, tail_lp = 0;
+  if (pair_lp == 0) {
+    static const char *tail_env = scema_env("SCEMA_MD_PAIR_TAIL");
+    int tn = 0, tp = 1;
+    if (tail_env && sscanf(tail_env, "%d:%d", &tn, &tp) == 2 && tn > 0 && tp > 1) {
+      while ((2 << tail_lp) <= std::min(tp, PAIR_MAXPARTS)) tail_lp++;
+      tail_n = tn;
+      for (int h = 0; h < nhalf; h++)
+        for (int k = std::max(0, hcnt[h] - tail_n); k < hcnt[h]; k++) e->h_sims[hbeg[h] + k].pair_lparts = tail_lp;
+    }
+  }
+  const int pair_parts = 1 << std::max(pair_lp, tail_lp);
+  // the split replicas among the first na of half h (the batch is sorted by steps: the active replicas are a prefix)
+  auto pair_ntail = [&](int h, int na) { return tail_lp > 0 ? std::max(0, na - std::max(0, hcnt[h] - tail_n)) : -1; };
   if ((size_t)64 * 3 * mmax * 16 + 4096 > 160 * 1024)
     return fail(e, SCEMA_MD_ERR_ARG, "k-space index range (|n| up to %d) too large for the LDS phase tables; raise cut_coul or loosen kspace_accuracy", mmax - 1);
   HIPCHK(e->d_kpack.ensure(kpack.size() * sizeof(int) + 64));
@@ -593,6 +611,12 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   }
   const int ev = (spec.sample || spec.ev_always || (spec.nh && spec.npt)) ? 1 : 0;   // the barostat needs the virial of every step
   const bool allow_side = nhalf == 1;
+  // The replicas of a launch (a half batch where the batch runs as two) rebuild their rows together (k_cell_build), at every batch size: same
+  // box, own trigger / together, evaluations/s: 2 replicas 118.3 / 122.5, 4: 189.0 / 204.6, 9: 263.8 / 297.6, 18: 319.0 / 348.4, 24: 331.7 / 357.1,
+  // 36: 378.3 / 405.7, 72: 425.4 / 438.2, 144: 447.8 / 450.3, 288: 458.4 / 458.6, 576: 462.8 / 463.3 (profiles/r06_g_ab.log, r06_h_ab.log).
+  // SCEMA_MD_REBUILD_TOGETHER = 0: every replica on its own trigger.
+  static const bool together_on = !(scema_env("SCEMA_MD_REBUILD_TOGETHER") && atoi(scema_env("SCEMA_MD_REBUILD_TOGETHER")) == 0);
+  const bool nb_together = ns > 1 && together_on;
   // ---- setup (step 0) ----
   for (int h = 0; h < nhalf; h++) {
     hipStream_t st = hs[h];
@@ -600,9 +624,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     const int nh = hcnt[h];
     mdk_phase_init(st, Dh, nh);
     if (any_validate) mdk_keep_validate(st, Dh, nh, maxatoms);
-    mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj);
+    mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj, true, nb_together);
     { const int rcp = pppm_fork(st, hbeg[h], nh, true); if (rcp) return rcp; }
-    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts);
+    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, -1, pair_ntail(h, nh));
     HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
     if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], nh, true); if (rcp) return rcp; }
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
@@ -633,7 +657,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
         mdk_min_pre(st, D, ns);
         mdk_min_move(st, D, ns, maxatoms, x0s, hsd);
         mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
-        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly, P.cut_coul <= P.cut_lj, pair_parts);
+        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, -1, pair_ntail(0, ns));
         HIPCHK(force_stage(e, st, false, D, ns, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, 1, 0));
         { const int rcp = pppm_stage(st, 0, ns, false); if (rcp) return rcp; }
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
@@ -673,7 +697,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // (a single replica: 14.2 against 17.4 us); a thread per SHAKE cluster gathers less well than the three kernels stream, so large
   // batches keep them (576 replicas: 452 against 426 us).  SCEMA_MD_FUSED_TAIL = 0 / 1 forces either.
   static const int fused_tail_env = scema_env("SCEMA_MD_FUSED_TAIL") ? atoi(scema_env("SCEMA_MD_FUSED_TAIL")) : -1;
-  const bool fused_tail = (fused_tail_env < 0 ? ns <= 32 : fused_tail_env != 0) && !spec.nh && maxk == 0 && !spec.ev_always;
+  const bool fused_tail = (fused_tail_env < 0 ? hcnt[0] <= 32 : fused_tail_env != 0) && !spec.nh && maxk == 0 && !spec.ev_always;   // (by the size of a launch: a batch of 36 as two halves +0.9 %, of 72 +-0, of 144 -0.3 %, profiles/r06_i_ab.log)
   // List rebuilds beside the pair kernel (round 6; a what-if that LOST and is off unless SCEMA_MD_NB_SIDE=1 asks for it): a step of 9 replicas
   // spends 67 of its 290 us in the cell / list kernels of the ONE replica that rebuilds, on a quarter of the chip, while the other eight
   // wait.  With those kernels on a stream of their own beside a first pair launch for the replicas whose rows stand, and a second pair
@@ -685,28 +709,32 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   static const int nb_side_max = scema_env("SCEMA_MD_NB_SIDE_MAX") ? atoi(scema_env("SCEMA_MD_NB_SIDE_MAX")) : 0;
   const bool nb_side = nhalf == 1 && e->stream3 != nullptr && e->ev_nb_fork != nullptr && !spec.nh && !spec.ev_always &&
                        (nb_side_env < 0 ? ns < nb_side_max : nb_side_env != 0);
-  // ... and the end of the step inside that pass (k_finish's last workgroup of a replica does k_post's work: one launch less again), and the
-  // bonded kernel behind the PPPM chain on the side stream on steps whose chain is short (no new influence function): a single replica's step
-  // is two chains of dependent launches, the pair chain the longer one on those steps.  SCEMA_MD_FUSED_POST / SCEMA_MD_BONDED_SIDE = 0: off.
-  static const bool fused_post = !(scema_env("SCEMA_MD_FUSED_POST") && atoi(scema_env("SCEMA_MD_FUSED_POST")) == 0);
+  // The bonded kernel behind the PPPM chain on the side stream on steps whose chain is short (no new influence function), for batches of 8
+  // replicas and more, where the pair kernel is the longer of the step's two chains of dependent launches: +4 % at 9 replicas, +2 % at 18;
+  // below 8 the PPPM chain is the longer one and the move costs 4-8 % (profiles/r06_d_ab.log).  SCEMA_MD_BONDED_SIDE = 0: off.
+  // (k_post's work inside k_finish -- the replica's last workgroup, found by a ticket, does the end of the step -- was built and measured in
+  // the same series: nothing at 1-4 replicas, where k_finish, k_post, k_remap and k_initial_integrate already run back to back without a gap,
+  // and -2.5 / -3.6 % at 9 / 18 replicas, where the device-scope release and acquire around the ticket write back and invalidate the XCD's L2
+  // with the replica's freshly stored velocities and forces in it.  Removed.)
   static const bool bonded_side_on = !(scema_env("SCEMA_MD_BONDED_SIDE") && atoi(scema_env("SCEMA_MD_BONDED_SIDE")) == 0);
+  static const int bonded_side_min = scema_env("SCEMA_MD_BONDED_SIDE_MIN") ? atoi(scema_env("SCEMA_MD_BONDED_SIDE_MIN")) : 8;
   auto launch_step = [&](int h, int na, bool timed) -> int {
     hipStream_t st = hs[h];
     const SimDev *Dh = D + hbeg[h];
     if (spec.nh) { mdk_pre_nh(st, Dh, na); mdk_initial_integrate_nh(st, Dh, na, maxatoms); }
     else mdk_initial_integrate(st, Dh, na, maxatoms, fuse_pack);   // (its k_pre: at the end of the step before, in k_post; for step 1 below)
     // the PPPM chain needs the new positions only: it leaves for its side stream before the list kernels are issued, not behind them
-    const bool bonded_side = bonded_side_on && pppm_side && fused_tail && !(spec.deform || (spec.nh && spec.npt));
+    const bool bonded_side = bonded_side_on && pppm_side && fused_tail && ns >= bonded_side_min && !(spec.deform || (spec.nh && spec.npt));
     { const int rcp = pppm_fork(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt), bonded_side); if (rcp) return rcp; }
     if (nb_side) {
       // the cell / list kernels (which leave at once for a replica that does not rebuild: the usual case) on a stream of their own, beside
       // the pair forces of the replicas whose rows stand; the replicas that do rebuild get their pair forces in a second launch behind it
       HIPCHK(hipEventRecord(e->ev_nb_fork, st));
       HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_nb_fork, 0));
-      mdk_neighbor(e->stream3, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack);
+      mdk_neighbor(e->stream3, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack, nb_together);
       HIPCHK(hipEventRecord(e->ev_nb_join, e->stream3));
     } else
-      mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack);
+      mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack, nb_together);
     if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;
@@ -718,11 +746,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
     if (nb_side) {
-      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, 0);
+      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, 0, pair_ntail(h, na));
       HIPCHK(hipStreamWaitEvent(st, e->ev_nb_join, 0));
-      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, 1);
+      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, 1, pair_ntail(h, na));
     } else
-      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts);
+      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, -1, pair_ntail(h, na));
     if (timed) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;
@@ -734,7 +762,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       if (!bonded_side) mdk_bonded(st, Dh, na, maxbt, maxloc, maxcoef, 0);
       if (pppm_side) HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
       else { const int rcp = pppm_stage(st, hbeg[h], na, spec.deform, 0); if (rcp) return rcp; }
-      mdk_finish(st, Dh, na, maxunits, ev, maxgrid > 0 ? 1 : 0, fused_post ? 2 : 0);
+      mdk_finish(st, Dh, na, maxunits, ev, maxgrid > 0 ? 1 : 0);
     } else {
       HIPCHK(force_stage(e, st, allow_side, Dh, na, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
       if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt)); if (rcp) return rcp; }
@@ -742,7 +770,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       mdk_final_integrate(st, Dh, na, maxatoms, 1);
     }
     if (spec.nh) mdk_post_nh(st, Dh, na);
-    else if (!(fused_tail && fused_post)) mdk_post(st, Dh, na, 1);
+    else mdk_post(st, Dh, na, 1);
     if (spec.deform) mdk_remap(st, Dh, na, maxatoms);
     return SCEMA_MD_OK;
   };

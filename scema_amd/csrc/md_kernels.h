@@ -7,13 +7,13 @@ void mdk_keep_validate(hipStream_t st, const SimDev *d, int ns, int maxatoms);
 void mdk_setup_post(hipStream_t st, const SimDev *d, int ns);
 void mdk_pre(hipStream_t st, const SimDev *d, int ns);
 void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, bool pack = false);   // pack: also the slot records of k_pair (then no k_pack)
-void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj, bool pack = true);
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj, bool pack = true, bool together = false);   // together: as soon as one replica of the launch rebuilds its rows, all do (k_cell_build)
 void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int maxrow, int capj);
 // dynamic LDS of the tile kernels for a j-table capacity (the engine sizes the cell grid so that these fit)
 size_t mdk_pair_lds_bytes(int capj);
 size_t mdk_neigh_lds_bytes(int capj, int maxrow);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly, int cle = 0, int parts = 1, int pass = -1);   // cle: cut_coul <= cut_lj for the whole batch; parts: workgroups per tile (2^max pair_lparts); pass 0 / 1: only the replicas that do not / do rebuild their rows in this step
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly, int cle = 0, int parts = 1, int pass = -1, int ntail = -1);   // cle: cut_coul <= cut_lj for the whole batch; parts: workgroups per tile (2^max pair_lparts); pass 0 / 1: only the replicas that do not / do rebuild their rows in this step; ntail: the last ntail replicas of the launch are the split ones (-1: all)
 // bonded terms + special pairs, one workgroup per bonded tile; parts != 0: per-part virial/energy (parity hook)
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int maxcoef, int parts);
 // reciprocal Ewald sum in two parts, so that the first (structure factors; needs only positions) can run on a
@@ -23,7 +23,7 @@ void mdk_ewald_recip(hipStream_t st, const SimDev *d, int ns, int maxk, int mmax
 void mdk_ewald_force(hipStream_t st, const SimDev *d, int ns, int maxatoms, int pairvir, int fkeep = 0);   // fkeep: add to the forces a PPPM chain left in f
 void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfsq_scale);
 // assembly of f + fix shake + second half-kick in one pass (steps without a per-atom reciprocal sum); fkeep: PPPM forces wait in f
-void mdk_finish(hipStream_t st, const SimDev *d, int ns, int maxunits, int pairvir, int fkeep, int post = 0);   // post 1: k_post's work by the replica's last workgroup; 2: and the next step's k_pre
+void mdk_finish(hipStream_t st, const SimDev *d, int ns, int maxunits, int pairvir, int fkeep);
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick);
 void mdk_post(hipStream_t st, const SimDev *d, int ns, int next_pre = 0);
 void mdk_remap(hipStream_t st, const SimDev *d, int ns, int maxatoms);

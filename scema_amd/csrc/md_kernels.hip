@@ -386,10 +386,20 @@ __device__ __forceinline__ void pack_slot(const SimDev &S, int s, int a, double 
 // atoms.  Larger replicas keep the three kernels above (mdk_neighbor decides; SCEMA_MD_CELL_BUILD=0 forces them).
 #define CB_TPB 1024
 #define CB_MAXATOMS 65536
-__global__ __launch_bounds__(CB_TPB) void k_cell_build(const SimDev *sims) {
+// coord > 0 (small launch groups that run whole, run_phase): the replicas of the launch rebuild TOGETHER -- as soon as one of them asks for
+// it, all do.  A lone replica's rebuild keeps a quarter of the chip busy at the speed of its latencies (110-140 us for PE-10k) while the rest
+// of the group waits: at 9 replicas that was 70 us of every 330-us step; nine rebuilds in one set of launches take little longer than one.
+// Building a list before its displacement test asks for it is always valid (results do not depend on when a list is built).
+__global__ __launch_bounds__(CB_TPB) void k_cell_build(const SimDev *sims, int coord) {
   const SimDev &S = sims[blockIdx.x];
   SimScalars &sc = *S.sc;
-  if (!sc.rebuild) return;
+  if (coord > 0) {
+    int any = 0;
+    for (int j = threadIdx.x; j < coord; j += CB_TPB) any |= sims[j].sc->rebuild;   // (set by the kernels before this one; a flag raised below by another workgroup of this launch only confirms what its own scan found)
+    any = __syncthreads_or(any);
+    if (!any) return;
+    if (threadIdx.x == 0) sc.rebuild = 1;   // for the kernels behind this one
+  } else if (!sc.rebuild) return;
   __shared__ int s_cnt[BIN_MAXCELLS], s_start[BIN_MAXCELLS];
   __shared__ int s_wsum[CB_TPB / 64];
   const int ncells = S.ncells, natoms = S.natoms;
@@ -1155,11 +1165,7 @@ __device__ __forceinline__ void finish_cluster(const SimDev &S, const BoxD &b, i
 #pragma unroll
   for (int a = 0; a <= NB; a++) kick_atom(S, ia[a], invm[a], f[a], v0[a], ke);
 }
-__device__ __forceinline__ void post_scalars(const SimDev &S, SimScalars &sc);
-// post: the end of the step (k_post's work, and the k_pre of the next step where `post` is 2) is done by the LAST workgroup of the replica to
-// have added its sums -- a ticket per replica, taken behind the workgroup's atomics with release/acquire at device scope -- instead of by a
-// launch of its own: a batch of a few replicas is a chain of dependent launches 6-7 us apart, and k_post is 10 us of one thread (round 6)
-__global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairvir, int fkeep, int post) {
+__global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairvir, int fkeep) {
   const SimDev &S = sims[blockIdx.y];
   SimScalars &sc = *S.sc;
   const int nunits = S.use_shake ? S.nclus + S.nfree : S.natoms;
@@ -1202,29 +1208,6 @@ __global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairv
   }
   if (S.use_shake) block_atomic_add<6>(sv, sc.vir + P_SHAKE * 6, s_red);
   block_atomic_add<6>(ke, sc.ke, s_red);
-  if (post) {
-    __shared__ int s_last, s_more;
-    __threadfence();   // this thread's atomics are performed at device scope ...
-    __syncthreads();   // ... for every thread of the workgroup, before its ticket is taken
-    if (threadIdx.x == 0) {
-      const int nblk = (nunits + TPB - 1) / TPB;
-      const int t = __hip_atomic_fetch_add(&sc.post_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (t == nblk - 1);
-      s_more = 0;
-      if (s_last) {
-        __hip_atomic_store(&sc.post_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the sums of all workgroups, not what this CU's caches may hold of them
-        post_scalars(S, sc);
-        s_more = post == 2 && sc.step < S.nsteps;
-        if (s_more) pre_scalars(S, sc);
-      }
-    }
-    __syncthreads();
-    if (s_last && s_more) {
-      for (int k = threadIdx.x; k < 2 * S.nk; k += TPB) S.sfac[k] = 0.0;
-      for (int k = threadIdx.x; k < S.ncells; k += TPB) S.cell_count[k] = 0;
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1232,6 +1215,7 @@ __global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairv
 // ------------------------------------------------------------------------------------------
 // next_pre: a simulation with steps left also does the k_pre of its next step here (one launch less per step; the first step of a run
 // has its own k_pre)
+__device__ __forceinline__ void post_scalars(const SimDev &S, SimScalars &sc);
 __global__ void k_post(const SimDev *sims, int next_pre) {
   const SimDev &S = sims[blockIdx.x];
   SimScalars &sc = *S.sc;
@@ -1348,9 +1332,9 @@ void mdk_initial_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms
   if (pack) hipLaunchKernelGGL(k_initial_integrate<true>, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
   else hipLaunchKernelGGL(k_initial_integrate<false>, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d);
 }
-void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj, bool pack) {
+void mdk_neighbor(hipStream_t st, const SimDev *d, int ns, int maxatoms, int maxpad, int maxcells, int maxrow, int capj, bool pack, bool together) {
   static const bool one_launch = !(scema_env("SCEMA_MD_CELL_BUILD") && atoi(scema_env("SCEMA_MD_CELL_BUILD")) == 0);
-  if (one_launch && maxatoms <= CB_MAXATOMS && maxcells <= BIN_MAXCELLS) hipLaunchKernelGGL(k_cell_build, dim3(ns), dim3(CB_TPB), 0, st, d);
+  if (one_launch && maxatoms <= CB_MAXATOMS && maxcells <= BIN_MAXCELLS) hipLaunchKernelGGL(k_cell_build, dim3(ns), dim3(CB_TPB), 0, st, d, together ? ns : 0);
   else {
     hipLaunchKernelGGL(k_bin, grid2(cdiv(maxatoms, TPB * BIN_APT), ns), dim3(TPB), 0, st, d);
     hipLaunchKernelGGL(k_cell_scan, dim3(ns), dim3(TPB), 0, st, d);
@@ -1392,8 +1376,8 @@ void mdk_shake(hipStream_t st, const SimDev *d, int ns, int maxclus, double dtfs
   if (maxclus <= 0) return;
   hipLaunchKernelGGL(k_shake, grid2(cdiv(maxclus, TPB), ns), dim3(TPB), 0, st, d, dtfsq_scale);
 }
-void mdk_finish(hipStream_t st, const SimDev *d, int ns, int maxunits, int pairvir, int fkeep, int post) {
-  hipLaunchKernelGGL(k_finish, grid2(cdiv(maxunits, TPB), ns), dim3(TPB), 0, st, d, pairvir, fkeep, post);
+void mdk_finish(hipStream_t st, const SimDev *d, int ns, int maxunits, int pairvir, int fkeep) {
+  hipLaunchKernelGGL(k_finish, grid2(cdiv(maxunits, TPB), ns), dim3(TPB), 0, st, d, pairvir, fkeep);
 }
 void mdk_final_integrate(hipStream_t st, const SimDev *d, int ns, int maxatoms, int kick) {
   hipLaunchKernelGGL(k_final_integrate, grid2(cdiv(maxatoms, TPB), ns), dim3(TPB), 0, st, d, kick);

@@ -85,8 +85,7 @@ struct SimScalars {
   int nlwin;
   int pppm_ticket;     // k_pppm_solve as two workgroups per replica: how many of them have read the charge grid (the last one zeroes it)
   // minimiser state (one line search at a time, decided on the device between two force evaluations)
-  int min_phase, min_stop, min_iter, min_neval, min_newdir;
-  int post_ticket;     // k_finish with the end of the step inside: workgroups of this replica that have added their sums (the last one does k_post's work)
+  int min_phase, min_stop, min_iter, min_neval, min_newdir, pad2_;
   double min_alpha_now, min_alpha_next;   // where x sits on the current search line before / after the move of this evaluation (min_incremental)
   double min_alpha, min_alphamax, min_fdothall, min_eorig, min_eprev, min_fhprev, min_engprev, min_alphaprev, min_fh_trial, min_ecur, min_einit;
   double min_dots[4];  // f.h, f.f, max |f| of the last evaluation (+ spare)
