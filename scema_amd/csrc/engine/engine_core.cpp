@@ -48,11 +48,6 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_SPLIT_MAX", "launch groups of this many replicas and more run whole instead of as two half batches (default: none)"},
     {"SCEMA_MD_SPLIT", "0: never run a launch group of 32 simulations and more as two half batches on two streams"},
     {"SCEMA_MD_PPPM_SIDE_MIN", "smallest batch whose PPPM chain runs on the side stream next to the pair kernel (default 1; 4 until round 5)"},
-    {"SCEMA_MD_PAIR_PARTS", "workgroups per tile of the pair kernel (1, 2, 4, 8; default: by the size of the launch group -- groups that do not fill the chip split their tiles)"},
-    {"SCEMA_MD_PAIR_TAIL", "n:parts -- only the last n replicas of every pair launch run their tiles as `parts` workgroups (what-if: shorter workgroups while the launch drains)"},
-    {"SCEMA_MD_PAIR_FILL", "workgroups of a pair launch up to which its tiles are split once more (default 1536 = three rounds of the chip's 512 slots)"},
-    {"SCEMA_MD_NB_SIDE", "0 / 1: the cell and list kernels of a step on the main stream before the pair kernel / on a stream of their own beside the pair forces of the replicas that do not rebuild (default: off -- measured and lost, DESIGN.md 5.4)"},
-    {"SCEMA_MD_NB_SIDE_MAX", "batch size below which the list kernels run beside the pair kernel (default 0: never)"},
     {"SCEMA_MD_CELLS_TARGET", "what-if: take the cell grid (= tiling of the pair kernel) whose number of cells is closest to this among the grids that fit"},
     {"SCEMA_MD_ONE_STREAM", "no side stream (bonded / k-space chain beside the pair kernel)"},
     {"SCEMA_MD_KEEP_LIST", "0: the sampling run of an evaluation rebuilds its neighbour rows at its start even where those of the straining run still hold"},
@@ -141,6 +136,9 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     delete e;
     return SCEMA_MD_ERR_DEVICE;  // no GPU: the product path has no CPU fallback
   }
+  // (hipExtStreamCreateWithCUMask for the streams of the two half batches -- odd CUs for one, even CUs for the other, every XCD in both sets --
+  // was measured in round 6, VERDICT r5 item 5: 439.3 / 441.9 against 441.7 / 441.9 evaluations/s at 72 replicas, 469.3 / 469.1 against 469.6 /
+  // 469.6 at 576, profiles/r06_l_cumask_ragged_ab.log.  Neither half gains from not sharing CUs with the other; removed.)
   if (hipSetDevice(e->p.device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
     delete e;
     return SCEMA_MD_ERR_DEVICE;
@@ -149,10 +147,6 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
   if (const char *sp = scema_env("SCEMA_MD_SPLIT_MAX")) e->split_max = std::max(0, atoi(sp));
   if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess)
     e->stream3 = nullptr;   // an optimisation only
-  if (e->stream3 && (hipEventCreateWithFlags(&e->ev_nb_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_nb_join, hipEventDisableTiming) != hipSuccess)) {
-    if (e->ev_nb_fork) (void)hipEventDestroy(e->ev_nb_fork);
-    e->ev_nb_fork = e->ev_nb_join = nullptr;
-  }
   if (const char *sx = scema_env("SCEMA_MD_SKIN_EXTRA")) e->skin_extra_fixed = std::max(-0.75 * e->p.skin, atof(sx));
   if (const char *sx = scema_env("SCEMA_MD_SKIN_ADAPT")) e->skin_adapt = atoi(sx) != 0;
   if (!scema_env("SCEMA_MD_ONE_STREAM")) {
@@ -187,8 +181,6 @@ void scema_md_destroy(scema_md_engine *e) {
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-  if (e->ev_nb_fork) (void)hipEventDestroy(e->ev_nb_fork);
-  if (e->ev_nb_join) (void)hipEventDestroy(e->ev_nb_join);
   if (e->rx_fork) (void)hipEventDestroy(e->rx_fork);
   if (e->rx_side1) (void)hipStreamDestroy(e->rx_side1);
   for (int k = 0; k < 4; k++) if (e->rx_side1_ev[k]) (void)hipEventDestroy(e->rx_side1_ev[k]);

@@ -8,7 +8,6 @@ namespace scema_eng {
 // one "run" of a batch
 // -------------------------------------------------------------------------------------------
 // slots: every cell is padded to a multiple of MD_CLUSTER slots (i-clusters never straddle cells)
-static const int PAIR_MAXPARTS = 8;   // workgroups a tile of k_pair may run as (SimDev::pair_lparts <= 3)
 static int padded_slots(int natoms, int ncells) { return (natoms + (MD_CLUSTER - 1) * ncells + 255) / 256 * 256; }
 
 int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncells, int nk, int capj) {
@@ -46,7 +45,7 @@ int ensure_slot(scema_md_engine *e, Slot &sl, int natoms, int maxneigh, int ncel
     HIPCHK(sl.cell_fill.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.tile_nj.ensure((size_t)(ncells + 1) * 4));
     HIPCHK(sl.tile_wstart.ensure((size_t)(ncells + 1) * 9 * 4));
-    HIPCHK(sl.virp.ensure((size_t)(ncells + 1) * PAIR_MAXPARTS * MD_TILE_WAVES * 6 * 8));   // a row of 6 per (cell, part, wave) of k_pair
+    HIPCHK(sl.virp.ensure((size_t)(ncells + 1) * MD_TILE_WAVES * 6 * 8));
     sl.cap_cells = ncells + 1;
   }
   if ((size_t)ncells * capj > sl.cap_jtab || sl.cap_jtab == 0) {
@@ -459,36 +458,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     maxunits = std::max(maxunits, S.use_shake ? S.nclus + S.nfree : S.natoms);
     maxsteps = std::max(maxsteps, A.nsteps);
   }
-  // Workgroups per tile of k_pair: every tile as 2, 4 or 8 workgroups, each with a part of every row (md_pair.hip) -- the what-if of
-  // VERDICT r5 item 1c for launch groups that do not fill the chip's 512 workgroup slots.  Measured in round 6: it LOSES at
-  // every batch size from 1 to 18 replicas (a single replica: k_pair 40.3 -> 38.1 us with four parts, but the update 14.6 -> 15.9 ms) -- the
-  // rows are a small part of a lone tile's life next to its table load and its flush, whose memory-side atomics grow with the parts, and
-  // the extra workgroups take the CUs the PPPM chain beside it runs on.  So the default is one workgroup per tile whatever the size;
-  // SCEMA_MD_PAIR_PARTS forces a number, SCEMA_MD_PAIR_FILL a fill target.
-  int pair_lp = 0;
-  {
-    static const int parts_env = scema_env("SCEMA_MD_PAIR_PARTS") ? atoi(scema_env("SCEMA_MD_PAIR_PARTS")) : 0;
-    static const int parts_fill = scema_env("SCEMA_MD_PAIR_FILL") ? atoi(scema_env("SCEMA_MD_PAIR_FILL")) : 0;
-    const long wgs = (long)hcnt[0] * std::max(maxcells, 1);
-    if (parts_env > 0) { while ((2 << pair_lp) <= std::min(parts_env, PAIR_MAXPARTS)) pair_lp++; }
-    else while (pair_lp < 2 && (wgs << (pair_lp + 1)) <= parts_fill) pair_lp++;
-    for (int pos = 0; pos < ns; pos++) e->h_sims[pos].pair_lparts = pair_lp;
-  }
-  // ... or only the LAST replicas of every launch (SCEMA_MD_PAIR_TAIL="n:parts"): the workgroups that run while the launch drains are shorter
-  int tail_n = 0, tail_lp = 0;
-  if (pair_lp == 0) {
-    static const char *tail_env = scema_env("SCEMA_MD_PAIR_TAIL");
-    int tn = 0, tp = 1;
-    if (tail_env && sscanf(tail_env, "%d:%d", &tn, &tp) == 2 && tn > 0 && tp > 1) {
-      while ((2 << tail_lp) <= std::min(tp, PAIR_MAXPARTS)) tail_lp++;
-      tail_n = tn;
-      for (int h = 0; h < nhalf; h++)
-        for (int k = std::max(0, hcnt[h] - tail_n); k < hcnt[h]; k++) e->h_sims[hbeg[h] + k].pair_lparts = tail_lp;
-    }
-  }
-  const int pair_parts = 1 << std::max(pair_lp, tail_lp);
-  // the split replicas among the first na of half h (the batch is sorted by steps: the active replicas are a prefix)
-  auto pair_ntail = [&](int h, int na) { return tail_lp > 0 ? std::max(0, na - std::max(0, hcnt[h] - tail_n)) : -1; };
+  // (Round 6 measured three ways of giving a launch that does not fill the chip more, shorter workgroups of k_pair -- every tile as 2 / 4 / 8
+  // workgroups with a part of every row each; only the last replicas of a launch split that way; and the list kernels on a stream of their own
+  // beside a first pair launch for the replicas whose rows stand -- and all three LOST at every batch size from 1 to 144 replicas: DESIGN.md 5.4,
+  // profiles/r06_a_pair_parts_ab.log, r06_k_pair_tail_ab.log, r06_b_ab.log.  They were removed again; commit 992bf45 holds the code.)
   if ((size_t)64 * 3 * mmax * 16 + 4096 > 160 * 1024)
     return fail(e, SCEMA_MD_ERR_ARG, "k-space index range (|n| up to %d) too large for the LDS phase tables; raise cut_coul or loosen kspace_accuracy", mmax - 1);
   HIPCHK(e->d_kpack.ensure(kpack.size() * sizeof(int) + 64));
@@ -626,7 +599,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (any_validate) mdk_keep_validate(st, Dh, nh, maxatoms);
     mdk_neighbor(st, Dh, nh, maxatoms, maxpad, maxcells, maxrow, maxcapj, true, nb_together);
     { const int rcp = pppm_fork(st, hbeg[h], nh, true); if (rcp) return rcp; }
-    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, -1, pair_ntail(h, nh));
+    mdk_pair(st, Dh, nh, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
     HIPCHK(force_stage(e, st, allow_side, Dh, nh, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, spec.ev_always, (ev && !spec.ev_always) ? 1 : 0, pppm_side));
     if (!pppm_side) { const int rcp = pppm_stage(st, hbeg[h], nh, true); if (rcp) return rcp; }
     if (!spec.static_only) mdk_shake(st, Dh, nh, maxclus, 0.5);
@@ -657,7 +630,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
         mdk_min_pre(st, D, ns);
         mdk_min_move(st, D, ns, maxatoms, x0s, hsd);
         mdk_neighbor(st, D, ns, maxatoms, maxpad, maxcells, maxrow, maxcapj);
-        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, -1, pair_ntail(0, ns));
+        mdk_pair(st, D, ns, maxcells, maxcapj, 1, 1, maxpoly, P.cut_coul <= P.cut_lj);
         HIPCHK(force_stage(e, st, false, D, ns, maxbt, maxloc, maxcoef, maxatoms, maxk, mmax, maxgrp, 1, 0));
         { const int rcp = pppm_stage(st, 0, ns, false); if (rcp) return rcp; }
         mdk_min_reduce(st, D, ns, maxatoms, hsd);
@@ -698,17 +671,6 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // batches keep them (576 replicas: 452 against 426 us).  SCEMA_MD_FUSED_TAIL = 0 / 1 forces either.
   static const int fused_tail_env = scema_env("SCEMA_MD_FUSED_TAIL") ? atoi(scema_env("SCEMA_MD_FUSED_TAIL")) : -1;
   const bool fused_tail = (fused_tail_env < 0 ? hcnt[0] <= 32 : fused_tail_env != 0) && !spec.nh && maxk == 0 && !spec.ev_always;   // (by the size of a launch: a batch of 36 as two halves +0.9 %, of 72 +-0, of 144 -0.3 %, profiles/r06_i_ab.log)
-  // List rebuilds beside the pair kernel (round 6; a what-if that LOST and is off unless SCEMA_MD_NB_SIDE=1 asks for it): a step of 9 replicas
-  // spends 67 of its 290 us in the cell / list kernels of the ONE replica that rebuilds, on a quarter of the chip, while the other eight
-  // wait.  With those kernels on a stream of their own beside a first pair launch for the replicas whose rows stand, and a second pair
-  // launch for the others: 228 against 238-248 evaluations/s at 9 replicas, 295 against 308 at 18, 70 against 73 for a single one
-  // (profiles/r06_b_ab.log).  The trace says why (profiles/r06_c_nb_timeline_9sims.txt): the list kernel's 1 080 workgroups of 80 kB of LDS
-  // each, which leave at once on a step without a rebuild, cannot start while the pair launch holds every CU's LDS -- 44 us instead of 4 --,
-  // the pair launch beside them runs 177 instead of 157 us, and the second pair launch and its event edges add 19 us to every step.
-  static const int nb_side_env = scema_env("SCEMA_MD_NB_SIDE") ? atoi(scema_env("SCEMA_MD_NB_SIDE")) : -1;
-  static const int nb_side_max = scema_env("SCEMA_MD_NB_SIDE_MAX") ? atoi(scema_env("SCEMA_MD_NB_SIDE_MAX")) : 0;
-  const bool nb_side = nhalf == 1 && e->stream3 != nullptr && e->ev_nb_fork != nullptr && !spec.nh && !spec.ev_always &&
-                       (nb_side_env < 0 ? ns < nb_side_max : nb_side_env != 0);
   // The bonded kernel behind the PPPM chain on the side stream on steps whose chain is short (no new influence function), for batches of 8
   // replicas and more, where the pair kernel is the longer of the step's two chains of dependent launches: +4 % at 9 replicas, +2 % at 18;
   // below 8 the PPPM chain is the longer one and the move costs 4-8 % (profiles/r06_d_ab.log).  SCEMA_MD_BONDED_SIDE = 0: off.
@@ -726,15 +688,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     // the PPPM chain needs the new positions only: it leaves for its side stream before the list kernels are issued, not behind them
     const bool bonded_side = bonded_side_on && pppm_side && fused_tail && ns >= bonded_side_min && !(spec.deform || (spec.nh && spec.npt));
     { const int rcp = pppm_fork(st, hbeg[h], na, spec.deform || (spec.nh && spec.npt), bonded_side); if (rcp) return rcp; }
-    if (nb_side) {
-      // the cell / list kernels (which leave at once for a replica that does not rebuild: the usual case) on a stream of their own, beside
-      // the pair forces of the replicas whose rows stand; the replicas that do rebuild get their pair forces in a second launch behind it
-      HIPCHK(hipEventRecord(e->ev_nb_fork, st));
-      HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_nb_fork, 0));
-      mdk_neighbor(e->stream3, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack, nb_together);
-      HIPCHK(hipEventRecord(e->ev_nb_join, e->stream3));
-    } else
-      mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack, nb_together);
+    mdk_neighbor(st, Dh, na, maxatoms, maxpad, maxcells, maxrow, maxcapj, spec.nh != 0 || !fuse_pack, nb_together);
     if (timed) {
       if (ev_used + 2 > e->ev_pool.size()) {
         hipEvent_t a, b;
@@ -745,12 +699,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
-    if (nb_side) {
-      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, 0, pair_ntail(h, na));
-      HIPCHK(hipStreamWaitEvent(st, e->ev_nb_join, 0));
-      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, 1, pair_ntail(h, na));
-    } else
-      mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj, pair_parts, -1, pair_ntail(h, na));
+    mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
     if (timed) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;

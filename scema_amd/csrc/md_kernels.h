@@ -13,7 +13,7 @@ void mdk_neigh_build(hipStream_t st, const SimDev *d, int ns, int maxcells, int 
 size_t mdk_pair_lds_bytes(int capj);
 size_t mdk_neigh_lds_bytes(int capj, int maxrow);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly, int cle = 0, int parts = 1, int pass = -1, int ntail = -1);   // cle: cut_coul <= cut_lj for the whole batch; parts: workgroups per tile (2^max pair_lparts); pass 0 / 1: only the replicas that do not / do rebuild their rows in this step; ntail: the last ntail replicas of the launch are the split ones (-1: all)
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly, int cle = 0);   // cle: cut_coul <= cut_lj for the whole batch
 // bonded terms + special pairs, one workgroup per bonded tile; parts != 0: per-part virial/energy (parity hook)
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int maxcoef, int parts);
 // reciprocal Ewald sum in two parts, so that the first (structure factors; needs only positions) can run on a

@@ -911,7 +911,7 @@ __global__ __launch_bounds__(EWF_T) void k_ewald_force(const SimDev *sims, int p
       }
     }
   if (pairvir) {
-    const int nrows = (S.ncells << S.pair_lparts) * MD_TILE_WAVES;   // one row of 6 per cell, part and wave of k_pair
+    const int nrows = S.ncells * MD_TILE_WAVES;   // one row of 6 per cell and wave of k_pair
     const int nblk = (S.natoms + EWF_T * EWF_APT - 1) / (EWF_T * EWF_APT);   // blocks of this simulation that got this far
     for (int r = blockIdx.x * EWF_T + threadIdx.x; r < nrows; r += nblk * EWF_T) {
       const double *vp = S.virp + (size_t)r * 6;
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairv
   }
   if (pairvir) {
     const int nblk = (nunits + TPB - 1) / TPB;   // blocks of this simulation that got this far
-    const int nrows = (S.ncells << S.pair_lparts) * MD_TILE_WAVES;  // one row of 6 per cell, part and wave of k_pair
+    const int nrows = S.ncells * MD_TILE_WAVES;  // one row of 6 per cell and wave of k_pair
     for (int r = blockIdx.x * TPB + threadIdx.x; r < nrows; r += nblk * TPB) {
       const double *vp = S.virp + (size_t)r * 6;
 #pragma unroll

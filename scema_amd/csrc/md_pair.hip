@@ -43,34 +43,14 @@ extern __shared__ double s_pair[];  // [capj][3] reaction-force accumulators, th
 // CLE: the coulomb cutoff does not exceed the LJ cutoff (the reference's 9 / 12): every interacting lane has an LJ term, which then
 // defines the force factor without a zero to start from, and the cutoff test is one instead of two
 template <bool VIR, bool ENG, int NP, bool CLE = false>
-__global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj, int lparts, int pass, int ntail) {
-  // Launch groups that cannot fill the chip with one workgroup per tile (a single replica: 120 tiles on 512 workgroup slots) run every
-  // tile as 2^lparts workgroups: part p of P takes the chunks [C p / P, C (p + 1) / P) of EVERY row of the tile -- the schedule entry's
-  // own mechanism for parts of rows --, with its own LDS accumulators and its own flush.  Consecutive blocks of an XCD are the parts of
-  // one tile (same j table, same records: that XCD's L2).  A replica whose 2^SimDev::pair_lparts is smaller than the launch's leaves the
-  // surplus workgroups at once.  Results do not depend on the split (FP64 atomics: to the summation order).
-  // ntail < nsims: only the LAST ntail replicas of the launch are split (the blocks behind those of the others): the workgroups that run
-  // when the launch drains are then a quarter as long -- the tail of a launch of some ten rounds of workgroups is one workgroup's life.
-  int sim, cell, part = 0;
-  const int head = nsims - ntail, nhead = head * ntiles;
-  if ((int)blockIdx.x < nhead) {
-    if (!xcd_map_at((int)blockIdx.x, ntiles, head, sim, cell)) return;
-  } else {
-    if (!xcd_map_at((int)blockIdx.x - nhead, ntiles << lparts, ntail, sim, cell)) return;
-    sim += head;
-    part = cell & ((1 << lparts) - 1);
-    cell >>= lparts;
-  }
+__global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims, int ntiles, int nsims, int capj) {
+  int sim, cell;
+  if (!xcd_map(ntiles, nsims, sim, cell)) return;
   const SimDev &S = sims[sim];
   if (cell >= S.ncells) return;
-  // pass 0 / 1: only the replicas that do not / do rebuild their neighbour rows in this step (run_phase launches the kernel twice where the
-  // rebuild chain of the few rebuilding replicas runs on another stream beside the pair forces of the others); -1: every replica
-  if (pass >= 0 && (S.sc->rebuild != 0) != (pass != 0)) return;
-  const int lnp = S.pair_lparts, nparts = 1 << lnp;   // (this replica's parts, 1, 2, 4, ...: they size its virp rows)
-  if (part >= nparts) return;
   const int cs = S.cell_start[cell], ce = S.cell_start[cell + 1];
   if (ce == cs) {   // empty cell: its virial partials are still read by k_ewald_force
-    if (VIR && !ENG && threadIdx.x < TW * 6) S.virp[((size_t)cell * nparts + part) * TW * 6 + threadIdx.x] = 0.0;
+    if (VIR && !ENG && threadIdx.x < TW * 6) S.virp[(size_t)cell * TW * 6 + threadIdx.x] = 0.0;
     return;
   }
   SimScalars &sc = *S.sc;
@@ -112,9 +92,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     const int ent = S.tile_order[2 * (cs / NI) + p_begin + lane];
     h_cl = ent & 0xFFFFF;
     const int n = S.numneigh[2 * h_cl] + (need_far ? S.numneigh[2 * h_cl + 1] : 0);   // [A|B|C1], then C2
-    int pa = (ent >> 20) & 31, pb = (ent >> 25) & 31;
-    if (lnp > 0) { const int w = pb - pa, a0 = pa; pa = a0 + ((w * part) >> lnp); pb = a0 + ((w * (part + 1)) >> lnp); }   // this workgroup's part of the entry's range
-    const int C = (n + 63) >> 6;
+    const int C = (n + 63) >> 6, pa = (ent >> 20) & 31, pb = (ent >> 25) & 31;
     const int kb = 64 * ((C * pa) >> 4), ke = 64 * ((C * pb) >> 4);   // whole chunks: the row's last one is padded with empty entries
     h_nn = (max(ke, kb) << 16) | kb;
   }
@@ -414,7 +392,7 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
     }
   }
   if (VIR && !ENG) {
-    double *vp = S.virp + (((size_t)cell * nparts + part) * TW + wave) * 6;
+    double *vp = S.virp + ((size_t)cell * TW + wave) * 6;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const double t = wave_sum(vl[k]);
@@ -447,35 +425,32 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
 
 size_t mdk_pair_lds_bytes(int capj) { return (size_t)capj * (3 * sizeof(double) + sizeof(int)); }
 template <bool VIR, bool ENG, int NP, bool CLE = false>
-static void launch_pair_v(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj, int lparts, int pass, int ntail) {
+static void launch_pair_v(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj) {
   const size_t lds = mdk_pair_lds_bytes(capj);
   static size_t optin_tab[16] = {0};
   size_t &optin = lds_optin_slot(optin_tab);
   if (lds > 48 * 1024 && lds > optin) { (void)hipFuncSetAttribute((const void *)k_pair<VIR, ENG, NP, CLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); optin = lds; }
-  hipLaunchKernelGGL((k_pair<VIR, ENG, NP, CLE>), dim3((unsigned)((ns - ntail) * ntiles + ntail * (ntiles << lparts)), 1, 1), dim3(TT), lds, st, d, ntiles, ns, capj, lparts, pass, ntail);
+  hipLaunchKernelGGL((k_pair<VIR, ENG, NP, CLE>), grid_xcd(ntiles, ns), dim3(TT), lds, st, d, ntiles, ns, capj);
 }
 
 template <int NP>
-static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj, int vir, int eng, int cle, int lp, int pass, int ntail) {
-  if (eng) launch_pair_v<true, true, NP>(st, d, ns, ntiles, capj, lp, pass, ntail);
-  else if (vir) { if (cle) launch_pair_v<true, false, NP, true>(st, d, ns, ntiles, capj, lp, pass, ntail); else launch_pair_v<true, false, NP>(st, d, ns, ntiles, capj, lp, pass, ntail); }
-  else { if (cle) launch_pair_v<false, false, NP, true>(st, d, ns, ntiles, capj, lp, pass, ntail); else launch_pair_v<false, false, NP>(st, d, ns, ntiles, capj, lp, pass, ntail); }
+static void launch_pair(hipStream_t st, const SimDev *d, int ns, int ntiles, int capj, int vir, int eng, int cle) {
+  if (eng) launch_pair_v<true, true, NP>(st, d, ns, ntiles, capj);
+  else if (vir) { if (cle) launch_pair_v<true, false, NP, true>(st, d, ns, ntiles, capj); else launch_pair_v<true, false, NP>(st, d, ns, ntiles, capj); }
+  else { if (cle) launch_pair_v<false, false, NP, true>(st, d, ns, ntiles, capj); else launch_pair_v<false, false, NP>(st, d, ns, ntiles, capj); }
 }
 
-void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly, int cle, int parts, int pass, int ntail) {
-  if (ntail < 0 || ntail > ns) ntail = ns;   // (-1: every replica of the launch is split)
-  int lp = 0;
-  while ((2 << lp) <= parts) lp++;   // parts = 2^(the largest SimDev::pair_lparts of the launch)
-  if (npoly <= 6) launch_pair<6>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 8) launch_pair<8>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 10) launch_pair<10>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 14) launch_pair<14>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 15) launch_pair<15>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 16) launch_pair<16>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 18) launch_pair<18>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 20) launch_pair<20>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 24) launch_pair<24>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else if (npoly <= 32) launch_pair<32>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
-  else launch_pair<MD_MAXPOLY>(st, d, ns, maxcells, capj, vir, eng, cle, lp, pass, ntail);
+void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly, int cle) {
+  if (npoly <= 6) launch_pair<6>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 8) launch_pair<8>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 10) launch_pair<10>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 12) launch_pair<12>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 14) launch_pair<14>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 15) launch_pair<15>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 16) launch_pair<16>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 18) launch_pair<18>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 20) launch_pair<20>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 24) launch_pair<24>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else if (npoly <= 32) launch_pair<32>(st, d, ns, maxcells, capj, vir, eng, cle);
+  else launch_pair<MD_MAXPOLY>(st, d, ns, maxcells, capj, vir, eng, cle);
 }

@@ -29,7 +29,8 @@
 // groups of 8 simulations; the last nsims % 8 simulations (all of them in a small batch, e.g. the
 // single-replica check of BASELINE config 2) spread their tiles over all XCDs instead, so no XCD
 // idles.  Placement only affects speed, never results.
-__device__ __forceinline__ bool xcd_map_at(int L, int ntiles, int nsims, int &sim, int &tile) {
+__device__ __forceinline__ bool xcd_map(int ntiles, int nsims, int &sim, int &tile) {
+  const int L = blockIdx.x;
   const int full = nsims & ~7;
   if (L < full * ntiles) {
     const int x = L & 7, w = L >> 3;
@@ -42,8 +43,6 @@ __device__ __forceinline__ bool xcd_map_at(int L, int ntiles, int nsims, int &si
   }
   return sim < nsims;
 }
-
-__device__ __forceinline__ bool xcd_map(int ntiles, int nsims, int &sim, int &tile) { return xcd_map_at((int)blockIdx.x, ntiles, nsims, sim, tile); }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -163,7 +163,7 @@ struct SimDev {
   int MD_G *slot_of;     // atom -> slot
   int MD_G *tile_nj;     // per cell: entries of its j table
   int MD_G *tile_order;  // per cell, at its cluster range: the cell's clusters grouped by the wave of k_pair that takes them
-  double MD_G *virp;     // per cell, part (pair_lparts) and wave of k_pair: 6 partial sums of the pair virial's image-shift part (no atomics)
+  double MD_G *virp;     // per cell and wave of k_pair: 6 partial sums of the pair virial's image-shift part (no atomics)
   int MD_G *tile_wstart; // per cell: 9 group boundaries into tile_order (k_pair's schedule, fixed at build time)
   int MD_G *tile_jtab;   // per cell: capj entries (image code | slot), own cell first
   // pair structures
@@ -183,8 +183,7 @@ struct SimDev {
   double MD_G *sfac;     // 2 per k
   double MD_G *kvec;     // 4 per k : kx,ky,kz,ug
   // PPPM (md_pppm.hip; pg[0] == 0: the Ewald sum above is used)
-  int pg[3];
-  int pair_lparts;         // k_pair runs every tile of this replica as 2^pair_lparts workgroups (launch groups too small to fill the chip); virp has a row of 6 per (cell, part, wave)
+  int pg[3], pad_pg_;
   double MD_G *pgrid;    // complex grid [nz][ny][nx] (x fastest) of this simulation: charge density / its transform
   double MD_G *pfield;   // the three complex field grids of this simulation, pgstride complex elements apart (the batch keeps the charge
                     // grids of all simulations together, and all field grids: one batched, contiguous transform per direction)
