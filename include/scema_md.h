@@ -346,8 +346,9 @@ int scema_md_get_concurrency(const scema_md_engine *e, int32_t *out);
  * info[6]: longest neighbour row, row capacity, bond-row capacity, CG iterations, image search (0 = minimum image), longest bond row */
 int scema_md_reax_debug_compute(scema_md_engine *e, int32_t qp_id, const char *matid, int32_t replica, double *f, double *eparts,
                                 double *virial, double *q, double *info);
-/* out[6]: conjugate-gradient iterations, solves (two systems each), list skin, tolerance, solves finished by the single-workgroup
- * loop, iterations currently issued as batch launches per solve */
+/* out[7]: conjugate-gradient iterations, solves (two systems each), list skin, tolerance, solves finished by the single-workgroup
+ * loop, iterations currently issued as batch launches per solve, evaluations repeated with the Jacobi preconditioner of fix qeq/reax
+ * because the charge solve did not converge with the engine's own */
 int scema_md_reax_stats(const scema_md_engine *e, double *out);
 
 typedef struct {

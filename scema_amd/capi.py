@@ -474,10 +474,10 @@ class Engine:
         return length, dict(stop=int(info[0]), iterations=int(info[1]), evaluations=int(info[2]), e_initial=info[3], e_final=info[4])
 
     def reax_stats(self) -> dict:
-        out = np.zeros(6)
+        out = np.zeros(7)
         self._chk(lib().scema_md_reax_stats(self.h, _p(out)))
         return dict(qeq_iters=int(out[0]), qeq_solves=int(out[1]), skin=out[2], qeq_tol=out[3], qeq_slow_solves=int(out[4]),
-                    qeq_launched_iters=int(out[5]))
+                    qeq_launched_iters=int(out[5]), precond_fallbacks=int(out[6]))
 
     def profile(self, reset=False) -> dict:
         p = Profile()

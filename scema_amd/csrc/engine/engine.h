@@ -303,6 +303,8 @@ struct scema_md_engine {
   int split_min = 32, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
                                          // at 576 and left large groups whole; with round 4's kernels the halves give 437 against 429, profiles/r04_zs_*)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool rx_qeq_failed = false;             // the last ReaxFF run ended with a charge solve that did not converge (eval_chunk's one retry with the Jacobi preconditioner)
+  long long rx_precond_fallbacks = 0;     // evaluations that were repeated that way
   bool rx_precond = true;                 // bonded-pattern sparse approximate inverse as the preconditioner of the charge equilibration (SCEMA_REAX_QEQ_PRECOND=0: the reference's Jacobi one)
   int rx_halves = 2, rx_overlap = 1;      // scema_md_reax_concurrency: part batches (1 = one sequence of launches) and side streams (initial values from SCEMA_REAX_HALVES / SCEMA_REAX_OVERLAP)
   // ReaxFF runs as rx_halves part batches on as many streams (part 0: stream + stream2), each with a side stream for its bond-order chain and

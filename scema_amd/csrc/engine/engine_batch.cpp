@@ -71,7 +71,13 @@ static int backup_states(scema_md_engine *e, std::vector<ActiveSim> &chunk, bool
 // full evaluation (phase A + phase B) of a chunk of simulations, with overflow retry
 int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt &opt, size_t pool_off) {
   const int ns = (int)chunk.size();
+  // ReaxFF: the approximate-inverse preconditioner of the charge solve is symmetrised by hand and not guaranteed positive definite on every
+  // geometry; conjugate gradients that stall on it end the run with "did not converge".  The evaluation is then repeated ONCE
+  // from its backup with the preconditioner fix qeq/reax itself uses (the diagonal), which is, before the error is reported.
+  struct PrecondScope { scema_md_engine *e; bool saved; ~PrecondScope() { e->rx_precond = saved; } } precond_scope{e, e->rx_precond};
+  bool precond_retry = false;
   for (int attempt = 0; attempt < 6; attempt++) {
+    e->rx_qeq_failed = false;
     int rc = prepare_slots(e, chunk);
     if (rc) return rc;
     // backup for a retry after neighbour overflow
@@ -115,6 +121,16 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
       }
       e->prof.evals += ns;
       return SCEMA_MD_OK;
+    }
+    if (rc != SCEMA_MD_ERR_OVERFLOW && e->rx_qeq_failed && e->rx_precond && !precond_retry) {
+      precond_retry = true;
+      e->rx_precond = false;
+      e->rx_precond_fallbacks += 1;
+      fprintf(stderr, "[scema_md] the charge equilibration did not converge with the approximate-inverse preconditioner: the evaluation of these %d replicas is repeated with the Jacobi preconditioner of fix qeq/reax\n", ns);
+      rc = backup_states(e, chunk, true, pool_off);
+      if (rc) return rc;
+      HIPCHK(hipStreamSynchronize(e->stream));
+      continue;
     }
     if (rc != SCEMA_MD_ERR_OVERFLOW) {
       // instability, box error, non-finite stress, device error: the reference would have stopped before write_restart

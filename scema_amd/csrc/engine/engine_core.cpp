@@ -80,6 +80,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_TEST_FAIL_INCOMING", "rank on which the allocation of a state that migrates in fails (-1: on whichever rank receives one); the failure must reach every rank through the handshake"},
     {"SCEMA_MD_TEST_FAIL_MIGRATE", "<what>[:<rank>] -- an injected failure of the exchange of replica states: dbox / upload (before the handshake: every rank ends the call, nothing is posted), enqueue / group / hostcopy (after it: the exchange is completed, the error travels in the status word of the stress all-gather)"},
     {"SCEMA_MD_TEST_SELF_MOVE", "1 (RCCL, one rank): every simulation that continues from a state held here receives it through ncclSend / ncclRecv from this very rank"},
+    {"SCEMA_MD_TEST_QEQ_PRECOND_FAILS", "1: a ReaxFF run whose charge solve uses the approximate-inverse preconditioner reports that it did not converge (the evaluation must come back from its one retry with the Jacobi preconditioner)"},
     {"SCEMA_MD_QCAP16", "capacity of k_neigh_build's group lists in sixteenths of the table: small values force the whole-table walk"},
     {"SCEMA_MD_RX_COL32", "32-bit column indices in the ReaxFF charge matrix whatever the replica size"},
     {"SCEMA_MD_RX_NB_ONCE", "0: the both-ends ReaxFF non-bonded kernel"},

@@ -111,7 +111,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   bool col16 = !(scema_env("SCEMA_MD_RX_COL32") && atoi(scema_env("SCEMA_MD_RX_COL32")) != 0);   // (test switch: 32-bit columns for any size)
   for (int i = 0; i < ns; i++) col16 = col16 && sims[i].st->topo->natoms <= 65536;
   e->h_zerotab.clear();
-  bool any_precond = false, any_validate = false;
+  bool any_precond = false, any_validate = false, inject_precond_failure = false;
   bool all_sym = col16 && e->rx_sym;
   for (int pos = 0; pos < ns; pos++) {
     const int i = order[pos];
@@ -244,6 +244,7 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     RXSET(V.s_hist, R.s_hist.as<double>()); RXSET(V.t_hist, R.t_hist.as<double>()); RXSET(V.qwork, R.qwork.as<double>());
     // the bonded-pattern preconditioner needs one image per neighbour (boxes at least two list radii wide: every production replica)
     V.pm_on = (e->rx_precond && V.mimg[0] == 0 && V.mimg[1] == 0 && V.mimg[2] == 0) ? 1 : 0;
+    if (V.pm_on && scema_env("SCEMA_MD_TEST_QEQ_PRECOND_FAILS")) inject_precond_failure = true;   // test hook: this run reports a solve that did not converge
     any_precond = any_precond || V.pm_on;
     // the symmetric form of the solve: rows sorted by partner (one image per neighbour), both vectors of the replica in a workgroup's LDS
     all_sym = all_sym && V.mimg[0] == 0 && V.mimg[1] == 0 && V.mimg[2] == 0 && 2 * (size_t)npad * 16 + 4096 <= 128 * 1024;
@@ -352,7 +353,10 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     int fault_m = 0;
     for (int i = 0; i < ns; i++) fault_m |= e->h_sc[i].overflow;
     if (fault_m & 16) return fail(e, SCEMA_MD_ERR_ARG, "a simulation became unstable during the minimisation (non-finite positions)");
-    if (fault_m & 32) return fail(e, SCEMA_MD_ERR_ARG, "charge equilibration did not converge to %.1e in %d iterations", e->rx_qeq_tol, e->rx_qeq_maxiter);
+    if (fault_m & 32) {
+      e->rx_qeq_failed = true;   // (eval_chunk retries once with the reference's Jacobi preconditioner if the approximate inverse was on)
+      return fail(e, SCEMA_MD_ERR_ARG, "charge equilibration did not converge to %.1e in %d iterations", e->rx_qeq_tol, e->rx_qeq_maxiter);
+    }
     e->overflow_bits = (fault_m & 1) ? 8 : 0;
     if (fault_m & 1) return SCEMA_MD_ERR_OVERFLOW;
     if (!all_done) return fail(e, SCEMA_MD_ERR_ARG, "minimiser did not stop within its evaluation budget");
@@ -504,7 +508,10 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     if (most_cold > 0) e->rx_qeq_launch_cold = std::max(4, most_cold + 1);
   }
   if (fault & 16) return fail(e, SCEMA_MD_ERR_ARG, "a simulation became unstable (non-finite or runaway atom positions): overlapping atoms or a time step too long for ReaxFF");
-  if (fault & 32) return fail(e, SCEMA_MD_ERR_ARG, "charge equilibration did not converge to %.1e in %d iterations", e->rx_qeq_tol, e->rx_qeq_maxiter);
+  if ((fault & 32) || inject_precond_failure) {
+      e->rx_qeq_failed = true;   // (eval_chunk retries once with the reference's Jacobi preconditioner if the approximate inverse was on)
+      return fail(e, SCEMA_MD_ERR_ARG, "charge equilibration did not converge to %.1e in %d iterations", e->rx_qeq_tol, e->rx_qeq_maxiter);
+    }
   e->overflow_bits = ((fault & 1) ? (1 | 8) : 0) | (fault & 64);
   if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
   if (fault & 64) return SCEMA_MD_ERR_OVERFLOW;   // the barostat took the box out of the range this segment was laid out for
@@ -685,6 +692,7 @@ int scema_md_reax_stats(const scema_md_engine *e, double *out) {
   out[3] = e->rx_qeq_tol;
   out[4] = (double)e->rx_qeq_slow;
   out[5] = (double)e->rx_qeq_launch;
+  out[6] = (double)e->rx_precond_fallbacks;
   return SCEMA_MD_OK;
 }
 

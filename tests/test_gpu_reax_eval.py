@@ -206,3 +206,50 @@ def test_kept_reax_neighbour_rows_equal_rebuilt_ones(tmp_path):
     assert np.abs(a - b).max() < 1e-7 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
     assert res["keep"]["steps"] == res["nokeep"]["steps"]
     assert res["keep"]["builds"] <= res["nokeep"]["builds"] - 4, (res["keep"]["builds"], res["nokeep"]["builds"])
+
+
+def test_a_charge_solve_that_fails_with_the_engines_preconditioner_is_repeated_with_the_references(gold, scripts, monkeypatch):
+    """the approximate-inverse preconditioner of the charge equilibration is symmetrised by hand and not guaranteed positive
+    definite on every geometry; a solve that does not converge with it must not end the update before the evaluation has been repeated
+    once with the Jacobi preconditioner of fix qeq/reax.  The system is the H/C/N/O mixture (not polyethylene: four elements, every type
+    pair) as a 2 x 2 x 2 supercell -- the 21-A cell itself is thinner than two list radii and keeps the Jacobi preconditioner anyway; the
+    periodic copy has the same dynamics and therefore the oracle's stress of the single cell.  First as it is: the engine's preconditioner
+    is on (few iterations per solve) and no retry is needed.  Then with a run that REPORTS a failed solve whenever that preconditioner is
+    on (SCEMA_MD_TEST_QEQ_PRECOND_FAILS): the evaluation comes back from its retry, counted, within the tolerance of the oracle's stress."""
+    sym1, x1, box1, v1 = _mixture(gold)
+    L = box1[3:6] - box1[:3]
+    shifts = np.array([[i, j, k] for i in range(2) for j in range(2) for k in range(2)], float) * L
+    sym = sym1 * 8
+    x = np.concatenate([x1 + s for s in shifts])
+    v = np.concatenate([v1] * 8)
+    box = np.array(box1, float)
+    box[3:6] = box[:3] + 2.0 * L
+    ch = gold["mixture"]["chains"][0]
+    exp = np.array(ch["evals"][0]["stress"])
+    strain = 2.0 * np.array(ch["evals"][0]["strain_len"])     # the same strain: lengths are in A
+    res = {}
+    for name, hook in (("plain", False), ("retry", True)):
+        if hook:
+            monkeypatch.setenv("SCEMA_MD_TEST_QEQ_PRECOND_FAILS", "1")
+        e = capi.Engine()
+        e.register_replica("g0", 1, capi.reax_system(sym, x, box, v=v))
+        out = e.strain_batch([_sim(0, strain, gold, scripts, capi.QP_NONE)])
+        res[name] = np.array(list(out[0].stress))
+        st = e.reax_stats()
+        its = st["qeq_iters"] / st["qeq_solves"]
+        err = np.abs(res[name] - exp).max() / np.abs(exp).max()
+        print(f"reax mixture 2x2x2 ({len(sym)} atoms), {name}: max rel err vs the oracle's single cell {err:.2e}, {its:.1f} CG iterations per solve, "
+              f"evaluations repeated with the Jacobi preconditioner {st['precond_fallbacks']}")
+        assert st["precond_fallbacks"] == (1 if hook else 0), (name, st)
+        assert out[0].stress_updated and err < TOL, (name, err)
+        if not hook:
+            assert its < 9.0, its      # the approximate inverse is on for this system (Jacobi: 12-13 iterations per solve)
+        else:
+            assert its > 9.0, its      # the evaluation that counts ran with the Jacobi preconditioner
+            # the engine's own setting is back after the retry: the next evaluation uses the approximate inverse again
+            monkeypatch.delenv("SCEMA_MD_TEST_QEQ_PRECOND_FAILS")
+            out2 = e.strain_batch([_sim(0, 0.5 * strain, gold, scripts, 0)])
+            assert out2[0].stress_updated and e.reax_stats()["precond_fallbacks"] == 1
+        e.close()
+    # the two answers differ by the solver's tolerance, not more
+    assert np.abs(res["retry"] - res["plain"]).max() < 1e-4 * np.abs(res["plain"]).max()
