@@ -72,7 +72,6 @@ const EnvSwitch k_env[] = {
     {"SCEMA_REAX_OVERLAP", "0: the bond-order chain of the ReaxFF force stage on the same stream as the charge chain instead of next to it"},
     {"SCEMA_REAX_QEQ_PRECOND", "0: the conjugate gradients of the charge equilibration with the Jacobi preconditioner of fix qeq/reax instead of the bonded-pattern approximate inverse"},
     {"SCEMA_REAX_QEQ_SYM", "0: the matrix of the charge equilibration as full rows (every pair in both rows) instead of each pair once in its owner's row"},
-    {"SCEMA_REAX_QEQ_FUSED", "what-if: 1 = the vector step of a conjugate-gradient iteration inside the symmetric sweep (the replica's last workgroup, found by a ticket) instead of a launch of its own"},
     {"SCEMA_REAX_QEQ_ZLDS", "0: the matrix sweep of the charge equilibration gathers through the caches instead of from an LDS copy"},
     {"SCEMA_REAX_QEQ_LAUNCH", "conjugate-gradient iterations issued as launches per charge solve (default: adaptive)"},
     // test hooks: force rarely-taken paths

@@ -253,7 +253,6 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
     RXSET(V.qstat, (int *)(R.misc.as<char>() + 128));             // 6 ints
     RXSET(V.overflow, (int *)(R.misc.as<char>() + 160));
     RXSET(V.sweep_acc, (long long *)(R.misc.as<char>() + 168));   // 2 x 8 bytes
-    RXSET(V.qticket, (int *)(R.misc.as<char>() + 184));
     e->h_zerotab.push_back(MdkZero{sl.wrapn.as<int>(), 3 * (long long)n});
     e->h_sims[pos] = S;
     e->h_rxviews[pos] = V;

@@ -328,7 +328,9 @@ __global__ __launch_bounds__(PP_SOLVE_TPB) void k_pppm_solve(const SimDev *sims)
   if (two) {
     __shared__ int s_last;
     if (threadIdx.x == 0) {
-      const int t = __hip_atomic_fetch_add(&S.sc->pppm_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      // (relaxed: this workgroup's reads of the grid are complete -- their values are in LDS, behind the barrier above --, and nothing it wrote is
+      // read by the other; a release / acquire at device scope would write back and invalidate this XCD's L2)
+      const int t = __hip_atomic_fetch_add(&S.sc->pppm_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = (t == 1);
       if (t == 1) __hip_atomic_store(&S.sc->pppm_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

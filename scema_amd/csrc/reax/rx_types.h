@@ -153,7 +153,6 @@ typedef struct {
   int RX_G *overflow;          // bit 1: neighbour row full, bit 2: bond row full, bit 4: charge equilibration did not converge
   long long RX_G *sweep_acc;   // [2] since the start of the run: matrix entries and rows that launches of k_rx_qeq_sweep passed over for this
                           // replica (stored entries of its rows x sweeps it took part in): the kernel's algorithmic traffic (bench.py)
-  int RX_G *qticket;           // symmetric sweep with the vector step inside (what-if): workgroups of the replica that have flushed their part of y
 } RxView;
 #ifdef __cplusplus
 static_assert(sizeof(double RX_G *) == sizeof(double *), "the qualified pointers of RxView have the size of plain ones: host and device passes see one layout");
