@@ -626,3 +626,39 @@ def test_kept_neighbour_rows_equal_rebuilt_ones(small_pe):
     # 6 evaluations x 2 runs rebuild at their start without the kept rows; with them only the very first run of each state and the run
     # that follows the replaced state do
     assert keep["builds"] <= nokeep["builds"] - 6, (keep["builds"], nokeep["builds"])
+
+
+def test_round6_launch_variants_give_the_same_stresses(small_pe):
+    """Round 6 changed WHEN and WHERE things run for small batches, never what is computed: the replicas of a launch rebuild their neighbour
+    rows together as soon as one asks for it (SCEMA_MD_REBUILD_TOGETHER=0: each on its own trigger), the bonded kernel follows the PPPM chain on
+    the side stream for batches of 8 and more (SCEMA_MD_BONDED_SIDE=0), the in-LDS PPPM solve of batches under 8 is two workgroups per replica
+    (SCEMA_MD_PPPM_SOLVE_TWO=0), every batch that runs whole takes the grid with the most cells (SCEMA_MD_SMALL_BATCH_MAX=0: the largest
+    cells).  A 9-replica update sequence with different strains per replica (so that their lists age differently) and a 2-replica one: the
+    same stresses with every switch, and more list builds with the common trigger than with the replicas' own."""
+    code = ("import json, os, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "d = build_pe(2, 3, 5, jitter=0.05, seed=7); d['box'][6:9] = [0.7, -0.4, 0.5]\n"
+            "kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)\n"
+            "e = capi.Engine(capi.default_params(**kw))\n"
+            "e.register_replica('pe', 1, d)\n"
+            "L = d['box'][3:6] - d['box'][:3]\n"
+            "st = np.array([-3e-4 * L[0], -3e-4 * L[1], 1e-3 * L[2], 2e-5 * L[2], 0, 0])\n"
+            "out = []\n"
+            "for n in (9, 2):\n"
+            "    a = e.strain_batch([capi.make_sim(100 * n + q, 'pe', 1, st * (1 + 0.3 * q), nss=40, most_recent=capi.QP_NONE) for q in range(n)])\n"
+            "    out += [list(o.stress) for o in a]\n"
+            "    a = e.strain_batch([capi.make_sim(100 * n + q, 'pe', 1, -st * (1 + 0.1 * q), nss=40) for q in range(n)])\n"
+            "    out += [list(o.stress) for o in a]\n"
+            "p = e.profile()\n"
+            "print(json.dumps({'s': out, 'builds': p['neigh_builds'], 'steps': p['md_steps']}))\n")
+    ref = _child(code, {})
+    a = np.array(ref["s"])
+    for env in ({"SCEMA_MD_REBUILD_TOGETHER": "0"}, {"SCEMA_MD_BONDED_SIDE": "0"}, {"SCEMA_MD_PPPM_SOLVE_TWO": "0"}, {"SCEMA_MD_SMALL_BATCH_MAX": "0"},
+                {"SCEMA_MD_REBUILD_TOGETHER": "0", "SCEMA_MD_BONDED_SIDE": "0", "SCEMA_MD_PPPM_SOLVE_TWO": "0", "SCEMA_MD_SMALL_BATCH_MAX": "0"}):
+        other = _child(code, env)
+        b = np.array(other["s"])
+        assert np.abs(a - b).max() < 1e-9 * np.abs(b).max(), (env, np.abs(a - b).max() / np.abs(b).max())
+        assert other["steps"] == ref["steps"]
+        if env.get("SCEMA_MD_REBUILD_TOGETHER") == "0" and len(env) == 1:
+            assert ref["builds"] >= other["builds"], (ref["builds"], other["builds"])   # a common trigger builds at least as often
