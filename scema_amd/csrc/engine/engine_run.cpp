@@ -584,12 +584,14 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   }
   const int ev = (spec.sample || spec.ev_always || (spec.nh && spec.npt)) ? 1 : 0;   // the barostat needs the virial of every step
   const bool allow_side = nhalf == 1;
-  // The replicas of a launch (a half batch where the batch runs as two) rebuild their rows together (k_cell_build), at every batch size: same
+  // The replicas of a launch (a half batch where the batch runs as two) rebuild their rows together (k_cell_build): same
   // box, own trigger / together, evaluations/s: 2 replicas 118.3 / 122.5, 4: 189.0 / 204.6, 9: 263.8 / 297.6, 18: 319.0 / 348.4, 24: 331.7 / 357.1,
   // 36: 378.3 / 405.7, 72: 425.4 / 438.2, 144: 447.8 / 450.3, 288: 458.4 / 458.6, 576: 462.8 / 463.3 (profiles/r06_g_ab.log, r06_h_ab.log).
-  // SCEMA_MD_REBUILD_TOGETHER = 0: every replica on its own trigger.
-  static const bool together_on = !(scema_env("SCEMA_MD_REBUILD_TOGETHER") && atoi(scema_env("SCEMA_MD_REBUILD_TOGETHER")) == 0);
-  const bool nb_together = ns > 1 && together_on;
+  // A common trigger fires at the earliest of the launch's replicas: with 288 of them per launch a list lives 12.6 instead of 18.2 steps, and
+  // the builds that adds (at full occupancy: +4 % list-build time) buy nothing where scattered rebuilds already find the chip full.  So: launches
+  // of fewer than 128 replicas.  SCEMA_MD_REBUILD_TOGETHER = 0 / 1: every replica on its own trigger / together at every size.
+  static const int together_env = scema_env("SCEMA_MD_REBUILD_TOGETHER") ? atoi(scema_env("SCEMA_MD_REBUILD_TOGETHER")) : -1;
+  const bool nb_together = ns > 1 && (together_env < 0 ? hcnt[0] < 128 : together_env != 0);
   // ---- setup (step 0) ----
   for (int h = 0; h < nhalf; h++) {
     hipStream_t st = hs[h];
