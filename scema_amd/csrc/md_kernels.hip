@@ -452,6 +452,16 @@ __global__ __launch_bounds__(CB_TPB) void k_cell_build(const SimDev *sims, int c
     S.slot_of[i] = atomicAdd(&s_cnt[cell], 1);
   }
   __syncthreads();
+#ifdef PAIR_WHATIF_TILE_ORDER
+  // what-if: the tiles of k_pair in descending order of their atoms (= rows), so that the last workgroups of a launch
+  // are the cheapest ones; the permutation lives in cell_fill, which this path does not use otherwise
+  for (int c = threadIdx.x; c < ncells; c += CB_TPB) {
+    const int mine = s_cnt[c];
+    int rank = 0;
+    for (int o = 0; o < ncells; o++) rank += (s_cnt[o] > mine || (s_cnt[o] == mine && o < c)) ? 1 : 0;
+    S.cell_fill[rank] = c;
+  }
+#endif
   // pass 2: cell starts = exclusive scan of the counts padded to whole clusters (a cluster of MD_CLUSTER consecutive slots never
   // straddles two cells); every slot is a pad slot until k_cell_sort places an atom there
   {

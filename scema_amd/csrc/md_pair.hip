@@ -48,6 +48,9 @@ __global__ __launch_bounds__(TT, 4) void k_pair(const SimDev *__restrict__ sims,
   if (!xcd_map(ntiles, nsims, sim, cell)) return;
   const SimDev &S = sims[sim];
   if (cell >= S.ncells) return;
+#ifdef PAIR_WHATIF_TILE_ORDER
+  cell = S.cell_fill[cell];   // (what-if: tiles dispatched in descending order of their atoms, k_cell_build)
+#endif
   const int cs = S.cell_start[cell], ce = S.cell_start[cell + 1];
   if (ce == cs) {   // empty cell: its virial partials are still read by k_ewald_force
     if (VIR && !ENG && threadIdx.x < TW * 6) S.virp[(size_t)cell * TW * 6 + threadIdx.x] = 0.0;
