@@ -436,12 +436,12 @@ def run_leg(args, rank, world, device, cpu, torch, dist):
     n = args.sims
     from scema_amd import capi
     # ablation knobs for kernel experiments only (never set in a reported run)
-    extra = {k[12:].lower(): float(v) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
+    extra = {k[12:].lower(): (int(float(v)) if float(v).is_integer() else float(v)) for k, v in os.environ.items() if k.startswith("SCEMA_BENCH_")}
     extra["kspace_style"] = 1 if args.kspace == "pppm" else 0
-    eng = capi.Engine(capi.default_params(device=device, profile=1, **extra))
+    eng = capi.Engine(capi.default_params(**dict(dict(device=device, profile=1), **extra)))
     collective, comm0 = None, {"allgathers": 0, "handshakes": 0, "migrations": 0}
     if world > 1:
-        eng, collective, comm0 = attach_comm(eng, lambda: capi.Engine(capi.default_params(device=device, profile=1, **extra)), args, rank, world, device, dist)
+        eng, collective, comm0 = attach_comm(eng, lambda: capi.Engine(capi.default_params(**dict(dict(device=device, profile=1), **extra))), args, rank, world, device, dist)
 
     # ---- equilibrated replica (outside the timed region): rank 0 runs it, every rank registers the same state ----
     if reax:

@@ -385,7 +385,7 @@ int scema_md_get_profile(scema_md_engine *e, scema_md_profile *out, int32_t rese
 int scema_md_env_overrides(char *buf, int cap);
 
 /* Calibration of the box a measurement ran on (no counterpart in the reference; measurement aid of bench.py): independent FP64 FMA
- * chains on every SIMD of the device, no memory traffic, ~0.2 s.  The boxes of a pool differ by several per cent under the pair
+ * chains on every SIMD of the device, no memory traffic, ~0.1 s (a warm-up launch, then the best of three).  The boxes of a pool differ by several per cent under the pair
  * kernel's full-chip FP64 load; this figure (74-75 TFLOP/s on an MI355X at its sustained clock, 78.6 on the data sheet) lets
  * throughput values of different boxes be normalised.  Needs a HIP device; returns SCEMA_MD_ERR_DEVICE without one. */
 int scema_md_box_fma_tflops(int32_t device, double *tflops);

@@ -27,13 +27,16 @@ extern "C" int scema_md_box_fma_tflops(int32_t device, double *tflops) {
   int rc = SCEMA_MD_ERR_DEVICE;
   float ms = 0.f;
   if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-    hipLaunchKernelGGL(k_ubench_fma64, dim3(blocks), dim3(threads), 0, 0, d, 2000, 0.999999);   // clocks up, code object loaded
-    if (hipEventRecord(e0, 0) == hipSuccess) {
+    // the clocks of a chip that has just run a light workload need tens of milliseconds of full load to settle: a warm-up launch as long as
+    // the measured ones, then the best of three (the figure is a ceiling)
+    hipLaunchKernelGGL(k_ubench_fma64, dim3(blocks), dim3(threads), 0, 0, d, iters, 0.999999);
+    for (int rep = 0; rep < 3; rep++) {
+      if (hipEventRecord(e0, 0) != hipSuccess) break;
       hipLaunchKernelGGL(k_ubench_fma64, dim3(blocks), dim3(threads), 0, 0, d, iters, 0.999999);
-      if (hipEventRecord(e1, 0) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f) {
-        *tflops = 2.0 * (double)blocks * threads * iters * 64.0 / ms / 1e9;   // 64 FMAs per lane and iteration, 2 flop each
-        rc = SCEMA_MD_OK;
-      }
+      if (hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) break;
+      const double tf = 2.0 * (double)blocks * threads * iters * 64.0 / ms / 1e9;   // 64 FMAs per lane and iteration, 2 flop each
+      if (tf > *tflops) *tflops = tf;
+      rc = SCEMA_MD_OK;
     }
   }
   if (e0) (void)hipEventDestroy(e0);
