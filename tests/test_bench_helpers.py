@@ -68,3 +68,28 @@ def test_the_ragged_strain_set_is_levelled_over_8_ranks_in_the_dry_run():
     sims = [r["sims"] for r in out["config"]["per_rank"]]
     assert sum(sims) == 576 and max(sims) - min(sims) >= 1 and min(sims) > 40
     assert out["config"]["state_migrations"] >= 1
+
+
+def test_pair_pmc_counters_belong_to_the_kernel_sources_of_this_tree():
+    """VERDICT r5 / ADVICE r5: roofline.frac_valu_issue prices this run's launch time with SQ_INSTS_VALU of profiles/pair_pmc.json, which was
+    counted on ONE build of k_pair.  The file records the git blob hashes of the kernel's sources; bench.py drops the figure when the tree's
+    differ.  Here: the hash function is git's, and the committed counters are those of the committed sources (a change of md_pair.hip without a
+    fresh tools/pmc_pair.sh run fails this test instead of silently leaving frac_valu_issue null in the driver's line)."""
+    import hashlib
+    import json
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.kernel_source_hashes()
+    assert set(have) == {"md_pair.hip", "md_pair_dev.h", "md_device.h", "md_types.h"}
+    data = open(os.path.join(ROOT, "scema_amd", "csrc", "md_pair.hip"), "rb").read()
+    assert have["md_pair.hip"] == hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    try:   # (where git is at hand: the same number git prints)
+        out = subprocess.run(["git", "hash-object", os.path.join(ROOT, "scema_amd", "csrc", "md_pair.hip")], capture_output=True, text=True, timeout=30)
+        if out.returncode == 0 and out.stdout.strip():
+            assert out.stdout.strip() == have["md_pair.hip"]
+    except (OSError, subprocess.TimeoutExpired):
+        pass
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pair_pmc.json")))
+    assert pmc["kernel_sources"] == have, "profiles/pair_pmc.json was counted on other sources of k_pair: run tools/pmc_pair.sh on the GPU box and commit its pair_pmc_<tag>.json"
+    assert pmc["valu_insts_per_sim_step"] > 1e6 and pmc["hbm_bytes_per_sim_step_corrected"] > 1e6
