@@ -888,7 +888,10 @@ def main():
         dist.destroy_process_group()
     if _ABANDONED:   # a thread is still inside RCCL: no interpreter shutdown through it
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        # the line above says "rccl_fallback": true; a caller that ASKED for RCCL on the command line also gets a distinct exit code,
+        # the default invocation (the driver's) keeps 0: its number is valid, measured over the host transport and labelled so
+        asked = any(a == "--dist-backend" or a.startswith("--dist-backend=") for a in sys.argv[1:]) and args.dist_backend == "nccl"
+        os._exit(3 if asked else 0)
 
 
 if __name__ == "__main__":
