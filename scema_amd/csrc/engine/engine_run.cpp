@@ -873,10 +873,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
             (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);
     {   // (the persistent form adds the clocks of ALL its tile visits to the first replica of the launch order: the sum over the batch finds them)
-      unsigned long long a[5] = {0, 0, 0, 0, 0};
-      for (int i = 0; i < ns; i++) for (int k = 0; k < 5; k++) a[k] += e->h_sc[i].dbg[k];
-      if (a[4]) fprintf(stderr, "[scema_md] pair kernel wave clocks (whole batch, mean per wave and tile visit): prologue %.0f, rows %.0f, wait %.0f, flush (+ staging) %.0f (%llu visits)\n",
-                        (double)a[0] / a[4], (double)a[1] / a[4], (double)a[2] / a[4], (double)a[3] / a[4], a[4]);
+      unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < ns; i++) for (int k = 0; k < 6; k++) a[k] += e->h_sc[i].dbg[k];
+      if (a[4]) fprintf(stderr, "[scema_md] pair kernel wave clocks (whole batch, mean per wave and tile visit): prologue %.0f, rows %.0f, wait %.0f, flush %.0f (of which staging %.0f) (%llu visits)\n",
+                        (double)a[0] / a[4], (double)a[1] / a[4], (double)a[2] / a[4], (double)a[3] / a[4], (double)a[5] / a[4], a[4]);
     }
     if (c.nbuilds > 0) {
       const double nw = (double)c.nbuilds * S0.ncells * MD_TILE_WAVES;
