@@ -303,7 +303,6 @@ struct scema_md_engine {
   int split_min = 32, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
                                          // at 576 and left large groups whole; with round 4's kernels the halves give 437 against 429, profiles/r04_zs_*)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  DevBuf d_pairq;                         // tile queues of the persistent pair kernel: eight counters (one per XCD) for each of the two streams a batch may run on
   bool rx_qeq_failed = false;             // the last ReaxFF run ended with a charge solve that did not converge (eval_chunk's one retry with the Jacobi preconditioner)
   long long rx_precond_fallbacks = 0;     // evaluations that were repeated that way
   bool rx_precond = true;                 // bonded-pattern sparse approximate inverse as the preconditioner of the charge equilibration (SCEMA_REAX_QEQ_PRECOND=0: the reference's Jacobi one)

@@ -49,9 +49,6 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_SPLIT", "0: never run a launch group of 32 simulations and more as two half batches on two streams"},
     {"SCEMA_MD_PPPM_SIDE_MIN", "smallest batch whose PPPM chain runs on the side stream next to the pair kernel (default 1; 4 until round 5)"},
     {"SCEMA_MD_CELLS_TARGET", "what-if: take the cell grid (= tiling of the pair kernel) whose number of cells is closest to this among the grids that fit"},
-    {"SCEMA_MD_PAIR_PERSIST", "0 / 1: the pair kernel as one workgroup per tile (k_pair) / as persistent workgroups that walk a queue of tiles with two tables in LDS (k_pair_p) where the system fits"},
-    {"SCEMA_MD_PAIR_PERSIST_WGS", "workgroups of the persistent pair kernel (default 256: one per CU)"},
-    {"SCEMA_MD_PAIR_PERSIST_MIN", "tiles of a launch from which the persistent pair kernel is used (default 2048)"},
     {"SCEMA_MD_ONE_STREAM", "no side stream (bonded / k-space chain beside the pair kernel)"},
     {"SCEMA_MD_KEEP_LIST", "0: the sampling run of an evaluation rebuilds its neighbour rows at its start even where those of the straining run still hold"},
     {"SCEMA_MD_SKIN_EXTRA", "list skin = params.skin + this many Angstrom (results do not depend on it)"},

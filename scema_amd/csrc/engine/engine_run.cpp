@@ -158,7 +158,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   e->h_sims.assign(ns, SimDev());
   int maxbt = 1, maxloc = 1, maxcoef = 0;
   bool any_validate = false;   // some simulation may keep the rows its slot holds from the update before (SimDev::keep_list == 2)
-  int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxunits = 0, maxsteps = 0, maxtypes = 1;
+  int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxunits = 0, maxsteps = 0;
   // k-vector tables of all simulations (indices, row run lengths, groups), packed into one upload
   std::vector<int> &kpack = e->h_kpack;
   kpack.clear();
@@ -452,7 +452,6 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     maxatoms = std::max(maxatoms, S.natoms); maxpad = std::max(maxpad, S.npad); maxcells = std::max(maxcells, S.ncells);
     maxk = std::max(maxk, S.nk);
     maxpoly = std::max(maxpoly, S.coul_npoly);
-    maxtypes = std::max(maxtypes, S.ntypes);
     for (int d = 0; d < 3; d++) mmax = std::max(mmax, S.kmaxd[d] + 1);
     maxb = std::max(maxb, S.nbonds); maxa = std::max(maxa, S.nangles); maxd = std::max(maxd, S.ndihedrals);
     maxi = std::max(maxi, S.nimpropers); maxs = std::max(maxs, S.nspecial); maxclus = std::max(maxclus, S.use_shake ? S.nclus : 0);
@@ -683,18 +682,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // with the replica's freshly stored velocities and forces in it.  Removed.)
   static const bool bonded_side_on = !(scema_env("SCEMA_MD_BONDED_SIDE") && atoi(scema_env("SCEMA_MD_BONDED_SIDE")) == 0);
   static const int bonded_side_min = scema_env("SCEMA_MD_BONDED_SIDE_MIN") ? atoi(scema_env("SCEMA_MD_BONDED_SIDE_MIN")) : 8;
-  // The pair kernel as persistent workgroups (md_pair_p.hip) for launches that give every CU several tiles; the parity / energy form and small
-  // launches keep k_pair.  SCEMA_MD_PAIR_PERSIST = 0 / 1: never / whenever the system fits; SCEMA_MD_PAIR_PERSIST_WGS: workgroups (default 256).
-  static const int persist_env = scema_env("SCEMA_MD_PAIR_PERSIST") ? atoi(scema_env("SCEMA_MD_PAIR_PERSIST")) : 0;
-  static const int persist_wgs = scema_env("SCEMA_MD_PAIR_PERSIST_WGS") ? std::max(8, atoi(scema_env("SCEMA_MD_PAIR_PERSIST_WGS"))) : 256;
-  static const int persist_min = scema_env("SCEMA_MD_PAIR_PERSIST_MIN") ? atoi(scema_env("SCEMA_MD_PAIR_PERSIST_MIN")) : 2048;
-  auto launch_pair_persistent = [&](int h, hipStream_t st, const SimDev *Dh, int na) -> bool {
-    if (persist_env == 0 || spec.ev_always || (long)na * maxcells < persist_min) return false;
-    if (e->d_pairq.ensure(2 * 8 * sizeof(unsigned long long)) != hipSuccess) return false;
-    unsigned long long *q = e->d_pairq.as<unsigned long long>() + 8 * h;
-    if (hipMemsetAsync(q, 0, 8 * sizeof(unsigned long long), st) != hipSuccess) return false;
-    return mdk_pair_persistent(st, Dh, na, maxcells, maxcapj, maxtypes, ev, maxpoly, P.cut_coul <= P.cut_lj, q, 0ull, persist_wgs);
-  };
+  // (The pair kernel as PERSISTENT workgroups -- one 1 024-thread workgroup per CU for the whole launch, two tiles in LDS, rows taken off LDS
+  // counters, no barrier between a tile's rows and its flush -- was built in two forms in round 6 to recover the quarter of a wave's life that
+  // k_pair spends outside its row loop, and lost: 405 / 342 against 463 / 451 evaluations/s at 576 replicas.  k_pair sits at 120 of 128 vector
+  // registers; the persistent shell's dozen extra live scalars tip the allocation into scratch reloads inside the row loop, whose every wait then
+  // covers all loads in flight.  profiles/r06_q_persistent_pair.txt has the wave clocks and the ISA counts; commit 2371531 holds the code.)
   auto launch_step = [&](int h, int na, bool timed) -> int {
     hipStream_t st = hs[h];
     const SimDev *Dh = D + hbeg[h];
@@ -714,7 +706,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
       HIPCHK(hipEventRecord(e->ev_pool[ev_used], st));
     }
-    if (!launch_pair_persistent(h, st, Dh, na)) mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
+    mdk_pair(st, Dh, na, maxcells, maxcapj, ev, spec.ev_always, maxpoly, P.cut_coul <= P.cut_lj);
     if (timed) {
       HIPCHK(hipEventRecord(e->ev_pool[ev_used + 1], st));
       ev_used += 2;
@@ -872,7 +864,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
               (double)c.dbg2[5] / c.dbg2[7], (double)c.dbg2[6] / c.dbg2[7]);
     fprintf(stderr, "[scema_md] k_pair wave clocks (sim 0, mean per wave): prologue %.0f, rows %.0f, barrier wait %.0f, flush %.0f (%llu waves)\n",
             (double)c.dbg[0] / c.dbg[4], (double)c.dbg[1] / c.dbg[4], (double)c.dbg[2] / c.dbg[4], (double)c.dbg[3] / c.dbg[4], c.dbg[4]);
-    {   // (the persistent form adds the clocks of ALL its tile visits to the first replica of the launch order: the sum over the batch finds them)
+    {   // (the same clocks summed over the whole batch)
       unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
       for (int i = 0; i < ns; i++) for (int k = 0; k < 6; k++) a[k] += e->h_sc[i].dbg[k];
       if (a[4]) fprintf(stderr, "[scema_md] pair kernel wave clocks (whole batch, mean per wave and tile visit): prologue %.0f, rows %.0f, wait %.0f, flush %.0f (of which staging %.0f) (%llu visits)\n",

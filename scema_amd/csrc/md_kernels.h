@@ -14,9 +14,6 @@ size_t mdk_pair_lds_bytes(int capj);
 size_t mdk_neigh_lds_bytes(int capj, int maxrow);
 // vir: accumulate the pair virial (needed when the pressure is sampled); eng: also energies (parity hook)
 void mdk_pair(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int vir, int eng, int npoly, int cle = 0);   // cle: cut_coul <= cut_lj for the whole batch
-// the production form of k_pair as persistent workgroups (md_pair_p.hip): queue = eight counters in device memory that read qbase (the caller zeroes them or
-// passes what they hold); false: this system does not fit the form (the caller launches mdk_pair)
-bool mdk_pair_persistent(hipStream_t st, const SimDev *d, int ns, int maxcells, int capj, int ntypes_max, int vir, int npoly, int cle, unsigned long long *queue, unsigned long long qbase, int nwg);
 // bonded terms + special pairs, one workgroup per bonded tile; parts != 0: per-part virial/energy (parity hook)
 void mdk_bonded(hipStream_t st, const SimDev *d, int ns, int maxtiles, int maxloc, int maxcoef, int parts);
 // reciprocal Ewald sum in two parts, so that the first (structure factors; needs only positions) can run on a
