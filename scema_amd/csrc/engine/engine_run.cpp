@@ -666,6 +666,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // Small batches are launch-bound (a single replica: ~20 launches of 5-35 us per step), so there k_initial_integrate also writes the
   // slot-ordered records that k_pack would (scattered 16-byte stores: for 576 replicas that costs what the separate, coalesced
   // k_pack costs -- 304 against 170 + 125 us -- so large batches keep k_pack)
+  // (by the size of a LAUNCH instead -- the halves of a batch of 36 to 72 -- it loses 0.3-1 %: profiles/r06_s_fusepack_ab.log)
   const bool fuse_pack = ns <= 32;
   // Likewise the tail of the force stage of steps without a per-atom reciprocal sum (PPPM or no k-space; Verlet / fix nvt, production
   // virial): one pass (k_finish) instead of k_ewald_force + k_shake + k_final_integrate -- two launches less for a small batch
