@@ -300,7 +300,7 @@ struct scema_md_engine {
   hipStream_t stream3 = nullptr;          // second half batch of a large launch group (run_phase)
   hipEvent_t ev_up = nullptr;
   bool split_streams = true;              // SCEMA_MD_SPLIT=0 switches the two-half pipeline off
-  int split_min = 32, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
+  int split_min = 10, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
                                          // at 576 and left large groups whole; with round 4's kernels the halves give 437 against 429, profiles/r04_zs_*)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool rx_qeq_failed = false;             // the last ReaxFF run ended with a charge solve that did not converge (eval_chunk's one retry with the Jacobi preconditioner)
@@ -311,6 +311,7 @@ struct scema_md_engine {
   // four events (fork / mid / join of the side stream, the part's join with the main stream); created on first use
   struct RxPart { hipStream_t main = nullptr, side = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; };
   std::vector<RxPart> rx_parts;
+  std::vector<hipStream_t> md_part_streams;   // streams of the part batches of run_phase beyond the fourth (created when first needed, kept)
   hipStream_t rx_side1 = nullptr;         // side stream of the second part batch (its main stream is stream3): created with the engine, so that an engine has
                                           // exactly four streams in a fixed order of creation -- the runtime deals streams to its four hardware queues in that order,
                                           // and two of these four sharing a queue costs 7 % (bench: a second engine of a process drew such a deal)

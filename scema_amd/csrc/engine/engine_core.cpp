@@ -46,8 +46,11 @@ struct EnvSwitch { const char *name, *what; };
 const EnvSwitch k_env[] = {
     // performance switches with a measured default; a reported run sets none of them
     {"SCEMA_MD_SPLIT_MAX", "launch groups of this many replicas and more run whole instead of as two half batches (default: none)"},
-    {"SCEMA_MD_SPLIT", "0: never run a launch group of 32 simulations and more as two half batches on two streams"},
+    {"SCEMA_MD_SPLIT", "0: never run a launch group of 10 simulations and more as part batches on streams of their own"},
     {"SCEMA_MD_PPPM_SIDE_MIN", "smallest batch whose PPPM chain runs on the side stream next to the pair kernel (default 1; 4 until round 5)"},
+    {"SCEMA_MD_SPLIT_MIN", "launch groups from this many replicas on run as part batches on streams of their own (default 10)"},
+    {"SCEMA_MD_PART_MIN", "SCEMA_MD_PARTS applies to launch groups of this many replicas per part and more (default 2; smaller groups run as two parts)"},
+    {"SCEMA_MD_PARTS", "2-8: this many part batches for every launch group that is split (default: by the size of the group, engine_run.cpp)"},
     {"SCEMA_MD_CELLS_TARGET", "what-if: take the cell grid (= tiling of the pair kernel) whose number of cells is closest to this among the grids that fit"},
     {"SCEMA_MD_ONE_STREAM", "no side stream (bonded / k-space chain beside the pair kernel)"},
     {"SCEMA_MD_KEEP_LIST", "0: the sampling run of an evaluation rebuilds its neighbour rows at its start even where those of the straining run still hold"},
@@ -145,6 +148,7 @@ int scema_md_create(const scema_md_params *p, scema_md_engine **out) {
     return SCEMA_MD_ERR_DEVICE;
   }
   if (const char *sp = scema_env("SCEMA_MD_SPLIT")) e->split_streams = atoi(sp) != 0;
+  if (const char *sp = scema_env("SCEMA_MD_SPLIT_MIN")) e->split_min = std::max(2, atoi(sp));
   if (const char *sp = scema_env("SCEMA_MD_SPLIT_MAX")) e->split_max = std::max(0, atoi(sp));
   if (hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess)
     e->stream3 = nullptr;   // an optimisation only
@@ -185,6 +189,7 @@ void scema_md_destroy(scema_md_engine *e) {
   if (e->rx_fork) (void)hipEventDestroy(e->rx_fork);
   if (e->rx_side1) (void)hipStreamDestroy(e->rx_side1);
   for (int k = 0; k < 4; k++) if (e->rx_side1_ev[k]) (void)hipEventDestroy(e->rx_side1_ev[k]);
+  for (hipStream_t ps : e->md_part_streams) (void)hipStreamDestroy(ps);
   for (auto &pt : e->rx_parts) {
     if (pt.main) (void)hipStreamDestroy(pt.main);
     if (pt.side) (void)hipStreamDestroy(pt.side);

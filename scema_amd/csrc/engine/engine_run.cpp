@@ -141,20 +141,47 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (sims[a].nsteps != sims[b].nsteps) return sims[a].nsteps > sims[b].nsteps;
     return grid_key(a) < grid_key(b);
   });
-  // Two half batches on two streams (large batches only): every kernel but k_pair is latency bound and leaves most issue
-  // slots idle, while k_pair saturates them and holds every wave slot of the chip; with two independent halves in flight
-  // the small kernels of one half fill in as the pair workgroups of the other retire (the in-order streams fall half a
-  // step out of phase by themselves).  The halves take the even and the odd ranks of the length order, so each is
-  // itself sorted longest first.
-  const int nhalf = (e->split_streams && e->stream3 != nullptr && ns >= e->split_min && ns < e->split_max) ? 2 : 1;
-  if (nhalf == 2) {
+  // Part batches on streams of their own: every kernel but k_pair is latency bound and leaves most issue slots idle, while
+  // k_pair saturates them and holds every wave slot of the chip; with independent parts in flight the small kernels of
+  // one part fill in as the pair workgroups of another retire (the in-order streams fall out of phase by themselves).
+  // The parts take every nparts-th rank of the length order, so each is itself sorted longest first.  How many parts is
+  // a measured table (profiles/r06_t_parts_ab*.log, same-box A/B against the whole / two-half forms): under 10 replicas
+  // the batch runs whole with its PPPM chain on the side stream; 10-16 replicas +2..7 % as four parts, 17-31 +4.5..8 %
+  // as three, 32-63 +3.7..5.9 % as four; from 64 on two halves (three or four parts: -0.5..+0.7 %, the chip is full
+  // either way).  More parts than four never pay: a process has four hardware queues, further streams share them
+  // (six parts of a 36-replica batch: -12 %).  SCEMA_MD_PARTS (2-8) forces a count for batches of SCEMA_MD_PART_MIN
+  // (2) replicas per part and more, SCEMA_MD_SPLIT_MIN moves the lower end, SCEMA_MD_SPLIT=0 runs every batch whole.
+  constexpr int MAXP = 8;
+  static const int parts_env = [] { const char *s = scema_env("SCEMA_MD_PARTS"); return s ? std::min(8, std::max(2, atoi(s))) : 0; }();
+  static const int part_min_env = [] { const char *s = scema_env("SCEMA_MD_PART_MIN"); return s ? std::max(1, atoi(s)) : 2; }();
+  const bool can_split = e->split_streams && e->stream3 != nullptr && ns >= e->split_min && ns < e->split_max;
+  int nhalf = 1;
+  if (can_split) {
+    nhalf = parts_env > 0 ? (ns >= part_min_env * parts_env ? parts_env : 2) : ns < 17 ? 4 : ns < 32 ? 3 : ns < 64 ? 4 : 2;
+    if (e->stream2 == nullptr || e->rx_side1 == nullptr) nhalf = std::min(nhalf, 2);
+    nhalf = std::max(1, std::min(nhalf, ns / 2));
+  }
+  while (nhalf > 4 && (int)e->md_part_streams.size() < nhalf - 4) {
+    hipStream_t ps = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    e->md_part_streams.push_back(ps);
+  }
+  if (nhalf >= 2) {
     std::vector<int> o2;
     o2.reserve(ns);
-    for (int r = 0; r < ns; r += 2) o2.push_back(order[r]);
-    for (int r = 1; r < ns; r += 2) o2.push_back(order[r]);
+    for (int p = 0; p < nhalf; p++)
+      for (int r = p; r < ns; r += nhalf) o2.push_back(order[r]);
     order.swap(o2);
   }
-  const int hbeg[2] = {0, nhalf == 2 ? (ns + 1) / 2 : ns}, hcnt[2] = {nhalf == 2 ? (ns + 1) / 2 : ns, nhalf == 2 ? ns / 2 : 0};
+  int hbeg[MAXP], hcnt[MAXP];
+  for (int p = 0; p < MAXP; p++) hbeg[p] = p ? ns : 0, hcnt[p] = p ? 0 : ns;
+  if (nhalf >= 2)
+    for (int p = 0, b = 0; p < MAXP; p++) {
+      hbeg[p] = b;
+      hcnt[p] = p < nhalf ? (ns - p + nhalf - 1) / nhalf : 0;
+      b += hcnt[p];
+    }
+  const auto part_of = [&](int pos) { int h = 0; while (h + 1 < nhalf && pos >= hbeg[h + 1]) h++; return h; };
   e->h_sims.assign(ns, SimDev());
   int maxbt = 1, maxloc = 1, maxcoef = 0;
   bool any_validate = false;   // some simulation may keep the rows its slot holds from the update before (SimDev::keep_list == 2)
@@ -478,7 +505,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // are the field grids (three per simulation, simulation-major): one batched transform forward and ONE back for a launch
   // group whose simulations share the grid, which they do for one material
   int maxdims = 0;              // largest nx + ny + nz
-  bool pppm_clean[2] = {false, false};   // per half: the charge grids hold zeros (the buffer is laid out anew for every run)
+  bool pppm_clean[MAXP] = {};   // per half: the charge grids hold zeros (the buffer is laid out anew for every run)
   std::vector<std::pair<int, int>> pppm_runs;   // (first position, count) of neighbours in the launch order that share a grid; none crosses a half
   if (maxgrid > 0) {
     HIPCHK(e->d_pppm.ensure((size_t)ns * maxgrid * (4 * sizeof(double2) + sizeof(double))));
@@ -490,7 +517,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       S.pgstride = (long long)maxgrid;
       S.pgf = fbase + (size_t)pos * maxgrid;
       maxdims = std::max(maxdims, S.pg[0] + S.pg[1] + S.pg[2]);
-      const bool same = !pppm_runs.empty() && pos != hbeg[1] && S.pg[0] == e->h_sims[pos - 1].pg[0] && S.pg[1] == e->h_sims[pos - 1].pg[1] && S.pg[2] == e->h_sims[pos - 1].pg[2];
+      const bool same = !pppm_runs.empty() && pos != hbeg[part_of(pos)] && S.pg[0] == e->h_sims[pos - 1].pg[0] && S.pg[1] == e->h_sims[pos - 1].pg[1] && S.pg[2] == e->h_sims[pos - 1].pg[2];
       if (same) pppm_runs.back().second += 1;
       else pppm_runs.push_back({pos, 1});
     }
@@ -517,7 +544,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   auto pppm_stage = [&](hipStream_t st, int pos0, int na, bool new_box, int add = 1) -> int {
     if (maxgrid <= 0 || na <= 0) return SCEMA_MD_OK;
     const SimDev *Dp = e->d_sims.as<SimDev>() + pos0;
-    bool &clean = pppm_clean[(nhalf == 2 && pos0 == hbeg[1]) ? 1 : 0];
+    bool &clean = pppm_clean[part_of(pos0)];
     mdk_pppm_spread(st, Dp, na, maxgrid, maxatoms, clean ? 1 : 0, padx_ok ? maxgridp : 0);
     clean = false;
     if (pppm_in_lds) {   // small grids: the whole solve in one launch, in LDS (md_pppm.hip k_pppm_solve); it leaves the charge grids zeroed
@@ -577,10 +604,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   HIPCHK(hipMemcpyAsync(e->d_sims.p, e->h_sims.data(), (size_t)ns * sizeof(SimDev), hipMemcpyHostToDevice, e->stream));
   const auto t_laid_out = std::chrono::steady_clock::now();
   const SimDev *D = e->d_sims.as<SimDev>();
-  hipStream_t hs[2] = {e->stream, nhalf == 2 ? e->stream3 : e->stream};
-  if (nhalf == 2) {   // the second stream starts behind the uploads
+  hipStream_t hs[MAXP] = {e->stream, nhalf >= 2 ? e->stream3 : e->stream, e->stream2, e->rx_side1};
+  for (int h = 4; h < nhalf; h++) hs[h] = e->md_part_streams[h - 4];
+  if (nhalf >= 2) {   // the other streams start behind the uploads
     HIPCHK(hipEventRecord(e->ev_up, e->stream));
-    HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_up, 0));
+    for (int h = 1; h < nhalf; h++) HIPCHK(hipStreamWaitEvent(hs[h], e->ev_up, 0));
   }
   const int ev = (spec.sample || spec.ev_always || (spec.nh && spec.npt)) ? 1 : 0;   // the barostat needs the virial of every step
   const bool allow_side = nhalf == 1;
@@ -756,18 +784,24 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     const int na = active(0, step);
     if (na == 0) break;
     int run_len = e->h_sims[na - 1].nsteps - step + 1;   // steps until the active prefix shrinks (sorted by nsteps)
-    const int nb = nhalf == 2 ? active(1, step) : 0;
-    if (nb > 0) run_len = std::min(run_len, e->h_sims[hbeg[1] + nb - 1].nsteps - step + 1);
+    int nact[MAXP] = {na}, nsum = na;
+    for (int h = 1; h < nhalf; h++) {
+      nact[h] = active(h, step);
+      nsum += nact[h];
+      if (nact[h] > 0) run_len = std::min(run_len, e->h_sims[hbeg[h] + nact[h] - 1].nsteps - step + 1);
+    }
     {
       auto nxt = flip_at.lower_bound(step);
       if (nxt != flip_at.end()) run_len = std::min(run_len, nxt->first - step + 1);   // the launch group ends with the flipping step
     }
     for (int r = 0; r < run_len; r++) {
-      int rc_l = launch_step(0, na, prof);
-      if (rc_l) return rc_l;
-      if (nb > 0 && (rc_l = launch_step(1, nb, prof))) return rc_l;
+      for (int h = 0; h < nhalf; h++) {
+        if (nact[h] == 0) continue;
+        const int rc_l = launch_step(h, nact[h], prof);
+        if (rc_l) return rc_l;
+      }
     }
-    e->prof.md_steps += (long long)(na + nb) * run_len;
+    e->prof.md_steps += (long long)nsum * run_len;
     step += run_len;
     // flips detected at the end of step - 1: between the two steps the box takes its flipped tilts, the list rebuild of
     // the next step is forced and the k-vector list is re-expressed in the new reciprocal basis (same vectors:
@@ -777,7 +811,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       for (const auto &pk : fl->second) {
         const int pos = pk.first;
         const FlipEvent &fe = flips[pos][pk.second];
-        const int h = (nhalf == 2 && pos >= hbeg[1]) ? 1 : 0;
+        const int h = part_of(pos);
         SimDev &S = e->h_sims[pos];
         EwaldSetup &ew = ews[pos];
         if (S.nk > 0) {
@@ -814,8 +848,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
   }
   for (int h = 0; h < nhalf; h++) mdk_phase_end(hs[h], D + hbeg[h], hcnt[h], maxatoms);
-  if (nhalf == 2) {
-    HIPCHK(hipEventRecord(e->ev_up, e->stream3));
+  for (int h = 1; h < nhalf; h++) {
+    HIPCHK(hipEventRecord(e->ev_up, hs[h]));
     HIPCHK(hipStreamWaitEvent(e->stream, e->ev_up, 0));
   }
   hipStream_t st = e->stream;

@@ -662,3 +662,36 @@ def test_round6_launch_variants_give_the_same_stresses(small_pe):
         assert other["steps"] == ref["steps"]
         if env.get("SCEMA_MD_REBUILD_TOGETHER") == "0" and len(env) == 1:
             assert ref["builds"] >= other["builds"], (ref["builds"], other["builds"])   # a common trigger builds at least as often
+
+
+def test_part_batches_give_the_same_stresses_as_the_whole_batch():
+    """Batches of 10 replicas and more run as part batches on streams of their own (engine_run.cpp: four parts for 10-16, three for 17-31, four
+    for 32-63, two halves from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
+    13 replicas of ragged length (nss 40 down to 28) with different strains, then its reverse from the states it left: the same stresses
+    whole (SCEMA_MD_SPLIT=0), as the table's four parts, as two, three and six parts (six: two of them on streams the engine creates when first
+    asked), and the same number of MD steps."""
+    code = ("import json, os, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "d = build_pe(2, 3, 5, jitter=0.05, seed=7); d['box'][6:9] = [0.7, -0.4, 0.5]\n"
+            "kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)\n"
+            "e = capi.Engine(capi.default_params(**kw))\n"
+            "e.register_replica('pe', 1, d)\n"
+            "L = d['box'][3:6] - d['box'][:3]\n"
+            "st = np.array([-3e-4 * L[0], -3e-4 * L[1], 1e-3 * L[2], 2e-5 * L[2], 0, 0])\n"
+            "out = []\n"
+            "n = 13\n"
+            "a = e.strain_batch([capi.make_sim(q, 'pe', 1, st * (1 + 0.3 * q), nss=40 - q, most_recent=capi.QP_NONE) for q in range(n)])\n"
+            "out += [list(o.stress) for o in a]\n"
+            "a = e.strain_batch([capi.make_sim(q, 'pe', 1, -st * (1 + 0.1 * q), nss=28 + q) for q in range(n)])\n"
+            "out += [list(o.stress) for o in a]\n"
+            "p = e.profile()\n"
+            "print(json.dumps({'s': out, 'steps': p['md_steps']}))\n")
+    ref = _child(code, {"SCEMA_MD_SPLIT": "0"})
+    a = np.array(ref["s"])
+    assert a.shape == (26, 6) and np.isfinite(a).all()
+    for env in ({}, {"SCEMA_MD_PARTS": "2"}, {"SCEMA_MD_PARTS": "3"}, {"SCEMA_MD_PARTS": "6"}):
+        other = _child(code, env)
+        b = np.array(other["s"])
+        assert np.abs(a - b).max() < 1e-9 * np.abs(b).max(), (env, np.abs(a - b).max() / np.abs(b).max())
+        assert other["steps"] == ref["steps"]
