@@ -709,6 +709,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // the same series: nothing at 1-4 replicas, where k_finish, k_post, k_remap and k_initial_integrate already run back to back without a gap,
   // and -2.5 / -3.6 % at 9 / 18 replicas, where the device-scope release and acquire around the ticket write back and invalidate the XCD's L2
   // with the replica's freshly stored velocities and forces in it.  Removed.)
+  // (The bonded kernel of a batch under 8 replicas on a THIRD stream, beside both k_pair and the PPPM chain -- on paper 17 us off a lone replica's
+  // 127 us step -- lost: 66.5 against 77.1 evaluations/s for one replica, 188.7 / 201.2 for four, 290.2 / 294.2 for nine.  A second fork and join
+  // per step costs more than the 11 us kernel it hides.  profiles/r06_v_bonded_third_ab.log.  Removed.)
   static const bool bonded_side_on = !(scema_env("SCEMA_MD_BONDED_SIDE") && atoi(scema_env("SCEMA_MD_BONDED_SIDE")) == 0);
   static const int bonded_side_min = scema_env("SCEMA_MD_BONDED_SIDE_MIN") ? atoi(scema_env("SCEMA_MD_BONDED_SIDE_MIN")) : 8;
   // (The pair kernel as PERSISTENT workgroups -- one 1 024-thread workgroup per CU for the whole launch, two tiles in LDS, rows taken off LDS
