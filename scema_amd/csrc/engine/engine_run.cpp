@@ -709,6 +709,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // the same series: nothing at 1-4 replicas, where k_finish, k_post, k_remap and k_initial_integrate already run back to back without a gap,
   // and -2.5 / -3.6 % at 9 / 18 replicas, where the device-scope release and acquire around the ticket write back and invalidate the XCD's L2
   // with the replica's freshly stored velocities and forces in it.  Removed.)
+  // (The bonded tiles of such a batch as extra workgroups of the k_pair launch -- on the CUs its 180 pair tiles leave idle -- take the kernel and
+  // its launch gap off the main stream, 89 -> 72 us per step, and leave the PPPM chain beside it, fork 11 + 54 + join 11 us, the longer one:
+  // 76.6 against 76.2 evaluations/s for one replica, 208 / 204 for four, 257 / 259 for seven.  profiles/r06_w_bonded_in_pair_ab.log.  Removed.)
   // (The bonded kernel of a batch under 8 replicas on a THIRD stream, beside both k_pair and the PPPM chain -- on paper 17 us off a lone replica's
   // 127 us step -- lost: 66.5 against 77.1 evaluations/s for one replica, 188.7 / 201.2 for four, 290.2 / 294.2 for nine.  A second fork and join
   // per step costs more than the 11 us kernel it hides.  profiles/r06_v_bonded_third_ab.log.  Removed.)
