@@ -95,7 +95,10 @@ int run_phase_reax(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSp
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sims[a].nsteps > sims[b].nsteps; });
   // The batch runs as part batches on as many streams (the step loop below).  Part p takes the ranks p, p + P, ... of the length order and sits at
   // consecutive positions: each part is itself sorted longest first, and the parts carry the same mix of run lengths.
-  const int nparts_plan = (e->rx_halves >= 2 && ns >= 4 * e->rx_halves && !spec.minimize) ? e->rx_halves : 1;
+  // (From six replicas per part on: 8 / 10 replicas whole 494 / 595 evaluations/s, as two parts 460 / 564; 12 / 16 / 18 replicas 617 / 776 / 847
+  // whole, 661 / 852 / 910 as two.  Three and four parts lose at every size -- each part has a side stream too, and a process has four hardware
+  // queues: 36 replicas 1 171 as two parts, 902 as three.  profiles/r06_x_reax_parts_ab.log)
+  const int nparts_plan = (e->rx_halves >= 2 && ns >= 6 * e->rx_halves && !spec.minimize) ? e->rx_halves : 1;
   if (nparts_plan > 1) {
     std::vector<int> o2;
     o2.reserve(ns);

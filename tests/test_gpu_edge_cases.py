@@ -667,7 +667,8 @@ def test_round6_launch_variants_give_the_same_stresses(small_pe):
 def test_part_batches_give_the_same_stresses_as_the_whole_batch():
     """Batches of 10 replicas and more run as part batches on streams of their own (engine_run.cpp: four parts for 10-16, three for 17-31, four
     for 32-63, two halves from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
-    13 replicas of ragged length (nss 40 down to 28) with different strains, then its reverse from the states it left: the same stresses
+    13 replicas of ragged length (nss 40 down to 28) with different strains -- two of them sheared until their boxes flip, which is
+    host work between two steps of their part --, then its reverse from the states it left: the same stresses
     whole (SCEMA_MD_SPLIT=0), as the table's four parts, as two, three and six parts (six: two of them on streams the engine creates when first
     asked), and the same number of MD steps."""
     code = ("import json, os, numpy as np\n"
@@ -681,13 +682,16 @@ def test_part_batches_give_the_same_stresses_as_the_whole_batch():
             "st = np.array([-3e-4 * L[0], -3e-4 * L[1], 1e-3 * L[2], 2e-5 * L[2], 0, 0])\n"
             "out = []\n"
             "n = 13\n"
-            "a = e.strain_batch([capi.make_sim(q, 'pe', 1, st * (1 + 0.3 * q), nss=40 - q, most_recent=capi.QP_NONE) for q in range(n)])\n"
+            "big = np.array([0, 0, 0, 0.9 * L[0] * L[2] / L[1], 0, 0])\n"
+            "a = e.strain_batch([capi.make_sim(q, 'pe', 1, st * (1 + 0.3 * q) + (big if q in (2, 7) else 0), nss=40 - q, most_recent=capi.QP_NONE,\n"
+            "                                  strain_rate=1e-2 if q in (2, 7) else 1e-4) for q in range(n)])\n"
             "out += [list(o.stress) for o in a]\n"
             "a = e.strain_batch([capi.make_sim(q, 'pe', 1, -st * (1 + 0.1 * q), nss=28 + q) for q in range(n)])\n"
             "out += [list(o.stress) for o in a]\n"
             "p = e.profile()\n"
-            "print(json.dumps({'s': out, 'steps': p['md_steps']}))\n")
+            "print(json.dumps({'s': out, 'steps': p['md_steps'], 'flips': p['box_flips']}))\n")
     ref = _child(code, {"SCEMA_MD_SPLIT": "0"})
+    assert ref["flips"] >= 2
     a = np.array(ref["s"])
     assert a.shape == (26, 6) and np.isfinite(a).all()
     for env in ({}, {"SCEMA_MD_PARTS": "2"}, {"SCEMA_MD_PARTS": "3"}, {"SCEMA_MD_PARTS": "6"}):
@@ -695,3 +699,4 @@ def test_part_batches_give_the_same_stresses_as_the_whole_batch():
         b = np.array(other["s"])
         assert np.abs(a - b).max() < 1e-9 * np.abs(b).max(), (env, np.abs(a - b).max() / np.abs(b).max())
         assert other["steps"] == ref["steps"]
+        assert other["flips"] == ref["flips"]

@@ -142,8 +142,8 @@ def test_stresses_do_not_depend_on_how_the_batch_is_issued(gold, scripts):
     from scema_amd.systems import synthetic_strains
     sym, x, box, v = _mixture(gold)
     lens = box[3:6] - box[:3]
-    draw = synthetic_strains(13, lens, seed=7)
-    strains = [draw[k] * (0.4 + 0.2 * (k % 5)) for k in range(13)]
+    draw = synthetic_strains(19, lens, seed=7)   # (a batch runs as P parts from 6 P replicas on)
+    strains = [draw[k] * (0.4 + 0.2 * (k % 5)) for k in range(19)]
     res = []
     for parts, overlap in ((2, 1), (1, 0), (3, 1)):
         e = capi.Engine()

@@ -1,10 +1,10 @@
 #!/bin/bash
 # The batch-size curve.  usage on the GPU box, from the repo root: tools/batch_sweep.sh <tag> [sizes...]
-# OPLS PE-10k at 1 2 4 9 18 36 72 144 576 replicas per update and the ReaxFF set at 9 and 72, on ONE box: per size a plain bench run
+# OPLS PE-10k at 1 2 4 9 12 18 24 36 48 72 144 576 replicas per update and the ReaxFF set at 9 and 72, on ONE box: per size a plain bench run
 # (evaluations/s, ms per update, the pair kernel's chip-exclusive time per replica from the bench's own HIP events) and a profiled run
 # of the same workload (kernel launches, busy and idle time per MD step).  Table -> gpurun_out/<tag>_batch_sweep.txt
 T=${1:-r06_a}; shift
-SIZES=${@:-1 2 4 9 18 36 72 144 576}
+SIZES=${@:-1 2 4 9 12 18 24 36 48 72 144 576}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 C=gpurun_out/equil_pe10k.npz

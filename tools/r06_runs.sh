@@ -1,9 +1,12 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/r06_runs.sh <tag>   -- the measurement set of round 6 (logs under gpurun_out/)
+# usage (on the GPU box, from the repo root): tools/r06_runs.sh <tag> [a|b]  -- the measurement set of round 6 (logs under gpurun_out/);
+# a: the bench lines and kernel tables (steps 1-6), b: the batch-size curves of this tree and of the round-5 library (steps 7-8); default both
 T=${1:-r06_z}
+PART=${2:-ab}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 C=gpurun_out/equil_pe10k.npz
+if [[ $PART == *a* ]]; then
 # 1. the driver's command: headline + the all-tensile set timed after it (config.strain_set_monotonic_evals_per_s) + CPU baseline on every host core
 python bench.py --steps 20 --warmup 5 --equil-cache $C > gpurun_out/${T}_bench_576sims_driver.json.log 2> gpurun_out/${T}.err
 grep "^{" gpurun_out/${T}_bench_576sims_driver.json.log | cut -c1-220
@@ -38,10 +41,13 @@ done
 # 6. the ReaxFF set at the size of the headline batch
 python bench.py --force-field reax --sims 576 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/${T}_bench_reax_576sims.json.log
 python -c "import json; d=json.loads(open(\"gpurun_out/${T}_bench_reax_576sims.json.log\").read()); print(\"reax 576\", round(d[\"value\"],1), round(d[\"roofline\"][\"frac\"],3))"
+fi
+if [[ $PART == *b* ]]; then
 # 7. the batch-size curve of the same tree on the same box, kernel tables of a 9-replica and a single-replica batch as they run
 bash tools/batch_sweep.sh ${T} > gpurun_out/${T}_sweep.log 2>&1
 bash tools/small_prof.sh ${T} 9 > /dev/null 2>&1
 bash tools/small_prof.sh ${T} 1 > /dev/null 2>&1
 cat gpurun_out/${T}_batch_sweep.txt
 # 8. the curve of the round-5 library on the same box (scema_amd/libscema_md_r05.so: the tree of commit 9953bdf built with the same Makefile)
-[ -f scema_amd/libscema_md_r05.so ] && SCEMA_MD_LIB=libscema_md_r05.so bash tools/batch_sweep.sh ${T}_r05lib 1 2 4 9 18 36 72 144 576 > gpurun_out/${T}_r05lib_sweep.log 2>&1 && cat gpurun_out/${T}_r05lib_batch_sweep.txt
+[ -f scema_amd/libscema_md_r05.so ] && SCEMA_MD_LIB=libscema_md_r05.so bash tools/batch_sweep.sh ${T}_r05lib 1 2 4 9 12 18 24 36 48 72 144 576 > gpurun_out/${T}_r05lib_sweep.log 2>&1 && cat gpurun_out/${T}_r05lib_batch_sweep.txt
+fi
