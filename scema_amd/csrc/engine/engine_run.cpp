@@ -149,7 +149,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // the batch runs whole with its PPPM chain on the side stream; 10-16 replicas +2..7 % as four parts, 17-31 +4.5..8 %
   // as three, 32-63 +3.7..5.9 % as four; from 64 on two halves (three or four parts: -0.5..+0.7 %, the chip is full
   // either way).  More parts than four never pay: a process has four hardware queues, further streams share them
-  // (six parts of a 36-replica batch: -12 %).  SCEMA_MD_PARTS (2-8) forces a count for batches of SCEMA_MD_PART_MIN
+  // (six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 %).  SCEMA_MD_PARTS (2-8) forces a count for batches of SCEMA_MD_PART_MIN
   // (2) replicas per part and more, SCEMA_MD_SPLIT_MIN moves the lower end, SCEMA_MD_SPLIT=0 runs every batch whole.
   constexpr int MAXP = 8;
   static const int parts_env = [] { const char *s = scema_env("SCEMA_MD_PARTS"); return s ? std::min(8, std::max(2, atoi(s))) : 0; }();
