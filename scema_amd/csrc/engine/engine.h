@@ -311,7 +311,7 @@ struct scema_md_engine {
   // four events (fork / mid / join of the side stream, the part's join with the main stream); created on first use
   struct RxPart { hipStream_t main = nullptr, side = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; };
   std::vector<RxPart> rx_parts;
-  std::vector<hipStream_t> md_part_streams;   // streams of the part batches of run_phase beyond the fourth (created when first needed, kept)
+  std::vector<hipEvent_t> md_part_done;        // one event per part batch beyond the first: the end of its launches, which the main stream waits for
   hipStream_t rx_side1 = nullptr;         // side stream of the second part batch (its main stream is stream3): created with the engine, so that an engine has
                                           // exactly four streams in a fixed order of creation -- the runtime deals streams to its four hardware queues in that order,
                                           // and two of these four sharing a queue costs 7 % (bench: a second engine of a process drew such a deal)

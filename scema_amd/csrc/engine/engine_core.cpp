@@ -50,7 +50,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_PPPM_SIDE_MIN", "smallest batch whose PPPM chain runs on the side stream next to the pair kernel (default 1; 4 until round 5)"},
     {"SCEMA_MD_SPLIT_MIN", "launch groups from this many replicas on run as part batches on streams of their own (default 10)"},
     {"SCEMA_MD_PART_MIN", "SCEMA_MD_PARTS applies to launch groups of this many replicas per part and more (default 2; smaller groups run as two parts)"},
-    {"SCEMA_MD_PARTS", "2-8: this many part batches for every launch group that is split (default: by the size of the group, engine_run.cpp)"},
+    {"SCEMA_MD_PARTS", "2-4: this many part batches for every launch group that is split (default: by the size of the group, engine_run.cpp)"},
     {"SCEMA_MD_CELLS_TARGET", "what-if: take the cell grid (= tiling of the pair kernel) whose number of cells is closest to this among the grids that fit"},
     {"SCEMA_MD_ONE_STREAM", "no side stream (bonded / k-space chain beside the pair kernel)"},
     {"SCEMA_MD_KEEP_LIST", "0: the sampling run of an evaluation rebuilds its neighbour rows at its start even where those of the straining run still hold"},
@@ -189,7 +189,7 @@ void scema_md_destroy(scema_md_engine *e) {
   if (e->rx_fork) (void)hipEventDestroy(e->rx_fork);
   if (e->rx_side1) (void)hipStreamDestroy(e->rx_side1);
   for (int k = 0; k < 4; k++) if (e->rx_side1_ev[k]) (void)hipEventDestroy(e->rx_side1_ev[k]);
-  for (hipStream_t ps : e->md_part_streams) (void)hipStreamDestroy(ps);
+  for (hipEvent_t pe : e->md_part_done) (void)hipEventDestroy(pe);
   for (auto &pt : e->rx_parts) {
     if (pt.main) (void)hipStreamDestroy(pt.main);
     if (pt.side) (void)hipStreamDestroy(pt.side);

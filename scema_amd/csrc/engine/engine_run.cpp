@@ -148,11 +148,14 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // a measured table (profiles/r06_t_parts_ab*.log, same-box A/B against the whole / two-half forms): under 10 replicas
   // the batch runs whole with its PPPM chain on the side stream; 10-16 replicas +2..7 % as four parts, 17-31 +4.5..8 %
   // as three, 32-63 +3.7..5.9 % as four; from 64 on two halves (three or four parts: -0.5..+0.7 %, the chip is full
-  // either way).  More parts than four never pay: a process has four hardware queues, further streams share them
-  // (six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 %).  SCEMA_MD_PARTS (2-8) forces a count for batches of SCEMA_MD_PART_MIN
+  // either way).  Four is the most: a process has four hardware queues and further streams share them -- five to eight parts on
+  // streams of their own were measured (six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 %) and, as six or
+  // seven parts of two replicas each, gave stresses of some replicas that were off by 1e-4 in some runs and not in others (not
+  // understood; no such run with four parts or fewer in any size; profiles/r06_t_parts_ab.log) -- the code for them is gone.
+  // SCEMA_MD_PARTS (2-4) forces a count for batches of SCEMA_MD_PART_MIN
   // (2) replicas per part and more, SCEMA_MD_SPLIT_MIN moves the lower end, SCEMA_MD_SPLIT=0 runs every batch whole.
-  constexpr int MAXP = 8;
-  static const int parts_env = [] { const char *s = scema_env("SCEMA_MD_PARTS"); return s ? std::min(8, std::max(2, atoi(s))) : 0; }();
+  constexpr int MAXP = 4;
+  static const int parts_env = [] { const char *s = scema_env("SCEMA_MD_PARTS"); return s ? std::min(4, std::max(2, atoi(s))) : 0; }();
   static const int part_min_env = [] { const char *s = scema_env("SCEMA_MD_PART_MIN"); return s ? std::max(1, atoi(s)) : 2; }();
   const bool can_split = e->split_streams && e->stream3 != nullptr && ns >= e->split_min && ns < e->split_max;
   int nhalf = 1;
@@ -161,10 +164,10 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     if (e->stream2 == nullptr || e->rx_side1 == nullptr) nhalf = std::min(nhalf, 2);
     nhalf = std::max(1, std::min(nhalf, ns / 2));
   }
-  while (nhalf > 4 && (int)e->md_part_streams.size() < nhalf - 4) {
-    hipStream_t ps = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
-    e->md_part_streams.push_back(ps);
+  while ((int)e->md_part_done.size() < nhalf - 1) {
+    hipEvent_t pe = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&pe, hipEventDisableTiming));
+    e->md_part_done.push_back(pe);
   }
   if (nhalf >= 2) {
     std::vector<int> o2;
@@ -184,7 +187,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const auto part_of = [&](int pos) { int h = 0; while (h + 1 < nhalf && pos >= hbeg[h + 1]) h++; return h; };
   e->h_sims.assign(ns, SimDev());
   int maxbt = 1, maxloc = 1, maxcoef = 0;
-  bool any_validate = false;   // some simulation may keep the rows its slot holds from the update before (SimDev::keep_list == 2)
+  bool any_validate = false;   // some simulation may keep the rows its slot holds (SimDev::keep_list: 1 from the run, 2 from the update before)
   int maxrow = 64, maxcapj = 64, maxpoly = 1, maxatoms = 0, maxpad = 0, maxcells = 0, maxk = 0, mmax = 1, maxb = 0, maxa = 0, maxd = 0, maxi = 0, maxs = 0, maxclus = 0, maxunits = 0, maxsteps = 0;
   // k-vector tables of all simulations (indices, row run lengths, groups), packed into one upload
   std::vector<int> &kpack = e->h_kpack;
@@ -318,7 +321,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
     }
     S.keep_list = keep ? spec.keep_list : 0;
-    any_validate = any_validate || S.keep_list == 2;
+    any_validate = any_validate || S.keep_list != 0;
     // first among cell edges between rlist/2 and rlist; if no such grid fits, among edges down to rlist/4 (so that a
     // slightly denser system degrades gradually instead of dropping to the uniform fallback below)
     // replicas up to which the most-cells grid is taken: every launch group that runs whole (scanned again in round 6, profiles/r06_d_cells_scan.txt:
@@ -527,7 +530,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // all their field grids: three per simulation, simulation-major).  A plan owns work space, so each stream has its own.
   auto pppm_plan = [&](const int pg[3], int batch, hipStream_t st, hipfftHandle &plan) -> int {
     if ((long long)maxgrid > 0x7fffffffLL) return fail(e, SCEMA_MD_ERR_ARG, "PPPM grid of %d points is too large", maxgrid);
-    const std::array<int, 6> key = {pg[0], pg[1], pg[2], batch, st == e->stream ? 0 : st == e->stream2 ? 1 : 2, maxgrid};
+    const std::array<int, 6> key = {pg[0], pg[1], pg[2], batch, st == e->stream ? 0 : st == e->stream2 ? 1 : st == e->stream3 ? 2 : 3, maxgrid};   // (a plan owns work space: one per stream of a part batch)
     auto it = e->pppm_plans.find(key);
     if (it == e->pppm_plans.end()) {
       hipfftHandle h;
@@ -605,7 +608,6 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const auto t_laid_out = std::chrono::steady_clock::now();
   const SimDev *D = e->d_sims.as<SimDev>();
   hipStream_t hs[MAXP] = {e->stream, nhalf >= 2 ? e->stream3 : e->stream, e->stream2, e->rx_side1};
-  for (int h = 4; h < nhalf; h++) hs[h] = e->md_part_streams[h - 4];
   if (nhalf >= 2) {   // the other streams start behind the uploads
     HIPCHK(hipEventRecord(e->ev_up, e->stream));
     for (int h = 1; h < nhalf; h++) HIPCHK(hipStreamWaitEvent(hs[h], e->ev_up, 0));
@@ -854,9 +856,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
       }
   }
   for (int h = 0; h < nhalf; h++) mdk_phase_end(hs[h], D + hbeg[h], hcnt[h], maxatoms);
-  for (int h = 1; h < nhalf; h++) {
-    HIPCHK(hipEventRecord(e->ev_up, hs[h]));
-    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_up, 0));
+  for (int h = 1; h < nhalf; h++) {   // (an event of its own per part)
+    HIPCHK(hipEventRecord(e->md_part_done[h - 1], hs[h]));
+    HIPCHK(hipStreamWaitEvent(e->stream, e->md_part_done[h - 1], 0));
   }
   hipStream_t st = e->stream;
   HIPCHK(hipMemcpyAsync(e->h_sc.data(), e->d_sc.p, (size_t)ns * sizeof(SimScalars), hipMemcpyDeviceToHost, st));

@@ -45,13 +45,16 @@ __global__ void k_phase_init(const SimDev *sims) {
     sc.step = 0;
     // A LAMMPS run begins with a list build (Verlet::setup), and so does a run here -- unless it continues one that has just ended on
     // this slot with the same cell grid (the sampling run behind the straining run of an evaluation): positions and box are those of
-    // the last force evaluation, for which the rows on the device were checked, so they stand, with their age and reference positions.
-    // The far band is walked in the set-up evaluation (what moved since the build is only looked at from step 1 on).  A box flip that
+    // the last force evaluation but for the last remap of fix deform (k_post moves the box once more, k_remap carries the atoms along: 3e-3 A
+    // per step at the reference's strain rate, 0.3 A at a rate of 1e-2 per fs), so they stand where the list's own test says so for the
+    // positions and the box the run starts from -- the same test as for rows kept from the update before (below), with the rows' age and
+    // reference positions.  (Until round 6 they stood unchecked: a sheared replica at a rate of 1e-2 lost pairs in the set-up evaluation
+    // of its sampling run, 1e-7 of the stress.)  The far band is walked in the set-up evaluation (what moved since the build is only looked at from step 1 on).  A box flip that
     // is still pending forces the build as it would between two steps.  Results do not depend on when a list is built.
     int keep = S.keep_list && !sc.force_rebuild;
     sc.deltasq = 0.0;
-    if (keep && S.keep_list == 2) {
-      // rows from the update before: they stand only if the list's own test says so -- every atom within half the skin (less the motion of
+    if (keep) {
+      // rows from the run or the update before: they stand only if the list's own test says so -- every atom within half the skin (less the motion of
       // the box corners) of the position the rows were built for.  The box part here, the atoms in k_keep_validate.  A slot that last
       // served another state arrives with zeroed reference corners: the corner motion then exceeds any skin and the build is made.
       double c[24];
@@ -83,11 +86,11 @@ __global__ void k_phase_init(const SimDev *sims) {
   for (int k = threadIdx.x; k < S.ncells; k += blockDim.x) S.cell_count[k] = 0;
 }
 
-// k_keep_validate : rows kept from the update before (SimDev::keep_list == 2) stand only while every atom is within the list's displacement
+// k_keep_validate : rows kept from the run or the update before (SimDev::keep_list != 0) stand only while every atom is within the list's displacement
 // bound of its reference position -- the test k_initial_integrate makes every step, here for the positions the run starts from
 __global__ __launch_bounds__(TPB) void k_keep_validate(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.y];
-  if (S.keep_list != 2) return;
+  if (!S.keep_list) return;
   SimScalars &sc = *S.sc;
   if (sc.rebuild) return;
   const int i = blockIdx.x * TPB + threadIdx.x;
@@ -132,7 +135,10 @@ __device__ __forceinline__ void pre_scalars(const SimDev &S, SimScalars &sc) {
       double dx = c[3 * k] - sc.corners_hold[3 * k], dy = c[3 * k + 1] - sc.corners_hold[3 * k + 1],
              dz = c[3 * k + 2] - sc.corners_hold[3 * k + 2];
       double d = sqrt(dx * dx + dy * dy + dz * dz);
-      if (d > d1) d1 = d;
+      // (the two LARGEST: LAMMPS' Neighbor::check_distance drops the old maximum when a new one arrives -- `if (d > d1) d1 = d; else if
+      // (d > d2) d2 = d;` -- and so underestimates the corner motion of a box whose corners move by different amounts, by up to half.  A list
+      // may be built earlier than LAMMPS builds its own, never later than its validity: results do not depend on when a valid list is built.)
+      if (d > d1) { d2 = d1; d1 = d; }
       else if (d > d2) d2 = d;
     }
     double delta = 0.5 * (S.skin - (d1 + d2));
@@ -389,7 +395,10 @@ __device__ __forceinline__ void pack_slot(const SimDev &S, int s, int a, double 
 // coord > 0 (small launch groups that run whole, run_phase): the replicas of the launch rebuild TOGETHER -- as soon as one of them asks for
 // it, all do.  A lone replica's rebuild keeps a quarter of the chip busy at the speed of its latencies (110-140 us for PE-10k) while the rest
 // of the group waits: at 9 replicas that was 70 us of every 330-us step; nine rebuilds in one set of launches take little longer than one.
-// Building a list before its displacement test asks for it is always valid (results do not depend on when a list is built).
+// Building a list before its displacement test asks for it is always valid: results do not depend on when a list is built -- as long as no
+// list is ever used past its validity, which `neigh_modify delay 5` (the reference's setting: no test for five steps after a build) only
+// guarantees while no atom covers half the skin in five steps.  Where one does (LAMMPS' "dangerous builds": a skin of 1 A on a hot or fast
+// sheared system, never the reference's 2 A at 300 K) LAMMPS' own result depends on the step its lists were built at, and so does this one.
 __global__ __launch_bounds__(CB_TPB) void k_cell_build(const SimDev *sims, int coord) {
   const SimDev &S = sims[blockIdx.x];
   SimScalars &sc = *S.sc;
@@ -1226,16 +1235,32 @@ __global__ __launch_bounds__(TPB, 2) void k_finish(const SimDev *sims, int pairv
 // next_pre: a simulation with steps left also does the k_pre of its next step here (one launch less per step; the first step of a run
 // has its own k_pre)
 __device__ __forceinline__ void post_scalars(const SimDev &S, SimScalars &sc);
+// The scalars of the replica are staged through LDS: one thread walking SimScalars in global memory is a chain of dependent round trips to
+// the L2 (the kernels before it wrote those lines on other CUs) -- 11 us for a lone replica, whose step is 120 us of dependent launches.  The
+// wave reads the structure with coalesced loads, thread 0 works on the copy, the wave writes back the part the two functions may change
+// (everything up to keep_nh; nothing else touches a replica's scalars while its k_post runs: the side stream has joined before k_finish).
 __global__ void k_post(const SimDev *sims, int next_pre) {
   const SimDev &S = sims[blockIdx.x];
-  SimScalars &sc = *S.sc;
+  __shared__ SimScalars s_sc;
   __shared__ int s_more;
-  if (threadIdx.x == 0) {
-    post_scalars(S, sc);
-    s_more = next_pre && sc.step < S.nsteps;
-    if (s_more) pre_scalars(S, sc);
+  static_assert(sizeof(SimScalars) % 8 == 0 && offsetof(SimScalars, keep_nh) % 4 == 0, "SimScalars is copied in 8- and 4-byte words");
+  {
+    const unsigned long long *src = (const unsigned long long *)S.sc;
+    unsigned long long *dst = (unsigned long long *)&s_sc;
+    for (int k = threadIdx.x; k < (int)(sizeof(SimScalars) / 8); k += blockDim.x) dst[k] = src[k];
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    post_scalars(S, s_sc);
+    s_more = next_pre && s_sc.step < S.nsteps;
+    if (s_more) pre_scalars(S, s_sc);
+  }
+  __syncthreads();
+  {
+    const int *src = (const int *)&s_sc;
+    int *dst = (int *)S.sc;
+    for (int k = threadIdx.x; k < (int)(offsetof(SimScalars, keep_nh) / 4); k += blockDim.x) dst[k] = src[k];
+  }
   if (!s_more) return;
   for (int k = threadIdx.x; k < 2 * S.nk; k += blockDim.x) S.sfac[k] = 0.0;
   for (int k = threadIdx.x; k < S.ncells; k += blockDim.x) S.cell_count[k] = 0;

@@ -669,13 +669,14 @@ def test_part_batches_give_the_same_stresses_as_the_whole_batch():
     for 32-63, two halves from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
     13 replicas of ragged length (nss 40 down to 28) with different strains -- two of them sheared until their boxes flip, which is
     host work between two steps of their part --, then its reverse from the states it left: the same stresses
-    whole (SCEMA_MD_SPLIT=0), as the table's four parts, as two, three and six parts (six: two of them on streams the engine creates when first
-    asked), and the same number of MD steps."""
+    whole (SCEMA_MD_SPLIT=0), as the table's four parts, as two and as three parts, and the same number of MD steps.  (neigh_modify delay 0: with the reference's `delay 5` and this test's skin of 1 A a list is
+    used past its validity wherever an atom covers half the skin within five steps of a build -- LAMMPS' "dangerous builds", certain in a box
+    sheared by 0.3 A per step -- and the result then depends on the step a list was built at, here as in LAMMPS.)"""
     code = ("import json, os, numpy as np\n"
             "from scema_amd import capi\n"
             "from scema_amd.systems import build_pe\n"
             "d = build_pe(2, 3, 5, jitter=0.05, seed=7); d['box'][6:9] = [0.7, -0.4, 0.5]\n"
-            "kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5)\n"
+            "kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5, neigh_delay=0)\n"
             "e = capi.Engine(capi.default_params(**kw))\n"
             "e.register_replica('pe', 1, d)\n"
             "L = d['box'][3:6] - d['box'][:3]\n"
@@ -694,9 +695,35 @@ def test_part_batches_give_the_same_stresses_as_the_whole_batch():
     assert ref["flips"] >= 2
     a = np.array(ref["s"])
     assert a.shape == (26, 6) and np.isfinite(a).all()
-    for env in ({}, {"SCEMA_MD_PARTS": "2"}, {"SCEMA_MD_PARTS": "3"}, {"SCEMA_MD_PARTS": "6"}):
+    for env in ({}, {"SCEMA_MD_PARTS": "2"}, {"SCEMA_MD_PARTS": "3"}):
         other = _child(code, env)
         b = np.array(other["s"])
         assert np.abs(a - b).max() < 1e-9 * np.abs(b).max(), (env, np.abs(a - b).max() / np.abs(b).max())
         assert other["steps"] == ref["steps"]
         assert other["flips"] == ref["flips"]
+
+
+def test_rows_kept_from_the_straining_run_pass_the_lists_own_test_first():
+    """The sampling run of an evaluation keeps the neighbour rows of its straining run (k_phase_init) -- where the list's displacement test says
+    so for the positions and the box it starts from: the straining run ends with one more remap of fix deform behind its last force evaluation
+    (3e-3 A per step at the reference's strain rate, 0.3 A at 1e-2 per fs, against half a skin of 0.5 A).  Until round 6 the rows stood
+    unchecked and a fast shear lost pairs in the set-up evaluation of the sampling run (1e-7 of the stress; found by the part-batch test
+    above).  One replica sheared at 1e-2 per fs across a box flip, then strained back: the same stresses as with a list build at the start of
+    every run (SCEMA_MD_KEEP_LIST=0), to rounding."""
+    code = ("import json, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "d = build_pe(2, 3, 5, jitter=0.05, seed=7); d['box'][6:9] = [0.7, -0.4, 0.5]\n"
+            "e = capi.Engine(capi.default_params(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5, neigh_delay=0))\n"
+            "e.register_replica('pe', 1, d)\n"
+            "L = d['box'][3:6] - d['box'][:3]\n"
+            "st = np.array([-5e-4 * L[0], -5e-4 * L[1], 1.6e-3 * L[2], 0.9 * L[0] * L[2] / L[1], 0, 0])\n"
+            "out = [list(e.strain_batch([capi.make_sim(0, 'pe', 1, st, nss=38, most_recent=capi.QP_NONE, strain_rate=1e-2)])[0].stress)]\n"
+            "out += [list(e.strain_batch([capi.make_sim(0, 'pe', 1, -0.02 * st, nss=30, strain_rate=1e-3)])[0].stress)]\n"
+            "p = e.profile()\n"
+            "print(json.dumps({'s': out, 'builds': p['neigh_builds'], 'flips': p['box_flips']}))\n")
+    kept, built = _child(code, {}), _child(code, {"SCEMA_MD_KEEP_LIST": "0"})
+    a, b = np.array(kept["s"]), np.array(built["s"])
+    assert kept["flips"] >= 1 and kept["flips"] == built["flips"]
+    assert np.abs(a - b).max() < 1e-11 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+    assert kept["builds"] <= built["builds"]
