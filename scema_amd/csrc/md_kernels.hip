@@ -119,7 +119,28 @@ __global__ void k_setup_post(const SimDev *sims) {
 // k_pre : beginning of a step (tiny, one block per simulation)
 // ------------------------------------------------------------------------------------------
 // the scalar part (one thread per simulation)
-__device__ __forceinline__ void pre_scalars(const SimDev &S, SimScalars &sc) {
+// displacement of box corner k (ix = k & 1, iy = k >> 1 & 1, iz = k >> 2: the order of box_corners) since the rows were built
+__device__ __forceinline__ double corner_disp(const SimScalars &sc, int k) {
+  BoxD b;
+  box_derive(sc.box, b);
+  const int ix = k & 1, iy = (k >> 1) & 1, iz = k >> 2;
+  const double dx = b.h[0] * ix + b.h[5] * iy + b.h[4] * iz + b.lo[0] - sc.corners_hold[3 * k];
+  const double dy = b.h[1] * iy + b.h[3] * iz + b.lo[1] - sc.corners_hold[3 * k + 1];
+  const double dz = b.h[2] * iz + b.lo[2] - sc.corners_hold[3 * k + 2];
+  return sqrt(dx * dx + dy * dy + dz * dz);
+}
+// the two LARGEST of the eight: LAMMPS' Neighbor::check_distance drops the old maximum when a new one arrives -- `if (d > d1) d1 = d; else
+// if (d > d2) d2 = d;` -- and so underestimates the corner motion of a box whose corners move by different amounts, by up to half.  A list
+// may be built earlier than LAMMPS builds its own, never later than its validity: results do not depend on when a valid list is built.
+__device__ __forceinline__ void two_largest(const double *d, double &d1, double &d2) {
+  d1 = 0.0; d2 = 0.0;
+  for (int k = 0; k < 8; k++) {
+    if (d[k] > d1) { d2 = d1; d1 = d[k]; }
+    else if (d[k] > d2) d2 = d[k];
+  }
+}
+// d1, d2: the two largest corner displacements (k_post has eight lanes compute the eight; the overload below does it alone)
+__device__ __forceinline__ void pre_scalars(const SimDev &S, SimScalars &sc, double d1, double d2) {
   {
     sc.step += 1;
     sc.ago += 1;
@@ -127,22 +148,10 @@ __device__ __forceinline__ void pre_scalars(const SimDev &S, SimScalars &sc) {
     sc.force_rebuild = 0;
     sc.check = (sc.ago >= S.neigh_delay) ? 1 : 0;
     // neighbour trigger threshold with a deforming triclinic box: the two largest box-corner
-    // displacements since the last build are taken off the skin
-    double c[24];
-    box_corners(sc.box, c);
-    double d1 = 0.0, d2 = 0.0;
-    for (int k = 0; k < 8; k++) {
-      double dx = c[3 * k] - sc.corners_hold[3 * k], dy = c[3 * k + 1] - sc.corners_hold[3 * k + 1],
-             dz = c[3 * k + 2] - sc.corners_hold[3 * k + 2];
-      double d = sqrt(dx * dx + dy * dy + dz * dz);
-      // (the two LARGEST: LAMMPS' Neighbor::check_distance drops the old maximum when a new one arrives -- `if (d > d1) d1 = d; else if
-      // (d > d2) d2 = d;` -- and so underestimates the corner motion of a box whose corners move by different amounts, by up to half.  A list
-      // may be built earlier than LAMMPS builds its own, never later than its validity: results do not depend on when a valid list is built.)
-      if (d > d1) { d2 = d1; d1 = d; }
-      else if (d > d2) d2 = d;
-    }
-    double delta = 0.5 * (S.skin - (d1 + d2));
-    sc.deltasq = delta * delta;
+    // displacements since the last build are taken off the skin (corners that have moved by the whole skin: every displacement
+    // triggers -- LAMMPS squares the negative difference and tests against that)
+    const double delta = 0.5 * (S.skin - (d1 + d2));
+    sc.deltasq = delta > 0.0 ? delta * delta : 0.0;
     // far skin band: a pair listed at r0 >= cutmax + far_band is inside the cutoff only after
     // 2 dmax + (d1 + d2) >= far_band
     const double far = 0.5 * (S.far_band - (d1 + d2));
@@ -153,6 +162,12 @@ __device__ __forceinline__ void pre_scalars(const SimDev &S, SimScalars &sc) {
     for (int k = 0; k < MD_NPART * 6; k++) sc.vir[k] = 0.0;
     for (int k = 0; k < MD_NPART; k++) sc.eng[k] = 0.0;
   }
+}
+__device__ __forceinline__ void pre_scalars(const SimDev &S, SimScalars &sc) {
+  double d[8], d1, d2;
+  for (int k = 0; k < 8; k++) d[k] = corner_disp(sc, k);
+  two_largest(d, d1, d2);
+  pre_scalars(S, sc, d1, d2);
 }
 __global__ void k_pre(const SimDev *sims) {
   const SimDev &S = sims[blockIdx.x];
@@ -1250,10 +1265,20 @@ __global__ void k_post(const SimDev *sims, int next_pre) {
     for (int k = threadIdx.x; k < (int)(sizeof(SimScalars) / 8); k += blockDim.x) dst[k] = src[k];
   }
   __syncthreads();
+  __shared__ double s_d[8];
   if (threadIdx.x == 0) {
     post_scalars(S, s_sc);
     s_more = next_pre && s_sc.step < S.nsteps;
-    if (s_more) pre_scalars(S, s_sc);
+  }
+  __syncthreads();
+  if (s_more) {   // (the eight corner displacements -- a box_derive and a square root each -- on eight lanes instead of one after the other)
+    if (threadIdx.x < 8) s_d[threadIdx.x] = corner_disp(s_sc, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double d1, d2;
+      two_largest(s_d, d1, d2);
+      pre_scalars(S, s_sc, d1, d2);
+    }
   }
   __syncthreads();
   {

@@ -17,18 +17,25 @@ if f:
              x.get('Stream_Id') or x.get('Queue_Id') or '0') for x in csv.DictReader(open(f[0]))]
     rows.sort()
     gmax = max(g for s, e, k, g, q in rows if anchor in k)
-    big = [i for i, x in enumerate(rows) if anchor in x[2] and 2 * x[3] >= gmax]   # whole and half batches; not the one-replica equilibration
+    # whole batches and part batches (run_phase: four parts for 10-16 replicas, three for 17-31, four for 32-63, two halves beyond; the
+    # smallest part of p holds at least n // p of the n replicas); not the one-replica equilibration
+    pmax = 1 if n < 10 or anchor != 'k_pair' else 4 if n < 17 else 3 if n < 32 else 4 if n < 64 else 2
+    if anchor != 'k_pair': pmax = 2
+    fmin = (n // pmax) / n * 0.999 if n >= 2 * pmax else 0.5
+    fmin = min(fmin, 0.5) if pmax > 1 else 0.999 if n > 1 else 0.5
+    is_big = lambda x: anchor in x[2] and x[3] >= fmin * gmax
+    big = [i for i, x in enumerate(rows) if is_big(x)]
     lo, hi = big[len(big) // 3], big[-1]
     win = rows[lo:hi]
-    streams = {x[4] for x in win if anchor in x[2] and 2 * x[3] >= gmax}
-    nanchor = sum(1 for x in win if anchor in x[2] and 2 * x[3] >= gmax)
+    streams = {x[4] for x in win if is_big(x)}
+    nanchor = sum(1 for x in win if is_big(x))
     steps = nanchor / max(len(streams), 1)          # MD steps of the batch in the window (each part batch has its own stream)
     busy, cur = 0, rows[lo][0]
     for s, e, k, g, q in win:
         busy += max(0, e - max(s, cur))
         cur = max(cur, e)
     wall = rows[hi][0] - rows[lo][0]
-    ak = [x for x in win if anchor in x[2] and 2 * x[3] >= gmax]
+    ak = [x for x in win if is_big(x)]
     row.update({'launches_per_step': len(win) / steps, 'busy_us_per_step': busy / steps / 1e3, 'idle_us_per_step': (wall - busy) / steps / 1e3,
                 'wall_us_per_step': wall / steps / 1e3, 'anchor_avg_us': sum(x[1] - x[0] for x in ak) / len(ak) / 1e3,
                 'anchor_streams': len(streams), 'anchor_us_per_replica_as_run': sum(x[1] - x[0] for x in ak) / len(ak) / 1e3 / (n / max(len(streams), 1))})
