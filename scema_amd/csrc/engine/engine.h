@@ -339,6 +339,7 @@ struct scema_md_engine {
   double neigh_grow = 1.0;   // headroom factor of the cluster rows, x1.5 per overflow
   double jtab_grow = 1.0;    // headroom factor of the tile j tables, x1.25 per overflow (-> smaller cells)
   int overflow_bits = 0;     // what overflowed in the last run: 4 = a tile's j table, 8 = a cluster row
+  double overflow_need_j = 1.0, overflow_need_row = 1.0;   // ... and the largest demand / capacity the run saw (the retry grows by at least that)
   long long unsettled_updates = 0;   // updates of a world > 1 without a communicator that the next call found unsettled and let stand
   // ReaxFF path (force_field "reax"): the force-field tables, settings of fix qeq/reax, list skin
   bool rx_ready = false, reax_active = false;

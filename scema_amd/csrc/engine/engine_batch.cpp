@@ -143,8 +143,9 @@ int eval_chunk(scema_md_engine *e, std::vector<ActiveSim> &chunk, const EvalOpt 
     rc = backup_states(e, chunk, true, pool_off);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->overflow_bits & 4) e->jtab_grow *= 1.25;
-    if ((e->overflow_bits & 8) || !(e->overflow_bits & 4)) e->neigh_grow *= 1.5;
+    // (by the demand the failed run saw where that is more than the fixed step: a capacity far too small is found in one retry, not six)
+    if (e->overflow_bits & 4) e->jtab_grow *= std::max(1.25, std::min(8.0, 1.1 * e->overflow_need_j));
+    if ((e->overflow_bits & 8) || !(e->overflow_bits & 4)) e->neigh_grow *= std::max(1.5, std::min(8.0, 1.1 * e->overflow_need_row));
   }
   return fail(e, SCEMA_MD_ERR_OVERFLOW, "neighbour capacity exceeded after regrowth");
 }

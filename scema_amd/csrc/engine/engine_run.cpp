@@ -932,10 +932,23 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     e->prof.unique_pairs_sum += 0.5 * (double)e->h_sc[i].nentries_ref;
     e->prof.unique_pairs_n += 1;
   }
+  // A capacity that overflowed comes first: the run went on with truncated rows or tables (nothing is written past a capacity, pairs are
+  // missing), so an instability or a stretched special pair later in the same run is its consequence, not the caller's input -- the retry
+  // with grown capacities starts from the backup and reports them if they are real.
+  e->overflow_bits = fault;
+  e->overflow_need_j = e->overflow_need_row = 1.0;
+  {   // (what the builds of this run saw -- a table's count runs on past its capacity, a row's stops a chunk beyond -- against the smallest capacity of the launch)
+    int seen_j = 0, seen_row = 0, cap_j = 1 << 30, cap_row = 1 << 30;
+    for (int i = 0; i < ns; i++) {
+      seen_j = std::max(seen_j, e->h_sc[i].maxj_seen); seen_row = std::max(seen_row, e->h_sc[i].maxneigh_seen);
+      cap_j = std::min(cap_j, std::max(1, e->h_sims[i].capj)); cap_row = std::min(cap_row, std::max(1, e->h_sims[i].maxneigh));
+    }
+    e->overflow_need_j = std::max(1.0, (double)seen_j / cap_j);
+    e->overflow_need_row = std::max(1.0, (double)seen_row / cap_row);
+  }
+  if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
   if (fault & 16) return fail(e, SCEMA_MD_ERR_ARG, "a simulation became unstable (non-finite or runaway atom positions): overlapping atoms or parameters far from the replica's equilibrium");
   if (fault & 2) return fail(e, SCEMA_MD_ERR_ARG, "an excluded (special) pair stretched beyond the exclusion gate; topology or state is broken");
-  e->overflow_bits = fault;
-  if (fault & 1) return SCEMA_MD_ERR_OVERFLOW;
   if (fault & 64) return SCEMA_MD_ERR_OVERFLOW;   // the barostat took the box out of the range this segment was laid out for
   for (int i = 0; i < ns; i++) {   // the rows on the device hold for the positions this run ended at
     ListSig &g = e->slots[i]->sig;
