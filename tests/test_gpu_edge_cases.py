@@ -676,7 +676,7 @@ def test_part_batches_give_the_same_stresses_as_the_whole_batch():
             "from scema_amd import capi\n"
             "from scema_amd.systems import build_pe\n"
             "d = build_pe(2, 3, 5, jitter=0.05, seed=7); d['box'][6:9] = [0.7, -0.4, 0.5]\n"
-            "kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5, neigh_delay=0)\n"
+            "kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5, neigh_delay=0, kspace_style=int(os.environ.get('TEST_KSPACE', '1')))\n"
             "e = capi.Engine(capi.default_params(**kw))\n"
             "e.register_replica('pe', 1, d)\n"
             "L = d['box'][3:6] - d['box'][:3]\n"
@@ -701,6 +701,11 @@ def test_part_batches_give_the_same_stresses_as_the_whole_batch():
         assert np.abs(a - b).max() < 1e-9 * np.abs(b).max(), (env, np.abs(a - b).max() / np.abs(b).max())
         assert other["steps"] == ref["steps"]
         assert other["flips"] == ref["flips"]
+    # the plain Ewald sum: a flip re-expresses the k-vector tables of its replica, uploaded on the stream of that replica's part
+    ref = _child(code, {"SCEMA_MD_SPLIT": "0", "TEST_KSPACE": "0"})
+    other = _child(code, {"TEST_KSPACE": "0"})
+    a, b = np.array(ref["s"]), np.array(other["s"])
+    assert np.abs(a - b).max() < 1e-9 * np.abs(b).max() and other["flips"] == ref["flips"] >= 2
 
 
 def test_rows_kept_from_the_straining_run_pass_the_lists_own_test_first():
@@ -727,3 +732,41 @@ def test_rows_kept_from_the_straining_run_pass_the_lists_own_test_first():
     assert kept["flips"] >= 1 and kept["flips"] == built["flips"]
     assert np.abs(a - b).max() < 1e-11 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
     assert kept["builds"] <= built["builds"]
+
+
+def test_part_batches_of_two_materials_give_the_same_stresses_as_the_whole_batch():
+    """A launch group of replicas of two materials of different size (1 080 and 1 728 atoms, different boxes, grids and PPPM meshes) and ragged
+    length, one of them sheared across a box flip, over two updates (the second continues the states of the first with the strains
+    reversed): whole, as the table's parts and as two halves -- the same stresses to rounding.  (delay 0 as in the test above.)"""
+    code = ("import json, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "a = build_pe(2, 3, 5, jitter=0.05, seed=7); a['box'][6:9] = [0.7, -0.4, 0.5]\n"
+            "b = build_pe(2, 4, 6, jitter=0.04, seed=11)\n"
+            "e = capi.Engine(capi.default_params(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5, neigh_delay=0))\n"
+            "e.register_replica('a', 1, a); e.register_replica('b', 1, b)\n"
+            "def st(d, q):\n"
+            "    L = d['box'][3:6] - d['box'][:3]\n"
+            "    return np.array([-3e-4 * L[0], 2e-4 * L[1], 1e-3 * L[2], 2e-5 * L[2], -1e-5 * L[2], 0]) * (1 + 0.2 * q)\n"
+            "La = a['box'][3:6] - a['box'][:3]\n"
+            "big = np.array([0, 0, 0, 0.9 * La[0] * La[2] / La[1], 0, 0])\n"
+            "n = 15\n"
+            "mat = lambda q: ('a', a, 0) if q % 3 else ('b', b, 1)\n"
+            "out = []\n"
+            "for sign, rec in ((1, capi.QP_NONE), (-1, None)):\n"
+            "    sims = []\n"
+            "    for q in range(n):\n"
+            "        name, d, m = mat(q)\n"
+            "        s = sign * st(d, q) + (big if (q == 4 and sign == 1) else 0)\n"
+            "        sims.append(capi.make_sim(q, name, 1, s, nss=22 + (5 * q) % 13, most_recent=rec, material=m, strain_rate=1e-2 if (q == 4 and sign == 1) else 1e-4))\n"
+            "    out += [list(o.stress) for o in e.strain_batch(sims)]\n"
+            "p = e.profile()\n"
+            "print(json.dumps({'s': out, 'steps': p['md_steps'], 'flips': p['box_flips']}))\n")
+    ref = _child(code, {"SCEMA_MD_SPLIT": "0"})
+    a = np.array(ref["s"])
+    assert a.shape == (30, 6) and np.isfinite(a).all() and ref["flips"] >= 1
+    for env in ({}, {"SCEMA_MD_PARTS": "2"}, {"SCEMA_MD_PARTS": "3"}):
+        other = _child(code, env)
+        b = np.array(other["s"])
+        assert np.abs(a - b).max() < 1e-9 * np.abs(b).max(), (env, np.abs(a - b).max() / np.abs(b).max())
+        assert other["steps"] == ref["steps"] and other["flips"] == ref["flips"]
