@@ -145,15 +145,15 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // k_pair saturates them and holds every wave slot of the chip; with independent parts in flight the small kernels of
   // one part fill in as the pair workgroups of another retire (the in-order streams fall out of phase by themselves).
   // The parts take every nparts-th rank of the length order, so each is itself sorted longest first.  How many parts is
-  // a measured table (profiles/r06_t_parts_ab*.log, same-box A/B against the whole / two-half forms): under 10 replicas
+  // a measured table (profiles/r06_t_parts_ab.log, same-box A/B against the whole / two-half forms): under 10 replicas
   // the batch runs whole with its PPPM chain on the side stream; 10-16 replicas +2..7 % as four parts, 17-31 +4.5..8 %
   // as three, 32-63 +3.7..5.9 % as four; from 64 on two halves (three or four parts: -0.5..+0.7 %, the chip is full
-  // either way).  Four is the most: a process has four hardware queues and further streams share them -- five to eight parts on
-  // streams of their own were measured (six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 %) and, as six or
-  // seven parts of two replicas each, gave stresses of some replicas that were off by 1e-4 in some runs and not in others (not
-  // understood; no such run with four parts or fewer in any size; profiles/r06_t_parts_ab.log) -- the code for them is gone.
-  // SCEMA_MD_PARTS (2-4) forces a count for batches of SCEMA_MD_PART_MIN
-  // (2) replicas per part and more, SCEMA_MD_SPLIT_MIN moves the lower end, SCEMA_MD_SPLIT=0 runs every batch whole.
+  // either way).  Four is the most: a process has four hardware queues and further streams share them.  Five to eight
+  // parts were measured -- six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 % -- and, as six or seven
+  // parts of two replicas each, gave stresses of two replicas that were off by 1e-4 in most runs (PPPM path only; never
+  // with four parts or fewer: 42 runs of three shapes; not understood, same log): the code for them is gone.
+  // SCEMA_MD_PARTS (2-4) forces a count for batches of SCEMA_MD_PART_MIN (2) replicas per part and more,
+  // SCEMA_MD_SPLIT_MIN moves the lower end, SCEMA_MD_SPLIT=0 runs every batch whole.
   constexpr int MAXP = 4;
   static const int parts_env = [] { const char *s = scema_env("SCEMA_MD_PARTS"); return s ? std::min(4, std::max(2, atoi(s))) : 0; }();
   static const int part_min_env = [] { const char *s = scema_env("SCEMA_MD_PART_MIN"); return s ? std::max(1, atoi(s)) : 2; }();
