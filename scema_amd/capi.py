@@ -36,7 +36,7 @@ SYMBOLS = [
     "scema_md_comm_world", "scema_md_comm_rank", "scema_md_comm_stats", "scema_md_comm_handshakes", "scema_md_state_owner", "scema_md_last_plan",
     "scema_plan_dir_create", "scema_plan_dir_destroy", "scema_plan_update", "scema_md_kspace_setup",
     "scema_md_save_state_dump", "scema_md_replica_natoms", "scema_md_save_replica_file", "scema_md_equilibrate", "scema_md_debug_minimize", "scema_md_debug_run_nh",
-    "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_concurrency", "scema_md_batch_split", "scema_md_get_concurrency", "scema_md_unsettled_updates", "scema_md_reax_debug_compute", "scema_md_reax_stats", "scema_md_box_fma_tflops",
+    "scema_md_reax_configure", "scema_md_reax_activate", "scema_md_reax_set", "scema_md_reax_concurrency", "scema_md_batch_split", "scema_md_get_concurrency", "scema_md_pppm_plan_count", "scema_md_unsettled_updates", "scema_md_reax_debug_compute", "scema_md_reax_stats", "scema_md_box_fma_tflops",
 ]
 COMM_ID_BYTES = 128
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -439,6 +439,11 @@ class Engine:
 
     def batch_split(self, on: int = -1):
         self._chk(lib().scema_md_batch_split(self.h, C.c_int32(on)))
+
+    def pppm_plan_count(self) -> int:
+        """batched hipFFT plans the engine holds (one per mesh size, batch count and stream)"""
+        lib().scema_md_pppm_plan_count.restype = C.c_int
+        return int(lib().scema_md_pppm_plan_count(self.h))
 
     def concurrency(self) -> dict:
         """the current issue settings: {"split": 0/1, "reax_halves": n, "reax_overlap": 0/1}"""

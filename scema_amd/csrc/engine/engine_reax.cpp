@@ -621,6 +621,7 @@ int scema_md_get_concurrency(const scema_md_engine *e, int32_t *out) {
   out[2] = e->rx_overlap ? 1 : 0;
   return SCEMA_MD_OK;
 }
+int scema_md_pppm_plan_count(const scema_md_engine *e) { return e ? (int)e->pppm_plans.size() : -SCEMA_MD_ERR_ARG; }
 int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms, int32_t qeq_maxiter) {
   if (!e || !e->rx_ready) return fail(e, SCEMA_MD_ERR_ARG, "no ReaxFF force field loaded");
   HIPCHK(hipSetDevice(e->p.device));

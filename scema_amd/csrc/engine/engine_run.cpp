@@ -149,9 +149,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // the batch runs whole with its PPPM chain on the side stream; 10-16 replicas +2..7 % as four parts, 17-31 +4.5..8 %
   // as three, 32-63 +3.7..5.9 % as four; from 64 on two halves (three or four parts: -0.5..+0.7 %, the chip is full
   // either way).  Four is the most: a process has four hardware queues and further streams share them.  Five to eight
-  // parts were measured -- six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 % -- and, as six or seven
-  // parts of two replicas each, gave stresses of two replicas that were off by 1e-4 in most runs (PPPM path only; never
-  // with four parts or fewer: 42 runs of three shapes; not understood, same log): the code for them is gone.
+  // parts were measured -- six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 % -- and removed.  (They
+  // also showed a bug: the hipFFT plans of the PPPM path were shared by all part streams beyond the second, pppm_plan below.)
   // SCEMA_MD_PARTS (2-4) forces a count for batches of SCEMA_MD_PART_MIN (2) replicas per part and more,
   // SCEMA_MD_SPLIT_MIN moves the lower end, SCEMA_MD_SPLIT=0 runs every batch whole.
   constexpr int MAXP = 4;
@@ -530,7 +529,12 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // all their field grids: three per simulation, simulation-major).  A plan owns work space, so each stream has its own.
   auto pppm_plan = [&](const int pg[3], int batch, hipStream_t st, hipfftHandle &plan) -> int {
     if ((long long)maxgrid > 0x7fffffffLL) return fail(e, SCEMA_MD_ERR_ARG, "PPPM grid of %d points is too large", maxgrid);
-    const std::array<int, 6> key = {pg[0], pg[1], pg[2], batch, st == e->stream ? 0 : st == e->stream2 ? 1 : st == e->stream3 ? 2 : 3, maxgrid};   // (a plan owns work space: one per stream of a part batch)
+    // A plan owns a work area and is bound to a stream when it runs: ONE PER STREAM that may run it.  (Until round 6 the key knew the main
+    // stream, the side stream and "the other one": with three or four part batches two parts shared the plans of their common mesh sizes --
+    // two replicas with the same mesh beyond the in-LDS solve, one in each, transformed through one work area at the same time.)
+    const int sk = st == e->stream ? 0 : st == e->stream2 ? 1 : st == e->stream3 ? 2 : st == e->rx_side1 ? 3 : -1;
+    if (sk < 0) return fail(e, SCEMA_MD_ERR_ARG, "PPPM transform on a stream the engine does not know");
+    const std::array<int, 6> key = {pg[0], pg[1], pg[2], batch, sk, maxgrid};
     auto it = e->pppm_plans.find(key);
     if (it == e->pppm_plans.end()) {
       hipfftHandle h;

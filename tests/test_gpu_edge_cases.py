@@ -664,14 +664,8 @@ def test_round6_launch_variants_give_the_same_stresses(small_pe):
             assert ref["builds"] >= other["builds"], (ref["builds"], other["builds"])   # a common trigger builds at least as often
 
 
-def test_part_batches_give_the_same_stresses_as_the_whole_batch():
-    """Batches of 10 replicas and more run as part batches on streams of their own (engine_run.cpp: four parts for 10-16, three for 17-31, four
-    for 32-63, two halves from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
-    13 replicas of ragged length (nss 40 down to 28) with different strains -- two of them sheared until their boxes flip, which is
-    host work between two steps of their part --, then its reverse from the states it left: the same stresses
-    whole (SCEMA_MD_SPLIT=0), as the table's four parts, as two and as three parts, and the same number of MD steps.  (neigh_modify delay 0: with the reference's `delay 5` and this test's skin of 1 A a list is
-    used past its validity wherever an atom covers half the skin within five steps of a build -- LAMMPS' "dangerous builds", certain in a box
-    sheared by 0.3 A per step -- and the result then depends on the step a list was built at, here as in LAMMPS.)"""
+def _parts_code(n=13, sheared=(2, 7)):
+    """the child process of the part-batch tests: n replicas of ragged length, two of them sheared across a box flip; two updates"""
     code = ("import json, os, numpy as np\n"
             "from scema_amd import capi\n"
             "from scema_amd.systems import build_pe\n"
@@ -691,6 +685,18 @@ def test_part_batches_give_the_same_stresses_as_the_whole_batch():
             "out += [list(o.stress) for o in a]\n"
             "p = e.profile()\n"
             "print(json.dumps({'s': out, 'steps': p['md_steps'], 'flips': p['box_flips']}))\n")
+    return code.replace("n = 13", f"n = {n}").replace("(2, 7)", repr(tuple(sheared)))
+
+
+def test_part_batches_give_the_same_stresses_as_the_whole_batch():
+    """Batches of 10 replicas and more run as part batches on streams of their own (engine_run.cpp: four parts for 10-16, three for 17-31, four
+    for 32-63, two halves from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
+    13 replicas of ragged length (nss 40 down to 28) with different strains -- two of them sheared until their boxes flip, which is
+    host work between two steps of their part --, then its reverse from the states it left: the same stresses
+    whole (SCEMA_MD_SPLIT=0), as the table's four parts, as two and as three parts, and the same number of MD steps.  (neigh_modify delay 0: with the reference's `delay 5` and this test's skin of 1 A a list is
+    used past its validity wherever an atom covers half the skin within five steps of a build -- LAMMPS' "dangerous builds", certain in a box
+    sheared by 0.3 A per step -- and the result then depends on the step a list was built at, here as in LAMMPS.)"""
+    code = _parts_code()
     ref = _child(code, {"SCEMA_MD_SPLIT": "0"})
     assert ref["flips"] >= 2
     a = np.array(ref["s"])
@@ -770,3 +776,27 @@ def test_part_batches_of_two_materials_give_the_same_stresses_as_the_whole_batch
         b = np.array(other["s"])
         assert np.abs(a - b).max() < 1e-9 * np.abs(b).max(), (env, np.abs(a - b).max() / np.abs(b).max())
         assert other["steps"] == ref["steps"] and other["flips"] == ref["flips"]
+
+
+def test_part_batches_transform_their_pppm_meshes_through_plans_of_their_own():
+    """Meshes beyond the in-LDS solve go through hipFFT, whose plans own a work area and are bound to a stream when they run: one per mesh
+    size, batch count AND stream.  Round 6's part batches first ran with plans keyed by "main stream / side stream / any other": the second
+    and the fourth part of a batch shared theirs, and two replicas with the same large mesh, one in each of those parts, came out wrong by
+    1e-4 in one run of ten (with six parts: nine of ten -- how it was found).  A race is no test; the plans are counted instead: twelve
+    replicas of one box, every mesh through hipFFT (SCEMA_MD_PPPM_FFT=1), as four parts of three hold 4 streams x (charge meshes, field
+    meshes) = 8 plans, the batch whole 2 -- and the stresses agree."""
+    code = ("import json, os, numpy as np\n"
+            "from scema_amd import capi\n"
+            "from scema_amd.systems import build_pe\n"
+            "d = build_pe(2, 3, 5, jitter=0.05, seed=7)\n"
+            "e = capi.Engine(capi.default_params(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-5, neigh_delay=0))\n"
+            "e.register_replica('pe', 1, d)\n"
+            "L = d['box'][3:6] - d['box'][:3]\n"
+            "st = np.array([-3e-4 * L[0], -3e-4 * L[1], 1e-3 * L[2], 2e-5 * L[2], 0, 0])\n"
+            "out = [list(o.stress) for o in e.strain_batch([capi.make_sim(q, 'pe', 1, st, nss=14, most_recent=capi.QP_NONE) for q in range(12)])]\n"
+            "print(json.dumps({'s': out, 'plans': e.pppm_plan_count()}))\n")
+    whole = _child(code, {"SCEMA_MD_SPLIT": "0", "SCEMA_MD_PPPM_FFT": "1"})
+    parts = _child(code, {"SCEMA_MD_PARTS": "4", "SCEMA_MD_PPPM_FFT": "1"})
+    assert whole["plans"] == 2 and parts["plans"] == 8, (whole["plans"], parts["plans"])
+    a, b = np.array(whole["s"]), np.array(parts["s"])
+    assert np.abs(a - b).max() < 1e-9 * np.abs(b).max()
