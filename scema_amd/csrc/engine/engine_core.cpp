@@ -63,7 +63,7 @@ const EnvSwitch k_env[] = {
     {"SCEMA_MD_FUSED_TAIL", "0 / 1: force assembly + SHAKE + second kick as three kernels / as k_finish (default: by batch size)"},
     {"SCEMA_MD_BONDED_SIDE", "0: the bonded kernel of a small batch always on the main stream behind the pair kernel (default: behind the PPPM chain on the side stream on steps without a new influence function)"},
     {"SCEMA_MD_BONDED_SIDE_MIN", "smallest batch whose bonded kernel follows the PPPM chain on the side stream (default 8: below, that chain is the longer one)"},
-    {"SCEMA_MD_SMALL_BATCH_MAX", "largest batch that takes the cell grid with the most cells instead of the largest cells (default 31: every launch group that runs whole)"},
+    {"SCEMA_MD_SMALL_BATCH_MAX", "largest batch that takes the cell grid with the most cells instead of the largest cells (default: launch groups of up to 31 replicas that run whole, i.e. not as part batches)"},
     {"SCEMA_MD_REBUILD_TOGETHER", "0 / 1: every replica rebuilds its neighbour rows on its own trigger / the replicas of a launch rebuild together as soon as one asks for it (default: together in launches of fewer than 128 replicas)"},
     {"SCEMA_MD_CELL_BUILD", "0: cell binning as k_bin + k_cell_scan + k_cell_fill instead of the one-launch k_cell_build"},
     {"SCEMA_MD_POLY_TOL", "fit target of the real-space Ewald polynomial (default 2e-13); parity tolerances assume the default"},

@@ -146,9 +146,9 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // one part fill in as the pair workgroups of another retire (the in-order streams fall out of phase by themselves).
   // The parts take every nparts-th rank of the length order, so each is itself sorted longest first.  How many parts is
   // a measured table (profiles/r06_t_parts_ab.log, same-box A/B against the whole / two-half forms): under 10 replicas
-  // the batch runs whole with its PPPM chain on the side stream; 10-16 replicas +2..7 % as four parts, 17-31 +4.5..8 %
-  // as three, 32-63 +3.7..5.9 % as four; from 64 on two halves (three or four parts: -0.5..+0.7 %, the chip is full
-  // either way).  Four is the most: a process has four hardware queues and further streams share them.  Five to eight
+  // the batch runs whole with its PPPM chain on the side stream; 10-63 replicas as four parts (with the largest cells,
+  // below: +6..12 % at 10-30 replicas, +4..6 % at 36-60; three parts 1-2 % behind, two 4-7 %); from 64 on two halves
+  // (three or four parts: -0.5..+0.7 %, the chip is full either way).  Four is the most: a process has four hardware queues and further streams share them.  Five to eight
   // parts were measured -- six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 % -- and removed.  (They
   // also showed a bug: the hipFFT plans of the PPPM path were shared by all part streams beyond the second, pppm_plan below.)
   // SCEMA_MD_PARTS (2-4) forces a count for batches of SCEMA_MD_PART_MIN (2) replicas per part and more,
@@ -159,7 +159,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const bool can_split = e->split_streams && e->stream3 != nullptr && ns >= e->split_min && ns < e->split_max;
   int nhalf = 1;
   if (can_split) {
-    nhalf = parts_env > 0 ? (ns >= part_min_env * parts_env ? parts_env : 2) : ns < 17 ? 4 : ns < 32 ? 3 : ns < 64 ? 4 : 2;
+    nhalf = parts_env > 0 ? (ns >= part_min_env * parts_env ? parts_env : 2) : ns < 64 ? 4 : 2;
     if (e->stream2 == nullptr || e->rx_side1 == nullptr) nhalf = std::min(nhalf, 2);
     nhalf = std::max(1, std::min(nhalf, ns / 2));
   }
@@ -326,8 +326,8 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
     // replicas up to which the most-cells grid is taken: every launch group that runs whole (scanned again in round 6, profiles/r06_d_cells_scan.txt:
     // 180 instead of 120 cells +5.4 % at 9 replicas, +2.4 % at 18; batches of 32 and more run as two half batches that fill the chip together and
     // are fastest with the largest cells: 120 against 180 cells 378 / 372 evaluations/s at 36, 422 / 417 at 72, 441 / 429 at 144)
-    static const int small_max = scema_env("SCEMA_MD_SMALL_BATCH_MAX") ? atoi(scema_env("SCEMA_MD_SMALL_BATCH_MAX")) : 31;
-    const bool small_batch = ns <= small_max;
+    static const int small_max = scema_env("SCEMA_MD_SMALL_BATCH_MAX") ? atoi(scema_env("SCEMA_MD_SMALL_BATCH_MAX")) : -1;
+    const bool small_batch = small_max >= 0 ? ns <= small_max : (nhalf == 1 && ns <= 31);   // (31: a large batch issued whole -- SCEMA_MD_SPLIT=0, the chip-exclusive timing of bench.py -- keeps the grid it has as two halves; part batches fill the chip together, like the two halves of a large batch: 120 against 180 cells 345 / 330 evaluations/s at 12 replicas, 370 / 361 at 18, 391 / 386 at 24, profiles/r06_t_parts_ab.log)
     static const int cells_target = scema_env("SCEMA_MD_CELLS_TARGET") ? atoi(scema_env("SCEMA_MD_CELLS_TARGET")) : 0;
     for (int pass = 0; pass < 2 && !fits; pass++) {
       int lo[3], hi[3];

@@ -689,8 +689,8 @@ def _parts_code(n=13, sheared=(2, 7)):
 
 
 def test_part_batches_give_the_same_stresses_as_the_whole_batch():
-    """Batches of 10 replicas and more run as part batches on streams of their own (engine_run.cpp: four parts for 10-16, three for 17-31, four
-    for 32-63, two halves from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
+    """Batches of 10 replicas and more run as part batches on streams of their own (engine_run.cpp: four parts for 10-63 replicas, two halves
+    from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
     13 replicas of ragged length (nss 40 down to 28) with different strains -- two of them sheared until their boxes flip, which is
     host work between two steps of their part --, then its reverse from the states it left: the same stresses
     whole (SCEMA_MD_SPLIT=0), as the table's four parts, as two and as three parts, and the same number of MD steps.  (neigh_modify delay 0: with the reference's `delay 5` and this test's skin of 1 A a list is
