@@ -335,7 +335,7 @@ int scema_md_reax_set(scema_md_engine *e, int32_t exact_gradient, int32_t terms,
    chain (default), 0 = one after the other.  -1 leaves a setting as it is.  A measurement aid: bench.py times the charge-equilibration sweep
    alone with both off.  (The reference has no counterpart: its LAMMPS ranks run one replica each, stmd_sync.h:583.) */
 int scema_md_reax_concurrency(scema_md_engine *e, int32_t halves, int32_t overlap);
-/* The same for the OPLS path: on = 1 (default) runs a launch group of 10 simulations and more as two to four part batches on streams of their own, 0 runs it whole
+/* The same for the OPLS path: on = 1 (default) runs a launch group of 9 simulations and more as two to four part batches on streams of their own, 0 runs it whole
  * (one sequence of launches: what a kernel's time is with the chip to itself), -1 keeps the setting.  Results do not depend on it. */
 int scema_md_batch_split(scema_md_engine *e, int32_t on);
 /* out[3]: the current settings {batch split, ReaxFF part batches, ReaxFF overlap}, so that a caller that changes them for a measurement can

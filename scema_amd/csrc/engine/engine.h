@@ -300,7 +300,7 @@ struct scema_md_engine {
   hipStream_t stream3 = nullptr;          // second half batch of a large launch group (run_phase)
   hipEvent_t ev_up = nullptr;
   bool split_streams = true;              // SCEMA_MD_SPLIT=0 switches the two-half pipeline off
-  int split_min = 10, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
+  int split_min = 9, split_max = 1 << 30;  // launch groups from this size on are split (SCEMA_MD_SPLIT_MAX puts an upper end back: round 2 measured 336 evals/s either way
                                          // at 576 and left large groups whole; with round 4's kernels the halves give 437 against 429, profiles/r04_zs_*)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool rx_qeq_failed = false;             // the last ReaxFF run ended with a charge solve that did not converge (eval_chunk's one retry with the Jacobi preconditioner)

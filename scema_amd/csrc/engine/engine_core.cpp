@@ -46,9 +46,9 @@ struct EnvSwitch { const char *name, *what; };
 const EnvSwitch k_env[] = {
     // performance switches with a measured default; a reported run sets none of them
     {"SCEMA_MD_SPLIT_MAX", "launch groups of this many replicas and more run whole instead of as two half batches (default: none)"},
-    {"SCEMA_MD_SPLIT", "0: never run a launch group of 10 simulations and more as part batches on streams of their own"},
+    {"SCEMA_MD_SPLIT", "0: never run a launch group of 9 simulations and more as part batches on streams of their own"},
     {"SCEMA_MD_PPPM_SIDE_MIN", "smallest batch whose PPPM chain runs on the side stream next to the pair kernel (default 1; 4 until round 5)"},
-    {"SCEMA_MD_SPLIT_MIN", "launch groups from this many replicas on run as part batches on streams of their own (default 10)"},
+    {"SCEMA_MD_SPLIT_MIN", "launch groups from this many replicas on run as part batches on streams of their own (default 9)"},
     {"SCEMA_MD_PART_MIN", "SCEMA_MD_PARTS applies to launch groups of this many replicas per part and more (default 2; smaller groups run as two parts)"},
     {"SCEMA_MD_PARTS", "2-4: this many part batches for every launch group that is split (default: by the size of the group, engine_run.cpp)"},
     {"SCEMA_MD_CELLS_TARGET", "what-if: take the cell grid (= tiling of the pair kernel) whose number of cells is closest to this among the grids that fit"},

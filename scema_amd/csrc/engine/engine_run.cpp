@@ -145,10 +145,11 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   // k_pair saturates them and holds every wave slot of the chip; with independent parts in flight the small kernels of
   // one part fill in as the pair workgroups of another retire (the in-order streams fall out of phase by themselves).
   // The parts take every nparts-th rank of the length order, so each is itself sorted longest first.  How many parts is
-  // a measured table (profiles/r06_t_parts_ab.log, same-box A/B against the whole / two-half forms): under 10 replicas
-  // the batch runs whole with its PPPM chain on the side stream; 10-63 replicas as four parts (with the largest cells,
-  // below: +6..12 % at 10-30 replicas, +4..6 % at 36-60; three parts 1-2 % behind, two 4-7 %); from 64 on two halves
-  // (three or four parts: -0.5..+0.7 %, the chip is full either way).  Four is the most: a process has four hardware queues and further streams share them.  Five to eight
+  // a measured table (profiles/r06_t_parts_ab.log, same-box A/B against the whole / two-half forms): under 9 replicas
+  // the batch runs whole with its PPPM chain on the side stream (8 replicas: 289 whole, 285 / 281 as three / four parts);
+  // 9 replicas as three parts of three (306 against 294); 10-63 replicas as four parts (with the largest cells, below:
+  // +6..12 % at 10-30 replicas, +4..6 % at 36-60; three parts 1-2 % behind, two 4-7 %); from 64 on two halves (three or
+  // four parts: -0.5..+0.7 %, the chip is full either way).  Four is the most: a process has four hardware queues and further streams share them.  Five to eight
   // parts were measured -- six parts of a 36-replica batch: -12 %; with GPU_MAX_HW_QUEUES=8 -29 % -- and removed.  (They
   // also showed a bug: the hipFFT plans of the PPPM path were shared by all part streams beyond the second, pppm_plan below.)
   // SCEMA_MD_PARTS (2-4) forces a count for batches of SCEMA_MD_PART_MIN (2) replicas per part and more,
@@ -159,7 +160,7 @@ int run_phase(scema_md_engine *e, std::vector<ActiveSim> &sims, const RunSpec &s
   const bool can_split = e->split_streams && e->stream3 != nullptr && ns >= e->split_min && ns < e->split_max;
   int nhalf = 1;
   if (can_split) {
-    nhalf = parts_env > 0 ? (ns >= part_min_env * parts_env ? parts_env : 2) : ns < 64 ? 4 : 2;
+    nhalf = parts_env > 0 ? (ns >= part_min_env * parts_env ? parts_env : 2) : ns < 10 ? 3 : ns < 64 ? 4 : 2;
     if (e->stream2 == nullptr || e->rx_side1 == nullptr) nhalf = std::min(nhalf, 2);
     nhalf = std::max(1, std::min(nhalf, ns / 2));
   }

@@ -633,7 +633,7 @@ def test_round6_launch_variants_give_the_same_stresses(small_pe):
     rows together as soon as one asks for it (SCEMA_MD_REBUILD_TOGETHER=0: each on its own trigger), the bonded kernel follows the PPPM chain on
     the side stream for batches of 8 and more (SCEMA_MD_BONDED_SIDE=0), the in-LDS PPPM solve of batches under 8 is two workgroups per replica
     (SCEMA_MD_PPPM_SOLVE_TWO=0), every batch that runs whole takes the grid with the most cells (SCEMA_MD_SMALL_BATCH_MAX=0: the largest
-    cells).  A 9-replica update sequence with different strains per replica (so that their lists age differently) and a 2-replica one: the
+    cells).  An 8-replica update sequence (the largest batch that runs whole) with different strains per replica (so that their lists age differently) and a 2-replica one: the
     same stresses with every switch, and more list builds with the common trigger than with the replicas' own."""
     code = ("import json, os, numpy as np\n"
             "from scema_amd import capi\n"
@@ -645,7 +645,7 @@ def test_round6_launch_variants_give_the_same_stresses(small_pe):
             "L = d['box'][3:6] - d['box'][:3]\n"
             "st = np.array([-3e-4 * L[0], -3e-4 * L[1], 1e-3 * L[2], 2e-5 * L[2], 0, 0])\n"
             "out = []\n"
-            "for n in (9, 2):\n"
+            "for n in (8, 2):\n"
             "    a = e.strain_batch([capi.make_sim(100 * n + q, 'pe', 1, st * (1 + 0.3 * q), nss=40, most_recent=capi.QP_NONE) for q in range(n)])\n"
             "    out += [list(o.stress) for o in a]\n"
             "    a = e.strain_batch([capi.make_sim(100 * n + q, 'pe', 1, -st * (1 + 0.1 * q), nss=40) for q in range(n)])\n"
@@ -689,8 +689,8 @@ def _parts_code(n=13, sheared=(2, 7)):
 
 
 def test_part_batches_give_the_same_stresses_as_the_whole_batch():
-    """Batches of 10 replicas and more run as part batches on streams of their own (engine_run.cpp: four parts for 10-63 replicas, two halves
-    from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
+    """Batches of 10 replicas and more run as part batches on streams of their own (engine_run.cpp: three parts for 9 replicas, four for 10-63, two
+    halves from 64 on); the parts are independent, so the count changes WHEN things run, never what is computed.  A batch of
     13 replicas of ragged length (nss 40 down to 28) with different strains -- two of them sheared until their boxes flip, which is
     host work between two steps of their part --, then its reverse from the states it left: the same stresses
     whole (SCEMA_MD_SPLIT=0), as the table's four parts, as two and as three parts, and the same number of MD steps.  (neigh_modify delay 0: with the reference's `delay 5` and this test's skin of 1 A a list is

@@ -43,9 +43,9 @@ python bench.py --force-field reax --sims 576 --steps 3 --warmup 1 --no-cpu-base
 python -c "import json; d=json.loads(open(\"gpurun_out/${T}_bench_reax_576sims.json.log\").read()); print(\"reax 576\", round(d[\"value\"],1), round(d[\"roofline\"][\"frac\"],3))"
 fi
 if [[ $PART == *b* ]]; then
-# 7. the batch-size curve of the same tree on the same box, kernel tables of a 9-replica and a single-replica batch as they run
+# 7. the batch-size curve of the same tree on the same box, kernel tables of an 8-replica (the largest batch that runs whole) and a single-replica batch as they run
 bash tools/batch_sweep.sh ${T} > gpurun_out/${T}_sweep.log 2>&1
-bash tools/small_prof.sh ${T} 9 > /dev/null 2>&1
+bash tools/small_prof.sh ${T} 8 > /dev/null 2>&1
 bash tools/small_prof.sh ${T} 1 > /dev/null 2>&1
 cat gpurun_out/${T}_batch_sweep.txt
 # 8. the curve of the round-5 library on the same box (scema_amd/libscema_md_r05.so: the tree of commit 9953bdf built with the same Makefile)

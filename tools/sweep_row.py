@@ -17,9 +17,9 @@ if f:
              x.get('Stream_Id') or x.get('Queue_Id') or '0') for x in csv.DictReader(open(f[0]))]
     rows.sort()
     gmax = max(g for s, e, k, g, q in rows if anchor in k)
-    # whole batches and part batches (run_phase: four parts for 10-63 replicas, two halves beyond; the
+    # whole batches and part batches (run_phase: three parts for 9 replicas, four for 10-63, two halves beyond; the
     # smallest part of p holds at least n // p of the n replicas); not the one-replica equilibration
-    pmax = 1 if n < 10 or anchor != 'k_pair' else 4 if n < 64 else 2
+    pmax = 1 if n < 9 or anchor != 'k_pair' else 3 if n < 10 else 4 if n < 64 else 2
     if anchor != 'k_pair': pmax = 2
     fmin = (n // pmax) / n * 0.999 if n >= 2 * pmax else 0.5
     fmin = min(fmin, 0.5) if pmax > 1 else 0.999 if n > 1 else 0.5
