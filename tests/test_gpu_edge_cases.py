@@ -701,7 +701,7 @@ def test_part_batches_give_the_same_stresses_as_the_whole_batch():
     assert ref["flips"] >= 2
     a = np.array(ref["s"])
     assert a.shape == (26, 6) and np.isfinite(a).all()
-    for env in ({}, {"SCEMA_MD_PARTS": "2"}, {"SCEMA_MD_PARTS": "3"}):
+    for env in ({}, {"SCEMA_MD_PARTS": "2"}, {"SCEMA_MD_PARTS": "3"}, {"SCEMA_MD_ONE_STREAM": "1"}):   # (ONE_STREAM: an engine without its side streams)
         other = _child(code, env)
         b = np.array(other["s"])
         assert np.abs(a - b).max() < 1e-9 * np.abs(b).max(), (env, np.abs(a - b).max() / np.abs(b).max())
