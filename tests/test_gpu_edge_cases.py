@@ -800,3 +800,37 @@ def test_part_batches_transform_their_pppm_meshes_through_plans_of_their_own():
     assert whole["plans"] == 2 and parts["plans"] == 8, (whole["plans"], parts["plans"])
     a, b = np.array(whole["s"]), np.array(parts["s"])
     assert np.abs(a - b).max() < 1e-9 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("n", [11, 23, 37])
+def test_a_replica_does_not_know_its_batch(n):
+    """What a replica returns does not depend on the company it is evaluated in: n replicas of ragged length and random strains in one
+    update() -- part batches, common list rebuilds, kept rows in the second update, which continues the states of the first with other
+    strains -- against every replica evaluated alone in an engine of its own, two updates each.  (delay 0: see the part-batch test.)"""
+    from scema_amd import capi
+    from scema_amd.systems import build_pe
+    d = build_pe(2, 3, 5, jitter=0.05, seed=7)
+    d["box"][6:9] = [0.4, -0.3, 0.2]
+    L = d["box"][3:6] - d["box"][:3]
+    rng = np.random.default_rng(100 + n)
+    amp = np.array([1e-3 * L[0], 1e-3 * L[1], 1e-3 * L[2], 3e-4 * L[2], 3e-4 * L[2], 3e-4 * L[1]])
+    strains = [rng.uniform(-1, 1, (n, 6)) * amp for _ in range(2)]
+    nss = [rng.integers(12, 30, n) for _ in range(2)]
+    kw = dict(cut_lj=5.0, cut_coul=4.0, skin=1.0, kspace_accuracy=1e-4, neigh_delay=0)
+
+    def run(qs):
+        e = capi.Engine(capi.default_params(**kw))
+        e.register_replica("pe", 1, d)
+        out = []
+        for u in range(2):
+            res = e.strain_batch([capi.make_sim(int(q), "pe", 1, strains[u][q], nss=int(nss[u][q]), most_recent=capi.QP_NONE if u == 0 else None) for q in qs])
+            out.append(np.array([list(o.stress) for o in res]))
+        e.close()
+        return out
+
+    together = run(range(n))
+    scale = max(np.abs(t).max() for t in together)
+    for q in rng.choice(n, size=min(n, 7), replace=False):
+        alone = run([int(q)])
+        for u in range(2):
+            assert np.abs(together[u][q] - alone[u][0]).max() < 1e-9 * scale, (int(q), u, np.abs(together[u][q] - alone[u][0]).max() / scale)
