@@ -180,3 +180,13 @@ def test_config1_and_config4_576_replicas_whole_and_as_one_eighth(golden, pe10k)
         print(f"config 4: rank {rank} of 8 (72 replicas) vs the same quadrature points in the 576 batch: {err:.3e}")
         assert err < 1e-9
         e8.close()
+    # the first n quadrature points as a batch of their own: 9 run as three part batches, 24 and 40 as four, 70 as two halves (engine_run.cpp)
+    for n in (9, 24, 40, 70):
+        en = capi.Engine()
+        en.register_replica("g0", 1, pe10k)
+        on = en.strain_batch([capi.make_sim(q, "g0", 1, strains[q], nss=p["nss"], most_recent=capi.QP_NONE) for q in range(n)])
+        got = np.array([list(o.stress) for o in on])
+        err = np.abs(got - whole[:n]).max() / np.abs(whole[:n]).max()
+        print(f"the first {n} quadrature points alone vs in the 576 batch: {err:.3e}")
+        assert err < 1e-9
+        en.close()
